@@ -1,0 +1,276 @@
+/*
+ * uvs_solver.h -- C ABI of the MI355X-native sliding-window back-end.
+ *
+ * This header is the drop-in boundary for ONE path of url-kaist/UV-SLAM: the
+ * nonlinear least-squares solve inside Estimator::optimization()
+ * (reference vins_estimator/src/estimator.cpp:761-1233).  In the reference
+ * that function builds a ceres::Problem and calls ceres::Solve; a maintainer
+ * replaces that body by "fill a uvs_window, call uvs_solve_window()" -- see
+ * INTEGRATION.md for the exact stub.
+ *
+ * Conventions (all taken from the reference, file:line cited per field):
+ *   - every scalar is IEEE double (the reference path is FP64 end to end);
+ *   - pose block = (px,py,pz, qx,qy,qz,qw)              estimator.cpp:530-537
+ *   - speed/bias block = (v[3], ba[3], bg[3])            estimator.cpp:539-549
+ *   - residual row order of an IMU block = (P,R,V,BA,BG) parameters.h:59-66
+ *   - parameter blocks are addressed by INDEX (frame id, landmark id), not by
+ *     pointer as in Ceres (SURVEY.md section 8b "Parameter memory").
+ *
+ * Plain pointers and sizes only; no C++ / torch types cross this boundary.
+ * All pointers are HOST pointers unless a function says otherwise.
+ */
+#ifndef UVS_SOLVER_H
+#define UVS_SOLVER_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UVS_ABI_VERSION 1
+
+#define UVS_WINDOW_SIZE 10                    /* parameters.h:12 WINDOW_SIZE  */
+#define UVS_NUM_FRAMES (UVS_WINDOW_SIZE + 1)  /* frames 0..WINDOW_SIZE        */
+#define UVS_SIZE_POSE 7                       /* parameters.h:51 SIZE_POSE    */
+#define UVS_SIZE_SPEEDBIAS 9                  /* parameters.h:52              */
+#define UVS_SIZE_LINE 4                       /* parameters.h:54              */
+#define UVS_MAX_ITER 64                       /* capacity of the per-iteration trace */
+#define UVS_MAX_PRIOR_BLOCKS 16               /* 10 poses + speedbias + ex + td (+slack) */
+#define UVS_MAX_PRIOR_DIM 96                  /* n <= 76 in the reference (a9) */
+
+/* ---- status codes (the reference has no error path: estimator.cpp:993-997
+ *      discards ceres::Solver::Summary; we return one and never abort) ---- */
+enum {
+    UVS_OK = 0,
+    UVS_ERR_INVALID_ARG = 1,    /* null pointer / index out of range / bad count */
+    UVS_ERR_UNSUPPORTED = 2,    /* estimate_td / relocalization blocks: not on this path yet */
+    UVS_ERR_NO_DEVICE = 3,      /* no HIP device / extension cannot run (never falls back to CPU) */
+    UVS_ERR_HIP = 4,            /* a HIP runtime call failed; see uvs_last_error() */
+    UVS_ERR_CAPACITY = 5,       /* window larger than the handle was created for */
+    UVS_ERR_NUMERIC = 6         /* non-finite cost / Cholesky breakdown reported by the device */
+};
+
+/* ---- termination reasons, named after Ceres ---- */
+enum {
+    UVS_TERM_NO_CONVERGENCE = 0,       /* max_num_iterations reached           */
+    UVS_TERM_GRADIENT_TOL = 1,
+    UVS_TERM_PARAMETER_TOL = 2,
+    UVS_TERM_FUNCTION_TOL = 3,
+    UVS_TERM_MIN_RADIUS = 4,
+    UVS_TERM_INVALID_STEPS = 5,        /* max_num_consecutive_invalid_steps    */
+    UVS_TERM_NUMERIC_FAILURE = 6
+};
+
+/* Solver options == the globals Estimator::optimization() reads
+ * (parameters.h:11-47, estimator.cpp:982-991) plus the Ceres defaults it
+ * relies on.  uvs_default_options() fills the EuRoC
+ * values of config/euroc/euroc_config.yaml. */
+typedef struct uvs_options {
+    int32_t max_num_iterations;        /* NUM_ITERATIONS, euroc_config.yaml:56 (10)        */
+    int32_t estimate_extrinsic;        /* ESTIMATE_EXTRINSIC (0): Ex_Pose constant         */
+    int32_t estimate_td;               /* ESTIMATE_TD (0); 1 -> UVS_ERR_UNSUPPORTED        */
+    int32_t function_tol_keeps_candidate; /* 0 = Ceres order: tolerance checks before accept (App. B.4) */
+    double focal_length;               /* FOCAL_LENGTH = fx, parameters.cpp:60 (461.6)     */
+    double point_sqrt_info;            /* FOCAL_LENGTH/1.6, estimator.cpp:17               */
+    double line_factor;                /* LINE_FACTOR (300)  euroc_config.yaml:86          */
+    double vp_factor;                  /* VP_FACTOR (10)     euroc_config.yaml:87          */
+    double loss_point;                 /* CauchyLoss(1.0)  estimator.cpp:765               */
+    double loss_line;                  /* CauchyLoss(0.1)  estimator.cpp:768               */
+    double loss_vp;                    /* CauchyLoss(1.0)  estimator.cpp:772               */
+    double gravity[3];                 /* G = (0,0,g_norm) parameters.cpp:12,79            */
+    /* Ceres trust-region defaults (not set by the reference => defaults apply) */
+    double initial_trust_region_radius;   /* 1e4  */
+    double max_trust_region_radius;       /* 1e16 */
+    double min_trust_region_radius;       /* 1e-32 */
+    double min_relative_decrease;         /* 1e-3 */
+    double min_lm_diagonal;               /* 1e-6 */
+    double max_lm_diagonal;               /* 1e32 */
+    double function_tolerance;            /* 1e-6 */
+    double gradient_tolerance;            /* 1e-10 */
+    double parameter_tolerance;           /* 1e-8 */
+    int32_t max_consecutive_invalid_steps;/* 5 */
+    int32_t jacobi_scaling;               /* 1 */
+} uvs_options;
+
+/* One IMU pre-integration block == the fields of IntegrationBase that
+ * IMUFactor::Evaluate reads (integration_base.h:188-203, imu_factor.h:19-182).
+ * Links frame i = index, frame j = index+1 (estimator.cpp:811-818).
+ * jacobian / covariance are 15x15 ROW-major here (Eigen's are column-major;
+ * the host shim transposes on copy). */
+typedef struct uvs_imu_block {
+    double sum_dt;
+    double delta_p[3];
+    double delta_q[4];                 /* (x,y,z,w) */
+    double delta_v[3];
+    double linearized_ba[3];
+    double linearized_bg[3];
+    double jacobian[15 * 15];
+    double covariance[15 * 15];
+    int32_t frame_i;                   /* j = frame_i + 1 */
+    int32_t skip;                      /* 1 when sum_dt > 10.0 (estimator.cpp:814) */
+} uvs_imu_block;
+
+/* Marginalization prior == what MarginalizationFactor::Evaluate reads from
+ * MarginalizationInfo (marginalization_factor.cpp:333-381, .h:64-69).
+ * n rows; kept block b has global size block_size[b] (7,9,1), column offset
+ * block_idx[b] (already minus m), linearization point x0 at x0[x0_off[b]..].
+ * linearized_jacobians is n x n ROW-major. */
+enum { UVS_BLOCK_POSE = 0, UVS_BLOCK_SPEEDBIAS = 1, UVS_BLOCK_EX_POSE = 2, UVS_BLOCK_TD = 3 };
+typedef struct uvs_prior {
+    int32_t n;                         /* 0 => no prior (last_marginalization_info == nullptr) */
+    int32_t n_blocks;
+    int32_t block_kind[UVS_MAX_PRIOR_BLOCKS];   /* UVS_BLOCK_*                                */
+    int32_t block_frame[UVS_MAX_PRIOR_BLOCKS];  /* frame index for POSE / SPEEDBIAS, else 0   */
+    int32_t block_size[UVS_MAX_PRIOR_BLOCKS];   /* keep_block_size (global size 7/9/1)        */
+    int32_t block_idx[UVS_MAX_PRIOR_BLOCKS];    /* keep_block_idx - m (local column offset)   */
+    int32_t x0_off[UVS_MAX_PRIOR_BLOCKS];       /* offset of keep_block_data in x0[]          */
+    double x0[UVS_MAX_PRIOR_BLOCKS * 9];
+    double linearized_residuals[UVS_MAX_PRIOR_DIM];
+    double linearized_jacobians[UVS_MAX_PRIOR_DIM * UVS_MAX_PRIOR_DIM];  /* row-major, leading dim n */
+} uvs_prior;
+
+/* The sliding window handed to the solver: exactly what optimization() feeds
+ * Ceres after vector2double() (estimator.cpp:800), flattened to SoA.
+ *
+ * Point residual blocks (estimator.cpp:823-866): one entry per
+ * ProjectionFactor(pts_i, pts_j) with blocks Pose[fi], Pose[fj], Ex_Pose,
+ * Feature[lm].  Entries of one landmark must be contiguous and lm must be
+ * non-decreasing (this is the order the reference loop emits them in).
+ *
+ * Line residual blocks (estimator.cpp:868-927): one entry per
+ * LineProjectionFactor(ric,tic,sp,ep) with blocks Pose[fj], Ortho[lm]; when
+ * has_vp != 0 the same entry also carries VPProjectionFactor(...,vp)
+ * (estimator.cpp:920-925, added iff vp(2)==1).  Same contiguity rule. */
+typedef struct uvs_window {
+    /* frame states: para_Pose / para_SpeedBias / para_Ex_Pose (estimator.h:114-121) */
+    double pose[UVS_NUM_FRAMES][UVS_SIZE_POSE];
+    double speedbias[UVS_NUM_FRAMES][UVS_SIZE_SPEEDBIAS];
+    double ex_pose[UVS_SIZE_POSE];
+    double td;                         /* para_Td (unused unless estimate_td) */
+
+    /* point landmarks: para_Feature[l][0] = inverse depth (feature_manager.cpp:290-306) */
+    int32_t n_points;
+    int32_t n_point_obs;
+    const double *inv_depth;           /* [n_points]            */
+    const int32_t *pt_lm;              /* [n_point_obs] feature_index            */
+    const int32_t *pt_fi;              /* [n_point_obs] imu_i (anchor frame)     */
+    const int32_t *pt_fj;              /* [n_point_obs] imu_j                    */
+    const double *pt_pi;               /* [n_point_obs][3] pts_i                 */
+    const double *pt_pj;               /* [n_point_obs][3] pts_j                 */
+
+    /* line landmarks: para_Ortho_plucker[l] = (psi_x,psi_y,psi_z,phi) (feature_manager.cpp:308-331) */
+    int32_t n_lines;
+    int32_t n_line_obs;
+    const double *line_orth;           /* [n_lines][4]          */
+    const int32_t *ln_lm;              /* [n_line_obs] line_feature_index        */
+    const int32_t *ln_fj;              /* [n_line_obs] imu_j                     */
+    const double *ln_sp;               /* [n_line_obs][3] start_point            */
+    const double *ln_ep;               /* [n_line_obs][3] end_point              */
+    const int32_t *ln_has_vp;          /* [n_line_obs] 1 iff vp(2)==1            */
+    const double *ln_vp;               /* [n_line_obs][3] vp                     */
+
+    /* IMU factors (estimator.cpp:811-818): up to WINDOW_SIZE blocks */
+    int32_t n_imu;
+    const uvs_imu_block *imu;          /* [n_imu] */
+
+    /* marginalization prior (estimator.cpp:803-809); may be NULL / n==0 */
+    const uvs_prior *prior;
+} uvs_window;
+
+/* Solver output == the para_* arrays after ceres::Solve and BEFORE
+ * double2vector() (estimator.cpp:999); caller allocates inv_depth[n_points]
+ * and line_orth[n_lines*4]. */
+typedef struct uvs_state {
+    double pose[UVS_NUM_FRAMES][UVS_SIZE_POSE];
+    double speedbias[UVS_NUM_FRAMES][UVS_SIZE_SPEEDBIAS];
+    double ex_pose[UVS_SIZE_POSE];
+    double td;
+    double *inv_depth;                 /* [n_points]   */
+    double *line_orth;                 /* [n_lines][4] */
+} uvs_state;
+
+/* Replaces ceres::Solver::Summary (discarded by the reference) with the trace
+ * needed for parity diffing. Entry 0 of the arrays is
+ * the initial evaluation; entry k>=1 is LM iteration k. */
+typedef struct uvs_report {
+    int32_t status;                    /* UVS_OK / UVS_ERR_NUMERIC */
+    int32_t termination;               /* UVS_TERM_* */
+    int32_t num_iterations;            /* LM iterations executed (successful or not) */
+    int32_t num_successful;
+    double initial_cost;
+    double final_cost;
+    double cost[UVS_MAX_ITER + 1];             /* cost of x after iteration k             */
+    double candidate_cost[UVS_MAX_ITER + 1];
+    double model_cost_change[UVS_MAX_ITER + 1];
+    double relative_decrease[UVS_MAX_ITER + 1];
+    double radius[UVS_MAX_ITER + 1];           /* trust region radius after iteration k   */
+    double step_norm[UVS_MAX_ITER + 1];
+    double gradient_max_norm[UVS_MAX_ITER + 1];
+    int32_t accepted[UVS_MAX_ITER + 1];        /* 1 accepted, 0 rejected, -1 invalid step */
+} uvs_report;
+
+/* Per-residual-block evaluation dump (uvs_evaluate): what
+ * cost_function->Evaluate + the Ceres corrector would hand the linear solver,
+ * in LOCAL (tangent) column size.  Used by the parity tests to compare the
+ * hand-derived HIP Jacobians element-wise with the oracle's Jets.
+ *   point block : r[2], J = [d/dPose_i (2x6) | d/dPose_j (2x6) | d/dEx (2x6) | d/dlambda (2x1)]  -> 2x19 row-major
+ *   line block  : r[2], J = [d/dPose_j (2x6) | d/dline (2x4)]                                  -> 2x10
+ *   vp block    : r[1], J = [d/dPose_j (1x6) | d/dline (1x4)]                                  -> 1x10 (zeros when !has_vp)
+ *   imu block   : r[15], J = [Pose_i (15x6) | SB_i (15x9) | Pose_j (15x6) | SB_j (15x9)]         -> 15x30
+ *   prior       : r[n]  (J is the constant linearized_jacobians)
+ * robust!=0 applies the Cauchy corrector (a10); cost = sum over blocks of 0.5*rho(s). */
+typedef struct uvs_eval {
+    double *pt_r;      /* [n_point_obs][2]   */
+    double *pt_J;      /* [n_point_obs][2*19]*/
+    double *ln_r;      /* [n_line_obs][2]    */
+    double *ln_J;      /* [n_line_obs][2*10] */
+    double *vp_r;      /* [n_line_obs][1]    */
+    double *vp_J;      /* [n_line_obs][10]   */
+    double *imu_r;     /* [n_imu][15]        */
+    double *imu_J;     /* [n_imu][15*30]     */
+    double *prior_r;   /* [prior n]          */
+    double cost;       /* out */
+} uvs_eval;
+
+typedef struct uvs_solver uvs_solver;  /* opaque: device buffers, stream, workspaces */
+
+/* ---- lifecycle ---- */
+int uvs_abi_version(void);
+void uvs_default_options(uvs_options *opts);
+/* device = HIP device ordinal. max_* size the per-window workspaces
+ * (reference capacities NUM_OF_F = NUM_OF_LF = 1000, parameters.h:14-16).
+ * Fails with UVS_ERR_NO_DEVICE when no GPU is present: there is no CPU path. */
+int uvs_create(const uvs_options *opts, int device, int max_batch, int max_points, int max_point_obs,
+               int max_lines, int max_line_obs, uvs_solver **out);
+void uvs_destroy(uvs_solver *s);
+const char *uvs_last_error(const uvs_solver *s);
+const char *uvs_status_string(int status);
+
+/* ---- the hot path: replaces problem build + ceres::Solve (estimator.cpp:763-997) ---- */
+int uvs_solve_window(uvs_solver *s, const uvs_window *w, uvs_state *out, uvs_report *rep);
+
+/* Batch of independent windows (BASELINE configs[2]). upload: host->HBM once;
+ * solve: device-resident, re-runnable (reads the uploaded initial state, writes
+ * separate outputs); elapsed_ms (may be NULL) = HIP-event time of the solve
+ * kernels on the solver's stream; download: HBM->host. */
+int uvs_batch_upload(uvs_solver *s, int n, const uvs_window *const *ws);
+int uvs_batch_solve(uvs_solver *s, float *elapsed_ms);
+int uvs_batch_download(uvs_solver *s, int n, uvs_state *states, uvs_report *reps);
+
+/* One evaluation of every residual block at the window's state (no solve). */
+int uvs_evaluate(uvs_solver *s, const uvs_window *w, int robust, uvs_eval *out);
+
+/* ---- marginalization (estimator.cpp:1002-1228, marginalization_factor.cpp) ----
+ * flag 0 = MARGIN_OLD, 1 = MARGIN_SECOND_NEW. `w` carries the POST-solve state
+ * (the reference calls vector2double() again at :1004). Output prior is already
+ * re-indexed for the next window (addr_shift, estimator.cpp:1139-1153). */
+int uvs_marginalize(uvs_solver *s, const uvs_window *w, int flag, uvs_prior *out);
+
+/* ---- size helpers for callers that serialise windows ---- */
+int uvs_reduced_dim(const uvs_options *opts);  /* 165 (+6 if estimate_extrinsic) */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UVS_SOLVER_H */
