@@ -261,6 +261,12 @@ int uvs_batch_download(uvs_solver *s, int n, uvs_state *states, uvs_report *reps
 /* One evaluation of every residual block at the window's state (no solve). */
 int uvs_evaluate(uvs_solver *s, const uvs_window *w, int robust, uvs_eval *out);
 
+/* Diagnostic (parity tests only): reduced system of the FIRST LM iteration of `w`:
+ * S_lower[176*176] row-major = damped, landmark-Schur-reduced frame system in the padded index space
+ * (16*frame + dof, dof 15 = dummy pivot), g/hd/dd/step[176], scal[8] = {cost, gmax, chol_ok, model_cost_change, step_norm^2}. */
+int uvs_debug_first_iteration(uvs_solver *s, const uvs_window *w, double *S_lower, double *g, double *hd, double *dd,
+                              double *step, double *scal);
+
 /* ---- marginalization (estimator.cpp:1002-1228, marginalization_factor.cpp) ----
  * flag 0 = MARGIN_OLD, 1 = MARGIN_SECOND_NEW. `w` carries the POST-solve state
  * (the reference calls vector2double() again at :1004). Output prior is already

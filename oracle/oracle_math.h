@@ -31,7 +31,8 @@ template <int N> inline Jet<N> operator*(const Jet<N>& f, const Jet<N>& g) { Jet
 template <int N> inline Jet<N> operator/(const Jet<N>& f, const Jet<N>& g) {
     // Ceres: h = f/g ; dh = (df - h dg)/g
     Jet<N> h; const double gi = 1.0 / g.a; h.a = f.a * gi;
-    for (int i = 0; i < N; ++i) h.v[i] = (f.v[i] - h.a * g.v[i]) * gi; return h; }
+    for (int i = 0; i < N; ++i) h.v[i] = (f.v[i] - h.a * g.v[i]) * gi;
+    return h; }
 template <int N> inline Jet<N> operator*(double s, const Jet<N>& f) { return Jet<N>(s) * f; }
 template <int N> inline Jet<N> operator*(const Jet<N>& f, double s) { return f * Jet<N>(s); }
 template <int N> inline Jet<N> operator+(double s, const Jet<N>& f) { return Jet<N>(s) + f; }

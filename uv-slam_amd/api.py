@@ -1,0 +1,138 @@
+"""ctypes binding of libuvs_solver.so (the HIP C ABI of include/uvs_solver.h).
+
+Plumbing only: every number is produced by the HIP kernels in csrc/.  Loading
+fails loudly when the shared library has not been built, and `Solver(...)`
+fails loudly (RuntimeError) when no GPU is present -- there is no CPU path.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libuvs_solver.so")
+_lib = None
+
+EXPORTS = [
+    "uvs_abi_version", "uvs_default_options", "uvs_create", "uvs_destroy", "uvs_last_error", "uvs_status_string",
+    "uvs_solve_window", "uvs_batch_upload", "uvs_batch_solve", "uvs_batch_download", "uvs_evaluate", "uvs_marginalize",
+    "uvs_reduced_dim",
+]
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        L.uvs_abi_version.restype = C.c_int
+        L.uvs_default_options.argtypes = [C.POINTER(abi.Options)]
+        L.uvs_create.argtypes = [C.POINTER(abi.Options), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.uvs_create.restype = C.c_int
+        L.uvs_destroy.argtypes = [C.c_void_p]
+        L.uvs_last_error.argtypes = [C.c_void_p]; L.uvs_last_error.restype = C.c_char_p
+        L.uvs_status_string.argtypes = [C.c_int]; L.uvs_status_string.restype = C.c_char_p
+        L.uvs_solve_window.argtypes = [C.c_void_p, C.POINTER(abi.WindowC), C.POINTER(abi.StateC), C.POINTER(abi.Report)]
+        L.uvs_solve_window.restype = C.c_int
+        L.uvs_batch_upload.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.POINTER(abi.WindowC))]
+        L.uvs_batch_upload.restype = C.c_int
+        L.uvs_batch_solve.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        L.uvs_batch_solve.restype = C.c_int
+        L.uvs_batch_download.argtypes = [C.c_void_p, C.c_int, C.POINTER(abi.StateC), C.POINTER(abi.Report)]
+        L.uvs_batch_download.restype = C.c_int
+        L.uvs_evaluate.argtypes = [C.c_void_p, C.POINTER(abi.WindowC), C.c_int, C.POINTER(abi.EvalC)]
+        L.uvs_evaluate.restype = C.c_int
+        L.uvs_marginalize.argtypes = [C.c_void_p, C.POINTER(abi.WindowC), C.c_int, C.POINTER(abi.Prior)]
+        L.uvs_marginalize.restype = C.c_int
+        L.uvs_debug_first_iteration.argtypes = [C.c_void_p, C.POINTER(abi.WindowC)] + [abi.c_double_p] * 6
+        L.uvs_debug_first_iteration.restype = C.c_int
+        L.uvs_reduced_dim.argtypes = [C.POINTER(abi.Options)]; L.uvs_reduced_dim.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+class Solver:
+    """Owns one `uvs_solver` handle (device buffers + stream) on one GPU."""
+
+    def __init__(self, opts=None, device=0, max_batch=1024):
+        self.opts = opts or abi.default_options()
+        self._h = C.c_void_p()
+        rc = lib().uvs_create(C.byref(self.opts), device, max_batch, 1000, 16000, 1000, 16000, C.byref(self._h))
+        if rc != abi.UVS_OK:
+            raise RuntimeError(f"uvs_create failed: {lib().uvs_status_string(rc).decode()} (rc={rc}); the HIP path is the only path")
+        self._keep = None
+        self._windows = None
+
+    def close(self):
+        if self._h:
+            lib().uvs_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, allow=(abi.UVS_OK,)):
+        if rc not in allow:
+            raise RuntimeError(f"uvs error {rc}: {lib().uvs_status_string(rc).decode()} / {lib().uvs_last_error(self._h).decode()}")
+        return rc
+
+    # ---- single window (host buffers in / out, PCIe inclusive) -------------
+    def solve(self, w: abi.Window):
+        wc, keep = w.to_c()
+        st = abi.State(len(w.inv_depth), len(w.line_orth)); sc = st.alloc_c()
+        rep = abi.Report()
+        self._check(lib().uvs_solve_window(self._h, C.byref(wc), C.byref(sc), C.byref(rep)), allow=(abi.UVS_OK, abi.UVS_ERR_NUMERIC))
+        return st.from_c(sc), rep
+
+    # ---- batch of independent windows, device resident --------------------
+    def upload(self, windows):
+        cs = [w.to_c() for w in windows]
+        arr = (C.POINTER(abi.WindowC) * len(cs))(*[C.pointer(c[0]) for c in cs])
+        self._check(lib().uvs_batch_upload(self._h, len(cs), arr))
+        self._windows = list(windows)
+
+    def solve_resident(self):
+        """Runs the solve kernel on the uploaded batch; returns the HIP-event time of the launch in ms."""
+        ms = C.c_float(0.0)
+        self._check(lib().uvs_batch_solve(self._h, C.byref(ms)))
+        return float(ms.value)
+
+    def download(self, n=None):
+        ws = self._windows
+        n = n or len(ws)
+        states = [abi.State(len(w.inv_depth), len(w.line_orth)) for w in ws[:n]]
+        sarr = (abi.StateC * n)()
+        for i, st in enumerate(states):
+            sarr[i].inv_depth = abi._dp(st.inv_depth); sarr[i].line_orth = abi._dp(st.line_orth)
+        reps = (abi.Report * n)()
+        self._check(lib().uvs_batch_download(self._h, n, sarr, reps), allow=(abi.UVS_OK, abi.UVS_ERR_NUMERIC))
+        for i, st in enumerate(states):
+            st.from_c(sarr[i])
+        return states, list(reps)
+
+    # ---- diagnostics -------------------------------------------------------
+    def evaluate(self, w: abi.Window, robust=True):
+        wc, keep = w.to_c()
+        ev = abi.Eval(w); ec = ev.alloc_c()
+        self._check(lib().uvs_evaluate(self._h, C.byref(wc), int(robust), C.byref(ec)))
+        ev.cost = ec.cost
+        return ev
+
+    def marginalize(self, w: abi.Window, flag=0):
+        wc, keep = w.to_c()
+        p = abi.Prior()
+        self._check(lib().uvs_marginalize(self._h, C.byref(wc), flag, C.byref(p)))
+        return p
+
+    def debug_first_iteration(self, w: abi.Window):
+        wc, keep = w.to_c()
+        S = np.zeros((176, 176)); g = np.zeros(176); hd = np.zeros(176); dd = np.zeros(176); step = np.zeros(176); scal = np.zeros(8)
+        self._check(lib().uvs_debug_first_iteration(self._h, C.byref(wc), *[abi._dp(a) for a in (S, g, hd, dd, step, scal)]))
+        return dict(S=S, g=g, hd=hd, dd=dd, step=step, cost=scal[0], gmax=scal[1], chol_ok=scal[2], mcc=scal[3], step2=scal[4])

@@ -1,0 +1,56 @@
+// uvs_layout.h -- HBM layout of one sliding window ("blob") and of its solver workspace.
+//
+// Host packs a uvs_window into one contiguous blob (SoA, 8-byte aligned) that is
+// read once per solve; the per-window workspace holds everything the persistent
+// solve kernel spills outside LDS (landmark parameters cur/candidate, the
+// Schur back-substitution store, whitened IMU Jacobians) and the outputs.
+// All `d_*` offsets are in doubles, all `i_*` offsets in int32, from the blob
+// base; `w_*` offsets are in doubles from the window's workspace base.
+#pragma once
+#include <stdint.h>
+
+#define UVS_NF 11                 // frames in the window (WINDOW_SIZE + 1)
+#define UVS_FD 16                 // padded per-frame dimension in the reduced system (15 + 1 dummy)
+#define UVS_RD (UVS_NF * UVS_FD)  // 176: padded reduced dimension
+#define UVS_NBLK (UVS_NF * (UVS_NF + 1) / 2)   // 66 lower 16x16 blocks
+#define UVS_BLK_LD 17             // padded row stride of a 16x16 LDS block (bank-conflict padding)
+#define UVS_BLK_SZ (16 * UVS_BLK_LD)            // 272 doubles
+#define UVS_S_DOUBLES (UVS_NBLK * UVS_BLK_SZ)   // 17952 doubles = 143616 B
+
+#define UVS_IMU_STRIDE 696        // doubles per IMU block: 20 header + jac 225 + cov 225 + W 225 (+1 pad)
+#define UVS_IMU_JAC 20
+#define UVS_IMU_COV 245
+#define UVS_IMU_W 470
+
+#define UVS_PT_REC 28             // LDS record per point observation: r[2] A[12] B[12] c[2]
+#define UVS_LN_REC 33             // LDS record per line observation: rl[2] Jlp[12] Jll[8] rv Jvp[6] Jvl[4]
+
+struct DevWin {
+    int32_t n_points, n_pt_obs, n_lines, n_ln_obs, n_imu, prior_n, prior_nb, n_chunks;
+    int32_t pt_stride, ln_stride;     // SoA strides of the measurement arrays
+    int32_t d_frames;                 // pose[11][7], sb[11][9], ex[7]  (184 doubles)
+    int32_t d_invd;                   // [n_points]
+    int32_t d_ptmeas;                 // 6 x pt_stride : pi_x pi_y pi_z pj_x pj_y pj_z
+    int32_t d_line;                   // [n_lines][4]
+    int32_t d_lnmeas;                 // 9 x ln_stride : sp xyz, ep xyz, vp xyz
+    int32_t d_imu;                    // n_imu x UVS_IMU_STRIDE
+    int32_t d_prior;                  // J0[n*n] H0[n*n] r0[n] b0[n] x0[144]
+    int32_t i_pt_lm, i_pt_fi, i_pt_fj, i_pt_beg;      // obs arrays + CSR begin[n_points+1]
+    int32_t i_ln_lm, i_ln_fj, i_ln_vp, i_ln_beg;      // obs arrays + CSR begin[n_lines+1]
+    int32_t i_imu;                    // [n_imu][2] : frame_i, skip
+    int32_t i_prior;                  // kind[16] frame[16] size[16] idx[16] x0off[16] colmap[96]
+    int32_t i_chunks;                 // [n_chunks][4] : type(0 pt,1 ln), lm_begin, lm_end, 0
+    // workspace
+    int32_t w_invd0, w_invd1, w_line0, w_line1;       // landmark parameters, two buffers (current / candidate)
+    int32_t w_scale_pt, w_scale_ln;                   // Jacobi scales of landmark parameters
+    int32_t w_pt_E, w_pt_x;           // Einv store 6*(n_pt_obs+n_points) ; per point {ginv, g, dd, 0}
+    int32_t w_ln_Y, w_ln_x;           // Y store 24*n_ln_obs ; per line {Hinv*g[4], g[4], dd[4]}
+    int32_t w_imu;                    // per block: Jraw[450] Jw[450] rraw[15] rw[15] (pad 936)
+    int32_t w_out;                    // final state: frames[184] (landmarks are read from the cur buffers)
+    int32_t ws_doubles;
+    int32_t blob_bytes;
+    int32_t cur_sel;                  // written by the kernel: which landmark buffer holds the final state
+    int32_t pad_;
+};
+
+#define UVS_WIMU_STRIDE 936

@@ -1,0 +1,982 @@
+// uvs_solve_kernel.h -- the persistent Levenberg-Marquardt kernel: ONE workgroup solves ONE window.
+//
+// Replaces ceres::Solve(options, &problem, &summary) at estimator.cpp:992 for the
+// problem built at estimator.cpp:763-927 (prior + IMU + point + line + VP blocks,
+// SPARSE_SCHUR + LEVENBERG_MARQUARDT, Ceres defaults).
+//
+// MI355X mapping:
+//   * the whole LM loop runs inside one launch; nothing returns to the host between iterations;
+//   * the 11 frame states (15 DoF each), the reduced 176x176 system (66 lower 16x16 blocks,
+//     padded rows) and all LM bookkeeping live in LDS (~155 KiB of the CU's 160 KiB);
+//   * residual blocks are evaluated one lane per block straight from coalesced SoA arrays;
+//   * landmark Schur elimination is an LDS-tiled, OUTPUT-STATIONARY reduction: every entry of the
+//     pose-pose system is owned by one lane that sums the landmarks of the staged chunk in a fixed
+//     order (no atomics => bitwise reproducible);
+//   * the reduced system is factored by a blocked right-looking Cholesky on 16x16 LDS blocks.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/uvs_solver.h"
+#include "uvs_layout.h"
+#include "uvs_factors.h"
+
+namespace uvsdev {
+
+static constexpr int NT = 512;                 // threads per workgroup (8 wavefronts)
+static constexpr int NW = NT / 64;
+
+// ---- LDS map (in doubles)
+static constexpr int L_S = 0;
+static constexpr int L_X = UVS_S_DOUBLES;      // pose[77] sb[99] ex[7] (+1 pad)
+static constexpr int L_XC = L_X + 184;
+static constexpr int L_G = L_XC + 184;         // gradient of the frame block, padded index space (176)
+static constexpr int L_DLT = L_G + UVS_RD;     // rhs / step
+static constexpr int L_HD = L_DLT + UVS_RD;    // diag(J^T J) of frame parameters (before Schur, before damping)
+static constexpr int L_SC = L_HD + UVS_RD;     // Jacobi scaling s_k
+static constexpr int L_DD = L_SC + UVS_RD;     // LM damping added to the diagonal
+static constexpr int L_DINV = L_DD + UVS_RD;   // 1 / L_kk of the Cholesky factor
+static constexpr int L_RF = L_DINV + UVS_RD;   // 11 rotation matrices (row-major) of the CURRENT evaluation point
+static constexpr int L_EX = L_RF + 104;        // ric[9] tic[3]
+static constexpr int L_PDX = L_EX + 16;        // prior dx
+static constexpr int L_PR = L_PDX + UVS_MAX_PRIOR_DIM;   // prior residual
+static constexpr int L_RED = L_PR + UVS_MAX_PRIOR_DIM;   // reduction scratch
+static constexpr int L_CTRL = L_RED + 64;
+static constexpr int L_TOTAL = L_CTRL + 32;
+static constexpr size_t LDS_BYTES = (size_t)L_TOTAL * 8;
+
+enum { C_COST = 0, C_RADIUS, C_DECR, C_XNORM, C_GMAX, C_CAND, C_MCC, C_STEP2, C_XC2, C_GO, C_IT, C_INVALID, C_CUR, C_FIRST,
+       C_TERM, C_NSUCC, C_CHOLOK, C_GMAXLM };
+
+struct KOpts {   // device copy of uvs_options
+    int max_it, ex_free, keep_cand, jacobi;
+    double sqrt_info, line_factor, vp_factor, loss_pt, loss_ln, loss_vp, G[3];
+    double r0, rmax, rmin, min_rel, dlo, dhi, ftol, gtol, ptol;
+    int max_invalid;
+    int debug;
+};
+
+__constant__ unsigned char c_blk_fa[UVS_NBLK];
+__constant__ unsigned char c_blk_fb[UVS_NBLK];
+
+UVS_DEV int sidx(int i, int j) {   // i >= j, padded index space
+    const int bi = i >> 4, bj = j >> 4;
+    return (((bi * (bi + 1)) >> 1) + bj) * UVS_BLK_SZ + (i & 15) * UVS_BLK_LD + (j & 15);
+}
+UVS_DEV double bcast_lane(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+UVS_DEV double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+UVS_DEV double wave_max(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
+    return v;
+}
+// Deterministic block reductions of up to 4 sums + 1 max.  Result broadcast to every thread.
+UVS_DEV void block_reduce(double* sh, double* s /*[4]*/, double* mx) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const double t = wave_sum(s[k]); if (lane == 0) sh[L_RED + wv * 5 + k] = t; }
+    { const double t = wave_max(*mx); if (lane == 0) sh[L_RED + wv * 5 + 4] = t; }
+    __syncthreads();
+    if (tid == 0) {
+        double a[4] = {0, 0, 0, 0}, m = 0.0;
+        for (int w = 0; w < NW; ++w) { for (int k = 0; k < 4; ++k) a[k] += sh[L_RED + w * 5 + k]; m = fmax(m, sh[L_RED + w * 5 + 4]); }
+        for (int k = 0; k < 4; ++k) sh[L_RED + 48 + k] = a[k];
+        sh[L_RED + 52] = m;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s[k] = sh[L_RED + 48 + k];
+    *mx = sh[L_RED + 52];
+}
+
+struct Ctx {
+    const DevWin* hdr;
+    const double* bd;      // blob as doubles
+    const int* bi;         // blob as ints
+    double* ws;            // workspace of this window
+    double* sh;            // LDS
+    KOpts o;
+};
+
+// rotation matrices of the evaluation point `x` (LDS, L_X or L_XC layout) -> L_RF / L_EX
+UVS_DEV void stage_rotations(const Ctx& c, const double* x) {
+    const int tid = threadIdx.x;
+    if (tid < UVS_NF) quat_to_R(x + 7 * tid + 3, c.sh + L_RF + 9 * tid);
+    else if (tid == UVS_NF) { quat_to_R(x + 176 + 3, c.sh + L_EX); c.sh[L_EX + 9] = x[176]; c.sh[L_EX + 10] = x[177]; c.sh[L_EX + 11] = x[178]; }
+}
+
+// ------------------------------------------------------------------ residual-only cost at `x` (LDS) / landmark buffer `sel`
+UVS_DEV void prior_dx(const Ctx& c, const double* x) {
+    const int tid = threadIdx.x;
+    const DevWin& h = *c.hdr;
+    if (h.prior_n > 0 && tid < h.prior_nb) {
+        const int* pt = c.bi + h.i_prior;
+        const int kind = pt[tid], frame = pt[16 + tid], size = pt[32 + tid], idx = pt[48 + tid], xo = pt[64 + tid];
+        const double* x0 = c.bd + h.d_prior + 2 * h.prior_n * h.prior_n + 2 * h.prior_n + xo;
+        const double* xb = (kind == UVS_BLOCK_POSE) ? x + 7 * frame : (kind == UVS_BLOCK_SPEEDBIAS) ? x + 77 + 9 * frame : x + 176;
+        double* dx = c.sh + L_PDX + idx;
+        if (size != 7) { for (int k = 0; k < size; ++k) dx[k] = xb[k] - x0[k]; }
+        else {   // marginalization_factor.cpp:352-362
+            dx[0] = xb[0] - x0[0]; dx[1] = xb[1] - x0[1]; dx[2] = xb[2] - x0[2];
+            double qi[4], e[4]; quat_inv(x0 + 3, qi); quat_mul(qi, xb + 3, e);
+            const double sg = (e[3] >= 0.0) ? 2.0 : -2.0;
+            dx[3] = sg * e[0]; dx[4] = sg * e[1]; dx[5] = sg * e[2];
+        }
+    }
+}
+UVS_DEV double prior_residual(const Ctx& c) {   // after prior_dx + barrier; fills L_PR, returns this thread's 0.5 r^2 share
+    const DevWin& h = *c.hdr;
+    const int n = h.prior_n, tid = threadIdx.x;
+    double cost = 0.0;
+    if (tid < n) {
+        const double* J0 = c.bd + h.d_prior;
+        double s = c.bd[h.d_prior + 2 * n * n + tid];
+        for (int k = 0; k < n; ++k) s += J0[tid * n + k] * c.sh[L_PDX + k];   // marginalization_factor.cpp:364
+        c.sh[L_PR + tid] = s;
+        cost = 0.5 * s * s;
+    }
+    return cost;
+}
+
+// cost of all residual blocks at the point staged in (x, RF/EX) with landmark buffers invd / line
+UVS_DEV double cost_pass(const Ctx& c, const double* x, const double* invd, const double* line) {
+    const DevWin& h = *c.hdr;
+    const int tid = threadIdx.x;
+    const double* RF = c.sh + L_RF; const double* ric = c.sh + L_EX; const double* tic = c.sh + L_EX + 9;
+    double cost = 0.0;
+    // points
+    for (int o = tid; o < h.n_pt_obs; o += NT) {
+        const int lm = c.bi[h.i_pt_lm + o], fi = c.bi[h.i_pt_fi + o], fj = c.bi[h.i_pt_fj + o];
+        const double* m = c.bd + h.d_ptmeas + o; const int st = h.pt_stride;
+        const double pi[3] = {m[0], m[st], m[2 * st]}, pj[3] = {m[3 * st], m[4 * st], m[5 * st]};
+        double r[2];
+        point_eval<false, false>(x + 7 * fi, RF + 9 * fi, x + 7 * fj, RF + 9 * fj, ric, tic, invd[lm], pi, pj, c.o.sqrt_info, r, nullptr, nullptr, nullptr, nullptr);
+        double sc; cost += 0.5 * cauchy(c.o.loss_pt, r[0] * r[0] + r[1] * r[1], &sc);
+    }
+    // lines + vp
+    for (int o = tid; o < h.n_ln_obs; o += NT) {
+        const int lm = c.bi[h.i_ln_lm + o], fj = c.bi[h.i_ln_fj + o], hv = c.bi[h.i_ln_vp + o];
+        const double* m = c.bd + h.d_lnmeas + o; const int st = h.ln_stride;
+        const double sp[3] = {m[0], m[st], m[2 * st]}, ep[3] = {m[3 * st], m[4 * st], m[5 * st]}, vp[3] = {m[6 * st], m[7 * st], m[8 * st]};
+        LineGeom g;
+        line_geom<false>(x + 7 * fj, x + 7 * fj + 3, RF + 9 * fj, ric, tic, line + 4 * lm, g);
+        double r[2], sc;
+        line_residual<false>(g, sp, ep, c.o.line_factor, r, nullptr, nullptr);
+        cost += 0.5 * cauchy(c.o.loss_ln, r[0] * r[0] + r[1] * r[1], &sc);
+        if (hv) { double rv; vp_residual<false>(g, vp, c.o.vp_factor, &rv, nullptr, nullptr); cost += 0.5 * cauchy(c.o.loss_vp, rv * rv, &sc); }
+    }
+    // IMU: one lane per block (residual only: 15x15 upper-triangular whitening)
+    if (tid < h.n_imu) {
+        const int fi = c.bi[h.i_imu + 2 * tid], skip = c.bi[h.i_imu + 2 * tid + 1];
+        if (!skip) {
+            const double* blk = c.bd + h.d_imu + (size_t)tid * UVS_IMU_STRIDE;
+            double r[15];
+            imu_raw(blk, blk + UVS_IMU_JAC, c.o.G, x + 7 * fi, x + 77 + 9 * fi, x + 7 * (fi + 1), x + 77 + 9 * (fi + 1), r, nullptr);
+            const double* W = blk + UVS_IMU_W;
+            for (int i = 0; i < 15; ++i) { double s = 0.0; for (int k = i; k < 15; ++k) s += W[i * 15 + k] * r[k]; cost += 0.5 * s * s; }
+        }
+    }
+    return cost;
+}
+
+// ------------------------------------------------------------------ blocked Cholesky of the LDS-resident reduced system
+// S (lower 16x16 blocks) <- L ; L_DINV <- 1/diag(L).  Returns via CTRL[C_CHOLOK].
+UVS_DEV void chol_factor(const Ctx& c) {
+    double* sh = c.sh;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) sh[L_CTRL + C_CHOLOK] = 1.0;
+    for (int k = 0; k < UVS_NF; ++k) {
+        double* Dk = sh + L_S + (((k * (k + 1)) >> 1) + k) * UVS_BLK_SZ;
+        __syncthreads();
+        // (1) diagonal block: lanes 0..15 of wave 0 hold one row each in registers
+        if (wv == 0) {
+            double a[16];
+            const int r = lane & 15;
+#pragma unroll
+            for (int cc = 0; cc < 16; ++cc) a[cc] = Dk[r * UVS_BLK_LD + cc];
+            bool ok = true;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const double piv = bcast_lane(a[j], j);
+                if (!(piv > 0.0)) ok = false;
+                const double inv = 1.0 / sqrt(piv);
+                const double l = (r == j) ? piv * inv : a[j] * inv;
+                a[j] = l;
+#pragma unroll
+                for (int cc = j + 1; cc < 16; ++cc) { const double lc = bcast_lane(l, cc); a[cc] -= l * lc; }
+            }
+            if (lane < 16) {
+#pragma unroll
+                for (int cc = 0; cc < 16; ++cc) if (cc <= r) Dk[r * UVS_BLK_LD + cc] = a[cc];
+                double mine = 0.0;
+#pragma unroll
+                for (int cc = 0; cc < 16; ++cc) if (cc == r) mine = a[cc];
+                sh[L_DINV + 16 * k + r] = 1.0 / mine;
+                if (!ok && lane == 0) sh[L_CTRL + C_CHOLOK] = 0.0;
+            }
+        }
+        __syncthreads();
+        // (2) panel: rows of blocks (i,k), i>k : x L_kk^T = a  (forward substitution along the row)
+        const int nrow = (UVS_NF - 1 - k) * 16;
+        if (tid < nrow) {
+            const int i = k + 1 + (tid >> 4), r = tid & 15;
+            double* B = sh + L_S + (((i * (i + 1)) >> 1) + k) * UVS_BLK_SZ + r * UVS_BLK_LD;
+            double x[16];
+#pragma unroll
+            for (int cc = 0; cc < 16; ++cc) x[cc] = B[cc];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                double s = x[j];
+#pragma unroll
+                for (int m = 0; m < j; ++m) s -= x[m] * Dk[j * UVS_BLK_LD + m];
+                x[j] = s * sh[L_DINV + 16 * k + j];
+            }
+#pragma unroll
+            for (int cc = 0; cc < 16; ++cc) B[cc] = x[cc];
+        }
+        __syncthreads();
+        // (3) trailing update S_ij -= X_i X_j^T for k < j <= i : 4x4 register tiles, 16 tiles per block
+        const int nb = UVS_NF - 1 - k;
+        const int ntile = ((nb * (nb + 1)) >> 1) * 16;
+        for (int t = tid; t < ntile; t += NT) {
+            const int pb = t >> 4, tl = t & 15;
+            // pb -> (ii, jj) with 0 <= jj <= ii < nb
+            int ii = (int)((sqrt(8.0 * pb + 1.0) - 1.0) * 0.5);
+            while (((ii + 1) * (ii + 2)) >> 1 <= pb) ++ii;
+            while (((ii * (ii + 1)) >> 1) > pb) --ii;
+            const int jj = pb - ((ii * (ii + 1)) >> 1);
+            const int bi_ = k + 1 + ii, bj_ = k + 1 + jj;
+            const int r0 = (tl >> 2) * 4, c0 = (tl & 3) * 4;
+            const double* Xi = sh + L_S + (((bi_ * (bi_ + 1)) >> 1) + k) * UVS_BLK_SZ + r0 * UVS_BLK_LD;
+            const double* Xj = sh + L_S + (((bj_ * (bj_ + 1)) >> 1) + k) * UVS_BLK_SZ + c0 * UVS_BLK_LD;
+            double* Cb = sh + L_S + (((bi_ * (bi_ + 1)) >> 1) + bj_) * UVS_BLK_SZ + r0 * UVS_BLK_LD + c0;
+            double acc[4][4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+#pragma unroll 4
+            for (int m = 0; m < 16; ++m) {
+                double xa[4], xb[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) { xa[a] = Xi[a * UVS_BLK_LD + m]; xb[a] = Xj[a * UVS_BLK_LD + m]; }
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) acc[a][b] += xa[a] * xb[b];
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) Cb[a * UVS_BLK_LD + b] -= acc[a][b];
+        }
+    }
+    __syncthreads();
+}
+
+// solve L L^T y = rhs in place (rhs in L_DLT)
+UVS_DEV void chol_solve(const Ctx& c) {
+    double* sh = c.sh;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    double* b = sh + L_DLT;
+    // forward
+    for (int k = 0; k < UVS_NF; ++k) {
+        const double* Dk = sh + L_S + (((k * (k + 1)) >> 1) + k) * UVS_BLK_SZ;
+        __syncthreads();
+        if (wv == 0) {
+            const int r = lane & 15;
+            double Lr[16];
+#pragma unroll
+            for (int cc = 0; cc < 16; ++cc) Lr[cc] = (cc < r) ? Dk[r * UVS_BLK_LD + cc] : 0.0;
+            double v = b[16 * k + r];
+            const double di = sh[L_DINV + 16 * k + r];
+            double y = 0.0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const double yj = bcast_lane(v * di, j);
+                if (r == j) y = yj;
+                v -= Lr[j] * yj;      // Lr[j] == 0 for j >= r
+            }
+            if (lane < 16) b[16 * k + r] = y;
+        }
+        __syncthreads();
+        const int nrow = (UVS_NF - 1 - k) * 16;
+        if (tid < nrow) {
+            const int i = k + 1 + (tid >> 4), r = tid & 15;
+            const double* B = sh + L_S + (((i * (i + 1)) >> 1) + k) * UVS_BLK_SZ + r * UVS_BLK_LD;
+            double s = 0.0;
+#pragma unroll
+            for (int cc = 0; cc < 16; ++cc) s += B[cc] * b[16 * k + cc];
+            b[16 * i + r] -= s;
+        }
+    }
+    // backward
+    for (int k = UVS_NF - 1; k >= 0; --k) {
+        const double* Dk = sh + L_S + (((k * (k + 1)) >> 1) + k) * UVS_BLK_SZ;
+        __syncthreads();
+        if (wv == 0) {
+            const int r = lane & 15;
+            double Lc[16];     // column r of L_kk : Lc[j] = L[j][r], j > r
+#pragma unroll
+            for (int j = 0; j < 16; ++j) Lc[j] = (j > r) ? Dk[j * UVS_BLK_LD + r] : 0.0;
+            double v = b[16 * k + r];
+            const double di = sh[L_DINV + 16 * k + r];
+            double x = 0.0;
+#pragma unroll
+            for (int j = 15; j >= 0; --j) {
+                const double xj = bcast_lane(v * di, j);
+                if (r == j) x = xj;
+                v -= Lc[j] * xj;
+            }
+            if (lane < 16) b[16 * k + r] = x;
+        }
+        __syncthreads();
+        const int ncol = k * 16;
+        if (tid < ncol) {
+            const int j = tid >> 4, cc = tid & 15;
+            const double* B = sh + L_S + (((k * (k + 1)) >> 1) + j) * UVS_BLK_SZ + cc;
+            double s = 0.0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s += B[r * UVS_BLK_LD] * b[16 * k + r];
+            b[16 * j + cc] -= s;
+        }
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------ linearization: builds S (damped, Schur-reduced), G, HD, cost, gmax
+struct GatherItem { int type, fa, fb, a, b; };   // type 0: S entry, 1: gradient entry, 2: diag(J^T J) entry, -1: none
+UVS_DEV GatherItem decode_item(int id) {
+    GatherItem it;
+    if (id < UVS_NBLK * 36) { const int blk = id / 36, e = id - blk * 36; it.type = 0; it.fa = c_blk_fa[blk]; it.fb = c_blk_fb[blk]; it.a = e / 6; it.b = e - it.a * 6; }
+    else if (id < UVS_NBLK * 36 + 66) { const int e = id - UVS_NBLK * 36; it.type = 1; it.fa = it.fb = e / 6; it.a = it.b = e - it.fa * 6; }
+    else if (id < UVS_NBLK * 36 + 132) { const int e = id - UVS_NBLK * 36 - 66; it.type = 2; it.fa = it.fb = e / 6; it.a = it.b = e - it.fa * 6; }
+    else { it.type = -1; it.fa = it.fb = it.a = it.b = 0; }
+    return it;
+}
+static constexpr int N_ITEMS = UVS_NBLK * 36 + 132;
+static constexpr int ITEMS_PER_THREAD = (N_ITEMS + NT - 1) / NT;   // 5
+
+UVS_DEV void linearize(const Ctx& c, const double* x, const double* invd, const double* line, bool first, double radius) {
+    const DevWin& h = *c.hdr;
+    double* sh = c.sh;
+    const int tid = threadIdx.x;
+    const double* RF = sh + L_RF; const double* ric = sh + L_EX; const double* tic = sh + L_EX + 9;
+    double cost = 0.0, gmax_lm = 0.0;
+    double acc[ITEMS_PER_THREAD];
+#pragma unroll
+    for (int q = 0; q < ITEMS_PER_THREAD; ++q) acc[q] = 0.0;
+
+    stage_rotations(c, x);
+    prior_dx(c, x);
+    __syncthreads();
+    // ---- IMU: raw residual/Jacobian, one lane per block (global scratch), whitened below by all lanes
+    if (tid < h.n_imu) {
+        const int fi = c.bi[h.i_imu + 2 * tid], skip = c.bi[h.i_imu + 2 * tid + 1];
+        double* wj = c.ws + h.w_imu + (size_t)tid * UVS_WIMU_STRIDE;
+        if (!skip) {
+            const double* blk = c.bd + h.d_imu + (size_t)tid * UVS_IMU_STRIDE;
+            double r[15];
+            imu_raw(blk, blk + UVS_IMU_JAC, c.o.G, x + 7 * fi, x + 77 + 9 * fi, x + 7 * (fi + 1), x + 77 + 9 * (fi + 1), r, wj);
+            for (int i = 0; i < 15; ++i) wj[900 + i] = r[i];
+        }
+    }
+    cost += prior_residual(c);
+
+    // ---- landmark chunks: stage -> per-landmark Schur prep -> output-stationary gather
+    const int* chunks = c.bi + h.i_chunks;
+    for (int ch = 0; ch < h.n_chunks; ++ch) {
+        const int type = chunks[4 * ch], k0 = chunks[4 * ch + 1], k1 = chunks[4 * ch + 2];
+        const int nlm = k1 - k0;
+        __syncthreads();     // previous chunk's gather done; S region free
+        if (type == 0) {
+            const int* beg = c.bi + h.i_pt_beg;
+            const int o0 = beg[k0], o1 = beg[k1], nob = o1 - o0;
+            double* rec = sh + L_S;                                  // [nob][28]
+            double* Eb = rec + (size_t)nob * UVS_PT_REC;             // [(nob + nlm)][6]
+            double* Xb = Eb + (size_t)(nob + nlm) * 6;               // [nlm][2] : hinv, ginv
+            signed char* slot = (signed char*)(Xb + 2 * nlm);        // [nlm][11]
+            // pass A: one lane per observation
+            for (int o = o0 + tid; o < o1; o += NT) {
+                const int lm = c.bi[h.i_pt_lm + o], fi = c.bi[h.i_pt_fi + o], fj = c.bi[h.i_pt_fj + o];
+                const double* m = c.bd + h.d_ptmeas + o; const int st = h.pt_stride;
+                const double pi[3] = {m[0], m[st], m[2 * st]}, pj[3] = {m[3 * st], m[4 * st], m[5 * st]};
+                double r[2], A[12], B[12], cl[2];
+                point_eval<true, false>(x + 7 * fi, RF + 9 * fi, x + 7 * fj, RF + 9 * fj, ric, tic, invd[lm], pi, pj, c.o.sqrt_info, r, A, B, cl, nullptr);
+                double sc; cost += 0.5 * cauchy(c.o.loss_pt, r[0] * r[0] + r[1] * r[1], &sc);
+                double* R = rec + (size_t)(o - o0) * UVS_PT_REC;
+                R[0] = sc * r[0]; R[1] = sc * r[1];
+#pragma unroll
+                for (int q = 0; q < 12; ++q) { R[2 + q] = sc * A[q]; R[14 + q] = sc * B[q]; }
+                R[26] = sc * cl[0]; R[27] = sc * cl[1];
+            }
+            __syncthreads();
+            // pass B: one lane per landmark
+            for (int li = tid; li < nlm; li += NT) {
+                const int k = k0 + li, b0 = beg[k] - o0, b1 = beg[k + 1] - o0;
+                double hd = 0.0, gl = 0.0;
+                for (int o = b0; o < b1; ++o) { const double* R = rec + (size_t)o * UVS_PT_REC; hd += R[26] * R[26] + R[27] * R[27]; gl += R[26] * R[0] + R[27] * R[1]; }
+                double sc;
+                if (first) { sc = c.o.jacobi ? 1.0 / (1.0 + sqrt(hd)) : 1.0; c.ws[h.w_scale_pt + k] = sc; } else sc = c.ws[h.w_scale_pt + k];
+                const double dd = fmin(fmax(sc * sc * hd, c.o.dlo), c.o.dhi) / (radius * sc * sc);
+                const double hinv = 1.0 / (hd + dd), ginv = gl * hinv;
+                Xb[2 * li] = hinv; Xb[2 * li + 1] = ginv;
+                double* px = c.ws + h.w_pt_x + 4 * (size_t)k; px[0] = ginv; px[1] = gl; px[2] = dd; px[3] = hd;
+                gmax_lm = fmax(gmax_lm, fabs(gl));
+                signed char* sm = slot + 11 * li;
+#pragma unroll
+                for (int f = 0; f < UVS_NF; ++f) sm[f] = -1;
+                double* E = Eb + (size_t)(b0 + li) * 6;
+                double* Eg = c.ws + h.w_pt_E + 6 * (size_t)(beg[k] + k);
+                double e0[6] = {0, 0, 0, 0, 0, 0};
+                for (int o = b0; o < b1; ++o) {
+                    const double* R = rec + (size_t)o * UVS_PT_REC;
+                    const int s = o - b0 + 1;
+                    sm[c.bi[h.i_pt_fj + o0 + o]] = (signed char)s;
+#pragma unroll
+                    for (int a = 0; a < 6; ++a) {
+                        e0[a] += R[26] * R[2 + a] + R[27] * R[8 + a];
+                        const double e = R[26] * R[14 + a] + R[27] * R[20 + a];
+                        E[6 * s + a] = e; Eg[6 * s + a] = e * hinv;
+                    }
+                }
+                if (b1 > b0) sm[c.bi[h.i_pt_fi + o0 + b0]] = 0;
+#pragma unroll
+                for (int a = 0; a < 6; ++a) { E[a] = e0[a]; Eg[a] = e0[a] * hinv; }
+            }
+            __syncthreads();
+            // pass C: output-stationary gather (fixed landmark order => deterministic)
+#pragma unroll
+            for (int q = 0; q < ITEMS_PER_THREAD; ++q) {
+                const GatherItem it = decode_item(tid + q * NT);
+                if (it.type < 0) continue;
+                double s = 0.0;
+                for (int li = 0; li < nlm; ++li) {
+                    const signed char* sm = slot + 11 * li;
+                    const int sa = sm[it.fa];
+                    if (sa < 0) continue;
+                    const int b0 = beg[k0 + li] - o0, b1 = beg[k0 + li + 1] - o0;
+                    const double* E = Eb + (size_t)(b0 + li) * 6;
+                    if (it.type == 0) {
+                        const int sb = sm[it.fb];
+                        if (sb < 0) continue;
+                        s -= E[6 * sa + it.a] * Xb[2 * li] * E[6 * sb + it.b];
+                        if (it.fa == it.fb) {
+                            if (sa == 0) { for (int o = b0; o < b1; ++o) { const double* R = rec + (size_t)o * UVS_PT_REC; s += R[2 + it.a] * R[2 + it.b] + R[8 + it.a] * R[8 + it.b]; } }
+                            else { const double* R = rec + (size_t)(b0 + sa - 1) * UVS_PT_REC; s += R[14 + it.a] * R[14 + it.b] + R[20 + it.a] * R[20 + it.b]; }
+                        } else if (sb == 0) { const double* R = rec + (size_t)(b0 + sa - 1) * UVS_PT_REC; s += R[14 + it.a] * R[2 + it.b] + R[20 + it.a] * R[8 + it.b]; }
+                    } else if (it.type == 1) {
+                        if (sa == 0) { for (int o = b0; o < b1; ++o) { const double* R = rec + (size_t)o * UVS_PT_REC; s += R[2 + it.a] * R[0] + R[8 + it.a] * R[1]; } }
+                        else { const double* R = rec + (size_t)(b0 + sa - 1) * UVS_PT_REC; s += R[14 + it.a] * R[0] + R[20 + it.a] * R[1]; }
+                        s -= E[6 * sa + it.a] * Xb[2 * li + 1];
+                    } else {
+                        if (sa == 0) { for (int o = b0; o < b1; ++o) { const double* R = rec + (size_t)o * UVS_PT_REC; s += R[2 + it.a] * R[2 + it.a] + R[8 + it.a] * R[8 + it.a]; } }
+                        else { const double* R = rec + (size_t)(b0 + sa - 1) * UVS_PT_REC; s += R[14 + it.a] * R[14 + it.a] + R[20 + it.a] * R[20 + it.a]; }
+                    }
+                }
+                acc[q] += s;
+            }
+        } else {
+            const int* beg = c.bi + h.i_ln_beg;
+            const int o0 = beg[k0], o1 = beg[k1], nob = o1 - o0;
+            double* rec = sh + L_S;                                  // [nob][33]
+            double* Eb = rec + (size_t)nob * UVS_LN_REC;             // [nob][24]  E[c][a] = (J_l^T J_p)
+            double* Yb = Eb + (size_t)nob * 24;                      // [nob][24]  Y = Hinv E
+            double* Xb = Yb + (size_t)nob * 24;                      // [nlm][20] : Hinv[16], Hinv*g[4]
+            signed char* slot = (signed char*)(Xb + 20 * nlm);       // [nlm][11]
+            // pass A
+            for (int o = o0 + tid; o < o1; o += NT) {
+                const int lm = c.bi[h.i_ln_lm + o], fj = c.bi[h.i_ln_fj + o], hv = c.bi[h.i_ln_vp + o];
+                const double* m = c.bd + h.d_lnmeas + o; const int st = h.ln_stride;
+                const double sp[3] = {m[0], m[st], m[2 * st]}, ep[3] = {m[3 * st], m[4 * st], m[5 * st]}, vp[3] = {m[6 * st], m[7 * st], m[8 * st]};
+                LineGeom g;
+                line_geom<true>(x + 7 * fj, x + 7 * fj + 3, RF + 9 * fj, ric, tic, line + 4 * lm, g);
+                double* R = rec + (size_t)(o - o0) * UVS_LN_REC;
+                double r[2], Jp[12], Jl[8], sc;
+                line_residual<true>(g, sp, ep, c.o.line_factor, r, Jp, Jl);
+                cost += 0.5 * cauchy(c.o.loss_ln, r[0] * r[0] + r[1] * r[1], &sc);
+                R[0] = sc * r[0]; R[1] = sc * r[1];
+#pragma unroll
+                for (int q = 0; q < 12; ++q) R[2 + q] = sc * Jp[q];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) R[14 + q] = sc * Jl[q];
+                if (hv) {
+                    double rv, Jvp[6], Jvl[4];
+                    vp_residual<true>(g, vp, c.o.vp_factor, &rv, Jvp, Jvl);
+                    cost += 0.5 * cauchy(c.o.loss_vp, rv * rv, &sc);
+                    R[22] = sc * rv;
+#pragma unroll
+                    for (int q = 0; q < 6; ++q) R[23 + q] = sc * Jvp[q];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) R[29 + q] = sc * Jvl[q];
+                } else {
+#pragma unroll
+                    for (int q = 22; q < 33; ++q) R[q] = 0.0;
+                }
+            }
+            __syncthreads();
+            // pass B1: one lane per line: H_ll, g_l, damping, 4x4 inverse
+            for (int li = tid; li < nlm; li += NT) {
+                const int k = k0 + li, b0 = beg[k] - o0, b1 = beg[k + 1] - o0;
+                double H[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, gl[4] = {0, 0, 0, 0};   // lower packed (0,0)(1,0)(1,1)(2,0)...
+                signed char* sm = slot + 11 * li;
+#pragma unroll
+                for (int f = 0; f < UVS_NF; ++f) sm[f] = -1;
+                for (int o = b0; o < b1; ++o) {
+                    const double* R = rec + (size_t)o * UVS_LN_REC;
+                    sm[c.bi[h.i_ln_fj + o0 + o]] = (signed char)(o - b0);
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        gl[a] += R[14 + a] * R[0] + R[18 + a] * R[1] + R[29 + a] * R[22];
+#pragma unroll
+                        for (int b = 0; b <= a; ++b) H[(a * (a + 1)) / 2 + b] += R[14 + a] * R[14 + b] + R[18 + a] * R[18 + b] + R[29 + a] * R[29 + b];
+                    }
+                }
+                double* lx = c.ws + h.w_ln_x + 12 * (size_t)k;
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    const double hd = H[(a * (a + 1)) / 2 + a];
+                    double sc;
+                    if (first) { sc = c.o.jacobi ? 1.0 / (1.0 + sqrt(hd)) : 1.0; c.ws[h.w_scale_ln + 4 * k + a] = sc; } else sc = c.ws[h.w_scale_ln + 4 * k + a];
+                    const double dd = fmin(fmax(sc * sc * hd, c.o.dlo), c.o.dhi) / (radius * sc * sc);
+                    H[(a * (a + 1)) / 2 + a] = hd + dd;
+                    lx[4 + a] = gl[a]; lx[8 + a] = dd;
+                    gmax_lm = fmax(gmax_lm, fabs(gl[a]));
+                }
+                // Cholesky of the 4x4 and explicit inverse
+                double L[10];
+                L[0] = sqrt(H[0]);
+                L[1] = H[1] / L[0]; L[2] = sqrt(H[2] - L[1] * L[1]);
+                L[3] = H[3] / L[0]; L[4] = (H[4] - L[3] * L[1]) / L[2]; L[5] = sqrt(H[5] - L[3] * L[3] - L[4] * L[4]);
+                L[6] = H[6] / L[0]; L[7] = (H[7] - L[6] * L[1]) / L[2]; L[8] = (H[8] - L[6] * L[3] - L[7] * L[4]) / L[5];
+                L[9] = sqrt(H[9] - L[6] * L[6] - L[7] * L[7] - L[8] * L[8]);
+                double* X = Xb + 20 * li;
+#pragma unroll
+                for (int cidx = 0; cidx < 4; ++cidx) {
+                    double e[4] = {0, 0, 0, 0}; e[cidx] = 1.0;
+                    e[0] = e[0] / L[0];
+                    e[1] = (e[1] - L[1] * e[0]) / L[2];
+                    e[2] = (e[2] - L[3] * e[0] - L[4] * e[1]) / L[5];
+                    e[3] = (e[3] - L[6] * e[0] - L[7] * e[1] - L[8] * e[2]) / L[9];
+                    e[3] = e[3] / L[9];
+                    e[2] = (e[2] - L[8] * e[3]) / L[5];
+                    e[1] = (e[1] - L[4] * e[2] - L[7] * e[3]) / L[2];
+                    e[0] = (e[0] - L[1] * e[1] - L[3] * e[2] - L[6] * e[3]) / L[0];
+                    X[0 * 4 + cidx] = e[0]; X[1 * 4 + cidx] = e[1]; X[2 * 4 + cidx] = e[2]; X[3 * 4 + cidx] = e[3];
+                }
+            }
+            __syncthreads();
+            // Hinv * g (needs the full inverse) + pass B2: one lane per line observation: E and Y = Hinv E
+            for (int li = tid; li < nlm; li += NT) {
+                const int k = k0 + li;
+                double* X = Xb + 20 * li; double* lx = c.ws + h.w_ln_x + 12 * (size_t)k;
+#pragma unroll
+                for (int a = 0; a < 4; ++a) { const double v = X[4 * a] * lx[4] + X[4 * a + 1] * lx[5] + X[4 * a + 2] * lx[6] + X[4 * a + 3] * lx[7]; X[16 + a] = v; lx[a] = v; }
+            }
+            for (int o = tid; o < nob; o += NT) {
+                const int li = c.bi[h.i_ln_lm + o0 + o] - k0;
+                const double* R = rec + (size_t)o * UVS_LN_REC;
+                const double* X = Xb + 20 * li;
+                double* E = Eb + (size_t)o * 24; double* Y = Yb + (size_t)o * 24;
+                double* Yg = c.ws + h.w_ln_Y + 24 * (size_t)(o0 + o);
+#pragma unroll
+                for (int a = 0; a < 6; ++a) {
+                    double e[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { e[q] = R[14 + q] * R[2 + a] + R[18 + q] * R[8 + a] + R[29 + q] * R[23 + a]; E[6 * q + a] = e[q]; }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { const double y = X[4 * q] * e[0] + X[4 * q + 1] * e[1] + X[4 * q + 2] * e[2] + X[4 * q + 3] * e[3]; Y[6 * q + a] = y; Yg[6 * q + a] = y; }
+                }
+            }
+            __syncthreads();
+            // pass C
+#pragma unroll
+            for (int q = 0; q < ITEMS_PER_THREAD; ++q) {
+                const GatherItem it = decode_item(tid + q * NT);
+                if (it.type < 0) continue;
+                double s = 0.0;
+                for (int li = 0; li < nlm; ++li) {
+                    const signed char* sm = slot + 11 * li;
+                    const int sa = sm[it.fa];
+                    if (sa < 0) continue;
+                    const int b0 = beg[k0 + li] - o0;
+                    const double* Ea = Eb + (size_t)(b0 + sa) * 24;
+                    const double* Ra = rec + (size_t)(b0 + sa) * UVS_LN_REC;
+                    if (it.type == 0) {
+                        const int sb = sm[it.fb];
+                        if (sb < 0) continue;
+                        const double* Y = Yb + (size_t)(b0 + sb) * 24;
+                        s -= Ea[it.a] * Y[it.b] + Ea[6 + it.a] * Y[6 + it.b] + Ea[12 + it.a] * Y[12 + it.b] + Ea[18 + it.a] * Y[18 + it.b];
+                        if (it.fa == it.fb) s += Ra[2 + it.a] * Ra[2 + it.b] + Ra[8 + it.a] * Ra[8 + it.b] + Ra[23 + it.a] * Ra[23 + it.b];
+                    } else if (it.type == 1) {
+                        const double* X = Xb + 20 * li;
+                        s += Ra[2 + it.a] * Ra[0] + Ra[8 + it.a] * Ra[1] + Ra[23 + it.a] * Ra[22];
+                        s -= Ea[it.a] * X[16] + Ea[6 + it.a] * X[17] + Ea[12 + it.a] * X[18] + Ea[18 + it.a] * X[19];
+                    } else {
+                        s += Ra[2 + it.a] * Ra[2 + it.a] + Ra[8 + it.a] * Ra[8 + it.a] + Ra[23 + it.a] * Ra[23 + it.a];
+                    }
+                }
+                acc[q] += s;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- assemble the reduced system in LDS
+    for (int i = tid; i < UVS_S_DOUBLES; i += NT) sh[L_S + i] = 0.0;
+    if (tid < UVS_RD) { sh[L_G + tid] = 0.0; sh[L_HD + tid] = 0.0; }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < ITEMS_PER_THREAD; ++q) {
+        const GatherItem it = decode_item(tid + q * NT);
+        if (it.type == 0) { if (it.fa != it.fb || it.a >= it.b) sh[L_S + sidx(16 * it.fa + it.a, 16 * it.fb + it.b)] = acc[q]; }
+        else if (it.type == 1) sh[L_G + 16 * it.fa + it.a] = acc[q];
+        else if (it.type == 2) sh[L_HD + 16 * it.fa + it.a] = acc[q];
+    }
+    // IMU whitening: Jw = W * Jraw (W upper triangular), rw = W * rraw
+    for (int t = tid; t < h.n_imu * 465; t += NT) {
+        const int b = t / 465, e = t - b * 465;
+        if (c.bi[h.i_imu + 2 * b + 1]) continue;
+        const double* W = c.bd + h.d_imu + (size_t)b * UVS_IMU_STRIDE + UVS_IMU_W;
+        double* wj = c.ws + h.w_imu + (size_t)b * UVS_WIMU_STRIDE;
+        if (e < 450) { const int r = e / 30, cc = e - r * 30; double s = 0.0; for (int k = r; k < 15; ++k) s += W[r * 15 + k] * wj[k * 30 + cc]; wj[450 + e] = s; }
+        else { const int r = e - 450; double s = 0.0; for (int k = r; k < 15; ++k) s += W[r * 15 + k] * wj[900 + k]; wj[915 + r] = s; cost += 0.5 * s * s; }
+    }
+    __syncthreads();
+    // IMU normal-equation blocks (even blocks, then odd blocks: consecutive blocks share a diagonal frame block)
+    for (int par = 0; par < 2; ++par) {
+        for (int t = tid; t < h.n_imu * 495; t += NT) {
+            const int b = t / 495, e = t - b * 495;
+            if ((b & 1) != par || c.bi[h.i_imu + 2 * b + 1]) continue;
+            const int fi = c.bi[h.i_imu + 2 * b];
+            const double* Jw = c.ws + h.w_imu + (size_t)b * UVS_WIMU_STRIDE + 450;
+            const double* rw = Jw + 465;
+            if (e < 465) {
+                int a = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+                while (((a + 1) * (a + 2)) >> 1 <= e) ++a;
+                while (((a * (a + 1)) >> 1) > e) --a;
+                const int cc = e - ((a * (a + 1)) >> 1);     // a >= cc
+                double s = 0.0;
+#pragma unroll
+                for (int r = 0; r < 15; ++r) s += Jw[r * 30 + a] * Jw[r * 30 + cc];
+                const int ia = 16 * (fi + (a >= 15)) + (a >= 15 ? a - 15 : a), ic = 16 * (fi + (cc >= 15)) + (cc >= 15 ? cc - 15 : cc);
+                sh[L_S + sidx(ia, ic)] += s;
+                if (a == cc) sh[L_HD + ia] += s;
+            } else {
+                const int a = e - 465;
+                double s = 0.0;
+#pragma unroll
+                for (int r = 0; r < 15; ++r) s += Jw[r * 30 + a] * rw[r];
+                sh[L_G + 16 * (fi + (a >= 15)) + (a >= 15 ? a - 15 : a)] += s;
+            }
+        }
+        __syncthreads();
+    }
+    // prior: H0 = J0^T J0 (precomputed), g = J0^T r
+    if (h.prior_n > 0) {
+        const int n = h.prior_n;
+        const int* cm = c.bi + h.i_prior + 80;
+        const double* J0 = c.bd + h.d_prior; const double* H0 = J0 + n * n;
+        for (int t = tid; t < n * n; t += NT) {
+            const int a = t / n, cc = t - a * n;
+            if (cc > a) continue;
+            const int ia = cm[a], ic = cm[cc];
+            if (ia < 0 || ic < 0) continue;
+            const double v = H0[a * n + cc];
+            sh[L_S + (ia >= ic ? sidx(ia, ic) : sidx(ic, ia))] += v;
+            if (a == cc) sh[L_HD + ia] += v;
+        }
+        if (tid < n && cm[tid] >= 0) {
+            double s = 0.0;
+            for (int i = 0; i < n; ++i) s += J0[i * n + tid] * sh[L_PR + i];
+            sh[L_G + cm[tid]] += s;
+        }
+    }
+    __syncthreads();
+    // frame damping, Jacobi scaling (first linearization only), dummy pivots, projected-gradient max norm
+    double gmax = gmax_lm;
+    if (tid < UVS_RD) {
+        const int k = tid & 15;
+        if (k < 15) {
+            const double hd = sh[L_HD + tid];
+            if (first) sh[L_SC + tid] = c.o.jacobi ? 1.0 / (1.0 + sqrt(hd)) : 1.0;
+            const double sc = sh[L_SC + tid];
+            const double dd = fmin(fmax(sc * sc * hd, c.o.dlo), c.o.dhi) / (radius * sc * sc);
+            sh[L_DD + tid] = dd;
+            sh[L_S + sidx(tid, tid)] += dd;
+            if (k >= 6) gmax = fmax(gmax, fabs(sh[L_G + tid]));
+        } else { sh[L_S + sidx(tid, tid)] = 1.0; sh[L_DD + tid] = 0.0; sh[L_G + tid] = 0.0; sh[L_SC + tid] = 1.0; }
+    }
+    if (tid < UVS_NF) {   // || x - Plus(x, -g) ||_inf on the pose block
+        double d[6], xp[7];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) d[k] = -sh[L_G + 16 * tid + k];
+        pose_plus(x + 7 * tid, d, xp);
+#pragma unroll
+        for (int k = 0; k < 7; ++k) gmax = fmax(gmax, fabs(x[7 * tid + k] - xp[k]));
+    }
+    double s4[4] = {cost, 0.0, 0.0, 0.0};
+    block_reduce(sh, s4, &gmax);
+    if (tid == 0) { sh[L_CTRL + C_COST] = s4[0]; sh[L_CTRL + C_GMAX] = gmax; }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------ back-substitution + candidate + model terms
+// frames: XC = X (+) DLT ; landmarks: cand = cur + delta.  Accumulates into CTRL: MCC, STEP2, XC2.
+UVS_DEV void backsub_candidate(const Ctx& c, const double* invd, const double* line, double* invd_c, double* line_c) {
+    const DevWin& h = *c.hdr;
+    double* sh = c.sh;
+    const int tid = threadIdx.x;
+    const double* d = sh + L_DLT;
+    double gd = 0.0, dd2 = 0.0, step2 = 0.0, xc2 = 0.0;
+    if (tid < UVS_RD && (tid & 15) < 15) { gd += sh[L_G + tid] * d[tid]; dd2 += sh[L_DD + tid] * d[tid] * d[tid]; }
+    if (tid < UVS_NF) {
+        double xp[7];
+        pose_plus(sh + L_X + 7 * tid, d + 16 * tid, xp);
+#pragma unroll
+        for (int k = 0; k < 7; ++k) { sh[L_XC + 7 * tid + k] = xp[k]; const double e = xp[k] - sh[L_X + 7 * tid + k]; step2 += e * e; xc2 += xp[k] * xp[k]; }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { const double v = sh[L_X + 77 + 9 * tid + k] + d[16 * tid + 6 + k]; sh[L_XC + 77 + 9 * tid + k] = v; step2 += d[16 * tid + 6 + k] * d[16 * tid + 6 + k]; xc2 += v * v; }
+    }
+    if (tid == UVS_NF) { for (int k = 0; k < 8; ++k) sh[L_XC + 176 + k] = sh[L_X + 176 + k]; }   // Ex_Pose constant (ESTIMATE_EXTRINSIC=0)
+    // points: delta = -ginv - sum_s Einv[s] . delta_pose(frame(s))
+    const int* pbeg = c.bi + h.i_pt_beg;
+    for (int k = tid; k < h.n_points; k += NT) {
+        const int b0 = pbeg[k], b1 = pbeg[k + 1];
+        const double* px = c.ws + h.w_pt_x + 4 * (size_t)k;
+        const double* Eg = c.ws + h.w_pt_E + 6 * (size_t)(b0 + k);
+        double dl = -px[0];
+        if (b1 > b0) {
+            const int fi = c.bi[h.i_pt_fi + b0];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) dl -= Eg[a] * d[16 * fi + a];
+            for (int o = b0; o < b1; ++o) {
+                const int fj = c.bi[h.i_pt_fj + o];
+                const double* e = Eg + 6 * (o - b0 + 1);
+#pragma unroll
+                for (int a = 0; a < 6; ++a) dl -= e[a] * d[16 * fj + a];
+            }
+        }
+        const double v = invd[k] + dl;
+        invd_c[k] = v;
+        gd += px[1] * dl; dd2 += px[2] * dl * dl; step2 += dl * dl; xc2 += v * v;
+    }
+    // lines: delta(4) = -Hinv g - sum_s Y[s] delta_pose
+    const int* lbeg = c.bi + h.i_ln_beg;
+    for (int k = tid; k < h.n_lines; k += NT) {
+        const int b0 = lbeg[k], b1 = lbeg[k + 1];
+        const double* lx = c.ws + h.w_ln_x + 12 * (size_t)k;
+        double dl[4] = {-lx[0], -lx[1], -lx[2], -lx[3]};
+        for (int o = b0; o < b1; ++o) {
+            const int fj = c.bi[h.i_ln_fj + o];
+            const double* Y = c.ws + h.w_ln_Y + 24 * (size_t)o;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int a = 0; a < 6; ++a) dl[q] -= Y[6 * q + a] * d[16 * fj + a];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const double v = line[4 * k + q] + dl[q];
+            line_c[4 * k + q] = v;
+            gd += lx[4 + q] * dl[q]; dd2 += lx[8 + q] * dl[q] * dl[q]; step2 += dl[q] * dl[q]; xc2 += v * v;
+        }
+    }
+    double s4[4] = {gd, dd2, step2, xc2};
+    double mx = 0.0;
+    block_reduce(sh, s4, &mx);
+    if (tid == 0) {
+        sh[L_CTRL + C_MCC] = 0.5 * (s4[1] - s4[0]);     // model_cost_change = -(J d).(r + J d/2) with (H + D) d = -g
+        sh[L_CTRL + C_STEP2] = s4[2];
+        sh[L_CTRL + C_XC2] = s4[3];
+    }
+    __syncthreads();
+}
+
+UVS_DEV double ambient_sqnorm(const Ctx& c, const double* x, const double* invd, const double* line) {
+    const DevWin& h = *c.hdr;
+    const int tid = threadIdx.x;
+    double s = 0.0;
+    if (tid < 176) s += x[tid] * x[tid];
+    for (int k = tid; k < h.n_points; k += NT) s += invd[k] * invd[k];
+    for (int k = tid; k < 4 * h.n_lines; k += NT) s += line[k] * line[k];
+    double s4[4] = {s, 0, 0, 0}, mx = 0.0;
+    block_reduce(c.sh, s4, &mx);
+    return s4[0];
+}
+
+// ------------------------------------------------------------------ the kernel
+// setup: IMU whitening matrices W = chol_lower(cov^-1)^T (imu_factor.h:64) and prior H0 = J0^T J0, once per solve.
+UVS_DEV void setup_window(const Ctx& c, double* blob_rw) {
+    const DevWin& h = *c.hdr;
+    const int tid = threadIdx.x;
+    if (tid < h.n_imu) {
+        double* blk = blob_rw + h.d_imu + (size_t)tid * UVS_IMU_STRIDE;
+        const double* cov = blk + UVS_IMU_COV; double* W = blk + UVS_IMU_W;
+        double* M = c.ws + h.w_imu + (size_t)tid * UVS_WIMU_STRIDE;      // scratch 15 x 30 (Gauss-Jordan with partial pivoting)
+        for (int i = 0; i < 15; ++i) for (int j = 0; j < 15; ++j) { M[i * 30 + j] = cov[i * 15 + j]; M[i * 30 + 15 + j] = (i == j) ? 1.0 : 0.0; }
+        for (int k = 0; k < 15; ++k) {
+            int piv = k; double best = fabs(M[k * 30 + k]);
+            for (int i = k + 1; i < 15; ++i) { const double v = fabs(M[i * 30 + k]); if (v > best) { best = v; piv = i; } }
+            if (piv != k) for (int j = 0; j < 30; ++j) { const double t = M[k * 30 + j]; M[k * 30 + j] = M[piv * 30 + j]; M[piv * 30 + j] = t; }
+            const double dinv = 1.0 / M[k * 30 + k];
+            for (int i = k + 1; i < 15; ++i) { const double f = M[i * 30 + k] * dinv; for (int j = k; j < 30; ++j) M[i * 30 + j] -= f * M[k * 30 + j]; }
+        }
+        for (int k = 14; k >= 0; --k) {
+            const double dinv = 1.0 / M[k * 30 + k];
+            for (int j = 0; j < 30; ++j) M[k * 30 + j] *= dinv;
+            for (int i = 0; i < k; ++i) { const double f = M[i * 30 + k]; for (int j = 0; j < 30; ++j) M[i * 30 + j] -= f * M[k * 30 + j]; }
+        }
+        // lower Cholesky of the inverse (read lower triangle), store transposed (upper)
+        double* Lm = M + 450;   // 225 scratch
+        for (int j = 0; j < 15; ++j) {
+            double dsum = M[j * 30 + 15 + j];
+            for (int k = 0; k < j; ++k) dsum -= Lm[j * 15 + k] * Lm[j * 15 + k];
+            const double ljj = sqrt(dsum);
+            Lm[j * 15 + j] = ljj;
+            for (int i = j + 1; i < 15; ++i) { double s = M[i * 30 + 15 + j]; for (int k = 0; k < j; ++k) s -= Lm[i * 15 + k] * Lm[j * 15 + k]; Lm[i * 15 + j] = s / ljj; }
+        }
+        for (int i = 0; i < 15; ++i) for (int j = 0; j < 15; ++j) W[i * 15 + j] = (j >= i) ? Lm[j * 15 + i] : 0.0;
+    }
+    if (h.prior_n > 0) {
+        const int n = h.prior_n;
+        const double* J0 = blob_rw + h.d_prior; double* H0 = blob_rw + h.d_prior + n * n;
+        for (int t = tid; t < n * n; t += NT) {
+            const int a = t / n, cc = t - a * n;
+            double s = 0.0;
+            for (int i = 0; i < n; ++i) s += J0[i * n + a] * J0[i * n + cc];
+            H0[t] = s;
+        }
+    }
+}
+
+struct DebugOut {   // optional dump of the first linearization (uvs_debug_linearize)
+    double* S;      // [176*176] dense lower (damped, Schur-reduced)
+    double* g;      // [176]
+    double* hd;     // [176]
+    double* dd;     // [176]
+    double* step;   // [176] solution of S y = -g
+    double* scal;   // [8] cost, gmax, chol_ok, mcc, step2
+};
+
+__global__ __launch_bounds__(NT) void k_solve(char* blobs, const long long* blob_off, double* ws_all, const long long* ws_off,
+                                              KOpts o, uvs_report* reports, DebugOut dbg) {
+    extern __shared__ __attribute__((aligned(16))) double sh[];
+    const int tid = threadIdx.x, wdx = blockIdx.x;
+    char* blob = blobs + blob_off[wdx];
+    Ctx c;
+    c.hdr = (const DevWin*)blob; c.bd = (const double*)blob; c.bi = (const int*)blob; c.ws = ws_all + ws_off[wdx]; c.sh = sh; c.o = o;
+    const DevWin& h = *c.hdr;
+    uvs_report* rep = reports + wdx;
+    // ---- init: frames -> LDS, landmark parameters -> workspace buffer 0
+    if (tid < 184) sh[L_X + tid] = (tid < 183) ? c.bd[h.d_frames + tid] : 0.0;
+    for (int k = tid; k < h.n_points; k += NT) c.ws[h.w_invd0 + k] = c.bd[h.d_invd + k];
+    for (int k = tid; k < 4 * h.n_lines; k += NT) c.ws[h.w_line0 + k] = c.bd[h.d_line + k];
+    for (int i = tid; i < (int)(sizeof(uvs_report) / 4); i += NT) ((int*)rep)[i] = 0;
+    setup_window(c, (double*)blob);
+    __syncthreads();
+    int cur = 0;
+    double* invd[2] = {c.ws + h.w_invd0, c.ws + h.w_invd1};
+    double* line[2] = {c.ws + h.w_line0, c.ws + h.w_line1};
+    double radius = o.r0, decr = 2.0;
+    linearize(c, sh + L_X, invd[0], line[0], true, radius);
+    const double xn2 = ambient_sqnorm(c, sh + L_X, invd[0], line[0]);
+    double cost = sh[L_CTRL + C_COST], gmax = sh[L_CTRL + C_GMAX], x_norm = sqrt(xn2);
+    int it = 0, invalid = 0, nsucc = 0, term = UVS_TERM_NO_CONVERGENCE, status = UVS_OK;
+    if (tid == 0) { rep->initial_cost = cost; rep->cost[0] = cost; rep->radius[0] = radius; rep->gradient_max_norm[0] = gmax; rep->accepted[0] = 1; }
+    bool relin = false;     // the LDS system is stale (radius changed after a rejected / invalid step)
+    if (!isfinite(cost)) { term = UVS_TERM_NUMERIC_FAILURE; status = UVS_ERR_NUMERIC; }
+    else if (gmax <= o.gtol) term = UVS_TERM_GRADIENT_TOL;
+    else while (true) {
+        if (it >= o.max_it) { term = UVS_TERM_NO_CONVERGENCE; break; }
+        if (gmax <= o.gtol) { term = UVS_TERM_GRADIENT_TOL; break; }
+        if (radius <= o.rmin) { term = UVS_TERM_MIN_RADIUS; break; }
+        ++it;
+        const int ti = it < UVS_MAX_ITER ? it : UVS_MAX_ITER;
+        if (relin) { linearize(c, sh + L_X, invd[cur], line[cur], false, radius); relin = false; }
+        // ---- step: (S) y = -g
+        if (tid < UVS_RD) sh[L_DLT + tid] = -sh[L_G + tid];
+        if (o.debug && it == 1 && dbg.S) {
+            __syncthreads();
+            for (int t = tid; t < UVS_RD * UVS_RD; t += NT) { const int i = t / UVS_RD, j = t - i * UVS_RD; dbg.S[t] = (j <= i) ? sh[L_S + sidx(i, j)] : 0.0; }
+            if (tid < UVS_RD) { dbg.g[tid] = sh[L_G + tid]; dbg.hd[tid] = sh[L_HD + tid]; dbg.dd[tid] = sh[L_DD + tid]; }
+        }
+        chol_factor(c);
+        chol_solve(c);
+        bool ok = sh[L_CTRL + C_CHOLOK] != 0.0;
+        backsub_candidate(c, invd[cur], line[cur], invd[cur ^ 1], line[cur ^ 1]);
+        const double mcc = sh[L_CTRL + C_MCC], step2 = sh[L_CTRL + C_STEP2], xc2 = sh[L_CTRL + C_XC2];
+        if (o.debug && it == 1 && dbg.S) {
+            if (tid < UVS_RD) dbg.step[tid] = sh[L_DLT + tid];
+            if (tid == 0) { dbg.scal[0] = cost; dbg.scal[1] = gmax; dbg.scal[2] = ok ? 1.0 : 0.0; dbg.scal[3] = mcc; dbg.scal[4] = step2; }
+        }
+        if (!isfinite(mcc) || !isfinite(step2)) ok = false;
+        if (tid == 0) rep->model_cost_change[ti] = mcc;
+        if (!ok || !(mcc > 0.0)) {    // invalid step
+            ++invalid;
+            radius = radius / decr; decr *= 2.0; relin = true;
+            if (tid == 0) { rep->accepted[ti] = -1; rep->cost[ti] = cost; rep->candidate_cost[ti] = cost; rep->radius[ti] = radius; rep->gradient_max_norm[ti] = gmax; }
+            if (invalid >= o.max_invalid) { term = UVS_TERM_INVALID_STEPS; break; }
+            continue;
+        }
+        invalid = 0;
+        // ---- candidate cost
+        __syncthreads();
+        stage_rotations(c, sh + L_XC);
+        prior_dx(c, sh + L_XC);
+        __syncthreads();
+        double cc_ = prior_residual(c);
+        cc_ += cost_pass(c, sh + L_XC, invd[cur ^ 1], line[cur ^ 1]);
+        double s4[4] = {cc_, 0, 0, 0}, mx = 0.0;
+        block_reduce(sh, s4, &mx);
+        double cand = s4[0];
+        if (!isfinite(cand)) cand = 1.7976931348623157e308;
+        const double step_norm = sqrt(step2);
+        const double rel = (cost - cand) / mcc;
+        const bool successful = rel > o.min_rel;
+        if (tid == 0) { rep->candidate_cost[ti] = cand; rep->step_norm[ti] = step_norm; rep->relative_decrease[ti] = rel; rep->cost[ti] = cost; rep->radius[ti] = radius; rep->gradient_max_norm[ti] = gmax; }
+        bool stop = false;
+        if (step_norm <= o.ptol * (x_norm + o.ptol)) { term = UVS_TERM_PARAMETER_TOL; stop = true; }
+        else if (fabs(cost - cand) <= o.ftol * cost) { term = UVS_TERM_FUNCTION_TOL; stop = true; }
+        if (stop) {
+            if (o.keep_cand && successful) {
+                __syncthreads();
+                if (tid < 184) sh[L_X + tid] = sh[L_XC + tid];
+                cur ^= 1; cost = cand; ++nsucc;
+                if (tid == 0) { rep->cost[ti] = cost; rep->accepted[ti] = 1; }
+            }
+            break;
+        }
+        if (successful) {
+            __syncthreads();
+            if (tid < 184) sh[L_X + tid] = sh[L_XC + tid];
+            cur ^= 1; ++nsucc;
+            x_norm = sqrt(xc2);
+            radius = radius / fmax(1.0 / 3.0, 1.0 - pow(2.0 * rel - 1.0, 3.0));
+            radius = fmin(o.rmax, radius);
+            decr = 2.0;
+            __syncthreads();
+            linearize(c, sh + L_X, invd[cur], line[cur], false, radius);
+            cost = sh[L_CTRL + C_COST]; gmax = sh[L_CTRL + C_GMAX];
+            if (tid == 0) rep->accepted[ti] = 1;
+        } else {
+            radius = radius / decr; decr *= 2.0; relin = true;
+            if (tid == 0) rep->accepted[ti] = 0;
+        }
+        if (tid == 0) { rep->cost[ti] = cost; rep->radius[ti] = radius; rep->gradient_max_norm[ti] = gmax; }
+    }
+    __syncthreads();
+    if (tid < 184) c.ws[h.w_out + tid] = sh[L_X + tid];
+    if (tid == 0) {
+        rep->status = status; rep->termination = term; rep->num_iterations = it; rep->num_successful = nsucc; rep->final_cost = cost;
+        ((DevWin*)blob)->cur_sel = cur;
+    }
+}
+
+}  // namespace uvsdev

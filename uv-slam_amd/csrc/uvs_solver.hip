@@ -1,0 +1,437 @@
+// uvs_solver.hip -- C ABI (include/uvs_solver.h) + host-side packing for the MI355X sliding-window solver.
+//
+// Build (see __graft_entry__.build()):
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC uvs_solver.hip -o ../libuvs_solver.so
+//
+// There is NO CPU path in this library: uvs_create() fails with UVS_ERR_NO_DEVICE when no HIP device
+// is present and every compute entry point runs HIP kernels.  The CPU oracle under oracle/ is test
+// infrastructure and is never linked or called from here.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/uvs_solver.h"
+#include "uvs_layout.h"
+#include "uvs_factors.h"
+#include "uvs_solve_kernel.h"
+#include "uvs_eval_kernel.h"
+#include "uvs_marg.h"
+
+using namespace uvsdev;
+
+struct uvs_solver {
+    uvs_options opts;
+    int device;
+    int max_batch;
+    hipStream_t stream;
+    hipEvent_t ev0, ev1;
+    std::string err;
+    // batch state
+    int n_loaded = 0;
+    std::vector<DevWin> hdrs;                // host copies of the per-window headers
+    std::vector<long long> blob_off, ws_off;
+    std::vector<char> host_blobs;
+    char* d_blobs = nullptr; size_t d_blobs_cap = 0;
+    double* d_ws = nullptr; size_t d_ws_cap = 0;
+    long long* d_blob_off = nullptr; long long* d_ws_off = nullptr; size_t d_off_cap = 0;
+    uvs_report* d_reports = nullptr; size_t d_rep_cap = 0;
+    double* d_dbg = nullptr;
+};
+
+#define HIPCHK(s, call)                                                                              \
+    do {                                                                                             \
+        hipError_t e_ = (call);                                                                      \
+        if (e_ != hipSuccess) { (s)->err = std::string(#call) + ": " + hipGetErrorString(e_); return UVS_ERR_HIP; } \
+    } while (0)
+
+static KOpts make_kopts(const uvs_options& o, int debug) {
+    KOpts k;
+    k.max_it = o.max_num_iterations; k.ex_free = o.estimate_extrinsic; k.keep_cand = o.function_tol_keeps_candidate; k.jacobi = o.jacobi_scaling;
+    k.sqrt_info = o.point_sqrt_info; k.line_factor = o.line_factor; k.vp_factor = o.vp_factor;
+    k.loss_pt = o.loss_point; k.loss_ln = o.loss_line; k.loss_vp = o.loss_vp;
+    k.G[0] = o.gravity[0]; k.G[1] = o.gravity[1]; k.G[2] = o.gravity[2];
+    k.r0 = o.initial_trust_region_radius; k.rmax = o.max_trust_region_radius; k.rmin = o.min_trust_region_radius;
+    k.min_rel = o.min_relative_decrease; k.dlo = o.min_lm_diagonal; k.dhi = o.max_lm_diagonal;
+    k.ftol = o.function_tolerance; k.gtol = o.gradient_tolerance; k.ptol = o.parameter_tolerance;
+    k.max_invalid = o.max_consecutive_invalid_steps; k.debug = debug;
+    return k;
+}
+
+extern "C" {
+
+int uvs_abi_version(void) { return UVS_ABI_VERSION; }
+
+void uvs_default_options(uvs_options* o) {
+    if (!o) return;
+    std::memset(o, 0, sizeof(*o));
+    o->max_num_iterations = 10;          // euroc_config.yaml:56
+    o->estimate_extrinsic = 0;           // :26
+    o->estimate_td = 0;                  // :73
+    o->function_tol_keeps_candidate = 0;
+    o->focal_length = 461.6;             // :20
+    o->point_sqrt_info = 461.6 / 1.6;    // estimator.cpp:17
+    o->line_factor = 300.0; o->vp_factor = 10.0;   // :86-87
+    o->loss_point = 1.0; o->loss_line = 0.1; o->loss_vp = 1.0;   // estimator.cpp:765-772
+    o->gravity[0] = 0.0; o->gravity[1] = 0.0; o->gravity[2] = 9.81007;   // :64
+    o->initial_trust_region_radius = 1e4; o->max_trust_region_radius = 1e16; o->min_trust_region_radius = 1e-32;
+    o->min_relative_decrease = 1e-3; o->min_lm_diagonal = 1e-6; o->max_lm_diagonal = 1e32;
+    o->function_tolerance = 1e-6; o->gradient_tolerance = 1e-10; o->parameter_tolerance = 1e-8;
+    o->max_consecutive_invalid_steps = 5; o->jacobi_scaling = 1;
+}
+
+const char* uvs_status_string(int st) {
+    switch (st) {
+        case UVS_OK: return "ok";
+        case UVS_ERR_INVALID_ARG: return "invalid argument";
+        case UVS_ERR_UNSUPPORTED: return "unsupported configuration";
+        case UVS_ERR_NO_DEVICE: return "no HIP device (this library has no CPU path)";
+        case UVS_ERR_HIP: return "HIP runtime error";
+        case UVS_ERR_CAPACITY: return "capacity exceeded";
+        case UVS_ERR_NUMERIC: return "numeric failure";
+    }
+    return "unknown";
+}
+
+const char* uvs_last_error(const uvs_solver* s) { return s ? s->err.c_str() : "null solver"; }
+
+int uvs_reduced_dim(const uvs_options* o) { return 15 * UVS_NUM_FRAMES + ((o && o->estimate_extrinsic) ? 6 : 0); }
+
+int uvs_create(const uvs_options* opts, int device, int max_batch, int /*max_points*/, int /*max_point_obs*/, int /*max_lines*/,
+               int /*max_line_obs*/, uvs_solver** out) {
+    if (!opts || !out || max_batch < 1) return UVS_ERR_INVALID_ARG;
+    if (opts->estimate_td || opts->estimate_extrinsic) return UVS_ERR_UNSUPPORTED;
+    if (opts->max_num_iterations < 0) return UVS_ERR_INVALID_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return UVS_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return UVS_ERR_NO_DEVICE;
+    uvs_solver* s = new uvs_solver();
+    s->opts = *opts; s->device = device; s->max_batch = max_batch;
+    if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess) { delete s; return UVS_ERR_HIP; }
+    // block table for the output-stationary gather
+    unsigned char fa[UVS_NBLK], fb[UVS_NBLK];
+    for (int i = 0, b = 0; i < UVS_NF; ++i) for (int j = 0; j <= i; ++j, ++b) { fa[b] = (unsigned char)i; fb[b] = (unsigned char)j; }
+    if (hipMemcpyToSymbol(HIP_SYMBOL(c_blk_fa), fa, sizeof(fa)) != hipSuccess || hipMemcpyToSymbol(HIP_SYMBOL(c_blk_fb), fb, sizeof(fb)) != hipSuccess) { delete s; return UVS_ERR_HIP; }
+    if (hipFuncSetAttribute((const void*)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES) != hipSuccess) { delete s; return UVS_ERR_HIP; }
+    *out = s;
+    return UVS_OK;
+}
+
+void uvs_destroy(uvs_solver* s) {
+    if (!s) return;
+    hipSetDevice(s->device);
+    if (s->d_blobs) hipFree(s->d_blobs);
+    if (s->d_ws) hipFree(s->d_ws);
+    if (s->d_blob_off) hipFree(s->d_blob_off);
+    if (s->d_ws_off) hipFree(s->d_ws_off);
+    if (s->d_reports) hipFree(s->d_reports);
+    if (s->d_dbg) hipFree(s->d_dbg);
+    hipEventDestroy(s->ev0); hipEventDestroy(s->ev1);
+    hipStreamDestroy(s->stream);
+    delete s;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------ host packing: uvs_window -> blob
+static inline int rup(int v, int m) { return (v + m - 1) / m * m; }
+
+static int validate_window(const uvs_window* w, std::string& err) {
+    if (!w) { err = "null window"; return UVS_ERR_INVALID_ARG; }
+    if (w->n_points < 0 || w->n_point_obs < 0 || w->n_lines < 0 || w->n_line_obs < 0 || w->n_imu < 0 || w->n_imu > UVS_WINDOW_SIZE) { err = "bad counts"; return UVS_ERR_INVALID_ARG; }
+    if ((w->n_point_obs && (!w->pt_lm || !w->pt_fi || !w->pt_fj || !w->pt_pi || !w->pt_pj || !w->inv_depth)) ||
+        (w->n_line_obs && (!w->ln_lm || !w->ln_fj || !w->ln_sp || !w->ln_ep || !w->ln_has_vp || !w->ln_vp || !w->line_orth)) || (w->n_imu && !w->imu)) { err = "null array"; return UVS_ERR_INVALID_ARG; }
+    int prev = -1, prev_fj = -1, anchor = -1;
+    for (int k = 0; k < w->n_point_obs; ++k) {
+        const int lm = w->pt_lm[k], fi = w->pt_fi[k], fj = w->pt_fj[k];
+        if (lm < 0 || lm >= w->n_points || lm < prev) { err = "point observations must be grouped by non-decreasing landmark index"; return UVS_ERR_INVALID_ARG; }
+        if (fi < 0 || fj <= fi || fj >= UVS_NUM_FRAMES) { err = "point observation needs 0 <= imu_i < imu_j <= WINDOW_SIZE"; return UVS_ERR_INVALID_ARG; }
+        if (lm != prev) { anchor = fi; prev_fj = -1; }
+        if (fi != anchor || fj <= prev_fj) { err = "point observations of one landmark must share imu_i and have increasing imu_j"; return UVS_ERR_INVALID_ARG; }
+        prev = lm; prev_fj = fj;
+    }
+    prev = -1; prev_fj = -1;
+    for (int k = 0; k < w->n_line_obs; ++k) {
+        const int lm = w->ln_lm[k], fj = w->ln_fj[k];
+        if (lm < 0 || lm >= w->n_lines || lm < prev) { err = "line observations must be grouped by non-decreasing landmark index"; return UVS_ERR_INVALID_ARG; }
+        if (fj < 0 || fj >= UVS_NUM_FRAMES) { err = "line observation frame out of range"; return UVS_ERR_INVALID_ARG; }
+        if (lm != prev) prev_fj = -1;
+        if (fj <= prev_fj) { err = "line observations of one landmark must have increasing imu_j"; return UVS_ERR_INVALID_ARG; }
+        prev = lm; prev_fj = fj;
+    }
+    for (int b = 0; b < w->n_imu; ++b) if (w->imu[b].frame_i < 0 || w->imu[b].frame_i >= UVS_WINDOW_SIZE) { err = "imu frame_i out of range"; return UVS_ERR_INVALID_ARG; }
+    if (w->prior && w->prior->n > 0) {
+        const uvs_prior& p = *w->prior;
+        if (p.n > UVS_MAX_PRIOR_DIM || p.n_blocks < 1 || p.n_blocks > UVS_MAX_PRIOR_BLOCKS) { err = "prior too large"; return UVS_ERR_CAPACITY; }
+        for (int b = 0; b < p.n_blocks; ++b) {
+            if (p.block_kind[b] == UVS_BLOCK_TD) { err = "td block in prior"; return UVS_ERR_UNSUPPORTED; }
+            const int loc = p.block_size[b] == 7 ? 6 : p.block_size[b];
+            if (p.block_idx[b] < 0 || p.block_idx[b] + loc > p.n) { err = "prior block index out of range"; return UVS_ERR_INVALID_ARG; }
+            if ((p.block_kind[b] == UVS_BLOCK_POSE || p.block_kind[b] == UVS_BLOCK_SPEEDBIAS) && (p.block_frame[b] < 0 || p.block_frame[b] >= UVS_NUM_FRAMES)) { err = "prior frame out of range"; return UVS_ERR_INVALID_ARG; }
+        }
+    }
+    return UVS_OK;
+}
+
+// appends the blob of `w` to `out` (8-byte aligned) and returns its header
+static int pack_window(const uvs_window* w, std::vector<char>& out, DevWin& hdr, std::string& err) {
+    int rc = validate_window(w, err);
+    if (rc != UVS_OK) return rc;
+    DevWin h; std::memset(&h, 0, sizeof(h));
+    h.n_points = w->n_points; h.n_pt_obs = w->n_point_obs; h.n_lines = w->n_lines; h.n_ln_obs = w->n_line_obs; h.n_imu = w->n_imu;
+    const bool have_prior = w->prior && w->prior->n > 0;
+    h.prior_n = have_prior ? w->prior->n : 0; h.prior_nb = have_prior ? w->prior->n_blocks : 0;
+    h.pt_stride = rup(std::max(h.n_pt_obs, 1), 8); h.ln_stride = rup(std::max(h.n_ln_obs, 1), 8);
+    // CSR by landmark
+    std::vector<int> pbeg(h.n_points + 1, 0), lbeg(h.n_lines + 1, 0);
+    for (int k = 0; k < h.n_pt_obs; ++k) pbeg[w->pt_lm[k] + 1]++;
+    for (int k = 0; k < h.n_points; ++k) pbeg[k + 1] += pbeg[k];
+    for (int k = 0; k < h.n_ln_obs; ++k) lbeg[w->ln_lm[k] + 1]++;
+    for (int k = 0; k < h.n_lines; ++k) lbeg[k + 1] += lbeg[k];
+    // chunks: greedy packing of whole landmarks into the LDS staging area (UVS_S_DOUBLES doubles)
+    std::vector<int> chunks;
+    {
+        int k0 = 0; long nob = 0;
+        for (int k = 0; k < h.n_points; ++k) {
+            const long no = pbeg[k + 1] - pbeg[k];
+            const long nlm = k - k0 + 1;
+            const long need = (long)UVS_PT_REC * (nob + no) + 6 * (nob + no + nlm) + 2 * nlm + (11 * nlm + 7) / 8;
+            if (need > UVS_S_DOUBLES && k > k0) { chunks.insert(chunks.end(), {0, k0, k, 0}); k0 = k; nob = 0; }
+            nob += no;
+            if ((long)UVS_PT_REC * nob + 6 * (nob + 1) + 2 + 2 > UVS_S_DOUBLES) { err = "single point landmark exceeds LDS staging"; return UVS_ERR_CAPACITY; }
+        }
+        if (h.n_points > k0) chunks.insert(chunks.end(), {0, k0, h.n_points, 0});
+        k0 = 0; nob = 0;
+        for (int k = 0; k < h.n_lines; ++k) {
+            const long no = lbeg[k + 1] - lbeg[k];
+            const long nlm = k - k0 + 1;
+            const long need = (long)(UVS_LN_REC + 48) * (nob + no) + 20 * nlm + (11 * nlm + 7) / 8;
+            if (need > UVS_S_DOUBLES && k > k0) { chunks.insert(chunks.end(), {1, k0, k, 0}); k0 = k; nob = 0; }
+            nob += no;
+        }
+        if (h.n_lines > k0) chunks.insert(chunks.end(), {1, k0, h.n_lines, 0});
+    }
+    h.n_chunks = (int)chunks.size() / 4;
+    // layout
+    int d = (int)((sizeof(DevWin) + 7) / 8);
+    h.d_frames = d; d += 184;
+    h.d_invd = d; d += rup(std::max(h.n_points, 1), 2);
+    h.d_ptmeas = d; d += 6 * h.pt_stride;
+    h.d_line = d; d += 4 * std::max(h.n_lines, 1);
+    h.d_lnmeas = d; d += 9 * h.ln_stride;
+    h.d_imu = d; d += std::max(h.n_imu, 1) * UVS_IMU_STRIDE;
+    h.d_prior = d; d += 2 * h.prior_n * h.prior_n + 2 * h.prior_n + 144;
+    int i = 2 * d;
+    h.i_pt_lm = i; i += h.pt_stride; h.i_pt_fi = i; i += h.pt_stride; h.i_pt_fj = i; i += h.pt_stride; h.i_pt_beg = i; i += rup(h.n_points + 1, 2);
+    h.i_ln_lm = i; i += h.ln_stride; h.i_ln_fj = i; i += h.ln_stride; h.i_ln_vp = i; i += h.ln_stride; h.i_ln_beg = i; i += rup(h.n_lines + 1, 2);
+    h.i_imu = i; i += 2 * std::max(h.n_imu, 1);
+    h.i_prior = i; i += 80 + UVS_MAX_PRIOR_DIM;
+    h.i_chunks = i; i += 4 * std::max(h.n_chunks, 1);
+    h.blob_bytes = rup(4 * i, 256);
+    // workspace layout
+    int wsz = 0;
+    h.w_invd0 = wsz; wsz += rup(std::max(h.n_points, 1), 2); h.w_invd1 = wsz; wsz += rup(std::max(h.n_points, 1), 2);
+    h.w_line0 = wsz; wsz += 4 * std::max(h.n_lines, 1); h.w_line1 = wsz; wsz += 4 * std::max(h.n_lines, 1);
+    h.w_scale_pt = wsz; wsz += rup(std::max(h.n_points, 1), 2); h.w_scale_ln = wsz; wsz += 4 * std::max(h.n_lines, 1);
+    h.w_pt_E = wsz; wsz += 6 * (h.n_pt_obs + h.n_points) + 6; h.w_pt_x = wsz; wsz += 4 * std::max(h.n_points, 1);
+    h.w_ln_Y = wsz; wsz += 24 * std::max(h.n_ln_obs, 1); h.w_ln_x = wsz; wsz += 12 * std::max(h.n_lines, 1);
+    h.w_imu = wsz; wsz += std::max(h.n_imu, 1) * UVS_WIMU_STRIDE;
+    h.w_out = wsz; wsz += 184;
+    h.ws_doubles = rup(wsz, 32);
+    // fill
+    const size_t base = out.size();
+    out.resize(base + h.blob_bytes, 0);
+    char* B = out.data() + base;
+    double* D = (double*)B; int* I = (int*)B;
+    std::memcpy(B, &h, sizeof(h));
+    std::memcpy(D + h.d_frames, w->pose, sizeof(double) * 77);
+    std::memcpy(D + h.d_frames + 77, w->speedbias, sizeof(double) * 99);
+    std::memcpy(D + h.d_frames + 176, w->ex_pose, sizeof(double) * 7);
+    for (int k = 0; k < h.n_points; ++k) D[h.d_invd + k] = w->inv_depth[k];
+    for (int k = 0; k < h.n_pt_obs; ++k) {
+        for (int q = 0; q < 3; ++q) { D[h.d_ptmeas + q * h.pt_stride + k] = w->pt_pi[3 * k + q]; D[h.d_ptmeas + (3 + q) * h.pt_stride + k] = w->pt_pj[3 * k + q]; }
+        I[h.i_pt_lm + k] = w->pt_lm[k]; I[h.i_pt_fi + k] = w->pt_fi[k]; I[h.i_pt_fj + k] = w->pt_fj[k];
+    }
+    for (int k = 0; k <= h.n_points; ++k) I[h.i_pt_beg + k] = pbeg[k];
+    for (int k = 0; k < 4 * h.n_lines; ++k) D[h.d_line + k] = w->line_orth[k];
+    for (int k = 0; k < h.n_ln_obs; ++k) {
+        for (int q = 0; q < 3; ++q) {
+            D[h.d_lnmeas + q * h.ln_stride + k] = w->ln_sp[3 * k + q]; D[h.d_lnmeas + (3 + q) * h.ln_stride + k] = w->ln_ep[3 * k + q];
+            D[h.d_lnmeas + (6 + q) * h.ln_stride + k] = w->ln_vp[3 * k + q];
+        }
+        I[h.i_ln_lm + k] = w->ln_lm[k]; I[h.i_ln_fj + k] = w->ln_fj[k]; I[h.i_ln_vp + k] = w->ln_has_vp[k] ? 1 : 0;
+    }
+    for (int k = 0; k <= h.n_lines; ++k) I[h.i_ln_beg + k] = lbeg[k];
+    for (int b = 0; b < h.n_imu; ++b) {
+        const uvs_imu_block& ib = w->imu[b];
+        double* blk = D + h.d_imu + (size_t)b * UVS_IMU_STRIDE;
+        blk[0] = ib.sum_dt;
+        for (int q = 0; q < 3; ++q) { blk[1 + q] = ib.delta_p[q]; blk[8 + q] = ib.delta_v[q]; blk[11 + q] = ib.linearized_ba[q]; blk[14 + q] = ib.linearized_bg[q]; }
+        for (int q = 0; q < 4; ++q) blk[4 + q] = ib.delta_q[q];
+        std::memcpy(blk + UVS_IMU_JAC, ib.jacobian, sizeof(double) * 225);
+        std::memcpy(blk + UVS_IMU_COV, ib.covariance, sizeof(double) * 225);
+        I[h.i_imu + 2 * b] = ib.frame_i; I[h.i_imu + 2 * b + 1] = ib.skip ? 1 : 0;
+    }
+    if (have_prior) {
+        const uvs_prior& p = *w->prior;
+        const int n = p.n;
+        for (int r = 0; r < n; ++r) for (int cc = 0; cc < n; ++cc) D[h.d_prior + r * n + cc] = p.linearized_jacobians[r * n + cc];
+        for (int r = 0; r < n; ++r) D[h.d_prior + 2 * n * n + r] = p.linearized_residuals[r];
+        std::memcpy(D + h.d_prior + 2 * n * n + 2 * n, p.x0, sizeof(double) * 144);
+        int* pt = I + h.i_prior;
+        for (int q = 0; q < 80 + UVS_MAX_PRIOR_DIM; ++q) pt[q] = -1;
+        for (int b = 0; b < p.n_blocks; ++b) {
+            pt[b] = p.block_kind[b]; pt[16 + b] = p.block_frame[b]; pt[32 + b] = p.block_size[b]; pt[48 + b] = p.block_idx[b]; pt[64 + b] = p.x0_off[b];
+            const int loc = p.block_size[b] == 7 ? 6 : p.block_size[b];
+            int basecol = -1;
+            if (p.block_kind[b] == UVS_BLOCK_POSE) basecol = 16 * p.block_frame[b];
+            else if (p.block_kind[b] == UVS_BLOCK_SPEEDBIAS) basecol = 16 * p.block_frame[b] + 6;
+            // Ex_Pose is constant (ESTIMATE_EXTRINSIC == 0): its columns are dropped
+            for (int q = 0; q < loc; ++q) pt[80 + p.block_idx[b] + q] = basecol < 0 ? -1 : basecol + q;
+        }
+    }
+    for (size_t q = 0; q < chunks.size(); ++q) I[h.i_chunks + q] = chunks[q];
+    hdr = h;
+    return UVS_OK;
+}
+
+static int ensure(uvs_solver* s, void** p, size_t* cap, size_t need) {
+    if (*cap >= need) return UVS_OK;
+    if (*p) hipFree(*p);
+    *p = nullptr; *cap = 0;
+    HIPCHK(s, hipMalloc(p, need));
+    *cap = need;
+    return UVS_OK;
+}
+
+extern "C" {
+
+int uvs_batch_upload(uvs_solver* s, int n, const uvs_window* const* ws) {
+    if (!s || n < 1 || !ws) return UVS_ERR_INVALID_ARG;
+    if (n > s->max_batch) { s->err = "batch larger than max_batch"; return UVS_ERR_CAPACITY; }
+    HIPCHK(s, hipSetDevice(s->device));
+    s->host_blobs.clear(); s->hdrs.resize(n); s->blob_off.resize(n); s->ws_off.resize(n);
+    long long wtot = 0;
+    for (int b = 0; b < n; ++b) {
+        s->blob_off[b] = (long long)s->host_blobs.size();
+        int rc = pack_window(ws[b], s->host_blobs, s->hdrs[b], s->err);
+        if (rc != UVS_OK) { s->n_loaded = 0; return rc; }
+        s->ws_off[b] = wtot; wtot += s->hdrs[b].ws_doubles;
+    }
+    int rc;
+    if ((rc = ensure(s, (void**)&s->d_blobs, &s->d_blobs_cap, s->host_blobs.size())) != UVS_OK) return rc;
+    if ((rc = ensure(s, (void**)&s->d_ws, &s->d_ws_cap, (size_t)wtot * 8)) != UVS_OK) return rc;
+    size_t offcap = s->d_off_cap;
+    if ((rc = ensure(s, (void**)&s->d_blob_off, &offcap, (size_t)n * 8)) != UVS_OK) return rc;
+    if ((rc = ensure(s, (void**)&s->d_ws_off, &s->d_off_cap, (size_t)n * 8)) != UVS_OK) return rc;
+    if ((rc = ensure(s, (void**)&s->d_reports, &s->d_rep_cap, (size_t)n * sizeof(uvs_report))) != UVS_OK) return rc;
+    HIPCHK(s, hipMemcpyAsync(s->d_blobs, s->host_blobs.data(), s->host_blobs.size(), hipMemcpyHostToDevice, s->stream));
+    HIPCHK(s, hipMemcpyAsync(s->d_blob_off, s->blob_off.data(), (size_t)n * 8, hipMemcpyHostToDevice, s->stream));
+    HIPCHK(s, hipMemcpyAsync(s->d_ws_off, s->ws_off.data(), (size_t)n * 8, hipMemcpyHostToDevice, s->stream));
+    HIPCHK(s, hipStreamSynchronize(s->stream));
+    s->n_loaded = n;
+    return UVS_OK;
+}
+
+static int launch_solve(uvs_solver* s, int debug, float* elapsed_ms) {
+    if (s->n_loaded < 1) { s->err = "no batch uploaded"; return UVS_ERR_INVALID_ARG; }
+    HIPCHK(s, hipSetDevice(s->device));
+    KOpts ko = make_kopts(s->opts, debug);
+    DebugOut dbg; std::memset(&dbg, 0, sizeof(dbg));
+    if (debug) {
+        if (!s->d_dbg) HIPCHK(s, hipMalloc((void**)&s->d_dbg, sizeof(double) * (UVS_RD * UVS_RD + 5 * UVS_RD + 8)));
+        dbg.S = s->d_dbg; dbg.g = dbg.S + UVS_RD * UVS_RD; dbg.hd = dbg.g + UVS_RD; dbg.dd = dbg.hd + UVS_RD; dbg.step = dbg.dd + UVS_RD; dbg.scal = dbg.step + UVS_RD;
+    }
+    HIPCHK(s, hipEventRecord(s->ev0, s->stream));
+    hipLaunchKernelGGL(k_solve, dim3(s->n_loaded), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_blob_off, s->d_ws, s->d_ws_off, ko, s->d_reports, dbg);
+    HIPCHK(s, hipGetLastError());
+    HIPCHK(s, hipEventRecord(s->ev1, s->stream));
+    HIPCHK(s, hipStreamSynchronize(s->stream));
+    if (elapsed_ms) HIPCHK(s, hipEventElapsedTime(elapsed_ms, s->ev0, s->ev1));
+    return UVS_OK;
+}
+
+int uvs_batch_solve(uvs_solver* s, float* elapsed_ms) {
+    if (!s) return UVS_ERR_INVALID_ARG;
+    return launch_solve(s, 0, elapsed_ms);
+}
+
+int uvs_batch_download(uvs_solver* s, int n, uvs_state* states, uvs_report* reps) {
+    if (!s || n < 1 || n > s->n_loaded) return UVS_ERR_INVALID_ARG;
+    HIPCHK(s, hipSetDevice(s->device));
+    int worst = UVS_OK;
+    std::vector<double> buf;
+    for (int b = 0; b < n; ++b) {
+        const DevWin& h = s->hdrs[b];
+        if (reps) {
+            HIPCHK(s, hipMemcpy(&reps[b], s->d_reports + b, sizeof(uvs_report), hipMemcpyDeviceToHost));
+            if (reps[b].status != UVS_OK) worst = reps[b].status;
+        }
+        if (states) {
+            buf.resize(h.ws_doubles);
+            HIPCHK(s, hipMemcpy(buf.data(), s->d_ws + s->ws_off[b], (size_t)h.ws_doubles * 8, hipMemcpyDeviceToHost));
+            DevWin dh;
+            HIPCHK(s, hipMemcpy(&dh, s->d_blobs + s->blob_off[b], sizeof(DevWin), hipMemcpyDeviceToHost));
+            uvs_state& st = states[b];
+            std::memcpy(st.pose, buf.data() + h.w_out, sizeof(double) * 77);
+            std::memcpy(st.speedbias, buf.data() + h.w_out + 77, sizeof(double) * 99);
+            std::memcpy(st.ex_pose, buf.data() + h.w_out + 176, sizeof(double) * 7);
+            st.td = 0.0;
+            const int sel = dh.cur_sel;
+            if (st.inv_depth) std::memcpy(st.inv_depth, buf.data() + (sel ? h.w_invd1 : h.w_invd0), sizeof(double) * h.n_points);
+            if (st.line_orth) std::memcpy(st.line_orth, buf.data() + (sel ? h.w_line1 : h.w_line0), sizeof(double) * 4 * h.n_lines);
+        }
+    }
+    return worst;
+}
+
+int uvs_solve_window(uvs_solver* s, const uvs_window* w, uvs_state* out, uvs_report* rep) {
+    if (!s || !w || !out || !rep) return UVS_ERR_INVALID_ARG;
+    const uvs_window* arr[1] = {w};
+    int rc = uvs_batch_upload(s, 1, arr);
+    if (rc != UVS_OK) return rc;
+    rc = launch_solve(s, 0, nullptr);
+    if (rc != UVS_OK) return rc;
+    out->td = w->td;
+    return uvs_batch_download(s, 1, out, rep);
+}
+
+// Diagnostic entry (parity tests): reduced system of the FIRST linearization of window 0 of the uploaded batch.
+// S_lower[176*176] row-major (damped, landmark-Schur-reduced, padded index 16*frame+dof), g/hd/dd/step[176], scal[8].
+int uvs_debug_first_iteration(uvs_solver* s, const uvs_window* w, double* S_lower, double* g, double* hd, double* dd, double* step, double* scal) {
+    if (!s || !w) return UVS_ERR_INVALID_ARG;
+    const uvs_window* arr[1] = {w};
+    int rc = uvs_batch_upload(s, 1, arr);
+    if (rc != UVS_OK) return rc;
+    rc = launch_solve(s, 1, nullptr);
+    if (rc != UVS_OK) return rc;
+    const size_t nS = (size_t)UVS_RD * UVS_RD;
+    if (S_lower) HIPCHK(s, hipMemcpy(S_lower, s->d_dbg, nS * 8, hipMemcpyDeviceToHost));
+    if (g) HIPCHK(s, hipMemcpy(g, s->d_dbg + nS, UVS_RD * 8, hipMemcpyDeviceToHost));
+    if (hd) HIPCHK(s, hipMemcpy(hd, s->d_dbg + nS + UVS_RD, UVS_RD * 8, hipMemcpyDeviceToHost));
+    if (dd) HIPCHK(s, hipMemcpy(dd, s->d_dbg + nS + 2 * UVS_RD, UVS_RD * 8, hipMemcpyDeviceToHost));
+    if (step) HIPCHK(s, hipMemcpy(step, s->d_dbg + nS + 3 * UVS_RD, UVS_RD * 8, hipMemcpyDeviceToHost));
+    if (scal) HIPCHK(s, hipMemcpy(scal, s->d_dbg + nS + 4 * UVS_RD, 8 * 8, hipMemcpyDeviceToHost));
+    return UVS_OK;
+}
+
+int uvs_evaluate(uvs_solver* s, const uvs_window* w, int robust, uvs_eval* out) {
+    if (!s || !w || !out) return UVS_ERR_INVALID_ARG;
+    const uvs_window* arr[1] = {w};
+    int rc = uvs_batch_upload(s, 1, arr);
+    if (rc != UVS_OK) return rc;
+    return run_evaluate(s->device, s->stream, s->d_blobs, s->d_ws, s->hdrs[0], make_kopts(s->opts, 0), robust, out, s->err);
+}
+
+int uvs_marginalize(uvs_solver* s, const uvs_window* w, int flag, uvs_prior* out) {
+    if (!s || !w || !out || (flag != 0 && flag != 1)) return UVS_ERR_INVALID_ARG;
+    const uvs_window* arr[1] = {w};
+    int rc = uvs_batch_upload(s, 1, arr);
+    if (rc != UVS_OK) return rc;
+    return run_marginalize(s->device, s->stream, s->d_blobs, s->d_ws, s->hdrs[0], w, make_kopts(s->opts, 0), flag, out, s->err);
+}
+
+}  // extern "C"
