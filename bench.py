@@ -1,0 +1,169 @@
+#!/usr/bin/env python
+"""bench.py -- sliding-window solves/s on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the hot path (the persistent LM solve kernel) over one
+batch of synthetic W10-P150-L40-V3 windows that is ALREADY RESIDENT in HBM
+(uvs_batch_upload is outside the timed region; the PCIe-inclusive single-window
+rate is reported separately and in DESIGN.md).  With --gpus N every rank owns
+its own batch (independent windows => replicas, no data-path collective,
+"scaling": "weak"); timing is barrier + synchronize on both sides, max over ranks.
+
+Rank 0 prints ONE JSON line with the contract fields plus `roofline` and
+`cpu_baseline` (the CPU oracle -- a single-thread port of the reference solve --
+timed on a bounded sample of the same windows on this box's host cores).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_PEAK_TFLOPS = 78.6      # MI355X FP64 vector = FP64 matrix (datasheet; not listed in MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def algorithmic_flops(w, n_iterations):
+    """SURVEY.md section 8d flop model: (1 + it) linearizations + it cost-only evaluations."""
+    n_po, n_lo = len(w.pt_lm), len(w.ln_lm)
+    n_vp = int(np.sum(w.ln_has_vp))
+    n_imu = len(w.imu)
+    n = w.prior.n if w.prior is not None else 0
+    D = 165
+    acc = lambda r, c: 2 * r * c + r * c * (c + 1)
+    ev = 600 * n_po + 800 * n_lo + 400 * n_vp + (2 * 15 * 15 * 30 + 2000) * n_imu + 4 * n * n
+    ac = acc(2, 13) * n_po + acc(2, 10) * n_lo + acc(1, 10) * n_vp + acc(15, 30) * n_imu
+    def schur(d, q):
+        return d ** 3 / 3 + 2 * q * d * d + q * (q + 1) * d + 2 * q * d
+    # frames touched per landmark from the CSR structure
+    sch = 0.0
+    pt_cnt = np.bincount(w.pt_lm, minlength=len(w.inv_depth)) if n_po else np.zeros(0)
+    for c in pt_cnt:
+        sch += schur(1, 6 * (int(c) + 1))
+    ln_cnt = np.bincount(w.ln_lm, minlength=len(w.line_orth)) if n_lo else np.zeros(0)
+    for c in ln_cnt:
+        sch += schur(4, 6 * int(c))
+    chol = D ** 3 / 3 + 2 * D * D
+    lin = ev + ac + sch + chol
+    cost_only = 0.3 * (600 * n_po + 800 * n_lo + 400 * n_vp) + 2000 * n_imu + 2 * n * n
+    return (1 + n_iterations) * lin + n_iterations * cost_only
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="independent windows per GPU per step (BASELINE configs[2])")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="windows timed on the CPU oracle (0 = auto ~15 s)")
+    ap.add_argument("--no-prior", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    import torch
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    uvs = importlib.import_module("uv-slam_amd")
+    synth, abi, api = uvs.synth, uvs.abi, uvs.api
+
+    solver = api.Solver(device=local_rank, max_batch=max(args.batch, 1))
+    # ---- synthetic inputs (seed = 1000 + global window index); prior from the PRODUCT's own marginalization
+    marg = None if args.no_prior else (lambda win, flag: solver.marginalize(win, flag))
+    t_gen = time.time()
+    windows = [synth.make_window(rank * args.batch + i, with_prior=marg is not None, marginalize_fn=marg) for i in range(args.batch)]
+    t_gen = time.time() - t_gen
+    solver.upload(windows)
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        solver.solve_resident()
+    sync()
+    t0 = time.perf_counter()
+    kernel_ms = []
+    for _ in range(args.steps):
+        kernel_ms.append(solver.solve_resident())
+    sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    states, reps = solver.download()
+    n_total = args.batch * world * args.steps
+    value = n_total / elapsed
+
+    if rank == 0:
+        its = np.array([r.num_iterations for r in reps])
+        bytes_per_launch = float(sum(synth.algorithmic_bytes(w) for w in windows))
+        flops_per_launch = float(sum(algorithmic_flops(w, int(r.num_iterations)) for w, r in zip(windows, reps)))
+        k_ms = float(np.mean(kernel_ms))
+        ach_tflops = flops_per_launch / (k_ms * 1e-3) / 1e12
+        ach_gbs = bytes_per_launch / (k_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {"bound": "mfma", "kernel": "uvsdev::k_solve", "achieved": ach_tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": ach_tflops / FP64_PEAK_TFLOPS, "traffic": traffic,
+                    "kernel_ms_per_launch": k_ms, "algorithmic_flops_per_launch": flops_per_launch,
+                    "algorithmic_bytes_per_launch": bytes_per_launch, "hbm_achieved_GBps": ach_gbs, "hbm_frac": ach_gbs / HBM_PEAK_GBS,
+                    "note": "FP64 path (no MFMA use yet): 'mfma' bound = FP64 FLOP roof 78.6 TF/s; flop/byte model of SURVEY.md 8d"}
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from oracle_binding import Oracle     # CPU oracle: baseline leg only
+            orc = Oracle()
+            t1 = time.perf_counter(); orc.solve(windows[0]); one = time.perf_counter() - t1
+            ns = args.cpu_sample or int(max(8, min(args.batch, 15.0 / max(one, 1e-3))))
+            t1 = time.perf_counter()
+            for w in windows[:ns]:
+                orc.solve(w)
+            tc = time.perf_counter() - t1
+            cpu = {"value": ns / tc, "unit": "solves/s", "cores": 1, "kind": "port",
+                   "sample": f"first {ns} windows of the same batch, single-thread C++ oracle (oracle/uvs_oracle.cpp), {tc:.1f} s",
+                   "host_cpus": os.cpu_count()}
+        # single-window latency mode (BASELINE configs[1]): one window resident, one launch per solve
+        solver.upload(windows[:1])
+        for _ in range(3):
+            solver.solve_resident()
+        lat = [solver.solve_resident() for _ in range(10)]
+        t1 = time.perf_counter(); solver.solve(windows[0]); pcie = time.perf_counter() - t1
+        out = {
+            "metric": "sliding-window solves/sec (10 KF, 150 pts, 40 lines, 3 VP)", "value": value, "unit": "solves/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"W10-P150-L40-V3 x {args.batch} independent windows per GPU (BASELINE configs[2]); "
+                                   "single-window latency (configs[1]) in single_window_*",
+                       "windows_per_gpu": args.batch, "frames": 11, "points": 150, "lines": 40, "vp_tagged_lines": 30,
+                       "prior": (not args.no_prior), "max_lm_iterations": 10, "parallelism": f"replicas x{world}"},
+            "lm_iterations_mean": float(its.mean()), "final_cost_mean": float(np.mean([r.final_cost for r in reps])),
+            "single_window_ms": float(np.median(lat)), "single_window_solves_per_s": 1e3 / float(np.median(lat)),
+            "single_window_pcie_inclusive_ms": pcie * 1e3,
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    solver.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -751,41 +751,44 @@ UVS_DEV void backsub_candidate(const Ctx& c, const double* invd, const double* l
         const int b0 = pbeg[k], b1 = pbeg[k + 1];
         const double* px = c.ws + h.w_pt_x + 4 * (size_t)k;
         const double* Eg = c.ws + h.w_pt_E + 6 * (size_t)(b0 + k);
-        double dl = -px[0];
+        double t = 0.0;      // Einv . delta_pose  (the landmark's share of the frame step)
         if (b1 > b0) {
             const int fi = c.bi[h.i_pt_fi + b0];
 #pragma unroll
-            for (int a = 0; a < 6; ++a) dl -= Eg[a] * d[16 * fi + a];
+            for (int a = 0; a < 6; ++a) t += Eg[a] * d[16 * fi + a];
             for (int o = b0; o < b1; ++o) {
                 const int fj = c.bi[h.i_pt_fj + o];
                 const double* e = Eg + 6 * (o - b0 + 1);
 #pragma unroll
-                for (int a = 0; a < 6; ++a) dl -= e[a] * d[16 * fj + a];
+                for (int a = 0; a < 6; ++a) t += e[a] * d[16 * fj + a];
             }
         }
+        const double dl = -px[0] - t;
         const double v = invd[k] + dl;
         invd_c[k] = v;
-        gd += px[1] * dl; dd2 += px[2] * dl * dl; step2 += dl * dl; xc2 += v * v;
+        // L_G holds the Schur-REDUCED frame gradient g_f - E^T h^-1 g_l; (E delta_f) h^-1 g_l = t * g_l restores the full g_f . delta_f
+        gd += px[1] * (dl + t); dd2 += px[2] * dl * dl; step2 += dl * dl; xc2 += v * v;
     }
     // lines: delta(4) = -Hinv g - sum_s Y[s] delta_pose
     const int* lbeg = c.bi + h.i_ln_beg;
     for (int k = tid; k < h.n_lines; k += NT) {
         const int b0 = lbeg[k], b1 = lbeg[k + 1];
         const double* lx = c.ws + h.w_ln_x + 12 * (size_t)k;
-        double dl[4] = {-lx[0], -lx[1], -lx[2], -lx[3]};
+        double t[4] = {0.0, 0.0, 0.0, 0.0};
         for (int o = b0; o < b1; ++o) {
             const int fj = c.bi[h.i_ln_fj + o];
             const double* Y = c.ws + h.w_ln_Y + 24 * (size_t)o;
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int a = 0; a < 6; ++a) dl[q] -= Y[6 * q + a] * d[16 * fj + a];
+                for (int a = 0; a < 6; ++a) t[q] += Y[6 * q + a] * d[16 * fj + a];
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const double v = line[4 * k + q] + dl[q];
+            const double dl = -lx[q] - t[q];
+            const double v = line[4 * k + q] + dl;
             line_c[4 * k + q] = v;
-            gd += lx[4 + q] * dl[q]; dd2 += lx[8 + q] * dl[q] * dl[q]; step2 += dl[q] * dl[q]; xc2 += v * v;
+            gd += lx[4 + q] * (dl + t[q]); dd2 += lx[8 + q] * dl * dl; step2 += dl * dl; xc2 += v * v;
         }
     }
     double s4[4] = {gd, dd2, step2, xc2};
