@@ -263,7 +263,7 @@ int uvs_evaluate(uvs_solver *s, const uvs_window *w, int robust, uvs_eval *out);
 
 /* Diagnostic (parity tests only): reduced system of the FIRST LM iteration of `w`:
  * S_lower[176*176] row-major = damped, landmark-Schur-reduced frame system in the padded index space
- * (16*frame + dof, dof 15 = dummy pivot), g/hd/dd/step[176], scal[8] = {cost, gmax, chol_ok, model_cost_change, step_norm^2}. */
+ * (16*frame + dof, dof 15 = dummy pivot), g/hd/dd/step[176], scal[24] = {cost, gmax, chol_ok, model_cost_change, step_norm^2, -, -, -, per-phase shader cycles[10]}. */
 int uvs_debug_first_iteration(uvs_solver *s, const uvs_window *w, double *S_lower, double *g, double *hd, double *dd,
                               double *step, double *scal);
 

@@ -49,3 +49,9 @@ s.upload(ws[:1])
 for it in range(3):
     ms = s.solve_resident()
     print("single window: %.3f ms -> %.0f solves/s" % (ms, 1 / (ms * 1e-3)))
+d = s.debug_first_iteration(w)
+tot = sum(d["cycles"].values())
+print("phase cycles (whole solve, thread 0 of the workgroup):")
+for k, v in d["cycles"].items():
+    print("   %-9s %12.0f  %5.1f%%" % (k, v, 100 * v / tot))
+print("   total %.0f cycles" % tot)

@@ -40,7 +40,10 @@ static constexpr int L_PDX = L_EX + 16;        // prior dx
 static constexpr int L_PR = L_PDX + UVS_MAX_PRIOR_DIM;   // prior residual
 static constexpr int L_RED = L_PR + UVS_MAX_PRIOR_DIM;   // reduction scratch
 static constexpr int L_CTRL = L_RED + 64;
-static constexpr int L_TOTAL = L_CTRL + 32;
+static constexpr int L_PROF = L_CTRL + 32;      // per-phase cycle counters (debug launches only)
+static constexpr int L_TOTAL = L_PROF + 16;
+enum { P_SETUP = 0, P_OBS, P_LMPREP, P_GATHER, P_ASSEMBLE, P_CHOL, P_TRSV, P_BACKSUB, P_COST, P_MISC, P_LAST };
+#define UVS_PROF(c, k) do { if ((c).o.debug && threadIdx.x == 0) { const long long now_ = clock64(); (c).sh[L_PROF + (k)] += (double)(now_ - (long long)(c).sh[L_PROF + 15]); (c).sh[L_PROF + 15] = (double)now_; } } while (0)
 static constexpr size_t LDS_BYTES = (size_t)L_TOTAL * 8;
 
 enum { C_COST = 0, C_RADIUS, C_DECR, C_XNORM, C_GMAX, C_CAND, C_MCC, C_STEP2, C_XC2, C_GO, C_IT, C_INVALID, C_CUR, C_FIRST,
@@ -374,6 +377,7 @@ UVS_DEV void linearize(const Ctx& c, const double* x, const double* invd, const 
 #pragma unroll
     for (int q = 0; q < ITEMS_PER_THREAD; ++q) acc[q] = 0.0;
 
+    UVS_PROF(c, P_MISC);
     stage_rotations(c, x);
     prior_dx(c, x);
     __syncthreads();
@@ -396,6 +400,7 @@ UVS_DEV void linearize(const Ctx& c, const double* x, const double* invd, const 
         const int type = chunks[4 * ch], k0 = chunks[4 * ch + 1], k1 = chunks[4 * ch + 2];
         const int nlm = k1 - k0;
         __syncthreads();     // previous chunk's gather done; S region free
+        UVS_PROF(c, P_GATHER);
         if (type == 0) {
             const int* beg = c.bi + h.i_pt_beg;
             const int o0 = beg[k0], o1 = beg[k1], nob = o1 - o0;
@@ -418,6 +423,7 @@ UVS_DEV void linearize(const Ctx& c, const double* x, const double* invd, const 
                 R[26] = sc * cl[0]; R[27] = sc * cl[1];
             }
             __syncthreads();
+            UVS_PROF(c, P_OBS);
             // pass B: one lane per landmark
             for (int li = tid; li < nlm; li += NT) {
                 const int k = k0 + li, b0 = beg[k] - o0, b1 = beg[k + 1] - o0;
@@ -452,6 +458,7 @@ UVS_DEV void linearize(const Ctx& c, const double* x, const double* invd, const 
                 for (int a = 0; a < 6; ++a) { E[a] = e0[a]; Eg[a] = e0[a] * hinv; }
             }
             __syncthreads();
+            UVS_PROF(c, P_LMPREP);
             // pass C: output-stationary gather (fixed landmark order => deterministic)
 #pragma unroll
             for (int q = 0; q < ITEMS_PER_THREAD; ++q) {
@@ -522,6 +529,7 @@ UVS_DEV void linearize(const Ctx& c, const double* x, const double* invd, const 
                 }
             }
             __syncthreads();
+            UVS_PROF(c, P_OBS);
             // pass B1: one lane per line: H_ll, g_l, damping, 4x4 inverse
             for (int li = tid; li < nlm; li += NT) {
                 const int k = k0 + li, b0 = beg[k] - o0, b1 = beg[k + 1] - o0;
@@ -596,6 +604,7 @@ UVS_DEV void linearize(const Ctx& c, const double* x, const double* invd, const 
                 }
             }
             __syncthreads();
+            UVS_PROF(c, P_LMPREP);
             // pass C
 #pragma unroll
             for (int q = 0; q < ITEMS_PER_THREAD; ++q) {
@@ -628,6 +637,7 @@ UVS_DEV void linearize(const Ctx& c, const double* x, const double* invd, const 
         }
     }
     __syncthreads();
+    UVS_PROF(c, P_GATHER);
     // ---- assemble the reduced system in LDS
     for (int i = tid; i < UVS_S_DOUBLES; i += NT) sh[L_S + i] = 0.0;
     if (tid < UVS_RD) { sh[L_G + tid] = 0.0; sh[L_HD + tid] = 0.0; }
@@ -725,6 +735,7 @@ UVS_DEV void linearize(const Ctx& c, const double* x, const double* invd, const 
     block_reduce(sh, s4, &gmax);
     if (tid == 0) { sh[L_CTRL + C_COST] = s4[0]; sh[L_CTRL + C_GMAX] = gmax; }
     __syncthreads();
+    UVS_PROF(c, P_ASSEMBLE);
 }
 
 // ------------------------------------------------------------------ back-substitution + candidate + model terms
@@ -882,8 +893,10 @@ __global__ __launch_bounds__(NT) void k_solve(char* blobs, const long long* blob
     for (int k = tid; k < h.n_points; k += NT) c.ws[h.w_invd0 + k] = c.bd[h.d_invd + k];
     for (int k = tid; k < 4 * h.n_lines; k += NT) c.ws[h.w_line0 + k] = c.bd[h.d_line + k];
     for (int i = tid; i < (int)(sizeof(uvs_report) / 4); i += NT) ((int*)rep)[i] = 0;
+    if (tid < 16) sh[L_PROF + tid] = (tid == 15) ? (double)clock64() : 0.0;
     setup_window(c, (double*)blob);
     __syncthreads();
+    UVS_PROF(c, P_SETUP);
     int cur = 0;
     double* invd[2] = {c.ws + h.w_invd0, c.ws + h.w_invd1};
     double* line[2] = {c.ws + h.w_line0, c.ws + h.w_line1};
@@ -910,10 +923,14 @@ __global__ __launch_bounds__(NT) void k_solve(char* blobs, const long long* blob
             for (int t = tid; t < UVS_RD * UVS_RD; t += NT) { const int i = t / UVS_RD, j = t - i * UVS_RD; dbg.S[t] = (j <= i) ? sh[L_S + sidx(i, j)] : 0.0; }
             if (tid < UVS_RD) { dbg.g[tid] = sh[L_G + tid]; dbg.hd[tid] = sh[L_HD + tid]; dbg.dd[tid] = sh[L_DD + tid]; }
         }
+        UVS_PROF(c, P_MISC);
         chol_factor(c);
+        UVS_PROF(c, P_CHOL);
         chol_solve(c);
+        UVS_PROF(c, P_TRSV);
         bool ok = sh[L_CTRL + C_CHOLOK] != 0.0;
         backsub_candidate(c, invd[cur], line[cur], invd[cur ^ 1], line[cur ^ 1]);
+        UVS_PROF(c, P_BACKSUB);
         const double mcc = sh[L_CTRL + C_MCC], step2 = sh[L_CTRL + C_STEP2], xc2 = sh[L_CTRL + C_XC2];
         if (o.debug && it == 1 && dbg.S) {
             if (tid < UVS_RD) dbg.step[tid] = sh[L_DLT + tid];
@@ -938,6 +955,7 @@ __global__ __launch_bounds__(NT) void k_solve(char* blobs, const long long* blob
         cc_ += cost_pass(c, sh + L_XC, invd[cur ^ 1], line[cur ^ 1]);
         double s4[4] = {cc_, 0, 0, 0}, mx = 0.0;
         block_reduce(sh, s4, &mx);
+        UVS_PROF(c, P_COST);
         double cand = s4[0];
         if (!isfinite(cand)) cand = 1.7976931348623157e308;
         const double step_norm = sqrt(step2);
@@ -975,6 +993,8 @@ __global__ __launch_bounds__(NT) void k_solve(char* blobs, const long long* blob
         if (tid == 0) { rep->cost[ti] = cost; rep->radius[ti] = radius; rep->gradient_max_norm[ti] = gmax; }
     }
     __syncthreads();
+    UVS_PROF(c, P_MISC);
+    if (o.debug && dbg.scal && tid < P_LAST) dbg.scal[8 + tid] = sh[L_PROF + tid];
     if (tid < 184) c.ws[h.w_out + tid] = sh[L_X + tid];
     if (tid == 0) {
         rep->status = status; rep->termination = term; rep->num_iterations = it; rep->num_successful = nsucc; rep->final_cost = cost;
