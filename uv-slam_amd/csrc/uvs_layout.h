@@ -39,7 +39,9 @@ struct DevWin {
     int32_t i_ln_lm, i_ln_fj, i_ln_vp, i_ln_beg;      // obs arrays + CSR begin[n_lines+1]
     int32_t i_imu;                    // [n_imu][2] : frame_i, skip
     int32_t i_prior;                  // kind[16] frame[16] size[16] idx[16] x0off[16] colmap[96]
-    int32_t i_chunks;                 // [n_chunks][4] : type(0 pt,1 ln), lm_begin, lm_end, 0
+    int32_t i_chunks;                 // [n_chunks][6] : type(0 pt,1 ln), lm_begin, lm_end, offset of the chunk's gather lists in i_lists, their length, 0
+    int32_t i_wblk;                   // [8 waves][9] pose-block ids owned by each wave in the gather (-1 = none), balanced by list length
+    int32_t i_lists;                  // per chunk: schur_off[67] direct_off[67] entries[...]  (see build_lists in uvs_solver.hip)
     // workspace
     int32_t w_invd0, w_invd1, w_line0, w_line1;       // landmark parameters, two buffers (current / candidate)
     int32_t w_scale_pt, w_scale_ln;                   // Jacobi scales of landmark parameters

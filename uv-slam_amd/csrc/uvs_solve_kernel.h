@@ -41,7 +41,8 @@ static constexpr int L_PR = L_PDX + UVS_MAX_PRIOR_DIM;   // prior residual
 static constexpr int L_RED = L_PR + UVS_MAX_PRIOR_DIM;   // reduction scratch
 static constexpr int L_CTRL = L_RED + 64;
 static constexpr int L_PROF = L_CTRL + 32;      // per-phase cycle counters (debug launches only)
-static constexpr int L_TOTAL = L_PROF + 16;
+static constexpr int L_WPROF = L_PROF + 16;     // per-wave gather cycles (debug)
+static constexpr int L_TOTAL = L_WPROF + 8;
 enum { P_SETUP = 0, P_OBS, P_LMPREP, P_GATHER, P_ASSEMBLE, P_CHOL, P_TRSV, P_BACKSUB, P_COST, P_MISC, P_LAST };
 #define UVS_PROF(c, k) do { if ((c).o.debug && threadIdx.x == 0) { const long long now_ = clock64(); (c).sh[L_PROF + (k)] += (double)(now_ - (long long)(c).sh[L_PROF + 15]); (c).sh[L_PROF + 15] = (double)now_; } } while (0)
 static constexpr size_t LDS_BYTES = (size_t)L_TOTAL * 8;
@@ -78,6 +79,19 @@ UVS_DEV double wave_max(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
     return v;
+}
+// sqrt(x) and 1/sqrt(x) together from the hardware seed (v_rsq_f64) + two Goldschmidt steps (FMA only, no divide):
+// a few ulp, which is all the Cholesky pivots need; x <= 0 or non-finite yields NaN and is caught by the caller.
+UVS_DEV void rsqrt_pair(double x, double* sq, double* rsq) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, hh = 0.5 * y;
+    double r = fma(-hh, g, 0.5);
+    g = fma(g, r, g); hh = fma(hh, r, hh);
+    r = fma(-hh, g, 0.5);
+    g = fma(g, r, g); hh = fma(hh, r, hh);
+    const double d = fma(-g, g, x);
+    g = fma(d, hh, g);
+    *sq = g; *rsq = 2.0 * hh;
 }
 // Deterministic block reductions of up to 4 sums + 1 max.  Result broadcast to every thread.
 UVS_DEV void block_reduce(double* sh, double* s /*[4]*/, double* mx) {
@@ -209,8 +223,8 @@ UVS_DEV void chol_factor(const Ctx& c) {
             for (int j = 0; j < 16; ++j) {
                 const double piv = bcast_lane(a[j], j);
                 if (!(piv > 0.0)) ok = false;
-                const double inv = 1.0 / sqrt(piv);
-                const double l = (r == j) ? piv * inv : a[j] * inv;
+                double ljj, inv; rsqrt_pair(piv, &ljj, &inv);
+                const double l = (r == j) ? ljj : a[j] * inv;
                 a[j] = l;
 #pragma unroll
                 for (int cc = j + 1; cc < 16; ++cc) { const double lc = bcast_lane(l, cc); a[cc] -= l * lc; }
@@ -355,17 +369,164 @@ UVS_DEV void chol_solve(const Ctx& c) {
 }
 
 // ------------------------------------------------------------------ linearization: builds S (damped, Schur-reduced), G, HD, cost, gmax
-struct GatherItem { int type, fa, fb, a, b; };   // type 0: S entry, 1: gradient entry, 2: diag(J^T J) entry, -1: none
-UVS_DEV GatherItem decode_item(int id) {
-    GatherItem it;
-    if (id < UVS_NBLK * 36) { const int blk = id / 36, e = id - blk * 36; it.type = 0; it.fa = c_blk_fa[blk]; it.fb = c_blk_fb[blk]; it.a = e / 6; it.b = e - it.a * 6; }
-    else if (id < UVS_NBLK * 36 + 66) { const int e = id - UVS_NBLK * 36; it.type = 1; it.fa = it.fb = e / 6; it.a = it.b = e - it.fa * 6; }
-    else if (id < UVS_NBLK * 36 + 132) { const int e = id - UVS_NBLK * 36 - 66; it.type = 2; it.fa = it.fb = e / 6; it.a = it.b = e - it.fa * 6; }
-    else { it.type = -1; it.fa = it.fb = it.a = it.b = 0; }
-    return it;
+// Gather work split: wave w owns the 6x6 pose blocks b = w, w+8, ... of the 66 lower blocks; lanes 0..35 own the
+// block's entries, and on diagonal blocks lanes 36..41 / 42..47 own that frame's gradient / diag(J^T J) entries.
+// For every block the host packed two index lists per landmark chunk (uvs_solver.hip: build_lists):
+//   Schur list : (landmark, slot_a, slot_b) for each landmark observed in both frames   -> - E_a^T H_ll^-1 E_b
+//   direct list: (observation, kind) for each observation contributing J^T J to the block
+// A wave walks its lists front to back, so every sum has a fixed order (bitwise reproducible, no atomics).
+static constexpr int BLOCKS_PER_WAVE = (UVS_NBLK + NW - 1) / NW;   // 9
+
+// Branch-free inner loops: every operand is addressed as S0[scalar(entry) + lane constant] (integer selects only --
+// selecting between POINTERS makes the compiler fall back to flat loads and scratch), list entries are decoded on the
+// scalar unit, and several entries are in flight at a time so that LDS latency is paid per group, not per entry.
+UVS_DEV void gather_points(const int* wblk, const int* lists, const double* S0, int oE, int oEI, int oX, double* acc) {
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int role = lane < 36 ? 0 : lane < 42 ? 1 : lane < 48 ? 2 : 3;
+    const int a = role == 0 ? lane / 6 : role == 1 ? lane - 36 : role == 2 ? lane - 42 : 0;
+    const int bb = role == 0 ? lane - 6 * (lane / 6) : 0;
+    const bool r0 = role == 0, r1 = role == 1;
+    // Schur second operand: role0 -> EI[6*(sl+sb) + bb], else -> X[2*li + 1]
+    const int k2sb = r0 ? 6 : 0, k2li = r0 ? 0 : 2, k2c = r0 ? oEI + bb : oX + 1;
+    // direct second operand: role0 -> R[offB + bb], role1 -> R[0] (residual), else -> R[offA + a]
+    const int kdB = r0 ? 1 : 0, kdA = (r0 || r1) ? 0 : 1, kdc = r0 ? bb : r1 ? 0 : a, kdd = r1 ? 1 : 6;
+    const int* ent = lists + 2 * (UVS_NBLK + 1);
+#pragma unroll
+    for (int q = 0; q < BLOCKS_PER_WAVE; ++q) {
+        const int b = wblk[wv * BLOCKS_PER_WAVE + q];      // host-balanced block -> wave assignment (-1 = none)
+        if (b >= 0) {
+            const bool diag = c_blk_fa[b] == c_blk_fb[b];
+            const double ms = (r0 || (diag && r1)) ? 1.0 : 0.0;            // Schur-term mask
+            const double md = (r0 || (diag && role < 3)) ? 1.0 : 0.0;      // direct-term mask
+            double s = 0.0;
+            int e0 = lists[b], e1 = lists[b + 1];
+            for (int base = e0; base < e1; base += 64) {
+                const int mine = (base + lane < e1) ? ent[base + lane] : 0;
+                const int n = min(64, e1 - base);
+                int i = 0;
+                for (; i + 8 <= n; i += 8) {
+                    double v1[8], v2[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int e = __builtin_amdgcn_readlane(mine, i + u);
+                        const int li = e & 1023, sa = (e >> 10) & 15, sb = (e >> 14) & 15, sl = (e >> 18) & 16383;
+                        v1[u] = S0[oE + 6 * (sl + sa) + a];
+                        v2[u] = S0[k2sb * (sl + sb) + k2li * li + k2c];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) s -= ms * v1[u] * v2[u];
+                }
+                for (; i < n; ++i) {
+                    const int e = __builtin_amdgcn_readlane(mine, i);
+                    const int li = e & 1023, sa = (e >> 10) & 15, sb = (e >> 14) & 15, sl = (e >> 18) & 16383;
+                    s -= ms * S0[oE + 6 * (sl + sa) + a] * S0[k2sb * (sl + sb) + k2li * li + k2c];
+                }
+            }
+            e0 = lists[UVS_NBLK + 1 + b]; e1 = lists[UVS_NBLK + 2 + b];
+            for (int base = e0; base < e1; base += 64) {
+                const int mine = (base + lane < e1) ? ent[base + lane] : 0;
+                const int n = min(64, e1 - base);
+                int i = 0;
+                for (; i + 4 <= n; i += 4) {
+                    double p0[4], p1[4], q0[4], q1[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int e = __builtin_amdgcn_readlane(mine, i + u);
+                        const int o = e & 16383, ty = e >> 14;            // 0: A^T A (anchor), 1: B^T B, 2: B^T A
+                        const int offA = ty == 0 ? 2 : 14, offB = ty == 1 ? 14 : 2;
+                        const int ro = o * UVS_PT_REC;
+                        const int iq = ro + kdB * offB + kdA * offA + kdc;
+                        p0[u] = S0[ro + offA + a]; p1[u] = S0[ro + offA + 6 + a];
+                        q0[u] = S0[iq]; q1[u] = S0[iq + kdd];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) s += md * (p0[u] * q0[u] + p1[u] * q1[u]);
+                }
+                for (; i < n; ++i) {
+                    const int e = __builtin_amdgcn_readlane(mine, i);
+                    const int o = e & 16383, ty = e >> 14;
+                    const int offA = ty == 0 ? 2 : 14, offB = ty == 1 ? 14 : 2;
+                    const int ro = o * UVS_PT_REC;
+                    const int iq = ro + kdB * offB + kdA * offA + kdc;
+                    s += md * (S0[ro + offA + a] * S0[iq] + S0[ro + offA + 6 + a] * S0[iq + kdd]);
+                }
+            }
+            acc[q] += s;
+        }
+    }
 }
-static constexpr int N_ITEMS = UVS_NBLK * 36 + 132;
-static constexpr int ITEMS_PER_THREAD = (N_ITEMS + NT - 1) / NT;   // 5
+
+UVS_DEV void gather_lines(const int* wblk, const int* lists, const double* S0, int oE, int oY, int oX, double* acc) {
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int role = lane < 36 ? 0 : lane < 42 ? 1 : lane < 48 ? 2 : 3;
+    const int a = role == 0 ? lane / 6 : role == 1 ? lane - 36 : role == 2 ? lane - 42 : 0;
+    const int bb = role == 0 ? lane - 6 * (lane / 6) : 0;
+    const bool r0 = role == 0, r1 = role == 1;
+    // Schur second operand: role0 -> Y[24*(sl+sb) + bb + 6k], else -> X[20*li + 16 + k]
+    const int k2sb = r0 ? 24 : 0, k2li = r0 ? 0 : 20, k2c = r0 ? oY + bb : oX + 16, qs = r0 ? 6 : 1;
+    // direct second operand rows: role0 -> (2+bb, 8+bb, 23+bb), role1 -> (0, 1, 22), else -> (2+a, 8+a, 23+a)
+    const int d0 = r0 ? 2 + bb : r1 ? 0 : 2 + a, d1 = r0 ? 8 + bb : r1 ? 1 : 8 + a, d2 = r0 ? 23 + bb : r1 ? 22 : 23 + a;
+    const int* ent = lists + 2 * (UVS_NBLK + 1);
+#pragma unroll
+    for (int q = 0; q < BLOCKS_PER_WAVE; ++q) {
+        const int b = wblk[wv * BLOCKS_PER_WAVE + q];      // host-balanced block -> wave assignment (-1 = none)
+        if (b >= 0) {
+            const bool diag = c_blk_fa[b] == c_blk_fb[b];
+            const double ms = (r0 || (diag && r1)) ? 1.0 : 0.0;
+            const double md = (r0 || (diag && role < 3)) ? 1.0 : 0.0;
+            double s = 0.0;
+            int e0 = lists[b], e1 = lists[b + 1];
+            for (int base = e0; base < e1; base += 64) {
+                const int mine = (base + lane < e1) ? ent[base + lane] : 0;
+                const int n = min(64, e1 - base);
+                int i = 0;
+                for (; i + 2 <= n; i += 2) {
+                    double ea[2][4], qq[2][4];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int e = __builtin_amdgcn_readlane(mine, i + u);
+                        const int li = e & 1023, sa = (e >> 10) & 15, sb = (e >> 14) & 15, sl = (e >> 18) & 16383;
+                        const int ia = oE + 24 * (sl + sa) + a, iq = k2sb * (sl + sb) + k2li * li + k2c;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) { ea[u][k] = S0[ia + 6 * k]; qq[u][k] = S0[iq + qs * k]; }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) s -= ms * (ea[u][0] * qq[u][0] + ea[u][1] * qq[u][1] + ea[u][2] * qq[u][2] + ea[u][3] * qq[u][3]);
+                }
+                for (; i < n; ++i) {
+                    const int e = __builtin_amdgcn_readlane(mine, i);
+                    const int li = e & 1023, sa = (e >> 10) & 15, sb = (e >> 14) & 15, sl = (e >> 18) & 16383;
+                    const int ia = oE + 24 * (sl + sa) + a, iq = k2sb * (sl + sb) + k2li * li + k2c;
+                    s -= ms * (S0[ia] * S0[iq] + S0[ia + 6] * S0[iq + qs] + S0[ia + 12] * S0[iq + 2 * qs] + S0[ia + 18] * S0[iq + 3 * qs]);
+                }
+            }
+            e0 = lists[UVS_NBLK + 1 + b]; e1 = lists[UVS_NBLK + 2 + b];
+            for (int base = e0; base < e1; base += 64) {
+                const int mine = (base + lane < e1) ? ent[base + lane] : 0;
+                const int n = min(64, e1 - base);
+                int i = 0;
+                for (; i + 2 <= n; i += 2) {
+                    double p[2][3], qv[2][3];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int ro = (__builtin_amdgcn_readlane(mine, i + u) & 16383) * UVS_LN_REC;
+                        p[u][0] = S0[ro + 2 + a]; p[u][1] = S0[ro + 8 + a]; p[u][2] = S0[ro + 23 + a];
+                        qv[u][0] = S0[ro + d0]; qv[u][1] = S0[ro + d1]; qv[u][2] = S0[ro + d2];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) s += md * (p[u][0] * qv[u][0] + p[u][1] * qv[u][1] + p[u][2] * qv[u][2]);
+                }
+                for (; i < n; ++i) {
+                    const int ro = (__builtin_amdgcn_readlane(mine, i) & 16383) * UVS_LN_REC;
+                    s += md * (S0[ro + 2 + a] * S0[ro + d0] + S0[ro + 8 + a] * S0[ro + d1] + S0[ro + 23 + a] * S0[ro + d2]);
+                }
+            }
+            acc[q] += s;
+        }
+    }
+}
 
 UVS_DEV void linearize(const Ctx& c, const double* x, const double* invd, const double* line, bool first, double radius) {
     const DevWin& h = *c.hdr;
@@ -373,41 +534,75 @@ UVS_DEV void linearize(const Ctx& c, const double* x, const double* invd, const 
     const int tid = threadIdx.x;
     const double* RF = sh + L_RF; const double* ric = sh + L_EX; const double* tic = sh + L_EX + 9;
     double cost = 0.0, gmax_lm = 0.0;
-    double acc[ITEMS_PER_THREAD];
+    double acc[BLOCKS_PER_WAVE];
 #pragma unroll
-    for (int q = 0; q < ITEMS_PER_THREAD; ++q) acc[q] = 0.0;
+    for (int q = 0; q < BLOCKS_PER_WAVE; ++q) acc[q] = 0.0;
 
     UVS_PROF(c, P_MISC);
     stage_rotations(c, x);
     prior_dx(c, x);
     __syncthreads();
-    // ---- IMU: raw residual/Jacobian, one lane per block (global scratch), whitened below by all lanes
-    if (tid < h.n_imu) {
-        const int fi = c.bi[h.i_imu + 2 * tid], skip = c.bi[h.i_imu + 2 * tid + 1];
-        double* wj = c.ws + h.w_imu + (size_t)tid * UVS_WIMU_STRIDE;
-        if (!skip) {
+    cost += prior_residual(c);
+    // ---- IMU blocks, staged in the (still free) S region: per block Jraw[450] rraw[15] | Jw[450] rw[15]
+    {
+        double* IM = sh + L_S;
+        if (tid < h.n_imu && !c.bi[h.i_imu + 2 * tid + 1]) {
+            const int fi = c.bi[h.i_imu + 2 * tid];
             const double* blk = c.bd + h.d_imu + (size_t)tid * UVS_IMU_STRIDE;
             double r[15];
-            imu_raw(blk, blk + UVS_IMU_JAC, c.o.G, x + 7 * fi, x + 77 + 9 * fi, x + 7 * (fi + 1), x + 77 + 9 * (fi + 1), r, wj);
-            for (int i = 0; i < 15; ++i) wj[900 + i] = r[i];
+            imu_raw(blk, blk + UVS_IMU_JAC, c.o.G, x + 7 * fi, x + 77 + 9 * fi, x + 7 * (fi + 1), x + 77 + 9 * (fi + 1), r, IM + 930 * tid);
+            for (int i = 0; i < 15; ++i) IM[930 * tid + 450 + i] = r[i];
+        }
+        __syncthreads();
+        for (int t = tid; t < h.n_imu * 465; t += NT) {      // whitening: W upper triangular (imu_factor.h:64-66)
+            const int b = t / 465, e = t - b * 465;
+            if (c.bi[h.i_imu + 2 * b + 1]) continue;
+            const double* W = c.bd + h.d_imu + (size_t)b * UVS_IMU_STRIDE + UVS_IMU_W;
+            const double* raw = IM + 930 * b;
+            if (e < 450) { const int r = e / 30, cc = e - r * 30; double s = 0.0; for (int k = r; k < 15; ++k) s += W[r * 15 + k] * raw[k * 30 + cc]; IM[930 * b + 465 + e] = s; }
+            else { const int r = e - 450; double s = 0.0; for (int k = r; k < 15; ++k) s += W[r * 15 + k] * raw[450 + k]; IM[930 * b + 465 + 450 + r] = s; cost += 0.5 * s * s; }
+        }
+        __syncthreads();
+        for (int t = tid; t < h.n_imu * 495; t += NT) {      // J^T J (465 lower entries) and J^T r (30) -> global scratch, added after the gather
+            const int b = t / 495, e = t - b * 495;
+            if (c.bi[h.i_imu + 2 * b + 1]) continue;
+            const double* Jw = IM + 930 * b + 465; const double* rw = Jw + 450;
+            double s = 0.0;
+            if (e < 465) {
+                int a = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+                while (((a + 1) * (a + 2)) >> 1 <= e) ++a;
+                while (((a * (a + 1)) >> 1) > e) --a;
+                const int cc = e - ((a * (a + 1)) >> 1);
+#pragma unroll
+                for (int r = 0; r < 15; ++r) s += Jw[r * 30 + a] * Jw[r * 30 + cc];
+            } else {
+                const int a = e - 465;
+#pragma unroll
+                for (int r = 0; r < 15; ++r) s += Jw[r * 30 + a] * rw[r];
+            }
+            c.ws[h.w_imu + (size_t)b * UVS_WIMU_STRIDE + e] = s;
         }
     }
-    cost += prior_residual(c);
+    UVS_PROF(c, P_ASSEMBLE);
 
-    // ---- landmark chunks: stage -> per-landmark Schur prep -> output-stationary gather
+    // ---- landmark chunks: stage -> per-landmark Schur prep -> list-driven gather
     const int* chunks = c.bi + h.i_chunks;
     for (int ch = 0; ch < h.n_chunks; ++ch) {
-        const int type = chunks[4 * ch], k0 = chunks[4 * ch + 1], k1 = chunks[4 * ch + 2];
+        const int type = chunks[6 * ch], k0 = chunks[6 * ch + 1], k1 = chunks[6 * ch + 2];
+        const int* glists = c.bi + h.i_lists + chunks[6 * ch + 3];      // gather lists of this chunk (HBM)
+        const int nlist = chunks[6 * ch + 4];
         const int nlm = k1 - k0;
-        __syncthreads();     // previous chunk's gather done; S region free
+        __syncthreads();     // previous users of the S region are done
         UVS_PROF(c, P_GATHER);
         if (type == 0) {
             const int* beg = c.bi + h.i_pt_beg;
             const int o0 = beg[k0], o1 = beg[k1], nob = o1 - o0;
             double* rec = sh + L_S;                                  // [nob][28]
             double* Eb = rec + (size_t)nob * UVS_PT_REC;             // [(nob + nlm)][6]
-            double* Xb = Eb + (size_t)(nob + nlm) * 6;               // [nlm][2] : hinv, ginv
-            signed char* slot = (signed char*)(Xb + 2 * nlm);        // [nlm][11]
+            double* EIb = Eb + (size_t)(nob + nlm) * 6;              // [(nob + nlm)][6]  Einv = E / h_ll
+            double* Xb = EIb + (size_t)(nob + nlm) * 6;              // [nlm][2] : hinv, ginv
+            int* lists = (int*)(Xb + 2 * nlm);                       // gather lists staged in LDS (one HBM latency per chunk)
+            for (int t = tid; t < nlist; t += NT) lists[t] = glists[t];
             // pass A: one lane per observation
             for (int o = o0 + tid; o < o1; o += NT) {
                 const int lm = c.bi[h.i_pt_lm + o], fi = c.bi[h.i_pt_fi + o], fj = c.bi[h.i_pt_fj + o];
@@ -424,72 +619,44 @@ UVS_DEV void linearize(const Ctx& c, const double* x, const double* invd, const 
             }
             __syncthreads();
             UVS_PROF(c, P_OBS);
-            // pass B: one lane per landmark
-            for (int li = tid; li < nlm; li += NT) {
-                const int k = k0 + li, b0 = beg[k] - o0, b1 = beg[k + 1] - o0;
+            // pass B: one lane per observation (its landmark's h_ll / g_l are recomputed per lane, cheap);
+            // the lane of a landmark's first observation also owns the anchor slot and the per-landmark scalars
+            for (int ol = tid; ol < nob; ol += NT) {
+                const int k = c.bi[h.i_pt_lm + o0 + ol], li = k - k0, b0 = beg[k] - o0, b1 = beg[k + 1] - o0;
                 double hd = 0.0, gl = 0.0;
                 for (int o = b0; o < b1; ++o) { const double* R = rec + (size_t)o * UVS_PT_REC; hd += R[26] * R[26] + R[27] * R[27]; gl += R[26] * R[0] + R[27] * R[1]; }
+                const bool lead = ol == b0;
                 double sc;
-                if (first) { sc = c.o.jacobi ? 1.0 / (1.0 + sqrt(hd)) : 1.0; c.ws[h.w_scale_pt + k] = sc; } else sc = c.ws[h.w_scale_pt + k];
+                if (first) { sc = c.o.jacobi ? 1.0 / (1.0 + sqrt(hd)) : 1.0; if (lead) c.ws[h.w_scale_pt + k] = sc; } else sc = c.ws[h.w_scale_pt + k];
                 const double dd = fmin(fmax(sc * sc * hd, c.o.dlo), c.o.dhi) / (radius * sc * sc);
                 const double hinv = 1.0 / (hd + dd), ginv = gl * hinv;
-                Xb[2 * li] = hinv; Xb[2 * li + 1] = ginv;
-                double* px = c.ws + h.w_pt_x + 4 * (size_t)k; px[0] = ginv; px[1] = gl; px[2] = dd; px[3] = hd;
-                gmax_lm = fmax(gmax_lm, fabs(gl));
-                signed char* sm = slot + 11 * li;
-#pragma unroll
-                for (int f = 0; f < UVS_NF; ++f) sm[f] = -1;
-                double* E = Eb + (size_t)(b0 + li) * 6;
+                const int s = ol - b0 + 1;
+                double* E = Eb + (size_t)(b0 + li) * 6; double* EI = EIb + (size_t)(b0 + li) * 6;
                 double* Eg = c.ws + h.w_pt_E + 6 * (size_t)(beg[k] + k);
-                double e0[6] = {0, 0, 0, 0, 0, 0};
-                for (int o = b0; o < b1; ++o) {
-                    const double* R = rec + (size_t)o * UVS_PT_REC;
-                    const int s = o - b0 + 1;
-                    sm[c.bi[h.i_pt_fj + o0 + o]] = (signed char)s;
+                {
+                    const double* R = rec + (size_t)ol * UVS_PT_REC;
 #pragma unroll
-                    for (int a = 0; a < 6; ++a) {
-                        e0[a] += R[26] * R[2 + a] + R[27] * R[8 + a];
-                        const double e = R[26] * R[14 + a] + R[27] * R[20 + a];
-                        E[6 * s + a] = e; Eg[6 * s + a] = e * hinv;
-                    }
+                    for (int a = 0; a < 6; ++a) { const double e = R[26] * R[14 + a] + R[27] * R[20 + a]; E[6 * s + a] = e; EI[6 * s + a] = e * hinv; Eg[6 * s + a] = e * hinv; }
                 }
-                if (b1 > b0) sm[c.bi[h.i_pt_fi + o0 + b0]] = 0;
+                if (lead) {
+                    Xb[2 * li] = hinv; Xb[2 * li + 1] = ginv;
+                    double* px = c.ws + h.w_pt_x + 4 * (size_t)k; px[0] = ginv; px[1] = gl; px[2] = dd; px[3] = hd;
+                    gmax_lm = fmax(gmax_lm, fabs(gl));
+                    double e0[6] = {0, 0, 0, 0, 0, 0};
+                    for (int o = b0; o < b1; ++o) {
+                        const double* R = rec + (size_t)o * UVS_PT_REC;
 #pragma unroll
-                for (int a = 0; a < 6; ++a) { E[a] = e0[a]; Eg[a] = e0[a] * hinv; }
+                        for (int a = 0; a < 6; ++a) e0[a] += R[26] * R[2 + a] + R[27] * R[8 + a];
+                    }
+#pragma unroll
+                    for (int a = 0; a < 6; ++a) { E[a] = e0[a]; EI[a] = e0[a] * hinv; Eg[a] = e0[a] * hinv; }
+                }
             }
             __syncthreads();
             UVS_PROF(c, P_LMPREP);
-            // pass C: output-stationary gather (fixed landmark order => deterministic)
-#pragma unroll
-            for (int q = 0; q < ITEMS_PER_THREAD; ++q) {
-                const GatherItem it = decode_item(tid + q * NT);
-                if (it.type < 0) continue;
-                double s = 0.0;
-                for (int li = 0; li < nlm; ++li) {
-                    const signed char* sm = slot + 11 * li;
-                    const int sa = sm[it.fa];
-                    if (sa < 0) continue;
-                    const int b0 = beg[k0 + li] - o0, b1 = beg[k0 + li + 1] - o0;
-                    const double* E = Eb + (size_t)(b0 + li) * 6;
-                    if (it.type == 0) {
-                        const int sb = sm[it.fb];
-                        if (sb < 0) continue;
-                        s -= E[6 * sa + it.a] * Xb[2 * li] * E[6 * sb + it.b];
-                        if (it.fa == it.fb) {
-                            if (sa == 0) { for (int o = b0; o < b1; ++o) { const double* R = rec + (size_t)o * UVS_PT_REC; s += R[2 + it.a] * R[2 + it.b] + R[8 + it.a] * R[8 + it.b]; } }
-                            else { const double* R = rec + (size_t)(b0 + sa - 1) * UVS_PT_REC; s += R[14 + it.a] * R[14 + it.b] + R[20 + it.a] * R[20 + it.b]; }
-                        } else if (sb == 0) { const double* R = rec + (size_t)(b0 + sa - 1) * UVS_PT_REC; s += R[14 + it.a] * R[2 + it.b] + R[20 + it.a] * R[8 + it.b]; }
-                    } else if (it.type == 1) {
-                        if (sa == 0) { for (int o = b0; o < b1; ++o) { const double* R = rec + (size_t)o * UVS_PT_REC; s += R[2 + it.a] * R[0] + R[8 + it.a] * R[1]; } }
-                        else { const double* R = rec + (size_t)(b0 + sa - 1) * UVS_PT_REC; s += R[14 + it.a] * R[0] + R[20 + it.a] * R[1]; }
-                        s -= E[6 * sa + it.a] * Xb[2 * li + 1];
-                    } else {
-                        if (sa == 0) { for (int o = b0; o < b1; ++o) { const double* R = rec + (size_t)o * UVS_PT_REC; s += R[2 + it.a] * R[2 + it.a] + R[8 + it.a] * R[8 + it.a]; } }
-                        else { const double* R = rec + (size_t)(b0 + sa - 1) * UVS_PT_REC; s += R[14 + it.a] * R[14 + it.a] + R[20 + it.a] * R[20 + it.a]; }
-                    }
-                }
-                acc[q] += s;
-            }
+            const long long tg0_ = clock64();
+            gather_points(c.bi + h.i_wblk, lists, rec, (int)(Eb - rec), (int)(EIb - rec), (int)(Xb - rec), acc);
+            if (c.o.debug && (tid & 63) == 0) sh[L_WPROF + (tid >> 6)] += (double)(clock64() - tg0_);
         } else {
             const int* beg = c.bi + h.i_ln_beg;
             const int o0 = beg[k0], o1 = beg[k1], nob = o1 - o0;
@@ -497,7 +664,8 @@ UVS_DEV void linearize(const Ctx& c, const double* x, const double* invd, const 
             double* Eb = rec + (size_t)nob * UVS_LN_REC;             // [nob][24]  E[c][a] = (J_l^T J_p)
             double* Yb = Eb + (size_t)nob * 24;                      // [nob][24]  Y = Hinv E
             double* Xb = Yb + (size_t)nob * 24;                      // [nlm][20] : Hinv[16], Hinv*g[4]
-            signed char* slot = (signed char*)(Xb + 20 * nlm);       // [nlm][11]
+            int* lists = (int*)(Xb + 20 * nlm);
+            for (int t = tid; t < nlist; t += NT) lists[t] = glists[t];
             // pass A
             for (int o = o0 + tid; o < o1; o += NT) {
                 const int lm = c.bi[h.i_ln_lm + o], fj = c.bi[h.i_ln_fj + o], hv = c.bi[h.i_ln_vp + o];
@@ -534,12 +702,8 @@ UVS_DEV void linearize(const Ctx& c, const double* x, const double* invd, const 
             for (int li = tid; li < nlm; li += NT) {
                 const int k = k0 + li, b0 = beg[k] - o0, b1 = beg[k + 1] - o0;
                 double H[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, gl[4] = {0, 0, 0, 0};   // lower packed (0,0)(1,0)(1,1)(2,0)...
-                signed char* sm = slot + 11 * li;
-#pragma unroll
-                for (int f = 0; f < UVS_NF; ++f) sm[f] = -1;
                 for (int o = b0; o < b1; ++o) {
                     const double* R = rec + (size_t)o * UVS_LN_REC;
-                    sm[c.bi[h.i_ln_fj + o0 + o]] = (signed char)(o - b0);
 #pragma unroll
                     for (int a = 0; a < 4; ++a) {
                         gl[a] += R[14 + a] * R[0] + R[18 + a] * R[1] + R[29 + a] * R[22];
@@ -566,6 +730,7 @@ UVS_DEV void linearize(const Ctx& c, const double* x, const double* invd, const 
                 L[6] = H[6] / L[0]; L[7] = (H[7] - L[6] * L[1]) / L[2]; L[8] = (H[8] - L[6] * L[3] - L[7] * L[4]) / L[5];
                 L[9] = sqrt(H[9] - L[6] * L[6] - L[7] * L[7] - L[8] * L[8]);
                 double* X = Xb + 20 * li;
+                double hg[4] = {0, 0, 0, 0};
 #pragma unroll
                 for (int cidx = 0; cidx < 4; ++cidx) {
                     double e[4] = {0, 0, 0, 0}; e[cidx] = 1.0;
@@ -578,16 +743,14 @@ UVS_DEV void linearize(const Ctx& c, const double* x, const double* invd, const 
                     e[1] = (e[1] - L[4] * e[2] - L[7] * e[3]) / L[2];
                     e[0] = (e[0] - L[1] * e[1] - L[3] * e[2] - L[6] * e[3]) / L[0];
                     X[0 * 4 + cidx] = e[0]; X[1 * 4 + cidx] = e[1]; X[2 * 4 + cidx] = e[2]; X[3 * 4 + cidx] = e[3];
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) hg[a] += e[a] * gl[cidx];
                 }
+#pragma unroll
+                for (int a = 0; a < 4; ++a) { X[16 + a] = hg[a]; lx[a] = hg[a]; }
             }
             __syncthreads();
-            // Hinv * g (needs the full inverse) + pass B2: one lane per line observation: E and Y = Hinv E
-            for (int li = tid; li < nlm; li += NT) {
-                const int k = k0 + li;
-                double* X = Xb + 20 * li; double* lx = c.ws + h.w_ln_x + 12 * (size_t)k;
-#pragma unroll
-                for (int a = 0; a < 4; ++a) { const double v = X[4 * a] * lx[4] + X[4 * a + 1] * lx[5] + X[4 * a + 2] * lx[6] + X[4 * a + 3] * lx[7]; X[16 + a] = v; lx[a] = v; }
-            }
+            // pass B2: one lane per line observation: E and Y = Hinv E
             for (int o = tid; o < nob; o += NT) {
                 const int li = c.bi[h.i_ln_lm + o0 + o] - k0;
                 const double* R = rec + (size_t)o * UVS_LN_REC;
@@ -605,35 +768,9 @@ UVS_DEV void linearize(const Ctx& c, const double* x, const double* invd, const 
             }
             __syncthreads();
             UVS_PROF(c, P_LMPREP);
-            // pass C
-#pragma unroll
-            for (int q = 0; q < ITEMS_PER_THREAD; ++q) {
-                const GatherItem it = decode_item(tid + q * NT);
-                if (it.type < 0) continue;
-                double s = 0.0;
-                for (int li = 0; li < nlm; ++li) {
-                    const signed char* sm = slot + 11 * li;
-                    const int sa = sm[it.fa];
-                    if (sa < 0) continue;
-                    const int b0 = beg[k0 + li] - o0;
-                    const double* Ea = Eb + (size_t)(b0 + sa) * 24;
-                    const double* Ra = rec + (size_t)(b0 + sa) * UVS_LN_REC;
-                    if (it.type == 0) {
-                        const int sb = sm[it.fb];
-                        if (sb < 0) continue;
-                        const double* Y = Yb + (size_t)(b0 + sb) * 24;
-                        s -= Ea[it.a] * Y[it.b] + Ea[6 + it.a] * Y[6 + it.b] + Ea[12 + it.a] * Y[12 + it.b] + Ea[18 + it.a] * Y[18 + it.b];
-                        if (it.fa == it.fb) s += Ra[2 + it.a] * Ra[2 + it.b] + Ra[8 + it.a] * Ra[8 + it.b] + Ra[23 + it.a] * Ra[23 + it.b];
-                    } else if (it.type == 1) {
-                        const double* X = Xb + 20 * li;
-                        s += Ra[2 + it.a] * Ra[0] + Ra[8 + it.a] * Ra[1] + Ra[23 + it.a] * Ra[22];
-                        s -= Ea[it.a] * X[16] + Ea[6 + it.a] * X[17] + Ea[12 + it.a] * X[18] + Ea[18 + it.a] * X[19];
-                    } else {
-                        s += Ra[2 + it.a] * Ra[2 + it.a] + Ra[8 + it.a] * Ra[8 + it.a] + Ra[23 + it.a] * Ra[23 + it.a];
-                    }
-                }
-                acc[q] += s;
-            }
+            const long long tg0_ = clock64();
+            gather_lines(c.bi + h.i_wblk, lists, rec, (int)(Eb - rec), (int)(Yb - rec), (int)(Xb - rec), acc);
+            if (c.o.debug && (tid & 63) == 0) sh[L_WPROF + (tid >> 6)] += (double)(clock64() - tg0_);
         }
     }
     __syncthreads();
@@ -642,47 +779,40 @@ UVS_DEV void linearize(const Ctx& c, const double* x, const double* invd, const 
     for (int i = tid; i < UVS_S_DOUBLES; i += NT) sh[L_S + i] = 0.0;
     if (tid < UVS_RD) { sh[L_G + tid] = 0.0; sh[L_HD + tid] = 0.0; }
     __syncthreads();
+    {
+        const int lane = tid & 63, wv = tid >> 6;
+        const int role = lane < 36 ? 0 : lane < 42 ? 1 : lane < 48 ? 2 : 3;
+        const int a = role == 0 ? lane / 6 : role == 1 ? lane - 36 : role == 2 ? lane - 42 : 0;
+        const int bb = role == 0 ? lane - 6 * (lane / 6) : 0;
 #pragma unroll
-    for (int q = 0; q < ITEMS_PER_THREAD; ++q) {
-        const GatherItem it = decode_item(tid + q * NT);
-        if (it.type == 0) { if (it.fa != it.fb || it.a >= it.b) sh[L_S + sidx(16 * it.fa + it.a, 16 * it.fb + it.b)] = acc[q]; }
-        else if (it.type == 1) sh[L_G + 16 * it.fa + it.a] = acc[q];
-        else if (it.type == 2) sh[L_HD + 16 * it.fa + it.a] = acc[q];
-    }
-    // IMU whitening: Jw = W * Jraw (W upper triangular), rw = W * rraw
-    for (int t = tid; t < h.n_imu * 465; t += NT) {
-        const int b = t / 465, e = t - b * 465;
-        if (c.bi[h.i_imu + 2 * b + 1]) continue;
-        const double* W = c.bd + h.d_imu + (size_t)b * UVS_IMU_STRIDE + UVS_IMU_W;
-        double* wj = c.ws + h.w_imu + (size_t)b * UVS_WIMU_STRIDE;
-        if (e < 450) { const int r = e / 30, cc = e - r * 30; double s = 0.0; for (int k = r; k < 15; ++k) s += W[r * 15 + k] * wj[k * 30 + cc]; wj[450 + e] = s; }
-        else { const int r = e - 450; double s = 0.0; for (int k = r; k < 15; ++k) s += W[r * 15 + k] * wj[900 + k]; wj[915 + r] = s; cost += 0.5 * s * s; }
+        for (int q = 0; q < BLOCKS_PER_WAVE; ++q) {
+            const int b = c.bi[h.i_wblk + wv * BLOCKS_PER_WAVE + q];
+            if (b >= 0) {
+                const int fa = c_blk_fa[b], fb = c_blk_fb[b];
+                if (role == 0) { if (fa != fb || a >= bb) sh[L_S + sidx(16 * fa + a, 16 * fb + bb)] = acc[q]; }
+                else if (fa == fb && role == 1) sh[L_G + 16 * fa + a] = acc[q];
+                else if (fa == fb && role == 2) sh[L_HD + 16 * fa + a] = acc[q];
+            }
+        }
     }
     __syncthreads();
-    // IMU normal-equation blocks (even blocks, then odd blocks: consecutive blocks share a diagonal frame block)
+    // IMU normal-equation blocks from global scratch (even blocks, then odd: consecutive blocks share a diagonal frame block)
     for (int par = 0; par < 2; ++par) {
         for (int t = tid; t < h.n_imu * 495; t += NT) {
             const int b = t / 495, e = t - b * 495;
             if ((b & 1) != par || c.bi[h.i_imu + 2 * b + 1]) continue;
             const int fi = c.bi[h.i_imu + 2 * b];
-            const double* Jw = c.ws + h.w_imu + (size_t)b * UVS_WIMU_STRIDE + 450;
-            const double* rw = Jw + 465;
+            const double s = c.ws[h.w_imu + (size_t)b * UVS_WIMU_STRIDE + e];
             if (e < 465) {
                 int a = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
                 while (((a + 1) * (a + 2)) >> 1 <= e) ++a;
                 while (((a * (a + 1)) >> 1) > e) --a;
                 const int cc = e - ((a * (a + 1)) >> 1);     // a >= cc
-                double s = 0.0;
-#pragma unroll
-                for (int r = 0; r < 15; ++r) s += Jw[r * 30 + a] * Jw[r * 30 + cc];
                 const int ia = 16 * (fi + (a >= 15)) + (a >= 15 ? a - 15 : a), ic = 16 * (fi + (cc >= 15)) + (cc >= 15 ? cc - 15 : cc);
                 sh[L_S + sidx(ia, ic)] += s;
                 if (a == cc) sh[L_HD + ia] += s;
             } else {
                 const int a = e - 465;
-                double s = 0.0;
-#pragma unroll
-                for (int r = 0; r < 15; ++r) s += Jw[r * 30 + a] * rw[r];
                 sh[L_G + 16 * (fi + (a >= 15)) + (a >= 15 ? a - 15 : a)] += s;
             }
         }
@@ -827,36 +957,45 @@ UVS_DEV double ambient_sqnorm(const Ctx& c, const double* x, const double* invd,
 
 // ------------------------------------------------------------------ the kernel
 // setup: IMU whitening matrices W = chol_lower(cov^-1)^T (imu_factor.h:64) and prior H0 = J0^T J0, once per solve.
+// One wavefront per IMU block; the 15x30 Gauss-Jordan tableau and the Cholesky factor live in the (free) S region.
+// Same operation order as a sequential partial-pivoting Gauss-Jordan, lanes own tableau columns.
 UVS_DEV void setup_window(const Ctx& c, double* blob_rw) {
     const DevWin& h = *c.hdr;
-    const int tid = threadIdx.x;
-    if (tid < h.n_imu) {
-        double* blk = blob_rw + h.d_imu + (size_t)tid * UVS_IMU_STRIDE;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int b = wv; b < h.n_imu; b += NW) {
+        double* blk = blob_rw + h.d_imu + (size_t)b * UVS_IMU_STRIDE;
         const double* cov = blk + UVS_IMU_COV; double* W = blk + UVS_IMU_W;
-        double* M = c.ws + h.w_imu + (size_t)tid * UVS_WIMU_STRIDE;      // scratch 15 x 30 (Gauss-Jordan with partial pivoting)
-        for (int i = 0; i < 15; ++i) for (int j = 0; j < 15; ++j) { M[i * 30 + j] = cov[i * 15 + j]; M[i * 30 + 15 + j] = (i == j) ? 1.0 : 0.0; }
+        volatile double* M = c.sh + L_S + 704 * wv;      // 15 x 30 tableau, then 15 x 15 factor at +450
+        if (lane < 30) for (int i = 0; i < 15; ++i) M[i * 30 + lane] = lane < 15 ? cov[i * 15 + lane] : (i == lane - 15 ? 1.0 : 0.0);
         for (int k = 0; k < 15; ++k) {
+            // partial pivoting: first row with the largest |M[i][k]|, i >= k
             int piv = k; double best = fabs(M[k * 30 + k]);
             for (int i = k + 1; i < 15; ++i) { const double v = fabs(M[i * 30 + k]); if (v > best) { best = v; piv = i; } }
-            if (piv != k) for (int j = 0; j < 30; ++j) { const double t = M[k * 30 + j]; M[k * 30 + j] = M[piv * 30 + j]; M[piv * 30 + j] = t; }
+            if (piv != k && lane < 30) { const double t = M[k * 30 + lane]; M[k * 30 + lane] = M[piv * 30 + lane]; M[piv * 30 + lane] = t; }
             const double dinv = 1.0 / M[k * 30 + k];
-            for (int i = k + 1; i < 15; ++i) { const double f = M[i * 30 + k] * dinv; for (int j = k; j < 30; ++j) M[i * 30 + j] -= f * M[k * 30 + j]; }
+            for (int i = k + 1; i < 15; ++i) {
+                const double f = M[i * 30 + k] * dinv;
+                if (lane >= k && lane < 30) M[i * 30 + lane] -= f * M[k * 30 + lane];
+            }
         }
         for (int k = 14; k >= 0; --k) {
             const double dinv = 1.0 / M[k * 30 + k];
-            for (int j = 0; j < 30; ++j) M[k * 30 + j] *= dinv;
-            for (int i = 0; i < k; ++i) { const double f = M[i * 30 + k]; for (int j = 0; j < 30; ++j) M[i * 30 + j] -= f * M[k * 30 + j]; }
+            if (lane < 30) M[k * 30 + lane] *= dinv;
+            for (int i = 0; i < k; ++i) {
+                const double f = M[i * 30 + k];
+                if (lane < 30) M[i * 30 + lane] -= f * M[k * 30 + lane];
+            }
         }
-        // lower Cholesky of the inverse (read lower triangle), store transposed (upper)
-        double* Lm = M + 450;   // 225 scratch
+        // lower Cholesky of the inverse (reads its lower triangle), lanes own rows
+        volatile double* Lm = M + 450;
         for (int j = 0; j < 15; ++j) {
             double dsum = M[j * 30 + 15 + j];
             for (int k = 0; k < j; ++k) dsum -= Lm[j * 15 + k] * Lm[j * 15 + k];
             const double ljj = sqrt(dsum);
-            Lm[j * 15 + j] = ljj;
-            for (int i = j + 1; i < 15; ++i) { double s = M[i * 30 + 15 + j]; for (int k = 0; k < j; ++k) s -= Lm[i * 15 + k] * Lm[j * 15 + k]; Lm[i * 15 + j] = s / ljj; }
+            if (lane > j && lane < 15) { double s = M[lane * 30 + 15 + j]; for (int k = 0; k < j; ++k) s -= Lm[lane * 15 + k] * Lm[j * 15 + k]; Lm[lane * 15 + j] = s / ljj; }
+            if (lane == j) Lm[j * 15 + j] = ljj;
         }
-        for (int i = 0; i < 15; ++i) for (int j = 0; j < 15; ++j) W[i * 15 + j] = (j >= i) ? Lm[j * 15 + i] : 0.0;
+        for (int t = lane; t < 225; t += 64) { const int i = t / 15, j = t - 15 * i; W[t] = (j >= i) ? Lm[j * 15 + i] : 0.0; }
     }
     if (h.prior_n > 0) {
         const int n = h.prior_n;
@@ -894,6 +1033,7 @@ __global__ __launch_bounds__(NT) void k_solve(char* blobs, const long long* blob
     for (int k = tid; k < 4 * h.n_lines; k += NT) c.ws[h.w_line0 + k] = c.bd[h.d_line + k];
     for (int i = tid; i < (int)(sizeof(uvs_report) / 4); i += NT) ((int*)rep)[i] = 0;
     if (tid < 16) sh[L_PROF + tid] = (tid == 15) ? (double)clock64() : 0.0;
+    if (tid < 8) sh[L_WPROF + tid] = 0.0;
     setup_window(c, (double*)blob);
     __syncthreads();
     UVS_PROF(c, P_SETUP);
@@ -995,6 +1135,7 @@ __global__ __launch_bounds__(NT) void k_solve(char* blobs, const long long* blob
     __syncthreads();
     UVS_PROF(c, P_MISC);
     if (o.debug && dbg.scal && tid < P_LAST) dbg.scal[8 + tid] = sh[L_PROF + tid];
+    if (o.debug && dbg.scal && tid < 8) dbg.scal[20 + tid] = sh[L_WPROF + tid];
     if (tid < 184) c.ws[h.w_out + tid] = sh[L_X + tid];
     if (tid == 0) {
         rep->status = status; rep->termination = term; rep->num_iterations = it; rep->num_successful = nsucc; rep->final_cost = cost;

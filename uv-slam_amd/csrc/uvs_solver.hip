@@ -7,6 +7,7 @@
 // is present and every compute entry point runs HIP kernels.  The CPU oracle under oracle/ is test
 // infrastructure and is never linked or called from here.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -191,30 +192,96 @@ static int pack_window(const uvs_window* w, std::vector<char>& out, DevWin& hdr,
     for (int k = 0; k < h.n_points; ++k) pbeg[k + 1] += pbeg[k];
     for (int k = 0; k < h.n_ln_obs; ++k) lbeg[w->ln_lm[k] + 1]++;
     for (int k = 0; k < h.n_lines; ++k) lbeg[k + 1] += lbeg[k];
-    // chunks: greedy packing of whole landmarks into the LDS staging area (UVS_S_DOUBLES doubles)
-    std::vector<int> chunks;
+    // chunks: greedy packing of whole landmarks into the LDS staging area (UVS_S_DOUBLES doubles).  A chunk holds the
+    // observation records, the per-landmark Schur factors AND its gather lists (ints, 2 per double).
+    std::vector<int> chunks;     // 6 ints per chunk
     {
-        int k0 = 0; long nob = 0;
+        const long list_hdr = 2 * (UVS_NBLK + 1);
+        int k0 = 0; long nob = 0, nli = list_hdr;
         for (int k = 0; k < h.n_points; ++k) {
             const long no = pbeg[k + 1] - pbeg[k];
+            const long li_k = no ? (no + 1) * (no + 2) / 2 + 3 * no : 0;
             const long nlm = k - k0 + 1;
-            const long need = (long)UVS_PT_REC * (nob + no) + 6 * (nob + no + nlm) + 2 * nlm + (11 * nlm + 7) / 8;
-            if (need > UVS_S_DOUBLES && k > k0) { chunks.insert(chunks.end(), {0, k0, k, 0}); k0 = k; nob = 0; }
-            nob += no;
-            if ((long)UVS_PT_REC * nob + 6 * (nob + 1) + 2 + 2 > UVS_S_DOUBLES) { err = "single point landmark exceeds LDS staging"; return UVS_ERR_CAPACITY; }
+            const long need = (long)UVS_PT_REC * (nob + no) + 12 * (nob + no + nlm) + 2 * nlm + (nli + li_k + 1) / 2;
+            if ((need > UVS_S_DOUBLES || nlm > 1023 || nob + no + nlm > 16383) && k > k0) { chunks.insert(chunks.end(), {0, k0, k, 0, 0, 0}); k0 = k; nob = 0; nli = list_hdr; }
+            nob += no; nli += li_k;
+            if ((long)UVS_PT_REC * nob + 12 * (nob + 1) + 2 + (nli + 1) / 2 > UVS_S_DOUBLES) { err = "single point landmark exceeds LDS staging"; return UVS_ERR_CAPACITY; }
         }
-        if (h.n_points > k0) chunks.insert(chunks.end(), {0, k0, h.n_points, 0});
-        k0 = 0; nob = 0;
+        if (h.n_points > k0) chunks.insert(chunks.end(), {0, k0, h.n_points, 0, 0, 0});
+        k0 = 0; nob = 0; nli = list_hdr;
         for (int k = 0; k < h.n_lines; ++k) {
             const long no = lbeg[k + 1] - lbeg[k];
+            const long li_k = no * (no + 1) / 2 + no;
             const long nlm = k - k0 + 1;
-            const long need = (long)(UVS_LN_REC + 48) * (nob + no) + 20 * nlm + (11 * nlm + 7) / 8;
-            if (need > UVS_S_DOUBLES && k > k0) { chunks.insert(chunks.end(), {1, k0, k, 0}); k0 = k; nob = 0; }
-            nob += no;
+            const long need = (long)(UVS_LN_REC + 48) * (nob + no) + 20 * nlm + (nli + li_k + 1) / 2;
+            if ((need > UVS_S_DOUBLES || nlm > 1023 || nob + no > 16383) && k > k0) { chunks.insert(chunks.end(), {1, k0, k, 0, 0, 0}); k0 = k; nob = 0; nli = list_hdr; }
+            nob += no; nli += li_k;
         }
-        if (h.n_lines > k0) chunks.insert(chunks.end(), {1, k0, h.n_lines, 0});
+        if (h.n_lines > k0) chunks.insert(chunks.end(), {1, k0, h.n_lines, 0, 0, 0});
     }
-    h.n_chunks = (int)chunks.size() / 4;
+    // gather lists (one pair per chunk and per lower 6x6 pose block, see uvs_solve_kernel.h: gather_points / gather_lines)
+    //   Schur entry : li | slot_a << 10 | slot_b << 14 | first_slot << 18      (landmark observed in both frames of the block)
+    //   direct entry: local observation index | kind << 14                      (kind 0: A^T A, 1: B^T B, 2: B^T A ; lines: 0)
+    std::vector<int> lists;
+    std::vector<long> blk_work(UVS_NBLK, 0);
+    auto blk_of = [](int fa, int fb) { return fa * (fa + 1) / 2 + fb; };   // fa >= fb
+    for (size_t q = 0; q < chunks.size(); q += 6) {
+        const int type = chunks[q], k0 = chunks[q + 1], k1 = chunks[q + 2];
+        std::vector<std::vector<int>> sch(UVS_NBLK), dir(UVS_NBLK);
+        if (type == 0) {
+            const int o0 = pbeg[k0];
+            for (int k = k0; k < k1; ++k) {
+                const int li = k - k0, b0 = pbeg[k] - o0, b1 = pbeg[k + 1] - o0;
+                if (b1 == b0) continue;
+                const int first_slot = b0 + li;
+                int fr[UVS_NUM_FRAMES + 1], nf = 0;
+                fr[nf++] = w->pt_fi[o0 + b0];
+                for (int o = b0; o < b1; ++o) fr[nf++] = w->pt_fj[o0 + o];
+                for (int sa = 0; sa < nf; ++sa) for (int sb = 0; sb <= sa; ++sb)      // frames increase with the slot => fr[sa] >= fr[sb]
+                    sch[blk_of(fr[sa], fr[sb])].push_back(li | (sa << 10) | (sb << 14) | (first_slot << 18));
+                for (int o = b0; o < b1; ++o) {
+                    const int fi = w->pt_fi[o0 + o], fj = w->pt_fj[o0 + o];
+                    dir[blk_of(fi, fi)].push_back(o | (0 << 14));
+                    dir[blk_of(fj, fj)].push_back(o | (1 << 14));
+                    dir[blk_of(fj, fi)].push_back(o | (2 << 14));
+                }
+            }
+        } else {
+            const int o0 = lbeg[k0];
+            for (int k = k0; k < k1; ++k) {
+                const int li = k - k0, b0 = lbeg[k] - o0, b1 = lbeg[k + 1] - o0;
+                for (int sa = 0; sa < b1 - b0; ++sa) for (int sb = 0; sb <= sa; ++sb)
+                    sch[blk_of(w->ln_fj[o0 + b0 + sa], w->ln_fj[o0 + b0 + sb])].push_back(li | (sa << 10) | (sb << 14) | (b0 << 18));
+                for (int o = b0; o < b1; ++o) dir[blk_of(w->ln_fj[o0 + o], w->ln_fj[o0 + o])].push_back(o);
+            }
+        }
+        for (int b = 0; b < UVS_NBLK; ++b) blk_work[b] += (type == 0 ? 1 : 3) * (long)sch[b].size() + (type == 0 ? 2 : 2) * (long)dir[b].size();
+        chunks[q + 3] = (int)lists.size();
+        const size_t base = lists.size();
+        lists.resize(base + 2 * (UVS_NBLK + 1));
+        int run = 0;
+        for (int b = 0; b < UVS_NBLK; ++b) { lists[base + b] = run; run += (int)sch[b].size(); }
+        lists[base + UVS_NBLK] = run;
+        for (int b = 0; b < UVS_NBLK; ++b) { lists[base + UVS_NBLK + 1 + b] = run; run += (int)dir[b].size(); }
+        lists[base + 2 * UVS_NBLK + 1] = run;
+        for (int b = 0; b < UVS_NBLK; ++b) lists.insert(lists.end(), sch[b].begin(), sch[b].end());
+        for (int b = 0; b < UVS_NBLK; ++b) lists.insert(lists.end(), dir[b].begin(), dir[b].end());
+        chunks[q + 4] = (int)(lists.size() - base);
+    }
+    // balance the 66 pose blocks over the 8 gather waves (longest list first, at most 9 blocks per wave)
+    int wblk[NW * BLOCKS_PER_WAVE];
+    {
+        for (int q = 0; q < NW * BLOCKS_PER_WAVE; ++q) wblk[q] = -1;
+        std::vector<int> order(UVS_NBLK); for (int b = 0; b < UVS_NBLK; ++b) order[b] = b;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b2) { return blk_work[a] > blk_work[b2]; });
+        long load[NW] = {0}; int cnt[NW] = {0};
+        for (int b : order) {
+            int best = -1;
+            for (int wv = 0; wv < NW; ++wv) if (cnt[wv] < BLOCKS_PER_WAVE && (best < 0 || load[wv] < load[best])) best = wv;
+            wblk[best * BLOCKS_PER_WAVE + cnt[best]++] = b; load[best] += blk_work[b] + 8;
+        }
+    }
+    h.n_chunks = (int)chunks.size() / 6;
     // layout
     int d = (int)((sizeof(DevWin) + 7) / 8);
     h.d_frames = d; d += 184;
@@ -229,7 +296,9 @@ static int pack_window(const uvs_window* w, std::vector<char>& out, DevWin& hdr,
     h.i_ln_lm = i; i += h.ln_stride; h.i_ln_fj = i; i += h.ln_stride; h.i_ln_vp = i; i += h.ln_stride; h.i_ln_beg = i; i += rup(h.n_lines + 1, 2);
     h.i_imu = i; i += 2 * std::max(h.n_imu, 1);
     h.i_prior = i; i += 80 + UVS_MAX_PRIOR_DIM;
-    h.i_chunks = i; i += 4 * std::max(h.n_chunks, 1);
+    h.i_chunks = i; i += 6 * std::max(h.n_chunks, 1);
+    h.i_wblk = i; i += NW * BLOCKS_PER_WAVE;
+    h.i_lists = i; i += (int)lists.size() + 2;
     h.blob_bytes = rup(4 * i, 256);
     // workspace layout
     int wsz = 0;
@@ -294,6 +363,8 @@ static int pack_window(const uvs_window* w, std::vector<char>& out, DevWin& hdr,
         }
     }
     for (size_t q = 0; q < chunks.size(); ++q) I[h.i_chunks + q] = chunks[q];
+    for (size_t q = 0; q < lists.size(); ++q) I[h.i_lists + q] = lists[q];
+    for (int q = 0; q < NW * BLOCKS_PER_WAVE; ++q) I[h.i_wblk + q] = wblk[q];
     hdr = h;
     return UVS_OK;
 }
@@ -342,7 +413,7 @@ static int launch_solve(uvs_solver* s, int debug, float* elapsed_ms) {
     KOpts ko = make_kopts(s->opts, debug);
     DebugOut dbg; std::memset(&dbg, 0, sizeof(dbg));
     if (debug) {
-        if (!s->d_dbg) HIPCHK(s, hipMalloc((void**)&s->d_dbg, sizeof(double) * (UVS_RD * UVS_RD + 5 * UVS_RD + 24)));
+        if (!s->d_dbg) HIPCHK(s, hipMalloc((void**)&s->d_dbg, sizeof(double) * (UVS_RD * UVS_RD + 5 * UVS_RD + 32)));
         dbg.S = s->d_dbg; dbg.g = dbg.S + UVS_RD * UVS_RD; dbg.hd = dbg.g + UVS_RD; dbg.dd = dbg.hd + UVS_RD; dbg.step = dbg.dd + UVS_RD; dbg.scal = dbg.step + UVS_RD;
     }
     HIPCHK(s, hipEventRecord(s->ev0, s->stream));
@@ -414,7 +485,7 @@ int uvs_debug_first_iteration(uvs_solver* s, const uvs_window* w, double* S_lowe
     if (hd) HIPCHK(s, hipMemcpy(hd, s->d_dbg + nS + UVS_RD, UVS_RD * 8, hipMemcpyDeviceToHost));
     if (dd) HIPCHK(s, hipMemcpy(dd, s->d_dbg + nS + 2 * UVS_RD, UVS_RD * 8, hipMemcpyDeviceToHost));
     if (step) HIPCHK(s, hipMemcpy(step, s->d_dbg + nS + 3 * UVS_RD, UVS_RD * 8, hipMemcpyDeviceToHost));
-    if (scal) HIPCHK(s, hipMemcpy(scal, s->d_dbg + nS + 4 * UVS_RD, 24 * 8, hipMemcpyDeviceToHost));
+    if (scal) HIPCHK(s, hipMemcpy(scal, s->d_dbg + nS + 4 * UVS_RD, 32 * 8, hipMemcpyDeviceToHost));
     return UVS_OK;
 }
 
