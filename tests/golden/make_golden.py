@@ -1,0 +1,85 @@
+"""Regenerates tests/golden/*.npz.
+
+PARITY UNPINNED: the reference ships no golden vectors and cannot be compiled here, so these fixtures are produced by
+the CPU oracle (oracle/uvs_oracle.cpp), whose factors are independently pinned by tests/test_oracle_factors.py
+(torch autograd) and whose LM loop is pinned by the known-answer tests.  They freeze inputs + expected outputs so that
+(a) the oracle cannot drift silently and (b) the GPU box (which has no /root/reference and needs none) checks the HIP
+solver against committed numbers.  Run:  python tests/golden/make_golden.py
+"""
+import importlib
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+uvs = importlib.import_module("uv-slam_amd")
+from oracle_binding import Oracle  # noqa: E402
+
+WINDOW_FIELDS = ("pose", "speedbias", "ex_pose", "inv_depth", "pt_lm", "pt_fi", "pt_fj", "pt_pi", "pt_pj", "line_orth", "ln_lm", "ln_fj",
+                 "ln_sp", "ln_ep", "ln_has_vp", "ln_vp")
+IMU_FIELDS = ("sum_dt", "delta_p", "delta_q", "delta_v", "linearized_ba", "linearized_bg", "jacobian", "covariance", "frame_i", "skip")
+
+
+def window_to_dict(w):
+    d = {k: np.asarray(getattr(w, k)) for k in WINDOW_FIELDS}
+    for f in IMU_FIELDS:
+        d["imu_" + f] = np.array([np.asarray(b[f]) for b in w.imu])
+    if w.prior is not None and w.prior.n > 0:
+        p = w.prior; nb = p.n_blocks
+        d["prior_n"] = np.array(p.n); d["prior_J0"] = p.J0(); d["prior_r0"] = p.r0(); d["prior_x0"] = np.array(p.x0[:])
+        for f in ("block_kind", "block_frame", "block_size", "block_idx", "x0_off"):
+            d["prior_" + f] = np.array(getattr(p, f)[:nb])
+    return d
+
+
+def dict_to_window(d):
+    abi = uvs.abi
+    w = abi.Window()
+    for k in WINDOW_FIELDS:
+        setattr(w, k, np.array(d[k]))
+    n = len(d["imu_sum_dt"])
+    w.imu = [{f: (d["imu_" + f][b] if d["imu_" + f].ndim > 1 else d["imu_" + f][b].item()) for f in IMU_FIELDS} for b in range(n)]
+    if "prior_n" in d:
+        p = abi.Prior(); n = int(d["prior_n"]); nb = len(d["prior_block_kind"])
+        p.n = n; p.n_blocks = nb
+        for f in ("block_kind", "block_frame", "block_size", "block_idx", "x0_off"):
+            for b in range(nb):
+                getattr(p, f)[b] = int(d["prior_" + f][b])
+        for i, v in enumerate(d["prior_x0"]): p.x0[i] = float(v)
+        for i, v in enumerate(d["prior_r0"]): p.linearized_residuals[i] = float(v)
+        J = np.asarray(d["prior_J0"]).reshape(-1)
+        for i, v in enumerate(J): p.linearized_jacobians[i] = float(v)
+        w.prior = p
+    return w
+
+
+def main():
+    orc = Oracle()
+    marg = lambda win, flag: orc.marginalize(win, flag)
+    cases = {
+        "small_noprior": uvs.synth.make_window(101, n_points=40, n_lines=10, n_tagged=8),
+        "small_prior": uvs.synth.make_window(102, n_points=40, n_lines=10, n_tagged=8, with_prior=True, marginalize_fn=marg),
+        "points_only": uvs.synth.make_window(103, n_points=30, n_lines=0, n_tagged=0),
+    }
+    for name, w in cases.items():
+        st, rep = orc.solve(w)
+        ev = orc.evaluate(w, robust=True)
+        d = window_to_dict(w)
+        k = rep.num_iterations + 1
+        d.update(out_pose=st.pose, out_speedbias=st.speedbias, out_inv_depth=st.inv_depth, out_line_orth=st.line_orth,
+                 out_cost=np.array(rep.cost[:k]), out_radius=np.array(rep.radius[:k]), out_accepted=np.array(rep.accepted[:k]),
+                 out_final_cost=np.array(rep.final_cost), out_termination=np.array(rep.termination),
+                 ev_cost=np.array(ev.cost), ev_pt_r=ev.pt_r, ev_ln_r=ev.ln_r, ev_vp_r=ev.vp_r, ev_imu_r=ev.imu_r,
+                 ev_pt_J0=ev.pt_J[:4], ev_ln_J0=ev.ln_J[:4], ev_vp_J0=ev.vp_J[:4], ev_imu_J0=ev.imu_J[:1])
+        if w.prior is not None:
+            nxt = orc.marginalize(w.with_state(st), 0)
+            d.update(marg_n=np.array(nxt.n), marg_A=nxt.J0().T @ nxt.J0(), marg_b=nxt.J0().T @ nxt.r0())
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **d)
+        print(name, "iters", rep.num_iterations, "cost", rep.initial_cost, "->", rep.final_cost)
+
+
+if __name__ == "__main__":
+    main()

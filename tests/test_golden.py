@@ -1,0 +1,67 @@
+"""Committed golden fixtures (tests/golden/*.npz, made by tests/golden/make_golden.py with the CPU oracle).
+
+CPU leg: the oracle still reproduces them (regression pin).  GPU leg: the HIP solver reproduces them through the C ABI
+without anything from /root/reference or the oracle library being needed at run time for the comparison itself.
+"""
+import glob
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+from helpers import uvs, abi, pose_deltas
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+spec = importlib.util.spec_from_file_location("make_golden", os.path.join(HERE, "golden", "make_golden.py"))
+mg = importlib.util.module_from_spec(spec); spec.loader.exec_module(mg)
+CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(HERE, "golden", "*.npz")))
+
+
+def load(name):
+    d = dict(np.load(os.path.join(HERE, "golden", name + ".npz")))
+    return d, mg.dict_to_window(d)
+
+
+def test_fixtures_exist():
+    assert set(CASES) >= {"small_noprior", "small_prior", "points_only"}
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_reproduces_golden(oracle, name):
+    d, w = load(name)
+    st, rep = oracle.solve(w)
+    k = rep.num_iterations + 1
+    assert k == len(d["out_cost"]) and int(d["out_termination"]) == rep.termination
+    assert list(rep.accepted[:k]) == list(d["out_accepted"])
+    assert np.allclose(np.array(rep.cost[:k]), d["out_cost"], rtol=1e-9)
+    dp, da = pose_deltas(st.pose, d["out_pose"])
+    assert dp < 1e-8 and da < 1e-7
+    ev = oracle.evaluate(w, robust=True)
+    assert np.allclose(ev.pt_r, d["ev_pt_r"], rtol=1e-10, atol=1e-10) and np.allclose(ev.imu_r, d["ev_imu_r"], rtol=1e-9, atol=1e-7)
+    assert np.allclose(ev.ln_J[:4], d["ev_ln_J0"], rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_hip_solver_reproduces_golden(gpu_api, name):
+    d, w = load(name)
+    s = gpu_api.Solver(max_batch=4)
+    st, rep = s.solve(w)
+    ev = s.evaluate(w, robust=True)
+    k = rep.num_iterations + 1
+    assert rep.status == 0 and k == len(d["out_cost"]) and list(rep.accepted[:k]) == list(d["out_accepted"])
+    assert abs(rep.final_cost - float(d["out_final_cost"])) <= 1e-6 * float(d["out_final_cost"])
+    dp, da = pose_deltas(st.pose, d["out_pose"])
+    assert dp < 1e-4 and da < 1e-4                      # north_star tolerance: 1e-4 m / 1e-4 rad
+    assert np.abs(st.speedbias - d["out_speedbias"]).max() < 1e-4
+    assert np.abs(st.inv_depth - d["out_inv_depth"]).max() < 1e-4 and (len(d["out_line_orth"]) == 0 or np.abs(st.line_orth - d["out_line_orth"]).max() < 1e-4)
+    assert abs(ev.cost - float(d["ev_cost"])) <= 1e-9 * float(d["ev_cost"])
+    assert np.allclose(ev.pt_r, d["ev_pt_r"], rtol=1e-9, atol=1e-9) and np.allclose(ev.imu_r, d["ev_imu_r"], rtol=1e-8, atol=1e-6)
+    if "marg_n" in d:                                   # marginalization: compare the information form (J0 itself is sign/order ambiguous)
+        p = s.marginalize(w.with_state(st), 0)
+        assert p.n == int(d["marg_n"])
+        A = p.J0().T @ p.J0(); b = p.J0().T @ p.r0()
+        assert np.abs(A - d["marg_A"]).max() <= 1e-6 * np.abs(d["marg_A"]).max()
+        assert np.abs(b - d["marg_b"]).max() <= 1e-6 * max(1.0, np.abs(d["marg_b"]).max())
+    s.close()

@@ -243,7 +243,7 @@ def _cam(P, Q, ex):
 
 
 def _build(rng, Ps, Qs, Vs, ba, bg, blocks, ex, first, n_points, n_lines, n_tagged, pt_track, ln_track, noise, perturb,
-           pixel_sigma, pt_start_mod, ln_start_mod, manhattan):
+           pixel_sigma, pt_start_mod, ln_start_mod, manhattan, long_tracks=0):
     """Window over frames first..first+10 of the simulated trajectory."""
     NF = abi.NUM_FRAMES
     sig = pixel_sigma / FOCAL_LENGTH if noise else 0.0
@@ -256,14 +256,17 @@ def _build(rng, Ps, Qs, Vs, ba, bg, blocks, ex, first, n_points, n_lines, n_tagg
     # ---- points
     pt_start_mod = pt_start_mod or (NF - pt_track + 1)
     inv_depth, lm, fi, fj, pi, pj = [], [], [], [], [], []
-    for k in range(n_points):
-        s = k % pt_start_mod
+    for k in range(n_points + long_tracks):
+        # the last `long_tracks` landmarks are anchored at frame 0 and tracked through the whole window: they are what
+        # makes the marginalization prior of the NEXT window span Pose[0..9] (n = 75), as in a real VINS window
+        trk = pt_track if k < n_points else NF
+        s = k % pt_start_mod if k < n_points else 0
         for _ in range(100):
             xy = np.array([rng.uniform(-0.6, 0.6), rng.uniform(-0.4, 0.4)]); depth = rng.uniform(2.0, 10.0)
             Rc, tc = cams[s]
             X = Rc @ (depth * np.array([xy[0], xy[1], 1.0])) + tc
             obs, ok = [], True
-            for f in range(s, s + pt_track):
+            for f in range(s, s + trk):
                 Rf, tf = cams[f]
                 pc = Rf.T @ (X - tf)
                 if pc[2] < 0.2: ok = False; break
@@ -272,7 +275,7 @@ def _build(rng, Ps, Qs, Vs, ba, bg, blocks, ex, first, n_points, n_lines, n_tagg
         else:
             raise _Regenerate()
         inv_depth.append(1.0 / depth)
-        for o in range(1, pt_track):
+        for o in range(1, trk):
             lm.append(k); fi.append(s); fj.append(s + o); pi.append(obs[0]); pj.append(obs[o])
     # ---- lines
     ln_start_mod = ln_start_mod or (NF - ln_track + 1)
@@ -354,7 +357,8 @@ def _make(rng, n_points, n_lines, n_tagged, pt_track, ln_track, noise, perturb, 
         if marginalize_fn is None:
             raise ValueError("with_prior=True needs marginalize_fn")
         for first in range(n_before):
-            prev = _build(rng, Ps, Qs, Vs, ba, bg, blocks, ex, first, *args, perturb, pixel_sigma, pt_start_mod, ln_start_mod, manhattan)
+            prev = _build(rng, Ps, Qs, Vs, ba, bg, blocks, ex, first, *args, perturb, pixel_sigma, pt_start_mod, ln_start_mod, manhattan,
+                          long_tracks=12)
             if perturb:   # the previous estimate is closer to truth than a fresh initial guess
                 t = prev.truth
                 prev.pose[:, :3] = t["pose"][:, :3] + 0.3 * (prev.pose[:, :3] - t["pose"][:, :3])
