@@ -1,0 +1,36 @@
+"""Turns the rocprofv3 CSVs under gpurun_out/ into the small summaries committed under profiles/.
+
+Collected on MI355X with (each PMC group in its own pass, per MI355X_MICROARCH.md):
+  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_kt -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace ...   rocprofv3 --pmc WRITE_SIZE --kernel-trace ...   rocprofv3 --pmc SQ_... --kernel-trace ...
+"""
+import collections, csv, glob, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+out = {}
+rows = list(csv.DictReader(open(glob.glob(f"{ROOT}/gpurun_out/prof_kt/runc/*_kernel_trace.csv")[0])))
+dur = lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+big = [dur(r) for r in rows if "k_solve" in r["Kernel_Name"] and int(r["Grid_Size_X"]) > 512]
+one = [dur(r) for r in rows if "k_solve" in r["Kernel_Name"] and int(r["Grid_Size_X"]) == 512]
+out.update(k_solve_batch_launches=len(big), k_solve_batch_avg_ms=sum(big) / len(big), k_solve_batch_min_ms=min(big), k_solve_batch_max_ms=max(big),
+           k_solve_single_window_avg_ms=sum(one) / max(len(one), 1))
+for name in ("prof_fetch", "prof_write", "prof_sq"):
+    fs = glob.glob(f"{ROOT}/gpurun_out/{name}/runc/*_counter_collection.csv")
+    if not fs: continue
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(fs[0])):
+        if "k_solve" in r["Kernel_Name"] and int(r["Grid_Size"]) > 512:
+            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            out.update(vgpr=r["VGPR_Count"], sgpr=r["SGPR_Count"], lds_block_size=r["LDS_Block_Size"], scratch_size=r["Scratch_Size"], grid=r["Grid_Size"])
+    for k, v in agg.items():
+        out[k + "_per_launch_mean"] = sum(v) / len(v)
+# rocprofv3 FETCH_SIZE / WRITE_SIZE are KiB: hbm_bytes = (FETCH_SIZE + WRITE_SIZE) * 1024 (MI355X_MICROARCH.md, HBM section).  The guide's x2 correction of
+# FETCH_SIZE is calibrated for 16 B/lane streaming reads only; this kernel issues mostly 8-byte loads, for which the guide has no calibration, so the
+# uncorrected figure is reported together with the x2 upper bound.
+if "FETCH_SIZE_per_launch_mean" in out:
+    out["hbm_bytes_per_launch"] = (out["FETCH_SIZE_per_launch_mean"] + out["WRITE_SIZE_per_launch_mean"]) * 1024
+    out["hbm_bytes_per_launch_fetch_x2"] = (2 * out["FETCH_SIZE_per_launch_mean"] + out["WRITE_SIZE_per_launch_mean"]) * 1024
+json.dump(out, open(f"{ROOT}/profiles/{tag}_pmc_summary.json", "w"), indent=1)
+if "hbm_bytes_per_launch" in out:
+    json.dump({"hbm_bytes_per_launch": out["hbm_bytes_per_launch"], "source": f"profiles/{tag}_pmc_summary.json"}, open(f"{ROOT}/profiles/pmc_traffic.json", "w"))
+print(json.dumps(out, indent=1))
