@@ -380,9 +380,8 @@ static constexpr int BLOCKS_PER_WAVE = (UVS_NBLK + NW - 1) / NW;   // 9
 // Branch-free inner loops: every operand is addressed as S0[scalar(entry) + lane constant] (integer selects only --
 // selecting between POINTERS makes the compiler fall back to flat loads and scratch), list entries are decoded on the
 // scalar unit, and several entries are in flight at a time so that LDS latency is paid per group, not per entry.
-UVS_DEV void gather_points(const int* wblk, const int* lists, const double* S0, int oE, int oEI, int oX, double* acc) {
+UVS_DEV void gather_points(const int* wb, const int* lists, const double* S0, int oE, int oEI, int oX, double* acc) {
     const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int role = lane < 36 ? 0 : lane < 42 ? 1 : lane < 48 ? 2 : 3;
     const int a = role == 0 ? lane / 6 : role == 1 ? lane - 36 : role == 2 ? lane - 42 : 0;
     const int bb = role == 0 ? lane - 6 * (lane / 6) : 0;
@@ -394,9 +393,9 @@ UVS_DEV void gather_points(const int* wblk, const int* lists, const double* S0, 
     const int* ent = lists + 2 * (UVS_NBLK + 1);
 #pragma unroll
     for (int q = 0; q < BLOCKS_PER_WAVE; ++q) {
-        const int b = wblk[wv * BLOCKS_PER_WAVE + q];      // host-balanced block -> wave assignment (-1 = none)
-        if (b >= 0) {
-            const bool diag = c_blk_fa[b] == c_blk_fb[b];
+        if (wb[q] >= 0) {                                  // host-balanced block -> wave assignment (-1 = none), bit 8 = diagonal block
+            const int b = wb[q] & 255;
+            const bool diag = (wb[q] >> 8) != 0;
             const double ms = (r0 || (diag && r1)) ? 1.0 : 0.0;            // Schur-term mask
             const double md = (r0 || (diag && role < 3)) ? 1.0 : 0.0;      // direct-term mask
             double s = 0.0;
@@ -405,7 +404,7 @@ UVS_DEV void gather_points(const int* wblk, const int* lists, const double* S0, 
                 const int mine = (base + lane < e1) ? ent[base + lane] : 0;
                 const int n = min(64, e1 - base);
                 int i = 0;
-                for (; i + 8 <= n; i += 8) {
+                for (; i + 8 <= n; i += 8) {            // 8 entries in flight
                     double v1[8], v2[8];
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
@@ -457,9 +456,8 @@ UVS_DEV void gather_points(const int* wblk, const int* lists, const double* S0, 
     }
 }
 
-UVS_DEV void gather_lines(const int* wblk, const int* lists, const double* S0, int oE, int oY, int oX, double* acc) {
+UVS_DEV void gather_lines(const int* wb, const int* lists, const double* S0, int oE, int oY, int oX, double* acc) {
     const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int role = lane < 36 ? 0 : lane < 42 ? 1 : lane < 48 ? 2 : 3;
     const int a = role == 0 ? lane / 6 : role == 1 ? lane - 36 : role == 2 ? lane - 42 : 0;
     const int bb = role == 0 ? lane - 6 * (lane / 6) : 0;
@@ -471,9 +469,9 @@ UVS_DEV void gather_lines(const int* wblk, const int* lists, const double* S0, i
     const int* ent = lists + 2 * (UVS_NBLK + 1);
 #pragma unroll
     for (int q = 0; q < BLOCKS_PER_WAVE; ++q) {
-        const int b = wblk[wv * BLOCKS_PER_WAVE + q];      // host-balanced block -> wave assignment (-1 = none)
-        if (b >= 0) {
-            const bool diag = c_blk_fa[b] == c_blk_fb[b];
+        if (wb[q] >= 0) {
+            const int b = wb[q] & 255;
+            const bool diag = (wb[q] >> 8) != 0;
             const double ms = (r0 || (diag && r1)) ? 1.0 : 0.0;
             const double md = (r0 || (diag && role < 3)) ? 1.0 : 0.0;
             double s = 0.0;
@@ -535,8 +533,9 @@ UVS_DEV void linearize(const Ctx& c, const double* x, const double* invd, const 
     const double* RF = sh + L_RF; const double* ric = sh + L_EX; const double* tic = sh + L_EX + 9;
     double cost = 0.0, gmax_lm = 0.0;
     double acc[BLOCKS_PER_WAVE];
+    int wb[BLOCKS_PER_WAVE];       // this wave's pose blocks (wave-uniform => SGPRs), fetched once per linearization
 #pragma unroll
-    for (int q = 0; q < BLOCKS_PER_WAVE; ++q) acc[q] = 0.0;
+    for (int q = 0; q < BLOCKS_PER_WAVE; ++q) { acc[q] = 0.0; wb[q] = __builtin_amdgcn_readfirstlane(c.bi[h.i_wblk + (tid >> 6) * BLOCKS_PER_WAVE + q]); }
 
     UVS_PROF(c, P_MISC);
     stage_rotations(c, x);
@@ -553,11 +552,12 @@ UVS_DEV void linearize(const Ctx& c, const double* x, const double* invd, const 
             imu_raw(blk, blk + UVS_IMU_JAC, c.o.G, x + 7 * fi, x + 77 + 9 * fi, x + 7 * (fi + 1), x + 77 + 9 * (fi + 1), r, IM + 930 * tid);
             for (int i = 0; i < 15; ++i) IM[930 * tid + 450 + i] = r[i];
         }
+        for (int t = tid; t < h.n_imu * 225; t += NT) { const int b = t / 225; IM[9300 + t] = c.bd[h.d_imu + (size_t)b * UVS_IMU_STRIDE + UVS_IMU_W + (t - 225 * b)]; }
         __syncthreads();
         for (int t = tid; t < h.n_imu * 465; t += NT) {      // whitening: W upper triangular (imu_factor.h:64-66)
             const int b = t / 465, e = t - b * 465;
             if (c.bi[h.i_imu + 2 * b + 1]) continue;
-            const double* W = c.bd + h.d_imu + (size_t)b * UVS_IMU_STRIDE + UVS_IMU_W;
+            const double* W = IM + 9300 + 225 * b;          // whitening matrices staged in LDS above
             const double* raw = IM + 930 * b;
             if (e < 450) { const int r = e / 30, cc = e - r * 30; double s = 0.0; for (int k = r; k < 15; ++k) s += W[r * 15 + k] * raw[k * 30 + cc]; IM[930 * b + 465 + e] = s; }
             else { const int r = e - 450; double s = 0.0; for (int k = r; k < 15; ++k) s += W[r * 15 + k] * raw[450 + k]; IM[930 * b + 465 + 450 + r] = s; cost += 0.5 * s * s; }
@@ -655,7 +655,7 @@ UVS_DEV void linearize(const Ctx& c, const double* x, const double* invd, const 
             __syncthreads();
             UVS_PROF(c, P_LMPREP);
             const long long tg0_ = clock64();
-            gather_points(c.bi + h.i_wblk, lists, rec, (int)(Eb - rec), (int)(EIb - rec), (int)(Xb - rec), acc);
+            gather_points(wb, lists, rec, (int)(Eb - rec), (int)(EIb - rec), (int)(Xb - rec), acc);
             if (c.o.debug && (tid & 63) == 0) sh[L_WPROF + (tid >> 6)] += (double)(clock64() - tg0_);
         } else {
             const int* beg = c.bi + h.i_ln_beg;
@@ -769,7 +769,7 @@ UVS_DEV void linearize(const Ctx& c, const double* x, const double* invd, const 
             __syncthreads();
             UVS_PROF(c, P_LMPREP);
             const long long tg0_ = clock64();
-            gather_lines(c.bi + h.i_wblk, lists, rec, (int)(Eb - rec), (int)(Yb - rec), (int)(Xb - rec), acc);
+            gather_lines(wb, lists, rec, (int)(Eb - rec), (int)(Yb - rec), (int)(Xb - rec), acc);
             if (c.o.debug && (tid & 63) == 0) sh[L_WPROF + (tid >> 6)] += (double)(clock64() - tg0_);
         }
     }
@@ -786,8 +786,8 @@ UVS_DEV void linearize(const Ctx& c, const double* x, const double* invd, const 
         const int bb = role == 0 ? lane - 6 * (lane / 6) : 0;
 #pragma unroll
         for (int q = 0; q < BLOCKS_PER_WAVE; ++q) {
-            const int b = c.bi[h.i_wblk + wv * BLOCKS_PER_WAVE + q];
-            if (b >= 0) {
+            if (wb[q] >= 0) {
+                const int b = wb[q] & 255;
                 const int fa = c_blk_fa[b], fb = c_blk_fb[b];
                 if (role == 0) { if (fa != fb || a >= bb) sh[L_S + sidx(16 * fa + a, 16 * fb + bb)] = acc[q]; }
                 else if (fa == fb && role == 1) sh[L_G + 16 * fa + a] = acc[q];
@@ -1041,21 +1041,36 @@ __global__ __launch_bounds__(NT) void k_solve(char* blobs, const long long* blob
     double* invd[2] = {c.ws + h.w_invd0, c.ws + h.w_invd1};
     double* line[2] = {c.ws + h.w_line0, c.ws + h.w_line1};
     double radius = o.r0, decr = 2.0;
-    linearize(c, sh + L_X, invd[0], line[0], true, radius);
-    const double xn2 = ambient_sqnorm(c, sh + L_X, invd[0], line[0]);
-    double cost = sh[L_CTRL + C_COST], gmax = sh[L_CTRL + C_GMAX], x_norm = sqrt(xn2);
+    double cost = 0.0, gmax = 0.0, x_norm = 0.0;
     int it = 0, invalid = 0, nsucc = 0, term = UVS_TERM_NO_CONVERGENCE, status = UVS_OK;
-    if (tid == 0) { rep->initial_cost = cost; rep->cost[0] = cost; rep->radius[0] = radius; rep->gradient_max_norm[0] = gmax; rep->accepted[0] = 1; }
-    bool relin = false;     // the LDS system is stale (radius changed after a rejected / invalid step)
-    if (!isfinite(cost)) { term = UVS_TERM_NUMERIC_FAILURE; status = UVS_ERR_NUMERIC; }
-    else if (gmax <= o.gtol) term = UVS_TERM_GRADIENT_TOL;
-    else while (true) {
+    // ONE linearize() call site (the kernel is one big inlined body; a second copy doubles the instruction footprint):
+    // need_lin is raised at start, after an accepted step (new point) and after a rejected / invalid step (new radius).
+    bool need_lin = true, first = true;
+    int pending = 0;          // trace slot whose cost / gradient norm the next linearization fills in
+    while (true) {
+        if (it >= o.max_it && !first) { term = UVS_TERM_NO_CONVERGENCE; break; }
+        if (need_lin) {
+            linearize(c, sh + L_X, invd[cur], line[cur], first, radius);
+            need_lin = false;
+            const double lc = sh[L_CTRL + C_COST];
+            gmax = sh[L_CTRL + C_GMAX];
+            if (first) {
+                const double xn2 = ambient_sqnorm(c, sh + L_X, invd[0], line[0]);
+                x_norm = sqrt(xn2); cost = lc; first = false;
+                if (tid == 0) { rep->initial_cost = cost; rep->cost[0] = cost; rep->radius[0] = radius; rep->gradient_max_norm[0] = gmax; rep->accepted[0] = 1; }
+                if (!isfinite(cost)) { term = UVS_TERM_NUMERIC_FAILURE; status = UVS_ERR_NUMERIC; break; }
+            } else if (pending > 0) {           // re-evaluation after an accepted step (HandleSuccessfulStep)
+                cost = lc;
+                if (tid == 0) { rep->cost[pending] = cost; rep->gradient_max_norm[pending] = gmax; }
+            }
+            pending = 0;
+        }
+        // FinalizeIterationAndCheckIfMinimizerCanContinue
         if (it >= o.max_it) { term = UVS_TERM_NO_CONVERGENCE; break; }
         if (gmax <= o.gtol) { term = UVS_TERM_GRADIENT_TOL; break; }
         if (radius <= o.rmin) { term = UVS_TERM_MIN_RADIUS; break; }
         ++it;
         const int ti = it < UVS_MAX_ITER ? it : UVS_MAX_ITER;
-        if (relin) { linearize(c, sh + L_X, invd[cur], line[cur], false, radius); relin = false; }
         // ---- step: (S) y = -g
         if (tid < UVS_RD) sh[L_DLT + tid] = -sh[L_G + tid];
         if (o.debug && it == 1 && dbg.S) {
@@ -1078,9 +1093,9 @@ __global__ __launch_bounds__(NT) void k_solve(char* blobs, const long long* blob
         }
         if (!isfinite(mcc) || !isfinite(step2)) ok = false;
         if (tid == 0) rep->model_cost_change[ti] = mcc;
-        if (!ok || !(mcc > 0.0)) {    // invalid step
+        if (!ok || !(mcc > 0.0)) {    // invalid step (HandleInvalidStep)
             ++invalid;
-            radius = radius / decr; decr *= 2.0; relin = true;
+            radius = radius / decr; decr *= 2.0; need_lin = true;
             if (tid == 0) { rep->accepted[ti] = -1; rep->cost[ti] = cost; rep->candidate_cost[ti] = cost; rep->radius[ti] = radius; rep->gradient_max_norm[ti] = gmax; }
             if (invalid >= o.max_invalid) { term = UVS_TERM_INVALID_STEPS; break; }
             continue;
@@ -1105,16 +1120,8 @@ __global__ __launch_bounds__(NT) void k_solve(char* blobs, const long long* blob
         bool stop = false;
         if (step_norm <= o.ptol * (x_norm + o.ptol)) { term = UVS_TERM_PARAMETER_TOL; stop = true; }
         else if (fabs(cost - cand) <= o.ftol * cost) { term = UVS_TERM_FUNCTION_TOL; stop = true; }
-        if (stop) {
-            if (o.keep_cand && successful) {
-                __syncthreads();
-                if (tid < 184) sh[L_X + tid] = sh[L_XC + tid];
-                cur ^= 1; cost = cand; ++nsucc;
-                if (tid == 0) { rep->cost[ti] = cost; rep->accepted[ti] = 1; }
-            }
-            break;
-        }
-        if (successful) {
+        if (stop && !(o.keep_cand && successful)) break;
+        if (successful) {             // HandleSuccessfulStep: x <- x_c; the re-linearization happens at the loop top (skipped when we stop)
             __syncthreads();
             if (tid < 184) sh[L_X + tid] = sh[L_XC + tid];
             cur ^= 1; ++nsucc;
@@ -1122,15 +1129,14 @@ __global__ __launch_bounds__(NT) void k_solve(char* blobs, const long long* blob
             radius = radius / fmax(1.0 / 3.0, 1.0 - pow(2.0 * rel - 1.0, 3.0));
             radius = fmin(o.rmax, radius);
             decr = 2.0;
-            __syncthreads();
-            linearize(c, sh + L_X, invd[cur], line[cur], false, radius);
-            cost = sh[L_CTRL + C_COST]; gmax = sh[L_CTRL + C_GMAX];
-            if (tid == 0) rep->accepted[ti] = 1;
-        } else {
-            radius = radius / decr; decr *= 2.0; relin = true;
-            if (tid == 0) rep->accepted[ti] = 0;
+            cost = cand;              // replaced by the linearization's own sum if another iteration follows (equal up to summation order)
+            need_lin = true; pending = ti;
+            if (tid == 0) { rep->accepted[ti] = 1; rep->cost[ti] = cost; rep->radius[ti] = radius; }
+            if (stop) break;
+        } else {                      // HandleUnsuccessfulStep
+            radius = radius / decr; decr *= 2.0; need_lin = true;
+            if (tid == 0) { rep->accepted[ti] = 0; rep->radius[ti] = radius; }
         }
-        if (tid == 0) { rep->cost[ti] = cost; rep->radius[ti] = radius; rep->gradient_max_norm[ti] = gmax; }
     }
     __syncthreads();
     UVS_PROF(c, P_MISC);

@@ -278,7 +278,9 @@ static int pack_window(const uvs_window* w, std::vector<char>& out, DevWin& hdr,
         for (int b : order) {
             int best = -1;
             for (int wv = 0; wv < NW; ++wv) if (cnt[wv] < BLOCKS_PER_WAVE && (best < 0 || load[wv] < load[best])) best = wv;
-            wblk[best * BLOCKS_PER_WAVE + cnt[best]++] = b; load[best] += blk_work[b] + 8;
+            const int bfa = (int)((std::sqrt(8.0 * b + 1.0) - 1.0) * 0.5 + 1e-9);     // b = fa(fa+1)/2 + fb
+            const bool isdiag = (b - bfa * (bfa + 1) / 2) == bfa;
+            wblk[best * BLOCKS_PER_WAVE + cnt[best]++] = b | (isdiag ? 256 : 0); load[best] += blk_work[b] + 8;
         }
     }
     h.n_chunks = (int)chunks.size() / 6;
