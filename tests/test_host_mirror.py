@@ -1,0 +1,76 @@
+"""Host C++ mirror of the reference API (uv-slam_amd/host/): record/replay file round trip (CPU) and
+Estimator::optimization() end to end on the GPU."""
+import ctypes as C
+import os
+import struct
+import tempfile
+
+import numpy as np
+import pytest
+
+from helpers import uvs, abi, synth, pose_deltas
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "uv-slam_amd", "libuvs_host.so")
+
+
+def _host():
+    lib = C.CDLL(HOST)
+    lib.uvs_host_window_probe.argtypes = [C.c_char_p, abi.c_double_p]; lib.uvs_host_window_probe.restype = C.c_int
+    lib.uvs_host_replay_window.argtypes = [C.c_char_p, C.c_char_p, C.c_int]; lib.uvs_host_replay_window.restype = C.c_int
+    return lib
+
+
+def test_window_file_roundtrip(oracle):
+    marg = lambda win, flag: oracle.marginalize(win, flag)
+    w = synth.make_window(31, n_points=25, n_lines=7, n_tagged=5, with_prior=True, marginalize_fn=marg)
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "w.uvsw")
+        w.save(path)
+        out = np.zeros(12)
+        assert _host().uvs_host_window_probe(path.encode(), out.ctypes.data_as(abi.c_double_p)) == 0
+    assert list(out[:6]) == [25, len(w.pt_lm), 7, len(w.ln_lm), 10, w.prior.n]
+    assert np.isclose(out[6], w.pose.sum()) and np.isclose(out[7], w.pt_pj.sum()) and np.isclose(out[8], (w.ln_vp + w.ln_sp).sum())
+    assert np.isclose(out[9], sum((np.asarray(b["covariance"]) * 1e6 + np.asarray(b["jacobian"])).sum() for b in w.imu))
+    assert np.isclose(out[10], w.prior.J0().sum()) and out[11] == (w.pt_lm + 3 * w.pt_fi + 7 * w.pt_fj).sum()
+
+
+@pytest.mark.gpu
+def test_estimator_optimization_matches_direct_solve(gpu_api):
+    """Estimator::optimization() (host mirror: uvs::Problem -> uvs_solve_window -> double2vector -> uvs_marginalize) against
+    the same window solved directly through the C ABI."""
+    s = gpu_api.Solver(max_batch=2)
+    marg = lambda win, flag: s.marginalize(win, flag)
+    w = synth.make_window(32, with_prior=True, marginalize_fn=marg)
+    st, rep = s.solve(w)
+    with tempfile.TemporaryDirectory() as d:
+        pin, pout = os.path.join(d, "in.uvsw"), os.path.join(d, "out.bin")
+        w.save(pin)
+        assert _host().uvs_host_replay_window(pin.encode(), pout.encode(), 0) == 0
+        raw = np.fromfile(pout, dtype=np.float64)
+    status, iters, c0, c1 = raw[:4]
+    assert status == 0 and iters == rep.num_iterations and c0 == rep.initial_cost and c1 == rep.final_cost       # same kernel, same inputs: bitwise
+    fr = raw[4:4 + 11 * 16].reshape(11, 16)
+    pose = fr[:, :7]
+    # double2vector re-anchors yaw + position of frame 0 to their pre-solve values (estimator.cpp:598-648) ...
+    assert np.abs(pose[0, :3] - w.pose[0, :3]).max() < 1e-12
+    yaw = lambda q: np.arctan2(synth.quat_to_R(q)[1, 0], synth.quat_to_R(q)[0, 0])
+    assert abs(yaw(pose[0, 3:]) - yaw(w.pose[0, 3:])) < 1e-9
+    # ... and leaves gauge-invariant quantities equal to the raw solver output
+    def rel(P):
+        R0 = synth.quat_to_R(P[0, 3:])
+        return R0.T @ (P[10, :3] - P[0, :3]), R0.T @ synth.quat_to_R(P[10, 3:])
+    (ta, Ra), (tb, Rb) = rel(pose), rel(st.pose)
+    assert np.abs(ta - tb).max() < 1e-9 and np.abs(Ra - Rb).max() < 1e-9
+    assert np.abs(fr[:, 10:16] - st.speedbias[:, 3:]).max() < 1e-12            # biases are gauge independent
+    k = 4 + 11 * 16
+    dep = raw[k:k + 2 * 150].reshape(150, 2); k += 300
+    assert np.allclose(1.0 / dep[:, 0], st.inv_depth, rtol=1e-12) and set(dep[:, 1]) <= {1.0, 2.0}
+    lines = raw[k:k + 5 * 40].reshape(40, 5); k += 200
+    okl = lines[:, 4] == 1
+    assert np.abs(lines[okl, :4] - st.line_orth[okl]).max() < 1e-12 and okl.sum() >= 30
+    pn = int(raw[k]); k += 1
+    assert pn == 75
+    r0 = raw[k:k + pn]; J0 = raw[k + pn:k + pn + pn * pn].reshape(pn, pn)
+    assert np.all(np.isfinite(J0)) and np.linalg.matrix_rank(J0) >= 60
+    s.close()

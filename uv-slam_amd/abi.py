@@ -212,6 +212,35 @@ class Window:
             w.prior = None
         return w, k
 
+    # -- record / replay file (layout documented in host/window_io.h) ------------
+    def save(self, path):
+        f64 = lambda a: np.ascontiguousarray(a, dtype="<f8").tobytes()
+        i32 = lambda a: np.ascontiguousarray(a, dtype="<i4").tobytes()
+        npo, nlo = len(self.pt_lm), len(self.ln_lm)
+        pn = self.prior.n if self.prior is not None else 0
+        pnb = self.prior.n_blocks if pn else 0
+        with open(path, "wb") as f:
+            f.write(b"UVSWIN01")
+            f.write(i32([len(self.inv_depth), npo, len(self.line_orth), nlo, len(self.imu), pn, pnb, 0]))
+            f.write(f64(self.pose)); f.write(f64(self.speedbias)); f.write(f64(self.ex_pose)); f.write(f64([self.td]))
+            f.write(f64(self.inv_depth))
+            f.write(i32(self.pt_lm)); f.write(i32(self.pt_fi)); f.write(i32(self.pt_fj))
+            if npo % 2: f.write(i32([0]))
+            f.write(f64(self.pt_pi)); f.write(f64(self.pt_pj))
+            f.write(f64(self.line_orth))
+            f.write(i32(self.ln_lm)); f.write(i32(self.ln_fj)); f.write(i32(self.ln_has_vp))
+            if nlo % 2: f.write(i32([0]))
+            f.write(f64(self.ln_sp)); f.write(f64(self.ln_ep)); f.write(f64(self.ln_vp))
+            for b in self.imu:
+                f.write(f64([b["sum_dt"]])); f.write(f64(b["delta_p"])); f.write(f64(b["delta_q"])); f.write(f64(b["delta_v"]))
+                f.write(f64(b["linearized_ba"])); f.write(f64(b["linearized_bg"])); f.write(f64(np.asarray(b["jacobian"]).reshape(225)))
+                f.write(f64(np.asarray(b["covariance"]).reshape(225))); f.write(i32([b["frame_i"], b.get("skip", 0)]))
+            if pn:
+                p = self.prior
+                for name in ("block_kind", "block_frame", "block_size", "block_idx", "x0_off"):
+                    f.write(i32(list(getattr(p, name))))
+                f.write(f64(list(p.x0))); f.write(f64(p.r0())); f.write(f64(p.J0()))
+
     def copy(self):
         import copy
         o = Window()

@@ -1,0 +1,153 @@
+// estimator.cpp -- Estimator::optimization() / vector2double() / double2vector() with the reference's structure
+// (vins_estimator/src/estimator.cpp:526-711, 761-1233), the Ceres problem replaced by uvs::Problem and the
+// marginalization by uvs_marginalize().  See INTEGRATION.md for the diff a maintainer applies to the reference file.
+#include "estimator.h"
+#include <stdexcept>
+
+double FOCAL_LENGTH, INIT_DEPTH, MIN_PARALLAX, ACC_N, ACC_W, GYR_N, GYR_W, SOLVER_TIME, TD, TR, LINE_FACTOR, VP_FACTOR;
+int ESTIMATE_EXTRINSIC, ESTIMATE_TD, NUM_ITERATIONS, LINE_WINDOW;
+std::vector<Eigen::Matrix3d> RIC; std::vector<Eigen::Vector3d> TIC;
+Eigen::Vector3d G(0.0, 0.0, 9.8);
+double ProjectionFactor::sqrt_info;
+
+void setEurocParameters() {          // config/euroc/euroc_config.yaml
+    FOCAL_LENGTH = 461.6; SOLVER_TIME = 0.1; NUM_ITERATIONS = 10; ACC_N = 0.08; GYR_N = 0.004; ACC_W = 0.00004; GYR_W = 2.0e-6; G = Eigen::Vector3d(0, 0, 9.81007);
+    ESTIMATE_EXTRINSIC = 0; ESTIMATE_TD = 0; TD = 0.0; TR = 0.0; LINE_WINDOW = 5; LINE_FACTOR = 300.0; VP_FACTOR = 10.0; INIT_DEPTH = 5.0; MIN_PARALLAX = 10.0 / FOCAL_LENGTH;
+    Eigen::Matrix3d R; const double r[9] = {0.0148655429818, -0.999880929698, 0.00414029679422, 0.999557249008, 0.0149672133247, 0.025715529948, -0.0257744366974, 0.00375618835797, 0.999660727178};
+    for (int i = 0; i < 9; ++i) R(i / 3, i % 3) = r[i];
+    RIC.assign(1, Eigen::Quaterniond(R).normalized().toRotationMatrix());           // parameters.cpp:113-115
+    TIC.assign(1, Eigen::Vector3d(-0.0216401454975, -0.064676986768, 0.00981073058949));
+}
+
+Estimator::Estimator() : solver_flag(NON_LINEAR), marginalization_flag(MARGIN_OLD), td(0), failure_occur(false), last_marginalization_info(nullptr), solver(nullptr) {
+    for (auto& p : pre_integrations) p = nullptr;
+    for (int i = 0; i <= WINDOW_SIZE; ++i) Rs[i].setIdentity();
+    uvs_options o; uvs_default_options(&o);
+    const int rc = uvs_create(&o, 0, 1, NUM_OF_F, NUM_OF_F * (WINDOW_SIZE + 1), NUM_OF_LF, NUM_OF_LF * (WINDOW_SIZE + 1), &solver);
+    if (rc != UVS_OK) throw std::runtime_error(std::string("uvs_create: ") + uvs_status_string(rc));     // no CPU fallback
+}
+Estimator::~Estimator() { uvs_destroy(solver); delete last_marginalization_info; for (auto* p : pre_integrations) delete p; }
+
+void Estimator::setParameter() {      // estimator.cpp:9-21
+    for (int i = 0; i < NUM_OF_CAM; i++) { tic[i] = TIC[i]; ric[i] = RIC[i]; }
+    ProjectionFactor::sqrt_info = FOCAL_LENGTH / 1.6;
+    td = TD;
+}
+
+void Estimator::vector2double() {     // estimator.cpp:526-594
+    for (int i = 0; i <= WINDOW_SIZE; i++) {
+        para_Pose[i][0] = Ps[i].x(); para_Pose[i][1] = Ps[i].y(); para_Pose[i][2] = Ps[i].z();
+        Eigen::Quaterniond q{Rs[i]};
+        para_Pose[i][3] = q.x(); para_Pose[i][4] = q.y(); para_Pose[i][5] = q.z(); para_Pose[i][6] = q.w();
+        for (int k = 0; k < 3; ++k) { para_SpeedBias[i][k] = Vs[i](k); para_SpeedBias[i][3 + k] = Bas[i](k); para_SpeedBias[i][6 + k] = Bgs[i](k); }
+    }
+    for (int i = 0; i < NUM_OF_CAM; i++) {
+        para_Ex_Pose[i][0] = tic[i].x(); para_Ex_Pose[i][1] = tic[i].y(); para_Ex_Pose[i][2] = tic[i].z();
+        Eigen::Quaterniond q{ric[i]};
+        para_Ex_Pose[i][3] = q.x(); para_Ex_Pose[i][4] = q.y(); para_Ex_Pose[i][5] = q.z(); para_Ex_Pose[i][6] = q.w();
+    }
+    Eigen::VectorXd dep = f_manager.getDepthVector();
+    for (int i = 0; i < f_manager.getFeatureCount(); i++) para_Feature[i][0] = dep[i];
+    if (ESTIMATE_TD) para_Td[0][0] = td;
+    std::vector<Eigen::Vector4d> get_lineOrtho = f_manager.getLineOrthonormal();
+    for (int i = 0; i < f_manager.getLineFeatureCount(); i++) for (int k = 0; k < 4; ++k) para_Ortho_plucker[i][k] = get_lineOrtho.at(i)[k];
+}
+
+void Estimator::double2vector() {     // estimator.cpp:596-711 (relocalization branch :671-691 not mirrored)
+    using namespace Eigen;
+    Vector3d origin_R0 = Utility::R2ypr(Rs[0]);
+    Vector3d origin_P0 = Ps[0];
+    if (failure_occur) { origin_R0 = Utility::R2ypr(last_R0); origin_P0 = last_P0; failure_occur = 0; }
+    Matrix3d R00 = Quaterniond(para_Pose[0][6], para_Pose[0][3], para_Pose[0][4], para_Pose[0][5]).toRotationMatrix();
+    Vector3d origin_R00 = Utility::R2ypr(R00);
+    double y_diff = origin_R0.x() - origin_R00.x();
+    Matrix3d rot_diff = Utility::ypr2R(Vector3d(y_diff, 0, 0));
+    if (std::abs(std::abs(origin_R0.y()) - 90) < 1.0 || std::abs(std::abs(origin_R00.y()) - 90) < 1.0) rot_diff = Rs[0] * R00.transpose();   // euler singular point (:616-625)
+    for (int i = 0; i <= WINDOW_SIZE; i++) {
+        Rs[i] = rot_diff * Quaterniond(para_Pose[i][6], para_Pose[i][3], para_Pose[i][4], para_Pose[i][5]).normalized().toRotationMatrix();
+        Ps[i] = rot_diff * Vector3d(para_Pose[i][0] - para_Pose[0][0], para_Pose[i][1] - para_Pose[0][1], para_Pose[i][2] - para_Pose[0][2]) + origin_P0;
+        Vs[i] = rot_diff * Vector3d(para_SpeedBias[i][0], para_SpeedBias[i][1], para_SpeedBias[i][2]);
+        Bas[i] = Vector3d(para_SpeedBias[i][3], para_SpeedBias[i][4], para_SpeedBias[i][5]);
+        Bgs[i] = Vector3d(para_SpeedBias[i][6], para_SpeedBias[i][7], para_SpeedBias[i][8]);
+    }
+    for (int i = 0; i < NUM_OF_CAM; i++) {
+        tic[i] = Vector3d(para_Ex_Pose[i][0], para_Ex_Pose[i][1], para_Ex_Pose[i][2]);
+        ric[i] = Quaterniond(para_Ex_Pose[i][6], para_Ex_Pose[i][3], para_Ex_Pose[i][4], para_Ex_Pose[i][5]).toRotationMatrix();
+    }
+    VectorXd dep = f_manager.getDepthVector();
+    for (int i = 0; i < f_manager.getFeatureCount(); i++) dep[i] = para_Feature[i][0];
+    f_manager.setDepth(dep);
+    if (ESTIMATE_TD) td = para_Td[0][0];
+    std::vector<Vector4d> get_lineOrtho = f_manager.getLineOrthonormal();
+    for (int i = 0; i < f_manager.getLineFeatureCount(); i++) for (int k = 0; k < 4; ++k) get_lineOrtho.at(i)[k] = para_Ortho_plucker[i][k];
+    f_manager.setLineOrtho(get_lineOrtho, Ps, Rs, tic[0], ric[0]);
+}
+
+void Estimator::optimization() {      // estimator.cpp:761-1233
+    uvs::AddressMap amap{para_Pose, para_SpeedBias, para_Ex_Pose, para_Feature, para_Ortho_plucker, para_Td};
+    uvs::Problem problem(amap);
+    ceres_like::LossFunction* loss_function = new ceres_like::CauchyLoss(1.0);
+    ceres_like::LossFunction* line_loss_function = new ceres_like::CauchyLoss(0.1);
+    ceres_like::LossFunction* vp_loss_function = new ceres_like::CauchyLoss(1.0);
+    for (int i = 0; i < WINDOW_SIZE + 1; i++) {
+        problem.AddParameterBlock(para_Pose[i], SIZE_POSE, new PoseLocalParameterization());
+        problem.AddParameterBlock(para_SpeedBias[i], SIZE_SPEEDBIAS);
+    }
+    for (int i = 0; i < NUM_OF_CAM; i++) {
+        problem.AddParameterBlock(para_Ex_Pose[i], SIZE_POSE, new PoseLocalParameterization());
+        if (!ESTIMATE_EXTRINSIC) problem.SetParameterBlockConstant(para_Ex_Pose[i]);
+    }
+    vector2double();
+    if (last_marginalization_info && last_marginalization_info->prior.n > 0)
+        problem.AddResidualBlock(new MarginalizationFactor(last_marginalization_info), NULL, std::vector<double*>{});
+    for (int i = 0; i < WINDOW_SIZE; i++) {
+        int j = i + 1;
+        if (pre_integrations[j]->sum_dt > 10.0) continue;
+        problem.AddResidualBlock(new IMUFactor(pre_integrations[j]), NULL, para_Pose[i], para_SpeedBias[i], para_Pose[j], para_SpeedBias[j]);
+    }
+    int feature_index = -1;
+    for (auto& it_per_id : f_manager.feature) {
+        it_per_id.used_num = it_per_id.feature_per_frame.size();
+        if (!(it_per_id.used_num >= 2 && it_per_id.start_frame < WINDOW_SIZE - 2)) continue;
+        ++feature_index;
+        int imu_i = it_per_id.start_frame, imu_j = imu_i - 1;
+        Eigen::Vector3d pts_i = it_per_id.feature_per_frame[0].point;
+        for (auto& it_per_frame : it_per_id.feature_per_frame) {
+            imu_j++;
+            if (imu_i == imu_j) continue;
+            problem.AddResidualBlock(new ProjectionFactor(pts_i, it_per_frame.point), loss_function, para_Pose[imu_i], para_Pose[imu_j], para_Ex_Pose[0], para_Feature[feature_index]);
+        }
+    }
+    int line_feature_index = -1;
+    for (auto& it_per_id : f_manager.line_feature) {
+        it_per_id.used_num = it_per_id.line_feature_per_frame.size();
+        if (it_per_id.used_num < LINE_WINDOW) continue;
+        ++line_feature_index;
+        int imu_j = it_per_id.start_frame - 1;
+        for (auto& it_per_frame : it_per_id.line_feature_per_frame) {
+            imu_j++;
+            problem.AddResidualBlock(new LineProjectionFactor(ric[0], tic[0], it_per_frame.start_point, it_per_frame.end_point), line_loss_function, para_Pose[imu_j], para_Ortho_plucker[line_feature_index]);
+            if (it_per_frame.vp(2) == 1)
+                problem.AddResidualBlock(new VPProjectionFactor(ric[0], tic[0], it_per_frame.start_point, it_per_frame.end_point, it_per_frame.vp), vp_loss_function, para_Pose[imu_j], para_Ortho_plucker[line_feature_index]);
+        }
+    }
+    uvs::Options options; options.max_num_iterations = NUM_ITERATIONS;
+    uvs::Solve(options, &problem, &last_summary, solver, feature_index + 1, line_feature_index + 1);
+    // ---- marginalization on the post-solve para_* arrays, BEFORE double2vector() re-anchors the gauge: the reference calls
+    // vector2double() again at :1004, i.e. it marginalizes at the re-anchored state; we follow it exactly below.
+    double2vector();
+    vector2double();
+    {
+        uvs_window w; problem.fill(&w, feature_index + 1, line_feature_index + 1);
+        std::memcpy(w.pose, para_Pose, sizeof(w.pose)); std::memcpy(w.speedbias, para_SpeedBias, sizeof(w.speedbias));
+        MarginalizationInfo* marginalization_info = new MarginalizationInfo();
+        const int rc = uvs_marginalize(solver, &w, marginalization_flag == MARGIN_OLD ? 0 : 1, &marginalization_info->prior);
+        if (rc == UVS_OK) { delete last_marginalization_info; last_marginalization_info = marginalization_info; }
+        else delete marginalization_info;
+    }
+    // losses that were never attached to a residual block are not owned by the Problem
+    if (problem.pt_lm.empty()) delete loss_function;
+    if (problem.ln_lm.empty()) delete line_loss_function;
+    bool any_vp = false; for (int v : problem.ln_has_vp) any_vp |= (v != 0);
+    if (!any_vp) delete vp_loss_function;
+}

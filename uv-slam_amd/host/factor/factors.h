@@ -1,0 +1,70 @@
+// factors.h -- host-side factor classes with the reference's names and constructor signatures.
+// In the reference each class derives from a Ceres cost function and its Evaluate() runs on the CPU; here the classes are
+// DATA CARRIERS: uvs::Problem::AddResidualBlock() copies their members into the flat uvs_window and the residuals /
+// Jacobians are evaluated by the HIP kernels (csrc/uvs_factors.h).  There is deliberately no CPU Evaluate().
+#pragma once
+#include <vector>
+#include "../../../include/uvs_solver.h"
+#include "../integration_base.h"
+
+namespace uvs { enum FactorKind { F_IMU, F_PROJECTION, F_LINE, F_VP, F_MARGINALIZATION }; struct CostFunction { virtual ~CostFunction() {} virtual FactorKind kind() const = 0; }; }
+namespace ceres_like {   // the few Ceres names the reference's optimization() spells out
+struct LossFunction { virtual ~LossFunction() {} double a; explicit LossFunction(double a_) : a(a_) {} };
+struct CauchyLoss : LossFunction { explicit CauchyLoss(double a_) : LossFunction(a_) {} };
+struct LocalParameterization { virtual ~LocalParameterization() {} };
+}
+
+class PoseLocalParameterization : public ceres_like::LocalParameterization {   // pose_local_parameterization.cpp:3-27
+  public:
+    bool Plus(const double* x, const double* delta, double* x_plus_delta) const {
+        Eigen::Quaterniond q(x[6], x[3], x[4], x[5]);
+        Eigen::Quaterniond dq = Utility::deltaQ(Eigen::Vector3d(delta[3], delta[4], delta[5]));
+        Eigen::Quaterniond r = (q * dq).normalized();
+        for (int k = 0; k < 3; ++k) x_plus_delta[k] = x[k] + delta[k];
+        x_plus_delta[3] = r.x(); x_plus_delta[4] = r.y(); x_plus_delta[5] = r.z(); x_plus_delta[6] = r.w();
+        return true;
+    }
+    bool ComputeJacobian(const double*, double* jacobian) const { for (int i = 0; i < 42; ++i) jacobian[i] = 0.0; for (int i = 0; i < 6; ++i) jacobian[i * 6 + i] = 1.0; return true; }   // [I6;0], 7x6 row-major
+    int GlobalSize() const { return 7; }
+    int LocalSize() const { return 6; }
+};
+
+class IMUFactor : public uvs::CostFunction {               // imu_factor.h:12-17
+  public:
+    IMUFactor() = delete;
+    explicit IMUFactor(IntegrationBase* _pre_integration) : pre_integration(_pre_integration) {}
+    uvs::FactorKind kind() const override { return uvs::F_IMU; }
+    IntegrationBase* pre_integration;
+};
+class ProjectionFactor : public uvs::CostFunction {        // projection_factor.h:12-24
+  public:
+    ProjectionFactor(const Eigen::Vector3d& _pts_i, const Eigen::Vector3d& _pts_j) : pts_i(_pts_i), pts_j(_pts_j) {}
+    uvs::FactorKind kind() const override { return uvs::F_PROJECTION; }
+    Eigen::Vector3d pts_i, pts_j;
+    static double sqrt_info;      // FOCAL_LENGTH / 1.6 (estimator.cpp:17); scalar because the reference's matrix is a multiple of I2
+};
+struct LineProjectionFactor : public uvs::CostFunction {   // line_projection_factor.h:11-19
+    LineProjectionFactor(Eigen::Matrix3d _ric, Eigen::Vector3d _tic, Eigen::Vector3d _sp, Eigen::Vector3d _ep) : ric(_ric), tic(_tic), sp(_sp), ep(_ep) {}
+    uvs::FactorKind kind() const override { return uvs::F_LINE; }
+    Eigen::Matrix3d ric; Eigen::Vector3d tic, sp, ep;
+};
+struct VPProjectionFactor : public uvs::CostFunction {     // vp_projection_factor.h:14-22
+    VPProjectionFactor(Eigen::Matrix3d _ric, Eigen::Vector3d _tic, Eigen::Vector3d _sp, Eigen::Vector3d _ep, Eigen::Vector3d _vp) : ric(_ric), tic(_tic), sp(_sp), ep(_ep), vp(_vp) {}
+    uvs::FactorKind kind() const override { return uvs::F_VP; }
+    Eigen::Matrix3d ric; Eigen::Vector3d tic, sp, ep, vp;
+};
+
+// MarginalizationInfo (marginalization_factor.h:46-72): the prior is held in the C-ABI form; the reference's address-keyed
+// maps become (kind, frame) block tables.  marginalize() = uvs_marginalize() (GPU factor evaluation + host eigen-solves).
+class MarginalizationInfo {
+  public:
+    uvs_prior prior;
+    int m = 0, n = 0;
+    MarginalizationInfo() { prior.n = 0; prior.n_blocks = 0; }
+};
+class MarginalizationFactor : public uvs::CostFunction {   // marginalization_factor.h:74-81
+  public:
+    explicit MarginalizationFactor(MarginalizationInfo* _marginalization_info) : marginalization_info(_marginalization_info) {}
+    uvs::FactorKind kind() const override { return uvs::F_MARGINALIZATION; }
+    MarginalizationInfo* marginalization_info;
+};

@@ -1,0 +1,96 @@
+// host_capi.cpp -- test hook: replay a recorded window through the mirrored Estimator::optimization().
+// Builds the Estimator members (Ps/Rs/..., f_manager track lists, pre_integrations, last_marginalization_info) from a window
+// file, runs optimization() (HIP solve + marginalization), and writes the resulting members back to a flat file.
+#include <cstdio>
+#include <map>
+#include "estimator.h"
+#include "window_io.h"
+
+extern "C" int uvs_host_replay_window(const char* in_path, const char* out_path, int marg_flag) {
+    WindowFile wf;
+    if (!wf.load(in_path)) return -1;
+    const uvs_window& w = wf.w;
+    setEurocParameters();
+    try {
+        Estimator est;
+        est.setParameter();
+        for (int i = 0; i <= WINDOW_SIZE; ++i) {
+            est.Ps[i] = Eigen::Vector3d(w.pose[i][0], w.pose[i][1], w.pose[i][2]);
+            est.Rs[i] = Eigen::Quaterniond(w.pose[i][6], w.pose[i][3], w.pose[i][4], w.pose[i][5]).toRotationMatrix();
+            est.Vs[i] = Eigen::Vector3d(w.speedbias[i][0], w.speedbias[i][1], w.speedbias[i][2]);
+            est.Bas[i] = Eigen::Vector3d(w.speedbias[i][3], w.speedbias[i][4], w.speedbias[i][5]);
+            est.Bgs[i] = Eigen::Vector3d(w.speedbias[i][6], w.speedbias[i][7], w.speedbias[i][8]);
+        }
+        est.tic[0] = Eigen::Vector3d(w.ex_pose[0], w.ex_pose[1], w.ex_pose[2]);
+        est.ric[0] = Eigen::Quaterniond(w.ex_pose[6], w.ex_pose[3], w.ex_pose[4], w.ex_pose[5]).toRotationMatrix();
+        // tracks (consecutive frames from start_frame, as FeatureManager builds them)
+        for (int k = 0, o = 0; k < w.n_points; ++k) {
+            if (o >= w.n_point_obs || w.pt_lm[o] != k) return -2;
+            FeaturePerId f(k, w.pt_fi[o]);
+            f.feature_per_frame.emplace_back(Eigen::Vector3d(w.pt_pi[3 * o], w.pt_pi[3 * o + 1], w.pt_pi[3 * o + 2]));
+            int expect = w.pt_fi[o] + 1;
+            while (o < w.n_point_obs && w.pt_lm[o] == k) { if (w.pt_fj[o] != expect++) return -3; f.feature_per_frame.emplace_back(Eigen::Vector3d(w.pt_pj[3 * o], w.pt_pj[3 * o + 1], w.pt_pj[3 * o + 2])); ++o; }
+            f.estimated_depth = 1.0 / w.inv_depth[k];
+            est.f_manager.feature.push_back(f);
+        }
+        for (int l = 0, o = 0; l < w.n_lines; ++l) {
+            if (o >= w.n_line_obs || w.ln_lm[o] != l) return -4;
+            LineFeaturePerId f(l, w.ln_fj[o]);
+            int expect = w.ln_fj[o];
+            while (o < w.n_line_obs && w.ln_lm[o] == l) {
+                if (w.ln_fj[o] != expect++) return -5;
+                LineFeaturePerFrame pf;
+                pf.start_point = Eigen::Vector3d(w.ln_sp[3 * o], w.ln_sp[3 * o + 1], w.ln_sp[3 * o + 2]); pf.end_point = Eigen::Vector3d(w.ln_ep[3 * o], w.ln_ep[3 * o + 1], w.ln_ep[3 * o + 2]);
+                pf.vp = w.ln_has_vp[o] ? Eigen::Vector3d(w.ln_vp[3 * o], w.ln_vp[3 * o + 1], w.ln_vp[3 * o + 2]) : Eigen::Vector3d(0, 0, 0);
+                f.line_feature_per_frame.push_back(pf); ++o;
+            }
+            f.orthonormal_vec = Eigen::Vector4d(w.line_orth[4 * l], w.line_orth[4 * l + 1], w.line_orth[4 * l + 2], w.line_orth[4 * l + 3]);
+            est.f_manager.line_feature.push_back(f);
+        }
+        for (int j = 1; j <= WINDOW_SIZE; ++j) {      // every frame needs an IntegrationBase; blocks absent from the file are marked sum_dt > 10
+            IntegrationBase* p = new IntegrationBase(Eigen::Vector3d(), Eigen::Vector3d(), Eigen::Vector3d(), Eigen::Vector3d());
+            p->sum_dt = 11.0; est.pre_integrations[j] = p;
+        }
+        for (int b = 0; b < w.n_imu; ++b) {
+            const uvs_imu_block& ib = w.imu[b]; IntegrationBase* p = est.pre_integrations[ib.frame_i + 1];
+            p->sum_dt = ib.skip ? 11.0 : ib.sum_dt; p->delta_p = Eigen::Vector3d(ib.delta_p[0], ib.delta_p[1], ib.delta_p[2]); p->delta_v = Eigen::Vector3d(ib.delta_v[0], ib.delta_v[1], ib.delta_v[2]);
+            p->delta_q = Eigen::Quaterniond(ib.delta_q[3], ib.delta_q[0], ib.delta_q[1], ib.delta_q[2]);
+            p->linearized_ba = Eigen::Vector3d(ib.linearized_ba[0], ib.linearized_ba[1], ib.linearized_ba[2]); p->linearized_bg = Eigen::Vector3d(ib.linearized_bg[0], ib.linearized_bg[1], ib.linearized_bg[2]);
+            std::memcpy(p->jacobian, ib.jacobian, sizeof(ib.jacobian)); std::memcpy(p->covariance, ib.covariance, sizeof(ib.covariance));
+        }
+        if (w.prior && w.prior->n > 0) { est.last_marginalization_info = new MarginalizationInfo(); est.last_marginalization_info->prior = *w.prior; }
+        est.marginalization_flag = marg_flag ? Estimator::MARGIN_SECOND_NEW : Estimator::MARGIN_OLD;
+        est.optimization();
+        FILE* f = std::fopen(out_path, "wb"); if (!f) return -6;
+        double hdr[4] = {(double)est.last_summary.status, (double)est.last_summary.report.num_iterations, est.last_summary.report.initial_cost, est.last_summary.report.final_cost};
+        std::fwrite(hdr, 8, 4, f);
+        for (int i = 0; i <= WINDOW_SIZE; ++i) {
+            Eigen::Quaterniond q(est.Rs[i]);
+            double row[16] = {est.Ps[i].x(), est.Ps[i].y(), est.Ps[i].z(), q.x(), q.y(), q.z(), q.w(), est.Vs[i].x(), est.Vs[i].y(), est.Vs[i].z(),
+                              est.Bas[i].x(), est.Bas[i].y(), est.Bas[i].z(), est.Bgs[i].x(), est.Bgs[i].y(), est.Bgs[i].z()};
+            std::fwrite(row, 8, 16, f);
+        }
+        for (auto& it : est.f_manager.feature) { double d[2] = {it.estimated_depth, (double)it.solve_flag}; std::fwrite(d, 8, 2, f); }
+        for (auto& it : est.f_manager.line_feature) { double d[5] = {it.orthonormal_vec[0], it.orthonormal_vec[1], it.orthonormal_vec[2], it.orthonormal_vec[3], (double)it.solve_flag}; std::fwrite(d, 8, 5, f); }
+        const uvs_prior& p = est.last_marginalization_info ? est.last_marginalization_info->prior : uvs_prior();
+        double pn = est.last_marginalization_info ? p.n : 0; std::fwrite(&pn, 8, 1, f);
+        if (pn > 0) { std::fwrite(p.linearized_residuals, 8, p.n, f); std::fwrite(p.linearized_jacobians, 8, (size_t)p.n * p.n, f); }
+        std::fclose(f);
+    } catch (const std::exception& e) { std::fprintf(stderr, "uvs_host_replay_window: %s\n", e.what()); return -7; }
+    return 0;
+}
+
+// CPU-only probe used by the record/replay round-trip test: loads a window file and returns counts + checksums.
+extern "C" int uvs_host_window_probe(const char* path, double* out /*[12]*/) {
+    WindowFile wf;
+    if (!wf.load(path)) return -1;
+    const uvs_window& w = wf.w;
+    out[0] = w.n_points; out[1] = w.n_point_obs; out[2] = w.n_lines; out[3] = w.n_line_obs; out[4] = w.n_imu; out[5] = w.prior ? w.prior->n : 0;
+    double s = 0; for (int i = 0; i < 11; ++i) for (int k = 0; k < 7; ++k) s += w.pose[i][k]; out[6] = s;
+    s = 0; for (int k = 0; k < 3 * w.n_point_obs; ++k) s += w.pt_pj[k]; out[7] = s;
+    s = 0; for (int k = 0; k < 3 * w.n_line_obs; ++k) s += w.ln_vp[k] + w.ln_sp[k]; out[8] = s;
+    s = 0; for (int b = 0; b < w.n_imu; ++b) for (int k = 0; k < 225; ++k) s += w.imu[b].covariance[k] * 1e6 + w.imu[b].jacobian[k]; out[9] = s;
+    s = 0; if (w.prior) for (int k = 0; k < w.prior->n * w.prior->n; ++k) s += w.prior->linearized_jacobians[k]; out[10] = s;
+    s = 0; for (int k = 0; k < w.n_point_obs; ++k) s += w.pt_lm[k] + 3 * w.pt_fi[k] + 7 * w.pt_fj[k]; out[11] = s;
+    return 0;
+}

@@ -1,0 +1,59 @@
+// window_io.h -- binary record / replay format of one sliding window.
+// The reference never serialises the estimator window; this file is what a dump hook placed after vector2double()
+// (estimator.cpp:800) writes and what the GPU box replays without ROS.  Little-endian, 8-byte aligned:
+//   char magic[8] = "UVSWIN01"; int32 n_points, n_point_obs, n_lines, n_line_obs, n_imu, prior_n, prior_nblocks, reserved;
+//   double pose[77] sb[99] ex[7] td; double inv_depth[np]; int32 pt_lm/fi/fj[npo]; double pt_pi[3npo] pt_pj[3npo];
+//   double line_orth[4nl]; int32 ln_lm/fj/has_vp[nlo]; double ln_sp/ep/vp[3nlo]; imu: n_imu x (467 doubles + int32 frame_i, skip);
+//   prior (if prior_n): int32 kind/frame/size/idx/x0off[16 each]; double x0[144] r0[n] J0[n*n].
+// The same layout is written / read by uv-slam_amd/abi.py (Window.save / Window.load).
+#pragma once
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/uvs_solver.h"
+
+struct WindowFile {      // owns the arrays a uvs_window points to
+    uvs_window w;
+    std::vector<double> inv_depth, pt_pi, pt_pj, line_orth, ln_sp, ln_ep, ln_vp;
+    std::vector<int32_t> pt_lm, pt_fi, pt_fj, ln_lm, ln_fj, ln_has_vp;
+    std::vector<uvs_imu_block> imu;
+    uvs_prior prior;
+    bool load(const std::string& path) {
+        FILE* f = std::fopen(path.c_str(), "rb"); if (!f) return false;
+        char magic[8]; int32_t hd[8];
+        bool ok = std::fread(magic, 1, 8, f) == 8 && std::memcmp(magic, "UVSWIN01", 8) == 0 && std::fread(hd, 4, 8, f) == 8;
+        auto rd = [&](void* p, size_t sz, size_t n) { if (ok && n) ok = std::fread(p, sz, n, f) == n; };
+        std::memset(&w, 0, sizeof(w));
+        if (ok) {
+            const int np = hd[0], npo = hd[1], nl = hd[2], nlo = hd[3], ni = hd[4], pn = hd[5], pnb = hd[6];
+            rd(w.pose, 8, 77); rd(w.speedbias, 8, 99); rd(w.ex_pose, 8, 7); rd(&w.td, 8, 1);
+            inv_depth.resize(np); rd(inv_depth.data(), 8, np);
+            pt_lm.resize(npo); pt_fi.resize(npo); pt_fj.resize(npo); rd(pt_lm.data(), 4, npo); rd(pt_fi.data(), 4, npo); rd(pt_fj.data(), 4, npo);
+            if (npo % 2) { int32_t pad; rd(&pad, 4, 1); }
+            pt_pi.resize(3 * npo); pt_pj.resize(3 * npo); rd(pt_pi.data(), 8, 3 * npo); rd(pt_pj.data(), 8, 3 * npo);
+            line_orth.resize(4 * nl); rd(line_orth.data(), 8, 4 * nl);
+            ln_lm.resize(nlo); ln_fj.resize(nlo); ln_has_vp.resize(nlo); rd(ln_lm.data(), 4, nlo); rd(ln_fj.data(), 4, nlo); rd(ln_has_vp.data(), 4, nlo);
+            if (nlo % 2) { int32_t pad; rd(&pad, 4, 1); }
+            ln_sp.resize(3 * nlo); ln_ep.resize(3 * nlo); ln_vp.resize(3 * nlo); rd(ln_sp.data(), 8, 3 * nlo); rd(ln_ep.data(), 8, 3 * nlo); rd(ln_vp.data(), 8, 3 * nlo);
+            imu.resize(ni);
+            for (int b = 0; b < ni; ++b) {
+                double h[17]; rd(h, 8, 17); uvs_imu_block& ib = imu[b]; std::memset(&ib, 0, sizeof(ib));
+                ib.sum_dt = h[0]; std::memcpy(ib.delta_p, h + 1, 24); std::memcpy(ib.delta_q, h + 4, 32); std::memcpy(ib.delta_v, h + 8, 24); std::memcpy(ib.linearized_ba, h + 11, 24); std::memcpy(ib.linearized_bg, h + 14, 24);
+                rd(ib.jacobian, 8, 225); rd(ib.covariance, 8, 225); int32_t fs[2]; rd(fs, 4, 2); ib.frame_i = fs[0]; ib.skip = fs[1];
+            }
+            std::memset(&prior, 0, sizeof(prior));
+            if (pn > 0) {
+                prior.n = pn; prior.n_blocks = pnb;
+                rd(prior.block_kind, 4, 16); rd(prior.block_frame, 4, 16); rd(prior.block_size, 4, 16); rd(prior.block_idx, 4, 16); rd(prior.x0_off, 4, 16);
+                rd(prior.x0, 8, 144); rd(prior.linearized_residuals, 8, pn); rd(prior.linearized_jacobians, 8, (size_t)pn * pn);
+            }
+            w.n_points = np; w.n_point_obs = npo; w.n_lines = nl; w.n_line_obs = nlo; w.n_imu = ni;
+            w.inv_depth = inv_depth.data(); w.pt_lm = pt_lm.data(); w.pt_fi = pt_fi.data(); w.pt_fj = pt_fj.data(); w.pt_pi = pt_pi.data(); w.pt_pj = pt_pj.data();
+            w.line_orth = line_orth.data(); w.ln_lm = ln_lm.data(); w.ln_fj = ln_fj.data(); w.ln_has_vp = ln_has_vp.data(); w.ln_sp = ln_sp.data(); w.ln_ep = ln_ep.data(); w.ln_vp = ln_vp.data();
+            w.imu = imu.data(); w.prior = pn > 0 ? &prior : nullptr;
+        }
+        std::fclose(f);
+        return ok;
+    }
+};
