@@ -133,7 +133,7 @@ class Solver:
 
     def debug_first_iteration(self, w: abi.Window):
         wc, keep = w.to_c()
-        S = np.zeros((176, 176)); g = np.zeros(176); hd = np.zeros(176); dd = np.zeros(176); step = np.zeros(176); scal = np.zeros(32)
+        S = np.zeros((176, 176)); g = np.zeros(176); hd = np.zeros(176); dd = np.zeros(176); step = np.zeros(176); scal = np.zeros(40)
         self._check(lib().uvs_debug_first_iteration(self._h, C.byref(wc), *[abi._dp(a) for a in (S, g, hd, dd, step, scal)]))
         return dict(S=S, g=g, hd=hd, dd=dd, step=step, cost=scal[0], gmax=scal[1], chol_ok=scal[2], mcc=scal[3], step2=scal[4],
-                    cycles=dict(zip(['setup', 'obs', 'lmprep', 'gather', 'assemble', 'chol', 'trsv', 'backsub', 'cost', 'misc'], scal[8:18])), wave_gather=scal[20:28].copy())
+                    cycles=dict(zip(['setup', 'obs', 'lmprep', 'gather', 'assemble', 'chol', 'trsv', 'backsub', 'cost', 'misc', 'chol_diag', 'chol_panel', 'chol_trail', 'asm_imu', 'asm_zero', 'asm_add'], scal[8:24])), wave_gather=scal[24:32].copy())

@@ -41,10 +41,10 @@ static constexpr int L_PR = L_PDX + UVS_MAX_PRIOR_DIM;   // prior residual
 static constexpr int L_RED = L_PR + UVS_MAX_PRIOR_DIM;   // reduction scratch
 static constexpr int L_CTRL = L_RED + 64;
 static constexpr int L_PROF = L_CTRL + 32;      // per-phase cycle counters (debug launches only)
-static constexpr int L_WPROF = L_PROF + 16;     // per-wave gather cycles (debug)
+static constexpr int L_WPROF = L_PROF + 24;     // per-wave gather cycles (debug)
 static constexpr int L_TOTAL = L_WPROF + 8;
-enum { P_SETUP = 0, P_OBS, P_LMPREP, P_GATHER, P_ASSEMBLE, P_CHOL, P_TRSV, P_BACKSUB, P_COST, P_MISC, P_LAST };
-#define UVS_PROF(c, k) do { if ((c).o.debug && threadIdx.x == 0) { const long long now_ = clock64(); (c).sh[L_PROF + (k)] += (double)(now_ - (long long)(c).sh[L_PROF + 15]); (c).sh[L_PROF + 15] = (double)now_; } } while (0)
+enum { P_SETUP = 0, P_OBS, P_LMPREP, P_GATHER, P_ASSEMBLE, P_CHOL, P_TRSV, P_BACKSUB, P_COST, P_MISC, P_CH_DIAG, P_CH_PANEL, P_CH_TRAIL, P_AS_IMU, P_AS_ZERO, P_AS_ADD, P_LAST };
+#define UVS_PROF(c, k) do { if ((c).o.debug && threadIdx.x == 0) { const long long now_ = clock64(); (c).sh[L_PROF + (k)] += (double)(now_ - (long long)(c).sh[L_PROF + 23]); (c).sh[L_PROF + 23] = (double)now_; } } while (0)
 static constexpr size_t LDS_BYTES = (size_t)L_TOTAL * 8;
 
 enum { C_COST = 0, C_RADIUS, C_DECR, C_XNORM, C_GMAX, C_CAND, C_MCC, C_STEP2, C_XC2, C_GO, C_IT, C_INVALID, C_CUR, C_FIRST,
@@ -205,10 +205,16 @@ UVS_DEV double cost_pass(const Ctx& c, const double* x, const double* invd, cons
 
 // ------------------------------------------------------------------ blocked Cholesky of the LDS-resident reduced system
 // S (lower 16x16 blocks) <- L ; L_DINV <- 1/diag(L).  Returns via CTRL[C_CHOLOK].
+typedef double d4_t __attribute__((ext_vector_type(4)));
+
+// Factors S = L L^T in place and, because the right-hand side is carried along as one extra row of the panel,
+// leaves y = L^-1 rhs in L_DLT (the forward substitution costs one 16-step register solve per block column).
 UVS_DEV void chol_factor(const Ctx& c) {
     double* sh = c.sh;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    double* b = sh + L_DLT;
     if (tid == 0) sh[L_CTRL + C_CHOLOK] = 1.0;
+    UVS_PROF(c, P_MISC);
     for (int k = 0; k < UVS_NF; ++k) {
         double* Dk = sh + L_S + (((k * (k + 1)) >> 1) + k) * UVS_BLK_SZ;
         __syncthreads();
@@ -218,7 +224,9 @@ UVS_DEV void chol_factor(const Ctx& c) {
             const int r = lane & 15;
 #pragma unroll
             for (int cc = 0; cc < 16; ++cc) a[cc] = Dk[r * UVS_BLK_LD + cc];
+            double rhs = b[16 * k + r];
             bool ok = true;
+            double dinv_r = 0.0;
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const double piv = bcast_lane(a[j], j);
@@ -226,21 +234,24 @@ UVS_DEV void chol_factor(const Ctx& c) {
                 double ljj, inv; rsqrt_pair(piv, &ljj, &inv);
                 const double l = (r == j) ? ljj : a[j] * inv;
                 a[j] = l;
+                if (r == j) dinv_r = inv;
 #pragma unroll
                 for (int cc = j + 1; cc < 16; ++cc) { const double lc = bcast_lane(l, cc); a[cc] -= l * lc; }
+                // forward substitution of the right-hand side rides along: y_j = rhs_j / L_jj ; rhs_r -= L_rj y_j
+                const double yj = bcast_lane(rhs * inv, j);
+                rhs = (r == j) ? yj : (r > j ? rhs - l * yj : rhs);
             }
             if (lane < 16) {
 #pragma unroll
                 for (int cc = 0; cc < 16; ++cc) if (cc <= r) Dk[r * UVS_BLK_LD + cc] = a[cc];
-                double mine = 0.0;
-#pragma unroll
-                for (int cc = 0; cc < 16; ++cc) if (cc == r) mine = a[cc];
-                sh[L_DINV + 16 * k + r] = 1.0 / mine;
+                sh[L_DINV + 16 * k + r] = dinv_r;
+                b[16 * k + r] = rhs;
                 if (!ok && lane == 0) sh[L_CTRL + C_CHOLOK] = 0.0;
             }
         }
         __syncthreads();
-        // (2) panel: rows of blocks (i,k), i>k : x L_kk^T = a  (forward substitution along the row)
+        UVS_PROF(c, P_CH_DIAG);
+        // (2) panel: rows of blocks (i,k), i>k : x L_kk^T = a, column sweep (axpy form: the only serial chain is x_j -> x_j+1)
         const int nrow = (UVS_NF - 1 - k) * 16;
         if (tid < nrow) {
             const int i = k + 1 + (tid >> 4), r = tid & 15;
@@ -248,92 +259,52 @@ UVS_DEV void chol_factor(const Ctx& c) {
             double x[16];
 #pragma unroll
             for (int cc = 0; cc < 16; ++cc) x[cc] = B[cc];
+            double dot = 0.0;
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                double s = x[j];
+                x[j] *= sh[L_DINV + 16 * k + j];
 #pragma unroll
-                for (int m = 0; m < j; ++m) s -= x[m] * Dk[j * UVS_BLK_LD + m];
-                x[j] = s * sh[L_DINV + 16 * k + j];
+                for (int m = j + 1; m < 16; ++m) x[m] -= x[j] * Dk[m * UVS_BLK_LD + j];
+                dot += x[j] * b[16 * k + j];
             }
 #pragma unroll
             for (int cc = 0; cc < 16; ++cc) B[cc] = x[cc];
+            b[16 * i + r] -= dot;                     // right-hand side row of the trailing update
         }
         __syncthreads();
-        // (3) trailing update S_ij -= X_i X_j^T for k < j <= i : 4x4 register tiles, 16 tiles per block
+        UVS_PROF(c, P_CH_PANEL);
+        // (3) trailing update S_ij -= X_i X_j^T for k < j <= i : one wave per 16x16 block, 4 x v_mfma_f64_16x16x4_f64
         const int nb = UVS_NF - 1 - k;
-        const int ntile = ((nb * (nb + 1)) >> 1) * 16;
-        for (int t = tid; t < ntile; t += NT) {
-            const int pb = t >> 4, tl = t & 15;
-            // pb -> (ii, jj) with 0 <= jj <= ii < nb
-            int ii = (int)((sqrt(8.0 * pb + 1.0) - 1.0) * 0.5);
+        const int nblk = (nb * (nb + 1)) >> 1;
+        for (int pb = wv; pb < nblk; pb += NW) {
+            int ii = (int)((sqrtf(8.0f * pb + 1.0f) - 1.0f) * 0.5f);
             while (((ii + 1) * (ii + 2)) >> 1 <= pb) ++ii;
             while (((ii * (ii + 1)) >> 1) > pb) --ii;
             const int jj = pb - ((ii * (ii + 1)) >> 1);
             const int bi_ = k + 1 + ii, bj_ = k + 1 + jj;
-            const int r0 = (tl >> 2) * 4, c0 = (tl & 3) * 4;
-            const double* Xi = sh + L_S + (((bi_ * (bi_ + 1)) >> 1) + k) * UVS_BLK_SZ + r0 * UVS_BLK_LD;
-            const double* Xj = sh + L_S + (((bj_ * (bj_ + 1)) >> 1) + k) * UVS_BLK_SZ + c0 * UVS_BLK_LD;
-            double* Cb = sh + L_S + (((bi_ * (bi_ + 1)) >> 1) + bj_) * UVS_BLK_SZ + r0 * UVS_BLK_LD + c0;
-            double acc[4][4];
+            const double* Xi = sh + L_S + (((bi_ * (bi_ + 1)) >> 1) + k) * UVS_BLK_SZ + (lane & 15) * UVS_BLK_LD + (lane >> 4);
+            const double* Xj = sh + L_S + (((bj_ * (bj_ + 1)) >> 1) + k) * UVS_BLK_SZ + (lane & 15) * UVS_BLK_LD + (lane >> 4);
+            double* Cb = sh + L_S + (((bi_ * (bi_ + 1)) >> 1) + bj_) * UVS_BLK_SZ + (lane >> 4) * UVS_BLK_LD + (lane & 15);
+            d4_t acc;      // C/D layout of the f64 MFMA: row = (lane >> 4) + 4 * reg, col = lane & 15
 #pragma unroll
-            for (int a = 0; a < 4; ++a)
+            for (int q = 0; q < 4; ++q) acc[q] = Cb[4 * q * UVS_BLK_LD];
 #pragma unroll
-                for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
-#pragma unroll 4
-            for (int m = 0; m < 16; ++m) {
-                double xa[4], xb[4];
+            for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Xi[4 * kk], Xj[4 * kk], acc, 0, 0, 0);
 #pragma unroll
-                for (int a = 0; a < 4; ++a) { xa[a] = Xi[a * UVS_BLK_LD + m]; xb[a] = Xj[a * UVS_BLK_LD + m]; }
-#pragma unroll
-                for (int a = 0; a < 4; ++a)
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) acc[a][b] += xa[a] * xb[b];
-            }
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b) Cb[a * UVS_BLK_LD + b] -= acc[a][b];
+            for (int q = 0; q < 4; ++q) Cb[4 * q * UVS_BLK_LD] = acc[q];
         }
+        __syncthreads();
+        UVS_PROF(c, P_CH_TRAIL);
     }
     __syncthreads();
 }
 
-// solve L L^T y = rhs in place (rhs in L_DLT)
+// backward substitution L^T x = y in place (y in L_DLT, produced by chol_factor)
 UVS_DEV void chol_solve(const Ctx& c) {
     double* sh = c.sh;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     double* b = sh + L_DLT;
-    // forward
-    for (int k = 0; k < UVS_NF; ++k) {
-        const double* Dk = sh + L_S + (((k * (k + 1)) >> 1) + k) * UVS_BLK_SZ;
-        __syncthreads();
-        if (wv == 0) {
-            const int r = lane & 15;
-            double Lr[16];
-#pragma unroll
-            for (int cc = 0; cc < 16; ++cc) Lr[cc] = (cc < r) ? Dk[r * UVS_BLK_LD + cc] : 0.0;
-            double v = b[16 * k + r];
-            const double di = sh[L_DINV + 16 * k + r];
-            double y = 0.0;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const double yj = bcast_lane(v * di, j);
-                if (r == j) y = yj;
-                v -= Lr[j] * yj;      // Lr[j] == 0 for j >= r
-            }
-            if (lane < 16) b[16 * k + r] = y;
-        }
-        __syncthreads();
-        const int nrow = (UVS_NF - 1 - k) * 16;
-        if (tid < nrow) {
-            const int i = k + 1 + (tid >> 4), r = tid & 15;
-            const double* B = sh + L_S + (((i * (i + 1)) >> 1) + k) * UVS_BLK_SZ + r * UVS_BLK_LD;
-            double s = 0.0;
-#pragma unroll
-            for (int cc = 0; cc < 16; ++cc) s += B[cc] * b[16 * k + cc];
-            b[16 * i + r] -= s;
-        }
-    }
+    // the forward substitution was carried by chol_factor(); only L^T x = y remains
     // backward
     for (int k = UVS_NF - 1; k >= 0; --k) {
         const double* Dk = sh + L_S + (((k * (k + 1)) >> 1) + k) * UVS_BLK_SZ;
@@ -583,7 +554,7 @@ UVS_DEV void linearize(const Ctx& c, const double* x, const double* invd, const 
             c.ws[h.w_imu + (size_t)b * UVS_WIMU_STRIDE + e] = s;
         }
     }
-    UVS_PROF(c, P_ASSEMBLE);
+    UVS_PROF(c, P_AS_IMU);
 
     // ---- landmark chunks: stage -> per-landmark Schur prep -> list-driven gather
     const int* chunks = c.bi + h.i_chunks;
@@ -796,6 +767,7 @@ UVS_DEV void linearize(const Ctx& c, const double* x, const double* invd, const 
         }
     }
     __syncthreads();
+    UVS_PROF(c, P_AS_ZERO);
     // IMU normal-equation blocks from global scratch (even blocks, then odd: consecutive blocks share a diagonal frame block)
     for (int par = 0; par < 2; ++par) {
         for (int t = tid; t < h.n_imu * 495; t += NT) {
@@ -839,6 +811,7 @@ UVS_DEV void linearize(const Ctx& c, const double* x, const double* invd, const 
         }
     }
     __syncthreads();
+    UVS_PROF(c, P_AS_ADD);
     // frame damping, Jacobi scaling (first linearization only), dummy pivots, projected-gradient max norm
     double gmax = gmax_lm;
     if (tid < UVS_RD) {
@@ -1032,7 +1005,7 @@ __global__ __launch_bounds__(NT) void k_solve(char* blobs, const long long* blob
     for (int k = tid; k < h.n_points; k += NT) c.ws[h.w_invd0 + k] = c.bd[h.d_invd + k];
     for (int k = tid; k < 4 * h.n_lines; k += NT) c.ws[h.w_line0 + k] = c.bd[h.d_line + k];
     for (int i = tid; i < (int)(sizeof(uvs_report) / 4); i += NT) ((int*)rep)[i] = 0;
-    if (tid < 16) sh[L_PROF + tid] = (tid == 15) ? (double)clock64() : 0.0;
+    if (tid < 24) sh[L_PROF + tid] = (tid == 23) ? (double)clock64() : 0.0;
     if (tid < 8) sh[L_WPROF + tid] = 0.0;
     setup_window(c, (double*)blob);
     __syncthreads();
@@ -1141,7 +1114,7 @@ __global__ __launch_bounds__(NT) void k_solve(char* blobs, const long long* blob
     __syncthreads();
     UVS_PROF(c, P_MISC);
     if (o.debug && dbg.scal && tid < P_LAST) dbg.scal[8 + tid] = sh[L_PROF + tid];
-    if (o.debug && dbg.scal && tid < 8) dbg.scal[20 + tid] = sh[L_WPROF + tid];
+    if (o.debug && dbg.scal && tid < 8) dbg.scal[24 + tid] = sh[L_WPROF + tid];
     if (tid < 184) c.ws[h.w_out + tid] = sh[L_X + tid];
     if (tid == 0) {
         rep->status = status; rep->termination = term; rep->num_iterations = it; rep->num_successful = nsucc; rep->final_cost = cost;

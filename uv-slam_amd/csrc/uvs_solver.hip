@@ -415,7 +415,7 @@ static int launch_solve(uvs_solver* s, int debug, float* elapsed_ms) {
     KOpts ko = make_kopts(s->opts, debug);
     DebugOut dbg; std::memset(&dbg, 0, sizeof(dbg));
     if (debug) {
-        if (!s->d_dbg) HIPCHK(s, hipMalloc((void**)&s->d_dbg, sizeof(double) * (UVS_RD * UVS_RD + 5 * UVS_RD + 32)));
+        if (!s->d_dbg) HIPCHK(s, hipMalloc((void**)&s->d_dbg, sizeof(double) * (UVS_RD * UVS_RD + 5 * UVS_RD + 40)));
         dbg.S = s->d_dbg; dbg.g = dbg.S + UVS_RD * UVS_RD; dbg.hd = dbg.g + UVS_RD; dbg.dd = dbg.hd + UVS_RD; dbg.step = dbg.dd + UVS_RD; dbg.scal = dbg.step + UVS_RD;
     }
     HIPCHK(s, hipEventRecord(s->ev0, s->stream));
@@ -487,7 +487,7 @@ int uvs_debug_first_iteration(uvs_solver* s, const uvs_window* w, double* S_lowe
     if (hd) HIPCHK(s, hipMemcpy(hd, s->d_dbg + nS + UVS_RD, UVS_RD * 8, hipMemcpyDeviceToHost));
     if (dd) HIPCHK(s, hipMemcpy(dd, s->d_dbg + nS + 2 * UVS_RD, UVS_RD * 8, hipMemcpyDeviceToHost));
     if (step) HIPCHK(s, hipMemcpy(step, s->d_dbg + nS + 3 * UVS_RD, UVS_RD * 8, hipMemcpyDeviceToHost));
-    if (scal) HIPCHK(s, hipMemcpy(scal, s->d_dbg + nS + 4 * UVS_RD, 32 * 8, hipMemcpyDeviceToHost));
+    if (scal) HIPCHK(s, hipMemcpy(scal, s->d_dbg + nS + 4 * UVS_RD, 40 * 8, hipMemcpyDeviceToHost));
     return UVS_OK;
 }
 
