@@ -22,7 +22,11 @@
 #define UVS_IMU_COV 245
 #define UVS_IMU_W 470
 
-#define UVS_PT_REC 29             // LDS record per point observation: r[2] A[12] B[12] c[2] (+1 pad: odd stride => no bank conflicts)
+#define UVS_PT_REC 31             // LDS record per point observation: r[2] A[12] c|rc[2] B[12] rc[2] pad  (rc = Schur-corrected residual; odd stride)
+#define UVS_PT_A 2
+#define UVS_PT_C 14
+#define UVS_PT_B 16
+#define UVS_PT_RC2 28
 #define UVS_LN_REC 33             // LDS record per line observation: rl[2] Jlp[12] Jll[8] rv Jvp[6] Jvl[4]
 
 struct DevWin {

@@ -348,49 +348,48 @@ UVS_DEV void chol_solve(const Ctx& c) {
 // A wave walks its lists front to back, so every sum has a fixed order (bitwise reproducible, no atomics).
 static constexpr int BLOCKS_PER_WAVE = (UVS_NBLK + NW - 1) / NW;   // 9
 
-// Branch-free inner loops: every operand is addressed as S0[scalar(entry) + lane constant] (integer selects only --
-// selecting between POINTERS makes the compiler fall back to flat loads and scratch), list entries are decoded on the
-// scalar unit, and several entries are in flight at a time so that LDS latency is paid per group, not per entry.
-UVS_DEV void gather_points(const int* wb, const int* lists, const double* S0, int oE, int oEI, int oX, double* acc) {
+// List entries are pre-expanded by the host into LDS offsets (two 16-bit fields, doubles relative to the staging base):
+//   Schur entry : offset of the E row (frame a) | offset of the E*H_ll^-1 (points) / H_ll^-1 E (lines) row (frame b) << 16
+//   direct entry: points: offset of the first Jacobian block | offset of the second << 16 ; lines: record offset
+// so the inner loops are: readlane, two scalar field extracts, LDS reads at (scalar + lane constant), FMAs.
+// Gradient lanes need no Schur list: pass B stores the Schur-CORRECTED residual rc = r - J_l H_ll^-1 g_l in every record,
+// and sum_o J_p^T rc IS the reduced gradient.
+UVS_DEV void gather_points(const int* wb, const int* lists, const double* S0, double* acc) {
     const int lane = threadIdx.x & 63;
     const int role = lane < 36 ? 0 : lane < 42 ? 1 : lane < 48 ? 2 : 3;
     const int a = role == 0 ? lane / 6 : role == 1 ? lane - 36 : role == 2 ? lane - 42 : 0;
     const int bb = role == 0 ? lane - 6 * (lane / 6) : 0;
     const bool r0 = role == 0, r1 = role == 1;
-    // Schur second operand: role0 -> EI[6*(sl+sb) + bb], else -> X[2*li + 1]
-    const int k2sb = r0 ? 6 : 0, k2li = r0 ? 0 : 2, k2c = r0 ? oEI + bb : oX + 1;
-    // direct second operand: role0 -> R[offB + bb], role1 -> R[0] (residual), else -> R[offA + a]
-    const int kdB = r0 ? 1 : 0, kdA = (r0 || r1) ? 0 : 1, kdc = r0 ? bb : r1 ? 0 : a, kdd = r1 ? 1 : 6;
+    const int kq = r0 ? bb : r1 ? 12 : a, kdd = r1 ? 1 : 6;      // direct second operand: J_b column / corrected residual / itself
     const int* ent = lists + 2 * (UVS_NBLK + 1);
 #pragma unroll
     for (int q = 0; q < BLOCKS_PER_WAVE; ++q) {
         if (wb[q] >= 0) {                                  // host-balanced block -> wave assignment (-1 = none), bit 8 = diagonal block
             const int b = wb[q] & 255;
             const bool diag = (wb[q] >> 8) != 0;
-            const double ms = (r0 || (diag && r1)) ? 1.0 : 0.0;            // Schur-term mask
             const double md = (r0 || (diag && role < 3)) ? 1.0 : 0.0;      // direct-term mask
             double s = 0.0;
             int e0 = lists[b], e1 = lists[b + 1];
             for (int base = e0; base < e1; base += 64) {
-                const int mine = (base + lane < e1) ? ent[base + lane] : 0;
+                const int mine = (base + lane < e1) ? ent[base + lane] : 0;      // every lane fetches (readlane needs all 64 slots)
                 const int n = min(64, e1 - base);
-                int i = 0;
-                for (; i + 8 <= n; i += 8) {            // 8 entries in flight
-                    double v1[8], v2[8];
+                if (r0) {
+                    int i = 0;
+                    for (; i + 8 <= n; i += 8) {            // 8 entries in flight
+                        double v1[8], v2[8];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int e = __builtin_amdgcn_readlane(mine, i + u);
-                        const int li = e & 1023, sa = (e >> 10) & 15, sb = (e >> 14) & 15, sl = (e >> 18) & 16383;
-                        v1[u] = S0[oE + 6 * (sl + sa) + a];
-                        v2[u] = S0[k2sb * (sl + sb) + k2li * li + k2c];
+                        for (int u = 0; u < 8; ++u) {
+                            const int e = __builtin_amdgcn_readlane(mine, i + u);
+                            v1[u] = S0[(e & 0xffff) + a];
+                            v2[u] = S0[((unsigned)e >> 16) + bb];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) s -= v1[u] * v2[u];
                     }
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) s -= ms * v1[u] * v2[u];
-                }
-                for (; i < n; ++i) {
-                    const int e = __builtin_amdgcn_readlane(mine, i);
-                    const int li = e & 1023, sa = (e >> 10) & 15, sb = (e >> 14) & 15, sl = (e >> 18) & 16383;
-                    s -= ms * S0[oE + 6 * (sl + sa) + a] * S0[k2sb * (sl + sb) + k2li * li + k2c];
+                    for (; i < n; ++i) {
+                        const int e = __builtin_amdgcn_readlane(mine, i);
+                        s -= S0[(e & 0xffff) + a] * S0[((unsigned)e >> 16) + bb];
+                    }
                 }
             }
             e0 = lists[UVS_NBLK + 1 + b]; e1 = lists[UVS_NBLK + 2 + b];
@@ -403,11 +402,9 @@ UVS_DEV void gather_points(const int* wb, const int* lists, const double* S0, in
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const int e = __builtin_amdgcn_readlane(mine, i + u);
-                        const int o = e & 16383, ty = e >> 14;            // 0: A^T A (anchor), 1: B^T B, 2: B^T A
-                        const int offA = ty == 0 ? 2 : 14, offB = ty == 1 ? 14 : 2;
-                        const int ro = o * UVS_PT_REC;
-                        const int iq = ro + kdB * offB + kdA * offA + kdc;
-                        p0[u] = S0[ro + offA + a]; p1[u] = S0[ro + offA + 6 + a];
+                        const int lo = e & 0xffff, hi = (unsigned)e >> 16;
+                        const int iq = (r0 ? hi : lo) + kq;
+                        p0[u] = S0[lo + a]; p1[u] = S0[lo + 6 + a];
                         q0[u] = S0[iq]; q1[u] = S0[iq + kdd];
                     }
 #pragma unroll
@@ -415,11 +412,9 @@ UVS_DEV void gather_points(const int* wb, const int* lists, const double* S0, in
                 }
                 for (; i < n; ++i) {
                     const int e = __builtin_amdgcn_readlane(mine, i);
-                    const int o = e & 16383, ty = e >> 14;
-                    const int offA = ty == 0 ? 2 : 14, offB = ty == 1 ? 14 : 2;
-                    const int ro = o * UVS_PT_REC;
-                    const int iq = ro + kdB * offB + kdA * offA + kdc;
-                    s += md * (S0[ro + offA + a] * S0[iq] + S0[ro + offA + 6 + a] * S0[iq + kdd]);
+                    const int lo = e & 0xffff, hi = (unsigned)e >> 16;
+                    const int iq = (r0 ? hi : lo) + kq;
+                    s += md * (S0[lo + a] * S0[iq] + S0[lo + 6 + a] * S0[iq + kdd]);
                 }
             }
             acc[q] += s;
@@ -427,48 +422,45 @@ UVS_DEV void gather_points(const int* wb, const int* lists, const double* S0, in
     }
 }
 
-UVS_DEV void gather_lines(const int* wb, const int* lists, const double* S0, int oE, int oY, int oX, double* acc) {
+UVS_DEV void gather_lines(const int* wb, const int* lists, const double* S0, double* acc) {
     const int lane = threadIdx.x & 63;
     const int role = lane < 36 ? 0 : lane < 42 ? 1 : lane < 48 ? 2 : 3;
     const int a = role == 0 ? lane / 6 : role == 1 ? lane - 36 : role == 2 ? lane - 42 : 0;
     const int bb = role == 0 ? lane - 6 * (lane / 6) : 0;
     const bool r0 = role == 0, r1 = role == 1;
-    // Schur second operand: role0 -> Y[24*(sl+sb) + bb + 6k], else -> X[20*li + 16 + k]
-    const int k2sb = r0 ? 24 : 0, k2li = r0 ? 0 : 20, k2c = r0 ? oY + bb : oX + 16, qs = r0 ? 6 : 1;
-    // direct second operand rows: role0 -> (2+bb, 8+bb, 23+bb), role1 -> (0, 1, 22), else -> (2+a, 8+a, 23+a)
-    const int d0 = r0 ? 2 + bb : r1 ? 0 : 2 + a, d1 = r0 ? 8 + bb : r1 ? 1 : 8 + a, d2 = r0 ? 23 + bb : r1 ? 22 : 23 + a;
+    // direct second operand rows: role0 -> (2+bb, 8+bb, 23+bb), role1 -> corrected residual (14, 15, 16), else -> (2+a, 8+a, 23+a)
+    const int d0 = r0 ? 2 + bb : r1 ? 14 : 2 + a, d1 = r0 ? 8 + bb : r1 ? 15 : 8 + a, d2 = r0 ? 23 + bb : r1 ? 16 : 23 + a;
     const int* ent = lists + 2 * (UVS_NBLK + 1);
 #pragma unroll
     for (int q = 0; q < BLOCKS_PER_WAVE; ++q) {
         if (wb[q] >= 0) {
             const int b = wb[q] & 255;
             const bool diag = (wb[q] >> 8) != 0;
-            const double ms = (r0 || (diag && r1)) ? 1.0 : 0.0;
             const double md = (r0 || (diag && role < 3)) ? 1.0 : 0.0;
             double s = 0.0;
             int e0 = lists[b], e1 = lists[b + 1];
             for (int base = e0; base < e1; base += 64) {
                 const int mine = (base + lane < e1) ? ent[base + lane] : 0;
                 const int n = min(64, e1 - base);
-                int i = 0;
-                for (; i + 2 <= n; i += 2) {
-                    double ea[2][4], qq[2][4];
+                if (r0) {
+                    int i = 0;
+                    for (; i + 2 <= n; i += 2) {
+                        double ea[2][4], qq[2][4];
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        const int e = __builtin_amdgcn_readlane(mine, i + u);
-                        const int li = e & 1023, sa = (e >> 10) & 15, sb = (e >> 14) & 15, sl = (e >> 18) & 16383;
-                        const int ia = oE + 24 * (sl + sa) + a, iq = k2sb * (sl + sb) + k2li * li + k2c;
+                        for (int u = 0; u < 2; ++u) {
+                            const int e = __builtin_amdgcn_readlane(mine, i + u);
+                            const int ia = (e & 0xffff) + a, iq = ((unsigned)e >> 16) + bb;
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) { ea[u][k] = S0[ia + 6 * k]; qq[u][k] = S0[iq + qs * k]; }
+                            for (int k = 0; k < 4; ++k) { ea[u][k] = S0[ia + 6 * k]; qq[u][k] = S0[iq + 6 * k]; }
+                        }
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) s -= ea[u][0] * qq[u][0] + ea[u][1] * qq[u][1] + ea[u][2] * qq[u][2] + ea[u][3] * qq[u][3];
                     }
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) s -= ms * (ea[u][0] * qq[u][0] + ea[u][1] * qq[u][1] + ea[u][2] * qq[u][2] + ea[u][3] * qq[u][3]);
-                }
-                for (; i < n; ++i) {
-                    const int e = __builtin_amdgcn_readlane(mine, i);
-                    const int li = e & 1023, sa = (e >> 10) & 15, sb = (e >> 14) & 15, sl = (e >> 18) & 16383;
-                    const int ia = oE + 24 * (sl + sa) + a, iq = k2sb * (sl + sb) + k2li * li + k2c;
-                    s -= ms * (S0[ia] * S0[iq] + S0[ia + 6] * S0[iq + qs] + S0[ia + 12] * S0[iq + 2 * qs] + S0[ia + 18] * S0[iq + 3 * qs]);
+                    for (; i < n; ++i) {
+                        const int e = __builtin_amdgcn_readlane(mine, i);
+                        const int ia = (e & 0xffff) + a, iq = ((unsigned)e >> 16) + bb;
+                        s -= S0[ia] * S0[iq] + S0[ia + 6] * S0[iq + 6] + S0[ia + 12] * S0[iq + 12] + S0[ia + 18] * S0[iq + 18];
+                    }
                 }
             }
             e0 = lists[UVS_NBLK + 1 + b]; e1 = lists[UVS_NBLK + 2 + b];
@@ -480,7 +472,7 @@ UVS_DEV void gather_lines(const int* wb, const int* lists, const double* S0, int
                     double p[2][3], qv[2][3];
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
-                        const int ro = (__builtin_amdgcn_readlane(mine, i + u) & 16383) * UVS_LN_REC;
+                        const int ro = __builtin_amdgcn_readlane(mine, i + u);
                         p[u][0] = S0[ro + 2 + a]; p[u][1] = S0[ro + 8 + a]; p[u][2] = S0[ro + 23 + a];
                         qv[u][0] = S0[ro + d0]; qv[u][1] = S0[ro + d1]; qv[u][2] = S0[ro + d2];
                     }
@@ -488,7 +480,7 @@ UVS_DEV void gather_lines(const int* wb, const int* lists, const double* S0, int
                     for (int u = 0; u < 2; ++u) s += md * (p[u][0] * qv[u][0] + p[u][1] * qv[u][1] + p[u][2] * qv[u][2]);
                 }
                 for (; i < n; ++i) {
-                    const int ro = (__builtin_amdgcn_readlane(mine, i) & 16383) * UVS_LN_REC;
+                    const int ro = __builtin_amdgcn_readlane(mine, i);
                     s += md * (S0[ro + 2 + a] * S0[ro + d0] + S0[ro + 8 + a] * S0[ro + d1] + S0[ro + 23 + a] * S0[ro + d2]);
                 }
             }
@@ -571,8 +563,7 @@ UVS_DEV void linearize(const Ctx& c, const double* x, const double* invd, const 
             double* rec = sh + L_S;                                  // [nob][28]
             double* Eb = rec + (size_t)nob * UVS_PT_REC;             // [(nob + nlm)][6]
             double* EIb = Eb + (size_t)(nob + nlm) * 6;              // [(nob + nlm)][6]  Einv = E / h_ll
-            double* Xb = EIb + (size_t)(nob + nlm) * 6;              // [nlm][2] : hinv, ginv
-            int* lists = (int*)(Xb + 2 * nlm);                       // gather lists staged in LDS (one HBM latency per chunk)
+            int* lists = (int*)(EIb + (size_t)(nob + nlm) * 6);      // gather lists staged in LDS (one HBM latency per chunk)
             for (int t = tid; t < nlist; t += NT) lists[t] = glists[t];
             // pass A: one lane per observation
             for (int o = o0 + tid; o < o1; o += NT) {
@@ -585,17 +576,19 @@ UVS_DEV void linearize(const Ctx& c, const double* x, const double* invd, const 
                 double* R = rec + (size_t)(o - o0) * UVS_PT_REC;
                 R[0] = sc * r[0]; R[1] = sc * r[1];
 #pragma unroll
-                for (int q = 0; q < 12; ++q) { R[2 + q] = sc * A[q]; R[14 + q] = sc * B[q]; }
-                R[26] = sc * cl[0]; R[27] = sc * cl[1];
+                for (int q = 0; q < 12; ++q) { R[UVS_PT_A + q] = sc * A[q]; R[UVS_PT_B + q] = sc * B[q]; }
+                R[UVS_PT_C] = sc * cl[0]; R[UVS_PT_C + 1] = sc * cl[1];      // d r / d lambda; replaced by the corrected residual in pass B
             }
             __syncthreads();
             UVS_PROF(c, P_OBS);
             // pass B: one lane per observation (its landmark's h_ll / g_l are recomputed per lane, cheap);
-            // the lane of a landmark's first observation also owns the anchor slot and the per-landmark scalars
+            // the lane of a landmark's first observation also owns the anchor slot and the per-landmark scalars.
+            // Reads of the d r/d lambda columns happen before the barrier, the corrected residuals overwrite them after it.
+            double rc0 = 0.0, rc1 = 0.0; int myrec = -1;
             for (int ol = tid; ol < nob; ol += NT) {
                 const int k = c.bi[h.i_pt_lm + o0 + ol], li = k - k0, b0 = beg[k] - o0, b1 = beg[k + 1] - o0;
                 double hd = 0.0, gl = 0.0;
-                for (int o = b0; o < b1; ++o) { const double* R = rec + (size_t)o * UVS_PT_REC; hd += R[26] * R[26] + R[27] * R[27]; gl += R[26] * R[0] + R[27] * R[1]; }
+                for (int o = b0; o < b1; ++o) { const double* R = rec + (size_t)o * UVS_PT_REC; hd += R[UVS_PT_C] * R[UVS_PT_C] + R[UVS_PT_C + 1] * R[UVS_PT_C + 1]; gl += R[UVS_PT_C] * R[0] + R[UVS_PT_C + 1] * R[1]; }
                 const bool lead = ol == b0;
                 double sc;
                 if (first) { sc = c.o.jacobi ? 1.0 / (1.0 + sqrt(hd)) : 1.0; if (lead) c.ws[h.w_scale_pt + k] = sc; } else sc = c.ws[h.w_scale_pt + k];
@@ -604,29 +597,30 @@ UVS_DEV void linearize(const Ctx& c, const double* x, const double* invd, const 
                 const int s = ol - b0 + 1;
                 double* E = Eb + (size_t)(b0 + li) * 6; double* EI = EIb + (size_t)(b0 + li) * 6;
                 double* Eg = c.ws + h.w_pt_E + 6 * (size_t)(beg[k] + k);
-                {
-                    const double* R = rec + (size_t)ol * UVS_PT_REC;
+                const double* R = rec + (size_t)ol * UVS_PT_REC;
+                const double c0 = R[UVS_PT_C], c1 = R[UVS_PT_C + 1];
 #pragma unroll
-                    for (int a = 0; a < 6; ++a) { const double e = R[26] * R[14 + a] + R[27] * R[20 + a]; E[6 * s + a] = e; EI[6 * s + a] = e * hinv; Eg[6 * s + a] = e * hinv; }
-                }
+                for (int a = 0; a < 6; ++a) { const double e = c0 * R[UVS_PT_B + a] + c1 * R[UVS_PT_B + 6 + a]; E[6 * s + a] = e; EI[6 * s + a] = e * hinv; Eg[6 * s + a] = e * hinv; }
+                rc0 = R[0] - c0 * ginv; rc1 = R[1] - c1 * ginv; myrec = ol;       // r - J_l h^-1 g_l
                 if (lead) {
-                    Xb[2 * li] = hinv; Xb[2 * li + 1] = ginv;
                     double* px = c.ws + h.w_pt_x + 4 * (size_t)k; px[0] = ginv; px[1] = gl; px[2] = dd; px[3] = hd;
                     gmax_lm = fmax(gmax_lm, fabs(gl));
                     double e0[6] = {0, 0, 0, 0, 0, 0};
                     for (int o = b0; o < b1; ++o) {
-                        const double* R = rec + (size_t)o * UVS_PT_REC;
+                        const double* Ro = rec + (size_t)o * UVS_PT_REC;
 #pragma unroll
-                        for (int a = 0; a < 6; ++a) e0[a] += R[26] * R[2 + a] + R[27] * R[8 + a];
+                        for (int a = 0; a < 6; ++a) e0[a] += Ro[UVS_PT_C] * Ro[UVS_PT_A + a] + Ro[UVS_PT_C + 1] * Ro[UVS_PT_A + 6 + a];
                     }
 #pragma unroll
                     for (int a = 0; a < 6; ++a) { E[a] = e0[a]; EI[a] = e0[a] * hinv; Eg[a] = e0[a] * hinv; }
                 }
             }
             __syncthreads();
+            if (myrec >= 0) { double* R = rec + (size_t)myrec * UVS_PT_REC; R[UVS_PT_C] = rc0; R[UVS_PT_C + 1] = rc1; R[UVS_PT_RC2] = rc0; R[UVS_PT_RC2 + 1] = rc1; }
+            __syncthreads();
             UVS_PROF(c, P_LMPREP);
             const long long tg0_ = clock64();
-            gather_points(wb, lists, rec, (int)(Eb - rec), (int)(EIb - rec), (int)(Xb - rec), acc);
+            gather_points(wb, lists, rec, acc);
             if (c.o.debug && (tid & 63) == 0) sh[L_WPROF + (tid >> 6)] += (double)(clock64() - tg0_);
         } else {
             const int* beg = c.bi + h.i_ln_beg;
@@ -736,11 +730,17 @@ UVS_DEV void linearize(const Ctx& c, const double* x, const double* invd, const 
 #pragma unroll
                     for (int q = 0; q < 4; ++q) { const double y = X[4 * q] * e[0] + X[4 * q + 1] * e[1] + X[4 * q + 2] * e[2] + X[4 * q + 3] * e[3]; Y[6 * q + a] = y; Yg[6 * q + a] = y; }
                 }
+                // Schur-corrected residual rc = r - J_l (H_ll^-1 g_l) for the 2 line rows and the VP row; J_l of this record is dead now
+                const double rc0 = R[0] - (R[14] * X[16] + R[15] * X[17] + R[16] * X[18] + R[17] * X[19]);
+                const double rc1 = R[1] - (R[18] * X[16] + R[19] * X[17] + R[20] * X[18] + R[21] * X[19]);
+                const double rc2 = R[22] - (R[29] * X[16] + R[30] * X[17] + R[31] * X[18] + R[32] * X[19]);
+                double* Rw = rec + (size_t)o * UVS_LN_REC;
+                Rw[14] = rc0; Rw[15] = rc1; Rw[16] = rc2;
             }
             __syncthreads();
             UVS_PROF(c, P_LMPREP);
             const long long tg0_ = clock64();
-            gather_lines(wb, lists, rec, (int)(Eb - rec), (int)(Yb - rec), (int)(Xb - rec), acc);
+            gather_lines(wb, lists, rec, acc);
             if (c.o.debug && (tid & 63) == 0) sh[L_WPROF + (tid >> 6)] += (double)(clock64() - tg0_);
         }
     }

@@ -202,10 +202,10 @@ static int pack_window(const uvs_window* w, std::vector<char>& out, DevWin& hdr,
             const long no = pbeg[k + 1] - pbeg[k];
             const long li_k = no ? (no + 1) * (no + 2) / 2 + 3 * no : 0;
             const long nlm = k - k0 + 1;
-            const long need = (long)UVS_PT_REC * (nob + no) + 12 * (nob + no + nlm) + 2 * nlm + (nli + li_k + 1) / 2;
+            const long need = (long)UVS_PT_REC * (nob + no) + 12 * (nob + no + nlm) + (nli + li_k + 1) / 2;
             if ((need > UVS_S_DOUBLES || nlm > 1023 || nob + no + nlm > 16383) && k > k0) { chunks.insert(chunks.end(), {0, k0, k, 0, 0, 0}); k0 = k; nob = 0; nli = list_hdr; }
             nob += no; nli += li_k;
-            if ((long)UVS_PT_REC * nob + 12 * (nob + 1) + 2 + (nli + 1) / 2 > UVS_S_DOUBLES) { err = "single point landmark exceeds LDS staging"; return UVS_ERR_CAPACITY; }
+            if ((long)UVS_PT_REC * nob + 12 * (nob + 1) + (nli + 1) / 2 > UVS_S_DOUBLES) { err = "single point landmark exceeds LDS staging"; return UVS_ERR_CAPACITY; }
         }
         if (h.n_points > k0) chunks.insert(chunks.end(), {0, k0, h.n_points, 0, 0, 0});
         k0 = 0; nob = 0; nli = list_hdr;
@@ -219,9 +219,11 @@ static int pack_window(const uvs_window* w, std::vector<char>& out, DevWin& hdr,
         }
         if (h.n_lines > k0) chunks.insert(chunks.end(), {1, k0, h.n_lines, 0, 0, 0});
     }
-    // gather lists (one pair per chunk and per lower 6x6 pose block, see uvs_solve_kernel.h: gather_points / gather_lines)
-    //   Schur entry : li | slot_a << 10 | slot_b << 14 | first_slot << 18      (landmark observed in both frames of the block)
-    //   direct entry: local observation index | kind << 14                      (kind 0: A^T A, 1: B^T B, 2: B^T A ; lines: 0)
+    // gather lists (one pair per chunk and per lower 6x6 pose block, see uvs_solve_kernel.h: gather_points / gather_lines),
+    // pre-expanded into LDS offsets (doubles from the staging base; the chunk layout below mirrors linearize()):
+    //   points: rec[nob][31] | E[(nob+nlm)][6] | EI[(nob+nlm)][6] | lists      lines: rec[nob][33] | E[nob][24] | Y[nob][24] | X[nlm][20] | lists
+    //   Schur entry : offset(E row of frame a) | offset(EI / Y row of frame b) << 16
+    //   direct entry: points: offset(first Jacobian block) | offset(second) << 16   (A^T A, B^T B, B^T A) ; lines: record offset
     std::vector<int> lists;
     std::vector<long> blk_work(UVS_NBLK, 0);
     auto blk_of = [](int fa, int fb) { return fa * (fa + 1) / 2 + fb; };   // fa >= fb
@@ -229,7 +231,8 @@ static int pack_window(const uvs_window* w, std::vector<char>& out, DevWin& hdr,
         const int type = chunks[q], k0 = chunks[q + 1], k1 = chunks[q + 2];
         std::vector<std::vector<int>> sch(UVS_NBLK), dir(UVS_NBLK);
         if (type == 0) {
-            const int o0 = pbeg[k0];
+            const int o0 = pbeg[k0], nob = pbeg[k1] - o0, nlm = k1 - k0;
+            const int oE = nob * UVS_PT_REC, oEI = oE + 6 * (nob + nlm);
             for (int k = k0; k < k1; ++k) {
                 const int li = k - k0, b0 = pbeg[k] - o0, b1 = pbeg[k + 1] - o0;
                 if (b1 == b0) continue;
@@ -238,21 +241,22 @@ static int pack_window(const uvs_window* w, std::vector<char>& out, DevWin& hdr,
                 fr[nf++] = w->pt_fi[o0 + b0];
                 for (int o = b0; o < b1; ++o) fr[nf++] = w->pt_fj[o0 + o];
                 for (int sa = 0; sa < nf; ++sa) for (int sb = 0; sb <= sa; ++sb)      // frames increase with the slot => fr[sa] >= fr[sb]
-                    sch[blk_of(fr[sa], fr[sb])].push_back(li | (sa << 10) | (sb << 14) | (first_slot << 18));
+                    sch[blk_of(fr[sa], fr[sb])].push_back((oE + 6 * (first_slot + sa)) | ((oEI + 6 * (first_slot + sb)) << 16));
                 for (int o = b0; o < b1; ++o) {
-                    const int fi = w->pt_fi[o0 + o], fj = w->pt_fj[o0 + o];
-                    dir[blk_of(fi, fi)].push_back(o | (0 << 14));
-                    dir[blk_of(fj, fj)].push_back(o | (1 << 14));
-                    dir[blk_of(fj, fi)].push_back(o | (2 << 14));
+                    const int fi = w->pt_fi[o0 + o], fj = w->pt_fj[o0 + o], ro = o * UVS_PT_REC;
+                    dir[blk_of(fi, fi)].push_back((ro + UVS_PT_A) | ((ro + UVS_PT_A) << 16));
+                    dir[blk_of(fj, fj)].push_back((ro + UVS_PT_B) | ((ro + UVS_PT_B) << 16));
+                    dir[blk_of(fj, fi)].push_back((ro + UVS_PT_B) | ((ro + UVS_PT_A) << 16));
                 }
             }
         } else {
-            const int o0 = lbeg[k0];
+            const int o0 = lbeg[k0], nob = lbeg[k1] - o0;
+            const int oE = nob * UVS_LN_REC, oY = oE + 24 * nob;
             for (int k = k0; k < k1; ++k) {
-                const int li = k - k0, b0 = lbeg[k] - o0, b1 = lbeg[k + 1] - o0;
+                const int b0 = lbeg[k] - o0, b1 = lbeg[k + 1] - o0;
                 for (int sa = 0; sa < b1 - b0; ++sa) for (int sb = 0; sb <= sa; ++sb)
-                    sch[blk_of(w->ln_fj[o0 + b0 + sa], w->ln_fj[o0 + b0 + sb])].push_back(li | (sa << 10) | (sb << 14) | (b0 << 18));
-                for (int o = b0; o < b1; ++o) dir[blk_of(w->ln_fj[o0 + o], w->ln_fj[o0 + o])].push_back(o);
+                    sch[blk_of(w->ln_fj[o0 + b0 + sa], w->ln_fj[o0 + b0 + sb])].push_back((oE + 24 * (b0 + sa)) | ((oY + 24 * (b0 + sb)) << 16));
+                for (int o = b0; o < b1; ++o) dir[blk_of(w->ln_fj[o0 + o], w->ln_fj[o0 + o])].push_back(o * UVS_LN_REC);
             }
         }
         for (int b = 0; b < UVS_NBLK; ++b) blk_work[b] += (type == 0 ? 1 : 3) * (long)sch[b].size() + (type == 0 ? 2 : 2) * (long)dir[b].size();
