@@ -273,6 +273,24 @@ int uvs_debug_first_iteration(uvs_solver *s, const uvs_window *w, double *S_lowe
  * re-indexed for the next window (addr_shift, estimator.cpp:1139-1153). */
 int uvs_marginalize(uvs_solver *s, const uvs_window *w, int flag, uvs_prior *out);
 
+/* ---- ONE large window spread over the GPU and, with an all-reduce between the steps, over several GPUs (BASELINE configs[3]) ----
+ * Landmarks shard (rank r holds the landmarks k with k % G == r; frames / IMU / prior are replicated); the only exchanged data are
+ * the pose-block partials returned by uvs_large_reduced() (SUM, except entry [n-7] which is a MAX) and the 5 scalars of
+ * uvs_large_scalars() (SUM).  Both are DEVICE pointers so that RCCL can reduce them in place.  On one GPU skip the all-reduces
+ * or call uvs_large_solve().  Loop: begin; while (!done) { if (need_linearize) { linearize; allreduce(reduced) } step; allreduce(scalars); decide } finish. */
+int uvs_large_begin(uvs_solver *s, const uvs_window *w);
+int uvs_large_need_linearize(const uvs_solver *s);
+int uvs_large_linearize(uvs_solver *s);
+double *uvs_large_reduced(uvs_solver *s, int *n);
+int uvs_large_step(uvs_solver *s);
+double *uvs_large_scalars(uvs_solver *s, int *n);
+int uvs_large_decide(uvs_solver *s);
+int uvs_large_done(const uvs_solver *s);
+double uvs_large_local_x2(const uvs_solver *s);
+void uvs_large_set_landmark_x2(uvs_solver *s, double all_ranks_x2);
+int uvs_large_finish(uvs_solver *s, uvs_state *out, uvs_report *rep);
+int uvs_large_solve(uvs_solver *s, const uvs_window *w, uvs_state *out, uvs_report *rep);
+
 /* ---- size helpers for callers that serialise windows ---- */
 int uvs_reduced_dim(const uvs_options *opts);  /* 165 (+6 if estimate_extrinsic) */
 

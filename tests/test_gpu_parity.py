@@ -95,3 +95,26 @@ def test_batch_matches_single(solver, oracle):
     states2, reps2 = solver.download()
     for a, b in zip(states, states2):
         assert np.array_equal(a.pose, b.pose) and np.array_equal(a.inv_depth, b.inv_depth) and np.array_equal(a.line_orth, b.line_orth)
+
+
+def test_large_window_path_matches_oracle(solver, oracle):
+    """configs[3] code path (grid of landmark chunks + reduce + single-workgroup solve + grid back-substitution) on a window the
+    oracle still solves in seconds."""
+    w = synth.make_window(40, n_points=900, n_lines=240, n_tagged=180)
+    sg, rg = solver.large_solve(w)
+    so, ro = oracle.solve(w)
+    assert rg.status == 0 and rg.num_iterations == ro.num_iterations
+    assert list(rg.accepted[: rg.num_iterations + 1]) == list(ro.accepted[: ro.num_iterations + 1])
+    dp, da = pose_deltas(sg.pose, so.pose)
+    assert dp < 1e-4 and da < 1e-4, (dp, da)
+    assert abs(rg.final_cost - ro.final_cost) <= 1e-6 * ro.final_cost
+    assert np.abs(sg.inv_depth - so.inv_depth).max() < 1e-4 and np.abs(sg.line_orth - so.line_orth).max() < 1e-4
+
+
+def test_large_path_equals_persistent_kernel(solver):
+    w = synth.make_window(41)
+    s1, r1 = solver.solve(w)
+    s2, r2 = solver.large_solve(w)
+    assert r1.num_iterations == r2.num_iterations and list(r1.accepted[:11]) == list(r2.accepted[:11])
+    assert abs(r1.final_cost - r2.final_cost) <= 1e-9 * r1.final_cost
+    assert pose_deltas(s1.pose, s2.pose)[0] < 1e-8

@@ -51,8 +51,29 @@ def lib():
         L.uvs_debug_first_iteration.argtypes = [C.c_void_p, C.POINTER(abi.WindowC)] + [abi.c_double_p] * 6
         L.uvs_debug_first_iteration.restype = C.c_int
         L.uvs_reduced_dim.argtypes = [C.POINTER(abi.Options)]; L.uvs_reduced_dim.restype = C.c_int
+        L.uvs_large_begin.argtypes = [C.c_void_p, C.POINTER(abi.WindowC)]; L.uvs_large_begin.restype = C.c_int
+        for name in ("uvs_large_need_linearize", "uvs_large_linearize", "uvs_large_step", "uvs_large_decide", "uvs_large_done"):
+            getattr(L, name).argtypes = [C.c_void_p]; getattr(L, name).restype = C.c_int
+        L.uvs_large_reduced.argtypes = [C.c_void_p, C.POINTER(C.c_int)]; L.uvs_large_reduced.restype = C.c_void_p
+        L.uvs_large_scalars.argtypes = [C.c_void_p, C.POINTER(C.c_int)]; L.uvs_large_scalars.restype = C.c_void_p
+        L.uvs_large_local_x2.argtypes = [C.c_void_p]; L.uvs_large_local_x2.restype = C.c_double
+        L.uvs_large_set_landmark_x2.argtypes = [C.c_void_p, C.c_double]
+        L.uvs_large_finish.argtypes = [C.c_void_p, C.POINTER(abi.StateC), C.POINTER(abi.Report)]; L.uvs_large_finish.restype = C.c_int
+        L.uvs_large_solve.argtypes = [C.c_void_p, C.POINTER(abi.WindowC), C.POINTER(abi.StateC), C.POINTER(abi.Report)]; L.uvs_large_solve.restype = C.c_int
         _lib = L
     return _lib
+
+
+class _DevPtr:
+    """Exposes a raw device pointer through __cuda_array_interface__ so that torch can wrap it without a copy."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (int(ptr), False), "version": 3, "strides": None}
+
+
+def _device_tensor(ptr, n, device=None):
+    import torch
+    return torch.as_tensor(_DevPtr(ptr, n), device=device or "cuda")
 
 
 class Solver:
@@ -116,6 +137,40 @@ class Solver:
         for i, st in enumerate(states):
             st.from_c(sarr[i])
         return states, list(reps)
+
+    # ---- one large window over the whole GPU / several GPUs (BASELINE configs[3]) ----
+    def large_solve(self, w: abi.Window, dist=None, device=None):
+        """Landmark-sharded solve of ONE window.  With `dist` (an initialised torch.distributed module) `w` must hold only this
+        rank's landmarks (synth.shard_landmarks); the pose-block partials and 5 scalars are all-reduced over RCCL in place."""
+        wc, keep = w.to_c()
+        st = abi.State(len(w.inv_depth), len(w.line_orth)); sc = st.alloc_c()
+        rep = abi.Report()
+        L = lib()
+        if dist is None:
+            self._check(L.uvs_large_solve(self._h, C.byref(wc), C.byref(sc), C.byref(rep)), allow=(abi.UVS_OK, abi.UVS_ERR_NUMERIC))
+            return st.from_c(sc), rep
+        import torch
+        self._check(L.uvs_large_begin(self._h, C.byref(wc)))
+        x2 = torch.tensor([L.uvs_large_local_x2(self._h)], dtype=torch.float64, device=device)
+        dist.all_reduce(x2)
+        L.uvs_large_set_landmark_x2(self._h, float(x2.item()))
+        n = C.c_int(0)
+        red = _device_tensor(L.uvs_large_reduced(self._h, C.byref(n)), n.value, device)
+        scal = _device_tensor(L.uvs_large_scalars(self._h, C.byref(n)), n.value, device)
+        while not L.uvs_large_done(self._h):
+            if L.uvs_large_need_linearize(self._h):
+                self._check(L.uvs_large_linearize(self._h))
+                mx = red[-7].clone()                       # entry LG_ACC + 1 is a max, everything else a sum
+                dist.all_reduce(red)                       # RCCL all-reduce of the pose-block partials (36.9 KB)
+                dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+                red[-7] = mx
+                torch.cuda.synchronize()
+            self._check(L.uvs_large_step(self._h))
+            dist.all_reduce(scal)
+            torch.cuda.synchronize()
+            self._check(L.uvs_large_decide(self._h))
+        self._check(L.uvs_large_finish(self._h, C.byref(sc), C.byref(rep)), allow=(abi.UVS_OK, abi.UVS_ERR_NUMERIC))
+        return st.from_c(sc), rep
 
     # ---- diagnostics -------------------------------------------------------
     def evaluate(self, w: abi.Window, robust=True):

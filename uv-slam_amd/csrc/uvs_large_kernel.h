@@ -1,0 +1,125 @@
+// uvs_large_kernel.h -- ONE large window (BASELINE configs[3]: 20 k points + 5 k lines) spread over the whole GPU
+// and, through an all-reduce of the pose-block partials, over several GPUs.
+//
+// Landmarks are conditionally independent given the 11 frame states, so the landmark chunks that k_solve walks
+// sequentially inside one workgroup become the GRID here:
+//   k_large_chunks   grid = #chunks : stage + Schur prep + gather of one chunk  -> per-chunk partial pose blocks
+//   k_large_reduce   sums the partials in chunk order (deterministic)           -> reduced[LG_RED]  (THE all-reduce payload)
+//   k_large_solve    1 workgroup    : IMU + prior + damping, Cholesky, step, frame candidate
+//   k_large_backsub  grid = #chunks : landmark back-substitution + candidate cost of the chunk's observations
+// The LM accept / reject logic runs on the host between launches (one small read-back per iteration).
+// Multi-GPU: every rank holds the landmarks k with k % G == rank; `reduced` (pose-pose Schur blocks, reduced gradient,
+// diag(J^T J), landmark cost) is summed with ONE RCCL all-reduce (36.9 KB, latency bound), every rank then solves the same
+// reduced system redundantly; the back-substitution scalars need a second 5-double all-reduce.
+#pragma once
+#include "uvs_solve_kernel.h"
+
+namespace uvsdev {
+
+static constexpr int LG_ACC = NW * BLOCKS_PER_WAVE * 64;   // 4608 raw accumulator slots [wave][block slot][lane]
+static constexpr int LG_RED = LG_ACC + 8;                  // + {landmark cost, max |g_l|, 6 spare}
+static constexpr int LG_STATE = 1024;                      // doubles: X[184] XC[184] DLT[176] G[176] DD[176] SC[176] (offsets below)
+enum { LS_X = 0, LS_XC = 184, LS_DLT = 368, LS_G = 544, LS_DD = 720, LS_SC = 896 };
+enum { LO_COST = 0, LO_GMAX, LO_CHOLOK, LO_GD, LO_DD2, LO_STEP2, LO_XC2, LO_FRAMECOST, LO_N };
+
+__global__ __launch_bounds__(NT) void k_large_chunks(char* blob, double* ws, KOpts o, const double* state, int sel, int first, double radius, double* partials) {
+    extern __shared__ __attribute__((aligned(16))) double sh[];
+    const int tid = threadIdx.x, ch = blockIdx.x;
+    Ctx c; c.hdr = (const DevWin*)blob; c.bd = (const double*)blob; c.bi = (const int*)blob; c.ws = ws; c.sh = sh; c.o = o; c.o.debug = 0;
+    const DevWin& h = *c.hdr;
+    if (tid < 184) sh[L_X + tid] = state[LS_X + tid];
+    __syncthreads();
+    stage_rotations(c, sh + L_X);
+    __syncthreads();
+    double acc[BLOCKS_PER_WAVE]; int wb[BLOCKS_PER_WAVE];
+#pragma unroll
+    for (int q = 0; q < BLOCKS_PER_WAVE; ++q) { acc[q] = 0.0; wb[q] = __builtin_amdgcn_readfirstlane(c.bi[h.i_wblk + (tid >> 6) * BLOCKS_PER_WAVE + q]); }
+    double cost = 0.0, gmax = 0.0;
+    const double* invd = ws + (sel ? h.w_invd1 : h.w_invd0); const double* line = ws + (sel ? h.w_line1 : h.w_line0);
+    lin_chunk(c, ch, sh + L_X, invd, line, first != 0, radius, wb, acc, cost, gmax);
+    double* P = partials + (size_t)ch * LG_RED;
+#pragma unroll
+    for (int q = 0; q < BLOCKS_PER_WAVE; ++q) P[((tid >> 6) * BLOCKS_PER_WAVE + q) * 64 + (tid & 63)] = acc[q];
+    double s4[4] = {cost, 0, 0, 0};
+    block_reduce(sh, s4, &gmax);
+    if (tid == 0) { P[LG_ACC] = s4[0]; P[LG_ACC + 1] = gmax; }
+}
+
+__global__ void k_large_reduce(const double* partials, int n_chunks, double* reduced) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= LG_RED) return;
+    double s = 0.0;
+    if (i == LG_ACC + 1) { for (int ch = 0; ch < n_chunks; ++ch) s = fmax(s, partials[(size_t)ch * LG_RED + i]); }
+    else for (int ch = 0; ch < n_chunks; ++ch) s += partials[(size_t)ch * LG_RED + i];      // fixed order => deterministic
+    reduced[i] = s;
+}
+
+// one workgroup: frame terms + assembly + Cholesky + step.  `reduced` holds the (all-reduced) landmark partials.
+__global__ __launch_bounds__(NT) void k_large_solve(char* blob, double* ws, KOpts o, double* state, const double* reduced, int first, double radius, double* out) {
+    extern __shared__ __attribute__((aligned(16))) double sh[];
+    const int tid = threadIdx.x;
+    Ctx c; c.hdr = (const DevWin*)blob; c.bd = (const double*)blob; c.bi = (const int*)blob; c.ws = ws; c.sh = sh; c.o = o; c.o.debug = 0;
+    const DevWin& h = *c.hdr;
+    if (tid < 184) sh[L_X + tid] = state[LS_X + tid];
+    if (tid < UVS_RD && !first) sh[L_SC + tid] = state[LS_SC + tid];
+    if (first) setup_window(c, (double*)blob);
+    __syncthreads();
+    double acc[BLOCKS_PER_WAVE]; int wb[BLOCKS_PER_WAVE];
+#pragma unroll
+    for (int q = 0; q < BLOCKS_PER_WAVE; ++q) { wb[q] = __builtin_amdgcn_readfirstlane(c.bi[h.i_wblk + (tid >> 6) * BLOCKS_PER_WAVE + q]); acc[q] = reduced[((tid >> 6) * BLOCKS_PER_WAVE + q) * 64 + (tid & 63)]; }
+    double cost = lin_frames(c, sh + L_X);
+    if (tid == 0) cost += reduced[LG_ACC];
+    __syncthreads();
+    lin_assemble(c, sh + L_X, first != 0, radius, wb, acc, cost, reduced[LG_ACC + 1]);
+    if (tid < UVS_RD) sh[L_DLT + tid] = -sh[L_G + tid];
+    chol_factor(c);
+    chol_solve(c);
+    backsub_candidate(c, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, true, out + LO_GD);      // frames only
+    if (tid < UVS_RD) { state[LS_DLT + tid] = sh[L_DLT + tid]; state[LS_G + tid] = sh[L_G + tid]; state[LS_DD + tid] = sh[L_DD + tid]; state[LS_SC + tid] = sh[L_SC + tid]; }
+    if (tid < 184) state[LS_XC + tid] = sh[L_XC + tid];
+    // frame-only part of the candidate cost (prior + IMU at x_c)
+    __syncthreads();
+    stage_rotations(c, sh + L_XC);
+    prior_dx(c, sh + L_XC);
+    __syncthreads();
+    double cc = prior_residual(c) + cost_pass(c, sh + L_XC, nullptr, nullptr, 0, 0, 0, 0, true);
+    double s4[4] = {cc, 0, 0, 0}, mx = 0.0;
+    block_reduce(sh, s4, &mx);
+    if (tid == 0) { out[LO_COST] = sh[L_CTRL + C_COST]; out[LO_GMAX] = sh[L_CTRL + C_GMAX]; out[LO_CHOLOK] = sh[L_CTRL + C_CHOLOK]; out[LO_FRAMECOST] = s4[0]; }
+}
+
+// per chunk: landmark back-substitution (candidate parameters into the other buffer) + candidate cost of the chunk's observations
+__global__ __launch_bounds__(NT) void k_large_backsub(char* blob, double* ws, KOpts o, const double* state, int sel, double* bsums) {
+    extern __shared__ __attribute__((aligned(16))) double sh[];
+    const int tid = threadIdx.x, ch = blockIdx.x;
+    Ctx c; c.hdr = (const DevWin*)blob; c.bd = (const double*)blob; c.bi = (const int*)blob; c.ws = ws; c.sh = sh; c.o = o; c.o.debug = 0;
+    const DevWin& h = *c.hdr;
+    if (tid < 184) sh[L_XC + tid] = state[LS_XC + tid];
+    if (tid < UVS_RD) sh[L_DLT + tid] = state[LS_DLT + tid];
+    __syncthreads();
+    stage_rotations(c, sh + L_XC);
+    const int* chunk = c.bi + h.i_chunks + 6 * ch;
+    const int type = chunk[0], k0 = chunk[1], k1 = chunk[2];
+    double* invd = ws + (sel ? h.w_invd1 : h.w_invd0); double* line = ws + (sel ? h.w_line1 : h.w_line0);
+    double* invd_c = ws + (sel ? h.w_invd0 : h.w_invd1); double* line_c = ws + (sel ? h.w_line0 : h.w_line1);
+    double* out = bsums + 8 * (size_t)ch;
+    backsub_candidate(c, invd, line, invd_c, line_c, type == 0 ? k0 : 0, type == 0 ? k1 : 0, type == 1 ? k0 : 0, type == 1 ? k1 : 0, false, out);
+    __threadfence_block();
+    __syncthreads();
+    const int* pbeg = c.bi + h.i_pt_beg; const int* lbeg = c.bi + h.i_ln_beg;
+    const int po0 = type == 0 ? pbeg[k0] : 0, po1 = type == 0 ? pbeg[k1] : 0, lo0 = type == 1 ? lbeg[k0] : 0, lo1 = type == 1 ? lbeg[k1] : 0;
+    double cc = cost_pass(c, sh + L_XC, invd_c, line_c, po0, po1, lo0, lo1, false);
+    double s4[4] = {cc, 0, 0, 0}, mx = 0.0;
+    block_reduce(sh, s4, &mx);
+    if (tid == 0) out[4] = s4[0];
+}
+
+__global__ void k_large_sum_bsums(const double* bsums, int n_chunks, double* out5) {
+    const int i = threadIdx.x;
+    if (i >= 5) return;
+    double s = 0.0;
+    for (int ch = 0; ch < n_chunks; ++ch) s += bsums[8 * (size_t)ch + i];
+    out5[i] = s;
+}
+
+}  // namespace uvsdev

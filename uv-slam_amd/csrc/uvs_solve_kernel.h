@@ -163,13 +163,13 @@ UVS_DEV double prior_residual(const Ctx& c) {   // after prior_dx + barrier; fil
 }
 
 // cost of all residual blocks at the point staged in (x, RF/EX) with landmark buffers invd / line
-UVS_DEV double cost_pass(const Ctx& c, const double* x, const double* invd, const double* line) {
+UVS_DEV double cost_pass(const Ctx& c, const double* x, const double* invd, const double* line, int po0, int po1, int lo0, int lo1, bool with_imu) {
     const DevWin& h = *c.hdr;
     const int tid = threadIdx.x;
     const double* RF = c.sh + L_RF; const double* ric = c.sh + L_EX; const double* tic = c.sh + L_EX + 9;
     double cost = 0.0;
     // points
-    for (int o = tid; o < h.n_pt_obs; o += NT) {
+    for (int o = po0 + tid; o < po1; o += NT) {
         const int lm = c.bi[h.i_pt_lm + o], fi = c.bi[h.i_pt_fi + o], fj = c.bi[h.i_pt_fj + o];
         const double* m = c.bd + h.d_ptmeas + o; const int st = h.pt_stride;
         const double pi[3] = {m[0], m[st], m[2 * st]}, pj[3] = {m[3 * st], m[4 * st], m[5 * st]};
@@ -178,7 +178,7 @@ UVS_DEV double cost_pass(const Ctx& c, const double* x, const double* invd, cons
         double sc; cost += 0.5 * cauchy(c.o.loss_pt, r[0] * r[0] + r[1] * r[1], &sc);
     }
     // lines + vp
-    for (int o = tid; o < h.n_ln_obs; o += NT) {
+    for (int o = lo0 + tid; o < lo1; o += NT) {
         const int lm = c.bi[h.i_ln_lm + o], fj = c.bi[h.i_ln_fj + o], hv = c.bi[h.i_ln_vp + o];
         const double* m = c.bd + h.d_lnmeas + o; const int st = h.ln_stride;
         const double sp[3] = {m[0], m[st], m[2 * st]}, ep[3] = {m[3 * st], m[4 * st], m[5 * st]}, vp[3] = {m[6 * st], m[7 * st], m[8 * st]};
@@ -190,7 +190,7 @@ UVS_DEV double cost_pass(const Ctx& c, const double* x, const double* invd, cons
         if (hv) { double rv; vp_residual<false>(g, vp, c.o.vp_factor, &rv, nullptr, nullptr); cost += 0.5 * cauchy(c.o.loss_vp, rv * rv, &sc); }
     }
     // IMU: one lane per block (residual only: 15x15 upper-triangular whitening)
-    if (tid < h.n_imu) {
+    if (with_imu && tid < h.n_imu) {
         const int fi = c.bi[h.i_imu + 2 * tid], skip = c.bi[h.i_imu + 2 * tid + 1];
         if (!skip) {
             const double* blk = c.bd + h.d_imu + (size_t)tid * UVS_IMU_STRIDE;
@@ -489,17 +489,12 @@ UVS_DEV void gather_lines(const int* wb, const int* lists, const double* S0, dou
     }
 }
 
-UVS_DEV void linearize(const Ctx& c, const double* x, const double* invd, const double* line, bool first, double radius) {
+// ---- linearization, part 1: frame-only terms at x (rotations, prior residual, IMU blocks -> workspace). Returns this lane's cost share.
+UVS_DEV double lin_frames(const Ctx& c, const double* x) {
     const DevWin& h = *c.hdr;
     double* sh = c.sh;
     const int tid = threadIdx.x;
-    const double* RF = sh + L_RF; const double* ric = sh + L_EX; const double* tic = sh + L_EX + 9;
-    double cost = 0.0, gmax_lm = 0.0;
-    double acc[BLOCKS_PER_WAVE];
-    int wb[BLOCKS_PER_WAVE];       // this wave's pose blocks (wave-uniform => SGPRs), fetched once per linearization
-#pragma unroll
-    for (int q = 0; q < BLOCKS_PER_WAVE; ++q) { acc[q] = 0.0; wb[q] = __builtin_amdgcn_readfirstlane(c.bi[h.i_wblk + (tid >> 6) * BLOCKS_PER_WAVE + q]); }
-
+    double cost = 0.0;
     UVS_PROF(c, P_MISC);
     stage_rotations(c, x);
     prior_dx(c, x);
@@ -547,10 +542,18 @@ UVS_DEV void linearize(const Ctx& c, const double* x, const double* invd, const 
         }
     }
     UVS_PROF(c, P_AS_IMU);
+    return cost;
+}
 
-    // ---- landmark chunks: stage -> per-landmark Schur prep -> list-driven gather
+// ---- linearization, part 2: one landmark chunk: stage -> per-landmark Schur prep -> list-driven gather into acc[]
+UVS_DEV void lin_chunk(const Ctx& c, int ch, const double* x, const double* invd, const double* line, bool first, double radius,
+                       const int* wb, double* acc, double& cost, double& gmax_lm) {
+    const DevWin& h = *c.hdr;
+    double* sh = c.sh;
+    const int tid = threadIdx.x;
+    const double* RF = sh + L_RF; const double* ric = sh + L_EX; const double* tic = sh + L_EX + 9;
     const int* chunks = c.bi + h.i_chunks;
-    for (int ch = 0; ch < h.n_chunks; ++ch) {
+    {
         const int type = chunks[6 * ch], k0 = chunks[6 * ch + 1], k1 = chunks[6 * ch + 2];
         const int* glists = c.bi + h.i_lists + chunks[6 * ch + 3];      // gather lists of this chunk (HBM)
         const int nlist = chunks[6 * ch + 4];
@@ -744,6 +747,13 @@ UVS_DEV void linearize(const Ctx& c, const double* x, const double* invd, const 
             if (c.o.debug && (tid & 63) == 0) sh[L_WPROF + (tid >> 6)] += (double)(clock64() - tg0_);
         }
     }
+}
+
+// ---- linearization, part 3: assemble the damped reduced system in LDS from the gathered pose blocks + IMU + prior
+UVS_DEV void lin_assemble(const Ctx& c, const double* x, bool first, double radius, const int* wb, const double* acc, double cost, double gmax_lm) {
+    const DevWin& h = *c.hdr;
+    double* sh = c.sh;
+    const int tid = threadIdx.x;
     __syncthreads();
     UVS_PROF(c, P_GATHER);
     // ---- assemble the reduced system in LDS
@@ -841,16 +851,29 @@ UVS_DEV void linearize(const Ctx& c, const double* x, const double* invd, const 
     UVS_PROF(c, P_ASSEMBLE);
 }
 
+UVS_DEV void linearize(const Ctx& c, const double* x, const double* invd, const double* line, bool first, double radius) {
+    const DevWin& h = *c.hdr;
+    const int tid = threadIdx.x;
+    double acc[BLOCKS_PER_WAVE];
+    int wb[BLOCKS_PER_WAVE];       // this wave's pose blocks (wave-uniform => SGPRs), fetched once per linearization
+#pragma unroll
+    for (int q = 0; q < BLOCKS_PER_WAVE; ++q) { acc[q] = 0.0; wb[q] = __builtin_amdgcn_readfirstlane(c.bi[h.i_wblk + (tid >> 6) * BLOCKS_PER_WAVE + q]); }
+    double cost = lin_frames(c, x), gmax_lm = 0.0;
+    for (int ch = 0; ch < h.n_chunks; ++ch) lin_chunk(c, ch, x, invd, line, first, radius, wb, acc, cost, gmax_lm);
+    lin_assemble(c, x, first, radius, wb, acc, cost, gmax_lm);
+}
+
 // ------------------------------------------------------------------ back-substitution + candidate + model terms
 // frames: XC = X (+) DLT ; landmarks: cand = cur + delta.  Accumulates into CTRL: MCC, STEP2, XC2.
-UVS_DEV void backsub_candidate(const Ctx& c, const double* invd, const double* line, double* invd_c, double* line_c) {
+UVS_DEV void backsub_candidate(const Ctx& c, const double* invd, const double* line, double* invd_c, double* line_c,
+                                  int pk0, int pk1, int lk0, int lk1, bool with_frames, double* sums_out) {
     const DevWin& h = *c.hdr;
     double* sh = c.sh;
     const int tid = threadIdx.x;
     const double* d = sh + L_DLT;
     double gd = 0.0, dd2 = 0.0, step2 = 0.0, xc2 = 0.0;
-    if (tid < UVS_RD && (tid & 15) < 15) { gd += sh[L_G + tid] * d[tid]; dd2 += sh[L_DD + tid] * d[tid] * d[tid]; }
-    if (tid < UVS_NF) {
+    if (with_frames && tid < UVS_RD && (tid & 15) < 15) { gd += sh[L_G + tid] * d[tid]; dd2 += sh[L_DD + tid] * d[tid] * d[tid]; }
+    if (with_frames && tid < UVS_NF) {
         double xp[7];
         pose_plus(sh + L_X + 7 * tid, d + 16 * tid, xp);
 #pragma unroll
@@ -858,10 +881,10 @@ UVS_DEV void backsub_candidate(const Ctx& c, const double* invd, const double* l
 #pragma unroll
         for (int k = 0; k < 9; ++k) { const double v = sh[L_X + 77 + 9 * tid + k] + d[16 * tid + 6 + k]; sh[L_XC + 77 + 9 * tid + k] = v; step2 += d[16 * tid + 6 + k] * d[16 * tid + 6 + k]; xc2 += v * v; }
     }
-    if (tid == UVS_NF) { for (int k = 0; k < 8; ++k) sh[L_XC + 176 + k] = sh[L_X + 176 + k]; }   // Ex_Pose constant (ESTIMATE_EXTRINSIC=0)
+    if (with_frames && tid == UVS_NF) { for (int k = 0; k < 8; ++k) sh[L_XC + 176 + k] = sh[L_X + 176 + k]; }   // Ex_Pose constant (ESTIMATE_EXTRINSIC=0)
     // points: delta = -ginv - sum_s Einv[s] . delta_pose(frame(s))
     const int* pbeg = c.bi + h.i_pt_beg;
-    for (int k = tid; k < h.n_points; k += NT) {
+    for (int k = pk0 + tid; k < pk1; k += NT) {
         const int b0 = pbeg[k], b1 = pbeg[k + 1];
         const double* px = c.ws + h.w_pt_x + 4 * (size_t)k;
         const double* Eg = c.ws + h.w_pt_E + 6 * (size_t)(b0 + k);
@@ -885,7 +908,7 @@ UVS_DEV void backsub_candidate(const Ctx& c, const double* invd, const double* l
     }
     // lines: delta(4) = -Hinv g - sum_s Y[s] delta_pose
     const int* lbeg = c.bi + h.i_ln_beg;
-    for (int k = tid; k < h.n_lines; k += NT) {
+    for (int k = lk0 + tid; k < lk1; k += NT) {
         const int b0 = lbeg[k], b1 = lbeg[k + 1];
         const double* lx = c.ws + h.w_ln_x + 12 * (size_t)k;
         double t[4] = {0.0, 0.0, 0.0, 0.0};
@@ -912,6 +935,7 @@ UVS_DEV void backsub_candidate(const Ctx& c, const double* invd, const double* l
         sh[L_CTRL + C_MCC] = 0.5 * (s4[1] - s4[0]);     // model_cost_change = -(J d).(r + J d/2) with (H + D) d = -g
         sh[L_CTRL + C_STEP2] = s4[2];
         sh[L_CTRL + C_XC2] = s4[3];
+        if (sums_out) { sums_out[0] = s4[0]; sums_out[1] = s4[1]; sums_out[2] = s4[2]; sums_out[3] = s4[3]; }
     }
     __syncthreads();
 }
@@ -1057,7 +1081,7 @@ __global__ __launch_bounds__(NT) void k_solve(char* blobs, const long long* blob
         chol_solve(c);
         UVS_PROF(c, P_TRSV);
         bool ok = sh[L_CTRL + C_CHOLOK] != 0.0;
-        backsub_candidate(c, invd[cur], line[cur], invd[cur ^ 1], line[cur ^ 1]);
+        backsub_candidate(c, invd[cur], line[cur], invd[cur ^ 1], line[cur ^ 1], 0, h.n_points, 0, h.n_lines, true, nullptr);
         UVS_PROF(c, P_BACKSUB);
         const double mcc = sh[L_CTRL + C_MCC], step2 = sh[L_CTRL + C_STEP2], xc2 = sh[L_CTRL + C_XC2];
         if (o.debug && it == 1 && dbg.S) {
@@ -1080,7 +1104,7 @@ __global__ __launch_bounds__(NT) void k_solve(char* blobs, const long long* blob
         prior_dx(c, sh + L_XC);
         __syncthreads();
         double cc_ = prior_residual(c);
-        cc_ += cost_pass(c, sh + L_XC, invd[cur ^ 1], line[cur ^ 1]);
+        cc_ += cost_pass(c, sh + L_XC, invd[cur ^ 1], line[cur ^ 1], 0, h.n_pt_obs, 0, h.n_ln_obs, true);
         double s4[4] = {cc_, 0, 0, 0}, mx = 0.0;
         block_reduce(sh, s4, &mx);
         UVS_PROF(c, P_COST);

@@ -21,6 +21,7 @@
 #include "uvs_solve_kernel.h"
 #include "uvs_eval_kernel.h"
 #include "uvs_marg.h"
+#include "uvs_large_kernel.h"
 
 using namespace uvsdev;
 
@@ -41,6 +42,15 @@ struct uvs_solver {
     long long* d_blob_off = nullptr; long long* d_ws_off = nullptr; size_t d_off_cap = 0;
     uvs_report* d_reports = nullptr; size_t d_rep_cap = 0;
     double* d_dbg = nullptr;
+    // large-window (configs[3]) run state
+    struct Large {
+        bool active = false; int n_chunks = 0, sel = 0, it = 0, invalid = 0, nsucc = 0, pending = 0, term = 0, status = 0;
+        bool need_lin = true, first = true, done = false;
+        double radius = 0, decr = 2, cost = 0, gmax = 0, x_norm = 0, local_x2 = 0;
+        double *d_state = nullptr, *d_partials = nullptr, *d_reduced = nullptr, *d_bsums = nullptr, *d_out = nullptr, *d_sc5 = nullptr;
+        size_t cap_partials = 0, cap_bsums = 0;
+        uvs_report rep;
+    } L;
 };
 
 #define HIPCHK(s, call)                                                                              \
@@ -509,6 +519,167 @@ int uvs_marginalize(uvs_solver* s, const uvs_window* w, int flag, uvs_prior* out
     int rc = uvs_batch_upload(s, 1, arr);
     if (rc != UVS_OK) return rc;
     return run_marginalize(s->device, s->stream, s->d_blobs, s->d_ws, s->hdrs[0], w, make_kopts(s->opts, 0), flag, out, s->err);
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------ large single window (configs[3]), optionally multi-GPU
+// Step-wise so that the caller can all-reduce the two device vectors between steps (RCCL through torch.distributed in
+// bench.py / api.py; nothing to reduce on one GPU):
+//   uvs_large_begin -> loop { uvs_large_linearize -> [all-reduce SUM of uvs_large_reduced()] -> uvs_large_step
+//                             -> [all-reduce SUM of uvs_large_scalars()] -> uvs_large_decide } -> uvs_large_finish
+extern "C" {
+
+int uvs_large_begin(uvs_solver* s, const uvs_window* w) {
+    if (!s || !w) return UVS_ERR_INVALID_ARG;
+    const uvs_window* arr[1] = {w};
+    int rc = uvs_batch_upload(s, 1, arr);
+    if (rc != UVS_OK) return rc;
+    auto& L = s->L; const DevWin& h = s->hdrs[0];
+    L = uvs_solver::Large{L.active, 0, 0, 0, 0, 0, 0, 0, 0, true, true, false, 0, 2, 0, 0, 0, 0, L.d_state, L.d_partials, L.d_reduced, L.d_bsums, L.d_out, L.d_sc5, L.cap_partials, L.cap_bsums, {}};
+    L.active = true; L.n_chunks = h.n_chunks; L.radius = s->opts.initial_trust_region_radius;
+    if (!L.d_state) { HIPCHK(s, hipMalloc((void**)&L.d_state, LG_STATE * 8)); HIPCHK(s, hipMalloc((void**)&L.d_reduced, LG_RED * 8)); HIPCHK(s, hipMalloc((void**)&L.d_out, 64 * 8)); HIPCHK(s, hipMalloc((void**)&L.d_sc5, 8 * 8)); }
+    int r2;
+    if ((r2 = ensure(s, (void**)&L.d_partials, &L.cap_partials, (size_t)std::max(L.n_chunks, 1) * LG_RED * 8)) != UVS_OK) return r2;
+    if ((r2 = ensure(s, (void**)&L.d_bsums, &L.cap_bsums, (size_t)std::max(L.n_chunks, 1) * 8 * 8)) != UVS_OK) return r2;
+    HIPCHK(s, hipMemsetAsync(L.d_state, 0, LG_STATE * 8, s->stream));
+    // frames -> state.X ; landmark parameters -> workspace buffer 0 (device-to-device from the blob)
+    HIPCHK(s, hipMemcpyAsync(L.d_state + LS_X, s->d_blobs + (size_t)h.d_frames * 8, 183 * 8, hipMemcpyDeviceToDevice, s->stream));
+    if (h.n_points) HIPCHK(s, hipMemcpyAsync(s->d_ws + h.w_invd0, s->d_blobs + (size_t)h.d_invd * 8, (size_t)h.n_points * 8, hipMemcpyDeviceToDevice, s->stream));
+    if (h.n_lines) HIPCHK(s, hipMemcpyAsync(s->d_ws + h.w_line0, s->d_blobs + (size_t)h.d_line * 8, (size_t)h.n_lines * 32, hipMemcpyDeviceToDevice, s->stream));
+    double x2 = 0.0;
+    for (int f = 0; f < UVS_NUM_FRAMES; ++f) { for (int k = 0; k < 7; ++k) x2 += w->pose[f][k] * w->pose[f][k]; for (int k = 0; k < 9; ++k) x2 += w->speedbias[f][k] * w->speedbias[f][k]; }
+    double l2 = 0.0;
+    for (int k = 0; k < w->n_points; ++k) l2 += w->inv_depth[k] * w->inv_depth[k];
+    for (int k = 0; k < 4 * w->n_lines; ++k) l2 += w->line_orth[k] * w->line_orth[k];
+    L.local_x2 = l2; L.x_norm = std::sqrt(x2 + l2);
+    std::memset(&L.rep, 0, sizeof(L.rep));
+    static bool attr = false;
+    if (!attr) {
+        HIPCHK(s, hipFuncSetAttribute((const void*)k_large_chunks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+        HIPCHK(s, hipFuncSetAttribute((const void*)k_large_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+        HIPCHK(s, hipFuncSetAttribute((const void*)k_large_backsub, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+        attr = true;
+    }
+    HIPCHK(s, hipStreamSynchronize(s->stream));
+    return UVS_OK;
+}
+
+// landmark part of ||x||^2 of THIS rank (sum over ranks + frames gives Ceres' x_norm^2); set the global value with uvs_large_set_landmark_x2
+double uvs_large_local_x2(const uvs_solver* s) { return s ? s->L.local_x2 : 0.0; }
+void uvs_large_set_landmark_x2(uvs_solver* s, double all_ranks_x2) { if (s) { auto& L = s->L; L.x_norm = std::sqrt(L.x_norm * L.x_norm - L.local_x2 + all_ranks_x2); L.local_x2 = all_ranks_x2; } }
+
+int uvs_large_need_linearize(const uvs_solver* s) { return s && s->L.active && !s->L.done && s->L.need_lin; }
+int uvs_large_done(const uvs_solver* s) { return !s || !s->L.active || s->L.done; }
+double* uvs_large_reduced(uvs_solver* s, int* n) { if (n) *n = LG_RED; return s ? s->L.d_reduced : nullptr; }     // DEVICE pointer; [LG_ACC+1] is a MAX entry
+double* uvs_large_scalars(uvs_solver* s, int* n) { if (n) *n = 5; return s ? s->L.d_sc5 : nullptr; }             // DEVICE pointer
+
+int uvs_large_linearize(uvs_solver* s) {
+    if (!s || !s->L.active) return UVS_ERR_INVALID_ARG;
+    auto& L = s->L;
+    HIPCHK(s, hipSetDevice(s->device));
+    KOpts ko = make_kopts(s->opts, 0);
+    if (L.n_chunks > 0) hipLaunchKernelGGL(k_large_chunks, dim3(L.n_chunks), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, L.sel, L.first ? 1 : 0, L.radius, L.d_partials);
+    hipLaunchKernelGGL(k_large_reduce, dim3((LG_RED + 255) / 256), dim3(256), 0, s->stream, L.d_partials, L.n_chunks, L.d_reduced);
+    HIPCHK(s, hipGetLastError());
+    HIPCHK(s, hipStreamSynchronize(s->stream));
+    return UVS_OK;
+}
+
+int uvs_large_step(uvs_solver* s) {
+    if (!s || !s->L.active) return UVS_ERR_INVALID_ARG;
+    auto& L = s->L;
+    HIPCHK(s, hipSetDevice(s->device));
+    KOpts ko = make_kopts(s->opts, 0);
+    hipLaunchKernelGGL(k_large_solve, dim3(1), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, L.d_reduced, L.first ? 1 : 0, L.radius, L.d_out);
+    if (L.n_chunks > 0) hipLaunchKernelGGL(k_large_backsub, dim3(L.n_chunks), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, L.sel, L.d_bsums);
+    hipLaunchKernelGGL(k_large_sum_bsums, dim3(1), dim3(64), 0, s->stream, L.d_bsums, L.n_chunks, L.d_sc5);
+    HIPCHK(s, hipGetLastError());
+    HIPCHK(s, hipStreamSynchronize(s->stream));
+    return UVS_OK;
+}
+
+// Host side of the trust-region loop (same order of tests as k_solve / SURVEY.md Appendix B).  Call after uvs_large_step (and after the
+// caller all-reduced uvs_large_scalars()).  Note: on this path a (re)linearization is implied by need_lin BEFORE the next step.
+int uvs_large_decide(uvs_solver* s) {
+    if (!s || !s->L.active) return UVS_ERR_INVALID_ARG;
+    auto& L = s->L; const uvs_options& o = s->opts;
+    double out[LO_N + 8], sc[5];
+    HIPCHK(s, hipMemcpy(out, L.d_out, sizeof(double) * (LO_N + 4), hipMemcpyDeviceToHost));
+    HIPCHK(s, hipMemcpy(sc, L.d_sc5, sizeof(sc), hipMemcpyDeviceToHost));
+    uvs_report& rep = L.rep;
+    const double lc = out[LO_COST]; const double gm = out[LO_GMAX];
+    if (L.first) {
+        L.cost = lc; L.gmax = gm; L.first = false;
+        rep.initial_cost = lc; rep.cost[0] = lc; rep.radius[0] = L.radius; rep.gradient_max_norm[0] = gm; rep.accepted[0] = 1;
+        if (!std::isfinite(lc)) { L.term = UVS_TERM_NUMERIC_FAILURE; L.status = UVS_ERR_NUMERIC; L.done = true; return UVS_OK; }
+    } else if (L.pending > 0) { L.cost = lc; L.gmax = gm; rep.cost[L.pending] = lc; rep.gradient_max_norm[L.pending] = gm; }
+    L.pending = 0; L.need_lin = false;
+    if (L.it >= o.max_num_iterations) { L.term = UVS_TERM_NO_CONVERGENCE; L.done = true; return UVS_OK; }
+    if (L.gmax <= o.gradient_tolerance) { L.term = UVS_TERM_GRADIENT_TOL; L.done = true; return UVS_OK; }
+    if (L.radius <= o.min_trust_region_radius) { L.term = UVS_TERM_MIN_RADIUS; L.done = true; return UVS_OK; }
+    ++L.it;
+    const int ti = L.it < UVS_MAX_ITER ? L.it : UVS_MAX_ITER;
+    const double gd = out[LO_GD] + sc[0], dd2 = out[LO_DD2] + sc[1], step2 = out[LO_STEP2] + sc[2], xc2 = out[LO_XC2] + sc[3];
+    const double mcc = 0.5 * (dd2 - gd);
+    double cand = out[LO_FRAMECOST] + sc[4];
+    bool ok = out[LO_CHOLOK] != 0.0 && std::isfinite(mcc) && std::isfinite(step2);
+    rep.model_cost_change[ti] = mcc;
+    if (!ok || !(mcc > 0.0)) {
+        ++L.invalid; L.radius /= L.decr; L.decr *= 2.0; L.need_lin = true;
+        rep.accepted[ti] = -1; rep.cost[ti] = L.cost; rep.candidate_cost[ti] = L.cost; rep.radius[ti] = L.radius; rep.gradient_max_norm[ti] = L.gmax;
+        if (L.invalid >= o.max_consecutive_invalid_steps) { L.term = UVS_TERM_INVALID_STEPS; L.done = true; }
+        return UVS_OK;
+    }
+    L.invalid = 0;
+    if (!std::isfinite(cand)) cand = 1.7976931348623157e308;
+    const double step_norm = std::sqrt(step2), rel = (L.cost - cand) / mcc;
+    const bool successful = rel > o.min_relative_decrease;
+    rep.candidate_cost[ti] = cand; rep.step_norm[ti] = step_norm; rep.relative_decrease[ti] = rel; rep.cost[ti] = L.cost; rep.radius[ti] = L.radius; rep.gradient_max_norm[ti] = L.gmax;
+    bool stop = false;
+    if (step_norm <= o.parameter_tolerance * (L.x_norm + o.parameter_tolerance)) { L.term = UVS_TERM_PARAMETER_TOL; stop = true; }
+    else if (std::fabs(L.cost - cand) <= o.function_tolerance * L.cost) { L.term = UVS_TERM_FUNCTION_TOL; stop = true; }
+    if (stop && !(o.function_tol_keeps_candidate && successful)) { L.done = true; return UVS_OK; }
+    if (successful) {
+        HIPCHK(s, hipMemcpy(L.d_state + LS_X, L.d_state + LS_XC, 184 * 8, hipMemcpyDeviceToDevice));
+        L.sel ^= 1; ++L.nsucc; L.x_norm = std::sqrt(xc2);
+        L.radius = L.radius / std::fmax(1.0 / 3.0, 1.0 - std::pow(2.0 * rel - 1.0, 3.0));
+        L.radius = std::fmin(o.max_trust_region_radius, L.radius); L.decr = 2.0;
+        L.cost = cand; L.need_lin = true; L.pending = ti;
+        rep.accepted[ti] = 1; rep.cost[ti] = L.cost; rep.radius[ti] = L.radius;
+        if (stop || L.it >= o.max_num_iterations) { if (!stop) L.term = UVS_TERM_NO_CONVERGENCE; L.done = true; }
+    } else {
+        L.radius /= L.decr; L.decr *= 2.0; L.need_lin = true;
+        rep.accepted[ti] = 0; rep.radius[ti] = L.radius;
+        if (L.it >= o.max_num_iterations) { L.term = UVS_TERM_NO_CONVERGENCE; L.done = true; }
+    }
+    return UVS_OK;
+}
+
+int uvs_large_finish(uvs_solver* s, uvs_state* out, uvs_report* rep) {
+    if (!s || !s->L.active || !out || !rep) return UVS_ERR_INVALID_ARG;
+    auto& L = s->L; const DevWin& h = s->hdrs[0];
+    L.rep.status = L.status; L.rep.termination = L.term; L.rep.num_iterations = L.it; L.rep.num_successful = L.nsucc; L.rep.final_cost = L.cost;
+    *rep = L.rep;
+    double fr[184];
+    HIPCHK(s, hipMemcpy(fr, L.d_state + LS_X, sizeof(fr), hipMemcpyDeviceToHost));
+    std::memcpy(out->pose, fr, 77 * 8); std::memcpy(out->speedbias, fr + 77, 99 * 8); std::memcpy(out->ex_pose, fr + 176, 7 * 8); out->td = 0.0;
+    if (out->inv_depth && h.n_points) HIPCHK(s, hipMemcpy(out->inv_depth, s->d_ws + (L.sel ? h.w_invd1 : h.w_invd0), (size_t)h.n_points * 8, hipMemcpyDeviceToHost));
+    if (out->line_orth && h.n_lines) HIPCHK(s, hipMemcpy(out->line_orth, s->d_ws + (L.sel ? h.w_line1 : h.w_line0), (size_t)h.n_lines * 32, hipMemcpyDeviceToHost));
+    L.active = false;
+    return L.status;
+}
+
+// single-GPU convenience: the loop above with nothing to all-reduce; elapsed_ms (may be NULL) = wall time of the loop
+int uvs_large_solve(uvs_solver* s, const uvs_window* w, uvs_state* out, uvs_report* rep) {
+    int rc = uvs_large_begin(s, w);
+    if (rc != UVS_OK) return rc;
+    while (!uvs_large_done(s)) {
+        if (uvs_large_need_linearize(s)) { if ((rc = uvs_large_linearize(s)) != UVS_OK) return rc; }
+        if ((rc = uvs_large_step(s)) != UVS_OK) return rc;
+        if ((rc = uvs_large_decide(s)) != UVS_OK) return rc;
+    }
+    return uvs_large_finish(s, out, rep);
 }
 
 }  // extern "C"

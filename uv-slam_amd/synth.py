@@ -383,3 +383,18 @@ def algorithmic_bytes(w: abi.Window):
         b_in += 8 * (n * n + n + 86)
     b_out = 8 * (16 * F + n_p + 4 * n_l)
     return b_in + b_out
+
+
+def shard_landmarks(w: abi.Window, rank: int, world: int):
+    """Sub-window holding the landmarks k with k % world == rank (frames / IMU / prior replicated) -- SURVEY.md section 8e."""
+    o = w.copy()
+    pk = np.arange(len(w.inv_depth)) % world == rank
+    lk = np.arange(len(w.line_orth)) % world == rank
+    pmap = np.cumsum(pk) - 1; lmap = np.cumsum(lk) - 1
+    po = pk[w.pt_lm] if len(w.pt_lm) else np.zeros(0, bool)
+    lo = lk[w.ln_lm] if len(w.ln_lm) else np.zeros(0, bool)
+    o.inv_depth = w.inv_depth[pk]; o.line_orth = w.line_orth[lk]
+    o.pt_lm = pmap[w.pt_lm[po]].astype(np.int32); o.pt_fi = w.pt_fi[po]; o.pt_fj = w.pt_fj[po]; o.pt_pi = w.pt_pi[po]; o.pt_pj = w.pt_pj[po]
+    o.ln_lm = lmap[w.ln_lm[lo]].astype(np.int32); o.ln_fj = w.ln_fj[lo]; o.ln_sp = w.ln_sp[lo]; o.ln_ep = w.ln_ep[lo]
+    o.ln_has_vp = w.ln_has_vp[lo]; o.ln_vp = w.ln_vp[lo]
+    return o, np.nonzero(pk)[0], np.nonzero(lk)[0]
