@@ -282,6 +282,7 @@ int uvs_large_begin(uvs_solver *s, const uvs_window *w);
 int uvs_large_need_linearize(const uvs_solver *s);
 int uvs_large_linearize(uvs_solver *s);
 double *uvs_large_reduced(uvs_solver *s, int *n);
+int uvs_large_exchange_host(uvs_solver *s, int which, double *buf, int set);   /* host-staged get/set of the two vectors (no GPU-aware transport) */
 int uvs_large_step(uvs_solver *s);
 double *uvs_large_scalars(uvs_solver *s, int *n);
 int uvs_large_decide(uvs_solver *s);

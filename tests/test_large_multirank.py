@@ -1,0 +1,119 @@
+"""configs[3] multi-rank path.
+
+CPU (gloo, world 2): the landmark-sharded partial normal equations sum to the full reduced system (the algebra behind the
+all-reduce), exchanged with a real torch.distributed all-reduce.
+GPU (marked gpu): two ranks SHARE the one GPU of the box (gloo, host-staged all-reduce) and run the real step-wise solver on
+their landmark shards; the result must equal the single-process large solve.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from helpers import uvs, abi, synth, dense_normal_equations, pose_deltas
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _visual_only(w):
+    v = w.copy(); v.imu = []; v.prior = None
+    return v
+
+
+def _reduced_partial(w, ev, n_full_points, n_full_lines):
+    """Schur complement of this window's landmarks onto the 165 frame dofs (undamped landmarks regularised by 1e-6)."""
+    H, g = dense_normal_equations(w, ev)
+    F = 165
+    Hll = H[F:, F:] + 1e-6 * np.eye(H.shape[0] - F)
+    S = H[:F, :F] - H[:F, F:] @ np.linalg.solve(Hll, H[F:, :F])
+    gr = g[:F] - H[:F, F:] @ np.linalg.solve(Hll, g[F:])
+    return S, gr
+
+
+def _cpu_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_binding import Oracle
+    from helpers import synth as sy
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    w = _visual_only(sy.make_window(51, n_points=60, n_lines=16, n_tagged=12))
+    shard, pk, lk = sy.shard_landmarks(w, rank, world)
+    ev = Oracle().evaluate(shard, robust=True)
+    S, g = _reduced_partial(shard, ev, 60, 16)
+    t = torch.from_numpy(np.concatenate([S.ravel(), g, [ev.cost]]))
+    dist.all_reduce(t)
+    q.put((rank, t.numpy().copy(), len(pk), len(lk)))
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_sharded_partials_sum_to_the_full_reduced_system(oracle):
+    world = 2
+    ctx = mp.get_context("spawn"); q = ctx.Queue(); port = _free_port()
+    procs = [ctx.Process(target=_cpu_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs: p.start()
+    res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda r: r[0])
+    for p in procs: p.join(60)
+    assert all(p.exitcode == 0 for p in procs)
+    assert res[0][2] + res[1][2] == 60 and res[0][3] + res[1][3] == 16
+    assert np.array_equal(res[0][1], res[1][1])                           # every rank holds the same reduced system
+    w = _visual_only(synth.make_window(51, n_points=60, n_lines=16, n_tagged=12))
+    ev = oracle.evaluate(w, robust=True)
+    S, g = _reduced_partial(w, ev, 60, 16)
+    full = np.concatenate([S.ravel(), g, [ev.cost]])
+    assert np.abs(res[0][1] - full).max() <= 1e-9 * np.abs(full).max()
+
+
+def test_shard_landmarks_partition():
+    w = synth.make_window(52)
+    parts = [synth.shard_landmarks(w, r, 4) for r in range(4)]
+    assert sorted(np.concatenate([p[1] for p in parts])) == list(range(150)) and sorted(np.concatenate([p[2] for p in parts])) == list(range(40))
+    assert sum(len(p[0].pt_lm) for p in parts) == 750 and sum(len(p[0].ln_lm) for p in parts) == 280
+    s0, pk, lk = parts[1]
+    assert np.array_equal(s0.inv_depth, w.inv_depth[pk]) and np.array_equal(s0.pose, w.pose) and len(s0.imu) == 10
+    k = 7; obs = np.nonzero(s0.pt_lm == k)[0]; gobs = np.nonzero(w.pt_lm == pk[k])[0]
+    assert np.array_equal(s0.pt_pj[obs], w.pt_pj[gobs])
+
+
+def _gpu_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import importlib
+    u = importlib.import_module("uv-slam_amd")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    w = u.synth.make_window(53, n_points=400, n_lines=100, n_tagged=75)
+    shard, pk, lk = u.synth.shard_landmarks(w, rank, world)
+    s = u.api.Solver(device=0, max_batch=2)
+    st, rep = s.large_solve(shard, dist=dist, device="cuda:0")
+    q.put((rank, st.pose.copy(), st.inv_depth.copy(), pk, rep.final_cost, rep.num_iterations, list(rep.accepted[:11])))
+    s.close()
+    dist.barrier(); dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_gpu_match_single_process(gpu_api):
+    world = 2
+    ctx = mp.get_context("spawn"); q = ctx.Queue(); port = _free_port()
+    procs = [ctx.Process(target=_gpu_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs: p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda r: r[0])
+    for p in procs: p.join(120)
+    assert all(p.exitcode == 0 for p in procs)
+    w = synth.make_window(53, n_points=400, n_lines=100, n_tagged=75)
+    s = gpu_api.Solver(max_batch=2)
+    st, rep = s.large_solve(w)
+    s.close()
+    for r in res:
+        assert r[5] == rep.num_iterations and r[6] == list(rep.accepted[:11])
+        assert abs(r[4] - rep.final_cost) <= 1e-9 * rep.final_cost
+        assert pose_deltas(r[1], st.pose)[0] < 1e-8
+        assert np.abs(r[2] - st.inv_depth[r[3]]).max() < 1e-8

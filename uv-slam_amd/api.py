@@ -56,6 +56,7 @@ def lib():
             getattr(L, name).argtypes = [C.c_void_p]; getattr(L, name).restype = C.c_int
         L.uvs_large_reduced.argtypes = [C.c_void_p, C.POINTER(C.c_int)]; L.uvs_large_reduced.restype = C.c_void_p
         L.uvs_large_scalars.argtypes = [C.c_void_p, C.POINTER(C.c_int)]; L.uvs_large_scalars.restype = C.c_void_p
+        L.uvs_large_exchange_host.argtypes = [C.c_void_p, C.c_int, abi.c_double_p, C.c_int]; L.uvs_large_exchange_host.restype = C.c_int
         L.uvs_large_local_x2.argtypes = [C.c_void_p]; L.uvs_large_local_x2.restype = C.c_double
         L.uvs_large_set_landmark_x2.argtypes = [C.c_void_p, C.c_double]
         L.uvs_large_finish.argtypes = [C.c_void_p, C.POINTER(abi.StateC), C.POINTER(abi.Report)]; L.uvs_large_finish.restype = C.c_int
@@ -151,23 +152,41 @@ class Solver:
             return st.from_c(sc), rep
         import torch
         self._check(L.uvs_large_begin(self._h, C.byref(wc)))
-        x2 = torch.tensor([L.uvs_large_local_x2(self._h)], dtype=torch.float64, device=device)
+        gpu_aware = dist.get_backend() == "nccl"          # RCCL reduces the solver's device buffers in place; otherwise stage through the host
+        x2 = torch.tensor([L.uvs_large_local_x2(self._h)], dtype=torch.float64, device=device if gpu_aware else "cpu")
         dist.all_reduce(x2)
         L.uvs_large_set_landmark_x2(self._h, float(x2.item()))
         n = C.c_int(0)
-        red = _device_tensor(L.uvs_large_reduced(self._h, C.byref(n)), n.value, device)
-        scal = _device_tensor(L.uvs_large_scalars(self._h, C.byref(n)), n.value, device)
+        p_red = L.uvs_large_reduced(self._h, C.byref(n)); n_red = n.value
+        p_sc = L.uvs_large_scalars(self._h, C.byref(n)); n_sc = n.value
+        if gpu_aware:
+            red = _device_tensor(p_red, n_red, device); scal = _device_tensor(p_sc, n_sc, device)
+
+        def exchange(which):
+            """SUM all-reduce of vector `which`; entry LG_ACC + 1 (= n - 7) of the reduced vector is a MAX."""
+            if gpu_aware:
+                t = red if which == 0 else scal
+                mx = t[-7:-6].clone() if which == 0 else None
+                dist.all_reduce(t)
+                if which == 0:
+                    dist.all_reduce(mx, op=dist.ReduceOp.MAX); t[-7:-6] = mx
+                torch.cuda.synchronize()
+            else:
+                buf = np.zeros(n_red if which == 0 else n_sc)
+                self._check(L.uvs_large_exchange_host(self._h, which, abi._dp(buf), 0))
+                t = torch.from_numpy(buf)
+                mx = t[-7:-6].clone() if which == 0 else None
+                dist.all_reduce(t)
+                if which == 0:
+                    dist.all_reduce(mx, op=dist.ReduceOp.MAX); t[-7:-6] = mx
+                self._check(L.uvs_large_exchange_host(self._h, which, abi._dp(buf), 1))
+
         while not L.uvs_large_done(self._h):
             if L.uvs_large_need_linearize(self._h):
                 self._check(L.uvs_large_linearize(self._h))
-                mx = red[-7].clone()                       # entry LG_ACC + 1 is a max, everything else a sum
-                dist.all_reduce(red)                       # RCCL all-reduce of the pose-block partials (36.9 KB)
-                dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-                red[-7] = mx
-                torch.cuda.synchronize()
+                exchange(0)                                # the pose-block partials (33.9 KB)
             self._check(L.uvs_large_step(self._h))
-            dist.all_reduce(scal)
-            torch.cuda.synchronize()
+            exchange(1)
             self._check(L.uvs_large_decide(self._h))
         self._check(L.uvs_large_finish(self._h, C.byref(sc), C.byref(rep)), allow=(abi.UVS_OK, abi.UVS_ERR_NUMERIC))
         return st.from_c(sc), rep

@@ -9,17 +9,18 @@
 //   k_large_backsub  grid = #chunks : landmark back-substitution + candidate cost of the chunk's observations
 // The LM accept / reject logic runs on the host between launches (one small read-back per iteration).
 // Multi-GPU: every rank holds the landmarks k with k % G == rank; `reduced` (pose-pose Schur blocks, reduced gradient,
-// diag(J^T J), landmark cost) is summed with ONE RCCL all-reduce (36.9 KB, latency bound), every rank then solves the same
+// diag(J^T J), landmark cost) is summed with ONE RCCL all-reduce (33.9 KB, latency bound), every rank then solves the same
 // reduced system redundantly; the back-substitution scalars need a second 5-double all-reduce.
 #pragma once
 #include "uvs_solve_kernel.h"
 
 namespace uvsdev {
 
-static constexpr int LG_ACC = NW * BLOCKS_PER_WAVE * 64;   // 4608 raw accumulator slots [wave][block slot][lane]
+static constexpr int LG_ACC = UVS_NBLK * 64;               // 4224 accumulator slots [pose block][lane] -- canonical, independent of the per-window wave balance
 static constexpr int LG_RED = LG_ACC + 8;                  // + {landmark cost, max |g_l|, 6 spare}
-static constexpr int LG_STATE = 1024;                      // doubles: X[184] XC[184] DLT[176] G[176] DD[176] SC[176] (offsets below)
-enum { LS_X = 0, LS_XC = 184, LS_DLT = 368, LS_G = 544, LS_DD = 720, LS_SC = 896 };
+enum { LS_X = 0, LS_XC = 184, LS_DLT = 368, LS_G = 544, LS_DD = 720, LS_SC = 896, LS_END = LS_SC + UVS_RD };
+static constexpr int LG_STATE = 1280;                      // doubles: X[184] XC[184] DLT[176] G[176] DD[176] SC[176]
+static_assert(LS_END <= LG_STATE, "large-path state vector overflows its allocation");
 enum { LO_COST = 0, LO_GMAX, LO_CHOLOK, LO_GD, LO_DD2, LO_STEP2, LO_XC2, LO_FRAMECOST, LO_N };
 
 __global__ __launch_bounds__(NT) void k_large_chunks(char* blob, double* ws, KOpts o, const double* state, int sel, int first, double radius, double* partials) {
@@ -39,7 +40,7 @@ __global__ __launch_bounds__(NT) void k_large_chunks(char* blob, double* ws, KOp
     lin_chunk(c, ch, sh + L_X, invd, line, first != 0, radius, wb, acc, cost, gmax);
     double* P = partials + (size_t)ch * LG_RED;
 #pragma unroll
-    for (int q = 0; q < BLOCKS_PER_WAVE; ++q) P[((tid >> 6) * BLOCKS_PER_WAVE + q) * 64 + (tid & 63)] = acc[q];
+    for (int q = 0; q < BLOCKS_PER_WAVE; ++q) if (wb[q] >= 0) P[(wb[q] & 255) * 64 + (tid & 63)] = acc[q];
     double s4[4] = {cost, 0, 0, 0};
     block_reduce(sh, s4, &gmax);
     if (tid == 0) { P[LG_ACC] = s4[0]; P[LG_ACC + 1] = gmax; }
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(NT) void k_large_solve(char* blob, double* ws, KOpt
     __syncthreads();
     double acc[BLOCKS_PER_WAVE]; int wb[BLOCKS_PER_WAVE];
 #pragma unroll
-    for (int q = 0; q < BLOCKS_PER_WAVE; ++q) { wb[q] = __builtin_amdgcn_readfirstlane(c.bi[h.i_wblk + (tid >> 6) * BLOCKS_PER_WAVE + q]); acc[q] = reduced[((tid >> 6) * BLOCKS_PER_WAVE + q) * 64 + (tid & 63)]; }
+    for (int q = 0; q < BLOCKS_PER_WAVE; ++q) { wb[q] = __builtin_amdgcn_readfirstlane(c.bi[h.i_wblk + (tid >> 6) * BLOCKS_PER_WAVE + q]); acc[q] = wb[q] >= 0 ? reduced[(wb[q] & 255) * 64 + (tid & 63)] : 0.0; }
     double cost = lin_frames(c, sh + L_X);
     if (tid == 0) cost += reduced[LG_ACC];
     __syncthreads();

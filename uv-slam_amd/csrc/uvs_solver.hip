@@ -574,6 +574,15 @@ int uvs_large_done(const uvs_solver* s) { return !s || !s->L.active || s->L.done
 double* uvs_large_reduced(uvs_solver* s, int* n) { if (n) *n = LG_RED; return s ? s->L.d_reduced : nullptr; }     // DEVICE pointer; [LG_ACC+1] is a MAX entry
 double* uvs_large_scalars(uvs_solver* s, int* n) { if (n) *n = 5; return s ? s->L.d_sc5 : nullptr; }             // DEVICE pointer
 
+// host-staged access to the two exchange vectors (which = 0: reduced[LG_RED], 1: scalars[5]); set != 0 writes host -> device
+int uvs_large_exchange_host(uvs_solver* s, int which, double* buf, int set) {
+    if (!s || !s->L.active || !buf) return UVS_ERR_INVALID_ARG;
+    double* d = which == 0 ? s->L.d_reduced : s->L.d_sc5; const size_t n = which == 0 ? LG_RED : 5;
+    HIPCHK(s, hipSetDevice(s->device));
+    if (set) HIPCHK(s, hipMemcpy(d, buf, n * 8, hipMemcpyHostToDevice)); else HIPCHK(s, hipMemcpy(buf, d, n * 8, hipMemcpyDeviceToHost));
+    return UVS_OK;
+}
+
 int uvs_large_linearize(uvs_solver* s) {
     if (!s || !s->L.active) return UVS_ERR_INVALID_ARG;
     auto& L = s->L;
@@ -641,7 +650,8 @@ int uvs_large_decide(uvs_solver* s) {
     else if (std::fabs(L.cost - cand) <= o.function_tolerance * L.cost) { L.term = UVS_TERM_FUNCTION_TOL; stop = true; }
     if (stop && !(o.function_tol_keeps_candidate && successful)) { L.done = true; return UVS_OK; }
     if (successful) {
-        HIPCHK(s, hipMemcpy(L.d_state + LS_X, L.d_state + LS_XC, 184 * 8, hipMemcpyDeviceToDevice));
+        HIPCHK(s, hipMemcpyAsync(L.d_state + LS_X, L.d_state + LS_XC, 184 * 8, hipMemcpyDeviceToDevice, s->stream));   // stream-ordered with the next launch (a plain D2D hipMemcpy
+        // runs on the null stream, which this non-blocking stream does not wait for)
         L.sel ^= 1; ++L.nsucc; L.x_norm = std::sqrt(xc2);
         L.radius = L.radius / std::fmax(1.0 / 3.0, 1.0 - std::pow(2.0 * rel - 1.0, 3.0));
         L.radius = std::fmin(o.max_trust_region_radius, L.radius); L.decr = 2.0;
