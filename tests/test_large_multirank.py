@@ -114,6 +114,8 @@ def test_two_ranks_on_one_gpu_match_single_process(gpu_api):
     s.close()
     for r in res:
         assert r[5] == rep.num_iterations and r[6] == list(rep.accepted[:11])
-        assert abs(r[4] - rep.final_cost) <= 1e-9 * rep.final_cost
-        assert pose_deltas(r[1], st.pose)[0] < 1e-8
-        assert np.abs(r[2] - st.inv_depth[r[3]]).max() < 1e-8
+        # the shards sum the pose-block partials in a different order; over 10 LM iterations from an initial cost of 1e10 the
+        # round-off difference grows to ~1e-8 relative in the final cost
+        assert abs(r[4] - rep.final_cost) <= 1e-7 * rep.final_cost
+        assert pose_deltas(r[1], st.pose)[0] < 1e-7
+        assert np.abs(r[2] - st.inv_depth[r[3]]).max() < 1e-7

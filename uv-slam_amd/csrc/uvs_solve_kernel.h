@@ -204,132 +204,192 @@ UVS_DEV double cost_pass(const Ctx& c, const double* x, const double* invd, cons
 }
 
 // ------------------------------------------------------------------ blocked Cholesky of the LDS-resident reduced system
-// S (lower 16x16 blocks) <- L ; L_DINV <- 1/diag(L).  Returns via CTRL[C_CHOLOK].
+// S (lower 16x16 blocks) <- L ; strictly-upper part of every diagonal block <- (L_kk^-1)^T ; L_DINV <- 1/diag(L).
+// Returns via CTRL[C_CHOLOK].
 typedef double d4_t __attribute__((ext_vector_type(4)));
 
-// Factors S = L L^T in place and, because the right-hand side is carried along as one extra row of the panel,
-// leaves y = L^-1 rhs in L_DLT (the forward substitution costs one 16-step register solve per block column).
-UVS_DEV void chol_factor(const Ctx& c) {
-    double* sh = c.sh;
+UVS_DEV double* sblk(double* sh, int i, int j) { return sh + L_S + (((i * (i + 1)) >> 1) + j) * UVS_BLK_SZ; }
+
+// 1/x from the hardware seed (v_rcp_f64) + two Newton steps: the pivot reciprocal sits on the serial chain of the factorization.
+UVS_DEV double rcp_newton(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, y, 1.0); y = fma(y, e, y);
+    e = fma(-x, y, 1.0); y = fma(y, e, y);
+    return y;
+}
+
+// LEFT-LOOKING blocked Cholesky, S = L L^T in place, with the right-hand side carried as block row 11 (one real row), so
+// L_DLT leaves as y = L^-1 rhs.  Per block column k (two workgroup barriers):
+//   S1  every block (i,k), i >= k, is owned by one wave and accumulates  S_ik - sum_{j<k} L_ij L_kj^T  in MFMA registers
+//       (4 x v_mfma_f64_16x16x4_f64 per term); the diagonal block stays in wave 0's registers;
+//   S2  wave 0 factors the 16x16 diagonal block WITHOUT leaving the MFMA C layout: row j of the (symmetric) block lives in
+//       lanes 16*(j&3).. of register j>>2, which is exactly k-slot (j&3) of the A/B operands, so pivot j is one readlane,
+//       one reciprocal and one rank-1 MFMA; a second MFMA per pivot runs the same elimination on the identity => W = L_kk^-1;
+//   S3  the panel X_ik = S_ik W^T (and the rhs row y_k = b_k W^T) is 4 MFMAs per block instead of a 16-step substitution.
+// C/D layout of the f64 MFMA: row = (lane >> 4) + 4 * reg, col = lane & 15;  A[i][k]: lane i + 16k;  B[k][j]: lane j + 16k.
+struct MiniCtx { double* sh; struct { int debug; } o; };      // what UVS_PROF needs inside the out-of-line phases
+#define UVS_NOINLINE __device__ __attribute__((noinline))
+// Out of line on purpose: k_solve is one huge inlined body at the 256-VGPR cap; as separate functions the dense-solve phases
+// get their own register allocation (no scratch reloads inside the pivot chain).
+UVS_NOINLINE void chol_factor_impl(double* sh, int debug) {
+    MiniCtx c; c.sh = sh; c.o.debug = debug;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
     double* b = sh + L_DLT;
     if (tid == 0) sh[L_CTRL + C_CHOLOK] = 1.0;
     UVS_PROF(c, P_MISC);
     for (int k = 0; k < UVS_NF; ++k) {
-        double* Dk = sh + L_S + (((k * (k + 1)) >> 1) + k) * UVS_BLK_SZ;
+        double* Dk = sblk(sh, k, k);
         __syncthreads();
-        // (1) diagonal block: lanes 0..15 of wave 0 hold one row each in registers
-        if (wv == 0) {
-            double a[16];
-            const int r = lane & 15;
+        // ---- S1: left-looking update of block column k (items t: i = k + t; i == UVS_NF is the right-hand-side row)
+        d4_t dacc = {0.0, 0.0, 0.0, 0.0};
+        const int nitem = UVS_NF + 1 - k;
+        // wave 0 owns the diagonal block (t = 0) and goes straight on to factor it; wave 4 sits on the same SIMD (waves are dealt to
+        // the 4 SIMDs round-robin) and would put its MFMAs between the pivots of that serial chain, so it takes no S1 work
+        const int s1w = (wv < 4) ? wv - 1 : wv - 2;       // workers 1,2,3,5,6,7 -> 0..5
+        for (int t = (wv == 0 ? 0 : (wv == 4 ? nitem : 1 + s1w)); t < nitem; t += (wv == 0 ? nitem : 6)) {
+            const int i = k + t;
+            const bool rhs = (i == UVS_NF);
+            d4_t acc;
+            if (t == 0) {        // diagonal block: symmetrise from the stored lower triangle
 #pragma unroll
-            for (int cc = 0; cc < 16; ++cc) a[cc] = Dk[r * UVS_BLK_LD + cc];
-            double rhs = b[16 * k + r];
-            bool ok = true;
-            double dinv_r = 0.0;
+                for (int q = 0; q < 4; ++q) { const int r = lk + 4 * q; acc[q] = (r >= li) ? Dk[r * UVS_BLK_LD + li] : Dk[li * UVS_BLK_LD + r]; }
+            } else if (!rhs) {
+                const double* Cb = sblk(sh, i, k) + lk * UVS_BLK_LD + li;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] = Cb[4 * q * UVS_BLK_LD];
+            } else {
+                acc[0] = (lk == 0) ? b[16 * k + li] : 0.0; acc[1] = 0.0; acc[2] = 0.0; acc[3] = 0.0;
+            }
+            d4_t acc2 = {0.0, 0.0, 0.0, 0.0};        // second accumulator: two independent MFMA chains
+            if (!rhs) {
+                const double* Bj = sblk(sh, k, 0) + li * UVS_BLK_LD + lk;
+                const double* Ai = sblk(sh, i, 0) + li * UVS_BLK_LD + lk;
+                for (int j = 0; j < k; ++j, Bj += UVS_BLK_SZ, Ai += UVS_BLK_SZ) {
+                    double av[4], bv[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { av[q] = -Ai[4 * q]; bv[q] = Bj[4 * q]; }
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0], bv[0], acc, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], bv[1], acc2, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2], bv[2], acc, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[3], bv[3], acc2, 0, 0, 0);
+                }
+            } else {
+                const double* Bj = sblk(sh, k, 0) + li * UVS_BLK_LD + lk;
+                for (int j = 0; j < k; ++j, Bj += UVS_BLK_SZ) {
+                    double av[4], bv[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { av[q] = (li == 0) ? -b[16 * j + 4 * q + lk] : 0.0; bv[q] = Bj[4 * q]; }
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0], bv[0], acc, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], bv[1], acc2, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2], bv[2], acc, 0, 0, 0);
+                    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[3], bv[3], acc2, 0, 0, 0);
+                }
+            }
+            acc += acc2;
+            if (t == 0) dacc = acc;
+            else if (!rhs) {
+                double* Cb = sblk(sh, i, k) + lk * UVS_BLK_LD + li;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) Cb[4 * q * UVS_BLK_LD] = acc[q];
+            } else if (lk == 0) b[16 * k + li] = acc[0];
+        }
+        UVS_PROF(c, P_CH_TRAIL);
+        // ---- S2: wave 0 factors the diagonal block in registers (L -> lower triangle, W^T -> strictly upper, 1/L_jj -> L_DINV).
+        // The serial chain per pivot is readlane -> reciprocal -> masked scale -> MFMA; with STRICT masks row j of both
+        // accumulators is left untouched after pivot j, so all square roots and the scaling by 1/L_jj happen once, lane-parallel,
+        // after the chain (unscaled row j of dacc = a_jc^(j), row j of T = unscaled row of W).
+        if (wv == 0) {
+            d4_t T;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) T[q] = (lk + 4 * q == li) ? 1.0 : 0.0;
+            double us_prev = 0.0;
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
-                const double piv = bcast_lane(a[j], j);
-                if (!(piv > 0.0)) ok = false;
-                double ljj, inv; rsqrt_pair(piv, &ljj, &inv);
-                const double l = (r == j) ? ljj : a[j] * inv;
-                a[j] = l;
-                if (r == j) dinv_r = inv;
-#pragma unroll
-                for (int cc = j + 1; cc < 16; ++cc) { const double lc = bcast_lane(l, cc); a[cc] -= l * lc; }
-                // forward substitution of the right-hand side rides along: y_j = rhs_j / L_jj ; rhs_r -= L_rj y_j
-                const double yj = bcast_lane(rhs * inv, j);
-                rhs = (r == j) ? yj : (r > j ? rhs - l * yj : rhs);
+                const int reg = j >> 2, slot = j & 3;
+                const double piv = bcast_lane(dacc[reg], 16 * slot + j);
+                // the inverse's elimination trails the factor's by one pivot, so its MFMA never sits between an MFMA result and the
+                // readlane that needs it (B operands need no masks: A is zero outside k-slot `slot` and outside rows > j)
+                if (j > 0) T = __builtin_amdgcn_mfma_f64_16x16x4f64(us_prev, T[(j - 1) >> 2], T, 0, 0, 0);
+                const double m = (lk == slot && li > j) ? dacc[reg] : 0.0;   // a[j][c], c > j, at lane 16*slot + c (symmetric => column j)
+                double y = __builtin_amdgcn_rcp(piv);                        // 1/piv: hardware seed (2^-24) + one third-order step
+                const double e = fma(-piv, y, 1.0);
+                y = fma(y, fma(e, e, e), y);
+                const double us = -m * y;
+                dacc = __builtin_amdgcn_mfma_f64_16x16x4f64(us, dacc[reg], dacc, 0, 0, 0);
+                us_prev = us;
             }
-            if (lane < 16) {
+            // (pivot 15 has no rows below it: nothing left to eliminate in T)
+            // square roots + scaling, lane-parallel: this lane's register q belongs to row j = lk + 4q, whose pivot sits untouched on
+            // the diagonal lane 16*lk + j of the same register
 #pragma unroll
-                for (int cc = 0; cc < 16; ++cc) if (cc <= r) Dk[r * UVS_BLK_LD + cc] = a[cc];
-                sh[L_DINV + 16 * k + r] = dinv_r;
-                b[16 * k + r] = rhs;
-                if (!ok && lane == 0) sh[L_CTRL + C_CHOLOK] = 0.0;
+            for (int q = 0; q < 4; ++q) {
+                const int j = lk + 4 * q;
+                double ljj, inv; rsqrt_pair(dacc[q], &ljj, &inv);            // meaningful on the diagonal lane only
+                if (li == j && !(dacc[q] > 0.0)) sh[L_CTRL + C_CHOLOK] = 0.0;
+                const int src = (16 * lk + j) << 2;
+                const int ilo = __builtin_amdgcn_ds_bpermute(src, __double2loint(inv)), ihi = __builtin_amdgcn_ds_bpermute(src, __double2hiint(inv));
+                const double invj = __hiloint2double(ihi, ilo);
+                Dk[li * UVS_BLK_LD + j] = (li > j) ? dacc[q] * invj : (li == j ? ljj : T[q] * invj);      // L[c][j] | W[j][m] at (m, j)
+                if (li == j) sh[L_DINV + 16 * k + j] = inv;
             }
         }
         __syncthreads();
         UVS_PROF(c, P_CH_DIAG);
-        // (2) panel: rows of blocks (i,k), i>k : x L_kk^T = a, column sweep (axpy form: the only serial chain is x_j -> x_j+1)
-        const int nrow = (UVS_NF - 1 - k) * 16;
-        if (tid < nrow) {
-            const int i = k + 1 + (tid >> 4), r = tid & 15;
-            double* B = sh + L_S + (((i * (i + 1)) >> 1) + k) * UVS_BLK_SZ + r * UVS_BLK_LD;
-            double x[16];
+        // ---- S3: panel  X_ik = S_ik W^T  (B operand W[c][m]: strictly-upper slot (m, c) of the diagonal block, 1/L_cc on the diagonal)
+        {
+            double Bw[4];
 #pragma unroll
-            for (int cc = 0; cc < 16; ++cc) x[cc] = B[cc];
-            double dot = 0.0;
+            for (int q = 0; q < 4; ++q) { const int m = 4 * q + lk; Bw[q] = (m < li) ? Dk[m * UVS_BLK_LD + li] : (m == li ? sh[L_DINV + 16 * k + li] : 0.0); }
+            for (int t = 1 + wv; t < nitem; t += NW) {
+                const int i = k + t;
+                const bool rhs = (i == UVS_NF);
+                d4_t acc = {0.0, 0.0, 0.0, 0.0};
+                if (!rhs) {
+                    double* Ai = sblk(sh, i, k) + li * UVS_BLK_LD + lk;
+                    double av[4];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                x[j] *= sh[L_DINV + 16 * k + j];
+                    for (int q = 0; q < 4; ++q) av[q] = Ai[4 * q];
 #pragma unroll
-                for (int m = j + 1; m < 16; ++m) x[m] -= x[j] * Dk[m * UVS_BLK_LD + j];
-                dot += x[j] * b[16 * k + j];
+                    for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], Bw[q], acc, 0, 0, 0);
+                    double* Cb = sblk(sh, i, k) + lk * UVS_BLK_LD + li;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) Cb[4 * q * UVS_BLK_LD] = acc[q];
+                } else {
+                    double av[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) av[q] = (li == 0) ? b[16 * k + 4 * q + lk] : 0.0;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], Bw[q], acc, 0, 0, 0);
+                    if (lk == 0) b[16 * k + li] = acc[0];
+                }
             }
-#pragma unroll
-            for (int cc = 0; cc < 16; ++cc) B[cc] = x[cc];
-            b[16 * i + r] -= dot;                     // right-hand side row of the trailing update
         }
-        __syncthreads();
         UVS_PROF(c, P_CH_PANEL);
-        // (3) trailing update S_ij -= X_i X_j^T for k < j <= i : one wave per 16x16 block, 4 x v_mfma_f64_16x16x4_f64
-        const int nb = UVS_NF - 1 - k;
-        const int nblk = (nb * (nb + 1)) >> 1;
-        for (int pb = wv; pb < nblk; pb += NW) {
-            int ii = (int)((sqrtf(8.0f * pb + 1.0f) - 1.0f) * 0.5f);
-            while (((ii + 1) * (ii + 2)) >> 1 <= pb) ++ii;
-            while (((ii * (ii + 1)) >> 1) > pb) --ii;
-            const int jj = pb - ((ii * (ii + 1)) >> 1);
-            const int bi_ = k + 1 + ii, bj_ = k + 1 + jj;
-            const double* Xi = sh + L_S + (((bi_ * (bi_ + 1)) >> 1) + k) * UVS_BLK_SZ + (lane & 15) * UVS_BLK_LD + (lane >> 4);
-            const double* Xj = sh + L_S + (((bj_ * (bj_ + 1)) >> 1) + k) * UVS_BLK_SZ + (lane & 15) * UVS_BLK_LD + (lane >> 4);
-            double* Cb = sh + L_S + (((bi_ * (bi_ + 1)) >> 1) + bj_) * UVS_BLK_SZ + (lane >> 4) * UVS_BLK_LD + (lane & 15);
-            d4_t acc;      // C/D layout of the f64 MFMA: row = (lane >> 4) + 4 * reg, col = lane & 15
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc[q] = Cb[4 * q * UVS_BLK_LD];
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Xi[4 * kk], Xj[4 * kk], acc, 0, 0, 0);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) Cb[4 * q * UVS_BLK_LD] = acc[q];
-        }
-        __syncthreads();
-        UVS_PROF(c, P_CH_TRAIL);
     }
     __syncthreads();
 }
 
-// backward substitution L^T x = y in place (y in L_DLT, produced by chol_factor)
-UVS_DEV void chol_solve(const Ctx& c) {
-    double* sh = c.sh;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+// backward substitution L^T x = y in place (y in L_DLT, produced by chol_factor); the diagonal solves are mat-vecs with W^T
+UVS_DEV void chol_factor(const Ctx& c) { chol_factor_impl(c.sh, c.o.debug); }
+
+UVS_NOINLINE void chol_solve_impl(double* sh) {
+    const int tid = threadIdx.x;
     double* b = sh + L_DLT;
-    // the forward substitution was carried by chol_factor(); only L^T x = y remains
-    // backward
     for (int k = UVS_NF - 1; k >= 0; --k) {
-        const double* Dk = sh + L_S + (((k * (k + 1)) >> 1) + k) * UVS_BLK_SZ;
+        const double* Dk = sblk(sh, k, k);
         __syncthreads();
-        if (wv == 0) {
-            const int r = lane & 15;
-            double Lc[16];     // column r of L_kk : Lc[j] = L[j][r], j > r
+        if (tid < 16) {          // x_k[c] = sum_{m >= c} W[m][c] r[m] ; W[m][c] (m > c) sits at (c, m)
+            double s = sh[L_DINV + 16 * k + tid] * b[16 * k + tid];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) Lc[j] = (j > r) ? Dk[j * UVS_BLK_LD + r] : 0.0;
-            double v = b[16 * k + r];
-            const double di = sh[L_DINV + 16 * k + r];
-            double x = 0.0;
-#pragma unroll
-            for (int j = 15; j >= 0; --j) {
-                const double xj = bcast_lane(v * di, j);
-                if (r == j) x = xj;
-                v -= Lc[j] * xj;
-            }
-            if (lane < 16) b[16 * k + r] = x;
+            for (int m = 1; m < 16; ++m) s += (m > tid) ? Dk[tid * UVS_BLK_LD + m] * b[16 * k + m] : 0.0;
+            b[16 * k + tid] = s;      // all lanes of the wave read r before any lane writes (same instruction stream)
         }
         __syncthreads();
         const int ncol = k * 16;
         if (tid < ncol) {
             const int j = tid >> 4, cc = tid & 15;
-            const double* B = sh + L_S + (((k * (k + 1)) >> 1) + j) * UVS_BLK_SZ + cc;
+            const double* B = sblk(sh, k, j) + cc;
             double s = 0.0;
 #pragma unroll
             for (int r = 0; r < 16; ++r) s += B[r * UVS_BLK_LD] * b[16 * k + r];
@@ -338,6 +398,7 @@ UVS_DEV void chol_solve(const Ctx& c) {
     }
     __syncthreads();
 }
+UVS_DEV void chol_solve(const Ctx& c) { chol_solve_impl(c.sh); }
 
 // ------------------------------------------------------------------ linearization: builds S (damped, Schur-reduced), G, HD, cost, gmax
 // Gather work split: wave w owns the 6x6 pose blocks b = w, w+8, ... of the 66 lower blocks; lanes 0..35 own the
