@@ -1,0 +1,6 @@
+import sys, os
+sys.path.insert(0, '/root/repo/tests'); sys.path.insert(0, '/root/repo')
+from helpers import uvs, synth
+s = uvs.api.Solver(max_batch=2)
+w = synth.make_window(0)
+s.upload([w])

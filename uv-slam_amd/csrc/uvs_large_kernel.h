@@ -16,7 +16,7 @@
 
 namespace uvsdev {
 
-static constexpr int LG_ACC = UVS_NBLK * 64;               // 4224 accumulator slots [pose block][lane] -- canonical, independent of the per-window wave balance
+static constexpr int LG_ACC = UVS_NBLK * 64;               // 4224 accumulator slots [pose block][row a][8] -- canonical, independent of the per-window group balance
 static constexpr int LG_RED = LG_ACC + 8;                  // + {landmark cost, max |g_l|, 6 spare}
 enum { LS_X = 0, LS_XC = 184, LS_DLT = 368, LS_G = 544, LS_DD = 720, LS_SC = 896, LS_END = LS_SC + UVS_RD };
 static constexpr int LG_STATE = 1280;                      // doubles: X[184] XC[184] DLT[176] G[176] DD[176] SC[176]
@@ -32,15 +32,31 @@ __global__ __launch_bounds__(NT) void k_large_chunks(char* blob, double* ws, KOp
     __syncthreads();
     stage_rotations(c, sh + L_X);
     __syncthreads();
-    double acc[BLOCKS_PER_WAVE]; int wb[BLOCKS_PER_WAVE];
-#pragma unroll
-    for (int q = 0; q < BLOCKS_PER_WAVE; ++q) { acc[q] = 0.0; wb[q] = __builtin_amdgcn_readfirstlane(c.bi[h.i_wblk + (tid >> 6) * BLOCKS_PER_WAVE + q]); }
+    const int grp = gather_group(c);
+    GAcc A; gacc_zero(A);
     double cost = 0.0, gmax = 0.0;
     const double* invd = ws + (sel ? h.w_invd1 : h.w_invd0); const double* line = ws + (sel ? h.w_line1 : h.w_line0);
-    lin_chunk(c, ch, sh + L_X, invd, line, first != 0, radius, wb, acc, cost, gmax);
-    double* P = partials + (size_t)ch * LG_RED;
+    lin_chunk(c, ch, sh + L_X, invd, line, first != 0, radius, grp, A, cost, gmax);
+    // canonical partial [pose block][row a][8] (6 block entries, gradient, diag(J^T J)), staged in LDS so that the two halves of a
+    // split block are summed in a fixed order and the HBM write is coalesced
+    __syncthreads();
+    for (int i = tid; i < LG_ACC; i += NT) sh[L_S + i] = 0.0;
+    __syncthreads();
+    for (int part = 0; part < h.n_parts; ++part) {
+        if (grp >= 0 && ((grp >> 9) & 15) == part) {
+            const int r0 = 3 * (tid & 1);
 #pragma unroll
-    for (int q = 0; q < BLOCKS_PER_WAVE; ++q) if (wb[q] >= 0) P[(wb[q] & 255) * 64 + (tid & 63)] = acc[q];
+            for (int r = 0; r < 3; ++r) {
+                double* Q = sh + L_S + (grp & 255) * 64 + (r0 + r) * 8;
+#pragma unroll
+                for (int q = 0; q < 6; ++q) Q[q] += A.v[6 * r + q];
+                Q[6] += A.g[r]; Q[7] += A.hd[r];
+            }
+        }
+        __syncthreads();
+    }
+    double* P = partials + (size_t)ch * LG_RED;
+    for (int i = tid; i < LG_ACC; i += NT) P[i] = sh[L_S + i];
     double s4[4] = {cost, 0, 0, 0};
     block_reduce(sh, s4, &gmax);
     if (tid == 0) { P[LG_ACC] = s4[0]; P[LG_ACC + 1] = gmax; }
@@ -65,13 +81,23 @@ __global__ __launch_bounds__(NT) void k_large_solve(char* blob, double* ws, KOpt
     if (tid < UVS_RD && !first) sh[L_SC + tid] = state[LS_SC + tid];
     if (first) setup_window(c, (double*)blob);
     __syncthreads();
-    double acc[BLOCKS_PER_WAVE]; int wb[BLOCKS_PER_WAVE];
+    const int grp = gather_group(c);
+    GAcc A;
+    {
+        const int r0 = 3 * (tid & 1);
+        const bool ld = grp >= 0 && !((grp >> 9) & 15);       // part 0 carries the whole (already summed) block
 #pragma unroll
-    for (int q = 0; q < BLOCKS_PER_WAVE; ++q) { wb[q] = __builtin_amdgcn_readfirstlane(c.bi[h.i_wblk + (tid >> 6) * BLOCKS_PER_WAVE + q]); acc[q] = wb[q] >= 0 ? reduced[(wb[q] & 255) * 64 + (tid & 63)] : 0.0; }
+        for (int r = 0; r < 3; ++r) {
+            const double* Q = reduced + (grp & 255) * 64 + (r0 + r) * 8;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) A.v[6 * r + q] = ld ? Q[q] : 0.0;
+            A.g[r] = ld ? Q[6] : 0.0; A.hd[r] = ld ? Q[7] : 0.0;
+        }
+    }
     double cost = lin_frames(c, sh + L_X);
     if (tid == 0) cost += reduced[LG_ACC];
     __syncthreads();
-    lin_assemble(c, sh + L_X, first != 0, radius, wb, acc, cost, reduced[LG_ACC + 1]);
+    lin_assemble(c, sh + L_X, first != 0, radius, grp, A, cost, reduced[LG_ACC + 1]);
     if (tid < UVS_RD) sh[L_DLT + tid] = -sh[L_G + tid];
     chol_factor(c);
     chol_solve(c);

@@ -22,12 +22,17 @@
 #define UVS_IMU_COV 245
 #define UVS_IMU_W 470
 
-#define UVS_PT_REC 31             // LDS record per point observation: r[2] A[12] c|rc[2] B[12] rc[2] pad  (rc = Schur-corrected residual; odd stride)
+#define UVS_PT_REC 30             // LDS record per point observation: r[2] A[12] c|rc[2] B[12] rc[2]  (rc = Schur-corrected residual);
+                                  // even stride and even field offsets: every Jacobian row is 16-byte aligned for ds_read_b128
 #define UVS_PT_A 2
 #define UVS_PT_C 14
 #define UVS_PT_B 16
 #define UVS_PT_RC2 28
-#define UVS_LN_REC 33             // LDS record per line observation: rl[2] Jlp[12] Jll[8] rv Jvp[6] Jvl[4]
+#define UVS_LN_REC 34             // LDS record per line observation: rl|rc[2] Jp[3][6] rv|rc2 pad Jl[3][4]  (row 2 = vanishing-point row)
+#define UVS_LN_JP 2               // pose-Jacobian rows at 2, 8, 14
+#define UVS_LN_RV 20              // VP residual, later its Schur-corrected value
+#define UVS_LN_JL 22              // line-parameter Jacobian rows at 22, 26, 30
+#define UVS_NGRP 256              // gather groups: 32 two-lane groups per wave x 8 waves; each owns one 6x6 pose block or one part of a split one
 
 struct DevWin {
     int32_t n_points, n_pt_obs, n_lines, n_ln_obs, n_imu, prior_n, prior_nb, n_chunks;
@@ -44,8 +49,8 @@ struct DevWin {
     int32_t i_imu;                    // [n_imu][2] : frame_i, skip
     int32_t i_prior;                  // kind[16] frame[16] size[16] idx[16] x0off[16] colmap[96]
     int32_t i_chunks;                 // [n_chunks][6] : type(0 pt,1 ln), lm_begin, lm_end, offset of the chunk's gather lists in i_lists, their length, 0
-    int32_t i_wblk;                   // [8 waves][9] pose-block ids owned by each wave in the gather (-1 = none), balanced by list length
-    int32_t i_lists;                  // per chunk: schur_off[67] direct_off[67] entries[...]  (see build_lists in uvs_solver.hip)
+    int32_t i_wblk;                   // [UVS_NGRP] gather group -> pose block id | 256 (diagonal block) | part << 9 (4 bits, split blocks) | fa << 13 | fb << 17; -1 = idle
+    int32_t i_lists;                  // per chunk: schur_off[81] direct_off[81] entries[...]  (group-major, see pack_window in uvs_solver.hip)
     // workspace
     int32_t w_invd0, w_invd1, w_line0, w_line1;       // landmark parameters, two buffers (current / candidate)
     int32_t w_scale_pt, w_scale_ln;                   // Jacobi scales of landmark parameters
@@ -56,7 +61,7 @@ struct DevWin {
     int32_t ws_doubles;
     int32_t blob_bytes;
     int32_t cur_sel;                  // written by the kernel: which landmark buffer holds the final state
-    int32_t pad_;
+    int32_t n_parts;                  // largest number of parts any pose block is split into (assembly rounds)
 };
 
 #define UVS_WIMU_STRIDE 936

@@ -401,151 +401,140 @@ UVS_NOINLINE void chol_solve_impl(double* sh) {
 UVS_DEV void chol_solve(const Ctx& c) { chol_solve_impl(c.sh); }
 
 // ------------------------------------------------------------------ linearization: builds S (damped, Schur-reduced), G, HD, cost, gmax
-// Gather work split: wave w owns the 6x6 pose blocks b = w, w+8, ... of the 66 lower blocks; lanes 0..35 own the
-// block's entries, and on diagonal blocks lanes 36..41 / 42..47 own that frame's gradient / diag(J^T J) entries.
-// For every block the host packed two index lists per landmark chunk (uvs_solver.hip: build_lists):
-//   Schur list : (landmark, slot_a, slot_b) for each landmark observed in both frames   -> - E_a^T H_ll^-1 E_b
-//   direct list: (observation, kind) for each observation contributing J^T J to the block
-// A wave walks its lists front to back, so every sum has a fixed order (bitwise reproducible, no atomics).
-static constexpr int BLOCKS_PER_WAVE = (UVS_NBLK + NW - 1) / NW;   // 9
-
-// List entries are pre-expanded by the host into LDS offsets (two 16-bit fields, doubles relative to the staging base):
+// Gather work split: the 512 lanes form 256 GROUPS of 2 lanes (32 per wave).  A group owns one lower 6x6 pose block -- or one
+// part of it: the host splits the heavy blocks (water-filling, pack_window) so that all groups carry similar work -- and lane t of
+// the group owns ROWS 3t..3t+2 of the block in registers, on diagonal blocks also those rows' gradient and diag(J^T J) entries.
+// Per landmark chunk the host packed, for every group, two index lists:
+//   Schur list : (E row of frame a, Einv/Y row of frame b) for each landmark observed in both frames   -> - E_a^T H_ll^-1 E_b
+//   direct list: the observation's Jacobian blocks contributing J^T J to the block
+// Rows-per-lane is what makes this LDS-bandwidth friendly: three 8-byte reads of the lane's own operands and three 16-byte
+// broadcast reads of the other row feed 18 FMAs (element-per-lane needed 2 reads per FMA and was LDS-bound; so was row-per-lane).
+// A group walks its lists front to back, so every sum has a fixed order (bitwise reproducible, no atomics).
+// List entries are pre-expanded by the host into LDS offsets (two 15-bit fields, doubles relative to the staging base):
 //   Schur entry : offset of the E row (frame a) | offset of the E*H_ll^-1 (points) / H_ll^-1 E (lines) row (frame b) << 16
 //   direct entry: points: offset of the first Jacobian block | offset of the second << 16 ; lines: record offset
-// so the inner loops are: readlane, two scalar field extracts, LDS reads at (scalar + lane constant), FMAs.
-// Gradient lanes need no Schur list: pass B stores the Schur-CORRECTED residual rc = r - J_l H_ll^-1 g_l in every record,
+// Gradient entries need no Schur list: pass B stores the Schur-CORRECTED residual rc = r - J_l H_ll^-1 g_l in every record,
 // and sum_o J_p^T rc IS the reduced gradient.
-UVS_DEV void gather_points(const int* wb, const int* lists, const double* S0, double* acc) {
-    const int lane = threadIdx.x & 63;
-    const int role = lane < 36 ? 0 : lane < 42 ? 1 : lane < 48 ? 2 : 3;
-    const int a = role == 0 ? lane / 6 : role == 1 ? lane - 36 : role == 2 ? lane - 42 : 0;
-    const int bb = role == 0 ? lane - 6 * (lane / 6) : 0;
-    const bool r0 = role == 0, r1 = role == 1;
-    const int kq = r0 ? bb : r1 ? 12 : a, kdd = r1 ? 1 : 6;      // direct second operand: J_b column / corrected residual / itself
-    const int* ent = lists + 2 * (UVS_NBLK + 1);
+static constexpr int GRP_PER_WAVE = 32;
+static constexpr int LIST_HDR = 2 * (UVS_NGRP + 1);
+typedef double d2_t __attribute__((ext_vector_type(2)));
+
+struct GAcc { double v[18], g[3], hd[3]; };     // v[6r + c]: rows 3t + r of the block; gradient and diag(J^T J) of those rows
+
+UVS_DEV d2_t lds2(const double* p) { return *(const d2_t*)p; }
+UVS_DEV void gacc_zero(GAcc& A) {
 #pragma unroll
-    for (int q = 0; q < BLOCKS_PER_WAVE; ++q) {
-        if (wb[q] >= 0) {                                  // host-balanced block -> wave assignment (-1 = none), bit 8 = diagonal block
-            const int b = wb[q] & 255;
-            const bool diag = (wb[q] >> 8) != 0;
-            const double md = (r0 || (diag && role < 3)) ? 1.0 : 0.0;      // direct-term mask
-            double s = 0.0;
-            int e0 = lists[b], e1 = lists[b + 1];
-            for (int base = e0; base < e1; base += 64) {
-                const int mine = (base + lane < e1) ? ent[base + lane] : 0;      // every lane fetches (readlane needs all 64 slots)
-                const int n = min(64, e1 - base);
-                if (r0) {
-                    int i = 0;
-                    for (; i + 8 <= n; i += 8) {            // 8 entries in flight
-                        double v1[8], v2[8];
+    for (int q = 0; q < 18; ++q) A.v[q] = 0.0;
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            const int e = __builtin_amdgcn_readlane(mine, i + u);
-                            v1[u] = S0[(e & 0xffff) + a];
-                            v2[u] = S0[((unsigned)e >> 16) + bb];
-                        }
+    for (int q = 0; q < 3; ++q) { A.g[q] = 0.0; A.hd[q] = 0.0; }
+}
+// A.v[6r + ..] += s * (row of 6 doubles held as 3 x d2_t)
+UVS_DEV void row_fma(double* v, double s, const d2_t* q) {
+    v[0] += s * q[0].x; v[1] += s * q[0].y; v[2] += s * q[1].x; v[3] += s * q[1].y; v[4] += s * q[2].x; v[5] += s * q[2].y;
+}
+
+// this lane's group descriptor (-1 = idle group), see uvs_layout.h: i_wblk
+UVS_DEV int gather_group(const Ctx& c) { return c.bi[c.hdr->i_wblk + (threadIdx.x >> 1)]; }
+
+UVS_DEV void gather_points(int grp, const int* lists, const double* S0, GAcc& A) {
+    const int g = threadIdx.x >> 1, r0 = 3 * (threadIdx.x & 1);
+    const bool on = grp >= 0;
+    const bool diag = on && ((grp >> 8) & 1);
+    const int* ent = lists + LIST_HDR;
+    // ---- Schur: acc[r][c] -= E_a[r0 + r] * Einv_b[c]
+    {
+        const int e0 = on ? lists[g] : 0, e1 = on ? lists[g + 1] : 0;
+        for (int i = e0; i < e1; i += 2) {
+            double ea[2][3]; d2_t q[2][3];
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) s -= v1[u] * v2[u];
-                    }
-                    for (; i < n; ++i) {
-                        const int e = __builtin_amdgcn_readlane(mine, i);
-                        s -= S0[(e & 0xffff) + a] * S0[((unsigned)e >> 16) + bb];
-                    }
-                }
+            for (int u = 0; u < 2; ++u) {
+                const bool ok = i + u < e1;
+                const int e = ok ? ent[i + u] : 0;
+                const double* pa = S0 + (e & 0x7fff) + r0;
+                const double* pb = S0 + ((unsigned)e >> 16);
+#pragma unroll
+                for (int r = 0; r < 3; ++r) ea[u][r] = ok ? -pa[r] : 0.0;
+                q[u][0] = lds2(pb); q[u][1] = lds2(pb + 2); q[u][2] = lds2(pb + 4);
             }
-            e0 = lists[UVS_NBLK + 1 + b]; e1 = lists[UVS_NBLK + 2 + b];
-            for (int base = e0; base < e1; base += 64) {
-                const int mine = (base + lane < e1) ? ent[base + lane] : 0;
-                const int n = min(64, e1 - base);
-                int i = 0;
-                for (; i + 4 <= n; i += 4) {
-                    double p0[4], p1[4], q0[4], q1[4];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int e = __builtin_amdgcn_readlane(mine, i + u);
-                        const int lo = e & 0xffff, hi = (unsigned)e >> 16;
-                        const int iq = (r0 ? hi : lo) + kq;
-                        p0[u] = S0[lo + a]; p1[u] = S0[lo + 6 + a];
-                        q0[u] = S0[iq]; q1[u] = S0[iq + kdd];
-                    }
+            for (int u = 0; u < 2; ++u)
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) s += md * (p0[u] * q0[u] + p1[u] * q1[u]);
-                }
-                for (; i < n; ++i) {
-                    const int e = __builtin_amdgcn_readlane(mine, i);
-                    const int lo = e & 0xffff, hi = (unsigned)e >> 16;
-                    const int iq = (r0 ? hi : lo) + kq;
-                    s += md * (S0[lo + a] * S0[iq] + S0[lo + 6 + a] * S0[iq + kdd]);
-                }
+                for (int r = 0; r < 3; ++r) row_fma(A.v + 6 * r, ea[u][r], q[u]);
+        }
+    }
+    // ---- direct: acc[r][c] += J1[0][r0+r] J2[0][c] + J1[1][r0+r] J2[1][c] ; diagonal blocks (J1 == J2) also g and diag(J^T J)
+    {
+        const int e0 = on ? lists[UVS_NGRP + 1 + g] : 0, e1 = on ? lists[UVS_NGRP + 2 + g] : 0;
+        int e = (e0 < e1) ? ent[e0] : 0;
+        for (int i = e0; i < e1; ++i) {
+            const int en = (i + 1 < e1) ? ent[i + 1] : 0;      // next entry in flight while this one is consumed
+            const int lo = e & 0x7fff;
+            const double* pa = S0 + lo + r0;
+            const double* pb = S0 + ((unsigned)e >> 16);
+            double p0[3], p1[3]; d2_t q0[3], q1[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) { p0[r] = pa[r]; p1[r] = pa[6 + r]; }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { q0[k] = lds2(pb + 2 * k); q1[k] = lds2(pb + 6 + 2 * k); }
+            const d2_t rc = lds2(S0 + lo + 12);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                row_fma(A.v + 6 * r, p0[r], q0); row_fma(A.v + 6 * r, p1[r], q1);
+                if (diag) { A.g[r] += p0[r] * rc.x + p1[r] * rc.y; A.hd[r] += p0[r] * p0[r] + p1[r] * p1[r]; }
             }
-            acc[q] += s;
+            e = en;
         }
     }
 }
 
-UVS_DEV void gather_lines(const int* wb, const int* lists, const double* S0, double* acc) {
-    const int lane = threadIdx.x & 63;
-    const int role = lane < 36 ? 0 : lane < 42 ? 1 : lane < 48 ? 2 : 3;
-    const int a = role == 0 ? lane / 6 : role == 1 ? lane - 36 : role == 2 ? lane - 42 : 0;
-    const int bb = role == 0 ? lane - 6 * (lane / 6) : 0;
-    const bool r0 = role == 0, r1 = role == 1;
-    // direct second operand rows: role0 -> (2+bb, 8+bb, 23+bb), role1 -> corrected residual (14, 15, 16), else -> (2+a, 8+a, 23+a)
-    const int d0 = r0 ? 2 + bb : r1 ? 14 : 2 + a, d1 = r0 ? 8 + bb : r1 ? 15 : 8 + a, d2 = r0 ? 23 + bb : r1 ? 16 : 23 + a;
-    const int* ent = lists + 2 * (UVS_NBLK + 1);
+UVS_DEV void gather_lines(int grp, const int* lists, const double* S0, GAcc& A) {
+    const int g = threadIdx.x >> 1, r0 = 3 * (threadIdx.x & 1);
+    const bool on = grp >= 0;
+    const int* ent = lists + LIST_HDR;
+    // ---- Schur: acc[r][c] -= sum_q E_a[q][r0 + r] * Y_b[q][c]
+    {
+        const int e0 = on ? lists[g] : 0, e1 = on ? lists[g + 1] : 0;
+        int e = (e0 < e1) ? ent[e0] : 0;
+        for (int i = e0; i < e1; ++i) {
+            const int en = (i + 1 < e1) ? ent[i + 1] : 0;
+            const double* pa = S0 + (e & 0x7fff) + r0;
+            const double* pb = S0 + ((unsigned)e >> 16);
+            double ea[4][3]; d2_t y[4][3];
 #pragma unroll
-    for (int q = 0; q < BLOCKS_PER_WAVE; ++q) {
-        if (wb[q] >= 0) {
-            const int b = wb[q] & 255;
-            const bool diag = (wb[q] >> 8) != 0;
-            const double md = (r0 || (diag && role < 3)) ? 1.0 : 0.0;
-            double s = 0.0;
-            int e0 = lists[b], e1 = lists[b + 1];
-            for (int base = e0; base < e1; base += 64) {
-                const int mine = (base + lane < e1) ? ent[base + lane] : 0;
-                const int n = min(64, e1 - base);
-                if (r0) {
-                    int i = 0;
-                    for (; i + 2 <= n; i += 2) {
-                        double ea[2][4], qq[2][4];
+            for (int q = 0; q < 4; ++q) {
 #pragma unroll
-                        for (int u = 0; u < 2; ++u) {
-                            const int e = __builtin_amdgcn_readlane(mine, i + u);
-                            const int ia = (e & 0xffff) + a, iq = ((unsigned)e >> 16) + bb;
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) { ea[u][k] = S0[ia + 6 * k]; qq[u][k] = S0[iq + 6 * k]; }
-                        }
-#pragma unroll
-                        for (int u = 0; u < 2; ++u) s -= ea[u][0] * qq[u][0] + ea[u][1] * qq[u][1] + ea[u][2] * qq[u][2] + ea[u][3] * qq[u][3];
-                    }
-                    for (; i < n; ++i) {
-                        const int e = __builtin_amdgcn_readlane(mine, i);
-                        const int ia = (e & 0xffff) + a, iq = ((unsigned)e >> 16) + bb;
-                        s -= S0[ia] * S0[iq] + S0[ia + 6] * S0[iq + 6] + S0[ia + 12] * S0[iq + 12] + S0[ia + 18] * S0[iq + 18];
-                    }
-                }
+                for (int r = 0; r < 3; ++r) ea[q][r] = -pa[6 * q + r];
+                y[q][0] = lds2(pb + 6 * q); y[q][1] = lds2(pb + 6 * q + 2); y[q][2] = lds2(pb + 6 * q + 4);
             }
-            e0 = lists[UVS_NBLK + 1 + b]; e1 = lists[UVS_NBLK + 2 + b];
-            for (int base = e0; base < e1; base += 64) {
-                const int mine = (base + lane < e1) ? ent[base + lane] : 0;
-                const int n = min(64, e1 - base);
-                int i = 0;
-                for (; i + 2 <= n; i += 2) {
-                    double p[2][3], qv[2][3];
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        const int ro = __builtin_amdgcn_readlane(mine, i + u);
-                        p[u][0] = S0[ro + 2 + a]; p[u][1] = S0[ro + 8 + a]; p[u][2] = S0[ro + 23 + a];
-                        qv[u][0] = S0[ro + d0]; qv[u][1] = S0[ro + d1]; qv[u][2] = S0[ro + d2];
-                    }
+            for (int q = 0; q < 4; ++q)
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) s += md * (p[u][0] * qv[u][0] + p[u][1] * qv[u][1] + p[u][2] * qv[u][2]);
-                }
-                for (; i < n; ++i) {
-                    const int ro = __builtin_amdgcn_readlane(mine, i);
-                    s += md * (S0[ro + 2 + a] * S0[ro + d0] + S0[ro + 8 + a] * S0[ro + d1] + S0[ro + 23 + a] * S0[ro + d2]);
-                }
+                for (int r = 0; r < 3; ++r) row_fma(A.v + 6 * r, ea[q][r], y[q]);
+            e = en;
+        }
+    }
+    // ---- direct (always a diagonal block): 3 pose-Jacobian rows (line, line, vanishing point) + corrected residuals
+    {
+        const int e0 = on ? lists[UVS_NGRP + 1 + g] : 0, e1 = on ? lists[UVS_NGRP + 2 + g] : 0;
+        int ro = (e0 < e1) ? ent[e0] : 0;
+        for (int i = e0; i < e1; ++i) {
+            const int rn = (i + 1 < e1) ? ent[i + 1] : 0;
+            const double* R = S0 + ro;
+            double p[3][3]; d2_t q[3][3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) p[k][r] = R[UVS_LN_JP + 6 * k + r0 + r];
+                q[k][0] = lds2(R + UVS_LN_JP + 6 * k); q[k][1] = lds2(R + UVS_LN_JP + 6 * k + 2); q[k][2] = lds2(R + UVS_LN_JP + 6 * k + 4);
             }
-            acc[q] += s;
+            const d2_t rc01 = lds2(R); const double rc2 = R[UVS_LN_RV];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { row_fma(A.v + 6 * r, p[k][r], q[k]); A.hd[r] += p[k][r] * p[k][r]; }
+                A.g[r] += p[0][r] * rc01.x + p[1][r] * rc01.y + p[2][r] * rc2;
+            }
+            ro = rn;
         }
     }
 }
@@ -608,7 +597,7 @@ UVS_DEV double lin_frames(const Ctx& c, const double* x) {
 
 // ---- linearization, part 2: one landmark chunk: stage -> per-landmark Schur prep -> list-driven gather into acc[]
 UVS_DEV void lin_chunk(const Ctx& c, int ch, const double* x, const double* invd, const double* line, bool first, double radius,
-                       const int* wb, double* acc, double& cost, double& gmax_lm) {
+                       int grp, GAcc& acc, double& cost, double& gmax_lm) {
     const DevWin& h = *c.hdr;
     double* sh = c.sh;
     const int tid = threadIdx.x;
@@ -684,7 +673,7 @@ UVS_DEV void lin_chunk(const Ctx& c, int ch, const double* x, const double* invd
             __syncthreads();
             UVS_PROF(c, P_LMPREP);
             const long long tg0_ = clock64();
-            gather_points(wb, lists, rec, acc);
+            gather_points(grp, lists, rec, acc);
             if (c.o.debug && (tid & 63) == 0) sh[L_WPROF + (tid >> 6)] += (double)(clock64() - tg0_);
         } else {
             const int* beg = c.bi + h.i_ln_beg;
@@ -708,21 +697,25 @@ UVS_DEV void lin_chunk(const Ctx& c, int ch, const double* x, const double* invd
                 cost += 0.5 * cauchy(c.o.loss_ln, r[0] * r[0] + r[1] * r[1], &sc);
                 R[0] = sc * r[0]; R[1] = sc * r[1];
 #pragma unroll
-                for (int q = 0; q < 12; ++q) R[2 + q] = sc * Jp[q];
+                for (int q = 0; q < 12; ++q) R[UVS_LN_JP + q] = sc * Jp[q];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) R[14 + q] = sc * Jl[q];
+                for (int q = 0; q < 8; ++q) R[UVS_LN_JL + q] = sc * Jl[q];
+                R[UVS_LN_RV + 1] = 0.0;
                 if (hv) {
                     double rv, Jvp[6], Jvl[4];
                     vp_residual<true>(g, vp, c.o.vp_factor, &rv, Jvp, Jvl);
                     cost += 0.5 * cauchy(c.o.loss_vp, rv * rv, &sc);
-                    R[22] = sc * rv;
+                    R[UVS_LN_RV] = sc * rv;
 #pragma unroll
-                    for (int q = 0; q < 6; ++q) R[23 + q] = sc * Jvp[q];
+                    for (int q = 0; q < 6; ++q) R[UVS_LN_JP + 12 + q] = sc * Jvp[q];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) R[29 + q] = sc * Jvl[q];
+                    for (int q = 0; q < 4; ++q) R[UVS_LN_JL + 8 + q] = sc * Jvl[q];
                 } else {
 #pragma unroll
-                    for (int q = 22; q < 33; ++q) R[q] = 0.0;
+                    for (int q = 0; q < 6; ++q) R[UVS_LN_JP + 12 + q] = 0.0;
+                    R[UVS_LN_RV] = 0.0;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) R[UVS_LN_JL + 8 + q] = 0.0;
                 }
             }
             __syncthreads();
@@ -735,9 +728,9 @@ UVS_DEV void lin_chunk(const Ctx& c, int ch, const double* x, const double* invd
                     const double* R = rec + (size_t)o * UVS_LN_REC;
 #pragma unroll
                     for (int a = 0; a < 4; ++a) {
-                        gl[a] += R[14 + a] * R[0] + R[18 + a] * R[1] + R[29 + a] * R[22];
+                        gl[a] += R[UVS_LN_JL + a] * R[0] + R[UVS_LN_JL + 4 + a] * R[1] + R[UVS_LN_JL + 8 + a] * R[UVS_LN_RV];
 #pragma unroll
-                        for (int b = 0; b <= a; ++b) H[(a * (a + 1)) / 2 + b] += R[14 + a] * R[14 + b] + R[18 + a] * R[18 + b] + R[29 + a] * R[29 + b];
+                        for (int b = 0; b <= a; ++b) H[(a * (a + 1)) / 2 + b] += R[UVS_LN_JL + a] * R[UVS_LN_JL + b] + R[UVS_LN_JL + 4 + a] * R[UVS_LN_JL + 4 + b] + R[UVS_LN_JL + 8 + a] * R[UVS_LN_JL + 8 + b];
                     }
                 }
                 double* lx = c.ws + h.w_ln_x + 12 * (size_t)k;
@@ -790,28 +783,29 @@ UVS_DEV void lin_chunk(const Ctx& c, int ch, const double* x, const double* invd
                 for (int a = 0; a < 6; ++a) {
                     double e[4];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) { e[q] = R[14 + q] * R[2 + a] + R[18 + q] * R[8 + a] + R[29 + q] * R[23 + a]; E[6 * q + a] = e[q]; }
+                    for (int q = 0; q < 4; ++q) { e[q] = R[UVS_LN_JL + q] * R[UVS_LN_JP + a] + R[UVS_LN_JL + 4 + q] * R[UVS_LN_JP + 6 + a] + R[UVS_LN_JL + 8 + q] * R[UVS_LN_JP + 12 + a]; E[6 * q + a] = e[q]; }
 #pragma unroll
                     for (int q = 0; q < 4; ++q) { const double y = X[4 * q] * e[0] + X[4 * q + 1] * e[1] + X[4 * q + 2] * e[2] + X[4 * q + 3] * e[3]; Y[6 * q + a] = y; Yg[6 * q + a] = y; }
                 }
                 // Schur-corrected residual rc = r - J_l (H_ll^-1 g_l) for the 2 line rows and the VP row; J_l of this record is dead now
-                const double rc0 = R[0] - (R[14] * X[16] + R[15] * X[17] + R[16] * X[18] + R[17] * X[19]);
-                const double rc1 = R[1] - (R[18] * X[16] + R[19] * X[17] + R[20] * X[18] + R[21] * X[19]);
-                const double rc2 = R[22] - (R[29] * X[16] + R[30] * X[17] + R[31] * X[18] + R[32] * X[19]);
+                const double* Jl = R + UVS_LN_JL;
+                const double rc0 = R[0] - (Jl[0] * X[16] + Jl[1] * X[17] + Jl[2] * X[18] + Jl[3] * X[19]);
+                const double rc1 = R[1] - (Jl[4] * X[16] + Jl[5] * X[17] + Jl[6] * X[18] + Jl[7] * X[19]);
+                const double rc2 = R[UVS_LN_RV] - (Jl[8] * X[16] + Jl[9] * X[17] + Jl[10] * X[18] + Jl[11] * X[19]);
                 double* Rw = rec + (size_t)o * UVS_LN_REC;
-                Rw[14] = rc0; Rw[15] = rc1; Rw[16] = rc2;
+                Rw[0] = rc0; Rw[1] = rc1; Rw[UVS_LN_RV] = rc2;
             }
             __syncthreads();
             UVS_PROF(c, P_LMPREP);
             const long long tg0_ = clock64();
-            gather_lines(wb, lists, rec, acc);
+            gather_lines(grp, lists, rec, acc);
             if (c.o.debug && (tid & 63) == 0) sh[L_WPROF + (tid >> 6)] += (double)(clock64() - tg0_);
         }
     }
 }
 
 // ---- linearization, part 3: assemble the damped reduced system in LDS from the gathered pose blocks + IMU + prior
-UVS_DEV void lin_assemble(const Ctx& c, const double* x, bool first, double radius, const int* wb, const double* acc, double cost, double gmax_lm) {
+UVS_DEV void lin_assemble(const Ctx& c, const double* x, bool first, double radius, int grp, const GAcc& A, double cost, double gmax_lm) {
     const DevWin& h = *c.hdr;
     double* sh = c.sh;
     const int tid = threadIdx.x;
@@ -821,23 +815,28 @@ UVS_DEV void lin_assemble(const Ctx& c, const double* x, bool first, double radi
     for (int i = tid; i < UVS_S_DOUBLES; i += NT) sh[L_S + i] = 0.0;
     if (tid < UVS_RD) { sh[L_G + tid] = 0.0; sh[L_HD + tid] = 0.0; }
     __syncthreads();
-    {
-        const int lane = tid & 63, wv = tid >> 6;
-        const int role = lane < 36 ? 0 : lane < 42 ? 1 : lane < 48 ? 2 : 3;
-        const int a = role == 0 ? lane / 6 : role == 1 ? lane - 36 : role == 2 ? lane - 42 : 0;
-        const int bb = role == 0 ? lane - 6 * (lane / 6) : 0;
+    // every group adds its rows of its pose block; the parts of a split block go in part order, one barrier apart (fixed sum order)
+    for (int part = 0; part < h.n_parts; ++part) {
+        if (grp >= 0 && ((grp >> 9) & 15) == part) {
+            const int r0 = 3 * (tid & 1);
+            const int fa = (grp >> 13) & 15, fb = (grp >> 17) & 15;
 #pragma unroll
-        for (int q = 0; q < BLOCKS_PER_WAVE; ++q) {
-            if (wb[q] >= 0) {
-                const int b = wb[q] & 255;
-                const int fa = c_blk_fa[b], fb = c_blk_fb[b];
-                if (role == 0) { if (fa != fb || a >= bb) sh[L_S + sidx(16 * fa + a, 16 * fb + bb)] = acc[q]; }
-                else if (fa == fb && role == 1) sh[L_G + 16 * fa + a] = acc[q];
-                else if (fa == fb && role == 2) sh[L_HD + 16 * fa + a] = acc[q];
+            for (int r = 0; r < 3; ++r) {
+                const int a = r0 + r;
+                double* row = sh + L_S + sidx(16 * fa + a, 16 * fb);
+                if (fa != fb) {
+#pragma unroll
+                    for (int cc = 0; cc < 6; ++cc) row[cc] += A.v[6 * r + cc];
+                } else {
+#pragma unroll
+                    for (int cc = 0; cc < 6; ++cc) if (cc <= a) row[cc] += A.v[6 * r + cc];
+                    sh[L_G + 16 * fa + a] += A.g[r];
+                    sh[L_HD + 16 * fa + a] += A.hd[r];
+                }
             }
         }
+        __syncthreads();
     }
-    __syncthreads();
     UVS_PROF(c, P_AS_ZERO);
     // IMU normal-equation blocks from global scratch (even blocks, then odd: consecutive blocks share a diagonal frame block)
     for (int par = 0; par < 2; ++par) {
@@ -914,14 +913,11 @@ UVS_DEV void lin_assemble(const Ctx& c, const double* x, bool first, double radi
 
 UVS_DEV void linearize(const Ctx& c, const double* x, const double* invd, const double* line, bool first, double radius) {
     const DevWin& h = *c.hdr;
-    const int tid = threadIdx.x;
-    double acc[BLOCKS_PER_WAVE];
-    int wb[BLOCKS_PER_WAVE];       // this wave's pose blocks (wave-uniform => SGPRs), fetched once per linearization
-#pragma unroll
-    for (int q = 0; q < BLOCKS_PER_WAVE; ++q) { acc[q] = 0.0; wb[q] = __builtin_amdgcn_readfirstlane(c.bi[h.i_wblk + (tid >> 6) * BLOCKS_PER_WAVE + q]); }
+    const int grp = gather_group(c);       // this lane's gather group: pose block | flags (uvs_layout.h: i_wblk)
+    GAcc A; gacc_zero(A);
     double cost = lin_frames(c, x), gmax_lm = 0.0;
-    for (int ch = 0; ch < h.n_chunks; ++ch) lin_chunk(c, ch, x, invd, line, first, radius, wb, acc, cost, gmax_lm);
-    lin_assemble(c, x, first, radius, wb, acc, cost, gmax_lm);
+    for (int ch = 0; ch < h.n_chunks; ++ch) lin_chunk(c, ch, x, invd, line, first, radius, grp, A, cost, gmax_lm);
+    lin_assemble(c, x, first, radius, grp, A, cost, gmax_lm);
 }
 
 // ------------------------------------------------------------------ back-substitution + candidate + model terms

@@ -206,40 +206,54 @@ static int pack_window(const uvs_window* w, std::vector<char>& out, DevWin& hdr,
     // observation records, the per-landmark Schur factors AND its gather lists (ints, 2 per double).
     std::vector<int> chunks;     // 6 ints per chunk
     {
-        const long list_hdr = 2 * (UVS_NBLK + 1);
-        int k0 = 0; long nob = 0, nli = list_hdr;
-        for (int k = 0; k < h.n_points; ++k) {
-            const long no = pbeg[k + 1] - pbeg[k];
-            const long li_k = no ? (no + 1) * (no + 2) / 2 + 3 * no : 0;
-            const long nlm = k - k0 + 1;
-            const long need = (long)UVS_PT_REC * (nob + no) + 12 * (nob + no + nlm) + (nli + li_k + 1) / 2;
-            if ((need > UVS_S_DOUBLES || nlm > 1023 || nob + no + nlm > 16383) && k > k0) { chunks.insert(chunks.end(), {0, k0, k, 0, 0, 0}); k0 = k; nob = 0; nli = list_hdr; }
-            nob += no; nli += li_k;
-            if ((long)UVS_PT_REC * nob + 12 * (nob + 1) + (nli + 1) / 2 > UVS_S_DOUBLES) { err = "single point landmark exceeds LDS staging"; return UVS_ERR_CAPACITY; }
-        }
-        if (h.n_points > k0) chunks.insert(chunks.end(), {0, k0, h.n_points, 0, 0, 0});
-        k0 = 0; nob = 0; nli = list_hdr;
-        for (int k = 0; k < h.n_lines; ++k) {
-            const long no = lbeg[k + 1] - lbeg[k];
-            const long li_k = no * (no + 1) / 2 + no;
-            const long nlm = k - k0 + 1;
-            const long need = (long)(UVS_LN_REC + 48) * (nob + no) + 20 * nlm + (nli + li_k + 1) / 2;
-            if ((need > UVS_S_DOUBLES || nlm > 1023 || nob + no > 16383) && k > k0) { chunks.insert(chunks.end(), {1, k0, k, 0, 0, 0}); k0 = k; nob = 0; nli = list_hdr; }
-            nob += no; nli += li_k;
-        }
-        if (h.n_lines > k0) chunks.insert(chunks.end(), {1, k0, h.n_lines, 0, 0, 0});
+        const long list_hdr = 2 * (UVS_NGRP + 1);
+        // LDS doubles a chunk of landmarks [k0, k1) needs (records + Schur factors + gather lists), -1 if an index field overflows
+        auto need_pt = [&](int k0, int k1) -> long {
+            long nob = pbeg[k1] - pbeg[k0], nlm = k1 - k0, nli = list_hdr;
+            for (int k = k0; k < k1; ++k) { const long no = pbeg[k + 1] - pbeg[k]; nli += no ? (no + 1) * (no + 2) / 2 + 3 * no : 0; }
+            if (nlm > 1023 || nob + nlm > 16383) return -1;
+            return (long)UVS_PT_REC * nob + 12 * (nob + nlm) + (nli + 1) / 2;
+        };
+        auto need_ln = [&](int k0, int k1) -> long {
+            long nob = lbeg[k1] - lbeg[k0], nlm = k1 - k0, nli = list_hdr;
+            for (int k = k0; k < k1; ++k) { const long no = lbeg[k + 1] - lbeg[k]; nli += no * (no + 1) / 2 + no; }
+            if (nlm > 1023 || nob > 16383) return -1;
+            return (long)(UVS_LN_REC + 48) * nob + 20 * nlm + (nli + 1) / 2;
+        };
+        // smallest number of chunks whose EVEN split (by observation count) fits; the kernel pays a fixed cost per chunk, so a
+        // greedy fill that leaves a nearly empty last chunk would waste a whole pass
+        auto split = [&](int type, int n_lm, const std::vector<int>& beg, auto&& need) -> int {
+            if (n_lm == 0) return UVS_OK;
+            for (int n = 1; n <= n_lm; ++n) {
+                std::vector<int> cut(1, 0);
+                const long tot = beg[n_lm];
+                for (int j = 1; j < n; ++j) {
+                    int k = cut.back() + 1;
+                    while (k < n_lm && (long)beg[k] * n < tot * j) ++k;
+                    cut.push_back(std::min(k, n_lm - (n - j)));
+                }
+                cut.push_back(n_lm);
+                bool ok = true;
+                for (int j = 0; j < n && ok; ++j) { const long nd = need(cut[j], cut[j + 1]); ok = cut[j + 1] > cut[j] && nd >= 0 && nd <= UVS_S_DOUBLES; }
+                if (ok) { for (int j = 0; j < n; ++j) chunks.insert(chunks.end(), {type, cut[j], cut[j + 1], 0, 0, 0}); return UVS_OK; }
+            }
+            return UVS_ERR_CAPACITY;
+        };
+        if (split(0, h.n_points, pbeg, need_pt) != UVS_OK) { err = "single point landmark exceeds LDS staging"; return UVS_ERR_CAPACITY; }
+        if (split(1, h.n_lines, lbeg, need_ln) != UVS_OK) { err = "single line landmark exceeds LDS staging"; return UVS_ERR_CAPACITY; }
     }
-    // gather lists (one pair per chunk and per lower 6x6 pose block, see uvs_solve_kernel.h: gather_points / gather_lines),
-    // pre-expanded into LDS offsets (doubles from the staging base; the chunk layout below mirrors linearize()):
-    //   points: rec[nob][31] | E[(nob+nlm)][6] | EI[(nob+nlm)][6] | lists      lines: rec[nob][33] | E[nob][24] | Y[nob][24] | X[nlm][20] | lists
+    // gather lists per chunk and per lower 6x6 pose block (see uvs_solve_kernel.h: gather_points / gather_lines),
+    // pre-expanded into LDS offsets (doubles from the staging base; the chunk layout below mirrors lin_chunk()):
+    //   points: rec[nob][30] | E[(nob+nlm)][6] | EI[(nob+nlm)][6] | lists      lines: rec[nob][34] | E[nob][24] | Y[nob][24] | X[nlm][20] | lists
     //   Schur entry : offset(E row of frame a) | offset(EI / Y row of frame b) << 16
     //   direct entry: points: offset(first Jacobian block) | offset(second) << 16   (A^T A, B^T B, B^T A) ; lines: record offset
-    std::vector<int> lists;
+    const int n_ch = (int)chunks.size() / 6;
+    std::vector<std::vector<std::vector<int>>> sch(n_ch, std::vector<std::vector<int>>(UVS_NBLK)), dir(n_ch, std::vector<std::vector<int>>(UVS_NBLK));
     std::vector<long> blk_work(UVS_NBLK, 0);
     auto blk_of = [](int fa, int fb) { return fa * (fa + 1) / 2 + fb; };   // fa >= fb
-    for (size_t q = 0; q < chunks.size(); q += 6) {
-        const int type = chunks[q], k0 = chunks[q + 1], k1 = chunks[q + 2];
-        std::vector<std::vector<int>> sch(UVS_NBLK), dir(UVS_NBLK);
+    for (int qc = 0; qc < n_ch; ++qc) {
+        const int type = chunks[6 * qc], k0 = chunks[6 * qc + 1], k1 = chunks[6 * qc + 2];
+        auto& S = sch[qc]; auto& Dr = dir[qc];
         if (type == 0) {
             const int o0 = pbeg[k0], nob = pbeg[k1] - o0, nlm = k1 - k0;
             const int oE = nob * UVS_PT_REC, oEI = oE + 6 * (nob + nlm);
@@ -251,12 +265,12 @@ static int pack_window(const uvs_window* w, std::vector<char>& out, DevWin& hdr,
                 fr[nf++] = w->pt_fi[o0 + b0];
                 for (int o = b0; o < b1; ++o) fr[nf++] = w->pt_fj[o0 + o];
                 for (int sa = 0; sa < nf; ++sa) for (int sb = 0; sb <= sa; ++sb)      // frames increase with the slot => fr[sa] >= fr[sb]
-                    sch[blk_of(fr[sa], fr[sb])].push_back((oE + 6 * (first_slot + sa)) | ((oEI + 6 * (first_slot + sb)) << 16));
+                    S[blk_of(fr[sa], fr[sb])].push_back((oE + 6 * (first_slot + sa)) | ((oEI + 6 * (first_slot + sb)) << 16));
                 for (int o = b0; o < b1; ++o) {
                     const int fi = w->pt_fi[o0 + o], fj = w->pt_fj[o0 + o], ro = o * UVS_PT_REC;
-                    dir[blk_of(fi, fi)].push_back((ro + UVS_PT_A) | ((ro + UVS_PT_A) << 16));
-                    dir[blk_of(fj, fj)].push_back((ro + UVS_PT_B) | ((ro + UVS_PT_B) << 16));
-                    dir[blk_of(fj, fi)].push_back((ro + UVS_PT_B) | ((ro + UVS_PT_A) << 16));
+                    Dr[blk_of(fi, fi)].push_back((ro + UVS_PT_A) | ((ro + UVS_PT_A) << 16));
+                    Dr[blk_of(fj, fj)].push_back((ro + UVS_PT_B) | ((ro + UVS_PT_B) << 16));
+                    Dr[blk_of(fj, fi)].push_back((ro + UVS_PT_B) | ((ro + UVS_PT_A) << 16));
                 }
             }
         } else {
@@ -265,36 +279,69 @@ static int pack_window(const uvs_window* w, std::vector<char>& out, DevWin& hdr,
             for (int k = k0; k < k1; ++k) {
                 const int b0 = lbeg[k] - o0, b1 = lbeg[k + 1] - o0;
                 for (int sa = 0; sa < b1 - b0; ++sa) for (int sb = 0; sb <= sa; ++sb)
-                    sch[blk_of(w->ln_fj[o0 + b0 + sa], w->ln_fj[o0 + b0 + sb])].push_back((oE + 24 * (b0 + sa)) | ((oY + 24 * (b0 + sb)) << 16));
-                for (int o = b0; o < b1; ++o) dir[blk_of(w->ln_fj[o0 + o], w->ln_fj[o0 + o])].push_back(o * UVS_LN_REC);
+                    S[blk_of(w->ln_fj[o0 + b0 + sa], w->ln_fj[o0 + b0 + sb])].push_back((oE + 24 * (b0 + sa)) | ((oY + 24 * (b0 + sb)) << 16));
+                for (int o = b0; o < b1; ++o) Dr[blk_of(w->ln_fj[o0 + o], w->ln_fj[o0 + o])].push_back(o * UVS_LN_REC);
             }
         }
-        for (int b = 0; b < UVS_NBLK; ++b) blk_work[b] += (type == 0 ? 1 : 3) * (long)sch[b].size() + (type == 0 ? 2 : 2) * (long)dir[b].size();
-        chunks[q + 3] = (int)lists.size();
-        const size_t base = lists.size();
-        lists.resize(base + 2 * (UVS_NBLK + 1));
-        int run = 0;
-        for (int b = 0; b < UVS_NBLK; ++b) { lists[base + b] = run; run += (int)sch[b].size(); }
-        lists[base + UVS_NBLK] = run;
-        for (int b = 0; b < UVS_NBLK; ++b) { lists[base + UVS_NBLK + 1 + b] = run; run += (int)dir[b].size(); }
-        lists[base + 2 * UVS_NBLK + 1] = run;
-        for (int b = 0; b < UVS_NBLK; ++b) lists.insert(lists.end(), sch[b].begin(), sch[b].end());
-        for (int b = 0; b < UVS_NBLK; ++b) lists.insert(lists.end(), dir[b].begin(), dir[b].end());
-        chunks[q + 4] = (int)(lists.size() - base);
+        // work units ~ LDS read instructions per entry of the row-per-lane gather
+        for (int b = 0; b < UVS_NBLK; ++b) blk_work[b] += (type == 0 ? 4 : 16) * (long)S[b].size() + (type == 0 ? 9 : 12) * (long)Dr[b].size();
     }
-    // balance the 66 pose blocks over the 8 gather waves (longest list first, at most 9 blocks per wave)
-    int wblk[NW * BLOCKS_PER_WAVE];
+    // gather groups: 256 two-lane groups, at least one per pose block; the spare ones split the heaviest blocks further.  Groups are dealt to
+    // the waves heaviest first (similar list lengths inside a wave => little divergence); the wave order pairs heavy with light
+    // waves on a SIMD (waves w and w+4 share one).
+    int wblk[UVS_NGRP], g_blk[UVS_NGRP], g_part[UVS_NGRP], g_np[UVS_NGRP];
     {
-        for (int q = 0; q < NW * BLOCKS_PER_WAVE; ++q) wblk[q] = -1;
-        std::vector<int> order(UVS_NBLK); for (int b = 0; b < UVS_NBLK; ++b) order[b] = b;
-        std::stable_sort(order.begin(), order.end(), [&](int a, int b2) { return blk_work[a] > blk_work[b2]; });
-        long load[NW] = {0}; int cnt[NW] = {0};
-        for (int b : order) {
+        struct Item { int b, part, np; long work; };
+        // water-filling: hand the spare groups, one at a time, to the block whose per-group share is largest (at most 16 parts)
+        int np[UVS_NBLK]; int used = UVS_NBLK;
+        for (int b = 0; b < UVS_NBLK; ++b) np[b] = 1;
+        while (used < UVS_NGRP) {
             int best = -1;
-            for (int wv = 0; wv < NW; ++wv) if (cnt[wv] < BLOCKS_PER_WAVE && (best < 0 || load[wv] < load[best])) best = wv;
-            const int bfa = (int)((std::sqrt(8.0 * b + 1.0) - 1.0) * 0.5 + 1e-9);     // b = fa(fa+1)/2 + fb
-            const bool isdiag = (b - bfa * (bfa + 1) / 2) == bfa;
-            wblk[best * BLOCKS_PER_WAVE + cnt[best]++] = b | (isdiag ? 256 : 0); load[best] += blk_work[b] + 8;
+            for (int b = 0; b < UVS_NBLK; ++b) if (np[b] < 16 && blk_work[b] > 0 && (best < 0 || blk_work[b] * np[best] > blk_work[best] * np[b])) best = b;
+            if (best < 0) break;
+            ++np[best]; ++used;
+        }
+        std::vector<Item> items;
+        for (int b = 0; b < UVS_NBLK; ++b) for (int q = 0; q < np[b]; ++q) items.push_back({b, q, np[b], blk_work[b] / np[b]});
+        std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b2) { return a.work > b2.work; });
+        static const int wave_of_rank[NW] = {0, 1, 2, 3, 7, 6, 5, 4};
+        h.n_parts = 1;
+        for (int b = 0; b < UVS_NBLK; ++b) h.n_parts = std::max(h.n_parts, np[b]);
+        for (int g = 0; g < UVS_NGRP; ++g) { wblk[g] = -1; g_blk[g] = -1; g_part[g] = 0; g_np[g] = 1; }
+        for (size_t q = 0; q < items.size(); ++q) {
+            const int g = wave_of_rank[q / GRP_PER_WAVE] * GRP_PER_WAVE + (int)(q % GRP_PER_WAVE);
+            const int b = items[q].b;
+            const int bfa = (int)((std::sqrt(8.0 * b + 1.0) - 1.0) * 0.5 + 1e-9), bfb = b - bfa * (bfa + 1) / 2;     // b = fa(fa+1)/2 + fb
+            wblk[g] = b | (bfa == bfb ? 256 : 0) | (items[q].part << 9) | (bfa << 13) | (bfb << 17);
+            g_blk[g] = b; g_part[g] = items[q].part; g_np[g] = items[q].np;
+        }
+    }
+    std::vector<int> lists;
+    for (int qc = 0; qc < n_ch; ++qc) {
+        chunks[6 * qc + 3] = (int)lists.size();
+        const size_t base = lists.size();
+        lists.resize(base + 2 * (UVS_NGRP + 1));
+        std::vector<int> ent;
+        for (int pass = 0; pass < 2; ++pass) {
+            const auto& L = pass == 0 ? sch[qc] : dir[qc];
+            for (int g = 0; g < UVS_NGRP; ++g) {
+                lists[base + pass * (UVS_NGRP + 1) + g] = (int)ent.size();
+                if (g_blk[g] < 0) continue;
+                const auto& v = L[g_blk[g]];
+                const size_t n = v.size(), lo = n * g_part[g] / g_np[g], hi = n * (g_part[g] + 1) / g_np[g];
+                ent.insert(ent.end(), v.begin() + lo, v.begin() + hi);
+            }
+            lists[base + pass * (UVS_NGRP + 1) + UVS_NGRP] = (int)ent.size();
+        }
+        lists.insert(lists.end(), ent.begin(), ent.end());
+        chunks[6 * qc + 4] = (int)(lists.size() - base);
+        if (getenv("UVS_DEBUG_LISTS")) {
+            fprintf(stderr, "chunk %d type %d lm [%d,%d):\n", qc, chunks[6 * qc], chunks[6 * qc + 1], chunks[6 * qc + 2]);
+            for (int wv = 0; wv < NW; ++wv) {
+                fprintf(stderr, "  wave %d:", wv);
+                for (int q = 0; q < GRP_PER_WAVE; ++q) { const int g = wv * GRP_PER_WAVE + q; fprintf(stderr, " b%d.%d(%d,%d)", g_blk[g], g_part[g], lists[base + g + 1] - lists[base + g], lists[base + UVS_NGRP + 2 + g] - lists[base + UVS_NGRP + 1 + g]); }
+                fprintf(stderr, "\n");
+            }
         }
     }
     h.n_chunks = (int)chunks.size() / 6;
@@ -313,7 +360,7 @@ static int pack_window(const uvs_window* w, std::vector<char>& out, DevWin& hdr,
     h.i_imu = i; i += 2 * std::max(h.n_imu, 1);
     h.i_prior = i; i += 80 + UVS_MAX_PRIOR_DIM;
     h.i_chunks = i; i += 6 * std::max(h.n_chunks, 1);
-    h.i_wblk = i; i += NW * BLOCKS_PER_WAVE;
+    h.i_wblk = i; i += UVS_NGRP;
     h.i_lists = i; i += (int)lists.size() + 2;
     h.blob_bytes = rup(4 * i, 256);
     // workspace layout
@@ -380,7 +427,7 @@ static int pack_window(const uvs_window* w, std::vector<char>& out, DevWin& hdr,
     }
     for (size_t q = 0; q < chunks.size(); ++q) I[h.i_chunks + q] = chunks[q];
     for (size_t q = 0; q < lists.size(); ++q) I[h.i_lists + q] = lists[q];
-    for (int q = 0; q < NW * BLOCKS_PER_WAVE; ++q) I[h.i_wblk + q] = wblk[q];
+    for (int q = 0; q < UVS_NGRP; ++q) I[h.i_wblk + q] = wblk[q];
     hdr = h;
     return UVS_OK;
 }
