@@ -32,7 +32,8 @@
 #define UVS_LN_JP 2               // pose-Jacobian rows at 2, 8, 14
 #define UVS_LN_RV 20              // VP residual, later its Schur-corrected value
 #define UVS_LN_JL 22              // line-parameter Jacobian rows at 22, 26, 30
-#define UVS_NGRP 256              // gather groups: 32 two-lane groups per wave x 8 waves; each owns one 6x6 pose block or one part of a split one
+#define UVS_NT 256                // threads per workgroup of the solve kernels
+#define UVS_NGRP (UVS_NT / 2)      // gather groups: 32 two-lane groups per wave; each owns one 6x6 pose block or one part of a split one
 
 struct DevWin {
     int32_t n_points, n_pt_obs, n_lines, n_ln_obs, n_imu, prior_n, prior_nb, n_chunks;

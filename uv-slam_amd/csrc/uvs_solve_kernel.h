@@ -21,7 +21,7 @@
 
 namespace uvsdev {
 
-static constexpr int NT = 512;                 // threads per workgroup (8 wavefronts)
+static constexpr int NT = UVS_NT;              // threads per workgroup
 static constexpr int NW = NT / 64;
 
 // ---- LDS map (in doubles)
@@ -246,8 +246,10 @@ UVS_NOINLINE void chol_factor_impl(double* sh, int debug) {
         const int nitem = UVS_NF + 1 - k;
         // wave 0 owns the diagonal block (t = 0) and goes straight on to factor it; wave 4 sits on the same SIMD (waves are dealt to
         // the 4 SIMDs round-robin) and would put its MFMAs between the pivots of that serial chain, so it takes no S1 work
-        const int s1w = (wv < 4) ? wv - 1 : wv - 2;       // workers 1,2,3,5,6,7 -> 0..5
-        for (int t = (wv == 0 ? 0 : (wv == 4 ? nitem : 1 + s1w)); t < nitem; t += (wv == 0 ? nitem : 6)) {
+        const int nwork = (NW == 8) ? 6 : NW - 1;
+        const int s1w = (NW == 8) ? ((wv < 4) ? wv - 1 : wv - 2) : wv - 1;       // 8 waves: workers 1,2,3,5,6,7 -> 0..5
+        const bool s1idle = (NW == 8) && wv == 4;
+        for (int t = (wv == 0 ? 0 : (s1idle ? nitem : 1 + s1w)); t < nitem; t += (wv == 0 ? nitem : nwork)) {
             const int i = k + t;
             const bool rhs = (i == UVS_NF);
             d4_t acc;
@@ -401,7 +403,7 @@ UVS_NOINLINE void chol_solve_impl(double* sh) {
 UVS_DEV void chol_solve(const Ctx& c) { chol_solve_impl(c.sh); }
 
 // ------------------------------------------------------------------ linearization: builds S (damped, Schur-reduced), G, HD, cost, gmax
-// Gather work split: the 512 lanes form 256 GROUPS of 2 lanes (32 per wave).  A group owns one lower 6x6 pose block -- or one
+// Gather work split: the lanes form UVS_NGRP GROUPS of 2 lanes (32 per wave).  A group owns one lower 6x6 pose block -- or one
 // part of it: the host splits the heavy blocks (water-filling, pack_window) so that all groups carry similar work -- and lane t of
 // the group owns ROWS 3t..3t+2 of the block in registers, on diagonal blocks also those rows' gradient and diag(J^T J) entries.
 // Per landmark chunk the host packed, for every group, two index lists:
@@ -436,6 +438,69 @@ UVS_DEV void row_fma(double* v, double s, const d2_t* q) {
 // this lane's group descriptor (-1 = idle group), see uvs_layout.h: i_wblk
 UVS_DEV int gather_group(const Ctx& c) { return c.bi[c.hdr->i_wblk + (threadIdx.x >> 1)]; }
 
+// Operand sets of the four gather loops.  Every loop is software-pipelined by hand: the operands of entry i+1 are requested from
+// LDS before the FMAs of entry i issue (one wave per SIMD => nothing else hides the LDS latency).
+struct PSch { double ea[3]; d2_t q[3]; };              // point Schur entry
+struct PDir { double p0[3], p1[3]; d2_t q0[3], q1[3], rc; };
+struct LSch { double ea[4][3]; d2_t y[4][3]; };
+struct LDir { double p[3][3]; d2_t q[3][3], rc01; double rc2; };
+
+UVS_DEV void load_psch(PSch& o, const double* S0, int e, bool ok, int r0) {
+    const double* pa = S0 + (e & 0x7fff) + r0;
+    const double* pb = S0 + ((unsigned)e >> 16);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) o.ea[r] = ok ? -pa[r] : 0.0;
+    o.q[0] = lds2(pb); o.q[1] = lds2(pb + 2); o.q[2] = lds2(pb + 4);
+}
+UVS_DEV void load_pdir(PDir& o, const double* S0, int e, bool ok, int r0) {
+    const int lo = e & 0x7fff;
+    const double* pa = S0 + lo + r0;
+    const double* pb = S0 + ((unsigned)e >> 16);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { o.p0[r] = ok ? pa[r] : 0.0; o.p1[r] = ok ? pa[6 + r] : 0.0; }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { o.q0[k] = lds2(pb + 2 * k); o.q1[k] = lds2(pb + 6 + 2 * k); }
+    o.rc = lds2(S0 + lo + 12);
+}
+UVS_DEV void load_lsch(LSch& o, const double* S0, int e, bool ok, int r0) {
+    const double* pa = S0 + (e & 0x7fff) + r0;
+    const double* pb = S0 + ((unsigned)e >> 16);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) o.ea[q][r] = ok ? -pa[6 * q + r] : 0.0;
+        o.y[q][0] = lds2(pb + 6 * q); o.y[q][1] = lds2(pb + 6 * q + 2); o.y[q][2] = lds2(pb + 6 * q + 4);
+    }
+}
+UVS_DEV void load_ldir(LDir& o, const double* S0, int ro, bool ok, int r0) {
+    const double* R = S0 + ro;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) o.p[k][r] = ok ? R[UVS_LN_JP + 6 * k + r0 + r] : 0.0;
+        o.q[k][0] = lds2(R + UVS_LN_JP + 6 * k); o.q[k][1] = lds2(R + UVS_LN_JP + 6 * k + 2); o.q[k][2] = lds2(R + UVS_LN_JP + 6 * k + 4);
+    }
+    o.rc01 = lds2(R); o.rc2 = R[UVS_LN_RV];
+}
+
+// Generic pipelined walk of one list: entries [e0, e1) of `ent`; LOAD fetches the operands of one entry, USE consumes them.
+// Entry indices are fetched two ahead, operands one ahead.  Out-of-range slots load entry 0 of the staging area with zeroed
+// own-operands, so they add exactly 0.
+#define UVS_GATHER_LOOP(SET_T, LOAD, USE)                                                         \
+    {                                                                                             \
+        SET_T s0, s1;                                                                             \
+        int en = (e0 + 1 < e1) ? ent[e0 + 1] : 0;                                                 \
+        LOAD(s0, S0, (e0 < e1) ? ent[e0] : 0, e0 < e1, r0);                                       \
+        for (int i = e0; i < e1; i += 2) {                                                        \
+            const int en2 = (i + 2 < e1) ? ent[i + 2] : 0;                                        \
+            LOAD(s1, S0, en, i + 1 < e1, r0);                                                     \
+            USE(s0);                                                                              \
+            en = (i + 3 < e1) ? ent[i + 3] : 0;                                                   \
+            LOAD(s0, S0, en2, i + 2 < e1, r0);                                                    \
+            USE(s1);                                                                              \
+        }                                                                                         \
+    }
+
 UVS_DEV void gather_points(int grp, const int* lists, const double* S0, GAcc& A) {
     const int g = threadIdx.x >> 1, r0 = 3 * (threadIdx.x & 1);
     const bool on = grp >= 0;
@@ -444,46 +509,16 @@ UVS_DEV void gather_points(int grp, const int* lists, const double* S0, GAcc& A)
     // ---- Schur: acc[r][c] -= E_a[r0 + r] * Einv_b[c]
     {
         const int e0 = on ? lists[g] : 0, e1 = on ? lists[g + 1] : 0;
-        for (int i = e0; i < e1; i += 2) {
-            double ea[2][3]; d2_t q[2][3];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const bool ok = i + u < e1;
-                const int e = ok ? ent[i + u] : 0;
-                const double* pa = S0 + (e & 0x7fff) + r0;
-                const double* pb = S0 + ((unsigned)e >> 16);
-#pragma unroll
-                for (int r = 0; r < 3; ++r) ea[u][r] = ok ? -pa[r] : 0.0;
-                q[u][0] = lds2(pb); q[u][1] = lds2(pb + 2); q[u][2] = lds2(pb + 4);
-            }
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                for (int r = 0; r < 3; ++r) row_fma(A.v + 6 * r, ea[u][r], q[u]);
-        }
+#define UVS_USE_PSCH(s) { _Pragma("unroll") for (int r = 0; r < 3; ++r) row_fma(A.v + 6 * r, s.ea[r], s.q); }
+        UVS_GATHER_LOOP(PSch, load_psch, UVS_USE_PSCH)
     }
     // ---- direct: acc[r][c] += J1[0][r0+r] J2[0][c] + J1[1][r0+r] J2[1][c] ; diagonal blocks (J1 == J2) also g and diag(J^T J)
     {
         const int e0 = on ? lists[UVS_NGRP + 1 + g] : 0, e1 = on ? lists[UVS_NGRP + 2 + g] : 0;
-        int e = (e0 < e1) ? ent[e0] : 0;
-        for (int i = e0; i < e1; ++i) {
-            const int en = (i + 1 < e1) ? ent[i + 1] : 0;      // next entry in flight while this one is consumed
-            const int lo = e & 0x7fff;
-            const double* pa = S0 + lo + r0;
-            const double* pb = S0 + ((unsigned)e >> 16);
-            double p0[3], p1[3]; d2_t q0[3], q1[3];
-#pragma unroll
-            for (int r = 0; r < 3; ++r) { p0[r] = pa[r]; p1[r] = pa[6 + r]; }
-#pragma unroll
-            for (int k = 0; k < 3; ++k) { q0[k] = lds2(pb + 2 * k); q1[k] = lds2(pb + 6 + 2 * k); }
-            const d2_t rc = lds2(S0 + lo + 12);
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                row_fma(A.v + 6 * r, p0[r], q0); row_fma(A.v + 6 * r, p1[r], q1);
-                if (diag) { A.g[r] += p0[r] * rc.x + p1[r] * rc.y; A.hd[r] += p0[r] * p0[r] + p1[r] * p1[r]; }
-            }
-            e = en;
-        }
+#define UVS_USE_PDIR(s) { _Pragma("unroll") for (int r = 0; r < 3; ++r) {                                           \
+            row_fma(A.v + 6 * r, s.p0[r], s.q0); row_fma(A.v + 6 * r, s.p1[r], s.q1);                                 \
+            if (diag) { A.g[r] += s.p0[r] * s.rc.x + s.p1[r] * s.rc.y; A.hd[r] += s.p0[r] * s.p0[r] + s.p1[r] * s.p1[r]; } } }
+        UVS_GATHER_LOOP(PDir, load_pdir, UVS_USE_PDIR)
     }
 }
 
@@ -494,48 +529,16 @@ UVS_DEV void gather_lines(int grp, const int* lists, const double* S0, GAcc& A) 
     // ---- Schur: acc[r][c] -= sum_q E_a[q][r0 + r] * Y_b[q][c]
     {
         const int e0 = on ? lists[g] : 0, e1 = on ? lists[g + 1] : 0;
-        int e = (e0 < e1) ? ent[e0] : 0;
-        for (int i = e0; i < e1; ++i) {
-            const int en = (i + 1 < e1) ? ent[i + 1] : 0;
-            const double* pa = S0 + (e & 0x7fff) + r0;
-            const double* pb = S0 + ((unsigned)e >> 16);
-            double ea[4][3]; d2_t y[4][3];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-#pragma unroll
-                for (int r = 0; r < 3; ++r) ea[q][r] = -pa[6 * q + r];
-                y[q][0] = lds2(pb + 6 * q); y[q][1] = lds2(pb + 6 * q + 2); y[q][2] = lds2(pb + 6 * q + 4);
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int r = 0; r < 3; ++r) row_fma(A.v + 6 * r, ea[q][r], y[q]);
-            e = en;
-        }
+#define UVS_USE_LSCH(s) { _Pragma("unroll") for (int q = 0; q < 4; ++q) { _Pragma("unroll") for (int r = 0; r < 3; ++r) row_fma(A.v + 6 * r, s.ea[q][r], s.y[q]); } }
+        UVS_GATHER_LOOP(LSch, load_lsch, UVS_USE_LSCH)
     }
     // ---- direct (always a diagonal block): 3 pose-Jacobian rows (line, line, vanishing point) + corrected residuals
     {
         const int e0 = on ? lists[UVS_NGRP + 1 + g] : 0, e1 = on ? lists[UVS_NGRP + 2 + g] : 0;
-        int ro = (e0 < e1) ? ent[e0] : 0;
-        for (int i = e0; i < e1; ++i) {
-            const int rn = (i + 1 < e1) ? ent[i + 1] : 0;
-            const double* R = S0 + ro;
-            double p[3][3]; d2_t q[3][3];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-#pragma unroll
-                for (int r = 0; r < 3; ++r) p[k][r] = R[UVS_LN_JP + 6 * k + r0 + r];
-                q[k][0] = lds2(R + UVS_LN_JP + 6 * k); q[k][1] = lds2(R + UVS_LN_JP + 6 * k + 2); q[k][2] = lds2(R + UVS_LN_JP + 6 * k + 4);
-            }
-            const d2_t rc01 = lds2(R); const double rc2 = R[UVS_LN_RV];
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-#pragma unroll
-                for (int k = 0; k < 3; ++k) { row_fma(A.v + 6 * r, p[k][r], q[k]); A.hd[r] += p[k][r] * p[k][r]; }
-                A.g[r] += p[0][r] * rc01.x + p[1][r] * rc01.y + p[2][r] * rc2;
-            }
-            ro = rn;
-        }
+#define UVS_USE_LDIR(s) { _Pragma("unroll") for (int r = 0; r < 3; ++r) {                                            \
+            _Pragma("unroll") for (int k = 0; k < 3; ++k) { row_fma(A.v + 6 * r, s.p[k][r], s.q[k]); A.hd[r] += s.p[k][r] * s.p[k][r]; }   \
+            A.g[r] += s.p[0][r] * s.rc01.x + s.p[1][r] * s.rc01.y + s.p[2][r] * s.rc2; } }
+        UVS_GATHER_LOOP(LDir, load_ldir, UVS_USE_LDIR)
     }
 }
 
@@ -637,7 +640,6 @@ UVS_DEV void lin_chunk(const Ctx& c, int ch, const double* x, const double* invd
             // pass B: one lane per observation (its landmark's h_ll / g_l are recomputed per lane, cheap);
             // the lane of a landmark's first observation also owns the anchor slot and the per-landmark scalars.
             // Reads of the d r/d lambda columns happen before the barrier, the corrected residuals overwrite them after it.
-            double rc0 = 0.0, rc1 = 0.0; int myrec = -1;
             for (int ol = tid; ol < nob; ol += NT) {
                 const int k = c.bi[h.i_pt_lm + o0 + ol], li = k - k0, b0 = beg[k] - o0, b1 = beg[k + 1] - o0;
                 double hd = 0.0, gl = 0.0;
@@ -650,11 +652,14 @@ UVS_DEV void lin_chunk(const Ctx& c, int ch, const double* x, const double* invd
                 const int s = ol - b0 + 1;
                 double* E = Eb + (size_t)(b0 + li) * 6; double* EI = EIb + (size_t)(b0 + li) * 6;
                 double* Eg = c.ws + h.w_pt_E + 6 * (size_t)(beg[k] + k);
-                const double* R = rec + (size_t)ol * UVS_PT_REC;
-                const double c0 = R[UVS_PT_C], c1 = R[UVS_PT_C + 1];
+                double* R = rec + (size_t)ol * UVS_PT_REC;
+                const double c0 = R[UVS_PT_C], c1 = R[UVS_PT_C + 1], rr0 = R[0], rr1 = R[1];
+                double Bv[12];      // all LDS reads of the record BEFORE the first LDS write (the compiler must assume E / EI alias it)
 #pragma unroll
-                for (int a = 0; a < 6; ++a) { const double e = c0 * R[UVS_PT_B + a] + c1 * R[UVS_PT_B + 6 + a]; E[6 * s + a] = e; EI[6 * s + a] = e * hinv; Eg[6 * s + a] = e * hinv; }
-                rc0 = R[0] - c0 * ginv; rc1 = R[1] - c1 * ginv; myrec = ol;       // r - J_l h^-1 g_l
+                for (int a = 0; a < 12; ++a) Bv[a] = R[UVS_PT_B + a];
+#pragma unroll
+                for (int a = 0; a < 6; ++a) { const double e = c0 * Bv[a] + c1 * Bv[6 + a]; E[6 * s + a] = e; EI[6 * s + a] = e * hinv; Eg[6 * s + a] = e * hinv; }
+                R[UVS_PT_RC2] = rr0 - c0 * ginv; R[UVS_PT_RC2 + 1] = rr1 - c1 * ginv;       // rc = r - J_l h^-1 g_l (slot nobody reads in this pass)
                 if (lead) {
                     double* px = c.ws + h.w_pt_x + 4 * (size_t)k; px[0] = ginv; px[1] = gl; px[2] = dd; px[3] = hd;
                     gmax_lm = fmax(gmax_lm, fabs(gl));
@@ -669,7 +674,7 @@ UVS_DEV void lin_chunk(const Ctx& c, int ch, const double* x, const double* invd
                 }
             }
             __syncthreads();
-            if (myrec >= 0) { double* R = rec + (size_t)myrec * UVS_PT_REC; R[UVS_PT_C] = rc0; R[UVS_PT_C + 1] = rc1; R[UVS_PT_RC2] = rc0; R[UVS_PT_RC2 + 1] = rc1; }
+            for (int ol = tid; ol < nob; ol += NT) { double* R = rec + (size_t)ol * UVS_PT_REC; R[UVS_PT_C] = R[UVS_PT_RC2]; R[UVS_PT_C + 1] = R[UVS_PT_RC2 + 1]; }
             __syncthreads();
             UVS_PROF(c, P_LMPREP);
             const long long tg0_ = clock64();
@@ -775,25 +780,30 @@ UVS_DEV void lin_chunk(const Ctx& c, int ch, const double* x, const double* invd
             // pass B2: one lane per line observation: E and Y = Hinv E
             for (int o = tid; o < nob; o += NT) {
                 const int li = c.bi[h.i_ln_lm + o0 + o] - k0;
-                const double* R = rec + (size_t)o * UVS_LN_REC;
-                const double* X = Xb + 20 * li;
+                double* R = rec + (size_t)o * UVS_LN_REC;
                 double* E = Eb + (size_t)o * 24; double* Y = Yb + (size_t)o * 24;
                 double* Yg = c.ws + h.w_ln_Y + 24 * (size_t)(o0 + o);
+                // all LDS reads BEFORE the first LDS write (the compiler must assume the E / Y stores alias the record)
+                double Xv[20], Jl[12], Jp[18];
+#pragma unroll
+                for (int q = 0; q < 20; ++q) Xv[q] = Xb[20 * li + q];
+#pragma unroll
+                for (int q = 0; q < 12; ++q) Jl[q] = R[UVS_LN_JL + q];
+#pragma unroll
+                for (int q = 0; q < 18; ++q) Jp[q] = R[UVS_LN_JP + q];
+                const double rr0 = R[0], rr1 = R[1], rr2 = R[UVS_LN_RV];
 #pragma unroll
                 for (int a = 0; a < 6; ++a) {
                     double e[4];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) { e[q] = R[UVS_LN_JL + q] * R[UVS_LN_JP + a] + R[UVS_LN_JL + 4 + q] * R[UVS_LN_JP + 6 + a] + R[UVS_LN_JL + 8 + q] * R[UVS_LN_JP + 12 + a]; E[6 * q + a] = e[q]; }
+                    for (int q = 0; q < 4; ++q) { e[q] = Jl[q] * Jp[a] + Jl[4 + q] * Jp[6 + a] + Jl[8 + q] * Jp[12 + a]; E[6 * q + a] = e[q]; }
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) { const double y = X[4 * q] * e[0] + X[4 * q + 1] * e[1] + X[4 * q + 2] * e[2] + X[4 * q + 3] * e[3]; Y[6 * q + a] = y; Yg[6 * q + a] = y; }
+                    for (int q = 0; q < 4; ++q) { const double y = Xv[4 * q] * e[0] + Xv[4 * q + 1] * e[1] + Xv[4 * q + 2] * e[2] + Xv[4 * q + 3] * e[3]; Y[6 * q + a] = y; Yg[6 * q + a] = y; }
                 }
-                // Schur-corrected residual rc = r - J_l (H_ll^-1 g_l) for the 2 line rows and the VP row; J_l of this record is dead now
-                const double* Jl = R + UVS_LN_JL;
-                const double rc0 = R[0] - (Jl[0] * X[16] + Jl[1] * X[17] + Jl[2] * X[18] + Jl[3] * X[19]);
-                const double rc1 = R[1] - (Jl[4] * X[16] + Jl[5] * X[17] + Jl[6] * X[18] + Jl[7] * X[19]);
-                const double rc2 = R[UVS_LN_RV] - (Jl[8] * X[16] + Jl[9] * X[17] + Jl[10] * X[18] + Jl[11] * X[19]);
-                double* Rw = rec + (size_t)o * UVS_LN_REC;
-                Rw[0] = rc0; Rw[1] = rc1; Rw[UVS_LN_RV] = rc2;
+                // Schur-corrected residual rc = r - J_l (H_ll^-1 g_l) for the 2 line rows and the VP row
+                R[0] = rr0 - (Jl[0] * Xv[16] + Jl[1] * Xv[17] + Jl[2] * Xv[18] + Jl[3] * Xv[19]);
+                R[1] = rr1 - (Jl[4] * Xv[16] + Jl[5] * Xv[17] + Jl[6] * Xv[18] + Jl[7] * Xv[19]);
+                R[UVS_LN_RV] = rr2 - (Jl[8] * Xv[16] + Jl[9] * Xv[17] + Jl[10] * Xv[18] + Jl[11] * Xv[19]);
             }
             __syncthreads();
             UVS_PROF(c, P_LMPREP);

@@ -249,7 +249,7 @@ static int pack_window(const uvs_window* w, std::vector<char>& out, DevWin& hdr,
     //   direct entry: points: offset(first Jacobian block) | offset(second) << 16   (A^T A, B^T B, B^T A) ; lines: record offset
     const int n_ch = (int)chunks.size() / 6;
     std::vector<std::vector<std::vector<int>>> sch(n_ch, std::vector<std::vector<int>>(UVS_NBLK)), dir(n_ch, std::vector<std::vector<int>>(UVS_NBLK));
-    std::vector<long> blk_work(UVS_NBLK, 0);
+    std::vector<long> blk_work(UVS_NBLK, 0), blk_s(UVS_NBLK, 0), blk_d(UVS_NBLK, 0);
     auto blk_of = [](int fa, int fb) { return fa * (fa + 1) / 2 + fb; };   // fa >= fb
     for (int qc = 0; qc < n_ch; ++qc) {
         const int type = chunks[6 * qc], k0 = chunks[6 * qc + 1], k1 = chunks[6 * qc + 2];
@@ -283,15 +283,16 @@ static int pack_window(const uvs_window* w, std::vector<char>& out, DevWin& hdr,
                 for (int o = b0; o < b1; ++o) Dr[blk_of(w->ln_fj[o0 + o], w->ln_fj[o0 + o])].push_back(o * UVS_LN_REC);
             }
         }
-        // work units ~ LDS read instructions per entry of the row-per-lane gather
-        for (int b = 0; b < UVS_NBLK; ++b) blk_work[b] += (type == 0 ? 4 : 16) * (long)S[b].size() + (type == 0 ? 9 : 12) * (long)Dr[b].size();
+        // work units = FP64 FMAs per lane and entry of the rows-per-lane gather (the loops are FMA-issue bound)
+        for (int b = 0; b < UVS_NBLK; ++b) { blk_s[b] += (type == 0 ? 18 : 72) * (long)S[b].size(); blk_d[b] += (type == 0 ? 54 : 63) * (long)Dr[b].size(); }
     }
     // gather groups: 256 two-lane groups, at least one per pose block; the spare ones split the heaviest blocks further.  Groups are dealt to
     // the waves heaviest first (similar list lengths inside a wave => little divergence); the wave order pairs heavy with light
     // waves on a SIMD (waves w and w+4 share one).
     int wblk[UVS_NGRP], g_blk[UVS_NGRP], g_part[UVS_NGRP], g_np[UVS_NGRP];
     {
-        struct Item { int b, part, np; long work; };
+        for (int b = 0; b < UVS_NBLK; ++b) blk_work[b] = blk_s[b] + blk_d[b];
+        struct Item { int b, part, np; long work; double shape; };
         // water-filling: hand the spare groups, one at a time, to the block whose per-group share is largest (at most 16 parts)
         int np[UVS_NBLK]; int used = UVS_NBLK;
         for (int b = 0; b < UVS_NBLK; ++b) np[b] = 1;
@@ -302,9 +303,12 @@ static int pack_window(const uvs_window* w, std::vector<char>& out, DevWin& hdr,
             ++np[best]; ++used;
         }
         std::vector<Item> items;
-        for (int b = 0; b < UVS_NBLK; ++b) for (int q = 0; q < np[b]; ++q) items.push_back({b, q, np[b], blk_work[b] / np[b]});
-        std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b2) { return a.work > b2.work; });
-        static const int wave_of_rank[NW] = {0, 1, 2, 3, 7, 6, 5, 4};
+        for (int b = 0; b < UVS_NBLK; ++b) for (int q = 0; q < np[b]; ++q) items.push_back({b, q, np[b], blk_work[b] / np[b], blk_work[b] ? (double)blk_d[b] / (double)blk_work[b] : -1.0});
+        // a wave runs max(Schur count) + max(direct count) iterations over its 32 groups: deal groups of similar SHAPE (share of
+        // direct work) to the same wave, idle groups last
+        std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b2) { return a.shape != b2.shape ? a.shape > b2.shape : a.work > b2.work; });
+        int wave_of_rank[NW];
+        for (int r = 0; r < NW; ++r) wave_of_rank[r] = r < 4 ? r : NW - 1 - (r - 4);
         h.n_parts = 1;
         for (int b = 0; b < UVS_NBLK; ++b) h.n_parts = std::max(h.n_parts, np[b]);
         for (int g = 0; g < UVS_NGRP; ++g) { wblk[g] = -1; g_blk[g] = -1; g_part[g] = 0; g_np[g] = 1; }
