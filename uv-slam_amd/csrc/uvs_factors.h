@@ -346,6 +346,9 @@ UVS_DEV void vp_residual(const LineGeom& g, const double* vp, double vp_factor, 
 // Replaces IMUFactor::Evaluate (imu_factor.h:19-182) + IntegrationBase::evaluate (integration_base.h:160-186).
 // blk: [0]=sum_dt, [1..3]=delta_p, [4..7]=delta_q(x,y,z,w), [8..10]=delta_v, [11..13]=lin_ba, [14..16]=lin_bg; jac: 15x15 row-major.
 // Raw (un-whitened) residual r[15]; if Jraw != nullptr the raw 15x30 Jacobian is written (row-major, zero-filled first).
+// Jraw (may be NULL) receives the 15 x 30 Jacobian at Jraw[row * LD + col + (col >= 15 ? GAP : 0)]; ZERO = clear the 450 entries first
+// (LD = 30, GAP = 0: dense row-major; the solve kernel uses LD = 48, GAP = 1 into a pre-zeroed, frame-padded MFMA operand tile).
+template <int LD = 30, int GAP = 0, bool ZERO = true>
 UVS_DEV void imu_raw(const double* blk, const double* jac, const double* G, const double* pose_i, const double* sb_i,
                      const double* pose_j, const double* sb_j, double* r, double* Jraw) {
     const double sum_dt = blk[0];
@@ -383,18 +386,19 @@ UVS_DEV void imu_raw(const double* blk, const double* jac, const double* G, cons
     r[9] = Baj[0] - Bai[0]; r[10] = Baj[1] - Bai[1]; r[11] = Baj[2] - Bai[2];      // :180
     r[12] = Bgj[0] - Bgi[0]; r[13] = Bgj[1] - Bgi[1]; r[14] = Bgj[2] - Bgi[2];     // :181
     if (!Jraw) return;
-    for (int k = 0; k < 450; ++k) Jraw[k] = 0.0;
+    if (ZERO) for (int k = 0; k < 450; ++k) Jraw[k] = 0.0;
     double RiT[9]; quat_to_R(Qi_inv, RiT);                                         // Qi.inverse().toRotationMatrix()
+    auto cm = [](int col) { return col + (col >= 15 ? GAP : 0); };
     auto put = [&](int r0, int c0, const double* M, double s) {
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
-            for (int j = 0; j < 3; ++j) Jraw[(r0 + i) * 30 + c0 + j] = s * M[3 * i + j];
+            for (int j = 0; j < 3; ++j) Jraw[(r0 + i) * LD + cm(c0 + j)] = s * M[3 * i + j];
     };
     auto putskew = [&](int r0, int c0, const double* v) {
-        Jraw[(r0 + 0) * 30 + c0 + 1] = -v[2]; Jraw[(r0 + 0) * 30 + c0 + 2] = v[1];
-        Jraw[(r0 + 1) * 30 + c0 + 0] = v[2];  Jraw[(r0 + 1) * 30 + c0 + 2] = -v[0];
-        Jraw[(r0 + 2) * 30 + c0 + 0] = -v[1]; Jraw[(r0 + 2) * 30 + c0 + 1] = v[0];
+        Jraw[(r0 + 0) * LD + cm(c0 + 1)] = -v[2]; Jraw[(r0 + 0) * LD + cm(c0 + 2)] = v[1];
+        Jraw[(r0 + 1) * LD + cm(c0 + 0)] = v[2];  Jraw[(r0 + 1) * LD + cm(c0 + 2)] = -v[0];
+        Jraw[(r0 + 2) * LD + cm(c0 + 0)] = -v[1]; Jraw[(r0 + 2) * LD + cm(c0 + 1)] = v[0];
     };
     // Qleft(a).bottomRight3x3 = a.w I + skew(a.vec) ; Qright(b).bottomRight = b.w I - skew(b.vec)
     // (Qleft(a) Qright(b)).bottomRight3x3 [i][j] = a.v[i]*(-b.v[j]) + sum_k (a.w I + [a.v]x)[i][k] (b.w I - [b.v]x)[k][j]
@@ -429,14 +433,14 @@ UVS_DEV void imu_raw(const double* blk, const double* jac, const double* G, cons
     for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            Jraw[(0 + i) * 30 + 6 + 3 + j] = -jac[(0 + i) * 15 + 9 + j];     // -dp_dba
-            Jraw[(0 + i) * 30 + 6 + 6 + j] = -jac[(0 + i) * 15 + 12 + j];    // -dp_dbg
-            Jraw[(6 + i) * 30 + 6 + 3 + j] = -jac[(6 + i) * 15 + 9 + j];     // -dv_dba
-            Jraw[(6 + i) * 30 + 6 + 6 + j] = -jac[(6 + i) * 15 + 12 + j];    // -dv_dbg
+            Jraw[(0 + i) * LD + cm(6 + 3 + j)] = -jac[(0 + i) * 15 + 9 + j];     // -dp_dba
+            Jraw[(0 + i) * LD + cm(6 + 6 + j)] = -jac[(0 + i) * 15 + 12 + j];    // -dp_dbg
+            Jraw[(6 + i) * LD + cm(6 + 3 + j)] = -jac[(6 + i) * 15 + 9 + j];     // -dv_dba
+            Jraw[(6 + i) * LD + cm(6 + 6 + j)] = -jac[(6 + i) * 15 + 12 + j];    // -dv_dbg
         }
     put(6, 6 + 0, RiT, -1.0);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) { Jraw[(9 + i) * 30 + 6 + 3 + i] = -1.0; Jraw[(12 + i) * 30 + 6 + 6 + i] = -1.0; }
+    for (int i = 0; i < 3; ++i) { Jraw[(9 + i) * LD + cm(6 + 3 + i)] = -1.0; Jraw[(12 + i) * LD + cm(6 + 6 + i)] = -1.0; }
     // pose_j  (:149-155)
     put(0, 15 + 0, RiT, 1.0);
     { double q3[4]; quat_mul(cq_inv, qij, q3);
@@ -445,7 +449,7 @@ UVS_DEV void imu_raw(const double* blk, const double* jac, const double* G, cons
     // speedbias_j  (:168-172)
     put(6, 21 + 0, RiT, 1.0);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) { Jraw[(9 + i) * 30 + 21 + 3 + i] = 1.0; Jraw[(12 + i) * 30 + 21 + 6 + i] = 1.0; }
+    for (int i = 0; i < 3; ++i) { Jraw[(9 + i) * LD + cm(21 + 3 + i)] = 1.0; Jraw[(12 + i) * LD + cm(21 + 6 + i)] = 1.0; }
 }
 
 // ---------------------------------------------------------------- a3: PoseLocalParameterization::Plus

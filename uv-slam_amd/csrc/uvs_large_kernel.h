@@ -94,10 +94,11 @@ __global__ __launch_bounds__(NT) void k_large_solve(char* blob, double* ws, KOpt
             A.g[r] = ld ? Q[6] : 0.0; A.hd[r] = ld ? Q[7] : 0.0;
         }
     }
-    double cost = lin_frames(c, sh + L_X);
+    ImuN N;
+    double cost = lin_frames(c, sh + L_X, N);
     if (tid == 0) cost += reduced[LG_ACC];
     __syncthreads();
-    lin_assemble(c, sh + L_X, first != 0, radius, grp, A, cost, reduced[LG_ACC + 1]);
+    lin_assemble(c, sh + L_X, first != 0, radius, grp, A, N, cost, reduced[LG_ACC + 1]);
     if (tid < UVS_RD) sh[L_DLT + tid] = -sh[L_G + tid];
     chol_factor(c);
     chol_solve(c);

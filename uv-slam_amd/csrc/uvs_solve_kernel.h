@@ -542,57 +542,71 @@ UVS_DEV void gather_lines(int grp, const int* lists, const double* S0, GAcc& A) 
     }
 }
 
-// ---- linearization, part 1: frame-only terms at x (rotations, prior residual, IMU blocks -> workspace). Returns this lane's cost share.
-UVS_DEV double lin_frames(const Ctx& c, const double* x) {
+// ---- linearization, part 1: frame-only terms at x (rotations, prior residual, IMU normal equations). Returns this lane's cost share.
+// IMU blocks go through the FP64 matrix cores: per block the raw 15 x 30 Jacobian and the raw residual are laid out as one
+// frame-padded 16 x 32 operand  Jaug = [ J_i | 0 | J_j | r ]  (column 16 f + dof, residual in column 31), whitened with
+// T = W Jaug (W = chol(cov^-1)^T, imu_factor.h:64-66; 8 MFMAs) and squared, N = T^T T (lower 16 x 16 tiles (0,0) (1,0) (1,1);
+// 12 MFMAs).  N holds J^T J in its frame blocks, J^T r in row 31 and r^T r in (31,31); the three accumulator tiles stay in
+// registers until lin_assemble adds them to the pose blocks (i,i) (j,i) (j,j) of S.
+static constexpr int IMU_JLD = 48;                       // row stride of Jaug / T in LDS (16 rows; 48 = 16 mod 32: no bank conflicts between k-groups)
+static constexpr int IMU_WOFF = 16 * IMU_JLD;            // W as [16][17] after the operand tile
+static constexpr int IMU_BLK = IMU_WOFF + UVS_BLK_SZ;    // 1040 doubles of LDS staging per block
+static constexpr int IMU_SLOTS = (UVS_NF - 1 + NW - 1) / NW;   // IMU blocks per wave (block b -> wave b % NW, slot b / NW)
+struct ImuN { d4_t n00[IMU_SLOTS], n10[IMU_SLOTS], n11[IMU_SLOTS]; };
+
+UVS_DEV double lin_frames(const Ctx& c, const double* x, ImuN& N) {
     const DevWin& h = *c.hdr;
     double* sh = c.sh;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 15, lk = lane >> 4;
     double cost = 0.0;
     UVS_PROF(c, P_MISC);
     stage_rotations(c, x);
     prior_dx(c, x);
+    double* IM = sh + L_S;
+    for (int t = tid; t < h.n_imu * IMU_BLK; t += NT) IM[t] = 0.0;      // operand tiles are mostly structural zeros
     __syncthreads();
     cost += prior_residual(c);
-    // ---- IMU blocks, staged in the (still free) S region: per block Jraw[450] rraw[15] | Jw[450] rw[15]
-    {
-        double* IM = sh + L_S;
-        if (tid < h.n_imu && !c.bi[h.i_imu + 2 * tid + 1]) {
-            const int fi = c.bi[h.i_imu + 2 * tid];
-            const double* blk = c.bd + h.d_imu + (size_t)tid * UVS_IMU_STRIDE;
-            double r[15];
-            imu_raw(blk, blk + UVS_IMU_JAC, c.o.G, x + 7 * fi, x + 77 + 9 * fi, x + 7 * (fi + 1), x + 77 + 9 * (fi + 1), r, IM + 930 * tid);
-            for (int i = 0; i < 15; ++i) IM[930 * tid + 450 + i] = r[i];
-        }
-        for (int t = tid; t < h.n_imu * 225; t += NT) { const int b = t / 225; IM[9300 + t] = c.bd[h.d_imu + (size_t)b * UVS_IMU_STRIDE + UVS_IMU_W + (t - 225 * b)]; }
-        __syncthreads();
-        for (int t = tid; t < h.n_imu * 465; t += NT) {      // whitening: W upper triangular (imu_factor.h:64-66)
-            const int b = t / 465, e = t - b * 465;
-            if (c.bi[h.i_imu + 2 * b + 1]) continue;
-            const double* W = IM + 9300 + 225 * b;          // whitening matrices staged in LDS above
-            const double* raw = IM + 930 * b;
-            if (e < 450) { const int r = e / 30, cc = e - r * 30; double s = 0.0; for (int k = r; k < 15; ++k) s += W[r * 15 + k] * raw[k * 30 + cc]; IM[930 * b + 465 + e] = s; }
-            else { const int r = e - 450; double s = 0.0; for (int k = r; k < 15; ++k) s += W[r * 15 + k] * raw[450 + k]; IM[930 * b + 465 + 450 + r] = s; cost += 0.5 * s * s; }
-        }
-        __syncthreads();
-        for (int t = tid; t < h.n_imu * 495; t += NT) {      // J^T J (465 lower entries) and J^T r (30) -> global scratch, added after the gather
-            const int b = t / 495, e = t - b * 495;
-            if (c.bi[h.i_imu + 2 * b + 1]) continue;
-            const double* Jw = IM + 930 * b + 465; const double* rw = Jw + 450;
-            double s = 0.0;
-            if (e < 465) {
-                int a = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
-                while (((a + 1) * (a + 2)) >> 1 <= e) ++a;
-                while (((a * (a + 1)) >> 1) > e) --a;
-                const int cc = e - ((a * (a + 1)) >> 1);
+    if (tid < h.n_imu && !c.bi[h.i_imu + 2 * tid + 1]) {
+        const int fi = c.bi[h.i_imu + 2 * tid];
+        const double* blk = c.bd + h.d_imu + (size_t)tid * UVS_IMU_STRIDE;
+        double r[15];
+        imu_raw<IMU_JLD, 1, false>(blk, blk + UVS_IMU_JAC, c.o.G, x + 7 * fi, x + 77 + 9 * fi, x + 7 * (fi + 1), x + 77 + 9 * (fi + 1), r, IM + IMU_BLK * tid);
+        for (int i = 0; i < 15; ++i) IM[IMU_BLK * tid + i * IMU_JLD + 31] = r[i];
+    }
+    for (int t = tid; t < h.n_imu * 225; t += NT) {
+        const int b = t / 225, e = t - 225 * b, i = e / 15, k = e - 15 * i;
+        IM[IMU_BLK * b + IMU_WOFF + i * UVS_BLK_LD + k] = c.bd[h.d_imu + (size_t)b * UVS_IMU_STRIDE + UVS_IMU_W + e];
+    }
+    __syncthreads();
 #pragma unroll
-                for (int r = 0; r < 15; ++r) s += Jw[r * 30 + a] * Jw[r * 30 + cc];
-            } else {
-                const int a = e - 465;
+    for (int s = 0; s < IMU_SLOTS; ++s) {
+        const int b = wv + s * NW;
+        d4_t n00 = {0.0, 0.0, 0.0, 0.0}, n10 = n00, n11 = n00;
+        if (b < h.n_imu && !c.bi[h.i_imu + 2 * b + 1]) {
+            double* Jb = IM + IMU_BLK * b; const double* Wb = Jb + IMU_WOFF;
+            d4_t t0 = {0.0, 0.0, 0.0, 0.0}, t1 = t0;
+            double wa[4], j0[4], j1[4];
 #pragma unroll
-                for (int r = 0; r < 15; ++r) s += Jw[r * 30 + a] * rw[r];
+            for (int q = 0; q < 4; ++q) { wa[q] = Wb[li * UVS_BLK_LD + 4 * q + lk]; j0[q] = Jb[(4 * q + lk) * IMU_JLD + li]; j1[q] = Jb[(4 * q + lk) * IMU_JLD + 16 + li]; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { t0 = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[q], j0[q], t0, 0, 0, 0); t1 = __builtin_amdgcn_mfma_f64_16x16x4f64(wa[q], j1[q], t1, 0, 0, 0); }
+            // T overwrites Jaug in place (all of this wave's reads of it are consumed above), C layout: row = lk + 4q, col = li
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { Jb[(lk + 4 * q) * IMU_JLD + li] = t0[q]; Jb[(lk + 4 * q) * IMU_JLD + 16 + li] = t1[q]; }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { j0[q] = Jb[(4 * q + lk) * IMU_JLD + li]; j1[q] = Jb[(4 * q + lk) * IMU_JLD + 16 + li]; }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                n00 = __builtin_amdgcn_mfma_f64_16x16x4f64(j0[q], j0[q], n00, 0, 0, 0);
+                n10 = __builtin_amdgcn_mfma_f64_16x16x4f64(j1[q], j0[q], n10, 0, 0, 0);
+                n11 = __builtin_amdgcn_mfma_f64_16x16x4f64(j1[q], j1[q], n11, 0, 0, 0);
             }
-            c.ws[h.w_imu + (size_t)b * UVS_WIMU_STRIDE + e] = s;
+            if (lane == 63) cost += 0.5 * n11[3];       // r^T W^T W r sits at N[31][31] = tile (1,1), row 15, col 15
         }
+        N.n00[s] = n00; N.n10[s] = n10; N.n11[s] = n11;
     }
     UVS_PROF(c, P_AS_IMU);
     return cost;
@@ -815,7 +829,7 @@ UVS_DEV void lin_chunk(const Ctx& c, int ch, const double* x, const double* invd
 }
 
 // ---- linearization, part 3: assemble the damped reduced system in LDS from the gathered pose blocks + IMU + prior
-UVS_DEV void lin_assemble(const Ctx& c, const double* x, bool first, double radius, int grp, const GAcc& A, double cost, double gmax_lm) {
+UVS_DEV void lin_assemble(const Ctx& c, const double* x, bool first, double radius, int grp, const GAcc& A, const ImuN& N, double cost, double gmax_lm) {
     const DevWin& h = *c.hdr;
     double* sh = c.sh;
     const int tid = threadIdx.x;
@@ -848,24 +862,29 @@ UVS_DEV void lin_assemble(const Ctx& c, const double* x, bool first, double radi
         __syncthreads();
     }
     UVS_PROF(c, P_AS_ZERO);
-    // IMU normal-equation blocks from global scratch (even blocks, then odd: consecutive blocks share a diagonal frame block)
+    // IMU normal-equation tiles from the registers of lin_frames (even blocks, then odd: consecutive blocks share a diagonal frame block)
     for (int par = 0; par < 2; ++par) {
-        for (int t = tid; t < h.n_imu * 495; t += NT) {
-            const int b = t / 495, e = t - b * 495;
-            if ((b & 1) != par || c.bi[h.i_imu + 2 * b + 1]) continue;
-            const int fi = c.bi[h.i_imu + 2 * b];
-            const double s = c.ws[h.w_imu + (size_t)b * UVS_WIMU_STRIDE + e];
-            if (e < 465) {
-                int a = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
-                while (((a + 1) * (a + 2)) >> 1 <= e) ++a;
-                while (((a * (a + 1)) >> 1) > e) --a;
-                const int cc = e - ((a * (a + 1)) >> 1);     // a >= cc
-                const int ia = 16 * (fi + (a >= 15)) + (a >= 15 ? a - 15 : a), ic = 16 * (fi + (cc >= 15)) + (cc >= 15 ? cc - 15 : cc);
-                sh[L_S + sidx(ia, ic)] += s;
-                if (a == cc) sh[L_HD + ia] += s;
-            } else {
-                const int a = e - 465;
-                sh[L_G + 16 * (fi + (a >= 15)) + (a >= 15 ? a - 15 : a)] += s;
+        const int lane = tid & 63, wv = tid >> 6, li = lane & 15, lk = lane >> 4;
+#pragma unroll
+        for (int s = 0; s < IMU_SLOTS; ++s) {
+            const int b = wv + s * NW;
+            if (b < h.n_imu && (b & 1) == par && !c.bi[h.i_imu + 2 * b + 1] && li < 15) {
+                const int fi = c.bi[h.i_imu + 2 * b], fj = fi + 1;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int row = lk + 4 * q;      // C layout: row = lk + 4q, col = li
+                    if (row < 15) {
+                        sh[L_S + sidx(16 * fj + row, 16 * fi + li)] += N.n10[s][q];
+                        if (li <= row) {
+                            sh[L_S + sidx(16 * fi + row, 16 * fi + li)] += N.n00[s][q];
+                            sh[L_S + sidx(16 * fj + row, 16 * fj + li)] += N.n11[s][q];
+                            if (li == row) { sh[L_HD + 16 * fi + row] += N.n00[s][q]; sh[L_HD + 16 * fj + row] += N.n11[s][q]; }
+                        }
+                    } else {                          // row 15 of the lower tiles = J^T r
+                        sh[L_G + 16 * fi + li] += N.n10[s][q];
+                        sh[L_G + 16 * fj + li] += N.n11[s][q];
+                    }
+                }
             }
         }
         __syncthreads();
@@ -925,9 +944,10 @@ UVS_DEV void linearize(const Ctx& c, const double* x, const double* invd, const 
     const DevWin& h = *c.hdr;
     const int grp = gather_group(c);       // this lane's gather group: pose block | flags (uvs_layout.h: i_wblk)
     GAcc A; gacc_zero(A);
-    double cost = lin_frames(c, x), gmax_lm = 0.0;
+    ImuN N;
+    double cost = lin_frames(c, x, N), gmax_lm = 0.0;
     for (int ch = 0; ch < h.n_chunks; ++ch) lin_chunk(c, ch, x, invd, line, first, radius, grp, A, cost, gmax_lm);
-    lin_assemble(c, x, first, radius, grp, A, cost, gmax_lm);
+    lin_assemble(c, x, first, radius, grp, A, N, cost, gmax_lm);
 }
 
 // ------------------------------------------------------------------ back-substitution + candidate + model terms
