@@ -70,6 +70,13 @@ UVS_DEV double bcast_lane(double v, int lane) {
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
     return __hiloint2double(hi, lo);
 }
+// LDS traffic of ONE wave is processed in order; this only stops the compiler from moving accesses across the hand-over point
+UVS_DEV void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 UVS_DEV double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -229,9 +236,7 @@ UVS_DEV double rcp_newton(double x) {
 // C/D layout of the f64 MFMA: row = (lane >> 4) + 4 * reg, col = lane & 15;  A[i][k]: lane i + 16k;  B[k][j]: lane j + 16k.
 struct MiniCtx { double* sh; struct { int debug; } o; };      // what UVS_PROF needs inside the out-of-line phases
 #define UVS_NOINLINE __device__ __attribute__((noinline))
-// Out of line on purpose: k_solve is one huge inlined body at the 256-VGPR cap; as separate functions the dense-solve phases
-// get their own register allocation (no scratch reloads inside the pivot chain).
-UVS_NOINLINE void chol_factor_impl(double* sh, int debug) {
+UVS_DEV void chol_factor_impl(double* sh, int debug) {
     MiniCtx c; c.sh = sh; c.o.debug = debug;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int li = lane & 15, lk = lane >> 4;
@@ -255,13 +260,13 @@ UVS_NOINLINE void chol_factor_impl(double* sh, int debug) {
             d4_t acc;
             if (t == 0) {        // diagonal block: symmetrise from the stored lower triangle
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { const int r = lk + 4 * q; acc[q] = (r >= li) ? Dk[r * UVS_BLK_LD + li] : Dk[li * UVS_BLK_LD + r]; }
+                for (int q = 0; q < 4; ++q) { const int r = lk + 4 * q; const int hi_ = r >= li ? r : li, lo_ = r >= li ? li : r; acc[q] = Dk[hi_ * UVS_BLK_LD + lo_]; }
             } else if (!rhs) {
                 const double* Cb = sblk(sh, i, k) + lk * UVS_BLK_LD + li;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) acc[q] = Cb[4 * q * UVS_BLK_LD];
             } else {
-                acc[0] = (lk == 0) ? b[16 * k + li] : 0.0; acc[1] = 0.0; acc[2] = 0.0; acc[3] = 0.0;
+                { const double bv0 = b[16 * k + li]; acc[0] = (lk == 0) ? bv0 : 0.0; } acc[1] = 0.0; acc[2] = 0.0; acc[3] = 0.0;
             }
             d4_t acc2 = {0.0, 0.0, 0.0, 0.0};        // second accumulator: two independent MFMA chains
             if (!rhs) {
@@ -281,7 +286,7 @@ UVS_NOINLINE void chol_factor_impl(double* sh, int debug) {
                 for (int j = 0; j < k; ++j, Bj += UVS_BLK_SZ) {
                     double av[4], bv[4];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) { av[q] = (li == 0) ? -b[16 * j + 4 * q + lk] : 0.0; bv[q] = Bj[4 * q]; }
+                    for (int q = 0; q < 4; ++q) { const double yv = b[16 * j + 4 * q + lk]; av[q] = (li == 0) ? -yv : 0.0; bv[q] = Bj[4 * q]; }
                     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0], bv[0], acc, 0, 0, 0);
                     acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], bv[1], acc2, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2], bv[2], acc, 0, 0, 0);
@@ -342,7 +347,11 @@ UVS_NOINLINE void chol_factor_impl(double* sh, int debug) {
         {
             double Bw[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { const int m = 4 * q + lk; Bw[q] = (m < li) ? Dk[m * UVS_BLK_LD + li] : (m == li ? sh[L_DINV + 16 * k + li] : 0.0); }
+            for (int q = 0; q < 4; ++q) {      // unconditional loads + selects (a conditional LDS read becomes a branch per element)
+                const int m = 4 * q + lk;
+                const double up = Dk[m * UVS_BLK_LD + li], dg = sh[L_DINV + 16 * k + li];
+                Bw[q] = (m < li) ? up : (m == li ? dg : 0.0);
+            }
             for (int t = 1 + wv; t < nitem; t += NW) {
                 const int i = k + t;
                 const bool rhs = (i == UVS_NF);
@@ -360,7 +369,7 @@ UVS_NOINLINE void chol_factor_impl(double* sh, int debug) {
                 } else {
                     double av[4];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) av[q] = (li == 0) ? b[16 * k + 4 * q + lk] : 0.0;
+                    for (int q = 0; q < 4; ++q) { const double yv = b[16 * k + 4 * q + lk]; av[q] = (li == 0) ? yv : 0.0; }
 #pragma unroll
                     for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], Bw[q], acc, 0, 0, 0);
                     if (lk == 0) b[16 * k + li] = acc[0];
@@ -375,27 +384,44 @@ UVS_NOINLINE void chol_factor_impl(double* sh, int debug) {
 // backward substitution L^T x = y in place (y in L_DLT, produced by chol_factor); the diagonal solves are mat-vecs with W^T
 UVS_DEV void chol_factor(const Ctx& c) { chol_factor_impl(c.sh, c.o.debug); }
 
-UVS_NOINLINE void chol_solve_impl(double* sh) {
+// One wave does the whole back substitution: the chain x_k -> (update of the rows above) -> x_k-1 is serial anyway, and inside
+// a single wave it needs no workgroup barrier (22 of them otherwise).
+UVS_DEV void chol_solve_impl(double* sh) {
     const int tid = threadIdx.x;
     double* b = sh + L_DLT;
-    for (int k = UVS_NF - 1; k >= 0; --k) {
-        const double* Dk = sblk(sh, k, k);
-        __syncthreads();
-        if (tid < 16) {          // x_k[c] = sum_{m >= c} W[m][c] r[m] ; W[m][c] (m > c) sits at (c, m)
-            double s = sh[L_DINV + 16 * k + tid] * b[16 * k + tid];
+    __syncthreads();
+    if (tid < 64) {
+        for (int k = UVS_NF - 1; k >= 0; --k) {
+            const double* Dk = sblk(sh, k, k);
+            // x_k[c] = sum_{m >= c} W[m][c] r[m] ; W[m][c] (m > c) sits at (c, m).  All loads unconditional and up front, four
+            // partial sums: the only serial part left is LDS latency
+            const int c16 = tid & 15;
+            double wv_[16], rv[16];
 #pragma unroll
-            for (int m = 1; m < 16; ++m) s += (m > tid) ? Dk[tid * UVS_BLK_LD + m] * b[16 * k + m] : 0.0;
-            b[16 * k + tid] = s;      // all lanes of the wave read r before any lane writes (same instruction stream)
-        }
-        __syncthreads();
-        const int ncol = k * 16;
-        if (tid < ncol) {
-            const int j = tid >> 4, cc = tid & 15;
-            const double* B = sblk(sh, k, j) + cc;
-            double s = 0.0;
+            for (int m = 0; m < 16; ++m) { wv_[m] = Dk[c16 * UVS_BLK_LD + m]; rv[m] = b[16 * k + m]; }
+            const double dinv = sh[L_DINV + 16 * k + c16];
+            double p4[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s += B[r * UVS_BLK_LD] * b[16 * k + r];
-            b[16 * j + cc] -= s;
+            for (int m = 0; m < 16; ++m) { const double w = (m > c16) ? wv_[m] : (m == c16 ? dinv : 0.0); p4[m & 3] += w * rv[m]; }
+            const double s = (p4[0] + p4[1]) + (p4[2] + p4[3]);
+            wave_sync();
+            if (tid < 16) b[16 * k + tid] = s;
+            wave_sync();
+            double xk[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xk[r] = b[16 * k + r];
+            for (int t = tid; t < 16 * k; t += 64) {
+                const int j = t >> 4, cc = t & 15;
+                const double* B = sblk(sh, k, j) + cc;
+                double bv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) bv[r] = B[r * UVS_BLK_LD];
+                double u4[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int r = 0; r < 16; ++r) u4[r & 3] += bv[r] * xk[r];
+                b[16 * j + cc] -= (u4[0] + u4[1]) + (u4[2] + u4[3]);
+            }
+            wave_sync();
         }
     }
     __syncthreads();
@@ -1041,45 +1067,72 @@ UVS_DEV double ambient_sqnorm(const Ctx& c, const double* x, const double* invd,
 
 // ------------------------------------------------------------------ the kernel
 // setup: IMU whitening matrices W = chol_lower(cov^-1)^T (imu_factor.h:64) and prior H0 = J0^T J0, once per solve.
-// One wavefront per IMU block; the 15x30 Gauss-Jordan tableau and the Cholesky factor live in the (free) S region.
-// Same operation order as a sequential partial-pivoting Gauss-Jordan, lanes own tableau columns.
+// One wavefront per IMU block, the whole computation in REGISTERS: lane c < 30 owns column c of the 15 x 30 Gauss-Jordan tableau
+// [cov | I], the multipliers of a pivot step are v_readlane broadcasts out of the pivot column's lane.  Same operation order as a
+// sequential partial-pivoting Gauss-Jordan followed by a row-wise Cholesky (what the CPU oracle does), so the values agree with
+// it to the last bits; only the 15 x 15 inverse crosses lanes once through LDS (columns -> rows).
+UVS_DEV void imu_whiten_block(const double* cov, double* W, double* scr /* LDS, 225 doubles */, int lane) {
+    double m[15];
+#pragma unroll
+    for (int i = 0; i < 15; ++i) m[i] = lane < 15 ? cov[i * 15 + lane] : (i == lane - 15 ? 1.0 : 0.0);
+#pragma unroll
+    for (int k = 0; k < 15; ++k) {
+        // partial pivoting: first row with the largest |M[i][k]|, i >= k
+        int piv = k; double best = fabs(bcast_lane(m[k], k));
+#pragma unroll
+        for (int i = k + 1; i < 15; ++i) { const double v = fabs(bcast_lane(m[i], k)); if (v > best) { best = v; piv = i; } }
+        piv = __builtin_amdgcn_readfirstlane(piv);
+#pragma unroll
+        for (int i = k + 1; i < 15; ++i) if (piv == i) { const double t = m[k]; m[k] = m[i]; m[i] = t; }
+        const double dinv = 1.0 / bcast_lane(m[k], k);
+#pragma unroll
+        for (int i = k + 1; i < 15; ++i) {
+            const double f = bcast_lane(m[i], k) * dinv;
+            if (lane >= k) m[i] -= f * m[k];
+        }
+    }
+#pragma unroll
+    for (int k = 14; k >= 0; --k) {
+        const double dinv = 1.0 / bcast_lane(m[k], k);
+        m[k] *= dinv;
+#pragma unroll
+        for (int i = 0; i < k; ++i) {
+            const double f = bcast_lane(m[i], k);
+            m[i] -= f * m[k];
+        }
+    }
+    // inverse: lane 15 + c holds column c -> LDS -> lane r reads row r (its lower triangle)
+    if (lane >= 15 && lane < 30) {
+#pragma unroll
+        for (int i = 0; i < 15; ++i) scr[i * 15 + (lane - 15)] = m[i];
+    }
+    wave_sync();
+    double a[15], Lr[15];
+#pragma unroll
+    for (int j = 0; j < 15; ++j) { a[j] = (lane < 15) ? scr[lane * 15 + j] : 0.0; Lr[j] = 0.0; }
+    // lower Cholesky of the inverse, lanes own rows
+#pragma unroll
+    for (int j = 0; j < 15; ++j) {
+        double dsum = bcast_lane(a[j], j);
+        double sdot = a[j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) { const double ljk = bcast_lane(Lr[k], j); dsum -= ljk * ljk; sdot -= Lr[k] * ljk; }
+        const double ljj = sqrt(dsum);
+        Lr[j] = (lane == j) ? ljj : (lane > j ? sdot / ljj : 0.0);
+    }
+    if (lane < 15) {
+#pragma unroll
+        for (int i = 0; i < 15; ++i) W[i * 15 + lane] = (i <= lane) ? Lr[i] : 0.0;      // W = L^T: W[i][r] = L[r][i]
+    }
+    wave_sync();
+}
+
 UVS_DEV void setup_window(const Ctx& c, double* blob_rw) {
     const DevWin& h = *c.hdr;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     for (int b = wv; b < h.n_imu; b += NW) {
         double* blk = blob_rw + h.d_imu + (size_t)b * UVS_IMU_STRIDE;
-        const double* cov = blk + UVS_IMU_COV; double* W = blk + UVS_IMU_W;
-        volatile double* M = c.sh + L_S + 704 * wv;      // 15 x 30 tableau, then 15 x 15 factor at +450
-        if (lane < 30) for (int i = 0; i < 15; ++i) M[i * 30 + lane] = lane < 15 ? cov[i * 15 + lane] : (i == lane - 15 ? 1.0 : 0.0);
-        for (int k = 0; k < 15; ++k) {
-            // partial pivoting: first row with the largest |M[i][k]|, i >= k
-            int piv = k; double best = fabs(M[k * 30 + k]);
-            for (int i = k + 1; i < 15; ++i) { const double v = fabs(M[i * 30 + k]); if (v > best) { best = v; piv = i; } }
-            if (piv != k && lane < 30) { const double t = M[k * 30 + lane]; M[k * 30 + lane] = M[piv * 30 + lane]; M[piv * 30 + lane] = t; }
-            const double dinv = 1.0 / M[k * 30 + k];
-            for (int i = k + 1; i < 15; ++i) {
-                const double f = M[i * 30 + k] * dinv;
-                if (lane >= k && lane < 30) M[i * 30 + lane] -= f * M[k * 30 + lane];
-            }
-        }
-        for (int k = 14; k >= 0; --k) {
-            const double dinv = 1.0 / M[k * 30 + k];
-            if (lane < 30) M[k * 30 + lane] *= dinv;
-            for (int i = 0; i < k; ++i) {
-                const double f = M[i * 30 + k];
-                if (lane < 30) M[i * 30 + lane] -= f * M[k * 30 + lane];
-            }
-        }
-        // lower Cholesky of the inverse (reads its lower triangle), lanes own rows
-        volatile double* Lm = M + 450;
-        for (int j = 0; j < 15; ++j) {
-            double dsum = M[j * 30 + 15 + j];
-            for (int k = 0; k < j; ++k) dsum -= Lm[j * 15 + k] * Lm[j * 15 + k];
-            const double ljj = sqrt(dsum);
-            if (lane > j && lane < 15) { double s = M[lane * 30 + 15 + j]; for (int k = 0; k < j; ++k) s -= Lm[lane * 15 + k] * Lm[j * 15 + k]; Lm[lane * 15 + j] = s / ljj; }
-            if (lane == j) Lm[j * 15 + j] = ljj;
-        }
-        for (int t = lane; t < 225; t += 64) { const int i = t / 15, j = t - 15 * i; W[t] = (j >= i) ? Lm[j * 15 + i] : 0.0; }
+        imu_whiten_block(blk + UVS_IMU_COV, blk + UVS_IMU_W, c.sh + L_S + 256 * wv, lane);
     }
     if (h.prior_n > 0) {
         const int n = h.prior_n;
