@@ -225,92 +225,116 @@ UVS_DEV double rcp_newton(double x) {
     return y;
 }
 
-// LEFT-LOOKING blocked Cholesky, S = L L^T in place, with the right-hand side carried as block row 11 (one real row), so
-// L_DLT leaves as y = L^-1 rhs.  Per block column k (two workgroup barriers):
-//   S1  every block (i,k), i >= k, is owned by one wave and accumulates  S_ik - sum_{j<k} L_ij L_kj^T  in MFMA registers
-//       (4 x v_mfma_f64_16x16x4_f64 per term); the diagonal block stays in wave 0's registers;
-//   S2  wave 0 factors the 16x16 diagonal block WITHOUT leaving the MFMA C layout: row j of the (symmetric) block lives in
-//       lanes 16*(j&3).. of register j>>2, which is exactly k-slot (j&3) of the A/B operands, so pivot j is one readlane,
-//       one reciprocal and one rank-1 MFMA; a second MFMA per pivot runs the same elimination on the identity => W = L_kk^-1;
-//   S3  the panel X_ik = S_ik W^T (and the rhs row y_k = b_k W^T) is 4 MFMAs per block instead of a 16-step substitution.
+// LEFT-LOOKING blocked Cholesky with one column of LOOK-AHEAD:  S = L L^T in place, and the right-hand side carried as block
+// row 11 (one real row), so L_DLT leaves as y = L^-1 rhs.
+// Per block column k (two workgroup barriers):
+//   A   apply the LAST term (j = k-1) to the blocks (i,k): wave 0 keeps the diagonal block in its MFMA registers, the other waves
+//       do the blocks below it (4 x v_mfma_f64_16x16x4_f64 each);
+//   S2  wave 0 factors the 16x16 diagonal block WITHOUT leaving the MFMA C layout: row j of the (symmetric) block lives in lanes
+//       16*(j&3).. of register j>>2, which is exactly k-slot (j&3) of the A/B operands, so pivot j is one readlane, one reciprocal
+//       and one rank-1 MFMA; a second MFMA per pivot runs the same elimination on the identity => W = L_kk^-1; square roots only after the chain;
+//   LA  meanwhile the other waves apply the terms j < k to block column k+1 (the look-ahead), which is what keeps the matrix cores
+//       busy while the pivot chain runs and leaves only ONE term for phase A of the next column;
+//   S3  the panel L_ik = S_ik W^T (and the rhs row y_k = b_k W^T) is 4 MFMAs per block instead of a 16-step substitution.
 // C/D layout of the f64 MFMA: row = (lane >> 4) + 4 * reg, col = lane & 15;  A[i][k]: lane i + 16k;  B[k][j]: lane j + 16k.
-struct MiniCtx { double* sh; struct { int debug; } o; };      // what UVS_PROF needs inside the out-of-line phases
-#define UVS_NOINLINE __device__ __attribute__((noinline))
+struct MiniCtx { double* sh; struct { int debug; } o; };      // what UVS_PROF needs inside the dense-solve phases
+UVS_DEV void chol_update_item(double* sh, int i, int cc, int j0, int j1, int lane, d4_t& acc) {
+    // acc -= sum_{j in [j0, j1)} L_ij L_cj^T   (i == UVS_NF: the right-hand-side row, y_j^T in L_DLT)
+    const int li = lane & 15, lk = lane >> 4;
+    const bool rhs = (i == UVS_NF);
+    d4_t acc2 = {0.0, 0.0, 0.0, 0.0};        // second accumulator: two independent MFMA chains
+    const double* Bj = sblk(sh, cc, j0) + li * UVS_BLK_LD + lk;
+    const double* Ai = rhs ? sh + L_DLT + 16 * j0 + lk : sblk(sh, i, j0) + li * UVS_BLK_LD + lk;
+    const int astep = rhs ? 16 : UVS_BLK_SZ;
+    const bool azero = rhs && li != 0;
+    for (int j = j0; j < j1; ++j, Bj += UVS_BLK_SZ, Ai += astep) {
+        double av[4], bv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const double a = Ai[4 * q]; av[q] = azero ? 0.0 : -a; bv[q] = Bj[4 * q]; }
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0], bv[0], acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], bv[1], acc2, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2], bv[2], acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[3], bv[3], acc2, 0, 0, 0);
+    }
+    acc += acc2;
+}
+// C-layout load / store of block (i, cc); the diagonal block is symmetrised from its stored lower triangle; the rhs row lives in L_DLT
+UVS_DEV d4_t chol_load_item(double* sh, int i, int cc, int lane) {
+    const int li = lane & 15, lk = lane >> 4;
+    d4_t acc;
+    if (i == UVS_NF) { const double bv0 = sh[L_DLT + 16 * cc + li]; acc[0] = (lk == 0) ? bv0 : 0.0; acc[1] = 0.0; acc[2] = 0.0; acc[3] = 0.0; }
+    else if (i == cc) {
+        const double* Dk = sblk(sh, cc, cc);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int r = lk + 4 * q; const int hi_ = r >= li ? r : li, lo_ = r >= li ? li : r; acc[q] = Dk[hi_ * UVS_BLK_LD + lo_]; }
+    } else {
+        const double* Cb = sblk(sh, i, cc) + lk * UVS_BLK_LD + li;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = Cb[4 * q * UVS_BLK_LD];
+    }
+    return acc;
+}
+UVS_DEV void chol_store_item(double* sh, int i, int cc, int lane, const d4_t& acc) {
+    const int li = lane & 15, lk = lane >> 4;
+    if (i == UVS_NF) { if (lk == 0) sh[L_DLT + 16 * cc + li] = acc[0]; }
+    else if (i == cc) {      // diagonal block: only the lower triangle is storage of S (the upper one belongs to W)
+        double* Dk = sblk(sh, cc, cc);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int r = lk + 4 * q; if (r >= li) Dk[r * UVS_BLK_LD + li] = acc[q]; }
+    } else {
+        double* Cb = sblk(sh, i, cc) + lk * UVS_BLK_LD + li;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Cb[4 * q * UVS_BLK_LD] = acc[q];
+    }
+}
+
 UVS_DEV void chol_factor_impl(double* sh, int debug) {
     MiniCtx c; c.sh = sh; c.o.debug = debug;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform ON PURPOSE: item indices derived from it select code paths
     const int li = lane & 15, lk = lane >> 4;
-    double* b = sh + L_DLT;
     if (tid == 0) sh[L_CTRL + C_CHOLOK] = 1.0;
     UVS_PROF(c, P_MISC);
+    // wave 0 owns the diagonal blocks; with 8 waves, wave 4 sits on the same SIMD (waves are dealt to the 4 SIMDs round-robin) and
+    // would put its MFMAs between the pivots of the serial chain, so it only helps in S3
+    const int nwork = (NW == 8) ? 6 : NW - 1;
+    const int wrk = (wv == 0 || ((NW == 8) && wv == 4)) ? -1 : ((NW == 8) ? ((wv < 4) ? wv - 1 : wv - 2) : wv - 1);
     for (int k = 0; k < UVS_NF; ++k) {
         double* Dk = sblk(sh, k, k);
         __syncthreads();
-        // ---- S1: left-looking update of block column k (items t: i = k + t; i == UVS_NF is the right-hand-side row)
+        // ---- A: last term (j = k-1) of block column k
         d4_t dacc = {0.0, 0.0, 0.0, 0.0};
-        const int nitem = UVS_NF + 1 - k;
-        // wave 0 owns the diagonal block (t = 0) and goes straight on to factor it; wave 4 sits on the same SIMD (waves are dealt to
-        // the 4 SIMDs round-robin) and would put its MFMAs between the pivots of that serial chain, so it takes no S1 work
-        const int nwork = (NW == 8) ? 6 : NW - 1;
-        const int s1w = (NW == 8) ? ((wv < 4) ? wv - 1 : wv - 2) : wv - 1;       // 8 waves: workers 1,2,3,5,6,7 -> 0..5
-        const bool s1idle = (NW == 8) && wv == 4;
-        for (int t = (wv == 0 ? 0 : (s1idle ? nitem : 1 + s1w)); t < nitem; t += (wv == 0 ? nitem : nwork)) {
-            const int i = k + t;
-            const bool rhs = (i == UVS_NF);
-            d4_t acc;
-            if (t == 0) {        // diagonal block: symmetrise from the stored lower triangle
-#pragma unroll
-                for (int q = 0; q < 4; ++q) { const int r = lk + 4 * q; const int hi_ = r >= li ? r : li, lo_ = r >= li ? li : r; acc[q] = Dk[hi_ * UVS_BLK_LD + lo_]; }
-            } else if (!rhs) {
-                const double* Cb = sblk(sh, i, k) + lk * UVS_BLK_LD + li;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) acc[q] = Cb[4 * q * UVS_BLK_LD];
-            } else {
-                { const double bv0 = b[16 * k + li]; acc[0] = (lk == 0) ? bv0 : 0.0; } acc[1] = 0.0; acc[2] = 0.0; acc[3] = 0.0;
-            }
-            d4_t acc2 = {0.0, 0.0, 0.0, 0.0};        // second accumulator: two independent MFMA chains
-            if (!rhs) {
-                const double* Bj = sblk(sh, k, 0) + li * UVS_BLK_LD + lk;
-                const double* Ai = sblk(sh, i, 0) + li * UVS_BLK_LD + lk;
-                for (int j = 0; j < k; ++j, Bj += UVS_BLK_SZ, Ai += UVS_BLK_SZ) {
-                    double av[4], bv[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) { av[q] = -Ai[4 * q]; bv[q] = Bj[4 * q]; }
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0], bv[0], acc, 0, 0, 0);
-                    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], bv[1], acc2, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2], bv[2], acc, 0, 0, 0);
-                    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[3], bv[3], acc2, 0, 0, 0);
-                }
-            } else {
-                const double* Bj = sblk(sh, k, 0) + li * UVS_BLK_LD + lk;
-                for (int j = 0; j < k; ++j, Bj += UVS_BLK_SZ) {
-                    double av[4], bv[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) { const double yv = b[16 * j + 4 * q + lk]; av[q] = (li == 0) ? -yv : 0.0; bv[q] = Bj[4 * q]; }
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0], bv[0], acc, 0, 0, 0);
-                    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], bv[1], acc2, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2], bv[2], acc, 0, 0, 0);
-                    acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[3], bv[3], acc2, 0, 0, 0);
+        if (wv == 0) {
+            dacc = chol_load_item(sh, k, k, lane);
+            if (k > 0) chol_update_item(sh, k, k, k - 1, k, lane, dacc);
+        } else if (wrk >= 0) {
+            if (k > 0) {
+                for (int i = k + 1 + wrk; i <= UVS_NF; i += nwork) {
+                    d4_t acc = chol_load_item(sh, i, k, lane);
+                    chol_update_item(sh, i, k, k - 1, k, lane, acc);
+                    chol_store_item(sh, i, k, lane, acc);
                 }
             }
-            acc += acc2;
-            if (t == 0) dacc = acc;
-            else if (!rhs) {
-                double* Cb = sblk(sh, i, k) + lk * UVS_BLK_LD + li;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) Cb[4 * q * UVS_BLK_LD] = acc[q];
-            } else if (lk == 0) b[16 * k + li] = acc[0];
+            // ---- LA: terms j < k of block column k+1, while wave 0 runs the pivot chain
+            if (k > 0 && k + 1 < UVS_NF) {
+                for (int i = k + 1 + wrk; i <= UVS_NF; i += nwork) {
+                    d4_t acc = chol_load_item(sh, i, k + 1, lane);
+                    chol_update_item(sh, i, k + 1, 0, k, lane, acc);
+                    chol_store_item(sh, i, k + 1, lane, acc);
+                }
+            }
         }
         UVS_PROF(c, P_CH_TRAIL);
         // ---- S2: wave 0 factors the diagonal block in registers (L -> lower triangle, W^T -> strictly upper, 1/L_jj -> L_DINV).
-        // The serial chain per pivot is readlane -> reciprocal -> masked scale -> MFMA; with STRICT masks row j of both
-        // accumulators is left untouched after pivot j, so all square roots and the scaling by 1/L_jj happen once, lane-parallel,
-        // after the chain (unscaled row j of dacc = a_jc^(j), row j of T = unscaled row of W).
+        // The serial chain per pivot is readlane -> reciprocal -> masked scale -> MFMA; with STRICT masks row j of both accumulators
+        // is left untouched after pivot j (unscaled row j of dacc = a_jc^(j), row j of T = row of W), so the scaling by 1/d_j happens
+        // once, lane-parallel, after the chain.
         if (wv == 0) {
             d4_t T;
 #pragma unroll
             for (int q = 0; q < 4; ++q) T[q] = (lk + 4 * q == li) ? 1.0 : 0.0;
             double us_prev = 0.0;
+            double pivs[4] = {1.0, 1.0, 1.0, 1.0};      // pivs[q] = pivot of row lk + 4q (this lane's row of register q)
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
                 const int reg = j >> 2, slot = j & 3;
@@ -322,28 +346,23 @@ UVS_DEV void chol_factor_impl(double* sh, int debug) {
                 double y = __builtin_amdgcn_rcp(piv);                        // 1/piv: hardware seed (2^-24) + one third-order step
                 const double e = fma(-piv, y, 1.0);
                 y = fma(y, fma(e, e, e), y);
+                if (lk == slot) pivs[reg] = piv;
                 const double us = -m * y;
                 dacc = __builtin_amdgcn_mfma_f64_16x16x4f64(us, dacc[reg], dacc, 0, 0, 0);
                 us_prev = us;
             }
-            // (pivot 15 has no rows below it: nothing left to eliminate in T)
-            // square roots + scaling, lane-parallel: this lane's register q belongs to row j = lk + 4q, whose pivot sits untouched on
-            // the diagonal lane 16*lk + j of the same register
+            // square roots + scaling, lane-parallel and off the chain: register q of this lane belongs to row j = lk + 4q
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int j = lk + 4 * q;
-                double ljj, inv; rsqrt_pair(dacc[q], &ljj, &inv);            // meaningful on the diagonal lane only
-                if (li == j && !(dacc[q] > 0.0)) sh[L_CTRL + C_CHOLOK] = 0.0;
-                const int src = (16 * lk + j) << 2;
-                const int ilo = __builtin_amdgcn_ds_bpermute(src, __double2loint(inv)), ihi = __builtin_amdgcn_ds_bpermute(src, __double2hiint(inv));
-                const double invj = __hiloint2double(ihi, ilo);
-                Dk[li * UVS_BLK_LD + j] = (li > j) ? dacc[q] * invj : (li == j ? ljj : T[q] * invj);      // L[c][j] | W[j][m] at (m, j)
-                if (li == j) sh[L_DINV + 16 * k + j] = inv;
+                double ljj, inv; rsqrt_pair(pivs[q], &ljj, &inv);
+                Dk[li * UVS_BLK_LD + j] = (li > j) ? dacc[q] * inv : (li == j ? ljj : T[q] * inv);      // L[c][j] | W[j][m] at (m, j)
+                if (li == j) { sh[L_DINV + 16 * k + j] = inv; if (!(pivs[q] > 0.0)) sh[L_CTRL + C_CHOLOK] = 0.0; }
             }
         }
         __syncthreads();
         UVS_PROF(c, P_CH_DIAG);
-        // ---- S3: panel  X_ik = S_ik W^T  (B operand W[c][m]: strictly-upper slot (m, c) of the diagonal block, 1/L_cc on the diagonal)
+        // ---- S3: panel  L_ik = S_ik W^T  (B operand W[c][m]: strictly-upper slot (m, c) of the diagonal block, 1/L_cc on the diagonal)
         {
             double Bw[4];
 #pragma unroll
@@ -352,40 +371,32 @@ UVS_DEV void chol_factor_impl(double* sh, int debug) {
                 const double up = Dk[m * UVS_BLK_LD + li], dg = sh[L_DINV + 16 * k + li];
                 Bw[q] = (m < li) ? up : (m == li ? dg : 0.0);
             }
-            for (int t = 1 + wv; t < nitem; t += NW) {
-                const int i = k + t;
+            for (int i = k + 1 + wv; i <= UVS_NF; i += NW) {
                 const bool rhs = (i == UVS_NF);
                 d4_t acc = {0.0, 0.0, 0.0, 0.0};
+                double av[4];
                 if (!rhs) {
-                    double* Ai = sblk(sh, i, k) + li * UVS_BLK_LD + lk;
-                    double av[4];
+                    const double* Ai = sblk(sh, i, k) + li * UVS_BLK_LD + lk;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) av[q] = Ai[4 * q];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], Bw[q], acc, 0, 0, 0);
-                    double* Cb = sblk(sh, i, k) + lk * UVS_BLK_LD + li;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) Cb[4 * q * UVS_BLK_LD] = acc[q];
                 } else {
-                    double av[4];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) { const double yv = b[16 * k + 4 * q + lk]; av[q] = (li == 0) ? yv : 0.0; }
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], Bw[q], acc, 0, 0, 0);
-                    if (lk == 0) b[16 * k + li] = acc[0];
+                    for (int q = 0; q < 4; ++q) { const double yv = sh[L_DLT + 16 * k + 4 * q + lk]; av[q] = (li == 0) ? yv : 0.0; }
                 }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], Bw[q], acc, 0, 0, 0);
+                chol_store_item(sh, i, k, lane, acc);
             }
         }
         UVS_PROF(c, P_CH_PANEL);
     }
     __syncthreads();
 }
-
-// backward substitution L^T x = y in place (y in L_DLT, produced by chol_factor); the diagonal solves are mat-vecs with W^T
 UVS_DEV void chol_factor(const Ctx& c) { chol_factor_impl(c.sh, c.o.debug); }
 
-// One wave does the whole back substitution: the chain x_k -> (update of the rows above) -> x_k-1 is serial anyway, and inside
-// a single wave it needs no workgroup barrier (22 of them otherwise).
+// back substitution L^T x = y in place (y in L_DLT, produced by chol_factor); the diagonal solves are mat-vecs with W^T.
+// One wave does all of it: the chain x_k -> (update of the rows above) -> x_k-1 is serial anyway, and inside a single wave it
+// needs no workgroup barrier (22 of them otherwise).
 UVS_DEV void chol_solve_impl(double* sh) {
     const int tid = threadIdx.x;
     double* b = sh + L_DLT;
@@ -393,8 +404,8 @@ UVS_DEV void chol_solve_impl(double* sh) {
     if (tid < 64) {
         for (int k = UVS_NF - 1; k >= 0; --k) {
             const double* Dk = sblk(sh, k, k);
-            // x_k[c] = sum_{m >= c} W[m][c] r[m] ; W[m][c] (m > c) sits at (c, m).  All loads unconditional and up front, four
-            // partial sums: the only serial part left is LDS latency
+            // x_k[c] = sum_{m >= c} W[m][c] r[m] ; W[m][c] (m > c) sits at (c, m).  All loads unconditional and up front,
+            // four partial sums: the only serial part left is LDS latency
             const int c16 = tid & 15;
             double wv_[16], rv[16];
 #pragma unroll
@@ -464,69 +475,6 @@ UVS_DEV void row_fma(double* v, double s, const d2_t* q) {
 // this lane's group descriptor (-1 = idle group), see uvs_layout.h: i_wblk
 UVS_DEV int gather_group(const Ctx& c) { return c.bi[c.hdr->i_wblk + (threadIdx.x >> 1)]; }
 
-// Operand sets of the four gather loops.  Every loop is software-pipelined by hand: the operands of entry i+1 are requested from
-// LDS before the FMAs of entry i issue (one wave per SIMD => nothing else hides the LDS latency).
-struct PSch { double ea[3]; d2_t q[3]; };              // point Schur entry
-struct PDir { double p0[3], p1[3]; d2_t q0[3], q1[3], rc; };
-struct LSch { double ea[4][3]; d2_t y[4][3]; };
-struct LDir { double p[3][3]; d2_t q[3][3], rc01; double rc2; };
-
-UVS_DEV void load_psch(PSch& o, const double* S0, int e, bool ok, int r0) {
-    const double* pa = S0 + (e & 0x7fff) + r0;
-    const double* pb = S0 + ((unsigned)e >> 16);
-#pragma unroll
-    for (int r = 0; r < 3; ++r) o.ea[r] = ok ? -pa[r] : 0.0;
-    o.q[0] = lds2(pb); o.q[1] = lds2(pb + 2); o.q[2] = lds2(pb + 4);
-}
-UVS_DEV void load_pdir(PDir& o, const double* S0, int e, bool ok, int r0) {
-    const int lo = e & 0x7fff;
-    const double* pa = S0 + lo + r0;
-    const double* pb = S0 + ((unsigned)e >> 16);
-#pragma unroll
-    for (int r = 0; r < 3; ++r) { o.p0[r] = ok ? pa[r] : 0.0; o.p1[r] = ok ? pa[6 + r] : 0.0; }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { o.q0[k] = lds2(pb + 2 * k); o.q1[k] = lds2(pb + 6 + 2 * k); }
-    o.rc = lds2(S0 + lo + 12);
-}
-UVS_DEV void load_lsch(LSch& o, const double* S0, int e, bool ok, int r0) {
-    const double* pa = S0 + (e & 0x7fff) + r0;
-    const double* pb = S0 + ((unsigned)e >> 16);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-#pragma unroll
-        for (int r = 0; r < 3; ++r) o.ea[q][r] = ok ? -pa[6 * q + r] : 0.0;
-        o.y[q][0] = lds2(pb + 6 * q); o.y[q][1] = lds2(pb + 6 * q + 2); o.y[q][2] = lds2(pb + 6 * q + 4);
-    }
-}
-UVS_DEV void load_ldir(LDir& o, const double* S0, int ro, bool ok, int r0) {
-    const double* R = S0 + ro;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-#pragma unroll
-        for (int r = 0; r < 3; ++r) o.p[k][r] = ok ? R[UVS_LN_JP + 6 * k + r0 + r] : 0.0;
-        o.q[k][0] = lds2(R + UVS_LN_JP + 6 * k); o.q[k][1] = lds2(R + UVS_LN_JP + 6 * k + 2); o.q[k][2] = lds2(R + UVS_LN_JP + 6 * k + 4);
-    }
-    o.rc01 = lds2(R); o.rc2 = R[UVS_LN_RV];
-}
-
-// Generic pipelined walk of one list: entries [e0, e1) of `ent`; LOAD fetches the operands of one entry, USE consumes them.
-// Entry indices are fetched two ahead, operands one ahead.  Out-of-range slots load entry 0 of the staging area with zeroed
-// own-operands, so they add exactly 0.
-#define UVS_GATHER_LOOP(SET_T, LOAD, USE)                                                         \
-    {                                                                                             \
-        SET_T s0, s1;                                                                             \
-        int en = (e0 + 1 < e1) ? ent[e0 + 1] : 0;                                                 \
-        LOAD(s0, S0, (e0 < e1) ? ent[e0] : 0, e0 < e1, r0);                                       \
-        for (int i = e0; i < e1; i += 2) {                                                        \
-            const int en2 = (i + 2 < e1) ? ent[i + 2] : 0;                                        \
-            LOAD(s1, S0, en, i + 1 < e1, r0);                                                     \
-            USE(s0);                                                                              \
-            en = (i + 3 < e1) ? ent[i + 3] : 0;                                                   \
-            LOAD(s0, S0, en2, i + 2 < e1, r0);                                                    \
-            USE(s1);                                                                              \
-        }                                                                                         \
-    }
-
 UVS_DEV void gather_points(int grp, const int* lists, const double* S0, GAcc& A) {
     const int g = threadIdx.x >> 1, r0 = 3 * (threadIdx.x & 1);
     const bool on = grp >= 0;
@@ -535,16 +483,46 @@ UVS_DEV void gather_points(int grp, const int* lists, const double* S0, GAcc& A)
     // ---- Schur: acc[r][c] -= E_a[r0 + r] * Einv_b[c]
     {
         const int e0 = on ? lists[g] : 0, e1 = on ? lists[g + 1] : 0;
-#define UVS_USE_PSCH(s) { _Pragma("unroll") for (int r = 0; r < 3; ++r) row_fma(A.v + 6 * r, s.ea[r], s.q); }
-        UVS_GATHER_LOOP(PSch, load_psch, UVS_USE_PSCH)
+        for (int i = e0; i < e1; i += 2) {
+            double ea[2][3]; d2_t q[2][3];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const bool ok = i + u < e1;
+                const int e = ok ? ent[i + u] : 0;
+                const double* pa = S0 + (e & 0x7fff) + r0;
+                const double* pb = S0 + ((unsigned)e >> 16);
+#pragma unroll
+                for (int r = 0; r < 3; ++r) ea[u][r] = ok ? -pa[r] : 0.0;
+                q[u][0] = lds2(pb); q[u][1] = lds2(pb + 2); q[u][2] = lds2(pb + 4);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < 3; ++r) row_fma(A.v + 6 * r, ea[u][r], q[u]);
+        }
     }
     // ---- direct: acc[r][c] += J1[0][r0+r] J2[0][c] + J1[1][r0+r] J2[1][c] ; diagonal blocks (J1 == J2) also g and diag(J^T J)
     {
         const int e0 = on ? lists[UVS_NGRP + 1 + g] : 0, e1 = on ? lists[UVS_NGRP + 2 + g] : 0;
-#define UVS_USE_PDIR(s) { _Pragma("unroll") for (int r = 0; r < 3; ++r) {                                           \
-            row_fma(A.v + 6 * r, s.p0[r], s.q0); row_fma(A.v + 6 * r, s.p1[r], s.q1);                                 \
-            if (diag) { A.g[r] += s.p0[r] * s.rc.x + s.p1[r] * s.rc.y; A.hd[r] += s.p0[r] * s.p0[r] + s.p1[r] * s.p1[r]; } } }
-        UVS_GATHER_LOOP(PDir, load_pdir, UVS_USE_PDIR)
+        int e = (e0 < e1) ? ent[e0] : 0;
+        for (int i = e0; i < e1; ++i) {
+            const int en = (i + 1 < e1) ? ent[i + 1] : 0;      // next entry in flight while this one is consumed
+            const int lo = e & 0x7fff;
+            const double* pa = S0 + lo + r0;
+            const double* pb = S0 + ((unsigned)e >> 16);
+            double p0[3], p1[3]; d2_t q0[3], q1[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) { p0[r] = pa[r]; p1[r] = pa[6 + r]; }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { q0[k] = lds2(pb + 2 * k); q1[k] = lds2(pb + 6 + 2 * k); }
+            const d2_t rc = lds2(S0 + lo + 12);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                row_fma(A.v + 6 * r, p0[r], q0); row_fma(A.v + 6 * r, p1[r], q1);
+                if (diag) { A.g[r] += p0[r] * rc.x + p1[r] * rc.y; A.hd[r] += p0[r] * p0[r] + p1[r] * p1[r]; }
+            }
+            e = en;
+        }
     }
 }
 
@@ -555,16 +533,48 @@ UVS_DEV void gather_lines(int grp, const int* lists, const double* S0, GAcc& A) 
     // ---- Schur: acc[r][c] -= sum_q E_a[q][r0 + r] * Y_b[q][c]
     {
         const int e0 = on ? lists[g] : 0, e1 = on ? lists[g + 1] : 0;
-#define UVS_USE_LSCH(s) { _Pragma("unroll") for (int q = 0; q < 4; ++q) { _Pragma("unroll") for (int r = 0; r < 3; ++r) row_fma(A.v + 6 * r, s.ea[q][r], s.y[q]); } }
-        UVS_GATHER_LOOP(LSch, load_lsch, UVS_USE_LSCH)
+        int e = (e0 < e1) ? ent[e0] : 0;
+        for (int i = e0; i < e1; ++i) {
+            const int en = (i + 1 < e1) ? ent[i + 1] : 0;
+            const double* pa = S0 + (e & 0x7fff) + r0;
+            const double* pb = S0 + ((unsigned)e >> 16);
+            double ea[4][3]; d2_t y[4][3];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) ea[q][r] = -pa[6 * q + r];
+                y[q][0] = lds2(pb + 6 * q); y[q][1] = lds2(pb + 6 * q + 2); y[q][2] = lds2(pb + 6 * q + 4);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int r = 0; r < 3; ++r) row_fma(A.v + 6 * r, ea[q][r], y[q]);
+            e = en;
+        }
     }
     // ---- direct (always a diagonal block): 3 pose-Jacobian rows (line, line, vanishing point) + corrected residuals
     {
         const int e0 = on ? lists[UVS_NGRP + 1 + g] : 0, e1 = on ? lists[UVS_NGRP + 2 + g] : 0;
-#define UVS_USE_LDIR(s) { _Pragma("unroll") for (int r = 0; r < 3; ++r) {                                            \
-            _Pragma("unroll") for (int k = 0; k < 3; ++k) { row_fma(A.v + 6 * r, s.p[k][r], s.q[k]); A.hd[r] += s.p[k][r] * s.p[k][r]; }   \
-            A.g[r] += s.p[0][r] * s.rc01.x + s.p[1][r] * s.rc01.y + s.p[2][r] * s.rc2; } }
-        UVS_GATHER_LOOP(LDir, load_ldir, UVS_USE_LDIR)
+        int ro = (e0 < e1) ? ent[e0] : 0;
+        for (int i = e0; i < e1; ++i) {
+            const int rn = (i + 1 < e1) ? ent[i + 1] : 0;
+            const double* R = S0 + ro;
+            double p[3][3]; d2_t q[3][3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) p[k][r] = R[UVS_LN_JP + 6 * k + r0 + r];
+                q[k][0] = lds2(R + UVS_LN_JP + 6 * k); q[k][1] = lds2(R + UVS_LN_JP + 6 * k + 2); q[k][2] = lds2(R + UVS_LN_JP + 6 * k + 4);
+            }
+            const d2_t rc01 = lds2(R); const double rc2 = R[UVS_LN_RV];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { row_fma(A.v + 6 * r, p[k][r], q[k]); A.hd[r] += p[k][r] * p[k][r]; }
+                A.g[r] += p[0][r] * rc01.x + p[1][r] * rc01.y + p[2][r] * rc2;
+            }
+            ro = rn;
+        }
     }
 }
 
@@ -580,18 +590,26 @@ static constexpr int IMU_BLK = IMU_WOFF + UVS_BLK_SZ;    // 1040 doubles of LDS 
 static constexpr int IMU_SLOTS = (UVS_NF - 1 + NW - 1) / NW;   // IMU blocks per wave (block b -> wave b % NW, slot b / NW)
 struct ImuN { d4_t n00[IMU_SLOTS], n10[IMU_SLOTS], n11[IMU_SLOTS]; };
 
-UVS_DEV double lin_frames(const Ctx& c, const double* x, ImuN& N) {
+// rotations of the evaluation point + prior residual (L_PR); returns this lane's share of the prior cost
+UVS_DEV double lin_prep(const Ctx& c, const double* x) {
+    UVS_PROF(c, P_MISC);
+    stage_rotations(c, x);
+    prior_dx(c, x);
+    __syncthreads();
+    return prior_residual(c);
+}
+// IMU normal-equation tiles; staged in the S region, so it runs when no landmark chunk is staged there (after the last gather,
+// right before the assembly: the 9 accumulator tiles per wave then live only across lin_assemble)
+UVS_DEV double lin_imu(const Ctx& c, const double* x, ImuN& N) {
     const DevWin& h = *c.hdr;
     double* sh = c.sh;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 15, lk = lane >> 4;
     double cost = 0.0;
-    UVS_PROF(c, P_MISC);
-    stage_rotations(c, x);
-    prior_dx(c, x);
+    __syncthreads();      // previous users of the S region are done
+    UVS_PROF(c, P_GATHER);
     double* IM = sh + L_S;
     for (int t = tid; t < h.n_imu * IMU_BLK; t += NT) IM[t] = 0.0;      // operand tiles are mostly structural zeros
     __syncthreads();
-    cost += prior_residual(c);
     if (tid < h.n_imu && !c.bi[h.i_imu + 2 * tid + 1]) {
         const int fi = c.bi[h.i_imu + 2 * tid];
         const double* blk = c.bd + h.d_imu + (size_t)tid * UVS_IMU_STRIDE;
@@ -637,6 +655,7 @@ UVS_DEV double lin_frames(const Ctx& c, const double* x, ImuN& N) {
     UVS_PROF(c, P_AS_IMU);
     return cost;
 }
+UVS_DEV double lin_frames(const Ctx& c, const double* x, ImuN& N) { const double pc = lin_prep(c, x); return pc + lin_imu(c, x, N); }
 
 // ---- linearization, part 2: one landmark chunk: stage -> per-landmark Schur prep -> list-driven gather into acc[]
 UVS_DEV void lin_chunk(const Ctx& c, int ch, const double* x, const double* invd, const double* line, bool first, double radius,
@@ -862,7 +881,7 @@ UVS_DEV void lin_assemble(const Ctx& c, const double* x, bool first, double radi
     __syncthreads();
     UVS_PROF(c, P_GATHER);
     // ---- assemble the reduced system in LDS
-    for (int i = tid; i < UVS_S_DOUBLES; i += NT) sh[L_S + i] = 0.0;
+    { const d2_t z2 = {0.0, 0.0}; for (int i = tid; i < UVS_S_DOUBLES / 2; i += NT) *(d2_t*)(sh + L_S + 2 * i) = z2; }      // ds_write_b128
     if (tid < UVS_RD) { sh[L_G + tid] = 0.0; sh[L_HD + tid] = 0.0; }
     __syncthreads();
     // every group adds its rows of its pose block; the parts of a split block go in part order, one barrier apart (fixed sum order)
@@ -970,9 +989,10 @@ UVS_DEV void linearize(const Ctx& c, const double* x, const double* invd, const 
     const DevWin& h = *c.hdr;
     const int grp = gather_group(c);       // this lane's gather group: pose block | flags (uvs_layout.h: i_wblk)
     GAcc A; gacc_zero(A);
-    ImuN N;
-    double cost = lin_frames(c, x, N), gmax_lm = 0.0;
+    double cost = lin_prep(c, x), gmax_lm = 0.0;
     for (int ch = 0; ch < h.n_chunks; ++ch) lin_chunk(c, ch, x, invd, line, first, radius, grp, A, cost, gmax_lm);
+    ImuN N;
+    cost += lin_imu(c, x, N);
     lin_assemble(c, x, first, radius, grp, A, N, cost, gmax_lm);
 }
 
@@ -1263,7 +1283,7 @@ __global__ __launch_bounds__(NT) void k_solve(char* blobs, const long long* blob
             if (tid < 184) sh[L_X + tid] = sh[L_XC + tid];
             cur ^= 1; ++nsucc;
             x_norm = sqrt(xc2);
-            radius = radius / fmax(1.0 / 3.0, 1.0 - pow(2.0 * rel - 1.0, 3.0));
+            { const double t3 = 2.0 * rel - 1.0; radius = radius / fmax(1.0 / 3.0, 1.0 - t3 * t3 * t3); }     // (a generic pow() costs hundreds of instructions)
             radius = fmin(o.rmax, radius);
             decr = 2.0;
             cost = cand;              // replaced by the linearization's own sum if another iteration follows (equal up to summation order)
