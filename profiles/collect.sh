@@ -1,0 +1,23 @@
+#!/bin/bash
+# Collects the rocprofv3 evidence summarised under profiles/ (run on the GPU box through gpurun from the repo root):
+#   gpurun --timeout 1500 -- 'bash profiles/collect.sh r01b'
+# One pass for the kernel trace, separate passes per PMC group (FETCH_SIZE and WRITE_SIZE do not fit one pass; PMC is never
+# combined with sys/hip/hsa traces).  Raw CSVs stay in gpurun_out/ (scratch); profiles/summarize.py writes the tracked summary.
+set -u
+TAG=${1:-r01}
+R=$(pwd)
+export TMPDIR=/tmp
+CMD="python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline"
+cd /tmp
+rm -rf $R/gpurun_out/prof_kt $R/gpurun_out/prof_fetch $R/gpurun_out/prof_write $R/gpurun_out/prof_sq $R/gpurun_out/prof_sq2
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_kt -o runc -- $CMD > $R/gpurun_out/prof_kt.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/prof_fetch -o runc -- $CMD > $R/gpurun_out/prof_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/prof_write -o runc -- $CMD > $R/gpurun_out/prof_write.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $R/gpurun_out/prof_sq -o runc -- $CMD > $R/gpurun_out/prof_sq.log 2>&1
+rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INSTS_SALU SQ_INSTS_SMEM --kernel-trace --output-format csv -d $R/gpurun_out/prof_sq2 -o runc -- $CMD > $R/gpurun_out/prof_sq2.log 2>&1
+cd $R
+python profiles/summarize.py $TAG
+# keep the per-kernel stats table of the trace pass
+f=$(ls gpurun_out/prof_kt/runc*kernel_stats.csv gpurun_out/prof_kt/*/*kernel_stats.csv 2>/dev/null | head -1)
+[ -n "$f" ] && cp "$f" profiles/${TAG}_kernel_stats_bench256.csv
+ls -la profiles/

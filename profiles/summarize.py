@@ -8,18 +8,21 @@ import collections, csv, glob, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 out = {}
-rows = list(csv.DictReader(open(glob.glob(f"{ROOT}/gpurun_out/prof_kt/runc/*_kernel_trace.csv")[0])))
+def _find(d, suffix):
+    fs = glob.glob(f"{ROOT}/gpurun_out/{d}/**/*{suffix}", recursive=True)
+    return fs[0] if fs else None
+rows = list(csv.DictReader(open(_find("prof_kt", "_kernel_trace.csv"))))
 dur = lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
-big = [dur(r) for r in rows if "k_solve" in r["Kernel_Name"] and int(r["Grid_Size_X"]) > 512]
-one = [dur(r) for r in rows if "k_solve" in r["Kernel_Name"] and int(r["Grid_Size_X"]) == 512]
+big = [dur(r) for r in rows if "k_solve" in r["Kernel_Name"] and int(r["Grid_Size_X"]) > 1024]      # batch launches (256 windows x 256 threads)
+one = [dur(r) for r in rows if "k_solve" in r["Kernel_Name"] and int(r["Grid_Size_X"]) <= 1024]    # single-window launches
 out.update(k_solve_batch_launches=len(big), k_solve_batch_avg_ms=sum(big) / len(big), k_solve_batch_min_ms=min(big), k_solve_batch_max_ms=max(big),
            k_solve_single_window_avg_ms=sum(one) / max(len(one), 1))
-for name in ("prof_fetch", "prof_write", "prof_sq"):
-    fs = glob.glob(f"{ROOT}/gpurun_out/{name}/runc/*_counter_collection.csv")
-    if not fs: continue
+for name in ("prof_fetch", "prof_write", "prof_sq", "prof_sq2"):
+    f = _find(name, "_counter_collection.csv")
+    if not f: continue
     agg = collections.defaultdict(list)
-    for r in csv.DictReader(open(fs[0])):
-        if "k_solve" in r["Kernel_Name"] and int(r["Grid_Size"]) > 512:
+    for r in csv.DictReader(open(f)):
+        if "k_solve" in r["Kernel_Name"] and int(r["Grid_Size"]) > 1024:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
             out.update(vgpr=r["VGPR_Count"], sgpr=r["SGPR_Count"], lds_block_size=r["LDS_Block_Size"], scratch_size=r["Scratch_Size"], grid=r["Grid_Size"])
     for k, v in agg.items():
