@@ -42,7 +42,10 @@ static constexpr int L_RED = L_PR + UVS_MAX_PRIOR_DIM;   // reduction scratch
 static constexpr int L_CTRL = L_RED + 64;
 static constexpr int L_PROF = L_CTRL + 32;      // per-phase cycle counters (debug launches only)
 static constexpr int L_WPROF = L_PROF + 24;     // per-wave gather cycles (debug)
-static constexpr int L_TOTAL = L_WPROF + 8;
+static constexpr int L_LCOST = L_WPROF + 8;     // per-lane cost accumulator of the current linearization (kept in LDS, not in a register that
+static constexpr int L_LGMAX = L_LCOST + NT;    // would have to live across every phase) ; per-lane max |g_landmark|
+static constexpr int L_TOTAL = L_LGMAX + NT;
+static_assert(L_TOTAL * 8 <= 160 * 1024, "LDS map exceeds the 160 KB of a CU");
 enum { P_SETUP = 0, P_OBS, P_LMPREP, P_GATHER, P_ASSEMBLE, P_CHOL, P_TRSV, P_BACKSUB, P_COST, P_MISC, P_CH_DIAG, P_CH_PANEL, P_CH_TRAIL, P_AS_IMU, P_AS_ZERO, P_AS_ADD, P_LAST };
 #define UVS_PROF(c, k) do { if ((c).o.debug && threadIdx.x == 0) { const long long now_ = clock64(); (c).sh[L_PROF + (k)] += (double)(now_ - (long long)(c).sh[L_PROF + 23]); (c).sh[L_PROF + 23] = (double)now_; } } while (0)
 static constexpr size_t LDS_BYTES = (size_t)L_TOTAL * 8;
@@ -659,12 +662,13 @@ UVS_DEV double lin_frames(const Ctx& c, const double* x, ImuN& N) { const double
 
 // ---- linearization, part 2: one landmark chunk: stage -> per-landmark Schur prep -> list-driven gather into acc[]
 UVS_DEV void lin_chunk(const Ctx& c, int ch, const double* x, const double* invd, const double* line, bool first, double radius,
-                       int grp, GAcc& acc, double& cost, double& gmax_lm) {
+                       int grp, GAcc& acc) {
     const DevWin& h = *c.hdr;
     double* sh = c.sh;
     const int tid = threadIdx.x;
     const double* RF = sh + L_RF; const double* ric = sh + L_EX; const double* tic = sh + L_EX + 9;
     const int* chunks = c.bi + h.i_chunks;
+    double cost = 0.0, gmax_lm = 0.0;      // this chunk's share; flushed to the per-lane LDS accumulators before the gather
     {
         const int type = chunks[6 * ch], k0 = chunks[6 * ch + 1], k1 = chunks[6 * ch + 2];
         const int* glists = c.bi + h.i_lists + chunks[6 * ch + 3];      // gather lists of this chunk (HBM)
@@ -736,6 +740,7 @@ UVS_DEV void lin_chunk(const Ctx& c, int ch, const double* x, const double* invd
             for (int ol = tid; ol < nob; ol += NT) { double* R = rec + (size_t)ol * UVS_PT_REC; R[UVS_PT_C] = R[UVS_PT_RC2]; R[UVS_PT_C + 1] = R[UVS_PT_RC2 + 1]; }
             __syncthreads();
             UVS_PROF(c, P_LMPREP);
+            sh[L_LCOST + tid] += cost; sh[L_LGMAX + tid] = fmax(sh[L_LGMAX + tid], gmax_lm);
             const long long tg0_ = clock64();
             gather_points(grp, lists, rec, acc);
             if (c.o.debug && (tid & 63) == 0) sh[L_WPROF + (tid >> 6)] += (double)(clock64() - tg0_);
@@ -866,6 +871,7 @@ UVS_DEV void lin_chunk(const Ctx& c, int ch, const double* x, const double* invd
             }
             __syncthreads();
             UVS_PROF(c, P_LMPREP);
+            sh[L_LCOST + tid] += cost; sh[L_LGMAX + tid] = fmax(sh[L_LGMAX + tid], gmax_lm);
             const long long tg0_ = clock64();
             gather_lines(grp, lists, rec, acc);
             if (c.o.debug && (tid & 63) == 0) sh[L_WPROF + (tid >> 6)] += (double)(clock64() - tg0_);
@@ -889,64 +895,98 @@ UVS_DEV void lin_assemble(const Ctx& c, const double* x, bool first, double radi
         if (grp >= 0 && ((grp >> 9) & 15) == part) {
             const int r0 = 3 * (tid & 1);
             const int fa = (grp >> 13) & 15, fb = (grp >> 17) & 15;
+            const bool dg = fa == fb;
+            double* row0 = sh + L_S + sidx(16 * fa + r0, 16 * fb);
+            double cur[18], cg[3], chd[3];      // all reads before the first write (every "+=" to LDS otherwise waits for the one before)
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
-                const int a = r0 + r;
-                double* row = sh + L_S + sidx(16 * fa + a, 16 * fb);
-                if (fa != fb) {
 #pragma unroll
-                    for (int cc = 0; cc < 6; ++cc) row[cc] += A.v[6 * r + cc];
-                } else {
+                for (int cc = 0; cc < 6; ++cc) cur[6 * r + cc] = row0[r * UVS_BLK_LD + cc];
+                cg[r] = sh[L_G + 16 * fa + r0 + r]; chd[r] = sh[L_HD + 16 * fa + r0 + r];
+            }
 #pragma unroll
-                    for (int cc = 0; cc < 6; ++cc) if (cc <= a) row[cc] += A.v[6 * r + cc];
-                    sh[L_G + 16 * fa + a] += A.g[r];
-                    sh[L_HD + 16 * fa + a] += A.hd[r];
-                }
+            for (int r = 0; r < 3; ++r) {
+#pragma unroll
+                for (int cc = 0; cc < 6; ++cc) if (!dg || cc <= r0 + r) row0[r * UVS_BLK_LD + cc] = cur[6 * r + cc] + A.v[6 * r + cc];
+                if (dg) { sh[L_G + 16 * fa + r0 + r] = cg[r] + A.g[r]; sh[L_HD + 16 * fa + r0 + r] = chd[r] + A.hd[r]; }
             }
         }
         __syncthreads();
     }
     UVS_PROF(c, P_AS_ZERO);
-    // IMU normal-equation tiles from the registers of lin_frames (even blocks, then odd: consecutive blocks share a diagonal frame block)
-    for (int par = 0; par < 2; ++par) {
+    // IMU normal-equation tiles from the registers of lin_imu (even blocks, then odd: consecutive blocks share a diagonal frame block)
+    {
         const int lane = tid & 63, wv = tid >> 6, li = lane & 15, lk = lane >> 4;
+        int fis[IMU_SLOTS]; bool act[IMU_SLOTS];
 #pragma unroll
-        for (int s = 0; s < IMU_SLOTS; ++s) {
+        for (int s = 0; s < IMU_SLOTS; ++s) {      // block table fetched once (HBM/L2 latency), not once per pass
             const int b = wv + s * NW;
-            if (b < h.n_imu && (b & 1) == par && !c.bi[h.i_imu + 2 * b + 1] && li < 15) {
-                const int fi = c.bi[h.i_imu + 2 * b], fj = fi + 1;
+            act[s] = b < h.n_imu && !c.bi[h.i_imu + 2 * (b < h.n_imu ? b : 0) + 1] && li < 15;
+            fis[s] = c.bi[h.i_imu + 2 * (b < h.n_imu ? b : 0)];
+        }
+        for (int par = 0; par < 2; ++par) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int row = lk + 4 * q;      // C layout: row = lk + 4q, col = li
-                    if (row < 15) {
-                        sh[L_S + sidx(16 * fj + row, 16 * fi + li)] += N.n10[s][q];
-                        if (li <= row) {
-                            sh[L_S + sidx(16 * fi + row, 16 * fi + li)] += N.n00[s][q];
-                            sh[L_S + sidx(16 * fj + row, 16 * fj + li)] += N.n11[s][q];
-                            if (li == row) { sh[L_HD + 16 * fi + row] += N.n00[s][q]; sh[L_HD + 16 * fj + row] += N.n11[s][q]; }
+            for (int s = 0; s < IMU_SLOTS; ++s) {
+                const int b = wv + s * NW;
+                if (act[s] && (b & 1) == par) {
+                    const int fi = fis[s], fj = fi + 1;
+                    // C layout: row = lk + 4q, col = li.  Rows < 15 go to S (lower triangles of the diagonal tiles), row 15 is J^T r.
+                    double* b10 = sblk(sh, fj, fi) + lk * UVS_BLK_LD + li;
+                    double* b00 = sblk(sh, fi, fi) + lk * UVS_BLK_LD + li;
+                    double* b11 = sblk(sh, fj, fj) + lk * UVS_BLK_LD + li;
+                    double c10[4], c00[4], c11[4];      // reads first, then writes
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int row = lk + 4 * q;
+                        const bool isg = row == 15;
+                        c10[q] = isg ? sh[L_G + 16 * fi + li] : b10[4 * q * UVS_BLK_LD];
+                        c11[q] = isg ? sh[L_G + 16 * fj + li] : b11[4 * q * UVS_BLK_LD];
+                        c00[q] = b00[4 * q * UVS_BLK_LD];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int row = lk + 4 * q;
+                        if (row < 15) {
+                            b10[4 * q * UVS_BLK_LD] = c10[q] + N.n10[s][q];
+                            if (li <= row) {
+                                b00[4 * q * UVS_BLK_LD] = c00[q] + N.n00[s][q];
+                                b11[4 * q * UVS_BLK_LD] = c11[q] + N.n11[s][q];
+                                if (li == row) { sh[L_HD + 16 * fi + row] += N.n00[s][q]; sh[L_HD + 16 * fj + row] += N.n11[s][q]; }
+                            }
+                        } else {
+                            sh[L_G + 16 * fi + li] = c10[q] + N.n10[s][q];
+                            sh[L_G + 16 * fj + li] = c11[q] + N.n11[s][q];
                         }
-                    } else {                          // row 15 of the lower tiles = J^T r
-                        sh[L_G + 16 * fi + li] += N.n10[s][q];
-                        sh[L_G + 16 * fj + li] += N.n11[s][q];
                     }
                 }
             }
+            __syncthreads();
         }
-        __syncthreads();
     }
     // prior: H0 = J0^T J0 (precomputed), g = J0^T r
     if (h.prior_n > 0) {
         const int n = h.prior_n;
         const int* cm = c.bi + h.i_prior + 80;
         const double* J0 = c.bd + h.d_prior; const double* H0 = J0 + n * n;
-        for (int t = tid; t < n * n; t += NT) {
-            const int a = t / n, cc = t - a * n;
-            if (cc > a) continue;
-            const int ia = cm[a], ic = cm[cc];
-            if (ia < 0 || ic < 0) continue;
-            const double v = H0[a * n + cc];
-            sh[L_S + (ia >= ic ? sidx(ia, ic) : sidx(ic, ia))] += v;
-            if (a == cc) sh[L_HD + ia] += v;
+        for (int t0 = tid; t0 < n * n; t0 += 4 * NT) {      // 4 entries per trip: global loads, then LDS reads, then LDS writes
+            int idx[4], ihd[4]; double v[4], cur[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = t0 + u * NT;
+                const bool in = t < n * n;
+                const int a = in ? t / n : 0, cc = in ? t - a * n : 0;
+                const int ia = cm[a], ic = cm[cc];
+                const bool ok = in && cc <= a && ia >= 0 && ic >= 0;
+                idx[u] = ok ? (ia >= ic ? sidx(ia, ic) : sidx(ic, ia)) : -1;
+                ihd[u] = (ok && a == cc) ? ia : -1;
+                v[u] = ok ? H0[a * n + cc] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) cur[u] = sh[L_S + (idx[u] >= 0 ? idx[u] : 0)];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (idx[u] >= 0) sh[L_S + idx[u]] = cur[u] + v[u];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (ihd[u] >= 0) sh[L_HD + ihd[u]] += v[u];
         }
         if (tid < n && cm[tid] >= 0) {
             double s = 0.0;
@@ -989,11 +1029,11 @@ UVS_DEV void linearize(const Ctx& c, const double* x, const double* invd, const 
     const DevWin& h = *c.hdr;
     const int grp = gather_group(c);       // this lane's gather group: pose block | flags (uvs_layout.h: i_wblk)
     GAcc A; gacc_zero(A);
-    double cost = lin_prep(c, x), gmax_lm = 0.0;
-    for (int ch = 0; ch < h.n_chunks; ++ch) lin_chunk(c, ch, x, invd, line, first, radius, grp, A, cost, gmax_lm);
+    { const double pc = lin_prep(c, x); c.sh[L_LCOST + threadIdx.x] = pc; c.sh[L_LGMAX + threadIdx.x] = 0.0; }
+    for (int ch = 0; ch < h.n_chunks; ++ch) lin_chunk(c, ch, x, invd, line, first, radius, grp, A);
     ImuN N;
-    cost += lin_imu(c, x, N);
-    lin_assemble(c, x, first, radius, grp, A, N, cost, gmax_lm);
+    const double ic = lin_imu(c, x, N);
+    lin_assemble(c, x, first, radius, grp, A, N, c.sh[L_LCOST + threadIdx.x] + ic, c.sh[L_LGMAX + threadIdx.x]);
 }
 
 // ------------------------------------------------------------------ back-substitution + candidate + model terms
