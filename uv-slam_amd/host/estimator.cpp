@@ -20,6 +20,7 @@ void setEurocParameters() {          // config/euroc/euroc_config.yaml
 }
 
 Estimator::Estimator() : solver_flag(NON_LINEAR), marginalization_flag(MARGIN_OLD), td(0), failure_occur(false), last_marginalization_info(nullptr), solver(nullptr) {
+    f_manager.Rs = Rs;      // estimator.cpp:9 `f_manager{Rs}`
     for (auto& p : pre_integrations) p = nullptr;
     for (int i = 0; i <= WINDOW_SIZE; ++i) Rs[i].setIdentity();
     uvs_options o; uvs_default_options(&o);

@@ -1,7 +1,10 @@
 // feature_manager.h -- the part of FeatureManager (vins_estimator/src/feature_manager.{h,cpp}) that Estimator::optimization()
 // and vector2double()/double2vector() touch: the per-id track lists and the get/set of solver parameters.
-// Triangulation / parallax / slide-window bookkeeping (feature_manager.cpp:73-158,427-725) are NOT mirrored.
+// SURVEY.md 8f row 3 (the producers / consumers either side of the solve) is mirrored too: triangulate (:427-481),
+// triangulateLine (:504-589) with calcPluckerLine (:827-902), getDepthVector / getLineOrthonormal (:290-331), setDepth (:235-253),
+// setLineOrtho (:333-423).  Parallax / slide-window bookkeeping (feature_manager.cpp:73-158,591-725) is NOT mirrored (front-end side).
 #pragma once
+#include <cmath>
 #include <list>
 #include <vector>
 #include "parameters.h"
@@ -20,10 +23,115 @@ class LineFeaturePerId {
     LineFeaturePerId(int id, int start) : feature_id(id), start_frame(start), used_num(0), solve_flag(0) {}
 };
 
+// eigenvector of the smallest eigenvalue of a symmetric 4x4 (cyclic Jacobi): the right singular vector the reference takes from
+// JacobiSVD(svd_A, ComputeThinV).matrixV().rightCols<1>() is that eigenvector of svd_A^T svd_A (up to sign, which cancels in v2/v3)
+inline void uvs_smallest_eigvec4(double A[4][4], double v[4]) {
+    double V[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0; for (int p = 0; p < 4; ++p) for (int q = p + 1; q < 4; ++q) off += A[p][q] * A[p][q];
+        if (off < 1e-300) break;
+        for (int p = 0; p < 4; ++p) for (int q = p + 1; q < 4; ++q) {
+            if (A[p][q] == 0.0) continue;
+            const double th = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+            const double t = (th >= 0 ? 1.0 : -1.0) / (std::fabs(th) + std::sqrt(th * th + 1.0)), c = 1.0 / std::sqrt(t * t + 1.0), sn = t * c;
+            for (int k = 0; k < 4; ++k) { const double akp = A[k][p], akq = A[k][q]; A[k][p] = c * akp - sn * akq; A[k][q] = sn * akp + c * akq; }
+            for (int k = 0; k < 4; ++k) { const double apk = A[p][k], aqk = A[q][k]; A[p][k] = c * apk - sn * aqk; A[q][k] = sn * apk + c * aqk; }
+            for (int k = 0; k < 4; ++k) { const double vkp = V[k][p], vkq = V[k][q]; V[k][p] = c * vkp - sn * vkq; V[k][q] = sn * vkp + c * vkq; }
+        }
+    }
+    int m = 0; for (int k = 1; k < 4; ++k) if (A[k][k] < A[m][m]) m = k;
+    for (int k = 0; k < 4; ++k) v[k] = V[k][m];
+}
+
 class FeatureManager {
   public:
     std::list<FeaturePerId> feature;
     std::list<LineFeaturePerId> line_feature;
+    const Eigen::Matrix3d* Rs = nullptr;            // the estimator's Rs[] (feature_manager.h: `const Matrix3d *Rs`, set by the constructor)
+    FeatureManager() {}
+    explicit FeatureManager(Eigen::Matrix3d _Rs[]) : Rs(_Rs) {}
+
+    // feature_manager.cpp:427-481 -- linear (DLT) triangulation of every used point that has no depth yet, in its start frame
+    void triangulate(Eigen::Vector3d Ps[], Eigen::Vector3d tic[], Eigen::Matrix3d ric[]) {
+        using namespace Eigen;
+        for (auto& it : feature) {
+            if (!usedPoint(it)) continue;
+            if (it.estimated_depth > 0) continue;
+            const int imu_i = it.start_frame;
+            const Vector3d t0 = Ps[imu_i] + Rs[imu_i] * tic[0];
+            const Matrix3d R0 = Rs[imu_i] * ric[0];
+            double AtA[4][4] = {{0}};
+            int imu_j = imu_i - 1;
+            for (auto& pf : it.feature_per_frame) {
+                ++imu_j;
+                const Vector3d t1 = Ps[imu_j] + Rs[imu_j] * tic[0];
+                const Matrix3d R1 = Rs[imu_j] * ric[0];
+                const Vector3d t = R0.transpose() * (t1 - t0);
+                const Matrix3d Rt = (R0.transpose() * R1).transpose();      // P = [R^T | -R^T t]
+                const Vector3d mt = -(Rt * t);
+                const double n = pf.point.norm();
+                const Vector3d f = pf.point / n;
+                double P[3][4];
+                for (int r = 0; r < 3; ++r) { for (int cidx = 0; cidx < 3; ++cidx) P[r][cidx] = Rt(r, cidx); P[r][3] = mt(r); }
+                double row[2][4];
+                for (int cidx = 0; cidx < 4; ++cidx) { row[0][cidx] = f[0] * P[2][cidx] - f[2] * P[0][cidx]; row[1][cidx] = f[1] * P[2][cidx] - f[2] * P[1][cidx]; }
+                for (int r = 0; r < 2; ++r) for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) AtA[a][b] += row[r][a] * row[r][b];
+            }
+            double v[4]; uvs_smallest_eigvec4(AtA, v);
+            it.estimated_depth = v[2] / v[3];
+            if (it.estimated_depth < 0.1) it.estimated_depth = INIT_DEPTH;
+        }
+    }
+
+    // feature_manager.cpp:827-902 -- the line through two back-projected planes, as the dual Plucker matrix pi1 pi2^T - pi2 pi1^T:
+    // plane = [sp x ep ; -(sp x ep) . origin]; direction = (L(2,1), L(0,2), L(1,0)) = b x a, normal = (L(0,3), L(1,3), L(2,3)) = a*beta - b*alpha
+    static void calcPluckerLine(const Eigen::Vector3d& prev_sp, const Eigen::Vector3d& prev_ep, const Eigen::Vector3d& curr_sp, const Eigen::Vector3d& curr_ep,
+                                const Eigen::Vector3d& origin_prev, const Eigen::Vector3d& origin_curr, Eigen::Vector3d& out_direction, Eigen::Vector3d& out_normal,
+                                Eigen::Vector4d& prev_plane, Eigen::Vector4d& curr_plane) {
+        const Eigen::Vector3d a = prev_sp.cross(prev_ep), b = curr_sp.cross(curr_ep);
+        const double alpha = -a.dot(origin_prev), beta = -b.dot(origin_curr);
+        prev_plane = Eigen::Vector4d(a(0), a(1), a(2), alpha); curr_plane = Eigen::Vector4d(b(0), b(1), b(2), beta);
+        out_direction = b.cross(a);
+        out_normal = a * beta - b * alpha;
+    }
+
+    // Eigen 3.3 Matrix3d::eulerAngles(0, 1, 2) (the branch the reference gets at feature_manager.cpp:584): R = Rx(a) Ry(b) Rz(c), a in [0, pi]
+    static Eigen::Vector3d eulerAnglesXYZ(const Eigen::Matrix3d& m) {
+        const double pi = 3.14159265358979323846;
+        double r0 = std::atan2(m(1, 2), m(2, 2)), r1;
+        const double c2 = std::sqrt(m(0, 0) * m(0, 0) + m(0, 1) * m(0, 1));
+        if (r0 > 0.0) { r0 -= pi; r1 = std::atan2(-m(0, 2), -c2); } else r1 = std::atan2(-m(0, 2), c2);
+        const double s1 = std::sin(r0), c1 = std::cos(r0);
+        const double r2 = std::atan2(s1 * m(2, 0) - c1 * m(1, 0), c1 * m(1, 1) - s1 * m(2, 1));
+        return Eigen::Vector3d(-r0, -r1, -r2);
+    }
+
+    // feature_manager.cpp:504-589 -- two-view line triangulation (first and last observation) of every line without parameters yet
+    // (orthonormal_vec[3] == 0).  The reference's cv::Mat argument only feeds a debug drawing and is dropped.
+    void triangulateLine(Eigen::Vector3d Ps[], Eigen::Matrix3d /*Rs_estimate*/[], Eigen::Vector3d tic[], Eigen::Matrix3d ric[]) {
+        using namespace Eigen;
+        for (auto& it : line_feature) {
+            it.used_num = (int)it.line_feature_per_frame.size();
+            if (it.orthonormal_vec[3] != 0 || it.line_feature_per_frame.size() < 2) continue;
+            const int imu_i = it.start_frame, imu_j = it.start_frame + it.used_num - 1;
+            const Matrix3d R_left = Rs[imu_i] * ric[0], R_right = Rs[imu_j] * ric[0];
+            const Vector3d t_left = Rs[imu_i] * tic[0] + Ps[imu_i], t_right = Rs[imu_j] * tic[0] + Ps[imu_j];
+            const Matrix3d R_rel = R_left.transpose() * R_right;
+            const Vector3d t_rel = R_left.transpose() * (t_right - t_left);
+            const Vector3d left_sp = it.line_feature_per_frame[0].start_point, left_ep = it.line_feature_per_frame[0].end_point;
+            const Vector3d right_sp_l = R_rel * it.line_feature_per_frame[it.used_num - 1].start_point, right_ep_l = R_rel * it.line_feature_per_frame[it.used_num - 1].end_point;
+            Vector3d direction_l, normal_l; Vector4d left_plane, right_plane;
+            calcPluckerLine(left_sp, left_ep, right_sp_l, right_ep_l, Vector3d(0, 0, 0), t_rel, direction_l, normal_l, left_plane, right_plane);
+            // line_w = T_wl line_l with T_wl = [R [t]x R ; 0 R]
+            const Vector3d d_w = R_left * direction_l;
+            const Vector3d n_w = R_left * normal_l + t_left.cross(d_w);
+            const Vector3d u0 = n_w / n_w.norm(), u1 = d_w / d_w.norm(), nxd = n_w.cross(d_w), u2 = nxd / nxd.norm();
+            Matrix3d U;
+            for (int r = 0; r < 3; ++r) { U(r, 0) = u0(r); U(r, 1) = u1(r); U(r, 2) = u2(r); }
+            const Vector3d psi = eulerAnglesXYZ(U);
+            it.orthonormal_vec = Vector4d(psi(0), psi(1), psi(2), std::atan2(d_w.norm(), n_w.norm()));
+        }
+    }
     static bool usedPoint(FeaturePerId& it) { it.used_num = (int)it.feature_per_frame.size(); return it.used_num >= 2 && it.start_frame < WINDOW_SIZE - 2; }   // estimator.cpp:826
     static bool usedLine(LineFeaturePerId& it) { it.used_num = (int)it.line_feature_per_frame.size(); return it.used_num >= LINE_WINDOW; }                    // estimator.cpp:873
     int getFeatureCount() { int c = 0; for (auto& it : feature) c += usedPoint(it); return c; }

@@ -94,3 +94,42 @@ extern "C" int uvs_host_window_probe(const char* path, double* out /*[12]*/) {
     s = 0; for (int k = 0; k < w.n_point_obs; ++k) s += w.pt_lm[k] + 3 * w.pt_fi[k] + 7 * w.pt_fj[k]; out[11] = s;
     return 0;
 }
+
+// CPU-only hook for the FeatureManager producers: triangulate() / triangulateLine() on flat arrays.
+//   poses[11][7] = (p, q xyzw) ; ex[7] ; point tracks: pt_start[n_pt], pt_nobs[n_pt], pt_obs (concatenated normalized-plane xyz) ;
+//   line tracks: ln_start[n_ln], ln_nobs[n_ln], ln_sp / ln_ep (concatenated xyz).  depth_io[n_pt]: <= 0 means "not triangulated yet";
+//   orth_io[n_ln][4]: orth[3] == 0 means "no parameters yet".  Both are updated in place exactly as the members would be.
+extern "C" int uvs_host_triangulate(const double* poses, const double* ex, int n_pt, const int* pt_start, const int* pt_nobs, const double* pt_obs,
+                                    int n_ln, const int* ln_start, const int* ln_nobs, const double* ln_sp, const double* ln_ep,
+                                    double* depth_io, double* orth_io) {
+    setEurocParameters();
+    Eigen::Vector3d Ps[WINDOW_SIZE + 1]; Eigen::Matrix3d Rs[WINDOW_SIZE + 1];
+    for (int i = 0; i <= WINDOW_SIZE; ++i) {
+        Ps[i] = Eigen::Vector3d(poses[7 * i], poses[7 * i + 1], poses[7 * i + 2]);
+        Rs[i] = Eigen::Quaterniond(poses[7 * i + 6], poses[7 * i + 3], poses[7 * i + 4], poses[7 * i + 5]).toRotationMatrix();
+    }
+    Eigen::Vector3d tic[1] = {Eigen::Vector3d(ex[0], ex[1], ex[2])};
+    Eigen::Matrix3d ric[1] = {Eigen::Quaterniond(ex[6], ex[3], ex[4], ex[5]).toRotationMatrix()};
+    FeatureManager fm(Rs);
+    for (int k = 0, o = 0; k < n_pt; ++k) {
+        FeaturePerId f(k, pt_start[k]);
+        for (int q = 0; q < pt_nobs[k]; ++q, ++o) f.feature_per_frame.emplace_back(Eigen::Vector3d(pt_obs[3 * o], pt_obs[3 * o + 1], pt_obs[3 * o + 2]));
+        f.estimated_depth = depth_io[k];
+        fm.feature.push_back(f);
+    }
+    for (int l = 0, o = 0; l < n_ln; ++l) {
+        LineFeaturePerId f(l, ln_start[l]);
+        for (int q = 0; q < ln_nobs[l]; ++q, ++o) {
+            LineFeaturePerFrame pf;
+            pf.start_point = Eigen::Vector3d(ln_sp[3 * o], ln_sp[3 * o + 1], ln_sp[3 * o + 2]); pf.end_point = Eigen::Vector3d(ln_ep[3 * o], ln_ep[3 * o + 1], ln_ep[3 * o + 2]);
+            f.line_feature_per_frame.push_back(pf);
+        }
+        f.orthonormal_vec = Eigen::Vector4d(orth_io[4 * l], orth_io[4 * l + 1], orth_io[4 * l + 2], orth_io[4 * l + 3]);
+        fm.line_feature.push_back(f);
+    }
+    fm.triangulate(Ps, tic, ric);
+    fm.triangulateLine(Ps, Rs, tic, ric);
+    int k = 0; for (auto& it : fm.feature) depth_io[k++] = it.estimated_depth;
+    int l = 0; for (auto& it : fm.line_feature) { for (int q = 0; q < 4; ++q) orth_io[4 * l + q] = it.orthonormal_vec[q]; ++l; }
+    return 0;
+}
