@@ -44,11 +44,11 @@ struct DevWin {
     int32_t d_line;                   // [n_lines][4]
     int32_t d_lnmeas;                 // 9 x ln_stride : sp xyz, ep xyz, vp xyz
     int32_t d_imu;                    // n_imu x UVS_IMU_STRIDE
-    int32_t d_prior;                  // J0[n*n] H0[n*n] r0[n] b0[n] x0[144]
+    int32_t d_prior;                  // J0[n*n] J0^T[n*n] r0[n] b0[n] x0[144]
     int32_t i_pt_lm, i_pt_fi, i_pt_fj, i_pt_beg;      // obs arrays + CSR begin[n_points+1]
     int32_t i_ln_lm, i_ln_fj, i_ln_vp, i_ln_beg;      // obs arrays + CSR begin[n_lines+1]
     int32_t i_imu;                    // [n_imu][2] : frame_i, skip
-    int32_t i_prior;                  // kind[16] frame[16] size[16] idx[16] x0off[16] colmap[96]
+    int32_t i_prior;                  // kind[16] frame[16] size[16] idx[16] x0off[16] colmap[96] inverse colmap[176] touched S blocks[66]
     int32_t i_chunks;                 // [n_chunks][6] : type(0 pt,1 ln), lm_begin, lm_end, offset of the chunk's gather lists in i_lists, their length, 0
     int32_t i_wblk;                   // [UVS_NGRP] gather group -> pose block id | 256 (diagonal block) | part << 9 (4 bits, split blocks) | fa << 13 | fb << 17; -1 = idle
     int32_t i_lists;                  // per chunk: schur_off[81] direct_off[81] entries[...]  (group-major, see pack_window in uvs_solver.hip)
@@ -59,6 +59,8 @@ struct DevWin {
     int32_t w_ln_Y, w_ln_x;           // Y store 24*n_ln_obs ; per line {Hinv*g[4], g[4], dd[4]}
     int32_t w_imu;                    // per block: Jraw[450] Jw[450] rraw[15] rw[15] (pad 936)
     int32_t w_out;                    // final state: frames[184] (landmarks are read from the cur buffers)
+    int32_t w_prior_img;              // J0^T J0 scattered into S block layout: n_pblk x 272 doubles (written by setup_window, added per linearization)
+    int32_t n_pblk;                   // pose blocks of S the prior touches (ids in i_prior + 352)
     int32_t ws_doubles;
     int32_t blob_bytes;
     int32_t cur_sel;                  // written by the kernel: which landmark buffer holds the final state

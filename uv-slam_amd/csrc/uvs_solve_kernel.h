@@ -163,9 +163,18 @@ UVS_DEV double prior_residual(const Ctx& c) {   // after prior_dx + barrier; fil
     const int n = h.prior_n, tid = threadIdx.x;
     double cost = 0.0;
     if (tid < n) {
-        const double* J0 = c.bd + h.d_prior;
+        const double* J0T = c.bd + h.d_prior + n * n;      // transposed copy: consecutive lanes read consecutive addresses
         double s = c.bd[h.d_prior + 2 * n * n + tid];
-        for (int k = 0; k < n; ++k) s += J0[tid * n + k] * c.sh[L_PDX + k];   // marginalization_factor.cpp:364
+        {   // marginalization_factor.cpp:364; 8 independent partial sums keep 8 HBM/L2 loads in flight (a dependent chain pays the full latency 75 times)
+            double p8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            int k = 0;
+            for (; k + 8 <= n; k += 8) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) p8[u] += J0T[(k + u) * n + tid] * c.sh[L_PDX + k + u];
+            }
+            for (; k < n; ++k) p8[0] += J0T[k * n + tid] * c.sh[L_PDX + k];
+            s += ((p8[0] + p8[1]) + (p8[2] + p8[3])) + ((p8[4] + p8[5]) + (p8[6] + p8[7]));
+        }
         c.sh[L_PR + tid] = s;
         cost = 0.5 * s * s;
     }
@@ -967,31 +976,36 @@ UVS_DEV void lin_assemble(const Ctx& c, const double* x, bool first, double radi
     if (h.prior_n > 0) {
         const int n = h.prior_n;
         const int* cm = c.bi + h.i_prior + 80;
-        const double* J0 = c.bd + h.d_prior; const double* H0 = J0 + n * n;
-        for (int t0 = tid; t0 < n * n; t0 += 4 * NT) {      // 4 entries per trip: global loads, then LDS reads, then LDS writes
-            int idx[4], ihd[4]; double v[4], cur[4];
+        const double* J0 = c.bd + h.d_prior;
+        {   // H0 image (setup_window): values + precomputed S offsets, 8 independent loads in flight per trip
+            const double* img = c.ws + h.w_prior_img;
+            const int tot = h.n_pblk * UVS_BLK_SZ;
+            const int* off = (const int*)(img + tot);
+            for (int t0 = tid; t0 < tot; t0 += 8 * NT) {
+                int idx[8]; double v[8], cur[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int t = t0 + u * NT;
-                const bool in = t < n * n;
-                const int a = in ? t / n : 0, cc = in ? t - a * n : 0;
-                const int ia = cm[a], ic = cm[cc];
-                const bool ok = in && cc <= a && ia >= 0 && ic >= 0;
-                idx[u] = ok ? (ia >= ic ? sidx(ia, ic) : sidx(ic, ia)) : -1;
-                ihd[u] = (ok && a == cc) ? ia : -1;
-                v[u] = ok ? H0[a * n + cc] : 0.0;
+                for (int u = 0; u < 8; ++u) { const int t = t0 + u * NT; const bool in = t < tot; idx[u] = in ? off[t] : -1; v[u] = in ? img[t] : 0.0; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) cur[u] = sh[L_S + (idx[u] >= 0 ? idx[u] : 0)];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) if (idx[u] >= 0) sh[L_S + idx[u]] = cur[u] + v[u];
             }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) cur[u] = sh[L_S + (idx[u] >= 0 ? idx[u] : 0)];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) if (idx[u] >= 0) sh[L_S + idx[u]] = cur[u] + v[u];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) if (ihd[u] >= 0) sh[L_HD + ihd[u]] += v[u];
+            // diag(J0^T J0) -> HD: read back from the touched diagonal blocks' prior share is not separable any more, so use the image
+            const int* pb = c.bi + h.i_prior + 80 + UVS_MAX_PRIOR_DIM + UVS_RD;
+            for (int t = tid; t < h.n_pblk * 16; t += NT) {
+                const int sl = t >> 4, r = t & 15, b = pb[sl];
+                if (c_blk_fa[b] == c_blk_fb[b]) sh[L_HD + 16 * c_blk_fa[b] + r] += img[sl * UVS_BLK_SZ + r * UVS_BLK_LD + r];
+            }
         }
         if (tid < n && cm[tid] >= 0) {
-            double s = 0.0;
-            for (int i = 0; i < n; ++i) s += J0[i * n + tid] * sh[L_PR + i];
-            sh[L_G + cm[tid]] += s;
+            double p8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            int i = 0;
+            for (; i + 8 <= n; i += 8) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) p8[u] += J0[(i + u) * n + tid] * sh[L_PR + i + u];
+            }
+            for (; i < n; ++i) p8[0] += J0[i * n + tid] * sh[L_PR + i];
+            sh[L_G + cm[tid]] += ((p8[0] + p8[1]) + (p8[2] + p8[3])) + ((p8[4] + p8[5]) + (p8[6] + p8[7]));
         }
     }
     __syncthreads();
@@ -1195,13 +1209,26 @@ UVS_DEV void setup_window(const Ctx& c, double* blob_rw) {
         imu_whiten_block(blk + UVS_IMU_COV, blk + UVS_IMU_W, c.sh + L_S + 256 * wv, lane);
     }
     if (h.prior_n > 0) {
+        // prior normal matrix J0^T J0, computed ONCE per solve straight into S's block layout ("image" of the touched pose blocks in the
+        // workspace): every image entry is owned by one thread (no read-modify-write), J0 is staged in LDS first (coalesced)
         const int n = h.prior_n;
-        const double* J0 = blob_rw + h.d_prior; double* H0 = blob_rw + h.d_prior + n * n;
-        for (int t = tid; t < n * n; t += NT) {
-            const int a = t / n, cc = t - a * n;
-            double s = 0.0;
-            for (int i = 0; i < n; ++i) s += J0[i * n + a] * J0[i * n + cc];
-            H0[t] = s;
+        const double* J0 = blob_rw + h.d_prior;
+        double* Jl = c.sh + L_S + 2048;                      // [n][n], beside the whitening scratch
+        const int* inv = c.bi + h.i_prior + 80 + UVS_MAX_PRIOR_DIM;
+        const int* pb = inv + UVS_RD;
+        for (int t = tid; t < n * n; t += NT) Jl[t] = J0[t];
+        __syncthreads();
+        double* img = c.ws + h.w_prior_img;
+        for (int t = tid; t < h.n_pblk * UVS_BLK_SZ; t += NT) {
+            const int sl = t / UVS_BLK_SZ, e = t - sl * UVS_BLK_SZ, r = e / UVS_BLK_LD, cc = e - r * UVS_BLK_LD;
+            const int b = pb[sl], fa = c_blk_fa[b], fb = c_blk_fb[b];
+            double v = 0.0;
+            if (cc < 16) {
+                const int a = inv[16 * fa + r], a2 = inv[16 * fb + cc];
+                if (a >= 0 && a2 >= 0) for (int i = 0; i < n; ++i) v += Jl[i * n + a] * Jl[i * n + a2];
+            }
+            img[t] = v;
+            ((int*)(img + h.n_pblk * UVS_BLK_SZ))[t] = b * UVS_BLK_SZ + e;      // where the entry goes in S: the per-linearization add needs no index math
         }
     }
 }

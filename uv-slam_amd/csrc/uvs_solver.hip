@@ -362,7 +362,7 @@ static int pack_window(const uvs_window* w, std::vector<char>& out, DevWin& hdr,
     h.i_pt_lm = i; i += h.pt_stride; h.i_pt_fi = i; i += h.pt_stride; h.i_pt_fj = i; i += h.pt_stride; h.i_pt_beg = i; i += rup(h.n_points + 1, 2);
     h.i_ln_lm = i; i += h.ln_stride; h.i_ln_fj = i; i += h.ln_stride; h.i_ln_vp = i; i += h.ln_stride; h.i_ln_beg = i; i += rup(h.n_lines + 1, 2);
     h.i_imu = i; i += 2 * std::max(h.n_imu, 1);
-    h.i_prior = i; i += 80 + UVS_MAX_PRIOR_DIM;
+    h.i_prior = i; i += 80 + UVS_MAX_PRIOR_DIM + UVS_RD + UVS_NBLK;
     h.i_chunks = i; i += 6 * std::max(h.n_chunks, 1);
     h.i_wblk = i; i += UVS_NGRP;
     h.i_lists = i; i += (int)lists.size() + 2;
@@ -376,6 +376,16 @@ static int pack_window(const uvs_window* w, std::vector<char>& out, DevWin& hdr,
     h.w_ln_Y = wsz; wsz += 24 * std::max(h.n_ln_obs, 1); h.w_ln_x = wsz; wsz += 12 * std::max(h.n_lines, 1);
     h.w_imu = wsz; wsz += std::max(h.n_imu, 1) * UVS_WIMU_STRIDE;
     h.w_out = wsz; wsz += 184;
+    // S blocks touched by the prior (all pairs of frames that own a kept pose / speed-bias block)
+    std::vector<int> pblk;
+    if (have_prior) {
+        bool in[UVS_NUM_FRAMES] = {false};
+        for (int b = 0; b < w->prior->n_blocks; ++b)
+            if (w->prior->block_kind[b] == UVS_BLOCK_POSE || w->prior->block_kind[b] == UVS_BLOCK_SPEEDBIAS) in[w->prior->block_frame[b]] = true;
+        for (int fa = 0; fa < UVS_NUM_FRAMES; ++fa) for (int fb = 0; fb <= fa; ++fb) if (in[fa] && in[fb]) pblk.push_back(fa * (fa + 1) / 2 + fb);
+    }
+    h.n_pblk = (int)pblk.size();
+    h.w_prior_img = wsz; wsz += std::max(h.n_pblk, 1) * UVS_BLK_SZ * 3 / 2 + 2;      // values, then their int32 S offsets
     h.ws_doubles = rup(wsz, 32);
     // fill
     const size_t base = out.size();
@@ -414,11 +424,11 @@ static int pack_window(const uvs_window* w, std::vector<char>& out, DevWin& hdr,
     if (have_prior) {
         const uvs_prior& p = *w->prior;
         const int n = p.n;
-        for (int r = 0; r < n; ++r) for (int cc = 0; cc < n; ++cc) D[h.d_prior + r * n + cc] = p.linearized_jacobians[r * n + cc];
+        for (int r = 0; r < n; ++r) for (int cc = 0; cc < n; ++cc) { D[h.d_prior + r * n + cc] = p.linearized_jacobians[r * n + cc]; D[h.d_prior + n * n + cc * n + r] = p.linearized_jacobians[r * n + cc]; }
         for (int r = 0; r < n; ++r) D[h.d_prior + 2 * n * n + r] = p.linearized_residuals[r];
         std::memcpy(D + h.d_prior + 2 * n * n + 2 * n, p.x0, sizeof(double) * 144);
         int* pt = I + h.i_prior;
-        for (int q = 0; q < 80 + UVS_MAX_PRIOR_DIM; ++q) pt[q] = -1;
+        for (int q = 0; q < 80 + UVS_MAX_PRIOR_DIM + UVS_RD + UVS_NBLK; ++q) pt[q] = -1;
         for (int b = 0; b < p.n_blocks; ++b) {
             pt[b] = p.block_kind[b]; pt[16 + b] = p.block_frame[b]; pt[32 + b] = p.block_size[b]; pt[48 + b] = p.block_idx[b]; pt[64 + b] = p.x0_off[b];
             const int loc = p.block_size[b] == 7 ? 6 : p.block_size[b];
@@ -427,7 +437,9 @@ static int pack_window(const uvs_window* w, std::vector<char>& out, DevWin& hdr,
             else if (p.block_kind[b] == UVS_BLOCK_SPEEDBIAS) basecol = 16 * p.block_frame[b] + 6;
             // Ex_Pose is constant (ESTIMATE_EXTRINSIC == 0): its columns are dropped
             for (int q = 0; q < loc; ++q) pt[80 + p.block_idx[b] + q] = basecol < 0 ? -1 : basecol + q;
+            if (basecol >= 0) for (int q = 0; q < loc; ++q) pt[80 + UVS_MAX_PRIOR_DIM + basecol + q] = p.block_idx[b] + q;      // S index -> prior column
         }
+        for (size_t q = 0; q < pblk.size(); ++q) pt[80 + UVS_MAX_PRIOR_DIM + UVS_RD + q] = pblk[q];
     }
     for (size_t q = 0; q < chunks.size(); ++q) I[h.i_chunks + q] = chunks[q];
     for (size_t q = 0; q < lists.size(); ++q) I[h.i_lists + q] = lists[q];
