@@ -80,10 +80,10 @@ def _device_tensor(ptr, n, device=None):
 class Solver:
     """Owns one `uvs_solver` handle (device buffers + stream) on one GPU."""
 
-    def __init__(self, opts=None, device=0, max_batch=1024):
+    def __init__(self, opts=None, device=0, max_batch=1024, max_points=1000, max_point_obs=16000, max_lines=1000, max_line_obs=16000):
         self.opts = opts or abi.default_options()
         self._h = C.c_void_p()
-        rc = lib().uvs_create(C.byref(self.opts), device, max_batch, 1000, 16000, 1000, 16000, C.byref(self._h))
+        rc = lib().uvs_create(C.byref(self.opts), device, max_batch, max_points, max_point_obs, max_lines, max_line_obs, C.byref(self._h))
         if rc != abi.UVS_OK:
             raise RuntimeError(f"uvs_create failed: {lib().uvs_status_string(rc).decode()} (rc={rc}); the HIP path is the only path")
         self._keep = None

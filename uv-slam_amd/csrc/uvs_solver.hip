@@ -29,6 +29,7 @@ struct uvs_solver {
     uvs_options opts;
     int device;
     int max_batch;
+    int max_points = 0, max_point_obs = 0, max_lines = 0, max_line_obs = 0;      // per-window capacities promised at uvs_create
     hipStream_t stream;
     hipEvent_t ev0, ev1;
     std::string err;
@@ -111,9 +112,9 @@ const char* uvs_last_error(const uvs_solver* s) { return s ? s->err.c_str() : "n
 
 int uvs_reduced_dim(const uvs_options* o) { return 15 * UVS_NUM_FRAMES + ((o && o->estimate_extrinsic) ? 6 : 0); }
 
-int uvs_create(const uvs_options* opts, int device, int max_batch, int /*max_points*/, int /*max_point_obs*/, int /*max_lines*/,
-               int /*max_line_obs*/, uvs_solver** out) {
-    if (!opts || !out || max_batch < 1) return UVS_ERR_INVALID_ARG;
+int uvs_create(const uvs_options* opts, int device, int max_batch, int max_points, int max_point_obs, int max_lines,
+               int max_line_obs, uvs_solver** out) {
+    if (!opts || !out || max_batch < 1 || max_points < 0 || max_point_obs < 0 || max_lines < 0 || max_line_obs < 0) return UVS_ERR_INVALID_ARG;
     if (opts->estimate_td || opts->estimate_extrinsic) return UVS_ERR_UNSUPPORTED;
     if (opts->max_num_iterations < 0) return UVS_ERR_INVALID_ARG;
     int ndev = 0;
@@ -121,6 +122,7 @@ int uvs_create(const uvs_options* opts, int device, int max_batch, int /*max_poi
     if (hipSetDevice(device) != hipSuccess) return UVS_ERR_NO_DEVICE;
     uvs_solver* s = new uvs_solver();
     s->opts = *opts; s->device = device; s->max_batch = max_batch;
+    s->max_points = max_points; s->max_point_obs = max_point_obs; s->max_lines = max_lines; s->max_line_obs = max_line_obs;
     if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess) { delete s; return UVS_ERR_HIP; }
     // block table for the output-stationary gather
     unsigned char fa[UVS_NBLK], fb[UVS_NBLK];
@@ -466,6 +468,9 @@ int uvs_batch_upload(uvs_solver* s, int n, const uvs_window* const* ws) {
     s->host_blobs.clear(); s->hdrs.resize(n); s->blob_off.resize(n); s->ws_off.resize(n);
     long long wtot = 0;
     for (int b = 0; b < n; ++b) {
+        if (ws[b] && (ws[b]->n_points > s->max_points || ws[b]->n_point_obs > s->max_point_obs || ws[b]->n_lines > s->max_lines || ws[b]->n_line_obs > s->max_line_obs)) {
+            s->err = "window exceeds the capacity given to uvs_create (max_points / max_point_obs / max_lines / max_line_obs)"; s->n_loaded = 0; return UVS_ERR_CAPACITY;
+        }
         s->blob_off[b] = (long long)s->host_blobs.size();
         int rc = pack_window(ws[b], s->host_blobs, s->hdrs[b], s->err);
         if (rc != UVS_OK) { s->n_loaded = 0; return rc; }
