@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define UVS_ABI_VERSION 1
+#define UVS_ABI_VERSION 2
 
 #define UVS_WINDOW_SIZE 10                    /* parameters.h:12 WINDOW_SIZE  */
 #define UVS_NUM_FRAMES (UVS_WINDOW_SIZE + 1)  /* frames 0..WINDOW_SIZE        */
@@ -44,7 +44,7 @@ extern "C" {
 enum {
     UVS_OK = 0,
     UVS_ERR_INVALID_ARG = 1,    /* null pointer / index out of range / bad count */
-    UVS_ERR_UNSUPPORTED = 2,    /* estimate_td / relocalization blocks: not on this path yet */
+    UVS_ERR_UNSUPPORTED = 2,    /* estimate_extrinsic / relocalization blocks: not on this path yet */
     UVS_ERR_NO_DEVICE = 3,      /* no HIP device / extension cannot run (never falls back to CPU) */
     UVS_ERR_HIP = 4,            /* a HIP runtime call failed; see uvs_last_error() */
     UVS_ERR_CAPACITY = 5,       /* window larger than the handle was created for */
@@ -69,7 +69,7 @@ enum {
 typedef struct uvs_options {
     int32_t max_num_iterations;        /* NUM_ITERATIONS, euroc_config.yaml:56 (10)        */
     int32_t estimate_extrinsic;        /* ESTIMATE_EXTRINSIC (0): Ex_Pose constant         */
-    int32_t estimate_td;               /* ESTIMATE_TD (0); 1 -> UVS_ERR_UNSUPPORTED        */
+    int32_t estimate_td;               /* ESTIMATE_TD (0); 1: ProjectionTdFactor + para_Td (estimator.cpp:790-797,853-858) */
     int32_t function_tol_keeps_candidate; /* 0 = Ceres order: tolerance checks before accept (App. B.4) */
     double focal_length;               /* FOCAL_LENGTH = fx, parameters.cpp:60 (461.6)     */
     double point_sqrt_info;            /* FOCAL_LENGTH/1.6, estimator.cpp:17               */
@@ -176,6 +176,15 @@ typedef struct uvs_window {
 
     /* marginalization prior (estimator.cpp:803-809); may be NULL / n==0 */
     const uvs_prior *prior;
+
+    /* ProjectionTdFactor inputs (projection_td_factor.cpp:3-16,51-52), read only when options.estimate_td != 0, else may be NULL:
+     * image-plane feature velocities of the anchor / current observation and their time offsets.  The rolling-shutter term is
+     * folded in by the caller: pt_td_i = cur_td_i - TR / ROW * (row_i - ROW / 2), so that
+     *   pts_i_td = pts_i - (td - pt_td_i) * (vel_i, 0)          (same for j). */
+    const double *pt_vel_i;            /* [n_point_obs][2] */
+    const double *pt_vel_j;            /* [n_point_obs][2] */
+    const double *pt_td_i;             /* [n_point_obs]    */
+    const double *pt_td_j;             /* [n_point_obs]    */
 } uvs_window;
 
 /* Solver output == the para_* arrays after ceres::Solve and BEFORE
@@ -231,6 +240,7 @@ typedef struct uvs_eval {
     double *imu_J;     /* [n_imu][15*30]     */
     double *prior_r;   /* [prior n]          */
     double cost;       /* out */
+    double *pt_Jtd;    /* [n_point_obs][2] d r / d td of ProjectionTdFactor (only with estimate_td; may be NULL) */
 } uvs_eval;
 
 typedef struct uvs_solver uvs_solver;  /* opaque: device buffers, stream, workspaces */

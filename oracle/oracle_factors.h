@@ -116,6 +116,36 @@ inline void point_eval(const double* pose_i, const double* pose_j, const double*
         J[i * 19 + c] = reduce[i][0] * jac[0][c] + reduce[i][1] * jac[1][c] + reduce[i][2] * jac[2][c];
 }
 
+// ProjectionTdFactor::Evaluate, projection_td_factor.cpp:34-145: the a5 projection of the TIME-SHIFTED observations
+//   pts_i_td = pts_i - (td - td_i) * (vel_i, 0),  pts_j_td = pts_j - (td - td_j) * (vel_j, 0)            (:51-52; the rolling-shutter term
+// TR / ROW * row is folded into td_i / td_j by the caller, include/uvs_solver.h) plus a fifth 1-dof block td (:135-140):
+//   d r / d td = reduce * ric^T Rj^T Ri ric * vel_i * (-1 / inv_dep) + sqrt_info * vel_j.xy.
+// J is 2 x 20 row-major: the 19 columns of point_eval at the shifted observations, then the td column.
+inline void point_td_eval(const double* pose_i, const double* pose_j, const double* ex, double inv_dep, const double* pi3, const double* pj3,
+                          const double* vel_i2, const double* vel_j2, double td_i, double td_j, double td, double sqrt_info, double* r, double* J) {
+    const double pi_td[3] = {pi3[0] - (td - td_i) * vel_i2[0], pi3[1] - (td - td_i) * vel_i2[1], pi3[2]};
+    const double pj_td[3] = {pj3[0] - (td - td_j) * vel_j2[0], pj3[1] - (td - td_j) * vel_j2[1], pj3[2]};
+    double J19[38];
+    point_eval(pose_i, pose_j, ex, inv_dep, pi_td, pj_td, sqrt_info, r, J ? J19 : nullptr);
+    if (!J) return;
+    for (int i = 0; i < 2; ++i) for (int c = 0; c < 19; ++c) J[i * 20 + c] = J19[i * 19 + c];
+    // column 18 of point_eval is reduce * tmp_r * pts_i_td * (-1 / inv_dep^2) with tmp_r = ric^T Rj^T Ri ric (:166 / td :131); the td column needs
+    // reduce * tmp_r * vel_i * (-1 / inv_dep): same linear map applied to (vel_i, 0), so evaluate it with a unit-depth trick:
+    //   reduce * tmp_r * v = -inv_dep^2 * (column 18 of a point_eval whose pts_i is v)   -- but reduce depends on pts_i, so compute it directly.
+    Qd Qi = quat_xyzw(pose_i + 3), Qj = quat_xyzw(pose_j + 3), qic = quat_xyzw(ex + 3);
+    V3d Pi = v3(pose_i), Pj = v3(pose_j), tic = v3(ex);
+    V3d pts_camera_i = {pi_td[0] / inv_dep, pi_td[1] / inv_dep, pi_td[2] / inv_dep};
+    V3d pts_camera_j = qrot(qinv(qic), qrot(qinv(Qj), qrot(Qi, qrot(qic, pts_camera_i) + tic) + Pi - Pj) - tic);
+    const double dep_j = pts_camera_j.z;
+    const double reduce[2][3] = {{sqrt_info / dep_j, 0.0, -sqrt_info * pts_camera_j.x / (dep_j * dep_j)},
+                                 {0.0, sqrt_info / dep_j, -sqrt_info * pts_camera_j.y / (dep_j * dep_j)}};
+    M3d tmp_r = mul(mul(mul(transpose(qmat(qic)), transpose(qmat(Qj))), qmat(Qi)), qmat(qic));
+    V3d vi = {vel_i2[0], vel_i2[1], 0.0};
+    V3d tv = mul(tmp_r, vi);
+    for (int i = 0; i < 2; ++i)
+        J[i * 20 + 19] = (reduce[i][0] * tv.x + reduce[i][1] * tv.y + reduce[i][2] * tv.z) * (-1.0 / inv_dep) + sqrt_info * vel_j2[i];
+}
+
 // ---- shared front part of a7/a8 (line_projection_factor.h:21-54, vp_projection_factor.h:24-57)
 template <typename T>
 inline void line_to_camera(const T* pose, const T* line, const M3d& ric_d, const V3d& tic_d, V3<T>* n_c, V3<T>* d_c) {

@@ -37,6 +37,7 @@ struct State {
     double pose[UVS_NUM_FRAMES][7];
     double sb[UVS_NUM_FRAMES][9];
     double ex[7];
+    double td;
     std::vector<double> invd, line;
 };
 
@@ -44,11 +45,12 @@ struct Problem {
     const uvs_options* opt;
     const uvs_window* w;
     int F, Np, Nl, P;
-    bool ex_free;
+    bool ex_free, td_free;
     std::vector<double> W;    // n_imu x 225 sqrt_info
     int off_pose(int f) const { return 15 * f; }
     int off_sb(int f) const { return 15 * f + 6; }
     int off_ex() const { return 15 * UVS_NUM_FRAMES; }
+    int off_td() const { return 15 * UVS_NUM_FRAMES + (ex_free ? 6 : 0); }      // para_Td, 1 dof (estimator.cpp:790-797)
     int off_pt(int k) const { return F + k; }
     int off_ln(int l) const { return F + Np + 4 * l; }
 };
@@ -56,7 +58,8 @@ struct Problem {
 static void init_problem(Problem& pb, const uvs_options* opt, const uvs_window* w) {
     pb.opt = opt; pb.w = w;
     pb.ex_free = opt->estimate_extrinsic != 0;
-    pb.F = 15 * UVS_NUM_FRAMES + (pb.ex_free ? 6 : 0);
+    pb.td_free = opt->estimate_td != 0;
+    pb.F = 15 * UVS_NUM_FRAMES + (pb.ex_free ? 6 : 0) + (pb.td_free ? 1 : 0);
     pb.Np = w->n_points; pb.Nl = w->n_lines;
     pb.P = pb.F + pb.Np + 4 * pb.Nl;
     pb.W.assign((size_t)std::max(w->n_imu, 0) * 225, 0.0);
@@ -67,6 +70,7 @@ static void init_state(State& x, const uvs_window* w) {
     std::memcpy(x.pose, w->pose, sizeof(x.pose));
     std::memcpy(x.sb, w->speedbias, sizeof(x.sb));
     std::memcpy(x.ex, w->ex_pose, sizeof(x.ex));
+    x.td = w->td;
     x.invd.assign(w->inv_depth, w->inv_depth + w->n_points);
     x.line.assign(w->line_orth, w->line_orth + 4 * (size_t)w->n_lines);
 }
@@ -84,7 +88,7 @@ static double evaluate(const Problem& pb, const State& x, bool robust, std::vect
         std::vector<double> dx(n), r(n);
         auto get = [&](int kind, int frame) -> const double* {
             switch (kind) { case UVS_BLOCK_POSE: return x.pose[frame]; case UVS_BLOCK_SPEEDBIAS: return x.sb[frame];
-                            case UVS_BLOCK_EX_POSE: return x.ex; default: return &w->td; } };
+                            case UVS_BLOCK_EX_POSE: return x.ex; default: return &x.td; } };
         prior_eval(p, get, dx.data(), r.data());
         double s = 0.0; for (int i = 0; i < n; ++i) s += r[i] * r[i];
         cost += 0.5 * s;
@@ -97,6 +101,7 @@ static double evaluate(const Problem& pb, const State& x, bool robust, std::vect
                 if (p.block_kind[b] == UVS_BLOCK_POSE) base = pb.off_pose(p.block_frame[b]);
                 else if (p.block_kind[b] == UVS_BLOCK_SPEEDBIAS) base = pb.off_sb(p.block_frame[b]);
                 else if (p.block_kind[b] == UVS_BLOCK_EX_POSE) base = pb.ex_free ? pb.off_ex() : -1;   // constant block dropped
+                else if (p.block_kind[b] == UVS_BLOCK_TD) base = pb.td_free ? pb.off_td() : -1;
                 if (base < 0) continue;
                 for (int k = 0; k < local; ++k) { B.col.push_back(base + k); src.push_back(p.block_idx[b] + k); }   // marginalization_factor.cpp:368-378
             }
@@ -128,22 +133,31 @@ static double evaluate(const Problem& pb, const State& x, bool robust, std::vect
     // ---- points (estimator.cpp:823-866), CauchyLoss(1.0)
     for (int k = 0; k < w->n_point_obs; ++k) {
         const int lm = w->pt_lm[k], fi = w->pt_fi[k], fj = w->pt_fj[k];
-        double r[2], J[38];
-        point_eval(x.pose[fi], x.pose[fj], x.ex, x.invd[lm], w->pt_pi + 3 * k, w->pt_pj + 3 * k, o->point_sqrt_info, r, (blocks || dump) ? J : nullptr);
-        if (robust) cost += 0.5 * cauchy_correct(o->loss_point, 2, 19, r, (blocks || dump) ? J : nullptr);
+        double r[2], J[40];
+        const bool wantJ = blocks || dump;
+        const int ld = pb.td_free ? 20 : 19;        // ProjectionTdFactor (estimator.cpp:853-858) has a fifth block, td
+        if (pb.td_free) point_td_eval(x.pose[fi], x.pose[fj], x.ex, x.invd[lm], w->pt_pi + 3 * k, w->pt_pj + 3 * k, w->pt_vel_i + 2 * k, w->pt_vel_j + 2 * k,
+                                      w->pt_td_i[k], w->pt_td_j[k], x.td, o->point_sqrt_info, r, wantJ ? J : nullptr);
+        else point_eval(x.pose[fi], x.pose[fj], x.ex, x.invd[lm], w->pt_pi + 3 * k, w->pt_pj + 3 * k, o->point_sqrt_info, r, wantJ ? J : nullptr);
+        if (robust) cost += 0.5 * cauchy_correct(o->loss_point, 2, ld, r, wantJ ? J : nullptr);
         else cost += 0.5 * (r[0] * r[0] + r[1] * r[1]);
-        if (dump && dump->pt_r) { dump->pt_r[2 * k] = r[0]; dump->pt_r[2 * k + 1] = r[1]; if (dump->pt_J) std::memcpy(dump->pt_J + 38 * k, J, sizeof(J)); }
+        if (dump && dump->pt_r) {
+            dump->pt_r[2 * k] = r[0]; dump->pt_r[2 * k + 1] = r[1];
+            if (dump->pt_J) for (int i = 0; i < 2; ++i) for (int c = 0; c < 19; ++c) dump->pt_J[38 * k + 19 * i + c] = J[i * ld + c];
+            if (dump->pt_Jtd && pb.td_free) { dump->pt_Jtd[2 * k] = J[19]; dump->pt_Jtd[2 * k + 1] = J[39]; }
+        }
         if (blocks) {
             Block B; B.rows = 2; B.r.assign(r, r + 2);
             std::vector<int> src;
             for (int c = 0; c < 6; ++c) { B.col.push_back(pb.off_pose(fi) + c); src.push_back(c); }
             for (int c = 0; c < 6; ++c) { B.col.push_back(pb.off_pose(fj) + c); src.push_back(6 + c); }
             if (pb.ex_free) for (int c = 0; c < 6; ++c) { B.col.push_back(pb.off_ex() + c); src.push_back(12 + c); }
+            if (pb.td_free) { B.col.push_back(pb.off_td()); src.push_back(19); }
             B.lm_off = pb.off_pt(lm); B.lm_dim = 1;
             B.col.push_back(B.lm_off); src.push_back(18);
             const int nc = (int)B.col.size();
             B.J.resize(2 * nc);
-            for (int i = 0; i < 2; ++i) for (int c = 0; c < nc; ++c) B.J[i * nc + c] = J[i * 19 + src[c]];
+            for (int i = 0; i < 2; ++i) for (int c = 0; c < nc; ++c) B.J[i * nc + c] = J[i * ld + src[c]];
             blocks->push_back(std::move(B));
         }
     }
@@ -192,6 +206,7 @@ static void plus(const Problem& pb, const State& x, const double* d, State& out)
         for (int k = 0; k < 9; ++k) out.sb[f][k] = x.sb[f][k] + d[pb.off_sb(f) + k];
     }
     if (pb.ex_free) pose_plus(x.ex, d + pb.off_ex(), out.ex);
+    if (pb.td_free) out.td = x.td + d[pb.off_td()];
     for (int k = 0; k < pb.Np; ++k) out.invd[k] = x.invd[k] + d[pb.off_pt(k)];
     for (int k = 0; k < 4 * pb.Nl; ++k) out.line[k] = x.line[k] + d[pb.F + pb.Np + k];
 }
@@ -202,6 +217,7 @@ static double ambient_sqnorm(const Problem& pb, const State& x, const State* y) 
     auto acc = [&](const double* a, const double* b, int n) { for (int i = 0; i < n; ++i) { double v = b ? a[i] - b[i] : a[i]; s += v * v; } };
     for (int f = 0; f < UVS_NUM_FRAMES; ++f) { acc(x.pose[f], y ? y->pose[f] : nullptr, 7); acc(x.sb[f], y ? y->sb[f] : nullptr, 9); }
     if (pb.ex_free) acc(x.ex, y ? y->ex : nullptr, 7);
+    if (pb.td_free) acc(&x.td, y ? &y->td : nullptr, 1);
     acc(x.invd.data(), y ? y->invd.data() : nullptr, pb.Np);
     acc(x.line.data(), y ? y->line.data() : nullptr, 4 * pb.Nl);
     return s;
@@ -211,6 +227,7 @@ static double ambient_maxdiff(const Problem& pb, const State& x, const State& y)
     auto acc = [&](const double* a, const double* b, int n) { for (int i = 0; i < n; ++i) m = std::fmax(m, std::fabs(a[i] - b[i])); };
     for (int f = 0; f < UVS_NUM_FRAMES; ++f) { acc(x.pose[f], y.pose[f], 7); acc(x.sb[f], y.sb[f], 9); }
     if (pb.ex_free) acc(x.ex, y.ex, 7);
+    if (pb.td_free) acc(&x.td, &y.td, 1);
     acc(x.invd.data(), y.invd.data(), pb.Np);
     acc(x.line.data(), y.line.data(), 4 * pb.Nl);
     return m;
@@ -354,7 +371,7 @@ static void copy_state_out(const Problem& pb, const State& x, uvs_state* out) {
     std::memcpy(out->pose, x.pose, sizeof(x.pose));
     std::memcpy(out->speedbias, x.sb, sizeof(x.sb));
     std::memcpy(out->ex_pose, x.ex, sizeof(x.ex));
-    out->td = pb.w->td;
+    out->td = x.td;
     if (out->inv_depth) std::memcpy(out->inv_depth, x.invd.data(), sizeof(double) * pb.Np);
     if (out->line_orth) std::memcpy(out->line_orth, x.line.data(), sizeof(double) * 4 * pb.Nl);
 }
@@ -475,6 +492,7 @@ static int solve(const uvs_options* opt, const uvs_window* w, int linear_mode, u
 // ---------------------------------------------------------------- marginalization
 // Estimator::optimization(), estimator.cpp:1002-1228 restated on block indices.
 static int marginalize(const uvs_options* opt, const uvs_window* w, int flag, uvs_prior* out) {
+    if (opt->estimate_td) return UVS_ERR_UNSUPPORTED;      // the td block is not carried through the marginalization yet
     Problem pb; init_problem(pb, opt, w);
     State x; init_state(x, w);
     MargIds ids{pb.Np, pb.Nl};
@@ -598,7 +616,7 @@ extern "C" {
 
 int oracle_solve(const uvs_options* opt, const uvs_window* w, int linear_mode, uvs_state* out, uvs_report* rep) {
     if (!opt || !w || !out || !rep) return UVS_ERR_INVALID_ARG;
-    if (opt->estimate_td) return UVS_ERR_UNSUPPORTED;
+    if (opt->estimate_td && w->n_point_obs > 0 && (!w->pt_vel_i || !w->pt_vel_j || !w->pt_td_i || !w->pt_td_j)) return UVS_ERR_INVALID_ARG;
     return orc::solve(opt, w, linear_mode, out, rep);
 }
 

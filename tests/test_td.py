@@ -1,0 +1,86 @@
+"""ESTIMATE_TD path: ProjectionTdFactor (factor/projection_td_factor.cpp:34-145) + the 1-dof para_Td block.
+CPU: the oracle's restatement (finite differences, known answer).  GPU: the HIP path against the oracle through the C ABI."""
+import numpy as np
+import pytest
+
+from helpers import uvs, abi, synth, pose_deltas
+
+
+def _td_options():
+    o = abi.default_options(); o.estimate_td = 1
+    return o
+
+
+def test_oracle_td_jacobian_matches_finite_differences(oracle):
+    w = synth.add_time_offset(synth.make_window(81), td_true=0.006)
+    w.td = 0.002
+    o = _td_options()
+    ev = oracle.evaluate(w, robust=False, opts=o)
+    h = 1e-6
+    wp, wm = w.copy(), w.copy(); wp.td += h; wm.td -= h
+    fd = (oracle.evaluate(wp, robust=False, opts=o).pt_r - oracle.evaluate(wm, robust=False, opts=o).pt_r) / (2 * h)
+    assert np.abs(fd - ev.pt_Jtd).max() <= 1e-6 * max(1.0, np.abs(ev.pt_Jtd).max())
+    # the other 19 columns are those of ProjectionFactor at the shifted observations (projection_td_factor.cpp:51-52)
+    ws = w.copy(); ws.pt_pi = w.pt_pi.copy(); ws.pt_pj = w.pt_pj.copy()
+    ws.pt_pi[:, :2] -= (w.td - w.pt_td_i)[:, None] * w.pt_vel_i; ws.pt_pj[:, :2] -= (w.td - w.pt_td_j)[:, None] * w.pt_vel_j
+    e0 = oracle.evaluate(ws, robust=False)
+    assert np.abs(e0.pt_J - ev.pt_J).max() < 1e-12 and np.abs(e0.pt_r - ev.pt_r).max() < 1e-12
+
+
+def test_oracle_recovers_the_time_offset(oracle):
+    """Noise-free window whose observations were displaced by td_true * velocity: the solve must find td_true and zero cost."""
+    w = synth.add_time_offset(synth.make_window(82, noise=False, perturb=False), td_true=0.004)
+    st, rep = oracle.solve(w, opts=_td_options())
+    assert rep.status == 0 and rep.final_cost < 1e-8 and abs(st.td - 0.004) < 1e-8
+    # with the option off td stays put and the displaced observations cannot be explained
+    st0, rep0 = oracle.solve(w)
+    assert st0.td == 0.0 and rep0.final_cost > 1e-3
+
+
+@pytest.mark.gpu
+def test_td_evaluate_elementwise(gpu_api, oracle):
+    w = synth.add_time_offset(synth.make_window(83), td_true=0.005); w.td = 0.001
+    s = gpu_api.Solver(opts=_td_options(), max_batch=2)
+    for robust in (True, False):
+        eg = s.evaluate(w, robust=robust); eo = oracle.evaluate(w, robust=robust, opts=_td_options())
+        for name in ("pt_r", "pt_J", "pt_Jtd", "ln_r", "ln_J", "vp_r", "imu_r"):
+            a, b = getattr(eg, name), getattr(eo, name)
+            assert np.abs(a - b).max() <= 1e-9 * max(1.0, np.abs(b).max()), name
+        assert abs(eg.cost - eo.cost) <= 1e-10 * abs(eo.cost)
+    s.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("index", [84, 85])
+def test_td_solve_matches_oracle(gpu_api, oracle, index):
+    w = synth.add_time_offset(synth.make_window(index), td_true=0.005)
+    s = gpu_api.Solver(opts=_td_options(), max_batch=2)
+    sg, rg = s.solve(w)
+    s.close()
+    so, ro = oracle.solve(w, opts=_td_options())
+    assert rg.status == 0 and rg.num_iterations == ro.num_iterations
+    assert list(rg.accepted[: rg.num_iterations + 1]) == list(ro.accepted[: ro.num_iterations + 1])
+    dp, da = pose_deltas(sg.pose, so.pose)
+    assert dp < 1e-4 and da < 1e-4, (dp, da)
+    assert abs(sg.td - so.td) < 1e-7 and abs(rg.final_cost - ro.final_cost) <= 1e-6 * ro.final_cost
+    assert abs(rg.initial_cost - ro.initial_cost) <= 1e-10 * ro.initial_cost
+
+
+@pytest.mark.gpu
+def test_td_known_answer_on_the_gpu(gpu_api):
+    w = synth.add_time_offset(synth.make_window(86, noise=False, perturb=False), td_true=0.004)
+    s = gpu_api.Solver(opts=_td_options(), max_batch=2)
+    sg, rg = s.solve(w)
+    s.close()
+    assert rg.status == 0 and rg.final_cost < 1e-8 and abs(sg.td - 0.004) < 1e-8
+
+
+@pytest.mark.gpu
+def test_td_off_ignores_the_td_inputs(gpu_api, oracle):
+    """ESTIMATE_TD = 0 (the EuRoC configuration): identical results with and without the velocity arrays present."""
+    w0 = synth.make_window(87)
+    w1 = synth.add_time_offset(w0, td_true=0.0)
+    s = gpu_api.Solver(max_batch=2)
+    a, ra = s.solve(w0); b, rb = s.solve(w1)
+    s.close()
+    assert np.array_equal(a.pose, b.pose) and ra.final_cost == rb.final_cost

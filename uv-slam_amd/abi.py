@@ -107,6 +107,7 @@ class WindowC(C.Structure):
         ("ln_has_vp", c_int_p), ("ln_vp", c_double_p),
         ("n_imu", C.c_int32), ("imu", C.POINTER(ImuBlock)),
         ("prior", C.POINTER(Prior)),
+        ("pt_vel_i", c_double_p), ("pt_vel_j", c_double_p), ("pt_td_i", c_double_p), ("pt_td_j", c_double_p),
     ]
 
 
@@ -138,7 +139,7 @@ class Report(C.Structure):
 class EvalC(C.Structure):
     _fields_ = [
         ("pt_r", c_double_p), ("pt_J", c_double_p), ("ln_r", c_double_p), ("ln_J", c_double_p), ("vp_r", c_double_p), ("vp_J", c_double_p),
-        ("imu_r", c_double_p), ("imu_J", c_double_p), ("prior_r", c_double_p), ("cost", C.c_double),
+        ("imu_r", c_double_p), ("imu_J", c_double_p), ("prior_r", c_double_p), ("cost", C.c_double), ("pt_Jtd", c_double_p),
     ]
 
 
@@ -164,6 +165,7 @@ class Window:
         self.inv_depth = np.zeros(0)
         self.pt_lm = np.zeros(0, np.int32); self.pt_fi = np.zeros(0, np.int32); self.pt_fj = np.zeros(0, np.int32)
         self.pt_pi = np.zeros((0, 3)); self.pt_pj = np.zeros((0, 3))
+        self.pt_vel_i = None; self.pt_vel_j = None; self.pt_td_i = None; self.pt_td_j = None      # ProjectionTdFactor inputs (estimate_td), [n_obs,2] / [n_obs]
         self.line_orth = np.zeros((0, 4))
         self.ln_lm = np.zeros(0, np.int32); self.ln_fj = np.zeros(0, np.int32)
         self.ln_sp = np.zeros((0, 3)); self.ln_ep = np.zeros((0, 3))
@@ -188,6 +190,9 @@ class Window:
             k[name] = f64(getattr(self, name)); setattr(w, name, _dp(k[name]))
         for name in ("pt_lm", "pt_fi", "pt_fj", "ln_lm", "ln_fj", "ln_has_vp"):
             k[name] = i32(getattr(self, name)); setattr(w, name, _ip(k[name]))
+        for name in ("pt_vel_i", "pt_vel_j", "pt_td_i", "pt_td_j"):
+            if getattr(self, name) is not None:
+                k[name] = f64(getattr(self, name)); setattr(w, name, _dp(k[name]))
         w.n_points = len(k["inv_depth"]); w.n_point_obs = len(k["pt_lm"])
         w.n_lines = len(k["line_orth"]); w.n_line_obs = len(k["ln_lm"])
         n_imu = len(self.imu)
@@ -258,6 +263,7 @@ class Window:
         o = self.copy()
         o.pose = st.pose.copy(); o.speedbias = st.speedbias.copy(); o.ex_pose = st.ex_pose.copy()
         o.inv_depth = st.inv_depth.copy(); o.line_orth = st.line_orth.copy()
+        o.td = float(getattr(st, "td", o.td))
         return o
 
 
@@ -287,7 +293,7 @@ class Eval:
     def __init__(self, w: Window):
         npo, nlo, ni = len(w.pt_lm), len(w.ln_lm), len(w.imu)
         n = w.prior.n if w.prior is not None else 0
-        self.pt_r = np.zeros((npo, 2)); self.pt_J = np.zeros((npo, 2, 19))
+        self.pt_r = np.zeros((npo, 2)); self.pt_J = np.zeros((npo, 2, 19)); self.pt_Jtd = np.zeros((npo, 2))
         self.ln_r = np.zeros((nlo, 2)); self.ln_J = np.zeros((nlo, 2, 10))
         self.vp_r = np.zeros((nlo, 1)); self.vp_J = np.zeros((nlo, 1, 10))
         self.imu_r = np.zeros((ni, 15)); self.imu_J = np.zeros((ni, 15, 30))
@@ -296,6 +302,6 @@ class Eval:
 
     def alloc_c(self):
         e = EvalC()
-        for name in ("pt_r", "pt_J", "ln_r", "ln_J", "vp_r", "vp_J", "imu_r", "imu_J", "prior_r"):
+        for name in ("pt_r", "pt_J", "ln_r", "ln_J", "vp_r", "vp_J", "imu_r", "imu_J", "prior_r", "pt_Jtd"):
             setattr(e, name, _dp(getattr(self, name)))
         return e

@@ -12,7 +12,7 @@
 namespace uvsdev {
 
 struct EvalOut {   // device pointers
-    double *pt_r, *pt_J, *ln_r, *ln_J, *vp_r, *vp_J, *imu_r, *imu_J, *prior_r, *cost;
+    double *pt_r, *pt_J, *ln_r, *ln_J, *vp_r, *vp_J, *imu_r, *imu_J, *prior_r, *cost, *pt_Jtd;
 };
 
 __global__ __launch_bounds__(NT) void k_evaluate(char* blob, double* ws, KOpts o, int robust, EvalOut out) {
@@ -21,7 +21,7 @@ __global__ __launch_bounds__(NT) void k_evaluate(char* blob, double* ws, KOpts o
     Ctx c;
     c.hdr = (const DevWin*)blob; c.bd = (const double*)blob; c.bi = (const int*)blob; c.ws = ws; c.sh = sh; c.o = o;
     const DevWin& h = *c.hdr;
-    if (tid < 184) sh[L_X + tid] = (tid < 183) ? c.bd[h.d_frames + tid] : 0.0;
+    if (tid < 184) sh[L_X + tid] = c.bd[h.d_frames + tid];
     setup_window(c, (double*)blob);
     __syncthreads();
     const double* x = sh + L_X;
@@ -34,10 +34,10 @@ __global__ __launch_bounds__(NT) void k_evaluate(char* blob, double* ws, KOpts o
     if (tid < h.prior_n) out.prior_r[tid] = sh[L_PR + tid];
     for (int ob = tid; ob < h.n_pt_obs; ob += NT) {
         const int lm = c.bi[h.i_pt_lm + ob], fi = c.bi[h.i_pt_fi + ob], fj = c.bi[h.i_pt_fj + ob];
-        const double* m = c.bd + h.d_ptmeas + ob; const int st = h.pt_stride;
-        const double pi[3] = {m[0], m[st], m[2 * st]}, pj[3] = {m[3 * st], m[4 * st], m[5 * st]};
+        double pi[3], pj[3], vij[4] = {0.0, 0.0, 0.0, 0.0}, jtd[2] = {0.0, 0.0};
+        load_point_obs(c, ob, x[183], pi, pj, vij);
         double r[2], A[12], B[12], cl[2], E[12];
-        point_eval<true, true>(x + 7 * fi, RF + 9 * fi, x + 7 * fj, RF + 9 * fj, ric, tic, invd[lm], pi, pj, o.sqrt_info, r, A, B, cl, E);
+        point_eval<true, true>(x + 7 * fi, RF + 9 * fi, x + 7 * fj, RF + 9 * fj, ric, tic, invd[lm], pi, pj, o.sqrt_info, r, A, B, cl, E, vij, vij + 2, h.td_on ? jtd : nullptr);
         double sc = 1.0;
         if (robust) cost += 0.5 * cauchy(o.loss_pt, r[0] * r[0] + r[1] * r[1], &sc); else cost += 0.5 * (r[0] * r[0] + r[1] * r[1]);
         out.pt_r[2 * ob] = sc * r[0]; out.pt_r[2 * ob + 1] = sc * r[1];
@@ -46,6 +46,7 @@ __global__ __launch_bounds__(NT) void k_evaluate(char* blob, double* ws, KOpts o
             for (int q = 0; q < 6; ++q) { J[row * 19 + q] = sc * A[6 * row + q]; J[row * 19 + 6 + q] = sc * B[6 * row + q]; J[row * 19 + 12 + q] = sc * E[6 * row + q]; }
             J[row * 19 + 18] = sc * cl[row];
         }
+        if (out.pt_Jtd) { out.pt_Jtd[2 * ob] = sc * jtd[0]; out.pt_Jtd[2 * ob + 1] = sc * jtd[1]; }
     }
     for (int ob = tid; ob < h.n_ln_obs; ob += NT) {
         const int lm = c.bi[h.i_ln_lm + ob], fj = c.bi[h.i_ln_fj + ob], hv = c.bi[h.i_ln_vp + ob];
@@ -98,7 +99,7 @@ static int run_evaluate(int device, hipStream_t stream, char* d_blob, double* d_
     auto chk = [&](hipError_t e, const char* what) { if (e != hipSuccess) { err = std::string(what) + ": " + hipGetErrorString(e); return false; } return true; };
     if (!chk(hipSetDevice(device), "hipSetDevice")) return UVS_ERR_HIP;
     const size_t npo = (size_t)std::max(h.n_pt_obs, 1), nlo = (size_t)std::max(h.n_ln_obs, 1), ni = (size_t)std::max(h.n_imu, 1);
-    const size_t sizes[10] = {2 * npo, 38 * npo, 2 * nlo, 20 * nlo, nlo, 10 * nlo, 15 * ni, 450 * ni, (size_t)UVS_MAX_PRIOR_DIM, 8};
+    const size_t sizes[11] = {2 * npo, 38 * npo, 2 * nlo, 20 * nlo, nlo, 10 * nlo, 15 * ni, 450 * ni, (size_t)UVS_MAX_PRIOR_DIM, 8, 2 * npo};
     size_t tot = 0; for (size_t v : sizes) tot += v;
     if (!chk(hipFuncSetAttribute((const void*)k_evaluate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES), "hipFuncSetAttribute")) return UVS_ERR_HIP;
     double* d = nullptr;
@@ -106,7 +107,7 @@ static int run_evaluate(int device, hipStream_t stream, char* d_blob, double* d_
     hipMemsetAsync(d, 0, tot * 8, stream);
     EvalOut eo; double* p = d;
     eo.pt_r = p; p += sizes[0]; eo.pt_J = p; p += sizes[1]; eo.ln_r = p; p += sizes[2]; eo.ln_J = p; p += sizes[3]; eo.vp_r = p; p += sizes[4];
-    eo.vp_J = p; p += sizes[5]; eo.imu_r = p; p += sizes[6]; eo.imu_J = p; p += sizes[7]; eo.prior_r = p; p += sizes[8]; eo.cost = p;
+    eo.vp_J = p; p += sizes[5]; eo.imu_r = p; p += sizes[6]; eo.imu_J = p; p += sizes[7]; eo.prior_r = p; p += sizes[8]; eo.cost = p; p += sizes[9]; eo.pt_Jtd = p;
     hipLaunchKernelGGL(k_evaluate, dim3(1), dim3(NT), LDS_BYTES, stream, d_blob, d_ws, ko, robust, eo);
     bool ok = chk(hipGetLastError(), "k_evaluate launch") && chk(hipStreamSynchronize(stream), "k_evaluate");
     auto back = [&](double* dst, const double* src, size_t n) { if (ok && dst && n) ok = chk(hipMemcpy(dst, src, n * 8, hipMemcpyDeviceToHost), "memcpy D2H"); };
@@ -116,6 +117,7 @@ static int run_evaluate(int device, hipStream_t stream, char* d_blob, double* d_
     back(out->imu_r, eo.imu_r, 15 * (size_t)h.n_imu); back(out->imu_J, eo.imu_J, 450 * (size_t)h.n_imu);
     back(out->prior_r, eo.prior_r, (size_t)h.prior_n);
     back(&out->cost, eo.cost, 1);
+    if (h.td_on) back(out->pt_Jtd, eo.pt_Jtd, 2 * (size_t)h.n_pt_obs);
     hipFree(d);
     return ok ? UVS_OK : UVS_ERR_HIP;
 }

@@ -116,7 +116,8 @@ UVS_DEV double cauchy(double a, double sq_norm, double* scale) {
 template <bool WITH_J, bool WITH_EX>
 UVS_DEV void point_eval(const double* Pi, const double* Ri, const double* Pj, const double* Rj, const double* ric, const double* tic,
                         double inv_dep, const double* pts_i, const double* pts_j, double sqrt_info,
-                        double* r, double* Ji, double* Jj, double* Jl, double* Jex) {
+                        double* r, double* Ji, double* Jj, double* Jl, double* Jex,
+                        const double* vel_i = nullptr, const double* vel_j = nullptr, double* Jtd = nullptr) {
     double pc_i[3] = {pts_i[0] / inv_dep, pts_i[1] / inv_dep, pts_i[2] / inv_dep};      // :44
     double p_imu_i[3]; mat_vec(ric, pc_i, p_imu_i);
     p_imu_i[0] += tic[0]; p_imu_i[1] += tic[1]; p_imu_i[2] += tic[2];                    // :45
@@ -165,6 +166,12 @@ UVS_DEV void point_eval(const double* Pi, const double* Ri, const double* Pj, co
     { double v[3]; mat_vec(T, pts_i, v);
       const double s = -1.0 / (inv_dep * inv_dep);
       Jl[0] = (r00 * v[0] + r02 * v[2]) * s; Jl[1] = (r00 * v[1] + r12 * v[2]) * s; }
+    if (Jtd) {   // ProjectionTdFactor, projection_td_factor.cpp:135-140: reduce * tmp_r * (vel_i, 0) * (-1 / inv_dep) + sqrt_info * vel_j.xy (pts_i / pts_j are the shifted ones)
+        const double v0 = T[0] * vel_i[0] + T[1] * vel_i[1], v1 = T[3] * vel_i[0] + T[4] * vel_i[1], v2 = T[6] * vel_i[0] + T[7] * vel_i[1];
+        const double s = -1.0 / inv_dep;
+        Jtd[0] = (r00 * v0 + r02 * v2) * s + sqrt_info * vel_j[0];
+        Jtd[1] = (r00 * v1 + r12 * v2) * s + sqrt_info * vel_j[1];
+    }
     if (WITH_EX) {   // :143-147
         double ricT[9];
 #pragma unroll

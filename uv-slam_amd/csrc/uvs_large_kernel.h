@@ -16,7 +16,7 @@
 
 namespace uvsdev {
 
-static constexpr int LG_ACC = UVS_NBLK * 64;               // 4224 accumulator slots [pose block][row a][8] -- canonical, independent of the per-window group balance
+static constexpr int LG_ACC = UVS_NBLKX * 64;               // 4992 accumulator slots [gather block (66 pose blocks + 12 time-offset blocks)][row a][8] -- canonical, independent of the per-window group balance
 static constexpr int LG_RED = LG_ACC + 8;                  // + {landmark cost, max |g_l|, 6 spare}
 enum { LS_X = 0, LS_XC = 184, LS_DLT = 368, LS_G = 544, LS_DD = 720, LS_SC = 896, LS_END = LS_SC + UVS_RD };
 static constexpr int LG_STATE = 1280;                      // doubles: X[184] XC[184] DLT[176] G[176] DD[176] SC[176]
@@ -46,8 +46,10 @@ __global__ __launch_bounds__(NT) void k_large_chunks(char* blob, double* ws, KOp
     for (int part = 0; part < h.n_parts; ++part) {
         if (grp >= 0 && ((grp >> 9) & 15) == part) {
             const int r0 = 3 * (tid & 1);
+            const bool tdrow = ((grp >> 13) & 15) == UVS_NF;       // time-offset blocks: only row 0 is real
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
+                if (tdrow && (r0 + r) != 0) continue;
                 double* Q = sh + L_S + (grp & 255) * 64 + (r0 + r) * 8;
 #pragma unroll
                 for (int q = 0; q < 6; ++q) Q[q] += A.v[6 * r + q];

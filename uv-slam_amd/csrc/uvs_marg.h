@@ -55,7 +55,7 @@ static int run_marginalize(int device, hipStream_t stream, char* d_blob, double*
         ln_J(20 * (size_t)std::max(h.n_ln_obs, 1)), vp_r((size_t)std::max(h.n_ln_obs, 1)), vp_J(10 * (size_t)std::max(h.n_ln_obs, 1)),
         imu_r(15 * (size_t)std::max(h.n_imu, 1)), imu_J(450 * (size_t)std::max(h.n_imu, 1)), prior_r(UVS_MAX_PRIOR_DIM);
     uvs_eval ev; ev.pt_r = pt_r.data(); ev.pt_J = pt_J.data(); ev.ln_r = ln_r.data(); ev.ln_J = ln_J.data(); ev.vp_r = vp_r.data(); ev.vp_J = vp_J.data();
-    ev.imu_r = imu_r.data(); ev.imu_J = imu_J.data(); ev.prior_r = prior_r.data(); ev.cost = 0.0;
+    ev.imu_r = imu_r.data(); ev.imu_J = imu_J.data(); ev.prior_r = prior_r.data(); ev.cost = 0.0; ev.pt_Jtd = nullptr;
     int rc = run_evaluate(device, stream, d_blob, d_ws, h, ko, 1, &ev, err);
     if (rc != UVS_OK) return rc;
     // ---- host: block bookkeeping.  ids: pose f -> f ; speedbias f -> 11+f ; ex -> 22 ; point k -> 23+k ; line l -> 23+Np+l

@@ -139,6 +139,20 @@ UVS_DEV void stage_rotations(const Ctx& c, const double* x) {
     else if (tid == UVS_NF) { quat_to_R(x + 176 + 3, c.sh + L_EX); c.sh[L_EX + 9] = x[176]; c.sh[L_EX + 10] = x[177]; c.sh[L_EX + 11] = x[178]; }
 }
 
+// measurements of point residual block `o`; with ESTIMATE_TD the time-shifted ones of ProjectionTdFactor (projection_td_factor.cpp:51-52):
+//   pts_i_td = pts_i - (td - td_i) * (vel_i, 0), same for j  (rolling-shutter term folded into td_i / td_j by the caller).  vij = vel_i.xy, vel_j.xy
+UVS_DEV void load_point_obs(const Ctx& c, int o, double td, double* pi, double* pj, double* vij) {
+    const DevWin& h = *c.hdr;
+    const double* m = c.bd + h.d_ptmeas + o; const int st = h.pt_stride;
+    pi[0] = m[0]; pi[1] = m[st]; pi[2] = m[2 * st]; pj[0] = m[3 * st]; pj[1] = m[4 * st]; pj[2] = m[5 * st];
+    if (h.td_on) {
+        const double* v = c.bd + h.d_ptvel + o;
+        vij[0] = v[0]; vij[1] = v[st]; vij[2] = v[2 * st]; vij[3] = v[3 * st];
+        const double di = td - v[4 * st], dj = td - v[5 * st];
+        pi[0] -= di * vij[0]; pi[1] -= di * vij[1]; pj[0] -= dj * vij[2]; pj[1] -= dj * vij[3];
+    }
+}
+
 // ------------------------------------------------------------------ residual-only cost at `x` (LDS) / landmark buffer `sel`
 UVS_DEV void prior_dx(const Ctx& c, const double* x) {
     const int tid = threadIdx.x;
@@ -147,7 +161,7 @@ UVS_DEV void prior_dx(const Ctx& c, const double* x) {
         const int* pt = c.bi + h.i_prior;
         const int kind = pt[tid], frame = pt[16 + tid], size = pt[32 + tid], idx = pt[48 + tid], xo = pt[64 + tid];
         const double* x0 = c.bd + h.d_prior + 2 * h.prior_n * h.prior_n + 2 * h.prior_n + xo;
-        const double* xb = (kind == UVS_BLOCK_POSE) ? x + 7 * frame : (kind == UVS_BLOCK_SPEEDBIAS) ? x + 77 + 9 * frame : x + 176;
+        const double* xb = (kind == UVS_BLOCK_POSE) ? x + 7 * frame : (kind == UVS_BLOCK_SPEEDBIAS) ? x + 77 + 9 * frame : (kind == UVS_BLOCK_TD) ? x + 183 : x + 176;
         double* dx = c.sh + L_PDX + idx;
         if (size != 7) { for (int k = 0; k < size; ++k) dx[k] = xb[k] - x0[k]; }
         else {   // marginalization_factor.cpp:352-362
@@ -190,8 +204,8 @@ UVS_DEV double cost_pass(const Ctx& c, const double* x, const double* invd, cons
     // points
     for (int o = po0 + tid; o < po1; o += NT) {
         const int lm = c.bi[h.i_pt_lm + o], fi = c.bi[h.i_pt_fi + o], fj = c.bi[h.i_pt_fj + o];
-        const double* m = c.bd + h.d_ptmeas + o; const int st = h.pt_stride;
-        const double pi[3] = {m[0], m[st], m[2 * st]}, pj[3] = {m[3 * st], m[4 * st], m[5 * st]};
+        double pi[3], pj[3], vij[4];
+        load_point_obs(c, o, x[183], pi, pj, vij);
         double r[2];
         point_eval<false, false>(x + 7 * fi, RF + 9 * fi, x + 7 * fj, RF + 9 * fj, ric, tic, invd[lm], pi, pj, c.o.sqrt_info, r, nullptr, nullptr, nullptr, nullptr);
         double sc; cost += 0.5 * cauchy(c.o.loss_pt, r[0] * r[0] + r[1] * r[1], &sc);
@@ -491,6 +505,9 @@ UVS_DEV void gather_points(int grp, const int* lists, const double* S0, GAcc& A)
     const int g = threadIdx.x >> 1, r0 = 3 * (threadIdx.x & 1);
     const bool on = grp >= 0;
     const bool diag = on && ((grp >> 8) & 1);
+    const bool tdg = on && ((grp >> 13) & 15) == UVS_NF;       // block row of the time offset: J1 = (J_td[0], J_td[1]) adjacent, residual 16 doubles below
+    const int p1off = tdg ? 1 : 6, rcoff = tdg ? UVS_PT_C - UVS_PT_TD : 12;
+    const bool dirv = !(tdg && diag);                           // (td, td): the direct term is the scalar J_td . J_td = the hd accumulator
     const int* ent = lists + LIST_HDR;
     // ---- Schur: acc[r][c] -= E_a[r0 + r] * Einv_b[c]
     {
@@ -524,13 +541,13 @@ UVS_DEV void gather_points(int grp, const int* lists, const double* S0, GAcc& A)
             const double* pb = S0 + ((unsigned)e >> 16);
             double p0[3], p1[3]; d2_t q0[3], q1[3];
 #pragma unroll
-            for (int r = 0; r < 3; ++r) { p0[r] = pa[r]; p1[r] = pa[6 + r]; }
+            for (int r = 0; r < 3; ++r) { p0[r] = pa[r]; p1[r] = pa[p1off + r]; }
 #pragma unroll
             for (int k = 0; k < 3; ++k) { q0[k] = lds2(pb + 2 * k); q1[k] = lds2(pb + 6 + 2 * k); }
-            const d2_t rc = lds2(S0 + lo + 12);
+            const d2_t rc = lds2(S0 + lo + rcoff);
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
-                row_fma(A.v + 6 * r, p0[r], q0); row_fma(A.v + 6 * r, p1[r], q1);
+                if (dirv) { row_fma(A.v + 6 * r, p0[r], q0); row_fma(A.v + 6 * r, p1[r], q1); }
                 if (diag) { A.g[r] += p0[r] * rc.x + p1[r] * rc.y; A.hd[r] += p0[r] * p0[r] + p1[r] * p1[r]; }
             }
             e = en;
@@ -688,24 +705,27 @@ UVS_DEV void lin_chunk(const Ctx& c, int ch, const double* x, const double* invd
         if (type == 0) {
             const int* beg = c.bi + h.i_pt_beg;
             const int o0 = beg[k0], o1 = beg[k1], nob = o1 - o0;
-            double* rec = sh + L_S;                                  // [nob][28]
-            double* Eb = rec + (size_t)nob * UVS_PT_REC;             // [(nob + nlm)][6]
-            double* EIb = Eb + (size_t)(nob + nlm) * 6;              // [(nob + nlm)][6]  Einv = E / h_ll
-            int* lists = (int*)(EIb + (size_t)(nob + nlm) * 6);      // gather lists staged in LDS (one HBM latency per chunk)
+            const int PREC = h.pt_rec, XS = h.pt_xslots;
+            double* rec = sh + L_S;                                  // [nob][PREC]
+            double* Eb = rec + (size_t)nob * PREC;                   // [(nob + XS * nlm)][6]   slots per landmark: anchor, observations, (td)
+            double* EIb = Eb + (size_t)(nob + XS * nlm) * 6;         // [(nob + XS * nlm)][6]  Einv = E / h_ll
+            int* lists = (int*)(EIb + (size_t)(nob + XS * nlm) * 6); // gather lists staged in LDS (one HBM latency per chunk)
             for (int t = tid; t < nlist; t += NT) lists[t] = glists[t];
             // pass A: one lane per observation
             for (int o = o0 + tid; o < o1; o += NT) {
                 const int lm = c.bi[h.i_pt_lm + o], fi = c.bi[h.i_pt_fi + o], fj = c.bi[h.i_pt_fj + o];
-                const double* m = c.bd + h.d_ptmeas + o; const int st = h.pt_stride;
-                const double pi[3] = {m[0], m[st], m[2 * st]}, pj[3] = {m[3 * st], m[4 * st], m[5 * st]};
-                double r[2], A[12], B[12], cl[2];
-                point_eval<true, false>(x + 7 * fi, RF + 9 * fi, x + 7 * fj, RF + 9 * fj, ric, tic, invd[lm], pi, pj, c.o.sqrt_info, r, A, B, cl, nullptr);
+                double pi[3], pj[3], vij[4] = {0.0, 0.0, 0.0, 0.0};
+                load_point_obs(c, o, x[183], pi, pj, vij);
+                double r[2], A[12], B[12], cl[2], jtd[2] = {0.0, 0.0};
+                point_eval<true, false>(x + 7 * fi, RF + 9 * fi, x + 7 * fj, RF + 9 * fj, ric, tic, invd[lm], pi, pj, c.o.sqrt_info, r, A, B, cl, nullptr,
+                                        vij, vij + 2, h.td_on ? jtd : nullptr);
                 double sc; cost += 0.5 * cauchy(c.o.loss_pt, r[0] * r[0] + r[1] * r[1], &sc);
-                double* R = rec + (size_t)(o - o0) * UVS_PT_REC;
+                double* R = rec + (size_t)(o - o0) * PREC;
                 R[0] = sc * r[0]; R[1] = sc * r[1];
 #pragma unroll
                 for (int q = 0; q < 12; ++q) { R[UVS_PT_A + q] = sc * A[q]; R[UVS_PT_B + q] = sc * B[q]; }
                 R[UVS_PT_C] = sc * cl[0]; R[UVS_PT_C + 1] = sc * cl[1];      // d r / d lambda; replaced by the corrected residual in pass B
+                if (h.td_on) { R[UVS_PT_TD] = sc * jtd[0]; R[UVS_PT_TD + 1] = sc * jtd[1]; R[UVS_PT_TD + 2] = 0.0; R[UVS_PT_TD + 3] = 0.0; }
             }
             __syncthreads();
             UVS_PROF(c, P_OBS);
@@ -715,16 +735,16 @@ UVS_DEV void lin_chunk(const Ctx& c, int ch, const double* x, const double* invd
             for (int ol = tid; ol < nob; ol += NT) {
                 const int k = c.bi[h.i_pt_lm + o0 + ol], li = k - k0, b0 = beg[k] - o0, b1 = beg[k + 1] - o0;
                 double hd = 0.0, gl = 0.0;
-                for (int o = b0; o < b1; ++o) { const double* R = rec + (size_t)o * UVS_PT_REC; hd += R[UVS_PT_C] * R[UVS_PT_C] + R[UVS_PT_C + 1] * R[UVS_PT_C + 1]; gl += R[UVS_PT_C] * R[0] + R[UVS_PT_C + 1] * R[1]; }
+                for (int o = b0; o < b1; ++o) { const double* R = rec + (size_t)o * PREC; hd += R[UVS_PT_C] * R[UVS_PT_C] + R[UVS_PT_C + 1] * R[UVS_PT_C + 1]; gl += R[UVS_PT_C] * R[0] + R[UVS_PT_C + 1] * R[1]; }
                 const bool lead = ol == b0;
                 double sc;
                 if (first) { sc = c.o.jacobi ? 1.0 / (1.0 + sqrt(hd)) : 1.0; if (lead) c.ws[h.w_scale_pt + k] = sc; } else sc = c.ws[h.w_scale_pt + k];
                 const double dd = fmin(fmax(sc * sc * hd, c.o.dlo), c.o.dhi) / (radius * sc * sc);
                 const double hinv = 1.0 / (hd + dd), ginv = gl * hinv;
                 const int s = ol - b0 + 1;
-                double* E = Eb + (size_t)(b0 + li) * 6; double* EI = EIb + (size_t)(b0 + li) * 6;
-                double* Eg = c.ws + h.w_pt_E + 6 * (size_t)(beg[k] + k);
-                double* R = rec + (size_t)ol * UVS_PT_REC;
+                double* E = Eb + (size_t)(b0 + XS * li) * 6; double* EI = EIb + (size_t)(b0 + XS * li) * 6;
+                double* Eg = c.ws + h.w_pt_E + 6 * (size_t)(beg[k] + XS * k);
+                double* R = rec + (size_t)ol * PREC;
                 const double c0 = R[UVS_PT_C], c1 = R[UVS_PT_C + 1], rr0 = R[0], rr1 = R[1];
                 double Bv[12];      // all LDS reads of the record BEFORE the first LDS write (the compiler must assume E / EI alias it)
 #pragma unroll
@@ -735,18 +755,24 @@ UVS_DEV void lin_chunk(const Ctx& c, int ch, const double* x, const double* invd
                 if (lead) {
                     double* px = c.ws + h.w_pt_x + 4 * (size_t)k; px[0] = ginv; px[1] = gl; px[2] = dd; px[3] = hd;
                     gmax_lm = fmax(gmax_lm, fabs(gl));
-                    double e0[6] = {0, 0, 0, 0, 0, 0};
+                    double e0[6] = {0, 0, 0, 0, 0, 0}, etd = 0.0;
                     for (int o = b0; o < b1; ++o) {
-                        const double* Ro = rec + (size_t)o * UVS_PT_REC;
+                        const double* Ro = rec + (size_t)o * PREC;
 #pragma unroll
                         for (int a = 0; a < 6; ++a) e0[a] += Ro[UVS_PT_C] * Ro[UVS_PT_A + a] + Ro[UVS_PT_C + 1] * Ro[UVS_PT_A + 6 + a];
+                        if (h.td_on) etd += Ro[UVS_PT_C] * Ro[UVS_PT_TD] + Ro[UVS_PT_C + 1] * Ro[UVS_PT_TD + 1];
                     }
 #pragma unroll
                     for (int a = 0; a < 6; ++a) { E[a] = e0[a]; EI[a] = e0[a] * hinv; Eg[a] = e0[a] * hinv; }
+                    if (h.td_on) {      // last slot of the landmark: the time-offset "row" J_l^T J_td (a 6-vector whose first entry is the only real one)
+                        const int st_ = 6 * (b1 - b0 + 1);
+#pragma unroll
+                        for (int a = 0; a < 6; ++a) { const double e = a == 0 ? etd : 0.0; E[st_ + a] = e; EI[st_ + a] = e * hinv; Eg[st_ + a] = e * hinv; }
+                    }
                 }
             }
             __syncthreads();
-            for (int ol = tid; ol < nob; ol += NT) { double* R = rec + (size_t)ol * UVS_PT_REC; R[UVS_PT_C] = R[UVS_PT_RC2]; R[UVS_PT_C + 1] = R[UVS_PT_RC2 + 1]; }
+            for (int ol = tid; ol < nob; ol += NT) { double* R = rec + (size_t)ol * PREC; R[UVS_PT_C] = R[UVS_PT_RC2]; R[UVS_PT_C + 1] = R[UVS_PT_RC2 + 1]; }
             __syncthreads();
             UVS_PROF(c, P_LMPREP);
             sh[L_LCOST + tid] += cost; sh[L_LGMAX + tid] = fmax(sh[L_LGMAX + tid], gmax_lm);
@@ -904,6 +930,21 @@ UVS_DEV void lin_assemble(const Ctx& c, const double* x, bool first, double radi
         if (grp >= 0 && ((grp >> 9) & 15) == part) {
             const int r0 = 3 * (tid & 1);
             const int fa = (grp >> 13) & 15, fb = (grp >> 17) & 15;
+            if (fa == UVS_NF) {      // time-offset row (ESTIMATE_TD): row UVS_TD_INDEX of S, only row 0 of lane 0 of the group is real
+                if (r0 == 0) {
+                    if (fb < UVS_NF) {
+                        double* row = sh + L_S + sidx(UVS_TD_INDEX, 16 * fb);
+                        double cur[6];
+#pragma unroll
+                        for (int cc = 0; cc < 6; ++cc) cur[cc] = row[cc];
+#pragma unroll
+                        for (int cc = 0; cc < 6; ++cc) row[cc] = cur[cc] + A.v[cc];
+                    } else {
+                        sh[L_S + sidx(UVS_TD_INDEX, UVS_TD_INDEX)] += A.v[0] + A.hd[0];      // Schur part + J_td . J_td
+                        sh[L_G + UVS_TD_INDEX] += A.g[0]; sh[L_HD + UVS_TD_INDEX] += A.hd[0];
+                    }
+                }
+            } else {
             const bool dg = fa == fb;
             double* row0 = sh + L_S + sidx(16 * fa + r0, 16 * fb);
             double cur[18], cg[3], chd[3];      // all reads before the first write (every "+=" to LDS otherwise waits for the one before)
@@ -918,6 +959,7 @@ UVS_DEV void lin_assemble(const Ctx& c, const double* x, bool first, double radi
 #pragma unroll
                 for (int cc = 0; cc < 6; ++cc) if (!dg || cc <= r0 + r) row0[r * UVS_BLK_LD + cc] = cur[6 * r + cc] + A.v[6 * r + cc];
                 if (dg) { sh[L_G + 16 * fa + r0 + r] = cg[r] + A.g[r]; sh[L_HD + 16 * fa + r0 + r] = chd[r] + A.hd[r]; }
+            }
             }
         }
         __syncthreads();
@@ -1014,7 +1056,7 @@ UVS_DEV void lin_assemble(const Ctx& c, const double* x, bool first, double radi
     double gmax = gmax_lm;
     if (tid < UVS_RD) {
         const int k = tid & 15;
-        if (k < 15) {
+        if (k < 15 || (h.td_on && tid == UVS_TD_INDEX)) {
             const double hd = sh[L_HD + tid];
             if (first) sh[L_SC + tid] = c.o.jacobi ? 1.0 / (1.0 + sqrt(hd)) : 1.0;
             const double sc = sh[L_SC + tid];
@@ -1059,7 +1101,8 @@ UVS_DEV void backsub_candidate(const Ctx& c, const double* invd, const double* l
     const int tid = threadIdx.x;
     const double* d = sh + L_DLT;
     double gd = 0.0, dd2 = 0.0, step2 = 0.0, xc2 = 0.0;
-    if (with_frames && tid < UVS_RD && (tid & 15) < 15) { gd += sh[L_G + tid] * d[tid]; dd2 += sh[L_DD + tid] * d[tid] * d[tid]; }
+    const bool td_on = h.td_on != 0;
+    if (with_frames && tid < UVS_RD && ((tid & 15) < 15 || (td_on && tid == UVS_TD_INDEX))) { gd += sh[L_G + tid] * d[tid]; dd2 += sh[L_DD + tid] * d[tid] * d[tid]; }
     if (with_frames && tid < UVS_NF) {
         double xp[7];
         pose_plus(sh + L_X + 7 * tid, d + 16 * tid, xp);
@@ -1068,13 +1111,18 @@ UVS_DEV void backsub_candidate(const Ctx& c, const double* invd, const double* l
 #pragma unroll
         for (int k = 0; k < 9; ++k) { const double v = sh[L_X + 77 + 9 * tid + k] + d[16 * tid + 6 + k]; sh[L_XC + 77 + 9 * tid + k] = v; step2 += d[16 * tid + 6 + k] * d[16 * tid + 6 + k]; xc2 += v * v; }
     }
-    if (with_frames && tid == UVS_NF) { for (int k = 0; k < 8; ++k) sh[L_XC + 176 + k] = sh[L_X + 176 + k]; }   // Ex_Pose constant (ESTIMATE_EXTRINSIC=0)
+    if (with_frames && tid == UVS_NF) {   // Ex_Pose constant (ESTIMATE_EXTRINSIC=0); para_Td moves only with ESTIMATE_TD
+        for (int k = 0; k < 7; ++k) sh[L_XC + 176 + k] = sh[L_X + 176 + k];
+        const double dtd = td_on ? d[UVS_TD_INDEX] : 0.0, tdc = sh[L_X + 183] + dtd;
+        sh[L_XC + 183] = tdc;
+        if (td_on) { step2 += dtd * dtd; xc2 += tdc * tdc; }
+    }
     // points: delta = -ginv - sum_s Einv[s] . delta_pose(frame(s))
     const int* pbeg = c.bi + h.i_pt_beg;
     for (int k = pk0 + tid; k < pk1; k += NT) {
         const int b0 = pbeg[k], b1 = pbeg[k + 1];
         const double* px = c.ws + h.w_pt_x + 4 * (size_t)k;
-        const double* Eg = c.ws + h.w_pt_E + 6 * (size_t)(b0 + k);
+        const double* Eg = c.ws + h.w_pt_E + 6 * (size_t)(b0 + h.pt_xslots * k);
         double t = 0.0;      // Einv . delta_pose  (the landmark's share of the frame step)
         if (b1 > b0) {
             const int fi = c.bi[h.i_pt_fi + b0];
@@ -1086,6 +1134,7 @@ UVS_DEV void backsub_candidate(const Ctx& c, const double* invd, const double* l
 #pragma unroll
                 for (int a = 0; a < 6; ++a) t += e[a] * d[16 * fj + a];
             }
+            if (td_on) t += Eg[6 * (b1 - b0 + 1)] * d[UVS_TD_INDEX];
         }
         const double dl = -px[0] - t;
         const double v = invd[k] + dl;
@@ -1132,6 +1181,7 @@ UVS_DEV double ambient_sqnorm(const Ctx& c, const double* x, const double* invd,
     const int tid = threadIdx.x;
     double s = 0.0;
     if (tid < 176) s += x[tid] * x[tid];
+    if (tid == 183 && h.td_on) s += x[183] * x[183];
     for (int k = tid; k < h.n_points; k += NT) s += invd[k] * invd[k];
     for (int k = tid; k < 4 * h.n_lines; k += NT) s += line[k] * line[k];
     double s4[4] = {s, 0, 0, 0}, mx = 0.0;
@@ -1252,7 +1302,7 @@ __global__ __launch_bounds__(NT) void k_solve(char* blobs, const long long* blob
     const DevWin& h = *c.hdr;
     uvs_report* rep = reports + wdx;
     // ---- init: frames -> LDS, landmark parameters -> workspace buffer 0
-    if (tid < 184) sh[L_X + tid] = (tid < 183) ? c.bd[h.d_frames + tid] : 0.0;
+    if (tid < 184) sh[L_X + tid] = c.bd[h.d_frames + tid];      // pose[77] sb[99] ex[7] td
     for (int k = tid; k < h.n_points; k += NT) c.ws[h.w_invd0 + k] = c.bd[h.d_invd + k];
     for (int k = tid; k < 4 * h.n_lines; k += NT) c.ws[h.w_line0 + k] = c.bd[h.d_line + k];
     for (int i = tid; i < (int)(sizeof(uvs_report) / 4); i += NT) ((int*)rep)[i] = 0;

@@ -115,7 +115,7 @@ int uvs_reduced_dim(const uvs_options* o) { return 15 * UVS_NUM_FRAMES + ((o && 
 int uvs_create(const uvs_options* opts, int device, int max_batch, int max_points, int max_point_obs, int max_lines,
                int max_line_obs, uvs_solver** out) {
     if (!opts || !out || max_batch < 1 || max_points < 0 || max_point_obs < 0 || max_lines < 0 || max_line_obs < 0) return UVS_ERR_INVALID_ARG;
-    if (opts->estimate_td || opts->estimate_extrinsic) return UVS_ERR_UNSUPPORTED;
+    if (opts->estimate_extrinsic) return UVS_ERR_UNSUPPORTED;
     if (opts->max_num_iterations < 0) return UVS_ERR_INVALID_ARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return UVS_ERR_NO_DEVICE;
@@ -180,7 +180,6 @@ static int validate_window(const uvs_window* w, std::string& err) {
         const uvs_prior& p = *w->prior;
         if (p.n > UVS_MAX_PRIOR_DIM || p.n_blocks < 1 || p.n_blocks > UVS_MAX_PRIOR_BLOCKS) { err = "prior too large"; return UVS_ERR_CAPACITY; }
         for (int b = 0; b < p.n_blocks; ++b) {
-            if (p.block_kind[b] == UVS_BLOCK_TD) { err = "td block in prior"; return UVS_ERR_UNSUPPORTED; }
             const int loc = p.block_size[b] == 7 ? 6 : p.block_size[b];
             if (p.block_idx[b] < 0 || p.block_idx[b] + loc > p.n) { err = "prior block index out of range"; return UVS_ERR_INVALID_ARG; }
             if ((p.block_kind[b] == UVS_BLOCK_POSE || p.block_kind[b] == UVS_BLOCK_SPEEDBIAS) && (p.block_frame[b] < 0 || p.block_frame[b] >= UVS_NUM_FRAMES)) { err = "prior frame out of range"; return UVS_ERR_INVALID_ARG; }
@@ -190,14 +189,18 @@ static int validate_window(const uvs_window* w, std::string& err) {
 }
 
 // appends the blob of `w` to `out` (8-byte aligned) and returns its header
-static int pack_window(const uvs_window* w, std::vector<char>& out, DevWin& hdr, std::string& err) {
+static int pack_window(const uvs_window* w, const uvs_options& opts, std::vector<char>& out, DevWin& hdr, std::string& err) {
     int rc = validate_window(w, err);
     if (rc != UVS_OK) return rc;
+    const bool td_on = opts.estimate_td != 0;
+    if (td_on && w->n_point_obs > 0 && (!w->pt_vel_i || !w->pt_vel_j || !w->pt_td_i || !w->pt_td_j)) { err = "estimate_td needs pt_vel_i / pt_vel_j / pt_td_i / pt_td_j"; return UVS_ERR_INVALID_ARG; }
     DevWin h; std::memset(&h, 0, sizeof(h));
     h.n_points = w->n_points; h.n_pt_obs = w->n_point_obs; h.n_lines = w->n_lines; h.n_ln_obs = w->n_line_obs; h.n_imu = w->n_imu;
     const bool have_prior = w->prior && w->prior->n > 0;
     h.prior_n = have_prior ? w->prior->n : 0; h.prior_nb = have_prior ? w->prior->n_blocks : 0;
     h.pt_stride = rup(std::max(h.n_pt_obs, 1), 8); h.ln_stride = rup(std::max(h.n_ln_obs, 1), 8);
+    h.td_on = td_on ? 1 : 0; h.pt_rec = td_on ? UVS_PT_REC_TD : UVS_PT_REC; h.pt_xslots = td_on ? 2 : 1;
+    const int PREC = h.pt_rec, XS = h.pt_xslots;
     // CSR by landmark
     std::vector<int> pbeg(h.n_points + 1, 0), lbeg(h.n_lines + 1, 0);
     for (int k = 0; k < h.n_pt_obs; ++k) pbeg[w->pt_lm[k] + 1]++;
@@ -212,9 +215,9 @@ static int pack_window(const uvs_window* w, std::vector<char>& out, DevWin& hdr,
         // LDS doubles a chunk of landmarks [k0, k1) needs (records + Schur factors + gather lists), -1 if an index field overflows
         auto need_pt = [&](int k0, int k1) -> long {
             long nob = pbeg[k1] - pbeg[k0], nlm = k1 - k0, nli = list_hdr;
-            for (int k = k0; k < k1; ++k) { const long no = pbeg[k + 1] - pbeg[k]; nli += no ? (no + 1) * (no + 2) / 2 + 3 * no : 0; }
-            if (nlm > 1023 || nob + nlm > 16383) return -1;
-            return (long)UVS_PT_REC * nob + 12 * (nob + nlm) + (nli + 1) / 2;
+            for (int k = k0; k < k1; ++k) { const long no = pbeg[k + 1] - pbeg[k]; nli += no ? (no + XS) * (no + XS + 1) / 2 + 3 * no * XS : 0; }
+            if (nlm > 1023 || nob + XS * nlm > 16383) return -1;
+            return (long)PREC * nob + 12 * (nob + XS * nlm) + (nli + 1) / 2;
         };
         auto need_ln = [&](int k0, int k1) -> long {
             long nob = lbeg[k1] - lbeg[k0], nlm = k1 - k0, nli = list_hdr;
@@ -250,29 +253,35 @@ static int pack_window(const uvs_window* w, std::vector<char>& out, DevWin& hdr,
     //   Schur entry : offset(E row of frame a) | offset(EI / Y row of frame b) << 16
     //   direct entry: points: offset(first Jacobian block) | offset(second) << 16   (A^T A, B^T B, B^T A) ; lines: record offset
     const int n_ch = (int)chunks.size() / 6;
-    std::vector<std::vector<std::vector<int>>> sch(n_ch, std::vector<std::vector<int>>(UVS_NBLK)), dir(n_ch, std::vector<std::vector<int>>(UVS_NBLK));
-    std::vector<long> blk_work(UVS_NBLK, 0), blk_s(UVS_NBLK, 0), blk_d(UVS_NBLK, 0);
-    auto blk_of = [](int fa, int fb) { return fa * (fa + 1) / 2 + fb; };   // fa >= fb
+    std::vector<std::vector<std::vector<int>>> sch(n_ch, std::vector<std::vector<int>>(UVS_NBLKX)), dir(n_ch, std::vector<std::vector<int>>(UVS_NBLKX));
+    std::vector<long> blk_work(UVS_NBLKX, 0), blk_s(UVS_NBLKX, 0), blk_d(UVS_NBLKX, 0);
+    auto blk_of = [](int fa, int fb) { return fa * (fa + 1) / 2 + fb; };   // fa >= fb ; fa == 11 is the time-offset pseudo frame: 66 + fb
     for (int qc = 0; qc < n_ch; ++qc) {
         const int type = chunks[6 * qc], k0 = chunks[6 * qc + 1], k1 = chunks[6 * qc + 2];
         auto& S = sch[qc]; auto& Dr = dir[qc];
         if (type == 0) {
             const int o0 = pbeg[k0], nob = pbeg[k1] - o0, nlm = k1 - k0;
-            const int oE = nob * UVS_PT_REC, oEI = oE + 6 * (nob + nlm);
+            const int oE = nob * PREC, oEI = oE + 6 * (nob + XS * nlm);
             for (int k = k0; k < k1; ++k) {
                 const int li = k - k0, b0 = pbeg[k] - o0, b1 = pbeg[k + 1] - o0;
                 if (b1 == b0) continue;
-                const int first_slot = b0 + li;
-                int fr[UVS_NUM_FRAMES + 1], nf = 0;
+                const int first_slot = b0 + XS * li;
+                int fr[UVS_NUM_FRAMES + 2], nf = 0;
                 fr[nf++] = w->pt_fi[o0 + b0];
                 for (int o = b0; o < b1; ++o) fr[nf++] = w->pt_fj[o0 + o];
+                if (td_on) fr[nf++] = UVS_NUM_FRAMES;                                  // last slot: the td row of this landmark
                 for (int sa = 0; sa < nf; ++sa) for (int sb = 0; sb <= sa; ++sb)      // frames increase with the slot => fr[sa] >= fr[sb]
                     S[blk_of(fr[sa], fr[sb])].push_back((oE + 6 * (first_slot + sa)) | ((oEI + 6 * (first_slot + sb)) << 16));
                 for (int o = b0; o < b1; ++o) {
-                    const int fi = w->pt_fi[o0 + o], fj = w->pt_fj[o0 + o], ro = o * UVS_PT_REC;
+                    const int fi = w->pt_fi[o0 + o], fj = w->pt_fj[o0 + o], ro = o * PREC;
                     Dr[blk_of(fi, fi)].push_back((ro + UVS_PT_A) | ((ro + UVS_PT_A) << 16));
                     Dr[blk_of(fj, fj)].push_back((ro + UVS_PT_B) | ((ro + UVS_PT_B) << 16));
                     Dr[blk_of(fj, fi)].push_back((ro + UVS_PT_B) | ((ro + UVS_PT_A) << 16));
+                    if (td_on) {                                                       // J_td^T [A | B | J_td]
+                        Dr[blk_of(UVS_NUM_FRAMES, fi)].push_back((ro + UVS_PT_TD) | ((ro + UVS_PT_A) << 16));
+                        Dr[blk_of(UVS_NUM_FRAMES, fj)].push_back((ro + UVS_PT_TD) | ((ro + UVS_PT_B) << 16));
+                        Dr[blk_of(UVS_NUM_FRAMES, UVS_NUM_FRAMES)].push_back((ro + UVS_PT_TD) | ((ro + UVS_PT_TD) << 16));
+                    }
                 }
             }
         } else {
@@ -286,38 +295,38 @@ static int pack_window(const uvs_window* w, std::vector<char>& out, DevWin& hdr,
             }
         }
         // work units = FP64 FMAs per lane and entry of the rows-per-lane gather (the loops are FMA-issue bound)
-        for (int b = 0; b < UVS_NBLK; ++b) { blk_s[b] += (type == 0 ? 18 : 72) * (long)S[b].size(); blk_d[b] += (type == 0 ? 54 : 63) * (long)Dr[b].size(); }
+        for (int b = 0; b < UVS_NBLKX; ++b) { blk_s[b] += (type == 0 ? 18 : 72) * (long)S[b].size(); blk_d[b] += (type == 0 ? 54 : 63) * (long)Dr[b].size(); }
     }
     // gather groups: 256 two-lane groups, at least one per pose block; the spare ones split the heaviest blocks further.  Groups are dealt to
     // the waves heaviest first (similar list lengths inside a wave => little divergence); the wave order pairs heavy with light
     // waves on a SIMD (waves w and w+4 share one).
     int wblk[UVS_NGRP], g_blk[UVS_NGRP], g_part[UVS_NGRP], g_np[UVS_NGRP];
     {
-        for (int b = 0; b < UVS_NBLK; ++b) blk_work[b] = blk_s[b] + blk_d[b];
+        for (int b = 0; b < UVS_NBLKX; ++b) blk_work[b] = blk_s[b] + blk_d[b];
         struct Item { int b, part, np; long work; double shape; };
         // water-filling: hand the spare groups, one at a time, to the block whose per-group share is largest (at most 16 parts)
-        int np[UVS_NBLK]; int used = UVS_NBLK;
-        for (int b = 0; b < UVS_NBLK; ++b) np[b] = 1;
+        int np[UVS_NBLKX]; int used = 0;
+        for (int b = 0; b < UVS_NBLKX; ++b) { np[b] = (b < UVS_NBLK || td_on) ? 1 : 0; used += np[b]; }      // the td row blocks only exist with ESTIMATE_TD
         while (used < UVS_NGRP) {
             int best = -1;
-            for (int b = 0; b < UVS_NBLK; ++b) if (np[b] < 16 && blk_work[b] > 0 && (best < 0 || blk_work[b] * np[best] > blk_work[best] * np[b])) best = b;
+            for (int b = 0; b < UVS_NBLKX; ++b) if (np[b] < 16 && blk_work[b] > 0 && (best < 0 || blk_work[b] * np[best] > blk_work[best] * np[b])) best = b;
             if (best < 0) break;
             ++np[best]; ++used;
         }
         std::vector<Item> items;
-        for (int b = 0; b < UVS_NBLK; ++b) for (int q = 0; q < np[b]; ++q) items.push_back({b, q, np[b], blk_work[b] / np[b], blk_work[b] ? (double)blk_d[b] / (double)blk_work[b] : -1.0});
+        for (int b = 0; b < UVS_NBLKX; ++b) for (int q = 0; q < np[b]; ++q) items.push_back({b, q, np[b], blk_work[b] / np[b], blk_work[b] ? (double)blk_d[b] / (double)blk_work[b] : -1.0});
         // a wave runs max(Schur count) + max(direct count) iterations over its 32 groups: deal groups of similar SHAPE (share of
         // direct work) to the same wave, idle groups last
         std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b2) { return a.shape != b2.shape ? a.shape > b2.shape : a.work > b2.work; });
         int wave_of_rank[NW];
         for (int r = 0; r < NW; ++r) wave_of_rank[r] = r < 4 ? r : NW - 1 - (r - 4);
         h.n_parts = 1;
-        for (int b = 0; b < UVS_NBLK; ++b) h.n_parts = std::max(h.n_parts, np[b]);
+        for (int b = 0; b < UVS_NBLKX; ++b) h.n_parts = std::max(h.n_parts, np[b]);
         for (int g = 0; g < UVS_NGRP; ++g) { wblk[g] = -1; g_blk[g] = -1; g_part[g] = 0; g_np[g] = 1; }
         for (size_t q = 0; q < items.size(); ++q) {
             const int g = wave_of_rank[q / GRP_PER_WAVE] * GRP_PER_WAVE + (int)(q % GRP_PER_WAVE);
             const int b = items[q].b;
-            const int bfa = (int)((std::sqrt(8.0 * b + 1.0) - 1.0) * 0.5 + 1e-9), bfb = b - bfa * (bfa + 1) / 2;     // b = fa(fa+1)/2 + fb
+            const int bfa = b >= UVS_NBLK ? UVS_NUM_FRAMES : (int)((std::sqrt(8.0 * b + 1.0) - 1.0) * 0.5 + 1e-9), bfb = b - bfa * (bfa + 1) / 2;     // b = fa(fa+1)/2 + fb
             wblk[g] = b | (bfa == bfb ? 256 : 0) | (items[q].part << 9) | (bfa << 13) | (bfb << 17);
             g_blk[g] = b; g_part[g] = items[q].part; g_np[g] = items[q].np;
         }
@@ -356,6 +365,7 @@ static int pack_window(const uvs_window* w, std::vector<char>& out, DevWin& hdr,
     h.d_frames = d; d += 184;
     h.d_invd = d; d += rup(std::max(h.n_points, 1), 2);
     h.d_ptmeas = d; d += 6 * h.pt_stride;
+    h.d_ptvel = d; d += td_on ? 6 * h.pt_stride : 0;
     h.d_line = d; d += 4 * std::max(h.n_lines, 1);
     h.d_lnmeas = d; d += 9 * h.ln_stride;
     h.d_imu = d; d += std::max(h.n_imu, 1) * UVS_IMU_STRIDE;
@@ -374,7 +384,7 @@ static int pack_window(const uvs_window* w, std::vector<char>& out, DevWin& hdr,
     h.w_invd0 = wsz; wsz += rup(std::max(h.n_points, 1), 2); h.w_invd1 = wsz; wsz += rup(std::max(h.n_points, 1), 2);
     h.w_line0 = wsz; wsz += 4 * std::max(h.n_lines, 1); h.w_line1 = wsz; wsz += 4 * std::max(h.n_lines, 1);
     h.w_scale_pt = wsz; wsz += rup(std::max(h.n_points, 1), 2); h.w_scale_ln = wsz; wsz += 4 * std::max(h.n_lines, 1);
-    h.w_pt_E = wsz; wsz += 6 * (h.n_pt_obs + h.n_points) + 6; h.w_pt_x = wsz; wsz += 4 * std::max(h.n_points, 1);
+    h.w_pt_E = wsz; wsz += 6 * (h.n_pt_obs + XS * h.n_points) + 6; h.w_pt_x = wsz; wsz += 4 * std::max(h.n_points, 1);
     h.w_ln_Y = wsz; wsz += 24 * std::max(h.n_ln_obs, 1); h.w_ln_x = wsz; wsz += 12 * std::max(h.n_lines, 1);
     h.w_imu = wsz; wsz += std::max(h.n_imu, 1) * UVS_WIMU_STRIDE;
     h.w_out = wsz; wsz += 184;
@@ -384,6 +394,7 @@ static int pack_window(const uvs_window* w, std::vector<char>& out, DevWin& hdr,
         bool in[UVS_NUM_FRAMES] = {false};
         for (int b = 0; b < w->prior->n_blocks; ++b)
             if (w->prior->block_kind[b] == UVS_BLOCK_POSE || w->prior->block_kind[b] == UVS_BLOCK_SPEEDBIAS) in[w->prior->block_frame[b]] = true;
+            else if (w->prior->block_kind[b] == UVS_BLOCK_TD && td_on) in[UVS_NUM_FRAMES - 1] = true;       // td lives in the last frame's block row
         for (int fa = 0; fa < UVS_NUM_FRAMES; ++fa) for (int fb = 0; fb <= fa; ++fb) if (in[fa] && in[fb]) pblk.push_back(fa * (fa + 1) / 2 + fb);
     }
     h.n_pblk = (int)pblk.size();
@@ -398,10 +409,15 @@ static int pack_window(const uvs_window* w, std::vector<char>& out, DevWin& hdr,
     std::memcpy(D + h.d_frames, w->pose, sizeof(double) * 77);
     std::memcpy(D + h.d_frames + 77, w->speedbias, sizeof(double) * 99);
     std::memcpy(D + h.d_frames + 176, w->ex_pose, sizeof(double) * 7);
+    D[h.d_frames + 183] = w->td;
     for (int k = 0; k < h.n_points; ++k) D[h.d_invd + k] = w->inv_depth[k];
     for (int k = 0; k < h.n_pt_obs; ++k) {
         for (int q = 0; q < 3; ++q) { D[h.d_ptmeas + q * h.pt_stride + k] = w->pt_pi[3 * k + q]; D[h.d_ptmeas + (3 + q) * h.pt_stride + k] = w->pt_pj[3 * k + q]; }
         I[h.i_pt_lm + k] = w->pt_lm[k]; I[h.i_pt_fi + k] = w->pt_fi[k]; I[h.i_pt_fj + k] = w->pt_fj[k];
+        if (td_on) {
+            for (int q = 0; q < 2; ++q) { D[h.d_ptvel + q * h.pt_stride + k] = w->pt_vel_i[2 * k + q]; D[h.d_ptvel + (2 + q) * h.pt_stride + k] = w->pt_vel_j[2 * k + q]; }
+            D[h.d_ptvel + 4 * h.pt_stride + k] = w->pt_td_i[k]; D[h.d_ptvel + 5 * h.pt_stride + k] = w->pt_td_j[k];
+        }
     }
     for (int k = 0; k <= h.n_points; ++k) I[h.i_pt_beg + k] = pbeg[k];
     for (int k = 0; k < 4 * h.n_lines; ++k) D[h.d_line + k] = w->line_orth[k];
@@ -437,6 +453,7 @@ static int pack_window(const uvs_window* w, std::vector<char>& out, DevWin& hdr,
             int basecol = -1;
             if (p.block_kind[b] == UVS_BLOCK_POSE) basecol = 16 * p.block_frame[b];
             else if (p.block_kind[b] == UVS_BLOCK_SPEEDBIAS) basecol = 16 * p.block_frame[b] + 6;
+            else if (p.block_kind[b] == UVS_BLOCK_TD && td_on) basecol = UVS_TD_INDEX;
             // Ex_Pose is constant (ESTIMATE_EXTRINSIC == 0): its columns are dropped
             for (int q = 0; q < loc; ++q) pt[80 + p.block_idx[b] + q] = basecol < 0 ? -1 : basecol + q;
             if (basecol >= 0) for (int q = 0; q < loc; ++q) pt[80 + UVS_MAX_PRIOR_DIM + basecol + q] = p.block_idx[b] + q;      // S index -> prior column
@@ -472,7 +489,7 @@ int uvs_batch_upload(uvs_solver* s, int n, const uvs_window* const* ws) {
             s->err = "window exceeds the capacity given to uvs_create (max_points / max_point_obs / max_lines / max_line_obs)"; s->n_loaded = 0; return UVS_ERR_CAPACITY;
         }
         s->blob_off[b] = (long long)s->host_blobs.size();
-        int rc = pack_window(ws[b], s->host_blobs, s->hdrs[b], s->err);
+        int rc = pack_window(ws[b], s->opts, s->host_blobs, s->hdrs[b], s->err);
         if (rc != UVS_OK) { s->n_loaded = 0; return rc; }
         s->ws_off[b] = wtot; wtot += s->hdrs[b].ws_doubles;
     }
@@ -534,7 +551,7 @@ int uvs_batch_download(uvs_solver* s, int n, uvs_state* states, uvs_report* reps
             std::memcpy(st.pose, buf.data() + h.w_out, sizeof(double) * 77);
             std::memcpy(st.speedbias, buf.data() + h.w_out + 77, sizeof(double) * 99);
             std::memcpy(st.ex_pose, buf.data() + h.w_out + 176, sizeof(double) * 7);
-            st.td = 0.0;
+            st.td = buf[h.w_out + 183];
             const int sel = dh.cur_sel;
             if (st.inv_depth) std::memcpy(st.inv_depth, buf.data() + (sel ? h.w_invd1 : h.w_invd0), sizeof(double) * h.n_points);
             if (st.line_orth) std::memcpy(st.line_orth, buf.data() + (sel ? h.w_line1 : h.w_line0), sizeof(double) * 4 * h.n_lines);
@@ -550,7 +567,6 @@ int uvs_solve_window(uvs_solver* s, const uvs_window* w, uvs_state* out, uvs_rep
     if (rc != UVS_OK) return rc;
     rc = launch_solve(s, 0, nullptr);
     if (rc != UVS_OK) return rc;
-    out->td = w->td;
     return uvs_batch_download(s, 1, out, rep);
 }
 
@@ -583,6 +599,7 @@ int uvs_evaluate(uvs_solver* s, const uvs_window* w, int robust, uvs_eval* out) 
 
 int uvs_marginalize(uvs_solver* s, const uvs_window* w, int flag, uvs_prior* out) {
     if (!s || !w || !out || (flag != 0 && flag != 1)) return UVS_ERR_INVALID_ARG;
+    if (s->opts.estimate_td) { s->err = "marginalization does not carry the td block yet"; return UVS_ERR_UNSUPPORTED; }
     const uvs_window* arr[1] = {w};
     int rc = uvs_batch_upload(s, 1, arr);
     if (rc != UVS_OK) return rc;
@@ -612,11 +629,12 @@ int uvs_large_begin(uvs_solver* s, const uvs_window* w) {
     if ((r2 = ensure(s, (void**)&L.d_bsums, &L.cap_bsums, (size_t)std::max(L.n_chunks, 1) * 8 * 8)) != UVS_OK) return r2;
     HIPCHK(s, hipMemsetAsync(L.d_state, 0, LG_STATE * 8, s->stream));
     // frames -> state.X ; landmark parameters -> workspace buffer 0 (device-to-device from the blob)
-    HIPCHK(s, hipMemcpyAsync(L.d_state + LS_X, s->d_blobs + (size_t)h.d_frames * 8, 183 * 8, hipMemcpyDeviceToDevice, s->stream));
+    HIPCHK(s, hipMemcpyAsync(L.d_state + LS_X, s->d_blobs + (size_t)h.d_frames * 8, 184 * 8, hipMemcpyDeviceToDevice, s->stream));
     if (h.n_points) HIPCHK(s, hipMemcpyAsync(s->d_ws + h.w_invd0, s->d_blobs + (size_t)h.d_invd * 8, (size_t)h.n_points * 8, hipMemcpyDeviceToDevice, s->stream));
     if (h.n_lines) HIPCHK(s, hipMemcpyAsync(s->d_ws + h.w_line0, s->d_blobs + (size_t)h.d_line * 8, (size_t)h.n_lines * 32, hipMemcpyDeviceToDevice, s->stream));
     double x2 = 0.0;
     for (int f = 0; f < UVS_NUM_FRAMES; ++f) { for (int k = 0; k < 7; ++k) x2 += w->pose[f][k] * w->pose[f][k]; for (int k = 0; k < 9; ++k) x2 += w->speedbias[f][k] * w->speedbias[f][k]; }
+    if (s->opts.estimate_td) x2 += w->td * w->td;
     double l2 = 0.0;
     for (int k = 0; k < w->n_points; ++k) l2 += w->inv_depth[k] * w->inv_depth[k];
     for (int k = 0; k < 4 * w->n_lines; ++k) l2 += w->line_orth[k] * w->line_orth[k];
@@ -741,7 +759,7 @@ int uvs_large_finish(uvs_solver* s, uvs_state* out, uvs_report* rep) {
     *rep = L.rep;
     double fr[184];
     HIPCHK(s, hipMemcpy(fr, L.d_state + LS_X, sizeof(fr), hipMemcpyDeviceToHost));
-    std::memcpy(out->pose, fr, 77 * 8); std::memcpy(out->speedbias, fr + 77, 99 * 8); std::memcpy(out->ex_pose, fr + 176, 7 * 8); out->td = 0.0;
+    std::memcpy(out->pose, fr, 77 * 8); std::memcpy(out->speedbias, fr + 77, 99 * 8); std::memcpy(out->ex_pose, fr + 176, 7 * 8); out->td = fr[183];
     if (out->inv_depth && h.n_points) HIPCHK(s, hipMemcpy(out->inv_depth, s->d_ws + (L.sel ? h.w_invd1 : h.w_invd0), (size_t)h.n_points * 8, hipMemcpyDeviceToHost));
     if (out->line_orth && h.n_lines) HIPCHK(s, hipMemcpy(out->line_orth, s->d_ws + (L.sel ? h.w_line1 : h.w_line0), (size_t)h.n_lines * 32, hipMemcpyDeviceToHost));
     L.active = false;

@@ -398,3 +398,24 @@ def shard_landmarks(w: abi.Window, rank: int, world: int):
     o.ln_lm = lmap[w.ln_lm[lo]].astype(np.int32); o.ln_fj = w.ln_fj[lo]; o.ln_sp = w.ln_sp[lo]; o.ln_ep = w.ln_ep[lo]
     o.ln_has_vp = w.ln_has_vp[lo]; o.ln_vp = w.ln_vp[lo]
     return o, np.nonzero(pk)[0], np.nonzero(lk)[0]
+
+
+def add_time_offset(w, td_true=0.004, vel_sigma=0.6, seed=0):
+    """Turns `w` into an ESTIMATE_TD window (ProjectionTdFactor, projection_td_factor.cpp:34-145): every point observation gets an
+    image-plane velocity (normalised units / s; the anchor observation's is shared by the landmark, it is feature_per_frame[0].velocity),
+    cur_td = 0, and the stored observations are displaced by td_true * velocity, so that the factor's time shift
+    pts - (td - cur_td) * velocity recovers the original projection exactly at td = td_true.  The state starts at td = 0."""
+    rng = np.random.default_rng([seed, 77])
+    o = w.copy()
+    n = len(o.pt_lm)
+    v_lm = vel_sigma * rng.standard_normal((len(o.inv_depth), 2))
+    o.pt_vel_i = v_lm[o.pt_lm].copy()
+    o.pt_vel_j = vel_sigma * rng.standard_normal((n, 2))
+    o.pt_td_i = np.zeros(n); o.pt_td_j = np.zeros(n)
+    o.pt_pi = o.pt_pi.copy(); o.pt_pj = o.pt_pj.copy()
+    o.pt_pi[:, :2] += td_true * o.pt_vel_i
+    o.pt_pj[:, :2] += td_true * o.pt_vel_j
+    o.td = 0.0
+    if o.truth is not None:
+        o.truth = dict(o.truth); o.truth["td"] = td_true
+    return o
