@@ -70,9 +70,10 @@ struct MargIds {
     int pose(int f) const { return f; }
     int sb(int f) const { return UVS_NUM_FRAMES + f; }
     int ex() const { return 2 * UVS_NUM_FRAMES; }
-    int pt(int k) const { return 2 * UVS_NUM_FRAMES + 1 + k; }
-    int ln(int l) const { return 2 * UVS_NUM_FRAMES + 1 + Np + l; }
-    int count() const { return 2 * UVS_NUM_FRAMES + 1 + Np + Nl; }
+    int td() const { return 2 * UVS_NUM_FRAMES + 1; }
+    int pt(int k) const { return 2 * UVS_NUM_FRAMES + 2 + k; }
+    int ln(int l) const { return 2 * UVS_NUM_FRAMES + 2 + Np + l; }
+    int count() const { return 2 * UVS_NUM_FRAMES + 2 + Np + Nl; }
 };
 
 // Core of MarginalizationInfo::marginalize(). pos_of[id] = column offset (dropped first), returns m, n, J0 (n x n), r0 (n)

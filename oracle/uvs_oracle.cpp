@@ -492,7 +492,6 @@ static int solve(const uvs_options* opt, const uvs_window* w, int linear_mode, u
 // ---------------------------------------------------------------- marginalization
 // Estimator::optimization(), estimator.cpp:1002-1228 restated on block indices.
 static int marginalize(const uvs_options* opt, const uvs_window* w, int flag, uvs_prior* out) {
-    if (opt->estimate_td) return UVS_ERR_UNSUPPORTED;      // the td block is not carried through the marginalization yet
     Problem pb; init_problem(pb, opt, w);
     State x; init_state(x, w);
     MargIds ids{pb.Np, pb.Nl};
@@ -500,6 +499,7 @@ static int marginalize(const uvs_options* opt, const uvs_window* w, int flag, uv
     std::vector<int> local_size(ids.count(), 0), global_size(ids.count(), 0);
     for (int f = 0; f < UVS_NUM_FRAMES; ++f) { local_size[ids.pose(f)] = 6; global_size[ids.pose(f)] = 7; local_size[ids.sb(f)] = 9; global_size[ids.sb(f)] = 9; }
     local_size[ids.ex()] = 6; global_size[ids.ex()] = 7;
+    local_size[ids.td()] = 1; global_size[ids.td()] = 1;
     for (int k = 0; k < pb.Np; ++k) { local_size[ids.pt(k)] = 1; global_size[ids.pt(k)] = 1; }
     for (int l = 0; l < pb.Nl; ++l) { local_size[ids.ln(l)] = 4; global_size[ids.ln(l)] = 4; }
     std::vector<MargFactor> factors;
@@ -513,11 +513,11 @@ static int marginalize(const uvs_options* opt, const uvs_window* w, int flag, uv
         std::vector<double> dx(n);
         auto get = [&](int kind, int frame) -> const double* {
             switch (kind) { case UVS_BLOCK_POSE: return x.pose[frame]; case UVS_BLOCK_SPEEDBIAS: return x.sb[frame];
-                            case UVS_BLOCK_EX_POSE: return x.ex; default: return &w->td; } };
+                            case UVS_BLOCK_EX_POSE: return x.ex; default: return &x.td; } };
         prior_eval(p, get, dx.data(), f.r.data());
         std::vector<int> src;
         for (int b = 0; b < p.n_blocks; ++b) {
-            int id = p.block_kind[b] == UVS_BLOCK_POSE ? ids.pose(p.block_frame[b]) : p.block_kind[b] == UVS_BLOCK_SPEEDBIAS ? ids.sb(p.block_frame[b]) : ids.ex();
+            int id = p.block_kind[b] == UVS_BLOCK_POSE ? ids.pose(p.block_frame[b]) : p.block_kind[b] == UVS_BLOCK_SPEEDBIAS ? ids.sb(p.block_frame[b]) : p.block_kind[b] == UVS_BLOCK_TD ? ids.td() : ids.ex();
             f.blk.push_back(id); f.bsz.push_back(local_size[id]);
             used[id] = 1; if (is_dropped(p.block_kind[b], p.block_frame[b])) dropped[id] = 1;
             for (int k = 0; k < local_size[id]; ++k) src.push_back(p.block_idx[b] + k);
@@ -543,10 +543,19 @@ static int marginalize(const uvs_options* opt, const uvs_window* w, int flag, uv
         for (int k = 0; k < w->n_point_obs; ++k) {                                                                   // :1037-1080
             if (w->pt_fi[k] != 0) continue;
             const int lm = w->pt_lm[k], fj = w->pt_fj[k];
-            MargFactor f; f.rows = 2; f.r.resize(2); f.J.resize(38);
-            point_eval(x.pose[0], x.pose[fj], x.ex, x.invd[lm], w->pt_pi + 3 * k, w->pt_pj + 3 * k, o->point_sqrt_info, f.r.data(), f.J.data());
-            cauchy_correct(o->loss_point, 2, 19, f.r.data(), f.J.data());
-            f.blk = {ids.pose(0), ids.pose(fj), ids.ex(), ids.pt(lm)}; f.bsz = {6, 6, 6, 1};
+            MargFactor f; f.rows = 2; f.r.resize(2);
+            if (pb.td_free) {      // ProjectionTdFactor with its fifth block td, which is kept (estimator.cpp:1062-1070: drop_set {0, 3})
+                f.J.resize(40);
+                point_td_eval(x.pose[0], x.pose[fj], x.ex, x.invd[lm], w->pt_pi + 3 * k, w->pt_pj + 3 * k, w->pt_vel_i + 2 * k, w->pt_vel_j + 2 * k,
+                              w->pt_td_i[k], w->pt_td_j[k], x.td, o->point_sqrt_info, f.r.data(), f.J.data());
+                cauchy_correct(o->loss_point, 2, 20, f.r.data(), f.J.data());
+                f.blk = {ids.pose(0), ids.pose(fj), ids.ex(), ids.pt(lm), ids.td()}; f.bsz = {6, 6, 6, 1, 1};
+            } else {
+                f.J.resize(38);
+                point_eval(x.pose[0], x.pose[fj], x.ex, x.invd[lm], w->pt_pi + 3 * k, w->pt_pj + 3 * k, o->point_sqrt_info, f.r.data(), f.J.data());
+                cauchy_correct(o->loss_point, 2, 19, f.r.data(), f.J.data());
+                f.blk = {ids.pose(0), ids.pose(fj), ids.ex(), ids.pt(lm)}; f.bsz = {6, 6, 6, 1};
+            }
             for (int id : f.blk) used[id] = 1;
             dropped[ids.pose(0)] = 1; dropped[ids.pt(lm)] = 1;                                                     // drop_set {0,3}
             factors.push_back(std::move(f));
@@ -597,10 +606,11 @@ static int marginalize(const uvs_options* opt, const uvs_window* w, int flag, uv
         int kind, frame = 0; const double* data;
         if (id < UVS_NUM_FRAMES) { kind = UVS_BLOCK_POSE; frame = id; data = x.pose[frame]; }
         else if (id < 2 * UVS_NUM_FRAMES) { kind = UVS_BLOCK_SPEEDBIAS; frame = id - UVS_NUM_FRAMES; data = x.sb[frame]; }
+        else if (id == ids.td()) { kind = UVS_BLOCK_TD; data = &x.td; }
         else { kind = UVS_BLOCK_EX_POSE; data = x.ex; }
         // addr_shift (estimator.cpp:1139-1152 / :1196-1219)
         int nf = frame;
-        if (kind != UVS_BLOCK_EX_POSE) { if (flag == 0) nf = frame - 1; else nf = (frame == UVS_WINDOW_SIZE) ? frame - 1 : frame; }
+        if (kind == UVS_BLOCK_POSE || kind == UVS_BLOCK_SPEEDBIAS) { if (flag == 0) nf = frame - 1; else nf = (frame == UVS_WINDOW_SIZE) ? frame - 1 : frame; }
         out->block_kind[b] = kind; out->block_frame[b] = nf; out->block_size[b] = global_size[id];
         out->block_idx[b] = pos_of[id] - m; out->x0_off[b] = xo;
         for (int k = 0; k < global_size[id]; ++k) out->x0[xo + k] = data[k];

@@ -16,6 +16,7 @@ MAX_PRIOR_BLOCKS = 16
 MAX_PRIOR_DIM = 96
 
 UVS_OK, UVS_ERR_INVALID_ARG, UVS_ERR_UNSUPPORTED, UVS_ERR_NO_DEVICE, UVS_ERR_HIP, UVS_ERR_CAPACITY, UVS_ERR_NUMERIC = range(7)
+UVS_BLOCK_POSE, UVS_BLOCK_SPEEDBIAS, UVS_BLOCK_EX_POSE, UVS_BLOCK_TD = range(4)      # uvs_prior.block_kind
 TERM_NAMES = ["NO_CONVERGENCE", "GRADIENT_TOL", "PARAMETER_TOL", "FUNCTION_TOL", "MIN_RADIUS", "INVALID_STEPS", "NUMERIC_FAILURE"]
 BLOCK_POSE, BLOCK_SPEEDBIAS, BLOCK_EX_POSE, BLOCK_TD = range(4)
 
@@ -226,12 +227,15 @@ class Window:
         pnb = self.prior.n_blocks if pn else 0
         with open(path, "wb") as f:
             f.write(b"UVSWIN01")
-            f.write(i32([len(self.inv_depth), npo, len(self.line_orth), nlo, len(self.imu), pn, pnb, 0]))
+            has_td = self.pt_vel_i is not None
+            f.write(i32([len(self.inv_depth), npo, len(self.line_orth), nlo, len(self.imu), pn, pnb, 1 if has_td else 0]))
             f.write(f64(self.pose)); f.write(f64(self.speedbias)); f.write(f64(self.ex_pose)); f.write(f64([self.td]))
             f.write(f64(self.inv_depth))
             f.write(i32(self.pt_lm)); f.write(i32(self.pt_fi)); f.write(i32(self.pt_fj))
             if npo % 2: f.write(i32([0]))
             f.write(f64(self.pt_pi)); f.write(f64(self.pt_pj))
+            if has_td:      # ProjectionTdFactor inputs (header word 8 = 1)
+                f.write(f64(self.pt_vel_i)); f.write(f64(self.pt_vel_j)); f.write(f64(self.pt_td_i)); f.write(f64(self.pt_td_j))
             f.write(f64(self.line_orth))
             f.write(i32(self.ln_lm)); f.write(i32(self.ln_fj)); f.write(i32(self.ln_has_vp))
             if nlo % 2: f.write(i32([0]))

@@ -44,24 +44,25 @@ static void host_sym_eig(int n, std::vector<double>& M, std::vector<double>& V, 
     for (int i = 0; i < n; ++i) lam[i] = M[(size_t)i * n + i];
 }
 
-struct MFactor { int rows; int nb; int id[4]; int sz[4]; const double* r; const double* J; int ld; int coff[4]; };   // J row stride ld, column offset per block
+struct MFactor { int rows; int nb; int id[5]; int sz[5]; const double* r; const double* J; int ld; int coff[5]; const double* Jx; int xcol; };   // J row stride ld, column offset per block; block with coff < 0 reads its single column from Jx[row stride 1... 2 entries]   // J row stride ld, column offset per block
 
 static int run_marginalize(int device, hipStream_t stream, char* d_blob, double* d_ws, const DevWin& h, const uvs_window* w, const KOpts& ko,
                            int flag, uvs_prior* out, std::string& err) {
+    const bool td_on = h.td_on != 0;
     const double eps = 1e-8;                           // marginalization_factor.h:70
     const int NFR = UVS_NF;
     // ---- GPU: evaluate all blocks with loss correction at the window's (post-solve) state
     std::vector<double> pt_r(2 * (size_t)std::max(h.n_pt_obs, 1)), pt_J(38 * (size_t)std::max(h.n_pt_obs, 1)), ln_r(2 * (size_t)std::max(h.n_ln_obs, 1)),
         ln_J(20 * (size_t)std::max(h.n_ln_obs, 1)), vp_r((size_t)std::max(h.n_ln_obs, 1)), vp_J(10 * (size_t)std::max(h.n_ln_obs, 1)),
-        imu_r(15 * (size_t)std::max(h.n_imu, 1)), imu_J(450 * (size_t)std::max(h.n_imu, 1)), prior_r(UVS_MAX_PRIOR_DIM);
+        imu_r(15 * (size_t)std::max(h.n_imu, 1)), imu_J(450 * (size_t)std::max(h.n_imu, 1)), prior_r(UVS_MAX_PRIOR_DIM), pt_Jtd(2 * (size_t)std::max(h.n_pt_obs, 1));
     uvs_eval ev; ev.pt_r = pt_r.data(); ev.pt_J = pt_J.data(); ev.ln_r = ln_r.data(); ev.ln_J = ln_J.data(); ev.vp_r = vp_r.data(); ev.vp_J = vp_J.data();
-    ev.imu_r = imu_r.data(); ev.imu_J = imu_J.data(); ev.prior_r = prior_r.data(); ev.cost = 0.0; ev.pt_Jtd = nullptr;
+    ev.imu_r = imu_r.data(); ev.imu_J = imu_J.data(); ev.prior_r = prior_r.data(); ev.cost = 0.0; ev.pt_Jtd = td_on ? pt_Jtd.data() : nullptr;
     int rc = run_evaluate(device, stream, d_blob, d_ws, h, ko, 1, &ev, err);
     if (rc != UVS_OK) return rc;
-    // ---- host: block bookkeeping.  ids: pose f -> f ; speedbias f -> 11+f ; ex -> 22 ; point k -> 23+k ; line l -> 23+Np+l
-    const int Np = w->n_points, Nl = w->n_lines, NID = 23 + Np + Nl;
-    auto lsize = [&](int id) { return id < NFR ? 6 : id < 2 * NFR ? 9 : id == 22 ? 6 : id < 23 + Np ? 1 : 4; };
-    auto gsize = [&](int id) { return id < NFR ? 7 : id < 2 * NFR ? 9 : id == 22 ? 7 : id < 23 + Np ? 1 : 4; };
+    // ---- host: block bookkeeping.  ids: pose f -> f ; speedbias f -> 11+f ; ex -> 22 ; td -> 23 ; point k -> 24+k ; line l -> 24+Np+l
+    const int Np = w->n_points, Nl = w->n_lines, PT0 = 24, NID = PT0 + Np + Nl;
+    auto lsize = [&](int id) { return id < NFR ? 6 : id < 2 * NFR ? 9 : id == 22 ? 6 : id == 23 ? 1 : id < PT0 + Np ? 1 : 4; };
+    auto gsize = [&](int id) { return id < NFR ? 7 : id < 2 * NFR ? 9 : id == 22 ? 7 : id == 23 ? 1 : id < PT0 + Np ? 1 : 4; };
     std::vector<char> used(NID, 0), drop(NID, 0);
     std::vector<MFactor> fs;
     const bool have_prior = w->prior && w->prior->n > 0;
@@ -84,7 +85,7 @@ static int run_marginalize(int device, hipStream_t stream, char* d_blob, double*
             if (!use) { *out = p; return UVS_OK; }
         }
         for (int b = 0; b < p.n_blocks; ++b) {
-            const int id = p.block_kind[b] == UVS_BLOCK_POSE ? p.block_frame[b] : p.block_kind[b] == UVS_BLOCK_SPEEDBIAS ? NFR + p.block_frame[b] : 22;
+            const int id = p.block_kind[b] == UVS_BLOCK_POSE ? p.block_frame[b] : p.block_kind[b] == UVS_BLOCK_SPEEDBIAS ? NFR + p.block_frame[b] : p.block_kind[b] == UVS_BLOCK_TD ? 23 : 22;
             used[id] = 1;
             if (flag == 0 && (id == 0 || id == NFR)) drop[id] = 1;                        // drop Pose[0], SpeedBias[0]  (:1008-1015)
             if (flag == 1 && id == UVS_WINDOW_SIZE - 1) drop[id] = 1;                     // drop Pose[9]               (:1170-1176)
@@ -94,7 +95,7 @@ static int run_marginalize(int device, hipStream_t stream, char* d_blob, double*
     if (flag == 0) {
         for (int b = 0; b < w->n_imu; ++b) {                                                // :1026-1035
             if (w->imu[b].frame_i != 0 || !(w->imu[b].sum_dt < 10.0)) continue;
-            MFactor f; f.rows = 15; f.nb = 4; f.id[0] = 0; f.id[1] = NFR; f.id[2] = 1; f.id[3] = NFR + 1; f.sz[0] = 6; f.sz[1] = 9; f.sz[2] = 6; f.sz[3] = 9;
+            MFactor f; f.Jx = nullptr; f.xcol = -1; f.rows = 15; f.nb = 4; f.id[0] = 0; f.id[1] = NFR; f.id[2] = 1; f.id[3] = NFR + 1; f.sz[0] = 6; f.sz[1] = 9; f.sz[2] = 6; f.sz[3] = 9;
             f.coff[0] = 0; f.coff[1] = 6; f.coff[2] = 15; f.coff[3] = 21; f.r = &imu_r[15 * (size_t)b]; f.J = &imu_J[450 * (size_t)b]; f.ld = 30;
             for (int q = 0; q < 4; ++q) used[f.id[q]] = 1;
             drop[0] = 1; drop[NFR] = 1;
@@ -102,10 +103,11 @@ static int run_marginalize(int device, hipStream_t stream, char* d_blob, double*
         }
         for (int k = 0; k < w->n_point_obs; ++k) {                                          // :1037-1080
             if (w->pt_fi[k] != 0) continue;
-            MFactor f; f.rows = 2; f.nb = 4; f.id[0] = 0; f.id[1] = w->pt_fj[k]; f.id[2] = 22; f.id[3] = 23 + w->pt_lm[k];
+            MFactor f; f.Jx = nullptr; f.xcol = -1; f.rows = 2; f.nb = 4; f.id[0] = 0; f.id[1] = w->pt_fj[k]; f.id[2] = 22; f.id[3] = PT0 + w->pt_lm[k];
             f.sz[0] = 6; f.sz[1] = 6; f.sz[2] = 6; f.sz[3] = 1; f.coff[0] = 0; f.coff[1] = 6; f.coff[2] = 12; f.coff[3] = 18;
             f.r = &pt_r[2 * (size_t)k]; f.J = &pt_J[38 * (size_t)k]; f.ld = 19;
-            for (int q = 0; q < 4; ++q) used[f.id[q]] = 1;
+            if (td_on) { f.nb = 5; f.id[4] = 23; f.sz[4] = 1; f.coff[4] = -1; f.Jx = &pt_Jtd[2 * (size_t)k]; }      // ProjectionTdFactor: fifth block td (estimator.cpp:1062-1070), kept
+            for (int q = 0; q < f.nb; ++q) used[f.id[q]] = 1;
             drop[0] = 1; drop[f.id[3]] = 1;
             fs.push_back(f);
         }
@@ -114,7 +116,7 @@ static int run_marginalize(int device, hipStream_t stream, char* d_blob, double*
         for (int k = 0; k < w->n_line_obs; ++k) {                                           // :1082-1129
             const int lm = w->ln_lm[k], fj = w->ln_fj[k];
             if (start[lm] != 0 || fj == 0) continue;
-            MFactor f; f.rows = 2; f.nb = 2; f.id[0] = fj; f.id[1] = 23 + Np + lm; f.sz[0] = 6; f.sz[1] = 4; f.coff[0] = 0; f.coff[1] = 6;
+            MFactor f; f.Jx = nullptr; f.xcol = -1; f.rows = 2; f.nb = 2; f.id[0] = fj; f.id[1] = PT0 + Np + lm; f.sz[0] = 6; f.sz[1] = 4; f.coff[0] = 0; f.coff[1] = 6;
             f.r = &ln_r[2 * (size_t)k]; f.J = &ln_J[20 * (size_t)k]; f.ld = 10;
             used[f.id[0]] = 1; used[f.id[1]] = 1; drop[f.id[1]] = 1;
             fs.push_back(f);
@@ -148,14 +150,16 @@ static int run_marginalize(int device, hipStream_t stream, char* d_blob, double*
     }
     for (const MFactor& f : fs) {
         int gc[32], lc[32], nc = 0;
-        for (int q = 0; q < f.nb; ++q) for (int k = 0; k < f.sz[q]; ++k) { gc[nc] = pos[f.id[q]] + k; lc[nc] = f.coff[q] + k; ++nc; }
+        for (int q = 0; q < f.nb; ++q) for (int k = 0; k < f.sz[q]; ++k) { gc[nc] = pos[f.id[q]] + k; lc[nc] = f.coff[q] < 0 ? -1 : f.coff[q] + k; ++nc; }
         for (int i = 0; i < f.rows; ++i) {
             const double* Ji = f.J + (size_t)i * f.ld;
+            double row[32];
+            for (int a = 0; a < nc; ++a) row[a] = lc[a] < 0 ? f.Jx[i] : Ji[lc[a]];      // the td column lives in its own array (uvs_eval.pt_Jtd)
             for (int a = 0; a < nc; ++a) {
-                const double ja = Ji[lc[a]];
+                const double ja = row[a];
                 if (ja == 0.0) continue;
                 bv[gc[a]] += ja * f.r[i];
-                for (int c2 = 0; c2 < nc; ++c2) A[(size_t)gc[a] * N + gc[c2]] += ja * Ji[lc[c2]];
+                for (int c2 = 0; c2 < nc; ++c2) A[(size_t)gc[a] * N + gc[c2]] += ja * row[c2];
             }
         }
     }
@@ -198,9 +202,10 @@ static int run_marginalize(int device, hipStream_t stream, char* d_blob, double*
         int kind, frame = 0; const double* data;
         if (id < NFR) { kind = UVS_BLOCK_POSE; frame = id; data = w->pose[frame]; }
         else if (id < 2 * NFR) { kind = UVS_BLOCK_SPEEDBIAS; frame = id - NFR; data = w->speedbias[frame]; }
+        else if (id == 23) { kind = UVS_BLOCK_TD; data = &w->td; }
         else { kind = UVS_BLOCK_EX_POSE; data = w->ex_pose; }
         int nf = frame;
-        if (kind != UVS_BLOCK_EX_POSE) nf = (flag == 0) ? frame - 1 : (frame == UVS_WINDOW_SIZE ? frame - 1 : frame);
+        if (kind == UVS_BLOCK_POSE || kind == UVS_BLOCK_SPEEDBIAS) nf = (flag == 0) ? frame - 1 : (frame == UVS_WINDOW_SIZE ? frame - 1 : frame);
         out->block_kind[b] = kind; out->block_frame[b] = nf; out->block_size[b] = gsize(id); out->block_idx[b] = pos[id] - m; out->x0_off[b] = xo;
         for (int q = 0; q < gsize(id); ++q) out->x0[xo + q] = data[q];
         xo += gsize(id);

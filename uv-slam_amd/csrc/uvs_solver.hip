@@ -599,7 +599,6 @@ int uvs_evaluate(uvs_solver* s, const uvs_window* w, int robust, uvs_eval* out) 
 
 int uvs_marginalize(uvs_solver* s, const uvs_window* w, int flag, uvs_prior* out) {
     if (!s || !w || !out || (flag != 0 && flag != 1)) return UVS_ERR_INVALID_ARG;
-    if (s->opts.estimate_td) { s->err = "marginalization does not carry the td block yet"; return UVS_ERR_UNSUPPORTED; }
     const uvs_window* arr[1] = {w};
     int rc = uvs_batch_upload(s, 1, arr);
     if (rc != UVS_OK) return rc;

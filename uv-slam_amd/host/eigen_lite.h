@@ -28,6 +28,9 @@ struct Vector3d {
     static Vector3d Zero() { return {}; }
 };
 inline Vector3d operator*(double s, const Vector3d& a) { return a * s; }
+struct Vector2d { double v[2]; Vector2d() : v{0, 0} {} Vector2d(double a, double b) : v{a, b} {}
+    double& x() { return v[0]; } double& y() { return v[1]; } double x() const { return v[0]; } double y() const { return v[1]; }
+    double& operator()(int i) { return v[i]; } double operator()(int i) const { return v[i]; } };
 struct Vector4d { double v[4]; Vector4d() : v{0, 0, 0, 0} {} Vector4d(double a, double b, double c, double d) : v{a, b, c, d} {}
     double& operator[](int i) { return v[i]; } double operator[](int i) const { return v[i]; } double& operator()(int i) { return v[i]; } double operator()(int i) const { return v[i]; } };
 struct Matrix3d {

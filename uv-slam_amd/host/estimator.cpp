@@ -4,7 +4,7 @@
 #include "estimator.h"
 #include <stdexcept>
 
-double FOCAL_LENGTH, INIT_DEPTH, MIN_PARALLAX, ACC_N, ACC_W, GYR_N, GYR_W, SOLVER_TIME, TD, TR, LINE_FACTOR, VP_FACTOR;
+double FOCAL_LENGTH, INIT_DEPTH, MIN_PARALLAX, ACC_N, ACC_W, GYR_N, GYR_W, SOLVER_TIME, TD, TR, LINE_FACTOR, VP_FACTOR, ROW, COL;
 int ESTIMATE_EXTRINSIC, ESTIMATE_TD, NUM_ITERATIONS, LINE_WINDOW;
 std::vector<Eigen::Matrix3d> RIC; std::vector<Eigen::Vector3d> TIC;
 Eigen::Vector3d G(0.0, 0.0, 9.8);
@@ -12,7 +12,7 @@ double ProjectionFactor::sqrt_info;
 
 void setEurocParameters() {          // config/euroc/euroc_config.yaml
     FOCAL_LENGTH = 461.6; SOLVER_TIME = 0.1; NUM_ITERATIONS = 10; ACC_N = 0.08; GYR_N = 0.004; ACC_W = 0.00004; GYR_W = 2.0e-6; G = Eigen::Vector3d(0, 0, 9.81007);
-    ESTIMATE_EXTRINSIC = 0; ESTIMATE_TD = 0; TD = 0.0; TR = 0.0; LINE_WINDOW = 5; LINE_FACTOR = 300.0; VP_FACTOR = 10.0; INIT_DEPTH = 5.0; MIN_PARALLAX = 10.0 / FOCAL_LENGTH;
+    ESTIMATE_EXTRINSIC = 0; ESTIMATE_TD = 0; TD = 0.0; TR = 0.0; ROW = 480.0; COL = 752.0; LINE_WINDOW = 5; LINE_FACTOR = 300.0; VP_FACTOR = 10.0; INIT_DEPTH = 5.0; MIN_PARALLAX = 10.0 / FOCAL_LENGTH;
     Eigen::Matrix3d R; const double r[9] = {0.0148655429818, -0.999880929698, 0.00414029679422, 0.999557249008, 0.0149672133247, 0.025715529948, -0.0257744366974, 0.00375618835797, 0.999660727178};
     for (int i = 0; i < 9; ++i) R(i / 3, i % 3) = r[i];
     RIC.assign(1, Eigen::Quaterniond(R).normalized().toRotationMatrix());           // parameters.cpp:113-115
@@ -24,6 +24,7 @@ Estimator::Estimator() : solver_flag(NON_LINEAR), marginalization_flag(MARGIN_OL
     for (auto& p : pre_integrations) p = nullptr;
     for (int i = 0; i <= WINDOW_SIZE; ++i) Rs[i].setIdentity();
     uvs_options o; uvs_default_options(&o);
+    o.estimate_td = ESTIMATE_TD;      // fixed for the lifetime of the handle, like the reference's global (parameters.cpp)
     const int rc = uvs_create(&o, 0, 1, NUM_OF_F, NUM_OF_F * (WINDOW_SIZE + 1), NUM_OF_LF, NUM_OF_LF * (WINDOW_SIZE + 1), &solver);
     if (rc != UVS_OK) throw std::runtime_error(std::string("uvs_create: ") + uvs_status_string(rc));     // no CPU fallback
 }
@@ -98,6 +99,7 @@ void Estimator::optimization() {      // estimator.cpp:761-1233
         problem.AddParameterBlock(para_Ex_Pose[i], SIZE_POSE, new PoseLocalParameterization());
         if (!ESTIMATE_EXTRINSIC) problem.SetParameterBlockConstant(para_Ex_Pose[i]);
     }
+    if (ESTIMATE_TD) problem.AddParameterBlock(para_Td[0], 1);                                    // estimator.cpp:790-797
     vector2double();
     if (last_marginalization_info && last_marginalization_info->prior.n > 0)
         problem.AddResidualBlock(new MarginalizationFactor(last_marginalization_info), NULL, std::vector<double*>{});
@@ -116,7 +118,12 @@ void Estimator::optimization() {      // estimator.cpp:761-1233
         for (auto& it_per_frame : it_per_id.feature_per_frame) {
             imu_j++;
             if (imu_i == imu_j) continue;
-            problem.AddResidualBlock(new ProjectionFactor(pts_i, it_per_frame.point), loss_function, para_Pose[imu_i], para_Pose[imu_j], para_Ex_Pose[0], para_Feature[feature_index]);
+            if (ESTIMATE_TD)                                                                      // estimator.cpp:853-858
+                problem.AddResidualBlock(new ProjectionTdFactor(pts_i, it_per_frame.point, it_per_id.feature_per_frame[0].velocity, it_per_frame.velocity,
+                                                                it_per_id.feature_per_frame[0].cur_td, it_per_frame.cur_td, it_per_id.feature_per_frame[0].uv.y(), it_per_frame.uv.y()),
+                                         loss_function, para_Pose[imu_i], para_Pose[imu_j], para_Ex_Pose[0], para_Feature[feature_index], para_Td[0]);
+            else
+                problem.AddResidualBlock(new ProjectionFactor(pts_i, it_per_frame.point), loss_function, para_Pose[imu_i], para_Pose[imu_j], para_Ex_Pose[0], para_Feature[feature_index]);
         }
     }
     int line_feature_index = -1;

@@ -7,7 +7,7 @@
 #include "../../../include/uvs_solver.h"
 #include "../integration_base.h"
 
-namespace uvs { enum FactorKind { F_IMU, F_PROJECTION, F_LINE, F_VP, F_MARGINALIZATION }; struct CostFunction { virtual ~CostFunction() {} virtual FactorKind kind() const = 0; }; }
+namespace uvs { enum FactorKind { F_IMU, F_PROJECTION, F_PROJECTION_TD, F_LINE, F_VP, F_MARGINALIZATION }; struct CostFunction { virtual ~CostFunction() {} virtual FactorKind kind() const = 0; }; }
 namespace ceres_like {   // the few Ceres names the reference's optimization() spells out
 struct LossFunction { virtual ~LossFunction() {} double a; explicit LossFunction(double a_) : a(a_) {} };
 struct CauchyLoss : LossFunction { explicit CauchyLoss(double a_) : LossFunction(a_) {} };
@@ -42,6 +42,14 @@ class ProjectionFactor : public uvs::CostFunction {        // projection_factor.
     uvs::FactorKind kind() const override { return uvs::F_PROJECTION; }
     Eigen::Vector3d pts_i, pts_j;
     static double sqrt_info;      // FOCAL_LENGTH / 1.6 (estimator.cpp:17); scalar because the reference's matrix is a multiple of I2
+};
+class ProjectionTdFactor : public uvs::CostFunction {      // projection_td_factor.h:11-33; ctor projection_td_factor.cpp:6-16 (row_i = _row_i - ROW / 2)
+  public:
+    ProjectionTdFactor(const Eigen::Vector3d& _pts_i, const Eigen::Vector3d& _pts_j, const Eigen::Vector2d& _velocity_i, const Eigen::Vector2d& _velocity_j,
+                       const double _td_i, const double _td_j, const double _row_i, const double _row_j)
+        : pts_i(_pts_i), pts_j(_pts_j), velocity_i(_velocity_i), velocity_j(_velocity_j), td_i(_td_i), td_j(_td_j), row_i(_row_i - ROW / 2), row_j(_row_j - ROW / 2) {}
+    uvs::FactorKind kind() const override { return uvs::F_PROJECTION_TD; }
+    Eigen::Vector3d pts_i, pts_j; Eigen::Vector2d velocity_i, velocity_j; double td_i, td_j, row_i, row_j;
 };
 struct LineProjectionFactor : public uvs::CostFunction {   // line_projection_factor.h:11-19
     LineProjectionFactor(Eigen::Matrix3d _ric, Eigen::Vector3d _tic, Eigen::Vector3d _sp, Eigen::Vector3d _ep) : ric(_ric), tic(_tic), sp(_sp), ep(_ep) {}

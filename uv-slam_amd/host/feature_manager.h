@@ -10,7 +10,12 @@
 #include "parameters.h"
 #include "utility.h"
 
-class FeaturePerFrame { public: FeaturePerFrame(const Eigen::Vector3d& p) : point(p), cur_td(0) {} Eigen::Vector3d point; double cur_td; };
+class FeaturePerFrame {      // feature_manager.h:18-43: point = normalised (x, y, 1), uv = pixel, velocity = image-plane velocity, cur_td = td at capture
+  public:
+    FeaturePerFrame(const Eigen::Vector3d& p) : point(p), cur_td(0) {}
+    FeaturePerFrame(const Eigen::Vector3d& p, const Eigen::Vector2d& _uv, const Eigen::Vector2d& _velocity, double td) : point(p), uv(_uv), velocity(_velocity), cur_td(td) {}
+    Eigen::Vector3d point; Eigen::Vector2d uv, velocity; double cur_td;
+};
 class FeaturePerId {
   public:
     const int feature_id; int start_frame; std::vector<FeaturePerFrame> feature_per_frame; int used_num; double estimated_depth; int solve_flag;

@@ -11,8 +11,10 @@ extern "C" int uvs_host_replay_window(const char* in_path, const char* out_path,
     if (!wf.load(in_path)) return -1;
     const uvs_window& w = wf.w;
     setEurocParameters();
+    ESTIMATE_TD = wf.has_td ? 1 : 0;      // a window recorded with the ProjectionTdFactor inputs replays with ESTIMATE_TD (euroc_config.yaml: estimate_td)
     try {
         Estimator est;
+        est.td = w.td;
         est.setParameter();
         for (int i = 0; i <= WINDOW_SIZE; ++i) {
             est.Ps[i] = Eigen::Vector3d(w.pose[i][0], w.pose[i][1], w.pose[i][2]);
@@ -27,9 +29,12 @@ extern "C" int uvs_host_replay_window(const char* in_path, const char* out_path,
         for (int k = 0, o = 0; k < w.n_points; ++k) {
             if (o >= w.n_point_obs || w.pt_lm[o] != k) return -2;
             FeaturePerId f(k, w.pt_fi[o]);
-            f.feature_per_frame.emplace_back(Eigen::Vector3d(w.pt_pi[3 * o], w.pt_pi[3 * o + 1], w.pt_pi[3 * o + 2]));
+            // uv.y = ROW / 2 => row - ROW / 2 = 0: the recorded td_i / td_j already carry the rolling-shutter term
+            auto ppf = [&](const double* p3, const double* v2, const double* tdp) {
+                return wf.has_td ? FeaturePerFrame(Eigen::Vector3d(p3[0], p3[1], p3[2]), Eigen::Vector2d(0.0, ROW / 2), Eigen::Vector2d(v2[0], v2[1]), *tdp) : FeaturePerFrame(Eigen::Vector3d(p3[0], p3[1], p3[2])); };
+            f.feature_per_frame.push_back(ppf(w.pt_pi + 3 * o, wf.has_td ? w.pt_vel_i + 2 * o : nullptr, wf.has_td ? w.pt_td_i + o : nullptr));
             int expect = w.pt_fi[o] + 1;
-            while (o < w.n_point_obs && w.pt_lm[o] == k) { if (w.pt_fj[o] != expect++) return -3; f.feature_per_frame.emplace_back(Eigen::Vector3d(w.pt_pj[3 * o], w.pt_pj[3 * o + 1], w.pt_pj[3 * o + 2])); ++o; }
+            while (o < w.n_point_obs && w.pt_lm[o] == k) { if (w.pt_fj[o] != expect++) return -3; f.feature_per_frame.push_back(ppf(w.pt_pj + 3 * o, wf.has_td ? w.pt_vel_j + 2 * o : nullptr, wf.has_td ? w.pt_td_j + o : nullptr)); ++o; }
             f.estimated_depth = 1.0 / w.inv_depth[k];
             est.f_manager.feature.push_back(f);
         }
@@ -75,6 +80,7 @@ extern "C" int uvs_host_replay_window(const char* in_path, const char* out_path,
         const uvs_prior& p = est.last_marginalization_info ? est.last_marginalization_info->prior : uvs_prior();
         double pn = est.last_marginalization_info ? p.n : 0; std::fwrite(&pn, 8, 1, f);
         if (pn > 0) { std::fwrite(p.linearized_residuals, 8, p.n, f); std::fwrite(p.linearized_jacobians, 8, (size_t)p.n * p.n, f); }
+        std::fwrite(&est.td, 8, 1, f);      // trailing: Estimator::td after double2vector (estimator.cpp:706-707)
         std::fclose(f);
     } catch (const std::exception& e) { std::fprintf(stderr, "uvs_host_replay_window: %s\n", e.what()); return -7; }
     return 0;

@@ -58,6 +58,14 @@ class Problem {
                 for (int k = 0; k < 3; ++k) { pt_pi.push_back(f->pts_i(k)); pt_pj.push_back(f->pts_j(k)); }
                 break;
             }
+            case F_PROJECTION_TD: {      // same point arrays + the time-offset inputs; TR / ROW * row folded into the per-observation td (include/uvs_solver.h)
+                ProjectionTdFactor* f = static_cast<ProjectionTdFactor*>(cost);
+                pt_fi.push_back(map.resolve(blocks.at(0)).index); pt_fj.push_back(map.resolve(blocks.at(1)).index); pt_lm.push_back(map.resolve(blocks.at(3)).index);
+                for (int k = 0; k < 3; ++k) { pt_pi.push_back(f->pts_i(k)); pt_pj.push_back(f->pts_j(k)); }
+                for (int k = 0; k < 2; ++k) { pt_vel_i.push_back(f->velocity_i(k)); pt_vel_j.push_back(f->velocity_j(k)); }
+                pt_td_i.push_back(f->td_i - TR / ROW * f->row_i); pt_td_j.push_back(f->td_j - TR / ROW * f->row_j);
+                break;
+            }
             case F_LINE: {
                 LineProjectionFactor* f = static_cast<LineProjectionFactor*>(cost);
                 ln_fj.push_back(map.resolve(blocks.at(0)).index); ln_lm.push_back(map.resolve(blocks.at(1)).index); ln_has_vp.push_back(0);
@@ -74,6 +82,7 @@ class Problem {
     }
     void AddResidualBlock(CostFunction* c, ceres_like::LossFunction* l, double* a, double* b) { AddResidualBlock(c, l, std::vector<double*>{a, b}); }
     void AddResidualBlock(CostFunction* c, ceres_like::LossFunction* l, double* a, double* b, double* c2, double* d) { AddResidualBlock(c, l, std::vector<double*>{a, b, c2, d}); }
+    void AddResidualBlock(CostFunction* c, ceres_like::LossFunction* l, double* a, double* b, double* c2, double* d, double* e) { AddResidualBlock(c, l, std::vector<double*>{a, b, c2, d, e}); }
 
     // assembled view (valid while the Problem lives)
     void fill(uvs_window* w, int n_points, int n_lines) const {
@@ -84,13 +93,15 @@ class Problem {
         w->n_lines = n_lines; w->n_line_obs = (int)ln_lm.size(); w->line_orth = &map.ortho[0][0];
         w->ln_lm = ln_lm.data(); w->ln_fj = ln_fj.data(); w->ln_sp = ln_sp.data(); w->ln_ep = ln_ep.data(); w->ln_has_vp = ln_has_vp.data(); w->ln_vp = ln_vp.data();
         w->n_imu = (int)imu.size(); w->imu = imu.data(); w->prior = prior;
+        w->td = map.td[0][0];
+        if (!pt_td_i.empty()) { w->pt_vel_i = pt_vel_i.data(); w->pt_vel_j = pt_vel_j.data(); w->pt_td_i = pt_td_i.data(); w->pt_td_j = pt_td_j.data(); }
     }
     AddressMap map;
     bool ex_constant = false;
     const uvs_prior* prior = nullptr;
     std::vector<uvs_imu_block> imu;
     std::vector<int32_t> pt_lm, pt_fi, pt_fj, ln_lm, ln_fj, ln_has_vp;
-    std::vector<double> pt_pi, pt_pj, ln_sp, ln_ep, ln_vp;
+    std::vector<double> pt_pi, pt_pj, ln_sp, ln_ep, ln_vp, pt_vel_i, pt_vel_j, pt_td_i, pt_td_j;
   private:
     std::vector<CostFunction*> owned_costs; std::vector<ceres_like::LossFunction*> owned_loss; std::vector<ceres_like::LocalParameterization*> owned_param;
 };
@@ -104,6 +115,7 @@ inline void Solve(const Options& options, Problem* problem, Summary* summary, uv
     summary->status = uvs_solve_window(solver, &w, &st, &summary->report);
     if (summary->status != UVS_OK && summary->status != UVS_ERR_NUMERIC) return;      // like the reference, the caller ignores the summary
     std::memcpy(problem->map.pose, st.pose, sizeof(st.pose)); std::memcpy(problem->map.speedbias, st.speedbias, sizeof(st.speedbias));
+    problem->map.td[0][0] = st.td;
     for (int k = 0; k < n_points; ++k) problem->map.feature[k][0] = invd[k];
     for (int k = 0; k < 4 * n_lines; ++k) (&problem->map.ortho[0][0])[k] = lines[k];
 }

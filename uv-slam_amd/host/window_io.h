@@ -1,8 +1,9 @@
 // window_io.h -- binary record / replay format of one sliding window.
 // The reference never serialises the estimator window; this file is what a dump hook placed after vector2double()
 // (estimator.cpp:800) writes and what the GPU box replays without ROS.  Little-endian, 8-byte aligned:
-//   char magic[8] = "UVSWIN01"; int32 n_points, n_point_obs, n_lines, n_line_obs, n_imu, prior_n, prior_nblocks, reserved;
+//   char magic[8] = "UVSWIN01"; int32 n_points, n_point_obs, n_lines, n_line_obs, n_imu, prior_n, prior_nblocks, has_td;
 //   double pose[77] sb[99] ex[7] td; double inv_depth[np]; int32 pt_lm/fi/fj[npo]; double pt_pi[3npo] pt_pj[3npo];
+//   (has_td: double pt_vel_i[2npo] pt_vel_j[2npo] pt_td_i[npo] pt_td_j[npo] -- the ProjectionTdFactor inputs);
 //   double line_orth[4nl]; int32 ln_lm/fj/has_vp[nlo]; double ln_sp/ep/vp[3nlo]; imu: n_imu x (467 doubles + int32 frame_i, skip);
 //   prior (if prior_n): int32 kind/frame/size/idx/x0off[16 each]; double x0[144] r0[n] J0[n*n].
 // The same layout is written / read by uv-slam_amd/abi.py (Window.save / Window.load).
@@ -15,7 +16,8 @@
 
 struct WindowFile {      // owns the arrays a uvs_window points to
     uvs_window w;
-    std::vector<double> inv_depth, pt_pi, pt_pj, line_orth, ln_sp, ln_ep, ln_vp;
+    std::vector<double> inv_depth, pt_pi, pt_pj, line_orth, ln_sp, ln_ep, ln_vp, pt_vel_i, pt_vel_j, pt_td_i, pt_td_j;
+    bool has_td = false;
     std::vector<int32_t> pt_lm, pt_fi, pt_fj, ln_lm, ln_fj, ln_has_vp;
     std::vector<uvs_imu_block> imu;
     uvs_prior prior;
@@ -32,6 +34,9 @@ struct WindowFile {      // owns the arrays a uvs_window points to
             pt_lm.resize(npo); pt_fi.resize(npo); pt_fj.resize(npo); rd(pt_lm.data(), 4, npo); rd(pt_fi.data(), 4, npo); rd(pt_fj.data(), 4, npo);
             if (npo % 2) { int32_t pad; rd(&pad, 4, 1); }
             pt_pi.resize(3 * npo); pt_pj.resize(3 * npo); rd(pt_pi.data(), 8, 3 * npo); rd(pt_pj.data(), 8, 3 * npo);
+            has_td = hd[7] != 0;
+            if (has_td) { pt_vel_i.resize(2 * npo); pt_vel_j.resize(2 * npo); pt_td_i.resize(npo); pt_td_j.resize(npo);
+                          rd(pt_vel_i.data(), 8, 2 * npo); rd(pt_vel_j.data(), 8, 2 * npo); rd(pt_td_i.data(), 8, npo); rd(pt_td_j.data(), 8, npo); }
             line_orth.resize(4 * nl); rd(line_orth.data(), 8, 4 * nl);
             ln_lm.resize(nlo); ln_fj.resize(nlo); ln_has_vp.resize(nlo); rd(ln_lm.data(), 4, nlo); rd(ln_fj.data(), 4, nlo); rd(ln_has_vp.data(), 4, nlo);
             if (nlo % 2) { int32_t pad; rd(&pad, 4, 1); }
@@ -52,6 +57,7 @@ struct WindowFile {      // owns the arrays a uvs_window points to
             w.inv_depth = inv_depth.data(); w.pt_lm = pt_lm.data(); w.pt_fi = pt_fi.data(); w.pt_fj = pt_fj.data(); w.pt_pi = pt_pi.data(); w.pt_pj = pt_pj.data();
             w.line_orth = line_orth.data(); w.ln_lm = ln_lm.data(); w.ln_fj = ln_fj.data(); w.ln_has_vp = ln_has_vp.data(); w.ln_sp = ln_sp.data(); w.ln_ep = ln_ep.data(); w.ln_vp = ln_vp.data();
             w.imu = imu.data(); w.prior = pn > 0 ? &prior : nullptr;
+            if (has_td) { w.pt_vel_i = pt_vel_i.data(); w.pt_vel_j = pt_vel_j.data(); w.pt_td_i = pt_td_i.data(); w.pt_td_j = pt_td_j.data(); }
         }
         std::fclose(f);
         return ok;
