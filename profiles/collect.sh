@@ -16,8 +16,5 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/p
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $R/gpurun_out/prof_sq -o runc -- $CMD > $R/gpurun_out/prof_sq.log 2>&1
 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INSTS_SALU SQ_INSTS_SMEM --kernel-trace --output-format csv -d $R/gpurun_out/prof_sq2 -o runc -- $CMD > $R/gpurun_out/prof_sq2.log 2>&1
 cd $R
-python profiles/summarize.py $TAG
-# keep the per-kernel stats table of the trace pass
-f=$(ls gpurun_out/prof_kt/runc*kernel_stats.csv gpurun_out/prof_kt/*/*kernel_stats.csv 2>/dev/null | head -1)
-[ -n "$f" ] && cp "$f" profiles/${TAG}_kernel_stats_bench256.csv
-ls -la profiles/
+python profiles/summarize.py $TAG      # printed for the log; gpurun only merges gpurun_out/ back, so re-run these two lines locally afterwards:
+#   python profiles/summarize.py $TAG && cp gpurun_out/prof_kt/runc_kernel_stats.csv profiles/${TAG}_kernel_stats_bench256.csv
