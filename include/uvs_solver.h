@@ -44,7 +44,7 @@ extern "C" {
 enum {
     UVS_OK = 0,
     UVS_ERR_INVALID_ARG = 1,    /* null pointer / index out of range / bad count */
-    UVS_ERR_UNSUPPORTED = 2,    /* estimate_extrinsic / relocalization blocks: not on this path yet */
+    UVS_ERR_UNSUPPORTED = 2,    /* relocalization blocks (estimator.cpp:944-978): not on this path yet */
     UVS_ERR_NO_DEVICE = 3,      /* no HIP device / extension cannot run (never falls back to CPU) */
     UVS_ERR_HIP = 4,            /* a HIP runtime call failed; see uvs_last_error() */
     UVS_ERR_CAPACITY = 5,       /* window larger than the handle was created for */
@@ -68,7 +68,7 @@ enum {
  * values of config/euroc/euroc_config.yaml. */
 typedef struct uvs_options {
     int32_t max_num_iterations;        /* NUM_ITERATIONS, euroc_config.yaml:56 (10)        */
-    int32_t estimate_extrinsic;        /* ESTIMATE_EXTRINSIC (0): Ex_Pose constant         */
+    int32_t estimate_extrinsic;        /* ESTIMATE_EXTRINSIC (0): Ex_Pose constant; != 0: free 6-dof block (estimator.cpp:784-788) */
     int32_t estimate_td;               /* ESTIMATE_TD (0); 1: ProjectionTdFactor + para_Td (estimator.cpp:790-797,853-858) */
     int32_t function_tol_keeps_candidate; /* 0 = Ceres order: tolerance checks before accept (App. B.4) */
     double focal_length;               /* FOCAL_LENGTH = fx, parameters.cpp:60 (461.6)     */

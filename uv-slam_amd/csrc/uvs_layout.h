@@ -13,7 +13,9 @@
 #define UVS_FD 16                 // padded per-frame dimension in the reduced system (15 + 1 dummy)
 #define UVS_RD (UVS_NF * UVS_FD)  // 176: padded reduced dimension
 #define UVS_NBLK (UVS_NF * (UVS_NF + 1) / 2)   // 66 lower 16x16 blocks
-#define UVS_NBLKX (UVS_NBLK + UVS_NF + 1)      // + the 12 gather blocks of the time-offset row (td, frame f) = 66 + f, (td, td) = 77 (ESTIMATE_TD)
+#define UVS_NBLKX (UVS_NBLK + UVS_NF + 1 + UVS_NF + 2)      // + the gather blocks of the two pseudo frames: 11 = time offset (ESTIMATE_TD): (td, f) = 66 + f, (td, td) = 77;
+                                               // 12 = camera extrinsic (ESTIMATE_EXTRINSIC): (ex, f) = 78 + f, (ex, td) = 89, (ex, ex) = 90
+#define UVS_EX_INDEX(a) (16 * (a) + 15)        // the 6 dofs of para_Ex_Pose sit in the spare 16th slots of frames 0..5
 #define UVS_TD_INDEX (UVS_RD - 1)              // para_Td sits in the spare 16th slot of the last frame (index 175 of the padded reduced system)
 #define UVS_BLK_LD 17             // padded row stride of a 16x16 LDS block (bank-conflict padding)
 #define UVS_BLK_SZ (16 * UVS_BLK_LD)            // 272 doubles
@@ -32,6 +34,8 @@
 #define UVS_PT_RC2 28
 #define UVS_PT_TD 30               // d r / d td (2 doubles) + 2 zero pads: only in ESTIMATE_TD records (34 doubles)
 #define UVS_PT_REC_TD 34
+#define UVS_PT_EX 34               // d r / d ex_pose (2 x 6) : only in ESTIMATE_EXTRINSIC records (46 doubles)
+#define UVS_PT_REC_EX 46
 #define UVS_LN_REC 34             // LDS record per line observation: rl|rc[2] Jp[3][6] rv|rc2 pad Jl[3][4]  (row 2 = vanishing-point row)
 #define UVS_LN_JP 2               // pose-Jacobian rows at 2, 8, 14
 #define UVS_LN_RV 20              // VP residual, later its Schur-corrected value
@@ -47,8 +51,9 @@ struct DevWin {
     int32_t d_ptmeas;                 // 6 x pt_stride : pi_x pi_y pi_z pj_x pj_y pj_z
     int32_t d_ptvel;                  // ESTIMATE_TD only: 6 x pt_stride : vel_i.xy vel_j.xy td_i td_j
     int32_t td_on;                    // options.estimate_td
+    int32_t ex_on;                    // options.estimate_extrinsic
     int32_t pt_rec;                   // doubles per point record in the LDS staging area (30, or 34 with the td Jacobian)
-    int32_t pt_xslots;                // Schur slots per point landmark beyond its observations: 1 (anchor) or 2 (anchor + td)
+    int32_t pt_xslots;                // Schur slots per point landmark beyond its observations: anchor (+ td) (+ ex)
     int32_t d_line;                   // [n_lines][4]
     int32_t d_lnmeas;                 // 9 x ln_stride : sp xyz, ep xyz, vp xyz
     int32_t d_imu;                    // n_imu x UVS_IMU_STRIDE

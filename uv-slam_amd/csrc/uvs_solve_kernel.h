@@ -501,13 +501,17 @@ UVS_DEV void row_fma(double* v, double s, const d2_t* q) {
 // this lane's group descriptor (-1 = idle group), see uvs_layout.h: i_wblk
 UVS_DEV int gather_group(const Ctx& c) { return c.bi[c.hdr->i_wblk + (threadIdx.x >> 1)]; }
 
+// EXT = the window has pseudo-frame blocks (ESTIMATE_TD / ESTIMATE_EXTRINSIC); the default instantiation folds all their special cases away
+template <bool EXT>
 UVS_DEV void gather_points(int grp, const int* lists, const double* S0, GAcc& A) {
     const int g = threadIdx.x >> 1, r0 = 3 * (threadIdx.x & 1);
     const bool on = grp >= 0;
     const bool diag = on && ((grp >> 8) & 1);
-    const bool tdg = on && ((grp >> 13) & 15) == UVS_NF;       // block row of the time offset: J1 = (J_td[0], J_td[1]) adjacent, residual 16 doubles below
-    const int p1off = tdg ? 1 : 6, rcoff = tdg ? UVS_PT_C - UVS_PT_TD : 12;
-    const bool dirv = !(tdg && diag);                           // (td, td): the direct term is the scalar J_td . J_td = the hd accumulator
+    const bool tdg = EXT && on && ((grp >> 13) & 15) == UVS_NF;       // block row of the time offset: J1 = (J_td[0], J_td[1]) adjacent, residual 16 doubles below
+    const bool exg = EXT && on && ((grp >> 13) & 15) == UVS_NF + 1;   // block rows of the camera extrinsic: J1 = the 2 x 6 J_ex block of the record
+    const bool tdcol = exg && ((grp >> 17) & 15) == UVS_NF;           // (ex, td): J2 is the adjacent J_td pair and only column 0 is real
+    const int p1off = tdg ? 1 : 6, rcoff = tdg ? UVS_PT_C - UVS_PT_TD : exg ? UVS_PT_C - UVS_PT_EX : 12;
+    const bool dirv = !(tdg && diag) && !tdcol;                 // (td, td): the direct term is the scalar J_td . J_td = the hd accumulator
     const int* ent = lists + LIST_HDR;
     // ---- Schur: acc[r][c] -= E_a[r0 + r] * Einv_b[c]
     {
@@ -548,6 +552,7 @@ UVS_DEV void gather_points(int grp, const int* lists, const double* S0, GAcc& A)
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
                 if (dirv) { row_fma(A.v + 6 * r, p0[r], q0); row_fma(A.v + 6 * r, p1[r], q1); }
+                if (tdcol) A.v[6 * r] += p0[r] * q0[0].x + p1[r] * q0[0].y;
                 if (diag) { A.g[r] += p0[r] * rc.x + p1[r] * rc.y; A.hd[r] += p0[r] * p0[r] + p1[r] * p1[r]; }
             }
             e = en;
@@ -725,7 +730,14 @@ UVS_DEV void lin_chunk(const Ctx& c, int ch, const double* x, const double* invd
 #pragma unroll
                 for (int q = 0; q < 12; ++q) { R[UVS_PT_A + q] = sc * A[q]; R[UVS_PT_B + q] = sc * B[q]; }
                 R[UVS_PT_C] = sc * cl[0]; R[UVS_PT_C + 1] = sc * cl[1];      // d r / d lambda; replaced by the corrected residual in pass B
-                if (h.td_on) { R[UVS_PT_TD] = sc * jtd[0]; R[UVS_PT_TD + 1] = sc * jtd[1]; R[UVS_PT_TD + 2] = 0.0; R[UVS_PT_TD + 3] = 0.0; }
+                if (h.td_on || h.ex_on) { R[UVS_PT_TD] = sc * jtd[0]; R[UVS_PT_TD + 1] = sc * jtd[1]; R[UVS_PT_TD + 2] = 0.0; R[UVS_PT_TD + 3] = 0.0; }
+                if (h.ex_on) {      // ESTIMATE_EXTRINSIC only: the 2 x 6 block d r / d ex_pose from a second evaluation, in its own scope so that the
+                                    // default path keeps its register footprint (the kernel sits at the 512-register cap)
+                    double r2[2], A2[12], B2[12], cl2[2], jex[12];
+                    point_eval<true, true>(x + 7 * fi, RF + 9 * fi, x + 7 * fj, RF + 9 * fj, ric, tic, invd[lm], pi, pj, c.o.sqrt_info, r2, A2, B2, cl2, jex);
+#pragma unroll
+                    for (int q = 0; q < 12; ++q) R[UVS_PT_EX + q] = sc * jex[q];
+                }
             }
             __syncthreads();
             UVS_PROF(c, P_OBS);
@@ -764,10 +776,21 @@ UVS_DEV void lin_chunk(const Ctx& c, int ch, const double* x, const double* invd
                     }
 #pragma unroll
                     for (int a = 0; a < 6; ++a) { E[a] = e0[a]; EI[a] = e0[a] * hinv; Eg[a] = e0[a] * hinv; }
-                    if (h.td_on) {      // last slot of the landmark: the time-offset "row" J_l^T J_td (a 6-vector whose first entry is the only real one)
+                    if (h.td_on) {      // slot after the observations: the time-offset "row" J_l^T J_td (a 6-vector whose first entry is the only real one)
                         const int st_ = 6 * (b1 - b0 + 1);
 #pragma unroll
                         for (int a = 0; a < 6; ++a) { const double e = a == 0 ? etd : 0.0; E[st_ + a] = e; EI[st_ + a] = e * hinv; Eg[st_ + a] = e * hinv; }
+                    }
+                    if (h.ex_on) {      // last slot: the extrinsic row J_l^T J_ex
+                        double ex6[6] = {0, 0, 0, 0, 0, 0};
+                        for (int o = b0; o < b1; ++o) {
+                            const double* Ro = rec + (size_t)o * PREC;
+#pragma unroll
+                            for (int a = 0; a < 6; ++a) ex6[a] += Ro[UVS_PT_C] * Ro[UVS_PT_EX + a] + Ro[UVS_PT_C + 1] * Ro[UVS_PT_EX + 6 + a];
+                        }
+                        const int st_ = 6 * (b1 - b0 + 1 + (h.td_on ? 1 : 0));
+#pragma unroll
+                        for (int a = 0; a < 6; ++a) { E[st_ + a] = ex6[a]; EI[st_ + a] = ex6[a] * hinv; Eg[st_ + a] = ex6[a] * hinv; }
                     }
                 }
             }
@@ -777,7 +800,7 @@ UVS_DEV void lin_chunk(const Ctx& c, int ch, const double* x, const double* invd
             UVS_PROF(c, P_LMPREP);
             sh[L_LCOST + tid] += cost; sh[L_LGMAX + tid] = fmax(sh[L_LGMAX + tid], gmax_lm);
             const long long tg0_ = clock64();
-            gather_points(grp, lists, rec, acc);
+            if (h.td_on | h.ex_on) gather_points<true>(grp, lists, rec, acc); else gather_points<false>(grp, lists, rec, acc);
             if (c.o.debug && (tid & 63) == 0) sh[L_WPROF + (tid >> 6)] += (double)(clock64() - tg0_);
         } else {
             const int* beg = c.bi + h.i_ln_beg;
@@ -930,7 +953,21 @@ UVS_DEV void lin_assemble(const Ctx& c, const double* x, bool first, double radi
         if (grp >= 0 && ((grp >> 9) & 15) == part) {
             const int r0 = 3 * (tid & 1);
             const int fa = (grp >> 13) & 15, fb = (grp >> 17) & 15;
-            if (fa == UVS_NF) {      // time-offset row (ESTIMATE_TD): row UVS_TD_INDEX of S, only row 0 of lane 0 of the group is real
+            if (fa == UVS_NF + 1) {  // camera-extrinsic rows (ESTIMATE_EXTRINSIC): dof a of Ex_Pose sits at S index 16 a + 15, anywhere relative to the column
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const int a = r0 + r, i = UVS_EX_INDEX(a);
+                    if (fb < UVS_NF) {
+#pragma unroll
+                        for (int cc = 0; cc < 6; ++cc) { const int j = 16 * fb + cc; sh[L_S + (i >= j ? sidx(i, j) : sidx(j, i))] += A.v[6 * r + cc]; }
+                    } else if (fb == UVS_NF) sh[L_S + sidx(UVS_TD_INDEX, i)] += A.v[6 * r];
+                    else {
+#pragma unroll
+                        for (int cc = 0; cc < 6; ++cc) if (cc <= a) sh[L_S + sidx(i, UVS_EX_INDEX(cc))] += A.v[6 * r + cc];
+                        sh[L_G + i] += A.g[r]; sh[L_HD + i] += A.hd[r];
+                    }
+                }
+            } else if (fa == UVS_NF) {      // time-offset row (ESTIMATE_TD): row UVS_TD_INDEX of S, only row 0 of lane 0 of the group is real
                 if (r0 == 0) {
                     if (fb < UVS_NF) {
                         double* row = sh + L_S + sidx(UVS_TD_INDEX, 16 * fb);
@@ -1056,14 +1093,14 @@ UVS_DEV void lin_assemble(const Ctx& c, const double* x, bool first, double radi
     double gmax = gmax_lm;
     if (tid < UVS_RD) {
         const int k = tid & 15;
-        if (k < 15 || (h.td_on && tid == UVS_TD_INDEX)) {
+        if (k < 15 || (h.td_on && tid == UVS_TD_INDEX) || (h.ex_on && tid < 96)) {      // spare slots in use: td at 175, Ex_Pose dofs at 15, 31, ... 95
             const double hd = sh[L_HD + tid];
             if (first) sh[L_SC + tid] = c.o.jacobi ? 1.0 / (1.0 + sqrt(hd)) : 1.0;
             const double sc = sh[L_SC + tid];
             const double dd = fmin(fmax(sc * sc * hd, c.o.dlo), c.o.dhi) / (radius * sc * sc);
             sh[L_DD + tid] = dd;
             sh[L_S + sidx(tid, tid)] += dd;
-            if (k >= 6) gmax = fmax(gmax, fabs(sh[L_G + tid]));
+            if (k >= 6 && !(k == 15 && tid < 96)) gmax = fmax(gmax, fabs(sh[L_G + tid]));      // Euclidean blocks (the Ex_Pose slots are a manifold block, below)
         } else { sh[L_S + sidx(tid, tid)] = 1.0; sh[L_DD + tid] = 0.0; sh[L_G + tid] = 0.0; sh[L_SC + tid] = 1.0; }
     }
     if (tid < UVS_NF) {   // || x - Plus(x, -g) ||_inf on the pose block
@@ -1073,6 +1110,14 @@ UVS_DEV void lin_assemble(const Ctx& c, const double* x, bool first, double radi
         pose_plus(x + 7 * tid, d, xp);
 #pragma unroll
         for (int k = 0; k < 7; ++k) gmax = fmax(gmax, fabs(x[7 * tid + k] - xp[k]));
+    }
+    if (h.ex_on && tid == UVS_NF) {   // same projected-gradient measure for the extrinsic pose block
+        double d[6], xp[7];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) d[k] = -sh[L_G + UVS_EX_INDEX(k)];
+        pose_plus(x + 176, d, xp);
+#pragma unroll
+        for (int k = 0; k < 7; ++k) gmax = fmax(gmax, fabs(x[176 + k] - xp[k]));
     }
     double s4[4] = {cost, 0.0, 0.0, 0.0};
     block_reduce(sh, s4, &gmax);
@@ -1102,7 +1147,8 @@ UVS_DEV void backsub_candidate(const Ctx& c, const double* invd, const double* l
     const double* d = sh + L_DLT;
     double gd = 0.0, dd2 = 0.0, step2 = 0.0, xc2 = 0.0;
     const bool td_on = h.td_on != 0;
-    if (with_frames && tid < UVS_RD && ((tid & 15) < 15 || (td_on && tid == UVS_TD_INDEX))) { gd += sh[L_G + tid] * d[tid]; dd2 += sh[L_DD + tid] * d[tid] * d[tid]; }
+    const bool ex_on = h.ex_on != 0;
+    if (with_frames && tid < UVS_RD && ((tid & 15) < 15 || (td_on && tid == UVS_TD_INDEX) || (ex_on && tid < 96))) { gd += sh[L_G + tid] * d[tid]; dd2 += sh[L_DD + tid] * d[tid] * d[tid]; }
     if (with_frames && tid < UVS_NF) {
         double xp[7];
         pose_plus(sh + L_X + 7 * tid, d + 16 * tid, xp);
@@ -1111,8 +1157,15 @@ UVS_DEV void backsub_candidate(const Ctx& c, const double* invd, const double* l
 #pragma unroll
         for (int k = 0; k < 9; ++k) { const double v = sh[L_X + 77 + 9 * tid + k] + d[16 * tid + 6 + k]; sh[L_XC + 77 + 9 * tid + k] = v; step2 += d[16 * tid + 6 + k] * d[16 * tid + 6 + k]; xc2 += v * v; }
     }
-    if (with_frames && tid == UVS_NF) {   // Ex_Pose constant (ESTIMATE_EXTRINSIC=0); para_Td moves only with ESTIMATE_TD
-        for (int k = 0; k < 7; ++k) sh[L_XC + 176 + k] = sh[L_X + 176 + k];
+    if (with_frames && tid == UVS_NF) {   // Ex_Pose moves only with ESTIMATE_EXTRINSIC, para_Td only with ESTIMATE_TD
+        if (ex_on) {
+            double de[6], xp[7];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) de[k] = d[UVS_EX_INDEX(k)];
+            pose_plus(sh + L_X + 176, de, xp);
+#pragma unroll
+            for (int k = 0; k < 7; ++k) { sh[L_XC + 176 + k] = xp[k]; const double e = xp[k] - sh[L_X + 176 + k]; step2 += e * e; xc2 += xp[k] * xp[k]; }
+        } else for (int k = 0; k < 7; ++k) sh[L_XC + 176 + k] = sh[L_X + 176 + k];
         const double dtd = td_on ? d[UVS_TD_INDEX] : 0.0, tdc = sh[L_X + 183] + dtd;
         sh[L_XC + 183] = tdc;
         if (td_on) { step2 += dtd * dtd; xc2 += tdc * tdc; }
@@ -1135,6 +1188,11 @@ UVS_DEV void backsub_candidate(const Ctx& c, const double* invd, const double* l
                 for (int a = 0; a < 6; ++a) t += e[a] * d[16 * fj + a];
             }
             if (td_on) t += Eg[6 * (b1 - b0 + 1)] * d[UVS_TD_INDEX];
+            if (ex_on) {
+                const double* e = Eg + 6 * (b1 - b0 + 1 + (td_on ? 1 : 0));
+#pragma unroll
+                for (int a = 0; a < 6; ++a) t += e[a] * d[UVS_EX_INDEX(a)];
+            }
         }
         const double dl = -px[0] - t;
         const double v = invd[k] + dl;
@@ -1182,6 +1240,7 @@ UVS_DEV double ambient_sqnorm(const Ctx& c, const double* x, const double* invd,
     double s = 0.0;
     if (tid < 176) s += x[tid] * x[tid];
     if (tid == 183 && h.td_on) s += x[183] * x[183];
+    if (tid >= 176 && tid < 183 && h.ex_on) s += x[tid] * x[tid];
     for (int k = tid; k < h.n_points; k += NT) s += invd[k] * invd[k];
     for (int k = tid; k < 4 * h.n_lines; k += NT) s += line[k] * line[k];
     double s4[4] = {s, 0, 0, 0}, mx = 0.0;

@@ -115,7 +115,6 @@ int uvs_reduced_dim(const uvs_options* o) { return 15 * UVS_NUM_FRAMES + ((o && 
 int uvs_create(const uvs_options* opts, int device, int max_batch, int max_points, int max_point_obs, int max_lines,
                int max_line_obs, uvs_solver** out) {
     if (!opts || !out || max_batch < 1 || max_points < 0 || max_point_obs < 0 || max_lines < 0 || max_line_obs < 0) return UVS_ERR_INVALID_ARG;
-    if (opts->estimate_extrinsic) return UVS_ERR_UNSUPPORTED;
     if (opts->max_num_iterations < 0) return UVS_ERR_INVALID_ARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return UVS_ERR_NO_DEVICE;
@@ -199,7 +198,9 @@ static int pack_window(const uvs_window* w, const uvs_options& opts, std::vector
     const bool have_prior = w->prior && w->prior->n > 0;
     h.prior_n = have_prior ? w->prior->n : 0; h.prior_nb = have_prior ? w->prior->n_blocks : 0;
     h.pt_stride = rup(std::max(h.n_pt_obs, 1), 8); h.ln_stride = rup(std::max(h.n_ln_obs, 1), 8);
-    h.td_on = td_on ? 1 : 0; h.pt_rec = td_on ? UVS_PT_REC_TD : UVS_PT_REC; h.pt_xslots = td_on ? 2 : 1;
+    const bool ex_on = opts.estimate_extrinsic != 0;
+    h.td_on = td_on ? 1 : 0; h.ex_on = ex_on ? 1 : 0;
+    h.pt_rec = ex_on ? UVS_PT_REC_EX : td_on ? UVS_PT_REC_TD : UVS_PT_REC; h.pt_xslots = 1 + (td_on ? 1 : 0) + (ex_on ? 1 : 0);
     const int PREC = h.pt_rec, XS = h.pt_xslots;
     // CSR by landmark
     std::vector<int> pbeg(h.n_points + 1, 0), lbeg(h.n_lines + 1, 0);
@@ -266,10 +267,11 @@ static int pack_window(const uvs_window* w, const uvs_options& opts, std::vector
                 const int li = k - k0, b0 = pbeg[k] - o0, b1 = pbeg[k + 1] - o0;
                 if (b1 == b0) continue;
                 const int first_slot = b0 + XS * li;
-                int fr[UVS_NUM_FRAMES + 2], nf = 0;
+                int fr[UVS_NUM_FRAMES + 3], nf = 0;
                 fr[nf++] = w->pt_fi[o0 + b0];
                 for (int o = b0; o < b1; ++o) fr[nf++] = w->pt_fj[o0 + o];
-                if (td_on) fr[nf++] = UVS_NUM_FRAMES;                                  // last slot: the td row of this landmark
+                if (td_on) fr[nf++] = UVS_NUM_FRAMES;                                  // then the td slot of this landmark (pseudo frame 11)
+                if (ex_on) fr[nf++] = UVS_NUM_FRAMES + 1;                              // then its extrinsic slot (pseudo frame 12)
                 for (int sa = 0; sa < nf; ++sa) for (int sb = 0; sb <= sa; ++sb)      // frames increase with the slot => fr[sa] >= fr[sb]
                     S[blk_of(fr[sa], fr[sb])].push_back((oE + 6 * (first_slot + sa)) | ((oEI + 6 * (first_slot + sb)) << 16));
                 for (int o = b0; o < b1; ++o) {
@@ -281,6 +283,13 @@ static int pack_window(const uvs_window* w, const uvs_options& opts, std::vector
                         Dr[blk_of(UVS_NUM_FRAMES, fi)].push_back((ro + UVS_PT_TD) | ((ro + UVS_PT_A) << 16));
                         Dr[blk_of(UVS_NUM_FRAMES, fj)].push_back((ro + UVS_PT_TD) | ((ro + UVS_PT_B) << 16));
                         Dr[blk_of(UVS_NUM_FRAMES, UVS_NUM_FRAMES)].push_back((ro + UVS_PT_TD) | ((ro + UVS_PT_TD) << 16));
+                    }
+                    if (ex_on) {                                                       // J_ex^T [A | B | J_td | J_ex]
+                        const int X = UVS_NUM_FRAMES + 1;
+                        Dr[blk_of(X, fi)].push_back((ro + UVS_PT_EX) | ((ro + UVS_PT_A) << 16));
+                        Dr[blk_of(X, fj)].push_back((ro + UVS_PT_EX) | ((ro + UVS_PT_B) << 16));
+                        if (td_on) Dr[blk_of(X, UVS_NUM_FRAMES)].push_back((ro + UVS_PT_EX) | ((ro + UVS_PT_TD) << 16));
+                        Dr[blk_of(X, X)].push_back((ro + UVS_PT_EX) | ((ro + UVS_PT_EX) << 16));
                     }
                 }
             }
@@ -306,7 +315,10 @@ static int pack_window(const uvs_window* w, const uvs_options& opts, std::vector
         struct Item { int b, part, np; long work; double shape; };
         // water-filling: hand the spare groups, one at a time, to the block whose per-group share is largest (at most 16 parts)
         int np[UVS_NBLKX]; int used = 0;
-        for (int b = 0; b < UVS_NBLKX; ++b) { np[b] = (b < UVS_NBLK || td_on) ? 1 : 0; used += np[b]; }      // the td row blocks only exist with ESTIMATE_TD
+        for (int b = 0; b < UVS_NBLKX; ++b) {      // the pseudo-frame blocks only exist with their option
+            const bool tdb = b >= UVS_NBLK && b < UVS_NBLK + UVS_NF + 1, exb = b >= UVS_NBLK + UVS_NF + 1;
+            np[b] = (b < UVS_NBLK || (tdb && td_on) || (exb && ex_on && (td_on || b != UVS_NBLK + UVS_NF + 1 + UVS_NF))) ? 1 : 0; used += np[b];
+        }
         while (used < UVS_NGRP) {
             int best = -1;
             for (int b = 0; b < UVS_NBLKX; ++b) if (np[b] < 16 && blk_work[b] > 0 && (best < 0 || blk_work[b] * np[best] > blk_work[best] * np[b])) best = b;
@@ -326,7 +338,7 @@ static int pack_window(const uvs_window* w, const uvs_options& opts, std::vector
         for (size_t q = 0; q < items.size(); ++q) {
             const int g = wave_of_rank[q / GRP_PER_WAVE] * GRP_PER_WAVE + (int)(q % GRP_PER_WAVE);
             const int b = items[q].b;
-            const int bfa = b >= UVS_NBLK ? UVS_NUM_FRAMES : (int)((std::sqrt(8.0 * b + 1.0) - 1.0) * 0.5 + 1e-9), bfb = b - bfa * (bfa + 1) / 2;     // b = fa(fa+1)/2 + fb
+            const int bfa = b >= UVS_NBLK + UVS_NF + 1 ? UVS_NUM_FRAMES + 1 : b >= UVS_NBLK ? UVS_NUM_FRAMES : (int)((std::sqrt(8.0 * b + 1.0) - 1.0) * 0.5 + 1e-9), bfb = b - bfa * (bfa + 1) / 2;     // b = fa(fa+1)/2 + fb
             wblk[g] = b | (bfa == bfb ? 256 : 0) | (items[q].part << 9) | (bfa << 13) | (bfb << 17);
             g_blk[g] = b; g_part[g] = items[q].part; g_np[g] = items[q].np;
         }
@@ -395,6 +407,7 @@ static int pack_window(const uvs_window* w, const uvs_options& opts, std::vector
         for (int b = 0; b < w->prior->n_blocks; ++b)
             if (w->prior->block_kind[b] == UVS_BLOCK_POSE || w->prior->block_kind[b] == UVS_BLOCK_SPEEDBIAS) in[w->prior->block_frame[b]] = true;
             else if (w->prior->block_kind[b] == UVS_BLOCK_TD && td_on) in[UVS_NUM_FRAMES - 1] = true;       // td lives in the last frame's block row
+            else if (w->prior->block_kind[b] == UVS_BLOCK_EX_POSE && ex_on) for (int q = 0; q < 6; ++q) in[q] = true;      // ex dofs live in frames 0..5
         for (int fa = 0; fa < UVS_NUM_FRAMES; ++fa) for (int fb = 0; fb <= fa; ++fb) if (in[fa] && in[fb]) pblk.push_back(fa * (fa + 1) / 2 + fb);
     }
     h.n_pblk = (int)pblk.size();
@@ -454,9 +467,13 @@ static int pack_window(const uvs_window* w, const uvs_options& opts, std::vector
             if (p.block_kind[b] == UVS_BLOCK_POSE) basecol = 16 * p.block_frame[b];
             else if (p.block_kind[b] == UVS_BLOCK_SPEEDBIAS) basecol = 16 * p.block_frame[b] + 6;
             else if (p.block_kind[b] == UVS_BLOCK_TD && td_on) basecol = UVS_TD_INDEX;
-            // Ex_Pose is constant (ESTIMATE_EXTRINSIC == 0): its columns are dropped
-            for (int q = 0; q < loc; ++q) pt[80 + p.block_idx[b] + q] = basecol < 0 ? -1 : basecol + q;
-            if (basecol >= 0) for (int q = 0; q < loc; ++q) pt[80 + UVS_MAX_PRIOR_DIM + basecol + q] = p.block_idx[b] + q;      // S index -> prior column
+            const bool exb = p.block_kind[b] == UVS_BLOCK_EX_POSE && ex_on;
+            // a constant Ex_Pose (ESTIMATE_EXTRINSIC == 0) drops its columns; a free one maps dof q to the spare slot of frame q
+            for (int q = 0; q < loc; ++q) {
+                const int si = exb ? UVS_EX_INDEX(q) : (basecol < 0 ? -1 : basecol + q);
+                pt[80 + p.block_idx[b] + q] = si;
+                if (si >= 0) pt[80 + UVS_MAX_PRIOR_DIM + si] = p.block_idx[b] + q;      // S index -> prior column
+            }
         }
         for (size_t q = 0; q < pblk.size(); ++q) pt[80 + UVS_MAX_PRIOR_DIM + UVS_RD + q] = pblk[q];
     }
@@ -634,6 +651,7 @@ int uvs_large_begin(uvs_solver* s, const uvs_window* w) {
     double x2 = 0.0;
     for (int f = 0; f < UVS_NUM_FRAMES; ++f) { for (int k = 0; k < 7; ++k) x2 += w->pose[f][k] * w->pose[f][k]; for (int k = 0; k < 9; ++k) x2 += w->speedbias[f][k] * w->speedbias[f][k]; }
     if (s->opts.estimate_td) x2 += w->td * w->td;
+    if (s->opts.estimate_extrinsic) for (int k = 0; k < 7; ++k) x2 += w->ex_pose[k] * w->ex_pose[k];
     double l2 = 0.0;
     for (int k = 0; k < w->n_points; ++k) l2 += w->inv_depth[k] * w->inv_depth[k];
     for (int k = 0; k < 4 * w->n_lines; ++k) l2 += w->line_orth[k] * w->line_orth[k];

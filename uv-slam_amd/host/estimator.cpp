@@ -24,7 +24,7 @@ Estimator::Estimator() : solver_flag(NON_LINEAR), marginalization_flag(MARGIN_OL
     for (auto& p : pre_integrations) p = nullptr;
     for (int i = 0; i <= WINDOW_SIZE; ++i) Rs[i].setIdentity();
     uvs_options o; uvs_default_options(&o);
-    o.estimate_td = ESTIMATE_TD;      // fixed for the lifetime of the handle, like the reference's global (parameters.cpp)
+    o.estimate_td = ESTIMATE_TD; o.estimate_extrinsic = ESTIMATE_EXTRINSIC != 0;      // fixed for the lifetime of the handle, like the reference's globals (parameters.cpp)
     const int rc = uvs_create(&o, 0, 1, NUM_OF_F, NUM_OF_F * (WINDOW_SIZE + 1), NUM_OF_LF, NUM_OF_LF * (WINDOW_SIZE + 1), &solver);
     if (rc != UVS_OK) throw std::runtime_error(std::string("uvs_create: ") + uvs_status_string(rc));     // no CPU fallback
 }

@@ -116,6 +116,7 @@ inline void Solve(const Options& options, Problem* problem, Summary* summary, uv
     if (summary->status != UVS_OK && summary->status != UVS_ERR_NUMERIC) return;      // like the reference, the caller ignores the summary
     std::memcpy(problem->map.pose, st.pose, sizeof(st.pose)); std::memcpy(problem->map.speedbias, st.speedbias, sizeof(st.speedbias));
     problem->map.td[0][0] = st.td;
+    std::memcpy(problem->map.ex_pose[0], st.ex_pose, sizeof(st.ex_pose));      // unchanged unless ESTIMATE_EXTRINSIC
     for (int k = 0; k < n_points; ++k) problem->map.feature[k][0] = invd[k];
     for (int k = 0; k < 4 * n_lines; ++k) (&problem->map.ortho[0][0])[k] = lines[k];
 }
