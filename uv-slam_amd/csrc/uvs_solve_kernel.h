@@ -172,23 +172,33 @@ UVS_DEV void prior_dx(const Ctx& c, const double* x) {
         }
     }
 }
-UVS_DEV double prior_residual(const Ctx& c) {   // after prior_dx + barrier; fills L_PR, returns this thread's 0.5 r^2 share
+// r = r0 + J0 dx (marginalization_factor.cpp:364) after prior_dx + barrier; fills L_PR, returns this thread's 0.5 r^2 share.
+// Every row's dot product is split over up to 4 lanes (NT / n) with 8 loads in flight each: the 45 KB of J0 come from L2 / HBM on every
+// evaluation and a 75-lane, 75-deep dependent chain paid the full memory latency 75 times.  Partials meet in the (dead) S region;
+// contains one workgroup barrier, so all threads must call it.
+UVS_DEV double prior_residual(const Ctx& c) {
     const DevWin& h = *c.hdr;
     const int n = h.prior_n, tid = threadIdx.x;
     double cost = 0.0;
-    if (tid < n) {
+    if (n <= 0) return cost;
+    const int parts = (NT / n) < 4 ? (NT / n) : 4;
+    const int part = tid / n, row = tid - part * n;
+    if (part < parts) {
         const double* J0T = c.bd + h.d_prior + n * n;      // transposed copy: consecutive lanes read consecutive addresses
-        double s = c.bd[h.d_prior + 2 * n * n + tid];
-        {   // marginalization_factor.cpp:364; 8 independent partial sums keep 8 HBM/L2 loads in flight (a dependent chain pays the full latency 75 times)
-            double p8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            int k = 0;
-            for (; k + 8 <= n; k += 8) {
+        const int kb = (n * part) / parts, ke = (n * (part + 1)) / parts;
+        double p8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int k = kb;
+        for (; k + 8 <= ke; k += 8) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) p8[u] += J0T[(k + u) * n + tid] * c.sh[L_PDX + k + u];
-            }
-            for (; k < n; ++k) p8[0] += J0T[k * n + tid] * c.sh[L_PDX + k];
-            s += ((p8[0] + p8[1]) + (p8[2] + p8[3])) + ((p8[4] + p8[5]) + (p8[6] + p8[7]));
+            for (int u = 0; u < 8; ++u) p8[u] += J0T[(k + u) * n + row] * c.sh[L_PDX + k + u];
         }
+        for (; k < ke; ++k) p8[0] += J0T[k * n + row] * c.sh[L_PDX + k];
+        c.sh[L_S + 128 * part + row] = ((p8[0] + p8[1]) + (p8[2] + p8[3])) + ((p8[4] + p8[5]) + (p8[6] + p8[7]));
+    }
+    __syncthreads();
+    if (tid < n) {
+        double s = c.bd[h.d_prior + 2 * n * n + tid];
+        for (int p = 0; p < parts; ++p) s += c.sh[L_S + 128 * p + tid];
         c.sh[L_PR + tid] = s;
         cost = 0.5 * s * s;
     }
@@ -1060,31 +1070,39 @@ UVS_DEV void lin_assemble(const Ctx& c, const double* x, bool first, double radi
             const double* img = c.ws + h.w_prior_img;
             const int tot = h.n_pblk * UVS_BLK_SZ;
             const int* off = (const int*)(img + tot);
-            for (int t0 = tid; t0 < tot; t0 += 8 * NT) {
-                int idx[8]; double v[8], cur[8];
+            for (int t0 = tid; t0 < tot; t0 += 16 * NT) {      // 32 independent loads in flight per trip (one trip for the 5-frame prior)
+                int idx[16]; double v[16], cur[16];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) { const int t = t0 + u * NT; const bool in = t < tot; idx[u] = in ? off[t] : -1; v[u] = in ? img[t] : 0.0; }
+                for (int u = 0; u < 16; ++u) { const int t = t0 + u * NT; const bool in = t < tot; idx[u] = in ? off[t] : -1; v[u] = in ? img[t] : 0.0; }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) cur[u] = sh[L_S + (idx[u] >= 0 ? idx[u] : 0)];
+                for (int u = 0; u < 16; ++u) cur[u] = sh[L_S + (idx[u] >= 0 ? idx[u] : 0)];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) if (idx[u] >= 0) sh[L_S + idx[u]] = cur[u] + v[u];
+                for (int u = 0; u < 16; ++u) if (idx[u] >= 0) sh[L_S + idx[u]] = cur[u] + v[u];
             }
-            // diag(J0^T J0) -> HD: read back from the touched diagonal blocks' prior share is not separable any more, so use the image
-            const int* pb = c.bi + h.i_prior + 80 + UVS_MAX_PRIOR_DIM + UVS_RD;
-            for (int t = tid; t < h.n_pblk * 16; t += NT) {
-                const int sl = t >> 4, r = t & 15, b = pb[sl];
-                if (c_blk_fa[b] == c_blk_fb[b]) sh[L_HD + 16 * c_blk_fa[b] + r] += img[sl * UVS_BLK_SZ + r * UVS_BLK_LD + r];
-            }
+            if (tid < UVS_RD) sh[L_HD + tid] += img[(tot * 3) / 2 + 2 + tid];      // diag(J0^T J0) by S index (setup_window)
         }
-        if (tid < n && cm[tid] >= 0) {
-            double p8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            int i = 0;
-            for (; i + 8 <= n; i += 8) {
+        {   // g += J0^T r, each column's dot product split over up to 3 lanes; partials in LDS words that are free right now (x_c, rhs, 1/L_kk)
+            const int parts = (NT / n) < 3 ? (NT / n) : 3;
+            const int part = tid / n, col = tid - part * n;
+            double* scr = part == 0 ? sh + L_XC : part == 1 ? sh + L_DLT : sh + L_DINV;
+            if (part < parts) {
+                const int ib = (n * part) / parts, ie = (n * (part + 1)) / parts;
+                double p8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                int i = ib;
+                for (; i + 8 <= ie; i += 8) {
 #pragma unroll
-                for (int u = 0; u < 8; ++u) p8[u] += J0[(i + u) * n + tid] * sh[L_PR + i + u];
+                    for (int u = 0; u < 8; ++u) p8[u] += J0[(i + u) * n + col] * sh[L_PR + i + u];
+                }
+                for (; i < ie; ++i) p8[0] += J0[i * n + col] * sh[L_PR + i];
+                scr[col] = ((p8[0] + p8[1]) + (p8[2] + p8[3])) + ((p8[4] + p8[5]) + (p8[6] + p8[7]));
             }
-            for (; i < n; ++i) p8[0] += J0[i * n + tid] * sh[L_PR + i];
-            sh[L_G + cm[tid]] += ((p8[0] + p8[1]) + (p8[2] + p8[3])) + ((p8[4] + p8[5]) + (p8[6] + p8[7]));
+            __syncthreads();
+            if (tid < n && cm[tid] >= 0) {
+                double sg = sh[L_XC + tid];
+                if (parts > 1) sg += sh[L_DLT + tid];
+                if (parts > 2) sg += sh[L_DINV + tid];
+                sh[L_G + cm[tid]] += sg;
+            }
         }
     }
     __syncthreads();
@@ -1338,6 +1356,13 @@ UVS_DEV void setup_window(const Ctx& c, double* blob_rw) {
             }
             img[t] = v;
             ((int*)(img + h.n_pblk * UVS_BLK_SZ))[t] = b * UVS_BLK_SZ + e;      // where the entry goes in S: the per-linearization add needs no index math
+        }
+        double* hdp = img + (h.n_pblk * UVS_BLK_SZ * 3) / 2 + 2;       // diag(J0^T J0) by S index (added to L_HD per linearization)
+        if (tid < UVS_RD) {
+            const int a = inv[tid];
+            double v = 0.0;
+            if (a >= 0) for (int i = 0; i < n; ++i) v += Jl[i * n + a] * Jl[i * n + a];
+            hdp[tid] = v;
         }
     }
 }

@@ -411,7 +411,7 @@ static int pack_window(const uvs_window* w, const uvs_options& opts, std::vector
         for (int fa = 0; fa < UVS_NUM_FRAMES; ++fa) for (int fb = 0; fb <= fa; ++fb) if (in[fa] && in[fb]) pblk.push_back(fa * (fa + 1) / 2 + fb);
     }
     h.n_pblk = (int)pblk.size();
-    h.w_prior_img = wsz; wsz += std::max(h.n_pblk, 1) * UVS_BLK_SZ * 3 / 2 + 2;      // values, then their int32 S offsets
+    h.w_prior_img = wsz; wsz += std::max(h.n_pblk, 1) * UVS_BLK_SZ * 3 / 2 + 2 + UVS_RD;      // values, their int32 S offsets, diag(J0^T J0) per S index
     h.ws_doubles = rup(wsz, 32);
     // fill
     const size_t base = out.size();
