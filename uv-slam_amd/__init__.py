@@ -10,7 +10,7 @@ Layout:
 The directory name contains a hyphen (it is the name the build contract asks for), so import it with
 `importlib.import_module("uv-slam_amd")`.
 """
-from . import abi, synth, dist  # noqa: F401
+from . import abi, synth, dist, sequence  # noqa: F401
 
 
 def __getattr__(name):

@@ -250,6 +250,44 @@ class Window:
                     f.write(i32(list(getattr(p, name))))
                 f.write(f64(list(p.x0))); f.write(f64(p.r0())); f.write(f64(p.J0()))
 
+    @staticmethod
+    def load(path):
+        """Reads a window file (the layout of save() / host/window_io.h), e.g. one written by the UVS_DUMP_WINDOWS record hook."""
+        buf = open(path, "rb").read()
+        if buf[:8] != b"UVSWIN01": raise ValueError("not a window file: %s" % path)
+        pos = [8]
+
+        def take(dtype, n):
+            a = np.frombuffer(buf, dtype=dtype, count=n, offset=pos[0]).copy(); pos[0] += a.nbytes; return a
+
+        np_, npo, nl, nlo, ni, pn, pnb, has_td = (int(v) for v in take("<i4", 8))
+        w = Window()
+        w.pose = take("<f8", 77).reshape(NUM_FRAMES, 7); w.speedbias = take("<f8", 99).reshape(NUM_FRAMES, 9); w.ex_pose = take("<f8", 7); w.td = float(take("<f8", 1)[0])
+        w.inv_depth = take("<f8", np_)
+        w.pt_lm, w.pt_fi, w.pt_fj = take("<i4", npo), take("<i4", npo), take("<i4", npo)
+        if npo % 2: take("<i4", 1)
+        w.pt_pi = take("<f8", 3 * npo).reshape(-1, 3); w.pt_pj = take("<f8", 3 * npo).reshape(-1, 3)
+        if has_td:
+            w.pt_vel_i = take("<f8", 2 * npo).reshape(-1, 2); w.pt_vel_j = take("<f8", 2 * npo).reshape(-1, 2); w.pt_td_i = take("<f8", npo); w.pt_td_j = take("<f8", npo)
+        w.line_orth = take("<f8", 4 * nl).reshape(-1, 4)
+        w.ln_lm, w.ln_fj, w.ln_has_vp = take("<i4", nlo), take("<i4", nlo), take("<i4", nlo)
+        if nlo % 2: take("<i4", 1)
+        w.ln_sp = take("<f8", 3 * nlo).reshape(-1, 3); w.ln_ep = take("<f8", 3 * nlo).reshape(-1, 3); w.ln_vp = take("<f8", 3 * nlo).reshape(-1, 3)
+        for _ in range(ni):
+            h = take("<f8", 17); jac = take("<f8", 225).reshape(15, 15); cov = take("<f8", 225).reshape(15, 15); fs = take("<i4", 2)
+            w.imu.append(dict(sum_dt=float(h[0]), delta_p=h[1:4], delta_q=h[4:8], delta_v=h[8:11], linearized_ba=h[11:14], linearized_bg=h[14:17],
+                              jacobian=jac, covariance=cov, frame_i=int(fs[0]), skip=int(fs[1])))
+        if pn > 0:
+            p = Prior(); p.n = pn; p.n_blocks = pnb
+            for name in ("block_kind", "block_frame", "block_size", "block_idx", "x0_off"):
+                v = take("<i4", 16)
+                for k in range(16): getattr(p, name)[k] = int(v[k])
+            x0 = take("<f8", 144); r0 = take("<f8", pn); J0 = take("<f8", pn * pn)
+            for k in range(144): p.x0[k] = x0[k]
+            C.memmove(p.linearized_residuals, r0.ctypes.data, r0.nbytes); C.memmove(p.linearized_jacobians, J0.ctypes.data, J0.nbytes)
+            w.prior = p
+        return w
+
     def copy(self):
         import copy
         o = Window()

@@ -81,5 +81,7 @@ struct Quaterniond {
     static Quaterniond Identity() { return {}; }
 };
 typedef std::vector<double> VectorXd;
+// the front-end hands features over as Eigen::Matrix<double, 7, 1> / <double, 15, 1> columns (estimator.h:41-42): element access only
+template <typename T, int R, int C> struct Matrix { T v[R * C]; Matrix() { for (auto& e : v) e = 0; } T& operator()(int i) { return v[i]; } T operator()(int i) const { return v[i]; } };
 }  // namespace Eigen
 #endif

@@ -2,7 +2,9 @@
 // (vins_estimator/src/estimator.cpp:526-711, 761-1233), the Ceres problem replaced by uvs::Problem and the
 // marginalization by uvs_marginalize().  See INTEGRATION.md for the diff a maintainer applies to the reference file.
 #include "estimator.h"
+#include <cstdlib>
 #include <stdexcept>
+#include "window_io.h"
 
 double FOCAL_LENGTH, INIT_DEPTH, MIN_PARALLAX, ACC_N, ACC_W, GYR_N, GYR_W, SOLVER_TIME, TD, TR, LINE_FACTOR, VP_FACTOR, ROW, COL;
 int ESTIMATE_EXTRINSIC, ESTIMATE_TD, NUM_ITERATIONS, LINE_WINDOW;
@@ -19,7 +21,7 @@ void setEurocParameters() {          // config/euroc/euroc_config.yaml
     TIC.assign(1, Eigen::Vector3d(-0.0216401454975, -0.064676986768, 0.00981073058949));
 }
 
-Estimator::Estimator() : solver_flag(NON_LINEAR), marginalization_flag(MARGIN_OLD), td(0), failure_occur(false), last_marginalization_info(nullptr), solver(nullptr) {
+Estimator::Estimator() : frame_count(0), first_imu(false), sum_of_back(0), sum_of_front(0), solver_flag(NON_LINEAR), marginalization_flag(MARGIN_OLD), td(0), failure_occur(false), last_marginalization_info(nullptr), solver(nullptr) {
     f_manager.Rs = Rs;      // estimator.cpp:9 `f_manager{Rs}`
     for (auto& p : pre_integrations) p = nullptr;
     for (int i = 0; i <= WINDOW_SIZE; ++i) Rs[i].setIdentity();
@@ -139,6 +141,14 @@ void Estimator::optimization() {      // estimator.cpp:761-1233
                 problem.AddResidualBlock(new VPProjectionFactor(ric[0], tic[0], it_per_frame.start_point, it_per_frame.end_point, it_per_frame.vp), vp_loss_function, para_Pose[imu_j], para_Ortho_plucker[line_feature_index]);
         }
     }
+    // record hook (the reference has no serialisation): UVS_DUMP_WINDOWS=<dir> writes every window exactly as the
+    // solver receives it (the state after vector2double(), estimator.cpp:800) to <dir>/window_NNNN.bin for replay without ROS
+    if (const char* dump_dir = std::getenv("UVS_DUMP_WINDOWS")) {
+        static int dump_index = 0;
+        uvs_window dw; problem.fill(&dw, feature_index + 1, line_feature_index + 1);
+        char name[32]; std::snprintf(name, sizeof(name), "/window_%04d.bin", dump_index++);
+        WindowFile::save(std::string(dump_dir) + name, dw);
+    }
     uvs::Options options; options.max_num_iterations = NUM_ITERATIONS;
     uvs::Solve(options, &problem, &last_summary, solver, feature_index + 1, line_feature_index + 1);
     // ---- marginalization on the post-solve para_* arrays, BEFORE double2vector() re-anchors the gauge: the reference calls
@@ -158,4 +168,154 @@ void Estimator::optimization() {      // estimator.cpp:761-1233
     if (problem.ln_lm.empty()) delete line_loss_function;
     bool any_vp = false; for (int v : problem.ln_has_vp) any_vp |= (v != 0);
     if (!any_vp) delete vp_loss_function;
+}
+
+// ====================================================================== per-frame state machine (post-initialization part)
+void Estimator::clearState() {        // estimator.cpp:23-82 (the members this mirror has)
+    for (int i = 0; i < WINDOW_SIZE + 1; i++) {
+        Rs[i].setIdentity(); Ps[i].setZero(); Vs[i].setZero(); Bas[i].setZero(); Bgs[i].setZero();
+        dt_buf[i].clear(); linear_acceleration_buf[i].clear(); angular_velocity_buf[i].clear();
+        delete pre_integrations[i]; pre_integrations[i] = nullptr;
+    }
+    for (int i = 0; i < NUM_OF_CAM; i++) { tic[i] = Eigen::Vector3d::Zero(); ric[i] = Eigen::Matrix3d::Identity(); }
+    solver_flag = INITIAL; first_imu = false; sum_of_back = 0; sum_of_front = 0; frame_count = 0; td = TD;
+    delete last_marginalization_info; last_marginalization_info = nullptr;
+    f_manager.clearState();
+    failure_occur = 0;
+}
+
+void Estimator::processIMU(double dt, const Eigen::Vector3d& linear_acceleration, const Eigen::Vector3d& angular_velocity) {   // estimator.cpp:84-118
+    if (!first_imu) { first_imu = true; acc_0 = linear_acceleration; gyr_0 = angular_velocity; }
+    if (!pre_integrations[frame_count]) pre_integrations[frame_count] = new IntegrationBase{acc_0, gyr_0, Bas[frame_count], Bgs[frame_count]};
+    if (frame_count != 0) {
+        pre_integrations[frame_count]->push_back(dt, linear_acceleration, angular_velocity);
+        dt_buf[frame_count].push_back(dt);
+        linear_acceleration_buf[frame_count].push_back(linear_acceleration);
+        angular_velocity_buf[frame_count].push_back(angular_velocity);
+        const int j = frame_count;
+        Eigen::Vector3d un_acc_0 = Rs[j] * (acc_0 - Bas[j]) - G;
+        Eigen::Vector3d un_gyr = (gyr_0 + angular_velocity) * 0.5 - Bgs[j];
+        Rs[j] = Rs[j] * Utility::deltaQ(un_gyr * dt).toRotationMatrix();
+        Eigen::Vector3d un_acc_1 = Rs[j] * (linear_acceleration - Bas[j]) - G;
+        Eigen::Vector3d un_acc = (un_acc_0 + un_acc_1) * 0.5;
+        Ps[j] = Ps[j] + Vs[j] * dt + un_acc * (0.5 * dt * dt);
+        Vs[j] = Vs[j] + un_acc * dt;
+    }
+    acc_0 = linear_acceleration; gyr_0 = angular_velocity;
+}
+
+void Estimator::processImage(const FeatureManager::ImagePoints& image, const FeatureManager::ImageLines& image_line, const std_msgs::Header& header) {   // estimator.cpp:120-222
+    marginalization_flag = f_manager.addFeatureCheckParallax(frame_count, image, image_line, td) ? MARGIN_OLD : MARGIN_SECOND_NEW;
+    Headers[frame_count] = header;
+    // (all_image_frame / tmp_pre_integration feed initialStructure only; the ESTIMATE_EXTRINSIC == 2 rotation calibration is initialization too)
+    if (solver_flag == INITIAL) {      // :161-190
+        if (frame_count == WINDOW_SIZE) {
+            if (ESTIMATE_EXTRINSIC != 2 && initialStructure()) {
+                solver_flag = NON_LINEAR;
+                solveOdometry();
+                slideWindow();
+                f_manager.removeFailures();
+                f_manager.removeLineFailures();
+                last_R = Rs[WINDOW_SIZE]; last_P = Ps[WINDOW_SIZE]; last_R0 = Rs[0]; last_P0 = Ps[0];
+            } else slideWindow();
+        } else frame_count++;
+        return;
+    }
+    solveOdometry();
+    if (failureDetection()) { failure_occur = 1; clearState(); setParameter(); return; }
+    slideWindow();
+    f_manager.removeFailures();
+    f_manager.removeLineFailures();
+    key_poses.clear();
+    for (int i = 0; i <= WINDOW_SIZE; i++) key_poses.push_back(Ps[i]);
+    last_R = Rs[WINDOW_SIZE]; last_P = Ps[WINDOW_SIZE]; last_R0 = Rs[0]; last_P0 = Ps[0];
+}
+
+void Estimator::setInitialWindow(const double (*pose)[7], const double (*speedbias)[9]) {
+    initial_window.assign(&pose[0][0], &pose[0][0] + 7 * (WINDOW_SIZE + 1));
+    initial_window.insert(initial_window.end(), &speedbias[0][0], &speedbias[0][0] + 9 * (WINDOW_SIZE + 1));
+}
+
+bool Estimator::initialStructure() {
+    // stand-in: installs what initialStructure() + visualInitialAlign() leave behind (estimator.cpp:370-446) -- window states,
+    // pre-integrations re-propagated with the aligned biases (:385-390), depths cleared for re-triangulation (:392-398)
+    if (initial_window.empty()) return false;
+    const double* pose = initial_window.data(); const double* sb = pose + 7 * (WINDOW_SIZE + 1);
+    for (int i = 0; i <= WINDOW_SIZE; ++i, pose += 7, sb += 9) {
+        Ps[i] = Eigen::Vector3d(pose[0], pose[1], pose[2]);
+        Rs[i] = Eigen::Quaterniond(pose[6], pose[3], pose[4], pose[5]).normalized().toRotationMatrix();
+        Vs[i] = Eigen::Vector3d(sb[0], sb[1], sb[2]); Bas[i] = Eigen::Vector3d(sb[3], sb[4], sb[5]); Bgs[i] = Eigen::Vector3d(sb[6], sb[7], sb[8]);
+        if (pre_integrations[i] && i > 0) pre_integrations[i]->repropagate(Bas[i], Bgs[i]);
+    }
+    for (auto& it : f_manager.feature) it.estimated_depth = -1;
+    initial_window.clear();
+    return true;
+}
+
+void Estimator::solveOdometry() {      // estimator.cpp:511-524
+    if (frame_count < WINDOW_SIZE) return;
+    if (solver_flag == NON_LINEAR) {
+        f_manager.triangulate(Ps, tic, ric);
+        f_manager.triangulateLine(Ps, Rs, tic, ric);
+        optimization();
+    }
+}
+
+bool Estimator::failureDetection() {   // estimator.cpp:713-760 (the checks that return true)
+    if (Bas[WINDOW_SIZE].norm() > 2.5) return true;
+    if (Bgs[WINDOW_SIZE].norm() > 1.0) return true;
+    Eigen::Vector3d tmp_P = Ps[WINDOW_SIZE];
+    if ((tmp_P - last_P).norm() > 5) return true;
+    if (std::abs(tmp_P.z() - last_P.z()) > 1) return true;
+    return false;
+}
+
+void Estimator::slideWindow() {        // estimator.cpp:1235-1331
+    if (marginalization_flag == MARGIN_OLD) {
+        back_R0 = Rs[0]; back_P0 = Ps[0];
+        if (frame_count == WINDOW_SIZE) {
+            for (int i = 0; i < WINDOW_SIZE; i++) {
+                std::swap(Rs[i], Rs[i + 1]);
+                std::swap(pre_integrations[i], pre_integrations[i + 1]);
+                dt_buf[i].swap(dt_buf[i + 1]); linear_acceleration_buf[i].swap(linear_acceleration_buf[i + 1]); angular_velocity_buf[i].swap(angular_velocity_buf[i + 1]);
+                Headers[i] = Headers[i + 1];
+                std::swap(Ps[i], Ps[i + 1]); std::swap(Vs[i], Vs[i + 1]); std::swap(Bas[i], Bas[i + 1]); std::swap(Bgs[i], Bgs[i + 1]);
+            }
+            Headers[WINDOW_SIZE] = Headers[WINDOW_SIZE - 1];
+            Ps[WINDOW_SIZE] = Ps[WINDOW_SIZE - 1]; Vs[WINDOW_SIZE] = Vs[WINDOW_SIZE - 1]; Rs[WINDOW_SIZE] = Rs[WINDOW_SIZE - 1];
+            Bas[WINDOW_SIZE] = Bas[WINDOW_SIZE - 1]; Bgs[WINDOW_SIZE] = Bgs[WINDOW_SIZE - 1];
+            delete pre_integrations[WINDOW_SIZE];
+            pre_integrations[WINDOW_SIZE] = new IntegrationBase{acc_0, gyr_0, Bas[WINDOW_SIZE], Bgs[WINDOW_SIZE]};
+            dt_buf[WINDOW_SIZE].clear(); linear_acceleration_buf[WINDOW_SIZE].clear(); angular_velocity_buf[WINDOW_SIZE].clear();
+            slideWindowOld();
+        }
+    } else if (frame_count == WINDOW_SIZE) {
+        for (unsigned int i = 0; i < dt_buf[frame_count].size(); i++) {
+            const double tmp_dt = dt_buf[frame_count][i];
+            const Eigen::Vector3d tmp_linear_acceleration = linear_acceleration_buf[frame_count][i], tmp_angular_velocity = angular_velocity_buf[frame_count][i];
+            pre_integrations[frame_count - 1]->push_back(tmp_dt, tmp_linear_acceleration, tmp_angular_velocity);
+            dt_buf[frame_count - 1].push_back(tmp_dt);
+            linear_acceleration_buf[frame_count - 1].push_back(tmp_linear_acceleration);
+            angular_velocity_buf[frame_count - 1].push_back(tmp_angular_velocity);
+        }
+        Headers[frame_count - 1] = Headers[frame_count];
+        Ps[frame_count - 1] = Ps[frame_count]; Vs[frame_count - 1] = Vs[frame_count]; Rs[frame_count - 1] = Rs[frame_count];
+        Bas[frame_count - 1] = Bas[frame_count]; Bgs[frame_count - 1] = Bgs[frame_count];
+        delete pre_integrations[WINDOW_SIZE];
+        pre_integrations[WINDOW_SIZE] = new IntegrationBase{acc_0, gyr_0, Bas[WINDOW_SIZE], Bgs[WINDOW_SIZE]};
+        dt_buf[WINDOW_SIZE].clear(); linear_acceleration_buf[WINDOW_SIZE].clear(); angular_velocity_buf[WINDOW_SIZE].clear();
+        slideWindowNew();
+    }
+}
+
+void Estimator::slideWindowNew() { sum_of_front++; f_manager.removeFront(frame_count); f_manager.removeLineFront(frame_count); }      // :1333-1338
+
+void Estimator::slideWindowOld() {     // :1340-1359
+    sum_of_back++;
+    if (solver_flag == NON_LINEAR) {
+        Eigen::Matrix3d R0 = back_R0 * ric[0], R1 = Rs[0] * ric[0];
+        Eigen::Vector3d P0 = back_P0 + back_R0 * tic[0], P1 = Ps[0] + Rs[0] * tic[0];
+        f_manager.removeBackShiftDepth(R0, P0, R1, P1);
+    } else f_manager.removeBack();
+    f_manager.removeLineBack();
 }

@@ -1,11 +1,17 @@
 // estimator.h -- host mirror of the hot-path part of class Estimator (vins_estimator/src/estimator.h:28-146):
-// same member names, same optimization() / vector2double() / double2vector() signatures.  The state machine around it
-// (processIMU / processImage / initialStructure / slideWindow / failureDetection) is out of scope.
+// same member names, same optimization() / vector2double() / double2vector() signatures.  For closed-loop replay of a frame
+// sequence the post-initialization part of the state machine around it is mirrored too: processIMU (:84-118), processImage
+// (:120-222, NON_LINEAR branch), solveOdometry (:511-524), failureDetection (:713-760), slideWindow / slideWindowNew /
+// slideWindowOld (:1235-1359).  initialStructure (:224-446: SfM + visual-inertial alignment) stays out of scope: the
+// replay hands the estimator the aligned initial window instead (setInitialWindow).
 #pragma once
 #include <algorithm>
+#include <map>
 #include "parameters.h"
 #include "feature_manager.h"
 #include "problem.h"
+
+namespace std_msgs { struct Header { struct Stamp { double t = 0; double toSec() const { return t; } } stamp; }; }      // the one field of std_msgs::Header the estimator reads
 
 class Estimator {
   public:
@@ -15,6 +21,29 @@ class Estimator {
     void optimization();
     void vector2double();
     void double2vector();
+    // ---- per-frame state machine (post-initialization)
+    void processIMU(double t, const Eigen::Vector3d& linear_acceleration, const Eigen::Vector3d& angular_velocity);
+    void processImage(const FeatureManager::ImagePoints& image, const FeatureManager::ImageLines& image_line, const std_msgs::Header& header);
+    void solveOdometry();
+    void slideWindow();
+    void slideWindowNew();
+    void slideWindowOld();
+    bool failureDetection();
+    void clearState();
+    // initialStructure() (:224-446) itself is out of scope; the replay supplies what it would leave behind (aligned states of frames
+    // 0..WINDOW_SIZE) through setInitialWindow(), and the stand-in below installs them when the window is full
+    void setInitialWindow(const double (*pose)[7], const double (*speedbias)[9]);
+    bool initialStructure();
+    std::vector<double> initial_window;      // [11][7] poses then [11][9] speed/bias; empty = none supplied => initialStructure() fails
+    int frame_count;
+    bool first_imu;
+    Eigen::Vector3d acc_0, gyr_0;
+    std::vector<double> dt_buf[(WINDOW_SIZE + 1)];
+    std::vector<Eigen::Vector3d> linear_acceleration_buf[(WINDOW_SIZE + 1)], angular_velocity_buf[(WINDOW_SIZE + 1)];
+    std_msgs::Header Headers[(WINDOW_SIZE + 1)];
+    Eigen::Matrix3d back_R0, last_R; Eigen::Vector3d back_P0, last_P;
+    int sum_of_back, sum_of_front;
+    std::vector<Eigen::Vector3d> key_poses;
     enum SolverFlag { INITIAL, NON_LINEAR };
     enum MarginalizationFlag { MARGIN_OLD = 0, MARGIN_SECOND_NEW = 1 };
     SolverFlag solver_flag;

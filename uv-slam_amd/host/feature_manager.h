@@ -2,10 +2,14 @@
 // and vector2double()/double2vector() touch: the per-id track lists and the get/set of solver parameters.
 // SURVEY.md 8f row 3 (the producers / consumers either side of the solve) is mirrored too: triangulate (:427-481),
 // triangulateLine (:504-589) with calcPluckerLine (:827-902), getDepthVector / getLineOrthonormal (:290-331), setDepth (:235-253),
-// setLineOrtho (:333-423).  Parallax / slide-window bookkeeping (feature_manager.cpp:73-158,591-725) is NOT mirrored (front-end side).
+// setLineOrtho (:333-423); and, for closed-loop replay of a frame sequence, the track bookkeeping either side of the solve:
+// addFeatureCheckParallax (:73-158) with compensatedParallax2 (:727-760), removeFailures / removeLineFailures (:255-276),
+// removeBackShiftDepth / removeBack / removeFront (:607-685), removeLineBack / removeLineFront (:687-725).
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <list>
+#include <map>
 #include <vector>
 #include "parameters.h"
 #include "utility.h"
@@ -13,6 +17,7 @@
 class FeaturePerFrame {      // feature_manager.h:18-43: point = normalised (x, y, 1), uv = pixel, velocity = image-plane velocity, cur_td = td at capture
   public:
     FeaturePerFrame(const Eigen::Vector3d& p) : point(p), cur_td(0) {}
+    FeaturePerFrame(const Eigen::Matrix<double, 7, 1>& _point, double td) : point(_point(0), _point(1), _point(2)), uv(_point(3), _point(4)), velocity(_point(5), _point(6)), cur_td(td) {}   // feature_manager.h:139-150
     FeaturePerFrame(const Eigen::Vector3d& p, const Eigen::Vector2d& _uv, const Eigen::Vector2d& _velocity, double td) : point(p), uv(_uv), velocity(_velocity), cur_td(td) {}
     Eigen::Vector3d point; Eigen::Vector2d uv, velocity; double cur_td;
 };
@@ -20,12 +25,20 @@ class FeaturePerId {
   public:
     const int feature_id; int start_frame; std::vector<FeaturePerFrame> feature_per_frame; int used_num; double estimated_depth; int solve_flag;
     FeaturePerId(int id, int start) : feature_id(id), start_frame(start), used_num(0), estimated_depth(-1.0), solve_flag(0) {}
+    int endFrame() const { return start_frame + (int)feature_per_frame.size() - 1; }      // feature_manager.cpp:8-11
 };
-class LineFeaturePerFrame { public: Eigen::Vector3d start_point, end_point, vp; };
+class LineFeaturePerFrame {
+  public:
+    LineFeaturePerFrame() {}
+    LineFeaturePerFrame(const Eigen::Matrix<double, 15, 1>& _point, double /*td*/)      // feature_manager.h:32-53: (sp.xy, ep.xy, uv x4, velocities x4, vp.xyz); only sp/ep/vp reach the solve
+        : start_point(_point(0), _point(1), 1.0), end_point(_point(2), _point(3), 1.0), vp(_point(12), _point(13), _point(14)) {}
+    Eigen::Vector3d start_point, end_point, vp;
+};
 class LineFeaturePerId {
   public:
     const int feature_id; int start_frame; std::vector<LineFeaturePerFrame> line_feature_per_frame; int used_num; Eigen::Vector4d orthonormal_vec; int solve_flag;
     LineFeaturePerId(int id, int start) : feature_id(id), start_frame(start), used_num(0), solve_flag(0) {}
+    int endFrame() const { return start_frame + (int)line_feature_per_frame.size() - 1; }      // feature_manager.cpp:3-6
 };
 
 // eigenvector of the smallest eigenvalue of a symmetric 4x4 (cyclic Jacobi): the right singular vector the reference takes from
@@ -137,6 +150,97 @@ class FeatureManager {
             it.orthonormal_vec = Vector4d(psi(0), psi(1), psi(2), std::atan2(d_w.norm(), n_w.norm()));
         }
     }
+    // ---------------------------------------------------------------- track bookkeeping around the solve (closed-loop replay)
+    int last_track_num = 0;
+    typedef std::map<int, std::vector<std::pair<int, Eigen::Matrix<double, 7, 1>>>> ImagePoints;
+    typedef std::map<int, std::vector<Eigen::Matrix<double, 15, 1>>> ImageLines;
+    // feature_manager.cpp:73-158: append this frame's observations to the tracks (new ids start a track at frame_count); returns true when
+    // the second-newest frame is a KEYFRAME (few tracked points, or enough parallax between frames frame_count-2 and frame_count-1)
+    bool addFeatureCheckParallax(int frame_count, const ImagePoints& image, const ImageLines& image_line, double td) {
+        double parallax_sum = 0; int parallax_num = 0;
+        last_track_num = 0;
+        for (auto& id_pts : image) {
+            FeaturePerFrame f_per_fra(id_pts.second[0].second, td);
+            const int feature_id = id_pts.first;
+            auto it = std::find_if(feature.begin(), feature.end(), [feature_id](const FeaturePerId& f) { return f.feature_id == feature_id; });
+            if (it == feature.end()) { feature.push_back(FeaturePerId(feature_id, frame_count)); feature.back().feature_per_frame.push_back(f_per_fra); }
+            else { it->feature_per_frame.push_back(f_per_fra); last_track_num++; }
+        }
+        for (auto& id_lines : image_line) {
+            LineFeaturePerFrame l_per_fra(id_lines.second[0], td);
+            const int line_id = id_lines.first;
+            auto it = std::find_if(line_feature.begin(), line_feature.end(), [line_id](const LineFeaturePerId& f) { return f.feature_id == line_id; });
+            if (it == line_feature.end()) { line_feature.push_back(LineFeaturePerId(line_id, frame_count)); line_feature.back().line_feature_per_frame.push_back(l_per_fra); }
+            else it->line_feature_per_frame.push_back(l_per_fra);
+        }
+        if (frame_count < 2 || last_track_num < 20) return true;
+        for (auto& it_per_id : feature)
+            if (it_per_id.start_frame <= frame_count - 2 && it_per_id.start_frame + int(it_per_id.feature_per_frame.size()) - 1 >= frame_count - 1) {
+                parallax_sum += compensatedParallax2(it_per_id, frame_count); parallax_num++;
+            }
+        if (parallax_num == 0) return true;
+        return parallax_sum / parallax_num >= MIN_PARALLAX;
+    }
+    // :727-760 (the rotation compensation is commented out upstream, so both candidates are the plain displacement)
+    static double compensatedParallax2(const FeaturePerId& it_per_id, int frame_count) {
+        const FeaturePerFrame& frame_i = it_per_id.feature_per_frame[frame_count - 2 - it_per_id.start_frame];
+        const FeaturePerFrame& frame_j = it_per_id.feature_per_frame[frame_count - 1 - it_per_id.start_frame];
+        const double u_j = frame_j.point(0), v_j = frame_j.point(1);
+        const double dep_i = frame_i.point(2), u_i = frame_i.point(0) / dep_i, v_i = frame_i.point(1) / dep_i;
+        const double du = u_i - u_j, dv = v_i - v_j;
+        return std::max(0.0, std::sqrt(du * du + dv * dv));
+    }
+    void removeFailures() { for (auto it = feature.begin(); it != feature.end();) it = (it->solve_flag == 2) ? feature.erase(it) : std::next(it); }                    // :255-264
+    void removeLineFailures() { for (auto it = line_feature.begin(); it != line_feature.end();) it = (it->solve_flag == 2) ? line_feature.erase(it) : std::next(it); }  // :266-276
+    // :607-645 -- the oldest frame leaves: tracks anchored there lose their first observation and their depth moves to the new anchor frame
+    void removeBackShiftDepth(const Eigen::Matrix3d& marg_R, const Eigen::Vector3d& marg_P, const Eigen::Matrix3d& new_R, const Eigen::Vector3d& new_P) {
+        for (auto it = feature.begin(); it != feature.end();) {
+            if (it->start_frame != 0) { it->start_frame--; ++it; continue; }
+            const Eigen::Vector3d uv_i = it->feature_per_frame[0].point;
+            it->feature_per_frame.erase(it->feature_per_frame.begin());
+            if (it->feature_per_frame.size() < 2) { it = feature.erase(it); continue; }
+            const Eigen::Vector3d pts_i = uv_i * it->estimated_depth;
+            const Eigen::Vector3d w_pts_i = marg_R * pts_i + marg_P;
+            const Eigen::Vector3d pts_j = new_R.transpose() * (w_pts_i - new_P);
+            const double dep_j = pts_j(2);
+            it->estimated_depth = dep_j > 0 ? dep_j : INIT_DEPTH;
+            ++it;
+        }
+    }
+    void removeBack() {                                                                                                  // :647-663
+        for (auto it = feature.begin(); it != feature.end();) {
+            if (it->start_frame != 0) { it->start_frame--; ++it; continue; }
+            it->feature_per_frame.erase(it->feature_per_frame.begin());
+            it = it->feature_per_frame.empty() ? feature.erase(it) : std::next(it);
+        }
+    }
+    void removeFront(int frame_count) {                                                                                  // :665-685
+        for (auto it = feature.begin(); it != feature.end();) {
+            if (it->start_frame == frame_count) { it->start_frame--; ++it; continue; }
+            const int j = WINDOW_SIZE - 1 - it->start_frame;
+            if (it->endFrame() < frame_count - 1) { ++it; continue; }
+            it->feature_per_frame.erase(it->feature_per_frame.begin() + j);
+            it = it->feature_per_frame.empty() ? feature.erase(it) : std::next(it);
+        }
+    }
+    void removeLineBack() {                                                                                              // :687-703
+        for (auto it = line_feature.begin(); it != line_feature.end();) {
+            if (it->start_frame != 0) { it->start_frame--; ++it; continue; }
+            it->line_feature_per_frame.erase(it->line_feature_per_frame.begin());
+            it = it->line_feature_per_frame.empty() ? line_feature.erase(it) : std::next(it);
+        }
+    }
+    void removeLineFront(int frame_count) {                                                                              // :705-725
+        for (auto it = line_feature.begin(); it != line_feature.end();) {
+            if (it->start_frame == frame_count) { it->start_frame--; ++it; continue; }
+            const int j = WINDOW_SIZE - 1 - it->start_frame;
+            if (it->endFrame() < frame_count - 1) { ++it; continue; }
+            it->line_feature_per_frame.erase(it->line_feature_per_frame.begin() + j);
+            it = it->line_feature_per_frame.empty() ? line_feature.erase(it) : std::next(it);
+        }
+    }
+    void clearState() { feature.clear(); line_feature.clear(); }                                                         // :28-32
+
     static bool usedPoint(FeaturePerId& it) { it.used_num = (int)it.feature_per_frame.size(); return it.used_num >= 2 && it.start_frame < WINDOW_SIZE - 2; }   // estimator.cpp:826
     static bool usedLine(LineFeaturePerId& it) { it.used_num = (int)it.line_feature_per_frame.size(); return it.used_num >= LINE_WINDOW; }                    // estimator.cpp:873
     int getFeatureCount() { int c = 0; for (auto& it : feature) c += usedPoint(it); return c; }

@@ -139,3 +139,73 @@ extern "C" int uvs_host_triangulate(const double* poses, const double* ex, int n
     int l = 0; for (auto& it : fm.line_feature) { for (int q = 0; q < 4; ++q) orth_io[4 * l + q] = it.orthonormal_vec[q]; ++l; }
     return 0;
 }
+
+// Closed-loop replay of a FRAME SEQUENCE through the mirrored per-frame state machine (processIMU / processImage / solveOdometry /
+// slideWindow around optimization()): what `rosbag play` drives in the reference (estimator_node.cpp:352-509 feeds exactly these two
+// calls), minus initialStructure() -- the sequence file carries the aligned initial window instead.
+// File (all float64):  magic 0x55565351 ("UVSQ"), n_frames, pose0[11][7], speedbias0[11][9], then per frame:
+//   stamp, n_imu, n_imu x (dt, acc[3], gyr[3]), n_pts, n_pts x (id, x, y, z, u, v, vx, vy), n_lines, n_lines x (id, 15 values of the line message)
+// Output (float64): n_rows, then per frame processed after initialization 24 values:
+//   frame, marginalization_flag, Ps[W](3), q(Rs[W]) xyzw(4), Vs[W](3), Bas[W](3), Bgs[W](3), initial cost, final cost, iterations, points, lines, status
+extern "C" int uvs_host_replay_sequence(const char* in_path, const char* out_path) {
+    FILE* f = std::fopen(in_path, "rb");
+    if (!f) return -1;
+    std::vector<double> d;
+    { std::fseek(f, 0, SEEK_END); const long sz = std::ftell(f); std::fseek(f, 0, SEEK_SET); d.resize(sz / 8); if (std::fread(d.data(), 8, d.size(), f) != d.size()) { std::fclose(f); return -1; } std::fclose(f); }
+    size_t p = 0;
+    auto next = [&]() -> double { return p < d.size() ? d[p++] : 0.0; };
+    if (next() != (double)0x55565351) return -2;
+    const int n_frames = (int)next();
+    if (d.size() < 2 + 11 * 16) return -2;
+    const double* pose0 = d.data() + p; p += 77;
+    const double* sb0 = d.data() + p; p += 99;
+    setEurocParameters();
+    std::vector<double> out;
+    try {
+        Estimator est;
+        est.clearState();
+        est.setParameter();
+        est.setInitialWindow((const double (*)[7])pose0, (const double (*)[9])sb0);
+        for (int fr = 0; fr < n_frames; ++fr) {
+            std_msgs::Header header; header.stamp.t = next();
+            const int n_imu = (int)next();
+            for (int k = 0; k < n_imu; ++k) {
+                const double dt = next(); double a[3], g[3];
+                for (double& v : a) v = next();
+                for (double& v : g) v = next();
+                est.processIMU(dt, Eigen::Vector3d(a[0], a[1], a[2]), Eigen::Vector3d(g[0], g[1], g[2]));
+            }
+            FeatureManager::ImagePoints image; FeatureManager::ImageLines image_line;
+            const int n_pts = (int)next();
+            for (int k = 0; k < n_pts; ++k) {
+                const int id = (int)next(); Eigen::Matrix<double, 7, 1> m;
+                for (int q = 0; q < 7; ++q) m(q) = next();
+                image[id].emplace_back(0, m);
+            }
+            const int n_lines = (int)next();
+            for (int k = 0; k < n_lines; ++k) {
+                const int id = (int)next(); Eigen::Matrix<double, 15, 1> m;
+                for (int q = 0; q < 15; ++q) m(q) = next();
+                image_line[id].push_back(m);
+            }
+            if (p > d.size()) return -3;
+            const bool was_initial = est.solver_flag == Estimator::INITIAL;
+            const int fc = est.frame_count;
+            est.processImage(image, image_line, header);
+            if (was_initial && fc < WINDOW_SIZE) continue;      // still filling the window
+            if (est.solver_flag == Estimator::INITIAL) return -4;      // initialization did not happen / failure detection rebooted the estimator
+            const Eigen::Quaterniond q(est.last_R);
+            const uvs_report& rep = est.last_summary.report;
+            const double row[24] = {(double)fr, (double)est.marginalization_flag, est.last_P.x(), est.last_P.y(), est.last_P.z(), q.x(), q.y(), q.z(), q.w(),
+                                    est.Vs[WINDOW_SIZE].x(), est.Vs[WINDOW_SIZE].y(), est.Vs[WINDOW_SIZE].z(), est.Bas[WINDOW_SIZE].x(), est.Bas[WINDOW_SIZE].y(), est.Bas[WINDOW_SIZE].z(),
+                                    est.Bgs[WINDOW_SIZE].x(), est.Bgs[WINDOW_SIZE].y(), est.Bgs[WINDOW_SIZE].z(), rep.initial_cost, rep.final_cost, (double)rep.num_iterations,
+                                    (double)est.f_manager.getFeatureCount(), (double)est.f_manager.getLineFeatureCount(), (double)est.last_summary.status};
+            out.insert(out.end(), row, row + 24);
+        }
+    } catch (const std::exception& e) { std::fprintf(stderr, "uvs_host_replay_sequence: %s\n", e.what()); return -10; }
+    FILE* g = std::fopen(out_path, "wb");
+    if (!g) return -5;
+    const double n_rows = (double)(out.size() / 24);
+    std::fwrite(&n_rows, 8, 1, g); std::fwrite(out.data(), 8, out.size(), g); std::fclose(g);
+    return 0;
+}

@@ -62,4 +62,32 @@ struct WindowFile {      // owns the arrays a uvs_window points to
         std::fclose(f);
         return ok;
     }
+    // the dump hook's writer: any uvs_window (e.g. the one uvs::Problem::fill() assembled after vector2double(), estimator.cpp:800)
+    static bool save(const std::string& path, const uvs_window& w) {
+        FILE* f = std::fopen(path.c_str(), "wb"); if (!f) return false;
+        const bool td = w.pt_vel_i && w.pt_vel_j && w.pt_td_i && w.pt_td_j;
+        const int np = w.n_points, npo = w.n_point_obs, nl = w.n_lines, nlo = w.n_line_obs, ni = w.n_imu, pn = w.prior ? w.prior->n : 0;
+        const int32_t hd[8] = {np, npo, nl, nlo, ni, pn, pn ? w.prior->n_blocks : 0, td ? 1 : 0}, pad = 0;
+        bool ok = true;
+        auto wr = [&](const void* p, size_t sz, size_t n) { if (ok && n) ok = std::fwrite(p, sz, n, f) == n; };
+        wr("UVSWIN01", 1, 8); wr(hd, 4, 8);
+        wr(w.pose, 8, 77); wr(w.speedbias, 8, 99); wr(w.ex_pose, 8, 7); wr(&w.td, 8, 1);
+        wr(w.inv_depth, 8, np); wr(w.pt_lm, 4, npo); wr(w.pt_fi, 4, npo); wr(w.pt_fj, 4, npo); if (npo % 2) wr(&pad, 4, 1);
+        wr(w.pt_pi, 8, 3 * npo); wr(w.pt_pj, 8, 3 * npo);
+        if (td) { wr(w.pt_vel_i, 8, 2 * npo); wr(w.pt_vel_j, 8, 2 * npo); wr(w.pt_td_i, 8, npo); wr(w.pt_td_j, 8, npo); }
+        wr(w.line_orth, 8, 4 * nl); wr(w.ln_lm, 4, nlo); wr(w.ln_fj, 4, nlo); wr(w.ln_has_vp, 4, nlo); if (nlo % 2) wr(&pad, 4, 1);
+        wr(w.ln_sp, 8, 3 * nlo); wr(w.ln_ep, 8, 3 * nlo); wr(w.ln_vp, 8, 3 * nlo);
+        for (int b = 0; b < ni; ++b) {
+            const uvs_imu_block& ib = w.imu[b];
+            wr(&ib.sum_dt, 8, 1); wr(ib.delta_p, 8, 3); wr(ib.delta_q, 8, 4); wr(ib.delta_v, 8, 3); wr(ib.linearized_ba, 8, 3); wr(ib.linearized_bg, 8, 3);
+            wr(ib.jacobian, 8, 225); wr(ib.covariance, 8, 225); const int32_t fs[2] = {ib.frame_i, ib.skip}; wr(fs, 4, 2);
+        }
+        if (pn > 0) {
+            const uvs_prior& p = *w.prior;
+            wr(p.block_kind, 4, 16); wr(p.block_frame, 4, 16); wr(p.block_size, 4, 16); wr(p.block_idx, 4, 16); wr(p.x0_off, 4, 16);
+            wr(p.x0, 8, 144); wr(p.linearized_residuals, 8, pn); wr(p.linearized_jacobians, 8, (size_t)pn * pn);
+        }
+        std::fclose(f);
+        return ok;
+    }
 };

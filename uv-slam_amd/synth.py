@@ -200,8 +200,9 @@ class _Regenerate(Exception):
     pass
 
 
-def _simulate_frames(rng, n_total):
-    """Returns per-frame truth (P,Q,V), true biases, and the IMU blocks linking consecutive frames."""
+def _simulate_frames(rng, n_total, samples=None):
+    """Returns per-frame truth (P,Q,V), true biases, and the IMU blocks linking consecutive frames.
+    `samples` (a list) receives, per frame, the raw (dt, acc, gyr) messages a front-end would feed Estimator::processIMU."""
     ba = rng.normal(0, 0.02, 3)
     bg = rng.normal(0, 0.002, 3)
     # smooth excitation
@@ -221,12 +222,16 @@ def _simulate_frames(rng, n_total):
         meas = lambda tt, qq: (quat_to_R(qq).T @ (acc_world(tt) + G) + ba, gyr_true(tt) + bg)
         a0, g0 = meas(t, q_sim)
         pre = PreIntegration(a0, g0, ba, bg)
+        if samples is not None:
+            if f == 0: samples.append([(0.0, a0, g0)])
+            samples.append([])
         for _ in range(steps):
             w_mid = gyr_true(t + 0.5 * IMU_DT)
             q_sim = quat_mul(q_sim, exp_quat(w_mid * IMU_DT)); q_sim /= np.linalg.norm(q_sim)
             t += IMU_DT
             a1, g1 = meas(t, q_sim)
             pre.push_back(IMU_DT, a1, g1)
+            if samples is not None: samples[-1].append((IMU_DT, a1, g1))
         Ri = quat_to_R(Qs[-1]); dt = pre.sum_dt
         Pn = Ps[-1] + Vs[-1] * dt - 0.5 * G * dt * dt + Ri @ pre.delta_p
         Vn = Vs[-1] - G * dt + Ri @ pre.delta_v
