@@ -63,6 +63,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="windows timed on the CPU oracle (0 = auto ~15 s)")
     ap.add_argument("--no-prior", action="store_true")
+    ap.add_argument("--no-replay", action="store_true", help="skip the closed-loop sequence replay (profiling runs)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -126,7 +127,7 @@ def main():
                     "algorithmic_bytes_per_launch": bytes_per_launch, "hbm_achieved_GBps": ach_gbs, "hbm_frac": ach_gbs / HBM_PEAK_GBS,
                     "note": "'mfma' bound = FP64 FLOP roof 78.6 TF/s (FP64 MFMA rate = FP64 vector rate on MI355X); flop/byte model of SURVEY.md 8d; "
                             "dense reduced solve + IMU blocks run on v_mfma_f64_16x16x4_f64, the sparse 6x6 Schur gather on VALU; the kernel is latency bound "
-                            "(rocprofv3: 68% of wave cycles in SQ_WAIT_ANY, profiles/r01c_pmc_summary.json); traffic = FETCH_SIZE+WRITE_SIZE of the same command"}
+                            "(rocprofv3: 65% of wave cycles in SQ_WAIT_ANY, profiles/r01d_pmc_summary.json); traffic = FETCH_SIZE+WRITE_SIZE of the same command"}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -147,6 +148,32 @@ def main():
             solver.solve_resident()
         lat = [solver.solve_resident() for _ in range(10)]
         t1 = time.perf_counter(); solver.solve(windows[0]); pcie = time.perf_counter() - t1
+        # closed-loop replay of a synthetic frame sequence through the product host library (ATE half of BASELINE.json's metric;
+        # the stand-in for configs[4]): processIMU / processImage / optimization (HIP) / marginalization (HIP) / slideWindow
+        replay = None
+        if world == 1 and not args.no_replay:
+            import ctypes as C, tempfile
+            seqm = uvs.sequence
+            seq = seqm.make_sequence(0, n_frames=36)
+            tmpd = tempfile.mkdtemp()
+            pin, pout = os.path.join(tmpd, "seq.bin"), os.path.join(tmpd, "out.bin")
+            seqm.save(seq, pin)
+
+            def run_replay(lib_path):
+                lib = C.CDLL(lib_path)
+                lib.uvs_host_replay_sequence.argtypes = [C.c_char_p, C.c_char_p]; lib.uvs_host_replay_sequence.restype = C.c_int
+                t1 = time.perf_counter(); rc = lib.uvs_host_replay_sequence(pin.encode(), pout.encode()); dt = time.perf_counter() - t1
+                if rc != 0:
+                    raise RuntimeError("sequence replay failed: %d" % rc)
+                r = seqm.load_result(pout)
+                return seqm.ate(r["P"], seq.truth_pose[r["frame"], :3]), dt / len(r["frame"]) * 1e3, len(r["frame"])
+
+            ate_m, ms_frame, nfr = run_replay(os.path.join(ROOT, "uv-slam_amd", "libuvs_host.so"))
+            replay = {"workload": "36-frame synthetic sequence (0.5 px noise), 26 chained windows, both marginalization kinds",
+                      "ate_vs_truth_m": ate_m, "ms_per_frame_solve_plus_marginalize": ms_frame, "frames_solved": nfr}
+            if cpu is not None:       # the same state machine with the CPU oracle behind the C ABI (baseline leg only)
+                ate_o, ms_o, _ = run_replay(os.path.join(ROOT, "oracle", "libuvs_host_oracle.so"))
+                cpu["replay_ate_vs_truth_m"] = ate_o; cpu["replay_ms_per_frame"] = ms_o
         out = {
             "metric": "sliding-window solves/sec (10 KF, 150 pts, 40 lines, 3 VP)", "value": value, "unit": "solves/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -158,7 +185,7 @@ def main():
             "lm_iterations_mean": float(its.mean()), "final_cost_mean": float(np.mean([r.final_cost for r in reps])),
             "single_window_ms": float(np.median(lat)), "single_window_solves_per_s": 1e3 / float(np.median(lat)),
             "single_window_pcie_inclusive_ms": pcie * 1e3,
-            "roofline": roofline, "cpu_baseline": cpu,
+            "replay": replay, "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
     solver.close()
