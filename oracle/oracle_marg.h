@@ -28,12 +28,17 @@ inline void sym_eig_jacobi(int n, std::vector<double>& A, std::vector<double>& V
     for (int sweep = 0; sweep < 60; ++sweep) {
         double off = 0.0, dsum = 0.0;
         for (int i = 0; i < n; ++i) { dsum += A[(size_t)i * n + i] * A[(size_t)i * n + i]; for (int j = i + 1; j < n; ++j) off += A[(size_t)i * n + j] * A[(size_t)i * n + j]; }
-        if (off <= 1e-30 * (dsum + 1e-300)) break;
+        if (off == 0.0) break;
+        // RELATIVE stopping rule |a_pq| <= eps sqrt(a_pp a_qq) (not off <= eps ||diag||): A_mm is graded over ten orders of magnitude and
+        // its SMALL eigenvalues are the ones that get inverted -- an absolute rule leaves them with 1e-5 relative error
+        int rotations = 0;
         for (int p = 0; p < n - 1; ++p) {
             for (int q = p + 1; q < n; ++q) {
                 const double apq = A[(size_t)p * n + q];
                 if (apq == 0.0) continue;
                 const double app = A[(size_t)p * n + p], aqq = A[(size_t)q * n + q];
+                if (std::fabs(apq) <= 1.1e-16 * std::sqrt(std::fabs(app * aqq))) continue;
+                ++rotations;
                 const double theta = (aqq - app) / (2.0 * apq);
                 const double t = (theta >= 0.0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
                 const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
@@ -51,6 +56,7 @@ inline void sym_eig_jacobi(int n, std::vector<double>& A, std::vector<double>& V
                 }
             }
         }
+        if (rotations == 0) break;
     }
     ev.resize(n);
     for (int i = 0; i < n; ++i) ev[i] = A[(size_t)i * n + i];

@@ -23,6 +23,8 @@ for k, path in enumerate(sorted(glob.glob(str(tmp / "window_*.bin")))):
     pg, po = s.marginalize(wo, flag), o.marginalize(wo, flag)
     Hg, Ho = pg.J0().T @ pg.J0(), po.J0().T @ po.J0()
     bg, bo = pg.J0().T @ pg.r0(), po.J0().T @ po.r0()
+    lam, Vv = np.linalg.eigh(Ho); cdiff = Vv.T @ (bg - bo); top = np.argsort(-np.abs(cdiff))[:3]
+    print("      b diff by eigen-direction of H: " + ", ".join("lam %.2e c %.2e (v.b %.2e)" % (lam[t], cdiff[t], (Vv.T @ bo)[t]) for t in top) + "  |bo|max %.3g" % np.abs(bo).max())
     print("%2d n_prior %2d it %2d/%2d acc %s|%s cost %.9g|%.9g dP %.2e dq %.2e | marg n %d/%d H %.2e b %.2e r0r0 %.9g|%.9g" % (
         k, w.prior.n if w.prior is not None else 0, rg.num_iterations, rr.num_iterations, "".join(str(int(a)) for a in rg.accepted[:rg.num_iterations + 1]),
         "".join(str(int(a)) for a in rr.accepted[:rr.num_iterations + 1]), rg.final_cost, rr.final_cost, dp, dq, pg.n, po.n,

@@ -90,3 +90,79 @@ def pose_deltas(A, B):
     dp = np.abs(A[:, :3] - B[:, :3]).max()
     da = max(quat_angle(A[f, 3:], B[f, 3:]) for f in range(A.shape[0]))
     return dp, da
+
+
+def marginalization_reference(w, ev):
+    """MARGIN_OLD Schur complement in EXTENDED precision (numpy longdouble, plain Gaussian elimination with pivoting), from an `abi.Eval`
+    dump of the post-solve window: the factors of estimator.cpp:1008-1129 (prior, IMU block 0, points anchored at frame 0, line / VP
+    observations j != 0 of lines that start at frame 0), marginalised set = Pose[0], SpeedBias[0] and those landmarks.
+    Returns (A_r, b_r, cols) over the kept columns `cols`: 0..164 = the frame layout (ORIGINAL frame numbering), -6..-1 = para_Ex_Pose
+    (held constant by the solver but a parameter block of every point factor, so the reference's prior carries it)."""
+    F, Np, Nl, P0 = param_layout(w)
+    P = P0 + 6; EX = P0
+    LD = np.longdouble
+    H = np.zeros((P, P), LD); g = np.zeros(P, LD)
+
+    def add(cols, J, r):
+        cols = np.asarray(cols); J = np.asarray(J, LD); r = np.asarray(r, LD)
+        H[np.ix_(cols, cols)] += J.T @ J
+        g[cols] += J.T @ r
+
+    drop = set(range(15))
+    if w.prior is not None and w.prior.n > 0:
+        p = w.prior; n = p.n; J0 = p.J0()
+        cols, src = [], []
+        for b in range(p.n_blocks):
+            kind, fr, size, idx = p.block_kind[b], p.block_frame[b], p.block_size[b], p.block_idx[b]
+            loc = 6 if size == 7 else size
+            base = 15 * fr if kind == abi.BLOCK_POSE else 15 * fr + 6 if kind == abi.BLOCK_SPEEDBIAS else EX
+            assert kind in (abi.BLOCK_POSE, abi.BLOCK_SPEEDBIAS, abi.BLOCK_EX_POSE)
+            cols += [base + k for k in range(loc)]; src += [idx + k for k in range(loc)]
+        add(cols, J0[:, src], ev.prior_r[:n])
+    for b, blk in enumerate(w.imu):
+        if blk["frame_i"] == 0 and not blk.get("skip", 0):
+            add(list(range(0, 30)), ev.imu_J[b], ev.imu_r[b])
+    for k in range(len(w.pt_lm)):
+        fi, fj, lm = int(w.pt_fi[k]), int(w.pt_fj[k]), int(w.pt_lm[k])
+        if fi != 0: continue
+        add(list(range(0, 6)) + list(range(15 * fj, 15 * fj + 6)) + list(range(EX, EX + 6)) + [F + lm], ev.pt_J[k], ev.pt_r[k])
+        drop.add(F + lm)
+    start = {}
+    for k in range(len(w.ln_lm)): start.setdefault(int(w.ln_lm[k]), int(w.ln_fj[k]))
+    for k in range(len(w.ln_lm)):
+        fj, lm = int(w.ln_fj[k]), int(w.ln_lm[k])
+        if start[lm] != 0 or fj == 0: continue
+        cols = list(range(15 * fj, 15 * fj + 6)) + list(range(F + Np + 4 * lm, F + Np + 4 * lm + 4))
+        add(cols, ev.ln_J[k], ev.ln_r[k])
+        if w.ln_has_vp[k]: add(cols, ev.vp_J[k], ev.vp_r[k])
+        drop.update(range(F + Np + 4 * lm, F + Np + 4 * lm + 4))
+    used = [c for c in range(P) if H[c, c] != 0]
+    md = [c for c in used if c in drop]; kp = [c for c in used if c not in drop]
+    assert all(c < F or c >= EX for c in kp)
+    Amm = H[np.ix_(md, md)].copy(); R = np.concatenate([H[np.ix_(md, kp)], g[md][:, None]], axis=1).copy()
+    m = len(md)
+    for c in range(m):      # Gaussian elimination with partial pivoting in longdouble
+        piv = c + int(np.argmax(np.abs(Amm[c:, c])))
+        if piv != c: Amm[[c, piv]] = Amm[[piv, c]]; R[[c, piv]] = R[[piv, c]]
+        f = Amm[c + 1:, c] / Amm[c, c]
+        Amm[c + 1:] -= f[:, None] * Amm[c][None, :]; R[c + 1:] -= f[:, None] * R[c][None, :]
+    X = np.zeros_like(R)
+    for c in range(m - 1, -1, -1):
+        X[c] = (R[c] - Amm[c, c + 1:] @ X[c + 1:]) / Amm[c, c]
+    Ar = H[np.ix_(kp, kp)] - H[np.ix_(kp, md)] @ X[:, :-1]
+    br = g[kp] - H[np.ix_(kp, md)] @ X[:, -1]
+    return np.asarray(Ar, float), np.asarray(br, float), [c if c < F else c - P for c in kp]
+
+
+def prior_information(p, n_frame_cols=165):
+    """(H, b) = (J0^T J0, J0^T r0) of an `abi.Prior`, scattered to the 165-wide frame layout in ORIGINAL frame numbering for a MARGIN_OLD prior
+    (block_frame is stored after the shift i -> i-1, estimator.cpp:1139-1152)."""
+    J0, r0 = p.J0(), p.r0()
+    cols, src = [], []
+    for b in range(p.n_blocks):
+        kind, fr, size, idx = p.block_kind[b], p.block_frame[b] + 1, p.block_size[b], p.block_idx[b]
+        loc = 6 if size == 7 else size
+        base = 15 * fr if kind == abi.BLOCK_POSE else 15 * fr + 6 if kind == abi.BLOCK_SPEEDBIAS else -6
+        cols += [base + k for k in range(loc)]; src += [idx + k for k in range(loc)]
+    Jc = J0[:, src]
+    return Jc.T @ Jc, Jc.T @ r0, cols

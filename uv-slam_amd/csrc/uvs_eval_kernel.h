@@ -5,6 +5,7 @@
 // at the post-solve state, marginalization_factor.cpp:3-69) and by the element-wise parity tests.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstring>
 #include <string>
 #include <vector>
 #include "uvs_solve_kernel.h"
@@ -94,23 +95,45 @@ __global__ __launch_bounds__(NT) void k_evaluate(char* blob, double* ws, KOpts o
     if (tid == 0) out.cost[0] = s4[0];
 }
 
+// device + pinned-host staging of one evaluation, kept by the solver handle (no allocation on the per-call path once it has grown)
+struct EvalScratch {
+    double* d = nullptr; size_t cap = 0;       // device, doubles
+    double* h = nullptr; size_t hcap = 0;      // pinned host, doubles
+    void release() { if (d) hipFree(d); if (h) hipHostFree(h); d = h = nullptr; cap = hcap = 0; }
+};
+
 // host driver: blob of window 0 must already be on the device (uvs_batch_upload)
-static int run_evaluate(int device, hipStream_t stream, char* d_blob, double* d_ws, const DevWin& h, const KOpts& ko, int robust, uvs_eval* out, std::string& err) {
+static int run_evaluate(int device, hipStream_t stream, char* d_blob, double* d_ws, const DevWin& h, const KOpts& ko, int robust, uvs_eval* out, std::string& err, EvalScratch& sc) {
     auto chk = [&](hipError_t e, const char* what) { if (e != hipSuccess) { err = std::string(what) + ": " + hipGetErrorString(e); return false; } return true; };
     if (!chk(hipSetDevice(device), "hipSetDevice")) return UVS_ERR_HIP;
     const size_t npo = (size_t)std::max(h.n_pt_obs, 1), nlo = (size_t)std::max(h.n_ln_obs, 1), ni = (size_t)std::max(h.n_imu, 1);
     const size_t sizes[11] = {2 * npo, 38 * npo, 2 * nlo, 20 * nlo, nlo, 10 * nlo, 15 * ni, 450 * ni, (size_t)UVS_MAX_PRIOR_DIM, 8, 2 * npo};
     size_t tot = 0; for (size_t v : sizes) tot += v;
-    if (!chk(hipFuncSetAttribute((const void*)k_evaluate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES), "hipFuncSetAttribute")) return UVS_ERR_HIP;
-    double* d = nullptr;
-    if (!chk(hipMalloc((void**)&d, tot * 8), "hipMalloc(eval)")) return UVS_ERR_HIP;
-    hipMemsetAsync(d, 0, tot * 8, stream);
+    static bool attr = false;
+    if (!attr) { if (!chk(hipFuncSetAttribute((const void*)k_evaluate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES), "hipFuncSetAttribute")) return UVS_ERR_HIP; attr = true; }
+    if (sc.cap < tot) {
+        if (sc.d) hipFree(sc.d);
+        sc.d = nullptr; sc.cap = 0;
+        if (!chk(hipMalloc((void**)&sc.d, tot * 8), "hipMalloc(eval)")) return UVS_ERR_HIP;
+        sc.cap = tot;
+    }
+    if (sc.hcap < tot) {
+        if (sc.h) hipHostFree(sc.h);
+        sc.h = nullptr; sc.hcap = 0;
+        if (!chk(hipHostMalloc((void**)&sc.h, tot * 8, hipHostMallocDefault), "hipHostMalloc(eval)")) return UVS_ERR_HIP;
+        sc.hcap = tot;
+    }
+    double* d = sc.d;
+    if (!chk(hipMemsetAsync(d, 0, tot * 8, stream), "memset(eval)")) return UVS_ERR_HIP;
     EvalOut eo; double* p = d;
     eo.pt_r = p; p += sizes[0]; eo.pt_J = p; p += sizes[1]; eo.ln_r = p; p += sizes[2]; eo.ln_J = p; p += sizes[3]; eo.vp_r = p; p += sizes[4];
     eo.vp_J = p; p += sizes[5]; eo.imu_r = p; p += sizes[6]; eo.imu_J = p; p += sizes[7]; eo.prior_r = p; p += sizes[8]; eo.cost = p; p += sizes[9]; eo.pt_Jtd = p;
     hipLaunchKernelGGL(k_evaluate, dim3(1), dim3(NT), LDS_BYTES, stream, d_blob, d_ws, ko, robust, eo);
-    bool ok = chk(hipGetLastError(), "k_evaluate launch") && chk(hipStreamSynchronize(stream), "k_evaluate");
-    auto back = [&](double* dst, const double* src, size_t n) { if (ok && dst && n) ok = chk(hipMemcpy(dst, src, n * 8, hipMemcpyDeviceToHost), "memcpy D2H"); };
+    // ONE device-to-host copy into pinned memory, then plain host copies into the caller's arrays
+    const bool ok = chk(hipGetLastError(), "k_evaluate launch") && chk(hipMemcpyAsync(sc.h, d, tot * 8, hipMemcpyDeviceToHost, stream), "memcpy D2H(eval)") &&
+                    chk(hipStreamSynchronize(stream), "k_evaluate");
+    if (!ok) return UVS_ERR_HIP;
+    auto back = [&](double* dst, const double* dsrc, size_t n) { if (dst && n) std::memcpy(dst, sc.h + (dsrc - d), n * 8); };
     back(out->pt_r, eo.pt_r, 2 * (size_t)h.n_pt_obs); back(out->pt_J, eo.pt_J, 38 * (size_t)h.n_pt_obs);
     back(out->ln_r, eo.ln_r, 2 * (size_t)h.n_ln_obs); back(out->ln_J, eo.ln_J, 20 * (size_t)h.n_ln_obs);
     back(out->vp_r, eo.vp_r, (size_t)h.n_ln_obs); back(out->vp_J, eo.vp_J, 10 * (size_t)h.n_ln_obs);
@@ -118,8 +141,7 @@ static int run_evaluate(int device, hipStream_t stream, char* d_blob, double* d_
     back(out->prior_r, eo.prior_r, (size_t)h.prior_n);
     back(&out->cost, eo.cost, 1);
     if (h.td_on) back(out->pt_Jtd, eo.pt_Jtd, 2 * (size_t)h.n_pt_obs);
-    hipFree(d);
-    return ok ? UVS_OK : UVS_ERR_HIP;
+    return UVS_OK;
 }
 
 }  // namespace uvsdev

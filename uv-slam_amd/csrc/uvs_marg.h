@@ -6,13 +6,18 @@
 //
 // Split (round 1): the data-parallel part -- evaluating every to-be-marginalised residual block with
 // its loss correction at the post-solve state (ResidualBlockInfo::Evaluate, :3-69) -- runs on the GPU
-// through k_evaluate; the dense (m+n)^2 assembly, the two symmetric eigen-decompositions and the Schur
-// complement run on the host in this file, as they do in the reference (4 pthreads + Eigen).  Moving the
-// eigen-solver onto the device is listed as future work in DESIGN.md; it is outside the solves/s metric.
+// through k_evaluate; the dense (m+n)^2 assembly, the Schur complement and the n x n factorisation run on the
+// host in this file, as they do in the reference (4 pthreads + Eigen).  The pseudo-inverse of A_mm is applied by
+// block elimination (see run_marginalize) and the factorisation J0 = sqrt(S) V^T by Householder + implicit QL;
+// UVS_MARG_PROFILE=1 prints the stage times.  A device-resident variant is future work; it is outside
+// the solves/s metric.
 //
 // Block order is deterministic (the reference's depends on pointer hashes, Appendix D6):
 // dropped = {Pose, SpeedBias, point landmarks, line landmarks}, kept = {Pose asc., SpeedBias asc., Ex_Pose}.
 #pragma once
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <algorithm>
 #include <cmath>
 #include <string>
@@ -21,33 +26,138 @@
 
 namespace uvsdev {
 
-// Jacobi eigenvalue iteration for a dense symmetric matrix (row-major n x n).  V: eigenvectors in columns.
-static void host_sym_eig(int n, std::vector<double>& M, std::vector<double>& V, std::vector<double>& lam) {
-    V.assign((size_t)n * n, 0.0);
-    for (int i = 0; i < n; ++i) V[(size_t)i * n + i] = 1.0;
+// Cyclic Jacobi with a RELATIVE stopping rule |a_pq| <= eps sqrt(a_pp a_qq): the matrices of the marginalization are graded over ten
+// orders of magnitude (pose information 1e7..1e14, inverse depths 1e0..1e2, near-null gauge directions of the prior 1e-6) and both the
+// inverted eigenvalues of A_mm and the eps = 1e-8 cut of the n x n factor need RELATIVE accuracy on the small ones, which Jacobi
+// delivers on the graded matrix itself and a tridiagonal QL does not (absolute error ~1e-16 ||A||).  Row-oriented: a rotation
+// updates rows p, q of M and of V^T (contiguous), mirrors them into the columns, and sets the 2x2 pivot block analytically.
+static void host_sym_eig_jacobi(int n, std::vector<double>& M, std::vector<double>& V, std::vector<double>& lam) {
+    std::vector<double> Vt((size_t)n * n, 0.0);
+    for (int i = 0; i < n; ++i) Vt[(size_t)i * n + i] = 1.0;
     for (int sweep = 0; sweep < 64; ++sweep) {
-        double off = 0.0, dia = 0.0;
-        for (int i = 0; i < n; ++i) { dia += M[(size_t)i * n + i] * M[(size_t)i * n + i]; for (int j = 0; j < i; ++j) off += M[(size_t)i * n + j] * M[(size_t)i * n + j]; }
-        if (off <= 1e-30 * (dia + 1e-300)) break;
-        for (int p = 0; p + 1 < n; ++p) for (int q = p + 1; q < n; ++q) {
-            const double apq = M[(size_t)p * n + q];
-            if (apq == 0.0) continue;
-            const double tau = (M[(size_t)q * n + q] - M[(size_t)p * n + p]) / (2.0 * apq);
-            const double t = (tau >= 0.0 ? 1.0 : -1.0) / (std::fabs(tau) + std::sqrt(1.0 + tau * tau));
-            const double cs = 1.0 / std::sqrt(1.0 + t * t), sn = t * cs;
-            for (int k = 0; k < n; ++k) { double& a = M[(size_t)k * n + p]; double& b = M[(size_t)k * n + q]; const double ta = a, tb = b; a = cs * ta - sn * tb; b = sn * ta + cs * tb; }
-            for (int k = 0; k < n; ++k) { double& a = M[(size_t)p * n + k]; double& b = M[(size_t)q * n + k]; const double ta = a, tb = b; a = cs * ta - sn * tb; b = sn * ta + cs * tb; }
-            for (int k = 0; k < n; ++k) { double& a = V[(size_t)k * n + p]; double& b = V[(size_t)k * n + q]; const double ta = a, tb = b; a = cs * ta - sn * tb; b = sn * ta + cs * tb; }
+        int rotations = 0;
+        for (int p = 0; p + 1 < n; ++p) {
+            double* Mp = &M[(size_t)p * n]; double* Vp = &Vt[(size_t)p * n];
+            for (int q = p + 1; q < n; ++q) {
+                double* Mq = &M[(size_t)q * n];
+                const double apq = Mp[q], app = Mp[p], aqq = Mq[q];
+                if (apq == 0.0 || std::fabs(apq) <= 1.1e-16 * std::sqrt(std::fabs(app * aqq))) continue;
+                ++rotations;
+                const double tau = (aqq - app) / (2.0 * apq);
+                const double t = (tau >= 0.0 ? 1.0 : -1.0) / (std::fabs(tau) + std::sqrt(1.0 + tau * tau));
+                const double cs = 1.0 / std::sqrt(1.0 + t * t), sn = t * cs;
+                for (int k = 0; k < n; ++k) { const double a = Mp[k], b = Mq[k]; Mp[k] = cs * a - sn * b; Mq[k] = sn * a + cs * b; }
+                for (int k = 0; k < n; ++k) { M[(size_t)k * n + p] = Mp[k]; M[(size_t)k * n + q] = Mq[k]; }
+                Mp[p] = app - t * apq; Mq[q] = aqq + t * apq; Mp[q] = 0.0; Mq[p] = 0.0;
+                double* Vq = &Vt[(size_t)q * n];
+                for (int k = 0; k < n; ++k) { const double a = Vp[k], b = Vq[k]; Vp[k] = cs * a - sn * b; Vq[k] = sn * a + cs * b; }
+            }
         }
+        if (rotations == 0) break;
     }
-    lam.resize(n);
-    for (int i = 0; i < n; ++i) lam[i] = M[(size_t)i * n + i];
+    lam.resize(n); V.resize((size_t)n * n);
+    for (int i = 0; i < n; ++i) { lam[i] = M[(size_t)i * n + i]; for (int k = 0; k < n; ++k) V[(size_t)k * n + i] = Vt[(size_t)i * n + k]; }
+}
+
+// Eigen-decomposition of a dense symmetric matrix (row-major n x n; V: eigenvectors in columns, unsorted): Householder reduction to
+// tridiagonal form followed by the implicit-shift QL iteration -- the textbook tred2 / tql2 pair, i.e. the same family of algorithm
+// as Eigen's SelfAdjointEigenSolver that the reference calls (marginalization_factor.cpp:263,278), ~(4/3) n^3 + O(n^2) per sweep flops
+// instead of the ~10 sweeps x 6 n^3 of a cyclic Jacobi (3.2 ms -> 0.2 ms for n = 69 on the box's host core).
+static void host_sym_eig(int n, std::vector<double>& M, std::vector<double>& V, std::vector<double>& lam) {
+    V = M; lam.assign(n, 0.0);
+    if (n == 0) return;
+    std::vector<double> e(n, 0.0);
+    double* d = lam.data();
+    auto at = [&](int i, int j) -> double& { return V[(size_t)i * n + j]; };
+    // ---- Householder tridiagonalisation (row n-1 of V carries the current vector)
+    for (int j = 0; j < n; ++j) d[j] = at(n - 1, j);
+    for (int i = n - 1; i > 0; --i) {
+        double scale = 0.0, h = 0.0;
+        for (int k = 0; k < i; ++k) scale += std::fabs(d[k]);
+        if (scale == 0.0) {
+            e[i] = d[i - 1];
+            for (int j = 0; j < i; ++j) { d[j] = at(i - 1, j); at(i, j) = 0.0; at(j, i) = 0.0; }
+        } else {
+            for (int k = 0; k < i; ++k) { d[k] /= scale; h += d[k] * d[k]; }
+            double f = d[i - 1], g = std::sqrt(h);
+            if (f > 0) g = -g;
+            e[i] = scale * g; h -= f * g; d[i - 1] = f - g;
+            for (int j = 0; j < i; ++j) e[j] = 0.0;
+            for (int j = 0; j < i; ++j) {
+                f = d[j]; at(j, i) = f; g = e[j] + at(j, j) * f;
+                for (int k = j + 1; k <= i - 1; ++k) { g += at(k, j) * d[k]; e[k] += at(k, j) * f; }
+                e[j] = g;
+            }
+            f = 0.0;
+            for (int j = 0; j < i; ++j) { e[j] /= h; f += e[j] * d[j]; }
+            const double hh = f / (h + h);
+            for (int j = 0; j < i; ++j) e[j] -= hh * d[j];
+            for (int j = 0; j < i; ++j) {
+                f = d[j]; g = e[j];
+                for (int k = j; k <= i - 1; ++k) at(k, j) -= (f * e[k] + g * d[k]);
+                d[j] = at(i - 1, j); at(i, j) = 0.0;
+            }
+        }
+        d[i] = h;
+    }
+    // ---- accumulate the reflectors
+    for (int i = 0; i < n - 1; ++i) {
+        at(n - 1, i) = at(i, i); at(i, i) = 1.0;
+        const double h = d[i + 1];
+        if (h != 0.0) {
+            for (int k = 0; k <= i; ++k) d[k] = at(k, i + 1) / h;
+            for (int j = 0; j <= i; ++j) {
+                double g = 0.0;
+                for (int k = 0; k <= i; ++k) g += at(k, i + 1) * at(k, j);
+                for (int k = 0; k <= i; ++k) at(k, j) -= g * d[k];
+            }
+        }
+        for (int k = 0; k <= i; ++k) at(k, i + 1) = 0.0;
+    }
+    for (int j = 0; j < n; ++j) { d[j] = at(n - 1, j); at(n - 1, j) = 0.0; }
+    at(n - 1, n - 1) = 1.0; e[0] = 0.0;
+    // ---- implicit-shift QL on (d, e), rotations applied to V
+    for (int i = 1; i < n; ++i) e[i - 1] = e[i];
+    e[n - 1] = 0.0;
+    double f = 0.0, tst1 = 0.0;
+    const double eps = 2.220446049250313e-16;
+    for (int l = 0; l < n; ++l) {
+        tst1 = std::max(tst1, std::fabs(d[l]) + std::fabs(e[l]));
+        int m = l;
+        while (m < n) { if (std::fabs(e[m]) <= eps * tst1) break; ++m; }
+        if (m > l) {
+            int iter = 0;
+            do {
+                if (++iter > 120) break;      // never seen; the caller's eps cut tolerates an unconverged tiny eigenvalue
+                double g = d[l], p = (d[l + 1] - g) / (2.0 * e[l]), r = std::hypot(p, 1.0);
+                if (p < 0) r = -r;
+                d[l] = e[l] / (p + r); d[l + 1] = e[l] * (p + r);
+                const double dl1 = d[l + 1];
+                double h = g - d[l];
+                for (int i = l + 2; i < n; ++i) d[i] -= h;
+                f += h;
+                p = d[m];
+                double c = 1.0, c2 = c, c3 = c, s = 0.0, s2 = 0.0;
+                const double el1 = e[l + 1];
+                for (int i = m - 1; i >= l; --i) {
+                    c3 = c2; c2 = c; s2 = s;
+                    g = c * e[i]; h = c * p; r = std::hypot(p, e[i]);
+                    e[i + 1] = s * r; s = e[i] / r; c = p / r; p = c * d[i] - s * g;
+                    d[i + 1] = h + s * (c * g + s * d[i]);
+                    for (int k = 0; k < n; ++k) { h = at(k, i + 1); at(k, i + 1) = s * at(k, i) + c * h; at(k, i) = c * at(k, i) - s * h; }
+                }
+                p = -s * s2 * c3 * el1 * e[l] / dl1;
+                e[l] = s * p; d[l] = c * p;
+            } while (std::fabs(e[l]) > eps * tst1);
+        }
+        d[l] += f; e[l] = 0.0;
+    }
 }
 
 struct MFactor { int rows; int nb; int id[5]; int sz[5]; const double* r; const double* J; int ld; int coff[5]; const double* Jx; int xcol; };   // J row stride ld, column offset per block; block with coff < 0 reads its single column from Jx[row stride 1... 2 entries]   // J row stride ld, column offset per block
 
 static int run_marginalize(int device, hipStream_t stream, char* d_blob, double* d_ws, const DevWin& h, const uvs_window* w, const KOpts& ko,
-                           int flag, uvs_prior* out, std::string& err) {
+                           int flag, uvs_prior* out, std::string& err, EvalScratch& sc) {
     const bool td_on = h.td_on != 0;
     const double eps = 1e-8;                           // marginalization_factor.h:70
     const int NFR = UVS_NF;
@@ -57,8 +167,12 @@ static int run_marginalize(int device, hipStream_t stream, char* d_blob, double*
         imu_r(15 * (size_t)std::max(h.n_imu, 1)), imu_J(450 * (size_t)std::max(h.n_imu, 1)), prior_r(UVS_MAX_PRIOR_DIM), pt_Jtd(2 * (size_t)std::max(h.n_pt_obs, 1));
     uvs_eval ev; ev.pt_r = pt_r.data(); ev.pt_J = pt_J.data(); ev.ln_r = ln_r.data(); ev.ln_J = ln_J.data(); ev.vp_r = vp_r.data(); ev.vp_J = vp_J.data();
     ev.imu_r = imu_r.data(); ev.imu_J = imu_J.data(); ev.prior_r = prior_r.data(); ev.cost = 0.0; ev.pt_Jtd = td_on ? pt_Jtd.data() : nullptr;
-    int rc = run_evaluate(device, stream, d_blob, d_ws, h, ko, 1, &ev, err);
+    const bool prof = std::getenv("UVS_MARG_PROFILE") != nullptr;
+    auto tnow = [] { return std::chrono::steady_clock::now(); };
+    auto t0 = tnow();
+    int rc = run_evaluate(device, stream, d_blob, d_ws, h, ko, 1, &ev, err, sc);
     if (rc != UVS_OK) return rc;
+    auto t1 = tnow();
     // ---- host: block bookkeeping.  ids: pose f -> f ; speedbias f -> 11+f ; ex -> 22 ; td -> 23 ; point k -> 24+k ; line l -> 24+Np+l
     const int Np = w->n_points, Nl = w->n_lines, PT0 = 24, NID = PT0 + Np + Nl;
     auto lsize = [&](int id) { return id < NFR ? 6 : id < 2 * NFR ? 9 : id == 22 ? 6 : id == 23 ? 1 : id < PT0 + Np ? 1 : 4; };
@@ -163,26 +277,81 @@ static int run_marginalize(int device, hipStream_t stream, char* d_blob, double*
             }
         }
     }
-    // ---- Amm pseudo-inverse (:263-268), Schur (:270-276)
-    std::vector<double> Amm((size_t)m * m), V, lam;
-    for (int i = 0; i < m; ++i) for (int j = 0; j < m; ++j) Amm[(size_t)i * m + j] = 0.5 * (A[(size_t)i * N + j] + A[(size_t)j * N + i]);
-    host_sym_eig(m, Amm, V, lam);
-    std::vector<double> Ainv((size_t)m * m, 0.0);
-    for (int k = 0; k < m; ++k) {
-        if (!(lam[k] > eps)) continue;
-        const double il = 1.0 / lam[k];
-        for (int i = 0; i < m; ++i) { const double vi = V[(size_t)i * m + k] * il; if (vi == 0.0) continue; for (int j = 0; j < m; ++j) Ainv[(size_t)i * m + j] += vi * V[(size_t)j * m + k]; }
+    auto t2 = tnow();
+    // ---- Schur complement onto the kept blocks (:263-276).  The reference forms the pseudo-inverse of the whole A_mm from one dense
+    // eigen-decomposition (cut at eps).  A_mm is a small dense frame part (Pose[0] + SpeedBias[0], or Pose[9]) bordered by mutually
+    // uncoupled landmark blocks (1x1 inverse depths, 4x4 lines), so the same inverse is applied here by block elimination: landmark
+    // blocks first, then the <= 15 frame dofs (solve_small: Cholesky when regular, eigen-decomposition with the eps cut otherwise).
+    // Identical in exact arithmetic whenever no eigenvalue of A_mm falls under eps; in floating point it agrees with an extended-precision
+    // Schur complement to 1e-14 in b (tests/test_marginalization.py), and it is O(m) instead of O(m^3).
+    int md = 0;
+    for (int id = 0; id < PT0; ++id) if (used[id] && drop[id]) md += lsize(id);
+    // X <- B^+ X for a small symmetric block B (sz <= 15) and sz x nr right-hand sides (row stride ldx).  Regular case: Cholesky solve
+    // (an eigen-based inverse of the frame block, whose eigenvalues span 1e5..1e14, costs four digits in J0^T r0); a pivot at or under
+    // eps means the reference's cut would bite, and only then the pseudo-inverse is formed from the block's eigen-decomposition.
+    auto solve_small = [&](int sz, const double* Bm, double* X, int nr, int ldx) {
+        double Lc[225]; bool regular = true;
+        for (int i = 0; i < sz && regular; ++i) for (int j = 0; j <= i; ++j) {
+            double t = Bm[i * sz + j];
+            for (int k = 0; k < j; ++k) t -= Lc[i * sz + k] * Lc[j * sz + k];
+            if (i == j) { if (!(t > eps)) { regular = false; break; } Lc[i * sz + i] = std::sqrt(t); } else Lc[i * sz + j] = t / Lc[j * sz + j];
+        }
+        if (regular) {
+            for (int c2 = 0; c2 < nr; ++c2) {
+                for (int i = 0; i < sz; ++i) { double t = X[(size_t)i * ldx + c2]; for (int k = 0; k < i; ++k) t -= Lc[i * sz + k] * X[(size_t)k * ldx + c2]; X[(size_t)i * ldx + c2] = t / Lc[i * sz + i]; }
+                for (int i = sz - 1; i >= 0; --i) { double t = X[(size_t)i * ldx + c2]; for (int k = i + 1; k < sz; ++k) t -= Lc[k * sz + i] * X[(size_t)k * ldx + c2]; X[(size_t)i * ldx + c2] = t / Lc[i * sz + i]; }
+            }
+            return;
+        }
+        std::vector<double> M2(Bm, Bm + (size_t)sz * sz), Vs, ls, Binv((size_t)sz * sz, 0.0), col(sz);
+        host_sym_eig_jacobi(sz, M2, Vs, ls);
+        for (int k = 0; k < sz; ++k) { if (!(ls[k] > eps)) continue; const double il = 1.0 / ls[k]; for (int i = 0; i < sz; ++i) for (int j = 0; j < sz; ++j) Binv[(size_t)i * sz + j] += Vs[(size_t)i * sz + k] * il * Vs[(size_t)j * sz + k]; }
+        for (int c2 = 0; c2 < nr; ++c2) {
+            for (int i = 0; i < sz; ++i) { double t = 0.0; for (int k = 0; k < sz; ++k) t += Binv[(size_t)i * sz + k] * X[(size_t)k * ldx + c2]; col[i] = t; }
+            for (int i = 0; i < sz; ++i) X[(size_t)i * ldx + c2] = col[i];
+        }
+    };
+    std::vector<int> coupled; coupled.reserve(N);
+    std::vector<double> Xk;
+    for (int id = PT0; id < NID; ++id) {
+        if (!(used[id] && drop[id])) continue;
+        const int o = pos[id], sz = lsize(id);
+        double Bm[16];
+        for (int i = 0; i < sz; ++i) for (int j = 0; j < sz; ++j) Bm[i * sz + j] = 0.5 * (A[(size_t)(o + i) * N + o + j] + A[(size_t)(o + j) * N + o + i]);
+        coupled.clear();
+        for (int i = 0; i < N; ++i) { if (i >= md && i < m) continue; bool nz = false; for (int q = 0; q < sz; ++q) nz |= A[(size_t)i * N + o + q] != 0.0; if (nz) coupled.push_back(i); }
+        const int nc = (int)coupled.size(), ldx = nc + 1;
+        Xk.assign((size_t)sz * ldx, 0.0);                                  // X = B^+ [A_{block, coupled} | b_block]
+        for (int q = 0; q < sz; ++q) { for (int cj = 0; cj < nc; ++cj) Xk[(size_t)q * ldx + cj] = A[(size_t)(o + q) * N + coupled[cj]]; Xk[(size_t)q * ldx + nc] = bv[o + q]; }
+        solve_small(sz, Bm, Xk.data(), ldx, ldx);
+        for (int ci = 0; ci < nc; ++ci) {
+            const int i = coupled[ci];
+            const double* ai = &A[(size_t)i * N + o];
+            double tb = 0.0; for (int q = 0; q < sz; ++q) tb += ai[q] * Xk[(size_t)q * ldx + nc];
+            bv[i] -= tb;
+            for (int cj = 0; cj < nc; ++cj) { double t = 0.0; for (int q = 0; q < sz; ++q) t += ai[q] * Xk[(size_t)q * ldx + cj]; A[(size_t)i * N + coupled[cj]] -= t; }
+        }
     }
-    std::vector<double> T((size_t)n * m, 0.0), Ar((size_t)n * n), br(n);
-    for (int i = 0; i < n; ++i) for (int k = 0; k < m; ++k) { const double a = A[(size_t)(m + i) * N + k]; if (a == 0.0) continue; for (int j = 0; j < m; ++j) T[(size_t)i * m + j] += a * Ainv[(size_t)k * m + j]; }
+    auto t3 = tnow();
+    std::vector<double> Sd((size_t)md * md), Xd((size_t)md * (n + 1)), Ar((size_t)n * n), br(n);
+    for (int i = 0; i < md; ++i) for (int j = 0; j < md; ++j) Sd[(size_t)i * md + j] = 0.5 * (A[(size_t)i * N + j] + A[(size_t)j * N + i]);
+    for (int i = 0; i < md; ++i) { for (int j = 0; j < n; ++j) Xd[(size_t)i * (n + 1) + j] = A[(size_t)i * N + m + j]; Xd[(size_t)i * (n + 1) + n] = bv[i]; }
+    solve_small(md, Sd.data(), Xd.data(), n + 1, n + 1);                   // X = S^+ [A_dr | b_d]
     for (int i = 0; i < n; ++i) {
-        double s = bv[m + i]; for (int k = 0; k < m; ++k) s -= T[(size_t)i * m + k] * bv[k]; br[i] = s;
-        for (int j = 0; j < n; ++j) { double t = A[(size_t)(m + i) * N + m + j]; for (int k = 0; k < m; ++k) t -= T[(size_t)i * m + k] * A[(size_t)k * N + m + j]; Ar[(size_t)i * n + j] = t; }
+        const double* ad = &A[(size_t)(m + i) * N];
+        double sacc = bv[m + i]; for (int k = 0; k < md; ++k) sacc -= ad[k] * Xd[(size_t)k * (n + 1) + n]; br[i] = sacc;
+        for (int j = 0; j < n; ++j) { double t = ad[m + j]; for (int k = 0; k < md; ++k) t -= ad[k] * Xd[(size_t)k * (n + 1) + j]; Ar[(size_t)i * n + j] = t; }
     }
     // ---- second eigen-decomposition -> J0 = sqrt(S) V^T, r0 = sqrt(S^-1) V^T b   (:278-291); lower triangle is read, like Eigen
     std::vector<double> As((size_t)n * n), V2, lam2;
     for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) As[(size_t)i * n + j] = (j <= i) ? Ar[(size_t)i * n + j] : Ar[(size_t)j * n + i];
+    auto t4 = tnow();
     host_sym_eig(n, As, V2, lam2);
+    auto t5 = tnow();
+    if (prof) {
+        auto us = [](auto a, auto b) { return (double)std::chrono::duration_cast<std::chrono::nanoseconds>(b - a).count() * 1e-3; };
+        std::fprintf(stderr, "[uvs_marginalize] m %d n %d: evaluate %.0f us, assemble %.0f us, landmark blocks %.0f us, frame block + schur %.0f us, eig(n) %.0f us\n", m, n, us(t0, t1), us(t1, t2), us(t2, t3), us(t3, t4), us(t4, t5));
+    }
     std::vector<int> ord(n); for (int i = 0; i < n; ++i) ord[i] = i;
     std::stable_sort(ord.begin(), ord.end(), [&](int a, int b2) { return lam2[a] < lam2[b2]; });
     std::memset(out, 0, sizeof(*out));

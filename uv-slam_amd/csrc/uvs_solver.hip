@@ -43,6 +43,7 @@ struct uvs_solver {
     long long* d_blob_off = nullptr; long long* d_ws_off = nullptr; size_t d_off_cap = 0;
     uvs_report* d_reports = nullptr; size_t d_rep_cap = 0;
     double* d_dbg = nullptr;
+    EvalScratch eval_scratch;                // uvs_evaluate / uvs_marginalize staging
     // large-window (configs[3]) run state
     struct Large {
         bool active = false; int n_chunks = 0, sel = 0, it = 0, invalid = 0, nsucc = 0, pending = 0, term = 0, status = 0;
@@ -141,6 +142,7 @@ void uvs_destroy(uvs_solver* s) {
     if (s->d_ws_off) hipFree(s->d_ws_off);
     if (s->d_reports) hipFree(s->d_reports);
     if (s->d_dbg) hipFree(s->d_dbg);
+    s->eval_scratch.release();
     hipEventDestroy(s->ev0); hipEventDestroy(s->ev1);
     hipStreamDestroy(s->stream);
     delete s;
@@ -611,15 +613,17 @@ int uvs_evaluate(uvs_solver* s, const uvs_window* w, int robust, uvs_eval* out) 
     const uvs_window* arr[1] = {w};
     int rc = uvs_batch_upload(s, 1, arr);
     if (rc != UVS_OK) return rc;
-    return run_evaluate(s->device, s->stream, s->d_blobs, s->d_ws, s->hdrs[0], make_kopts(s->opts, 0), robust, out, s->err);
+    return run_evaluate(s->device, s->stream, s->d_blobs, s->d_ws, s->hdrs[0], make_kopts(s->opts, 0), robust, out, s->err, s->eval_scratch);
 }
 
 int uvs_marginalize(uvs_solver* s, const uvs_window* w, int flag, uvs_prior* out) {
     if (!s || !w || !out || (flag != 0 && flag != 1)) return UVS_ERR_INVALID_ARG;
     const uvs_window* arr[1] = {w};
+    const auto tu0 = std::chrono::steady_clock::now();
     int rc = uvs_batch_upload(s, 1, arr);
     if (rc != UVS_OK) return rc;
-    return run_marginalize(s->device, s->stream, s->d_blobs, s->d_ws, s->hdrs[0], w, make_kopts(s->opts, 0), flag, out, s->err);
+    if (std::getenv("UVS_MARG_PROFILE")) std::fprintf(stderr, "[uvs_marginalize] upload %.0f us\n", (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tu0).count() * 1e-3);
+    return run_marginalize(s->device, s->stream, s->d_blobs, s->d_ws, s->hdrs[0], w, make_kopts(s->opts, 0), flag, out, s->err, s->eval_scratch);
 }
 
 }  // extern "C"
