@@ -278,21 +278,31 @@ UVS_DEV void chol_update_item(double* sh, int i, int cc, int j0, int j1, int lan
     // acc -= sum_{j in [j0, j1)} L_ij L_cj^T   (i == UVS_NF: the right-hand-side row, y_j^T in L_DLT)
     const int li = lane & 15, lk = lane >> 4;
     const bool rhs = (i == UVS_NF);
-    d4_t acc2 = {0.0, 0.0, 0.0, 0.0};        // second accumulator: two independent MFMA chains
     const double* Bj = sblk(sh, cc, j0) + li * UVS_BLK_LD + lk;
     const double* Ai = rhs ? sh + L_DLT + 16 * j0 + lk : sblk(sh, i, j0) + li * UVS_BLK_LD + lk;
     const int astep = rhs ? 16 : UVS_BLK_SZ;
-    const bool azero = rhs && li != 0;
-    for (int j = j0; j < j1; ++j, Bj += UVS_BLK_SZ, Ai += astep) {
-        double av[4], bv[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { const double a = Ai[4 * q]; av[q] = azero ? 0.0 : -a; bv[q] = Bj[4 * q]; }
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[0], bv[0], acc, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[1], bv[1], acc2, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2], bv[2], acc, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[3], bv[3], acc2, 0, 0, 0);
+    if (j0 >= j1) return;
+    // Operands of term j+1 are fetched from LDS while the four 64-cycle MFMAs of term j run; two register sets in ping-pong (no copies).
+    // Nothing touches a loaded value before its MFMA: the sign is the MFMA's own neg modifier (blgp bit 0 = -A for the f64 shapes), and
+    // the right-hand-side row needs no masking -- row i of the product depends on row i of A only, the row-0 result is the only one stored,
+    // and whatever accumulates in the other rows is never read.  (A negation or select on the prefetched registers makes the compiler
+    // wait for the prefetch before issuing the current term's MFMAs: 437 instead of ~260 cycles per term.)
+    // ONE accumulator chain: back-to-back MFMAs that feed their own result as SrcC issue at full rate, while a second chain makes the
+    // compiler shuttle it between AGPRs and VGPRs across the loop back-edge (a pipeline drain plus 16 moves every other term).
+    double a0[4], b0[4], a1[4], b1[4];
+#define UVS_CH_LOAD(AV, BV) { _Pragma("unroll") for (int q = 0; q < 4; ++q) { AV[q] = Ai[4 * q]; BV[q] = Bj[4 * q]; } Bj += UVS_BLK_SZ; Ai += astep; }
+#define UVS_CH_MFMA(AV, BV) { _Pragma("unroll") for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(AV[q], BV[q], acc, 0, 0, 1); }
+    UVS_CH_LOAD(a0, b0)
+    for (int j = j0;;) {
+        if (j + 1 < j1) UVS_CH_LOAD(a1, b1)
+        UVS_CH_MFMA(a0, b0)
+        if (++j >= j1) break;
+        if (j + 1 < j1) UVS_CH_LOAD(a0, b0)
+        UVS_CH_MFMA(a1, b1)
+        if (++j >= j1) break;
     }
-    acc += acc2;
+#undef UVS_CH_LOAD
+#undef UVS_CH_MFMA
 }
 // C-layout load / store of block (i, cc); the diagonal block is symmetrised from its stored lower triangle; the rhs row lives in L_DLT
 UVS_DEV d4_t chol_load_item(double* sh, int i, int cc, int lane) {
@@ -338,6 +348,7 @@ UVS_DEV void chol_factor_impl(double* sh, int debug) {
     for (int k = 0; k < UVS_NF; ++k) {
         double* Dk = sblk(sh, k, k);
         __syncthreads();
+        const long long tw0_ = debug ? clock64() : 0;
         // ---- A: last term (j = k-1) of block column k
         d4_t dacc = {0.0, 0.0, 0.0, 0.0};
         if (wv == 0) {
@@ -351,7 +362,6 @@ UVS_DEV void chol_factor_impl(double* sh, int debug) {
                     chol_store_item(sh, i, k, lane, acc);
                 }
             }
-            // ---- LA: terms j < k of block column k+1, while wave 0 runs the pivot chain
             if (k > 0 && k + 1 < UVS_NF) {
                 for (int i = k + 1 + wrk; i <= UVS_NF; i += nwork) {
                     d4_t acc = chol_load_item(sh, i, k + 1, lane);
@@ -396,6 +406,7 @@ UVS_DEV void chol_factor_impl(double* sh, int debug) {
                 if (li == j) { sh[L_DINV + 16 * k + j] = inv; if (!(pivs[q] > 0.0)) sh[L_CTRL + C_CHOLOK] = 0.0; }
             }
         }
+        if (debug && lane == 0) sh[L_WPROF + 4 + wv] += (double)(clock64() - tw0_);      // busy time of this wave in A + (pivot chain | look-ahead), without the barrier wait
         __syncthreads();
         UVS_PROF(c, P_CH_DIAG);
         // ---- S3: panel  L_ik = S_ik W^T  (B operand W[c][m]: strictly-upper slot (m, c) of the diagonal block, 1/L_cc on the diagonal)
@@ -428,7 +439,15 @@ UVS_DEV void chol_factor_impl(double* sh, int debug) {
     }
     __syncthreads();
 }
-UVS_DEV void chol_factor(const Ctx& c) { chol_factor_impl(c.sh, c.o.debug); }
+// The dense solve is a REAL call (not inlined into the 500-register linearization code of k_solve / k_large_solve): its register
+// allocation is then independent of the gather / factor code around it, and changes in here cannot perturb that code's allocation
+// (a build at the 512-register cap once produced a wrong cost).  The LDS base is re-declared inside, so the callee still addresses
+// LDS with ds_* instructions (a `double*` parameter would degrade to flat loads).
+__device__ __attribute__((noinline)) void chol_factor_call(int debug) {
+    extern __shared__ __attribute__((aligned(16))) double sh_chol[];
+    chol_factor_impl(sh_chol, debug);
+}
+UVS_DEV void chol_factor(const Ctx& c) { chol_factor_call(c.o.debug); }
 
 // back substitution L^T x = y in place (y in L_DLT, produced by chol_factor); the diagonal solves are mat-vecs with W^T.
 // One wave does all of it: the chain x_k -> (update of the rows above) -> x_k-1 is serial anyway, and inside a single wave it
