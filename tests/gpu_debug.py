@@ -55,4 +55,4 @@ print("phase cycles (whole solve, thread 0 of the workgroup):")
 for k, v in d["cycles"].items():
     print("   %-9s %12.0f  %5.1f%%" % (k, v, 100 * v / tot))
 print("   total %.0f cycles" % tot)
-print("per-wave gather cycles:", d["wave_gather"])
+print("sub-timers", d["sub_timers"])

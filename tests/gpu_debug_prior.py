@@ -14,4 +14,4 @@ s.upload([w])
 print("single window ms", [round(s.solve_resident(), 3) for _ in range(4)])
 st, rep = s.solve(w)
 print("iters", rep.num_iterations, "accepted", list(rep.accepted[:11]), "final", rep.final_cost, "initial", rep.initial_cost)
-print("wave gather", d["wave_gather"][:4], "chol busy per wave (A + chain|LA)", d["wave_gather"][4:8])
+print("sub-timers", d["sub_timers"])

@@ -210,4 +210,4 @@ class Solver:
         S = np.zeros((176, 176)); g = np.zeros(176); hd = np.zeros(176); dd = np.zeros(176); step = np.zeros(176); scal = np.zeros(40)
         self._check(lib().uvs_debug_first_iteration(self._h, C.byref(wc), *[abi._dp(a) for a in (S, g, hd, dd, step, scal)]))
         return dict(S=S, g=g, hd=hd, dd=dd, step=step, cost=scal[0], gmax=scal[1], chol_ok=scal[2], mcc=scal[3], step2=scal[4],
-                    cycles=dict(zip(['setup', 'obs', 'lmprep', 'gather', 'assemble', 'chol', 'trsv', 'backsub', 'cost', 'misc', 'chol_diag', 'chol_panel', 'chol_trail', 'asm_imu', 'asm_zero', 'asm_add'], scal[8:24])), wave_gather=scal[24:32].copy())
+                    cycles=dict(zip(['setup', 'obs', 'lmprep', 'gather', 'assemble', 'chol', 'trsv', 'backsub', 'cost', 'misc', 'chol_diag', 'chol_panel', 'chol_trail', 'asm_imu', 'asm_zero', 'asm_add'], scal[8:24])), sub_timers=dict(cost_phase=dict(zip(['stage_dx', 'prior_residual', 'observations', 'imu'], scal[24:28])), chol_busy_per_wave=scal[28:32].copy()))

@@ -210,11 +210,17 @@ struct LineGeom {
     double dn_dl[12], dd_dl[12];           // 3x4 each
 };
 
+UVS_DEV void line_trig(const double* line, double* tr) {      // (sa, ca, sb, cb, sc, cc, sp, cp) of the orthonormal line parameters
+    sincos(line[0], &tr[0], &tr[1]); sincos(line[1], &tr[2], &tr[3]); sincos(line[2], &tr[4], &tr[5]); sincos(line[3], &tr[6], &tr[7]);
+}
+// `trig` (optional) = line_trig(line) computed once per parameter update: a line is observed from ~7 frames and evaluated ~22 times per
+// solve, and four double-precision sincos are most of the arithmetic of one observation
 template <bool WITH_J>
-UVS_DEV void line_geom(const double* t, const double* q, const double* R, const double* ric, const double* tic, const double* line, LineGeom& g) {
+UVS_DEV void line_geom(const double* t, const double* q, const double* R, const double* ric, const double* tic, const double* line, LineGeom& g, const double* trig = nullptr) {
     // U = Rx(psi_x) Ry(psi_y) Rz(psi_z)   (:23-31)
     double sa, ca, sb, cb, sc, cc, sp, cp;
-    sincos(line[0], &sa, &ca); sincos(line[1], &sb, &cb); sincos(line[2], &sc, &cc); sincos(line[3], &sp, &cp);
+    if (trig) { sa = trig[0]; ca = trig[1]; sb = trig[2]; cb = trig[3]; sc = trig[4]; cc = trig[5]; sp = trig[6]; cp = trig[7]; }
+    else { sincos(line[0], &sa, &ca); sincos(line[1], &sb, &cb); sincos(line[2], &sc, &cc); sincos(line[3], &sp, &cp); }
     const double U0[3] = {cb * cc, sa * sb * cc + ca * sc, -ca * sb * cc + sa * sc};
     const double U1[3] = {-cb * sc, -sa * sb * sc + ca * cc, ca * sb * sc + sa * cc};
     const double n_w[3] = {cp * U0[0], cp * U0[1], cp * U0[2]};        // :33

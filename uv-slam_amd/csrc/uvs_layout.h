@@ -67,6 +67,7 @@ struct DevWin {
     int32_t i_lists;                  // per chunk: schur_off[81] direct_off[81] entries[...]  (group-major, see pack_window in uvs_solver.hip)
     // workspace
     int32_t w_invd0, w_invd1, w_line0, w_line1;       // landmark parameters, two buffers (current / candidate)
+    int32_t w_ltrig0, w_ltrig1;                        // sin/cos of the four orthonormal line angles, [n_lines][8], one per parameter buffer (k_solve only)
     int32_t w_scale_pt, w_scale_ln;                   // Jacobi scales of landmark parameters
     int32_t w_pt_E, w_pt_x;           // Einv store 6*(n_pt_obs+n_points) ; per point {ginv, g, dd, 0}
     int32_t w_ln_Y, w_ln_x;           // Y store 24*n_ln_obs ; per line {Hinv*g[4], g[4], dd[4]}

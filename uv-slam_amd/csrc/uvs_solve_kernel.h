@@ -41,7 +41,7 @@ static constexpr int L_PR = L_PDX + UVS_MAX_PRIOR_DIM;   // prior residual
 static constexpr int L_RED = L_PR + UVS_MAX_PRIOR_DIM;   // reduction scratch
 static constexpr int L_CTRL = L_RED + 64;
 static constexpr int L_PROF = L_CTRL + 32;      // per-phase cycle counters (debug launches only)
-static constexpr int L_WPROF = L_PROF + 24;     // per-wave gather cycles (debug)
+static constexpr int L_WPROF = L_PROF + 24;     // debug sub-timers: [0..3] candidate-cost phase (stage + dx, prior residual, observations, IMU), [4..7] busy cycles of each wave in the Cholesky column phase
 static constexpr int L_LCOST = L_WPROF + 8;     // per-lane cost accumulator of the current linearization (kept in LDS, not in a register that
 static constexpr int L_LGMAX = L_LCOST + NT;    // would have to live across every phase) ; per-lane max |g_landmark|
 static constexpr int L_TOTAL = L_LGMAX + NT;
@@ -130,7 +130,15 @@ struct Ctx {
     double* ws;            // workspace of this window
     double* sh;            // LDS
     KOpts o;
+    int ltrig_ok = 0;      // the sin/cos cache of the line parameters (w_ltrig0/1) is maintained (k_solve) -- the step-wise large-window kernels leave it off
 };
+
+// sin/cos cache that belongs to the line-parameter buffer `line` (nullptr: compute on the fly)
+UVS_DEV const double* line_trig_of(const Ctx& c, const double* line) {
+    const DevWin& h = *c.hdr;
+    if (!c.ltrig_ok) return nullptr;
+    return line == c.ws + h.w_line0 ? c.ws + h.w_ltrig0 : (line == c.ws + h.w_line1 ? c.ws + h.w_ltrig1 : nullptr);
+}
 
 // rotation matrices of the evaluation point `x` (LDS, L_X or L_XC layout) -> L_RF / L_EX
 UVS_DEV void stage_rotations(const Ctx& c, const double* x) {
@@ -210,39 +218,99 @@ UVS_DEV double cost_pass(const Ctx& c, const double* x, const double* invd, cons
     const DevWin& h = *c.hdr;
     const int tid = threadIdx.x;
     const double* RF = c.sh + L_RF; const double* ric = c.sh + L_EX; const double* tic = c.sh + L_EX + 9;
+    const double* ltrig = line_trig_of(c, line);
     double cost = 0.0;
-    // points
-    for (int o = po0 + tid; o < po1; o += NT) {
-        const int lm = c.bi[h.i_pt_lm + o], fi = c.bi[h.i_pt_fi + o], fj = c.bi[h.i_pt_fj + o];
-        double pi[3], pj[3], vij[4];
-        load_point_obs(c, o, x[183], pi, pj, vij);
-        double r[2];
-        point_eval<false, false>(x + 7 * fi, RF + 9 * fi, x + 7 * fj, RF + 9 * fj, ric, tic, invd[lm], pi, pj, c.o.sqrt_info, r, nullptr, nullptr, nullptr, nullptr);
-        double sc; cost += 0.5 * cauchy(c.o.loss_pt, r[0] * r[0] + r[1] * r[1], &sc);
-    }
-    // lines + vp
-    for (int o = lo0 + tid; o < lo1; o += NT) {
-        const int lm = c.bi[h.i_ln_lm + o], fj = c.bi[h.i_ln_fj + o], hv = c.bi[h.i_ln_vp + o];
-        const double* m = c.bd + h.d_lnmeas + o; const int st = h.ln_stride;
-        const double sp[3] = {m[0], m[st], m[2 * st]}, ep[3] = {m[3 * st], m[4 * st], m[5 * st]}, vp[3] = {m[6 * st], m[7 * st], m[8 * st]};
-        LineGeom g;
-        line_geom<false>(x + 7 * fj, x + 7 * fj + 3, RF + 9 * fj, ric, tic, line + 4 * lm, g);
-        double r[2], sc;
-        line_residual<false>(g, sp, ep, c.o.line_factor, r, nullptr, nullptr);
-        cost += 0.5 * cauchy(c.o.loss_ln, r[0] * r[0] + r[1] * r[1], &sc);
-        if (hv) { double rv; vp_residual<false>(g, vp, c.o.vp_factor, &rv, nullptr, nullptr); cost += 0.5 * cauchy(c.o.loss_vp, rv * rv, &sc); }
-    }
-    // IMU: one lane per block (residual only: 15x15 upper-triangular whitening)
-    if (with_imu && tid < h.n_imu) {
-        const int fi = c.bi[h.i_imu + 2 * tid], skip = c.bi[h.i_imu + 2 * tid + 1];
-        if (!skip) {
-            const double* blk = c.bd + h.d_imu + (size_t)tid * UVS_IMU_STRIDE;
-            double r[15];
-            imu_raw(blk, blk + UVS_IMU_JAC, c.o.G, x + 7 * fi, x + 77 + 9 * fi, x + 7 * (fi + 1), x + 77 + 9 * (fi + 1), r, nullptr);
-            const double* W = blk + UVS_IMU_W;
-            for (int i = 0; i < 15; ++i) { double s = 0.0; for (int k = i; k < 15; ++k) s += W[i * 15 + k] * r[k]; cost += 0.5 * s * s; }
+    long long tq_ = clock64();
+#define UVS_CQ(slot) if (c.o.debug && tid == 0) { const long long t_ = clock64(); c.sh[L_WPROF + slot] += (double)(t_ - tq_); tq_ = t_; }
+    // Observations in batches of four per lane: the index loads and the measurement loads of a batch go out together and the
+    // landmark parameters (the only loads whose address depends on an index) follow as a second group, so a lane pays two HBM/L2
+    // round trips per BATCH instead of two per observation (one wave per SIMD: nothing else hides that latency).
+    for (int o0 = po0 + tid; o0 < po1; o0 += 4 * NT) {
+        int lm[4], fi[4], fj[4]; bool in[4];
+        double pi[4][3], pj[4][3], vij[4][4], idp[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int o = o0 + u * NT; in[u] = o < po1;
+            const int oo = in[u] ? o : o0;
+            lm[u] = c.bi[h.i_pt_lm + oo]; fi[u] = c.bi[h.i_pt_fi + oo]; fj[u] = c.bi[h.i_pt_fj + oo];
+            load_point_obs(c, oo, x[183], pi[u], pj[u], vij[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) idp[u] = invd[lm[u]];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (!in[u]) continue;
+            double r[2];
+            point_eval<false, false>(x + 7 * fi[u], RF + 9 * fi[u], x + 7 * fj[u], RF + 9 * fj[u], ric, tic, idp[u], pi[u], pj[u], c.o.sqrt_info, r, nullptr, nullptr, nullptr, nullptr);
+            double sc; cost += 0.5 * cauchy(c.o.loss_pt, r[0] * r[0] + r[1] * r[1], &sc);
         }
     }
+    // lines + vp, two per batch
+    for (int o0 = lo0 + tid; o0 < lo1; o0 += 2 * NT) {
+        int lm[2], fj[2], hv[2]; bool in[2];
+        double ms[2][9], lp[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, tg[2][8];
+        const int st = h.ln_stride;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int o = o0 + u * NT; in[u] = o < lo1;
+            const int oo = in[u] ? o : o0;
+            lm[u] = c.bi[h.i_ln_lm + oo]; fj[u] = c.bi[h.i_ln_fj + oo]; hv[u] = c.bi[h.i_ln_vp + oo];
+            const double* m = c.bd + h.d_lnmeas + oo;
+#pragma unroll
+            for (int q = 0; q < 9; ++q) ms[u][q] = m[q * st];
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (ltrig) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) tg[u][q] = ltrig[8 * lm[u] + q];
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) lp[u][q] = line[4 * lm[u] + q];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (!in[u]) continue;
+            const double sp[3] = {ms[u][0], ms[u][1], ms[u][2]}, ep[3] = {ms[u][3], ms[u][4], ms[u][5]}, vp[3] = {ms[u][6], ms[u][7], ms[u][8]};
+            LineGeom g;
+            line_geom<false>(x + 7 * fj[u], x + 7 * fj[u] + 3, RF + 9 * fj[u], ric, tic, lp[u], g, ltrig ? tg[u] : nullptr);
+            double r[2], sc;
+            line_residual<false>(g, sp, ep, c.o.line_factor, r, nullptr, nullptr);
+            cost += 0.5 * cauchy(c.o.loss_ln, r[0] * r[0] + r[1] * r[1], &sc);
+            if (hv[u]) { double rv; vp_residual<false>(g, vp, c.o.vp_factor, &rv, nullptr, nullptr); cost += 0.5 * cauchy(c.o.loss_vp, rv * rv, &sc); }
+        }
+    }
+    UVS_CQ(2)
+    // IMU: the raw 15-vector by one lane per block (serial quaternion algebra), then the 15x15 upper-triangular whitening with one lane
+    // per (block, row): 120 dependent-latency loads of W per block no longer sit on a single lane.  Scratch: the S region, which holds
+    // nothing live between the triangular solve and the next linearization (prior_residual uses its first 512 doubles the same way).
+    if (with_imu) {
+        double* rs = c.sh + L_S + 1024;
+        if (tid < h.n_imu) {
+            const int fi = c.bi[h.i_imu + 2 * tid], skip = c.bi[h.i_imu + 2 * tid + 1];
+            if (!skip) {
+                const double* blk = c.bd + h.d_imu + (size_t)tid * UVS_IMU_STRIDE;
+                double r[15];
+                imu_raw(blk, blk + UVS_IMU_JAC, c.o.G, x + 7 * fi, x + 77 + 9 * fi, x + 7 * (fi + 1), x + 77 + 9 * (fi + 1), r, nullptr);
+#pragma unroll
+                for (int i = 0; i < 15; ++i) rs[16 * tid + i] = r[i];
+            }
+        }
+        __syncthreads();
+        const int b = tid >> 4, i = tid & 15;
+        if (b < h.n_imu && i < 15 && !c.bi[h.i_imu + 2 * b + 1]) {
+            const double* W = c.bd + h.d_imu + (size_t)b * UVS_IMU_STRIDE + UVS_IMU_W + i * 15;
+            double wv[15];
+#pragma unroll
+            for (int k = 0; k < 15; ++k) wv[k] = (k >= i) ? W[k] : 0.0;
+            double sacc = 0.0;
+#pragma unroll
+            for (int k = 0; k < 15; ++k) sacc += wv[k] * rs[16 * b + k];
+            cost += 0.5 * sacc * sacc;
+        }
+    }
+    UVS_CQ(3)
     return cost;
 }
 
@@ -828,9 +896,7 @@ UVS_DEV void lin_chunk(const Ctx& c, int ch, const double* x, const double* invd
             __syncthreads();
             UVS_PROF(c, P_LMPREP);
             sh[L_LCOST + tid] += cost; sh[L_LGMAX + tid] = fmax(sh[L_LGMAX + tid], gmax_lm);
-            const long long tg0_ = clock64();
             if (h.td_on | h.ex_on) gather_points<true>(grp, lists, rec, acc); else gather_points<false>(grp, lists, rec, acc);
-            if (c.o.debug && (tid & 63) == 0) sh[L_WPROF + (tid >> 6)] += (double)(clock64() - tg0_);
         } else {
             const int* beg = c.bi + h.i_ln_beg;
             const int o0 = beg[k0], o1 = beg[k1], nob = o1 - o0;
@@ -841,12 +907,13 @@ UVS_DEV void lin_chunk(const Ctx& c, int ch, const double* x, const double* invd
             int* lists = (int*)(Xb + 20 * nlm);
             for (int t = tid; t < nlist; t += NT) lists[t] = glists[t];
             // pass A
+            const double* ltrig = line_trig_of(c, line);
             for (int o = o0 + tid; o < o1; o += NT) {
                 const int lm = c.bi[h.i_ln_lm + o], fj = c.bi[h.i_ln_fj + o], hv = c.bi[h.i_ln_vp + o];
                 const double* m = c.bd + h.d_lnmeas + o; const int st = h.ln_stride;
                 const double sp[3] = {m[0], m[st], m[2 * st]}, ep[3] = {m[3 * st], m[4 * st], m[5 * st]}, vp[3] = {m[6 * st], m[7 * st], m[8 * st]};
                 LineGeom g;
-                line_geom<true>(x + 7 * fj, x + 7 * fj + 3, RF + 9 * fj, ric, tic, line + 4 * lm, g);
+                line_geom<true>(x + 7 * fj, x + 7 * fj + 3, RF + 9 * fj, ric, tic, line + 4 * lm, g, ltrig ? ltrig + 8 * lm : nullptr);
                 double* R = rec + (size_t)(o - o0) * UVS_LN_REC;
                 double r[2], Jp[12], Jl[8], sc;
                 line_residual<true>(g, sp, ep, c.o.line_factor, r, Jp, Jl);
@@ -959,9 +1026,7 @@ UVS_DEV void lin_chunk(const Ctx& c, int ch, const double* x, const double* invd
             __syncthreads();
             UVS_PROF(c, P_LMPREP);
             sh[L_LCOST + tid] += cost; sh[L_LGMAX + tid] = fmax(sh[L_LGMAX + tid], gmax_lm);
-            const long long tg0_ = clock64();
             gather_lines(grp, lists, rec, acc);
-            if (c.o.debug && (tid & 63) == 0) sh[L_WPROF + (tid >> 6)] += (double)(clock64() - tg0_);
         }
     }
 }
@@ -1185,6 +1250,7 @@ UVS_DEV void backsub_candidate(const Ctx& c, const double* invd, const double* l
     double gd = 0.0, dd2 = 0.0, step2 = 0.0, xc2 = 0.0;
     const bool td_on = h.td_on != 0;
     const bool ex_on = h.ex_on != 0;
+    double* ltrig_c = const_cast<double*>(line_trig_of(c, line_c));
     if (with_frames && tid < UVS_RD && ((tid & 15) < 15 || (td_on && tid == UVS_TD_INDEX) || (ex_on && tid < 96))) { gd += sh[L_G + tid] * d[tid]; dd2 += sh[L_DD + tid] * d[tid] * d[tid]; }
     if (with_frames && tid < UVS_NF) {
         double xp[7];
@@ -1251,13 +1317,15 @@ UVS_DEV void backsub_candidate(const Ctx& c, const double* invd, const double* l
 #pragma unroll
                 for (int a = 0; a < 6; ++a) t[q] += Y[6 * q + a] * d[16 * fj + a];
         }
+        double vn[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const double dl = -lx[q] - t[q];
             const double v = line[4 * k + q] + dl;
-            line_c[4 * k + q] = v;
+            line_c[4 * k + q] = v; vn[q] = v;
             gd += lx[4 + q] * (dl + t[q]); dd2 += lx[8 + q] * dl * dl; step2 += dl * dl; xc2 += v * v;
         }
+        if (ltrig_c) line_trig(vn, ltrig_c + 8 * k);      // sin/cos of the candidate parameters, once per line instead of once per observation
     }
     double s4[4] = {gd, dd2, step2, xc2};
     double mx = 0.0;
@@ -1408,6 +1476,8 @@ __global__ __launch_bounds__(NT) void k_solve(char* blobs, const long long* blob
     if (tid < 184) sh[L_X + tid] = c.bd[h.d_frames + tid];      // pose[77] sb[99] ex[7] td
     for (int k = tid; k < h.n_points; k += NT) c.ws[h.w_invd0 + k] = c.bd[h.d_invd + k];
     for (int k = tid; k < 4 * h.n_lines; k += NT) c.ws[h.w_line0 + k] = c.bd[h.d_line + k];
+    for (int k = tid; k < h.n_lines; k += NT) line_trig(c.bd + h.d_line + 4 * k, c.ws + h.w_ltrig0 + 8 * k);
+    c.ltrig_ok = 1;
     for (int i = tid; i < (int)(sizeof(uvs_report) / 4); i += NT) ((int*)rep)[i] = 0;
     if (tid < 24) sh[L_PROF + tid] = (tid == 23) ? (double)clock64() : 0.0;
     if (tid < 8) sh[L_WPROF + tid] = 0.0;
@@ -1480,10 +1550,13 @@ __global__ __launch_bounds__(NT) void k_solve(char* blobs, const long long* blob
         invalid = 0;
         // ---- candidate cost
         __syncthreads();
+        long long tc_ = clock64();
         stage_rotations(c, sh + L_XC);
         prior_dx(c, sh + L_XC);
         __syncthreads();
+        if (o.debug && tid == 0) { const long long t_ = clock64(); sh[L_WPROF + 0] += (double)(t_ - tc_); tc_ = t_; }
         double cc_ = prior_residual(c);
+        if (o.debug && tid == 0) { const long long t_ = clock64(); sh[L_WPROF + 1] += (double)(t_ - tc_); tc_ = t_; }
         cc_ += cost_pass(c, sh + L_XC, invd[cur ^ 1], line[cur ^ 1], 0, h.n_pt_obs, 0, h.n_ln_obs, true);
         double s4[4] = {cc_, 0, 0, 0}, mx = 0.0;
         block_reduce(sh, s4, &mx);

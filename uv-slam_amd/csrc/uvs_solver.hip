@@ -397,6 +397,7 @@ static int pack_window(const uvs_window* w, const uvs_options& opts, std::vector
     int wsz = 0;
     h.w_invd0 = wsz; wsz += rup(std::max(h.n_points, 1), 2); h.w_invd1 = wsz; wsz += rup(std::max(h.n_points, 1), 2);
     h.w_line0 = wsz; wsz += 4 * std::max(h.n_lines, 1); h.w_line1 = wsz; wsz += 4 * std::max(h.n_lines, 1);
+    h.w_ltrig0 = wsz; wsz += 8 * std::max(h.n_lines, 1); h.w_ltrig1 = wsz; wsz += 8 * std::max(h.n_lines, 1);
     h.w_scale_pt = wsz; wsz += rup(std::max(h.n_points, 1), 2); h.w_scale_ln = wsz; wsz += 4 * std::max(h.n_lines, 1);
     h.w_pt_E = wsz; wsz += 6 * (h.n_pt_obs + XS * h.n_points) + 6; h.w_pt_x = wsz; wsz += 4 * std::max(h.n_points, 1);
     h.w_ln_Y = wsz; wsz += 24 * std::max(h.n_ln_obs, 1); h.w_ln_x = wsz; wsz += 12 * std::max(h.n_lines, 1);
