@@ -1433,20 +1433,42 @@ UVS_DEV void setup_window(const Ctx& c, double* blob_rw) {
         for (int t = tid; t < n * n; t += NT) Jl[t] = J0[t];
         __syncthreads();
         double* img = c.ws + h.w_prior_img;
+        // column map and block list into LDS: a dependent global load per use otherwise (one wave per SIMD: ~1.5 k cycles each)
+        int* invL = (int*)(c.sh + L_S + 1024); int* pbL = invL + UVS_RD;
+        if (tid < UVS_RD) invL[tid] = inv[tid];
+        if (tid < h.n_pblk) pbL[tid] = pb[tid];
+        __syncthreads();
         for (int t = tid; t < h.n_pblk * UVS_BLK_SZ; t += NT) {
-            const int sl = t / UVS_BLK_SZ, e = t - sl * UVS_BLK_SZ, r = e / UVS_BLK_LD, cc = e - r * UVS_BLK_LD;
-            const int b = pb[sl], fa = c_blk_fa[b], fb = c_blk_fb[b];
-            double v = 0.0;
-            if (cc < 16) {
-                const int a = inv[16 * fa + r], a2 = inv[16 * fb + cc];
-                if (a >= 0 && a2 >= 0) for (int i = 0; i < n; ++i) v += Jl[i * n + a] * Jl[i * n + a2];
+            const int sl = t / UVS_BLK_SZ, e = t - sl * UVS_BLK_SZ;
+            if (e % UVS_BLK_LD == 16) img[t] = 0.0;                             // the padding column of the S layout
+            ((int*)(img + h.n_pblk * UVS_BLK_SZ))[t] = (pbL[sl] & 255) * UVS_BLK_SZ + e;     // where the entry goes in S: the per-linearization add needs no index math
+        }
+        // the 16x16 tiles are a true contraction over the n rows of J0: tile(fa, fb)[r][c] = sum_i J0[i][col(fa, r)] J0[i][col(fb, c)],
+        // 19 x v_mfma_f64_16x16x4_f64 per tile, one tile per wave at a time (A[r][k]: lane r + 16k, B[k][c]: lane c + 16k).
+        // Operands go out five steps at a time.
+        const int li = lane & 15, lk = lane >> 4;
+        for (int sl = wv; sl < h.n_pblk; sl += NW) {
+            const int pk = pbL[sl], fa = (pk >> 8) & 15, fb = (pk >> 12) & 15;      // the host packs (block | fa << 8 | fb << 12)
+            const int ca = invL[16 * fa + li], cb = invL[16 * fb + li];
+            const double* Ja = Jl + (ca >= 0 ? ca : 0); const double* Jb = Jl + (cb >= 0 ? cb : 0);
+            d4_t acc = {0.0, 0.0, 0.0, 0.0};
+            for (int k0 = 0; k0 < n; k0 += 20) {
+                double av[5], bv[5];
+#pragma unroll
+                for (int u = 0; u < 5; ++u) {
+                    const int i = k0 + 4 * u + lk, ic = i < n ? i : n - 1;
+                    const double a = Ja[ic * n], bq = Jb[ic * n];                   // unconditional loads + selects
+                    av[u] = (ca >= 0 && i < n) ? a : 0.0; bv[u] = (cb >= 0 && i < n) ? bq : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 5; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
             }
-            img[t] = v;
-            ((int*)(img + h.n_pblk * UVS_BLK_SZ))[t] = b * UVS_BLK_SZ + e;      // where the entry goes in S: the per-linearization add needs no index math
+#pragma unroll
+            for (int q = 0; q < 4; ++q) img[sl * UVS_BLK_SZ + (lk + 4 * q) * UVS_BLK_LD + li] = acc[q];
         }
         double* hdp = img + (h.n_pblk * UVS_BLK_SZ * 3) / 2 + 2;       // diag(J0^T J0) by S index (added to L_HD per linearization)
         if (tid < UVS_RD) {
-            const int a = inv[tid];
+            const int a = invL[tid];
             double v = 0.0;
             if (a >= 0) for (int i = 0; i < n; ++i) v += Jl[i * n + a] * Jl[i * n + a];
             hdp[tid] = v;

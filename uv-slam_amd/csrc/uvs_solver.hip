@@ -411,7 +411,7 @@ static int pack_window(const uvs_window* w, const uvs_options& opts, std::vector
             if (w->prior->block_kind[b] == UVS_BLOCK_POSE || w->prior->block_kind[b] == UVS_BLOCK_SPEEDBIAS) in[w->prior->block_frame[b]] = true;
             else if (w->prior->block_kind[b] == UVS_BLOCK_TD && td_on) in[UVS_NUM_FRAMES - 1] = true;       // td lives in the last frame's block row
             else if (w->prior->block_kind[b] == UVS_BLOCK_EX_POSE && ex_on) for (int q = 0; q < 6; ++q) in[q] = true;      // ex dofs live in frames 0..5
-        for (int fa = 0; fa < UVS_NUM_FRAMES; ++fa) for (int fb = 0; fb <= fa; ++fb) if (in[fa] && in[fb]) pblk.push_back(fa * (fa + 1) / 2 + fb);
+        for (int fa = 0; fa < UVS_NUM_FRAMES; ++fa) for (int fb = 0; fb <= fa; ++fb) if (in[fa] && in[fb]) pblk.push_back((fa * (fa + 1) / 2 + fb) | (fa << 8) | (fb << 12));      // block | fa << 8 | fb << 12
     }
     h.n_pblk = (int)pblk.size();
     h.w_prior_img = wsz; wsz += std::max(h.n_pblk, 1) * UVS_BLK_SZ * 3 / 2 + 2 + UVS_RD;      // values, their int32 S offsets, diag(J0^T J0) per S index
