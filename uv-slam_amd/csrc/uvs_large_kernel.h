@@ -65,13 +65,27 @@ __global__ __launch_bounds__(NT) void k_large_chunks(char* blob, double* ws, KOp
     if (tid == 0) { P[LG_ACC] = s4[0]; P[LG_ACC + 1] = gmax; }
 }
 
-__global__ void k_large_reduce(const double* partials, int n_chunks, double* reduced) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= LG_RED) return;
+// Deterministic two-level sum of the per-chunk partials: a workgroup owns 16 consecutive entries i, its 16 x 16 threads split the chunk
+// range into 16 contiguous slices (summed in chunk order, loads independent of each other), the 16 slice sums are then added in slice
+// order.  (One thread per entry walking all chunks serially took 137 us for 340 chunks -- more than k_large_chunks itself.)
+__global__ __launch_bounds__(256) void k_large_reduce(const double* partials, int n_chunks, double* reduced) {
+    __shared__ double part[16][17];
+    const int il = threadIdx.x & 15, p = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + il;
+    const bool is_max = (i == LG_ACC + 1);
+    const int per = (n_chunks + 15) / 16, c0 = p * per, c1 = (c0 + per < n_chunks) ? c0 + per : n_chunks;
     double s = 0.0;
-    if (i == LG_ACC + 1) { for (int ch = 0; ch < n_chunks; ++ch) s = fmax(s, partials[(size_t)ch * LG_RED + i]); }
-    else for (int ch = 0; ch < n_chunks; ++ch) s += partials[(size_t)ch * LG_RED + i];      // fixed order => deterministic
-    reduced[i] = s;
+    if (i < LG_RED) {
+        if (is_max) { for (int ch = c0; ch < c1; ++ch) s = fmax(s, partials[(size_t)ch * LG_RED + i]); }
+        else for (int ch = c0; ch < c1; ++ch) s += partials[(size_t)ch * LG_RED + i];
+    }
+    part[p][il] = s;
+    __syncthreads();
+    if (p == 0 && i < LG_RED) {
+        double t = part[0][il];
+        for (int q = 1; q < 16; ++q) t = is_max ? fmax(t, part[q][il]) : t + part[q][il];      // fixed order => deterministic
+        reduced[i] = t;
+    }
 }
 
 // one workgroup: frame terms + assembly + Cholesky + step.  `reduced` holds the (all-reduced) landmark partials.
@@ -145,12 +159,16 @@ __global__ __launch_bounds__(NT) void k_large_backsub(char* blob, double* ws, KO
     if (tid == 0) out[4] = s4[0];
 }
 
-__global__ void k_large_sum_bsums(const double* bsums, int n_chunks, double* out5) {
-    const int i = threadIdx.x;
-    if (i >= 5) return;
+__global__ __launch_bounds__(256) void k_large_sum_bsums(const double* bsums, int n_chunks, double* out5) {
+    // 5 scalars x n_chunks: 32 contiguous chunk slices per scalar (8 lanes idle per slice row), slice sums added in slice order
+    __shared__ double part[32][8];
+    const int i = threadIdx.x & 7, p = threadIdx.x >> 3;
+    const int per = (n_chunks + 31) / 32, c0 = p * per, c1 = (c0 + per < n_chunks) ? c0 + per : n_chunks;
     double s = 0.0;
-    for (int ch = 0; ch < n_chunks; ++ch) s += bsums[8 * (size_t)ch + i];
-    out5[i] = s;
+    if (i < 5) for (int ch = c0; ch < c1; ++ch) s += bsums[8 * (size_t)ch + i];
+    part[p][i] = s;
+    __syncthreads();
+    if (p == 0 && i < 5) { double t = part[0][i]; for (int q = 1; q < 32; ++q) t += part[q][i]; out5[i] = t; }
 }
 
 }  // namespace uvsdev

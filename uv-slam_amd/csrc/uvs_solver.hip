@@ -697,7 +697,7 @@ int uvs_large_linearize(uvs_solver* s) {
     HIPCHK(s, hipSetDevice(s->device));
     KOpts ko = make_kopts(s->opts, 0);
     if (L.n_chunks > 0) hipLaunchKernelGGL(k_large_chunks, dim3(L.n_chunks), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, L.sel, L.first ? 1 : 0, L.radius, L.d_partials);
-    hipLaunchKernelGGL(k_large_reduce, dim3((LG_RED + 255) / 256), dim3(256), 0, s->stream, L.d_partials, L.n_chunks, L.d_reduced);
+    hipLaunchKernelGGL(k_large_reduce, dim3((LG_RED + 15) / 16), dim3(256), 0, s->stream, L.d_partials, L.n_chunks, L.d_reduced);
     HIPCHK(s, hipGetLastError());
     HIPCHK(s, hipStreamSynchronize(s->stream));
     return UVS_OK;
@@ -710,7 +710,7 @@ int uvs_large_step(uvs_solver* s) {
     KOpts ko = make_kopts(s->opts, 0);
     hipLaunchKernelGGL(k_large_solve, dim3(1), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, L.d_reduced, L.first ? 1 : 0, L.radius, L.d_out);
     if (L.n_chunks > 0) hipLaunchKernelGGL(k_large_backsub, dim3(L.n_chunks), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, L.sel, L.d_bsums);
-    hipLaunchKernelGGL(k_large_sum_bsums, dim3(1), dim3(64), 0, s->stream, L.d_bsums, L.n_chunks, L.d_sc5);
+    hipLaunchKernelGGL(k_large_sum_bsums, dim3(1), dim3(256), 0, s->stream, L.d_bsums, L.n_chunks, L.d_sc5);
     HIPCHK(s, hipGetLastError());
     HIPCHK(s, hipStreamSynchronize(s->stream));
     return UVS_OK;
