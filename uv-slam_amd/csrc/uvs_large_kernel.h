@@ -4,12 +4,12 @@
 // Landmarks are conditionally independent given the 11 frame states, so the landmark chunks that k_solve walks
 // sequentially inside one workgroup become the GRID here:
 //   k_large_chunks   grid = #chunks : stage + Schur prep + gather of one chunk  -> per-chunk partial pose blocks
-//   k_large_reduce   sums the partials in chunk order (deterministic)           -> reduced[LG_RED]  (THE all-reduce payload)
+//   k_large_reduce   sums the partials in a fixed two-level order (deterministic) -> reduced[LG_RED]  (THE all-reduce payload)
 //   k_large_solve    1 workgroup    : IMU + prior + damping, Cholesky, step, frame candidate
 //   k_large_backsub  grid = #chunks : landmark back-substitution + candidate cost of the chunk's observations
 // The LM accept / reject logic runs on the host between launches (one small read-back per iteration).
 // Multi-GPU: every rank holds the landmarks k with k % G == rank; `reduced` (pose-pose Schur blocks, reduced gradient,
-// diag(J^T J), landmark cost) is summed with ONE RCCL all-reduce (33.9 KB, latency bound), every rank then solves the same
+// diag(J^T J), landmark cost) is summed with ONE RCCL all-reduce (46.7 KB, latency bound), every rank then solves the same
 // reduced system redundantly; the back-substitution scalars need a second 5-double all-reduce.
 #pragma once
 #include "uvs_solve_kernel.h"
