@@ -184,7 +184,7 @@ class Solver:
         while not L.uvs_large_done(self._h):
             if L.uvs_large_need_linearize(self._h):
                 self._check(L.uvs_large_linearize(self._h))
-                exchange(0)                                # the pose-block partials (33.9 KB)
+                exchange(0)                                # the pose-block partials (46.7 KB)
             self._check(L.uvs_large_step(self._h))
             exchange(1)
             self._check(L.uvs_large_decide(self._h))
