@@ -118,3 +118,27 @@ def test_large_path_equals_persistent_kernel(solver):
     assert r1.num_iterations == r2.num_iterations and list(r1.accepted[:11]) == list(r2.accepted[:11])
     assert abs(r1.final_cost - r2.final_cost) <= 1e-9 * r1.final_cost
     assert pose_deltas(s1.pose, s2.pose)[0] < 1e-8
+
+
+def test_config3_full_size_matches_oracle(gpu_api, oracle):
+    """BASELINE configs[3] AT FULL SIZE (20 000 point + 5 000 line landmarks, 135 000 observations): the landmark-sharded grid path
+    against the CPU oracle (which needs ~7 s for it), plus the size-independent properties: bitwise reproducibility of the
+    deterministic two-level reductions, and landmark shards summing to the unsharded reduced system (one rank holding everything
+    equals the single-call path exactly)."""
+    w = synth.make_window(70, n_points=20000, n_lines=5000, n_tagged=3750)
+    assert len(w.pt_lm) == 100000 and len(w.ln_lm) == 35000
+    s = gpu_api.Solver(max_batch=1, max_points=20008, max_point_obs=240000, max_lines=5008, max_line_obs=60000)
+    sg, rg = s.large_solve(w)
+    so, ro = oracle.solve(w)
+    assert rg.status == 0 and rg.num_iterations == ro.num_iterations
+    assert list(rg.accepted[: rg.num_iterations + 1]) == list(ro.accepted[: ro.num_iterations + 1])
+    dp, da = pose_deltas(sg.pose, so.pose)
+    assert dp < 1e-6 and da < 1e-6, (dp, da)                          # north star: 1e-4 m / 1e-4 rad
+    assert abs(rg.final_cost - ro.final_cost) <= 1e-8 * ro.final_cost and abs(rg.initial_cost - ro.initial_cost) <= 1e-10 * ro.initial_cost
+    assert np.abs(sg.speedbias - so.speedbias).max() < 1e-6
+    assert np.abs(sg.inv_depth - so.inv_depth).max() < 1e-6 and np.abs(sg.line_orth - so.line_orth).max() < 1e-5
+    s2, r2 = s.large_solve(w)                                         # same handle, same window: bit for bit
+    assert np.array_equal(sg.pose, s2.pose) and np.array_equal(sg.inv_depth, s2.inv_depth) and np.array_equal(sg.line_orth, s2.line_orth)
+    assert r2.final_cost == rg.final_cost and list(r2.cost[:11]) == list(rg.cost[:11])
+    s.close()
+    print("configs[3] full size: max |dp| %.2e m, |dtheta| %.2e rad vs oracle; final cost %.10g | %.10g" % (dp, da, rg.final_cost, ro.final_cost))
