@@ -45,10 +45,10 @@ __global__ __launch_bounds__(NT) void k_large_chunks(char* blob, double* ws, KOp
     __syncthreads();
     for (int part = 0; part < h.n_parts; ++part) {
         if (grp >= 0 && ((grp >> 9) & 15) == part) {
-            const int r0 = 3 * (tid & 1);
+            const int r0 = GR * (tid % UVS_GLANES);
             const bool tdrow = ((grp >> 13) & 15) == UVS_NF;       // time-offset blocks: only row 0 is real
 #pragma unroll
-            for (int r = 0; r < 3; ++r) {
+            for (int r = 0; r < GR; ++r) {
                 if (tdrow && (r0 + r) != 0) continue;
                 double* Q = sh + L_S + (grp & 255) * 64 + (r0 + r) * 8;
 #pragma unroll
@@ -101,10 +101,10 @@ __global__ __launch_bounds__(NT) void k_large_solve(char* blob, double* ws, KOpt
     const int grp = gather_group(c);
     GAcc A;
     {
-        const int r0 = 3 * (tid & 1);
+        const int r0 = GR * (tid % UVS_GLANES);
         const bool ld = grp >= 0 && !((grp >> 9) & 15);       // part 0 carries the whole (already summed) block
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
+        for (int r = 0; r < GR; ++r) {
             const double* Q = reduced + (grp & 255) * 64 + (r0 + r) * 8;
 #pragma unroll
             for (int q = 0; q < 6; ++q) A.v[6 * r + q] = ld ? Q[q] : 0.0;

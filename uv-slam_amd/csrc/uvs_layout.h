@@ -41,7 +41,11 @@
 #define UVS_LN_RV 20              // VP residual, later its Schur-corrected value
 #define UVS_LN_JL 22              // line-parameter Jacobian rows at 22, 26, 30
 #define UVS_NT 256                // threads per workgroup of the solve kernels
-#define UVS_NGRP (UVS_NT / 2)      // gather groups: 32 two-lane groups per wave; each owns one 6x6 pose block or one part of a split one
+#ifndef UVS_GLANES
+#define UVS_GLANES 2                // lanes per gather group: 2 = three rows of the 6x6 block per lane, 1 = all six rows in one lane
+#endif
+#define UVS_GROWS (6 / UVS_GLANES)  // block rows held by one lane
+#define UVS_NGRP (UVS_NT / UVS_GLANES)      // gather groups; each owns one 6x6 pose block or one part of a split one
 
 struct DevWin {
     int32_t n_points, n_pt_obs, n_lines, n_ln_obs, n_imu, prior_n, prior_nb, n_chunks;

@@ -577,18 +577,19 @@ UVS_DEV void chol_solve(const Ctx& c) { chol_solve_impl(c.sh); }
 //   direct entry: points: offset of the first Jacobian block | offset of the second << 16 ; lines: record offset
 // Gradient entries need no Schur list: pass B stores the Schur-CORRECTED residual rc = r - J_l H_ll^-1 g_l in every record,
 // and sum_o J_p^T rc IS the reduced gradient.
-static constexpr int GRP_PER_WAVE = 32;
+static constexpr int GRP_PER_WAVE = 64 / UVS_GLANES;
+static constexpr int GR = UVS_GROWS;      // block rows per lane
 static constexpr int LIST_HDR = 2 * (UVS_NGRP + 1);
 typedef double d2_t __attribute__((ext_vector_type(2)));
 
-struct GAcc { double v[18], g[3], hd[3]; };     // v[6r + c]: rows 3t + r of the block; gradient and diag(J^T J) of those rows
+struct GAcc { double v[6 * GR], g[GR], hd[GR]; };     // v[6r + c]: rows r0 + r of the block (r0 = GR * lane-in-group); gradient and diag(J^T J) of those rows
 
 UVS_DEV d2_t lds2(const double* p) { return *(const d2_t*)p; }
 UVS_DEV void gacc_zero(GAcc& A) {
 #pragma unroll
-    for (int q = 0; q < 18; ++q) A.v[q] = 0.0;
+    for (int q = 0; q < 6 * GR; ++q) A.v[q] = 0.0;
 #pragma unroll
-    for (int q = 0; q < 3; ++q) { A.g[q] = 0.0; A.hd[q] = 0.0; }
+    for (int q = 0; q < GR; ++q) { A.g[q] = 0.0; A.hd[q] = 0.0; }
 }
 // A.v[6r + ..] += s * (row of 6 doubles held as 3 x d2_t)
 UVS_DEV void row_fma(double* v, double s, const d2_t* q) {
@@ -596,12 +597,12 @@ UVS_DEV void row_fma(double* v, double s, const d2_t* q) {
 }
 
 // this lane's group descriptor (-1 = idle group), see uvs_layout.h: i_wblk
-UVS_DEV int gather_group(const Ctx& c) { return c.bi[c.hdr->i_wblk + (threadIdx.x >> 1)]; }
+UVS_DEV int gather_group(const Ctx& c) { return c.bi[c.hdr->i_wblk + (threadIdx.x / UVS_GLANES)]; }
 
 // EXT = the window has pseudo-frame blocks (ESTIMATE_TD / ESTIMATE_EXTRINSIC); the default instantiation folds all their special cases away
 template <bool EXT>
 UVS_DEV void gather_points(int grp, const int* lists, const double* S0, GAcc& A) {
-    const int g = threadIdx.x >> 1, r0 = 3 * (threadIdx.x & 1);
+    const int g = threadIdx.x / UVS_GLANES, r0 = GR * (threadIdx.x % UVS_GLANES);
     const bool on = grp >= 0;
     const bool diag = on && ((grp >> 8) & 1);
     const bool tdg = EXT && on && ((grp >> 13) & 15) == UVS_NF;       // block row of the time offset: J1 = (J_td[0], J_td[1]) adjacent, residual 16 doubles below
@@ -614,7 +615,7 @@ UVS_DEV void gather_points(int grp, const int* lists, const double* S0, GAcc& A)
     {
         const int e0 = on ? lists[g] : 0, e1 = on ? lists[g + 1] : 0;
         for (int i = e0; i < e1; i += 2) {
-            double ea[2][3]; d2_t q[2][3];
+            double ea[2][GR]; d2_t q[2][3];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const bool ok = i + u < e1;
@@ -622,13 +623,13 @@ UVS_DEV void gather_points(int grp, const int* lists, const double* S0, GAcc& A)
                 const double* pa = S0 + (e & 0x7fff) + r0;
                 const double* pb = S0 + ((unsigned)e >> 16);
 #pragma unroll
-                for (int r = 0; r < 3; ++r) ea[u][r] = ok ? -pa[r] : 0.0;
+                for (int r = 0; r < GR; ++r) ea[u][r] = ok ? -pa[r] : 0.0;
                 q[u][0] = lds2(pb); q[u][1] = lds2(pb + 2); q[u][2] = lds2(pb + 4);
             }
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll
-                for (int r = 0; r < 3; ++r) row_fma(A.v + 6 * r, ea[u][r], q[u]);
+                for (int r = 0; r < GR; ++r) row_fma(A.v + 6 * r, ea[u][r], q[u]);
         }
     }
     // ---- direct: acc[r][c] += J1[0][r0+r] J2[0][c] + J1[1][r0+r] J2[1][c] ; diagonal blocks (J1 == J2) also g and diag(J^T J)
@@ -640,14 +641,14 @@ UVS_DEV void gather_points(int grp, const int* lists, const double* S0, GAcc& A)
             const int lo = e & 0x7fff;
             const double* pa = S0 + lo + r0;
             const double* pb = S0 + ((unsigned)e >> 16);
-            double p0[3], p1[3]; d2_t q0[3], q1[3];
+            double p0[GR], p1[GR]; d2_t q0[3], q1[3];
 #pragma unroll
-            for (int r = 0; r < 3; ++r) { p0[r] = pa[r]; p1[r] = pa[p1off + r]; }
+            for (int r = 0; r < GR; ++r) { p0[r] = pa[r]; p1[r] = pa[p1off + r]; }
 #pragma unroll
             for (int k = 0; k < 3; ++k) { q0[k] = lds2(pb + 2 * k); q1[k] = lds2(pb + 6 + 2 * k); }
             const d2_t rc = lds2(S0 + lo + rcoff);
 #pragma unroll
-            for (int r = 0; r < 3; ++r) {
+            for (int r = 0; r < GR; ++r) {
                 if (dirv) { row_fma(A.v + 6 * r, p0[r], q0); row_fma(A.v + 6 * r, p1[r], q1); }
                 if (tdcol) A.v[6 * r] += p0[r] * q0[0].x + p1[r] * q0[0].y;
                 if (diag) { A.g[r] += p0[r] * rc.x + p1[r] * rc.y; A.hd[r] += p0[r] * p0[r] + p1[r] * p1[r]; }
@@ -658,7 +659,7 @@ UVS_DEV void gather_points(int grp, const int* lists, const double* S0, GAcc& A)
 }
 
 UVS_DEV void gather_lines(int grp, const int* lists, const double* S0, GAcc& A) {
-    const int g = threadIdx.x >> 1, r0 = 3 * (threadIdx.x & 1);
+    const int g = threadIdx.x / UVS_GLANES, r0 = GR * (threadIdx.x % UVS_GLANES);
     const bool on = grp >= 0;
     const int* ent = lists + LIST_HDR;
     // ---- Schur: acc[r][c] -= sum_q E_a[q][r0 + r] * Y_b[q][c]
@@ -669,17 +670,17 @@ UVS_DEV void gather_lines(int grp, const int* lists, const double* S0, GAcc& A) 
             const int en = (i + 1 < e1) ? ent[i + 1] : 0;
             const double* pa = S0 + (e & 0x7fff) + r0;
             const double* pb = S0 + ((unsigned)e >> 16);
-            double ea[4][3]; d2_t y[4][3];
+            double ea[4][GR]; d2_t y[4][3];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
 #pragma unroll
-                for (int r = 0; r < 3; ++r) ea[q][r] = -pa[6 * q + r];
+                for (int r = 0; r < GR; ++r) ea[q][r] = -pa[6 * q + r];
                 y[q][0] = lds2(pb + 6 * q); y[q][1] = lds2(pb + 6 * q + 2); y[q][2] = lds2(pb + 6 * q + 4);
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int r = 0; r < 3; ++r) row_fma(A.v + 6 * r, ea[q][r], y[q]);
+                for (int r = 0; r < GR; ++r) row_fma(A.v + 6 * r, ea[q][r], y[q]);
             e = en;
         }
     }
@@ -690,16 +691,16 @@ UVS_DEV void gather_lines(int grp, const int* lists, const double* S0, GAcc& A) 
         for (int i = e0; i < e1; ++i) {
             const int rn = (i + 1 < e1) ? ent[i + 1] : 0;
             const double* R = S0 + ro;
-            double p[3][3]; d2_t q[3][3];
+            double p[3][GR]; d2_t q[3][3];
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
 #pragma unroll
-                for (int r = 0; r < 3; ++r) p[k][r] = R[UVS_LN_JP + 6 * k + r0 + r];
+                for (int r = 0; r < GR; ++r) p[k][r] = R[UVS_LN_JP + 6 * k + r0 + r];
                 q[k][0] = lds2(R + UVS_LN_JP + 6 * k); q[k][1] = lds2(R + UVS_LN_JP + 6 * k + 2); q[k][2] = lds2(R + UVS_LN_JP + 6 * k + 4);
             }
             const d2_t rc01 = lds2(R); const double rc2 = R[UVS_LN_RV];
 #pragma unroll
-            for (int r = 0; r < 3; ++r) {
+            for (int r = 0; r < GR; ++r) {
 #pragma unroll
                 for (int k = 0; k < 3; ++k) { row_fma(A.v + 6 * r, p[k][r], q[k]); A.hd[r] += p[k][r] * p[k][r]; }
                 A.g[r] += p[0][r] * rc01.x + p[1][r] * rc01.y + p[2][r] * rc2;
@@ -1045,11 +1046,11 @@ UVS_DEV void lin_assemble(const Ctx& c, const double* x, bool first, double radi
     // every group adds its rows of its pose block; the parts of a split block go in part order, one barrier apart (fixed sum order)
     for (int part = 0; part < h.n_parts; ++part) {
         if (grp >= 0 && ((grp >> 9) & 15) == part) {
-            const int r0 = 3 * (tid & 1);
+            const int r0 = GR * (tid % UVS_GLANES);
             const int fa = (grp >> 13) & 15, fb = (grp >> 17) & 15;
             if (fa == UVS_NF + 1) {  // camera-extrinsic rows (ESTIMATE_EXTRINSIC): dof a of Ex_Pose sits at S index 16 a + 15, anywhere relative to the column
 #pragma unroll
-                for (int r = 0; r < 3; ++r) {
+                for (int r = 0; r < GR; ++r) {
                     const int a = r0 + r, i = UVS_EX_INDEX(a);
                     if (fb < UVS_NF) {
 #pragma unroll
@@ -1078,15 +1079,15 @@ UVS_DEV void lin_assemble(const Ctx& c, const double* x, bool first, double radi
             } else {
             const bool dg = fa == fb;
             double* row0 = sh + L_S + sidx(16 * fa + r0, 16 * fb);
-            double cur[18], cg[3], chd[3];      // all reads before the first write (every "+=" to LDS otherwise waits for the one before)
+            double cur[6 * GR], cg[GR], chd[GR];      // all reads before the first write (every "+=" to LDS otherwise waits for the one before)
 #pragma unroll
-            for (int r = 0; r < 3; ++r) {
+            for (int r = 0; r < GR; ++r) {
 #pragma unroll
                 for (int cc = 0; cc < 6; ++cc) cur[6 * r + cc] = row0[r * UVS_BLK_LD + cc];
                 cg[r] = sh[L_G + 16 * fa + r0 + r]; chd[r] = sh[L_HD + 16 * fa + r0 + r];
             }
 #pragma unroll
-            for (int r = 0; r < 3; ++r) {
+            for (int r = 0; r < GR; ++r) {
 #pragma unroll
                 for (int cc = 0; cc < 6; ++cc) if (!dg || cc <= r0 + r) row0[r * UVS_BLK_LD + cc] = cur[6 * r + cc] + A.v[6 * r + cc];
                 if (dg) { sh[L_G + 16 * fa + r0 + r] = cg[r] + A.g[r]; sh[L_HD + 16 * fa + r0 + r] = chd[r] + A.hd[r]; }

@@ -323,7 +323,9 @@ static int pack_window(const uvs_window* w, const uvs_options& opts, std::vector
         int np[UVS_NBLKX]; int used = 0;
         for (int b = 0; b < UVS_NBLKX; ++b) {      // the pseudo-frame blocks only exist with their option
             const bool tdb = b >= UVS_NBLK && b < UVS_NBLK + UVS_NF + 1, exb = b >= UVS_NBLK + UVS_NF + 1;
-            np[b] = (b < UVS_NBLK || (tdb && td_on) || (exb && ex_on && (td_on || b != UVS_NBLK + UVS_NF + 1 + UVS_NF))) ? 1 : 0; used += np[b];
+            // a block nothing contributes to (frames further apart than the longest track, pseudo-frame blocks of an option that is off) gets
+            // no group at all: S is zeroed anyway, and its group goes to a heavy block instead (15 of 128 groups for the canonical window)
+            np[b] = ((b < UVS_NBLK || (tdb && td_on) || (exb && ex_on && (td_on || b != UVS_NBLK + UVS_NF + 1 + UVS_NF))) && blk_work[b] > 0) ? 1 : 0; used += np[b];
         }
         while (used < UVS_NGRP) {
             int best = -1;
