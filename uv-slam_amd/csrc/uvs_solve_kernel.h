@@ -474,7 +474,7 @@ UVS_DEV void chol_factor_impl(double* sh, int debug) {
                 if (li == j) { sh[L_DINV + 16 * k + j] = inv; if (!(pivs[q] > 0.0)) sh[L_CTRL + C_CHOLOK] = 0.0; }
             }
         }
-        if (debug && lane == 0) sh[L_WPROF + 4 + wv] += (double)(clock64() - tw0_);      // busy time of this wave in A + (pivot chain | look-ahead), without the barrier wait
+        if (debug == 1 && lane == 0) sh[L_WPROF + 4 + wv] += (double)(clock64() - tw0_);      // busy time of this wave in A + (pivot chain | look-ahead), without the barrier wait
         __syncthreads();
         UVS_PROF(c, P_CH_DIAG);
         // ---- S3: panel  L_ik = S_ik W^T  (B operand W[c][m]: strictly-upper slot (m, c) of the diagonal block, 1/L_cc on the diagonal)
@@ -897,7 +897,9 @@ UVS_DEV void lin_chunk(const Ctx& c, int ch, const double* x, const double* invd
             __syncthreads();
             UVS_PROF(c, P_LMPREP);
             sh[L_LCOST + tid] += cost; sh[L_LGMAX + tid] = fmax(sh[L_LGMAX + tid], gmax_lm);
+            const long long tg0_ = clock64();
             if (h.td_on | h.ex_on) gather_points<true>(grp, lists, rec, acc); else gather_points<false>(grp, lists, rec, acc);
+            if (c.o.debug == 2 && (tid & 63) == 0) sh[L_WPROF + 4 + (tid >> 6)] += (double)(clock64() - tg0_);
         } else {
             const int* beg = c.bi + h.i_ln_beg;
             const int o0 = beg[k0], o1 = beg[k1], nob = o1 - o0;

@@ -261,7 +261,7 @@ static int pack_window(const uvs_window* w, const uvs_options& opts, std::vector
     //   direct entry: points: offset(first Jacobian block) | offset(second) << 16   (A^T A, B^T B, B^T A) ; lines: record offset
     const int n_ch = (int)chunks.size() / 6;
     std::vector<std::vector<std::vector<int>>> sch(n_ch, std::vector<std::vector<int>>(UVS_NBLKX)), dir(n_ch, std::vector<std::vector<int>>(UVS_NBLKX));
-    std::vector<long> blk_work(UVS_NBLKX, 0), blk_s(UVS_NBLKX, 0), blk_d(UVS_NBLKX, 0);
+    std::vector<long> blk_work(UVS_NBLKX, 0), blk_s(UVS_NBLKX, 0), blk_d(UVS_NBLKX, 0), blk_wp(UVS_NBLKX, 0), blk_wl(UVS_NBLKX, 0);
     auto blk_of = [](int fa, int fb) { return fa * (fa + 1) / 2 + fb; };   // fa >= fb ; fa == 11 is the time-offset pseudo frame: 66 + fb
     for (int qc = 0; qc < n_ch; ++qc) {
         const int type = chunks[6 * qc], k0 = chunks[6 * qc + 1], k1 = chunks[6 * qc + 2];
@@ -309,8 +309,13 @@ static int pack_window(const uvs_window* w, const uvs_options& opts, std::vector
                 for (int o = b0; o < b1; ++o) Dr[blk_of(w->ln_fj[o0 + o], w->ln_fj[o0 + o])].push_back(o * UVS_LN_REC);
             }
         }
-        // work units = FP64 FMAs per lane and entry of the rows-per-lane gather (the loops are FMA-issue bound)
-        for (int b = 0; b < UVS_NBLKX; ++b) { blk_s[b] += (type == 0 ? 18 : 72) * (long)S[b].size(); blk_d[b] += (type == 0 ? 54 : 63) * (long)Dr[b].size(); }
+        // work units ~ cycles per entry of the rows-per-lane gather
+        for (int b = 0; b < UVS_NBLKX; ++b) {
+            // measured per entry on MI355X (per-wave timers, UVS_DEBUG_GATHER_TIMERS): point Schur 350 cycles, point direct 675 cycles
+            const long ws_ = (type == 0 ? 18 : 72) * (long)S[b].size(), wd_ = (type == 0 ? 35 : 63) * (long)Dr[b].size();
+            blk_s[b] += ws_; blk_d[b] += wd_;
+            (type == 0 ? blk_wp : blk_wl)[b] += ws_ + wd_;      // per landmark family: the chunks of a family are separated by barriers
+        }
     }
     // gather groups: 256 two-lane groups, at least one per pose block; the spare ones split the heaviest blocks further.  Groups are dealt to
     // the waves heaviest first (similar list lengths inside a wave => little divergence); the wave order pairs heavy with light
@@ -327,9 +332,26 @@ static int pack_window(const uvs_window* w, const uvs_options& opts, std::vector
             // no group at all: S is zeroed anyway, and its group goes to a heavy block instead (15 of 128 groups for the canonical window)
             np[b] = ((b < UVS_NBLK || (tdb && td_on) || (exb && ex_on && (td_on || b != UVS_NBLK + UVS_NF + 1 + UVS_NF))) && blk_work[b] > 0) ? 1 : 0; used += np[b];
         }
+        // The waves run in lock step inside a chunk and the chunks of the two landmark families are separated by barriers, so what counts
+        // is the LARGEST per-group share within each family, not the per-group total: a block that is heavy in the point chunks only (the
+        // diagonal blocks: all the J^T J terms) must be split until its point share matches the others', even if its total looks average.
+        // Greedy: the next spare group goes to the family whose current maximum weighs more, and there to the block that holds it.
         while (used < UVS_NGRP) {
+            int bp = -1, bl = -1;
+            for (int b = 0; b < UVS_NBLKX; ++b) {
+                if (np[b] == 0 || np[b] >= 16) continue;
+                if (blk_wp[b] > 0 && (bp < 0 || blk_wp[b] * np[bp] > blk_wp[bp] * np[b])) bp = b;
+                if (blk_wl[b] > 0 && (bl < 0 || blk_wl[b] * np[bl] > blk_wl[bl] * np[b])) bl = b;
+            }
+            // the true maxima include the blocks that cannot be split any further
+            double mp = 0.0, ml = 0.0;
+            for (int b = 0; b < UVS_NBLKX; ++b) if (np[b] > 0) { mp = std::max(mp, (double)blk_wp[b] / np[b]); ml = std::max(ml, (double)blk_wl[b] / np[b]); }
             int best = -1;
-            for (int b = 0; b < UVS_NBLKX; ++b) if (np[b] < 16 && blk_work[b] > 0 && (best < 0 || blk_work[b] * np[best] > blk_work[best] * np[b])) best = b;
+            const double sp_ = bp >= 0 ? (double)blk_wp[bp] / np[bp] : -1.0, sl_ = bl >= 0 ? (double)blk_wl[bl] / np[bl] : -1.0;
+            if (bp >= 0 && sp_ >= mp && (mp >= ml || bl < 0 || sl_ < ml)) best = bp;
+            else if (bl >= 0 && sl_ >= ml) best = bl;
+            else if (bp >= 0 && (bl < 0 || sp_ >= sl_)) best = bp;
+            else best = bl;
             if (best < 0) break;
             ++np[best]; ++used;
         }
@@ -603,7 +625,7 @@ int uvs_debug_first_iteration(uvs_solver* s, const uvs_window* w, double* S_lowe
     const uvs_window* arr[1] = {w};
     int rc = uvs_batch_upload(s, 1, arr);
     if (rc != UVS_OK) return rc;
-    rc = launch_solve(s, 1, nullptr);
+    rc = launch_solve(s, std::getenv("UVS_DEBUG_GATHER_TIMERS") ? 2 : 1, nullptr);
     if (rc != UVS_OK) return rc;
     const size_t nS = (size_t)UVS_RD * UVS_RD;
     if (S_lower) HIPCHK(s, hipMemcpy(S_lower, s->d_dbg, nS * 8, hipMemcpyDeviceToHost));
