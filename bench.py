@@ -73,8 +73,15 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # one rank per GPU over RCCL (backend "nccl" on ROCm).  UVS_BENCH_BACKEND=gloo is a dry-run hook for a box with fewer GPUs than
+        # ranks: the ranks then share the visible devices round-robin and the barrier / max-reduce go through gloo on the host.
+        backend = os.environ.get("UVS_BENCH_BACKEND", "nccl")
+        local_rank = local_rank % max(torch.cuda.device_count(), 1) if backend != "nccl" else local_rank
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     uvs = importlib.import_module("uv-slam_amd")
     synth, abi, api = uvs.synth, uvs.abi, uvs.api
 
@@ -101,7 +108,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     states, reps = solver.download()
