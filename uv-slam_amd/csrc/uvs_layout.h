@@ -76,7 +76,7 @@ struct DevWin {
     int32_t w_pt_E, w_pt_x;           // Einv store 6*(n_pt_obs+n_points) ; per point {ginv, g, dd, 0}
     int32_t w_ln_Y, w_ln_x;           // Y store 24*n_ln_obs ; per line {Hinv*g[4], g[4], dd[4]}
     int32_t w_imu;                    // per block: Jraw[450] Jw[450] rraw[15] rw[15] (pad 936)
-    int32_t w_out;                    // final state: frames[184] (landmarks are read from the cur buffers)
+    int32_t w_out;                    // final state: frames[184] | inv_depth[n_points] | line_orth[4 n_lines] (k_solve; the large path reads the cur buffers)
     int32_t w_prior_img;              // J0^T J0 scattered into S block layout: n_pblk x 272 doubles (written by setup_window, added per linearization)
     int32_t n_pblk;                   // pose blocks of S the prior touches (ids in i_prior + 352)
     int32_t ws_doubles;

@@ -1618,6 +1618,9 @@ __global__ __launch_bounds__(NT) void k_solve(char* blobs, const long long* blob
     if (o.debug && dbg.scal && tid < P_LAST) dbg.scal[8 + tid] = sh[L_PROF + tid];
     if (o.debug && dbg.scal && tid < 8) dbg.scal[24 + tid] = sh[L_WPROF + tid];
     if (tid < 184) c.ws[h.w_out + tid] = sh[L_X + tid];
+    // the accepted landmark parameters follow the frames, so that the host fetches ONE small contiguous block per window
+    for (int k = tid; k < h.n_points; k += NT) c.ws[h.w_out + 184 + k] = invd[cur][k];
+    for (int k = tid; k < 4 * h.n_lines; k += NT) c.ws[h.w_out + 184 + h.n_points + k] = line[cur][k];
     if (tid == 0) {
         rep->status = status; rep->termination = term; rep->num_iterations = it; rep->num_successful = nsucc; rep->final_cost = cost;
         ((DevWin*)blob)->cur_sel = cur;

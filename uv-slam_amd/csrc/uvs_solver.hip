@@ -430,7 +430,7 @@ static int pack_window(const uvs_window* w, const uvs_options& opts, std::vector
     h.w_pt_E = wsz; wsz += 6 * (h.n_pt_obs + XS * h.n_points) + 6; h.w_pt_x = wsz; wsz += 4 * std::max(h.n_points, 1);
     h.w_ln_Y = wsz; wsz += 24 * std::max(h.n_ln_obs, 1); h.w_ln_x = wsz; wsz += 12 * std::max(h.n_lines, 1);
     h.w_imu = wsz; wsz += std::max(h.n_imu, 1) * UVS_WIMU_STRIDE;
-    h.w_out = wsz; wsz += 184;
+    h.w_out = wsz; wsz += 184 + std::max(h.n_points, 0) + 4 * std::max(h.n_lines, 0);
     // S blocks touched by the prior (all pairs of frames that own a kept pose / speed-bias block)
     std::vector<int> pblk;
     if (have_prior) {
@@ -583,27 +583,24 @@ int uvs_batch_download(uvs_solver* s, int n, uvs_state* states, uvs_report* reps
     if (!s || n < 1 || n > s->n_loaded) return UVS_ERR_INVALID_ARG;
     HIPCHK(s, hipSetDevice(s->device));
     int worst = UVS_OK;
+    // reports: one copy for the whole batch; states: one small contiguous block per window (frames | inv_depth | line_orth, written by k_solve)
+    if (reps) {
+        HIPCHK(s, hipMemcpy(reps, s->d_reports, sizeof(uvs_report) * (size_t)n, hipMemcpyDeviceToHost));
+        for (int b = 0; b < n; ++b) if (reps[b].status != UVS_OK) worst = reps[b].status;
+    }
     std::vector<double> buf;
-    for (int b = 0; b < n; ++b) {
+    for (int b = 0; states && b < n; ++b) {
         const DevWin& h = s->hdrs[b];
-        if (reps) {
-            HIPCHK(s, hipMemcpy(&reps[b], s->d_reports + b, sizeof(uvs_report), hipMemcpyDeviceToHost));
-            if (reps[b].status != UVS_OK) worst = reps[b].status;
-        }
-        if (states) {
-            buf.resize(h.ws_doubles);
-            HIPCHK(s, hipMemcpy(buf.data(), s->d_ws + s->ws_off[b], (size_t)h.ws_doubles * 8, hipMemcpyDeviceToHost));
-            DevWin dh;
-            HIPCHK(s, hipMemcpy(&dh, s->d_blobs + s->blob_off[b], sizeof(DevWin), hipMemcpyDeviceToHost));
-            uvs_state& st = states[b];
-            std::memcpy(st.pose, buf.data() + h.w_out, sizeof(double) * 77);
-            std::memcpy(st.speedbias, buf.data() + h.w_out + 77, sizeof(double) * 99);
-            std::memcpy(st.ex_pose, buf.data() + h.w_out + 176, sizeof(double) * 7);
-            st.td = buf[h.w_out + 183];
-            const int sel = dh.cur_sel;
-            if (st.inv_depth) std::memcpy(st.inv_depth, buf.data() + (sel ? h.w_invd1 : h.w_invd0), sizeof(double) * h.n_points);
-            if (st.line_orth) std::memcpy(st.line_orth, buf.data() + (sel ? h.w_line1 : h.w_line0), sizeof(double) * 4 * h.n_lines);
-        }
+        const size_t cnt = 184 + (size_t)h.n_points + 4 * (size_t)h.n_lines;
+        buf.resize(cnt);
+        HIPCHK(s, hipMemcpy(buf.data(), s->d_ws + s->ws_off[b] + h.w_out, cnt * 8, hipMemcpyDeviceToHost));
+        uvs_state& st = states[b];
+        std::memcpy(st.pose, buf.data(), sizeof(double) * 77);
+        std::memcpy(st.speedbias, buf.data() + 77, sizeof(double) * 99);
+        std::memcpy(st.ex_pose, buf.data() + 176, sizeof(double) * 7);
+        st.td = buf[183];
+        if (st.inv_depth) std::memcpy(st.inv_depth, buf.data() + 184, sizeof(double) * h.n_points);
+        if (st.line_orth) std::memcpy(st.line_orth, buf.data() + 184 + h.n_points, sizeof(double) * 4 * h.n_lines);
     }
     return worst;
 }
