@@ -18,3 +18,15 @@ for _ in range(10):
 print("solve (PCIe inclusive): median %.3f ms" % (1e3 * np.median(ts)))
 if os.environ.get("UVS_MARG_PROFILE"):
     pass
+ts = []
+for _ in range(20):
+    t = time.perf_counter(); s.upload([w]); ts.append(time.perf_counter() - t)
+print("upload (pack + H2D) alone: median %.3f ms" % (1e3 * np.median(ts)))
+ts = []
+for _ in range(20):
+    t = time.perf_counter(); s.solve_resident(); ts.append(time.perf_counter() - t)
+print("solve_resident wall: median %.3f ms" % (1e3 * np.median(ts)))
+ts = []
+for _ in range(20):
+    t = time.perf_counter(); s.download(); ts.append(time.perf_counter() - t)
+print("download alone: median %.3f ms" % (1e3 * np.median(ts)))

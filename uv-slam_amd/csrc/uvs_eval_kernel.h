@@ -23,7 +23,7 @@ __global__ __launch_bounds__(NT) void k_evaluate(char* blob, double* ws, KOpts o
     c.hdr = (const DevWin*)blob; c.bd = (const double*)blob; c.bi = (const int*)blob; c.ws = ws; c.sh = sh; c.o = o;
     const DevWin& h = *c.hdr;
     if (tid < 184) sh[L_X + tid] = c.bd[h.d_frames + tid];
-    setup_window(c, (double*)blob);
+    setup_window(c, (double*)blob, false);
     __syncthreads();
     const double* x = sh + L_X;
     stage_rotations(c, x);

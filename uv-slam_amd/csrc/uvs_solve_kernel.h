@@ -1418,14 +1418,14 @@ UVS_DEV void imu_whiten_block(const double* cov, double* W, double* scr /* LDS, 
     wave_sync();
 }
 
-UVS_DEV void setup_window(const Ctx& c, double* blob_rw) {
+UVS_DEV void setup_window(const Ctx& c, double* blob_rw, bool with_prior_image = true) {      // k_evaluate needs the IMU whitening only
     const DevWin& h = *c.hdr;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     for (int b = wv; b < h.n_imu; b += NW) {
         double* blk = blob_rw + h.d_imu + (size_t)b * UVS_IMU_STRIDE;
         imu_whiten_block(blk + UVS_IMU_COV, blk + UVS_IMU_W, c.sh + L_S + 256 * wv, lane);
     }
-    if (h.prior_n > 0) {
+    if (h.prior_n > 0 && with_prior_image) {
         // prior normal matrix J0^T J0, computed ONCE per solve straight into S's block layout ("image" of the touched pose blocks in the
         // workspace): every image entry is owned by one thread (no read-modify-write), J0 is staged in LDS first (coalesced)
         const int n = h.prior_n;
