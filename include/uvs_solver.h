@@ -282,6 +282,11 @@ int uvs_debug_first_iteration(uvs_solver *s, const uvs_window *w, double *S_lowe
  * (the reference calls vector2double() again at :1004). Output prior is already
  * re-indexed for the next window (addr_shift, estimator.cpp:1139-1153). */
 int uvs_marginalize(uvs_solver *s, const uvs_window *w, int flag, uvs_prior *out);
+/* Same, for the usual sequence "solve window w, then marginalize it" (Estimator::optimization()): the caller promises that the
+ * residual blocks of `w` are the ones of the LAST upload of this handle (uvs_solve_window / uvs_batch_upload with n = 1) and that
+ * only the state fields (pose, speedbias, ex_pose, td, inv_depth, line_orth) changed; the resident factors are reused and only the
+ * state is sent to the device.  Returns UVS_ERR_INVALID_ARG when the block counts do not match the resident window. */
+int uvs_marginalize_resident(uvs_solver *s, const uvs_window *w, int flag, uvs_prior *out);
 
 /* ---- ONE large window spread over the GPU and, with an all-reduce between the steps, over several GPUs (BASELINE configs[3]) ----
  * Landmarks shard (rank r holds the landmarks k with k % G == r; frames / IMU / prior are replicated); the only exchanged data are

@@ -34,4 +34,5 @@ const char* uvs_last_error(const uvs_solver* s) { return s ? s->err.c_str() : "n
 const char* uvs_status_string(int st) { return st == UVS_OK ? "ok" : "oracle error"; }
 int uvs_solve_window(uvs_solver* s, const uvs_window* w, uvs_state* out, uvs_report* rep) { return oracle_solve(&s->opt, w, 0, out, rep); }
 int uvs_marginalize(uvs_solver* s, const uvs_window* w, int flag, uvs_prior* out) { return oracle_marginalize(&s->opt, w, flag, out); }
+int uvs_marginalize_resident(uvs_solver* s, const uvs_window* w, int flag, uvs_prior* out) { return oracle_marginalize(&s->opt, w, flag, out); }
 }

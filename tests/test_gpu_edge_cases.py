@@ -113,3 +113,22 @@ def test_baseline_batch_is_bitwise_reproducible(solver):
     assert np.array_equal(alone.pose, s1[137].pose) and ralone.final_cost == r1[137].final_cost
     costs = np.array([r.final_cost for r in r1]); init = np.array([r.initial_cost for r in r1])
     assert np.all(costs < 1e-6 * init)                        # every window converges from the perturbed start
+
+
+def test_marginalize_resident_equals_marginalize(gpu_api, oracle):
+    """uvs_marginalize_resident (state-only upload after a solve of the same window) gives bit-for-bit the prior of uvs_marginalize,
+    for both marginalization kinds, and refuses a window that does not match the resident one."""
+    s = gpu_api.Solver(max_batch=2)
+    w = synth.make_window(64, with_prior=True, marginalize_fn=lambda win, flag: s.marginalize(win, flag))
+    st, rep = s.solve(w)                                   # leaves w's factors resident
+    post = w.with_state(st)
+    for flag in (0, 1):
+        pr = s.marginalize(post, flag, resident=True)
+        s.solve(w)
+        pf = s.marginalize(post, flag)
+        assert pr.n == pf.n and np.array_equal(pr.J0(), pf.J0()) and np.array_equal(pr.r0(), pf.r0())
+        s.solve(w)
+    other = synth.make_window(65, n_points=40, n_lines=10, n_tagged=8)
+    with pytest.raises(RuntimeError):
+        s.marginalize(other, 0, resident=True)
+    s.close()

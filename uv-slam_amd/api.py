@@ -17,7 +17,7 @@ _lib = None
 
 EXPORTS = [
     "uvs_abi_version", "uvs_default_options", "uvs_create", "uvs_destroy", "uvs_last_error", "uvs_status_string",
-    "uvs_solve_window", "uvs_batch_upload", "uvs_batch_solve", "uvs_batch_download", "uvs_evaluate", "uvs_marginalize",
+    "uvs_solve_window", "uvs_batch_upload", "uvs_batch_solve", "uvs_batch_download", "uvs_evaluate", "uvs_marginalize", "uvs_marginalize_resident",
     "uvs_reduced_dim",
 ]
 
@@ -48,6 +48,8 @@ def lib():
         L.uvs_evaluate.restype = C.c_int
         L.uvs_marginalize.argtypes = [C.c_void_p, C.POINTER(abi.WindowC), C.c_int, C.POINTER(abi.Prior)]
         L.uvs_marginalize.restype = C.c_int
+        L.uvs_marginalize_resident.argtypes = [C.c_void_p, C.POINTER(abi.WindowC), C.c_int, C.POINTER(abi.Prior)]
+        L.uvs_marginalize_resident.restype = C.c_int
         L.uvs_debug_first_iteration.argtypes = [C.c_void_p, C.POINTER(abi.WindowC)] + [abi.c_double_p] * 6
         L.uvs_debug_first_iteration.restype = C.c_int
         L.uvs_reduced_dim.argtypes = [C.POINTER(abi.Options)]; L.uvs_reduced_dim.restype = C.c_int
@@ -199,10 +201,12 @@ class Solver:
         ev.cost = ec.cost
         return ev
 
-    def marginalize(self, w: abi.Window, flag=0):
+    def marginalize(self, w: abi.Window, flag=0, resident=False):
+        """resident=True: the factors of `w` are those of the last single-window upload / solve of this handle; only its state is sent."""
         wc, keep = w.to_c()
         p = abi.Prior()
-        self._check(lib().uvs_marginalize(self._h, C.byref(wc), flag, C.byref(p)))
+        fn = lib().uvs_marginalize_resident if resident else lib().uvs_marginalize
+        self._check(fn(self._h, C.byref(wc), flag, C.byref(p)))
         return p
 
     def debug_first_iteration(self, w: abi.Window):

@@ -652,6 +652,26 @@ int uvs_marginalize(uvs_solver* s, const uvs_window* w, int flag, uvs_prior* out
     return run_marginalize(s->device, s->stream, s->d_blobs, s->d_ws, s->hdrs[0], w, make_kopts(s->opts, 0), flag, out, s->err, s->eval_scratch);
 }
 
+
+int uvs_marginalize_resident(uvs_solver* s, const uvs_window* w, int flag, uvs_prior* out) {
+    if (!s || !w || !out || (flag != 0 && flag != 1)) return UVS_ERR_INVALID_ARG;
+    if (s->n_loaded != 1) { s->err = "uvs_marginalize_resident: no single resident window"; return UVS_ERR_INVALID_ARG; }
+    const DevWin& h = s->hdrs[0];
+    const int pn = (w->prior && w->prior->n > 0) ? w->prior->n : 0;
+    if (h.n_points != w->n_points || h.n_pt_obs != w->n_point_obs || h.n_lines != w->n_lines || h.n_ln_obs != w->n_line_obs || h.n_imu != w->n_imu || h.prior_n != pn) {
+        s->err = "uvs_marginalize_resident: the window does not match the resident one"; return UVS_ERR_INVALID_ARG;
+    }
+    HIPCHK(s, hipSetDevice(s->device));
+    // state sections of the resident blob: frames[184] = pose | speedbias | ex_pose | td, inverse depths, line parameters
+    double fr[184];
+    std::memcpy(fr, w->pose, 77 * 8); std::memcpy(fr + 77, w->speedbias, 99 * 8); std::memcpy(fr + 176, w->ex_pose, 7 * 8); fr[183] = w->td;
+    char* blob = s->d_blobs + s->blob_off[0];
+    HIPCHK(s, hipMemcpyAsync(blob + (size_t)h.d_frames * 8, fr, sizeof(fr), hipMemcpyHostToDevice, s->stream));
+    if (h.n_points) HIPCHK(s, hipMemcpyAsync(blob + (size_t)h.d_invd * 8, w->inv_depth, (size_t)h.n_points * 8, hipMemcpyHostToDevice, s->stream));
+    if (h.n_lines) HIPCHK(s, hipMemcpyAsync(blob + (size_t)h.d_line * 8, w->line_orth, (size_t)h.n_lines * 32, hipMemcpyHostToDevice, s->stream));
+    return run_marginalize(s->device, s->stream, s->d_blobs, s->d_ws, s->hdrs[0], w, make_kopts(s->opts, 0), flag, out, s->err, s->eval_scratch);
+}
+
 }  // extern "C"
 
 // ------------------------------------------------------------------ large single window (configs[3]), optionally multi-GPU

@@ -159,7 +159,8 @@ void Estimator::optimization() {      // estimator.cpp:761-1233
         uvs_window w; problem.fill(&w, feature_index + 1, line_feature_index + 1);
         std::memcpy(w.pose, para_Pose, sizeof(w.pose)); std::memcpy(w.speedbias, para_SpeedBias, sizeof(w.speedbias));
         MarginalizationInfo* marginalization_info = new MarginalizationInfo();
-        const int rc = uvs_marginalize(solver, &w, marginalization_flag == MARGIN_OLD ? 0 : 1, &marginalization_info->prior);
+        // the factors are the ones uvs::Solve() just uploaded; only the (re-anchored) state goes to the device again
+        const int rc = uvs_marginalize_resident(solver, &w, marginalization_flag == MARGIN_OLD ? 0 : 1, &marginalization_info->prior);
         if (rc == UVS_OK) { delete last_marginalization_info; last_marginalization_info = marginalization_info; }
         else delete marginalization_info;
     }
