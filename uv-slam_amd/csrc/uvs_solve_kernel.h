@@ -38,7 +38,8 @@ static constexpr int L_RF = L_DINV + UVS_RD;   // 11 rotation matrices (row-majo
 static constexpr int L_EX = L_RF + 104;        // ric[9] tic[3]
 static constexpr int L_PDX = L_EX + 16;        // prior dx
 static constexpr int L_PR = L_PDX + UVS_MAX_PRIOR_DIM;   // prior residual
-static constexpr int L_RED = L_PR + UVS_MAX_PRIOR_DIM;   // reduction scratch
+static constexpr int L_PRC = L_PR + UVS_MAX_PRIOR_DIM;   // prior residual at the CANDIDATE (becomes the current one when the step is accepted)
+static constexpr int L_RED = L_PRC + UVS_MAX_PRIOR_DIM;  // reduction scratch
 static constexpr int L_CTRL = L_RED + 64;
 static constexpr int L_PROF = L_CTRL + 32;      // per-phase cycle counters (debug launches only)
 static constexpr int L_WPROF = L_PROF + 24;     // debug sub-timers: [0..3] candidate-cost phase (stage + dx, prior residual, observations, IMU), [4..7] busy cycles of each wave in the Cholesky column phase
@@ -184,7 +185,7 @@ UVS_DEV void prior_dx(const Ctx& c, const double* x) {
 // Every row's dot product is split over up to 4 lanes (NT / n) with 8 loads in flight each: the 45 KB of J0 come from L2 / HBM on every
 // evaluation and a 75-lane, 75-deep dependent chain paid the full memory latency 75 times.  Partials meet in the (dead) S region;
 // contains one workgroup barrier, so all threads must call it.
-UVS_DEV double prior_residual(const Ctx& c) {
+UVS_DEV double prior_residual(const Ctx& c, int dst = L_PR) {
     const DevWin& h = *c.hdr;
     const int n = h.prior_n, tid = threadIdx.x;
     double cost = 0.0;
@@ -207,7 +208,7 @@ UVS_DEV double prior_residual(const Ctx& c) {
     if (tid < n) {
         double s = c.bd[h.d_prior + 2 * n * n + tid];
         for (int p = 0; p < parts; ++p) s += c.sh[L_S + 128 * p + tid];
-        c.sh[L_PR + tid] = s;
+        c.sh[dst + tid] = s;
         cost = 0.5 * s * s;
     }
     return cost;
@@ -723,12 +724,23 @@ static constexpr int IMU_SLOTS = (UVS_NF - 1 + NW - 1) / NW;   // IMU blocks per
 struct ImuN { d4_t n00[IMU_SLOTS], n10[IMU_SLOTS], n11[IMU_SLOTS]; };
 
 // rotations of the evaluation point + prior residual (L_PR); returns this lane's share of the prior cost
-UVS_DEV double lin_prep(const Ctx& c, const double* x) {
+// mode 0: everything.  The persistent kernel knows more: after an ACCEPTED step (mode 1) x is the candidate the cost pass has just
+// evaluated, so the rotations staged in L_RF / L_EX are already x's and the prior residual r0 + J0 dx sits in L_PRC (the 75 x 75
+// mat-vec from HBM is not repeated); after a REJECTED or invalid step (mode 2) x and L_PR are unchanged, only the rotations are restaged.
+UVS_DEV double lin_prep(const Ctx& c, const double* x, int mode = 0) {
     UVS_PROF(c, P_MISC);
-    stage_rotations(c, x);
-    prior_dx(c, x);
+    const int tid = threadIdx.x, n = c.hdr->prior_n;
+    if (mode == 0) {
+        stage_rotations(c, x);
+        prior_dx(c, x);
+        __syncthreads();
+        return prior_residual(c);
+    }
+    if (mode == 2) stage_rotations(c, x);
+    double r = 0.0;
+    if (tid < n) { r = c.sh[(mode == 1 ? L_PRC : L_PR) + tid]; if (mode == 1) c.sh[L_PR + tid] = r; }
     __syncthreads();
-    return prior_residual(c);
+    return 0.5 * r * r;
 }
 // IMU normal-equation tiles; staged in the S region, so it runs when no landmark chunk is staged there (after the last gather,
 // right before the assembly: the 9 accumulator tiles per wave then live only across lin_assemble)
@@ -1231,11 +1243,11 @@ UVS_DEV void lin_assemble(const Ctx& c, const double* x, bool first, double radi
     UVS_PROF(c, P_ASSEMBLE);
 }
 
-UVS_DEV void linearize(const Ctx& c, const double* x, const double* invd, const double* line, bool first, double radius) {
+UVS_DEV void linearize(const Ctx& c, const double* x, const double* invd, const double* line, bool first, double radius, int prep_mode = 0) {
     const DevWin& h = *c.hdr;
     const int grp = gather_group(c);       // this lane's gather group: pose block | flags (uvs_layout.h: i_wblk)
     GAcc A; gacc_zero(A);
-    { const double pc = lin_prep(c, x); c.sh[L_LCOST + threadIdx.x] = pc; c.sh[L_LGMAX + threadIdx.x] = 0.0; }
+    { const double pc = lin_prep(c, x, prep_mode); c.sh[L_LCOST + threadIdx.x] = pc; c.sh[L_LGMAX + threadIdx.x] = 0.0; }
     for (int ch = 0; ch < h.n_chunks; ++ch) lin_chunk(c, ch, x, invd, line, first, radius, grp, A);
     ImuN N;
     const double ic = lin_imu(c, x, N);
@@ -1518,11 +1530,12 @@ __global__ __launch_bounds__(NT) void k_solve(char* blobs, const long long* blob
     // ONE linearize() call site (the kernel is one big inlined body; a second copy doubles the instruction footprint):
     // need_lin is raised at start, after an accepted step (new point) and after a rejected / invalid step (new radius).
     bool need_lin = true, first = true;
+    int prep_mode = 0;        // how much of lin_prep the next linearization can skip (0 nothing, 1 after an accepted step, 2 after a rejected / invalid one)
     int pending = 0;          // trace slot whose cost / gradient norm the next linearization fills in
     while (true) {
         if (it >= o.max_it && !first) { term = UVS_TERM_NO_CONVERGENCE; break; }
         if (need_lin) {
-            linearize(c, sh + L_X, invd[cur], line[cur], first, radius);
+            linearize(c, sh + L_X, invd[cur], line[cur], first, radius, prep_mode);
             need_lin = false;
             const double lc = sh[L_CTRL + C_COST];
             gmax = sh[L_CTRL + C_GMAX];
@@ -1567,7 +1580,7 @@ __global__ __launch_bounds__(NT) void k_solve(char* blobs, const long long* blob
         if (tid == 0) rep->model_cost_change[ti] = mcc;
         if (!ok || !(mcc > 0.0)) {    // invalid step (HandleInvalidStep)
             ++invalid;
-            radius = radius / decr; decr *= 2.0; need_lin = true;
+            radius = radius / decr; decr *= 2.0; need_lin = true; prep_mode = 2;
             if (tid == 0) { rep->accepted[ti] = -1; rep->cost[ti] = cost; rep->candidate_cost[ti] = cost; rep->radius[ti] = radius; rep->gradient_max_norm[ti] = gmax; }
             if (invalid >= o.max_invalid) { term = UVS_TERM_INVALID_STEPS; break; }
             continue;
@@ -1580,7 +1593,7 @@ __global__ __launch_bounds__(NT) void k_solve(char* blobs, const long long* blob
         prior_dx(c, sh + L_XC);
         __syncthreads();
         if (o.debug && tid == 0) { const long long t_ = clock64(); sh[L_WPROF + 0] += (double)(t_ - tc_); tc_ = t_; }
-        double cc_ = prior_residual(c);
+        double cc_ = prior_residual(c, L_PRC);
         if (o.debug && tid == 0) { const long long t_ = clock64(); sh[L_WPROF + 1] += (double)(t_ - tc_); tc_ = t_; }
         cc_ += cost_pass(c, sh + L_XC, invd[cur ^ 1], line[cur ^ 1], 0, h.n_pt_obs, 0, h.n_ln_obs, true);
         double s4[4] = {cc_, 0, 0, 0}, mx = 0.0;
@@ -1605,11 +1618,11 @@ __global__ __launch_bounds__(NT) void k_solve(char* blobs, const long long* blob
             radius = fmin(o.rmax, radius);
             decr = 2.0;
             cost = cand;              // replaced by the linearization's own sum if another iteration follows (equal up to summation order)
-            need_lin = true; pending = ti;
+            need_lin = true; pending = ti; prep_mode = 1;
             if (tid == 0) { rep->accepted[ti] = 1; rep->cost[ti] = cost; rep->radius[ti] = radius; }
             if (stop) break;
         } else {                      // HandleUnsuccessfulStep
-            radius = radius / decr; decr *= 2.0; need_lin = true;
+            radius = radius / decr; decr *= 2.0; need_lin = true; prep_mode = 2;
             if (tid == 0) { rep->accepted[ti] = 0; rep->radius[ti] = radius; }
         }
     }
