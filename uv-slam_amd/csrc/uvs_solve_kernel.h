@@ -1296,14 +1296,24 @@ UVS_DEV void backsub_candidate(const Ctx& c, const double* invd, const double* l
         const double* Eg = c.ws + h.w_pt_E + 6 * (size_t)(b0 + h.pt_xslots * k);
         double t = 0.0;      // Einv . delta_pose  (the landmark's share of the frame step)
         if (b1 > b0) {
-            const int fi = c.bi[h.i_pt_fi + b0];
+            // slots (anchor, observations) four at a time: the frame indices and the 6-vectors of a batch are independent loads, so a lane
+            // pays one HBM/L2 round trip per BATCH instead of one per observation
+            const int ns = b1 - b0 + 1;
+            for (int s0 = 0; s0 < ns; s0 += 4) {
+                int fr[4]; double ev[4][6];
 #pragma unroll
-            for (int a = 0; a < 6; ++a) t += Eg[a] * d[16 * fi + a];
-            for (int o = b0; o < b1; ++o) {
-                const int fj = c.bi[h.i_pt_fj + o];
-                const double* e = Eg + 6 * (o - b0 + 1);
+                for (int u = 0; u < 4; ++u) {
+                    const int sl = s0 + u, slc = sl < ns ? sl : 0;
+                    fr[u] = slc == 0 ? c.bi[h.i_pt_fi + b0] : c.bi[h.i_pt_fj + b0 + slc - 1];
 #pragma unroll
-                for (int a = 0; a < 6; ++a) t += e[a] * d[16 * fj + a];
+                    for (int a = 0; a < 6; ++a) ev[u][a] = Eg[6 * slc + a];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (s0 + u >= ns) continue;
+#pragma unroll
+                    for (int a = 0; a < 6; ++a) t += ev[u][a] * d[16 * fr[u] + a];
+                }
             }
             if (td_on) t += Eg[6 * (b1 - b0 + 1)] * d[UVS_TD_INDEX];
             if (ex_on) {
@@ -1324,13 +1334,24 @@ UVS_DEV void backsub_candidate(const Ctx& c, const double* invd, const double* l
         const int b0 = lbeg[k], b1 = lbeg[k + 1];
         const double* lx = c.ws + h.w_ln_x + 12 * (size_t)k;
         double t[4] = {0.0, 0.0, 0.0, 0.0};
-        for (int o = b0; o < b1; ++o) {
-            const int fj = c.bi[h.i_ln_fj + o];
-            const double* Y = c.ws + h.w_ln_Y + 24 * (size_t)o;
+        for (int o = b0; o < b1; o += 2) {      // two observations per batch (2 x 24 independent loads)
+            int fr[2]; double yv[2][24];
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+            for (int u = 0; u < 2; ++u) {
+                const int oc = o + u < b1 ? o + u : o;
+                fr[u] = c.bi[h.i_ln_fj + oc];
+                const double* Y = c.ws + h.w_ln_Y + 24 * (size_t)oc;
 #pragma unroll
-                for (int a = 0; a < 6; ++a) t[q] += Y[6 * q + a] * d[16 * fj + a];
+                for (int q = 0; q < 24; ++q) yv[u][q] = Y[q];
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (o + u >= b1) continue;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int a = 0; a < 6; ++a) t[q] += yv[u][6 * q + a] * d[16 * fr[u] + a];
+            }
         }
         double vn[4];
 #pragma unroll
