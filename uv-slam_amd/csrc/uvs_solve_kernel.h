@@ -458,11 +458,12 @@ UVS_DEV void chol_factor_impl(double* sh, int debug) {
                 // readlane that needs it (B operands need no masks: A is zero outside k-slot `slot` and outside rows > j)
                 if (j > 0) T = __builtin_amdgcn_mfma_f64_16x16x4f64(us_prev, T[(j - 1) >> 2], T, 0, 0, 0);
                 const double m = (lk == slot && li > j) ? dacc[reg] : 0.0;   // a[j][c], c > j, at lane 16*slot + c (symmetric => column j)
-                double y = __builtin_amdgcn_rcp(piv);                        // 1/piv: hardware seed (2^-24) + one third-order step
-                const double e = fma(-piv, y, 1.0);
-                y = fma(y, fma(e, e, e), y);
+                // us = -m / piv on the serial chain: hardware seed y0 (2^-24) and one third-order correction, 1/piv = y0 (1 + e + e^2) with
+                // e = 1 - piv y0, arranged so that the seed-only product -m y0 runs beside the error term: rcp -> e -> e + e^2 -> us
+                const double y0 = __builtin_amdgcn_rcp(piv);
+                const double e = fma(-piv, y0, 1.0), us0 = -m * y0;
+                const double us = fma(us0, fma(e, e, e), us0);
                 if (lk == slot) pivs[reg] = piv;
-                const double us = -m * y;
                 dacc = __builtin_amdgcn_mfma_f64_16x16x4f64(us, dacc[reg], dacc, 0, 0, 0);
                 us_prev = us;
             }
