@@ -99,7 +99,7 @@ __global__ __launch_bounds__(NT) void k_evaluate(char* blob, double* ws, KOpts o
 struct EvalScratch {
     double* d = nullptr; size_t cap = 0;       // device, doubles
     double* h = nullptr; size_t hcap = 0;      // pinned host, doubles
-    void release() { if (d) hipFree(d); if (h) hipHostFree(h); d = h = nullptr; cap = hcap = 0; }
+    void release() { if (d) (void)hipFree(d); if (h) (void)hipHostFree(h); d = h = nullptr; cap = hcap = 0; }
 };
 
 // host driver: blob of window 0 must already be on the device (uvs_batch_upload)
@@ -112,13 +112,13 @@ static int run_evaluate(int device, hipStream_t stream, char* d_blob, double* d_
     static bool attr = false;
     if (!attr) { if (!chk(hipFuncSetAttribute((const void*)k_evaluate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES), "hipFuncSetAttribute")) return UVS_ERR_HIP; attr = true; }
     if (sc.cap < tot) {
-        if (sc.d) hipFree(sc.d);
+        if (sc.d) (void)hipFree(sc.d);
         sc.d = nullptr; sc.cap = 0;
         if (!chk(hipMalloc((void**)&sc.d, tot * 8), "hipMalloc(eval)")) return UVS_ERR_HIP;
         sc.cap = tot;
     }
     if (sc.hcap < tot) {
-        if (sc.h) hipHostFree(sc.h);
+        if (sc.h) (void)hipHostFree(sc.h);
         sc.h = nullptr; sc.hcap = 0;
         if (!chk(hipHostMalloc((void**)&sc.h, tot * 8, hipHostMallocDefault), "hipHostMalloc(eval)")) return UVS_ERR_HIP;
         sc.hcap = tot;

@@ -93,7 +93,6 @@ __global__ __launch_bounds__(NT) void k_large_solve(char* blob, double* ws, KOpt
     extern __shared__ __attribute__((aligned(16))) double sh[];
     const int tid = threadIdx.x;
     Ctx c; c.hdr = (const DevWin*)blob; c.bd = (const double*)blob; c.bi = (const int*)blob; c.ws = ws; c.sh = sh; c.o = o; c.o.debug = 0;
-    const DevWin& h = *c.hdr;
     if (tid < 184) sh[L_X + tid] = state[LS_X + tid];
     if (tid < UVS_RD && !first) sh[L_SC + tid] = state[LS_SC + tid];
     if (first) setup_window(c, (double*)blob);

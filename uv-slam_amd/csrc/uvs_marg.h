@@ -180,14 +180,6 @@ static int run_marginalize(int device, hipStream_t stream, char* d_blob, double*
     std::vector<char> used(NID, 0), drop(NID, 0);
     std::vector<MFactor> fs;
     const bool have_prior = w->prior && w->prior->n > 0;
-    std::vector<double> priorJ;     // prior Jacobian restricted to local columns, in block order
-    auto add_prior = [&](int drop_kind_pose_frame, bool drop_sb0) {
-        const uvs_prior& p = *w->prior; const int n = p.n;
-        // the prior is a single factor over all its kept blocks; we emit it as one MFactor per ... no: one dense factor.
-        // represent as a factor with many blocks by splitting columns: handled separately below via `pcols`.
-        (void)drop_kind_pose_frame; (void)drop_sb0; (void)n;
-    };
-    (void)add_prior;
     // column map of the (single) prior factor
     std::vector<int> p_id, p_src;     // per local column: block id, source column in J0
     if (have_prior && (flag == 0 || flag == 1)) {

@@ -135,16 +135,16 @@ int uvs_create(const uvs_options* opts, int device, int max_batch, int max_point
 
 void uvs_destroy(uvs_solver* s) {
     if (!s) return;
-    hipSetDevice(s->device);
-    if (s->d_blobs) hipFree(s->d_blobs);
-    if (s->d_ws) hipFree(s->d_ws);
-    if (s->d_blob_off) hipFree(s->d_blob_off);
-    if (s->d_ws_off) hipFree(s->d_ws_off);
-    if (s->d_reports) hipFree(s->d_reports);
-    if (s->d_dbg) hipFree(s->d_dbg);
+    (void)hipSetDevice(s->device);      // teardown: nothing useful to do with an error
+    if (s->d_blobs) (void)hipFree(s->d_blobs);
+    if (s->d_ws) (void)hipFree(s->d_ws);
+    if (s->d_blob_off) (void)hipFree(s->d_blob_off);
+    if (s->d_ws_off) (void)hipFree(s->d_ws_off);
+    if (s->d_reports) (void)hipFree(s->d_reports);
+    if (s->d_dbg) (void)hipFree(s->d_dbg);
     s->eval_scratch.release();
-    hipEventDestroy(s->ev0); hipEventDestroy(s->ev1);
-    hipStreamDestroy(s->stream);
+    (void)hipEventDestroy(s->ev0); (void)hipEventDestroy(s->ev1);
+    (void)hipStreamDestroy(s->stream);
     delete s;
 }
 
@@ -517,7 +517,7 @@ static int pack_window(const uvs_window* w, const uvs_options& opts, std::vector
 
 static int ensure(uvs_solver* s, void** p, size_t* cap, size_t need) {
     if (*cap >= need) return UVS_OK;
-    if (*p) hipFree(*p);
+    if (*p) (void)hipFree(*p);
     *p = nullptr; *cap = 0;
     HIPCHK(s, hipMalloc(p, need));
     *cap = need;
