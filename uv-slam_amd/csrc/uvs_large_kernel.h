@@ -41,10 +41,12 @@ __global__ __launch_bounds__(NT) void k_large_chunks(char* blob, double* ws, KOp
     // canonical partial [pose block][row a][8] (6 block entries, gradient, diag(J^T J)), staged in LDS so that the two halves of a
     // split block are summed in a fixed order and the HBM write is coalesced
     __syncthreads();
+    gacc_gather_parts(A, grp, sh + L_S);
+    __syncthreads();
     for (int i = tid; i < LG_ACC; i += NT) sh[L_S + i] = 0.0;
     __syncthreads();
-    for (int part = 0; part < h.n_parts; ++part) {
-        if (grp >= 0 && ((grp >> 9) & 15) == part) {
+    {
+        if (grp >= 0 && ((grp >> 9) & 15) == 0) {
             const int r0 = GR * (tid % UVS_GLANES);
             const bool tdrow = ((grp >> 13) & 15) == UVS_NF;       // time-offset blocks: only row 0 is real
 #pragma unroll

@@ -67,7 +67,7 @@ struct DevWin {
     int32_t i_imu;                    // [n_imu][2] : frame_i, skip
     int32_t i_prior;                  // kind[16] frame[16] size[16] idx[16] x0off[16] colmap[96] inverse colmap[176] touched S blocks[66]
     int32_t i_chunks;                 // [n_chunks][6] : type(0 pt,1 ln), lm_begin, lm_end, offset of the chunk's gather lists in i_lists, their length, 0
-    int32_t i_wblk;                   // [UVS_NGRP] gather group -> pose block id | 256 (diagonal block) | part << 9 (4 bits, split blocks) | fa << 13 | fb << 17; -1 = idle
+    int32_t i_wblk;                   // [UVS_NGRP] gather group -> pose block id | 256 (diagonal block) | part << 9 (4 bits, split blocks) | fa << 13 | fb << 17 | (parts - 1) << 21 (the parts of a block are consecutive groups); -1 = idle
     int32_t i_lists;                  // per chunk: schur_off[81] direct_off[81] entries[...]  (group-major, see pack_window in uvs_solver.hip)
     // workspace
     int32_t w_invd0, w_invd1, w_line0, w_line1;       // landmark parameters, two buffers (current / candidate)

@@ -587,6 +587,30 @@ typedef double d2_t __attribute__((ext_vector_type(2)));
 struct GAcc { double v[6 * GR], g[GR], hd[GR]; };     // v[6r + c]: rows r0 + r of the block (r0 = GR * lane-in-group); gradient and diag(J^T J) of those rows
 
 UVS_DEV d2_t lds2(const double* p) { return *(const d2_t*)p; }
+// Sum of a split block's parts into its part-0 group, through LDS scratch at `scr` (25 doubles per lane; must be free: the caller
+// brackets the call with barriers as documented).  Part order => the same fixed summation order as one add round per part, but
+// ONE barrier-separated step instead of up to 16 rounds.  All lanes must call it.
+UVS_DEV void gacc_gather_parts(GAcc& A, int grp, double* scr) {
+    const int tid = threadIdx.x;
+    const int part = grp >= 0 ? (grp >> 9) & 15 : 0, np = grp >= 0 ? ((grp >> 21) & 15) + 1 : 1;
+    if (part > 0) {
+        double* D = scr + 25 * tid;
+#pragma unroll
+        for (int q = 0; q < 6 * GR; ++q) D[q] = A.v[q];
+#pragma unroll
+        for (int q = 0; q < GR; ++q) { D[6 * GR + q] = A.g[q]; D[7 * GR + q] = A.hd[q]; }
+    }
+    __syncthreads();
+    if (part == 0) {
+        for (int p = 1; p < np; ++p) {
+            const double* D = scr + 25 * (tid + p * UVS_GLANES);
+#pragma unroll
+            for (int q = 0; q < 6 * GR; ++q) A.v[q] += D[q];
+#pragma unroll
+            for (int q = 0; q < GR; ++q) { A.g[q] += D[6 * GR + q]; A.hd[q] += D[7 * GR + q]; }
+        }
+    }
+}
 UVS_DEV void gacc_zero(GAcc& A) {
 #pragma unroll
     for (int q = 0; q < 6 * GR; ++q) A.v[q] = 0.0;
@@ -1048,19 +1072,23 @@ UVS_DEV void lin_chunk(const Ctx& c, int ch, const double* x, const double* invd
 }
 
 // ---- linearization, part 3: assemble the damped reduced system in LDS from the gathered pose blocks + IMU + prior
-UVS_DEV void lin_assemble(const Ctx& c, const double* x, bool first, double radius, int grp, const GAcc& A, const ImuN& N, double cost, double gmax_lm) {
+UVS_DEV void lin_assemble(const Ctx& c, const double* x, bool first, double radius, int grp, const GAcc& Ain, const ImuN& N, double cost, double gmax_lm) {
     const DevWin& h = *c.hdr;
     double* sh = c.sh;
     const int tid = threadIdx.x;
     __syncthreads();
     UVS_PROF(c, P_GATHER);
     // ---- assemble the reduced system in LDS
+    // parts of split blocks -> their part-0 group (the staging area is free now; S is zeroed only after the sums are in registers)
+    GAcc A = Ain;
+    gacc_gather_parts(A, grp, sh + L_S);
+    __syncthreads();
     { const d2_t z2 = {0.0, 0.0}; for (int i = tid; i < UVS_S_DOUBLES / 2; i += NT) *(d2_t*)(sh + L_S + 2 * i) = z2; }      // ds_write_b128
     if (tid < UVS_RD) { sh[L_G + tid] = 0.0; sh[L_HD + tid] = 0.0; }
     __syncthreads();
-    // every group adds its rows of its pose block; the parts of a split block go in part order, one barrier apart (fixed sum order)
-    for (int part = 0; part < h.n_parts; ++part) {
-        if (grp >= 0 && ((grp >> 9) & 15) == part) {
+    // the part-0 group of every pose block adds its rows (one writer per block: a single round)
+    {
+        if (grp >= 0 && ((grp >> 9) & 15) == 0) {
             const int r0 = GR * (tid % UVS_GLANES);
             const int fa = (grp >> 13) & 15, fb = (grp >> 17) & 15;
             if (fa == UVS_NF + 1) {  // camera-extrinsic rows (ESTIMATE_EXTRINSIC): dof a of Ex_Pose sits at S index 16 a + 15, anywhere relative to the column

@@ -369,7 +369,7 @@ static int pack_window(const uvs_window* w, const uvs_options& opts, std::vector
             const int g = wave_of_rank[q / GRP_PER_WAVE] * GRP_PER_WAVE + (int)(q % GRP_PER_WAVE);
             const int b = items[q].b;
             const int bfa = b >= UVS_NBLK + UVS_NF + 1 ? UVS_NUM_FRAMES + 1 : b >= UVS_NBLK ? UVS_NUM_FRAMES : (int)((std::sqrt(8.0 * b + 1.0) - 1.0) * 0.5 + 1e-9), bfb = b - bfa * (bfa + 1) / 2;     // b = fa(fa+1)/2 + fb
-            wblk[g] = b | (bfa == bfb ? 256 : 0) | (items[q].part << 9) | (bfa << 13) | (bfb << 17);
+            wblk[g] = b | (bfa == bfb ? 256 : 0) | (items[q].part << 9) | (bfa << 13) | (bfb << 17) | ((items[q].np - 1) << 21);      // parts of a block sit in consecutive groups
             g_blk[g] = b; g_part[g] = items[q].part; g_np[g] = items[q].np;
         }
     }
