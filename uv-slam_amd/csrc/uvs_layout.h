@@ -82,7 +82,7 @@ struct DevWin {
     int32_t ws_doubles;
     int32_t blob_bytes;
     int32_t cur_sel;                  // written by the kernel: which landmark buffer holds the final state
-    int32_t n_parts;                  // largest number of parts any pose block is split into (assembly rounds)
+    int32_t n_parts;                  // largest number of parts any pose block is split into (informational; gacc_gather_parts sums them in one step)
 };
 
 #define UVS_WIMU_STRIDE 936
