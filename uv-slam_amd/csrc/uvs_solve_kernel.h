@@ -587,14 +587,14 @@ typedef double d2_t __attribute__((ext_vector_type(2)));
 struct GAcc { double v[6 * GR], g[GR], hd[GR]; };     // v[6r + c]: rows r0 + r of the block (r0 = GR * lane-in-group); gradient and diag(J^T J) of those rows
 
 UVS_DEV d2_t lds2(const double* p) { return *(const d2_t*)p; }
-// Sum of a split block's parts into its part-0 group, through LDS scratch at `scr` (25 doubles per lane; must be free: the caller
+// Sum of a split block's parts into its part-0 group, through LDS scratch at `scr` (8 GR + 1 doubles per lane; must be free: the caller
 // brackets the call with barriers as documented).  Part order => the same fixed summation order as one add round per part, but
 // ONE barrier-separated step instead of up to 16 rounds.  All lanes must call it.
 UVS_DEV void gacc_gather_parts(GAcc& A, int grp, double* scr) {
     const int tid = threadIdx.x;
     const int part = grp >= 0 ? (grp >> 9) & 15 : 0, np = grp >= 0 ? ((grp >> 21) & 15) + 1 : 1;
     if (part > 0) {
-        double* D = scr + 25 * tid;
+        double* D = scr + (8 * GR + 1) * tid;
 #pragma unroll
         for (int q = 0; q < 6 * GR; ++q) D[q] = A.v[q];
 #pragma unroll
@@ -603,7 +603,7 @@ UVS_DEV void gacc_gather_parts(GAcc& A, int grp, double* scr) {
     __syncthreads();
     if (part == 0) {
         for (int p = 1; p < np; ++p) {
-            const double* D = scr + 25 * (tid + p * UVS_GLANES);
+            const double* D = scr + (8 * GR + 1) * (tid + p * UVS_GLANES);
 #pragma unroll
             for (int q = 0; q < 6 * GR; ++q) A.v[q] += D[q];
 #pragma unroll
