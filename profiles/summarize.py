@@ -27,12 +27,12 @@ for name in ("prof_fetch", "prof_write", "prof_sq", "prof_sq2"):
             out.update(vgpr=r["VGPR_Count"], sgpr=r["SGPR_Count"], lds_block_size=r["LDS_Block_Size"], scratch_size=r["Scratch_Size"], grid=r["Grid_Size"])
     for k, v in agg.items():
         out[k + "_per_launch_mean"] = sum(v) / len(v)
-# rocprofv3 FETCH_SIZE / WRITE_SIZE are KiB: hbm_bytes = (FETCH_SIZE + WRITE_SIZE) * 1024 (MI355X_MICROARCH.md, HBM section).  The guide's x2 correction of
-# FETCH_SIZE is calibrated for 16 B/lane streaming reads only; this kernel issues mostly 8-byte loads, for which the guide has no calibration, so the
-# uncorrected figure is reported together with the x2 upper bound.
+# rocprofv3 FETCH_SIZE / WRITE_SIZE are KiB.  MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE reports half of the bytes of a coalesced
+# 16 B/lane read, other widths and WRITE_SIZE uncalibrated -> calibrated here for this kernel's 8 B/lane accesses with tools/calib_fetch.hip
+# (profiles/fetch_calibration.txt): FETCH_SIZE x2.000, WRITE_SIZE x1.000.
 if "FETCH_SIZE_per_launch_mean" in out:
-    out["hbm_bytes_per_launch"] = (out["FETCH_SIZE_per_launch_mean"] + out["WRITE_SIZE_per_launch_mean"]) * 1024
-    out["hbm_bytes_per_launch_fetch_x2"] = (2 * out["FETCH_SIZE_per_launch_mean"] + out["WRITE_SIZE_per_launch_mean"]) * 1024
+    out["hbm_bytes_per_launch"] = (2 * out["FETCH_SIZE_per_launch_mean"] + out["WRITE_SIZE_per_launch_mean"]) * 1024
+    out["hbm_bytes_per_launch_uncorrected"] = (out["FETCH_SIZE_per_launch_mean"] + out["WRITE_SIZE_per_launch_mean"]) * 1024
 json.dump(out, open(f"{ROOT}/profiles/{tag}_pmc_summary.json", "w"), indent=1)
 if "hbm_bytes_per_launch" in out:
     json.dump({"hbm_bytes_per_launch": out["hbm_bytes_per_launch"], "source": f"profiles/{tag}_pmc_summary.json"}, open(f"{ROOT}/profiles/pmc_traffic.json", "w"))
