@@ -79,6 +79,7 @@ struct DevWin {
     int32_t w_out;                    // final state: frames[184] | inv_depth[n_points] | line_orth[4 n_lines] (k_solve; the large path reads the cur buffers)
     int32_t w_prior_img;              // J0^T J0 scattered into S block layout: n_pblk x 272 doubles (written by setup_window, added per linearization)
     int32_t n_pblk;                   // pose blocks of S the prior touches (ids in i_prior + 352)
+    int32_t n_cimg, i_cimg, w_prior_cimg;   // compact prior image: entries of J0^T J0 that are structurally non-zero in S (17 % of the touched blocks): int32 source index in the dense image [n_cimg] then S offset [n_cimg]; values in the workspace
     int32_t ws_doubles;
     int32_t blob_bytes;
     int32_t cur_sel;                  // written by the kernel: which landmark buffer holds the final state

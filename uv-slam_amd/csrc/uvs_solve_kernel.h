@@ -1194,20 +1194,20 @@ UVS_DEV void lin_assemble(const Ctx& c, const double* x, bool first, double radi
         const int n = h.prior_n;
         const int* cm = c.bi + h.i_prior + 80;
         const double* J0 = c.bd + h.d_prior;
-        {   // H0 image (setup_window): values + precomputed S offsets, 8 independent loads in flight per trip
-            const double* img = c.ws + h.w_prior_img;
-            const int tot = h.n_pblk * UVS_BLK_SZ;
-            const int* off = (const int*)(img + tot);
-            for (int t0 = tid; t0 < tot; t0 += 16 * NT) {      // 32 independent loads in flight per trip (one trip for the 5-frame prior)
+        {   // H0 = J0^T J0 (setup_window): compact image, value + precomputed S offset per structurally non-zero entry
+            const double* cimg = c.ws + h.w_prior_cimg;
+            const int tot = h.n_cimg;
+            const int* off = c.bi + h.i_cimg + tot;
+            for (int t0 = tid; t0 < tot; t0 += 16 * NT) {      // up to 32 independent loads in flight per trip (one trip for the 10-frame prior)
                 int idx[16]; double v[16], cur[16];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) { const int t = t0 + u * NT; const bool in = t < tot; idx[u] = in ? off[t] : -1; v[u] = in ? img[t] : 0.0; }
+                for (int u = 0; u < 16; ++u) { const int t = t0 + u * NT; const bool in = t < tot; idx[u] = in ? off[t] : -1; v[u] = in ? cimg[t] : 0.0; }
 #pragma unroll
                 for (int u = 0; u < 16; ++u) cur[u] = sh[L_S + (idx[u] >= 0 ? idx[u] : 0)];
 #pragma unroll
                 for (int u = 0; u < 16; ++u) if (idx[u] >= 0) sh[L_S + idx[u]] = cur[u] + v[u];
             }
-            if (tid < UVS_RD) sh[L_HD + tid] += img[(tot * 3) / 2 + 2 + tid];      // diag(J0^T J0) by S index (setup_window)
+            if (tid < UVS_RD) sh[L_HD + tid] += c.ws[h.w_prior_img + h.n_pblk * UVS_BLK_SZ + tid];      // diag(J0^T J0) by S index (setup_window)
         }
         {   // g += J0^T r, each column's dot product split over up to 3 lanes; partials in LDS words that are free right now (x_c, rhs, 1/L_kk)
             const int parts = (NT / n) < 3 ? (NT / n) : 3;
@@ -1503,11 +1503,6 @@ UVS_DEV void setup_window(const Ctx& c, double* blob_rw, bool with_prior_image =
         if (tid < UVS_RD) invL[tid] = inv[tid];
         if (tid < h.n_pblk) pbL[tid] = pb[tid];
         __syncthreads();
-        for (int t = tid; t < h.n_pblk * UVS_BLK_SZ; t += NT) {
-            const int sl = t / UVS_BLK_SZ, e = t - sl * UVS_BLK_SZ;
-            if (e % UVS_BLK_LD == 16) img[t] = 0.0;                             // the padding column of the S layout
-            ((int*)(img + h.n_pblk * UVS_BLK_SZ))[t] = (pbL[sl] & 255) * UVS_BLK_SZ + e;     // where the entry goes in S: the per-linearization add needs no index math
-        }
         // the 16x16 tiles are a true contraction over the n rows of J0: tile(fa, fb)[r][c] = sum_i J0[i][col(fa, r)] J0[i][col(fb, c)],
         // 19 x v_mfma_f64_16x16x4_f64 per tile, one tile per wave at a time (A[r][k]: lane r + 16k, B[k][c]: lane c + 16k).
         // Operands go out five steps at a time.
@@ -1531,7 +1526,16 @@ UVS_DEV void setup_window(const Ctx& c, double* blob_rw, bool with_prior_image =
 #pragma unroll
             for (int q = 0; q < 4; ++q) img[sl * UVS_BLK_SZ + (lk + 4 * q) * UVS_BLK_LD + li] = acc[q];
         }
-        double* hdp = img + (h.n_pblk * UVS_BLK_SZ * 3) / 2 + 2;       // diag(J0^T J0) by S index (added to L_HD per linearization)
+        // compact image: the structurally non-zero entries only (host tables: source index in the dense tiles, S offset), what the
+        // per-linearization add reads
+        __threadfence_block();
+        __syncthreads();
+        {
+            const int* csrc = c.bi + h.i_cimg;
+            double* cimg = c.ws + h.w_prior_cimg;
+            for (int j = tid; j < h.n_cimg; j += NT) cimg[j] = img[csrc[j]];
+        }
+        double* hdp = img + h.n_pblk * UVS_BLK_SZ;       // diag(J0^T J0) by S index (added to L_HD per linearization)
         if (tid < UVS_RD) {
             const int a = invL[tid];
             double v = 0.0;

@@ -410,6 +410,39 @@ static int pack_window(const uvs_window* w, const uvs_options& opts, std::vector
     h.d_ptvel = d; d += td_on ? 6 * h.pt_stride : 0;
     h.d_line = d; d += 4 * std::max(h.n_lines, 1);
     h.d_lnmeas = d; d += 9 * h.ln_stride;
+    // S blocks touched by the prior (all pairs of frames that own a kept pose / speed-bias block)
+    std::vector<int> pblk;
+    if (have_prior) {
+        bool in[UVS_NUM_FRAMES] = {false};
+        for (int b = 0; b < w->prior->n_blocks; ++b)
+            if (w->prior->block_kind[b] == UVS_BLOCK_POSE || w->prior->block_kind[b] == UVS_BLOCK_SPEEDBIAS) in[w->prior->block_frame[b]] = true;
+            else if (w->prior->block_kind[b] == UVS_BLOCK_TD && td_on) in[UVS_NUM_FRAMES - 1] = true;       // td lives in the last frame's block row
+            else if (w->prior->block_kind[b] == UVS_BLOCK_EX_POSE && ex_on) for (int q = 0; q < 6; ++q) in[q] = true;      // ex dofs live in frames 0..5
+        for (int fa = 0; fa < UVS_NUM_FRAMES; ++fa) for (int fb = 0; fb <= fa; ++fb) if (in[fa] && in[fb]) pblk.push_back((fa * (fa + 1) / 2 + fb) | (fa << 8) | (fb << 12));      // block | fa << 8 | fb << 12
+    }
+    // compact image: only the entries whose row AND column are prior columns (a pose block owns 6 of the 16 rows of its S block, so 36 of 272
+    // entries of a pose-pose block): what the per-linearization add reads (value + S offset) shrinks from 15 k to ~2.6 k entries
+    std::vector<int> csrc, coff;
+    if (have_prior) {
+        int inv_s[UVS_RD]; for (int q = 0; q < UVS_RD; ++q) inv_s[q] = -1;
+        const uvs_prior& p = *w->prior;
+        for (int b = 0; b < p.n_blocks; ++b) {
+            const int loc = p.block_size[b] == 7 ? 6 : p.block_size[b];
+            int basecol = -1;
+            if (p.block_kind[b] == UVS_BLOCK_POSE) basecol = 16 * p.block_frame[b];
+            else if (p.block_kind[b] == UVS_BLOCK_SPEEDBIAS) basecol = 16 * p.block_frame[b] + 6;
+            else if (p.block_kind[b] == UVS_BLOCK_TD && td_on) basecol = UVS_TD_INDEX;
+            const bool exb = p.block_kind[b] == UVS_BLOCK_EX_POSE && ex_on;
+            for (int q = 0; q < loc; ++q) { const int si = exb ? UVS_EX_INDEX(q) : (basecol < 0 ? -1 : basecol + q); if (si >= 0) inv_s[si] = p.block_idx[b] + q; }
+        }
+        for (size_t sl = 0; sl < pblk.size(); ++sl) {
+            const int b = pblk[sl] & 255, fa = (pblk[sl] >> 8) & 15, fb = (pblk[sl] >> 12) & 15;
+            for (int r = 0; r < 16; ++r) for (int cc = 0; cc < 16; ++cc)
+                if (inv_s[16 * fa + r] >= 0 && inv_s[16 * fb + cc] >= 0 && (fa != fb || cc <= r)) {
+                    csrc.push_back((int)sl * UVS_BLK_SZ + r * UVS_BLK_LD + cc); coff.push_back(b * UVS_BLK_SZ + r * UVS_BLK_LD + cc);
+                }
+        }
+    }
     h.d_imu = d; d += std::max(h.n_imu, 1) * UVS_IMU_STRIDE;
     h.d_prior = d; d += 2 * h.prior_n * h.prior_n + 2 * h.prior_n + 144;
     int i = 2 * d;
@@ -417,6 +450,7 @@ static int pack_window(const uvs_window* w, const uvs_options& opts, std::vector
     h.i_ln_lm = i; i += h.ln_stride; h.i_ln_fj = i; i += h.ln_stride; h.i_ln_vp = i; i += h.ln_stride; h.i_ln_beg = i; i += rup(h.n_lines + 1, 2);
     h.i_imu = i; i += 2 * std::max(h.n_imu, 1);
     h.i_prior = i; i += 80 + UVS_MAX_PRIOR_DIM + UVS_RD + UVS_NBLK;
+    h.i_cimg = i; i += 2 * (int)csrc.size() + 2;
     h.i_chunks = i; i += 6 * std::max(h.n_chunks, 1);
     h.i_wblk = i; i += UVS_NGRP;
     h.i_lists = i; i += (int)lists.size() + 2;
@@ -431,18 +465,10 @@ static int pack_window(const uvs_window* w, const uvs_options& opts, std::vector
     h.w_ln_Y = wsz; wsz += 24 * std::max(h.n_ln_obs, 1); h.w_ln_x = wsz; wsz += 12 * std::max(h.n_lines, 1);
     h.w_imu = wsz; wsz += std::max(h.n_imu, 1) * UVS_WIMU_STRIDE;
     h.w_out = wsz; wsz += 184 + std::max(h.n_points, 0) + 4 * std::max(h.n_lines, 0);
-    // S blocks touched by the prior (all pairs of frames that own a kept pose / speed-bias block)
-    std::vector<int> pblk;
-    if (have_prior) {
-        bool in[UVS_NUM_FRAMES] = {false};
-        for (int b = 0; b < w->prior->n_blocks; ++b)
-            if (w->prior->block_kind[b] == UVS_BLOCK_POSE || w->prior->block_kind[b] == UVS_BLOCK_SPEEDBIAS) in[w->prior->block_frame[b]] = true;
-            else if (w->prior->block_kind[b] == UVS_BLOCK_TD && td_on) in[UVS_NUM_FRAMES - 1] = true;       // td lives in the last frame's block row
-            else if (w->prior->block_kind[b] == UVS_BLOCK_EX_POSE && ex_on) for (int q = 0; q < 6; ++q) in[q] = true;      // ex dofs live in frames 0..5
-        for (int fa = 0; fa < UVS_NUM_FRAMES; ++fa) for (int fb = 0; fb <= fa; ++fb) if (in[fa] && in[fb]) pblk.push_back((fa * (fa + 1) / 2 + fb) | (fa << 8) | (fb << 12));      // block | fa << 8 | fb << 12
-    }
     h.n_pblk = (int)pblk.size();
-    h.w_prior_img = wsz; wsz += std::max(h.n_pblk, 1) * UVS_BLK_SZ * 3 / 2 + 2 + UVS_RD;      // values, their int32 S offsets, diag(J0^T J0) per S index
+    h.w_prior_img = wsz; wsz += std::max(h.n_pblk, 1) * UVS_BLK_SZ + UVS_RD;      // dense tiles (written once per solve), diag(J0^T J0) per S index
+    h.n_cimg = (int)csrc.size();
+    h.w_prior_cimg = wsz; wsz += rup(std::max(h.n_cimg, 1), 2);
     h.ws_doubles = rup(wsz, 32);
     // fill
     const size_t base = out.size();
@@ -507,6 +533,7 @@ static int pack_window(const uvs_window* w, const uvs_options& opts, std::vector
             }
         }
         for (size_t q = 0; q < pblk.size(); ++q) pt[80 + UVS_MAX_PRIOR_DIM + UVS_RD + q] = pblk[q];
+        for (size_t q = 0; q < csrc.size(); ++q) { I[h.i_cimg + q] = csrc[q]; I[h.i_cimg + csrc.size() + q] = coff[q]; }
     }
     for (size_t q = 0; q < chunks.size(); ++q) I[h.i_chunks + q] = chunks[q];
     for (size_t q = 0; q < lists.size(); ++q) I[h.i_lists + q] = lists[q];
