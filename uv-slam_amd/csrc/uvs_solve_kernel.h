@@ -195,13 +195,15 @@ UVS_DEV double prior_residual(const Ctx& c, int dst = L_PR) {
     if (part < parts) {
         const double* J0T = c.bd + h.d_prior + n * n;      // transposed copy: consecutive lanes read consecutive addresses
         const int kb = (n * part) / parts, ke = (n * (part + 1)) / parts;
+        // 24 independent loads in flight per trip: the n = 75 prior (19 rows per lane) is ONE HBM/L2 round trip, not three
         double p8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        int k = kb;
-        for (; k + 8 <= ke; k += 8) {
+        for (int k = kb; k < ke; k += 24) {
+            double jv[24];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) p8[u] += J0T[(k + u) * n + row] * c.sh[L_PDX + k + u];
+            for (int u = 0; u < 24; ++u) jv[u] = J0T[(k + u < ke ? k + u : kb) * n + row];
+#pragma unroll
+            for (int u = 0; u < 24; ++u) if (k + u < ke) p8[u & 7] += jv[u] * c.sh[L_PDX + k + u];
         }
-        for (; k < ke; ++k) p8[0] += J0T[k * n + row] * c.sh[L_PDX + k];
         c.sh[L_S + 128 * part + row] = ((p8[0] + p8[1]) + (p8[2] + p8[3])) + ((p8[4] + p8[5]) + (p8[6] + p8[7]));
     }
     __syncthreads();
@@ -1216,12 +1218,13 @@ UVS_DEV void lin_assemble(const Ctx& c, const double* x, bool first, double radi
             if (part < parts) {
                 const int ib = (n * part) / parts, ie = (n * (part + 1)) / parts;
                 double p8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                int i = ib;
-                for (; i + 8 <= ie; i += 8) {
+                for (int i = ib; i < ie; i += 32) {      // 32 independent loads in flight: one round trip for the 25 rows per lane of the n = 75 prior
+                    double jv[32];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) p8[u] += J0[(i + u) * n + col] * sh[L_PR + i + u];
+                    for (int u = 0; u < 32; ++u) jv[u] = J0[(i + u < ie ? i + u : ib) * n + col];
+#pragma unroll
+                    for (int u = 0; u < 32; ++u) if (i + u < ie) p8[u & 7] += jv[u] * sh[L_PR + i + u];
                 }
-                for (; i < ie; ++i) p8[0] += J0[i * n + col] * sh[L_PR + i];
                 scr[col] = ((p8[0] + p8[1]) + (p8[2] + p8[3])) + ((p8[4] + p8[5]) + (p8[6] + p8[7]));
             }
             __syncthreads();
