@@ -168,8 +168,11 @@ UVS_DEV void prior_dx(const Ctx& c, const double* x) {
     const DevWin& h = *c.hdr;
     if (h.prior_n > 0 && tid < h.prior_nb) {
         const int* pt = c.bi + h.i_prior;
-        const int kind = pt[tid], frame = pt[16 + tid], size = pt[32 + tid], idx = pt[48 + tid], xo = pt[64 + tid];
-        const double* x0 = c.bd + h.d_prior + 2 * h.prior_n * h.prior_n + 2 * h.prior_n + xo;
+        const int kind = pt[tid], frame = pt[16 + tid], size = pt[32 + tid], idx = pt[48 + tid];
+        const double* x0g = c.bd + h.d_prior + 2 * h.prior_n * h.prior_n + 2 * h.prior_n + 9 * tid;      // stride 9 per block (pack_window): independent of the table
+        double x0[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) x0[k] = x0g[k];
         const double* xb = (kind == UVS_BLOCK_POSE) ? x + 7 * frame : (kind == UVS_BLOCK_SPEEDBIAS) ? x + 77 + 9 * frame : (kind == UVS_BLOCK_TD) ? x + 183 : x + 176;
         double* dx = c.sh + L_PDX + idx;
         if (size != 7) { for (int k = 0; k < size; ++k) dx[k] = xb[k] - x0[k]; }

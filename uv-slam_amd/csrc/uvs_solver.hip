@@ -514,7 +514,8 @@ static int pack_window(const uvs_window* w, const uvs_options& opts, std::vector
         const int n = p.n;
         for (int r = 0; r < n; ++r) for (int cc = 0; cc < n; ++cc) { D[h.d_prior + r * n + cc] = p.linearized_jacobians[r * n + cc]; D[h.d_prior + n * n + cc * n + r] = p.linearized_jacobians[r * n + cc]; }
         for (int r = 0; r < n; ++r) D[h.d_prior + 2 * n * n + r] = p.linearized_residuals[r];
-        std::memcpy(D + h.d_prior + 2 * n * n + 2 * n, p.x0, sizeof(double) * 144);
+        // linearization point of block b at stride 9 (not at x0_off[b]): the kernel's loads of it then do not depend on a table load
+        for (int b = 0; b < p.n_blocks && b < 16; ++b) for (int k = 0; k < p.block_size[b] && k < 9; ++k) D[h.d_prior + 2 * n * n + 2 * n + 9 * b + k] = p.x0[p.x0_off[b] + k];
         int* pt = I + h.i_prior;
         for (int q = 0; q < 80 + UVS_MAX_PRIOR_DIM + UVS_RD + UVS_NBLK; ++q) pt[q] = -1;
         for (int b = 0; b < p.n_blocks; ++b) {
