@@ -374,7 +374,7 @@ UVS_DEV void imu_raw(const double* blk, const double* jac, const double* G, cons
     const double dbg[3] = {Bgi[0] - lin_bg[0], Bgi[1] - lin_bg[1], Bgi[2] - lin_bg[2]};
     auto J3 = [&](int r0, int c0, const double* v, double* o) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) o[i] = jac[(r0 + i) * 15 + c0] * v[0] + jac[(r0 + i) * 15 + c0 + 1] * v[1] + jac[(r0 + i) * 15 + c0 + 2] * v[2];
+        for (int i = 0; i < 3; ++i) o[i] = jac[UVS_IMU_JIDX(r0, c0, i, 0)] * v[0] + jac[UVS_IMU_JIDX(r0, c0, i, 1)] * v[1] + jac[UVS_IMU_JIDX(r0, c0, i, 2)] * v[2];
     };
     double th[3]; J3(3, 12, dbg, th);                                             // dq_dbg * dbg
     const double dq[4] = {th[0] / 2.0, th[1] / 2.0, th[2] / 2.0, 1.0};            // Utility::deltaQ
@@ -437,7 +437,7 @@ UVS_DEV void imu_raw(const double* blk, const double* jac, const double* G, cons
 #pragma unroll
       for (int i = 0; i < 3; ++i)
 #pragma unroll
-          for (int j = 0; j < 3; ++j) D[3 * i + j] = jac[(3 + i) * 15 + 12 + j];
+          for (int j = 0; j < 3; ++j) D[3 * i + j] = jac[UVS_IMU_JIDX(3, 12, i, j)];
       mat_mul(La, D, M); put(3, 6 + 6, M, -1.0); }
     putskew(6, 3, rav);
     // speedbias_i  (:119-137)
@@ -446,10 +446,10 @@ UVS_DEV void imu_raw(const double* blk, const double* jac, const double* G, cons
     for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            Jraw[(0 + i) * LD + cm(6 + 3 + j)] = -jac[(0 + i) * 15 + 9 + j];     // -dp_dba
-            Jraw[(0 + i) * LD + cm(6 + 6 + j)] = -jac[(0 + i) * 15 + 12 + j];    // -dp_dbg
-            Jraw[(6 + i) * LD + cm(6 + 3 + j)] = -jac[(6 + i) * 15 + 9 + j];     // -dv_dba
-            Jraw[(6 + i) * LD + cm(6 + 6 + j)] = -jac[(6 + i) * 15 + 12 + j];    // -dv_dbg
+            Jraw[(0 + i) * LD + cm(6 + 3 + j)] = -jac[UVS_IMU_JIDX(0, 9, i, j)];     // -dp_dba
+            Jraw[(0 + i) * LD + cm(6 + 6 + j)] = -jac[UVS_IMU_JIDX(0, 12, i, j)];    // -dp_dbg
+            Jraw[(6 + i) * LD + cm(6 + 3 + j)] = -jac[UVS_IMU_JIDX(6, 9, i, j)];     // -dv_dba
+            Jraw[(6 + i) * LD + cm(6 + 6 + j)] = -jac[UVS_IMU_JIDX(6, 12, i, j)];    // -dv_dbg
         }
     put(6, 6 + 0, RiT, -1.0);
 #pragma unroll

@@ -21,10 +21,12 @@
 #define UVS_BLK_SZ (16 * UVS_BLK_LD)            // 272 doubles
 #define UVS_S_DOUBLES (UVS_NBLK * UVS_BLK_SZ)   // 17952 doubles = 143616 B
 
-#define UVS_IMU_STRIDE 696        // doubles per IMU block: 20 header + jac 225 + cov 225 + W 225 (+1 pad)
-#define UVS_IMU_JAC 20
-#define UVS_IMU_COV 245
-#define UVS_IMU_W 470
+#define UVS_IMU_STRIDE 520        // doubles per IMU block: 20 header + packed jac 48 + cov 225 + W 225 (+2 pad)
+#define UVS_IMU_JAC 20            // the five 3x3 blocks of the pre-integration Jacobian the factor reads (dp_dba, dp_dbg, dq_dbg, dv_dba, dv_dbg), 9 doubles each
+#define UVS_IMU_COV 68
+#define UVS_IMU_W 293
+// packed index of jacobian(R + i, C + j) for (R, C) in {(0,9) (0,12) (3,12) (6,9) (6,12)}  (integration_base.h O_P/O_R/O_V rows, O_BA/O_BG columns)
+#define UVS_IMU_JIDX(R, C, i, j) (9 * ((R) == 0 ? ((C) == 9 ? 0 : 1) : (R) == 3 ? 2 : ((C) == 9 ? 3 : 4)) + 3 * (i) + (j))
 
 #define UVS_PT_REC 30             // LDS record per point observation: r[2] A[12] c|rc[2] B[12] rc[2]  (rc = Schur-corrected residual);
                                   // even stride and even field offsets: every Jacobian row is 16-byte aligned for ds_read_b128

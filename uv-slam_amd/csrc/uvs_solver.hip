@@ -505,7 +505,10 @@ static int pack_window(const uvs_window* w, const uvs_options& opts, std::vector
         blk[0] = ib.sum_dt;
         for (int q = 0; q < 3; ++q) { blk[1 + q] = ib.delta_p[q]; blk[8 + q] = ib.delta_v[q]; blk[11 + q] = ib.linearized_ba[q]; blk[14 + q] = ib.linearized_bg[q]; }
         for (int q = 0; q < 4; ++q) blk[4 + q] = ib.delta_q[q];
-        std::memcpy(blk + UVS_IMU_JAC, ib.jacobian, sizeof(double) * 225);
+        {   // only the five 3x3 blocks the factor reads, packed (UVS_IMU_JIDX)
+            const int RC[5][2] = {{0, 9}, {0, 12}, {3, 12}, {6, 9}, {6, 12}};
+            for (int q = 0; q < 5; ++q) for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) blk[UVS_IMU_JAC + 9 * q + 3 * i + j] = ib.jacobian[(RC[q][0] + i) * 15 + RC[q][1] + j];
+        }
         std::memcpy(blk + UVS_IMU_COV, ib.covariance, sizeof(double) * 225);
         I[h.i_imu + 2 * b] = ib.frame_i; I[h.i_imu + 2 * b + 1] = ib.skip ? 1 : 0;
     }
