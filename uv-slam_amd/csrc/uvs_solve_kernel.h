@@ -1013,25 +1013,27 @@ UVS_DEV void lin_chunk(const Ctx& c, int ch, const double* x, const double* invd
                     gmax_lm = fmax(gmax_lm, fabs(gl[a]));
                 }
                 // Cholesky of the 4x4 and explicit inverse
+                // one reciprocal per pivot (an FP64 division is ~30 instructions; the 4x4 factor + explicit inverse had 26 of them on ONE lane per
+                // line while the other lanes of the workgroup wait)
                 double L[10];
-                L[0] = sqrt(H[0]);
-                L[1] = H[1] / L[0]; L[2] = sqrt(H[2] - L[1] * L[1]);
-                L[3] = H[3] / L[0]; L[4] = (H[4] - L[3] * L[1]) / L[2]; L[5] = sqrt(H[5] - L[3] * L[3] - L[4] * L[4]);
-                L[6] = H[6] / L[0]; L[7] = (H[7] - L[6] * L[1]) / L[2]; L[8] = (H[8] - L[6] * L[3] - L[7] * L[4]) / L[5];
-                L[9] = sqrt(H[9] - L[6] * L[6] - L[7] * L[7] - L[8] * L[8]);
+                L[0] = sqrt(H[0]); const double i0 = 1.0 / L[0];
+                L[1] = H[1] * i0; L[2] = sqrt(H[2] - L[1] * L[1]); const double i1 = 1.0 / L[2];
+                L[3] = H[3] * i0; L[4] = (H[4] - L[3] * L[1]) * i1; L[5] = sqrt(H[5] - L[3] * L[3] - L[4] * L[4]); const double i2 = 1.0 / L[5];
+                L[6] = H[6] * i0; L[7] = (H[7] - L[6] * L[1]) * i1; L[8] = (H[8] - L[6] * L[3] - L[7] * L[4]) * i2;
+                L[9] = sqrt(H[9] - L[6] * L[6] - L[7] * L[7] - L[8] * L[8]); const double i3 = 1.0 / L[9];
                 double* X = Xb + 20 * li;
                 double hg[4] = {0, 0, 0, 0};
 #pragma unroll
                 for (int cidx = 0; cidx < 4; ++cidx) {
                     double e[4] = {0, 0, 0, 0}; e[cidx] = 1.0;
-                    e[0] = e[0] / L[0];
-                    e[1] = (e[1] - L[1] * e[0]) / L[2];
-                    e[2] = (e[2] - L[3] * e[0] - L[4] * e[1]) / L[5];
-                    e[3] = (e[3] - L[6] * e[0] - L[7] * e[1] - L[8] * e[2]) / L[9];
-                    e[3] = e[3] / L[9];
-                    e[2] = (e[2] - L[8] * e[3]) / L[5];
-                    e[1] = (e[1] - L[4] * e[2] - L[7] * e[3]) / L[2];
-                    e[0] = (e[0] - L[1] * e[1] - L[3] * e[2] - L[6] * e[3]) / L[0];
+                    e[0] = e[0] * i0;
+                    e[1] = (e[1] - L[1] * e[0]) * i1;
+                    e[2] = (e[2] - L[3] * e[0] - L[4] * e[1]) * i2;
+                    e[3] = (e[3] - L[6] * e[0] - L[7] * e[1] - L[8] * e[2]) * i3;
+                    e[3] = e[3] * i3;
+                    e[2] = (e[2] - L[8] * e[3]) * i2;
+                    e[1] = (e[1] - L[4] * e[2] - L[7] * e[3]) * i1;
+                    e[0] = (e[0] - L[1] * e[1] - L[3] * e[2] - L[6] * e[3]) * i0;
                     X[0 * 4 + cidx] = e[0]; X[1 * 4 + cidx] = e[1]; X[2 * 4 + cidx] = e[2]; X[3 * 4 + cidx] = e[3];
 #pragma unroll
                     for (int a = 0; a < 4; ++a) hg[a] += e[a] * gl[cidx];
