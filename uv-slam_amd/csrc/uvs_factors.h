@@ -89,7 +89,8 @@ UVS_DEV void quat_mul(const double* a, const double* b, double* o) {   // (x,y,z
 }
 UVS_DEV void quat_inv(const double* q, double* o) {   // Eigen inverse(): conjugate / squaredNorm
     const double n2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
-    o[0] = -q[0] / n2; o[1] = -q[1] / n2; o[2] = -q[2] / n2; o[3] = q[3] / n2;
+    const double in2 = 1.0 / n2;
+    o[0] = -q[0] * in2; o[1] = -q[1] * in2; o[2] = -q[2] * in2; o[3] = q[3] * in2;
 }
 UVS_DEV void quat_rot(const double* q, const double* v, double* o) {   // Eigen _transformVector
     double uv[3]; cross3(q, v, uv);
@@ -102,7 +103,7 @@ UVS_DEV void quat_rot(const double* q, const double* v, double* o) {   // Eigen 
 // Cauchy(a): rho'' < 0 always => the Ceres corrector reduces to scaling r and J by sqrt(rho')
 // (marginalization_factor.cpp:47-67, first branch).  Returns rho(s); *scale = sqrt(rho'(s)).
 UVS_DEV double cauchy(double a, double sq_norm, double* scale) {
-    const double b = a * a, c = 1.0 / b;
+    const double b = a * a, c = (a == 1.0) ? 1.0 : 1.0 / b;      // (the point and VP losses have a = 1: no division)
     const double sum = 1.0 + sq_norm * c;
     const double inv = 1.0 / sum;
     *scale = sqrt(fmax(2.2250738585072014e-308, inv));
@@ -118,7 +119,8 @@ UVS_DEV void point_eval(const double* Pi, const double* Ri, const double* Pj, co
                         double inv_dep, const double* pts_i, const double* pts_j, double sqrt_info,
                         double* r, double* Ji, double* Jj, double* Jl, double* Jex,
                         const double* vel_i = nullptr, const double* vel_j = nullptr, double* Jtd = nullptr) {
-    double pc_i[3] = {pts_i[0] / inv_dep, pts_i[1] / inv_dep, pts_i[2] / inv_dep};      // :44
+    const double dep = 1.0 / inv_dep;      // one reciprocal instead of three divisions (an FP64 division is ~30 instructions; this runs per observation and pass)
+    double pc_i[3] = {pts_i[0] * dep, pts_i[1] * dep, pts_i[2] * dep};      // :44
     double p_imu_i[3]; mat_vec(ric, pc_i, p_imu_i);
     p_imu_i[0] += tic[0]; p_imu_i[1] += tic[1]; p_imu_i[2] += tic[2];                    // :45
     double pw[3]; mat_vec(Ri, p_imu_i, pw);
@@ -164,11 +166,11 @@ UVS_DEV void point_eval(const double* Pi, const double* Ri, const double* Pj, co
     // inverse depth: reduce * (ARi*ric) * pts_i * (-1/lambda^2)   :166
     double T[9]; mat_mul(ARi, ric, T);
     { double v[3]; mat_vec(T, pts_i, v);
-      const double s = -1.0 / (inv_dep * inv_dep);
+      const double s = -(dep * dep);
       Jl[0] = (r00 * v[0] + r02 * v[2]) * s; Jl[1] = (r00 * v[1] + r12 * v[2]) * s; }
     if (Jtd) {   // ProjectionTdFactor, projection_td_factor.cpp:135-140: reduce * tmp_r * (vel_i, 0) * (-1 / inv_dep) + sqrt_info * vel_j.xy (pts_i / pts_j are the shifted ones)
         const double v0 = T[0] * vel_i[0] + T[1] * vel_i[1], v1 = T[3] * vel_i[0] + T[4] * vel_i[1], v2 = T[6] * vel_i[0] + T[7] * vel_i[1];
-        const double s = -1.0 / inv_dep;
+        const double s = -dep;
         Jtd[0] = (r00 * v0 + r02 * v2) * s + sqrt_info * vel_j[0];
         Jtd[1] = (r00 * v1 + r12 * v2) * s + sqrt_info * vel_j[1];
     }
@@ -306,7 +308,7 @@ UVS_DEV void line_residual(const LineGeom& g, const double* sp, const double* ep
     r[0] = line_factor * es * il;                                                     // :56
     r[1] = line_factor * ee * il;                                                     // :57
     if (!WITH_J) return;
-    const double il3 = il / l2;
+    const double il3 = il * il * il;      // 1 / l^3 without a second division
     double gs[3] = {line_factor * (sp[0] * il - es * g.n_c[0] * il3), line_factor * (sp[1] * il - es * g.n_c[1] * il3), line_factor * sp[2] * il};
     double ge[3] = {line_factor * (ep[0] * il - ee * g.n_c[0] * il3), line_factor * (ep[1] * il - ee * g.n_c[1] * il3), line_factor * ep[2] * il};
 #pragma unroll
@@ -328,7 +330,8 @@ UVS_DEV void vp_residual(const LineGeom& g, const double* vp, double vp_factor, 
     const double dn2 = dot3(g.d_c, g.d_c), vn2 = dot3(vp, vp);
     const double dn = sqrt(dn2), vn = sqrt(vn2);
     const double dv = dot3(g.d_c, vp);
-    const double c0 = dv / (dn * vn);
+    const double i1 = 1.0 / (dn * vn);      // the one division of this factor
+    const double c0 = dv * i1;
     const double c = fabs(c0);                                                        // :61
     const double s2 = 1.0 - c * c;
     if (!(s2 > kVpSin2Guard)) {      // documented deviation D8 (reference yields inf/NaN here)
@@ -344,7 +347,7 @@ UVS_DEV void vp_residual(const LineGeom& g, const double* vp, double vp_factor, 
     r[0] = vp_factor * acos(c);
     if (!WITH_J) return;
     const double k = vp_factor * (-1.0 / sqrt(s2)) * (c0 < 0.0 ? -1.0 : 1.0);
-    const double i1 = 1.0 / (dn * vn), i2 = dv / (dn2 * dn * vn);
+    const double i2 = c0 / dn2;      // dv / (|d|^3 |v|)
     const double gd[3] = {k * (vp[0] * i1 - g.d_c[0] * i2), k * (vp[1] * i1 - g.d_c[1] * i2), k * (vp[2] * i1 - g.d_c[2] * i2)};
 #pragma unroll
     for (int cidx = 0; cidx < 3; ++cidx) {
@@ -471,7 +474,8 @@ UVS_DEV void pose_plus(const double* x, const double* d, double* o) {   // pose_
     const double dq[4] = {d[3] / 2.0, d[4] / 2.0, d[5] / 2.0, 1.0};
     double qn[4]; quat_mul(x + 3, dq, qn);
     const double n = sqrt(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
-    o[3] = qn[0] / n; o[4] = qn[1] / n; o[5] = qn[2] / n; o[6] = qn[3] / n;
+    const double in = 1.0 / n;
+    o[3] = qn[0] * in; o[4] = qn[1] * in; o[5] = qn[2] * in; o[6] = qn[3] * in;
 }
 
 }  // namespace uvsdev
