@@ -105,8 +105,7 @@ UVS_DEV void quat_rot(const double* q, const double* v, double* o) {   // Eigen 
 UVS_DEV double cauchy(double a, double sq_norm, double* scale) {
     const double b = a * a, c = (a == 1.0) ? 1.0 : 1.0 / b;      // (the point and VP losses have a = 1: no division)
     const double sum = 1.0 + sq_norm * c;
-    const double inv = 1.0 / sum;
-    *scale = sqrt(fmax(2.2250738585072014e-308, inv));
+    *scale = rsqrt(fmin(sum, 1.7976931348623157e308));      // sqrt(rho') = sqrt(1 / sum): one reciprocal square root instead of a division and a square root
     return b * log(sum);
 }
 
