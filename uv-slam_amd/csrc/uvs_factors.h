@@ -302,7 +302,7 @@ UVS_DEV void line_geom(const double* t, const double* q, const double* R, const 
 template <bool WITH_J>
 UVS_DEV void line_residual(const LineGeom& g, const double* sp, const double* ep, double line_factor, double* r, double* Jp, double* Jl) {
     const double l2 = g.n_c[0] * g.n_c[0] + g.n_c[1] * g.n_c[1];
-    const double l = sqrt(l2), il = 1.0 / l;
+    const double il = rsqrt(l2);      // 1 / sqrt(n_x^2 + n_y^2)
     const double es = dot3(sp, g.n_c), ee = dot3(ep, g.n_c);
     r[0] = line_factor * es * il;                                                     // :56
     r[1] = line_factor * ee * il;                                                     // :57
@@ -327,9 +327,8 @@ UVS_DEV void line_residual(const LineGeom& g, const double* sp, const double* ep
 template <bool WITH_J>
 UVS_DEV void vp_residual(const LineGeom& g, const double* vp, double vp_factor, double* r, double* Jp, double* Jl) {
     const double dn2 = dot3(g.d_c, g.d_c), vn2 = dot3(vp, vp);
-    const double dn = sqrt(dn2), vn = sqrt(vn2);
     const double dv = dot3(g.d_c, vp);
-    const double i1 = 1.0 / (dn * vn);      // the one division of this factor
+    const double i1 = rsqrt(dn2 * vn2);      // 1 / (|d| |v|)
     const double c0 = dv * i1;
     const double c = fabs(c0);                                                        // :61
     const double s2 = 1.0 - c * c;
@@ -345,7 +344,7 @@ UVS_DEV void vp_residual(const LineGeom& g, const double* vp, double vp_factor, 
     }
     r[0] = vp_factor * acos(c);
     if (!WITH_J) return;
-    const double k = vp_factor * (-1.0 / sqrt(s2)) * (c0 < 0.0 ? -1.0 : 1.0);
+    const double k = vp_factor * (-rsqrt(s2)) * (c0 < 0.0 ? -1.0 : 1.0);
     const double i2 = c0 / dn2;      // dv / (|d|^3 |v|)
     const double gd[3] = {k * (vp[0] * i1 - g.d_c[0] * i2), k * (vp[1] * i1 - g.d_c[1] * i2), k * (vp[2] * i1 - g.d_c[2] * i2)};
 #pragma unroll
@@ -472,8 +471,7 @@ UVS_DEV void pose_plus(const double* x, const double* d, double* o) {   // pose_
     o[0] = x[0] + d[0]; o[1] = x[1] + d[1]; o[2] = x[2] + d[2];
     const double dq[4] = {d[3] / 2.0, d[4] / 2.0, d[5] / 2.0, 1.0};
     double qn[4]; quat_mul(x + 3, dq, qn);
-    const double n = sqrt(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
-    const double in = 1.0 / n;
+    const double in = rsqrt(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
     o[3] = qn[0] * in; o[4] = qn[1] * in; o[5] = qn[2] * in; o[6] = qn[3] * in;
 }
 
