@@ -112,16 +112,18 @@ UVS_DEV void block_reduce(double* sh, double* s /*[4]*/, double* mx) {
     for (int k = 0; k < 4; ++k) { const double t = wave_sum(s[k]); if (lane == 0) sh[L_RED + wv * 5 + k] = t; }
     { const double t = wave_max(*mx); if (lane == 0) sh[L_RED + wv * 5 + 4] = t; }
     __syncthreads();
-    if (tid == 0) {
-        double a[4] = {0, 0, 0, 0}, m = 0.0;
-        for (int w = 0; w < NW; ++w) { for (int k = 0; k < 4; ++k) a[k] += sh[L_RED + w * 5 + k]; m = fmax(m, sh[L_RED + w * 5 + 4]); }
-        for (int k = 0; k < 4; ++k) sh[L_RED + 48 + k] = a[k];
-        sh[L_RED + 52] = m;
-    }
-    __syncthreads();
+    // every lane adds the NW wave partials itself (broadcast LDS reads, wave order => the same sum everywhere): no single-lane stage and
+    // no third barrier; the entry barrier of the next call keeps these reads ahead of its writes
+    double a[4] = {0, 0, 0, 0}, m = 0.0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) s[k] = sh[L_RED + 48 + k];
-    *mx = sh[L_RED + 52];
+    for (int w = 0; w < NW; ++w) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a[k] += sh[L_RED + w * 5 + k];
+        m = fmax(m, sh[L_RED + w * 5 + 4]);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s[k] = a[k];
+    *mx = m;
 }
 
 struct Ctx {
