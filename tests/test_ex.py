@@ -87,3 +87,29 @@ def test_extrinsic_large_window_path(gpu_api, oracle):
     assert rg.status == 0 and rg.num_iterations == ro.num_iterations
     assert list(rg.accepted[: rg.num_iterations + 1]) == list(ro.accepted[: ro.num_iterations + 1])
     assert pose_deltas(sg.pose, so.pose)[0] < 1e-4 and np.abs(sg.ex_pose - so.ex_pose).max() < 1e-5
+
+
+@pytest.mark.parametrize("which", [1, 14])
+def test_td_and_extrinsic_full_chunks(gpu_api, oracle, which):
+    """Regression (found by tests/gpu_soak_options.py): with BOTH options on every observation has ten direct gather entries (3 + 3 td
+    + 3 ex + the (ex, td) one), the host's chunk-capacity estimate counted nine, and on windows whose chunks were nearly full the lists
+    ran past the LDS staging area into the LM state (initial cost inf, UVS_ERR_NUMERIC).  The layout is now also checked after the
+    lists are built."""
+    rng = np.random.default_rng(23000)
+    for i in range(which + 1):
+        npt, nln = int(rng.integers(20, 300)), int(rng.integers(0, 80))
+        ntag, ptt, lnt = int(rng.integers(0, nln + 1)), int(rng.integers(3, 10)), int(rng.integers(5, 10))
+        ex_noise = 0.01 * rng.standard_normal(3); q_noise = 0.005 * rng.standard_normal(4); td_true = float(rng.uniform(-0.01, 0.01))
+    w = synth.make_window(23000 + which, n_points=npt, n_lines=nln, n_tagged=ntag, pt_track=ptt, ln_track=lnt).copy()
+    w.ex_pose = w.ex_pose.copy(); w.ex_pose[:3] += ex_noise
+    q = w.ex_pose[3:] + q_noise; w.ex_pose[3:] = q / np.linalg.norm(q)
+    w = synth.add_time_offset(w, td_true=td_true, seed=which)
+    o = _opts(td=True)
+    s = gpu_api.Solver(opts=o, max_batch=2, max_points=320, max_point_obs=3600, max_lines=100, max_line_obs=1100)
+    sg, rg = s.solve(w)
+    s.close()
+    so, ro = oracle.solve(w, opts=o)
+    assert rg.status == 0 and np.isfinite(rg.initial_cost) and rg.num_iterations == ro.num_iterations
+    assert list(rg.accepted[: rg.num_iterations + 1]) == list(ro.accepted[: ro.num_iterations + 1])
+    dp, da = pose_deltas(sg.pose, so.pose)
+    assert dp < 1e-6 and da < 1e-6 and abs(sg.td - so.td) < 1e-8

@@ -218,7 +218,9 @@ static int pack_window(const uvs_window* w, const uvs_options& opts, std::vector
         // LDS doubles a chunk of landmarks [k0, k1) needs (records + Schur factors + gather lists), -1 if an index field overflows
         auto need_pt = [&](int k0, int k1) -> long {
             long nob = pbeg[k1] - pbeg[k0], nlm = k1 - k0, nli = list_hdr;
-            for (int k = k0; k < k1; ++k) { const long no = pbeg[k + 1] - pbeg[k]; nli += no ? (no + XS) * (no + XS + 1) / 2 + 3 * no * XS : 0; }
+            // Schur entries: all slot pairs of the landmark; direct entries per observation: 3, + 3 with td, + 3 with ex (+ 1 more with both: (ex, td))
+            const long dper = 3 + (td_on ? 3 : 0) + (ex_on ? 3 + (td_on ? 1 : 0) : 0);
+            for (int k = k0; k < k1; ++k) { const long no = pbeg[k + 1] - pbeg[k]; nli += no ? (no + XS) * (no + XS + 1) / 2 + dper * no : 0; }
             if (nlm > 1023 || nob + XS * nlm > 16383) return -1;
             return (long)PREC * nob + 12 * (nob + XS * nlm) + (nli + 1) / 2;
         };
@@ -392,6 +394,15 @@ static int pack_window(const uvs_window* w, const uvs_options& opts, std::vector
         }
         lists.insert(lists.end(), ent.begin(), ent.end());
         chunks[6 * qc + 4] = (int)(lists.size() - base);
+        {   // the chunk as the kernel lays it out must fit the staging area: records + Schur factors + the lists just built (an estimate that
+            // is too small would let the lists run over the LM state that follows S in LDS)
+            const int type = chunks[6 * qc], k0 = chunks[6 * qc + 1], k1 = chunks[6 * qc + 2];
+            const long nlist = (long)(lists.size() - base);
+            long used;
+            if (type == 0) { const long nob = pbeg[k1] - pbeg[k0], nlm = k1 - k0; used = (long)PREC * nob + 12 * (nob + XS * nlm) + (nlist + 1) / 2; }
+            else { const long nob = lbeg[k1] - lbeg[k0], nlm = k1 - k0; used = (long)(UVS_LN_REC + 48) * nob + 20 * nlm + (nlist + 1) / 2; }
+            if (used > UVS_S_DOUBLES) { err = "internal: chunk layout exceeds the LDS staging area"; return UVS_ERR_CAPACITY; }
+        }
         if (getenv("UVS_DEBUG_LISTS")) {
             fprintf(stderr, "chunk %d type %d lm [%d,%d):\n", qc, chunks[6 * qc], chunks[6 * qc + 1], chunks[6 * qc + 2]);
             for (int wv = 0; wv < NW; ++wv) {
