@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define UVS_ABI_VERSION 2
+#define UVS_ABI_VERSION 3
 
 #define UVS_WINDOW_SIZE 10                    /* parameters.h:12 WINDOW_SIZE  */
 #define UVS_NUM_FRAMES (UVS_WINDOW_SIZE + 1)  /* frames 0..WINDOW_SIZE        */
@@ -44,7 +44,8 @@ extern "C" {
 enum {
     UVS_OK = 0,
     UVS_ERR_INVALID_ARG = 1,    /* null pointer / index out of range / bad count */
-    UVS_ERR_UNSUPPORTED = 2,    /* relocalization blocks (estimator.cpp:944-978): not on this path yet */
+    UVS_ERR_UNSUPPORTED = 2,    /* a combination this path does not take: relocalization blocks together with estimate_extrinsic /
+                                 * estimate_td, or on the large-window path */
     UVS_ERR_NO_DEVICE = 3,      /* no HIP device / extension cannot run (never falls back to CPU) */
     UVS_ERR_HIP = 4,            /* a HIP runtime call failed; see uvs_last_error() */
     UVS_ERR_CAPACITY = 5,       /* window larger than the handle was created for */
@@ -185,6 +186,18 @@ typedef struct uvs_window {
     const double *pt_vel_j;            /* [n_point_obs][2] */
     const double *pt_td_i;             /* [n_point_obs]    */
     const double *pt_td_j;             /* [n_point_obs]    */
+
+    /* Relocalization residual blocks (estimator.cpp:944-978), n_relo_obs == 0 when relocalization_info == 0.  One entry per matched
+     * feature: ProjectionFactor(pts_i, pts_j) on the blocks Pose[start_frame], relo_Pose, Ex_Pose, Feature[lm] with pts_i = the
+     * feature's FIRST observation (feature_per_frame[0].point) and pts_j = (match_point.x, match_point.y, 1).  relo_Pose is a free
+     * 7-dof block with PoseLocalParameterization (estimator.cpp:947-948); it starts at para_Pose[relo_frame_local_index]
+     * (Estimator::setReloFrame, estimator.cpp:1361-1379).  relo_lm must be strictly increasing and every such landmark needs at least
+     * one ordinary observation (its anchor frame imu_i is taken from there).  Only with estimate_extrinsic == 0 and estimate_td == 0. */
+    int32_t n_relo_obs;
+    double relo_pose[UVS_SIZE_POSE];
+    const int32_t *relo_lm;            /* [n_relo_obs] feature_index */
+    const double *relo_pi;             /* [n_relo_obs][3] pts_i      */
+    const double *relo_pj;             /* [n_relo_obs][3] pts_j      */
 } uvs_window;
 
 /* Solver output == the para_* arrays after ceres::Solve and BEFORE
@@ -197,6 +210,7 @@ typedef struct uvs_state {
     double td;
     double *inv_depth;                 /* [n_points]   */
     double *line_orth;                 /* [n_lines][4] */
+    double relo_pose[UVS_SIZE_POSE];   /* relo_Pose after the solve (estimator.cpp:671-685 reads it); the input value when n_relo_obs == 0 */
 } uvs_state;
 
 /* Replaces ceres::Solver::Summary (discarded by the reference) with the trace

@@ -38,6 +38,7 @@ struct State {
     double sb[UVS_NUM_FRAMES][9];
     double ex[7];
     double td;
+    double relo[7];            // relo_Pose (estimator.cpp:947-948), only a parameter block when the window carries relocalization blocks
     std::vector<double> invd, line;
 };
 
@@ -45,12 +46,13 @@ struct Problem {
     const uvs_options* opt;
     const uvs_window* w;
     int F, Np, Nl, P;
-    bool ex_free, td_free;
+    bool ex_free, td_free, relo_on;
     std::vector<double> W;    // n_imu x 225 sqrt_info
     int off_pose(int f) const { return 15 * f; }
     int off_sb(int f) const { return 15 * f + 6; }
     int off_ex() const { return 15 * UVS_NUM_FRAMES; }
     int off_td() const { return 15 * UVS_NUM_FRAMES + (ex_free ? 6 : 0); }      // para_Td, 1 dof (estimator.cpp:790-797)
+    int off_relo() const { return 15 * UVS_NUM_FRAMES + (ex_free ? 6 : 0) + (td_free ? 1 : 0); }      // relo_Pose, 6 local dofs
     int off_pt(int k) const { return F + k; }
     int off_ln(int l) const { return F + Np + 4 * l; }
 };
@@ -59,7 +61,8 @@ static void init_problem(Problem& pb, const uvs_options* opt, const uvs_window* 
     pb.opt = opt; pb.w = w;
     pb.ex_free = opt->estimate_extrinsic != 0;
     pb.td_free = opt->estimate_td != 0;
-    pb.F = 15 * UVS_NUM_FRAMES + (pb.ex_free ? 6 : 0) + (pb.td_free ? 1 : 0);
+    pb.relo_on = w->n_relo_obs > 0;
+    pb.F = 15 * UVS_NUM_FRAMES + (pb.ex_free ? 6 : 0) + (pb.td_free ? 1 : 0) + (pb.relo_on ? 6 : 0);
     pb.Np = w->n_points; pb.Nl = w->n_lines;
     pb.P = pb.F + pb.Np + 4 * pb.Nl;
     pb.W.assign((size_t)std::max(w->n_imu, 0) * 225, 0.0);
@@ -71,6 +74,7 @@ static void init_state(State& x, const uvs_window* w) {
     std::memcpy(x.sb, w->speedbias, sizeof(x.sb));
     std::memcpy(x.ex, w->ex_pose, sizeof(x.ex));
     x.td = w->td;
+    std::memcpy(x.relo, w->relo_pose, sizeof(x.relo));
     x.invd.assign(w->inv_depth, w->inv_depth + w->n_points);
     x.line.assign(w->line_orth, w->line_orth + 4 * (size_t)w->n_lines);
 }
@@ -131,6 +135,7 @@ static double evaluate(const Problem& pb, const State& x, bool robust, std::vect
         }
     }
     // ---- points (estimator.cpp:823-866), CauchyLoss(1.0)
+    int relo_next = 0;
     for (int k = 0; k < w->n_point_obs; ++k) {
         const int lm = w->pt_lm[k], fi = w->pt_fi[k], fj = w->pt_fj[k];
         double r[2], J[40];
@@ -159,6 +164,33 @@ static double evaluate(const Problem& pb, const State& x, bool robust, std::vect
             B.J.resize(2 * nc);
             for (int i = 0; i < 2; ++i) for (int c = 0; c < nc; ++c) B.J[i * nc + c] = J[i * ld + src[c]];
             blocks->push_back(std::move(B));
+        }
+        // ---- relocalization block of this landmark (estimator.cpp:944-975): the plain ProjectionFactor between the landmark's start
+        // frame and relo_Pose, CauchyLoss(1.0).  The reference appends these after the line blocks; here each one follows its landmark's
+        // last ordinary observation so that the Schur elimination below sees a landmark's blocks together (only the summation order
+        // of the cost differs).
+        if (pb.relo_on && (k + 1 == w->n_point_obs || w->pt_lm[k + 1] != lm)) {
+            while (relo_next < w->n_relo_obs && w->relo_lm[relo_next] < lm) ++relo_next;
+            if (relo_next < w->n_relo_obs && w->relo_lm[relo_next] == lm) {
+                const int q = relo_next++;
+                double rr[2], Jr[40];
+                point_eval(x.pose[fi], x.relo, x.ex, x.invd[lm], w->relo_pi + 3 * q, w->relo_pj + 3 * q, o->point_sqrt_info, rr, blocks ? Jr : nullptr);
+                if (robust) cost += 0.5 * cauchy_correct(o->loss_point, 2, 19, rr, blocks ? Jr : nullptr);
+                else cost += 0.5 * (rr[0] * rr[0] + rr[1] * rr[1]);
+                if (blocks) {
+                    Block B; B.rows = 2; B.r.assign(rr, rr + 2);
+                    std::vector<int> src;
+                    for (int c = 0; c < 6; ++c) { B.col.push_back(pb.off_pose(fi) + c); src.push_back(c); }
+                    for (int c = 0; c < 6; ++c) { B.col.push_back(pb.off_relo() + c); src.push_back(6 + c); }
+                    if (pb.ex_free) for (int c = 0; c < 6; ++c) { B.col.push_back(pb.off_ex() + c); src.push_back(12 + c); }
+                    B.lm_off = pb.off_pt(lm); B.lm_dim = 1;
+                    B.col.push_back(B.lm_off); src.push_back(18);
+                    const int nc = (int)B.col.size();
+                    B.J.resize(2 * nc);
+                    for (int i = 0; i < 2; ++i) for (int c = 0; c < nc; ++c) B.J[i * nc + c] = Jr[i * 19 + src[c]];
+                    blocks->push_back(std::move(B));
+                }
+            }
         }
     }
     // ---- lines + VP (estimator.cpp:868-927), CauchyLoss(0.1) / CauchyLoss(1.0)
@@ -207,6 +239,7 @@ static void plus(const Problem& pb, const State& x, const double* d, State& out)
     }
     if (pb.ex_free) pose_plus(x.ex, d + pb.off_ex(), out.ex);
     if (pb.td_free) out.td = x.td + d[pb.off_td()];
+    if (pb.relo_on) pose_plus(x.relo, d + pb.off_relo(), out.relo);
     for (int k = 0; k < pb.Np; ++k) out.invd[k] = x.invd[k] + d[pb.off_pt(k)];
     for (int k = 0; k < 4 * pb.Nl; ++k) out.line[k] = x.line[k] + d[pb.F + pb.Np + k];
 }
@@ -218,6 +251,7 @@ static double ambient_sqnorm(const Problem& pb, const State& x, const State* y) 
     for (int f = 0; f < UVS_NUM_FRAMES; ++f) { acc(x.pose[f], y ? y->pose[f] : nullptr, 7); acc(x.sb[f], y ? y->sb[f] : nullptr, 9); }
     if (pb.ex_free) acc(x.ex, y ? y->ex : nullptr, 7);
     if (pb.td_free) acc(&x.td, y ? &y->td : nullptr, 1);
+    if (pb.relo_on) acc(x.relo, y ? y->relo : nullptr, 7);
     acc(x.invd.data(), y ? y->invd.data() : nullptr, pb.Np);
     acc(x.line.data(), y ? y->line.data() : nullptr, 4 * pb.Nl);
     return s;
@@ -228,6 +262,7 @@ static double ambient_maxdiff(const Problem& pb, const State& x, const State& y)
     for (int f = 0; f < UVS_NUM_FRAMES; ++f) { acc(x.pose[f], y.pose[f], 7); acc(x.sb[f], y.sb[f], 9); }
     if (pb.ex_free) acc(x.ex, y.ex, 7);
     if (pb.td_free) acc(&x.td, &y.td, 1);
+    if (pb.relo_on) acc(x.relo, y.relo, 7);
     acc(x.invd.data(), y.invd.data(), pb.Np);
     acc(x.line.data(), y.line.data(), 4 * pb.Nl);
     return m;
@@ -372,6 +407,7 @@ static void copy_state_out(const Problem& pb, const State& x, uvs_state* out) {
     std::memcpy(out->speedbias, x.sb, sizeof(x.sb));
     std::memcpy(out->ex_pose, x.ex, sizeof(x.ex));
     out->td = x.td;
+    std::memcpy(out->relo_pose, x.relo, sizeof(x.relo));
     if (out->inv_depth) std::memcpy(out->inv_depth, x.invd.data(), sizeof(double) * pb.Np);
     if (out->line_orth) std::memcpy(out->line_orth, x.line.data(), sizeof(double) * 4 * pb.Nl);
 }
@@ -633,6 +669,7 @@ int oracle_solve(const uvs_options* opt, const uvs_window* w, int linear_mode, u
 int oracle_evaluate(const uvs_options* opt, const uvs_window* w, int robust, uvs_eval* out) {
     if (!opt || !w || !out) return UVS_ERR_INVALID_ARG;
     orc::Problem pb; orc::init_problem(pb, opt, w);
+    pb.relo_on = false;      // like uvs_evaluate / the marginalization (estimator.cpp:1002-1228): relocalization blocks are solve-only
     orc::State x; orc::init_state(x, w);
     out->cost = orc::evaluate(pb, x, robust != 0, nullptr, out);
     return UVS_OK;

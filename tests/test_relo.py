@@ -1,0 +1,149 @@
+"""Relocalization residual blocks (estimator.cpp:944-978): ProjectionFactor(pts_i, pts_j) between a landmark's start frame and the free
+7-dof block relo_Pose, one per matched feature, CauchyLoss(1.0).  On the HIP path relo_Pose is pseudo frame 12: an ordinary second frame
+of a point observation whose six dofs sit in the spare 16th slots of frames 0..5 of the padded reduced system (only with a fixed
+extrinsic and no td); the oracle appends a 6-dof block after the frames.  Both are exact solves of the same system."""
+import numpy as np
+import pytest
+
+from helpers import uvs, abi, synth, pose_deltas, quat_angle
+
+
+def _rel(pa, pb):
+    Ra = synth.quat_to_R(pa[3:]); Rb = synth.quat_to_R(pb[3:])
+    return Ra.T @ (pb[:3] - pa[:3]), Ra.T @ Rb
+
+
+def _relo_window(index, **kw):
+    relo = {k: kw.pop(k) for k in ("relo_frame", "fraction", "offset", "pixel_sigma") if k in kw}
+    return synth.add_relocalization(synth.make_window(index, **kw), seed=index, **relo)
+
+
+# ---------------------------------------------------------------- oracle (CPU)
+def test_oracle_known_answer(oracle):
+    """Noise-free points + IMU + relocalization blocks: relo_Pose returns to the pose that generated the match points (relative to the
+    window, the gauge is free)."""
+    w = _relo_window(2, n_lines=0, n_tagged=0, noise=False, perturb=True, relo_frame=5)
+    assert len(w.relo_lm) > 20
+    o = abi.default_options(); o.max_num_iterations = 40
+    st, rep = oracle.solve(w, o)
+    assert rep.final_cost < 1e-12 * rep.initial_cost and rep.final_cost < 1e-10
+    t = w.truth
+    pe, Re = _rel(st.pose[5], st.relo_pose); pt, Rt = _rel(t["pose"][5], t["relo_pose"])
+    assert np.abs(pe - pt).max() < 1e-7 and np.abs(Re - Rt).max() < 1e-8
+    assert np.abs(st.relo_pose - w.relo_pose).max() > 0.05       # it did move (0.25 m / 4 deg away from Pose[5])
+
+
+def test_oracle_schur_equals_dense_with_relo(oracle):
+    w = _relo_window(3)
+    s0, r0 = oracle.solve(w, linear_mode=0)
+    s1, r1 = oracle.solve(w, linear_mode=1)
+    assert r0.num_iterations == r1.num_iterations
+    assert np.abs(s0.relo_pose - s1.relo_pose).max() < 1e-9 and pose_deltas(s0.pose, s1.pose)[0] < 1e-9
+    assert abs(r0.final_cost - r1.final_cost) <= 1e-9 * r1.final_cost
+
+
+def test_oracle_without_blocks_leaves_relo_pose(oracle):
+    w = synth.make_window(4); w.relo_pose = np.array([1.0, 2.0, 3.0, 0.0, 0.0, 0.0, 1.0])
+    st, rep = oracle.solve(w)
+    assert np.array_equal(st.relo_pose, w.relo_pose)
+
+
+def test_window_file_round_trip(tmp_path):
+    w = _relo_window(5)
+    p = str(tmp_path / "w.bin"); w.save(p)
+    v = abi.Window.load(p)
+    assert np.array_equal(v.relo_lm, w.relo_lm) and np.array_equal(v.relo_pi, w.relo_pi) and np.array_equal(v.relo_pj, w.relo_pj)
+    assert np.array_equal(v.relo_pose, w.relo_pose) and np.array_equal(v.pt_pj, w.pt_pj)
+
+
+# ---------------------------------------------------------------- HIP vs oracle
+@pytest.mark.gpu
+@pytest.mark.parametrize("index,kw", [(110, {}), (111, dict(relo_frame=8, fraction=1.0)), (112, dict(relo_frame=0, pixel_sigma=0.5)),
+                                      (113, dict(with_prior=False, n_points=60, n_lines=10, n_tagged=5))])
+def test_relo_solve_matches_oracle(gpu_api, oracle, index, kw):
+    w = _relo_window(index, **kw)
+    assert len(w.relo_lm) > 0
+    s = gpu_api.Solver(max_batch=2)
+    sg, rg = s.solve(w)
+    s.close()
+    so, ro = oracle.solve(w)
+    assert rg.status == 0 and rg.num_iterations == ro.num_iterations
+    assert list(rg.accepted[: rg.num_iterations + 1]) == list(ro.accepted[: ro.num_iterations + 1])
+    assert abs(rg.initial_cost - ro.initial_cost) <= 1e-10 * ro.initial_cost
+    dp, da = pose_deltas(sg.pose, so.pose)
+    assert dp < 1e-4 and da < 1e-4, (dp, da)                     # north-star tolerance; observed far below
+    assert np.abs(sg.relo_pose[:3] - so.relo_pose[:3]).max() < 1e-6 and quat_angle(sg.relo_pose[3:], so.relo_pose[3:]) < 1e-6
+    assert not np.array_equal(sg.relo_pose, w.relo_pose)
+    assert np.abs(sg.inv_depth - so.inv_depth).max() < 1e-6
+    assert abs(rg.final_cost - ro.final_cost) <= 1e-6 * ro.final_cost
+
+
+@pytest.mark.gpu
+def test_relo_first_iteration_step(gpu_api, oracle):
+    w = _relo_window(114)
+    o = abi.default_options(); o.max_num_iterations = 1
+    s = gpu_api.Solver(opts=o, max_batch=2)
+    sg, rg = s.solve(w)
+    s.close()
+    so, ro = oracle.solve(w, opts=o)
+    assert abs(rg.model_cost_change[1] - ro.model_cost_change[1]) <= 1e-8 * abs(ro.model_cost_change[1])
+    assert abs(rg.candidate_cost[1] - ro.candidate_cost[1]) <= 1e-8 * abs(ro.candidate_cost[1])
+    assert abs(rg.step_norm[1] - ro.step_norm[1]) <= 1e-8 * ro.step_norm[1]
+    assert abs(rg.gradient_max_norm[0] - ro.gradient_max_norm[0]) <= 1e-9 * ro.gradient_max_norm[0]
+    assert np.abs(sg.relo_pose - so.relo_pose).max() < 1e-9
+
+
+@pytest.mark.gpu
+def test_relo_known_answer_on_gpu(gpu_api):
+    w = _relo_window(2, n_lines=0, n_tagged=0, noise=False, perturb=True, relo_frame=5)
+    o = abi.default_options(); o.max_num_iterations = 40
+    s = gpu_api.Solver(opts=o, max_batch=2)
+    st, rep = s.solve(w)
+    s.close()
+    assert rep.final_cost < 1e-12 * rep.initial_cost
+    t = w.truth
+    pe, Re = _rel(st.pose[5], st.relo_pose); pt, Rt = _rel(t["pose"][5], t["relo_pose"])
+    assert np.abs(pe - pt).max() < 1e-7 and np.abs(Re - Rt).max() < 1e-8
+
+
+@pytest.mark.gpu
+def test_relo_in_a_batch_and_ignored_by_marginalization(gpu_api, oracle):
+    """A batch mixing windows with and without relocalization blocks equals the single solves bit for bit; uvs_evaluate /
+    uvs_marginalize keep the caller's observation numbering and leave the blocks out, as the reference's marginalization does."""
+    ws = [synth.make_window(120), _relo_window(121), _relo_window(122, relo_frame=2), synth.make_window(123)]
+    s = gpu_api.Solver(max_batch=4)
+    s.upload(ws); s.solve_resident()
+    states, reps = s.download()
+    for w, sb, rb in zip(ws, states, reps):
+        s1, r1 = s.solve(w)
+        assert np.array_equal(sb.pose, s1.pose) and np.array_equal(sb.relo_pose, s1.relo_pose) and rb.final_cost == r1.final_cost
+    w = ws[1]
+    plain = w.copy(); plain.relo_lm = np.zeros(0, np.int32); plain.relo_pi = np.zeros((0, 3)); plain.relo_pj = np.zeros((0, 3))
+    ev, ev0 = s.evaluate(w), s.evaluate(plain)
+    assert np.array_equal(ev.pt_r, ev0.pt_r) and np.array_equal(ev.pt_J, ev0.pt_J) and ev.cost == ev0.cost
+    pg, p0 = s.marginalize(w, 0), s.marginalize(plain, 0)
+    assert np.array_equal(pg.J0(), p0.J0()) and np.array_equal(pg.r0(), p0.r0())
+    sg, rg = s.solve(w)
+    pr = s.marginalize(w.with_state(sg), 0, resident=True)        # resident blob = the one the solve uploaded (with the blocks merged in)
+    pn = s.marginalize(w.with_state(sg), 0)
+    assert np.array_equal(pr.J0(), pn.J0())
+    s.close()
+
+
+@pytest.mark.gpu
+def test_relo_rejected_combinations(gpu_api):
+    w = _relo_window(124)
+    for field in ("estimate_extrinsic", "estimate_td"):
+        o = abi.default_options(); setattr(o, field, 1)
+        wq = synth.add_time_offset(w) if field == "estimate_td" else w
+        s = gpu_api.Solver(opts=o, max_batch=2)
+        with pytest.raises(RuntimeError, match="uvs error %d" % abi.UVS_ERR_UNSUPPORTED):
+            s.solve(wq)
+        s.close()
+    s = gpu_api.Solver(max_batch=2)
+    with pytest.raises(RuntimeError, match="uvs error %d" % abi.UVS_ERR_UNSUPPORTED):
+        s.large_solve(w)
+    bad = w.copy(); bad.relo_lm = bad.relo_lm[::-1].copy()
+    with pytest.raises(RuntimeError, match="uvs error %d" % abi.UVS_ERR_INVALID_ARG):
+        s.solve(bad)
+    s.close()

@@ -109,13 +109,14 @@ class WindowC(C.Structure):
         ("n_imu", C.c_int32), ("imu", C.POINTER(ImuBlock)),
         ("prior", C.POINTER(Prior)),
         ("pt_vel_i", c_double_p), ("pt_vel_j", c_double_p), ("pt_td_i", c_double_p), ("pt_td_j", c_double_p),
+        ("n_relo_obs", C.c_int32), ("relo_pose", C.c_double * 7), ("relo_lm", c_int_p), ("relo_pi", c_double_p), ("relo_pj", c_double_p),
     ]
 
 
 class StateC(C.Structure):
     _fields_ = [
         ("pose", (C.c_double * 7) * NUM_FRAMES), ("speedbias", (C.c_double * 9) * NUM_FRAMES), ("ex_pose", C.c_double * 7),
-        ("td", C.c_double), ("inv_depth", c_double_p), ("line_orth", c_double_p),
+        ("td", C.c_double), ("inv_depth", c_double_p), ("line_orth", c_double_p), ("relo_pose", C.c_double * 7),
     ]
 
 
@@ -167,6 +168,9 @@ class Window:
         self.pt_lm = np.zeros(0, np.int32); self.pt_fi = np.zeros(0, np.int32); self.pt_fj = np.zeros(0, np.int32)
         self.pt_pi = np.zeros((0, 3)); self.pt_pj = np.zeros((0, 3))
         self.pt_vel_i = None; self.pt_vel_j = None; self.pt_td_i = None; self.pt_td_j = None      # ProjectionTdFactor inputs (estimate_td), [n_obs,2] / [n_obs]
+        # relocalization blocks (estimator.cpp:944-978): landmark index, pts_i (first observation), pts_j (match point); relo_Pose
+        self.relo_pose = np.zeros(7); self.relo_pose[6] = 1.0
+        self.relo_lm = np.zeros(0, np.int32); self.relo_pi = np.zeros((0, 3)); self.relo_pj = np.zeros((0, 3))
         self.line_orth = np.zeros((0, 4))
         self.ln_lm = np.zeros(0, np.int32); self.ln_fj = np.zeros(0, np.int32)
         self.ln_sp = np.zeros((0, 3)); self.ln_ep = np.zeros((0, 3))
@@ -194,6 +198,9 @@ class Window:
         for name in ("pt_vel_i", "pt_vel_j", "pt_td_i", "pt_td_j"):
             if getattr(self, name) is not None:
                 k[name] = f64(getattr(self, name)); setattr(w, name, _dp(k[name]))
+        k["relo_lm"] = i32(self.relo_lm); k["relo_pi"] = f64(self.relo_pi); k["relo_pj"] = f64(self.relo_pj); relo = f64(self.relo_pose)
+        w.n_relo_obs = len(k["relo_lm"]); w.relo_lm = _ip(k["relo_lm"]); w.relo_pi = _dp(k["relo_pi"]); w.relo_pj = _dp(k["relo_pj"])
+        C.memmove(w.relo_pose, relo.ctypes.data, relo.nbytes)
         w.n_points = len(k["inv_depth"]); w.n_point_obs = len(k["pt_lm"])
         w.n_lines = len(k["line_orth"]); w.n_line_obs = len(k["ln_lm"])
         n_imu = len(self.imu)
@@ -228,7 +235,8 @@ class Window:
         with open(path, "wb") as f:
             f.write(b"UVSWIN01")
             has_td = self.pt_vel_i is not None
-            f.write(i32([len(self.inv_depth), npo, len(self.line_orth), nlo, len(self.imu), pn, pnb, 1 if has_td else 0]))
+            nrl = len(self.relo_lm)
+            f.write(i32([len(self.inv_depth), npo, len(self.line_orth), nlo, len(self.imu), pn, pnb, (1 if has_td else 0) | (2 if nrl else 0)]))
             f.write(f64(self.pose)); f.write(f64(self.speedbias)); f.write(f64(self.ex_pose)); f.write(f64([self.td]))
             f.write(f64(self.inv_depth))
             f.write(i32(self.pt_lm)); f.write(i32(self.pt_fi)); f.write(i32(self.pt_fj))
@@ -249,6 +257,10 @@ class Window:
                 for name in ("block_kind", "block_frame", "block_size", "block_idx", "x0_off"):
                     f.write(i32(list(getattr(p, name))))
                 f.write(f64(list(p.x0))); f.write(f64(p.r0())); f.write(f64(p.J0()))
+            if nrl:         # relocalization section (header word 8, bit 1): count, pad, relo_Pose, landmark indices (+pad), pts_i, pts_j
+                f.write(i32([nrl, 0])); f.write(f64(self.relo_pose)); f.write(i32(self.relo_lm))
+                if nrl % 2: f.write(i32([0]))
+                f.write(f64(self.relo_pi)); f.write(f64(self.relo_pj))
 
     @staticmethod
     def load(path):
@@ -260,7 +272,8 @@ class Window:
         def take(dtype, n):
             a = np.frombuffer(buf, dtype=dtype, count=n, offset=pos[0]).copy(); pos[0] += a.nbytes; return a
 
-        np_, npo, nl, nlo, ni, pn, pnb, has_td = (int(v) for v in take("<i4", 8))
+        np_, npo, nl, nlo, ni, pn, pnb, flags = (int(v) for v in take("<i4", 8))
+        has_td, has_relo = flags & 1, flags & 2
         w = Window()
         w.pose = take("<f8", 77).reshape(NUM_FRAMES, 7); w.speedbias = take("<f8", 99).reshape(NUM_FRAMES, 9); w.ex_pose = take("<f8", 7); w.td = float(take("<f8", 1)[0])
         w.inv_depth = take("<f8", np_)
@@ -286,6 +299,10 @@ class Window:
             for k in range(144): p.x0[k] = x0[k]
             C.memmove(p.linearized_residuals, r0.ctypes.data, r0.nbytes); C.memmove(p.linearized_jacobians, J0.ctypes.data, J0.nbytes)
             w.prior = p
+        if has_relo:
+            nrl = int(take("<i4", 2)[0]); w.relo_pose = take("<f8", 7); w.relo_lm = take("<i4", nrl)
+            if nrl % 2: take("<i4", 1)
+            w.relo_pi = take("<f8", 3 * nrl).reshape(-1, 3); w.relo_pj = take("<f8", 3 * nrl).reshape(-1, 3)
         return w
 
     def copy(self):
@@ -315,6 +332,7 @@ class State:
     def __init__(self, n_points, n_lines):
         self.pose = np.zeros((NUM_FRAMES, 7)); self.speedbias = np.zeros((NUM_FRAMES, 9)); self.ex_pose = np.zeros(7)
         self.td = 0.0
+        self.relo_pose = np.zeros(7)
         self.inv_depth = np.zeros(n_points); self.line_orth = np.zeros((n_lines, 4))
 
     def alloc_c(self):
@@ -328,6 +346,7 @@ class State:
         self.speedbias = np.array(s.speedbias).reshape(NUM_FRAMES, 9)
         self.ex_pose = np.array(s.ex_pose)
         self.td = s.td
+        self.relo_pose = np.array(s.relo_pose)
         return self
 
 

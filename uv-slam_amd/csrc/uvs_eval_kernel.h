@@ -22,7 +22,7 @@ __global__ __launch_bounds__(NT) void k_evaluate(char* blob, double* ws, KOpts o
     Ctx c;
     c.hdr = (const DevWin*)blob; c.bd = (const double*)blob; c.bi = (const int*)blob; c.ws = ws; c.sh = sh; c.o = o;
     const DevWin& h = *c.hdr;
-    if (tid < 184) sh[L_X + tid] = c.bd[h.d_frames + tid];
+    if (tid < UVS_XDIM) sh[L_X + tid] = c.bd[h.d_frames + tid];
     setup_window(c, (double*)blob, false);
     __syncthreads();
     const double* x = sh + L_X;
@@ -35,19 +35,23 @@ __global__ __launch_bounds__(NT) void k_evaluate(char* blob, double* ws, KOpts o
     if (tid < h.prior_n) out.prior_r[tid] = sh[L_PR + tid];
     for (int ob = tid; ob < h.n_pt_obs; ob += NT) {
         const int lm = c.bi[h.i_pt_lm + ob], fi = c.bi[h.i_pt_fi + ob], fj = c.bi[h.i_pt_fj + ob];
+        // relocalization blocks are solve-only (the reference's marginalization does not add them, estimator.cpp:1002-1228); outputs keep the
+        // caller's observation numbering
+        const int eo = h.relo_on ? c.bi[h.i_pt_eidx + ob] : ob;
+        if (eo < 0) continue;
         double pi[3], pj[3], vij[4] = {0.0, 0.0, 0.0, 0.0}, jtd[2] = {0.0, 0.0};
         load_point_obs(c, ob, x[183], pi, pj, vij);
         double r[2], A[12], B[12], cl[2], E[12];
         point_eval<true, true>(x + 7 * fi, RF + 9 * fi, x + 7 * fj, RF + 9 * fj, ric, tic, invd[lm], pi, pj, o.sqrt_info, r, A, B, cl, E, vij, vij + 2, h.td_on ? jtd : nullptr);
         double sc = 1.0;
         if (robust) cost += 0.5 * cauchy(o.loss_pt, r[0] * r[0] + r[1] * r[1], &sc); else cost += 0.5 * (r[0] * r[0] + r[1] * r[1]);
-        out.pt_r[2 * ob] = sc * r[0]; out.pt_r[2 * ob + 1] = sc * r[1];
-        double* J = out.pt_J + 38 * (size_t)ob;
+        out.pt_r[2 * eo] = sc * r[0]; out.pt_r[2 * eo + 1] = sc * r[1];
+        double* J = out.pt_J + 38 * (size_t)eo;
         for (int row = 0; row < 2; ++row) {
             for (int q = 0; q < 6; ++q) { J[row * 19 + q] = sc * A[6 * row + q]; J[row * 19 + 6 + q] = sc * B[6 * row + q]; J[row * 19 + 12 + q] = sc * E[6 * row + q]; }
             J[row * 19 + 18] = sc * cl[row];
         }
-        if (out.pt_Jtd) { out.pt_Jtd[2 * ob] = sc * jtd[0]; out.pt_Jtd[2 * ob + 1] = sc * jtd[1]; }
+        if (out.pt_Jtd) { out.pt_Jtd[2 * eo] = sc * jtd[0]; out.pt_Jtd[2 * eo + 1] = sc * jtd[1]; }
     }
     for (int ob = tid; ob < h.n_ln_obs; ob += NT) {
         const int lm = c.bi[h.i_ln_lm + ob], fj = c.bi[h.i_ln_fj + ob], hv = c.bi[h.i_ln_vp + ob];
@@ -134,13 +138,13 @@ static int run_evaluate(int device, hipStream_t stream, char* d_blob, double* d_
                     chk(hipStreamSynchronize(stream), "k_evaluate");
     if (!ok) return UVS_ERR_HIP;
     auto back = [&](double* dst, const double* dsrc, size_t n) { if (dst && n) std::memcpy(dst, sc.h + (dsrc - d), n * 8); };
-    back(out->pt_r, eo.pt_r, 2 * (size_t)h.n_pt_obs); back(out->pt_J, eo.pt_J, 38 * (size_t)h.n_pt_obs);
+    back(out->pt_r, eo.pt_r, 2 * (size_t)(h.n_pt_obs - h.n_relo)); back(out->pt_J, eo.pt_J, 38 * (size_t)(h.n_pt_obs - h.n_relo));
     back(out->ln_r, eo.ln_r, 2 * (size_t)h.n_ln_obs); back(out->ln_J, eo.ln_J, 20 * (size_t)h.n_ln_obs);
     back(out->vp_r, eo.vp_r, (size_t)h.n_ln_obs); back(out->vp_J, eo.vp_J, 10 * (size_t)h.n_ln_obs);
     back(out->imu_r, eo.imu_r, 15 * (size_t)h.n_imu); back(out->imu_J, eo.imu_J, 450 * (size_t)h.n_imu);
     back(out->prior_r, eo.prior_r, (size_t)h.prior_n);
     back(&out->cost, eo.cost, 1);
-    if (h.td_on) back(out->pt_Jtd, eo.pt_Jtd, 2 * (size_t)h.n_pt_obs);
+    if (h.td_on) back(out->pt_Jtd, eo.pt_Jtd, 2 * (size_t)(h.n_pt_obs - h.n_relo));
     return UVS_OK;
 }
 

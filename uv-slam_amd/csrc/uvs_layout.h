@@ -15,7 +15,11 @@
 #define UVS_NBLK (UVS_NF * (UVS_NF + 1) / 2)   // 66 lower 16x16 blocks
 #define UVS_NBLKX (UVS_NBLK + UVS_NF + 1 + UVS_NF + 2)      // + the gather blocks of the two pseudo frames: 11 = time offset (ESTIMATE_TD): (td, f) = 66 + f, (td, td) = 77;
                                                // 12 = camera extrinsic (ESTIMATE_EXTRINSIC): (ex, f) = 78 + f, (ex, td) = 89, (ex, ex) = 90
-#define UVS_EX_INDEX(a) (16 * (a) + 15)        // the 6 dofs of para_Ex_Pose sit in the spare 16th slots of frames 0..5
+#define UVS_EX_INDEX(a) (16 * (a) + 15)        // the 6 dofs of para_Ex_Pose sit in the spare 16th slots of frames 0..5 -- or, in a window with relocalization
+                                               // blocks (estimator.cpp:944-978; only with a fixed extrinsic), the 6 dofs of relo_Pose: pseudo frame 12 is then an
+                                               // ORDINARY second frame of a point observation whose S rows / columns are scattered to these slots
+#define UVS_RELO_FRAME (UVS_NF + 1)            // frame index of relo_Pose in pt_fj
+#define UVS_XDIM 192                           // frame state vector: pose[11][7] sb[11][9] ex[7] td relo_pose[7] pad
 #define UVS_TD_INDEX (UVS_RD - 1)              // para_Td sits in the spare 16th slot of the last frame (index 175 of the padded reduced system)
 #define UVS_BLK_LD 17             // padded row stride of a 16x16 LDS block (bank-conflict padding)
 #define UVS_BLK_SZ (16 * UVS_BLK_LD)            // 272 doubles
@@ -52,12 +56,15 @@
 struct DevWin {
     int32_t n_points, n_pt_obs, n_lines, n_ln_obs, n_imu, prior_n, prior_nb, n_chunks;
     int32_t pt_stride, ln_stride;     // SoA strides of the measurement arrays
-    int32_t d_frames;                 // pose[11][7], sb[11][9], ex[7]  (184 doubles)
+    int32_t d_frames;                 // pose[11][7], sb[11][9], ex[7], td, relo_pose[7], pad  (UVS_XDIM doubles)
     int32_t d_invd;                   // [n_points]
     int32_t d_ptmeas;                 // 6 x pt_stride : pi_x pi_y pi_z pj_x pj_y pj_z
     int32_t d_ptvel;                  // ESTIMATE_TD only: 6 x pt_stride : vel_i.xy vel_j.xy td_i td_j
     int32_t td_on;                    // options.estimate_td
     int32_t ex_on;                    // options.estimate_extrinsic
+    int32_t n_relo;                   // number of relocalization blocks among the n_pt_obs point observations
+    int32_t i_pt_eidx;                // relo_on only: [n_pt_obs] the caller's observation index of each packed observation, -1 = relocalization block
+    int32_t relo_on;                  // the window carries relocalization blocks: point observations with pt_fj == UVS_RELO_FRAME
     int32_t pt_rec;                   // doubles per point record in the LDS staging area (30, or 34 with the td Jacobian)
     int32_t pt_xslots;                // Schur slots per point landmark beyond its observations: anchor (+ td) (+ ex)
     int32_t d_line;                   // [n_lines][4]
@@ -78,7 +85,7 @@ struct DevWin {
     int32_t w_pt_E, w_pt_x;           // Einv store 6*(n_pt_obs+n_points) ; per point {ginv, g, dd, 0}
     int32_t w_ln_Y, w_ln_x;           // Y store 24*n_ln_obs ; per line {Hinv*g[4], g[4], dd[4]}
     int32_t w_imu;                    // per block: Jraw[450] Jw[450] rraw[15] rw[15] (pad 936)
-    int32_t w_out;                    // final state: frames[184] | inv_depth[n_points] | line_orth[4 n_lines] (k_solve; the large path reads the cur buffers)
+    int32_t w_out;                    // final state: frames[UVS_XDIM] | inv_depth[n_points] | line_orth[4 n_lines] (k_solve; the large path reads the cur buffers)
     int32_t w_prior_img;              // J0^T J0 scattered into S block layout: n_pblk x 272 doubles (written by setup_window, added per linearization)
     int32_t n_pblk;                   // pose blocks of S the prior touches (ids in i_prior + 352)
     int32_t n_cimg, i_cimg, w_prior_cimg;   // compact prior image: entries of J0^T J0 that are structurally non-zero in S (17 % of the touched blocks): int32 source index in the dense image [n_cimg] then S offset [n_cimg]; values in the workspace

@@ -27,20 +27,20 @@ static constexpr int NW = NT / 64;
 // ---- LDS map (in doubles)
 static constexpr int L_S = 0;
 static constexpr int L_X = UVS_S_DOUBLES;      // pose[77] sb[99] ex[7] (+1 pad)
-static constexpr int L_XC = L_X + 184;
-static constexpr int L_G = L_XC + 184;         // gradient of the frame block, padded index space (176)
-static constexpr int L_DLT = L_G + UVS_RD;     // rhs / step
-static constexpr int L_HD = L_DLT + UVS_RD;    // diag(J^T J) of frame parameters (before Schur, before damping)
+static constexpr int L_XC = L_X + UVS_XDIM;
+static constexpr int L_G = L_XC + UVS_XDIM;    // gradient of the frame block, padded index space (176)
+static constexpr int L_DLT = L_G + UVS_RD;     // rhs / step; [192..197] = copy of the relo_Pose step (pseudo frame 12) for the back-substitution
+static constexpr int L_HD = L_DLT + UVS_RD + 24;   // diag(J^T J) of frame parameters (before Schur, before damping)
 static constexpr int L_SC = L_HD + UVS_RD;     // Jacobi scaling s_k
 static constexpr int L_DD = L_SC + UVS_RD;     // LM damping added to the diagonal
 static constexpr int L_DINV = L_DD + UVS_RD;   // 1 / L_kk of the Cholesky factor
-static constexpr int L_RF = L_DINV + UVS_RD;   // 11 rotation matrices (row-major) of the CURRENT evaluation point
-static constexpr int L_EX = L_RF + 104;        // ric[9] tic[3]
+static constexpr int L_RF = L_DINV + UVS_RD;   // 11 rotation matrices (row-major) of the CURRENT evaluation point; slot 12 (offset 108) = relo_Pose's
+static constexpr int L_EX = L_RF + 120;        // ric[9] tic[3]
 static constexpr int L_PDX = L_EX + 16;        // prior dx
 static constexpr int L_PR = L_PDX + UVS_MAX_PRIOR_DIM;   // prior residual
 static constexpr int L_PRC = L_PR + UVS_MAX_PRIOR_DIM;   // prior residual at the CANDIDATE (becomes the current one when the step is accepted)
 static constexpr int L_RED = L_PRC + UVS_MAX_PRIOR_DIM;  // reduction scratch
-static constexpr int L_CTRL = L_RED + 64;
+static constexpr int L_CTRL = L_RED + 24;      // block_reduce uses 5 doubles per wave
 static constexpr int L_PROF = L_CTRL + 32;      // per-phase cycle counters (debug launches only)
 static constexpr int L_WPROF = L_PROF + 24;     // debug sub-timers: [0..3] candidate-cost phase (stage + dx, prior residual, observations, IMU), [4..7] busy cycles of each wave in the Cholesky column phase
 static constexpr int L_LCOST = L_WPROF + 8;     // per-lane cost accumulator of the current linearization (kept in LDS, not in a register that
@@ -148,7 +148,10 @@ UVS_DEV void stage_rotations(const Ctx& c, const double* x) {
     const int tid = threadIdx.x;
     if (tid < UVS_NF) quat_to_R(x + 7 * tid + 3, c.sh + L_RF + 9 * tid);
     else if (tid == UVS_NF) { quat_to_R(x + 176 + 3, c.sh + L_EX); c.sh[L_EX + 9] = x[176]; c.sh[L_EX + 10] = x[177]; c.sh[L_EX + 11] = x[178]; }
+    else if (tid == UVS_RELO_FRAME && c.hdr->relo_on) quat_to_R(x + 184 + 3, c.sh + L_RF + 9 * UVS_RELO_FRAME);
 }
+// pose block of frame f in a state vector; f == UVS_RELO_FRAME is relo_Pose (its rotation sits in slot 12 of L_RF, so RF + 9 f needs no select)
+UVS_DEV const double* pose_of(const double* x, int f) { return x + (f > UVS_NF ? 184 : 7 * f); }
 
 // measurements of point residual block `o`; with ESTIMATE_TD the time-shifted ones of ProjectionTdFactor (projection_td_factor.cpp:51-52):
 //   pts_i_td = pts_i - (td - td_i) * (vel_i, 0), same for j  (rolling-shutter term folded into td_i / td_j by the caller).  vij = vel_i.xy, vel_j.xy
@@ -249,7 +252,7 @@ UVS_DEV double cost_pass(const Ctx& c, const double* x, const double* invd, cons
         for (int u = 0; u < 4; ++u) {
             if (!in[u]) continue;
             double r[2];
-            point_eval<false, false>(x + 7 * fi[u], RF + 9 * fi[u], x + 7 * fj[u], RF + 9 * fj[u], ric, tic, idp[u], pi[u], pj[u], c.o.sqrt_info, r, nullptr, nullptr, nullptr, nullptr);
+            point_eval<false, false>(x + 7 * fi[u], RF + 9 * fi[u], pose_of(x, fj[u]), RF + 9 * fj[u], ric, tic, idp[u], pi[u], pj[u], c.o.sqrt_info, r, nullptr, nullptr, nullptr, nullptr);
             double sc; cost += 0.5 * cauchy(c.o.loss_pt, r[0] * r[0] + r[1] * r[1], &sc);
         }
     }
@@ -864,7 +867,7 @@ UVS_DEV void lin_chunk(const Ctx& c, int ch, const double* x, const double* invd
                 double pi[3], pj[3], vij[4] = {0.0, 0.0, 0.0, 0.0};
                 load_point_obs(c, o, x[183], pi, pj, vij);
                 double r[2], A[12], B[12], cl[2], jtd[2] = {0.0, 0.0};
-                point_eval<true, false>(x + 7 * fi, RF + 9 * fi, x + 7 * fj, RF + 9 * fj, ric, tic, invd[lm], pi, pj, c.o.sqrt_info, r, A, B, cl, nullptr,
+                point_eval<true, false>(x + 7 * fi, RF + 9 * fi, pose_of(x, fj), RF + 9 * fj, ric, tic, invd[lm], pi, pj, c.o.sqrt_info, r, A, B, cl, nullptr,
                                         vij, vij + 2, h.td_on ? jtd : nullptr);
                 double sc; cost += 0.5 * cauchy(c.o.loss_pt, r[0] * r[0] + r[1] * r[1], &sc);
                 double* R = rec + (size_t)(o - o0) * PREC;
@@ -1249,7 +1252,7 @@ UVS_DEV void lin_assemble(const Ctx& c, const double* x, bool first, double radi
     double gmax = gmax_lm;
     if (tid < UVS_RD) {
         const int k = tid & 15;
-        if (k < 15 || (h.td_on && tid == UVS_TD_INDEX) || (h.ex_on && tid < 96)) {      // spare slots in use: td at 175, Ex_Pose dofs at 15, 31, ... 95
+        if (k < 15 || (h.td_on && tid == UVS_TD_INDEX) || ((h.ex_on | h.relo_on) && tid < 96)) {      // spare slots in use: td at 175, Ex_Pose (or relo_Pose) dofs at 15, 31, ... 95
             const double hd = sh[L_HD + tid];
             if (first) sh[L_SC + tid] = c.o.jacobi ? 1.0 / (1.0 + sqrt(hd)) : 1.0;
             const double sc = sh[L_SC + tid];
@@ -1267,13 +1270,14 @@ UVS_DEV void lin_assemble(const Ctx& c, const double* x, bool first, double radi
 #pragma unroll
         for (int k = 0; k < 7; ++k) gmax = fmax(gmax, fabs(x[7 * tid + k] - xp[k]));
     }
-    if (h.ex_on && tid == UVS_NF) {   // same projected-gradient measure for the extrinsic pose block
+    if ((h.ex_on | h.relo_on) && tid == UVS_NF) {   // same projected-gradient measure for the extrinsic pose block / relo_Pose
+        const double* xa = x + (h.relo_on ? 184 : 176);
         double d[6], xp[7];
 #pragma unroll
         for (int k = 0; k < 6; ++k) d[k] = -sh[L_G + UVS_EX_INDEX(k)];
-        pose_plus(x + 176, d, xp);
+        pose_plus(xa, d, xp);
 #pragma unroll
-        for (int k = 0; k < 7; ++k) gmax = fmax(gmax, fabs(x[176 + k] - xp[k]));
+        for (int k = 0; k < 7; ++k) gmax = fmax(gmax, fabs(xa[k] - xp[k]));
     }
     double s4[4] = {cost, 0.0, 0.0, 0.0};
     block_reduce(sh, s4, &gmax);
@@ -1303,9 +1307,13 @@ UVS_DEV void backsub_candidate(const Ctx& c, const double* invd, const double* l
     const double* d = sh + L_DLT;
     double gd = 0.0, dd2 = 0.0, step2 = 0.0, xc2 = 0.0;
     const bool td_on = h.td_on != 0;
-    const bool ex_on = h.ex_on != 0;
+    const bool ex_on = h.ex_on != 0, relo_on = h.relo_on != 0;
     double* ltrig_c = const_cast<double*>(line_trig_of(c, line_c));
-    if (with_frames && tid < UVS_RD && ((tid & 15) < 15 || (td_on && tid == UVS_TD_INDEX) || (ex_on && tid < 96))) { gd += sh[L_G + tid] * d[tid]; dd2 += sh[L_DD + tid] * d[tid] * d[tid]; }
+    if (relo_on) {      // the step of relo_Pose where an observation of pseudo frame 12 looks for it: d[16 * 12 + a]
+        if (tid < 6) sh[L_DLT + 16 * UVS_RELO_FRAME + tid] = d[UVS_EX_INDEX(tid)];
+        __syncthreads();
+    }
+    if (with_frames && tid < UVS_RD && ((tid & 15) < 15 || (td_on && tid == UVS_TD_INDEX) || ((ex_on | relo_on) && tid < 96))) { gd += sh[L_G + tid] * d[tid]; dd2 += sh[L_DD + tid] * d[tid] * d[tid]; }
     if (with_frames && tid < UVS_NF) {
         double xp[7];
         pose_plus(sh + L_X + 7 * tid, d + 16 * tid, xp);
@@ -1326,6 +1334,14 @@ UVS_DEV void backsub_candidate(const Ctx& c, const double* invd, const double* l
         const double dtd = td_on ? d[UVS_TD_INDEX] : 0.0, tdc = sh[L_X + 183] + dtd;
         sh[L_XC + 183] = tdc;
         if (td_on) { step2 += dtd * dtd; xc2 += tdc * tdc; }
+        if (relo_on) {      // relo_Pose: a free pose block (estimator.cpp:947-948)
+            double de[6], xp[7];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) de[k] = d[UVS_EX_INDEX(k)];
+            pose_plus(sh + L_X + 184, de, xp);
+#pragma unroll
+            for (int k = 0; k < 7; ++k) { sh[L_XC + 184 + k] = xp[k]; const double e = xp[k] - sh[L_X + 184 + k]; step2 += e * e; xc2 += xp[k] * xp[k]; }
+        } else for (int k = 0; k < 7; ++k) sh[L_XC + 184 + k] = sh[L_X + 184 + k];
     }
     // points: delta = -ginv - sum_s Einv[s] . delta_pose(frame(s))
     const int* pbeg = c.bi + h.i_pt_beg;
@@ -1421,6 +1437,7 @@ UVS_DEV double ambient_sqnorm(const Ctx& c, const double* x, const double* invd,
     if (tid < 176) s += x[tid] * x[tid];
     if (tid == 183 && h.td_on) s += x[183] * x[183];
     if (tid >= 176 && tid < 183 && h.ex_on) s += x[tid] * x[tid];
+    if (tid >= 184 && tid < 191 && h.relo_on) s += x[tid] * x[tid];
     for (int k = tid; k < h.n_points; k += NT) s += invd[k] * invd[k];
     for (int k = tid; k < 4 * h.n_lines; k += NT) s += line[k] * line[k];
     double s4[4] = {s, 0, 0, 0}, mx = 0.0;
@@ -1574,7 +1591,7 @@ __global__ __launch_bounds__(NT) void k_solve(char* blobs, const long long* blob
     const DevWin& h = *c.hdr;
     uvs_report* rep = reports + wdx;
     // ---- init: frames -> LDS, landmark parameters -> workspace buffer 0
-    if (tid < 184) sh[L_X + tid] = c.bd[h.d_frames + tid];      // pose[77] sb[99] ex[7] td
+    if (tid < UVS_XDIM) sh[L_X + tid] = c.bd[h.d_frames + tid];      // pose[77] sb[99] ex[7] td relo[7]
     for (int k = tid; k < h.n_points; k += NT) c.ws[h.w_invd0 + k] = c.bd[h.d_invd + k];
     for (int k = tid; k < 4 * h.n_lines; k += NT) c.ws[h.w_line0 + k] = c.bd[h.d_line + k];
     for (int k = tid; k < h.n_lines; k += NT) line_trig(c.bd + h.d_line + 4 * k, c.ws + h.w_ltrig0 + 8 * k);
@@ -1675,7 +1692,7 @@ __global__ __launch_bounds__(NT) void k_solve(char* blobs, const long long* blob
         if (stop && !(o.keep_cand && successful)) break;
         if (successful) {             // HandleSuccessfulStep: x <- x_c; the re-linearization happens at the loop top (skipped when we stop)
             __syncthreads();
-            if (tid < 184) sh[L_X + tid] = sh[L_XC + tid];
+            if (tid < UVS_XDIM) sh[L_X + tid] = sh[L_XC + tid];
             cur ^= 1; ++nsucc;
             x_norm = sqrt(xc2);
             { const double t3 = 2.0 * rel - 1.0; radius = radius / fmax(1.0 / 3.0, 1.0 - t3 * t3 * t3); }     // (a generic pow() costs hundreds of instructions)
@@ -1694,10 +1711,10 @@ __global__ __launch_bounds__(NT) void k_solve(char* blobs, const long long* blob
     UVS_PROF(c, P_MISC);
     if (o.debug && dbg.scal && tid < P_LAST) dbg.scal[8 + tid] = sh[L_PROF + tid];
     if (o.debug && dbg.scal && tid < 8) dbg.scal[24 + tid] = sh[L_WPROF + tid];
-    if (tid < 184) c.ws[h.w_out + tid] = sh[L_X + tid];
+    if (tid < UVS_XDIM) c.ws[h.w_out + tid] = sh[L_X + tid];
     // the accepted landmark parameters follow the frames, so that the host fetches ONE small contiguous block per window
-    for (int k = tid; k < h.n_points; k += NT) c.ws[h.w_out + 184 + k] = invd[cur][k];
-    for (int k = tid; k < 4 * h.n_lines; k += NT) c.ws[h.w_out + 184 + h.n_points + k] = line[cur][k];
+    for (int k = tid; k < h.n_points; k += NT) c.ws[h.w_out + UVS_XDIM + k] = invd[cur][k];
+    for (int k = tid; k < 4 * h.n_lines; k += NT) c.ws[h.w_out + UVS_XDIM + h.n_points + k] = line[cur][k];
     if (tid == 0) {
         rep->status = status; rep->termination = term; rep->num_iterations = it; rep->num_successful = nsucc; rep->final_cost = cost;
         ((DevWin*)blob)->cur_sel = cur;

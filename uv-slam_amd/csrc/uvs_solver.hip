@@ -190,10 +190,40 @@ static int validate_window(const uvs_window* w, std::string& err) {
 }
 
 // appends the blob of `w` to `out` (8-byte aligned) and returns its header
-static int pack_window(const uvs_window* w, const uvs_options& opts, std::vector<char>& out, DevWin& hdr, std::string& err) {
-    int rc = validate_window(w, err);
+static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vector<char>& out, DevWin& hdr, std::string& err) {
+    int rc = validate_window(w_in, err);
     if (rc != UVS_OK) return rc;
     const bool td_on = opts.estimate_td != 0;
+    // Relocalization blocks (estimator.cpp:944-978) become ordinary point observations whose second frame is the pseudo frame 12 = relo_Pose,
+    // placed right after their landmark's last observation (the kernel wants a landmark's blocks together).  eidx maps a merged observation
+    // back to the caller's index (-1 for a relocalization block): uvs_evaluate / uvs_marginalize keep the caller's numbering and skip them.
+    const uvs_window* w = w_in;
+    uvs_window wm;
+    std::vector<int32_t> m_lm, m_fi, m_fj, eidx; std::vector<double> m_pi, m_pj;
+    const int n_relo = w_in->n_relo_obs;
+    if (n_relo < 0) { err = "bad counts"; return UVS_ERR_INVALID_ARG; }
+    if (n_relo > 0) {
+        if (td_on || opts.estimate_extrinsic != 0) { err = "relocalization blocks need estimate_extrinsic == 0 and estimate_td == 0 (relo_Pose takes the spare slots of the reduced system)"; return UVS_ERR_UNSUPPORTED; }
+        if (!w_in->relo_lm || !w_in->relo_pi || !w_in->relo_pj) { err = "null array"; return UVS_ERR_INVALID_ARG; }
+        const int npo = w_in->n_point_obs;
+        int q = 0;
+        for (int k = 0; k < npo; ++k) {
+            const int lm = w_in->pt_lm[k];
+            m_lm.push_back(lm); m_fi.push_back(w_in->pt_fi[k]); m_fj.push_back(w_in->pt_fj[k]); eidx.push_back(k);
+            for (int c = 0; c < 3; ++c) { m_pi.push_back(w_in->pt_pi[3 * k + c]); m_pj.push_back(w_in->pt_pj[3 * k + c]); }
+            if (k + 1 < npo && w_in->pt_lm[k + 1] == lm) continue;
+            if (q < n_relo && w_in->relo_lm[q] < lm) { err = "relo_lm must be strictly increasing and name landmarks that have observations"; return UVS_ERR_INVALID_ARG; }
+            if (q < n_relo && w_in->relo_lm[q] == lm) {
+                m_lm.push_back(lm); m_fi.push_back(w_in->pt_fi[k]); m_fj.push_back(UVS_RELO_FRAME); eidx.push_back(-1);
+                for (int c = 0; c < 3; ++c) { m_pi.push_back(w_in->relo_pi[3 * q + c]); m_pj.push_back(w_in->relo_pj[3 * q + c]); }
+                ++q;
+            }
+        }
+        if (q != n_relo) { err = "relo_lm must be strictly increasing and name landmarks that have observations"; return UVS_ERR_INVALID_ARG; }
+        wm = *w_in;
+        wm.n_point_obs = (int)m_lm.size(); wm.pt_lm = m_lm.data(); wm.pt_fi = m_fi.data(); wm.pt_fj = m_fj.data(); wm.pt_pi = m_pi.data(); wm.pt_pj = m_pj.data();
+        w = &wm;
+    }
     if (td_on && w->n_point_obs > 0 && (!w->pt_vel_i || !w->pt_vel_j || !w->pt_td_i || !w->pt_td_j)) { err = "estimate_td needs pt_vel_i / pt_vel_j / pt_td_i / pt_td_j"; return UVS_ERR_INVALID_ARG; }
     DevWin h; std::memset(&h, 0, sizeof(h));
     h.n_points = w->n_points; h.n_pt_obs = w->n_point_obs; h.n_lines = w->n_lines; h.n_ln_obs = w->n_line_obs; h.n_imu = w->n_imu;
@@ -202,6 +232,8 @@ static int pack_window(const uvs_window* w, const uvs_options& opts, std::vector
     h.pt_stride = rup(std::max(h.n_pt_obs, 1), 8); h.ln_stride = rup(std::max(h.n_ln_obs, 1), 8);
     const bool ex_on = opts.estimate_extrinsic != 0;
     h.td_on = td_on ? 1 : 0; h.ex_on = ex_on ? 1 : 0;
+    const bool relo_on = n_relo > 0;
+    h.relo_on = relo_on ? 1 : 0; h.n_relo = n_relo;
     h.pt_rec = ex_on ? UVS_PT_REC_EX : td_on ? UVS_PT_REC_TD : UVS_PT_REC; h.pt_xslots = 1 + (td_on ? 1 : 0) + (ex_on ? 1 : 0);
     const int PREC = h.pt_rec, XS = h.pt_xslots;
     // CSR by landmark
@@ -332,7 +364,7 @@ static int pack_window(const uvs_window* w, const uvs_options& opts, std::vector
             const bool tdb = b >= UVS_NBLK && b < UVS_NBLK + UVS_NF + 1, exb = b >= UVS_NBLK + UVS_NF + 1;
             // a block nothing contributes to (frames further apart than the longest track, pseudo-frame blocks of an option that is off) gets
             // no group at all: S is zeroed anyway, and its group goes to a heavy block instead (15 of 128 groups for the canonical window)
-            np[b] = ((b < UVS_NBLK || (tdb && td_on) || (exb && ex_on && (td_on || b != UVS_NBLK + UVS_NF + 1 + UVS_NF))) && blk_work[b] > 0) ? 1 : 0; used += np[b];
+            np[b] = ((b < UVS_NBLK || (tdb && td_on) || (exb && (ex_on || relo_on) && (td_on || b != UVS_NBLK + UVS_NF + 1 + UVS_NF))) && blk_work[b] > 0) ? 1 : 0; used += np[b];
         }
         // The waves run in lock step inside a chunk and the chunks of the two landmark families are separated by barriers, so what counts
         // is the LARGEST per-group share within each family, not the per-group total: a block that is heavy in the point chunks only (the
@@ -415,7 +447,7 @@ static int pack_window(const uvs_window* w, const uvs_options& opts, std::vector
     h.n_chunks = (int)chunks.size() / 6;
     // layout
     int d = (int)((sizeof(DevWin) + 7) / 8);
-    h.d_frames = d; d += 184;
+    h.d_frames = d; d += UVS_XDIM;
     h.d_invd = d; d += rup(std::max(h.n_points, 1), 2);
     h.d_ptmeas = d; d += 6 * h.pt_stride;
     h.d_ptvel = d; d += td_on ? 6 * h.pt_stride : 0;
@@ -458,6 +490,7 @@ static int pack_window(const uvs_window* w, const uvs_options& opts, std::vector
     h.d_prior = d; d += 2 * h.prior_n * h.prior_n + 2 * h.prior_n + 144;
     int i = 2 * d;
     h.i_pt_lm = i; i += h.pt_stride; h.i_pt_fi = i; i += h.pt_stride; h.i_pt_fj = i; i += h.pt_stride; h.i_pt_beg = i; i += rup(h.n_points + 1, 2);
+    h.i_pt_eidx = i; i += relo_on ? h.pt_stride : 0;
     h.i_ln_lm = i; i += h.ln_stride; h.i_ln_fj = i; i += h.ln_stride; h.i_ln_vp = i; i += h.ln_stride; h.i_ln_beg = i; i += rup(h.n_lines + 1, 2);
     h.i_imu = i; i += 2 * std::max(h.n_imu, 1);
     h.i_prior = i; i += 80 + UVS_MAX_PRIOR_DIM + UVS_RD + UVS_NBLK;
@@ -475,7 +508,7 @@ static int pack_window(const uvs_window* w, const uvs_options& opts, std::vector
     h.w_pt_E = wsz; wsz += 6 * (h.n_pt_obs + XS * h.n_points) + 6; h.w_pt_x = wsz; wsz += 4 * std::max(h.n_points, 1);
     h.w_ln_Y = wsz; wsz += 24 * std::max(h.n_ln_obs, 1); h.w_ln_x = wsz; wsz += 12 * std::max(h.n_lines, 1);
     h.w_imu = wsz; wsz += std::max(h.n_imu, 1) * UVS_WIMU_STRIDE;
-    h.w_out = wsz; wsz += 184 + std::max(h.n_points, 0) + 4 * std::max(h.n_lines, 0);
+    h.w_out = wsz; wsz += UVS_XDIM + std::max(h.n_points, 0) + 4 * std::max(h.n_lines, 0);
     h.n_pblk = (int)pblk.size();
     h.w_prior_img = wsz; wsz += std::max(h.n_pblk, 1) * UVS_BLK_SZ + UVS_RD;      // dense tiles (written once per solve), diag(J0^T J0) per S index
     h.n_cimg = (int)csrc.size();
@@ -491,6 +524,8 @@ static int pack_window(const uvs_window* w, const uvs_options& opts, std::vector
     std::memcpy(D + h.d_frames + 77, w->speedbias, sizeof(double) * 99);
     std::memcpy(D + h.d_frames + 176, w->ex_pose, sizeof(double) * 7);
     D[h.d_frames + 183] = w->td;
+    std::memcpy(D + h.d_frames + 184, w->relo_pose, sizeof(double) * 7);
+    if (relo_on) for (int k = 0; k < h.n_pt_obs; ++k) I[h.i_pt_eidx + k] = eidx[k];
     for (int k = 0; k < h.n_points; ++k) D[h.d_invd + k] = w->inv_depth[k];
     for (int k = 0; k < h.n_pt_obs; ++k) {
         for (int q = 0; q < 3; ++q) { D[h.d_ptmeas + q * h.pt_stride + k] = w->pt_pi[3 * k + q]; D[h.d_ptmeas + (3 + q) * h.pt_stride + k] = w->pt_pj[3 * k + q]; }
@@ -575,7 +610,7 @@ int uvs_batch_upload(uvs_solver* s, int n, const uvs_window* const* ws) {
     s->host_blobs.clear(); s->hdrs.resize(n); s->blob_off.resize(n); s->ws_off.resize(n);
     long long wtot = 0;
     for (int b = 0; b < n; ++b) {
-        if (ws[b] && (ws[b]->n_points > s->max_points || ws[b]->n_point_obs > s->max_point_obs || ws[b]->n_lines > s->max_lines || ws[b]->n_line_obs > s->max_line_obs)) {
+        if (ws[b] && (ws[b]->n_points > s->max_points || ws[b]->n_point_obs + std::max(ws[b]->n_relo_obs, 0) > s->max_point_obs || ws[b]->n_lines > s->max_lines || ws[b]->n_line_obs > s->max_line_obs)) {
             s->err = "window exceeds the capacity given to uvs_create (max_points / max_point_obs / max_lines / max_line_obs)"; s->n_loaded = 0; return UVS_ERR_CAPACITY;
         }
         s->blob_off[b] = (long long)s->host_blobs.size();
@@ -633,7 +668,7 @@ int uvs_batch_download(uvs_solver* s, int n, uvs_state* states, uvs_report* reps
     std::vector<double> buf;
     for (int b = 0; states && b < n; ++b) {
         const DevWin& h = s->hdrs[b];
-        const size_t cnt = 184 + (size_t)h.n_points + 4 * (size_t)h.n_lines;
+        const size_t cnt = UVS_XDIM + (size_t)h.n_points + 4 * (size_t)h.n_lines;
         buf.resize(cnt);
         HIPCHK(s, hipMemcpy(buf.data(), s->d_ws + s->ws_off[b] + h.w_out, cnt * 8, hipMemcpyDeviceToHost));
         uvs_state& st = states[b];
@@ -641,8 +676,9 @@ int uvs_batch_download(uvs_solver* s, int n, uvs_state* states, uvs_report* reps
         std::memcpy(st.speedbias, buf.data() + 77, sizeof(double) * 99);
         std::memcpy(st.ex_pose, buf.data() + 176, sizeof(double) * 7);
         st.td = buf[183];
-        if (st.inv_depth) std::memcpy(st.inv_depth, buf.data() + 184, sizeof(double) * h.n_points);
-        if (st.line_orth) std::memcpy(st.line_orth, buf.data() + 184 + h.n_points, sizeof(double) * 4 * h.n_lines);
+        std::memcpy(st.relo_pose, buf.data() + 184, sizeof(double) * 7);
+        if (st.inv_depth) std::memcpy(st.inv_depth, buf.data() + UVS_XDIM, sizeof(double) * h.n_points);
+        if (st.line_orth) std::memcpy(st.line_orth, buf.data() + UVS_XDIM + h.n_points, sizeof(double) * 4 * h.n_lines);
     }
     return worst;
 }
@@ -700,7 +736,7 @@ int uvs_marginalize_resident(uvs_solver* s, const uvs_window* w, int flag, uvs_p
     if (s->n_loaded != 1) { s->err = "uvs_marginalize_resident: no single resident window"; return UVS_ERR_INVALID_ARG; }
     const DevWin& h = s->hdrs[0];
     const int pn = (w->prior && w->prior->n > 0) ? w->prior->n : 0;
-    if (h.n_points != w->n_points || h.n_pt_obs != w->n_point_obs || h.n_lines != w->n_lines || h.n_ln_obs != w->n_line_obs || h.n_imu != w->n_imu || h.prior_n != pn) {
+    if (h.n_points != w->n_points || h.n_pt_obs - h.n_relo != w->n_point_obs || h.n_lines != w->n_lines || h.n_ln_obs != w->n_line_obs || h.n_imu != w->n_imu || h.prior_n != pn) {
         s->err = "uvs_marginalize_resident: the window does not match the resident one"; return UVS_ERR_INVALID_ARG;
     }
     HIPCHK(s, hipSetDevice(s->device));
@@ -725,6 +761,7 @@ extern "C" {
 
 int uvs_large_begin(uvs_solver* s, const uvs_window* w) {
     if (!s || !w) return UVS_ERR_INVALID_ARG;
+    if (w->n_relo_obs > 0) { s->err = "relocalization blocks are not taken by the large-window path"; return UVS_ERR_UNSUPPORTED; }
     const uvs_window* arr[1] = {w};
     int rc = uvs_batch_upload(s, 1, arr);
     if (rc != UVS_OK) return rc;
@@ -869,6 +906,7 @@ int uvs_large_finish(uvs_solver* s, uvs_state* out, uvs_report* rep) {
     double fr[184];
     HIPCHK(s, hipMemcpy(fr, L.d_state + LS_X, sizeof(fr), hipMemcpyDeviceToHost));
     std::memcpy(out->pose, fr, 77 * 8); std::memcpy(out->speedbias, fr + 77, 99 * 8); std::memcpy(out->ex_pose, fr + 176, 7 * 8); out->td = fr[183];
+    std::memset(out->relo_pose, 0, sizeof(out->relo_pose));
     if (out->inv_depth && h.n_points) HIPCHK(s, hipMemcpy(out->inv_depth, s->d_ws + (L.sel ? h.w_invd1 : h.w_invd0), (size_t)h.n_points * 8, hipMemcpyDeviceToHost));
     if (out->line_orth && h.n_lines) HIPCHK(s, hipMemcpy(out->line_orth, s->d_ws + (L.sel ? h.w_line1 : h.w_line0), (size_t)h.n_lines * 32, hipMemcpyDeviceToHost));
     L.active = false;

@@ -1,11 +1,13 @@
 // window_io.h -- binary record / replay format of one sliding window.
 // The reference never serialises the estimator window; this file is what a dump hook placed after vector2double()
 // (estimator.cpp:800) writes and what the GPU box replays without ROS.  Little-endian, 8-byte aligned:
-//   char magic[8] = "UVSWIN01"; int32 n_points, n_point_obs, n_lines, n_line_obs, n_imu, prior_n, prior_nblocks, has_td;
+//   char magic[8] = "UVSWIN01"; int32 n_points, n_point_obs, n_lines, n_line_obs, n_imu, prior_n, prior_nblocks, flags (1 = has_td, 2 = has_relo);
 //   double pose[77] sb[99] ex[7] td; double inv_depth[np]; int32 pt_lm/fi/fj[npo]; double pt_pi[3npo] pt_pj[3npo];
 //   (has_td: double pt_vel_i[2npo] pt_vel_j[2npo] pt_td_i[npo] pt_td_j[npo] -- the ProjectionTdFactor inputs);
 //   double line_orth[4nl]; int32 ln_lm/fj/has_vp[nlo]; double ln_sp/ep/vp[3nlo]; imu: n_imu x (467 doubles + int32 frame_i, skip);
-//   prior (if prior_n): int32 kind/frame/size/idx/x0off[16 each]; double x0[144] r0[n] J0[n*n].
+//   prior (if prior_n): int32 kind/frame/size/idx/x0off[16 each]; double x0[144] r0[n] J0[n*n];
+//   (has_relo: int32 n_relo, 0; double relo_pose[7]; int32 relo_lm[n_relo] (+pad to 8 bytes); double relo_pi[3 n_relo] relo_pj[3 n_relo]
+//    -- the relocalization blocks, estimator.cpp:944-978).
 // The same layout is written / read by uv-slam_amd/abi.py (Window.save / Window.load).
 #pragma once
 #include <cstdio>
@@ -16,7 +18,8 @@
 
 struct WindowFile {      // owns the arrays a uvs_window points to
     uvs_window w;
-    std::vector<double> inv_depth, pt_pi, pt_pj, line_orth, ln_sp, ln_ep, ln_vp, pt_vel_i, pt_vel_j, pt_td_i, pt_td_j;
+    std::vector<double> inv_depth, pt_pi, pt_pj, line_orth, ln_sp, ln_ep, ln_vp, pt_vel_i, pt_vel_j, pt_td_i, pt_td_j, relo_pi, relo_pj;
+    std::vector<int32_t> relo_lm;
     bool has_td = false;
     std::vector<int32_t> pt_lm, pt_fi, pt_fj, ln_lm, ln_fj, ln_has_vp;
     std::vector<uvs_imu_block> imu;
@@ -34,7 +37,7 @@ struct WindowFile {      // owns the arrays a uvs_window points to
             pt_lm.resize(npo); pt_fi.resize(npo); pt_fj.resize(npo); rd(pt_lm.data(), 4, npo); rd(pt_fi.data(), 4, npo); rd(pt_fj.data(), 4, npo);
             if (npo % 2) { int32_t pad; rd(&pad, 4, 1); }
             pt_pi.resize(3 * npo); pt_pj.resize(3 * npo); rd(pt_pi.data(), 8, 3 * npo); rd(pt_pj.data(), 8, 3 * npo);
-            has_td = hd[7] != 0;
+            has_td = (hd[7] & 1) != 0;
             if (has_td) { pt_vel_i.resize(2 * npo); pt_vel_j.resize(2 * npo); pt_td_i.resize(npo); pt_td_j.resize(npo);
                           rd(pt_vel_i.data(), 8, 2 * npo); rd(pt_vel_j.data(), 8, 2 * npo); rd(pt_td_i.data(), 8, npo); rd(pt_td_j.data(), 8, npo); }
             line_orth.resize(4 * nl); rd(line_orth.data(), 8, 4 * nl);
@@ -58,6 +61,12 @@ struct WindowFile {      // owns the arrays a uvs_window points to
             w.line_orth = line_orth.data(); w.ln_lm = ln_lm.data(); w.ln_fj = ln_fj.data(); w.ln_has_vp = ln_has_vp.data(); w.ln_sp = ln_sp.data(); w.ln_ep = ln_ep.data(); w.ln_vp = ln_vp.data();
             w.imu = imu.data(); w.prior = pn > 0 ? &prior : nullptr;
             if (has_td) { w.pt_vel_i = pt_vel_i.data(); w.pt_vel_j = pt_vel_j.data(); w.pt_td_i = pt_td_i.data(); w.pt_td_j = pt_td_j.data(); }
+            if (hd[7] & 2) {
+                int32_t nr[2] = {0, 0}; rd(nr, 4, 2); const int n = ok ? nr[0] : 0;
+                rd(w.relo_pose, 8, 7); relo_lm.resize(n); rd(relo_lm.data(), 4, n); if (n % 2) { int32_t pad; rd(&pad, 4, 1); }
+                relo_pi.resize(3 * n); relo_pj.resize(3 * n); rd(relo_pi.data(), 8, 3 * n); rd(relo_pj.data(), 8, 3 * n);
+                w.n_relo_obs = n; w.relo_lm = relo_lm.data(); w.relo_pi = relo_pi.data(); w.relo_pj = relo_pj.data();
+            }
         }
         std::fclose(f);
         return ok;
@@ -67,7 +76,8 @@ struct WindowFile {      // owns the arrays a uvs_window points to
         FILE* f = std::fopen(path.c_str(), "wb"); if (!f) return false;
         const bool td = w.pt_vel_i && w.pt_vel_j && w.pt_td_i && w.pt_td_j;
         const int np = w.n_points, npo = w.n_point_obs, nl = w.n_lines, nlo = w.n_line_obs, ni = w.n_imu, pn = w.prior ? w.prior->n : 0;
-        const int32_t hd[8] = {np, npo, nl, nlo, ni, pn, pn ? w.prior->n_blocks : 0, td ? 1 : 0}, pad = 0;
+        const int nrl = w.n_relo_obs;
+        const int32_t hd[8] = {np, npo, nl, nlo, ni, pn, pn ? w.prior->n_blocks : 0, (td ? 1 : 0) | (nrl > 0 ? 2 : 0)}, pad = 0;
         bool ok = true;
         auto wr = [&](const void* p, size_t sz, size_t n) { if (ok && n) ok = std::fwrite(p, sz, n, f) == n; };
         wr("UVSWIN01", 1, 8); wr(hd, 4, 8);
@@ -86,6 +96,10 @@ struct WindowFile {      // owns the arrays a uvs_window points to
             const uvs_prior& p = *w.prior;
             wr(p.block_kind, 4, 16); wr(p.block_frame, 4, 16); wr(p.block_size, 4, 16); wr(p.block_idx, 4, 16); wr(p.x0_off, 4, 16);
             wr(p.x0, 8, 144); wr(p.linearized_residuals, 8, pn); wr(p.linearized_jacobians, 8, (size_t)pn * pn);
+        }
+        if (nrl > 0) {
+            const int32_t nr[2] = {nrl, 0}; wr(nr, 4, 2); wr(w.relo_pose, 8, 7); wr(w.relo_lm, 4, nrl); if (nrl % 2) wr(&pad, 4, 1);
+            wr(w.relo_pi, 8, 3 * nrl); wr(w.relo_pj, 8, 3 * nrl);
         }
         std::fclose(f);
         return ok;

@@ -424,3 +424,35 @@ def add_time_offset(w, td_true=0.004, vel_sigma=0.6, seed=0):
     if o.truth is not None:
         o.truth = dict(o.truth); o.truth["td"] = td_true
     return o
+
+
+def add_relocalization(w, relo_frame=4, fraction=0.6, offset=(0.25, 4.0), pixel_sigma=0.0, seed=0):
+    """Adds the relocalization blocks of estimator.cpp:944-978 to `w`: an old keyframe whose true pose is the truth of frame `relo_frame`
+    moved by `offset` = (metres, degrees) in a random direction re-observes `fraction` of the landmarks that start at or before
+    `relo_frame` (the reference's `start <= relo_frame_local_index`); pts_j = its normalised observation (+ noise), pts_i = the
+    landmark's first observation.  relo_Pose starts at the window's current Pose[relo_frame] (Estimator::setReloFrame,
+    estimator.cpp:1361-1379); truth["relo_pose"] holds the pose that zeroes the blocks of a noise-free window."""
+    rng = np.random.default_rng([seed, 91])
+    o = w.copy()
+    t = o.truth
+    focal = 461.6
+    d = rng.standard_normal(3); d /= np.linalg.norm(d)
+    a = rng.standard_normal(3); a /= np.linalg.norm(a)
+    P = t["pose"][relo_frame, :3] + offset[0] * d
+    Q = quat_mul(t["pose"][relo_frame, 3:], exp_quat(np.deg2rad(offset[1]) * a)); Q = Q / np.linalg.norm(Q)
+    Rr, tr = _cam(P, Q, o.ex_pose)
+    lms, pis, pjs = [], [], []
+    first = np.r_[True, o.pt_lm[1:] != o.pt_lm[:-1]] if len(o.pt_lm) else np.zeros(0, bool)
+    for k in np.nonzero(first)[0]:
+        lm, fi = int(o.pt_lm[k]), int(o.pt_fi[k])
+        if fi > relo_frame or rng.uniform() > fraction: continue
+        Ri, ti = _cam(t["pose"][fi, :3], t["pose"][fi, 3:], o.ex_pose)
+        X = Ri @ (o.pt_pi[k] / t["inv_depth"][lm]) + ti
+        pc = Rr.T @ (X - tr)
+        if pc[2] < 0.2: continue
+        lms.append(lm); pis.append(o.pt_pi[k].copy())
+        pjs.append(np.array([pc[0] / pc[2] + rng.normal(0, 1) * pixel_sigma / focal, pc[1] / pc[2] + rng.normal(0, 1) * pixel_sigma / focal, 1.0]))
+    o.relo_lm = np.array(lms, np.int32); o.relo_pi = np.array(pis).reshape(-1, 3); o.relo_pj = np.array(pjs).reshape(-1, 3)
+    o.relo_pose = o.pose[relo_frame].copy()
+    o.truth = dict(t); o.truth["relo_pose"] = np.r_[P, Q]
+    return o
