@@ -147,3 +147,42 @@ def test_relo_rejected_combinations(gpu_api):
     with pytest.raises(RuntimeError, match="uvs error %d" % abi.UVS_ERR_INVALID_ARG):
         s.solve(bad)
     s.close()
+
+
+@pytest.mark.gpu
+def test_host_estimator_relocalization(gpu_api, tmp_path):
+    """Estimator::setReloFrame -> optimization() (relocalization blocks through uvs::Problem) -> double2vector() (estimator.cpp:671-691:
+    drift correction + relative pose of the loop pair) in the host mirror, against the same window solved through the C ABI and the
+    formulas evaluated in numpy."""
+    import ctypes as C, os
+    from test_host_mirror import _host
+    w = _relo_window(130, relo_frame=6)
+    s = gpu_api.Solver(max_batch=2)
+    st, rep = s.solve(w)
+    s.close()
+    pin, pout = str(tmp_path / "in.uvsw"), str(tmp_path / "out.bin")
+    w.save(pin)
+    assert _host().uvs_host_replay_window(pin.encode(), pout.encode(), 0) == 0
+    raw = np.fromfile(pout, dtype=np.float64)
+    status, iters, c0, c1 = raw[:4]
+    assert status == 0 and iters == rep.num_iterations and abs(c0 - rep.initial_cost) <= 1e-9 * c0 and abs(c1 - rep.final_cost) <= 1e-9 * c1
+    tail = raw[-28:]
+    relo_pose, dr, dt, rel_t, rel_q, rel_yaw, still_set = tail[:7], tail[7:16].reshape(3, 3), tail[16:19], tail[19:22], tail[22:26], tail[26], tail[27]
+    assert still_set == 0.0                                         # relocalization_info is consumed (:689)
+    assert np.abs(relo_pose - st.relo_pose).max() < 1e-9
+    R = synth.quat_to_R
+    yaw = lambda M: np.degrees(np.arctan2(M[1, 0], M[0, 0]))
+    Rz = lambda deg: np.array([[np.cos(np.radians(deg)), -np.sin(np.radians(deg)), 0], [np.sin(np.radians(deg)), np.cos(np.radians(deg)), 0], [0, 0, 1.0]])
+    rot_diff = Rz(yaw(R(w.pose[0, 3:])) - yaw(R(st.pose[0, 3:])))
+    k = w.relo_frame
+    relo_r = rot_diff @ R(st.relo_pose[3:]); relo_t = rot_diff @ (st.relo_pose[:3] - st.pose[0, :3]) + w.pose[0, :3]
+    Pk = rot_diff @ (st.pose[k, :3] - st.pose[0, :3]) + w.pose[0, :3]; Rk = rot_diff @ R(st.pose[k, 3:])
+    old_r, old_t = Rz(30.0), np.array([1.0, -2.0, 0.5])
+    dr_e = Rz(yaw(old_r) - yaw(relo_r))
+    assert np.abs(dr - dr_e).max() < 1e-8 and np.abs(dt - (old_t - dr_e @ relo_t)).max() < 1e-8
+    assert np.abs(rel_t - relo_r.T @ (Pk - relo_t)).max() < 1e-8
+    assert np.abs(R(rel_q) - relo_r.T @ Rk).max() < 1e-8
+    e = yaw(Rk) - yaw(relo_r); e = e - 360.0 * np.floor((e + 180.0) / 360.0)
+    assert abs(rel_yaw - e) < 1e-7
+    # gauge-free cross-check straight from the raw solver output
+    assert np.abs(rel_t - R(st.relo_pose[3:]).T @ (st.pose[k, :3] - st.relo_pose[:3])).max() < 1e-8

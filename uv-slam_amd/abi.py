@@ -170,6 +170,7 @@ class Window:
         self.pt_vel_i = None; self.pt_vel_j = None; self.pt_td_i = None; self.pt_td_j = None      # ProjectionTdFactor inputs (estimate_td), [n_obs,2] / [n_obs]
         # relocalization blocks (estimator.cpp:944-978): landmark index, pts_i (first observation), pts_j (match point); relo_Pose
         self.relo_pose = np.zeros(7); self.relo_pose[6] = 1.0
+        self.relo_frame = 0    # relo_frame_local_index: not an input of the solve (Estimator::double2vector reads it), carried by the window file
         self.relo_lm = np.zeros(0, np.int32); self.relo_pi = np.zeros((0, 3)); self.relo_pj = np.zeros((0, 3))
         self.line_orth = np.zeros((0, 4))
         self.ln_lm = np.zeros(0, np.int32); self.ln_fj = np.zeros(0, np.int32)
@@ -257,8 +258,8 @@ class Window:
                 for name in ("block_kind", "block_frame", "block_size", "block_idx", "x0_off"):
                     f.write(i32(list(getattr(p, name))))
                 f.write(f64(list(p.x0))); f.write(f64(p.r0())); f.write(f64(p.J0()))
-            if nrl:         # relocalization section (header word 8, bit 1): count, pad, relo_Pose, landmark indices (+pad), pts_i, pts_j
-                f.write(i32([nrl, 0])); f.write(f64(self.relo_pose)); f.write(i32(self.relo_lm))
+            if nrl:         # relocalization section (header word 8, bit 1): count, relo_frame_local_index, relo_Pose, landmark indices (+pad), pts_i, pts_j
+                f.write(i32([nrl, int(self.relo_frame)])); f.write(f64(self.relo_pose)); f.write(i32(self.relo_lm))
                 if nrl % 2: f.write(i32([0]))
                 f.write(f64(self.relo_pi)); f.write(f64(self.relo_pj))
 
@@ -300,7 +301,7 @@ class Window:
             C.memmove(p.linearized_residuals, r0.ctypes.data, r0.nbytes); C.memmove(p.linearized_jacobians, J0.ctypes.data, J0.nbytes)
             w.prior = p
         if has_relo:
-            nrl = int(take("<i4", 2)[0]); w.relo_pose = take("<f8", 7); w.relo_lm = take("<i4", nrl)
+            nrl, w.relo_frame = (int(v) for v in take("<i4", 2)); w.relo_pose = take("<f8", 7); w.relo_lm = take("<i4", nrl)
             if nrl % 2: take("<i4", 1)
             w.relo_pi = take("<f8", 3 * nrl).reshape(-1, 3); w.relo_pj = take("<f8", 3 * nrl).reshape(-1, 3)
         return w

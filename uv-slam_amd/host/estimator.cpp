@@ -21,7 +21,7 @@ void setEurocParameters() {          // config/euroc/euroc_config.yaml
     TIC.assign(1, Eigen::Vector3d(-0.0216401454975, -0.064676986768, 0.00981073058949));
 }
 
-Estimator::Estimator() : frame_count(0), first_imu(false), sum_of_back(0), sum_of_front(0), solver_flag(NON_LINEAR), marginalization_flag(MARGIN_OLD), td(0), failure_occur(false), last_marginalization_info(nullptr), solver(nullptr) {
+Estimator::Estimator() : frame_count(0), first_imu(false), sum_of_back(0), sum_of_front(0), solver_flag(NON_LINEAR), marginalization_flag(MARGIN_OLD), td(0), failure_occur(false), last_marginalization_info(nullptr), relocalization_info(false), relo_frame_stamp(0), relo_frame_index(0), relo_frame_local_index(0), relo_relative_yaw(0), solver(nullptr) {
     f_manager.Rs = Rs;      // estimator.cpp:9 `f_manager{Rs}`
     for (auto& p : pre_integrations) p = nullptr;
     for (int i = 0; i <= WINDOW_SIZE; ++i) Rs[i].setIdentity();
@@ -57,7 +57,7 @@ void Estimator::vector2double() {     // estimator.cpp:526-594
     for (int i = 0; i < f_manager.getLineFeatureCount(); i++) for (int k = 0; k < 4; ++k) para_Ortho_plucker[i][k] = get_lineOrtho.at(i)[k];
 }
 
-void Estimator::double2vector() {     // estimator.cpp:596-711 (relocalization branch :671-691 not mirrored)
+void Estimator::double2vector() {     // estimator.cpp:596-711
     using namespace Eigen;
     Vector3d origin_R0 = Utility::R2ypr(Rs[0]);
     Vector3d origin_P0 = Ps[0];
@@ -85,10 +85,37 @@ void Estimator::double2vector() {     // estimator.cpp:596-711 (relocalization b
     std::vector<Vector4d> get_lineOrtho = f_manager.getLineOrthonormal();
     for (int i = 0; i < f_manager.getLineFeatureCount(); i++) for (int k = 0; k < 4; ++k) get_lineOrtho.at(i)[k] = para_Ortho_plucker[i][k];
     f_manager.setLineOrtho(get_lineOrtho, Ps, Rs, tic[0], ric[0]);
+    if (relocalization_info) {        // relative info between two loop frames (:671-691)
+        Matrix3d relo_r = rot_diff * Quaterniond(relo_Pose[6], relo_Pose[3], relo_Pose[4], relo_Pose[5]).normalized().toRotationMatrix();
+        Vector3d relo_t = rot_diff * Vector3d(relo_Pose[0] - para_Pose[0][0], relo_Pose[1] - para_Pose[0][1], relo_Pose[2] - para_Pose[0][2]) + origin_P0;
+        const double drift_correct_yaw = Utility::R2ypr(prev_relo_r).x() - Utility::R2ypr(relo_r).x();
+        drift_correct_r = Utility::ypr2R(Vector3d(drift_correct_yaw, 0, 0));
+        drift_correct_t = prev_relo_t - drift_correct_r * relo_t;
+        relo_relative_t = relo_r.transpose() * (Ps[relo_frame_local_index] - relo_t);
+        relo_relative_q = Quaterniond(relo_r.transpose() * Rs[relo_frame_local_index]);
+        relo_relative_yaw = Utility::normalizeAngle(Utility::R2ypr(Rs[relo_frame_local_index]).x() - Utility::R2ypr(relo_r).x());
+        relocalization_info = 0;
+    }
+}
+
+void Estimator::setReloFrame(double _frame_stamp, int _frame_index, std::vector<Eigen::Vector3d>& _match_points, Eigen::Vector3d _relo_t, Eigen::Matrix3d _relo_r) {   // estimator.cpp:1361-1379
+    relo_frame_stamp = _frame_stamp;
+    relo_frame_index = _frame_index;
+    match_points.clear();
+    match_points = _match_points;
+    prev_relo_t = _relo_t;
+    prev_relo_r = _relo_r;
+    for (int i = 0; i < WINDOW_SIZE; i++) {
+        if (relo_frame_stamp == Headers[i].stamp.toSec()) {
+            relo_frame_local_index = i;
+            relocalization_info = 1;
+            for (int j = 0; j < SIZE_POSE; j++) relo_Pose[j] = para_Pose[i][j];
+        }
+    }
 }
 
 void Estimator::optimization() {      // estimator.cpp:761-1233
-    uvs::AddressMap amap{para_Pose, para_SpeedBias, para_Ex_Pose, para_Feature, para_Ortho_plucker, para_Td};
+    uvs::AddressMap amap{para_Pose, para_SpeedBias, para_Ex_Pose, para_Feature, para_Ortho_plucker, para_Td, relo_Pose};
     uvs::Problem problem(amap);
     ceres_like::LossFunction* loss_function = new ceres_like::CauchyLoss(1.0);
     ceres_like::LossFunction* line_loss_function = new ceres_like::CauchyLoss(0.1);
@@ -141,13 +168,34 @@ void Estimator::optimization() {      // estimator.cpp:761-1233
                 problem.AddResidualBlock(new VPProjectionFactor(ric[0], tic[0], it_per_frame.start_point, it_per_frame.end_point, it_per_frame.vp), vp_loss_function, para_Pose[imu_j], para_Ortho_plucker[line_feature_index]);
         }
     }
+    if (relocalization_info) {        // estimator.cpp:944-978
+        problem.AddParameterBlock(relo_Pose, SIZE_POSE, new PoseLocalParameterization());
+        int retrive_feature_index = 0;
+        int relo_feature_index = -1;
+        for (auto& it_per_id : f_manager.feature) {
+            it_per_id.used_num = it_per_id.feature_per_frame.size();
+            if (!(it_per_id.used_num >= 2 && it_per_id.start_frame < WINDOW_SIZE - 2)) continue;
+            ++relo_feature_index;
+            int start = it_per_id.start_frame;
+            if (start <= relo_frame_local_index) {
+                // (the reference reads match_points[retrive_feature_index] without a bound; an exhausted list simply matches nothing more)
+                while (retrive_feature_index < (int)match_points.size() && (int)match_points[retrive_feature_index].z() < it_per_id.feature_id) retrive_feature_index++;
+                if (retrive_feature_index < (int)match_points.size() && (int)match_points[retrive_feature_index].z() == it_per_id.feature_id) {
+                    Eigen::Vector3d pts_j = Eigen::Vector3d(match_points[retrive_feature_index].x(), match_points[retrive_feature_index].y(), 1.0);
+                    Eigen::Vector3d pts_i = it_per_id.feature_per_frame[0].point;
+                    problem.AddResidualBlock(new ProjectionFactor(pts_i, pts_j), loss_function, para_Pose[start], relo_Pose, para_Ex_Pose[0], para_Feature[relo_feature_index]);
+                    retrive_feature_index++;
+                }
+            }
+        }
+    }
     // record hook (the reference has no serialisation): UVS_DUMP_WINDOWS=<dir> writes every window exactly as the
     // solver receives it (the state after vector2double(), estimator.cpp:800) to <dir>/window_NNNN.bin for replay without ROS
     if (const char* dump_dir = std::getenv("UVS_DUMP_WINDOWS")) {
         static int dump_index = 0;
         uvs_window dw; problem.fill(&dw, feature_index + 1, line_feature_index + 1);
         char name[32]; std::snprintf(name, sizeof(name), "/window_%04d.bin", dump_index++);
-        WindowFile::save(std::string(dump_dir) + name, dw);
+        WindowFile::save(std::string(dump_dir) + name, dw, relo_frame_local_index);
     }
     uvs::Options options; options.max_num_iterations = NUM_ITERATIONS;
     uvs::Solve(options, &problem, &last_summary, solver, feature_index + 1, line_feature_index + 1);
@@ -183,6 +231,8 @@ void Estimator::clearState() {        // estimator.cpp:23-82 (the members this m
     delete last_marginalization_info; last_marginalization_info = nullptr;
     f_manager.clearState();
     failure_occur = 0;
+    relocalization_info = 0;
+    drift_correct_r = Eigen::Matrix3d::Identity(); drift_correct_t = Eigen::Vector3d::Zero();
 }
 
 void Estimator::processIMU(double dt, const Eigen::Vector3d& linear_acceleration, const Eigen::Vector3d& angular_velocity) {   // estimator.cpp:84-118

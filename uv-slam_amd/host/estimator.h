@@ -30,6 +30,7 @@ class Estimator {
     void slideWindowOld();
     bool failureDetection();
     void clearState();
+    void setReloFrame(double _frame_stamp, int _frame_index, std::vector<Eigen::Vector3d>& _match_points, Eigen::Vector3d _relo_t, Eigen::Matrix3d _relo_r);
     // initialStructure() (:224-446) itself is out of scope; the replay supplies what it would leave behind (aligned states of frames
     // 0..WINDOW_SIZE) through setInitialWindow(), and the stand-in below installs them when the window is full
     void setInitialWindow(const double (*pose)[7], const double (*speedbias)[9]);
@@ -63,6 +64,20 @@ class Estimator {
     double para_Td[1][1];
     double para_Ortho_plucker[NUM_OF_LF][SIZE_LINE_FEATURE];
     MarginalizationInfo* last_marginalization_info;
+    // relocalization variables (estimator.h:131-144)
+    bool relocalization_info;
+    double relo_frame_stamp;
+    double relo_frame_index;
+    int relo_frame_local_index;
+    std::vector<Eigen::Vector3d> match_points;
+    double relo_Pose[SIZE_POSE];
+    Eigen::Matrix3d drift_correct_r;
+    Eigen::Vector3d drift_correct_t;
+    Eigen::Vector3d prev_relo_t;
+    Eigen::Matrix3d prev_relo_r;
+    Eigen::Vector3d relo_relative_t;
+    Eigen::Quaterniond relo_relative_q;
+    double relo_relative_yaw;
     // the reference keeps a vector<double*> of the prior's parameter blocks; here the block table lives inside uvs_prior
     uvs_solver* solver;          // HIP back-end handle (created in the constructor; throws when no GPU is present)
     uvs::Summary last_summary;   // kept for diagnostics (the reference discards ceres::Solver::Summary)

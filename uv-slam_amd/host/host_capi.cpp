@@ -65,6 +65,16 @@ extern "C" int uvs_host_replay_window(const char* in_path, const char* out_path,
         }
         if (w.prior && w.prior->n > 0) { est.last_marginalization_info = new MarginalizationInfo(); est.last_marginalization_info->prior = *w.prior; }
         est.marginalization_flag = marg_flag ? Estimator::MARGIN_SECOND_NEW : Estimator::MARGIN_OLD;
+        if (w.n_relo_obs > 0) {      // relocalization blocks: what Estimator::setReloFrame (estimator.cpp:1361-1379) is handed by the pose graph
+            for (int i = 0; i <= WINDOW_SIZE; ++i) est.Headers[i].stamp.t = 100.0 + i;
+            std::vector<Eigen::Vector3d> match_points;      // (x, y, feature_id); feature ids of this harness = landmark indices
+            for (int q = 0; q < w.n_relo_obs; ++q) match_points.push_back(Eigen::Vector3d(w.relo_pj[3 * q], w.relo_pj[3 * q + 1], (double)w.relo_lm[q]));
+            est.vector2double();                             // para_Pose as the previous optimization() left it
+            // pose of the old keyframe in the pose-graph frame: any rigid transform works for the test; take a fixed yaw + shift
+            Eigen::Matrix3d old_r = Utility::ypr2R(Eigen::Vector3d(30.0, 0.0, 0.0)); Eigen::Vector3d old_t(1.0, -2.0, 0.5);
+            est.setReloFrame(100.0 + wf.relo_frame_local_index, 7, match_points, old_t, old_r);
+            std::memcpy(est.relo_Pose, w.relo_pose, sizeof(est.relo_Pose));      // replay the recorded start value exactly
+        }
         est.optimization();
         FILE* f = std::fopen(out_path, "wb"); if (!f) return -6;
         double hdr[4] = {(double)est.last_summary.status, (double)est.last_summary.report.num_iterations, est.last_summary.report.initial_cost, est.last_summary.report.final_cost};
@@ -81,6 +91,14 @@ extern "C" int uvs_host_replay_window(const char* in_path, const char* out_path,
         double pn = est.last_marginalization_info ? p.n : 0; std::fwrite(&pn, 8, 1, f);
         if (pn > 0) { std::fwrite(p.linearized_residuals, 8, p.n, f); std::fwrite(p.linearized_jacobians, 8, (size_t)p.n * p.n, f); }
         std::fwrite(&est.td, 8, 1, f);      // trailing: Estimator::td after double2vector (estimator.cpp:706-707)
+        if (w.n_relo_obs > 0) {             // then the relocalization outputs of double2vector (estimator.cpp:671-691): 7 + 9 + 3 + 3 + 4 + 1 + 1 doubles
+            std::fwrite(est.relo_Pose, 8, 7, f);
+            for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { const double v = est.drift_correct_r(r, c); std::fwrite(&v, 8, 1, f); }
+            double t[3] = {est.drift_correct_t.x(), est.drift_correct_t.y(), est.drift_correct_t.z()}; std::fwrite(t, 8, 3, f);
+            double rt[3] = {est.relo_relative_t.x(), est.relo_relative_t.y(), est.relo_relative_t.z()}; std::fwrite(rt, 8, 3, f);
+            double rq[4] = {est.relo_relative_q.x(), est.relo_relative_q.y(), est.relo_relative_q.z(), est.relo_relative_q.w()}; std::fwrite(rq, 8, 4, f);
+            double tail[2] = {est.relo_relative_yaw, est.relocalization_info ? 1.0 : 0.0}; std::fwrite(tail, 8, 2, f);
+        }
         std::fclose(f);
     } catch (const std::exception& e) { std::fprintf(stderr, "uvs_host_replay_window: %s\n", e.what()); return -7; }
     return 0;

@@ -11,10 +11,11 @@
 
 namespace uvs {
 
-struct BlockRef { int kind; int index; };      // UVS_BLOCK_* for frames; 100 = point landmark, 101 = line landmark
+struct BlockRef { int kind; int index; };      // UVS_BLOCK_* for frames; 100 = point landmark, 101 = line landmark, 102 = relo_Pose
 struct AddressMap {                             // filled by the Estimator with its para_* base addresses
     double (*pose)[SIZE_POSE]; double (*speedbias)[SIZE_SPEEDBIAS]; double (*ex_pose)[SIZE_POSE]; double (*feature)[SIZE_FEATURE];
     double (*ortho)[SIZE_LINE_FEATURE]; double (*td)[1];
+    double* relo_pose = nullptr;                // relo_Pose[SIZE_POSE] (estimator.h:137)
     BlockRef resolve(const double* p) const {
         auto in = [&](const void* base, size_t elem, int count, int* idx) { const char* b = (const char*)base; const char* q = (const char*)p; if (q < b || q >= b + elem * count) return false; *idx = (int)((q - b) / elem); return (q - b) % elem == 0; };
         int i;
@@ -24,6 +25,7 @@ struct AddressMap {                             // filled by the Estimator with 
         if (in(feature, sizeof(feature[0]), NUM_OF_F, &i)) return {100, i};
         if (in(ortho, sizeof(ortho[0]), NUM_OF_LF, &i)) return {101, i};
         if (in(td, sizeof(td[0]), 1, &i)) return {UVS_BLOCK_TD, 0};
+        if (relo_pose && p == relo_pose) return {102, 0};
         throw std::invalid_argument("uvs::Problem: parameter block is not one of the Estimator's para_* arrays");
     }
 };
@@ -54,6 +56,11 @@ class Problem {
             }
             case F_PROJECTION: {
                 ProjectionFactor* f = static_cast<ProjectionFactor*>(cost);
+                if (map.resolve(blocks.at(1)).kind == 102) {      // relocalization block (estimator.cpp:966-970): second pose block = relo_Pose
+                    relo_lm.push_back(map.resolve(blocks.at(3)).index);
+                    for (int k = 0; k < 3; ++k) { relo_pi.push_back(f->pts_i(k)); relo_pj.push_back(f->pts_j(k)); }
+                    break;
+                }
                 pt_fi.push_back(map.resolve(blocks.at(0)).index); pt_fj.push_back(map.resolve(blocks.at(1)).index); pt_lm.push_back(map.resolve(blocks.at(3)).index);
                 for (int k = 0; k < 3; ++k) { pt_pi.push_back(f->pts_i(k)); pt_pj.push_back(f->pts_j(k)); }
                 break;
@@ -94,14 +101,15 @@ class Problem {
         w->ln_lm = ln_lm.data(); w->ln_fj = ln_fj.data(); w->ln_sp = ln_sp.data(); w->ln_ep = ln_ep.data(); w->ln_has_vp = ln_has_vp.data(); w->ln_vp = ln_vp.data();
         w->n_imu = (int)imu.size(); w->imu = imu.data(); w->prior = prior;
         w->td = map.td[0][0];
+        if (!relo_lm.empty()) { w->n_relo_obs = (int)relo_lm.size(); w->relo_lm = relo_lm.data(); w->relo_pi = relo_pi.data(); w->relo_pj = relo_pj.data(); std::memcpy(w->relo_pose, map.relo_pose, sizeof(w->relo_pose)); }
         if (!pt_td_i.empty()) { w->pt_vel_i = pt_vel_i.data(); w->pt_vel_j = pt_vel_j.data(); w->pt_td_i = pt_td_i.data(); w->pt_td_j = pt_td_j.data(); }
     }
     AddressMap map;
     bool ex_constant = false;
     const uvs_prior* prior = nullptr;
     std::vector<uvs_imu_block> imu;
-    std::vector<int32_t> pt_lm, pt_fi, pt_fj, ln_lm, ln_fj, ln_has_vp;
-    std::vector<double> pt_pi, pt_pj, ln_sp, ln_ep, ln_vp, pt_vel_i, pt_vel_j, pt_td_i, pt_td_j;
+    std::vector<int32_t> pt_lm, pt_fi, pt_fj, ln_lm, ln_fj, ln_has_vp, relo_lm;
+    std::vector<double> pt_pi, pt_pj, ln_sp, ln_ep, ln_vp, pt_vel_i, pt_vel_j, pt_td_i, pt_td_j, relo_pi, relo_pj;
   private:
     std::vector<CostFunction*> owned_costs; std::vector<ceres_like::LossFunction*> owned_loss; std::vector<ceres_like::LocalParameterization*> owned_param;
 };
@@ -116,6 +124,7 @@ inline void Solve(const Options& options, Problem* problem, Summary* summary, uv
     if (summary->status != UVS_OK && summary->status != UVS_ERR_NUMERIC) return;      // like the reference, the caller ignores the summary
     std::memcpy(problem->map.pose, st.pose, sizeof(st.pose)); std::memcpy(problem->map.speedbias, st.speedbias, sizeof(st.speedbias));
     problem->map.td[0][0] = st.td;
+    if (w.n_relo_obs > 0) std::memcpy(problem->map.relo_pose, st.relo_pose, sizeof(st.relo_pose));
     std::memcpy(problem->map.ex_pose[0], st.ex_pose, sizeof(st.ex_pose));      // unchanged unless ESTIMATE_EXTRINSIC
     for (int k = 0; k < n_points; ++k) problem->map.feature[k][0] = invd[k];
     for (int k = 0; k < 4 * n_lines; ++k) (&problem->map.ortho[0][0])[k] = lines[k];

@@ -21,4 +21,9 @@ class Utility {
         Rx(0, 0) = 1; Rx(1, 1) = cos(r); Rx(1, 2) = -sin(r); Rx(2, 1) = sin(r); Rx(2, 2) = cos(r);
         return Rz * Ry * Rx;
     }
+    static double normalizeAngle(double angle_degrees) {          // :130-139
+        const double two_pi = 2.0 * 180;
+        if (angle_degrees > 0) return angle_degrees - two_pi * std::floor((angle_degrees + 180) / two_pi);
+        return angle_degrees + two_pi * std::floor((-angle_degrees + 180) / two_pi);
+    }
 };

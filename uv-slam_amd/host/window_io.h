@@ -6,7 +6,7 @@
 //   (has_td: double pt_vel_i[2npo] pt_vel_j[2npo] pt_td_i[npo] pt_td_j[npo] -- the ProjectionTdFactor inputs);
 //   double line_orth[4nl]; int32 ln_lm/fj/has_vp[nlo]; double ln_sp/ep/vp[3nlo]; imu: n_imu x (467 doubles + int32 frame_i, skip);
 //   prior (if prior_n): int32 kind/frame/size/idx/x0off[16 each]; double x0[144] r0[n] J0[n*n];
-//   (has_relo: int32 n_relo, 0; double relo_pose[7]; int32 relo_lm[n_relo] (+pad to 8 bytes); double relo_pi[3 n_relo] relo_pj[3 n_relo]
+//   (has_relo: int32 n_relo, relo_frame_local_index; double relo_pose[7]; int32 relo_lm[n_relo] (+pad to 8 bytes); double relo_pi[3 n_relo] relo_pj[3 n_relo]
 //    -- the relocalization blocks, estimator.cpp:944-978).
 // The same layout is written / read by uv-slam_amd/abi.py (Window.save / Window.load).
 #pragma once
@@ -20,6 +20,7 @@ struct WindowFile {      // owns the arrays a uvs_window points to
     uvs_window w;
     std::vector<double> inv_depth, pt_pi, pt_pj, line_orth, ln_sp, ln_ep, ln_vp, pt_vel_i, pt_vel_j, pt_td_i, pt_td_j, relo_pi, relo_pj;
     std::vector<int32_t> relo_lm;
+    int relo_frame_local_index = 0;      // not part of uvs_window (the solver does not need it); Estimator::double2vector does (estimator.cpp:683-685)
     bool has_td = false;
     std::vector<int32_t> pt_lm, pt_fi, pt_fj, ln_lm, ln_fj, ln_has_vp;
     std::vector<uvs_imu_block> imu;
@@ -62,7 +63,7 @@ struct WindowFile {      // owns the arrays a uvs_window points to
             w.imu = imu.data(); w.prior = pn > 0 ? &prior : nullptr;
             if (has_td) { w.pt_vel_i = pt_vel_i.data(); w.pt_vel_j = pt_vel_j.data(); w.pt_td_i = pt_td_i.data(); w.pt_td_j = pt_td_j.data(); }
             if (hd[7] & 2) {
-                int32_t nr[2] = {0, 0}; rd(nr, 4, 2); const int n = ok ? nr[0] : 0;
+                int32_t nr[2] = {0, 0}; rd(nr, 4, 2); const int n = ok ? nr[0] : 0; relo_frame_local_index = nr[1];
                 rd(w.relo_pose, 8, 7); relo_lm.resize(n); rd(relo_lm.data(), 4, n); if (n % 2) { int32_t pad; rd(&pad, 4, 1); }
                 relo_pi.resize(3 * n); relo_pj.resize(3 * n); rd(relo_pi.data(), 8, 3 * n); rd(relo_pj.data(), 8, 3 * n);
                 w.n_relo_obs = n; w.relo_lm = relo_lm.data(); w.relo_pi = relo_pi.data(); w.relo_pj = relo_pj.data();
@@ -72,7 +73,7 @@ struct WindowFile {      // owns the arrays a uvs_window points to
         return ok;
     }
     // the dump hook's writer: any uvs_window (e.g. the one uvs::Problem::fill() assembled after vector2double(), estimator.cpp:800)
-    static bool save(const std::string& path, const uvs_window& w) {
+    static bool save(const std::string& path, const uvs_window& w, int relo_frame = 0) {
         FILE* f = std::fopen(path.c_str(), "wb"); if (!f) return false;
         const bool td = w.pt_vel_i && w.pt_vel_j && w.pt_td_i && w.pt_td_j;
         const int np = w.n_points, npo = w.n_point_obs, nl = w.n_lines, nlo = w.n_line_obs, ni = w.n_imu, pn = w.prior ? w.prior->n : 0;
@@ -98,7 +99,7 @@ struct WindowFile {      // owns the arrays a uvs_window points to
             wr(p.x0, 8, 144); wr(p.linearized_residuals, 8, pn); wr(p.linearized_jacobians, 8, (size_t)pn * pn);
         }
         if (nrl > 0) {
-            const int32_t nr[2] = {nrl, 0}; wr(nr, 4, 2); wr(w.relo_pose, 8, 7); wr(w.relo_lm, 4, nrl); if (nrl % 2) wr(&pad, 4, 1);
+            const int32_t nr[2] = {nrl, relo_frame}; wr(nr, 4, 2); wr(w.relo_pose, 8, 7); wr(w.relo_lm, 4, nrl); if (nrl % 2) wr(&pad, 4, 1);
             wr(w.relo_pi, 8, 3 * nrl); wr(w.relo_pj, 8, 3 * nrl);
         }
         std::fclose(f);

@@ -453,6 +453,6 @@ def add_relocalization(w, relo_frame=4, fraction=0.6, offset=(0.25, 4.0), pixel_
         lms.append(lm); pis.append(o.pt_pi[k].copy())
         pjs.append(np.array([pc[0] / pc[2] + rng.normal(0, 1) * pixel_sigma / focal, pc[1] / pc[2] + rng.normal(0, 1) * pixel_sigma / focal, 1.0]))
     o.relo_lm = np.array(lms, np.int32); o.relo_pi = np.array(pis).reshape(-1, 3); o.relo_pj = np.array(pjs).reshape(-1, 3)
-    o.relo_pose = o.pose[relo_frame].copy()
+    o.relo_pose = o.pose[relo_frame].copy(); o.relo_frame = int(relo_frame)
     o.truth = dict(t); o.truth["relo_pose"] = np.r_[P, Q]
     return o
