@@ -27,6 +27,8 @@ def window_to_dict(w):
     d = {k: np.asarray(getattr(w, k)) for k in WINDOW_FIELDS}
     for f in IMU_FIELDS:
         d["imu_" + f] = np.array([np.asarray(b[f]) for b in w.imu])
+    if len(w.relo_lm):      # relocalization blocks (estimator.cpp:944-978)
+        d.update(relo_lm=np.asarray(w.relo_lm), relo_pi=np.asarray(w.relo_pi), relo_pj=np.asarray(w.relo_pj), relo_pose=np.asarray(w.relo_pose), relo_frame=np.array(w.relo_frame))
     if w.prior is not None and w.prior.n > 0:
         p = w.prior; nb = p.n_blocks
         d["prior_n"] = np.array(p.n); d["prior_J0"] = p.J0(); d["prior_r0"] = p.r0(); d["prior_x0"] = np.array(p.x0[:])
@@ -40,6 +42,8 @@ def dict_to_window(d):
     w = abi.Window()
     for k in WINDOW_FIELDS:
         setattr(w, k, np.array(d[k]))
+    if "relo_lm" in d:
+        w.relo_lm = np.array(d["relo_lm"], np.int32); w.relo_pi = np.array(d["relo_pi"]); w.relo_pj = np.array(d["relo_pj"]); w.relo_pose = np.array(d["relo_pose"]); w.relo_frame = int(d["relo_frame"])
     n = len(d["imu_sum_dt"])
     w.imu = [{f: (d["imu_" + f][b] if d["imu_" + f].ndim > 1 else d["imu_" + f][b].item()) for f in IMU_FIELDS} for b in range(n)]
     if "prior_n" in d:
@@ -63,15 +67,18 @@ def main():
         "small_noprior": uvs.synth.make_window(101, n_points=40, n_lines=10, n_tagged=8),
         "small_prior": uvs.synth.make_window(102, n_points=40, n_lines=10, n_tagged=8, with_prior=True, marginalize_fn=marg),
         "points_only": uvs.synth.make_window(103, n_points=30, n_lines=0, n_tagged=0),
+        "small_relo": uvs.synth.add_relocalization(uvs.synth.make_window(104, n_points=40, n_lines=10, n_tagged=8, with_prior=True, marginalize_fn=marg), relo_frame=5, seed=104),
     }
+    only = sys.argv[1:]
     for name, w in cases.items():
+        if only and name not in only: continue
         st, rep = orc.solve(w)
         ev = orc.evaluate(w, robust=True)
         d = window_to_dict(w)
         k = rep.num_iterations + 1
         d.update(out_pose=st.pose, out_speedbias=st.speedbias, out_inv_depth=st.inv_depth, out_line_orth=st.line_orth,
                  out_cost=np.array(rep.cost[:k]), out_radius=np.array(rep.radius[:k]), out_accepted=np.array(rep.accepted[:k]),
-                 out_final_cost=np.array(rep.final_cost), out_termination=np.array(rep.termination),
+                 out_final_cost=np.array(rep.final_cost), out_termination=np.array(rep.termination), out_relo_pose=st.relo_pose,
                  ev_cost=np.array(ev.cost), ev_pt_r=ev.pt_r, ev_ln_r=ev.ln_r, ev_vp_r=ev.vp_r, ev_imu_r=ev.imu_r,
                  ev_pt_J0=ev.pt_J[:4], ev_ln_J0=ev.ln_J[:4], ev_vp_J0=ev.vp_J[:4], ev_imu_J0=ev.imu_J[:1])
         if w.prior is not None:

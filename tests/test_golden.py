@@ -37,6 +37,7 @@ def test_oracle_reproduces_golden(oracle, name):
     assert np.allclose(np.array(rep.cost[:k]), d["out_cost"], rtol=1e-9)
     dp, da = pose_deltas(st.pose, d["out_pose"])
     assert dp < 1e-8 and da < 1e-7
+    if "relo_lm" in d: assert np.abs(st.relo_pose - d["out_relo_pose"]).max() < 1e-8
     ev = oracle.evaluate(w, robust=True)
     assert np.allclose(ev.pt_r, d["ev_pt_r"], rtol=1e-10, atol=1e-10) and np.allclose(ev.imu_r, d["ev_imu_r"], rtol=1e-9, atol=1e-7)
     assert np.allclose(ev.ln_J[:4], d["ev_ln_J0"], rtol=1e-9, atol=1e-9)
@@ -55,6 +56,7 @@ def test_hip_solver_reproduces_golden(gpu_api, name):
     dp, da = pose_deltas(st.pose, d["out_pose"])
     assert dp < 1e-4 and da < 1e-4                      # north_star tolerance: 1e-4 m / 1e-4 rad
     assert np.abs(st.speedbias - d["out_speedbias"]).max() < 1e-4
+    if "relo_lm" in d: assert np.abs(st.relo_pose - d["out_relo_pose"]).max() < 1e-4 and not np.array_equal(st.relo_pose, w.relo_pose)
     assert np.abs(st.inv_depth - d["out_inv_depth"]).max() < 1e-4 and (len(d["out_line_orth"]) == 0 or np.abs(st.line_orth - d["out_line_orth"]).max() < 1e-4)
     assert abs(ev.cost - float(d["ev_cost"])) <= 1e-9 * float(d["ev_cost"])
     assert np.allclose(ev.pt_r, d["ev_pt_r"], rtol=1e-9, atol=1e-9) and np.allclose(ev.imu_r, d["ev_imu_r"], rtol=1e-8, atol=1e-6)
