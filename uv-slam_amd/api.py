@@ -12,7 +12,7 @@ import numpy as np
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libuvs_solver.so")
+LIB_PATH = os.environ.get("UVS_SOLVER_LIB", os.path.join(_HERE, "libuvs_solver.so"))      # the override is for A/B builds of the same library (tuning experiments)
 _lib = None
 
 EXPORTS = [

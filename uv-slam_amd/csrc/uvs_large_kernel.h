@@ -34,10 +34,10 @@ __global__ __launch_bounds__(NT) void k_large_chunks(char* blob, double* ws, KOp
     __syncthreads();
     const int grp = gather_group(c);
     GAcc A; gacc_zero(A);
-    sh[L_LCOST + tid] = 0.0; sh[L_LGMAX + tid] = 0.0;
+    lacc_set(sh, 0.0, 0.0);
     const double* invd = ws + (sel ? h.w_invd1 : h.w_invd0); const double* line = ws + (sel ? h.w_line1 : h.w_line0);
     lin_chunk(c, ch, sh + L_X, invd, line, first != 0, radius, grp, A);
-    double cost = sh[L_LCOST + tid], gmax = sh[L_LGMAX + tid];
+    double cost = lacc_cost(sh), gmax = lacc_gmax(sh);
     // canonical partial [pose block][row a][8] (6 block entries, gradient, diag(J^T J)), staged in LDS so that the two halves of a
     // split block are summed in a fixed order and the HBM write is coalesced
     __syncthreads();

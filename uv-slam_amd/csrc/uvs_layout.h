@@ -46,7 +46,9 @@
 #define UVS_LN_JP 2               // pose-Jacobian rows at 2, 8, 14
 #define UVS_LN_RV 20              // VP residual, later its Schur-corrected value
 #define UVS_LN_JL 22              // line-parameter Jacobian rows at 22, 26, 30
+#ifndef UVS_NT
 #define UVS_NT 256                // threads per workgroup of the solve kernels
+#endif
 #ifndef UVS_GLANES
 #define UVS_GLANES 2                // lanes per gather group: 2 = three rows of the 6x6 block per lane, 1 = all six rows in one lane
 #endif

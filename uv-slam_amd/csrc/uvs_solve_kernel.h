@@ -44,8 +44,9 @@ static constexpr int L_CTRL = L_RED + 24;      // block_reduce uses 5 doubles pe
 static constexpr int L_PROF = L_CTRL + 32;      // per-phase cycle counters (debug launches only)
 static constexpr int L_WPROF = L_PROF + 24;     // debug sub-timers: [0..3] candidate-cost phase (stage + dx, prior residual, observations, IMU), [4..7] busy cycles of each wave in the Cholesky column phase
 static constexpr int L_LCOST = L_WPROF + 8;     // per-lane cost accumulator of the current linearization (kept in LDS, not in a register that
-static constexpr int L_LGMAX = L_LCOST + NT;    // would have to live across every phase) ; per-lane max |g_landmark|
-static constexpr int L_TOTAL = L_LGMAX + NT;
+static constexpr int LACC = NT > 256 ? NT / 256 : 1;      // lanes sharing one accumulator slot (the 512-thread build has no LDS left for one per lane)
+static constexpr int L_LGMAX = L_LCOST + NT / LACC;    // would have to live across every phase) ; per-lane max |g_landmark|
+static constexpr int L_TOTAL = L_LGMAX + NT / LACC;
 static_assert(L_TOTAL * 8 <= 160 * 1024, "LDS map exceeds the 160 KB of a CU");
 enum { P_SETUP = 0, P_OBS, P_LMPREP, P_GATHER, P_ASSEMBLE, P_CHOL, P_TRSV, P_BACKSUB, P_COST, P_MISC, P_CH_DIAG, P_CH_PANEL, P_CH_TRAIL, P_AS_IMU, P_AS_ZERO, P_AS_ADD, P_LAST };
 #define UVS_PROF(c, k) do { if ((c).o.debug && threadIdx.x == 0) { const long long now_ = clock64(); (c).sh[L_PROF + (k)] += (double)(now_ - (long long)(c).sh[L_PROF + 23]); (c).sh[L_PROF + 23] = (double)now_; } } while (0)
@@ -125,6 +126,20 @@ UVS_DEV void block_reduce(double* sh, double* s /*[4]*/, double* mx) {
     for (int k = 0; k < 4; ++k) s[k] = a[k];
     *mx = m;
 }
+
+// per-lane (or per lane pair) accumulators of the running linearization
+UVS_DEV void lacc_set(double* sh, double cost, double gmax) {
+    const int tid = threadIdx.x;
+    if (LACC == 2) { cost += __shfl_xor(cost, 1, 64); gmax = fmax(gmax, __shfl_xor(gmax, 1, 64)); }
+    if (tid % LACC == 0) { sh[L_LCOST + tid / LACC] = cost; sh[L_LGMAX + tid / LACC] = gmax; }
+}
+UVS_DEV void lacc_add(double* sh, double cost, double gmax) {
+    const int tid = threadIdx.x;
+    if (LACC == 2) { cost += __shfl_xor(cost, 1, 64); gmax = fmax(gmax, __shfl_xor(gmax, 1, 64)); }
+    if (tid % LACC == 0) { sh[L_LCOST + tid / LACC] += cost; sh[L_LGMAX + tid / LACC] = fmax(sh[L_LGMAX + tid / LACC], gmax); }
+}
+UVS_DEV double lacc_cost(const double* sh) { const int tid = threadIdx.x; return tid % LACC == 0 ? sh[L_LCOST + tid / LACC] : 0.0; }
+UVS_DEV double lacc_gmax(const double* sh) { return sh[L_LGMAX + threadIdx.x / LACC]; }
 
 struct Ctx {
     const DevWin* hdr;
@@ -943,7 +958,7 @@ UVS_DEV void lin_chunk(const Ctx& c, int ch, const double* x, const double* invd
             for (int ol = tid; ol < nob; ol += NT) { double* R = rec + (size_t)ol * PREC; R[UVS_PT_C] = R[UVS_PT_RC2]; R[UVS_PT_C + 1] = R[UVS_PT_RC2 + 1]; }
             __syncthreads();
             UVS_PROF(c, P_LMPREP);
-            sh[L_LCOST + tid] += cost; sh[L_LGMAX + tid] = fmax(sh[L_LGMAX + tid], gmax_lm);
+            lacc_add(sh, cost, gmax_lm);
             const long long tg0_ = clock64();
             if (h.td_on | h.ex_on) gather_points<true>(grp, lists, rec, acc); else gather_points<false>(grp, lists, rec, acc);
             if (c.o.debug == 2 && (tid & 63) == 0) sh[L_WPROF + 4 + (tid >> 6)] += (double)(clock64() - tg0_);
@@ -1077,7 +1092,7 @@ UVS_DEV void lin_chunk(const Ctx& c, int ch, const double* x, const double* invd
             }
             __syncthreads();
             UVS_PROF(c, P_LMPREP);
-            sh[L_LCOST + tid] += cost; sh[L_LGMAX + tid] = fmax(sh[L_LGMAX + tid], gmax_lm);
+            lacc_add(sh, cost, gmax_lm);
             gather_lines(grp, lists, rec, acc);
         }
     }
@@ -1290,11 +1305,11 @@ UVS_DEV void linearize(const Ctx& c, const double* x, const double* invd, const 
     const DevWin& h = *c.hdr;
     const int grp = gather_group(c);       // this lane's gather group: pose block | flags (uvs_layout.h: i_wblk)
     GAcc A; gacc_zero(A);
-    { const double pc = lin_prep(c, x, prep_mode); c.sh[L_LCOST + threadIdx.x] = pc; c.sh[L_LGMAX + threadIdx.x] = 0.0; }
+    { const double pc = lin_prep(c, x, prep_mode); lacc_set(c.sh, pc, 0.0); }
     for (int ch = 0; ch < h.n_chunks; ++ch) lin_chunk(c, ch, x, invd, line, first, radius, grp, A);
     ImuN N;
     const double ic = lin_imu(c, x, N);
-    lin_assemble(c, x, first, radius, grp, A, N, c.sh[L_LCOST + threadIdx.x] + ic, c.sh[L_LGMAX + threadIdx.x]);
+    lin_assemble(c, x, first, radius, grp, A, N, lacc_cost(c.sh) + ic, lacc_gmax(c.sh));
 }
 
 // ------------------------------------------------------------------ back-substitution + candidate + model terms
