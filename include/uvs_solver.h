@@ -291,6 +291,12 @@ int uvs_evaluate(uvs_solver *s, const uvs_window *w, int robust, uvs_eval *out);
 int uvs_debug_first_iteration(uvs_solver *s, const uvs_window *w, double *S_lower, double *g, double *hd, double *dd,
                               double *step, double *scal);
 
+/* Diagnostic, host only (no device is touched): packs `w` the way uvs_batch_upload() does and reports the layout:
+ * info[12] = {blob bytes, workspace doubles, landmark chunks, packed point observations (incl. relocalization blocks), relocalization
+ * blocks, doubles per point record, extra Schur slots per point landmark, LDS doubles of the fullest chunk, LDS staging capacity,
+ * largest split of a pose block, compact prior-image entries, pose blocks the prior touches}.  Same status codes as the upload. */
+int uvs_debug_pack_layout(const uvs_options *opts, const uvs_window *w, int32_t *info);
+
 /* ---- marginalization (estimator.cpp:1002-1228, marginalization_factor.cpp) ----
  * flag 0 = MARGIN_OLD, 1 = MARGIN_SECOND_NEW. `w` carries the POST-solve state
  * (the reference calls vector2double() again at :1004). Output prior is already

@@ -3,6 +3,7 @@
 No compute call is made here (there is no GPU in the build container and the library has no CPU path).
 """
 import ctypes as C
+import numpy as np
 import os
 import re
 import subprocess
@@ -78,3 +79,31 @@ def test_status_strings():
     lib = uvs.api.lib()
     assert b"no HIP device" in lib.uvs_status_string(abi.UVS_ERR_NO_DEVICE)
     assert lib.uvs_status_string(0) == b"ok"
+
+
+def test_pack_layout_host_only():
+    """uvs_debug_pack_layout: the packing of uvs_batch_upload() without a device.  Every option mix must keep its fullest chunk inside
+    the LDS staging area (the td + extrinsic capacity estimate was once an entry short per observation: only the GPU saw it)."""
+    lib = uvs.api.lib()
+    lib.uvs_debug_pack_layout.argtypes = [C.POINTER(abi.Options), C.POINTER(abi.WindowC), C.POINTER(C.c_int32)]
+    synth = uvs.synth
+    rng = np.random.default_rng(5)
+    for i in range(24):
+        npt, nln = int(rng.integers(20, 300)), int(rng.integers(0, 80))
+        w = synth.make_window(24000 + i, n_points=npt, n_lines=nln, n_tagged=int(rng.integers(0, nln + 1)), pt_track=int(rng.integers(3, 10)), ln_track=int(rng.integers(5, 10)))
+        mode = i % 4
+        o = abi.default_options()
+        if mode == 1: o.estimate_td = 1; w = synth.add_time_offset(w)
+        if mode == 2: o.estimate_extrinsic = 1; o.estimate_td = 1; w = synth.add_time_offset(w)
+        if mode == 3: w = synth.add_relocalization(w, relo_frame=int(rng.integers(0, 10)), fraction=1.0, seed=i)
+        wc, keep = w.to_c(); info = (C.c_int32 * 12)()
+        assert lib.uvs_debug_pack_layout(C.byref(o), C.byref(wc), info) == abi.UVS_OK
+        blob, wsd, nch, npo, nrelo, prec, xs, mx, cap = list(info)[:9]
+        assert 0 < mx <= cap == 17952 and nch >= 1 + (nln > 0) and blob % 256 == 0 and wsd > 0
+        assert npo == len(w.pt_lm) + len(w.relo_lm) and nrelo == len(w.relo_lm)
+        assert prec == (46 if mode == 2 else 34 if mode == 1 else 30) and xs == 1 + (mode in (1, 2)) + (mode == 2)
+    # relocalization blocks with the options they cannot share the spare slots with
+    w = synth.add_relocalization(synth.make_window(3), seed=3)
+    o = abi.default_options(); o.estimate_extrinsic = 1
+    wc, keep = w.to_c(); info = (C.c_int32 * 12)()
+    assert lib.uvs_debug_pack_layout(C.byref(o), C.byref(wc), info) == abi.UVS_ERR_UNSUPPORTED

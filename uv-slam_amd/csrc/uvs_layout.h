@@ -94,6 +94,7 @@ struct DevWin {
     int32_t ws_doubles;
     int32_t blob_bytes;
     int32_t cur_sel;                  // written by the kernel: which landmark buffer holds the final state
+    int32_t max_chunk_doubles;        // LDS doubles the fullest chunk occupies in the staging area (records + Schur factors + lists; <= UVS_S_DOUBLES; informational)
     int32_t n_parts;                  // largest number of parts any pose block is split into (informational; gacc_gather_parts sums them in one step)
 };
 

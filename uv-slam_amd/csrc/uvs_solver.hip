@@ -74,6 +74,9 @@ static KOpts make_kopts(const uvs_options& o, int debug) {
     return k;
 }
 
+struct DevWin;
+static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vector<char>& out, DevWin& hdr, std::string& err);
+
 extern "C" {
 
 int uvs_abi_version(void) { return UVS_ABI_VERSION; }
@@ -110,6 +113,17 @@ const char* uvs_status_string(int st) {
 }
 
 const char* uvs_last_error(const uvs_solver* s) { return s ? s->err.c_str() : "null solver"; }
+
+// host-only: the packing of `w` as uvs_batch_upload() would do it, nothing touches a device (CPU tests of the chunk / list layout, timing)
+int uvs_debug_pack_layout(const uvs_options* o, const uvs_window* w, int32_t* info) {
+    if (!o || !w || !info) return UVS_ERR_INVALID_ARG;
+    std::vector<char> blob; DevWin h; std::string err;
+    const int rc = pack_window(w, *o, blob, h, err);
+    if (rc != UVS_OK) return rc;
+    const int32_t v[12] = {h.blob_bytes, h.ws_doubles, h.n_chunks, h.n_pt_obs, h.n_relo, h.pt_rec, h.pt_xslots, h.max_chunk_doubles, UVS_S_DOUBLES, h.n_parts, h.n_cimg, h.n_pblk};
+    std::memcpy(info, v, sizeof(v));
+    return UVS_OK;
+}
 
 int uvs_reduced_dim(const uvs_options* o) { return 15 * UVS_NUM_FRAMES + ((o && o->estimate_extrinsic) ? 6 : 0); }
 
@@ -191,8 +205,12 @@ static int validate_window(const uvs_window* w, std::string& err) {
 
 // appends the blob of `w` to `out` (8-byte aligned) and returns its header
 static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vector<char>& out, DevWin& hdr, std::string& err) {
+    const bool prof_ = std::getenv("UVS_PACK_PROFILE") != nullptr;
+    auto t_prev_ = std::chrono::steady_clock::now();
+    auto lap_ = [&](const char* what) { if (prof_) { const auto n_ = std::chrono::steady_clock::now(); fprintf(stderr, "pack %-10s %.3f ms\n", what, std::chrono::duration<double, std::milli>(n_ - t_prev_).count()); t_prev_ = n_; } };
     int rc = validate_window(w_in, err);
     if (rc != UVS_OK) return rc;
+    lap_("validate");
     const bool td_on = opts.estimate_td != 0;
     // Relocalization blocks (estimator.cpp:944-978) become ordinary point observations whose second frame is the pseudo frame 12 = relo_Pose,
     // placed right after their landmark's last observation (the kernel wants a landmark's blocks together).  eidx maps a merged observation
@@ -288,18 +306,20 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
         if (split(0, h.n_points, pbeg, need_pt) != UVS_OK) { err = "single point landmark exceeds LDS staging"; return UVS_ERR_CAPACITY; }
         if (split(1, h.n_lines, lbeg, need_ln) != UVS_OK) { err = "single line landmark exceeds LDS staging"; return UVS_ERR_CAPACITY; }
     }
+    lap_("split");
     // gather lists per chunk and per lower 6x6 pose block (see uvs_solve_kernel.h: gather_points / gather_lines),
     // pre-expanded into LDS offsets (doubles from the staging base; the chunk layout below mirrors lin_chunk()):
     //   points: rec[nob][30] | E[(nob+nlm)][6] | EI[(nob+nlm)][6] | lists      lines: rec[nob][34] | E[nob][24] | Y[nob][24] | X[nlm][20] | lists
     //   Schur entry : offset(E row of frame a) | offset(EI / Y row of frame b) << 16
     //   direct entry: points: offset(first Jacobian block) | offset(second) << 16   (A^T A, B^T B, B^T A) ; lines: record offset
     const int n_ch = (int)chunks.size() / 6;
-    std::vector<std::vector<std::vector<int>>> sch(n_ch, std::vector<std::vector<int>>(UVS_NBLKX)), dir(n_ch, std::vector<std::vector<int>>(UVS_NBLKX));
+    // Two passes over the same generator: the first only COUNTS the entries per pose block (what the work split below needs), the second
+    // regenerates them chunk by chunk into one reused set of vectors while the lists are written.  (Keeping every chunk's entries
+    // alive between the passes cost 80 k small vectors on a configs[3]-sized window: two thirds of the packing time.)
     std::vector<long> blk_work(UVS_NBLKX, 0), blk_s(UVS_NBLKX, 0), blk_d(UVS_NBLKX, 0), blk_wp(UVS_NBLKX, 0), blk_wl(UVS_NBLKX, 0);
     auto blk_of = [](int fa, int fb) { return fa * (fa + 1) / 2 + fb; };   // fa >= fb ; fa == 11 is the time-offset pseudo frame: 66 + fb
-    for (int qc = 0; qc < n_ch; ++qc) {
+    auto chunk_entries = [&](int qc, auto&& addS, auto&& addD) {
         const int type = chunks[6 * qc], k0 = chunks[6 * qc + 1], k1 = chunks[6 * qc + 2];
-        auto& S = sch[qc]; auto& Dr = dir[qc];
         if (type == 0) {
             const int o0 = pbeg[k0], nob = pbeg[k1] - o0, nlm = k1 - k0;
             const int oE = nob * PREC, oEI = oE + 6 * (nob + XS * nlm);
@@ -313,23 +333,23 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
                 if (td_on) fr[nf++] = UVS_NUM_FRAMES;                                  // then the td slot of this landmark (pseudo frame 11)
                 if (ex_on) fr[nf++] = UVS_NUM_FRAMES + 1;                              // then its extrinsic slot (pseudo frame 12)
                 for (int sa = 0; sa < nf; ++sa) for (int sb = 0; sb <= sa; ++sb)      // frames increase with the slot => fr[sa] >= fr[sb]
-                    S[blk_of(fr[sa], fr[sb])].push_back((oE + 6 * (first_slot + sa)) | ((oEI + 6 * (first_slot + sb)) << 16));
+                    addS(blk_of(fr[sa], fr[sb]), (oE + 6 * (first_slot + sa)) | ((oEI + 6 * (first_slot + sb)) << 16));
                 for (int o = b0; o < b1; ++o) {
                     const int fi = w->pt_fi[o0 + o], fj = w->pt_fj[o0 + o], ro = o * PREC;
-                    Dr[blk_of(fi, fi)].push_back((ro + UVS_PT_A) | ((ro + UVS_PT_A) << 16));
-                    Dr[blk_of(fj, fj)].push_back((ro + UVS_PT_B) | ((ro + UVS_PT_B) << 16));
-                    Dr[blk_of(fj, fi)].push_back((ro + UVS_PT_B) | ((ro + UVS_PT_A) << 16));
+                    addD(blk_of(fi, fi), (ro + UVS_PT_A) | ((ro + UVS_PT_A) << 16));
+                    addD(blk_of(fj, fj), (ro + UVS_PT_B) | ((ro + UVS_PT_B) << 16));
+                    addD(blk_of(fj, fi), (ro + UVS_PT_B) | ((ro + UVS_PT_A) << 16));
                     if (td_on) {                                                       // J_td^T [A | B | J_td]
-                        Dr[blk_of(UVS_NUM_FRAMES, fi)].push_back((ro + UVS_PT_TD) | ((ro + UVS_PT_A) << 16));
-                        Dr[blk_of(UVS_NUM_FRAMES, fj)].push_back((ro + UVS_PT_TD) | ((ro + UVS_PT_B) << 16));
-                        Dr[blk_of(UVS_NUM_FRAMES, UVS_NUM_FRAMES)].push_back((ro + UVS_PT_TD) | ((ro + UVS_PT_TD) << 16));
+                        addD(blk_of(UVS_NUM_FRAMES, fi), (ro + UVS_PT_TD) | ((ro + UVS_PT_A) << 16));
+                        addD(blk_of(UVS_NUM_FRAMES, fj), (ro + UVS_PT_TD) | ((ro + UVS_PT_B) << 16));
+                        addD(blk_of(UVS_NUM_FRAMES, UVS_NUM_FRAMES), (ro + UVS_PT_TD) | ((ro + UVS_PT_TD) << 16));
                     }
                     if (ex_on) {                                                       // J_ex^T [A | B | J_td | J_ex]
                         const int X = UVS_NUM_FRAMES + 1;
-                        Dr[blk_of(X, fi)].push_back((ro + UVS_PT_EX) | ((ro + UVS_PT_A) << 16));
-                        Dr[blk_of(X, fj)].push_back((ro + UVS_PT_EX) | ((ro + UVS_PT_B) << 16));
-                        if (td_on) Dr[blk_of(X, UVS_NUM_FRAMES)].push_back((ro + UVS_PT_EX) | ((ro + UVS_PT_TD) << 16));
-                        Dr[blk_of(X, X)].push_back((ro + UVS_PT_EX) | ((ro + UVS_PT_EX) << 16));
+                        addD(blk_of(X, fi), (ro + UVS_PT_EX) | ((ro + UVS_PT_A) << 16));
+                        addD(blk_of(X, fj), (ro + UVS_PT_EX) | ((ro + UVS_PT_B) << 16));
+                        if (td_on) addD(blk_of(X, UVS_NUM_FRAMES), (ro + UVS_PT_EX) | ((ro + UVS_PT_TD) << 16));
+                        addD(blk_of(X, X), (ro + UVS_PT_EX) | ((ro + UVS_PT_EX) << 16));
                     }
                 }
             }
@@ -339,18 +359,24 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
             for (int k = k0; k < k1; ++k) {
                 const int b0 = lbeg[k] - o0, b1 = lbeg[k + 1] - o0;
                 for (int sa = 0; sa < b1 - b0; ++sa) for (int sb = 0; sb <= sa; ++sb)
-                    S[blk_of(w->ln_fj[o0 + b0 + sa], w->ln_fj[o0 + b0 + sb])].push_back((oE + 24 * (b0 + sa)) | ((oY + 24 * (b0 + sb)) << 16));
-                for (int o = b0; o < b1; ++o) Dr[blk_of(w->ln_fj[o0 + o], w->ln_fj[o0 + o])].push_back(o * UVS_LN_REC);
+                    addS(blk_of(w->ln_fj[o0 + b0 + sa], w->ln_fj[o0 + b0 + sb]), (oE + 24 * (b0 + sa)) | ((oY + 24 * (b0 + sb)) << 16));
+                for (int o = b0; o < b1; ++o) addD(blk_of(w->ln_fj[o0 + o], w->ln_fj[o0 + o]), o * UVS_LN_REC);
             }
         }
+    };
+    for (int qc = 0; qc < n_ch; ++qc) {
+        long cs[UVS_NBLKX] = {0}, cd[UVS_NBLKX] = {0};
+        chunk_entries(qc, [&](int b, int) { ++cs[b]; }, [&](int b, int) { ++cd[b]; });
+        const int type = chunks[6 * qc];
         // work units ~ cycles per entry of the rows-per-lane gather
         for (int b = 0; b < UVS_NBLKX; ++b) {
             // measured per entry on MI355X (per-wave timers, UVS_DEBUG_GATHER_TIMERS): point Schur 350 cycles, point direct 675 cycles
-            const long ws_ = (type == 0 ? 18 : 72) * (long)S[b].size(), wd_ = (type == 0 ? 35 : 63) * (long)Dr[b].size();
+            const long ws_ = (type == 0 ? 18 : 72) * cs[b], wd_ = (type == 0 ? 35 : 63) * cd[b];
             blk_s[b] += ws_; blk_d[b] += wd_;
             (type == 0 ? blk_wp : blk_wl)[b] += ws_ + wd_;      // per landmark family: the chunks of a family are separated by barriers
         }
     }
+    lap_("entries");
     // gather groups: 256 two-lane groups, at least one per pose block; the spare ones split the heaviest blocks further.  Groups are dealt to
     // the waves heaviest first (similar list lengths inside a wave => little divergence); the wave order pairs heavy with light
     // waves on a SIMD (waves w and w+4 share one).
@@ -407,14 +433,18 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
             g_blk[g] = b; g_part[g] = items[q].part; g_np[g] = items[q].np;
         }
     }
+    lap_("groups");
     std::vector<int> lists;
+    std::vector<std::vector<int>> eS(UVS_NBLKX), eD(UVS_NBLKX);
     for (int qc = 0; qc < n_ch; ++qc) {
+        for (int b = 0; b < UVS_NBLKX; ++b) { eS[b].clear(); eD[b].clear(); }
+        chunk_entries(qc, [&](int b, int v) { eS[b].push_back(v); }, [&](int b, int v) { eD[b].push_back(v); });
         chunks[6 * qc + 3] = (int)lists.size();
         const size_t base = lists.size();
         lists.resize(base + 2 * (UVS_NGRP + 1));
         std::vector<int> ent;
         for (int pass = 0; pass < 2; ++pass) {
-            const auto& L = pass == 0 ? sch[qc] : dir[qc];
+            const auto& L = pass == 0 ? eS : eD;
             for (int g = 0; g < UVS_NGRP; ++g) {
                 lists[base + pass * (UVS_NGRP + 1) + g] = (int)ent.size();
                 if (g_blk[g] < 0) continue;
@@ -434,6 +464,7 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
             if (type == 0) { const long nob = pbeg[k1] - pbeg[k0], nlm = k1 - k0; used = (long)PREC * nob + 12 * (nob + XS * nlm) + (nlist + 1) / 2; }
             else { const long nob = lbeg[k1] - lbeg[k0], nlm = k1 - k0; used = (long)(UVS_LN_REC + 48) * nob + 20 * nlm + (nlist + 1) / 2; }
             if (used > UVS_S_DOUBLES) { err = "internal: chunk layout exceeds the LDS staging area"; return UVS_ERR_CAPACITY; }
+            h.max_chunk_doubles = std::max(h.max_chunk_doubles, (int)used);
         }
         if (getenv("UVS_DEBUG_LISTS")) {
             fprintf(stderr, "chunk %d type %d lm [%d,%d):\n", qc, chunks[6 * qc], chunks[6 * qc + 1], chunks[6 * qc + 2]);
@@ -445,6 +476,7 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
         }
     }
     h.n_chunks = (int)chunks.size() / 6;
+    lap_("lists");
     // layout
     int d = (int)((sizeof(DevWin) + 7) / 8);
     h.d_frames = d; d += UVS_XDIM;
@@ -588,6 +620,7 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
     for (size_t q = 0; q < chunks.size(); ++q) I[h.i_chunks + q] = chunks[q];
     for (size_t q = 0; q < lists.size(); ++q) I[h.i_lists + q] = lists[q];
     for (int q = 0; q < UVS_NGRP; ++q) I[h.i_wblk + q] = wblk[q];
+    lap_("blob");
     hdr = h;
     return UVS_OK;
 }
