@@ -362,7 +362,10 @@ UVS_DEV void vp_residual(const LineGeom& g, const double* vp, double vp_factor, 
 // Raw (un-whitened) residual r[15]; if Jraw != nullptr the raw 15x30 Jacobian is written (row-major, zero-filled first).
 // Jraw (may be NULL) receives the 15 x 30 Jacobian at Jraw[row * LD + col + (col >= 15 ? GAP : 0)]; ZERO = clear the 450 entries first
 // (LD = 30, GAP = 0: dense row-major; the solve kernel uses LD = 48, GAP = 1 into a pre-zeroed, frame-padded MFMA operand tile).
-template <int LD = 30, int GAP = 0, bool ZERO = true>
+// PARTS = bit mask of the Jacobian groups to write (the solve kernel hands the four groups of a block to four different waves; every
+// group needs the same short preamble, the compiler drops what a group does not use):
+//   1 the five +-R_i^T blocks, 2 the skew blocks + the -jacobian copies + the +-1 entries, 4 blocks (3,3) and (3,12), 8 block (3,18)
+template <int LD = 30, int GAP = 0, bool ZERO = true, int PARTS = 15>
 UVS_DEV void imu_raw(const double* blk, const double* jac, const double* G, const double* pose_i, const double* sb_i,
                      const double* pose_j, const double* sb_j, double* r, double* Jraw) {
     const double sum_dt = blk[0];
@@ -427,9 +430,9 @@ UVS_DEV void imu_raw(const double* blk, const double* jac, const double* G, cons
     };
     double M[9];
     // pose_i  (imu_factor.h:94-104)
-    put(0, 0, RiT, -1.0);
-    putskew(0, 3, rap);
-    { double qji[4], Qj_inv[4]; quat_inv(Qj, Qj_inv); quat_mul(Qj_inv, Qi, qji);
+    if (PARTS & 1) put(0, 0, RiT, -1.0);
+    if (PARTS & 2) putskew(0, 3, rap);
+    if (PARTS & 4) { double qji[4], Qj_inv[4]; quat_inv(Qj, Qj_inv); quat_mul(Qj_inv, Qi, qji);
       LRbr(qji, cq, M); put(3, 3, M, -1.0);
       // speedbias_i O_R/O_BG (:128): -Qleft(Qj^-1 Qi delta_q).bottomRight * dq_dbg
       double qq[4]; quat_mul(qji, delta_q, qq);
@@ -440,9 +443,10 @@ UVS_DEV void imu_raw(const double* blk, const double* jac, const double* G, cons
 #pragma unroll
           for (int j = 0; j < 3; ++j) D[3 * i + j] = jac[UVS_IMU_JIDX(3, 12, i, j)];
       mat_mul(La, D, M); put(3, 6 + 6, M, -1.0); }
-    putskew(6, 3, rav);
+    if (PARTS & 2) putskew(6, 3, rav);
     // speedbias_i  (:119-137)
-    put(0, 6 + 0, RiT, -sum_dt);
+    if (PARTS & 1) put(0, 6 + 0, RiT, -sum_dt);
+    if (PARTS & 2)
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -452,16 +456,18 @@ UVS_DEV void imu_raw(const double* blk, const double* jac, const double* G, cons
             Jraw[(6 + i) * LD + cm(6 + 3 + j)] = -jac[UVS_IMU_JIDX(6, 9, i, j)];     // -dv_dba
             Jraw[(6 + i) * LD + cm(6 + 6 + j)] = -jac[UVS_IMU_JIDX(6, 12, i, j)];    // -dv_dbg
         }
-    put(6, 6 + 0, RiT, -1.0);
+    if (PARTS & 1) put(6, 6 + 0, RiT, -1.0);
+    if (PARTS & 2)
 #pragma unroll
     for (int i = 0; i < 3; ++i) { Jraw[(9 + i) * LD + cm(6 + 3 + i)] = -1.0; Jraw[(12 + i) * LD + cm(6 + 6 + i)] = -1.0; }
     // pose_j  (:149-155)
-    put(0, 15 + 0, RiT, 1.0);
-    { double q3[4]; quat_mul(cq_inv, qij, q3);
+    if (PARTS & 1) put(0, 15 + 0, RiT, 1.0);
+    if (PARTS & 8) { double q3[4]; quat_mul(cq_inv, qij, q3);
       double La[9] = {q3[3], -q3[2], q3[1], q3[2], q3[3], -q3[0], -q3[1], q3[0], q3[3]};
       put(3, 15 + 3, La, 1.0); }
     // speedbias_j  (:168-172)
-    put(6, 21 + 0, RiT, 1.0);
+    if (PARTS & 1) put(6, 21 + 0, RiT, 1.0);
+    if (PARTS & 2)
 #pragma unroll
     for (int i = 0; i < 3; ++i) { Jraw[(9 + i) * LD + cm(21 + 3 + i)] = 1.0; Jraw[(12 + i) * LD + cm(21 + 6 + i)] = 1.0; }
 }

@@ -802,25 +802,44 @@ UVS_DEV double lin_imu(const Ctx& c, const double* x, ImuN& N) {
     __syncthreads();      // previous users of the S region are done
     UVS_PROF(c, P_GATHER);
     double* IM = sh + L_S;
+    // the whitening matrices W (global, written by setup_window) are requested first and stored last: their latency runs beside the
+    // blocks' own loads and the raw evaluation instead of after them
+    constexpr int WPL = ((UVS_NF - 1) * 225 + NT - 1) / NT;
+    double wreg[WPL];
+#pragma unroll
+    for (int q = 0; q < WPL; ++q) {
+        const int t = tid + q * NT, tc = t < h.n_imu * 225 ? t : 0, b = tc / 225, e = tc - 225 * b;
+        wreg[q] = c.bd[h.d_imu + (size_t)b * UVS_IMU_STRIDE + UVS_IMU_W + e];
+    }
     for (int t = tid; t < h.n_imu * IMU_BLK; t += NT) IM[t] = 0.0;      // operand tiles are mostly structural zeros
     __syncthreads();
-    if (tid < h.n_imu && !c.bi[h.i_imu + 2 * tid + 1]) {
-        const int fi = c.bi[h.i_imu + 2 * tid];
-        const double* blk = c.bd + h.d_imu + (size_t)tid * UVS_IMU_STRIDE;
+    // raw residual + Jacobian of block `lane`, its four Jacobian groups on four different waves (one lane doing all of it was a 10 k-cycle
+    // serial chain with 246 lanes idle; divergent parts inside one wave would serialise just the same)
+    if (lane < h.n_imu && wv < 4 && !c.bi[h.i_imu + 2 * lane + 1]) {
+        const int fi = c.bi[h.i_imu + 2 * lane];
+        const double* blk = c.bd + h.d_imu + (size_t)lane * UVS_IMU_STRIDE;
+        double* T = IM + IMU_BLK * lane;
+        const double* pi_ = x + 7 * fi; const double* si_ = x + 77 + 9 * fi; const double* pj_ = x + 7 * (fi + 1); const double* sj_ = x + 77 + 9 * (fi + 1);
         double r[15];
-        imu_raw<IMU_JLD, 1, false>(blk, blk + UVS_IMU_JAC, c.o.G, x + 7 * fi, x + 77 + 9 * fi, x + 7 * (fi + 1), x + 77 + 9 * (fi + 1), r, IM + IMU_BLK * tid);
-        for (int i = 0; i < 15; ++i) IM[IMU_BLK * tid + i * IMU_JLD + 31] = r[i];
+        if (NW < 4) { imu_raw<IMU_JLD, 1, false>(blk, blk + UVS_IMU_JAC, c.o.G, pi_, si_, pj_, sj_, r, T); for (int i = 0; i < 15; ++i) T[i * IMU_JLD + 31] = r[i]; }
+        else if (wv == 0) { imu_raw<IMU_JLD, 1, false, 1>(blk, blk + UVS_IMU_JAC, c.o.G, pi_, si_, pj_, sj_, r, T); for (int i = 0; i < 15; ++i) T[i * IMU_JLD + 31] = r[i]; }
+        else if (wv == 1) imu_raw<IMU_JLD, 1, false, 2>(blk, blk + UVS_IMU_JAC, c.o.G, pi_, si_, pj_, sj_, r, T);
+        else if (wv == 2) imu_raw<IMU_JLD, 1, false, 4>(blk, blk + UVS_IMU_JAC, c.o.G, pi_, si_, pj_, sj_, r, T);
+        else imu_raw<IMU_JLD, 1, false, 8>(blk, blk + UVS_IMU_JAC, c.o.G, pi_, si_, pj_, sj_, r, T);
     }
-    for (int t = tid; t < h.n_imu * 225; t += NT) {
-        const int b = t / 225, e = t - 225 * b, i = e / 15, k = e - 15 * i;
-        IM[IMU_BLK * b + IMU_WOFF + i * UVS_BLK_LD + k] = c.bd[h.d_imu + (size_t)b * UVS_IMU_STRIDE + UVS_IMU_W + e];
+#pragma unroll
+    for (int q = 0; q < WPL; ++q) {
+        const int t = tid + q * NT;
+        if (t < h.n_imu * 225) { const int b = t / 225, e = t - 225 * b, i = e / 15, k = e - 15 * i; IM[IMU_BLK * b + IMU_WOFF + i * UVS_BLK_LD + k] = wreg[q]; }
     }
     __syncthreads();
+    // stage 1 for all of this wave's blocks, ONE wave-level hand-over, then stage 2: the LDS round trips and MFMA drains of the slots overlap
+    bool act[IMU_SLOTS];
 #pragma unroll
     for (int s = 0; s < IMU_SLOTS; ++s) {
         const int b = wv + s * NW;
-        d4_t n00 = {0.0, 0.0, 0.0, 0.0}, n10 = n00, n11 = n00;
-        if (b < h.n_imu && !c.bi[h.i_imu + 2 * b + 1]) {
+        act[s] = b < h.n_imu && !c.bi[h.i_imu + 2 * (b < h.n_imu ? b : 0) + 1];
+        if (act[s]) {
             double* Jb = IM + IMU_BLK * b; const double* Wb = Jb + IMU_WOFF;
             d4_t t0 = {0.0, 0.0, 0.0, 0.0}, t1 = t0;
             double wa[4], j0[4], j1[4];
@@ -831,9 +850,16 @@ UVS_DEV double lin_imu(const Ctx& c, const double* x, ImuN& N) {
             // T overwrites Jaug in place (all of this wave's reads of it are consumed above), C layout: row = lk + 4q, col = li
 #pragma unroll
             for (int q = 0; q < 4; ++q) { Jb[(lk + 4 * q) * IMU_JLD + li] = t0[q]; Jb[(lk + 4 * q) * IMU_JLD + 16 + li] = t1[q]; }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+    wave_sync();
+#pragma unroll
+    for (int s = 0; s < IMU_SLOTS; ++s) {
+        const int b = wv + s * NW;
+        d4_t n00 = {0.0, 0.0, 0.0, 0.0}, n10 = n00, n11 = n00;
+        if (act[s]) {
+            const double* Jb = IM + IMU_BLK * b;
+            double j0[4], j1[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) { j0[q] = Jb[(4 * q + lk) * IMU_JLD + li]; j1[q] = Jb[(4 * q + lk) * IMU_JLD + 16 + li]; }
 #pragma unroll
