@@ -1014,7 +1014,7 @@ UVS_DEV void lin_chunk(const Ctx& c, int ch, const double* x, const double* invd
                 for (int q = 0; q < 12; ++q) R[UVS_LN_JP + q] = sc * Jp[q];
 #pragma unroll
                 for (int q = 0; q < 8; ++q) R[UVS_LN_JL + q] = sc * Jl[q];
-                R[UVS_LN_RV + 1] = 0.0;
+                R[UVS_LN_RV + 1] = (double)(lm - k0);      // pad slot: the chunk-local line index, for pass B2
                 if (hv) {
                     double rv, Jvp[6], Jvl[4];
                     vp_residual<true>(g, vp, c.o.vp_factor, &rv, Jvp, Jvl);
@@ -1038,6 +1038,11 @@ UVS_DEV void lin_chunk(const Ctx& c, int ch, const double* x, const double* invd
             for (int li = tid; li < nlm; li += NT) {
                 const int k = k0 + li, b0 = beg[k] - o0, b1 = beg[k + 1] - o0;
                 double H[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, gl[4] = {0, 0, 0, 0};   // lower packed (0,0)(1,0)(1,1)(2,0)...
+                double scl[4] = {1.0, 1.0, 1.0, 1.0};      // Jacobi scales: requested before the accumulation loop, used after it
+                if (!first) {
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) scl[a] = c.ws[h.w_scale_ln + 4 * k + a];
+                }
                 for (int o = b0; o < b1; ++o) {
                     const double* R = rec + (size_t)o * UVS_LN_REC;
 #pragma unroll
@@ -1052,7 +1057,7 @@ UVS_DEV void lin_chunk(const Ctx& c, int ch, const double* x, const double* invd
                 for (int a = 0; a < 4; ++a) {
                     const double hd = H[(a * (a + 1)) / 2 + a];
                     double sc;
-                    if (first) { sc = c.o.jacobi ? 1.0 / (1.0 + sqrt(hd)) : 1.0; c.ws[h.w_scale_ln + 4 * k + a] = sc; } else sc = c.ws[h.w_scale_ln + 4 * k + a];
+                    if (first) { sc = c.o.jacobi ? 1.0 / (1.0 + sqrt(hd)) : 1.0; c.ws[h.w_scale_ln + 4 * k + a] = sc; } else sc = scl[a];
                     const double dd = fmin(fmax(sc * sc * hd, c.o.dlo), c.o.dhi) / (radius * sc * sc);
                     H[(a * (a + 1)) / 2 + a] = hd + dd;
                     lx[4 + a] = gl[a]; lx[8 + a] = dd;
@@ -1062,11 +1067,14 @@ UVS_DEV void lin_chunk(const Ctx& c, int ch, const double* x, const double* invd
                 // one reciprocal per pivot (an FP64 division is ~30 instructions; the 4x4 factor + explicit inverse had 26 of them on ONE lane per
                 // line while the other lanes of the workgroup wait)
                 double L[10];
-                L[0] = sqrt(H[0]); const double i0 = 1.0 / L[0];
-                L[1] = H[1] * i0; L[2] = sqrt(H[2] - L[1] * L[1]); const double i1 = 1.0 / L[2];
-                L[3] = H[3] * i0; L[4] = (H[4] - L[3] * L[1]) * i1; L[5] = sqrt(H[5] - L[3] * L[3] - L[4] * L[4]); const double i2 = 1.0 / L[5];
+                // pivots: sqrt and reciprocal sqrt together from the hardware seed + FMA-only refinement (rsqrt_pair): the sqrt / divide pairs were
+                // ~60 dependent instructions per pivot on the one lane that owns the line
+                double i0, i1, i2, i3;
+                rsqrt_pair(H[0], &L[0], &i0);
+                L[1] = H[1] * i0; rsqrt_pair(H[2] - L[1] * L[1], &L[2], &i1);
+                L[3] = H[3] * i0; L[4] = (H[4] - L[3] * L[1]) * i1; rsqrt_pair(H[5] - L[3] * L[3] - L[4] * L[4], &L[5], &i2);
                 L[6] = H[6] * i0; L[7] = (H[7] - L[6] * L[1]) * i1; L[8] = (H[8] - L[6] * L[3] - L[7] * L[4]) * i2;
-                L[9] = sqrt(H[9] - L[6] * L[6] - L[7] * L[7] - L[8] * L[8]); const double i3 = 1.0 / L[9];
+                rsqrt_pair(H[9] - L[6] * L[6] - L[7] * L[7] - L[8] * L[8], &L[9], &i3);
                 double* X = Xb + 20 * li;
                 double hg[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -1090,8 +1098,8 @@ UVS_DEV void lin_chunk(const Ctx& c, int ch, const double* x, const double* invd
             __syncthreads();
             // pass B2: one lane per line observation: E and Y = Hinv E
             for (int o = tid; o < nob; o += NT) {
-                const int li = c.bi[h.i_ln_lm + o0 + o] - k0;
                 double* R = rec + (size_t)o * UVS_LN_REC;
+                const int li = (int)R[UVS_LN_RV + 1];
                 double* E = Eb + (size_t)o * 24; double* Y = Yb + (size_t)o * 24;
                 double* Yg = c.ws + h.w_ln_Y + 24 * (size_t)(o0 + o);
                 // all LDS reads BEFORE the first LDS write (the compiler must assume the E / Y stores alias the record)
