@@ -1433,15 +1433,16 @@ UVS_DEV void backsub_candidate(const Ctx& c, const double* invd, const double* l
         gd += px[1] * (dl + t); dd2 += px[2] * dl * dl; step2 += dl * dl; xc2 += v * v;
     }
     // lines: delta(4) = -Hinv g - sum_s Y[s] delta_pose
+    constexpr int LNB = 4;
     const int* lbeg = c.bi + h.i_ln_beg;
     for (int k = lk0 + tid; k < lk1; k += NT) {
         const int b0 = lbeg[k], b1 = lbeg[k + 1];
         const double* lx = c.ws + h.w_ln_x + 12 * (size_t)k;
         double t[4] = {0.0, 0.0, 0.0, 0.0};
-        for (int o = b0; o < b1; o += 2) {      // two observations per batch (2 x 24 independent loads)
-            int fr[2]; double yv[2][24];
+        for (int o = b0; o < b1; o += LNB) {      // LNB observations per batch (LNB x 24 independent loads: one round trip per batch)
+            int fr[LNB]; double yv[LNB][24];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < LNB; ++u) {
                 const int oc = o + u < b1 ? o + u : o;
                 fr[u] = c.bi[h.i_ln_fj + oc];
                 const double* Y = c.ws + h.w_ln_Y + 24 * (size_t)oc;
@@ -1449,7 +1450,7 @@ UVS_DEV void backsub_candidate(const Ctx& c, const double* invd, const double* l
                 for (int q = 0; q < 24; ++q) yv[u][q] = Y[q];
             }
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < LNB; ++u) {
                 if (o + u >= b1) continue;
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
