@@ -135,7 +135,7 @@ def main():
                     "algorithmic_bytes_per_launch": bytes_per_launch, "hbm_achieved_GBps": ach_gbs, "hbm_frac": ach_gbs / HBM_PEAK_GBS,
                     "note": "'mfma' bound = FP64 FLOP roof 78.6 TF/s (FP64 MFMA rate = FP64 vector rate on MI355X); flop/byte model of SURVEY.md 8d; "
                             "dense reduced solve + IMU blocks run on v_mfma_f64_16x16x4_f64, the sparse 6x6 Schur gather on VALU; the kernel is latency bound "
-                            "(rocprofv3: 59% of wave cycles in SQ_WAIT_ANY, profiles/r01l_pmc_summary.json); traffic = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 of the same command (8 B/lane calibration: profiles/fetch_calibration.txt)"}
+                            "(rocprofv3: 59% of wave cycles in SQ_WAIT_ANY, profiles/r01m_pmc_summary.json); traffic = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 of the same command (8 B/lane calibration: profiles/fetch_calibration.txt)"}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
