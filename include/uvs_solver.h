@@ -282,7 +282,9 @@ int uvs_batch_upload(uvs_solver *s, int n, const uvs_window *const *ws);
 int uvs_batch_solve(uvs_solver *s, float *elapsed_ms);
 int uvs_batch_download(uvs_solver *s, int n, uvs_state *states, uvs_report *reps);
 
-/* One evaluation of every residual block at the window's state (no solve). */
+/* One evaluation of every residual block at the window's state (no solve).  Relocalization blocks (n_relo_obs) are solve-only: they are
+ * neither evaluated here nor marginalized below (the reference's marginalization does not add them, estimator.cpp:1002-1228), and the
+ * per-observation outputs keep the caller's numbering. */
 int uvs_evaluate(uvs_solver *s, const uvs_window *w, int robust, uvs_eval *out);
 
 /* Diagnostic (parity tests only): reduced system of the FIRST LM iteration of `w`:
