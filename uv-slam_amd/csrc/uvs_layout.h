@@ -49,6 +49,9 @@
 #ifndef UVS_NT
 #define UVS_NT 256                // threads per workgroup of the solve kernels
 #endif
+#if UVS_NT != 256 && !defined(UVS_ALLOW_EXPERIMENTAL_NT)
+#error "only the 256-thread workgroup is validated: the 512-thread build is an occupancy experiment (DESIGN.md 6b) whose results differ; define UVS_ALLOW_EXPERIMENTAL_NT to build it anyway"
+#endif
 #ifndef UVS_GLANES
 #define UVS_GLANES 2                // lanes per gather group: 2 = three rows of the 6x6 block per lane, 1 = all six rows in one lane
 #endif
