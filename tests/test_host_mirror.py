@@ -35,6 +35,23 @@ def test_window_file_roundtrip(oracle):
     assert np.isclose(out[10], w.prior.J0().sum()) and out[11] == (w.pt_lm + 3 * w.pt_fi + 7 * w.pt_fj).sum()
 
 
+def test_window_file_roundtrip_with_relocalization_section():
+    """The optional relocalization section (header flag 2): python writer -> C++ reader, and an old-style file still loads."""
+    w = synth.add_relocalization(synth.make_window(33, n_points=30, n_lines=5, n_tagged=3), relo_frame=6, seed=33)
+    lib = _host(); lib.uvs_host_window_probe_relo.argtypes = [C.c_char_p, abi.c_double_p]; lib.uvs_host_window_probe_relo.restype = C.c_int
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "w.uvsw"); w.save(path)
+        out = np.zeros(4); base = np.zeros(12)
+        assert lib.uvs_host_window_probe_relo(path.encode(), out.ctypes.data_as(abi.c_double_p)) == 0
+        assert lib.uvs_host_window_probe(path.encode(), base.ctypes.data_as(abi.c_double_p)) == 0
+        plain = synth.make_window(33, n_points=30, n_lines=5, n_tagged=3); p2 = os.path.join(d, "p.uvsw"); plain.save(p2)
+        out0 = np.ones(4)
+        assert lib.uvs_host_window_probe_relo(p2.encode(), out0.ctypes.data_as(abi.c_double_p)) == 0
+    assert out[0] == len(w.relo_lm) > 0 and out[1] == 6 and out[3] == w.relo_lm.sum()
+    assert np.isclose(out[2], w.relo_pose.sum() + (w.relo_pi + 2.0 * w.relo_pj).sum())
+    assert base[1] == len(w.pt_lm) and out0[0] == 0
+
+
 @pytest.mark.gpu
 def test_estimator_optimization_matches_direct_solve(gpu_api):
     """Estimator::optimization() (host mirror: uvs::Problem -> uvs_solve_window -> double2vector -> uvs_marginalize) against

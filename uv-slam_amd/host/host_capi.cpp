@@ -119,6 +119,19 @@ extern "C" int uvs_host_window_probe(const char* path, double* out /*[12]*/) {
     return 0;
 }
 
+// same for the relocalization section of a window file: count, relo_frame_local_index, checksums
+extern "C" int uvs_host_window_probe_relo(const char* path, double* out /*[4]*/) {
+    WindowFile wf;
+    if (!wf.load(path)) return -1;
+    const uvs_window& w = wf.w;
+    out[0] = w.n_relo_obs; out[1] = wf.relo_frame_local_index;
+    double s = 0; for (int k = 0; k < 7; ++k) s += w.relo_pose[k];
+    for (int k = 0; k < 3 * w.n_relo_obs; ++k) s += w.relo_pi[k] + 2.0 * w.relo_pj[k];
+    out[2] = s;
+    s = 0; for (int k = 0; k < w.n_relo_obs; ++k) s += w.relo_lm[k]; out[3] = s;
+    return 0;
+}
+
 // CPU-only hook for the FeatureManager producers: triangulate() / triangulateLine() on flat arrays.
 //   poses[11][7] = (p, q xyzw) ; ex[7] ; point tracks: pt_start[n_pt], pt_nobs[n_pt], pt_obs (concatenated normalized-plane xyz) ;
 //   line tracks: ln_start[n_ln], ln_nobs[n_ln], ln_sp / ln_ep (concatenated xyz).  depth_io[n_pt]: <= 0 means "not triangulated yet";
