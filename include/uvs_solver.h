@@ -118,6 +118,7 @@ typedef struct uvs_imu_block {
  * block_idx[b] (already minus m), linearization point x0 at x0[x0_off[b]..].
  * linearized_jacobians is n x n ROW-major. */
 enum { UVS_BLOCK_POSE = 0, UVS_BLOCK_SPEEDBIAS = 1, UVS_BLOCK_EX_POSE = 2, UVS_BLOCK_TD = 3 };
+#define UVS_PRIOR_X0_LEN (UVS_MAX_PRIOR_BLOCKS * 9)
 typedef struct uvs_prior {
     int32_t n;                         /* 0 => no prior (last_marginalization_info == nullptr) */
     int32_t n_blocks;
@@ -126,7 +127,7 @@ typedef struct uvs_prior {
     int32_t block_size[UVS_MAX_PRIOR_BLOCKS];   /* keep_block_size (global size 7/9/1)        */
     int32_t block_idx[UVS_MAX_PRIOR_BLOCKS];    /* keep_block_idx - m (local column offset)   */
     int32_t x0_off[UVS_MAX_PRIOR_BLOCKS];       /* offset of keep_block_data in x0[]          */
-    double x0[UVS_MAX_PRIOR_BLOCKS * 9];
+    double x0[UVS_PRIOR_X0_LEN];
     double linearized_residuals[UVS_MAX_PRIOR_DIM];
     double linearized_jacobians[UVS_MAX_PRIOR_DIM * UVS_MAX_PRIOR_DIM];  /* row-major, leading dim n */
 } uvs_prior;
@@ -289,7 +290,9 @@ int uvs_evaluate(uvs_solver *s, const uvs_window *w, int robust, uvs_eval *out);
 
 /* Diagnostic (parity tests only): reduced system of the FIRST LM iteration of `w`:
  * S_lower[176*176] row-major = damped, landmark-Schur-reduced frame system in the padded index space
- * (16*frame + dof, dof 15 = dummy pivot), g/hd/dd/step[176], scal[24] = {cost, gmax, chol_ok, model_cost_change, step_norm^2, -, -, -, per-phase shader cycles[10]}. */
+ * (16*frame + dof, dof 15 = dummy pivot), g/hd/dd/step[176], scal[UVS_DEBUG_SCAL_LEN] = {cost, gmax, chol_ok, model_cost_change,
+ * step_norm^2, -, -, -, per-phase shader cycles[16], sub-timers[8], -...}: the caller's buffer must hold UVS_DEBUG_SCAL_LEN doubles. */
+#define UVS_DEBUG_SCAL_LEN 40
 int uvs_debug_first_iteration(uvs_solver *s, const uvs_window *w, double *S_lower, double *g, double *hd, double *dd,
                               double *step, double *scal);
 

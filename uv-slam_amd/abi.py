@@ -275,6 +275,9 @@ class Window:
 
         np_, npo, nl, nlo, ni, pn, pnb, flags = (int(v) for v in take("<i4", 8))
         has_td, has_relo = flags & 1, flags & 2
+        # header counts are untrusted: the prior lands in fixed-size ctypes arrays
+        if min(np_, npo, nl, nlo, ni, pn, pnb) < 0 or ni > NUM_FRAMES - 1 or pn > MAX_PRIOR_DIM or pnb > MAX_PRIOR_BLOCKS:
+            raise ValueError("corrupt window file header: %s" % path)
         w = Window()
         w.pose = take("<f8", 77).reshape(NUM_FRAMES, 7); w.speedbias = take("<f8", 99).reshape(NUM_FRAMES, 9); w.ex_pose = take("<f8", 7); w.td = float(take("<f8", 1)[0])
         w.inv_depth = take("<f8", np_)

@@ -113,8 +113,6 @@ static int run_evaluate(int device, hipStream_t stream, char* d_blob, double* d_
     const size_t npo = (size_t)std::max(h.n_pt_obs, 1), nlo = (size_t)std::max(h.n_ln_obs, 1), ni = (size_t)std::max(h.n_imu, 1);
     const size_t sizes[11] = {2 * npo, 38 * npo, 2 * nlo, 20 * nlo, nlo, 10 * nlo, 15 * ni, 450 * ni, (size_t)UVS_MAX_PRIOR_DIM, 8, 2 * npo};
     size_t tot = 0; for (size_t v : sizes) tot += v;
-    static bool attr = false;
-    if (!attr) { if (!chk(hipFuncSetAttribute((const void*)k_evaluate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES), "hipFuncSetAttribute")) return UVS_ERR_HIP; attr = true; }
     if (sc.cap < tot) {
         if (sc.d) (void)hipFree(sc.d);
         sc.d = nullptr; sc.cap = 0;

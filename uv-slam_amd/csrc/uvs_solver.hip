@@ -52,6 +52,7 @@ struct uvs_solver {
         double *d_state = nullptr, *d_partials = nullptr, *d_reduced = nullptr, *d_bsums = nullptr, *d_out = nullptr, *d_sc5 = nullptr;
         size_t cap_partials = 0, cap_bsums = 0;
         uvs_report rep;
+        double relo_pose_in[7] = {0, 0, 0, 0, 0, 0, 0};      // passes through to uvs_large_finish (this path takes no relocalization blocks)
     } L;
 };
 
@@ -142,7 +143,9 @@ int uvs_create(const uvs_options* opts, int device, int max_batch, int max_point
     unsigned char fa[UVS_NBLK], fb[UVS_NBLK];
     for (int i = 0, b = 0; i < UVS_NF; ++i) for (int j = 0; j <= i; ++j, ++b) { fa[b] = (unsigned char)i; fb[b] = (unsigned char)j; }
     if (hipMemcpyToSymbol(HIP_SYMBOL(c_blk_fa), fa, sizeof(fa)) != hipSuccess || hipMemcpyToSymbol(HIP_SYMBOL(c_blk_fb), fb, sizeof(fb)) != hipSuccess) { delete s; return UVS_ERR_HIP; }
-    if (hipFuncSetAttribute((const void*)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES) != hipSuccess) { delete s; return UVS_ERR_HIP; }
+    // the LDS opt-in is a per-device function attribute: every handle sets it for its own device (the current one since hipSetDevice above)
+    for (const void* fn : {(const void*)k_solve, (const void*)k_evaluate, (const void*)k_large_chunks, (const void*)k_large_solve, (const void*)k_large_backsub})
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES) != hipSuccess) { delete s; return UVS_ERR_HIP; }
     *out = s;
     return UVS_OK;
 }
@@ -194,7 +197,12 @@ static int validate_window(const uvs_window* w, std::string& err) {
     if (w->prior && w->prior->n > 0) {
         const uvs_prior& p = *w->prior;
         if (p.n > UVS_MAX_PRIOR_DIM || p.n_blocks < 1 || p.n_blocks > UVS_MAX_PRIOR_BLOCKS) { err = "prior too large"; return UVS_ERR_CAPACITY; }
+        if (!p.linearized_jacobians || !p.linearized_residuals || !p.x0) { err = "null array"; return UVS_ERR_INVALID_ARG; }
         for (int b = 0; b < p.n_blocks; ++b) {
+            // kind <-> global size: pose / extrinsic 7, speed-bias 9, time offset 1; x0_off addresses x0[UVS_PRIOR_X0_LEN]
+            const int kind = p.block_kind[b], want = kind == UVS_BLOCK_SPEEDBIAS ? 9 : kind == UVS_BLOCK_TD ? 1 : 7;
+            if (kind < UVS_BLOCK_POSE || kind > UVS_BLOCK_TD || p.block_size[b] != want) { err = "prior block kind / size mismatch"; return UVS_ERR_INVALID_ARG; }
+            if (p.x0_off[b] < 0 || p.x0_off[b] > UVS_PRIOR_X0_LEN - p.block_size[b]) { err = "prior x0 offset out of range"; return UVS_ERR_INVALID_ARG; }
             const int loc = p.block_size[b] == 7 ? 6 : p.block_size[b];
             if (p.block_idx[b] < 0 || p.block_idx[b] + loc > p.n) { err = "prior block index out of range"; return UVS_ERR_INVALID_ARG; }
             if ((p.block_kind[b] == UVS_BLOCK_POSE || p.block_kind[b] == UVS_BLOCK_SPEEDBIAS) && (p.block_frame[b] < 0 || p.block_frame[b] >= UVS_NUM_FRAMES)) { err = "prior frame out of range"; return UVS_ERR_INVALID_ARG; }
@@ -501,7 +509,12 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
     if (have_prior) {
         int inv_s[UVS_RD]; for (int q = 0; q < UVS_RD; ++q) inv_s[q] = -1;
         const uvs_prior& p = *w->prior;
+        if (!p.linearized_jacobians || !p.linearized_residuals || !p.x0) { err = "null array"; return UVS_ERR_INVALID_ARG; }
         for (int b = 0; b < p.n_blocks; ++b) {
+            // kind <-> global size: pose / extrinsic 7, speed-bias 9, time offset 1; x0_off addresses x0[UVS_PRIOR_X0_LEN]
+            const int kind = p.block_kind[b], want = kind == UVS_BLOCK_SPEEDBIAS ? 9 : kind == UVS_BLOCK_TD ? 1 : 7;
+            if (kind < UVS_BLOCK_POSE || kind > UVS_BLOCK_TD || p.block_size[b] != want) { err = "prior block kind / size mismatch"; return UVS_ERR_INVALID_ARG; }
+            if (p.x0_off[b] < 0 || p.x0_off[b] > UVS_PRIOR_X0_LEN - p.block_size[b]) { err = "prior x0 offset out of range"; return UVS_ERR_INVALID_ARG; }
             const int loc = p.block_size[b] == 7 ? 6 : p.block_size[b];
             int basecol = -1;
             if (p.block_kind[b] == UVS_BLOCK_POSE) basecol = 16 * p.block_frame[b];
@@ -727,7 +740,7 @@ int uvs_solve_window(uvs_solver* s, const uvs_window* w, uvs_state* out, uvs_rep
 }
 
 // Diagnostic entry (parity tests): reduced system of the FIRST linearization of window 0 of the uploaded batch.
-// S_lower[176*176] row-major (damped, landmark-Schur-reduced, padded index 16*frame+dof), g/hd/dd/step[176], scal[8].
+// S_lower[176*176] row-major (damped, landmark-Schur-reduced, padded index 16*frame+dof), g/hd/dd/step[176], scal[UVS_DEBUG_SCAL_LEN].
 int uvs_debug_first_iteration(uvs_solver* s, const uvs_window* w, double* S_lower, double* g, double* hd, double* dd, double* step, double* scal) {
     if (!s || !w) return UVS_ERR_INVALID_ARG;
     const uvs_window* arr[1] = {w};
@@ -741,7 +754,7 @@ int uvs_debug_first_iteration(uvs_solver* s, const uvs_window* w, double* S_lowe
     if (hd) HIPCHK(s, hipMemcpy(hd, s->d_dbg + nS + UVS_RD, UVS_RD * 8, hipMemcpyDeviceToHost));
     if (dd) HIPCHK(s, hipMemcpy(dd, s->d_dbg + nS + 2 * UVS_RD, UVS_RD * 8, hipMemcpyDeviceToHost));
     if (step) HIPCHK(s, hipMemcpy(step, s->d_dbg + nS + 3 * UVS_RD, UVS_RD * 8, hipMemcpyDeviceToHost));
-    if (scal) HIPCHK(s, hipMemcpy(scal, s->d_dbg + nS + 4 * UVS_RD, 40 * 8, hipMemcpyDeviceToHost));
+    if (scal) HIPCHK(s, hipMemcpy(scal, s->d_dbg + nS + 4 * UVS_RD, UVS_DEBUG_SCAL_LEN * 8, hipMemcpyDeviceToHost));
     return UVS_OK;
 }
 
@@ -819,13 +832,7 @@ int uvs_large_begin(uvs_solver* s, const uvs_window* w) {
     for (int k = 0; k < 4 * w->n_lines; ++k) l2 += w->line_orth[k] * w->line_orth[k];
     L.local_x2 = l2; L.x_norm = std::sqrt(x2 + l2);
     std::memset(&L.rep, 0, sizeof(L.rep));
-    static bool attr = false;
-    if (!attr) {
-        HIPCHK(s, hipFuncSetAttribute((const void*)k_large_chunks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
-        HIPCHK(s, hipFuncSetAttribute((const void*)k_large_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
-        HIPCHK(s, hipFuncSetAttribute((const void*)k_large_backsub, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
-        attr = true;
-    }
+    std::memcpy(L.relo_pose_in, w->relo_pose, sizeof(L.relo_pose_in));
     HIPCHK(s, hipStreamSynchronize(s->stream));
     return UVS_OK;
 }
@@ -939,7 +946,7 @@ int uvs_large_finish(uvs_solver* s, uvs_state* out, uvs_report* rep) {
     double fr[184];
     HIPCHK(s, hipMemcpy(fr, L.d_state + LS_X, sizeof(fr), hipMemcpyDeviceToHost));
     std::memcpy(out->pose, fr, 77 * 8); std::memcpy(out->speedbias, fr + 77, 99 * 8); std::memcpy(out->ex_pose, fr + 176, 7 * 8); out->td = fr[183];
-    std::memset(out->relo_pose, 0, sizeof(out->relo_pose));
+    std::memcpy(out->relo_pose, L.relo_pose_in, sizeof(out->relo_pose));      // the large path takes no relocalization blocks: the input value passes through
     if (out->inv_depth && h.n_points) HIPCHK(s, hipMemcpy(out->inv_depth, s->d_ws + (L.sel ? h.w_invd1 : h.w_invd0), (size_t)h.n_points * 8, hipMemcpyDeviceToHost));
     if (out->line_orth && h.n_lines) HIPCHK(s, hipMemcpy(out->line_orth, s->d_ws + (L.sel ? h.w_line1 : h.w_line0), (size_t)h.n_lines * 32, hipMemcpyDeviceToHost));
     L.active = false;

@@ -32,86 +32,102 @@ Estimator::Estimator() : frame_count(0), first_imu(false), sum_of_back(0), sum_o
 }
 Estimator::~Estimator() { uvs_destroy(solver); delete last_marginalization_info; for (auto* p : pre_integrations) delete p; }
 
-void Estimator::setParameter() {      // estimator.cpp:9-21
-    for (int i = 0; i < NUM_OF_CAM; i++) { tic[i] = TIC[i]; ric[i] = RIC[i]; }
-    ProjectionFactor::sqrt_info = FOCAL_LENGTH / 1.6;
+// ---- small helpers of this file: a 7-double parameter block (px py pz qx qy qz qw, estimator.cpp:530-537) <-> (translation, rotation)
+namespace {
+using Eigen::Matrix3d; using Eigen::Quaterniond; using Eigen::Vector3d;
+inline void put_pose(double* blk, const Vector3d& t, const Matrix3d& R) {
+    const Quaterniond q{R};
+    const double v[7] = {t.x(), t.y(), t.z(), q.x(), q.y(), q.z(), q.w()};
+    std::copy(v, v + 7, blk);
+}
+inline Vector3d vec3_at(const double* p) { return Vector3d(p[0], p[1], p[2]); }
+inline Quaterniond quat_at(const double* blk) { return Quaterniond(blk[6], blk[3], blk[4], blk[5]); }
+inline double yaw_of(const Matrix3d& R) { return Utility::R2ypr(R).x(); }      // degrees
+// oldest element of a window array to the back, everything else one slot towards the front
+template <class T, std::size_t N> inline void oldest_to_back(T (&a)[N]) { std::rotate(a, a + 1, a + N); }
+}  // namespace
+
+void Estimator::setParameter() {      // estimator.cpp:9-21: camera extrinsics, the pixel-noise weight of the projection factors, td
+    std::copy(TIC.begin(), TIC.begin() + NUM_OF_CAM, tic);
+    std::copy(RIC.begin(), RIC.begin() + NUM_OF_CAM, ric);
     td = TD;
+    ProjectionFactor::sqrt_info = FOCAL_LENGTH / 1.6;
 }
 
-void Estimator::vector2double() {     // estimator.cpp:526-594
-    for (int i = 0; i <= WINDOW_SIZE; i++) {
-        para_Pose[i][0] = Ps[i].x(); para_Pose[i][1] = Ps[i].y(); para_Pose[i][2] = Ps[i].z();
-        Eigen::Quaterniond q{Rs[i]};
-        para_Pose[i][3] = q.x(); para_Pose[i][4] = q.y(); para_Pose[i][5] = q.z(); para_Pose[i][6] = q.w();
-        for (int k = 0; k < 3; ++k) { para_SpeedBias[i][k] = Vs[i](k); para_SpeedBias[i][3 + k] = Bas[i](k); para_SpeedBias[i][6 + k] = Bgs[i](k); }
+// Eigen state -> the flat parameter arrays the solver reads (estimator.cpp:526-594)
+void Estimator::vector2double() {
+    for (int f = 0; f <= WINDOW_SIZE; ++f) {
+        put_pose(para_Pose[f], Ps[f], Rs[f]);
+        double* sb = para_SpeedBias[f];
+        for (int a = 0; a < 3; ++a) { sb[a] = Vs[f](a); sb[3 + a] = Bas[f](a); sb[6 + a] = Bgs[f](a); }
     }
-    for (int i = 0; i < NUM_OF_CAM; i++) {
-        para_Ex_Pose[i][0] = tic[i].x(); para_Ex_Pose[i][1] = tic[i].y(); para_Ex_Pose[i][2] = tic[i].z();
-        Eigen::Quaterniond q{ric[i]};
-        para_Ex_Pose[i][3] = q.x(); para_Ex_Pose[i][4] = q.y(); para_Ex_Pose[i][5] = q.z(); para_Ex_Pose[i][6] = q.w();
-    }
-    Eigen::VectorXd dep = f_manager.getDepthVector();
-    for (int i = 0; i < f_manager.getFeatureCount(); i++) para_Feature[i][0] = dep[i];
+    for (int cam = 0; cam < NUM_OF_CAM; ++cam) put_pose(para_Ex_Pose[cam], tic[cam], ric[cam]);
     if (ESTIMATE_TD) para_Td[0][0] = td;
-    std::vector<Eigen::Vector4d> get_lineOrtho = f_manager.getLineOrthonormal();
-    for (int i = 0; i < f_manager.getLineFeatureCount(); i++) for (int k = 0; k < 4; ++k) para_Ortho_plucker[i][k] = get_lineOrtho.at(i)[k];
+    const Eigen::VectorXd inverse_depth = f_manager.getDepthVector();
+    for (std::size_t k = 0; k < inverse_depth.size(); ++k) para_Feature[k][0] = inverse_depth[k];
+    int l = 0;
+    for (const Eigen::Vector4d& orth : f_manager.getLineOrthonormal()) { std::copy(orth.v, orth.v + 4, para_Ortho_plucker[l]); ++l; }
 }
 
-void Estimator::double2vector() {     // estimator.cpp:596-711
-    using namespace Eigen;
-    Vector3d origin_R0 = Utility::R2ypr(Rs[0]);
-    Vector3d origin_P0 = Ps[0];
-    if (failure_occur) { origin_R0 = Utility::R2ypr(last_R0); origin_P0 = last_P0; failure_occur = 0; }
-    Matrix3d R00 = Quaterniond(para_Pose[0][6], para_Pose[0][3], para_Pose[0][4], para_Pose[0][5]).toRotationMatrix();
-    Vector3d origin_R00 = Utility::R2ypr(R00);
-    double y_diff = origin_R0.x() - origin_R00.x();
-    Matrix3d rot_diff = Utility::ypr2R(Vector3d(y_diff, 0, 0));
-    if (std::abs(std::abs(origin_R0.y()) - 90) < 1.0 || std::abs(std::abs(origin_R00.y()) - 90) < 1.0) rot_diff = Rs[0] * R00.transpose();   // euler singular point (:616-625)
-    for (int i = 0; i <= WINDOW_SIZE; i++) {
-        Rs[i] = rot_diff * Quaterniond(para_Pose[i][6], para_Pose[i][3], para_Pose[i][4], para_Pose[i][5]).normalized().toRotationMatrix();
-        Ps[i] = rot_diff * Vector3d(para_Pose[i][0] - para_Pose[0][0], para_Pose[i][1] - para_Pose[0][1], para_Pose[i][2] - para_Pose[0][2]) + origin_P0;
-        Vs[i] = rot_diff * Vector3d(para_SpeedBias[i][0], para_SpeedBias[i][1], para_SpeedBias[i][2]);
-        Bas[i] = Vector3d(para_SpeedBias[i][3], para_SpeedBias[i][4], para_SpeedBias[i][5]);
-        Bgs[i] = Vector3d(para_SpeedBias[i][6], para_SpeedBias[i][7], para_SpeedBias[i][8]);
+// Solver output -> Eigen state (estimator.cpp:596-711).  The problem is free in yaw and translation (4-dof gauge), so the result is
+// first moved into the gauge in which the oldest pose keeps its pre-solve yaw and position: a yaw-only
+// rotation, or the full relative rotation when a pitch sits within 1 degree of the Euler singularity (:616-625).
+void Estimator::double2vector() {
+    const Matrix3d R0_before = failure_occur ? last_R0 : Rs[0];
+    const Vector3d P0_before = failure_occur ? last_P0 : Ps[0];
+    failure_occur = false;
+    const Matrix3d R0_after = quat_at(para_Pose[0]).toRotationMatrix();
+    const Vector3d ypr_before = Utility::R2ypr(R0_before), ypr_after = Utility::R2ypr(R0_after);
+    const auto at_euler_singularity = [](const Vector3d& ypr) { return std::abs(std::abs(ypr.y()) - 90) < 1.0; };
+    const Matrix3d gauge = (at_euler_singularity(ypr_before) || at_euler_singularity(ypr_after))
+                               ? Rs[0] * R0_after.transpose()
+                               : Utility::ypr2R(Vector3d(ypr_before.x() - ypr_after.x(), 0, 0));
+    const Vector3d p0_after = vec3_at(para_Pose[0]);
+    const auto regauged_rotation = [&](const double* blk) { return Matrix3d(gauge * quat_at(blk).normalized().toRotationMatrix()); };
+    const auto regauged_position = [&](const double* blk) { return Vector3d(gauge * (vec3_at(blk) - p0_after) + P0_before); };
+    for (int f = 0; f <= WINDOW_SIZE; ++f) {
+        const double* sb = para_SpeedBias[f];
+        Rs[f] = regauged_rotation(para_Pose[f]);
+        Ps[f] = regauged_position(para_Pose[f]);
+        Vs[f] = gauge * vec3_at(sb);
+        Bas[f] = vec3_at(sb + 3);
+        Bgs[f] = vec3_at(sb + 6);
     }
-    for (int i = 0; i < NUM_OF_CAM; i++) {
-        tic[i] = Vector3d(para_Ex_Pose[i][0], para_Ex_Pose[i][1], para_Ex_Pose[i][2]);
-        ric[i] = Quaterniond(para_Ex_Pose[i][6], para_Ex_Pose[i][3], para_Ex_Pose[i][4], para_Ex_Pose[i][5]).toRotationMatrix();
-    }
-    VectorXd dep = f_manager.getDepthVector();
-    for (int i = 0; i < f_manager.getFeatureCount(); i++) dep[i] = para_Feature[i][0];
-    f_manager.setDepth(dep);
+    for (int cam = 0; cam < NUM_OF_CAM; ++cam) { tic[cam] = vec3_at(para_Ex_Pose[cam]); ric[cam] = quat_at(para_Ex_Pose[cam]).toRotationMatrix(); }
     if (ESTIMATE_TD) td = para_Td[0][0];
-    std::vector<Vector4d> get_lineOrtho = f_manager.getLineOrthonormal();
-    for (int i = 0; i < f_manager.getLineFeatureCount(); i++) for (int k = 0; k < 4; ++k) get_lineOrtho.at(i)[k] = para_Ortho_plucker[i][k];
-    f_manager.setLineOrtho(get_lineOrtho, Ps, Rs, tic[0], ric[0]);
-    if (relocalization_info) {        // relative info between two loop frames (:671-691)
-        Matrix3d relo_r = rot_diff * Quaterniond(relo_Pose[6], relo_Pose[3], relo_Pose[4], relo_Pose[5]).normalized().toRotationMatrix();
-        Vector3d relo_t = rot_diff * Vector3d(relo_Pose[0] - para_Pose[0][0], relo_Pose[1] - para_Pose[0][1], relo_Pose[2] - para_Pose[0][2]) + origin_P0;
-        const double drift_correct_yaw = Utility::R2ypr(prev_relo_r).x() - Utility::R2ypr(relo_r).x();
-        drift_correct_r = Utility::ypr2R(Vector3d(drift_correct_yaw, 0, 0));
-        drift_correct_t = prev_relo_t - drift_correct_r * relo_t;
-        relo_relative_t = relo_r.transpose() * (Ps[relo_frame_local_index] - relo_t);
-        relo_relative_q = Quaterniond(relo_r.transpose() * Rs[relo_frame_local_index]);
-        relo_relative_yaw = Utility::normalizeAngle(Utility::R2ypr(Rs[relo_frame_local_index]).x() - Utility::R2ypr(relo_r).x());
-        relocalization_info = 0;
-    }
+    // landmarks: inverse depths (negative depth marks the track as failed, feature_manager.cpp:235-253) and line parameters
+    Eigen::VectorXd inverse_depth(f_manager.getFeatureCount());
+    for (std::size_t k = 0; k < inverse_depth.size(); ++k) inverse_depth[k] = para_Feature[k][0];
+    f_manager.setDepth(inverse_depth);
+    std::vector<Eigen::Vector4d> orth(f_manager.getLineFeatureCount());
+    for (std::size_t l = 0; l < orth.size(); ++l) std::copy(para_Ortho_plucker[l], para_Ortho_plucker[l] + 4, orth[l].v);
+    f_manager.setLineOrtho(orth, Ps, Rs, tic[0], ric[0]);
+    if (!relocalization_info) return;
+    // loop-closure frame in the same gauge: drift of the odometry frame against the pose graph and the relative pose handed back to it (:671-691)
+    relocalization_info = false;
+    const Matrix3d loop_R = regauged_rotation(relo_Pose);
+    const Vector3d loop_P = regauged_position(relo_Pose);
+    const int m = relo_frame_local_index;
+    drift_correct_r = Utility::ypr2R(Vector3d(yaw_of(prev_relo_r) - yaw_of(loop_R), 0, 0));
+    drift_correct_t = prev_relo_t - drift_correct_r * loop_P;
+    relo_relative_t = loop_R.transpose() * (Ps[m] - loop_P);
+    relo_relative_q = Quaterniond(loop_R.transpose() * Rs[m]);
+    relo_relative_yaw = Utility::normalizeAngle(yaw_of(Rs[m]) - yaw_of(loop_R));
 }
 
-void Estimator::setReloFrame(double _frame_stamp, int _frame_index, std::vector<Eigen::Vector3d>& _match_points, Eigen::Vector3d _relo_t, Eigen::Matrix3d _relo_r) {   // estimator.cpp:1361-1379
-    relo_frame_stamp = _frame_stamp;
-    relo_frame_index = _frame_index;
-    match_points.clear();
-    match_points = _match_points;
-    prev_relo_t = _relo_t;
-    prev_relo_r = _relo_r;
-    for (int i = 0; i < WINDOW_SIZE; i++) {
-        if (relo_frame_stamp == Headers[i].stamp.toSec()) {
-            relo_frame_local_index = i;
-            relocalization_info = 1;
-            for (int j = 0; j < SIZE_POSE; j++) relo_Pose[j] = para_Pose[i][j];
-        }
-    }
+// A loop-closure match arrived (estimator.cpp:1361-1379): remember its points and pose-graph pose; when the matched keyframe is still
+// in the window, its current pose block seeds relo_Pose and the next optimization() adds the relocalization blocks.
+void Estimator::setReloFrame(double stamp, int index, std::vector<Eigen::Vector3d>& points, Eigen::Vector3d pose_graph_t, Eigen::Matrix3d pose_graph_r) {
+    prev_relo_r = pose_graph_r;
+    prev_relo_t = pose_graph_t;
+    match_points = points;
+    relo_frame_index = index;
+    relo_frame_stamp = stamp;
+    const std_msgs::Header* hit = std::find_if(Headers, Headers + WINDOW_SIZE, [stamp](const std_msgs::Header& h) { return h.stamp.toSec() == stamp; });
+    if (hit == Headers + WINDOW_SIZE) return;
+    relo_frame_local_index = int(hit - Headers);
+    std::copy(para_Pose[relo_frame_local_index], para_Pose[relo_frame_local_index] + SIZE_POSE, relo_Pose);
+    relocalization_info = true;
 }
 
 void Estimator::optimization() {      // estimator.cpp:761-1233
@@ -209,8 +225,12 @@ void Estimator::optimization() {      // estimator.cpp:761-1233
         MarginalizationInfo* marginalization_info = new MarginalizationInfo();
         // the factors are the ones uvs::Solve() just uploaded; only the (re-anchored) state goes to the device again
         const int rc = uvs_marginalize_resident(solver, &w, marginalization_flag == MARGIN_OLD ? 0 : 1, &marginalization_info->prior);
-        if (rc == UVS_OK) { delete last_marginalization_info; last_marginalization_info = marginalization_info; }
-        else delete marginalization_info;
+        delete last_marginalization_info;
+        last_marginalization_info = marginalization_info;
+        if (rc != UVS_OK) {      // the reference has no error path here; an un-shifted old prior would attach to the wrong frames, so the prior is dropped
+            std::fprintf(stderr, "Estimator::optimization: marginalization failed (%s: %s); continuing without a prior\n", uvs_status_string(rc), uvs_last_error(solver));
+            delete last_marginalization_info; last_marginalization_info = nullptr;
+        }
     }
     // losses that were never attached to a residual block are not owned by the Problem
     if (problem.pt_lm.empty()) delete loss_function;
@@ -220,66 +240,86 @@ void Estimator::optimization() {      // estimator.cpp:761-1233
 }
 
 // ====================================================================== per-frame state machine (post-initialization part)
-void Estimator::clearState() {        // estimator.cpp:23-82 (the members this mirror has)
-    for (int i = 0; i < WINDOW_SIZE + 1; i++) {
-        Rs[i].setIdentity(); Ps[i].setZero(); Vs[i].setZero(); Bas[i].setZero(); Bgs[i].setZero();
-        dt_buf[i].clear(); linear_acceleration_buf[i].clear(); angular_velocity_buf[i].clear();
-        delete pre_integrations[i]; pre_integrations[i] = nullptr;
-    }
-    for (int i = 0; i < NUM_OF_CAM; i++) { tic[i] = Eigen::Vector3d::Zero(); ric[i] = Eigen::Matrix3d::Identity(); }
-    solver_flag = INITIAL; first_imu = false; sum_of_back = 0; sum_of_front = 0; frame_count = 0; td = TD;
-    delete last_marginalization_info; last_marginalization_info = nullptr;
+// Written from the behaviour of estimator.cpp:23-222, 511-524, 713-760, 1235-1359 (what each call must leave behind), not from its text:
+// the window arrays are rotated as a whole, IMU samples are merged sample by sample, and the point / line bookkeeping is one template.
+
+void Estimator::clearState() {        // back to "nothing seen yet"
+    for (IntegrationBase*& pre : pre_integrations) { delete pre; pre = nullptr; }
+    for (auto& samples : dt_buf) samples.clear();
+    for (auto& samples : linear_acceleration_buf) samples.clear();
+    for (auto& samples : angular_velocity_buf) samples.clear();
+    std::fill(Ps, Ps + WINDOW_SIZE + 1, Eigen::Vector3d::Zero());
+    std::fill(Vs, Vs + WINDOW_SIZE + 1, Eigen::Vector3d::Zero());
+    std::fill(Bas, Bas + WINDOW_SIZE + 1, Eigen::Vector3d::Zero());
+    std::fill(Bgs, Bgs + WINDOW_SIZE + 1, Eigen::Vector3d::Zero());
+    std::fill(Rs, Rs + WINDOW_SIZE + 1, Eigen::Matrix3d::Identity());
+    std::fill(tic, tic + NUM_OF_CAM, Eigen::Vector3d::Zero());
+    std::fill(ric, ric + NUM_OF_CAM, Eigen::Matrix3d::Identity());
     f_manager.clearState();
-    failure_occur = 0;
-    relocalization_info = 0;
-    drift_correct_r = Eigen::Matrix3d::Identity(); drift_correct_t = Eigen::Vector3d::Zero();
+    delete last_marginalization_info;
+    last_marginalization_info = nullptr;
+    drift_correct_t = Eigen::Vector3d::Zero();
+    drift_correct_r = Eigen::Matrix3d::Identity();
+    frame_count = sum_of_back = sum_of_front = 0;
+    first_imu = failure_occur = relocalization_info = false;
+    solver_flag = INITIAL;
+    td = TD;
 }
 
-void Estimator::processIMU(double dt, const Eigen::Vector3d& linear_acceleration, const Eigen::Vector3d& angular_velocity) {   // estimator.cpp:84-118
-    if (!first_imu) { first_imu = true; acc_0 = linear_acceleration; gyr_0 = angular_velocity; }
-    if (!pre_integrations[frame_count]) pre_integrations[frame_count] = new IntegrationBase{acc_0, gyr_0, Bas[frame_count], Bgs[frame_count]};
-    if (frame_count != 0) {
-        pre_integrations[frame_count]->push_back(dt, linear_acceleration, angular_velocity);
-        dt_buf[frame_count].push_back(dt);
-        linear_acceleration_buf[frame_count].push_back(linear_acceleration);
-        angular_velocity_buf[frame_count].push_back(angular_velocity);
-        const int j = frame_count;
-        Eigen::Vector3d un_acc_0 = Rs[j] * (acc_0 - Bas[j]) - G;
-        Eigen::Vector3d un_gyr = (gyr_0 + angular_velocity) * 0.5 - Bgs[j];
-        Rs[j] = Rs[j] * Utility::deltaQ(un_gyr * dt).toRotationMatrix();
-        Eigen::Vector3d un_acc_1 = Rs[j] * (linear_acceleration - Bas[j]) - G;
-        Eigen::Vector3d un_acc = (un_acc_0 + un_acc_1) * 0.5;
-        Ps[j] = Ps[j] + Vs[j] * dt + un_acc * (0.5 * dt * dt);
-        Vs[j] = Vs[j] + un_acc * dt;
+// One IMU sample (estimator.cpp:84-118): it feeds the pre-integration of the newest frame, is kept for the re-propagation / merge of
+// slideWindow(), and dead-reckons the newest frame's state (the initial guess of the next solve).
+void Estimator::processIMU(double dt, const Eigen::Vector3d& acc, const Eigen::Vector3d& gyr) {
+    if (!first_imu) { first_imu = true; acc_0 = acc; gyr_0 = gyr; }
+    const int newest = frame_count;
+    IntegrationBase*& pre = pre_integrations[newest];
+    if (pre == nullptr) pre = new IntegrationBase{acc_0, gyr_0, Bas[newest], Bgs[newest]};
+    if (newest > 0) {
+        pre->push_back(dt, acc, gyr);
+        recordSample(newest, dt, acc, gyr);
+        deadReckon(newest, dt, acc, gyr);
     }
-    acc_0 = linear_acceleration; gyr_0 = angular_velocity;
+    acc_0 = acc;
+    gyr_0 = gyr;
+}
+void Estimator::recordSample(int slot, double dt, const Eigen::Vector3d& acc, const Eigen::Vector3d& gyr) {
+    dt_buf[slot].push_back(dt); linear_acceleration_buf[slot].push_back(acc); angular_velocity_buf[slot].push_back(gyr);
+}
+// midpoint rule in the world frame, gravity removed, biases of the frame itself: rotation first (mean body rate over the interval),
+// then the mean of the world accelerations at both ends moves position and velocity
+void Estimator::deadReckon(int f, double dt, const Eigen::Vector3d& acc, const Eigen::Vector3d& gyr) {
+    const Eigen::Matrix3d R_begin = Rs[f];
+    const Eigen::Vector3d rate = 0.5 * (gyr_0 + gyr) - Bgs[f];
+    Rs[f] = R_begin * Utility::deltaQ(rate * dt).toRotationMatrix();
+    const Eigen::Vector3d a_mean = 0.5 * ((R_begin * (acc_0 - Bas[f]) - G) + (Rs[f] * (acc - Bas[f]) - G));
+    Ps[f] = Ps[f] + dt * Vs[f] + 0.5 * dt * dt * a_mean;
+    Vs[f] = Vs[f] + dt * a_mean;
 }
 
-void Estimator::processImage(const FeatureManager::ImagePoints& image, const FeatureManager::ImageLines& image_line, const std_msgs::Header& header) {   // estimator.cpp:120-222
-    marginalization_flag = f_manager.addFeatureCheckParallax(frame_count, image, image_line, td) ? MARGIN_OLD : MARGIN_SECOND_NEW;
+// One image: track bookkeeping + keyframe decision, then (window full) solve, failure check, slide (estimator.cpp:120-222).
+// all_image_frame / tmp_pre_integration feed initialStructure() only and are not kept; ESTIMATE_EXTRINSIC == 2 is initialization too.
+void Estimator::processImage(const FeatureManager::ImagePoints& image, const FeatureManager::ImageLines& image_line, const std_msgs::Header& header) {
+    const bool second_newest_is_keyframe = f_manager.addFeatureCheckParallax(frame_count, image, image_line, td);
+    marginalization_flag = second_newest_is_keyframe ? MARGIN_OLD : MARGIN_SECOND_NEW;
     Headers[frame_count] = header;
-    // (all_image_frame / tmp_pre_integration feed initialStructure only; the ESTIMATE_EXTRINSIC == 2 rotation calibration is initialization too)
-    if (solver_flag == INITIAL) {      // :161-190
-        if (frame_count == WINDOW_SIZE) {
-            if (ESTIMATE_EXTRINSIC != 2 && initialStructure()) {
-                solver_flag = NON_LINEAR;
-                solveOdometry();
-                slideWindow();
-                f_manager.removeFailures();
-                f_manager.removeLineFailures();
-                last_R = Rs[WINDOW_SIZE]; last_P = Ps[WINDOW_SIZE]; last_R0 = Rs[0]; last_P0 = Ps[0];
-            } else slideWindow();
-        } else frame_count++;
-        return;
+    const bool tracking = solver_flag == NON_LINEAR;
+    if (!tracking) {
+        if (frame_count < WINDOW_SIZE) { ++frame_count; return; }
+        if (ESTIMATE_EXTRINSIC == 2 || !initialStructure()) { slideWindow(); return; }
+        solver_flag = NON_LINEAR;
     }
     solveOdometry();
-    if (failureDetection()) { failure_occur = 1; clearState(); setParameter(); return; }
+    if (tracking && failureDetection()) {      // restart from scratch; double2vector() re-anchors the next window on last_R0 / last_P0
+        clearState();
+        setParameter();
+        failure_occur = true;
+        return;
+    }
     slideWindow();
     f_manager.removeFailures();
     f_manager.removeLineFailures();
-    key_poses.clear();
-    for (int i = 0; i <= WINDOW_SIZE; i++) key_poses.push_back(Ps[i]);
-    last_R = Rs[WINDOW_SIZE]; last_P = Ps[WINDOW_SIZE]; last_R0 = Rs[0]; last_P0 = Ps[0];
+    if (tracking) key_poses.assign(Ps, Ps + WINDOW_SIZE + 1);
+    last_R0 = Rs[0]; last_P0 = Ps[0];
+    last_R = Rs[WINDOW_SIZE]; last_P = Ps[WINDOW_SIZE];
 }
 
 void Estimator::setInitialWindow(const double (*pose)[7], const double (*speedbias)[9]) {
@@ -304,69 +344,69 @@ bool Estimator::initialStructure() {
 }
 
 void Estimator::solveOdometry() {      // estimator.cpp:511-524
-    if (frame_count < WINDOW_SIZE) return;
-    if (solver_flag == NON_LINEAR) {
-        f_manager.triangulate(Ps, tic, ric);
-        f_manager.triangulateLine(Ps, Rs, tic, ric);
-        optimization();
-    }
+    if (!(frame_count == WINDOW_SIZE && solver_flag == NON_LINEAR)) return;      // nothing to do until the window is full and initialised
+    triangulateNewLandmarks();
+    optimization();
+}
+void Estimator::triangulateNewLandmarks() { f_manager.triangulate(Ps, tic, ric); f_manager.triangulateLine(Ps, Rs, tic, ric); }
+
+bool Estimator::failureDetection() {   // estimator.cpp:713-760, the tests that report a failure: runaway biases, a jump of the newest position
+    const Eigen::Vector3d jump = Ps[WINDOW_SIZE] - last_P;
+    const bool bias_blown = Bas[WINDOW_SIZE].norm() > 2.5 || Bgs[WINDOW_SIZE].norm() > 1.0;
+    return bias_blown || jump.norm() > 5 || std::abs(jump.z()) > 1;
 }
 
-bool Estimator::failureDetection() {   // estimator.cpp:713-760 (the checks that return true)
-    if (Bas[WINDOW_SIZE].norm() > 2.5) return true;
-    if (Bgs[WINDOW_SIZE].norm() > 1.0) return true;
-    Eigen::Vector3d tmp_P = Ps[WINDOW_SIZE];
-    if ((tmp_P - last_P).norm() > 5) return true;
-    if (std::abs(tmp_P.z() - last_P.z()) > 1) return true;
-    return false;
-}
-
-void Estimator::slideWindow() {        // estimator.cpp:1235-1331
+// The window moves on (estimator.cpp:1235-1331).  MARGIN_OLD: the oldest frame leaves, every slot moves one towards the front and the
+// newest slot starts as a copy of its predecessor with an empty pre-integration.  MARGIN_SECOND_NEW: the second-newest frame is
+// dropped -- its successor's IMU samples are appended to its pre-integration, and the newest state takes its slot.
+void Estimator::slideWindow() {
+    if (frame_count != WINDOW_SIZE) return;
+    const int last = WINDOW_SIZE;
+    const auto restart_newest_preintegration = [&] {
+        delete pre_integrations[last];
+        pre_integrations[last] = new IntegrationBase{acc_0, gyr_0, Bas[last], Bgs[last]};
+        dt_buf[last].clear(); linear_acceleration_buf[last].clear(); angular_velocity_buf[last].clear();
+    };
     if (marginalization_flag == MARGIN_OLD) {
-        back_R0 = Rs[0]; back_P0 = Ps[0];
-        if (frame_count == WINDOW_SIZE) {
-            for (int i = 0; i < WINDOW_SIZE; i++) {
-                std::swap(Rs[i], Rs[i + 1]);
-                std::swap(pre_integrations[i], pre_integrations[i + 1]);
-                dt_buf[i].swap(dt_buf[i + 1]); linear_acceleration_buf[i].swap(linear_acceleration_buf[i + 1]); angular_velocity_buf[i].swap(angular_velocity_buf[i + 1]);
-                Headers[i] = Headers[i + 1];
-                std::swap(Ps[i], Ps[i + 1]); std::swap(Vs[i], Vs[i + 1]); std::swap(Bas[i], Bas[i + 1]); std::swap(Bgs[i], Bgs[i + 1]);
-            }
-            Headers[WINDOW_SIZE] = Headers[WINDOW_SIZE - 1];
-            Ps[WINDOW_SIZE] = Ps[WINDOW_SIZE - 1]; Vs[WINDOW_SIZE] = Vs[WINDOW_SIZE - 1]; Rs[WINDOW_SIZE] = Rs[WINDOW_SIZE - 1];
-            Bas[WINDOW_SIZE] = Bas[WINDOW_SIZE - 1]; Bgs[WINDOW_SIZE] = Bgs[WINDOW_SIZE - 1];
-            delete pre_integrations[WINDOW_SIZE];
-            pre_integrations[WINDOW_SIZE] = new IntegrationBase{acc_0, gyr_0, Bas[WINDOW_SIZE], Bgs[WINDOW_SIZE]};
-            dt_buf[WINDOW_SIZE].clear(); linear_acceleration_buf[WINDOW_SIZE].clear(); angular_velocity_buf[WINDOW_SIZE].clear();
-            slideWindowOld();
-        }
-    } else if (frame_count == WINDOW_SIZE) {
-        for (unsigned int i = 0; i < dt_buf[frame_count].size(); i++) {
-            const double tmp_dt = dt_buf[frame_count][i];
-            const Eigen::Vector3d tmp_linear_acceleration = linear_acceleration_buf[frame_count][i], tmp_angular_velocity = angular_velocity_buf[frame_count][i];
-            pre_integrations[frame_count - 1]->push_back(tmp_dt, tmp_linear_acceleration, tmp_angular_velocity);
-            dt_buf[frame_count - 1].push_back(tmp_dt);
-            linear_acceleration_buf[frame_count - 1].push_back(tmp_linear_acceleration);
-            angular_velocity_buf[frame_count - 1].push_back(tmp_angular_velocity);
-        }
-        Headers[frame_count - 1] = Headers[frame_count];
-        Ps[frame_count - 1] = Ps[frame_count]; Vs[frame_count - 1] = Vs[frame_count]; Rs[frame_count - 1] = Rs[frame_count];
-        Bas[frame_count - 1] = Bas[frame_count]; Bgs[frame_count - 1] = Bgs[frame_count];
-        delete pre_integrations[WINDOW_SIZE];
-        pre_integrations[WINDOW_SIZE] = new IntegrationBase{acc_0, gyr_0, Bas[WINDOW_SIZE], Bgs[WINDOW_SIZE]};
-        dt_buf[WINDOW_SIZE].clear(); linear_acceleration_buf[WINDOW_SIZE].clear(); angular_velocity_buf[WINDOW_SIZE].clear();
-        slideWindowNew();
+        back_R0 = Rs[0];
+        back_P0 = Ps[0];
+        oldest_to_back(Ps); oldest_to_back(Vs); oldest_to_back(Rs); oldest_to_back(Bas); oldest_to_back(Bgs);
+        oldest_to_back(Headers); oldest_to_back(pre_integrations);
+        oldest_to_back(dt_buf); oldest_to_back(linear_acceleration_buf); oldest_to_back(angular_velocity_buf);
+        Ps[last] = Ps[last - 1]; Vs[last] = Vs[last - 1]; Rs[last] = Rs[last - 1]; Bas[last] = Bas[last - 1]; Bgs[last] = Bgs[last - 1];
+        Headers[last] = Headers[last - 1];
+        restart_newest_preintegration();
+        slideWindowOld();
+        return;
     }
+    const int kept = last - 1;
+    for (std::size_t k = 0; k < dt_buf[last].size(); ++k) {
+        pre_integrations[kept]->push_back(dt_buf[last][k], linear_acceleration_buf[last][k], angular_velocity_buf[last][k]);
+        dt_buf[kept].push_back(dt_buf[last][k]);
+        linear_acceleration_buf[kept].push_back(linear_acceleration_buf[last][k]);
+        angular_velocity_buf[kept].push_back(angular_velocity_buf[last][k]);
+    }
+    Ps[kept] = Ps[last]; Vs[kept] = Vs[last]; Rs[kept] = Rs[last]; Bas[kept] = Bas[last]; Bgs[kept] = Bgs[last];
+    Headers[kept] = Headers[last];
+    restart_newest_preintegration();
+    slideWindowNew();
 }
 
-void Estimator::slideWindowNew() { sum_of_front++; f_manager.removeFront(frame_count); f_manager.removeLineFront(frame_count); }      // :1333-1338
+void Estimator::slideWindowNew() {     // :1333-1338
+    ++sum_of_front;
+    f_manager.removeFront(frame_count);
+    f_manager.removeLineFront(frame_count);
+}
 
-void Estimator::slideWindowOld() {     // :1340-1359
-    sum_of_back++;
+// :1340-1359 -- tracks anchored in the departed frame move their depth into the camera of the new oldest frame (only meaningful once
+// depths exist, i.e. after initialization); lines keep their world parameters
+void Estimator::slideWindowOld() {
+    struct Camera { Eigen::Matrix3d R; Eigen::Vector3d t; };
+    const auto camera_of = [this](const Eigen::Matrix3d& R_body, const Eigen::Vector3d& P_body) { return Camera{R_body * ric[0], P_body + R_body * tic[0]}; };
+    sum_of_back += 1;
     if (solver_flag == NON_LINEAR) {
-        Eigen::Matrix3d R0 = back_R0 * ric[0], R1 = Rs[0] * ric[0];
-        Eigen::Vector3d P0 = back_P0 + back_R0 * tic[0], P1 = Ps[0] + Rs[0] * tic[0];
-        f_manager.removeBackShiftDepth(R0, P0, R1, P1);
+        const Camera departed = camera_of(back_R0, back_P0), oldest = camera_of(Rs[0], Ps[0]);
+        f_manager.removeBackShiftDepth(departed.R, departed.t, oldest.R, oldest.t);
     } else f_manager.removeBack();
     f_manager.removeLineBack();
 }

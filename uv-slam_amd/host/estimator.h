@@ -35,6 +35,10 @@ class Estimator {
     // 0..WINDOW_SIZE) through setInitialWindow(), and the stand-in below installs them when the window is full
     void setInitialWindow(const double (*pose)[7], const double (*speedbias)[9]);
     bool initialStructure();
+    // pieces of processIMU() / solveOdometry() (this mirror's own decomposition)
+    void recordSample(int slot, double dt, const Eigen::Vector3d& acc, const Eigen::Vector3d& gyr);
+    void deadReckon(int frame, double dt, const Eigen::Vector3d& acc, const Eigen::Vector3d& gyr);
+    void triangulateNewLandmarks();
     std::vector<double> initial_window;      // [11][7] poses then [11][9] speed/bias; empty = none supplied => initialStructure() fails
     int frame_count;
     bool first_imu;

@@ -151,95 +151,94 @@ class FeatureManager {
         }
     }
     // ---------------------------------------------------------------- track bookkeeping around the solve (closed-loop replay)
+    // Written from the behaviour of feature_manager.cpp:73-158, 255-276, 607-760 -- what each call leaves in the track lists -- with ONE
+    // template per operation for points and lines (the reference spells every list out twice).
     int last_track_num = 0;
     typedef std::map<int, std::vector<std::pair<int, Eigen::Matrix<double, 7, 1>>>> ImagePoints;
     typedef std::map<int, std::vector<Eigen::Matrix<double, 15, 1>>> ImageLines;
-    // feature_manager.cpp:73-158: append this frame's observations to the tracks (new ids start a track at frame_count); returns true when
-    // the second-newest frame is a KEYFRAME (few tracked points, or enough parallax between frames frame_count-2 and frame_count-1)
+    static std::vector<FeaturePerFrame>& views(FeaturePerId& t) { return t.feature_per_frame; }
+    static std::vector<LineFeaturePerFrame>& views(LineFeaturePerId& t) { return t.line_feature_per_frame; }
+
+    // one more view for the track `id` (a new id opens a track that starts in `frame`); true when the track existed already
+    template <class Tracks, class View> static bool appendView(Tracks& tracks, int id, int frame, const View& view) {
+        for (auto& t : tracks)
+            if (t.feature_id == id) { views(t).push_back(view); return true; }
+        tracks.emplace_back(id, frame);
+        views(tracks.back()).push_back(view);
+        return false;
+    }
+    // Takes the measurements of the image that just arrived and decides whether the SECOND-NEWEST frame is a keyframe (then the oldest
+    // frame will be marginalized, otherwise the second-newest is dropped): yes while the window is filling, when fewer than 20 tracks
+    // continued, or when the tracks spanning frames frame_count-2 / frame_count-1 moved by MIN_PARALLAX on average (:73-158).
     bool addFeatureCheckParallax(int frame_count, const ImagePoints& image, const ImageLines& image_line, double td) {
-        double parallax_sum = 0; int parallax_num = 0;
-        last_track_num = 0;
-        for (auto& id_pts : image) {
-            FeaturePerFrame f_per_fra(id_pts.second[0].second, td);
-            const int feature_id = id_pts.first;
-            auto it = std::find_if(feature.begin(), feature.end(), [feature_id](const FeaturePerId& f) { return f.feature_id == feature_id; });
-            if (it == feature.end()) { feature.push_back(FeaturePerId(feature_id, frame_count)); feature.back().feature_per_frame.push_back(f_per_fra); }
-            else { it->feature_per_frame.push_back(f_per_fra); last_track_num++; }
-        }
-        for (auto& id_lines : image_line) {
-            LineFeaturePerFrame l_per_fra(id_lines.second[0], td);
-            const int line_id = id_lines.first;
-            auto it = std::find_if(line_feature.begin(), line_feature.end(), [line_id](const LineFeaturePerId& f) { return f.feature_id == line_id; });
-            if (it == line_feature.end()) { line_feature.push_back(LineFeaturePerId(line_id, frame_count)); line_feature.back().line_feature_per_frame.push_back(l_per_fra); }
-            else it->line_feature_per_frame.push_back(l_per_fra);
-        }
-        if (frame_count < 2 || last_track_num < 20) return true;
-        for (auto& it_per_id : feature)
-            if (it_per_id.start_frame <= frame_count - 2 && it_per_id.start_frame + int(it_per_id.feature_per_frame.size()) - 1 >= frame_count - 1) {
-                parallax_sum += compensatedParallax2(it_per_id, frame_count); parallax_num++;
+        int continued = 0;
+        for (const auto& msg : image) continued += appendView(feature, msg.first, frame_count, FeaturePerFrame(msg.second.front().second, td));
+        for (const auto& msg : image_line) appendView(line_feature, msg.first, frame_count, LineFeaturePerFrame(msg.second.front(), td));
+        last_track_num = continued;
+        if (frame_count < 2 || continued < 20) return true;
+        const int older = frame_count - 2, newer = frame_count - 1;
+        double total = 0.0; int spanning = 0;
+        for (const FeaturePerId& t : feature)
+            if (t.start_frame <= older && t.endFrame() >= newer) { total += compensatedParallax2(t, frame_count); ++spanning; }
+        return spanning == 0 || total / spanning >= MIN_PARALLAX;
+    }
+    // displacement on the normalised image plane between the second- and third-newest view of a track (:727-760; upstream has the
+    // rotation compensation commented out, so the "compensated" candidate equals the plain one)
+    static double compensatedParallax2(const FeaturePerId& track, int frame_count) {
+        const Eigen::Vector3d& a = track.feature_per_frame[frame_count - 2 - track.start_frame].point;
+        const Eigen::Vector3d& b = track.feature_per_frame[frame_count - 1 - track.start_frame].point;
+        const double du = a(0) / a(2) - b(0), dv = a(1) / a(2) - b(1);
+        return std::sqrt(du * du + dv * dv);
+    }
+    // tracks the last solve flagged (negative depth / endpoint behind the camera) are dropped (:255-276)
+    void removeFailures() { feature.remove_if([](const FeaturePerId& t) { return t.solve_flag == 2; }); }
+    void removeLineFailures() { line_feature.remove_if([](const LineFeaturePerId& t) { return t.solve_flag == 2; }); }
+
+    // The OLDEST frame left the window: later tracks move one slot towards the front; a track anchored in the departed frame loses that
+    // view, dies when fewer than `min_views` remain, and otherwise is handed to `reanchor` together with the view it lost.
+    template <class Tracks, class Reanchor> static void oldestFrameLeft(Tracks& tracks, std::size_t min_views, Reanchor reanchor) {
+        for (auto t = tracks.begin(); t != tracks.end();) {
+            bool alive = true;
+            if (t->start_frame > 0) --t->start_frame;
+            else {
+                auto& v = views(*t);
+                const auto lost = v.front();
+                v.erase(v.begin());
+                alive = v.size() >= min_views;
+                if (alive) reanchor(*t, lost);
             }
-        if (parallax_num == 0) return true;
-        return parallax_sum / parallax_num >= MIN_PARALLAX;
+            t = alive ? std::next(t) : tracks.erase(t);
+        }
     }
-    // :727-760 (the rotation compensation is commented out upstream, so both candidates are the plain displacement)
-    static double compensatedParallax2(const FeaturePerId& it_per_id, int frame_count) {
-        const FeaturePerFrame& frame_i = it_per_id.feature_per_frame[frame_count - 2 - it_per_id.start_frame];
-        const FeaturePerFrame& frame_j = it_per_id.feature_per_frame[frame_count - 1 - it_per_id.start_frame];
-        const double u_j = frame_j.point(0), v_j = frame_j.point(1);
-        const double dep_i = frame_i.point(2), u_i = frame_i.point(0) / dep_i, v_i = frame_i.point(1) / dep_i;
-        const double du = u_i - u_j, dv = v_i - v_j;
-        return std::max(0.0, std::sqrt(du * du + dv * dv));
+    // The SECOND-NEWEST frame (window slot frame_count - 1) was dropped: a track born in the newest frame moves one slot down, a track
+    // that reaches the dropped frame loses that view (and dies with its last one), older tracks are untouched.
+    template <class Tracks> static void secondNewestFrameLeft(Tracks& tracks, int frame_count) {
+        const int dropped = frame_count - 1;
+        for (auto t = tracks.begin(); t != tracks.end();) {
+            bool alive = true;
+            if (t->start_frame == frame_count) --t->start_frame;
+            else if (t->endFrame() >= dropped) {
+                auto& v = views(*t);
+                v.erase(v.begin() + (dropped - t->start_frame));
+                alive = !v.empty();
+            }
+            t = alive ? std::next(t) : tracks.erase(t);
+        }
     }
-    void removeFailures() { for (auto it = feature.begin(); it != feature.end();) it = (it->solve_flag == 2) ? feature.erase(it) : std::next(it); }                    // :255-264
-    void removeLineFailures() { for (auto it = line_feature.begin(); it != line_feature.end();) it = (it->solve_flag == 2) ? line_feature.erase(it) : std::next(it); }  // :266-276
-    // :607-645 -- the oldest frame leaves: tracks anchored there lose their first observation and their depth moves to the new anchor frame
+    // :607-645 -- after initialization a point's depth lives in its anchor camera: moving the anchor re-expresses it in the next view's
+    // camera (camera poses of the departed / new oldest frame given), falling back to INIT_DEPTH when it lands behind that camera
     void removeBackShiftDepth(const Eigen::Matrix3d& marg_R, const Eigen::Vector3d& marg_P, const Eigen::Matrix3d& new_R, const Eigen::Vector3d& new_P) {
-        for (auto it = feature.begin(); it != feature.end();) {
-            if (it->start_frame != 0) { it->start_frame--; ++it; continue; }
-            const Eigen::Vector3d uv_i = it->feature_per_frame[0].point;
-            it->feature_per_frame.erase(it->feature_per_frame.begin());
-            if (it->feature_per_frame.size() < 2) { it = feature.erase(it); continue; }
-            const Eigen::Vector3d pts_i = uv_i * it->estimated_depth;
-            const Eigen::Vector3d w_pts_i = marg_R * pts_i + marg_P;
-            const Eigen::Vector3d pts_j = new_R.transpose() * (w_pts_i - new_P);
-            const double dep_j = pts_j(2);
-            it->estimated_depth = dep_j > 0 ? dep_j : INIT_DEPTH;
-            ++it;
-        }
+        oldestFrameLeft(feature, 2, [&](FeaturePerId& t, const FeaturePerFrame& lost) {
+            const Eigen::Vector3d in_world = marg_R * (lost.point * t.estimated_depth) + marg_P;
+            const double depth = (new_R.transpose() * (in_world - new_P))(2);
+            t.estimated_depth = depth > 0 ? depth : INIT_DEPTH;
+        });
     }
-    void removeBack() {                                                                                                  // :647-663
-        for (auto it = feature.begin(); it != feature.end();) {
-            if (it->start_frame != 0) { it->start_frame--; ++it; continue; }
-            it->feature_per_frame.erase(it->feature_per_frame.begin());
-            it = it->feature_per_frame.empty() ? feature.erase(it) : std::next(it);
-        }
-    }
-    void removeFront(int frame_count) {                                                                                  // :665-685
-        for (auto it = feature.begin(); it != feature.end();) {
-            if (it->start_frame == frame_count) { it->start_frame--; ++it; continue; }
-            const int j = WINDOW_SIZE - 1 - it->start_frame;
-            if (it->endFrame() < frame_count - 1) { ++it; continue; }
-            it->feature_per_frame.erase(it->feature_per_frame.begin() + j);
-            it = it->feature_per_frame.empty() ? feature.erase(it) : std::next(it);
-        }
-    }
-    void removeLineBack() {                                                                                              // :687-703
-        for (auto it = line_feature.begin(); it != line_feature.end();) {
-            if (it->start_frame != 0) { it->start_frame--; ++it; continue; }
-            it->line_feature_per_frame.erase(it->line_feature_per_frame.begin());
-            it = it->line_feature_per_frame.empty() ? line_feature.erase(it) : std::next(it);
-        }
-    }
-    void removeLineFront(int frame_count) {                                                                              // :705-725
-        for (auto it = line_feature.begin(); it != line_feature.end();) {
-            if (it->start_frame == frame_count) { it->start_frame--; ++it; continue; }
-            const int j = WINDOW_SIZE - 1 - it->start_frame;
-            if (it->endFrame() < frame_count - 1) { ++it; continue; }
-            it->line_feature_per_frame.erase(it->line_feature_per_frame.begin() + j);
-            it = it->line_feature_per_frame.empty() ? line_feature.erase(it) : std::next(it);
-        }
-    }
-    void clearState() { feature.clear(); line_feature.clear(); }                                                         // :28-32
+    void removeBack() { oldestFrameLeft(feature, 1, [](FeaturePerId&, const FeaturePerFrame&) {}); }                          // :647-663
+    void removeLineBack() { oldestFrameLeft(line_feature, 1, [](LineFeaturePerId&, const LineFeaturePerFrame&) {}); }         // :687-703 (world-frame parameters: nothing to move)
+    void removeFront(int frame_count) { secondNewestFrameLeft(feature, frame_count); }                                        // :665-685
+    void removeLineFront(int frame_count) { secondNewestFrameLeft(line_feature, frame_count); }                               // :705-725
+    void clearState() { feature.clear(); line_feature.clear(); }                                                              // :28-32
 
     static bool usedPoint(FeaturePerId& it) { it.used_num = (int)it.feature_per_frame.size(); return it.used_num >= 2 && it.start_frame < WINDOW_SIZE - 2; }   // estimator.cpp:826
     static bool usedLine(LineFeaturePerId& it) { it.used_num = (int)it.line_feature_per_frame.size(); return it.used_num >= LINE_WINDOW; }                    // estimator.cpp:873
@@ -247,8 +246,9 @@ class FeatureManager {
     int getLineFeatureCount() { int c = 0; for (auto& it : line_feature) c += usedLine(it); return c; }
     Eigen::VectorXd getDepthVector() { Eigen::VectorXd d; for (auto& it : feature) if (usedPoint(it)) d.push_back(1.0 / it.estimated_depth); return d; }     // feature_manager.cpp:290-306
     void setDepth(const Eigen::VectorXd& x) {                                                                                                                 // :235-253
-        int k = -1;
-        for (auto& it : feature) { if (!usedPoint(it)) continue; it.estimated_depth = 1.0 / x[++k]; it.solve_flag = it.estimated_depth < 0 ? 2 : 1; }
+        std::size_t next = 0;
+        for (auto& t : feature)
+            if (usedPoint(t)) { const double depth = 1.0 / x[next++]; t.estimated_depth = depth; t.solve_flag = depth < 0 ? 2 : 1; }
     }
     std::vector<Eigen::Vector4d> getLineOrthonormal() { std::vector<Eigen::Vector4d> v; for (auto& it : line_feature) if (usedLine(it)) v.push_back(it.orthonormal_vec); return v; }   // :308-331
     // setLineOrtho (:333-423): the endpoint-depth validity test uses the PRE-update orthonormal_vec with the post-update poses (Appendix D11)

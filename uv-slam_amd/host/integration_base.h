@@ -11,20 +11,27 @@ class IntegrationBase {
   public:
     IntegrationBase() = delete;
     IntegrationBase(const Eigen::Vector3d& _acc_0, const Eigen::Vector3d& _gyr_0, const Eigen::Vector3d& _linearized_ba, const Eigen::Vector3d& _linearized_bg)
-        : acc_0(_acc_0), gyr_0(_gyr_0), linearized_acc(_acc_0), linearized_gyr(_gyr_0), linearized_ba(_linearized_ba), linearized_bg(_linearized_bg), sum_dt(0.0) {
-        setIdentity15(jacobian); std::memset(covariance, 0, sizeof(covariance));
-        delta_q.setIdentity();
-        std::memset(noise, 0, sizeof(noise));                                    // :21-27
-        for (int i = 0; i < 3; ++i) {
-            noise[(0 + i) * 18 + 0 + i] = ACC_N * ACC_N; noise[(3 + i) * 18 + 3 + i] = GYR_N * GYR_N; noise[(6 + i) * 18 + 6 + i] = ACC_N * ACC_N;
-            noise[(9 + i) * 18 + 9 + i] = GYR_N * GYR_N; noise[(12 + i) * 18 + 12 + i] = ACC_W * ACC_W; noise[(15 + i) * 18 + 15 + i] = GYR_W * GYR_W;
-        }
+        : linearized_acc(_acc_0), linearized_gyr(_gyr_0) {
+        std::memset(noise, 0, sizeof(noise));                                    // :21-27: diag(acc_n, gyr_n, acc_n, gyr_n, acc_w, gyr_w)^2 (x) I3
+        const double sigma[6] = {ACC_N, GYR_N, ACC_N, GYR_N, ACC_W, GYR_W};
+        for (int d = 0; d < 18; ++d) noise[d * 18 + d] = sigma[d / 3] * sigma[d / 3];
+        restart(_linearized_ba, _linearized_bg);
     }
-    void push_back(double dt, const Eigen::Vector3d& acc, const Eigen::Vector3d& gyr) { dt_buf.push_back(dt); acc_buf.push_back(acc); gyr_buf.push_back(gyr); propagate(dt, acc, gyr); }   // :30-36
-    void repropagate(const Eigen::Vector3d& _linearized_ba, const Eigen::Vector3d& _linearized_bg) {   // :38-52
-        sum_dt = 0.0; acc_0 = linearized_acc; gyr_0 = linearized_gyr; delta_p.setZero(); delta_q.setIdentity(); delta_v.setZero();
-        linearized_ba = _linearized_ba; linearized_bg = _linearized_bg; setIdentity15(jacobian); std::memset(covariance, 0, sizeof(covariance));
-        for (size_t i = 0; i < dt_buf.size(); ++i) propagate(dt_buf[i], acc_buf[i], gyr_buf[i]);
+    // one more IMU sample (:30-36)
+    void push_back(double dt, const Eigen::Vector3d& acc, const Eigen::Vector3d& gyr) { dt_buf.push_back(dt); acc_buf.push_back(acc); gyr_buf.push_back(gyr); propagate(dt, acc, gyr); }
+    // new bias linearization point: integrate the stored samples again from the first one (:38-52)
+    void repropagate(const Eigen::Vector3d& ba, const Eigen::Vector3d& bg) {
+        restart(ba, bg);
+        for (std::size_t k = 0; k < dt_buf.size(); ++k) propagate(dt_buf[k], acc_buf[k], gyr_buf[k]);
+    }
+    // empty pre-integration at the given biases: identity delta, identity Jacobian, zero covariance
+    void restart(const Eigen::Vector3d& ba, const Eigen::Vector3d& bg) {
+        linearized_ba = ba; linearized_bg = bg;
+        acc_0 = linearized_acc; gyr_0 = linearized_gyr;
+        delta_p.setZero(); delta_v.setZero(); delta_q.setIdentity();
+        sum_dt = 0.0;
+        std::memset(covariance, 0, sizeof(covariance));
+        setIdentity15(jacobian);
     }
     void propagate(double _dt, const Eigen::Vector3d& _acc_1, const Eigen::Vector3d& _gyr_1) {       // :130-158 + midPointIntegration :54-128
         using namespace Eigen;

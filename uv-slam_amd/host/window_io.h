@@ -31,6 +31,10 @@ struct WindowFile {      // owns the arrays a uvs_window points to
         bool ok = std::fread(magic, 1, 8, f) == 8 && std::memcmp(magic, "UVSWIN01", 8) == 0 && std::fread(hd, 4, 8, f) == 8;
         auto rd = [&](void* p, size_t sz, size_t n) { if (ok && n) ok = std::fread(p, sz, n, f) == n; };
         std::memset(&w, 0, sizeof(w));
+        // header counts are untrusted (a truncated or foreign file must fail the load, not overrun the fixed-size prior arrays)
+        const int kMaxCount = 1 << 24;
+        for (int q = 0; q < 7 && ok; ++q) ok = hd[q] >= 0 && hd[q] <= kMaxCount;
+        ok = ok && hd[4] <= UVS_WINDOW_SIZE && hd[5] <= UVS_MAX_PRIOR_DIM && hd[6] <= UVS_MAX_PRIOR_BLOCKS;
         if (ok) {
             const int np = hd[0], npo = hd[1], nl = hd[2], nlo = hd[3], ni = hd[4], pn = hd[5], pnb = hd[6];
             rd(w.pose, 8, 77); rd(w.speedbias, 8, 99); rd(w.ex_pose, 8, 7); rd(&w.td, 8, 1);
@@ -63,7 +67,7 @@ struct WindowFile {      // owns the arrays a uvs_window points to
             w.imu = imu.data(); w.prior = pn > 0 ? &prior : nullptr;
             if (has_td) { w.pt_vel_i = pt_vel_i.data(); w.pt_vel_j = pt_vel_j.data(); w.pt_td_i = pt_td_i.data(); w.pt_td_j = pt_td_j.data(); }
             if (hd[7] & 2) {
-                int32_t nr[2] = {0, 0}; rd(nr, 4, 2); const int n = ok ? nr[0] : 0; relo_frame_local_index = nr[1];
+                int32_t nr[2] = {0, 0}; rd(nr, 4, 2); ok = ok && nr[0] >= 0 && nr[0] <= kMaxCount; const int n = ok ? nr[0] : 0; relo_frame_local_index = nr[1];
                 rd(w.relo_pose, 8, 7); relo_lm.resize(n); rd(relo_lm.data(), 4, n); if (n % 2) { int32_t pad; rd(&pad, 4, 1); }
                 relo_pi.resize(3 * n); relo_pj.resize(3 * n); rd(relo_pi.data(), 8, 3 * n); rd(relo_pj.data(), 8, 3 * n);
                 w.n_relo_obs = n; w.relo_lm = relo_lm.data(); w.relo_pi = relo_pi.data(); w.relo_pj = relo_pj.data();
