@@ -107,3 +107,45 @@ def test_pack_layout_host_only():
     o = abi.default_options(); o.estimate_extrinsic = 1
     wc, keep = w.to_c(); info = (C.c_int32 * 12)()
     assert lib.uvs_debug_pack_layout(C.byref(o), C.byref(wc), info) == abi.UVS_ERR_UNSUPPORTED
+
+
+def test_malformed_prior_is_rejected_not_dereferenced():
+    """validate_window() checked block_idx / block_frame of the prior but not x0_off, block_size or block_kind, and pack_window
+    then read x0[x0_off[b] + k] unchecked (a prior with x0_off = 1e8 crashed the process).  Host-only: no device is touched."""
+    lib = uvs.api.lib()
+    lib.uvs_debug_pack_layout.argtypes = [C.POINTER(abi.Options), C.POINTER(abi.WindowC), C.POINTER(C.c_int32)]
+    o = abi.default_options()
+
+    def status_with(mutate):
+        w = uvs.synth.make_window(11, n_points=30, n_lines=8, n_tagged=4)
+        p = abi.Prior(); p.n = 15; p.n_blocks = 2
+        p.block_kind[0] = abi.BLOCK_POSE; p.block_frame[0] = 0; p.block_size[0] = 7; p.block_idx[0] = 0; p.x0_off[0] = 0
+        p.block_kind[1] = abi.BLOCK_SPEEDBIAS; p.block_frame[1] = 0; p.block_size[1] = 9; p.block_idx[1] = 6; p.x0_off[1] = 7
+        p.x0[6] = 1.0
+        for k in range(15): p.linearized_jacobians[k * 15 + k] = 1.0
+        mutate(p)
+        w.prior = p
+        wc, keep = w.to_c(); info = (C.c_int32 * 12)()
+        return lib.uvs_debug_pack_layout(C.byref(o), C.byref(wc), info)
+
+    assert status_with(lambda p: None) == abi.UVS_OK
+    assert status_with(lambda p: p.x0_off.__setitem__(0, 100000000)) == abi.UVS_ERR_INVALID_ARG
+    assert status_with(lambda p: p.x0_off.__setitem__(1, -3)) == abi.UVS_ERR_INVALID_ARG
+    assert status_with(lambda p: p.x0_off.__setitem__(1, 144 - 8)) == abi.UVS_ERR_INVALID_ARG      # 9 doubles do not fit behind offset 136
+    assert status_with(lambda p: p.block_kind.__setitem__(0, 7)) == abi.UVS_ERR_INVALID_ARG
+    assert status_with(lambda p: p.block_size.__setitem__(0, 9)) == abi.UVS_ERR_INVALID_ARG         # a pose block is 7 wide
+    assert status_with(lambda p: p.block_size.__setitem__(1, 1000)) == abi.UVS_ERR_INVALID_ARG
+
+
+def test_window_file_loader_rejects_corrupt_headers(tmp_path):
+    """Window.load trusted the header counts (prior_n > 96 overran the fixed-size prior arrays)."""
+    import struct
+    w = uvs.synth.make_window(12, n_points=20, n_lines=6, n_tagged=3)
+    path = str(tmp_path / "w.bin"); w.save(path)
+    assert len(abi.Window.load(path).pt_lm) == len(w.pt_lm)
+    raw = bytearray(open(path, "rb").read())
+    for slot, value in ((5, 97), (6, 17), (4, 11), (0, -1)):       # prior_n, prior blocks, imu blocks, points
+        bad = bytearray(raw); struct.pack_into("<i", bad, 8 + 4 * slot, value)
+        open(path, "wb").write(bad)
+        with pytest.raises(ValueError):
+            abi.Window.load(path)

@@ -101,10 +101,13 @@ def test_errors_are_reported_not_swallowed(gpu_api):
     s.close()
 
 
-def test_baseline_batch_is_bitwise_reproducible(solver):
+def test_baseline_batch_is_bitwise_reproducible(solver, oracle):
     """BASELINE configs[2] size: 256 windows per launch; every sum has a fixed order (no atomics), so two launches agree bit for bit,
     and a window solved inside the batch equals the same window solved alone."""
-    ws = [synth.make_window(200 + i) for i in range(256)]
+    # the benchmarked batch: every window carries the n = 75 prior built by the product's own marginalization (bench.py does the same)
+    marg = lambda win, flag: solver.marginalize(win, flag)
+    ws = [synth.make_window(200 + i, with_prior=True, marginalize_fn=marg) for i in range(256)]
+    assert all(w.prior is not None and w.prior.n == 75 for w in ws)
     solver.upload(ws); solver.solve_resident(); s1, r1 = solver.download()
     solver.upload(ws); solver.solve_resident(); s2, r2 = solver.download()
     for a, b, ra, rb in zip(s1, s2, r1, r2):
@@ -113,6 +116,13 @@ def test_baseline_batch_is_bitwise_reproducible(solver):
     assert np.array_equal(alone.pose, s1[137].pose) and ralone.final_cost == r1[137].final_cost
     costs = np.array([r.final_cost for r in r1]); init = np.array([r.initial_cost for r in r1])
     assert np.all(costs < 1e-6 * init)                        # every window converges from the perturbed start
+    # and the batch equals the oracle on a sample of its windows (LM trace, final cost, poses)
+    from helpers import pose_deltas
+    for k in (0, 85, 170, 255):
+        so, ro = oracle.solve(ws[k])
+        assert r1[k].num_iterations == ro.num_iterations and list(r1[k].accepted[:ro.num_iterations + 1]) == list(ro.accepted[:ro.num_iterations + 1])
+        dp, dq = pose_deltas(s1[k].pose, so.pose)
+        assert dp < 1e-6 and dq < 1e-6 and abs(r1[k].final_cost - ro.final_cost) <= 1e-6 * ro.final_cost
 
 
 def test_marginalize_resident_equals_marginalize(gpu_api, oracle):
