@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define UVS_ABI_VERSION 3
+#define UVS_ABI_VERSION 4
 
 #define UVS_WINDOW_SIZE 10                    /* parameters.h:12 WINDOW_SIZE  */
 #define UVS_NUM_FRAMES (UVS_WINDOW_SIZE + 1)  /* frames 0..WINDOW_SIZE        */
@@ -331,6 +331,21 @@ double uvs_large_local_x2(const uvs_solver *s);
 void uvs_large_set_landmark_x2(uvs_solver *s, double all_ranks_x2);
 int uvs_large_finish(uvs_solver *s, uvs_state *out, uvs_report *rep);
 int uvs_large_solve(uvs_solver *s, const uvs_window *w, uvs_state *out, uvs_report *rep);
+
+/* ---- fused multi-GPU loop: the library owns the RCCL communicator (SURVEY.md 8b "library owns ... RCCL comm") and keeps the
+ * trust-region control on the device, so that one solve is one stream of launches with two in-place all-reduces per iteration and no
+ * host round trip.  Usage on every rank (one process per GPU, one handle per process):
+ *     rank 0: uvs_large_comm_unique_id(&id); broadcast `id` (128 bytes) to the other ranks by any host transport;
+ *     uvs_large_comm_init(s, nranks, rank, &id);            (nranks <= 8; nranks == 1 needs no id and no RCCL)
+ *     uvs_large_solve_fused(s, shard_of_this_rank, &state, &report, &ms);    w = the landmarks k with k % nranks == rank, frames / IMU /
+ *                                                                            prior replicated; frames of `state` identical on all ranks
+ *     uvs_large_comm_destroy(s);                             (also done by uvs_destroy)
+ * RCCL is looked up at run time (a copy already loaded by the process is reused; UVS_RCCL_LIB overrides): UVS_ERR_UNSUPPORTED if absent. */
+typedef struct uvs_rccl_id { char internal[128]; } uvs_rccl_id;      /* == ncclUniqueId */
+int uvs_large_comm_unique_id(uvs_rccl_id *id);
+int uvs_large_comm_init(uvs_solver *s, int nranks, int rank, const uvs_rccl_id *id);
+void uvs_large_comm_destroy(uvs_solver *s);
+int uvs_large_solve_fused(uvs_solver *s, const uvs_window *w, uvs_state *out, uvs_report *rep, float *loop_ms);
 
 /* ---- size helpers for callers that serialise windows ---- */
 int uvs_reduced_dim(const uvs_options *opts);  /* 165 (+6 if estimate_extrinsic) */

@@ -119,3 +119,41 @@ def test_two_ranks_on_one_gpu_match_single_process(gpu_api):
         assert abs(r[4] - rep.final_cost) <= 1e-7 * rep.final_cost
         assert pose_deltas(r[1], st.pose)[0] < 1e-7
         assert np.abs(r[2] - st.inv_depth[r[3]]).max() < 1e-7
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("comm", [None, "self"])
+def test_fused_device_side_loop_equals_the_host_driven_one(gpu_api, comm):
+    """uvs_large_solve_fused: trust-region control on the device, every launch of the solve enqueued without a host round trip, the
+    exchange vectors all-reduced in place by the handle's own RCCL communicator (comm == "self": a one-rank communicator, which is
+    what one GPU can exercise of it; None: no communicator).  Same kernels, same numbers as the step-wise host-driven loop."""
+    w = synth.make_window(54, n_points=900, n_lines=200, n_tagged=150)
+    s = gpu_api.Solver(max_batch=2, max_points=1000, max_point_obs=12000, max_lines=256, max_line_obs=3000)
+    st0, rep0 = s.large_solve(w)
+    s.large_comm_init(comm)
+    st1, rep1, ms = s.large_solve_fused(w)
+    st2, rep2, ms2 = s.large_solve_fused(w)          # the handle is reusable
+    s.close()
+    n = rep0.num_iterations
+    assert rep1.num_iterations == n and list(rep1.accepted[:n + 1]) == list(rep0.accepted[:n + 1]) and rep1.termination == rep0.termination
+    assert np.allclose(np.array(rep1.radius[:n + 1]), np.array(rep0.radius[:n + 1]), rtol=1e-12)
+    assert np.allclose(np.array(rep1.cost[:n + 1]), np.array(rep0.cost[:n + 1]), rtol=1e-12)
+    assert abs(rep1.final_cost - rep0.final_cost) <= 1e-12 * rep0.final_cost and rep1.initial_cost == rep0.initial_cost
+    assert pose_deltas(st1.pose, st0.pose)[0] < 1e-12 and np.abs(st1.inv_depth - st0.inv_depth).max() < 1e-12
+    assert np.abs(st1.line_orth - st0.line_orth).max() < 1e-10
+    assert np.array_equal(st1.pose, st2.pose) and rep2.final_cost == rep1.final_cost and 0.0 < ms < 100.0
+
+
+@pytest.mark.gpu
+def test_fused_loop_early_termination_and_zero_iterations(gpu_api):
+    w = synth.make_window(55, n_points=300, n_lines=60, n_tagged=40)
+    for kw in (dict(max_num_iterations=0), dict(max_num_iterations=40, function_tolerance=5e-3), dict(max_num_iterations=3)):
+        o = abi.default_options()
+        for k, v in kw.items(): setattr(o, k, v)
+        s = gpu_api.Solver(o, max_batch=2)
+        st0, rep0 = s.large_solve(w)
+        s.large_comm_init(None)
+        st1, rep1, ms = s.large_solve_fused(w)
+        s.close()
+        assert rep1.num_iterations == rep0.num_iterations and rep1.termination == rep0.termination, kw
+        assert abs(rep1.final_cost - rep0.final_cost) <= 1e-12 * rep0.final_cost and pose_deltas(st1.pose, st0.pose)[0] < 1e-12

@@ -63,6 +63,10 @@ def lib():
         L.uvs_large_set_landmark_x2.argtypes = [C.c_void_p, C.c_double]
         L.uvs_large_finish.argtypes = [C.c_void_p, C.POINTER(abi.StateC), C.POINTER(abi.Report)]; L.uvs_large_finish.restype = C.c_int
         L.uvs_large_solve.argtypes = [C.c_void_p, C.POINTER(abi.WindowC), C.POINTER(abi.StateC), C.POINTER(abi.Report)]; L.uvs_large_solve.restype = C.c_int
+        L.uvs_large_comm_unique_id.argtypes = [C.c_char_p]; L.uvs_large_comm_unique_id.restype = C.c_int
+        L.uvs_large_comm_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p]; L.uvs_large_comm_init.restype = C.c_int
+        L.uvs_large_comm_destroy.argtypes = [C.c_void_p]; L.uvs_large_comm_destroy.restype = None
+        L.uvs_large_solve_fused.argtypes = [C.c_void_p, C.POINTER(abi.WindowC), C.POINTER(abi.StateC), C.POINTER(abi.Report), C.POINTER(C.c_float)]; L.uvs_large_solve_fused.restype = C.c_int
         _lib = L
     return _lib
 
@@ -192,6 +196,33 @@ class Solver:
             self._check(L.uvs_large_decide(self._h))
         self._check(L.uvs_large_finish(self._h, C.byref(sc), C.byref(rep)), allow=(abi.UVS_OK, abi.UVS_ERR_NUMERIC))
         return st.from_c(sc), rep
+
+    def large_comm_init(self, dist=None):
+        """The handle's own RCCL communicator for large_solve_fused(): rank 0 draws the id, torch.distributed (any backend) carries its
+        128 bytes to the other ranks, every rank joins.  Without `dist` (or with one rank) nothing is exchanged and no RCCL is needed."""
+        L = lib()
+        if dist == "self":          # one-rank communicator through RCCL (tests: the dlopen'ed API, in-place all-reduce on the handle's stream)
+            buf = C.create_string_buffer(128)
+            self._check(L.uvs_large_comm_unique_id(buf)); self._check(L.uvs_large_comm_init(self._h, 1, 0, buf.raw)); return
+        if dist is None or dist.get_world_size() == 1:
+            self._check(L.uvs_large_comm_init(self._h, 1, 0, None)); return
+        rank, world = dist.get_rank(), dist.get_world_size()
+        buf = C.create_string_buffer(128)
+        if rank == 0:
+            self._check(L.uvs_large_comm_unique_id(buf))
+        box = [buf.raw]
+        dist.broadcast_object_list(box, src=0)
+        self._check(L.uvs_large_comm_init(self._h, world, rank, box[0]))
+
+    def large_solve_fused(self, w: abi.Window):
+        """One landmark shard of ONE large window through the fused loop (include/uvs_solver.h: uvs_large_solve_fused): the whole LM loop
+        is enqueued on the handle's stream, the pose-block partials and the step scalars are all-reduced in place by the handle's RCCL
+        communicator (large_comm_init), accept / reject runs on the device.  Returns (state, report, loop_ms)."""
+        wc, keep = w.to_c()
+        st = abi.State(len(w.inv_depth), len(w.line_orth)); sc = st.alloc_c()
+        rep = abi.Report(); ms = C.c_float(0.0)
+        self._check(lib().uvs_large_solve_fused(self._h, C.byref(wc), C.byref(sc), C.byref(rep), C.byref(ms)), allow=(abi.UVS_OK, abi.UVS_ERR_NUMERIC))
+        return st.from_c(sc), rep, float(ms.value)
 
     # ---- diagnostics -------------------------------------------------------
     def evaluate(self, w: abi.Window, robust=True):

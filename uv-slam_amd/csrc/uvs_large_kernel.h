@@ -22,10 +22,20 @@ enum { LS_X = 0, LS_XC = 184, LS_DLT = 368, LS_G = 544, LS_DD = 720, LS_SC = 896
 static constexpr int LG_STATE = 1280;                      // doubles: X[184] XC[184] DLT[176] G[176] DD[176] SC[176]
 static_assert(LS_END <= LG_STATE, "large-path state vector overflows its allocation");
 enum { LO_COST = 0, LO_GMAX, LO_CHOLOK, LO_GD, LO_DD2, LO_STEP2, LO_XC2, LO_FRAMECOST, LO_N };
+// ---- device-resident trust-region state of the FUSED loop (uvs_large_solve_fused: no host round trip per iteration).
+// The all-reduce payload of a linearization is reduced[0 .. LG_XCH): the LG_RED sums, then LX_X2 = this rank's landmark share of
+// ||x||^2 (first iteration only) and LX_GMAX + r = rank r's max |g_landmark| (zero in the other ranks' slots, so that ONE SUM
+// all-reduce also delivers the MAX: every rank takes the maximum over the slots afterwards).
+static constexpr int LG_MAXRANKS = 8;
+static constexpr int LX_X2 = LG_RED, LX_GMAX = LG_RED + 1, LG_XCH = LG_RED + 1 + LG_MAXRANKS + 7;      // 5016 doubles
+enum { LC_RADIUS = 0, LC_DECR, LC_COST, LC_GMAX, LC_XNORM, LC_FRAME_X2, LC_IT, LC_INVALID, LC_NSUCC, LC_PENDING, LC_TERM, LC_STATUS, LC_FIRST, LC_DONE, LC_SEL, LC_N };
+struct LargeCtl { const double* ctl; int rank, nranks; };      // ctl == nullptr: the step-wise API (host-side control, arguments as given)
 
-__global__ __launch_bounds__(NT) void k_large_chunks(char* blob, double* ws, KOpts o, const double* state, int sel, int first, double radius, double* partials) {
+
+__global__ __launch_bounds__(NT) void k_large_chunks(char* blob, double* ws, KOpts o, const double* state, int sel, int first, double radius, double* partials, LargeCtl lc) {
     extern __shared__ __attribute__((aligned(16))) double sh[];
     const int tid = threadIdx.x, ch = blockIdx.x;
+    if (lc.ctl) { if (lc.ctl[LC_DONE] != 0.0) return; sel = (int)lc.ctl[LC_SEL]; first = (int)lc.ctl[LC_FIRST]; radius = lc.ctl[LC_RADIUS]; }
     Ctx c; c.hdr = (const DevWin*)blob; c.bd = (const double*)blob; c.bi = (const int*)blob; c.ws = ws; c.sh = sh; c.o = o; c.o.debug = 0;
     const DevWin& h = *c.hdr;
     if (tid < 184) sh[L_X + tid] = state[LS_X + tid];
@@ -70,8 +80,9 @@ __global__ __launch_bounds__(NT) void k_large_chunks(char* blob, double* ws, KOp
 // Deterministic two-level sum of the per-chunk partials: a workgroup owns 16 consecutive entries i, its 16 x 16 threads split the chunk
 // range into 16 contiguous slices (summed in chunk order, loads independent of each other), the 16 slice sums are then added in slice
 // order.  (One thread per entry walking all chunks serially took 137 us for 340 chunks -- more than k_large_chunks itself.)
-__global__ __launch_bounds__(256) void k_large_reduce(const double* partials, int n_chunks, double* reduced) {
+__global__ __launch_bounds__(256) void k_large_reduce(const double* partials, int n_chunks, double* reduced, LargeCtl lc) {
     __shared__ double part[16][17];
+    if (lc.ctl && lc.ctl[LC_DONE] != 0.0) return;
     const int il = threadIdx.x & 15, p = threadIdx.x >> 4;
     const int i = blockIdx.x * 16 + il;
     const bool is_max = (i == LG_ACC + 1);
@@ -87,13 +98,22 @@ __global__ __launch_bounds__(256) void k_large_reduce(const double* partials, in
         double t = part[0][il];
         for (int q = 1; q < 16; ++q) t = is_max ? fmax(t, part[q][il]) : t + part[q][il];      // fixed order => deterministic
         reduced[i] = t;
+        // fused multi-GPU exchange: the landmark gradient max-norm travels in this rank's slot of a SUM all-reduce
+        if (is_max && lc.ctl) for (int r = 0; r < LG_MAXRANKS; ++r) reduced[LX_GMAX + r] = (r == lc.rank) ? t : 0.0;
     }
 }
 
 // one workgroup: frame terms + assembly + Cholesky + step.  `reduced` holds the (all-reduced) landmark partials.
-__global__ __launch_bounds__(NT) void k_large_solve(char* blob, double* ws, KOpts o, double* state, const double* reduced, int first, double radius, double* out) {
+__global__ __launch_bounds__(NT) void k_large_solve(char* blob, double* ws, KOpts o, double* state, const double* reduced, int first, double radius, double* out, LargeCtl lc) {
     extern __shared__ __attribute__((aligned(16))) double sh[];
     const int tid = threadIdx.x;
+    double gmax_lm = reduced[LG_ACC + 1];
+    if (lc.ctl) {
+        if (lc.ctl[LC_DONE] != 0.0) return;
+        first = (int)lc.ctl[LC_FIRST]; radius = lc.ctl[LC_RADIUS];
+        gmax_lm = 0.0;
+        for (int r = 0; r < LG_MAXRANKS; ++r) gmax_lm = fmax(gmax_lm, reduced[LX_GMAX + r]);
+    }
     Ctx c; c.hdr = (const DevWin*)blob; c.bd = (const double*)blob; c.bi = (const int*)blob; c.ws = ws; c.sh = sh; c.o = o; c.o.debug = 0;
     if (tid < 184) sh[L_X + tid] = state[LS_X + tid];
     if (tid < UVS_RD && !first) sh[L_SC + tid] = state[LS_SC + tid];
@@ -116,7 +136,7 @@ __global__ __launch_bounds__(NT) void k_large_solve(char* blob, double* ws, KOpt
     double cost = lin_frames(c, sh + L_X, N);
     if (tid == 0) cost += reduced[LG_ACC];
     __syncthreads();
-    lin_assemble(c, sh + L_X, first != 0, radius, grp, A, N, cost, reduced[LG_ACC + 1]);
+    lin_assemble(c, sh + L_X, first != 0, radius, grp, A, N, cost, gmax_lm);
     if (tid < UVS_RD) sh[L_DLT + tid] = -sh[L_G + tid];
     chol_factor(c);
     chol_solve(c);
@@ -135,9 +155,10 @@ __global__ __launch_bounds__(NT) void k_large_solve(char* blob, double* ws, KOpt
 }
 
 // per chunk: landmark back-substitution (candidate parameters into the other buffer) + candidate cost of the chunk's observations
-__global__ __launch_bounds__(NT) void k_large_backsub(char* blob, double* ws, KOpts o, const double* state, int sel, double* bsums) {
+__global__ __launch_bounds__(NT) void k_large_backsub(char* blob, double* ws, KOpts o, const double* state, int sel, double* bsums, LargeCtl lc) {
     extern __shared__ __attribute__((aligned(16))) double sh[];
     const int tid = threadIdx.x, ch = blockIdx.x;
+    if (lc.ctl) { if (lc.ctl[LC_DONE] != 0.0) return; sel = (int)lc.ctl[LC_SEL]; }
     Ctx c; c.hdr = (const DevWin*)blob; c.bd = (const double*)blob; c.bi = (const int*)blob; c.ws = ws; c.sh = sh; c.o = o; c.o.debug = 0;
     const DevWin& h = *c.hdr;
     if (tid < 184) sh[L_XC + tid] = state[LS_XC + tid];
@@ -160,7 +181,8 @@ __global__ __launch_bounds__(NT) void k_large_backsub(char* blob, double* ws, KO
     if (tid == 0) out[4] = s4[0];
 }
 
-__global__ __launch_bounds__(256) void k_large_sum_bsums(const double* bsums, int n_chunks, double* out5) {
+__global__ __launch_bounds__(256) void k_large_sum_bsums(const double* bsums, int n_chunks, double* out5, LargeCtl lc) {
+    if (lc.ctl && lc.ctl[LC_DONE] != 0.0) return;
     // 5 scalars x n_chunks: 32 contiguous chunk slices per scalar (8 lanes idle per slice row), slice sums added in slice order
     __shared__ double part[32][8];
     const int i = threadIdx.x & 7, p = threadIdx.x >> 3;
@@ -170,6 +192,79 @@ __global__ __launch_bounds__(256) void k_large_sum_bsums(const double* bsums, in
     part[p][i] = s;
     __syncthreads();
     if (p == 0 && i < 5) { double t = part[0][i]; for (int q = 1; q < 32; ++q) t += part[q][i]; out5[i] = t; }
+}
+
+// The trust-region bookkeeping of one iteration ON THE DEVICE (same order of tests as k_solve / uvs_large_decide / SURVEY.md Appendix B):
+// reads the frame part (out[LO_*], identical on every rank) and the all-reduced landmark scalars sc5 = {g.delta, delta D delta, |delta|^2,
+// |x_c|^2, candidate cost}, updates ctl / the report and, on acceptance, x <- x_c.  One workgroup; every rank runs it on identical inputs.
+__global__ __launch_bounds__(256) void k_large_decide(double* ctl, double* state, const double* out, const double* sc5, const double* reduced, KOpts o, uvs_report* rep) {
+    __shared__ int accept_sh;
+    const int tid = threadIdx.x;
+    if (ctl[LC_DONE] != 0.0) return;
+    if (tid == 0) {
+        accept_sh = 0;
+        double radius = ctl[LC_RADIUS], decr = ctl[LC_DECR], cost = ctl[LC_COST], gmax = ctl[LC_GMAX], x_norm = ctl[LC_XNORM];
+        int it = (int)ctl[LC_IT], invalid = (int)ctl[LC_INVALID], nsucc = (int)ctl[LC_NSUCC], pending = (int)ctl[LC_PENDING], sel = (int)ctl[LC_SEL];
+        int term = UVS_TERM_NO_CONVERGENCE, status = UVS_OK; bool done = false;
+        const double lc_ = out[LO_COST], gm = out[LO_GMAX];
+        if (ctl[LC_FIRST] != 0.0) {
+            cost = lc_; gmax = gm; ctl[LC_FIRST] = 0.0;
+            x_norm = sqrt(ctl[LC_FRAME_X2] + reduced[LX_X2]);      // frames (host) + every rank's landmarks (all-reduced)
+            rep->initial_cost = lc_; rep->cost[0] = lc_; rep->radius[0] = radius; rep->gradient_max_norm[0] = gm; rep->accepted[0] = 1;
+            if (!isfinite(lc_)) { term = UVS_TERM_NUMERIC_FAILURE; status = UVS_ERR_NUMERIC; done = true; }
+        } else if (pending > 0) { cost = lc_; gmax = gm; rep->cost[pending] = lc_; rep->gradient_max_norm[pending] = gm; }
+        pending = 0;
+        if (!done) {
+            if (it >= o.max_it) { term = UVS_TERM_NO_CONVERGENCE; done = true; }
+            else if (gmax <= o.gtol) { term = UVS_TERM_GRADIENT_TOL; done = true; }
+            else if (radius <= o.rmin) { term = UVS_TERM_MIN_RADIUS; done = true; }
+        }
+        if (!done) {
+            ++it;
+            const int ti = it < UVS_MAX_ITER ? it : UVS_MAX_ITER;
+            const double gd = out[LO_GD] + sc5[0], dd2 = out[LO_DD2] + sc5[1], step2 = out[LO_STEP2] + sc5[2], xc2 = out[LO_XC2] + sc5[3];
+            const double mcc = 0.5 * (dd2 - gd);
+            double cand = out[LO_FRAMECOST] + sc5[4];
+            const bool ok = out[LO_CHOLOK] != 0.0 && isfinite(mcc) && isfinite(step2);
+            rep->model_cost_change[ti] = mcc;
+            if (!ok || !(mcc > 0.0)) {
+                ++invalid; radius /= decr; decr *= 2.0;
+                rep->accepted[ti] = -1; rep->cost[ti] = cost; rep->candidate_cost[ti] = cost; rep->radius[ti] = radius; rep->gradient_max_norm[ti] = gmax;
+                if (invalid >= o.max_invalid) { term = UVS_TERM_INVALID_STEPS; done = true; }
+            } else {
+                invalid = 0;
+                if (!isfinite(cand)) cand = 1.7976931348623157e308;
+                const double step_norm = sqrt(step2), rel = (cost - cand) / mcc;
+                const bool successful = rel > o.min_rel;
+                rep->candidate_cost[ti] = cand; rep->step_norm[ti] = step_norm; rep->relative_decrease[ti] = rel; rep->cost[ti] = cost; rep->radius[ti] = radius; rep->gradient_max_norm[ti] = gmax;
+                bool stop = false;
+                if (step_norm <= o.ptol * (x_norm + o.ptol)) { term = UVS_TERM_PARAMETER_TOL; stop = true; }
+                else if (fabs(cost - cand) <= o.ftol * cost) { term = UVS_TERM_FUNCTION_TOL; stop = true; }
+                if (stop && !(o.keep_cand && successful)) done = true;
+                else if (successful) {
+                    accept_sh = 1;
+                    sel ^= 1; ++nsucc; x_norm = sqrt(xc2);
+                    { const double t3 = 2.0 * rel - 1.0; radius = radius / fmax(1.0 / 3.0, 1.0 - t3 * t3 * t3); }
+                    radius = fmin(o.rmax, radius); decr = 2.0;
+                    cost = cand; pending = ti;
+                    rep->accepted[ti] = 1; rep->cost[ti] = cost; rep->radius[ti] = radius;
+                    if (stop || it >= o.max_it) { if (!stop) term = UVS_TERM_NO_CONVERGENCE; done = true; }
+                } else {
+                    radius /= decr; decr *= 2.0;
+                    rep->accepted[ti] = 0; rep->radius[ti] = radius;
+                    if (it >= o.max_it) { term = UVS_TERM_NO_CONVERGENCE; done = true; }
+                }
+            }
+        }
+        ctl[LC_RADIUS] = radius; ctl[LC_DECR] = decr; ctl[LC_COST] = cost; ctl[LC_GMAX] = gmax; ctl[LC_XNORM] = x_norm;
+        ctl[LC_IT] = it; ctl[LC_INVALID] = invalid; ctl[LC_NSUCC] = nsucc; ctl[LC_PENDING] = pending; ctl[LC_SEL] = sel;
+        if (done) {
+            ctl[LC_DONE] = 1.0; ctl[LC_TERM] = term; ctl[LC_STATUS] = status;
+            rep->status = status; rep->termination = term; rep->num_iterations = it; rep->num_successful = nsucc; rep->final_cost = cost;
+        }
+    }
+    __syncthreads();
+    if (accept_sh && tid < 184) state[LS_X + tid] = state[LS_XC + tid];
 }
 
 }  // namespace uvsdev

@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <string>
 #include <vector>
 
@@ -41,6 +42,9 @@ struct uvs_solver {
     char* d_blobs = nullptr; size_t d_blobs_cap = 0;
     double* d_ws = nullptr; size_t d_ws_cap = 0;
     long long* d_blob_off = nullptr; long long* d_ws_off = nullptr; size_t d_off_cap = 0;
+    // packed download: per window {source offset in d_ws, doubles, destination offset} -> one contiguous device buffer -> ONE copy
+    std::vector<long long> out_tab; long long* d_out_tab = nullptr; size_t d_out_tab_cap = 0; double* d_outpack = nullptr; size_t d_outpack_cap = 0; long long out_total = 0;
+    std::vector<double> h_outpack;
     uvs_report* d_reports = nullptr; size_t d_rep_cap = 0;
     double* d_dbg = nullptr;
     EvalScratch eval_scratch;                // uvs_evaluate / uvs_marginalize staging
@@ -52,6 +56,9 @@ struct uvs_solver {
         double *d_state = nullptr, *d_partials = nullptr, *d_reduced = nullptr, *d_bsums = nullptr, *d_out = nullptr, *d_sc5 = nullptr;
         size_t cap_partials = 0, cap_bsums = 0;
         uvs_report rep;
+        double frame_x2 = 0;                                    // frame part of ||x||^2 (the landmark part is per rank: local_x2)
+        double* d_ctl = nullptr; uvs_report* d_rep = nullptr;   // fused loop: trust-region state and report on the device
+        void* comm = nullptr; int rank = 0, nranks = 1;         // RCCL communicator owned by the handle (uvs_large_comm_init)
         double relo_pose_in[7] = {0, 0, 0, 0, 0, 0, 0};      // passes through to uvs_large_finish (this path takes no relocalization blocks)
     } L;
 };
@@ -157,6 +164,11 @@ void uvs_destroy(uvs_solver* s) {
     if (s->d_ws) (void)hipFree(s->d_ws);
     if (s->d_blob_off) (void)hipFree(s->d_blob_off);
     if (s->d_ws_off) (void)hipFree(s->d_ws_off);
+    uvs_large_comm_destroy(s);
+    if (s->L.d_ctl) (void)hipFree(s->L.d_ctl);
+    if (s->L.d_rep) (void)hipFree(s->L.d_rep);
+    if (s->d_out_tab) (void)hipFree(s->d_out_tab);
+    if (s->d_outpack) (void)hipFree(s->d_outpack);
     if (s->d_reports) (void)hipFree(s->d_reports);
     if (s->d_dbg) (void)hipFree(s->d_dbg);
     s->eval_scratch.release();
@@ -647,6 +659,12 @@ static int ensure(uvs_solver* s, void** p, size_t* cap, size_t need) {
     return UVS_OK;
 }
 
+// gathers the per-window outputs into one contiguous buffer: tab[3 b] = {source offset in ws, doubles, destination offset}
+__global__ void k_pack_outputs(const double* ws, const long long* tab, double* out) {
+    const long long src = tab[3 * blockIdx.x], cnt = tab[3 * blockIdx.x + 1], dst = tab[3 * blockIdx.x + 2];
+    for (long long t = threadIdx.x; t < cnt; t += blockDim.x) out[dst + t] = ws[src + t];
+}
+
 extern "C" {
 
 int uvs_batch_upload(uvs_solver* s, int n, const uvs_window* const* ws) {
@@ -664,7 +682,17 @@ int uvs_batch_upload(uvs_solver* s, int n, const uvs_window* const* ws) {
         if (rc != UVS_OK) { s->n_loaded = 0; return rc; }
         s->ws_off[b] = wtot; wtot += s->hdrs[b].ws_doubles;
     }
+    s->out_tab.resize(3 * (size_t)n); s->out_total = 0;
+    for (int b = 0; b < n; ++b) {
+        const DevWin& h = s->hdrs[b];
+        const long long cnt = UVS_XDIM + (long long)h.n_points + 4 * (long long)h.n_lines;
+        s->out_tab[3 * b] = s->ws_off[b] + h.w_out; s->out_tab[3 * b + 1] = cnt; s->out_tab[3 * b + 2] = s->out_total;
+        s->out_total += cnt;
+    }
     int rc;
+    if ((rc = ensure(s, (void**)&s->d_out_tab, &s->d_out_tab_cap, (size_t)n * 24)) != UVS_OK) return rc;
+    if ((rc = ensure(s, (void**)&s->d_outpack, &s->d_outpack_cap, (size_t)s->out_total * 8)) != UVS_OK) return rc;
+    HIPCHK(s, hipMemcpyAsync(s->d_out_tab, s->out_tab.data(), (size_t)n * 24, hipMemcpyHostToDevice, s->stream));
     if ((rc = ensure(s, (void**)&s->d_blobs, &s->d_blobs_cap, s->host_blobs.size())) != UVS_OK) return rc;
     if ((rc = ensure(s, (void**)&s->d_ws, &s->d_ws_cap, (size_t)wtot * 8)) != UVS_OK) return rc;
     size_t offcap = s->d_off_cap;
@@ -711,20 +739,26 @@ int uvs_batch_download(uvs_solver* s, int n, uvs_state* states, uvs_report* reps
         HIPCHK(s, hipMemcpy(reps, s->d_reports, sizeof(uvs_report) * (size_t)n, hipMemcpyDeviceToHost));
         for (int b = 0; b < n; ++b) if (reps[b].status != UVS_OK) worst = reps[b].status;
     }
-    std::vector<double> buf;
+    if (states) {
+        // every window's final state (frames | inv_depth | line_orth, written by k_solve into its workspace) is gathered on the device and
+        // fetched with ONE copy: 256 windows were 256 synchronous round trips before
+        hipLaunchKernelGGL(k_pack_outputs, dim3(n), dim3(256), 0, s->stream, s->d_ws, s->d_out_tab, s->d_outpack);
+        const size_t tot = (size_t)(s->out_tab[3 * (size_t)(n - 1) + 2] + s->out_tab[3 * (size_t)(n - 1) + 1]);
+        s->h_outpack.resize(tot);
+        HIPCHK(s, hipMemcpyAsync(s->h_outpack.data(), s->d_outpack, tot * 8, hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(s, hipStreamSynchronize(s->stream));
+    }
     for (int b = 0; states && b < n; ++b) {
         const DevWin& h = s->hdrs[b];
-        const size_t cnt = UVS_XDIM + (size_t)h.n_points + 4 * (size_t)h.n_lines;
-        buf.resize(cnt);
-        HIPCHK(s, hipMemcpy(buf.data(), s->d_ws + s->ws_off[b] + h.w_out, cnt * 8, hipMemcpyDeviceToHost));
+        const double* buf = s->h_outpack.data() + s->out_tab[3 * (size_t)b + 2];
         uvs_state& st = states[b];
-        std::memcpy(st.pose, buf.data(), sizeof(double) * 77);
-        std::memcpy(st.speedbias, buf.data() + 77, sizeof(double) * 99);
-        std::memcpy(st.ex_pose, buf.data() + 176, sizeof(double) * 7);
+        std::memcpy(st.pose, buf, sizeof(double) * 77);
+        std::memcpy(st.speedbias, buf + 77, sizeof(double) * 99);
+        std::memcpy(st.ex_pose, buf + 176, sizeof(double) * 7);
         st.td = buf[183];
-        std::memcpy(st.relo_pose, buf.data() + 184, sizeof(double) * 7);
-        if (st.inv_depth) std::memcpy(st.inv_depth, buf.data() + UVS_XDIM, sizeof(double) * h.n_points);
-        if (st.line_orth) std::memcpy(st.line_orth, buf.data() + UVS_XDIM + h.n_points, sizeof(double) * 4 * h.n_lines);
+        std::memcpy(st.relo_pose, buf + 184, sizeof(double) * 7);
+        if (st.inv_depth) std::memcpy(st.inv_depth, buf + UVS_XDIM, sizeof(double) * h.n_points);
+        if (st.line_orth) std::memcpy(st.line_orth, buf + UVS_XDIM + h.n_points, sizeof(double) * 4 * h.n_lines);
     }
     return worst;
 }
@@ -812,9 +846,11 @@ int uvs_large_begin(uvs_solver* s, const uvs_window* w) {
     int rc = uvs_batch_upload(s, 1, arr);
     if (rc != UVS_OK) return rc;
     auto& L = s->L; const DevWin& h = s->hdrs[0];
+    double* keep_ctl = L.d_ctl; uvs_report* keep_rep = L.d_rep; void* keep_comm = L.comm; const int keep_rank = L.rank, keep_nranks = L.nranks;
     L = uvs_solver::Large{L.active, 0, 0, 0, 0, 0, 0, 0, 0, true, true, false, 0, 2, 0, 0, 0, 0, L.d_state, L.d_partials, L.d_reduced, L.d_bsums, L.d_out, L.d_sc5, L.cap_partials, L.cap_bsums, {}};
     L.active = true; L.n_chunks = h.n_chunks; L.radius = s->opts.initial_trust_region_radius;
-    if (!L.d_state) { HIPCHK(s, hipMalloc((void**)&L.d_state, LG_STATE * 8)); HIPCHK(s, hipMalloc((void**)&L.d_reduced, LG_RED * 8)); HIPCHK(s, hipMalloc((void**)&L.d_out, 64 * 8)); HIPCHK(s, hipMalloc((void**)&L.d_sc5, 8 * 8)); }
+    L.d_ctl = keep_ctl; L.d_rep = keep_rep; L.comm = keep_comm; L.rank = keep_rank; L.nranks = keep_nranks;
+    if (!L.d_state) { HIPCHK(s, hipMalloc((void**)&L.d_state, LG_STATE * 8)); HIPCHK(s, hipMalloc((void**)&L.d_reduced, LG_XCH * 8)); HIPCHK(s, hipMemset(L.d_reduced, 0, LG_XCH * 8)); HIPCHK(s, hipMalloc((void**)&L.d_out, 64 * 8)); HIPCHK(s, hipMalloc((void**)&L.d_sc5, 8 * 8)); }
     int r2;
     if ((r2 = ensure(s, (void**)&L.d_partials, &L.cap_partials, (size_t)std::max(L.n_chunks, 1) * LG_RED * 8)) != UVS_OK) return r2;
     if ((r2 = ensure(s, (void**)&L.d_bsums, &L.cap_bsums, (size_t)std::max(L.n_chunks, 1) * 8 * 8)) != UVS_OK) return r2;
@@ -830,7 +866,7 @@ int uvs_large_begin(uvs_solver* s, const uvs_window* w) {
     double l2 = 0.0;
     for (int k = 0; k < w->n_points; ++k) l2 += w->inv_depth[k] * w->inv_depth[k];
     for (int k = 0; k < 4 * w->n_lines; ++k) l2 += w->line_orth[k] * w->line_orth[k];
-    L.local_x2 = l2; L.x_norm = std::sqrt(x2 + l2);
+    L.local_x2 = l2; L.x_norm = std::sqrt(x2 + l2); L.frame_x2 = x2;
     std::memset(&L.rep, 0, sizeof(L.rep));
     std::memcpy(L.relo_pose_in, w->relo_pose, sizeof(L.relo_pose_in));
     HIPCHK(s, hipStreamSynchronize(s->stream));
@@ -860,8 +896,8 @@ int uvs_large_linearize(uvs_solver* s) {
     auto& L = s->L;
     HIPCHK(s, hipSetDevice(s->device));
     KOpts ko = make_kopts(s->opts, 0);
-    if (L.n_chunks > 0) hipLaunchKernelGGL(k_large_chunks, dim3(L.n_chunks), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, L.sel, L.first ? 1 : 0, L.radius, L.d_partials);
-    hipLaunchKernelGGL(k_large_reduce, dim3((LG_RED + 15) / 16), dim3(256), 0, s->stream, L.d_partials, L.n_chunks, L.d_reduced);
+    if (L.n_chunks > 0) hipLaunchKernelGGL(k_large_chunks, dim3(L.n_chunks), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, L.sel, L.first ? 1 : 0, L.radius, L.d_partials, LargeCtl{nullptr, 0, 0});
+    hipLaunchKernelGGL(k_large_reduce, dim3((LG_RED + 15) / 16), dim3(256), 0, s->stream, L.d_partials, L.n_chunks, L.d_reduced, LargeCtl{nullptr, 0, 0});
     HIPCHK(s, hipGetLastError());
     HIPCHK(s, hipStreamSynchronize(s->stream));
     return UVS_OK;
@@ -872,9 +908,9 @@ int uvs_large_step(uvs_solver* s) {
     auto& L = s->L;
     HIPCHK(s, hipSetDevice(s->device));
     KOpts ko = make_kopts(s->opts, 0);
-    hipLaunchKernelGGL(k_large_solve, dim3(1), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, L.d_reduced, L.first ? 1 : 0, L.radius, L.d_out);
-    if (L.n_chunks > 0) hipLaunchKernelGGL(k_large_backsub, dim3(L.n_chunks), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, L.sel, L.d_bsums);
-    hipLaunchKernelGGL(k_large_sum_bsums, dim3(1), dim3(256), 0, s->stream, L.d_bsums, L.n_chunks, L.d_sc5);
+    hipLaunchKernelGGL(k_large_solve, dim3(1), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, L.d_reduced, L.first ? 1 : 0, L.radius, L.d_out, LargeCtl{nullptr, 0, 0});
+    if (L.n_chunks > 0) hipLaunchKernelGGL(k_large_backsub, dim3(L.n_chunks), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, L.sel, L.d_bsums, LargeCtl{nullptr, 0, 0});
+    hipLaunchKernelGGL(k_large_sum_bsums, dim3(1), dim3(256), 0, s->stream, L.d_bsums, L.n_chunks, L.d_sc5, LargeCtl{nullptr, 0, 0});
     HIPCHK(s, hipGetLastError());
     HIPCHK(s, hipStreamSynchronize(s->stream));
     return UVS_OK;
@@ -963,6 +999,113 @@ int uvs_large_solve(uvs_solver* s, const uvs_window* w, uvs_state* out, uvs_repo
         if ((rc = uvs_large_decide(s)) != UVS_OK) return rc;
     }
     return uvs_large_finish(s, out, rep);
+}
+
+
+// ---------------------------------------------------------------- fused loop: RCCL communicator owned by the handle, control on the device
+// RCCL is resolved at run time (dlopen): the library itself carries no dependency on it, a process that already holds RCCL (PyTorch)
+// shares that copy.  UVS_RCCL_LIB overrides the search.
+namespace {
+struct RcclApi {
+    void* lib = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, uvs_rccl_id, int) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    std::string err;
+};
+RcclApi& rccl() {
+    static RcclApi api;
+    if (api.lib || !api.err.empty()) return api;
+    const char* env = std::getenv("UVS_RCCL_LIB");
+    const char* names[3] = {env ? env : "librccl.so", "librccl.so.1", "librccl.so"};
+    for (int pass = 0; pass < 2 && !api.lib; ++pass)              // first a copy that is already loaded, then a fresh one
+        for (const char* n : names) { api.lib = dlopen(n, RTLD_NOW | (pass == 0 ? RTLD_NOLOAD : 0)); if (api.lib) break; }
+    if (!api.lib) { api.err = "RCCL not found (librccl.so / librccl.so.1; set UVS_RCCL_LIB)"; return api; }
+    api.GetUniqueId = (int (*)(void*))dlsym(api.lib, "ncclGetUniqueId");
+    api.CommInitRank = (int (*)(void**, int, uvs_rccl_id, int))dlsym(api.lib, "ncclCommInitRank");
+    api.CommDestroy = (int (*)(void*))dlsym(api.lib, "ncclCommDestroy");
+    api.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(api.lib, "ncclAllReduce");
+    api.GetErrorString = (const char* (*)(int))dlsym(api.lib, "ncclGetErrorString");
+    if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllReduce) { api.err = "RCCL symbols missing"; api.lib = nullptr; }
+    return api;
+}
+constexpr int kNcclDouble = 8, kNcclSum = 0;      // rccl.h: ncclFloat64 = 8, ncclSum = 0
+}  // namespace
+
+int uvs_large_comm_unique_id(uvs_rccl_id* id) {
+    if (!id) return UVS_ERR_INVALID_ARG;
+    RcclApi& r = rccl();
+    if (!r.lib) return UVS_ERR_UNSUPPORTED;
+    return r.GetUniqueId(id) == 0 ? UVS_OK : UVS_ERR_HIP;
+}
+
+int uvs_large_comm_init(uvs_solver* s, int nranks, int rank, const uvs_rccl_id* id) {
+    if (!s || nranks < 1 || nranks > LG_MAXRANKS || rank < 0 || rank >= nranks || (nranks > 1 && !id)) return UVS_ERR_INVALID_ARG;
+    auto& L = s->L;
+    uvs_large_comm_destroy(s);
+    L.rank = rank; L.nranks = nranks;
+    if (nranks == 1 && !id) return UVS_OK;                        // nothing to exchange (with an id a one-rank communicator is built all the same: exercises the RCCL path on one GPU)
+    RcclApi& r = rccl();
+    if (!r.lib) { s->err = r.err; return UVS_ERR_UNSUPPORTED; }
+    HIPCHK(s, hipSetDevice(s->device));
+    const int rc = r.CommInitRank(&L.comm, nranks, *id, rank);
+    if (rc != 0) { s->err = std::string("ncclCommInitRank: ") + (r.GetErrorString ? r.GetErrorString(rc) : "error"); L.comm = nullptr; L.nranks = 1; L.rank = 0; return UVS_ERR_HIP; }
+    return UVS_OK;
+}
+
+void uvs_large_comm_destroy(uvs_solver* s) {
+    if (!s) return;
+    auto& L = s->L;
+    if (L.comm) { (void)hipSetDevice(s->device); rccl().CommDestroy(L.comm); L.comm = nullptr; }
+    L.rank = 0; L.nranks = 1;
+}
+
+// ONE large window, landmark-sharded over the ranks of the handle's communicator (`w` = this rank's landmarks, frames / IMU / prior
+// replicated), the whole Levenberg-Marquardt loop enqueued on the handle's stream without a host round trip: per iteration
+//   k_large_chunks -> k_large_reduce -> ncclAllReduce(reduced, SUM, in place) -> k_large_solve -> k_large_backsub -> k_large_sum_bsums
+//   -> ncclAllReduce(5 scalars) -> k_large_decide
+// Every rank decides on identical numbers, so all ranks follow the same path; kernels of iterations after termination return at once.
+int uvs_large_solve_fused(uvs_solver* s, const uvs_window* w, uvs_state* out, uvs_report* rep, float* loop_ms) {
+    if (!s || !w || !out || !rep) return UVS_ERR_INVALID_ARG;
+    int rc = uvs_large_begin(s, w);
+    if (rc != UVS_OK) return rc;
+    auto& L = s->L; const uvs_options& o = s->opts;
+    if (!L.d_ctl) { HIPCHK(s, hipMalloc((void**)&L.d_ctl, 64 * 8)); HIPCHK(s, hipMalloc((void**)&L.d_rep, sizeof(uvs_report))); }
+    double ctl[64] = {0};
+    ctl[LC_RADIUS] = o.initial_trust_region_radius; ctl[LC_DECR] = 2.0; ctl[LC_FIRST] = 1.0; ctl[LC_FRAME_X2] = L.frame_x2;
+    HIPCHK(s, hipMemcpyAsync(L.d_ctl, ctl, sizeof(ctl), hipMemcpyHostToDevice, s->stream));
+    HIPCHK(s, hipMemsetAsync(L.d_rep, 0, sizeof(uvs_report), s->stream));
+    HIPCHK(s, hipMemsetAsync(L.d_reduced, 0, LG_XCH * 8, s->stream));
+    HIPCHK(s, hipMemcpyAsync(L.d_reduced + LX_X2, &L.local_x2, 8, hipMemcpyHostToDevice, s->stream));
+    const KOpts ko = make_kopts(o, 0);
+    const LargeCtl lc{L.d_ctl, L.rank, L.nranks};
+    RcclApi& r = rccl();
+    const int passes = std::max(1, o.max_num_iterations);
+    HIPCHK(s, hipEventRecord(s->ev0, s->stream));
+    for (int p = 0; p < passes; ++p) {
+        if (L.n_chunks > 0) hipLaunchKernelGGL(k_large_chunks, dim3(L.n_chunks), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, 0, 0, 0.0, L.d_partials, lc);
+        hipLaunchKernelGGL(k_large_reduce, dim3((LG_RED + 15) / 16), dim3(256), 0, s->stream, L.d_partials, L.n_chunks, L.d_reduced, lc);
+        if (L.comm) { const int e = r.AllReduce(L.d_reduced, L.d_reduced, LG_XCH, kNcclDouble, kNcclSum, L.comm, s->stream); if (e != 0) { s->err = "ncclAllReduce failed"; return UVS_ERR_HIP; } }
+        hipLaunchKernelGGL(k_large_solve, dim3(1), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, L.d_reduced, 0, 0.0, L.d_out, lc);
+        if (L.n_chunks > 0) hipLaunchKernelGGL(k_large_backsub, dim3(L.n_chunks), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, 0, L.d_bsums, lc);
+        hipLaunchKernelGGL(k_large_sum_bsums, dim3(1), dim3(256), 0, s->stream, L.d_bsums, L.n_chunks, L.d_sc5, lc);
+        if (L.comm) { const int e = r.AllReduce(L.d_sc5, L.d_sc5, 8, kNcclDouble, kNcclSum, L.comm, s->stream); if (e != 0) { s->err = "ncclAllReduce failed"; return UVS_ERR_HIP; } }
+        hipLaunchKernelGGL(k_large_decide, dim3(1), dim3(256), 0, s->stream, L.d_ctl, L.d_state, L.d_out, L.d_sc5, L.d_reduced, ko, L.d_rep);
+    }
+    HIPCHK(s, hipEventRecord(s->ev1, s->stream));
+    HIPCHK(s, hipGetLastError());
+    HIPCHK(s, hipMemcpyAsync(ctl, L.d_ctl, sizeof(ctl), hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(s, hipMemcpyAsync(&L.rep, L.d_rep, sizeof(uvs_report), hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(s, hipStreamSynchronize(s->stream));
+    if (loop_ms) HIPCHK(s, hipEventElapsedTime(loop_ms, s->ev0, s->ev1));
+    if (ctl[LC_DONE] == 0.0) { s->err = "fused large-window loop did not terminate within max_num_iterations passes"; L.active = false; return UVS_ERR_NUMERIC; }
+    L.sel = (int)ctl[LC_SEL]; L.it = (int)ctl[LC_IT]; L.nsucc = (int)ctl[LC_NSUCC]; L.term = (int)ctl[LC_TERM]; L.status = (int)ctl[LC_STATUS]; L.cost = ctl[LC_COST]; L.done = true;
+    const uvs_report keep = L.rep;
+    rc = uvs_large_finish(s, out, rep);
+    *rep = keep;
+    return rc;
 }
 
 }  // extern "C"
