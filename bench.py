@@ -9,8 +9,18 @@ its own batch (independent windows => replicas, no data-path collective,
 "scaling": "weak"); timing is barrier + synchronize on both sides, max over ranks.
 
 Rank 0 prints ONE JSON line with the contract fields plus `roofline` and
-`cpu_baseline` (the CPU oracle -- a single-thread port of the reference solve --
-timed on a bounded sample of the same windows on this box's host cores).
+`cpu_baseline` (the CPU oracle -- a port of the reference solve -- timed on a
+bounded sample of the same windows on this box's host cores: one thread, which
+is what the reference gives Ceres (estimator.cpp:985 leaves num_threads = 1), and
+one window per core as the throughput comparator; built -O3 -march=native ON
+THE BOX for this leg so that the ratio is not quoted against a slow build).
+
+Also in the line (never `value`): `single_window` = BASELINE configs[1] (one
+resident window, its own roofline fraction, the PCIe-inclusive rate),
+`batch_pack_upload_ms` (host packing + H2D of the 256 windows, outside the timed
+region), `large_window` = configs[3] (20 000 points + 5 000 lines) through the
+fused loop -- with --gpus N the landmarks are sharded k mod N over the ranks and
+the reduced system is all-reduced over RCCL by the library's own communicator.
 """
 import argparse
 import importlib
@@ -26,6 +36,16 @@ sys.path.insert(0, ROOT)
 
 FP64_PEAK_TFLOPS = 78.6      # MI355X FP64 vector = FP64 matrix (datasheet; not listed in MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def kernel_source_tag():
+    """sha1 over the kernel sources: profiles/pmc_traffic.json carries the tag of the build it was measured on (profiles/summarize.py)."""
+    import hashlib
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "uv-slam_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def algorithmic_flops(w, n_iterations):
@@ -88,15 +108,22 @@ def main():
     solver = api.Solver(device=local_rank, max_batch=max(args.batch, 1))
     # ---- synthetic inputs (seed = 1000 + global window index); prior from the PRODUCT's own marginalization
     marg = None if args.no_prior else (lambda win, flag: solver.marginalize(win, flag))
-    t_gen = time.time()
     windows = [synth.make_window(rank * args.batch + i, with_prior=marg is not None, marginalize_fn=marg) for i in range(args.batch)]
-    t_gen = time.time() - t_gen
-    solver.upload(windows)
+    t0 = time.perf_counter()
+    solver.upload(windows)                    # host packing + H2D: OUTSIDE the timed region, reported as batch_pack_upload_ms
+    pack_upload_ms = (time.perf_counter() - t0) * 1e3
 
     def sync():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
     for _ in range(args.warmup):
         solver.solve_resident()
@@ -104,16 +131,43 @@ def main():
     t0 = time.perf_counter()
     kernel_ms = []
     for _ in range(args.steps):
-        kernel_ms.append(solver.solve_resident())
+        kernel_ms.append(solver.solve_resident())        # HIP events on the solver's own stream around the launch
     sync()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(time.perf_counter() - t0)
     states, reps = solver.download()
     n_total = args.batch * world * args.steps
     value = n_total / elapsed
+
+    # ---- BASELINE configs[3]: ONE window with 20 000 points + 5 000 lines, landmarks sharded k mod N over the ranks (all ranks take part)
+    large = None
+    if not args.no_large:
+        wl = synth.make_window(70, n_points=20000, n_lines=5000, n_tagged=3750)
+        shard = synth.shard_landmarks(wl, rank, world)[0] if world > 1 else wl
+        sl = api.Solver(device=local_rank, max_batch=1, max_points=20008, max_point_obs=240000, max_lines=5008, max_line_obs=60000)
+        sl.large_comm_init(dist if world > 1 and dist.get_backend() == "nccl" else None)
+        if world > 1 and dist.get_backend() != "nccl":
+            large = {"skipped": "the fused loop all-reduces over RCCL; dry runs on another backend skip it"}
+        else:
+            loop_ms, wall_ms = [], []
+            for rep_i in range(4):
+                sync(); t0 = time.perf_counter()
+                stl, repl, ms = sl.large_solve_fused(shard)
+                torch.cuda.synchronize(); wall = (time.perf_counter() - t0) * 1e3
+                if rep_i:                      # the first pass warms the code objects / the communicator
+                    loop_ms.append(max_over_ranks(ms)); wall_ms.append(max_over_ranks(wall))
+            fl = algorithmic_flops(wl, int(repl.num_iterations))
+            lm = float(np.median(loop_ms))
+            large = {"workload": f"configs[3]: 10-KF window, 20000 points / 100000 obs, 5000 lines / 35000 obs, landmarks sharded k mod {world} over {world} GPU(s), "
+                                 "reduced system all-reduced over RCCL by the library's communicator" if world > 1 else
+                                 "configs[3]: 10-KF window, 20000 points / 100000 obs, 5000 lines / 35000 obs, 1 GPU (fused loop: control on the device)",
+                     "n_gpus": world, "lm_iterations": int(repl.num_iterations), "final_cost": float(repl.final_cost),
+                     "resident_lm_loop_ms": lm, "wall_ms_pack_upload_loop_download": float(np.median(wall_ms)), "solves_per_s_resident": 1e3 / lm,
+                     "collectives_per_iteration": 2 if world > 1 else 0, "allreduce_payload_bytes": [5016 * 8, 64],
+                     "roofline": {"bound": "mfma", "kernels": "uvsdev::k_large_chunks / k_large_solve / k_large_backsub", "achieved": fl / (lm * 1e-3) / 1e12,
+                                  "peak": FP64_PEAK_TFLOPS * world, "unit": "TFLOP/s", "frac": fl / (lm * 1e-3) / 1e12 / (FP64_PEAK_TFLOPS * world),
+                                  "algorithmic_flops_per_solve": fl, "algorithmic_bytes_per_solve": float(synth.algorithmic_bytes(wl)), "traffic": None,
+                                  "note": "whole resident LM loop (all kernels + collectives) against N x the FP64 roof; SURVEY.md 8d flop model"}}
+        sl.close()
 
     if rank == 0:
         its = np.array([r.num_iterations for r in reps])
@@ -122,40 +176,72 @@ def main():
         k_ms = float(np.mean(kernel_ms))
         ach_tflops = flops_per_launch / (k_ms * 1e-3) / 1e12
         ach_gbs = bytes_per_launch / (k_ms * 1e-3) / 1e9
-        traffic = None
+        # HBM traffic per launch from the PMC passes of profiles/collect.sh -- only if it was measured on THIS kernel build
+        traffic, traffic_note = None, "no profiles/pmc_traffic.json"
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+                tj = json.load(open(tpath))
+                if tj.get("kernel_source_tag") == kernel_source_tag():
+                    traffic, traffic_note = tj.get("hbm_bytes_per_launch"), "rocprofv3 PMC, " + str(tj.get("source"))
+                else:
+                    traffic_note = "profiles/pmc_traffic.json was measured on another kernel build (tag %s, this build %s): not reported" % (tj.get("kernel_source_tag"), kernel_source_tag())
+            except Exception as e:
+                traffic_note = "unreadable profiles/pmc_traffic.json: %s" % e
         roofline = {"bound": "mfma", "kernel": "uvsdev::k_solve", "achieved": ach_tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": ach_tflops / FP64_PEAK_TFLOPS, "traffic": traffic,
+                    "frac": ach_tflops / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
                     "kernel_ms_per_launch": k_ms, "algorithmic_flops_per_launch": flops_per_launch,
                     "algorithmic_bytes_per_launch": bytes_per_launch, "hbm_achieved_GBps": ach_gbs, "hbm_frac": ach_gbs / HBM_PEAK_GBS,
                     "note": "'mfma' bound = FP64 FLOP roof 78.6 TF/s (FP64 MFMA rate = FP64 vector rate on MI355X); flop/byte model of SURVEY.md 8d; "
                             "dense reduced solve + IMU blocks run on v_mfma_f64_16x16x4_f64, the sparse 6x6 Schur gather on VALU; the kernel is latency bound "
-                            "(rocprofv3: 59% of wave cycles in SQ_WAIT_ANY, profiles/r01m_pmc_summary.json); traffic = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 of the same command (8 B/lane calibration: profiles/fetch_calibration.txt)"}
-        cpu = None
-        if world == 1 and not args.no_cpu_baseline:
-            sys.path.insert(0, os.path.join(ROOT, "tests"))
-            from oracle_binding import Oracle     # CPU oracle: baseline leg only
-            orc = Oracle()
-            t1 = time.perf_counter(); orc.solve(windows[0]); one = time.perf_counter() - t1
-            ns = args.cpu_sample or int(max(8, min(args.batch, 15.0 / max(one, 1e-3))))
-            t1 = time.perf_counter()
-            for w in windows[:ns]:
-                orc.solve(w)
-            tc = time.perf_counter() - t1
-            cpu = {"value": ns / tc, "unit": "solves/s", "cores": 1, "kind": "port",
-                   "sample": f"first {ns} windows of the same batch, single-thread C++ oracle (oracle/uvs_oracle.cpp), {tc:.1f} s",
-                   "host_cpus": os.cpu_count()}
+                            "(one wavefront per SIMD, see DESIGN.md section 5); traffic = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 of the same command (8 B/lane calibration: profiles/fetch_calibration.txt)"}
         # single-window latency mode (BASELINE configs[1]): one window resident, one launch per solve
         solver.upload(windows[:1])
         for _ in range(3):
             solver.solve_resident()
         lat = [solver.solve_resident() for _ in range(10)]
         t1 = time.perf_counter(); solver.solve(windows[0]); pcie = time.perf_counter() - t1
+        sw_ms = float(np.median(lat)); sw_fl = float(algorithmic_flops(windows[0], int(reps[0].num_iterations)))
+        single = {"workload": "BASELINE configs[1]: one resident W10-P150-L40-V3 window (with the n = 75 prior), one launch per solve",
+                  "ms": sw_ms, "solves_per_s": 1e3 / sw_ms, "pcie_inclusive_ms": pcie * 1e3, "pcie_inclusive_solves_per_s": 1.0 / pcie,
+                  "roofline": {"bound": "mfma", "kernel": "uvsdev::k_solve (1 workgroup on 1 of 256 CUs)", "achieved": sw_fl / (sw_ms * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS,
+                               "unit": "TFLOP/s", "frac": sw_fl / (sw_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, "frac_of_one_cu": sw_fl / (sw_ms * 1e-3) / 1e12 / (FP64_PEAK_TFLOPS / 256),
+                               "note": "a single window occupies one compute unit: the whole-chip fraction is bounded by 1/256, the per-CU fraction is the meaningful one"}}
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from oracle_binding import Oracle     # CPU oracle: baseline leg only
+            import subprocess, tempfile
+            from concurrent.futures import ThreadPoolExecutor
+            # the same oracle sources built -O3 -march=native on THIS host (the checker build is -O2 and portable)
+            native_dir = tempfile.mkdtemp(); native = os.path.join(native_dir, "liboracle_native.so"); build = "-O3 -march=native (built on this host)"
+            try:
+                subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "native", "OUT=" + native_dir], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                orc = Oracle(native)
+            except Exception:
+                orc = Oracle(); build = "-O2 checker build (the native build failed on this host)"
+            t1 = time.perf_counter(); orc.solve(windows[0]); one = time.perf_counter() - t1
+            ns = args.cpu_sample or int(max(8, min(args.batch, 10.0 / max(one, 1e-3))))
+            t1 = time.perf_counter()
+            for w in windows[:ns]:
+                orc.solve(w)
+            tc = time.perf_counter() - t1
+            # one window per core (ctypes releases the GIL; the oracle keeps no global state): the throughput comparator of BASELINE.md section 3
+            cores = os.cpu_count() or 1
+            threads = cores
+            nmt = int(min(20000, max(threads, threads * 8.0 / max(one, 1e-3))))      # ~8 s of wall time
+            jobs = [orc.prepare(w) for w in windows]                   # struct conversion happens under the GIL: outside the timed region
+            rounds = max(1, nmt // len(jobs)); nmt = rounds * len(jobs)
+            def run_slice(k):                                          # thread k solves windows k, k + threads, ... `rounds` times
+                for _ in range(rounds):
+                    for j in range(k, len(jobs), threads):
+                        orc.solve_prepared(jobs[j])
+            with ThreadPoolExecutor(max_workers=threads) as ex:
+                t1 = time.perf_counter(); list(ex.map(run_slice, range(threads))); tm = time.perf_counter() - t1
+            cpu = {"value": ns / tc, "unit": "solves/s", "cores": 1, "kind": "port",
+                   "sample": f"first {ns} windows of the same batch, single-thread C++ oracle (oracle/uvs_oracle.cpp, {build}), {tc:.1f} s",
+                   "host_cpus": cores,
+                   "multithread": {"value": nmt / tm, "unit": "solves/s", "cores": threads, "sample": f"{nmt} solves over the same batch, one window per thread on {threads} threads, {tm:.1f} s"}}
         # closed-loop replay of a synthetic frame sequence through the product host library (ATE half of BASELINE.json's metric;
         # the stand-in for configs[4]): processIMU / processImage / optimization (HIP) / marginalization (HIP) / slideWindow
         replay = None
@@ -182,38 +268,17 @@ def main():
             if cpu is not None:       # the same state machine with the CPU oracle behind the C ABI (baseline leg only)
                 ate_o, ms_o, _ = run_replay(os.path.join(ROOT, "oracle", "libuvs_host_oracle.so"))
                 cpu["replay_ate_vs_truth_m"] = ate_o; cpu["replay_ms_per_frame"] = ms_o
-        # BASELINE configs[3] on this one GPU (informational; the multi-GPU runs shard the landmarks, api.Solver.large_solve(dist=...)):
-        # 20 000 point + 5 000 line landmarks through the grid path; begin = host packing + upload, loop = resident LM iterations
-        large = None
-        if world == 1 and not args.no_large:
-            import ctypes as C
-            wl = synth.make_window(70, n_points=20000, n_lines=5000, n_tagged=3750)
-            sl = uvs.api.Solver(max_batch=1, max_points=20008, max_point_obs=240000, max_lines=5008, max_line_obs=60000)
-            Ll = uvs.api.lib()
-            wc, keep = wl.to_c(); stl = uvs.abi.State(len(wl.inv_depth), len(wl.line_orth)); scl = stl.alloc_c(); repl = uvs.abi.Report()
-            best = None
-            for _ in range(3):
-                t0 = time.perf_counter(); rc = Ll.uvs_large_begin(sl._h, C.byref(wc)); t1 = time.perf_counter()
-                while rc == 0 and not Ll.uvs_large_done(sl._h):
-                    if Ll.uvs_large_need_linearize(sl._h): Ll.uvs_large_linearize(sl._h)
-                    Ll.uvs_large_step(sl._h); Ll.uvs_large_decide(sl._h)
-                t2 = time.perf_counter(); Ll.uvs_large_finish(sl._h, C.byref(scl), C.byref(repl)); t3 = time.perf_counter()
-                cur = {"begin_pack_upload_ms": (t1 - t0) * 1e3, "resident_lm_loop_ms": (t2 - t1) * 1e3, "finish_download_ms": (t3 - t2) * 1e3}
-                if best is None or cur["resident_lm_loop_ms"] < best["resident_lm_loop_ms"]: best = cur
-            large = {"workload": "configs[3]: 10-KF window, 20000 points / 100000 obs, 5000 lines / 35000 obs, 1 GPU", "lm_iterations": int(repl.num_iterations),
-                     "final_cost": float(repl.final_cost), **best}
-            sl.close()
         out = {
             "metric": "sliding-window solves/sec (10 KF, 150 pts, 40 lines, 3 VP)", "value": value, "unit": "solves/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"W10-P150-L40-V3 x {args.batch} independent windows per GPU (BASELINE configs[2]); "
-                                   "single-window latency (configs[1]) in single_window_*",
+                                   "single window (configs[1]) in single_window, the 20k-point window (configs[3]) in large_window",
                        "windows_per_gpu": args.batch, "frames": 11, "points": 150, "lines": 40, "vp_tagged_lines": 30,
                        "prior": (not args.no_prior), "max_lm_iterations": 10, "parallelism": f"replicas x{world}"},
             "lm_iterations_mean": float(its.mean()), "final_cost_mean": float(np.mean([r.final_cost for r in reps])),
-            "single_window_ms": float(np.median(lat)), "single_window_solves_per_s": 1e3 / float(np.median(lat)),
-            "single_window_pcie_inclusive_ms": pcie * 1e3,
+            "batch_pack_upload_ms": pack_upload_ms,
+            "single_window": single, "single_window_ms": sw_ms, "single_window_solves_per_s": 1e3 / sw_ms, "single_window_pcie_inclusive_ms": pcie * 1e3,
             "replay": replay, "large_window": large, "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out))

@@ -35,5 +35,9 @@ if "FETCH_SIZE_per_launch_mean" in out:
     out["hbm_bytes_per_launch_uncorrected"] = (out["FETCH_SIZE_per_launch_mean"] + out["WRITE_SIZE_per_launch_mean"]) * 1024
 json.dump(out, open(f"{ROOT}/profiles/{tag}_pmc_summary.json", "w"), indent=1)
 if "hbm_bytes_per_launch" in out:
-    json.dump({"hbm_bytes_per_launch": out["hbm_bytes_per_launch"], "source": f"profiles/{tag}_pmc_summary.json"}, open(f"{ROOT}/profiles/pmc_traffic.json", "w"))
+    # bench.py reports this figure only while the kernel sources still hash to the tag recorded here (run summarize.py on the build that was profiled)
+    sys.path.insert(0, ROOT)
+    import bench
+    json.dump({"hbm_bytes_per_launch": out["hbm_bytes_per_launch"], "source": f"profiles/{tag}_pmc_summary.json", "kernel_source_tag": bench.kernel_source_tag()},
+              open(f"{ROOT}/profiles/pmc_traffic.json", "w"))
 print(json.dumps(out, indent=1))

@@ -23,8 +23,9 @@ def _build():
 
 
 class Oracle:
-    def __init__(self):
-        self.lib = C.CDLL(_build())
+    def __init__(self, lib_path=None):
+        """lib_path: another build of the same sources (bench.py's cpu_baseline leg times an -O3 -march=native build made on the box)."""
+        self.lib = C.CDLL(lib_path or _build())
         L = self.lib
         L.oracle_solve.argtypes = [C.POINTER(abi.Options), C.POINTER(abi.WindowC), C.c_int, C.POINTER(abi.StateC), C.POINTER(abi.Report)]
         L.oracle_solve.restype = C.c_int
@@ -46,6 +47,17 @@ class Oracle:
         assert rc in (abi.UVS_OK, abi.UVS_ERR_NUMERIC), rc
         st.from_c(sc)
         return st, rep
+
+    def prepare(self, w, opts=None):
+        """Everything of solve() that runs under the GIL (struct conversion, output buffers), so that a thread pool times only the C call."""
+        opts = opts or abi.default_options()
+        wc, keep = w.to_c()
+        st = abi.State(len(w.inv_depth), len(w.line_orth))
+        return (opts, wc, keep, st, st.alloc_c(), abi.Report())
+
+    def solve_prepared(self, job):
+        opts, wc, keep, st, sc, rep = job
+        return self.lib.oracle_solve(C.byref(opts), C.byref(wc), 0, C.byref(sc), C.byref(rep))      # ctypes releases the GIL for the call
 
     def evaluate(self, w, robust=True, opts=None):
         opts = opts or abi.default_options()

@@ -428,178 +428,119 @@ UVS_DEV void chol_store_item(double* sh, int i, int cc, int lane, const d4_t& ac
     }
 }
 
-// Factor the 16x16 diagonal block held in `dacc` WITHOUT leaving the MFMA C layout: row j of the (symmetric) block lives in lanes
-// 16*(j&3).. of register j>>2, which is exactly k-slot (j&3) of the A/B operands, so pivot j is one readlane, one reciprocal and one
-// rank-1 MFMA; a second MFMA per pivot runs the same elimination on the identity => W = L_kk^-1; square roots only after the chain.
-// Stores L (lower triangle), W^T (strictly upper) and 1/L_jj (dinv); false when a pivot is not positive.  One wavefront.
-// (A VALU formulation -- one matrix row per lane, DPP row broadcasts as FMA operands -- is kept in uvs_chol16.h with its test: it
-//  is correct but no faster on gfx950, 268 cycles per pivot without W against ~250 here: a dependent FP64 VALU operation costs 14
-//  cycles, a DPP one 21, and a link of that chain has ten of them.)
-UVS_DEV bool chol16_diag(d4_t dacc, int lane, double* Dk, double* dinv) {
-    const int li = lane & 15, lk = lane >> 4;
-    d4_t T;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) T[q] = (lk + 4 * q == li) ? 1.0 : 0.0;
-    double us_prev = 0.0;
-    double pivs[4] = {1.0, 1.0, 1.0, 1.0};      // pivs[q] = pivot of row lk + 4q (this lane's row of register q)
-    bool ok = true;
-    // The serial chain per pivot is readlane -> reciprocal -> masked scale -> MFMA; with STRICT masks row j of both accumulators is left
-    // untouched after pivot j (unscaled row j of dacc = a_jc^(j), row j of T = row of W), so the scaling by 1/d_j happens once,
-    // lane-parallel, after the chain.
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const int reg = j >> 2, slot = j & 3;
-        const double piv = bcast_lane(dacc[reg], 16 * slot + j);
-        ok = ok && (piv > 0.0);
-        // the inverse's elimination trails the factor's by one pivot, so its MFMA never sits between an MFMA result and the
-        // readlane that needs it (B operands need no masks: A is zero outside k-slot `slot` and outside rows > j)
-        if (j > 0) T = __builtin_amdgcn_mfma_f64_16x16x4f64(us_prev, T[(j - 1) >> 2], T, 0, 0, 0);
-        const double m = (lk == slot && li > j) ? dacc[reg] : 0.0;   // a[j][c], c > j, at lane 16*slot + c (symmetric => column j)
-        // us = -m / piv on the serial chain: hardware seed y0 (2^-24) and one third-order correction, 1/piv = y0 (1 + e + e^2) with
-        // e = 1 - piv y0, arranged so that the seed-only product -m y0 runs beside the error term: rcp -> e -> e + e^2 -> us
-        const double y0 = __builtin_amdgcn_rcp(piv);
-        const double e = fma(-piv, y0, 1.0), us0 = -m * y0;
-        const double us = fma(us0, fma(e, e, e), us0);
-        if (lk == slot) pivs[reg] = piv;
-        dacc = __builtin_amdgcn_mfma_f64_16x16x4f64(us, dacc[reg], dacc, 0, 0, 0);
-        us_prev = us;
-    }
-    // square roots + scaling, lane-parallel and off the chain: register q of this lane belongs to row j = lk + 4q
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int j = lk + 4 * q;
-        double ljj, inv; rsqrt_pair(pivs[q], &ljj, &inv);
-        Dk[li * UVS_BLK_LD + j] = (li > j) ? dacc[q] * inv : (li == j ? ljj : T[q] * inv);      // L[c][j] | W[j][m] at (m, j)
-        if (li == j) dinv[j] = inv;
-    }
-    return ok;
-}
-
-// Synchronisation of the factorization's task graph: one int per task in LDS (the x_c words, dead between the assembly and the
-// back-substitution), set once by the producer wave and polled by the consumers.  LDS operations of one wave execute in order and the
-// release / acquire pair orders the data stores before the flag and the data loads after it.
-static constexpr int CHF_L = 0;                       // [12][12] : L(i, j) final (i > j; row 11 = the right-hand side)
-static constexpr int CHF_DIAG = 144;                  // [11] : L_kk, W_k, 1/diag of block column k stored
-static constexpr int CHF_RDY_D = 156;                 // [12] : S(k, k) carries every term j < k - 1
-static constexpr int CHF_RDY_P = 168;                 // [12] : S(k, k - 1) carries every term j < k - 1 (all of them)
-static constexpr int CHF_COUNT = 180;
-static_assert(CHF_COUNT * 4 <= UVS_XDIM * 8, "factorization flags live in the x_c words");
-UVS_DEV void chf_set(int* fl, int idx, int lane) {
-    if (lane == 0) __hip_atomic_store(fl + idx, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-UVS_DEV void chf_wait(int* fl, int idx, long long* waited = nullptr) {
-    if (__hip_atomic_load(fl + idx, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0) return;
-    const long long t0 = waited ? clock64() : 0;
-    while (__hip_atomic_load(fl + idx, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(1);
-    if (waited) *waited += clock64() - t0;
-}
-// acc -= L_ij L_cj^T for j in [j0, j1), waiting for the row-c operands (row i belongs to the calling wave).  A row's panel blocks are
-// published in column order by ONE wave (its owner; the block next to the diagonal, by the diagonal wave, is never an operand here
-// except as the single term of phase (a)), so the flag of the LAST term covers the earlier ones.
-UVS_DEV void chol_update_waiting(double* sh, int* fl, int i, int cc, int j0, int j1, int lane, d4_t& acc, long long* waited) {
-    if (j0 >= j1) return;
-    if (i != cc) chf_wait(fl, CHF_L + 12 * cc + j1 - 1, waited);
-    chol_update_item(sh, i, cc, j0, j1, lane, acc);
-}
-// panel item: L_ik = S_ik W_k^T (B operand W_k[c][m]: strictly-upper slot (m, c) of the diagonal block, 1/L_cc on the diagonal)
-UVS_DEV void chol_panel_item(double* sh, int i, int k, int lane) {
-    const int li = lane & 15, lk = lane >> 4;
-    const double* Dk = sblk(sh, k, k);
-    double Bw[4], av[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {      // unconditional loads + selects (a conditional LDS read becomes a branch per element)
-        const int m = 4 * q + lk;
-        const double up = Dk[m * UVS_BLK_LD + li], dg = sh[L_DINV + 16 * k + li];
-        Bw[q] = (m < li) ? up : (m == li ? dg : 0.0);
-    }
-    if (i != UVS_NF) {
-        const double* Ai = sblk(sh, i, k) + li * UVS_BLK_LD + lk;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) av[q] = Ai[4 * q];
-    } else {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { const double yv = sh[L_DLT + 16 * k + 4 * q + lk]; av[q] = (li == 0) ? yv : 0.0; }
-    }
-    d4_t acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], Bw[q], acc, 0, 0, 0);
-    chol_store_item(sh, i, k, lane, acc);
-}
-
-// Blocked LEFT-LOOKING Cholesky with one column of look-ahead as a TASK GRAPH inside the workgroup (no workgroup barriers):
-//   wave 0 ("diagonal wave") owns the serial chain  D(k): factor block (k,k)  ->  P(k+1,k): panel block below it  ->  last term of
-//   block (k+1,k+1)  ->  D(k+1) ...  and never waits for anything but the two blocks it is about to read;
-//   the other waves own BLOCK ROWS (row i -> worker (i - 1) mod nwork; row 11 is the right-hand side, so the forward substitution
-//   is free) and per stage k  (a) apply term k-1 to their blocks of column k,  (b) apply the terms j < k to their blocks of column
-//   k+1 (the look-ahead),  (c) once D(k) is published, solve their panel blocks of column k.
-// With barriers every column cost the chain + the slowest worker + two barrier skews (8.1 k cycles per column measured); the
-// chain alone is ~5 k.
+// (Round 2 tried two restructurings of this factorization; both are correct and both lost on MI355X, so the barrier version stays:
+//  (1) the 16x16 diagonal block on the VALU, one matrix row per lane with DPP row broadcasts as FMA operands (csrc/uvs_chol16.h,
+//      tools/chol16_test.hip): 268 cycles per pivot without the inverse, 390 with it, against ~250 for the readlane -> rcp -> rank-1
+//      MFMA chain below -- a dependent FP64 VALU operation costs 14 cycles, a DPP one 21 (tools/micro_dpp.hip), and a link of that
+//      chain has about ten of them;
+//  (2) the block columns as a task graph without workgroup barriers (LDS flags: wave 0 runs only the diagonal chain and the block
+//      below it, the other three own block rows): 1.888 ms against 1.822 ms per 256-window launch in an A/B on one box -- three
+//      workers carry as many cycles per column as the chain itself, so the chain waits for them a quarter of the time.)
 UVS_DEV void chol_factor_impl(double* sh, int debug) {
     MiniCtx c; c.sh = sh; c.o.debug = debug;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform ON PURPOSE: item indices derived from it select code paths
-    int* fl = (int*)(sh + L_XC);
-    for (int t = tid; t < CHF_COUNT; t += NT) fl[t] = 0;
+    const int li = lane & 15, lk = lane >> 4;
     if (tid == 0) sh[L_CTRL + C_CHOLOK] = 1.0;
     UVS_PROF(c, P_MISC);
-    __syncthreads();
-    const long long tw0_ = debug ? clock64() : 0;
-    long long waited_ = 0; long long* wt = debug ? &waited_ : nullptr;      // debug launches: cycles this wave spent waiting for a flag
-    constexpr int nwork = NW - 1;
-    if (wv == 0) {
-        for (int k = 0; k < UVS_NF; ++k) {
-            double* Dk = sblk(sh, k, k);
-            if (k > 0) chf_wait(fl, CHF_RDY_D + k, wt);
-            d4_t dacc = chol_load_item(sh, k, k, lane);
-            if (k > 0) chol_update_item(sh, k, k, k - 1, k, lane, dacc);      // L(k, k-1) is this wave's own panel block
-            if (!chol16_diag(dacc, lane, Dk, sh + L_DINV + 16 * k)) { if (lane == 0) sh[L_CTRL + C_CHOLOK] = 0.0; }
-            chf_set(fl, CHF_DIAG + k, lane);
-            // the block right below the diagonal (for the last column that is the right-hand side row)
-            chf_wait(fl, CHF_RDY_P + k + 1, wt);
-            chol_panel_item(sh, k + 1, k, lane);
-            chf_set(fl, CHF_L + 12 * (k + 1) + k, lane);
-        }
-    } else {
-        const int wrk = wv - 1;
-        // (a) last term of block (i, k);  (b) look-ahead: terms j < k of block (i, k + 1)
-        const auto last_term = [&](int i, int k) {
-            d4_t acc = chol_load_item(sh, i, k, lane);
-            chol_update_waiting(sh, fl, i, k, k - 1, k, lane, acc, wt);
-            chol_store_item(sh, i, k, lane, acc);
-        };
-        const auto look_ahead = [&](int i, int k) {
-            d4_t acc = chol_load_item(sh, i, k + 1, lane);
-            chol_update_waiting(sh, fl, i, k + 1, 0, k, lane, acc, wt);
-            chol_store_item(sh, i, k + 1, lane, acc);
-        };
-        for (int k = 0; k < UVS_NF; ++k) {
-            // the two blocks the diagonal wave reads next come first: S(k+1, k) complete, S(k+1, k+1) up to its last term
-            const bool urgent = (k % nwork) == wrk;      // this wave owns row k + 1
-            if (urgent) {
-                if (k > 0) last_term(k + 1, k);
-                chf_set(fl, CHF_RDY_P + k + 1, lane);
-                if (k + 1 < UVS_NF) {
-                    if (k > 0) look_ahead(k + 1, k);
-                    chf_set(fl, CHF_RDY_D + k + 1, lane);
+    // wave 0 owns the diagonal blocks; with 8 waves, wave 4 sits on the same SIMD (waves are dealt to the 4 SIMDs round-robin) and
+    // would put its MFMAs between the pivots of the serial chain, so it only helps in S3
+    const int nwork = (NW == 8) ? 6 : NW - 1;
+    const int wrk = (wv == 0 || ((NW == 8) && wv == 4)) ? -1 : ((NW == 8) ? ((wv < 4) ? wv - 1 : wv - 2) : wv - 1);
+    for (int k = 0; k < UVS_NF; ++k) {
+        double* Dk = sblk(sh, k, k);
+        __syncthreads();
+        const long long tw0_ = debug ? clock64() : 0;
+        // ---- A: last term (j = k-1) of block column k
+        d4_t dacc = {0.0, 0.0, 0.0, 0.0};
+        if (wv == 0) {
+            dacc = chol_load_item(sh, k, k, lane);
+            if (k > 0) chol_update_item(sh, k, k, k - 1, k, lane, dacc);
+        } else if (wrk >= 0) {
+            if (k > 0) {
+                for (int i = k + 1 + wrk; i <= UVS_NF; i += nwork) {
+                    d4_t acc = chol_load_item(sh, i, k, lane);
+                    chol_update_item(sh, i, k, k - 1, k, lane, acc);
+                    chol_store_item(sh, i, k, lane, acc);
                 }
             }
-            if (k > 0) {
-                for (int i = k + 2; i <= UVS_NF; ++i) if ((i - 1) % nwork == wrk) last_term(i, k);
-                if (k + 1 < UVS_NF) for (int i = k + 2; i <= UVS_NF; ++i) if ((i - 1) % nwork == wrk) look_ahead(i, k);
-            }
-            // (c) panel of column k (row k + 1 is the diagonal wave's)
-            chf_wait(fl, CHF_DIAG + k, wt);
-            for (int i = k + 2; i <= UVS_NF; ++i) {
-                if ((i - 1) % nwork != wrk) continue;
-                chol_panel_item(sh, i, k, lane);
-                chf_set(fl, CHF_L + 12 * i + k, lane);
+            if (k > 0 && k + 1 < UVS_NF) {
+                for (int i = k + 1 + wrk; i <= UVS_NF; i += nwork) {
+                    d4_t acc = chol_load_item(sh, i, k + 1, lane);
+                    chol_update_item(sh, i, k + 1, 0, k, lane, acc);
+                    chol_store_item(sh, i, k + 1, lane, acc);
+                }
             }
         }
+        UVS_PROF(c, P_CH_TRAIL);
+        // ---- S2: wave 0 factors the diagonal block in registers (L -> lower triangle, W^T -> strictly upper, 1/L_jj -> L_DINV).
+        // The serial chain per pivot is readlane -> reciprocal -> masked scale -> MFMA; with STRICT masks row j of both accumulators
+        // is left untouched after pivot j (unscaled row j of dacc = a_jc^(j), row j of T = row of W), so the scaling by 1/d_j happens
+        // once, lane-parallel, after the chain.
+        if (wv == 0) {
+            d4_t T;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) T[q] = (lk + 4 * q == li) ? 1.0 : 0.0;
+            double us_prev = 0.0;
+            double pivs[4] = {1.0, 1.0, 1.0, 1.0};      // pivs[q] = pivot of row lk + 4q (this lane's row of register q)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int reg = j >> 2, slot = j & 3;
+                const double piv = bcast_lane(dacc[reg], 16 * slot + j);
+                // the inverse's elimination trails the factor's by one pivot, so its MFMA never sits between an MFMA result and the
+                // readlane that needs it (B operands need no masks: A is zero outside k-slot `slot` and outside rows > j)
+                if (j > 0) T = __builtin_amdgcn_mfma_f64_16x16x4f64(us_prev, T[(j - 1) >> 2], T, 0, 0, 0);
+                const double m = (lk == slot && li > j) ? dacc[reg] : 0.0;   // a[j][c], c > j, at lane 16*slot + c (symmetric => column j)
+                // us = -m / piv on the serial chain: hardware seed y0 (2^-24) and one third-order correction, 1/piv = y0 (1 + e + e^2) with
+                // e = 1 - piv y0, arranged so that the seed-only product -m y0 runs beside the error term: rcp -> e -> e + e^2 -> us
+                const double y0 = __builtin_amdgcn_rcp(piv);
+                const double e = fma(-piv, y0, 1.0), us0 = -m * y0;
+                const double us = fma(us0, fma(e, e, e), us0);
+                if (lk == slot) pivs[reg] = piv;
+                dacc = __builtin_amdgcn_mfma_f64_16x16x4f64(us, dacc[reg], dacc, 0, 0, 0);
+                us_prev = us;
+            }
+            // square roots + scaling, lane-parallel and off the chain: register q of this lane belongs to row j = lk + 4q
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int j = lk + 4 * q;
+                double ljj, inv; rsqrt_pair(pivs[q], &ljj, &inv);
+                Dk[li * UVS_BLK_LD + j] = (li > j) ? dacc[q] * inv : (li == j ? ljj : T[q] * inv);      // L[c][j] | W[j][m] at (m, j)
+                if (li == j) { sh[L_DINV + 16 * k + j] = inv; if (!(pivs[q] > 0.0)) sh[L_CTRL + C_CHOLOK] = 0.0; }
+            }
+        }
+        if (debug == 1 && lane == 0) sh[L_WPROF + 4 + wv] += (double)(clock64() - tw0_);      // busy time of this wave in A + (pivot chain | look-ahead), without the barrier wait
+        __syncthreads();
+        UVS_PROF(c, P_CH_DIAG);
+        // ---- S3: panel  L_ik = S_ik W^T  (B operand W[c][m]: strictly-upper slot (m, c) of the diagonal block, 1/L_cc on the diagonal)
+        {
+            double Bw[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {      // unconditional loads + selects (a conditional LDS read becomes a branch per element)
+                const int m = 4 * q + lk;
+                const double up = Dk[m * UVS_BLK_LD + li], dg = sh[L_DINV + 16 * k + li];
+                Bw[q] = (m < li) ? up : (m == li ? dg : 0.0);
+            }
+            for (int i = k + 1 + wv; i <= UVS_NF; i += NW) {
+                const bool rhs = (i == UVS_NF);
+                d4_t acc = {0.0, 0.0, 0.0, 0.0};
+                double av[4];
+                if (!rhs) {
+                    const double* Ai = sblk(sh, i, k) + li * UVS_BLK_LD + lk;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) av[q] = Ai[4 * q];
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { const double yv = sh[L_DLT + 16 * k + 4 * q + lk]; av[q] = (li == 0) ? yv : 0.0; }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], Bw[q], acc, 0, 0, 0);
+                chol_store_item(sh, i, k, lane, acc);
+            }
+        }
+        UVS_PROF(c, P_CH_PANEL);
     }
-    if (debug == 1 && lane == 0) sh[L_WPROF + 4 + wv] += (double)waited_;      // cycles this wave waited for flags (wave 0: the chain stalled)
-    (void)tw0_;
     __syncthreads();
-    UVS_PROF(c, P_CH_DIAG);
 }
 // The dense solve is a REAL call (not inlined into the 500-register linearization code of k_solve / k_large_solve): its register
 // allocation is then independent of the gather / factor code around it, and changes in here cannot perturb that code's allocation
