@@ -9,6 +9,7 @@
 extern "C" {
 int oracle_solve(const uvs_options* opt, const uvs_window* w, int linear_mode, uvs_state* out, uvs_report* rep);
 int oracle_marginalize(const uvs_options* opt, const uvs_window* w, int flag, uvs_prior* out);
+int oracle_evaluate(const uvs_options* opt, const uvs_window* w, int robust, uvs_eval* out);
 }
 
 struct uvs_solver { uvs_options opt; std::string err; };
@@ -33,6 +34,7 @@ void uvs_destroy(uvs_solver* s) { delete s; }
 const char* uvs_last_error(const uvs_solver* s) { return s ? s->err.c_str() : "null solver"; }
 const char* uvs_status_string(int st) { return st == UVS_OK ? "ok" : "oracle error"; }
 int uvs_solve_window(uvs_solver* s, const uvs_window* w, uvs_state* out, uvs_report* rep) { return oracle_solve(&s->opt, w, 0, out, rep); }
+int uvs_evaluate(uvs_solver* s, const uvs_window* w, int robust, uvs_eval* out) { return oracle_evaluate(&s->opt, w, robust, out); }
 int uvs_marginalize(uvs_solver* s, const uvs_window* w, int flag, uvs_prior* out) { return oracle_marginalize(&s->opt, w, flag, out); }
 int uvs_marginalize_resident(uvs_solver* s, const uvs_window* w, int flag, uvs_prior* out) { return oracle_marginalize(&s->opt, w, flag, out); }
 }

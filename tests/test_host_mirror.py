@@ -92,3 +92,51 @@ def test_estimator_optimization_matches_direct_solve(gpu_api):
     r0 = raw[k:k + pn]; J0 = raw[k + pn:k + pn + pn * pn].reshape(pn, pn)
     assert np.all(np.isfinite(J0)) and np.linalg.matrix_rank(J0) >= 60
     s.close()
+
+
+@pytest.mark.gpu
+def test_factor_classes_evaluate_through_the_gpu(gpu_api, oracle, tmp_path):
+    """SURVEY.md 8b "Factor API surface to keep": ProjectionFactor::Evaluate(parameters, residuals, jacobians) (+ check()), IMUFactor /
+    MarginalizationFactor::Evaluate, the LineProjectionFactor / VPProjectionFactor functors.  Each call is one uvs_evaluate() of a
+    one-block window; the outputs must equal the per-block entries of an evaluation of the WHOLE window (oracle, no loss), global-size
+    row-major with a zero 7th pose column."""
+    marg = lambda win, flag: oracle.marginalize(win, flag)
+    w = synth.make_window(31, with_prior=True, marginalize_fn=marg)
+    assert w.ln_has_vp[0] == 1
+    path = str(tmp_path / "w.bin"); w.save(path)
+    host = C.CDLL(os.path.join(ROOT, "uv-slam_amd", "libuvs_host.so"))
+    host.uvs_host_factor_api_probe.argtypes = [C.c_char_p, abi.c_double_p, C.c_int]; host.uvs_host_factor_api_probe.restype = C.c_int
+    buf = np.zeros(20000)
+    n = host.uvs_host_factor_api_probe(path.encode(), abi._dp(buf), len(buf))
+    assert n > 0, n
+    e = oracle.evaluate(w, robust=False)
+    pos = [0]
+    def take(k):
+        a = buf[pos[0]:pos[0] + k]; pos[0] += k; return a
+    close = lambda a, b: np.abs(np.asarray(a) - np.asarray(b)).max() <= 1e-9 * max(1.0, np.abs(np.asarray(b)).max())
+    # point block 0
+    assert close(take(2), e.pt_r[0])
+    for b in range(3):
+        J = take(14).reshape(2, 7)
+        assert close(J[:, :6], e.pt_J[0][:, 6 * b:6 * b + 6]) and np.all(J[:, 6] == 0.0)
+    assert close(take(2), e.pt_J[0][:, 18])
+    fd_gap = take(1)[0]
+    assert 0.0 <= fd_gap < 1e-3 * np.abs(e.pt_J[0]).max()          # ProjectionFactor::check(): analytic vs finite differences (eps 1e-6)
+    # line block 0 (+ VP)
+    assert close(take(2), e.ln_r[0])
+    J = take(14).reshape(2, 7); assert close(J[:, :6], e.ln_J[0][:, :6]) and np.all(J[:, 6] == 0.0)
+    assert close(take(8).reshape(2, 4), e.ln_J[0][:, 6:])
+    assert close(take(1), e.vp_r[0])
+    J = take(7); assert close(J[:6], e.vp_J[0][0, :6]) and J[6] == 0.0
+    assert close(take(4), e.vp_J[0][0, 6:])
+    # IMU block 0
+    assert close(take(15), e.imu_r[0])
+    for col0, loc, glob in ((0, 6, 7), (6, 9, 9), (15, 6, 7), (21, 9, 9)):
+        J = take(15 * glob).reshape(15, glob)
+        assert close(J[:, :loc], e.imu_J[0][:, col0:col0 + loc]) and (glob == loc or np.all(J[:, loc:] == 0.0))
+    # prior
+    p = w.prior
+    assert close(take(p.n), e.prior_r[:p.n])
+    size0 = p.block_size[0]; J = take(p.n * size0).reshape(p.n, size0)
+    assert close(J[:, :6], p.J0()[:, p.block_idx[0]:p.block_idx[0] + 6]) and np.all(J[:, 6] == 0.0)
+    assert pos[0] == n

@@ -29,8 +29,9 @@ Estimator::Estimator() : frame_count(0), first_imu(false), sum_of_back(0), sum_o
     o.estimate_td = ESTIMATE_TD; o.estimate_extrinsic = ESTIMATE_EXTRINSIC != 0;      // fixed for the lifetime of the handle, like the reference's globals (parameters.cpp)
     const int rc = uvs_create(&o, 0, 1, NUM_OF_F, NUM_OF_F * (WINDOW_SIZE + 1), NUM_OF_LF, NUM_OF_LF * (WINDOW_SIZE + 1), &solver);
     if (rc != UVS_OK) throw std::runtime_error(std::string("uvs_create: ") + uvs_status_string(rc));     // no CPU fallback
+    if (!uvs::evaluation_solver()) uvs::set_evaluation_solver(solver);      // the factor classes' per-block Evaluate() runs on this handle unless another was registered
 }
-Estimator::~Estimator() { uvs_destroy(solver); delete last_marginalization_info; for (auto* p : pre_integrations) delete p; }
+Estimator::~Estimator() { if (uvs::evaluation_solver() == solver) uvs::set_evaluation_solver(nullptr); uvs_destroy(solver); delete last_marginalization_info; for (auto* p : pre_integrations) delete p; }
 
 // ---- small helpers of this file: a 7-double parameter block (px py pz qx qy qz qw, estimator.cpp:530-537) <-> (translation, rotation)
 namespace {

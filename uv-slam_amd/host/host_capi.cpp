@@ -240,3 +240,75 @@ extern "C" int uvs_host_replay_sequence(const char* in_path, const char* out_pat
     std::fwrite(&n_rows, 8, 1, g); std::fwrite(out.data(), 8, out.size(), g); std::fclose(g);
     return 0;
 }
+
+// Test hook for the factor classes' per-block evaluation surface (host/factor/factors.h): evaluates, through the CLASS API, the first
+// point observation, the first line observation (and its VP block when tagged), IMU block 0 and the prior of the window file, and
+// returns the flat outputs  out = [pt r2 | J 2x7 2x7 2x7 2x1 | check() | ln r2 | J 2x7 2x4 | vp r1 | J 1x7 1x4 | imu r15 | J 15x7 15x9 15x7 15x9 |
+// prior r[n] | J of kept block 0 (n x size0)].  Returns the number of doubles written, < 0 on failure.
+extern "C" int uvs_host_factor_api_probe(const char* path, double* out, int cap) {
+    WindowFile wf;
+    if (!wf.load(path)) return -1;
+    setEurocParameters();
+    uvs_options o; uvs_default_options(&o);
+    uvs_solver* s = nullptr;
+    if (uvs_create(&o, 0, 1, 1000, 16000, 1000, 16000, &s) != UVS_OK) return -2;
+    uvs::set_evaluation_solver(s);
+    ProjectionFactor::sqrt_info = FOCAL_LENGTH / 1.6;
+    const uvs_window& w = wf.w;
+    std::vector<double> v;
+    auto fail = [&](int code) { uvs::set_evaluation_solver(nullptr); uvs_destroy(s); return code; };
+    const Eigen::Matrix3d ric = Eigen::Quaterniond(w.ex_pose[6], w.ex_pose[3], w.ex_pose[4], w.ex_pose[5]).toRotationMatrix();
+    const Eigen::Vector3d tic(w.ex_pose[0], w.ex_pose[1], w.ex_pose[2]);
+    if (w.n_point_obs > 0) {
+        ProjectionFactor f(Eigen::Vector3d(w.pt_pi[0], w.pt_pi[1], w.pt_pi[2]), Eigen::Vector3d(w.pt_pj[0], w.pt_pj[1], w.pt_pj[2]));
+        double lam = w.inv_depth[w.pt_lm[0]], r[2], J0[14], J1[14], J2[14], J3[2]; double* jac[4] = {J0, J1, J2, J3};
+        double pi_[7], pj_[7], ex_[7]; std::memcpy(pi_, w.pose[w.pt_fi[0]], 56); std::memcpy(pj_, w.pose[w.pt_fj[0]], 56); std::memcpy(ex_, w.ex_pose, 56);
+        double* params[4] = {pi_, pj_, ex_, &lam};
+        if (!f.Evaluate(params, r, jac)) return fail(-3);
+        v.insert(v.end(), r, r + 2); v.insert(v.end(), J0, J0 + 14); v.insert(v.end(), J1, J1 + 14); v.insert(v.end(), J2, J2 + 14); v.insert(v.end(), J3, J3 + 2);
+        v.push_back(f.check(params));
+    }
+    if (w.n_line_obs > 0) {
+        const Eigen::Vector3d sp(w.ln_sp[0], w.ln_sp[1], w.ln_sp[2]), ep(w.ln_ep[0], w.ln_ep[1], w.ln_ep[2]), vp(w.ln_vp[0], w.ln_vp[1], w.ln_vp[2]);
+        const double* pose = w.pose[w.ln_fj[0]]; const double* line = w.line_orth + 4 * w.ln_lm[0];
+        LineProjectionFactor lf(ric, tic, sp, ep);
+        double r[2], r2[2], Jp[14], Jl[8];
+        if (!lf(pose, line, r2) || !lf.EvaluateWithJacobians(pose, line, r, Jp, Jl) || r[0] != r2[0] || r[1] != r2[1]) return fail(-4);
+        v.insert(v.end(), r, r + 2); v.insert(v.end(), Jp, Jp + 14); v.insert(v.end(), Jl, Jl + 8);
+        if (w.ln_has_vp[0]) {
+            VPProjectionFactor vf(ric, tic, sp, ep, vp);
+            double rv[1], Jvp[7], Jvl[4];
+            if (!vf.EvaluateWithJacobians(pose, line, rv, Jvp, Jvl)) return fail(-5);
+            v.push_back(rv[0]); v.insert(v.end(), Jvp, Jvp + 7); v.insert(v.end(), Jvl, Jvl + 4);
+        }
+    }
+    if (w.n_imu > 0) {
+        const uvs_imu_block& b = w.imu[0];
+        IntegrationBase pre(Eigen::Vector3d(), Eigen::Vector3d(), Eigen::Vector3d(b.linearized_ba[0], b.linearized_ba[1], b.linearized_ba[2]), Eigen::Vector3d(b.linearized_bg[0], b.linearized_bg[1], b.linearized_bg[2]));
+        pre.sum_dt = b.sum_dt; pre.delta_p = Eigen::Vector3d(b.delta_p[0], b.delta_p[1], b.delta_p[2]); pre.delta_v = Eigen::Vector3d(b.delta_v[0], b.delta_v[1], b.delta_v[2]);
+        pre.delta_q = Eigen::Quaterniond(b.delta_q[3], b.delta_q[0], b.delta_q[1], b.delta_q[2]);
+        std::memcpy(pre.jacobian, b.jacobian, sizeof(pre.jacobian)); std::memcpy(pre.covariance, b.covariance, sizeof(pre.covariance));
+        IMUFactor f(&pre);
+        const int i = b.frame_i;
+        const double* params[4] = {w.pose[i], w.speedbias[i], w.pose[i + 1], w.speedbias[i + 1]};
+        double r[15]; std::vector<double> J0(105), J1(135), J2(105), J3(135); double* jac[4] = {J0.data(), J1.data(), J2.data(), J3.data()};
+        if (!f.Evaluate(params, r, jac)) return fail(-6);
+        v.insert(v.end(), r, r + 15);
+        for (auto* J : {&J0, &J1, &J2, &J3}) v.insert(v.end(), J->begin(), J->end());
+    }
+    if (w.prior && w.prior->n > 0) {
+        MarginalizationInfo info; info.prior = *w.prior;
+        MarginalizationFactor f(&info);
+        const uvs_prior& p = info.prior;
+        std::vector<const double*> params(p.n_blocks);
+        for (int b = 0; b < p.n_blocks; ++b)
+            params[b] = p.block_kind[b] == UVS_BLOCK_POSE ? w.pose[p.block_frame[b]] : p.block_kind[b] == UVS_BLOCK_SPEEDBIAS ? w.speedbias[p.block_frame[b]] : p.block_kind[b] == UVS_BLOCK_EX_POSE ? w.ex_pose : &w.td;
+        std::vector<double> r(p.n), J0((size_t)p.n * p.block_size[0]);
+        std::vector<double*> jac(p.n_blocks, nullptr); jac[0] = J0.data();
+        if (!f.Evaluate(params.data(), r.data(), jac.data())) return fail(-7);
+        v.insert(v.end(), r.begin(), r.end()); v.insert(v.end(), J0.begin(), J0.end());
+    }
+    if ((int)v.size() > cap) return fail(-8);
+    std::memcpy(out, v.data(), v.size() * sizeof(double));
+    return fail((int)v.size());
+}
