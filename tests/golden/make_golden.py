@@ -2,7 +2,10 @@
 
 PARITY UNPINNED: the reference ships no golden vectors and cannot be compiled here, so these fixtures are produced by
 the CPU oracle (oracle/uvs_oracle.cpp), whose factors are independently pinned by tests/test_oracle_factors.py
-(torch autograd) and whose LM loop is pinned by the known-answer tests.  They freeze inputs + expected outputs so that
+(torch autograd) and whose LM loop is pinned by the known-answer tests AND by the independent numpy controller of
+tests/pyref_lm.py: this script refuses to write a fixture unless both restatements produce the same accept / reject pattern,
+radii, costs and final state for it (the relocalization case is outside the numpy controller's block set and is exempt).
+They freeze inputs + expected outputs so that
 (a) the oracle cannot drift silently and (b) the GPU box (which has no /root/reference and needs none) checks the HIP
 solver against committed numbers.  Run:  python tests/golden/make_golden.py
 """
@@ -74,13 +77,22 @@ def main():
         if only and name not in only: continue
         st, rep = orc.solve(w)
         ev = orc.evaluate(w, robust=True)
+        pinned = 0
+        if not len(w.relo_lm):      # second, independent restatement of the LM loop (dense normal equations, Jacobi-scaled coordinates)
+            import pyref_lm
+            x, tr = pyref_lm.solve(w, lambda win: orc.evaluate(win, robust=True))
+            n = rep.num_iterations
+            assert tr.num_iterations == n and tr.termination == rep.termination and list(tr.accepted[:n + 1]) == list(rep.accepted[:n + 1]), name
+            assert np.allclose(tr.radius[:n + 1], np.array(rep.radius[:n + 1]), rtol=1e-7) and np.allclose(tr.cost[:n + 1], np.array(rep.cost[:n + 1]), rtol=1e-8), name
+            assert np.abs(x.pose - st.pose).max() < 1e-8 and np.abs(x.speedbias - st.speedbias).max() < 1e-8 and np.abs(x.inv_depth - st.inv_depth).max() < 1e-7, name
+            pinned = 1
         d = window_to_dict(w)
         k = rep.num_iterations + 1
         d.update(out_pose=st.pose, out_speedbias=st.speedbias, out_inv_depth=st.inv_depth, out_line_orth=st.line_orth,
                  out_cost=np.array(rep.cost[:k]), out_radius=np.array(rep.radius[:k]), out_accepted=np.array(rep.accepted[:k]),
                  out_final_cost=np.array(rep.final_cost), out_termination=np.array(rep.termination), out_relo_pose=st.relo_pose,
                  ev_cost=np.array(ev.cost), ev_pt_r=ev.pt_r, ev_ln_r=ev.ln_r, ev_vp_r=ev.vp_r, ev_imu_r=ev.imu_r,
-                 ev_pt_J0=ev.pt_J[:4], ev_ln_J0=ev.ln_J[:4], ev_vp_J0=ev.vp_J[:4], ev_imu_J0=ev.imu_J[:1])
+                 ev_pt_J0=ev.pt_J[:4], ev_ln_J0=ev.ln_J[:4], ev_vp_J0=ev.vp_J[:4], ev_imu_J0=ev.imu_J[:1], pinned_by_numpy_lm=np.array(pinned))
         if w.prior is not None:
             nxt = orc.marginalize(w.with_state(st), 0)
             d.update(marg_n=np.array(nxt.n), marg_A=nxt.J0().T @ nxt.J0(), marg_b=nxt.J0().T @ nxt.r0())
