@@ -6,6 +6,7 @@ fails loudly (RuntimeError) when no GPU is present -- there is no CPU path.
 """
 import ctypes as C
 import os
+import time
 
 import numpy as np
 
@@ -123,7 +124,9 @@ class Solver:
     def upload(self, windows):
         cs = [w.to_c() for w in windows]
         arr = (C.POINTER(abi.WindowC) * len(cs))(*[C.pointer(c[0]) for c in cs])
+        t0 = time.perf_counter()
         self._check(lib().uvs_batch_upload(self._h, len(cs), arr))
+        self.last_upload_ms = (time.perf_counter() - t0) * 1e3      # the C-ABI call alone: host packing + H2D (the ctypes conversion above is python overhead)
         self._windows = list(windows)
 
     def solve_resident(self):

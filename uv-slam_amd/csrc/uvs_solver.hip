@@ -14,6 +14,7 @@
 #include <cstring>
 #include <dlfcn.h>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/uvs_solver.h"
@@ -673,15 +674,41 @@ int uvs_batch_upload(uvs_solver* s, int n, const uvs_window* const* ws) {
     HIPCHK(s, hipSetDevice(s->device));
     s->host_blobs.clear(); s->hdrs.resize(n); s->blob_off.resize(n); s->ws_off.resize(n);
     long long wtot = 0;
-    for (int b = 0; b < n; ++b) {
+    for (int b = 0; b < n; ++b)
         if (ws[b] && (ws[b]->n_points > s->max_points || ws[b]->n_point_obs + std::max(ws[b]->n_relo_obs, 0) > s->max_point_obs || ws[b]->n_lines > s->max_lines || ws[b]->n_line_obs > s->max_line_obs)) {
             s->err = "window exceeds the capacity given to uvs_create (max_points / max_point_obs / max_lines / max_line_obs)"; s->n_loaded = 0; return UVS_ERR_CAPACITY;
         }
-        s->blob_off[b] = (long long)s->host_blobs.size();
-        int rc = pack_window(ws[b], s->opts, s->host_blobs, s->hdrs[b], s->err);
-        if (rc != UVS_OK) { s->n_loaded = 0; return rc; }
-        s->ws_off[b] = wtot; wtot += s->hdrs[b].ws_doubles;
+    // Packing (index bookkeeping of the gather lists: the analogue of Ceres' problem construction) is independent per window: a batch is
+    // packed by several host threads into per-window buffers and concatenated -- 0.3 ms per window on one core was 83 ms for the 256-window
+    // batch, 45 x the solve it feeds.  UVS_PACK_THREADS overrides the thread count (1 = the serial path, also taken for small batches).
+    int nthreads = 1;
+    if (n >= 8) {
+        const char* env = std::getenv("UVS_PACK_THREADS");
+        nthreads = env ? std::atoi(env) : (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+        nthreads = std::max(1, std::min(nthreads, n));
     }
+    if (nthreads == 1) {
+        for (int b = 0; b < n; ++b) {
+            s->blob_off[b] = (long long)s->host_blobs.size();
+            int rc = pack_window(ws[b], s->opts, s->host_blobs, s->hdrs[b], s->err);
+            if (rc != UVS_OK) { s->n_loaded = 0; return rc; }
+        }
+    } else {
+        std::vector<std::vector<char>> parts(n);
+        std::vector<int> rcs(n, UVS_OK); std::vector<std::string> errs(n);
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nthreads; ++t)
+            pool.emplace_back([&, t] { for (int b = t; b < n; b += nthreads) rcs[b] = pack_window(ws[b], s->opts, parts[b], s->hdrs[b], errs[b]); });
+        for (auto& th : pool) th.join();
+        size_t total = 0;
+        for (int b = 0; b < n; ++b) {
+            if (rcs[b] != UVS_OK) { s->err = errs[b]; s->n_loaded = 0; return rcs[b]; }      // the first failing window in batch order, as the serial path reports it
+            s->blob_off[b] = (long long)total; total += parts[b].size();
+        }
+        s->host_blobs.resize(total);
+        for (int b = 0; b < n; ++b) std::memcpy(s->host_blobs.data() + s->blob_off[b], parts[b].data(), parts[b].size());
+    }
+    for (int b = 0; b < n; ++b) { s->ws_off[b] = wtot; wtot += s->hdrs[b].ws_doubles; }
     s->out_tab.resize(3 * (size_t)n); s->out_total = 0;
     for (int b = 0; b < n; ++b) {
         const DevWin& h = s->hdrs[b];
