@@ -658,6 +658,32 @@ UVS_DEV void row_fma(double* v, double s, const d2_t* q) {
 // this lane's group descriptor (-1 = idle group), see uvs_layout.h: i_wblk
 UVS_DEV int gather_group(const Ctx& c) { return c.bi[c.hdr->i_wblk + (threadIdx.x / UVS_GLANES)]; }
 
+// Walks entries [e0, e1) of a gather list, K per stage, SOFTWARE PIPELINED over two register sets: while the FMAs of stage t issue, the
+// LDS loads of stage t + 1 (addresses from the entries fetched during stage t - 1) and the entry words of stage t + 2 are already in
+// flight.  One wave per SIMD executes in order and an LDS round trip is ~130 cycles: the un-pipelined loops paid two of them per stage
+// (entry word, then operands) with nothing to overlap, 275 cycles per Schur entry against ~145 of FMA issue.
+//   load(first entry index of the stage, entry words[K], Ops&)   -- issues the operand loads (entries beyond e1 are clamped by the caller)
+//   use(first entry index of the stage, Ops&)                    -- the FMAs; must ignore entries >= e1 itself when K > 1
+template <int K, class Ops, class Load, class Use>
+UVS_DEV void gather_walk(const int* ent, int e0, int e1, Load load, Use use) {
+    if (e0 >= e1) return;
+    Ops A, B;
+    int wa[K], wb[K];
+    const auto fetch = [&](int i, int* w) {
+#pragma unroll
+        for (int u = 0; u < K; ++u) w[u] = ent[i + u < e1 ? i + u : e0];      // clamped: always a valid entry of this group
+    };
+    fetch(e0, wa); load(e0, wa, A); fetch(e0 + K, wb);
+    for (int i = e0;;) {
+        load(i + K, wb, B); fetch(i + 2 * K, wa);
+        use(i, A);
+        i += K; if (i >= e1) break;
+        load(i + K, wa, A); fetch(i + 2 * K, wb);
+        use(i, B);
+        i += K; if (i >= e1) break;
+    }
+}
+
 // EXT = the window has pseudo-frame blocks (ESTIMATE_TD / ESTIMATE_EXTRINSIC); the default instantiation folds all their special cases away
 template <bool EXT>
 UVS_DEV void gather_points(int grp, const int* lists, const double* S0, GAcc& A) {
@@ -670,50 +696,53 @@ UVS_DEV void gather_points(int grp, const int* lists, const double* S0, GAcc& A)
     const int p1off = tdg ? 1 : 6, rcoff = tdg ? UVS_PT_C - UVS_PT_TD : exg ? UVS_PT_C - UVS_PT_EX : 12;
     const bool dirv = !(tdg && diag) && !tdcol;                 // (td, td): the direct term is the scalar J_td . J_td = the hd accumulator
     const int* ent = lists + LIST_HDR;
-    // ---- Schur: acc[r][c] -= E_a[r0 + r] * Einv_b[c]
+    // ---- Schur: acc[r][c] -= E_a[r0 + r] * Einv_b[c], two entries per stage
     {
+        struct Ops { double ea[2][GR]; d2_t q[2][3]; };
         const int e0 = on ? lists[g] : 0, e1 = on ? lists[g + 1] : 0;
-        for (int i = e0; i < e1; i += 2) {
-            double ea[2][GR]; d2_t q[2][3];
+        gather_walk<2, Ops>(ent, e0, e1,
+            [&](int, const int* w, Ops& o) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const bool ok = i + u < e1;
-                const int e = ok ? ent[i + u] : 0;
-                const double* pa = S0 + (e & 0x7fff) + r0;
-                const double* pb = S0 + ((unsigned)e >> 16);
+                for (int u = 0; u < 2; ++u) {
+                    const double* pa = S0 + (w[u] & 0x7fff) + r0;
+                    const double* pb = S0 + ((unsigned)w[u] >> 16);
 #pragma unroll
-                for (int r = 0; r < GR; ++r) ea[u][r] = ok ? -pa[r] : 0.0;
-                q[u][0] = lds2(pb); q[u][1] = lds2(pb + 2); q[u][2] = lds2(pb + 4);
-            }
+                    for (int r = 0; r < GR; ++r) o.ea[u][r] = pa[r];
+                    o.q[u][0] = lds2(pb); o.q[u][1] = lds2(pb + 2); o.q[u][2] = lds2(pb + 4);
+                }
+            },
+            [&](int i, Ops& o) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
+                for (int u = 0; u < 2; ++u) {
+                    const bool ok = i + u < e1;
 #pragma unroll
-                for (int r = 0; r < GR; ++r) row_fma(A.v + 6 * r, ea[u][r], q[u]);
-        }
+                    for (int r = 0; r < GR; ++r) row_fma(A.v + 6 * r, ok ? -o.ea[u][r] : 0.0, o.q[u]);
+                }
+            });
     }
     // ---- direct: acc[r][c] += J1[0][r0+r] J2[0][c] + J1[1][r0+r] J2[1][c] ; diagonal blocks (J1 == J2) also g and diag(J^T J)
     {
+        struct Ops { double p0[GR], p1[GR]; d2_t q0[3], q1[3], rc; };
         const int e0 = on ? lists[UVS_NGRP + 1 + g] : 0, e1 = on ? lists[UVS_NGRP + 2 + g] : 0;
-        int e = (e0 < e1) ? ent[e0] : 0;
-        for (int i = e0; i < e1; ++i) {
-            const int en = (i + 1 < e1) ? ent[i + 1] : 0;      // next entry in flight while this one is consumed
-            const int lo = e & 0x7fff;
-            const double* pa = S0 + lo + r0;
-            const double* pb = S0 + ((unsigned)e >> 16);
-            double p0[GR], p1[GR]; d2_t q0[3], q1[3];
+        gather_walk<1, Ops>(ent, e0, e1,
+            [&](int, const int* w, Ops& o) {
+                const int lo = w[0] & 0x7fff;
+                const double* pa = S0 + lo + r0;
+                const double* pb = S0 + ((unsigned)w[0] >> 16);
 #pragma unroll
-            for (int r = 0; r < GR; ++r) { p0[r] = pa[r]; p1[r] = pa[p1off + r]; }
+                for (int r = 0; r < GR; ++r) { o.p0[r] = pa[r]; o.p1[r] = pa[p1off + r]; }
 #pragma unroll
-            for (int k = 0; k < 3; ++k) { q0[k] = lds2(pb + 2 * k); q1[k] = lds2(pb + 6 + 2 * k); }
-            const d2_t rc = lds2(S0 + lo + rcoff);
+                for (int k = 0; k < 3; ++k) { o.q0[k] = lds2(pb + 2 * k); o.q1[k] = lds2(pb + 6 + 2 * k); }
+                o.rc = lds2(S0 + lo + rcoff);
+            },
+            [&](int, Ops& o) {
 #pragma unroll
-            for (int r = 0; r < GR; ++r) {
-                if (dirv) { row_fma(A.v + 6 * r, p0[r], q0); row_fma(A.v + 6 * r, p1[r], q1); }
-                if (tdcol) A.v[6 * r] += p0[r] * q0[0].x + p1[r] * q0[0].y;
-                if (diag) { A.g[r] += p0[r] * rc.x + p1[r] * rc.y; A.hd[r] += p0[r] * p0[r] + p1[r] * p1[r]; }
-            }
-            e = en;
-        }
+                for (int r = 0; r < GR; ++r) {
+                    if (dirv) { row_fma(A.v + 6 * r, o.p0[r], o.q0); row_fma(A.v + 6 * r, o.p1[r], o.q1); }
+                    if (tdcol) A.v[6 * r] += o.p0[r] * o.q0[0].x + o.p1[r] * o.q0[0].y;
+                    if (diag) { A.g[r] += o.p0[r] * o.rc.x + o.p1[r] * o.rc.y; A.hd[r] += o.p0[r] * o.p0[r] + o.p1[r] * o.p1[r]; }
+                }
+            });
     }
 }
 
@@ -723,49 +752,49 @@ UVS_DEV void gather_lines(int grp, const int* lists, const double* S0, GAcc& A) 
     const int* ent = lists + LIST_HDR;
     // ---- Schur: acc[r][c] -= sum_q E_a[q][r0 + r] * Y_b[q][c]
     {
+        struct Ops { double ea[4][GR]; d2_t y[4][3]; };
         const int e0 = on ? lists[g] : 0, e1 = on ? lists[g + 1] : 0;
-        int e = (e0 < e1) ? ent[e0] : 0;
-        for (int i = e0; i < e1; ++i) {
-            const int en = (i + 1 < e1) ? ent[i + 1] : 0;
-            const double* pa = S0 + (e & 0x7fff) + r0;
-            const double* pb = S0 + ((unsigned)e >> 16);
-            double ea[4][GR]; d2_t y[4][3];
+        gather_walk<1, Ops>(ent, e0, e1,
+            [&](int, const int* w, Ops& o) {
+                const double* pa = S0 + (w[0] & 0x7fff) + r0;
+                const double* pb = S0 + ((unsigned)w[0] >> 16);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+                for (int q = 0; q < 4; ++q) {
 #pragma unroll
-                for (int r = 0; r < GR; ++r) ea[q][r] = -pa[6 * q + r];
-                y[q][0] = lds2(pb + 6 * q); y[q][1] = lds2(pb + 6 * q + 2); y[q][2] = lds2(pb + 6 * q + 4);
-            }
+                    for (int r = 0; r < GR; ++r) o.ea[q][r] = pa[6 * q + r];
+                    o.y[q][0] = lds2(pb + 6 * q); o.y[q][1] = lds2(pb + 6 * q + 2); o.y[q][2] = lds2(pb + 6 * q + 4);
+                }
+            },
+            [&](int, Ops& o) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+                for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int r = 0; r < GR; ++r) row_fma(A.v + 6 * r, ea[q][r], y[q]);
-            e = en;
-        }
+                    for (int r = 0; r < GR; ++r) row_fma(A.v + 6 * r, -o.ea[q][r], o.y[q]);
+            });
     }
     // ---- direct (always a diagonal block): 3 pose-Jacobian rows (line, line, vanishing point) + corrected residuals
     {
+        struct Ops { double p[3][GR]; d2_t q[3][3], rc01; double rc2; };
         const int e0 = on ? lists[UVS_NGRP + 1 + g] : 0, e1 = on ? lists[UVS_NGRP + 2 + g] : 0;
-        int ro = (e0 < e1) ? ent[e0] : 0;
-        for (int i = e0; i < e1; ++i) {
-            const int rn = (i + 1 < e1) ? ent[i + 1] : 0;
-            const double* R = S0 + ro;
-            double p[3][GR]; d2_t q[3][3];
+        gather_walk<1, Ops>(ent, e0, e1,
+            [&](int, const int* w, Ops& o) {
+                const double* R = S0 + w[0];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
+                for (int k = 0; k < 3; ++k) {
 #pragma unroll
-                for (int r = 0; r < GR; ++r) p[k][r] = R[UVS_LN_JP + 6 * k + r0 + r];
-                q[k][0] = lds2(R + UVS_LN_JP + 6 * k); q[k][1] = lds2(R + UVS_LN_JP + 6 * k + 2); q[k][2] = lds2(R + UVS_LN_JP + 6 * k + 4);
-            }
-            const d2_t rc01 = lds2(R); const double rc2 = R[UVS_LN_RV];
+                    for (int r = 0; r < GR; ++r) o.p[k][r] = R[UVS_LN_JP + 6 * k + r0 + r];
+                    o.q[k][0] = lds2(R + UVS_LN_JP + 6 * k); o.q[k][1] = lds2(R + UVS_LN_JP + 6 * k + 2); o.q[k][2] = lds2(R + UVS_LN_JP + 6 * k + 4);
+                }
+                o.rc01 = lds2(R); o.rc2 = R[UVS_LN_RV];
+            },
+            [&](int, Ops& o) {
 #pragma unroll
-            for (int r = 0; r < GR; ++r) {
+                for (int r = 0; r < GR; ++r) {
 #pragma unroll
-                for (int k = 0; k < 3; ++k) { row_fma(A.v + 6 * r, p[k][r], q[k]); A.hd[r] += p[k][r] * p[k][r]; }
-                A.g[r] += p[0][r] * rc01.x + p[1][r] * rc01.y + p[2][r] * rc2;
-            }
-            ro = rn;
-        }
+                    for (int k = 0; k < 3; ++k) { row_fma(A.v + 6 * r, o.p[k][r], o.q[k]); A.hd[r] += o.p[k][r] * o.p[k][r]; }
+                    A.g[r] += o.p[0][r] * o.rc01.x + o.p[1][r] * o.rc01.y + o.p[2][r] * o.rc2;
+                }
+            });
     }
 }
 
