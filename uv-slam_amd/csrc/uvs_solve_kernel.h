@@ -436,48 +436,64 @@ UVS_DEV void chol_store_item(double* sh, int i, int cc, int lane, const d4_t& ac
 //  (2) the block columns as a task graph without workgroup barriers (LDS flags: wave 0 runs only the diagonal chain and the block
 //      below it, the other three own block rows): 1.888 ms against 1.822 ms per 256-window launch in an A/B on one box -- three
 //      workers carry as many cycles per column as the chain itself, so the chain waits for them a quarter of the time.)
+// One panel item: L_ik = S_ik W_k^T (and y_k = b_k W_k^T for the right-hand-side row i == UVS_NF); Bw = the B operand W_k[c][m]
+UVS_DEV void chol_panel_item(double* sh, int i, int k, int lane, const double* Bw) {
+    const int li = lane & 15, lk = lane >> 4;
+    d4_t acc = {0.0, 0.0, 0.0, 0.0};
+    double av[4];
+    if (i != UVS_NF) {
+        const double* Ai = sblk(sh, i, k) + li * UVS_BLK_LD + lk;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) av[q] = Ai[4 * q];
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const double yv = sh[L_DLT + 16 * k + 4 * q + lk]; av[q] = (li == 0) ? yv : 0.0; }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], Bw[q], acc, 0, 0, 0);
+    chol_store_item(sh, i, k, lane, acc);
+}
+UVS_DEV void chol_panel_operand(double* sh, int k, int lane, double* Bw) {      // W_k[c][m]: strictly-upper slot (m, c) of the diagonal block, 1/L_cc on the diagonal
+    const int li = lane & 15, lk = lane >> 4;
+    const double* Dk = sblk(sh, k, k);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {      // unconditional loads + selects (a conditional LDS read becomes a branch per element)
+        const int m = 4 * q + lk;
+        const double up = Dk[m * UVS_BLK_LD + li], dg = sh[L_DINV + 16 * k + li];
+        Bw[q] = (m < li) ? up : (m == li ? dg : 0.0);
+    }
+}
+
+// ONE workgroup barrier per block column.  Inside a column the rows are statically owned -- wave 0: the diagonal block (k, k) and the
+// block (k+1, k) below it; worker w: rows k+2+w, k+2+w+nwork, ... -- so a block's last term (A), its panel solve (S3) and the store in
+// between stay inside one wave, and the only cross-wave dependency left inside the column is W_k, which the workers wait for on an LDS
+// flag after they have done their look-ahead (terms j < k of column k+1).  The two-barrier version made every wave wait for the
+// slowest one twice per column and left the pivot chain idle during the whole panel phase.
 UVS_DEV void chol_factor_impl(double* sh, int debug) {
     MiniCtx c; c.sh = sh; c.o.debug = debug;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform ON PURPOSE: item indices derived from it select code paths
     const int li = lane & 15, lk = lane >> 4;
+    int* flg = (int*)(sh + L_XC);      // x_c is dead between the assembly and the back-substitution of the landmarks
+    if (tid < 16) flg[tid] = 0;      // [k]: W_k published
     if (tid == 0) sh[L_CTRL + C_CHOLOK] = 1.0;
     UVS_PROF(c, P_MISC);
-    // wave 0 owns the diagonal blocks; with 8 waves, wave 4 sits on the same SIMD (waves are dealt to the 4 SIMDs round-robin) and
-    // would put its MFMAs between the pivots of the serial chain, so it only helps in S3
-    const int nwork = (NW == 8) ? 6 : NW - 1;
-    const int wrk = (wv == 0 || ((NW == 8) && wv == 4)) ? -1 : ((NW == 8) ? ((wv < 4) ? wv - 1 : wv - 2) : wv - 1);
+    constexpr int nwork = NW - 1;
+    const int wrk = wv - 1;
     for (int k = 0; k < UVS_NF; ++k) {
         double* Dk = sblk(sh, k, k);
         __syncthreads();
         const long long tw0_ = debug ? clock64() : 0;
-        // ---- A: last term (j = k-1) of block column k
-        d4_t dacc = {0.0, 0.0, 0.0, 0.0};
         if (wv == 0) {
-            dacc = chol_load_item(sh, k, k, lane);
-            if (k > 0) chol_update_item(sh, k, k, k - 1, k, lane, dacc);
-        } else if (wrk >= 0) {
+            // ---- A: last term (j = k-1) of the diagonal block (kept in MFMA registers) and of the block below it
+            d4_t dacc = chol_load_item(sh, k, k, lane);
             if (k > 0) {
-                for (int i = k + 1 + wrk; i <= UVS_NF; i += nwork) {
-                    d4_t acc = chol_load_item(sh, i, k, lane);
-                    chol_update_item(sh, i, k, k - 1, k, lane, acc);
-                    chol_store_item(sh, i, k, lane, acc);
-                }
+                chol_update_item(sh, k, k, k - 1, k, lane, dacc);
+                d4_t below = chol_load_item(sh, k + 1, k, lane);
+                chol_update_item(sh, k + 1, k, k - 1, k, lane, below);
+                chol_store_item(sh, k + 1, k, lane, below);
             }
-            if (k > 0 && k + 1 < UVS_NF) {
-                for (int i = k + 1 + wrk; i <= UVS_NF; i += nwork) {
-                    d4_t acc = chol_load_item(sh, i, k + 1, lane);
-                    chol_update_item(sh, i, k + 1, 0, k, lane, acc);
-                    chol_store_item(sh, i, k + 1, lane, acc);
-                }
-            }
-        }
-        UVS_PROF(c, P_CH_TRAIL);
-        // ---- S2: wave 0 factors the diagonal block in registers (L -> lower triangle, W^T -> strictly upper, 1/L_jj -> L_DINV).
-        // The serial chain per pivot is readlane -> reciprocal -> masked scale -> MFMA; with STRICT masks row j of both accumulators
-        // is left untouched after pivot j (unscaled row j of dacc = a_jc^(j), row j of T = row of W), so the scaling by 1/d_j happens
-        // once, lane-parallel, after the chain.
-        if (wv == 0) {
+            // ---- S2: the diagonal block factored in registers (L -> lower triangle, W^T -> strictly upper, 1/L_jj -> L_DINV)
             d4_t T;
 #pragma unroll
             for (int q = 0; q < 4; ++q) T[q] = (lk + 4 * q == li) ? 1.0 : 0.0;
@@ -508,37 +524,34 @@ UVS_DEV void chol_factor_impl(double* sh, int debug) {
                 Dk[li * UVS_BLK_LD + j] = (li > j) ? dacc[q] * inv : (li == j ? ljj : T[q] * inv);      // L[c][j] | W[j][m] at (m, j)
                 if (li == j) { sh[L_DINV + 16 * k + j] = inv; if (!(pivs[q] > 0.0)) sh[L_CTRL + C_CHOLOK] = 0.0; }
             }
-        }
-        if (debug == 1 && lane == 0) sh[L_WPROF + 4 + wv] += (double)(clock64() - tw0_);      // busy time of this wave in A + (pivot chain | look-ahead), without the barrier wait
-        __syncthreads();
-        UVS_PROF(c, P_CH_DIAG);
-        // ---- S3: panel  L_ik = S_ik W^T  (B operand W[c][m]: strictly-upper slot (m, c) of the diagonal block, 1/L_cc on the diagonal)
-        {
-            double Bw[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {      // unconditional loads + selects (a conditional LDS read becomes a branch per element)
-                const int m = 4 * q + lk;
-                const double up = Dk[m * UVS_BLK_LD + li], dg = sh[L_DINV + 16 * k + li];
-                Bw[q] = (m < li) ? up : (m == li ? dg : 0.0);
-            }
-            for (int i = k + 1 + wv; i <= UVS_NF; i += NW) {
-                const bool rhs = (i == UVS_NF);
-                d4_t acc = {0.0, 0.0, 0.0, 0.0};
-                double av[4];
-                if (!rhs) {
-                    const double* Ai = sblk(sh, i, k) + li * UVS_BLK_LD + lk;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) av[q] = Ai[4 * q];
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) { const double yv = sh[L_DLT + 16 * k + 4 * q + lk]; av[q] = (li == 0) ? yv : 0.0; }
+            if (lane == 0) __hip_atomic_store(flg + k, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            // ---- S3 for the block below the diagonal (the right-hand-side row for the last column)
+            double Bw[4]; chol_panel_operand(sh, k, lane, Bw);
+            chol_panel_item(sh, k + 1, k, lane, Bw);
+            if (debug == 1 && lane == 0) sh[L_WPROF + 4] += (double)(clock64() - tw0_);
+        } else {
+            // ---- A: last term of this wave's rows of column k;  LA: terms j < k of column k + 1 (all rows, the diagonal block included)
+            if (k > 0) {
+                for (int i = k + 2 + wrk; i <= UVS_NF; i += nwork) {
+                    d4_t acc = chol_load_item(sh, i, k, lane);
+                    chol_update_item(sh, i, k, k - 1, k, lane, acc);
+                    chol_store_item(sh, i, k, lane, acc);
                 }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], Bw[q], acc, 0, 0, 0);
-                chol_store_item(sh, i, k, lane, acc);
+                if (k + 1 < UVS_NF) {
+                    for (int i = k + 1 + wrk; i <= UVS_NF; i += nwork) {
+                        d4_t acc = chol_load_item(sh, i, k + 1, lane);
+                        chol_update_item(sh, i, k + 1, 0, k, lane, acc);
+                        chol_store_item(sh, i, k + 1, lane, acc);
+                    }
+                }
             }
+            if (debug == 1 && lane == 0) sh[L_WPROF + 4 + wv] += (double)(clock64() - tw0_);
+            // ---- S3: panel of this wave's rows, once the diagonal wave has published W_k
+            while (__hip_atomic_load(flg + k, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(1);
+            double Bw[4]; chol_panel_operand(sh, k, lane, Bw);
+            for (int i = k + 2 + wrk; i <= UVS_NF; i += nwork) chol_panel_item(sh, i, k, lane, Bw);
         }
-        UVS_PROF(c, P_CH_PANEL);
+        UVS_PROF(c, P_CH_DIAG);
     }
     __syncthreads();
 }
