@@ -475,7 +475,7 @@ UVS_DEV void chol_factor_impl(double* sh, int debug) {
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform ON PURPOSE: item indices derived from it select code paths
     const int li = lane & 15, lk = lane >> 4;
     int* flg = (int*)(sh + L_XC);      // x_c is dead between the assembly and the back-substitution of the landmarks
-    if (tid < 16) flg[tid] = 0;      // [k]: W_k published
+    if (tid < 32) flg[tid] = 0;      // [k]: W_k published; [16 + k]: S(k+1, k) carries its last term
     if (tid == 0) sh[L_CTRL + C_CHOLOK] = 1.0;
     UVS_PROF(c, P_MISC);
     constexpr int nwork = NW - 1;
@@ -487,12 +487,7 @@ UVS_DEV void chol_factor_impl(double* sh, int debug) {
         if (wv == 0) {
             // ---- A: last term (j = k-1) of the diagonal block (kept in MFMA registers) and of the block below it
             d4_t dacc = chol_load_item(sh, k, k, lane);
-            if (k > 0) {
-                chol_update_item(sh, k, k, k - 1, k, lane, dacc);
-                d4_t below = chol_load_item(sh, k + 1, k, lane);
-                chol_update_item(sh, k + 1, k, k - 1, k, lane, below);
-                chol_store_item(sh, k + 1, k, lane, below);
-            }
+            if (k > 0) chol_update_item(sh, k, k, k - 1, k, lane, dacc);
             // ---- S2: the diagonal block factored in registers (L -> lower triangle, W^T -> strictly upper, 1/L_jj -> L_DINV)
             d4_t T;
 #pragma unroll
@@ -525,13 +520,21 @@ UVS_DEV void chol_factor_impl(double* sh, int debug) {
                 if (li == j) { sh[L_DINV + 16 * k + j] = inv; if (!(pivs[q] > 0.0)) sh[L_CTRL + C_CHOLOK] = 0.0; }
             }
             if (lane == 0) __hip_atomic_store(flg + k, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            // ---- S3 for the block below the diagonal (the right-hand-side row for the last column)
+            // ---- S3 for the block below the diagonal (the right-hand-side row for the last column); its last term was the first thing
+            // the lightest worker did in this column, 4 k cycles ago
+            if (k > 0) while (__hip_atomic_load(flg + 16 + k, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(1);
             double Bw[4]; chol_panel_operand(sh, k, lane, Bw);
             chol_panel_item(sh, k + 1, k, lane, Bw);
             if (debug == 1 && lane == 0) sh[L_WPROF + 4] += (double)(clock64() - tw0_);
         } else {
             // ---- A: last term of this wave's rows of column k;  LA: terms j < k of column k + 1 (all rows, the diagonal block included)
             if (k > 0) {
+                if (wrk == nwork - 1) {      // the last worker has the fewest rows: it takes the block below the diagonal (whose panel solve is wave 0's) first
+                    d4_t acc = chol_load_item(sh, k + 1, k, lane);
+                    chol_update_item(sh, k + 1, k, k - 1, k, lane, acc);
+                    chol_store_item(sh, k + 1, k, lane, acc);
+                    if (lane == 0) __hip_atomic_store(flg + 16 + k, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
                 for (int i = k + 2 + wrk; i <= UVS_NF; i += nwork) {
                     d4_t acc = chol_load_item(sh, i, k, lane);
                     chol_update_item(sh, i, k, k - 1, k, lane, acc);
