@@ -142,3 +142,25 @@ def test_marginalize_resident_equals_marginalize(gpu_api, oracle):
     with pytest.raises(RuntimeError):
         s.marginalize(other, 0, resident=True)
     s.close()
+
+
+def test_threaded_batch_packing_equals_serial(gpu_api):
+    """uvs_batch_upload packs the windows of a batch on several host threads (UVS_PACK_THREADS, default min(16, cores)) into per-window
+    buffers and concatenates them: the device must see the same bytes as from the serial path, i.e. bitwise equal solves -- on a
+    heterogeneous batch (different sizes => different blob lengths and chunk counts)."""
+    import os
+    rng = np.random.default_rng(11)
+    ws = [synth.make_window(900 + i, n_points=int(rng.integers(20, 200)), n_lines=int(rng.integers(0, 50)), n_tagged=0) for i in range(24)]
+    def run(threads):
+        old = os.environ.get("UVS_PACK_THREADS")
+        os.environ["UVS_PACK_THREADS"] = str(threads)
+        try:
+            s = gpu_api.Solver(max_batch=32)
+            s.upload(ws); s.solve_resident(); st, rep = s.download(); s.close()
+        finally:
+            if old is None: os.environ.pop("UVS_PACK_THREADS")
+            else: os.environ["UVS_PACK_THREADS"] = old
+        return st, rep
+    s1, r1 = run(1); s8, r8 = run(8)
+    for a, b, ra, rb in zip(s1, s8, r1, r8):
+        assert ra.status == 0 and ra.final_cost == rb.final_cost and np.array_equal(a.pose, b.pose) and np.array_equal(a.inv_depth, b.inv_depth) and np.array_equal(a.line_orth, b.line_orth)
