@@ -16,14 +16,18 @@ struct EvalOut {   // device pointers
     double *pt_r, *pt_J, *ln_r, *ln_J, *vp_r, *vp_J, *imu_r, *imu_J, *prior_r, *cost, *pt_Jtd;
 };
 
-__global__ __launch_bounds__(NT) void k_evaluate(char* blob, double* ws, KOpts o, int robust, EvalOut out) {
+// mode: bit 0 = apply the loss correction (robust); bit 1 = MARGIN_OLD subset: only the blocks that touch frame 0 are evaluated (prior,
+// the IMU block of frame 0, points anchored at frame 0, observations j != 0 of lines that start at frame 0 -- estimator.cpp:1008-1129); the
+// outputs of the other blocks are left untouched and `cost` is partial.
+__global__ __launch_bounds__(NT) void k_evaluate(char* blob, double* ws, KOpts o, int mode, EvalOut out) {
+    const int robust = mode & 1; const bool marg0 = (mode & 2) != 0;
     extern __shared__ __attribute__((aligned(16))) double sh[];   // same LDS map as the solver (launched with LDS_BYTES)
     const int tid = threadIdx.x;
     Ctx c;
     c.hdr = (const DevWin*)blob; c.bd = (const double*)blob; c.bi = (const int*)blob; c.ws = ws; c.sh = sh; c.o = o;
     const DevWin& h = *c.hdr;
     if (tid < UVS_XDIM) sh[L_X + tid] = c.bd[h.d_frames + tid];
-    setup_window(c, (double*)blob, false);
+    setup_window(c, (double*)blob, false, marg0 ? 0 : -1);
     __syncthreads();
     const double* x = sh + L_X;
     stage_rotations(c, x);
@@ -38,7 +42,7 @@ __global__ __launch_bounds__(NT) void k_evaluate(char* blob, double* ws, KOpts o
         // relocalization blocks are solve-only (the reference's marginalization does not add them, estimator.cpp:1002-1228); outputs keep the
         // caller's observation numbering
         const int eo = h.relo_on ? c.bi[h.i_pt_eidx + ob] : ob;
-        if (eo < 0) continue;
+        if (eo < 0 || (marg0 && fi != 0)) continue;
         double pi[3], pj[3], vij[4] = {0.0, 0.0, 0.0, 0.0}, jtd[2] = {0.0, 0.0};
         load_point_obs(c, ob, x[183], pi, pj, vij);
         double r[2], A[12], B[12], cl[2], E[12];
@@ -55,6 +59,7 @@ __global__ __launch_bounds__(NT) void k_evaluate(char* blob, double* ws, KOpts o
     }
     for (int ob = tid; ob < h.n_ln_obs; ob += NT) {
         const int lm = c.bi[h.i_ln_lm + ob], fj = c.bi[h.i_ln_fj + ob], hv = c.bi[h.i_ln_vp + ob];
+        if (marg0 && (fj == 0 || c.bi[h.i_ln_fj + c.bi[h.i_ln_beg + lm]] != 0)) continue;      // the line's first observation names its start frame
         const double* m = c.bd + h.d_lnmeas + ob; const int st = h.ln_stride;
         const double sp[3] = {m[0], m[st], m[2 * st]}, ep[3] = {m[3 * st], m[4 * st], m[5 * st]}, vp[3] = {m[6 * st], m[7 * st], m[8 * st]};
         LineGeom g;
@@ -76,7 +81,7 @@ __global__ __launch_bounds__(NT) void k_evaluate(char* blob, double* ws, KOpts o
         } else { out.vp_r[ob] = 0.0; for (int q = 0; q < 10; ++q) Jv[q] = 0.0; }
     }
     if (tid < h.n_imu) {
-        const int fi = c.bi[h.i_imu + 2 * tid], skip = c.bi[h.i_imu + 2 * tid + 1];
+        const int fi = c.bi[h.i_imu + 2 * tid], skip = c.bi[h.i_imu + 2 * tid + 1] | (marg0 && fi != 0);
         double* wj = c.ws + h.w_imu + (size_t)tid * UVS_WIMU_STRIDE;
         if (!skip) {
             const double* blk = c.bd + h.d_imu + (size_t)tid * UVS_IMU_STRIDE;
@@ -88,7 +93,7 @@ __global__ __launch_bounds__(NT) void k_evaluate(char* blob, double* ws, KOpts o
     __syncthreads();
     for (int t = tid; t < h.n_imu * 465; t += NT) {
         const int b = t / 465, e = t - b * 465;
-        const bool skip = c.bi[h.i_imu + 2 * b + 1] != 0;
+        const bool skip = c.bi[h.i_imu + 2 * b + 1] != 0 || (marg0 && c.bi[h.i_imu + 2 * b] != 0);
         const double* W = c.bd + h.d_imu + (size_t)b * UVS_IMU_STRIDE + UVS_IMU_W;
         const double* wj = c.ws + h.w_imu + (size_t)b * UVS_WIMU_STRIDE;
         if (e < 450) { const int r = e / 30, cc = e - r * 30; double s = 0.0; if (!skip) for (int k = r; k < 15; ++k) s += W[r * 15 + k] * wj[k * 30 + cc]; out.imu_J[450 * (size_t)b + e] = s; }

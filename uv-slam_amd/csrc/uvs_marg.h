@@ -170,7 +170,10 @@ static int run_marginalize(int device, hipStream_t stream, char* d_blob, double*
     const bool prof = std::getenv("UVS_MARG_PROFILE") != nullptr;
     auto tnow = [] { return std::chrono::steady_clock::now(); };
     auto t0 = tnow();
-    int rc = run_evaluate(device, stream, d_blob, d_ws, h, ko, 1, &ev, err, sc);
+    // MARGIN_OLD reads only the factors that touch frame 0 (a fifth of the window): the kernel skips the rest (mode bit 1); MARGIN_SECOND_NEW
+    // reads the prior residual only, which the same subset mode delivers without evaluating a single observation of frame 0... it does evaluate
+    // those, a few microseconds, to keep one code path
+    int rc = run_evaluate(device, stream, d_blob, d_ws, h, ko, 1 | 2, &ev, err, sc);
     if (rc != UVS_OK) return rc;
     auto t1 = tnow();
     // ---- host: block bookkeeping.  ids: pose f -> f ; speedbias f -> 11+f ; ex -> 22 ; td -> 23 ; point k -> 24+k ; line l -> 24+Np+l
@@ -244,14 +247,25 @@ static int run_marginalize(int device, hipStream_t stream, char* d_blob, double*
         const uvs_prior& p = *w->prior; const int pn = p.n, nc = (int)p_id.size();
         std::vector<int> gc(nc);
         { int run = 0, last = -1; for (int c2 = 0; c2 < nc; ++c2) { if (p_id[c2] != last) { last = p_id[c2]; run = 0; } gc[c2] = pos[p_id[c2]] + run++; } }
+        // J0^T J0 is the single largest piece of the assembly (n^3 / 1 multiply-adds): only the half c2 <= a is accumulated, into a dense
+        // nc x nc scratch with the gathered row contiguous, and mirrored when scattered (same products, same summation order over i, so
+        // the values are the ones the full loop produced)
+        std::vector<double> P((size_t)nc * nc, 0.0), rowv(nc);
         for (int i = 0; i < pn; ++i) {
             const double* Ji = &p.linearized_jacobians[(size_t)i * pn];
+            for (int a = 0; a < nc; ++a) rowv[a] = Ji[p_src[a]];
             for (int a = 0; a < nc; ++a) {
-                const double ja = Ji[p_src[a]];
+                const double ja = rowv[a];
                 if (ja == 0.0) continue;
                 bv[gc[a]] += ja * prior_r[i];
-                for (int c2 = 0; c2 < nc; ++c2) A[(size_t)gc[a] * N + gc[c2]] += ja * Ji[p_src[c2]];
+                double* Pa = &P[(size_t)a * nc];
+                for (int c2 = 0; c2 <= a; ++c2) Pa[c2] += ja * rowv[c2];
             }
+        }
+        for (int a = 0; a < nc; ++a) for (int c2 = 0; c2 <= a; ++c2) {
+            const double v = P[(size_t)a * nc + c2];
+            A[(size_t)gc[a] * N + gc[c2]] += v;
+            if (c2 != a) A[(size_t)gc[c2] * N + gc[a]] += v;
         }
     }
     for (const MFactor& f : fs) {

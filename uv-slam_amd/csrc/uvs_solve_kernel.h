@@ -1610,10 +1610,11 @@ UVS_DEV void imu_whiten_block(const double* cov, double* W, double* scr /* LDS, 
     wave_sync();
 }
 
-UVS_DEV void setup_window(const Ctx& c, double* blob_rw, bool with_prior_image = true) {      // k_evaluate needs the IMU whitening only
+UVS_DEV void setup_window(const Ctx& c, double* blob_rw, bool with_prior_image = true, int only_imu_frame = -1) {      // k_evaluate needs the IMU whitening only
     const DevWin& h = *c.hdr;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     for (int b = wv; b < h.n_imu; b += NW) {
+        if (only_imu_frame >= 0 && c.bi[h.i_imu + 2 * b] != only_imu_frame) continue;      // marginalization: the one block that touches the departing frame
         double* blk = blob_rw + h.d_imu + (size_t)b * UVS_IMU_STRIDE;
         imu_whiten_block(blk + UVS_IMU_COV, blk + UVS_IMU_W, c.sh + L_S + 256 * wv, lane);
     }
