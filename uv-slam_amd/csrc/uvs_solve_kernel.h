@@ -40,7 +40,7 @@ static constexpr int L_PDX = L_EX + 16;        // prior dx
 static constexpr int L_PR = L_PDX + UVS_MAX_PRIOR_DIM;   // prior residual
 static constexpr int L_PRC = L_PR + UVS_MAX_PRIOR_DIM;   // prior residual at the CANDIDATE (becomes the current one when the step is accepted)
 static constexpr int L_RED = L_PRC + UVS_MAX_PRIOR_DIM;  // reduction scratch
-static constexpr int L_CTRL = L_RED + 24;      // block_reduce uses 5 doubles per wave
+static constexpr int L_CTRL = L_RED + (5 * NW > 24 ? 5 * NW : 24);      // block_reduce uses 5 doubles per wave (an 8-wave build wrote waves 5..7 into the control words: the wrong final costs of the 512-thread experiments)
 static constexpr int L_PROF = L_CTRL + 32;      // per-phase cycle counters (debug launches only)
 static constexpr int L_WPROF = L_PROF + 24;     // debug sub-timers: [0..3] candidate-cost phase (stage + dx, prior residual, observations, IMU), [4..7] busy cycles of each wave in the Cholesky column phase
 static constexpr int L_LCOST = L_WPROF + 8;     // per-lane cost accumulator of the current linearization (kept in LDS, not in a register that
