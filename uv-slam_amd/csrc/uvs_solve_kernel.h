@@ -21,6 +21,16 @@
 
 namespace uvsdev {
 
+
+// threadIdx.x behind an optimization barrier.  With the plain intrinsic the compiler hoists every per-lane address computation of the
+// LM iteration (base + k * tid ...) out of the iteration loop, keeps ~50 of them alive across the whole loop -- the kernel sits at the
+// 512-register cap, so they are spilled to scratch once and RELOADED from scratch at each use, 75 global-memory loads per iteration whose
+// latency one wavefront per SIMD cannot hide.  Re-deriving them from an opaque value costs a few integer instructions instead.
+#ifndef UVS_X_PLAIN_TID
+static __device__ __forceinline__ int lane_tid() { int t = threadIdx.x; asm volatile("" : "+v"(t)); return t; }
+#else
+static __device__ __forceinline__ int lane_tid() { return threadIdx.x; }
+#endif
 static constexpr int NT = UVS_NT;              // threads per workgroup
 static constexpr int NW = NT / 64;
 
@@ -49,7 +59,7 @@ static constexpr int L_LGMAX = L_LCOST + NT / LACC;    // would have to live acr
 static constexpr int L_TOTAL = L_LGMAX + NT / LACC;
 static_assert(L_TOTAL * 8 <= 160 * 1024, "LDS map exceeds the 160 KB of a CU");
 enum { P_SETUP = 0, P_OBS, P_LMPREP, P_GATHER, P_ASSEMBLE, P_CHOL, P_TRSV, P_BACKSUB, P_COST, P_MISC, P_CH_DIAG, P_CH_PANEL, P_CH_TRAIL, P_AS_IMU, P_AS_ZERO, P_AS_ADD, P_LAST };
-#define UVS_PROF(c, k) do { if ((c).o.debug && threadIdx.x == 0) { const long long now_ = clock64(); (c).sh[L_PROF + (k)] += (double)(now_ - (long long)(c).sh[L_PROF + 23]); (c).sh[L_PROF + 23] = (double)now_; } } while (0)
+#define UVS_PROF(c, k) do { if ((c).o.debug && lane_tid() == 0) { const long long now_ = clock64(); (c).sh[L_PROF + (k)] += (double)(now_ - (long long)(c).sh[L_PROF + 23]); (c).sh[L_PROF + 23] = (double)now_; } } while (0)
 static constexpr size_t LDS_BYTES = (size_t)L_TOTAL * 8;
 
 enum { C_COST = 0, C_RADIUS, C_DECR, C_XNORM, C_GMAX, C_CAND, C_MCC, C_STEP2, C_XC2, C_GO, C_IT, C_INVALID, C_CUR, C_FIRST,
@@ -107,7 +117,7 @@ UVS_DEV void rsqrt_pair(double x, double* sq, double* rsq) {
 }
 // Deterministic block reductions of up to 4 sums + 1 max.  Result broadcast to every thread.
 UVS_DEV void block_reduce(double* sh, double* s /*[4]*/, double* mx) {
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = lane_tid(), lane = tid & 63, wv = tid >> 6;
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 4; ++k) { const double t = wave_sum(s[k]); if (lane == 0) sh[L_RED + wv * 5 + k] = t; }
@@ -129,17 +139,17 @@ UVS_DEV void block_reduce(double* sh, double* s /*[4]*/, double* mx) {
 
 // per-lane (or per lane pair) accumulators of the running linearization
 UVS_DEV void lacc_set(double* sh, double cost, double gmax) {
-    const int tid = threadIdx.x;
+    const int tid = lane_tid();
     if (LACC == 2) { cost += __shfl_xor(cost, 1, 64); gmax = fmax(gmax, __shfl_xor(gmax, 1, 64)); }
     if (tid % LACC == 0) { sh[L_LCOST + tid / LACC] = cost; sh[L_LGMAX + tid / LACC] = gmax; }
 }
 UVS_DEV void lacc_add(double* sh, double cost, double gmax) {
-    const int tid = threadIdx.x;
+    const int tid = lane_tid();
     if (LACC == 2) { cost += __shfl_xor(cost, 1, 64); gmax = fmax(gmax, __shfl_xor(gmax, 1, 64)); }
     if (tid % LACC == 0) { sh[L_LCOST + tid / LACC] += cost; sh[L_LGMAX + tid / LACC] = fmax(sh[L_LGMAX + tid / LACC], gmax); }
 }
-UVS_DEV double lacc_cost(const double* sh) { const int tid = threadIdx.x; return tid % LACC == 0 ? sh[L_LCOST + tid / LACC] : 0.0; }
-UVS_DEV double lacc_gmax(const double* sh) { return sh[L_LGMAX + threadIdx.x / LACC]; }
+UVS_DEV double lacc_cost(const double* sh) { const int tid = lane_tid(); return tid % LACC == 0 ? sh[L_LCOST + tid / LACC] : 0.0; }
+UVS_DEV double lacc_gmax(const double* sh) { return sh[L_LGMAX + lane_tid() / LACC]; }
 
 struct Ctx {
     const DevWin* hdr;
@@ -160,7 +170,7 @@ UVS_DEV const double* line_trig_of(const Ctx& c, const double* line) {
 
 // rotation matrices of the evaluation point `x` (LDS, L_X or L_XC layout) -> L_RF / L_EX
 UVS_DEV void stage_rotations(const Ctx& c, const double* x) {
-    const int tid = threadIdx.x;
+    const int tid = lane_tid();
     if (tid < UVS_NF) quat_to_R(x + 7 * tid + 3, c.sh + L_RF + 9 * tid);
     else if (tid == UVS_NF) { quat_to_R(x + 176 + 3, c.sh + L_EX); c.sh[L_EX + 9] = x[176]; c.sh[L_EX + 10] = x[177]; c.sh[L_EX + 11] = x[178]; }
     else if (tid == UVS_RELO_FRAME && c.hdr->relo_on) quat_to_R(x + 184 + 3, c.sh + L_RF + 9 * UVS_RELO_FRAME);
@@ -184,7 +194,7 @@ UVS_DEV void load_point_obs(const Ctx& c, int o, double td, double* pi, double* 
 
 // ------------------------------------------------------------------ residual-only cost at `x` (LDS) / landmark buffer `sel`
 UVS_DEV void prior_dx(const Ctx& c, const double* x) {
-    const int tid = threadIdx.x;
+    const int tid = lane_tid();
     const DevWin& h = *c.hdr;
     if (h.prior_n > 0 && tid < h.prior_nb) {
         const int* pt = c.bi + h.i_prior;
@@ -210,7 +220,7 @@ UVS_DEV void prior_dx(const Ctx& c, const double* x) {
 // contains one workgroup barrier, so all threads must call it.
 UVS_DEV double prior_residual(const Ctx& c, int dst = L_PR) {
     const DevWin& h = *c.hdr;
-    const int n = h.prior_n, tid = threadIdx.x;
+    const int n = h.prior_n, tid = lane_tid();
     double cost = 0.0;
     if (n <= 0) return cost;
     const int parts = (NT / n) < 4 ? (NT / n) : 4;
@@ -242,7 +252,7 @@ UVS_DEV double prior_residual(const Ctx& c, int dst = L_PR) {
 // cost of all residual blocks at the point staged in (x, RF/EX) with landmark buffers invd / line
 UVS_DEV double cost_pass(const Ctx& c, const double* x, const double* invd, const double* line, int po0, int po1, int lo0, int lo1, bool with_imu) {
     const DevWin& h = *c.hdr;
-    const int tid = threadIdx.x;
+    const int tid = lane_tid();
     const double* RF = c.sh + L_RF; const double* ric = c.sh + L_EX; const double* tic = c.sh + L_EX + 9;
     const double* ltrig = line_trig_of(c, line);
     double cost = 0.0;
@@ -471,7 +481,7 @@ UVS_DEV void chol_panel_operand(double* sh, int k, int lane, double* Bw) {      
 // slowest one twice per column and left the pivot chain idle during the whole panel phase.
 UVS_DEV void chol_factor_impl(double* sh, int debug) {
     MiniCtx c; c.sh = sh; c.o.debug = debug;
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = lane_tid(), lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform ON PURPOSE: item indices derived from it select code paths
     const int li = lane & 15, lk = lane >> 4;
     int* flg = (int*)(sh + L_XC);      // x_c is dead between the assembly and the back-substitution of the landmarks
@@ -572,7 +582,7 @@ UVS_DEV void chol_factor(const Ctx& c) { chol_factor_call(c.o.debug); }
 // One wave does all of it: the chain x_k -> (update of the rows above) -> x_k-1 is serial anyway, and inside a single wave it
 // needs no workgroup barrier (22 of them otherwise).
 UVS_DEV void chol_solve_impl(double* sh) {
-    const int tid = threadIdx.x;
+    const int tid = lane_tid();
     double* b = sh + L_DLT;
     __syncthreads();
     if (tid < 64) {
@@ -640,7 +650,7 @@ UVS_DEV d2_t lds2(const double* p) { return *(const d2_t*)p; }
 // brackets the call with barriers as documented).  Part order => the same fixed summation order as one add round per part, but
 // ONE barrier-separated step instead of up to 16 rounds.  All lanes must call it.
 UVS_DEV void gacc_gather_parts(GAcc& A, int grp, double* scr) {
-    const int tid = threadIdx.x;
+    const int tid = lane_tid();
     const int part = grp >= 0 ? (grp >> 9) & 15 : 0, np = grp >= 0 ? ((grp >> 21) & 15) + 1 : 1;
     if (part > 0) {
         double* D = scr + (8 * GR + 1) * tid;
@@ -672,7 +682,7 @@ UVS_DEV void row_fma(double* v, double s, const d2_t* q) {
 }
 
 // this lane's group descriptor (-1 = idle group), see uvs_layout.h: i_wblk
-UVS_DEV int gather_group(const Ctx& c) { return c.bi[c.hdr->i_wblk + (threadIdx.x / UVS_GLANES)]; }
+UVS_DEV int gather_group(const Ctx& c) { return c.bi[c.hdr->i_wblk + (lane_tid() / UVS_GLANES)]; }
 
 // Walks entries [e0, e1) of a gather list, K per stage, SOFTWARE PIPELINED over two register sets: while the FMAs of stage t issue, the
 // LDS loads of stage t + 1 (addresses from the entries fetched during stage t - 1) and the entry words of stage t + 2 are already in
@@ -703,7 +713,7 @@ UVS_DEV void gather_walk(const int* ent, int e0, int e1, Load load, Use use) {
 // EXT = the window has pseudo-frame blocks (ESTIMATE_TD / ESTIMATE_EXTRINSIC); the default instantiation folds all their special cases away
 template <bool EXT>
 UVS_DEV void gather_points(int grp, const int* lists, const double* S0, GAcc& A) {
-    const int g = threadIdx.x / UVS_GLANES, r0 = GR * (threadIdx.x % UVS_GLANES);
+    const int g = lane_tid() / UVS_GLANES, r0 = GR * (lane_tid() % UVS_GLANES);
     const bool on = grp >= 0;
     const bool diag = on && ((grp >> 8) & 1);
     const bool tdg = EXT && on && ((grp >> 13) & 15) == UVS_NF;       // block row of the time offset: J1 = (J_td[0], J_td[1]) adjacent, residual 16 doubles below
@@ -763,7 +773,7 @@ UVS_DEV void gather_points(int grp, const int* lists, const double* S0, GAcc& A)
 }
 
 UVS_DEV void gather_lines(int grp, const int* lists, const double* S0, GAcc& A) {
-    const int g = threadIdx.x / UVS_GLANES, r0 = GR * (threadIdx.x % UVS_GLANES);
+    const int g = lane_tid() / UVS_GLANES, r0 = GR * (lane_tid() % UVS_GLANES);
     const bool on = grp >= 0;
     const int* ent = lists + LIST_HDR;
     // ---- Schur: acc[r][c] -= sum_q E_a[q][r0 + r] * Y_b[q][c]
@@ -832,7 +842,7 @@ struct ImuN { d4_t n00[IMU_SLOTS], n10[IMU_SLOTS], n11[IMU_SLOTS]; };
 // mat-vec from HBM is not repeated); after a REJECTED or invalid step (mode 2) x and L_PR are unchanged, only the rotations are restaged.
 UVS_DEV double lin_prep(const Ctx& c, const double* x, int mode = 0) {
     UVS_PROF(c, P_MISC);
-    const int tid = threadIdx.x, n = c.hdr->prior_n;
+    const int tid = lane_tid(), n = c.hdr->prior_n;
     if (mode == 0) {
         stage_rotations(c, x);
         prior_dx(c, x);
@@ -850,7 +860,7 @@ UVS_DEV double lin_prep(const Ctx& c, const double* x, int mode = 0) {
 UVS_DEV double lin_imu(const Ctx& c, const double* x, ImuN& N) {
     const DevWin& h = *c.hdr;
     double* sh = c.sh;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 15, lk = lane >> 4;
+    const int tid = lane_tid(), lane = tid & 63, wv = tid >> 6, li = lane & 15, lk = lane >> 4;
     double cost = 0.0;
     __syncthreads();      // previous users of the S region are done
     UVS_PROF(c, P_GATHER);
@@ -935,7 +945,7 @@ UVS_DEV void lin_chunk(const Ctx& c, int ch, const double* x, const double* invd
                        int grp, GAcc& acc) {
     const DevWin& h = *c.hdr;
     double* sh = c.sh;
-    const int tid = threadIdx.x;
+    const int tid = lane_tid();
     const double* RF = sh + L_RF; const double* ric = sh + L_EX; const double* tic = sh + L_EX + 9;
     const int* chunks = c.bi + h.i_chunks;
     double cost = 0.0, gmax_lm = 0.0;      // this chunk's share; flushed to the per-lane LDS accumulators before the gather
@@ -1189,7 +1199,7 @@ UVS_DEV void lin_chunk(const Ctx& c, int ch, const double* x, const double* invd
 UVS_DEV void lin_assemble(const Ctx& c, const double* x, bool first, double radius, int grp, const GAcc& Ain, const ImuN& N, double cost, double gmax_lm) {
     const DevWin& h = *c.hdr;
     double* sh = c.sh;
-    const int tid = threadIdx.x;
+    const int tid = lane_tid();
     __syncthreads();
     UVS_PROF(c, P_GATHER);
     // ---- assemble the reduced system in LDS
@@ -1405,7 +1415,7 @@ UVS_DEV void backsub_candidate(const Ctx& c, const double* invd, const double* l
                                   int pk0, int pk1, int lk0, int lk1, bool with_frames, double* sums_out) {
     const DevWin& h = *c.hdr;
     double* sh = c.sh;
-    const int tid = threadIdx.x;
+    const int tid = lane_tid();
     const double* d = sh + L_DLT;
     double gd = 0.0, dd2 = 0.0, step2 = 0.0, xc2 = 0.0;
     const bool td_on = h.td_on != 0;
@@ -1535,7 +1545,7 @@ UVS_DEV void backsub_candidate(const Ctx& c, const double* invd, const double* l
 
 UVS_DEV double ambient_sqnorm(const Ctx& c, const double* x, const double* invd, const double* line) {
     const DevWin& h = *c.hdr;
-    const int tid = threadIdx.x;
+    const int tid = lane_tid();
     double s = 0.0;
     if (tid < 176) s += x[tid] * x[tid];
     if (tid == 183 && h.td_on) s += x[183] * x[183];
@@ -1612,7 +1622,7 @@ UVS_DEV void imu_whiten_block(const double* cov, double* W, double* scr /* LDS, 
 
 UVS_DEV void setup_window(const Ctx& c, double* blob_rw, bool with_prior_image = true, int only_imu_frame = -1) {      // k_evaluate needs the IMU whitening only
     const DevWin& h = *c.hdr;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = lane_tid(), lane = tid & 63, wv = tid >> 6;
     for (int b = wv; b < h.n_imu; b += NW) {
         if (only_imu_frame >= 0 && c.bi[h.i_imu + 2 * b] != only_imu_frame) continue;      // marginalization: the one block that touches the departing frame
         double* blk = blob_rw + h.d_imu + (size_t)b * UVS_IMU_STRIDE;
@@ -1688,7 +1698,7 @@ struct DebugOut {   // optional dump of the first linearization (uvs_debug_linea
 __global__ __launch_bounds__(NT) void k_solve(char* blobs, const long long* blob_off, double* ws_all, const long long* ws_off,
                                               KOpts o, uvs_report* reports, DebugOut dbg) {
     extern __shared__ __attribute__((aligned(16))) double sh[];
-    const int tid = threadIdx.x, wdx = blockIdx.x;
+    const int tid = lane_tid(), wdx = blockIdx.x;
     char* blob = blobs + blob_off[wdx];
     Ctx c;
     c.hdr = (const DevWin*)blob; c.bd = (const double*)blob; c.bi = (const int*)blob; c.ws = ws_all + ws_off[wdx]; c.sh = sh; c.o = o;
