@@ -117,7 +117,10 @@ class Solver:
         wc, keep = w.to_c()
         st = abi.State(len(w.inv_depth), len(w.line_orth)); sc = st.alloc_c()
         rep = abi.Report()
-        self._check(lib().uvs_solve_window(self._h, C.byref(wc), C.byref(sc), C.byref(rep)), allow=(abi.UVS_OK, abi.UVS_ERR_NUMERIC))
+        t0 = time.perf_counter()
+        rc = lib().uvs_solve_window(self._h, C.byref(wc), C.byref(sc), C.byref(rep))
+        self.last_solve_ms = (time.perf_counter() - t0) * 1e3      # the C-ABI call alone: pack + H2D + kernel + D2H (what a C++ caller pays)
+        self._check(rc, allow=(abi.UVS_OK, abi.UVS_ERR_NUMERIC))
         return st.from_c(sc), rep
 
     # ---- batch of independent windows, device resident --------------------

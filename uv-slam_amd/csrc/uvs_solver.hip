@@ -40,12 +40,16 @@ struct uvs_solver {
     std::vector<DevWin> hdrs;                // host copies of the per-window headers
     std::vector<long long> blob_off, ws_off;
     std::vector<char> host_blobs;
+    // ONE host -> device copy per upload: [blobs | blob_off[n] | ws_off[n] | out_tab[3 n]] staged in pinned memory; the three tables
+    // live behind the blobs in the same device allocation (d_blob_off / d_ws_off / d_out_tab point into it)
     char* d_blobs = nullptr; size_t d_blobs_cap = 0;
+    char* h_up = nullptr; size_t h_up_cap = 0;            // pinned upload staging
     double* d_ws = nullptr; size_t d_ws_cap = 0;
-    long long* d_blob_off = nullptr; long long* d_ws_off = nullptr; size_t d_off_cap = 0;
-    // packed download: per window {source offset in d_ws, doubles, destination offset} -> one contiguous device buffer -> ONE copy
-    std::vector<long long> out_tab; long long* d_out_tab = nullptr; size_t d_out_tab_cap = 0; double* d_outpack = nullptr; size_t d_outpack_cap = 0; long long out_total = 0;
-    std::vector<double> h_outpack;
+    long long* d_blob_off = nullptr; long long* d_ws_off = nullptr;
+    // ONE device -> host copy per download: per window {source offset in d_ws, doubles, destination offset} -> k_pack_outputs gathers the
+    // final states AND the reports into one contiguous device buffer [states | reports[n]] -> pinned host buffer
+    std::vector<long long> out_tab; long long* d_out_tab = nullptr; double* d_outpack = nullptr; size_t d_outpack_cap = 0; long long out_total = 0;
+    char* h_out = nullptr; size_t h_out_cap = 0;          // pinned download staging
     uvs_report* d_reports = nullptr; size_t d_rep_cap = 0;
     double* d_dbg = nullptr;
     EvalScratch eval_scratch;                // uvs_evaluate / uvs_marginalize staging
@@ -163,12 +167,11 @@ void uvs_destroy(uvs_solver* s) {
     (void)hipSetDevice(s->device);      // teardown: nothing useful to do with an error
     if (s->d_blobs) (void)hipFree(s->d_blobs);
     if (s->d_ws) (void)hipFree(s->d_ws);
-    if (s->d_blob_off) (void)hipFree(s->d_blob_off);
-    if (s->d_ws_off) (void)hipFree(s->d_ws_off);
+    if (s->h_up) (void)hipHostFree(s->h_up);
+    if (s->h_out) (void)hipHostFree(s->h_out);
     uvs_large_comm_destroy(s);
     if (s->L.d_ctl) (void)hipFree(s->L.d_ctl);
     if (s->L.d_rep) (void)hipFree(s->L.d_rep);
-    if (s->d_out_tab) (void)hipFree(s->d_out_tab);
     if (s->d_outpack) (void)hipFree(s->d_outpack);
     if (s->d_reports) (void)hipFree(s->d_reports);
     if (s->d_dbg) (void)hipFree(s->d_dbg);
@@ -660,15 +663,28 @@ static int ensure(uvs_solver* s, void** p, size_t* cap, size_t need) {
     return UVS_OK;
 }
 
-// gathers the per-window outputs into one contiguous buffer: tab[3 b] = {source offset in ws, doubles, destination offset}
-__global__ void k_pack_outputs(const double* ws, const long long* tab, double* out) {
-    const long long src = tab[3 * blockIdx.x], cnt = tab[3 * blockIdx.x + 1], dst = tab[3 * blockIdx.x + 2];
-    for (long long t = threadIdx.x; t < cnt; t += blockDim.x) out[dst + t] = ws[src + t];
+static int ensure_pinned(uvs_solver* s, char** p, size_t* cap, size_t need) {      // grow-only (pinning costs milliseconds: never per call)
+    if (*cap >= need) return UVS_OK;
+    if (*p) (void)hipHostFree(*p);
+    *p = nullptr; *cap = 0;
+    const size_t want = need + need / 2 + 4096;
+    HIPCHK(s, hipHostMalloc((void**)p, want, hipHostMallocDefault));
+    *cap = want;
+    return UVS_OK;
 }
 
-extern "C" {
+// gathers the per-window outputs into one contiguous buffer: tab[3 b] = {source offset in ws, doubles, destination offset}; the reports
+// follow the states (rep_dst = offset of the report array in `out`, in doubles; sizeof(uvs_report) is a multiple of 8)
+static_assert(sizeof(uvs_report) % 8 == 0, "uvs_report is copied as doubles");
+__global__ void k_pack_outputs(const double* ws, const long long* tab, double* out, const uvs_report* reps, long long rep_dst) {
+    const long long src = tab[3 * blockIdx.x], cnt = tab[3 * blockIdx.x + 1], dst = tab[3 * blockIdx.x + 2];
+    for (long long t = threadIdx.x; t < cnt; t += blockDim.x) out[dst + t] = ws[src + t];
+    constexpr int RD = (int)(sizeof(uvs_report) / 8);
+    const double* r = (const double*)(reps + blockIdx.x);
+    for (int t = threadIdx.x; t < RD; t += blockDim.x) out[rep_dst + (long long)blockIdx.x * RD + t] = r[t];
+}
 
-int uvs_batch_upload(uvs_solver* s, int n, const uvs_window* const* ws) {
+static int upload_windows(uvs_solver* s, int n, const uvs_window* const* ws, bool wait) {
     if (!s || n < 1 || !ws) return UVS_ERR_INVALID_ARG;
     if (n > s->max_batch) { s->err = "batch larger than max_batch"; return UVS_ERR_CAPACITY; }
     HIPCHK(s, hipSetDevice(s->device));
@@ -717,24 +733,31 @@ int uvs_batch_upload(uvs_solver* s, int n, const uvs_window* const* ws) {
         s->out_total += cnt;
     }
     int rc;
-    if ((rc = ensure(s, (void**)&s->d_out_tab, &s->d_out_tab_cap, (size_t)n * 24)) != UVS_OK) return rc;
-    if ((rc = ensure(s, (void**)&s->d_outpack, &s->d_outpack_cap, (size_t)s->out_total * 8)) != UVS_OK) return rc;
-    HIPCHK(s, hipMemcpyAsync(s->d_out_tab, s->out_tab.data(), (size_t)n * 24, hipMemcpyHostToDevice, s->stream));
-    if ((rc = ensure(s, (void**)&s->d_blobs, &s->d_blobs_cap, s->host_blobs.size())) != UVS_OK) return rc;
-    if ((rc = ensure(s, (void**)&s->d_ws, &s->d_ws_cap, (size_t)wtot * 8)) != UVS_OK) return rc;
-    size_t offcap = s->d_off_cap;
-    if ((rc = ensure(s, (void**)&s->d_blob_off, &offcap, (size_t)n * 8)) != UVS_OK) return rc;
-    if ((rc = ensure(s, (void**)&s->d_ws_off, &s->d_off_cap, (size_t)n * 8)) != UVS_OK) return rc;
-    if ((rc = ensure(s, (void**)&s->d_reports, &s->d_rep_cap, (size_t)n * sizeof(uvs_report))) != UVS_OK) return rc;
-    HIPCHK(s, hipMemcpyAsync(s->d_blobs, s->host_blobs.data(), s->host_blobs.size(), hipMemcpyHostToDevice, s->stream));
-    HIPCHK(s, hipMemcpyAsync(s->d_blob_off, s->blob_off.data(), (size_t)n * 8, hipMemcpyHostToDevice, s->stream));
-    HIPCHK(s, hipMemcpyAsync(s->d_ws_off, s->ws_off.data(), (size_t)n * 8, hipMemcpyHostToDevice, s->stream));
+    const size_t blob_bytes = (s->host_blobs.size() + 7) & ~(size_t)7, up_bytes = blob_bytes + (size_t)n * 40;
+    // the staging buffer may still feed the previous upload's copy (the single-window path does not wait for it): drain before reuse
     HIPCHK(s, hipStreamSynchronize(s->stream));
+    if ((rc = ensure_pinned(s, &s->h_up, &s->h_up_cap, up_bytes)) != UVS_OK) return rc;
+    if ((rc = ensure(s, (void**)&s->d_blobs, &s->d_blobs_cap, up_bytes)) != UVS_OK) return rc;
+    if ((rc = ensure(s, (void**)&s->d_outpack, &s->d_outpack_cap, (size_t)s->out_total * 8 + (size_t)n * sizeof(uvs_report))) != UVS_OK) return rc;
+    if ((rc = ensure(s, (void**)&s->d_ws, &s->d_ws_cap, (size_t)wtot * 8)) != UVS_OK) return rc;
+    if ((rc = ensure(s, (void**)&s->d_reports, &s->d_rep_cap, (size_t)n * sizeof(uvs_report))) != UVS_OK) return rc;
+    std::memcpy(s->h_up, s->host_blobs.data(), s->host_blobs.size());
+    long long* tabs = (long long*)(s->h_up + blob_bytes);
+    std::memcpy(tabs, s->blob_off.data(), (size_t)n * 8);
+    std::memcpy(tabs + n, s->ws_off.data(), (size_t)n * 8);
+    std::memcpy(tabs + 2 * (size_t)n, s->out_tab.data(), (size_t)n * 24);
+    s->d_blob_off = (long long*)(s->d_blobs + blob_bytes); s->d_ws_off = s->d_blob_off + n; s->d_out_tab = s->d_blob_off + 2 * (size_t)n;
+    HIPCHK(s, hipMemcpyAsync(s->d_blobs, s->h_up, up_bytes, hipMemcpyHostToDevice, s->stream));
+    if (wait) HIPCHK(s, hipStreamSynchronize(s->stream));
     s->n_loaded = n;
     return UVS_OK;
 }
 
-static int launch_solve(uvs_solver* s, int debug, float* elapsed_ms) {
+extern "C" {
+
+int uvs_batch_upload(uvs_solver* s, int n, const uvs_window* const* ws) { return upload_windows(s, n, ws, true); }
+
+static int launch_solve(uvs_solver* s, int debug, float* elapsed_ms, bool wait = true) {
     if (s->n_loaded < 1) { s->err = "no batch uploaded"; return UVS_ERR_INVALID_ARG; }
     HIPCHK(s, hipSetDevice(s->device));
     KOpts ko = make_kopts(s->opts, debug);
@@ -747,6 +770,7 @@ static int launch_solve(uvs_solver* s, int debug, float* elapsed_ms) {
     hipLaunchKernelGGL(k_solve, dim3(s->n_loaded), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_blob_off, s->d_ws, s->d_ws_off, ko, s->d_reports, dbg);
     HIPCHK(s, hipGetLastError());
     HIPCHK(s, hipEventRecord(s->ev1, s->stream));
+    if (!wait) return UVS_OK;
     HIPCHK(s, hipStreamSynchronize(s->stream));
     if (elapsed_ms) HIPCHK(s, hipEventElapsedTime(elapsed_ms, s->ev0, s->ev1));
     return UVS_OK;
@@ -761,23 +785,22 @@ int uvs_batch_download(uvs_solver* s, int n, uvs_state* states, uvs_report* reps
     if (!s || n < 1 || n > s->n_loaded) return UVS_ERR_INVALID_ARG;
     HIPCHK(s, hipSetDevice(s->device));
     int worst = UVS_OK;
-    // reports: one copy for the whole batch; states: one small contiguous block per window (frames | inv_depth | line_orth, written by k_solve)
-    if (reps) {
-        HIPCHK(s, hipMemcpy(reps, s->d_reports, sizeof(uvs_report) * (size_t)n, hipMemcpyDeviceToHost));
-        for (int b = 0; b < n; ++b) if (reps[b].status != UVS_OK) worst = reps[b].status;
-    }
-    if (states) {
-        // every window's final state (frames | inv_depth | line_orth, written by k_solve into its workspace) is gathered on the device and
-        // fetched with ONE copy: 256 windows were 256 synchronous round trips before
-        hipLaunchKernelGGL(k_pack_outputs, dim3(n), dim3(256), 0, s->stream, s->d_ws, s->d_out_tab, s->d_outpack);
-        const size_t tot = (size_t)(s->out_tab[3 * (size_t)(n - 1) + 2] + s->out_tab[3 * (size_t)(n - 1) + 1]);
-        s->h_outpack.resize(tot);
-        HIPCHK(s, hipMemcpyAsync(s->h_outpack.data(), s->d_outpack, tot * 8, hipMemcpyDeviceToHost, s->stream));
-        HIPCHK(s, hipStreamSynchronize(s->stream));
-    }
+    // every window's final state (frames | inv_depth | line_orth, written by k_solve into its workspace) and its report are gathered on the
+    // device and fetched with ONE copy into pinned memory (256 windows were 256 synchronous round trips once)
+    const size_t nst = (size_t)(s->out_tab[3 * (size_t)(n - 1) + 2] + s->out_tab[3 * (size_t)(n - 1) + 1]);      // doubles of the first n states
+    const size_t tot = nst * 8 + (size_t)n * sizeof(uvs_report);
+    int rc;
+    if ((rc = ensure_pinned(s, &s->h_out, &s->h_out_cap, tot)) != UVS_OK) return rc;
+    hipLaunchKernelGGL(k_pack_outputs, dim3(n), dim3(256), 0, s->stream, s->d_ws, s->d_out_tab, s->d_outpack, s->d_reports, (long long)nst);
+    HIPCHK(s, hipGetLastError());
+    HIPCHK(s, hipMemcpyAsync(s->h_out, s->d_outpack, tot, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(s, hipStreamSynchronize(s->stream));
+    const uvs_report* hr = (const uvs_report*)(s->h_out + nst * 8);
+    for (int b = 0; b < n; ++b) if (hr[b].status != UVS_OK) worst = hr[b].status;
+    if (reps) std::memcpy(reps, hr, sizeof(uvs_report) * (size_t)n);
     for (int b = 0; states && b < n; ++b) {
         const DevWin& h = s->hdrs[b];
-        const double* buf = s->h_outpack.data() + s->out_tab[3 * (size_t)b + 2];
+        const double* buf = (const double*)s->h_out + s->out_tab[3 * (size_t)b + 2];
         uvs_state& st = states[b];
         std::memcpy(st.pose, buf, sizeof(double) * 77);
         std::memcpy(st.speedbias, buf + 77, sizeof(double) * 99);
@@ -793,9 +816,10 @@ int uvs_batch_download(uvs_solver* s, int n, uvs_state* states, uvs_report* reps
 int uvs_solve_window(uvs_solver* s, const uvs_window* w, uvs_state* out, uvs_report* rep) {
     if (!s || !w || !out || !rep) return UVS_ERR_INVALID_ARG;
     const uvs_window* arr[1] = {w};
-    int rc = uvs_batch_upload(s, 1, arr);
+    // one stream, one wait: pinned upload -> k_solve -> k_pack_outputs -> pinned download (uvs_batch_download synchronizes)
+    int rc = upload_windows(s, 1, arr, false);
     if (rc != UVS_OK) return rc;
-    rc = launch_solve(s, 0, nullptr);
+    rc = launch_solve(s, 0, nullptr, false);
     if (rc != UVS_OK) return rc;
     return uvs_batch_download(s, 1, out, rep);
 }
