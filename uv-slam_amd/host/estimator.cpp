@@ -1,6 +1,7 @@
 // estimator.cpp -- Estimator::optimization() / vector2double() / double2vector() with the reference's structure
 // (vins_estimator/src/estimator.cpp:526-711, 761-1233), the Ceres problem replaced by uvs::Problem and the
 // marginalization by uvs_marginalize().  See INTEGRATION.md for the diff a maintainer applies to the reference file.
+#include <chrono>
 #include "estimator.h"
 #include <cstdlib>
 #include <stdexcept>
@@ -131,7 +132,10 @@ void Estimator::setReloFrame(double stamp, int index, std::vector<Eigen::Vector3
     relocalization_info = true;
 }
 
+namespace { double ms_since(std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); } }
+
 void Estimator::optimization() {      // estimator.cpp:761-1233
+    const auto t_begin = std::chrono::steady_clock::now();
     uvs::AddressMap amap{para_Pose, para_SpeedBias, para_Ex_Pose, para_Feature, para_Ortho_plucker, para_Td, relo_Pose};
     uvs::Problem problem(amap);
     ceres_like::LossFunction* loss_function = new ceres_like::CauchyLoss(1.0);
@@ -215,7 +219,7 @@ void Estimator::optimization() {      // estimator.cpp:761-1233
         WindowFile::save(std::string(dump_dir) + name, dw, relo_frame_local_index);
     }
     uvs::Options options; options.max_num_iterations = NUM_ITERATIONS;
-    uvs::Solve(options, &problem, &last_summary, solver, feature_index + 1, line_feature_index + 1);
+    { const auto t0 = std::chrono::steady_clock::now(); uvs::Solve(options, &problem, &last_summary, solver, feature_index + 1, line_feature_index + 1); solve_ms += ms_since(t0); }
     // ---- marginalization on the post-solve para_* arrays, BEFORE double2vector() re-anchors the gauge: the reference calls
     // vector2double() again at :1004, i.e. it marginalizes at the re-anchored state; we follow it exactly below.
     double2vector();
@@ -225,7 +229,9 @@ void Estimator::optimization() {      // estimator.cpp:761-1233
         std::memcpy(w.pose, para_Pose, sizeof(w.pose)); std::memcpy(w.speedbias, para_SpeedBias, sizeof(w.speedbias));
         MarginalizationInfo* marginalization_info = new MarginalizationInfo();
         // the factors are the ones uvs::Solve() just uploaded; only the (re-anchored) state goes to the device again
+        const auto t0 = std::chrono::steady_clock::now();
         const int rc = uvs_marginalize_resident(solver, &w, marginalization_flag == MARGIN_OLD ? 0 : 1, &marginalization_info->prior);
+        marginalize_ms += ms_since(t0);
         delete last_marginalization_info;
         last_marginalization_info = marginalization_info;
         if (rc != UVS_OK) {      // the reference has no error path here; an un-shifted old prior would attach to the wrong frames, so the prior is dropped
@@ -238,6 +244,7 @@ void Estimator::optimization() {      // estimator.cpp:761-1233
     if (problem.ln_lm.empty()) delete line_loss_function;
     bool any_vp = false; for (int v : problem.ln_has_vp) any_vp |= (v != 0);
     if (!any_vp) delete vp_loss_function;
+    optimization_ms += ms_since(t_begin); ++optimization_calls;
 }
 
 // ====================================================================== per-frame state machine (post-initialization part)

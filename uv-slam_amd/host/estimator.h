@@ -85,4 +85,6 @@ class Estimator {
     // the reference keeps a vector<double*> of the prior's parameter blocks; here the block table lives inside uvs_prior
     uvs_solver* solver;          // HIP back-end handle (created in the constructor; throws when no GPU is present)
     uvs::Summary last_summary;   // kept for diagnostics (the reference discards ceres::Solver::Summary)
+    // wall-clock spent inside optimization() (sums over the calls): whole call, uvs::Solve() alone, marginalization alone
+    double optimization_ms = 0, solve_ms = 0, marginalize_ms = 0; int optimization_calls = 0;
 };

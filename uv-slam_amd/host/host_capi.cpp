@@ -178,6 +178,11 @@ extern "C" int uvs_host_triangulate(const double* poses, const double* ex, int n
 //   stamp, n_imu, n_imu x (dt, acc[3], gyr[3]), n_pts, n_pts x (id, x, y, z, u, v, vx, vy), n_lines, n_lines x (id, 15 values of the line message)
 // Output (float64): n_rows, then per frame processed after initialization 24 values:
 //   frame, marginalization_flag, Ps[W](3), q(Rs[W]) xyzw(4), Vs[W](3), Bas[W](3), Bgs[W](3), initial cost, final cost, iterations, points, lines, status
+// timing of the last uvs_host_replay_sequence(): mean milliseconds per Estimator::optimization() call -- {whole call, uvs::Solve alone
+// (packing + H2D + k_solve + D2H), marginalization alone, number of calls}
+static double g_replay_timing[4] = {0, 0, 0, 0};
+extern "C" void uvs_host_replay_timing(double* out4) { for (int k = 0; k < 4; ++k) out4[k] = g_replay_timing[k]; }
+
 extern "C" int uvs_host_replay_sequence(const char* in_path, const char* out_path) {
     FILE* f = std::fopen(in_path, "rb");
     if (!f) return -1;
@@ -233,6 +238,8 @@ extern "C" int uvs_host_replay_sequence(const char* in_path, const char* out_pat
                                     (double)est.f_manager.getFeatureCount(), (double)est.f_manager.getLineFeatureCount(), (double)est.last_summary.status};
             out.insert(out.end(), row, row + 24);
         }
+        const double nc = est.optimization_calls > 0 ? est.optimization_calls : 1;
+        g_replay_timing[0] = est.optimization_ms / nc; g_replay_timing[1] = est.solve_ms / nc; g_replay_timing[2] = est.marginalize_ms / nc; g_replay_timing[3] = est.optimization_calls;
     } catch (const std::exception& e) { std::fprintf(stderr, "uvs_host_replay_sequence: %s\n", e.what()); return -10; }
     FILE* g = std::fopen(out_path, "wb");
     if (!g) return -5;
