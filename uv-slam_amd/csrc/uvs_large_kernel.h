@@ -34,7 +34,7 @@ struct LargeCtl { const double* ctl; int rank, nranks; };      // ctl == nullptr
 
 __global__ __launch_bounds__(NT) void k_large_chunks(char* blob, double* ws, KOpts o, const double* state, int sel, int first, double radius, double* partials, LargeCtl lc) {
     extern __shared__ __attribute__((aligned(16))) double sh[];
-    const int tid = threadIdx.x, ch = blockIdx.x;
+    const int tid = threadIdx.x;
     if (lc.ctl) { if (lc.ctl[LC_DONE] != 0.0) return; sel = (int)lc.ctl[LC_SEL]; first = (int)lc.ctl[LC_FIRST]; radius = lc.ctl[LC_RADIUS]; }
     Ctx c; c.hdr = (const DevWin*)blob; c.bd = (const double*)blob; c.bi = (const int*)blob; c.ws = ws; c.sh = sh; c.o = o; c.o.debug = 0;
     const DevWin& h = *c.hdr;
@@ -46,7 +46,9 @@ __global__ __launch_bounds__(NT) void k_large_chunks(char* blob, double* ws, KOp
     GAcc A; gacc_zero(A);
     lacc_set(sh, 0.0, 0.0);
     const double* invd = ws + (sel ? h.w_invd1 : h.w_invd0); const double* line = ws + (sel ? h.w_line1 : h.w_line0);
-    lin_chunk(c, ch, sh + L_X, invd, line, first != 0, radius, grp, A);
+    // PERSISTENT workgroups: workgroup b takes chunks b, b + gridDim.x, ... and accumulates them into ONE partial (the host sizes the chunks so
+    // that their number is a multiple of the grid: 340 LDS-filling chunks on 256 CUs were two full rounds for 1.33 rounds of work)
+    for (int ch = blockIdx.x; ch < h.n_chunks; ch += gridDim.x) lin_chunk(c, ch, sh + L_X, invd, line, first != 0, radius, grp, A);
     double cost = lacc_cost(sh), gmax = lacc_gmax(sh);
     // canonical partial [pose block][row a][8] (6 block entries, gradient, diag(J^T J)), staged in LDS so that the two halves of a
     // split block are summed in a fixed order and the HBM write is coalesced
@@ -70,7 +72,7 @@ __global__ __launch_bounds__(NT) void k_large_chunks(char* blob, double* ws, KOp
         }
         __syncthreads();
     }
-    double* P = partials + (size_t)ch * LG_RED;
+    double* P = partials + (size_t)blockIdx.x * LG_RED;
     for (int i = tid; i < LG_ACC; i += NT) P[i] = sh[L_S + i];
     double s4[4] = {cost, 0, 0, 0};
     block_reduce(sh, s4, &gmax);
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(NT) void k_large_solve(char* blob, double* ws, KOpt
 // per chunk: landmark back-substitution (candidate parameters into the other buffer) + candidate cost of the chunk's observations
 __global__ __launch_bounds__(NT) void k_large_backsub(char* blob, double* ws, KOpts o, const double* state, int sel, double* bsums, LargeCtl lc) {
     extern __shared__ __attribute__((aligned(16))) double sh[];
-    const int tid = threadIdx.x, ch = blockIdx.x;
+    const int tid = threadIdx.x;
     if (lc.ctl) { if (lc.ctl[LC_DONE] != 0.0) return; sel = (int)lc.ctl[LC_SEL]; }
     Ctx c; c.hdr = (const DevWin*)blob; c.bd = (const double*)blob; c.bi = (const int*)blob; c.ws = ws; c.sh = sh; c.o = o; c.o.debug = 0;
     const DevWin& h = *c.hdr;
@@ -165,22 +167,23 @@ __global__ __launch_bounds__(NT) void k_large_backsub(char* blob, double* ws, KO
     if (tid < UVS_RD) sh[L_DLT + tid] = state[LS_DLT + tid];
     __syncthreads();
     stage_rotations(c, sh + L_XC);
-    const int* chunk = c.bi + h.i_chunks + 6 * ch;
-    const int type = chunk[0], k0 = chunk[1], k1 = chunk[2];
     double* invd = ws + (sel ? h.w_invd1 : h.w_invd0); double* line = ws + (sel ? h.w_line1 : h.w_line0);
     double* invd_c = ws + (sel ? h.w_invd0 : h.w_invd1); double* line_c = ws + (sel ? h.w_line0 : h.w_line1);
-    double* out = bsums + 8 * (size_t)ch;
-    backsub_candidate(c, invd, line, invd_c, line_c, type == 0 ? k0 : 0, type == 0 ? k1 : 0, type == 1 ? k0 : 0, type == 1 ? k1 : 0, false, out);
-    __threadfence_block();
-    __syncthreads();
     const int* pbeg = c.bi + h.i_pt_beg; const int* lbeg = c.bi + h.i_ln_beg;
-    const int po0 = type == 0 ? pbeg[k0] : 0, po1 = type == 0 ? pbeg[k1] : 0, lo0 = type == 1 ? lbeg[k0] : 0, lo1 = type == 1 ? lbeg[k1] : 0;
-    double cc = cost_pass(c, sh + L_XC, invd_c, line_c, po0, po1, lo0, lo1, false);
-    double s4[4] = {cc, 0, 0, 0}, mx = 0.0;
-    block_reduce(sh, s4, &mx);
-    if (tid == 0) out[4] = s4[0];
+    for (int ch = blockIdx.x; ch < h.n_chunks; ch += gridDim.x) {      // persistent workgroups, as in k_large_chunks; the sums stay per chunk (8 doubles)
+        const int* chunk = c.bi + h.i_chunks + 6 * ch;
+        const int type = chunk[0], k0 = chunk[1], k1 = chunk[2];
+        double* out = bsums + 8 * (size_t)ch;
+        backsub_candidate(c, invd, line, invd_c, line_c, type == 0 ? k0 : 0, type == 0 ? k1 : 0, type == 1 ? k0 : 0, type == 1 ? k1 : 0, false, out);
+        __threadfence_block();
+        __syncthreads();
+        const int po0 = type == 0 ? pbeg[k0] : 0, po1 = type == 0 ? pbeg[k1] : 0, lo0 = type == 1 ? lbeg[k0] : 0, lo1 = type == 1 ? lbeg[k1] : 0;
+        double cc = cost_pass(c, sh + L_XC, invd_c, line_c, po0, po1, lo0, lo1, false);
+        double s4[4] = {cc, 0, 0, 0}, mx = 0.0;
+        block_reduce(sh, s4, &mx);
+        if (tid == 0) out[4] = s4[0];
+    }
 }
-
 __global__ __launch_bounds__(256) void k_large_sum_bsums(const double* bsums, int n_chunks, double* out5, LargeCtl lc) {
     if (lc.ctl && lc.ctl[LC_DONE] != 0.0) return;
     // 5 scalars x n_chunks: 32 contiguous chunk slices per scalar (8 lanes idle per slice row), slice sums added in slice order

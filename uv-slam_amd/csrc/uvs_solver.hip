@@ -32,6 +32,7 @@ struct uvs_solver {
     int device;
     int max_batch;
     int max_points = 0, max_point_obs = 0, max_lines = 0, max_line_obs = 0;      // per-window capacities promised at uvs_create
+    int n_cus = 256;                         // compute units of the device (grid of the persistent large-window kernels)
     hipStream_t stream;
     hipEvent_t ev0, ev1;
     std::string err;
@@ -65,6 +66,7 @@ struct uvs_solver {
         double* d_ctl = nullptr; uvs_report* d_rep = nullptr;   // fused loop: trust-region state and report on the device
         void* comm = nullptr; int rank = 0, nranks = 1;         // RCCL communicator owned by the handle (uvs_large_comm_init)
         double relo_pose_in[7] = {0, 0, 0, 0, 0, 0, 0};      // passes through to uvs_large_finish (this path takes no relocalization blocks)
+        int grid = 1;                                           // workgroups of k_large_chunks / k_large_backsub = partial rows (min(n_chunks, compute units))
     } L;
 };
 
@@ -88,7 +90,7 @@ static KOpts make_kopts(const uvs_options& o, int debug) {
 }
 
 struct DevWin;
-static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vector<char>& out, DevWin& hdr, std::string& err);
+static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vector<char>& out, DevWin& hdr, std::string& err, int chunk_grid = 0);
 
 extern "C" {
 
@@ -131,7 +133,8 @@ const char* uvs_last_error(const uvs_solver* s) { return s ? s->err.c_str() : "n
 int uvs_debug_pack_layout(const uvs_options* o, const uvs_window* w, int32_t* info) {
     if (!o || !w || !info) return UVS_ERR_INVALID_ARG;
     std::vector<char> blob; DevWin h; std::string err;
-    const int rc = pack_window(w, *o, blob, h, err);
+    const char* grid_env = std::getenv("UVS_DEBUG_CHUNK_GRID");      // CPU tests of the large-window chunking (uvs_large_begin passes the device's CU count)
+    const int rc = pack_window(w, *o, blob, h, err, grid_env ? std::atoi(grid_env) : 0);
     if (rc != UVS_OK) return rc;
     const int32_t v[12] = {h.blob_bytes, h.ws_doubles, h.n_chunks, h.n_pt_obs, h.n_relo, h.pt_rec, h.pt_xslots, h.max_chunk_doubles, UVS_S_DOUBLES, h.n_parts, h.n_cimg, h.n_pblk};
     std::memcpy(info, v, sizeof(v));
@@ -151,6 +154,7 @@ int uvs_create(const uvs_options* opts, int device, int max_batch, int max_point
     s->opts = *opts; s->device = device; s->max_batch = max_batch;
     s->max_points = max_points; s->max_point_obs = max_point_obs; s->max_lines = max_lines; s->max_line_obs = max_line_obs;
     if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&s->ev0) != hipSuccess || hipEventCreate(&s->ev1) != hipSuccess) { delete s; return UVS_ERR_HIP; }
+    { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) s->n_cus = cus; }
     // block table for the output-stationary gather
     unsigned char fa[UVS_NBLK], fb[UVS_NBLK];
     for (int i = 0, b = 0; i < UVS_NF; ++i) for (int j = 0; j <= i; ++j, ++b) { fa[b] = (unsigned char)i; fb[b] = (unsigned char)j; }
@@ -228,7 +232,10 @@ static int validate_window(const uvs_window* w, std::string& err) {
 }
 
 // appends the blob of `w` to `out` (8-byte aligned) and returns its header
-static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vector<char>& out, DevWin& hdr, std::string& err) {
+// chunk_grid > 0 (large-window path): the landmark chunks are made SMALLER than the LDS staging area allows so that their number is a
+// multiple of chunk_grid (the persistent workgroups of k_large_chunks / k_large_backsub then all carry the same number of chunks), or
+// -- a shard with few landmarks -- so that every compute unit gets one
+static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vector<char>& out, DevWin& hdr, std::string& err, int chunk_grid) {
     const bool prof_ = std::getenv("UVS_PACK_PROFILE") != nullptr;
     auto t_prev_ = std::chrono::steady_clock::now();
     auto lap_ = [&](const char* what) { if (prof_) { const auto n_ = std::chrono::steady_clock::now(); fprintf(stderr, "pack %-10s %.3f ms\n", what, std::chrono::duration<double, std::milli>(n_ - t_prev_).count()); t_prev_ = n_; } };
@@ -306,29 +313,52 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
         };
         // smallest number of chunks whose EVEN split (by observation count) fits; the kernel pays a fixed cost per chunk, so a
         // greedy fill that leaves a nearly empty last chunk would waste a whole pass
-        auto split = [&](int type, int n_lm, const std::vector<int>& beg, auto&& need) -> int {
+        // even split (by observation count) of a landmark family into n chunks; empty vector if some chunk does not fit the staging area
+        auto cuts_for = [&](int n, int n_lm, const std::vector<int>& beg, auto&& need) -> std::vector<int> {
+            std::vector<int> cut(1, 0);
+            const long tot = beg[n_lm];
+            for (int j = 1; j < n; ++j) {
+                int k = cut.back() + 1;
+                while (k < n_lm && (long)beg[k] * n < tot * j) ++k;
+                cut.push_back(std::min(k, n_lm - (n - j)));
+            }
+            cut.push_back(n_lm);
+            for (int j = 0; j < n; ++j) { const long nd = need(cut[j], cut[j + 1]); if (!(cut[j + 1] > cut[j] && nd >= 0 && nd <= UVS_S_DOUBLES)) return {}; }
+            return cut;
+        };
+        // smallest number of chunks >= n_from whose even split fits; the kernel pays a fixed cost per chunk, so a greedy fill that leaves a
+        // nearly empty last chunk would waste a whole pass
+        auto split = [&](int type, int n_lm, const std::vector<int>& beg, auto&& need, int n_from, std::vector<int>& cut) -> int {
+            cut.clear();
             if (n_lm == 0) return UVS_OK;
             // start at the capacity lower bound (records + Schur factors alone; the lists come on top): walking n = 1, 2, ... costs
             // O(n * landmarks) per attempt, milliseconds for the 340 chunks of configs[3]
             const long mine = type == 0 ? (long)PREC * h.n_pt_obs + 12L * (h.n_pt_obs + XS * h.n_points) : (long)(UVS_LN_REC + 48) * h.n_ln_obs + 20L * h.n_lines;
-            const int n_first = (int)std::min<long>(n_lm, std::max<long>(1, mine / UVS_S_DOUBLES));
-            for (int n = n_first; n <= n_lm; ++n) {
-                std::vector<int> cut(1, 0);
-                const long tot = beg[n_lm];
-                for (int j = 1; j < n; ++j) {
-                    int k = cut.back() + 1;
-                    while (k < n_lm && (long)beg[k] * n < tot * j) ++k;
-                    cut.push_back(std::min(k, n_lm - (n - j)));
-                }
-                cut.push_back(n_lm);
-                bool ok = true;
-                for (int j = 0; j < n && ok; ++j) { const long nd = need(cut[j], cut[j + 1]); ok = cut[j + 1] > cut[j] && nd >= 0 && nd <= UVS_S_DOUBLES; }
-                if (ok) { for (int j = 0; j < n; ++j) chunks.insert(chunks.end(), {type, cut[j], cut[j + 1], 0, 0, 0}); return UVS_OK; }
-            }
+            const int n_first = (int)std::min<long>(n_lm, std::max<long>(std::max(1, n_from), mine / UVS_S_DOUBLES));
+            for (int n = n_first; n <= n_lm; ++n) { cut = cuts_for(n, n_lm, beg, need); if (!cut.empty()) return UVS_OK; }
             return UVS_ERR_CAPACITY;
         };
-        if (split(0, h.n_points, pbeg, need_pt) != UVS_OK) { err = "single point landmark exceeds LDS staging"; return UVS_ERR_CAPACITY; }
-        if (split(1, h.n_lines, lbeg, need_ln) != UVS_OK) { err = "single line landmark exceeds LDS staging"; return UVS_ERR_CAPACITY; }
+        std::vector<int> cut_pt, cut_ln;
+        if (split(0, h.n_points, pbeg, need_pt, 1, cut_pt) != UVS_OK) { err = "single point landmark exceeds LDS staging"; return UVS_ERR_CAPACITY; }
+        if (split(1, h.n_lines, lbeg, need_ln, 1, cut_ln) != UVS_OK) { err = "single line landmark exceeds LDS staging"; return UVS_ERR_CAPACITY; }
+        if (chunk_grid > 0) {
+            const int n_pt = cut_pt.empty() ? 0 : (int)cut_pt.size() - 1, n_ln = cut_ln.empty() ? 0 : (int)cut_ln.size() - 1, n_min = n_pt + n_ln;
+            // work per family ~ its staging volume; a chunk should keep at least ~64 observations (its fixed cost is a few microseconds)
+            const double w_pt = (double)PREC * h.n_pt_obs + 12.0 * (h.n_pt_obs + XS * h.n_points), w_ln = (double)(UVS_LN_REC + 48) * h.n_ln_obs + 20.0 * h.n_lines;
+            const long by_size = (long)(h.n_pt_obs + h.n_ln_obs) / 64;
+            long target = n_min >= chunk_grid ? (long)((n_min + chunk_grid - 1) / chunk_grid) * chunk_grid : std::min<long>(chunk_grid, std::max<long>(n_min, by_size));
+            if (target > n_min && w_pt + w_ln > 0.0) {
+                int t_pt = (int)std::lround(target * w_pt / (w_pt + w_ln));
+                t_pt = std::max(n_pt, std::min(t_pt, (int)target - n_ln));
+                int t_ln = (int)target - t_pt;
+                t_pt = std::min(t_pt, h.n_points); t_ln = std::min(t_ln, h.n_lines);
+                std::vector<int> c2;
+                if (t_pt > n_pt && split(0, h.n_points, pbeg, need_pt, t_pt, c2) == UVS_OK) cut_pt = c2;
+                if (t_ln > n_ln && split(1, h.n_lines, lbeg, need_ln, t_ln, c2) == UVS_OK) cut_ln = c2;
+            }
+        }
+        for (size_t j = 0; j + 1 < cut_pt.size(); ++j) chunks.insert(chunks.end(), {0, cut_pt[j], cut_pt[j + 1], 0, 0, 0});
+        for (size_t j = 0; j + 1 < cut_ln.size(); ++j) chunks.insert(chunks.end(), {1, cut_ln[j], cut_ln[j + 1], 0, 0, 0});
     }
     lap_("split");
     // gather lists per chunk and per lower 6x6 pose block (see uvs_solve_kernel.h: gather_points / gather_lines),
@@ -684,7 +714,7 @@ __global__ void k_pack_outputs(const double* ws, const long long* tab, double* o
     for (int t = threadIdx.x; t < RD; t += blockDim.x) out[rep_dst + (long long)blockIdx.x * RD + t] = r[t];
 }
 
-static int upload_windows(uvs_solver* s, int n, const uvs_window* const* ws, bool wait) {
+static int upload_windows(uvs_solver* s, int n, const uvs_window* const* ws, bool wait, int chunk_grid = 0) {
     if (!s || n < 1 || !ws) return UVS_ERR_INVALID_ARG;
     if (n > s->max_batch) { s->err = "batch larger than max_batch"; return UVS_ERR_CAPACITY; }
     HIPCHK(s, hipSetDevice(s->device));
@@ -706,7 +736,7 @@ static int upload_windows(uvs_solver* s, int n, const uvs_window* const* ws, boo
     if (nthreads == 1) {
         for (int b = 0; b < n; ++b) {
             s->blob_off[b] = (long long)s->host_blobs.size();
-            int rc = pack_window(ws[b], s->opts, s->host_blobs, s->hdrs[b], s->err);
+            int rc = pack_window(ws[b], s->opts, s->host_blobs, s->hdrs[b], s->err, chunk_grid);
             if (rc != UVS_OK) { s->n_loaded = 0; return rc; }
         }
     } else {
@@ -714,7 +744,7 @@ static int upload_windows(uvs_solver* s, int n, const uvs_window* const* ws, boo
         std::vector<int> rcs(n, UVS_OK); std::vector<std::string> errs(n);
         std::vector<std::thread> pool;
         for (int t = 0; t < nthreads; ++t)
-            pool.emplace_back([&, t] { for (int b = t; b < n; b += nthreads) rcs[b] = pack_window(ws[b], s->opts, parts[b], s->hdrs[b], errs[b]); });
+            pool.emplace_back([&, t] { for (int b = t; b < n; b += nthreads) rcs[b] = pack_window(ws[b], s->opts, parts[b], s->hdrs[b], errs[b], chunk_grid); });
         for (auto& th : pool) th.join();
         size_t total = 0;
         for (int b = 0; b < n; ++b) {
@@ -894,16 +924,17 @@ int uvs_large_begin(uvs_solver* s, const uvs_window* w) {
     if (!s || !w) return UVS_ERR_INVALID_ARG;
     if (w->n_relo_obs > 0) { s->err = "relocalization blocks are not taken by the large-window path"; return UVS_ERR_UNSUPPORTED; }
     const uvs_window* arr[1] = {w};
-    int rc = uvs_batch_upload(s, 1, arr);
+    int rc = upload_windows(s, 1, arr, true, s->n_cus);
     if (rc != UVS_OK) return rc;
     auto& L = s->L; const DevWin& h = s->hdrs[0];
     double* keep_ctl = L.d_ctl; uvs_report* keep_rep = L.d_rep; void* keep_comm = L.comm; const int keep_rank = L.rank, keep_nranks = L.nranks;
     L = uvs_solver::Large{L.active, 0, 0, 0, 0, 0, 0, 0, 0, true, true, false, 0, 2, 0, 0, 0, 0, L.d_state, L.d_partials, L.d_reduced, L.d_bsums, L.d_out, L.d_sc5, L.cap_partials, L.cap_bsums, {}};
     L.active = true; L.n_chunks = h.n_chunks; L.radius = s->opts.initial_trust_region_radius;
+    L.grid = std::max(1, std::min(h.n_chunks, s->n_cus));
     L.d_ctl = keep_ctl; L.d_rep = keep_rep; L.comm = keep_comm; L.rank = keep_rank; L.nranks = keep_nranks;
     if (!L.d_state) { HIPCHK(s, hipMalloc((void**)&L.d_state, LG_STATE * 8)); HIPCHK(s, hipMalloc((void**)&L.d_reduced, LG_XCH * 8)); HIPCHK(s, hipMemset(L.d_reduced, 0, LG_XCH * 8)); HIPCHK(s, hipMalloc((void**)&L.d_out, 64 * 8)); HIPCHK(s, hipMalloc((void**)&L.d_sc5, 8 * 8)); }
     int r2;
-    if ((r2 = ensure(s, (void**)&L.d_partials, &L.cap_partials, (size_t)std::max(L.n_chunks, 1) * LG_RED * 8)) != UVS_OK) return r2;
+    if ((r2 = ensure(s, (void**)&L.d_partials, &L.cap_partials, (size_t)L.grid * LG_RED * 8)) != UVS_OK) return r2;
     if ((r2 = ensure(s, (void**)&L.d_bsums, &L.cap_bsums, (size_t)std::max(L.n_chunks, 1) * 8 * 8)) != UVS_OK) return r2;
     HIPCHK(s, hipMemsetAsync(L.d_state, 0, LG_STATE * 8, s->stream));
     // frames -> state.X ; landmark parameters -> workspace buffer 0 (device-to-device from the blob)
@@ -947,8 +978,8 @@ int uvs_large_linearize(uvs_solver* s) {
     auto& L = s->L;
     HIPCHK(s, hipSetDevice(s->device));
     KOpts ko = make_kopts(s->opts, 0);
-    if (L.n_chunks > 0) hipLaunchKernelGGL(k_large_chunks, dim3(L.n_chunks), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, L.sel, L.first ? 1 : 0, L.radius, L.d_partials, LargeCtl{nullptr, 0, 0});
-    hipLaunchKernelGGL(k_large_reduce, dim3((LG_RED + 15) / 16), dim3(256), 0, s->stream, L.d_partials, L.n_chunks, L.d_reduced, LargeCtl{nullptr, 0, 0});
+    if (L.n_chunks > 0) hipLaunchKernelGGL(k_large_chunks, dim3(L.grid), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, L.sel, L.first ? 1 : 0, L.radius, L.d_partials, LargeCtl{nullptr, 0, 0});
+    hipLaunchKernelGGL(k_large_reduce, dim3((LG_RED + 15) / 16), dim3(256), 0, s->stream, L.d_partials, L.n_chunks > 0 ? L.grid : 0, L.d_reduced, LargeCtl{nullptr, 0, 0});
     HIPCHK(s, hipGetLastError());
     HIPCHK(s, hipStreamSynchronize(s->stream));
     return UVS_OK;
@@ -960,7 +991,7 @@ int uvs_large_step(uvs_solver* s) {
     HIPCHK(s, hipSetDevice(s->device));
     KOpts ko = make_kopts(s->opts, 0);
     hipLaunchKernelGGL(k_large_solve, dim3(1), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, L.d_reduced, L.first ? 1 : 0, L.radius, L.d_out, LargeCtl{nullptr, 0, 0});
-    if (L.n_chunks > 0) hipLaunchKernelGGL(k_large_backsub, dim3(L.n_chunks), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, L.sel, L.d_bsums, LargeCtl{nullptr, 0, 0});
+    if (L.n_chunks > 0) hipLaunchKernelGGL(k_large_backsub, dim3(L.grid), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, L.sel, L.d_bsums, LargeCtl{nullptr, 0, 0});
     hipLaunchKernelGGL(k_large_sum_bsums, dim3(1), dim3(256), 0, s->stream, L.d_bsums, L.n_chunks, L.d_sc5, LargeCtl{nullptr, 0, 0});
     HIPCHK(s, hipGetLastError());
     HIPCHK(s, hipStreamSynchronize(s->stream));
@@ -1136,11 +1167,11 @@ int uvs_large_solve_fused(uvs_solver* s, const uvs_window* w, uvs_state* out, uv
     const int passes = std::max(1, o.max_num_iterations);
     HIPCHK(s, hipEventRecord(s->ev0, s->stream));
     for (int p = 0; p < passes; ++p) {
-        if (L.n_chunks > 0) hipLaunchKernelGGL(k_large_chunks, dim3(L.n_chunks), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, 0, 0, 0.0, L.d_partials, lc);
-        hipLaunchKernelGGL(k_large_reduce, dim3((LG_RED + 15) / 16), dim3(256), 0, s->stream, L.d_partials, L.n_chunks, L.d_reduced, lc);
+        if (L.n_chunks > 0) hipLaunchKernelGGL(k_large_chunks, dim3(L.grid), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, 0, 0, 0.0, L.d_partials, lc);
+        hipLaunchKernelGGL(k_large_reduce, dim3((LG_RED + 15) / 16), dim3(256), 0, s->stream, L.d_partials, L.n_chunks > 0 ? L.grid : 0, L.d_reduced, lc);
         if (L.comm) { const int e = r.AllReduce(L.d_reduced, L.d_reduced, LG_XCH, kNcclDouble, kNcclSum, L.comm, s->stream); if (e != 0) { s->err = "ncclAllReduce failed"; return UVS_ERR_HIP; } }
         hipLaunchKernelGGL(k_large_solve, dim3(1), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, L.d_reduced, 0, 0.0, L.d_out, lc);
-        if (L.n_chunks > 0) hipLaunchKernelGGL(k_large_backsub, dim3(L.n_chunks), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, 0, L.d_bsums, lc);
+        if (L.n_chunks > 0) hipLaunchKernelGGL(k_large_backsub, dim3(L.grid), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, 0, L.d_bsums, lc);
         hipLaunchKernelGGL(k_large_sum_bsums, dim3(1), dim3(256), 0, s->stream, L.d_bsums, L.n_chunks, L.d_sc5, lc);
         if (L.comm) { const int e = r.AllReduce(L.d_sc5, L.d_sc5, 8, kNcclDouble, kNcclSum, L.comm, s->stream); if (e != 0) { s->err = "ncclAllReduce failed"; return UVS_ERR_HIP; } }
         hipLaunchKernelGGL(k_large_decide, dim3(1), dim3(256), 0, s->stream, L.d_ctl, L.d_state, L.d_out, L.d_sc5, L.d_reduced, ko, L.d_rep);
