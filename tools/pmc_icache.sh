@@ -15,14 +15,15 @@ done
 cd $R
 python - <<'PY'
 import csv, glob, collections
+# the bench command launches k_solve both on the batch (grid = 256 x batch threads) and on one resident window (grid = 256): split by grid size
 for B in (256, 1):
     for d in sorted(glob.glob(f"gpurun_out/pmci_{B}_*/")):
         f = glob.glob(d + "**/*counter_collection.csv", recursive=True)
         if not f: print(d, "no csv"); continue
         acc = collections.defaultdict(list)
         for r in csv.DictReader(open(f[0])):
-            if "k_solve" in r["Kernel_Name"]: acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
-        for k, v in acc.items():
-            # per dispatch: sum over the rows of one dispatch is already done by rocprofv3 (one row per counter per dispatch)
-            print(f"batch {B:3d}  {k:36s} mean/launch {sum(v)/len(v):16.1f}  launches {len(v)}")
+            if "k_solve" in r["Kernel_Name"]: acc[(int(r["Grid_Size"]) // 256, r["Counter_Name"])].append(float(r["Counter_Value"]))
+        for (wgs, k), v in sorted(acc.items()):
+            if B == 256 and wgs != 256: continue      # the single-window launches of this run are covered by the batch-1 run
+            print(f"workgroups {wgs:4d}  {k:36s} mean/launch {sum(v)/len(v):16.1f}  launches {len(v)}")
 PY
