@@ -293,7 +293,7 @@ def main():
                                    "single window (configs[1]) in single_window, the 20k-point window (configs[3]) in large_window",
                        "windows_per_gpu": args.batch, "frames": 11, "points": 150, "lines": 40, "vp_tagged_lines": 30,
                        "prior": (not args.no_prior), "max_lm_iterations": 10, "parallelism": f"replicas x{world}"},
-            "lm_iterations_mean": float(its.mean()), "final_cost_mean": float(np.mean([r.final_cost for r in reps])),
+            "lm_iterations_mean": float(its.mean()), "lm_successful_steps_mean": float(np.mean([r.num_successful for r in reps])), "final_cost_mean": float(np.mean([r.final_cost for r in reps])),
             "batch_pack_upload_ms": pack_upload_ms,
             "single_window": single, "single_window_ms": sw_ms, "single_window_solves_per_s": 1e3 / sw_ms, "single_window_pcie_inclusive_ms": pcie * 1e3,
             "replay": replay, "large_window": large, "roofline": roofline, "cpu_baseline": cpu,
