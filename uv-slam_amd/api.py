@@ -227,7 +227,10 @@ class Solver:
         wc, keep = w.to_c()
         st = abi.State(len(w.inv_depth), len(w.line_orth)); sc = st.alloc_c()
         rep = abi.Report(); ms = C.c_float(0.0)
-        self._check(lib().uvs_large_solve_fused(self._h, C.byref(wc), C.byref(sc), C.byref(rep), C.byref(ms)), allow=(abi.UVS_OK, abi.UVS_ERR_NUMERIC))
+        t0 = time.perf_counter()
+        rc = lib().uvs_large_solve_fused(self._h, C.byref(wc), C.byref(sc), C.byref(rep), C.byref(ms))
+        self.last_solve_ms = (time.perf_counter() - t0) * 1e3      # the C-ABI call alone: pack + H2D + LM loop + D2H
+        self._check(rc, allow=(abi.UVS_OK, abi.UVS_ERR_NUMERIC))
         return st.from_c(sc), rep, float(ms.value)
 
     # ---- diagnostics -------------------------------------------------------

@@ -109,9 +109,9 @@ __global__ __launch_bounds__(256) void k_large_reduce(const double* partials, in
 __global__ __launch_bounds__(NT) void k_large_solve(char* blob, double* ws, KOpts o, double* state, const double* reduced, int first, double radius, double* out, LargeCtl lc) {
     extern __shared__ __attribute__((aligned(16))) double sh[];
     const int tid = threadIdx.x;
+    if (lc.ctl && lc.ctl[LC_DONE] != 0.0) return;
     double gmax_lm = reduced[LG_ACC + 1];
     if (lc.ctl) {
-        if (lc.ctl[LC_DONE] != 0.0) return;
         first = (int)lc.ctl[LC_FIRST]; radius = lc.ctl[LC_RADIUS];
         gmax_lm = 0.0;
         for (int r = 0; r < LG_MAXRANKS; ++r) gmax_lm = fmax(gmax_lm, reduced[LX_GMAX + r]);
@@ -200,10 +200,25 @@ __global__ __launch_bounds__(256) void k_large_sum_bsums(const double* bsums, in
 // The trust-region bookkeeping of one iteration ON THE DEVICE (same order of tests as k_solve / uvs_large_decide / SURVEY.md Appendix B):
 // reads the frame part (out[LO_*], identical on every rank) and the all-reduced landmark scalars sc5 = {g.delta, delta D delta, |delta|^2,
 // |x_c|^2, candidate cost}, updates ctl / the report and, on acceptance, x <- x_c.  One workgroup; every rank runs it on identical inputs.
-__global__ __launch_bounds__(256) void k_large_decide(double* ctl, double* state, const double* out, const double* sc5, const double* reduced, KOpts o, uvs_report* rep) {
+// `bsums` != nullptr (fused loop without a communicator): the 5 landmark scalars are summed here, in k_large_sum_bsums' order, instead of by a launch of their own.
+__global__ __launch_bounds__(256) void k_large_decide(double* ctl, double* state, const double* out, const double* sc5_in, const double* reduced, KOpts o, uvs_report* rep,
+                                                      const double* bsums, int n_rows) {
     __shared__ int accept_sh;
+    __shared__ double part[32][8];
+    __shared__ double sc5_sh[8];
     const int tid = threadIdx.x;
     if (ctl[LC_DONE] != 0.0) return;
+    if (bsums) {
+        const int i = tid & 7, p = tid >> 3;
+        const int per = (n_rows + 31) / 32, c0 = p * per, c1 = (c0 + per < n_rows) ? c0 + per : n_rows;
+        double sl = 0.0;
+        if (i < 5) for (int ch = c0; ch < c1; ++ch) sl += bsums[8 * (size_t)ch + i];
+        part[p][i] = sl;
+        __syncthreads();
+        if (p == 0 && i < 5) { double t = part[0][i]; for (int q = 1; q < 32; ++q) t += part[q][i]; sc5_sh[i] = t; }
+    } else if (tid < 5) sc5_sh[tid] = sc5_in[tid];
+    __syncthreads();
+    const double* sc5 = sc5_sh;
     if (tid == 0) {
         accept_sh = 0;
         double radius = ctl[LC_RADIUS], decr = ctl[LC_DECR], cost = ctl[LC_COST], gmax = ctl[LC_GMAX], x_norm = ctl[LC_XNORM];
@@ -268,6 +283,34 @@ __global__ __launch_bounds__(256) void k_large_decide(double* ctl, double* state
     }
     __syncthreads();
     if (accept_sh && tid < 184) state[LS_X + tid] = state[LS_XC + tid];
+}
+
+// Start of a fused solve, on the device: state <- frames of the blob, landmark buffers 0 <- blob, control words and report reset.  Replaces five
+// small host-side copies / memsets (each a separate stream operation) by one launch.
+__global__ __launch_bounds__(256) void k_large_init(const char* blob, double* ws, double* state, double* ctl, uvs_report* rep, double* reduced,
+                                                    double radius0, double frame_x2, double local_x2) {
+    const DevWin& h = *(const DevWin*)blob; const double* bd = (const double*)blob;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
+    for (int i = t; i < LG_STATE; i += nt) state[i] = (i >= LS_X && i < LS_X + 184) ? bd[h.d_frames + (i - LS_X)] : 0.0;
+    for (int i = t; i < h.n_points; i += nt) ws[h.w_invd0 + i] = bd[h.d_invd + i];
+    for (int i = t; i < 4 * h.n_lines; i += nt) ws[h.w_line0 + i] = bd[h.d_line + i];
+    for (int i = t; i < LG_XCH; i += nt) reduced[i] = (i == LX_X2) ? local_x2 : 0.0;
+    for (int i = t; i < 64; i += nt) ctl[i] = i == LC_RADIUS ? radius0 : i == LC_DECR ? 2.0 : i == LC_FIRST ? 1.0 : i == LC_FRAME_X2 ? frame_x2 : 0.0;
+    for (int i = t; i < (int)(sizeof(uvs_report) / 4); i += nt) ((int*)rep)[i] = 0;
+}
+// End of a fused solve: everything the host reads back, gathered into one buffer [ctl 64 | report | frames 184 | inverse depths | line parameters]
+// (the landmark buffer that holds the accepted values is only known on the device: ctl[LC_SEL])
+__global__ __launch_bounds__(256) void k_large_pack(const char* blob, const double* ws, const double* state, const double* ctl, const uvs_report* rep, double* out) {
+    const DevWin& h = *(const DevWin*)blob;
+    constexpr int RD = (int)(sizeof(uvs_report) / 8);
+    const int sel = (int)ctl[LC_SEL];
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
+    for (int i = t; i < 64; i += nt) out[i] = ctl[i];
+    for (int i = t; i < RD; i += nt) out[64 + i] = ((const double*)rep)[i];
+    for (int i = t; i < 184; i += nt) out[64 + RD + i] = state[LS_X + i];
+    double* o2 = out + 64 + RD + 184;
+    for (int i = t; i < h.n_points; i += nt) o2[i] = ws[(sel ? h.w_invd1 : h.w_invd0) + i];
+    for (int i = t; i < 4 * h.n_lines; i += nt) o2[h.n_points + i] = ws[(sel ? h.w_line1 : h.w_line0) + i];
 }
 
 }  // namespace uvsdev

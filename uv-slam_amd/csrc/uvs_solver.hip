@@ -766,18 +766,26 @@ static int upload_windows(uvs_solver* s, int n, const uvs_window* const* ws, boo
     const size_t blob_bytes = (s->host_blobs.size() + 7) & ~(size_t)7, up_bytes = blob_bytes + (size_t)n * 40;
     // the staging buffer may still feed the previous upload's copy (the single-window path does not wait for it): drain before reuse
     HIPCHK(s, hipStreamSynchronize(s->stream));
-    if ((rc = ensure_pinned(s, &s->h_up, &s->h_up_cap, up_bytes)) != UVS_OK) return rc;
+    if ((rc = ensure_pinned(s, &s->h_up, &s->h_up_cap, blob_bytes <= ((size_t)4 << 20) ? up_bytes : (size_t)n * 40)) != UVS_OK) return rc;
     if ((rc = ensure(s, (void**)&s->d_blobs, &s->d_blobs_cap, up_bytes)) != UVS_OK) return rc;
     if ((rc = ensure(s, (void**)&s->d_outpack, &s->d_outpack_cap, (size_t)s->out_total * 8 + (size_t)n * sizeof(uvs_report))) != UVS_OK) return rc;
     if ((rc = ensure(s, (void**)&s->d_ws, &s->d_ws_cap, (size_t)wtot * 8)) != UVS_OK) return rc;
     if ((rc = ensure(s, (void**)&s->d_reports, &s->d_rep_cap, (size_t)n * sizeof(uvs_report))) != UVS_OK) return rc;
-    std::memcpy(s->h_up, s->host_blobs.data(), s->host_blobs.size());
-    long long* tabs = (long long*)(s->h_up + blob_bytes);
+    // small uploads (the online single-window case) are staged in pinned memory together with their tables: ONE copy that the host need not wait
+    // for; a large blob (configs[3]: 20 MB) would pay a second pass over memory for it and goes from the pageable vector directly
+    const bool staged = blob_bytes <= ((size_t)4 << 20);
+    if (staged) std::memcpy(s->h_up, s->host_blobs.data(), s->host_blobs.size());
+    long long* tabs = (long long*)(s->h_up + (staged ? blob_bytes : 0));
     std::memcpy(tabs, s->blob_off.data(), (size_t)n * 8);
     std::memcpy(tabs + n, s->ws_off.data(), (size_t)n * 8);
     std::memcpy(tabs + 2 * (size_t)n, s->out_tab.data(), (size_t)n * 24);
     s->d_blob_off = (long long*)(s->d_blobs + blob_bytes); s->d_ws_off = s->d_blob_off + n; s->d_out_tab = s->d_blob_off + 2 * (size_t)n;
-    HIPCHK(s, hipMemcpyAsync(s->d_blobs, s->h_up, up_bytes, hipMemcpyHostToDevice, s->stream));
+    if (staged) HIPCHK(s, hipMemcpyAsync(s->d_blobs, s->h_up, up_bytes, hipMemcpyHostToDevice, s->stream));
+    else {
+        HIPCHK(s, hipMemcpyAsync(s->d_blobs, s->host_blobs.data(), s->host_blobs.size(), hipMemcpyHostToDevice, s->stream));
+        HIPCHK(s, hipMemcpyAsync(s->d_blobs + blob_bytes, s->h_up, (size_t)n * 40, hipMemcpyHostToDevice, s->stream));
+        wait = true;      // host_blobs is reused by the next upload
+    }
     if (wait) HIPCHK(s, hipStreamSynchronize(s->stream));
     s->n_loaded = n;
     return UVS_OK;
@@ -1151,43 +1159,75 @@ void uvs_large_comm_destroy(uvs_solver* s) {
 // Every rank decides on identical numbers, so all ranks follow the same path; kernels of iterations after termination return at once.
 int uvs_large_solve_fused(uvs_solver* s, const uvs_window* w, uvs_state* out, uvs_report* rep, float* loop_ms) {
     if (!s || !w || !out || !rep) return UVS_ERR_INVALID_ARG;
-    int rc = uvs_large_begin(s, w);
+    if (w->n_relo_obs > 0) { s->err = "relocalization blocks are not taken by the large-window path"; return UVS_ERR_UNSUPPORTED; }
+    // ONE stream, ONE wait: pinned upload -> k_large_init -> the passes -> k_large_pack -> pinned download.  (The step-wise API keeps
+    // uvs_large_begin's host-side copies; here every small copy / memset is a line of k_large_init.)
+    const uvs_window* arr[1] = {w};
+    int rc = upload_windows(s, 1, arr, false, s->n_cus);
     if (rc != UVS_OK) return rc;
-    auto& L = s->L; const uvs_options& o = s->opts;
+    auto& L = s->L; const DevWin& h = s->hdrs[0]; const uvs_options& o = s->opts;
+    {
+        double* keep_ctl = L.d_ctl; uvs_report* keep_rep = L.d_rep; void* keep_comm = L.comm; const int keep_rank = L.rank, keep_nranks = L.nranks;
+        L = uvs_solver::Large{L.active, 0, 0, 0, 0, 0, 0, 0, 0, true, true, false, 0, 2, 0, 0, 0, 0, L.d_state, L.d_partials, L.d_reduced, L.d_bsums, L.d_out, L.d_sc5, L.cap_partials, L.cap_bsums, {}};
+        L.active = true; L.n_chunks = h.n_chunks; L.radius = o.initial_trust_region_radius;
+        L.grid = std::max(1, std::min(h.n_chunks, s->n_cus));
+        L.d_ctl = keep_ctl; L.d_rep = keep_rep; L.comm = keep_comm; L.rank = keep_rank; L.nranks = keep_nranks;
+    }
+    if (!L.d_state) { HIPCHK(s, hipMalloc((void**)&L.d_state, LG_STATE * 8)); HIPCHK(s, hipMalloc((void**)&L.d_reduced, LG_XCH * 8)); HIPCHK(s, hipMalloc((void**)&L.d_out, 64 * 8)); HIPCHK(s, hipMalloc((void**)&L.d_sc5, 8 * 8)); }
     if (!L.d_ctl) { HIPCHK(s, hipMalloc((void**)&L.d_ctl, 64 * 8)); HIPCHK(s, hipMalloc((void**)&L.d_rep, sizeof(uvs_report))); }
-    double ctl[64] = {0};
-    ctl[LC_RADIUS] = o.initial_trust_region_radius; ctl[LC_DECR] = 2.0; ctl[LC_FIRST] = 1.0; ctl[LC_FRAME_X2] = L.frame_x2;
-    HIPCHK(s, hipMemcpyAsync(L.d_ctl, ctl, sizeof(ctl), hipMemcpyHostToDevice, s->stream));
-    HIPCHK(s, hipMemsetAsync(L.d_rep, 0, sizeof(uvs_report), s->stream));
-    HIPCHK(s, hipMemsetAsync(L.d_reduced, 0, LG_XCH * 8, s->stream));
-    HIPCHK(s, hipMemcpyAsync(L.d_reduced + LX_X2, &L.local_x2, 8, hipMemcpyHostToDevice, s->stream));
+    if ((rc = ensure(s, (void**)&L.d_partials, &L.cap_partials, (size_t)L.grid * LG_RED * 8)) != UVS_OK) return rc;
+    if ((rc = ensure(s, (void**)&L.d_bsums, &L.cap_bsums, (size_t)std::max(L.n_chunks, 1) * 8 * 8)) != UVS_OK) return rc;
+    constexpr int RD = (int)(sizeof(uvs_report) / 8);
+    const size_t out_doubles = 64 + RD + 184 + (size_t)h.n_points + 4 * (size_t)h.n_lines;
+    if ((rc = ensure(s, (void**)&s->d_outpack, &s->d_outpack_cap, out_doubles * 8)) != UVS_OK) return rc;
+    if ((rc = ensure_pinned(s, &s->h_out, &s->h_out_cap, out_doubles * 8)) != UVS_OK) return rc;
+    double x2 = 0.0, l2 = 0.0;      // ||x||^2: frames (identical on every rank) and this rank's landmarks (summed over the ranks by the first all-reduce)
+    for (int f = 0; f < UVS_NUM_FRAMES; ++f) { for (int k = 0; k < 7; ++k) x2 += w->pose[f][k] * w->pose[f][k]; for (int k = 0; k < 9; ++k) x2 += w->speedbias[f][k] * w->speedbias[f][k]; }
+    if (o.estimate_td) x2 += w->td * w->td;
+    if (o.estimate_extrinsic) for (int k = 0; k < 7; ++k) x2 += w->ex_pose[k] * w->ex_pose[k];
+    for (int k = 0; k < w->n_points; ++k) l2 += w->inv_depth[k] * w->inv_depth[k];
+    for (int k = 0; k < 4 * w->n_lines; ++k) l2 += w->line_orth[k] * w->line_orth[k];
+    L.local_x2 = l2; L.x_norm = std::sqrt(x2 + l2); L.frame_x2 = x2;
+    std::memcpy(L.relo_pose_in, w->relo_pose, sizeof(L.relo_pose_in));
+    hipLaunchKernelGGL(k_large_init, dim3(16), dim3(256), 0, s->stream, s->d_blobs, s->d_ws, L.d_state, L.d_ctl, L.d_rep, L.d_reduced, o.initial_trust_region_radius, L.frame_x2, L.local_x2);
     const KOpts ko = make_kopts(o, 0);
     const LargeCtl lc{L.d_ctl, L.rank, L.nranks};
     RcclApi& r = rccl();
     const int passes = std::max(1, o.max_num_iterations);
+    const int rows = L.n_chunks > 0 ? L.grid : 0;
     HIPCHK(s, hipEventRecord(s->ev0, s->stream));
     for (int p = 0; p < passes; ++p) {
         if (L.n_chunks > 0) hipLaunchKernelGGL(k_large_chunks, dim3(L.grid), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, 0, 0, 0.0, L.d_partials, lc);
-        hipLaunchKernelGGL(k_large_reduce, dim3((LG_RED + 15) / 16), dim3(256), 0, s->stream, L.d_partials, L.n_chunks > 0 ? L.grid : 0, L.d_reduced, lc);
+        // (summing the partial rows inside k_large_solve instead of by a launch of its own was measured: one workgroup needs 15-24 us for what 314 do in 5)
+        hipLaunchKernelGGL(k_large_reduce, dim3((LG_RED + 15) / 16), dim3(256), 0, s->stream, L.d_partials, rows, L.d_reduced, lc);
         if (L.comm) { const int e = r.AllReduce(L.d_reduced, L.d_reduced, LG_XCH, kNcclDouble, kNcclSum, L.comm, s->stream); if (e != 0) { s->err = "ncclAllReduce failed"; return UVS_ERR_HIP; } }
         hipLaunchKernelGGL(k_large_solve, dim3(1), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, L.d_reduced, 0, 0.0, L.d_out, lc);
         if (L.n_chunks > 0) hipLaunchKernelGGL(k_large_backsub, dim3(L.grid), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, 0, L.d_bsums, lc);
-        hipLaunchKernelGGL(k_large_sum_bsums, dim3(1), dim3(256), 0, s->stream, L.d_bsums, L.n_chunks, L.d_sc5, lc);
-        if (L.comm) { const int e = r.AllReduce(L.d_sc5, L.d_sc5, 8, kNcclDouble, kNcclSum, L.comm, s->stream); if (e != 0) { s->err = "ncclAllReduce failed"; return UVS_ERR_HIP; } }
-        hipLaunchKernelGGL(k_large_decide, dim3(1), dim3(256), 0, s->stream, L.d_ctl, L.d_state, L.d_out, L.d_sc5, L.d_reduced, ko, L.d_rep);
+        if (L.comm) {
+            hipLaunchKernelGGL(k_large_sum_bsums, dim3(1), dim3(256), 0, s->stream, L.d_bsums, L.n_chunks, L.d_sc5, lc);
+            const int e = r.AllReduce(L.d_sc5, L.d_sc5, 8, kNcclDouble, kNcclSum, L.comm, s->stream); if (e != 0) { s->err = "ncclAllReduce failed"; return UVS_ERR_HIP; }
+            hipLaunchKernelGGL(k_large_decide, dim3(1), dim3(256), 0, s->stream, L.d_ctl, L.d_state, L.d_out, L.d_sc5, L.d_reduced, ko, L.d_rep, (const double*)nullptr, 0);
+        } else hipLaunchKernelGGL(k_large_decide, dim3(1), dim3(256), 0, s->stream, L.d_ctl, L.d_state, L.d_out, L.d_sc5, L.d_reduced, ko, L.d_rep, (const double*)L.d_bsums, L.n_chunks);
     }
     HIPCHK(s, hipEventRecord(s->ev1, s->stream));
+    hipLaunchKernelGGL(k_large_pack, dim3(16), dim3(256), 0, s->stream, s->d_blobs, s->d_ws, L.d_state, L.d_ctl, L.d_rep, s->d_outpack);
     HIPCHK(s, hipGetLastError());
-    HIPCHK(s, hipMemcpyAsync(ctl, L.d_ctl, sizeof(ctl), hipMemcpyDeviceToHost, s->stream));
-    HIPCHK(s, hipMemcpyAsync(&L.rep, L.d_rep, sizeof(uvs_report), hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(s, hipMemcpyAsync(s->h_out, s->d_outpack, out_doubles * 8, hipMemcpyDeviceToHost, s->stream));
     HIPCHK(s, hipStreamSynchronize(s->stream));
     if (loop_ms) HIPCHK(s, hipEventElapsedTime(loop_ms, s->ev0, s->ev1));
-    if (ctl[LC_DONE] == 0.0) { s->err = "fused large-window loop did not terminate within max_num_iterations passes"; L.active = false; return UVS_ERR_NUMERIC; }
+    const double* ho = (const double*)s->h_out;
+    const double* ctl = ho;
+    L.active = false;
+    if (ctl[LC_DONE] == 0.0) { s->err = "fused large-window loop did not terminate within max_num_iterations passes"; return UVS_ERR_NUMERIC; }
     L.sel = (int)ctl[LC_SEL]; L.it = (int)ctl[LC_IT]; L.nsucc = (int)ctl[LC_NSUCC]; L.term = (int)ctl[LC_TERM]; L.status = (int)ctl[LC_STATUS]; L.cost = ctl[LC_COST]; L.done = true;
-    const uvs_report keep = L.rep;
-    rc = uvs_large_finish(s, out, rep);
-    *rep = keep;
-    return rc;
+    std::memcpy(rep, ho + 64, sizeof(uvs_report));
+    L.rep = *rep;
+    const double* fr = ho + 64 + RD;
+    std::memcpy(out->pose, fr, 77 * 8); std::memcpy(out->speedbias, fr + 77, 99 * 8); std::memcpy(out->ex_pose, fr + 176, 7 * 8); out->td = fr[183];
+    std::memcpy(out->relo_pose, L.relo_pose_in, sizeof(out->relo_pose));      // the large path takes no relocalization blocks: the input value passes through
+    if (out->inv_depth && h.n_points) std::memcpy(out->inv_depth, fr + 184, (size_t)h.n_points * 8);
+    if (out->line_orth && h.n_lines) std::memcpy(out->line_orth, fr + 184 + h.n_points, (size_t)h.n_lines * 32);
+    return L.status;
 }
 
 }  // extern "C"
