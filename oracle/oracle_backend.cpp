@@ -34,6 +34,7 @@ void uvs_destroy(uvs_solver* s) { delete s; }
 const char* uvs_last_error(const uvs_solver* s) { return s ? s->err.c_str() : "null solver"; }
 const char* uvs_status_string(int st) { return st == UVS_OK ? "ok" : "oracle error"; }
 int uvs_solve_window(uvs_solver* s, const uvs_window* w, uvs_state* out, uvs_report* rep) { return oracle_solve(&s->opt, w, 0, out, rep); }
+int uvs_large_solve_fused(uvs_solver* s, const uvs_window* w, uvs_state* out, uvs_report* rep, float* loop_ms) { if (loop_ms) *loop_ms = 0.0f; return oracle_solve(&s->opt, w, 0, out, rep); }      // the host mirror's default single-window path
 int uvs_evaluate(uvs_solver* s, const uvs_window* w, int robust, uvs_eval* out) { return oracle_evaluate(&s->opt, w, robust, out); }
 int uvs_marginalize(uvs_solver* s, const uvs_window* w, int flag, uvs_prior* out) { return oracle_marginalize(&s->opt, w, flag, out); }
 int uvs_marginalize_resident(uvs_solver* s, const uvs_window* w, int flag, uvs_prior* out) { return oracle_marginalize(&s->opt, w, flag, out); }

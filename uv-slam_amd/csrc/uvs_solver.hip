@@ -345,7 +345,8 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
             const int n_pt = cut_pt.empty() ? 0 : (int)cut_pt.size() - 1, n_ln = cut_ln.empty() ? 0 : (int)cut_ln.size() - 1, n_min = n_pt + n_ln;
             // work per family ~ its staging volume; a chunk should keep at least ~64 observations (its fixed cost is a few microseconds)
             const double w_pt = (double)PREC * h.n_pt_obs + 12.0 * (h.n_pt_obs + XS * h.n_points), w_ln = (double)(UVS_LN_REC + 48) * h.n_ln_obs + 20.0 * h.n_lines;
-            const long by_size = (long)(h.n_pt_obs + h.n_ln_obs) / 64;
+            static const long min_obs = std::getenv("UVS_CHUNK_MIN_OBS") ? std::max(1, std::atoi(std::getenv("UVS_CHUNK_MIN_OBS"))) : 64;
+            const long by_size = (long)(h.n_pt_obs + h.n_ln_obs) / min_obs;
             long target = n_min >= chunk_grid ? (long)((n_min + chunk_grid - 1) / chunk_grid) * chunk_grid : std::min<long>(chunk_grid, std::max<long>(n_min, by_size));
             if (target > n_min && w_pt + w_ln > 0.0) {
                 int t_pt = (int)std::lround(target * w_pt / (w_pt + w_ln));
