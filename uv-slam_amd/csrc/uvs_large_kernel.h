@@ -27,18 +27,39 @@ enum { LO_COST = 0, LO_GMAX, LO_CHOLOK, LO_GD, LO_DD2, LO_STEP2, LO_XC2, LO_FRAM
 // ||x||^2 (first iteration only) and LX_GMAX + r = rank r's max |g_landmark| (zero in the other ranks' slots, so that ONE SUM
 // all-reduce also delivers the MAX: every rank takes the maximum over the slots afterwards).
 static constexpr int LG_MAXRANKS = 8;
+// frame image written by the extra workgroup of k_large_chunks: S without the landmark blocks and without damping | gradient | diag(J^T J) | {cost of the frame terms}
+static constexpr int FI_S = 0, FI_G = UVS_S_DOUBLES, FI_HD = FI_G + UVS_RD, FI_COST = FI_HD + UVS_RD, LG_FIMG = FI_COST + 8;
 static constexpr int LX_X2 = LG_RED, LX_GMAX = LG_RED + 1, LG_XCH = LG_RED + 1 + LG_MAXRANKS + 7;      // 5016 doubles
 enum { LC_RADIUS = 0, LC_DECR, LC_COST, LC_GMAX, LC_XNORM, LC_FRAME_X2, LC_IT, LC_INVALID, LC_NSUCC, LC_PENDING, LC_TERM, LC_STATUS, LC_FIRST, LC_DONE, LC_SEL, LC_N };
 struct LargeCtl { const double* ctl; int rank, nranks; };      // ctl == nullptr: the step-wise API (host-side control, arguments as given)
 
 
-__global__ __launch_bounds__(NT) void k_large_chunks(char* blob, double* ws, KOpts o, const double* state, int sel, int first, double radius, double* partials, LargeCtl lc) {
+// The LAST workgroup of the grid (blockIdx.x == n_chunk_wgs) carries no landmarks: it builds the FRAME image of the reduced system -- IMU
+// tiles, prior, their gradient and cost (and, on the first linearization, the per-solve setup: IMU whitening, prior normal matrix) --
+// while the others run the landmark chunks, and writes it to `fimg`; k_large_solve then only adds the reduced landmark blocks and factors.
+// (Inside k_large_solve these 45 k cycles sat on the one-workgroup critical path of every iteration.)
+__global__ __launch_bounds__(NT) void k_large_chunks(char* blob, double* ws, KOpts o, const double* state, int sel, int first, double radius, double* partials, LargeCtl lc,
+                                                     int n_chunk_wgs, double* fimg) {
     extern __shared__ __attribute__((aligned(16))) double sh[];
     const int tid = threadIdx.x;
     if (lc.ctl) { if (lc.ctl[LC_DONE] != 0.0) return; sel = (int)lc.ctl[LC_SEL]; first = (int)lc.ctl[LC_FIRST]; radius = lc.ctl[LC_RADIUS]; }
     Ctx c; c.hdr = (const DevWin*)blob; c.bd = (const double*)blob; c.bi = (const int*)blob; c.ws = ws; c.sh = sh; c.o = o; c.o.debug = 0;
     const DevWin& h = *c.hdr;
     if (tid < 184) sh[L_X + tid] = state[LS_X + tid];
+    if ((int)blockIdx.x == n_chunk_wgs) {
+        if (first) setup_window(c, (double*)blob);
+        __syncthreads();
+        ImuN N; GAcc none; gacc_zero(none);
+        double cost = lin_frames(c, sh + L_X, N);
+        __syncthreads();
+        lin_assemble(c, sh + L_X, first != 0, radius, -1, none, N, 0.0, 0.0, 1);
+        for (int i = tid; i < UVS_S_DOUBLES; i += NT) fimg[FI_S + i] = sh[L_S + i];
+        if (tid < UVS_RD) { fimg[FI_G + tid] = sh[L_G + tid]; fimg[FI_HD + tid] = sh[L_HD + tid]; }
+        double s4[4] = {cost, 0, 0, 0}, mx = 0.0;
+        block_reduce(sh, s4, &mx);
+        if (tid == 0) fimg[FI_COST] = s4[0];
+        return;
+    }
     __syncthreads();
     stage_rotations(c, sh + L_X);
     __syncthreads();
@@ -48,7 +69,7 @@ __global__ __launch_bounds__(NT) void k_large_chunks(char* blob, double* ws, KOp
     const double* invd = ws + (sel ? h.w_invd1 : h.w_invd0); const double* line = ws + (sel ? h.w_line1 : h.w_line0);
     // PERSISTENT workgroups: workgroup b takes chunks b, b + gridDim.x, ... and accumulates them into ONE partial (the host sizes the chunks so
     // that their number is a multiple of the grid: 340 LDS-filling chunks on 256 CUs were two full rounds for 1.33 rounds of work)
-    for (int ch = blockIdx.x; ch < h.n_chunks; ch += gridDim.x) lin_chunk(c, ch, sh + L_X, invd, line, first != 0, radius, grp, A);
+    for (int ch = blockIdx.x; ch < h.n_chunks; ch += n_chunk_wgs) lin_chunk(c, ch, sh + L_X, invd, line, first != 0, radius, grp, A);
     double cost = lacc_cost(sh), gmax = lacc_gmax(sh);
     // canonical partial [pose block][row a][8] (6 block entries, gradient, diag(J^T J)), staged in LDS so that the two halves of a
     // split block are summed in a fixed order and the HBM write is coalesced
@@ -106,7 +127,8 @@ __global__ __launch_bounds__(256) void k_large_reduce(const double* partials, in
 }
 
 // one workgroup: frame terms + assembly + Cholesky + step.  `reduced` holds the (all-reduced) landmark partials.
-__global__ __launch_bounds__(NT) void k_large_solve(char* blob, double* ws, KOpts o, double* state, const double* reduced, int first, double radius, double* out, LargeCtl lc) {
+__global__ __launch_bounds__(NT) void k_large_solve(char* blob, double* ws, KOpts o, double* state, const double* reduced, int first, double radius, double* out, LargeCtl lc,
+                                                    const double* fimg) {
     extern __shared__ __attribute__((aligned(16))) double sh[];
     const int tid = threadIdx.x;
     if (lc.ctl && lc.ctl[LC_DONE] != 0.0) return;
@@ -119,8 +141,16 @@ __global__ __launch_bounds__(NT) void k_large_solve(char* blob, double* ws, KOpt
     Ctx c; c.hdr = (const DevWin*)blob; c.bd = (const double*)blob; c.bi = (const int*)blob; c.ws = ws; c.sh = sh; c.o = o; c.o.debug = 0;
     if (tid < 184) sh[L_X + tid] = state[LS_X + tid];
     if (tid < UVS_RD && !first) sh[L_SC + tid] = state[LS_SC + tid];
-    if (first) setup_window(c, (double*)blob);
-    __syncthreads();
+    // the frame image (k_large_chunks' extra workgroup): 147 KB, 16-byte loads, everything in flight before the first store
+    {
+        constexpr int N2 = UVS_S_DOUBLES / 2, PER = (N2 + NT - 1) / NT;
+        d2_t v[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) { const int i = tid + u * NT; v[u] = *(const d2_t*)(fimg + FI_S + 2 * (i < N2 ? i : 0)); }
+#pragma unroll
+        for (int u = 0; u < PER; ++u) { const int i = tid + u * NT; if (i < N2) *(d2_t*)(sh + L_S + 2 * i) = v[u]; }
+        if (tid < UVS_RD) { sh[L_G + tid] = fimg[FI_G + tid]; sh[L_HD + tid] = fimg[FI_HD + tid]; }
+    }
     const int grp = gather_group(c);
     GAcc A;
     {
@@ -134,30 +164,21 @@ __global__ __launch_bounds__(NT) void k_large_solve(char* blob, double* ws, KOpt
             A.g[r] = ld ? Q[6] : 0.0; A.hd[r] = ld ? Q[7] : 0.0;
         }
     }
-    ImuN N;
-    double cost = lin_frames(c, sh + L_X, N);
-    if (tid == 0) cost += reduced[LG_ACC];
-    __syncthreads();
-    lin_assemble(c, sh + L_X, first != 0, radius, grp, A, N, cost, gmax_lm);
+    ImuN N;      // unused in mode 2
+    const double cost = tid == 0 ? fimg[FI_COST] + reduced[LG_ACC] : 0.0;
+    lin_assemble(c, sh + L_X, first != 0, radius, grp, A, N, cost, gmax_lm, 2);
     if (tid < UVS_RD) sh[L_DLT + tid] = -sh[L_G + tid];
     chol_factor(c);
     chol_solve(c);
     backsub_candidate(c, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, true, out + LO_GD);      // frames only
     if (tid < UVS_RD) { state[LS_DLT + tid] = sh[L_DLT + tid]; state[LS_G + tid] = sh[L_G + tid]; state[LS_DD + tid] = sh[L_DD + tid]; state[LS_SC + tid] = sh[L_SC + tid]; }
     if (tid < 184) state[LS_XC + tid] = sh[L_XC + tid];
-    // frame-only part of the candidate cost (prior + IMU at x_c)
-    __syncthreads();
-    stage_rotations(c, sh + L_XC);
-    prior_dx(c, sh + L_XC);
-    __syncthreads();
-    double cc = prior_residual(c) + cost_pass(c, sh + L_XC, nullptr, nullptr, 0, 0, 0, 0, true);
-    double s4[4] = {cc, 0, 0, 0}, mx = 0.0;
-    block_reduce(sh, s4, &mx);
-    if (tid == 0) { out[LO_COST] = sh[L_CTRL + C_COST]; out[LO_GMAX] = sh[L_CTRL + C_GMAX]; out[LO_CHOLOK] = sh[L_CTRL + C_CHOLOK]; out[LO_FRAMECOST] = s4[0]; }
+    if (tid == 0) { out[LO_COST] = sh[L_CTRL + C_COST]; out[LO_GMAX] = sh[L_CTRL + C_GMAX]; out[LO_CHOLOK] = sh[L_CTRL + C_CHOLOK]; }
+    // (the frame part of the candidate cost -- prior + IMU at x_c -- is k_large_backsub's extra workgroup)
 }
 
 // per chunk: landmark back-substitution (candidate parameters into the other buffer) + candidate cost of the chunk's observations
-__global__ __launch_bounds__(NT) void k_large_backsub(char* blob, double* ws, KOpts o, const double* state, int sel, double* bsums, LargeCtl lc) {
+__global__ __launch_bounds__(NT) void k_large_backsub(char* blob, double* ws, KOpts o, const double* state, int sel, double* bsums, LargeCtl lc, int n_chunk_wgs, double* out) {
     extern __shared__ __attribute__((aligned(16))) double sh[];
     const int tid = threadIdx.x;
     if (lc.ctl) { if (lc.ctl[LC_DONE] != 0.0) return; sel = (int)lc.ctl[LC_SEL]; }
@@ -167,21 +188,30 @@ __global__ __launch_bounds__(NT) void k_large_backsub(char* blob, double* ws, KO
     if (tid < UVS_RD) sh[L_DLT + tid] = state[LS_DLT + tid];
     __syncthreads();
     stage_rotations(c, sh + L_XC);
+    if ((int)blockIdx.x == n_chunk_wgs) {      // the LAST workgroup: frame part of the candidate cost (prior + IMU at x_c), beside the landmark chunks
+        prior_dx(c, sh + L_XC);
+        __syncthreads();
+        double cc = prior_residual(c) + cost_pass(c, sh + L_XC, nullptr, nullptr, 0, 0, 0, 0, true);
+        double s4[4] = {cc, 0, 0, 0}, mx = 0.0;
+        block_reduce(sh, s4, &mx);
+        if (tid == 0) out[LO_FRAMECOST] = s4[0];
+        return;
+    }
     double* invd = ws + (sel ? h.w_invd1 : h.w_invd0); double* line = ws + (sel ? h.w_line1 : h.w_line0);
     double* invd_c = ws + (sel ? h.w_invd0 : h.w_invd1); double* line_c = ws + (sel ? h.w_line0 : h.w_line1);
     const int* pbeg = c.bi + h.i_pt_beg; const int* lbeg = c.bi + h.i_ln_beg;
-    for (int ch = blockIdx.x; ch < h.n_chunks; ch += gridDim.x) {      // persistent workgroups, as in k_large_chunks; the sums stay per chunk (8 doubles)
+    for (int ch = blockIdx.x; ch < h.n_chunks; ch += n_chunk_wgs) {      // persistent workgroups, as in k_large_chunks; the sums stay per chunk (8 doubles)
         const int* chunk = c.bi + h.i_chunks + 6 * ch;
         const int type = chunk[0], k0 = chunk[1], k1 = chunk[2];
-        double* out = bsums + 8 * (size_t)ch;
-        backsub_candidate(c, invd, line, invd_c, line_c, type == 0 ? k0 : 0, type == 0 ? k1 : 0, type == 1 ? k0 : 0, type == 1 ? k1 : 0, false, out);
+        double* bo = bsums + 8 * (size_t)ch;
+        backsub_candidate(c, invd, line, invd_c, line_c, type == 0 ? k0 : 0, type == 0 ? k1 : 0, type == 1 ? k0 : 0, type == 1 ? k1 : 0, false, bo);
         __threadfence_block();
         __syncthreads();
         const int po0 = type == 0 ? pbeg[k0] : 0, po1 = type == 0 ? pbeg[k1] : 0, lo0 = type == 1 ? lbeg[k0] : 0, lo1 = type == 1 ? lbeg[k1] : 0;
         double cc = cost_pass(c, sh + L_XC, invd_c, line_c, po0, po1, lo0, lo1, false);
         double s4[4] = {cc, 0, 0, 0}, mx = 0.0;
         block_reduce(sh, s4, &mx);
-        if (tid == 0) out[4] = s4[0];
+        if (tid == 0) bo[4] = s4[0];
     }
 }
 __global__ __launch_bounds__(256) void k_large_sum_bsums(const double* bsums, int n_chunks, double* out5, LargeCtl lc) {

@@ -1196,7 +1196,11 @@ UVS_DEV void lin_chunk(const Ctx& c, int ch, const double* x, const double* invd
 }
 
 // ---- linearization, part 3: assemble the damped reduced system in LDS from the gathered pose blocks + IMU + prior
-UVS_DEV void lin_assemble(const Ctx& c, const double* x, bool first, double radius, int grp, const GAcc& Ain, const ImuN& N, double cost, double gmax_lm) {
+// mode 0: everything (k_solve).  The large-window kernels split the work over two workgroups that run concurrently with the landmark
+// chunks resp. after them: mode 1 = the FRAME image only (zero, IMU tiles, prior; no landmark blocks, no damping: k_large_chunks' extra
+// workgroup writes S / G / HD to global memory), mode 2 = landmark blocks + damping / scaling / gradient norm ONTO an image already in LDS
+// (k_large_solve; `Ain` must hold the complete sums in the part-0 groups, nothing is gathered from other parts).
+UVS_DEV void lin_assemble(const Ctx& c, const double* x, bool first, double radius, int grp, const GAcc& Ain, const ImuN& N, double cost, double gmax_lm, int mode = 0) {
     const DevWin& h = *c.hdr;
     double* sh = c.sh;
     const int tid = lane_tid();
@@ -1205,13 +1209,14 @@ UVS_DEV void lin_assemble(const Ctx& c, const double* x, bool first, double radi
     // ---- assemble the reduced system in LDS
     // parts of split blocks -> their part-0 group (the staging area is free now; S is zeroed only after the sums are in registers)
     GAcc A = Ain;
-    gacc_gather_parts(A, grp, sh + L_S);
-    __syncthreads();
-    { const d2_t z2 = {0.0, 0.0}; for (int i = tid; i < UVS_S_DOUBLES / 2; i += NT) *(d2_t*)(sh + L_S + 2 * i) = z2; }      // ds_write_b128
-    if (tid < UVS_RD) { sh[L_G + tid] = 0.0; sh[L_HD + tid] = 0.0; }
-    __syncthreads();
+    if (mode == 0) { gacc_gather_parts(A, grp, sh + L_S); __syncthreads(); }
+    if (mode != 2) {
+        { const d2_t z2 = {0.0, 0.0}; for (int i = tid; i < UVS_S_DOUBLES / 2; i += NT) *(d2_t*)(sh + L_S + 2 * i) = z2; }      // ds_write_b128
+        if (tid < UVS_RD) { sh[L_G + tid] = 0.0; sh[L_HD + tid] = 0.0; }
+        __syncthreads();
+    }
     // the part-0 group of every pose block adds its rows (one writer per block: a single round)
-    {
+    if (mode != 1) {
         if (grp >= 0 && ((grp >> 9) & 15) == 0) {
             const int r0 = GR * (tid % UVS_GLANES);
             const int fa = (grp >> 13) & 15, fb = (grp >> 17) & 15;
@@ -1265,7 +1270,7 @@ UVS_DEV void lin_assemble(const Ctx& c, const double* x, bool first, double radi
     }
     UVS_PROF(c, P_AS_ZERO);
     // IMU normal-equation tiles from the registers of lin_imu (even blocks, then odd: consecutive blocks share a diagonal frame block)
-    {
+    if (mode != 2) {
         const int lane = tid & 63, wv = tid >> 6, li = lane & 15, lk = lane >> 4;
         int fis[IMU_SLOTS]; bool act[IMU_SLOTS];
 #pragma unroll
@@ -1314,7 +1319,7 @@ UVS_DEV void lin_assemble(const Ctx& c, const double* x, bool first, double radi
         }
     }
     // prior: H0 = J0^T J0 (precomputed), g = J0^T r
-    if (h.prior_n > 0) {
+    if (h.prior_n > 0 && mode != 2) {
         const int n = h.prior_n;
         const int* cm = c.bi + h.i_prior + 80;
         const double* J0 = c.bd + h.d_prior;
@@ -1360,6 +1365,7 @@ UVS_DEV void lin_assemble(const Ctx& c, const double* x, bool first, double radi
     }
     __syncthreads();
     UVS_PROF(c, P_AS_ADD);
+    if (mode == 1) return;
     // frame damping, Jacobi scaling (first linearization only), dummy pivots, projected-gradient max norm
     double gmax = gmax_lm;
     if (tid < UVS_RD) {

@@ -66,7 +66,8 @@ struct uvs_solver {
         double* d_ctl = nullptr; uvs_report* d_rep = nullptr;   // fused loop: trust-region state and report on the device
         void* comm = nullptr; int rank = 0, nranks = 1;         // RCCL communicator owned by the handle (uvs_large_comm_init)
         double relo_pose_in[7] = {0, 0, 0, 0, 0, 0, 0};      // passes through to uvs_large_finish (this path takes no relocalization blocks)
-        int grid = 1;                                           // workgroups of k_large_chunks / k_large_backsub = partial rows (min(n_chunks, compute units))
+        int grid = 0;                                           // chunk workgroups of k_large_chunks / k_large_backsub = partial rows (min(n_chunks, compute units)); every launch adds ONE for the frame terms
+        double* d_fimg = nullptr;                               // frame image of the reduced system (k_large_chunks' extra workgroup -> k_large_solve)
     } L;
 };
 
@@ -175,6 +176,7 @@ void uvs_destroy(uvs_solver* s) {
     if (s->h_out) (void)hipHostFree(s->h_out);
     uvs_large_comm_destroy(s);
     if (s->L.d_ctl) (void)hipFree(s->L.d_ctl);
+    if (s->L.d_fimg) (void)hipFree(s->L.d_fimg);
     if (s->L.d_rep) (void)hipFree(s->L.d_rep);
     if (s->d_outpack) (void)hipFree(s->d_outpack);
     if (s->d_reports) (void)hipFree(s->d_reports);
@@ -936,14 +938,15 @@ int uvs_large_begin(uvs_solver* s, const uvs_window* w) {
     int rc = upload_windows(s, 1, arr, true, s->n_cus);
     if (rc != UVS_OK) return rc;
     auto& L = s->L; const DevWin& h = s->hdrs[0];
-    double* keep_ctl = L.d_ctl; uvs_report* keep_rep = L.d_rep; void* keep_comm = L.comm; const int keep_rank = L.rank, keep_nranks = L.nranks;
+    double* keep_ctl = L.d_ctl; uvs_report* keep_rep = L.d_rep; void* keep_comm = L.comm; const int keep_rank = L.rank, keep_nranks = L.nranks; double* keep_fimg = L.d_fimg;
     L = uvs_solver::Large{L.active, 0, 0, 0, 0, 0, 0, 0, 0, true, true, false, 0, 2, 0, 0, 0, 0, L.d_state, L.d_partials, L.d_reduced, L.d_bsums, L.d_out, L.d_sc5, L.cap_partials, L.cap_bsums, {}};
     L.active = true; L.n_chunks = h.n_chunks; L.radius = s->opts.initial_trust_region_radius;
-    L.grid = std::max(1, std::min(h.n_chunks, s->n_cus));
-    L.d_ctl = keep_ctl; L.d_rep = keep_rep; L.comm = keep_comm; L.rank = keep_rank; L.nranks = keep_nranks;
+    L.grid = std::min(h.n_chunks, s->n_cus);
+    L.d_ctl = keep_ctl; L.d_rep = keep_rep; L.comm = keep_comm; L.rank = keep_rank; L.nranks = keep_nranks; L.d_fimg = keep_fimg;
     if (!L.d_state) { HIPCHK(s, hipMalloc((void**)&L.d_state, LG_STATE * 8)); HIPCHK(s, hipMalloc((void**)&L.d_reduced, LG_XCH * 8)); HIPCHK(s, hipMemset(L.d_reduced, 0, LG_XCH * 8)); HIPCHK(s, hipMalloc((void**)&L.d_out, 64 * 8)); HIPCHK(s, hipMalloc((void**)&L.d_sc5, 8 * 8)); }
+    if (!L.d_fimg) HIPCHK(s, hipMalloc((void**)&L.d_fimg, LG_FIMG * 8));
     int r2;
-    if ((r2 = ensure(s, (void**)&L.d_partials, &L.cap_partials, (size_t)L.grid * LG_RED * 8)) != UVS_OK) return r2;
+    if ((r2 = ensure(s, (void**)&L.d_partials, &L.cap_partials, (size_t)std::max(L.grid, 1) * LG_RED * 8)) != UVS_OK) return r2;
     if ((r2 = ensure(s, (void**)&L.d_bsums, &L.cap_bsums, (size_t)std::max(L.n_chunks, 1) * 8 * 8)) != UVS_OK) return r2;
     HIPCHK(s, hipMemsetAsync(L.d_state, 0, LG_STATE * 8, s->stream));
     // frames -> state.X ; landmark parameters -> workspace buffer 0 (device-to-device from the blob)
@@ -987,8 +990,8 @@ int uvs_large_linearize(uvs_solver* s) {
     auto& L = s->L;
     HIPCHK(s, hipSetDevice(s->device));
     KOpts ko = make_kopts(s->opts, 0);
-    if (L.n_chunks > 0) hipLaunchKernelGGL(k_large_chunks, dim3(L.grid), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, L.sel, L.first ? 1 : 0, L.radius, L.d_partials, LargeCtl{nullptr, 0, 0});
-    hipLaunchKernelGGL(k_large_reduce, dim3((LG_RED + 15) / 16), dim3(256), 0, s->stream, L.d_partials, L.n_chunks > 0 ? L.grid : 0, L.d_reduced, LargeCtl{nullptr, 0, 0});
+    hipLaunchKernelGGL(k_large_chunks, dim3(L.grid + 1), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, L.sel, L.first ? 1 : 0, L.radius, L.d_partials, LargeCtl{nullptr, 0, 0}, L.grid, L.d_fimg);
+    hipLaunchKernelGGL(k_large_reduce, dim3((LG_RED + 15) / 16), dim3(256), 0, s->stream, L.d_partials, L.grid, L.d_reduced, LargeCtl{nullptr, 0, 0});
     HIPCHK(s, hipGetLastError());
     HIPCHK(s, hipStreamSynchronize(s->stream));
     return UVS_OK;
@@ -999,8 +1002,8 @@ int uvs_large_step(uvs_solver* s) {
     auto& L = s->L;
     HIPCHK(s, hipSetDevice(s->device));
     KOpts ko = make_kopts(s->opts, 0);
-    hipLaunchKernelGGL(k_large_solve, dim3(1), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, L.d_reduced, L.first ? 1 : 0, L.radius, L.d_out, LargeCtl{nullptr, 0, 0});
-    if (L.n_chunks > 0) hipLaunchKernelGGL(k_large_backsub, dim3(L.grid), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, L.sel, L.d_bsums, LargeCtl{nullptr, 0, 0});
+    hipLaunchKernelGGL(k_large_solve, dim3(1), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, L.d_reduced, L.first ? 1 : 0, L.radius, L.d_out, LargeCtl{nullptr, 0, 0}, L.d_fimg);
+    hipLaunchKernelGGL(k_large_backsub, dim3(L.grid + 1), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, L.sel, L.d_bsums, LargeCtl{nullptr, 0, 0}, L.grid, L.d_out);
     hipLaunchKernelGGL(k_large_sum_bsums, dim3(1), dim3(256), 0, s->stream, L.d_bsums, L.n_chunks, L.d_sc5, LargeCtl{nullptr, 0, 0});
     HIPCHK(s, hipGetLastError());
     HIPCHK(s, hipStreamSynchronize(s->stream));
@@ -1168,15 +1171,16 @@ int uvs_large_solve_fused(uvs_solver* s, const uvs_window* w, uvs_state* out, uv
     if (rc != UVS_OK) return rc;
     auto& L = s->L; const DevWin& h = s->hdrs[0]; const uvs_options& o = s->opts;
     {
-        double* keep_ctl = L.d_ctl; uvs_report* keep_rep = L.d_rep; void* keep_comm = L.comm; const int keep_rank = L.rank, keep_nranks = L.nranks;
+        double* keep_ctl = L.d_ctl; uvs_report* keep_rep = L.d_rep; void* keep_comm = L.comm; const int keep_rank = L.rank, keep_nranks = L.nranks; double* keep_fimg = L.d_fimg;
         L = uvs_solver::Large{L.active, 0, 0, 0, 0, 0, 0, 0, 0, true, true, false, 0, 2, 0, 0, 0, 0, L.d_state, L.d_partials, L.d_reduced, L.d_bsums, L.d_out, L.d_sc5, L.cap_partials, L.cap_bsums, {}};
         L.active = true; L.n_chunks = h.n_chunks; L.radius = o.initial_trust_region_radius;
-        L.grid = std::max(1, std::min(h.n_chunks, s->n_cus));
-        L.d_ctl = keep_ctl; L.d_rep = keep_rep; L.comm = keep_comm; L.rank = keep_rank; L.nranks = keep_nranks;
+        L.grid = std::min(h.n_chunks, s->n_cus);
+        L.d_ctl = keep_ctl; L.d_rep = keep_rep; L.comm = keep_comm; L.rank = keep_rank; L.nranks = keep_nranks; L.d_fimg = keep_fimg;
     }
     if (!L.d_state) { HIPCHK(s, hipMalloc((void**)&L.d_state, LG_STATE * 8)); HIPCHK(s, hipMalloc((void**)&L.d_reduced, LG_XCH * 8)); HIPCHK(s, hipMalloc((void**)&L.d_out, 64 * 8)); HIPCHK(s, hipMalloc((void**)&L.d_sc5, 8 * 8)); }
+    if (!L.d_fimg) HIPCHK(s, hipMalloc((void**)&L.d_fimg, LG_FIMG * 8));
     if (!L.d_ctl) { HIPCHK(s, hipMalloc((void**)&L.d_ctl, 64 * 8)); HIPCHK(s, hipMalloc((void**)&L.d_rep, sizeof(uvs_report))); }
-    if ((rc = ensure(s, (void**)&L.d_partials, &L.cap_partials, (size_t)L.grid * LG_RED * 8)) != UVS_OK) return rc;
+    if ((rc = ensure(s, (void**)&L.d_partials, &L.cap_partials, (size_t)std::max(L.grid, 1) * LG_RED * 8)) != UVS_OK) return rc;
     if ((rc = ensure(s, (void**)&L.d_bsums, &L.cap_bsums, (size_t)std::max(L.n_chunks, 1) * 8 * 8)) != UVS_OK) return rc;
     constexpr int RD = (int)(sizeof(uvs_report) / 8);
     const size_t out_doubles = 64 + RD + 184 + (size_t)h.n_points + 4 * (size_t)h.n_lines;
@@ -1195,15 +1199,15 @@ int uvs_large_solve_fused(uvs_solver* s, const uvs_window* w, uvs_state* out, uv
     const LargeCtl lc{L.d_ctl, L.rank, L.nranks};
     RcclApi& r = rccl();
     const int passes = std::max(1, o.max_num_iterations);
-    const int rows = L.n_chunks > 0 ? L.grid : 0;
+    const int rows = L.grid;
     HIPCHK(s, hipEventRecord(s->ev0, s->stream));
     for (int p = 0; p < passes; ++p) {
-        if (L.n_chunks > 0) hipLaunchKernelGGL(k_large_chunks, dim3(L.grid), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, 0, 0, 0.0, L.d_partials, lc);
+        hipLaunchKernelGGL(k_large_chunks, dim3(L.grid + 1), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, 0, 0, 0.0, L.d_partials, lc, L.grid, L.d_fimg);
         // (summing the partial rows inside k_large_solve instead of by a launch of its own was measured: one workgroup needs 15-24 us for what 314 do in 5)
         hipLaunchKernelGGL(k_large_reduce, dim3((LG_RED + 15) / 16), dim3(256), 0, s->stream, L.d_partials, rows, L.d_reduced, lc);
         if (L.comm) { const int e = r.AllReduce(L.d_reduced, L.d_reduced, LG_XCH, kNcclDouble, kNcclSum, L.comm, s->stream); if (e != 0) { s->err = "ncclAllReduce failed"; return UVS_ERR_HIP; } }
-        hipLaunchKernelGGL(k_large_solve, dim3(1), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, L.d_reduced, 0, 0.0, L.d_out, lc);
-        if (L.n_chunks > 0) hipLaunchKernelGGL(k_large_backsub, dim3(L.grid), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, 0, L.d_bsums, lc);
+        hipLaunchKernelGGL(k_large_solve, dim3(1), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, L.d_reduced, 0, 0.0, L.d_out, lc, L.d_fimg);
+        hipLaunchKernelGGL(k_large_backsub, dim3(L.grid + 1), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, 0, L.d_bsums, lc, L.grid, L.d_out);
         if (L.comm) {
             hipLaunchKernelGGL(k_large_sum_bsums, dim3(1), dim3(256), 0, s->stream, L.d_bsums, L.n_chunks, L.d_sc5, lc);
             const int e = r.AllReduce(L.d_sc5, L.d_sc5, 8, kNcclDouble, kNcclSum, L.comm, s->stream); if (e != 0) { s->err = "ncclAllReduce failed"; return UVS_ERR_HIP; }
