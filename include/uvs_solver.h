@@ -340,7 +340,14 @@ int uvs_large_solve(uvs_solver *s, const uvs_window *w, uvs_state *out, uvs_repo
  *     uvs_large_solve_fused(s, shard_of_this_rank, &state, &report, &ms);    w = the landmarks k with k % nranks == rank, frames / IMU /
  *                                                                            prior replicated; frames of `state` identical on all ranks
  *     uvs_large_comm_destroy(s);                             (also done by uvs_destroy)
- * RCCL is looked up at run time (a copy already loaded by the process is reused; UVS_RCCL_LIB overrides): UVS_ERR_UNSUPPORTED if absent. */
+ * RCCL is looked up at run time (a copy already loaded by the process is reused; UVS_RCCL_LIB overrides): UVS_ERR_UNSUPPORTED if absent.
+ *
+ * WITHOUT a communicator (no uvs_large_comm_init, or nranks == 1) uvs_large_solve_fused() is also the LOW-LATENCY form for ONE window of
+ * any size on an otherwise idle GPU (the online case): the landmark chunks of every LM iteration run on many compute units, the frame
+ * terms in a workgroup beside them, the reduced solve in one workgroup; one upload, one stream of launches, one download, one wait.
+ * On MI355X a canonical 10-keyframe window takes 1.2 ms per call this way against 1.7 ms through uvs_solve_window() (which keeps the
+ * whole solve on one compute unit and is what a BATCH of windows uses per window).  Same LM controller, same results to rounding
+ * (tests/test_fused_single.py); relocalization blocks are only taken by uvs_solve_window(). */
 typedef struct uvs_rccl_id { char internal[128]; } uvs_rccl_id;      /* == ncclUniqueId */
 int uvs_large_comm_unique_id(uvs_rccl_id *id);
 int uvs_large_comm_init(uvs_solver *s, int nranks, int rank, const uvs_rccl_id *id);
