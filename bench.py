@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--no-prior", action="store_true")
     ap.add_argument("--no-replay", action="store_true", help="skip the closed-loop sequence replay (profiling runs)")
     ap.add_argument("--no-large", action="store_true", help="skip the configs[3] large-window timing (profiling runs)")
+    ap.add_argument("--no-fused-single", action="store_true", help="skip the multi-workgroup form of the single window (keeps a kernel trace of the configs[3] leg clean)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -208,12 +209,12 @@ def main():
         # the same window through the multi-workgroup fused loop (landmark chunks on many CUs, reduced solve in one workgroup, control on the device)
         solver.large_comm_init(None)
         fl_loop, fl_call = [], []
-        for i in range(7):
+        for i in range(0 if args.no_fused_single else 7):
             _, frep, lms = solver.large_solve_fused(windows[0])
             if i >= 2: fl_loop.append(lms); fl_call.append(solver.last_solve_ms)
         single = {"workload": "BASELINE configs[1]: one resident W10-P150-L40-V3 window (with the n = 75 prior), one launch per solve",
                   "ms": sw_ms, "solves_per_s": 1e3 / sw_ms, "pcie_inclusive_ms": pcie * 1e3, "pcie_inclusive_solves_per_s": 1.0 / pcie,
-                  "multi_workgroup": {"what": "uvs_large_solve_fused on the same window: the LM loop as a stream of launches over many compute units (an otherwise idle GPU), what the host mirror's Estimator::optimization() uses",
+                  "multi_workgroup": None if args.no_fused_single else {"what": "uvs_large_solve_fused on the same window: the LM loop as a stream of launches over many compute units (an otherwise idle GPU), what the host mirror's Estimator::optimization() uses",
                                       "lm_loop_ms": float(np.median(fl_loop)), "call_ms_with_packing_and_pcie": float(np.median(fl_call)), "solves_per_s_call": 1e3 / float(np.median(fl_call)),
                                       "lm_iterations": int(frep.num_iterations), "final_cost": float(frep.final_cost)},
                   "roofline": {"bound": "mfma", "kernel": "uvsdev::k_solve (1 workgroup on 1 of 256 CUs)", "achieved": sw_fl / (sw_ms * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS,

@@ -8,7 +8,7 @@ TAG=${1:-r01}
 R=$(pwd)
 export TMPDIR=/tmp
 CMD="python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-replay --no-large"
-LCMD="python $R/bench.py --steps 2 --warmup 1 --batch 4 --no-cpu-baseline --no-replay"      # the configs[3] window through the fused loop (kernel trace only)
+LCMD="python $R/bench.py --steps 2 --warmup 1 --batch 4 --no-cpu-baseline --no-replay --no-fused-single"      # the configs[3] window through the fused loop (kernel trace only)
 cd /tmp
 rm -rf $R/gpurun_out/prof_kt $R/gpurun_out/prof_fetch $R/gpurun_out/prof_write $R/gpurun_out/prof_sq $R/gpurun_out/prof_sq2
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_kt -o runc -- $CMD > $R/gpurun_out/prof_kt.log 2>&1
@@ -18,7 +18,10 @@ rocprofv3 --pmc SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_
 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INSTS_SALU SQ_INSTS_SMEM --kernel-trace --output-format csv -d $R/gpurun_out/prof_sq2 -o runc -- $CMD > $R/gpurun_out/prof_sq2.log 2>&1
 rm -rf $R/gpurun_out/prof_large
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_large -o runc -- $LCMD > $R/gpurun_out/prof_large.log 2>&1
+rm -rf $R/gpurun_out/prof_single_fused
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_single_fused -o runc -- python $R/tools/single_vs_fused.py > $R/gpurun_out/prof_single_fused.log 2>&1      # ONE canonical window through both single-window forms
 cd $R
 python profiles/summarize.py $TAG      # printed for the log; gpurun only merges gpurun_out/ back, so re-run these two lines locally afterwards:
 #   python profiles/summarize.py $TAG && cp gpurun_out/prof_kt/runc_kernel_stats.csv profiles/${TAG}_kernel_stats_bench256.csv
 #   cp gpurun_out/prof_large/runc_kernel_stats.csv profiles/${TAG}_kernel_stats_large.csv
+#   cp gpurun_out/prof_single_fused/runc_kernel_stats.csv profiles/${TAG}_kernel_stats_single_window_fused.csv

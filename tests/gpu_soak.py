@@ -1,6 +1,7 @@
 """Randomised parity soak (run by hand on the GPU box): N random windows of varying shape (landmark counts, track lengths, noise,
 with / without prior, VP share) solved by the HIP library and by the oracle; reports the worst pose / landmark / cost deviation and
-every window whose iteration count or accept pattern differs.   python tests/gpu_soak.py [N] [seed0]"""
+every window whose iteration count or accept pattern differs.   python tests/gpu_soak.py [N] [seed0] [persistent|fused]
+(the third argument picks the single-window form: the persistent kernel, default, or the multi-workgroup fused loop)"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -9,6 +10,7 @@ from oracle_binding import Oracle
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 5000
+fused = len(sys.argv) > 3 and sys.argv[3] == "fused"
 o = Oracle(); s = uvs.api.Solver(max_batch=2, max_points=400, max_point_obs=4400, max_lines=120, max_line_obs=1320)
 rng = np.random.default_rng(seed0)
 worst = dict(dp=0.0, dq=0.0, cost=0.0, invd=0.0, line=0.0); mism = []; t0 = time.time()
@@ -21,7 +23,9 @@ for i in range(N):
         w = synth.make_window(seed0 + i, with_prior=prior, marginalize_fn=(lambda win, flag: s.marginalize(win, flag)) if prior else None, **kw)
     except Exception as e:
         print("gen failed", i, kw, e); continue
-    sg, rg = s.solve(w); so, ro = o.solve(w)
+    if fused: sg, rg, _ = s.large_solve_fused(w)
+    else: sg, rg = s.solve(w)
+    so, ro = o.solve(w)
     same = rg.num_iterations == ro.num_iterations and list(rg.accepted[:rg.num_iterations + 1]) == list(ro.accepted[:ro.num_iterations + 1]) and rg.termination == ro.termination
     dp, dq = pose_deltas(sg.pose, so.pose)
     dc = abs(rg.final_cost - ro.final_cost) / max(ro.final_cost, 1e-300)

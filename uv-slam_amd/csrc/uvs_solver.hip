@@ -32,7 +32,8 @@ struct uvs_solver {
     int device;
     int max_batch;
     int max_points = 0, max_point_obs = 0, max_lines = 0, max_line_obs = 0;      // per-window capacities promised at uvs_create
-    int n_cus = 256;                         // compute units of the device (grid of the persistent large-window kernels)
+    int n_cus = 256;                         // compute units of the device
+    int chunk_wgs() const { return std::max(1, n_cus - 1); }      // chunk workgroups of the persistent large-window kernels: one compute unit stays free for the frame-terms workgroup of the same launch
     hipStream_t stream;
     hipEvent_t ev0, ev1;
     std::string err;
@@ -935,13 +936,13 @@ int uvs_large_begin(uvs_solver* s, const uvs_window* w) {
     if (!s || !w) return UVS_ERR_INVALID_ARG;
     if (w->n_relo_obs > 0) { s->err = "relocalization blocks are not taken by the large-window path"; return UVS_ERR_UNSUPPORTED; }
     const uvs_window* arr[1] = {w};
-    int rc = upload_windows(s, 1, arr, true, s->n_cus);
+    int rc = upload_windows(s, 1, arr, true, s->chunk_wgs());
     if (rc != UVS_OK) return rc;
     auto& L = s->L; const DevWin& h = s->hdrs[0];
     double* keep_ctl = L.d_ctl; uvs_report* keep_rep = L.d_rep; void* keep_comm = L.comm; const int keep_rank = L.rank, keep_nranks = L.nranks; double* keep_fimg = L.d_fimg;
     L = uvs_solver::Large{L.active, 0, 0, 0, 0, 0, 0, 0, 0, true, true, false, 0, 2, 0, 0, 0, 0, L.d_state, L.d_partials, L.d_reduced, L.d_bsums, L.d_out, L.d_sc5, L.cap_partials, L.cap_bsums, {}};
     L.active = true; L.n_chunks = h.n_chunks; L.radius = s->opts.initial_trust_region_radius;
-    L.grid = std::min(h.n_chunks, s->n_cus);
+    L.grid = std::min(h.n_chunks, s->chunk_wgs());
     L.d_ctl = keep_ctl; L.d_rep = keep_rep; L.comm = keep_comm; L.rank = keep_rank; L.nranks = keep_nranks; L.d_fimg = keep_fimg;
     if (!L.d_state) { HIPCHK(s, hipMalloc((void**)&L.d_state, LG_STATE * 8)); HIPCHK(s, hipMalloc((void**)&L.d_reduced, LG_XCH * 8)); HIPCHK(s, hipMemset(L.d_reduced, 0, LG_XCH * 8)); HIPCHK(s, hipMalloc((void**)&L.d_out, 64 * 8)); HIPCHK(s, hipMalloc((void**)&L.d_sc5, 8 * 8)); }
     if (!L.d_fimg) HIPCHK(s, hipMalloc((void**)&L.d_fimg, LG_FIMG * 8));
@@ -1167,14 +1168,14 @@ int uvs_large_solve_fused(uvs_solver* s, const uvs_window* w, uvs_state* out, uv
     // ONE stream, ONE wait: pinned upload -> k_large_init -> the passes -> k_large_pack -> pinned download.  (The step-wise API keeps
     // uvs_large_begin's host-side copies; here every small copy / memset is a line of k_large_init.)
     const uvs_window* arr[1] = {w};
-    int rc = upload_windows(s, 1, arr, false, s->n_cus);
+    int rc = upload_windows(s, 1, arr, false, s->chunk_wgs());
     if (rc != UVS_OK) return rc;
     auto& L = s->L; const DevWin& h = s->hdrs[0]; const uvs_options& o = s->opts;
     {
         double* keep_ctl = L.d_ctl; uvs_report* keep_rep = L.d_rep; void* keep_comm = L.comm; const int keep_rank = L.rank, keep_nranks = L.nranks; double* keep_fimg = L.d_fimg;
         L = uvs_solver::Large{L.active, 0, 0, 0, 0, 0, 0, 0, 0, true, true, false, 0, 2, 0, 0, 0, 0, L.d_state, L.d_partials, L.d_reduced, L.d_bsums, L.d_out, L.d_sc5, L.cap_partials, L.cap_bsums, {}};
         L.active = true; L.n_chunks = h.n_chunks; L.radius = o.initial_trust_region_radius;
-        L.grid = std::min(h.n_chunks, s->n_cus);
+        L.grid = std::min(h.n_chunks, s->chunk_wgs());
         L.d_ctl = keep_ctl; L.d_rep = keep_rep; L.comm = keep_comm; L.rank = keep_rank; L.nranks = keep_nranks; L.d_fimg = keep_fimg;
     }
     if (!L.d_state) { HIPCHK(s, hipMalloc((void**)&L.d_state, LG_STATE * 8)); HIPCHK(s, hipMalloc((void**)&L.d_reduced, LG_XCH * 8)); HIPCHK(s, hipMalloc((void**)&L.d_out, 64 * 8)); HIPCHK(s, hipMalloc((void**)&L.d_sc5, 8 * 8)); }
