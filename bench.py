@@ -38,12 +38,17 @@ FP64_PEAK_TFLOPS = 78.6      # MI355X FP64 vector = FP64 matrix (datasheet; not 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
+K_SOLVE_SOURCES = ("uvs_solve_kernel.h", "uvs_factors.h", "uvs_layout.h", "uvs_solver.hip")      # k_solve's device code + the packing that lays its inputs out
+
+
 def kernel_source_tag():
-    """sha1 over the kernel sources: profiles/pmc_traffic.json carries the tag of the build it was measured on (profiles/summarize.py)."""
+    """sha1 over the sources that determine k_solve's memory traffic (its device code and pack_window): profiles/pmc_traffic.json carries the
+    tag of the build it was measured on (profiles/summarize.py).  The marginalization / evaluation / large-window sources are left out: they
+    do not run in the profiled launch."""
     import hashlib
     h = hashlib.sha1()
     d = os.path.join(ROOT, "uv-slam_amd", "csrc")
-    for f in sorted(os.listdir(d)):
+    for f in K_SOLVE_SOURCES:
         h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
