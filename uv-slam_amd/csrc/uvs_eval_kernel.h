@@ -112,7 +112,10 @@ struct EvalScratch {
 };
 
 // host driver: blob of window 0 must already be on the device (uvs_batch_upload)
-static int run_evaluate(int device, hipStream_t stream, char* d_blob, double* d_ws, const DevWin& h, const KOpts& ko, int robust, uvs_eval* out, std::string& err, EvalScratch& sc) {
+// `view` (marginalization): *out receives POINTERS into the pinned staging buffer instead of copies into caller arrays (valid until the next
+// call on this handle), and the device buffer is not cleared first -- the subset mode writes, and the caller reads, only the selected blocks.
+static int run_evaluate(int device, hipStream_t stream, char* d_blob, double* d_ws, const DevWin& h, const KOpts& ko, int robust, uvs_eval* out, std::string& err, EvalScratch& sc,
+                        bool view = false) {
     auto chk = [&](hipError_t e, const char* what) { if (e != hipSuccess) { err = std::string(what) + ": " + hipGetErrorString(e); return false; } return true; };
     if (!chk(hipSetDevice(device), "hipSetDevice")) return UVS_ERR_HIP;
     const size_t npo = (size_t)std::max(h.n_pt_obs, 1), nlo = (size_t)std::max(h.n_ln_obs, 1), ni = (size_t)std::max(h.n_imu, 1);
@@ -131,7 +134,7 @@ static int run_evaluate(int device, hipStream_t stream, char* d_blob, double* d_
         sc.hcap = tot;
     }
     double* d = sc.d;
-    if (!chk(hipMemsetAsync(d, 0, tot * 8, stream), "memset(eval)")) return UVS_ERR_HIP;
+    if (!view && !chk(hipMemsetAsync(d, 0, tot * 8, stream), "memset(eval)")) return UVS_ERR_HIP;
     EvalOut eo; double* p = d;
     eo.pt_r = p; p += sizes[0]; eo.pt_J = p; p += sizes[1]; eo.ln_r = p; p += sizes[2]; eo.ln_J = p; p += sizes[3]; eo.vp_r = p; p += sizes[4];
     eo.vp_J = p; p += sizes[5]; eo.imu_r = p; p += sizes[6]; eo.imu_J = p; p += sizes[7]; eo.prior_r = p; p += sizes[8]; eo.cost = p; p += sizes[9]; eo.pt_Jtd = p;
@@ -140,6 +143,12 @@ static int run_evaluate(int device, hipStream_t stream, char* d_blob, double* d_
     const bool ok = chk(hipGetLastError(), "k_evaluate launch") && chk(hipMemcpyAsync(sc.h, d, tot * 8, hipMemcpyDeviceToHost, stream), "memcpy D2H(eval)") &&
                     chk(hipStreamSynchronize(stream), "k_evaluate");
     if (!ok) return UVS_ERR_HIP;
+    if (view) {
+        auto at = [&](const double* dsrc) { return sc.h + (dsrc - d); };
+        out->pt_r = at(eo.pt_r); out->pt_J = at(eo.pt_J); out->ln_r = at(eo.ln_r); out->ln_J = at(eo.ln_J); out->vp_r = at(eo.vp_r); out->vp_J = at(eo.vp_J);
+        out->imu_r = at(eo.imu_r); out->imu_J = at(eo.imu_J); out->prior_r = at(eo.prior_r); out->cost = *at(eo.cost); out->pt_Jtd = h.td_on ? at(eo.pt_Jtd) : nullptr;
+        return UVS_OK;
+    }
     auto back = [&](double* dst, const double* dsrc, size_t n) { if (dst && n) std::memcpy(dst, sc.h + (dsrc - d), n * 8); };
     back(out->pt_r, eo.pt_r, 2 * (size_t)(h.n_pt_obs - h.n_relo)); back(out->pt_J, eo.pt_J, 38 * (size_t)(h.n_pt_obs - h.n_relo));
     back(out->ln_r, eo.ln_r, 2 * (size_t)h.n_ln_obs); back(out->ln_J, eo.ln_J, 20 * (size_t)h.n_ln_obs);

@@ -62,13 +62,46 @@ static void host_sym_eig_jacobi(int n, std::vector<double>& M, std::vector<doubl
 // Eigen-decomposition of a dense symmetric matrix (row-major n x n; V: eigenvectors in columns, unsorted): Householder reduction to
 // tridiagonal form followed by the implicit-shift QL iteration -- the textbook tred2 / tql2 pair, i.e. the same family of algorithm
 // as Eigen's SelfAdjointEigenSolver that the reference calls (marginalization_factor.cpp:263,278), ~(4/3) n^3 + O(n^2) per sweep flops
-// instead of the ~10 sweeps x 6 n^3 of a cyclic Jacobi (3.2 ms -> 0.2 ms for n = 69 on the box's host core).
+// instead of the ~10 sweeps x 6 n^3 of a cyclic Jacobi (3.2 ms -> 0.25 ms for n = 69 on the box's host core).
+// The working matrix is kept TRANSPOSED (T[j][i] = V(i, j)): every O(n^3) loop of the pair runs down a column of V, which is then a
+// contiguous row of T -- unit stride, vectorisable (an AVX2 clone is selected at load time; contraction off, so both clones produce the
+// same bits).  The n = 69 factorisation is the largest single piece of a marginalization.
+#if !defined(__HIP_DEVICE_COMPILE__)
+#define UVS_HOST_SIMD __attribute__((target_clones("arch=haswell", "default")))
+#else
+#define UVS_HOST_SIMD
+#endif
+#pragma clang fp contract(off)
+UVS_HOST_SIMD static void eig_axpy2(int n, double* __restrict col, const double* __restrict e, const double* __restrict d, double f, double g) {      // col[k] -= f e[k] + g d[k]
+    for (int k = 0; k < n; ++k) col[k] -= (f * e[k] + g * d[k]);
+}
+UVS_HOST_SIMD static double eig_dot_axpy(int n, const double* __restrict col, const double* __restrict d, double* __restrict e, double f, double g) {   // g += col . d ; e += f col
+    {
+#pragma clang fp reassociate(on)      // the dot product may be summed in vector lanes (a different rounding of a Householder inner product, nothing else)
+        double acc = 0.0;
+        for (int k = 0; k < n; ++k) acc += col[k] * d[k];
+        g += acc;
+    }
+    for (int k = 0; k < n; ++k) e[k] += col[k] * f;
+    return g;
+}
+UVS_HOST_SIMD static double eig_dot(int n, const double* __restrict a, const double* __restrict b) {
+#pragma clang fp reassociate(on)
+    double acc = 0.0;
+    for (int k = 0; k < n; ++k) acc += a[k] * b[k];
+    return acc;
+}
+UVS_HOST_SIMD static void eig_axpy(int n, double* __restrict col, const double* __restrict d, double g) { for (int k = 0; k < n; ++k) col[k] -= g * d[k]; }
+UVS_HOST_SIMD static void eig_rotate(int n, double* __restrict a, double* __restrict b, double c, double s) {      // a = column i, b = column i + 1 of V
+    for (int k = 0; k < n; ++k) { const double h = b[k]; b[k] = s * a[k] + c * h; a[k] = c * a[k] - s * h; }
+}
 static void host_sym_eig(int n, std::vector<double>& M, std::vector<double>& V, std::vector<double>& lam) {
-    V = M; lam.assign(n, 0.0);
-    if (n == 0) return;
-    std::vector<double> e(n, 0.0);
+    lam.assign(n, 0.0);
+    if (n == 0) { V.clear(); return; }
+    std::vector<double> T(M), e(n, 0.0);      // M is symmetric: its transpose is itself
     double* d = lam.data();
-    auto at = [&](int i, int j) -> double& { return V[(size_t)i * n + j]; };
+    auto at = [&](int i, int j) -> double& { return T[(size_t)j * n + i]; };      // V(i, j)
+    auto colp = [&](int j) -> double* { return &T[(size_t)j * n]; };               // column j of V, contiguous
     // ---- Householder tridiagonalisation (row n-1 of V carries the current vector)
     for (int j = 0; j < n; ++j) d[j] = at(n - 1, j);
     for (int i = n - 1; i > 0; --i) {
@@ -85,8 +118,7 @@ static void host_sym_eig(int n, std::vector<double>& M, std::vector<double>& V, 
             for (int j = 0; j < i; ++j) e[j] = 0.0;
             for (int j = 0; j < i; ++j) {
                 f = d[j]; at(j, i) = f; g = e[j] + at(j, j) * f;
-                for (int k = j + 1; k <= i - 1; ++k) { g += at(k, j) * d[k]; e[k] += at(k, j) * f; }
-                e[j] = g;
+                e[j] = eig_dot_axpy(i - 1 - j, colp(j) + j + 1, d + j + 1, e.data() + j + 1, f, g);      // k = j + 1 .. i - 1
             }
             f = 0.0;
             for (int j = 0; j < i; ++j) { e[j] /= h; f += e[j] * d[j]; }
@@ -94,7 +126,7 @@ static void host_sym_eig(int n, std::vector<double>& M, std::vector<double>& V, 
             for (int j = 0; j < i; ++j) e[j] -= hh * d[j];
             for (int j = 0; j < i; ++j) {
                 f = d[j]; g = e[j];
-                for (int k = j; k <= i - 1; ++k) at(k, j) -= (f * e[k] + g * d[k]);
+                eig_axpy2(i - j, colp(j) + j, e.data() + j, d + j, f, g);                                  // k = j .. i - 1
                 d[j] = at(i - 1, j); at(i, j) = 0.0;
             }
         }
@@ -105,11 +137,11 @@ static void host_sym_eig(int n, std::vector<double>& M, std::vector<double>& V, 
         at(n - 1, i) = at(i, i); at(i, i) = 1.0;
         const double h = d[i + 1];
         if (h != 0.0) {
-            for (int k = 0; k <= i; ++k) d[k] = at(k, i + 1) / h;
+            const double* ci = colp(i + 1);
+            for (int k = 0; k <= i; ++k) d[k] = ci[k] / h;
             for (int j = 0; j <= i; ++j) {
-                double g = 0.0;
-                for (int k = 0; k <= i; ++k) g += at(k, i + 1) * at(k, j);
-                for (int k = 0; k <= i; ++k) at(k, j) -= g * d[k];
+                const double g = eig_dot(i + 1, ci, colp(j));
+                eig_axpy(i + 1, colp(j), d, g);
             }
         }
         for (int k = 0; k <= i; ++k) at(k, i + 1) = 0.0;
@@ -141,10 +173,10 @@ static void host_sym_eig(int n, std::vector<double>& M, std::vector<double>& V, 
                 const double el1 = e[l + 1];
                 for (int i = m - 1; i >= l; --i) {
                     c3 = c2; c2 = c; s2 = s;
-                    g = c * e[i]; h = c * p; r = std::hypot(p, e[i]);
+                    g = c * e[i]; h = c * p; r = std::sqrt(p * p + e[i] * e[i]);      // (entries are <= 1e15 in magnitude: no overflow guard needed)
                     e[i + 1] = s * r; s = e[i] / r; c = p / r; p = c * d[i] - s * g;
                     d[i + 1] = h + s * (c * g + s * d[i]);
-                    for (int k = 0; k < n; ++k) { h = at(k, i + 1); at(k, i + 1) = s * at(k, i) + c * h; at(k, i) = c * at(k, i) - s * h; }
+                    eig_rotate(n, colp(i), colp(i + 1), c, s);
                 }
                 p = -s * s2 * c3 * el1 * e[l] / dl1;
                 e[l] = s * p; d[l] = c * p;
@@ -152,7 +184,10 @@ static void host_sym_eig(int n, std::vector<double>& M, std::vector<double>& V, 
         }
         d[l] += f; e[l] = 0.0;
     }
+    V.assign((size_t)n * n, 0.0);      // back to the callers' convention: row-major V, eigenvectors in columns
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) V[(size_t)i * n + j] = T[(size_t)j * n + i];
 }
+#pragma clang fp contract(on)
 
 struct MFactor { int rows; int nb; int id[5]; int sz[5]; const double* r; const double* J; int ld; int coff[5]; const double* Jx; int xcol; };   // J row stride ld, column offset per block; block with coff < 0 reads its single column from Jx[row stride 1... 2 entries]   // J row stride ld, column offset per block
 
@@ -162,19 +197,16 @@ static int run_marginalize(int device, hipStream_t stream, char* d_blob, double*
     const double eps = 1e-8;                           // marginalization_factor.h:70
     const int NFR = UVS_NF;
     // ---- GPU: evaluate all blocks with loss correction at the window's (post-solve) state
-    std::vector<double> pt_r(2 * (size_t)std::max(h.n_pt_obs, 1)), pt_J(38 * (size_t)std::max(h.n_pt_obs, 1)), ln_r(2 * (size_t)std::max(h.n_ln_obs, 1)),
-        ln_J(20 * (size_t)std::max(h.n_ln_obs, 1)), vp_r((size_t)std::max(h.n_ln_obs, 1)), vp_J(10 * (size_t)std::max(h.n_ln_obs, 1)),
-        imu_r(15 * (size_t)std::max(h.n_imu, 1)), imu_J(450 * (size_t)std::max(h.n_imu, 1)), prior_r(UVS_MAX_PRIOR_DIM), pt_Jtd(2 * (size_t)std::max(h.n_pt_obs, 1));
-    uvs_eval ev; ev.pt_r = pt_r.data(); ev.pt_J = pt_J.data(); ev.ln_r = ln_r.data(); ev.ln_J = ln_J.data(); ev.vp_r = vp_r.data(); ev.vp_J = vp_J.data();
-    ev.imu_r = imu_r.data(); ev.imu_J = imu_J.data(); ev.prior_r = prior_r.data(); ev.cost = 0.0; ev.pt_Jtd = td_on ? pt_Jtd.data() : nullptr;
+    uvs_eval ev; std::memset(&ev, 0, sizeof(ev));      // views into the handle's pinned staging buffer (run_evaluate, view mode)
     const bool prof = std::getenv("UVS_MARG_PROFILE") != nullptr;
     auto tnow = [] { return std::chrono::steady_clock::now(); };
     auto t0 = tnow();
     // MARGIN_OLD reads only the factors that touch frame 0 (a fifth of the window): the kernel skips the rest (mode bit 1); MARGIN_SECOND_NEW
     // reads the prior residual only, which the same subset mode delivers without evaluating a single observation of frame 0... it does evaluate
     // those, a few microseconds, to keep one code path
-    int rc = run_evaluate(device, stream, d_blob, d_ws, h, ko, 1 | 2, &ev, err, sc);
+    int rc = run_evaluate(device, stream, d_blob, d_ws, h, ko, 1 | 2, &ev, err, sc, true);
     if (rc != UVS_OK) return rc;
+    const double *pt_r = ev.pt_r, *pt_J = ev.pt_J, *ln_r = ev.ln_r, *ln_J = ev.ln_J, *vp_r = ev.vp_r, *vp_J = ev.vp_J, *imu_r = ev.imu_r, *imu_J = ev.imu_J, *prior_r = ev.prior_r, *pt_Jtd = ev.pt_Jtd;
     auto t1 = tnow();
     // ---- host: block bookkeeping.  ids: pose f -> f ; speedbias f -> 11+f ; ex -> 22 ; td -> 23 ; point k -> 24+k ; line l -> 24+Np+l
     const int Np = w->n_points, Nl = w->n_lines, PT0 = 24, NID = PT0 + Np + Nl;

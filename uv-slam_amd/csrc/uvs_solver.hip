@@ -914,12 +914,19 @@ int uvs_marginalize_resident(uvs_solver* s, const uvs_window* w, int flag, uvs_p
     }
     HIPCHK(s, hipSetDevice(s->device));
     // state sections of the resident blob: frames[184] = pose | speedbias | ex_pose | td, inverse depths, line parameters
-    double fr[184];
+    // staged in the pinned upload buffer (copies from the caller's pageable arrays would each be a synchronous staging round trip)
+    const size_t nst = 184 + (size_t)h.n_points + 4 * (size_t)h.n_lines;
+    HIPCHK(s, hipStreamSynchronize(s->stream));      // the staging buffer may still feed an earlier copy
+    int rcp;
+    if ((rcp = ensure_pinned(s, &s->h_up, &s->h_up_cap, nst * 8)) != UVS_OK) return rcp;
+    double* fr = (double*)s->h_up;
     std::memcpy(fr, w->pose, 77 * 8); std::memcpy(fr + 77, w->speedbias, 99 * 8); std::memcpy(fr + 176, w->ex_pose, 7 * 8); fr[183] = w->td;
+    if (h.n_points) std::memcpy(fr + 184, w->inv_depth, (size_t)h.n_points * 8);
+    if (h.n_lines) std::memcpy(fr + 184 + h.n_points, w->line_orth, (size_t)h.n_lines * 32);
     char* blob = s->d_blobs + s->blob_off[0];
-    HIPCHK(s, hipMemcpyAsync(blob + (size_t)h.d_frames * 8, fr, sizeof(fr), hipMemcpyHostToDevice, s->stream));
-    if (h.n_points) HIPCHK(s, hipMemcpyAsync(blob + (size_t)h.d_invd * 8, w->inv_depth, (size_t)h.n_points * 8, hipMemcpyHostToDevice, s->stream));
-    if (h.n_lines) HIPCHK(s, hipMemcpyAsync(blob + (size_t)h.d_line * 8, w->line_orth, (size_t)h.n_lines * 32, hipMemcpyHostToDevice, s->stream));
+    HIPCHK(s, hipMemcpyAsync(blob + (size_t)h.d_frames * 8, fr, 184 * 8, hipMemcpyHostToDevice, s->stream));
+    if (h.n_points) HIPCHK(s, hipMemcpyAsync(blob + (size_t)h.d_invd * 8, fr + 184, (size_t)h.n_points * 8, hipMemcpyHostToDevice, s->stream));
+    if (h.n_lines) HIPCHK(s, hipMemcpyAsync(blob + (size_t)h.d_line * 8, fr + 184 + h.n_points, (size_t)h.n_lines * 32, hipMemcpyHostToDevice, s->stream));
     return run_marginalize(s->device, s->stream, s->d_blobs, s->d_ws, s->hdrs[0], w, make_kopts(s->opts, 0), flag, out, s->err, s->eval_scratch);
 }
 
