@@ -187,6 +187,7 @@ static void host_sym_eig(int n, std::vector<double>& M, std::vector<double>& V, 
     V.assign((size_t)n * n, 0.0);      // back to the callers' convention: row-major V, eigenvectors in columns
     for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) V[(size_t)i * n + j] = T[(size_t)j * n + i];
 }
+UVS_HOST_SIMD static void row_axpy(int n, double* __restrict y, const double* __restrict x, double a) { for (int k = 0; k < n; ++k) y[k] += a * x[k]; }      // y[0..n) += a x
 #pragma clang fp contract(on)
 
 struct MFactor { int rows; int nb; int id[5]; int sz[5]; const double* r; const double* J; int ld; int coff[5]; const double* Jx; int xcol; };   // J row stride ld, column offset per block; block with coff < 0 reads its single column from Jx[row stride 1... 2 entries]   // J row stride ld, column offset per block
@@ -274,7 +275,8 @@ static int run_marginalize(int device, hipStream_t stream, char* d_blob, double*
     const int n = N - m;
     if (n > UVS_MAX_PRIOR_DIM || (int)keep_ids.size() > UVS_MAX_PRIOR_BLOCKS) { err = "prior capacity"; return UVS_ERR_CAPACITY; }
     // ---- A = sum J^T J, b = sum J^T r   (ThreadsConstructA, :141-172)
-    std::vector<double> A((size_t)N * N, 0.0), bv(N, 0.0);
+    std::vector<double>&A = sc.work[0], &bv = sc.work[1];      // (kept in the handle's scratch: see EvalScratch::work)
+    A.assign((size_t)N * N, 0.0); bv.assign(N, 0.0);
     if (!p_id.empty()) {
         const uvs_prior& p = *w->prior; const int pn = p.n, nc = (int)p_id.size();
         std::vector<int> gc(nc);
@@ -282,7 +284,8 @@ static int run_marginalize(int device, hipStream_t stream, char* d_blob, double*
         // J0^T J0 is the single largest piece of the assembly (n^3 / 1 multiply-adds): only the half c2 <= a is accumulated, into a dense
         // nc x nc scratch with the gathered row contiguous, and mirrored when scattered (same products, same summation order over i, so
         // the values are the ones the full loop produced)
-        std::vector<double> P((size_t)nc * nc, 0.0), rowv(nc);
+        std::vector<double>&P = sc.work[2], &rowv = sc.work[3];
+        P.assign((size_t)nc * nc, 0.0); rowv.assign(nc, 0.0);
         for (int i = 0; i < pn; ++i) {
             const double* Ji = &p.linearized_jacobians[(size_t)i * pn];
             for (int a = 0; a < nc; ++a) rowv[a] = Ji[p_src[a]];
@@ -290,8 +293,7 @@ static int run_marginalize(int device, hipStream_t stream, char* d_blob, double*
                 const double ja = rowv[a];
                 if (ja == 0.0) continue;
                 bv[gc[a]] += ja * prior_r[i];
-                double* Pa = &P[(size_t)a * nc];
-                for (int c2 = 0; c2 <= a; ++c2) Pa[c2] += ja * rowv[c2];
+                row_axpy(a + 1, &P[(size_t)a * nc], rowv.data(), ja);      // P[a][c2] += ja * rowv[c2], c2 <= a (same products, same order over i)
             }
         }
         for (int a = 0; a < nc; ++a) for (int c2 = 0; c2 <= a; ++c2) {
@@ -350,7 +352,7 @@ static int run_marginalize(int device, hipStream_t stream, char* d_blob, double*
         }
     };
     std::vector<int> coupled; coupled.reserve(N);
-    std::vector<double> Xk;
+    std::vector<double>&Xk = sc.work[4], &Uk = sc.work[5];
     for (int id = PT0; id < NID; ++id) {
         if (!(used[id] && drop[id])) continue;
         const int o = pos[id], sz = lsize(id);
@@ -362,16 +364,25 @@ static int run_marginalize(int device, hipStream_t stream, char* d_blob, double*
         Xk.assign((size_t)sz * ldx, 0.0);                                  // X = B^+ [A_{block, coupled} | b_block]
         for (int q = 0; q < sz; ++q) { for (int cj = 0; cj < nc; ++cj) Xk[(size_t)q * ldx + cj] = A[(size_t)(o + q) * N + coupled[cj]]; Xk[(size_t)q * ldx + nc] = bv[o + q]; }
         solve_small(sz, Bm, Xk.data(), ldx, ldx);
+        // U = A_{coupled, block} X  (nc x (nc + 1), contiguous rows: the inner loops vectorise), then scattered; per entry the sum over q runs in
+        // the same order as the scalar loop it replaces
+        Uk.assign((size_t)nc * ldx, 0.0);
+        for (int ci = 0; ci < nc; ++ci) {
+            const double* ai = &A[(size_t)coupled[ci] * N + o];
+            double* u = &Uk[(size_t)ci * ldx];
+            for (int q = 0; q < sz; ++q) row_axpy(ldx, u, &Xk[(size_t)q * ldx], ai[q]);
+        }
         for (int ci = 0; ci < nc; ++ci) {
             const int i = coupled[ci];
-            const double* ai = &A[(size_t)i * N + o];
-            double tb = 0.0; for (int q = 0; q < sz; ++q) tb += ai[q] * Xk[(size_t)q * ldx + nc];
-            bv[i] -= tb;
-            for (int cj = 0; cj < nc; ++cj) { double t = 0.0; for (int q = 0; q < sz; ++q) t += ai[q] * Xk[(size_t)q * ldx + cj]; A[(size_t)i * N + coupled[cj]] -= t; }
+            const double* u = &Uk[(size_t)ci * ldx];
+            double* Ai = &A[(size_t)i * N];
+            bv[i] -= u[nc];
+            for (int cj = 0; cj < nc; ++cj) Ai[coupled[cj]] -= u[cj];
         }
     }
     auto t3 = tnow();
-    std::vector<double> Sd((size_t)md * md), Xd((size_t)md * (n + 1)), Ar((size_t)n * n), br(n);
+    std::vector<double> Sd((size_t)md * md), Xd((size_t)md * (n + 1)), br(n);
+    std::vector<double>& Ar = sc.work[6]; Ar.assign((size_t)n * n, 0.0);
     for (int i = 0; i < md; ++i) for (int j = 0; j < md; ++j) Sd[(size_t)i * md + j] = 0.5 * (A[(size_t)i * N + j] + A[(size_t)j * N + i]);
     for (int i = 0; i < md; ++i) { for (int j = 0; j < n; ++j) Xd[(size_t)i * (n + 1) + j] = A[(size_t)i * N + m + j]; Xd[(size_t)i * (n + 1) + n] = bv[i]; }
     solve_small(md, Sd.data(), Xd.data(), n + 1, n + 1);                   // X = S^+ [A_dr | b_d]
@@ -381,7 +392,8 @@ static int run_marginalize(int device, hipStream_t stream, char* d_blob, double*
         for (int j = 0; j < n; ++j) { double t = ad[m + j]; for (int k = 0; k < md; ++k) t -= ad[k] * Xd[(size_t)k * (n + 1) + j]; Ar[(size_t)i * n + j] = t; }
     }
     // ---- second eigen-decomposition -> J0 = sqrt(S) V^T, r0 = sqrt(S^-1) V^T b   (:278-291); lower triangle is read, like Eigen
-    std::vector<double> As((size_t)n * n), V2, lam2;
+    std::vector<double>&As = sc.work[7], &V2 = sc.work[8], &lam2 = sc.work[9];
+    As.assign((size_t)n * n, 0.0);
     for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) As[(size_t)i * n + j] = (j <= i) ? Ar[(size_t)i * n + j] : Ar[(size_t)j * n + i];
     auto t4 = tnow();
     host_sym_eig(n, As, V2, lam2);
