@@ -16,6 +16,16 @@ def solver(gpu_api):
     s.close()
 
 
+FORMS = ("persistent", "fused")      # uvs_solve_window (one workgroup per window) / uvs_large_solve_fused (many workgroups, one window)
+
+
+def _solve(solver, w, form):
+    if form == "fused":
+        st, rep, _ = solver.large_solve_fused(w)
+        return st, rep
+    return solver.solve(w)
+
+
 def _same_solution(sg, rg, so, ro, tol=1e-6):
     assert rg.status == 0 and rg.num_iterations == ro.num_iterations
     assert list(rg.accepted[: rg.num_iterations + 1]) == list(ro.accepted[: ro.num_iterations + 1])
@@ -26,14 +36,16 @@ def _same_solution(sg, rg, so, ro, tol=1e-6):
 
 @pytest.mark.parametrize("kw", [dict(n_lines=0, n_tagged=0), dict(n_points=0), dict(n_points=7, n_lines=3, n_tagged=2),
                                 dict(n_tagged=0), dict(pt_track=9, ln_track=10), dict(pt_track=2, ln_track=5)])
-def test_landmark_family_corner_cases(solver, oracle, kw):
+@pytest.mark.parametrize("form", FORMS)
+def test_landmark_family_corner_cases(solver, oracle, kw, form):
     w = synth.make_window(60, **kw)
-    sg, rg = solver.solve(w)
+    sg, rg = _solve(solver, w, form)
     so, ro = oracle.solve(w)
     _same_solution(sg, rg, so, ro)
 
 
-def test_ragged_tracks(solver, oracle):
+@pytest.mark.parametrize("form", FORMS)
+def test_ragged_tracks(solver, oracle, form):
     """Tracks of different lengths and start frames (the reference's tracks are whatever the front-end delivers)."""
     w = synth.make_window(61)
     rng = np.random.default_rng(5)
@@ -44,17 +56,18 @@ def test_ragged_tracks(solver, oracle):
             keep_p[obs[int(rng.integers(1, len(obs))):]] = False
     for name in ("pt_lm", "pt_fi", "pt_fj", "pt_pi", "pt_pj"):
         setattr(w, name, getattr(w, name)[keep_p])
-    sg, rg = solver.solve(w)
+    sg, rg = _solve(solver, w, form)
     so, ro = oracle.solve(w)
     _same_solution(sg, rg, so, ro)
 
 
-def test_skipped_imu_blocks(solver, oracle):
+@pytest.mark.parametrize("form", FORMS)
+def test_skipped_imu_blocks(solver, oracle, form):
     """pre_integrations[j]->sum_dt > 10 s => the IMU factor is not added (estimator.cpp:814-815)."""
     w = synth.make_window(62)
     for b in (2, 7):
         w.imu[b]["skip"] = 1
-    sg, rg = solver.solve(w)
+    sg, rg = _solve(solver, w, form)
     so, ro = oracle.solve(w)
     _same_solution(sg, rg, so, ro)
 
@@ -73,12 +86,13 @@ def test_prior_from_the_products_own_marginalization(solver, oracle):
     assert np.abs(Hg - Ho).max() <= 1e-6 * np.abs(Ho).max()
 
 
-def test_zero_and_one_iterations(gpu_api, oracle):
+@pytest.mark.parametrize("form", FORMS)
+def test_zero_and_one_iterations(gpu_api, oracle, form):
     w = synth.make_window(64)
     for n in (0, 1):
         o = abi.default_options(); o.max_num_iterations = n
         s = gpu_api.Solver(opts=o, max_batch=1)
-        sg, rg = s.solve(w)
+        sg, rg = _solve(s, w, form)
         s.close()
         so, ro = oracle.solve(w, opts=o)
         assert rg.num_iterations == ro.num_iterations == n
