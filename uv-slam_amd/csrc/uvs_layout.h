@@ -88,7 +88,7 @@ struct DevWin {
     int32_t w_ltrig0, w_ltrig1;                        // sin/cos of the four orthonormal line angles, [n_lines][8], one per parameter buffer (k_solve only)
     int32_t w_scale_pt, w_scale_ln;                   // Jacobi scales of landmark parameters
     int32_t w_pt_E, w_pt_x;           // Einv store 6*(n_pt_obs+n_points) ; per point {ginv, g, dd, 0}
-    int32_t w_ln_Y, w_ln_x;           // Y store 24*n_ln_obs ; per line {Hinv*g[4], g[4], dd[4]}
+    int32_t w_ln_Y, w_ln_x;           // Y store 24*n_ln_obs ; per line UVS_LN_X doubles {Hinv*g[4], g[4], dd[4], H[10]}
     int32_t w_imu;                    // per block: Jraw[450] Jw[450] rraw[15] rw[15] (pad 936)
     int32_t w_out;                    // final state: frames[UVS_XDIM] | inv_depth[n_points] | line_orth[4 n_lines] (k_solve; the large path reads the cur buffers)
     int32_t w_prior_img;              // J0^T J0 scattered into S block layout: n_pblk x 272 doubles (written by setup_window, added per linearization)
@@ -99,6 +99,9 @@ struct DevWin {
     int32_t cur_sel;                  // written by the kernel: which landmark buffer holds the final state
     int32_t max_chunk_doubles;        // LDS doubles the fullest chunk occupies in the staging area (records + Schur factors + lists; <= UVS_S_DOUBLES; informational)
     int32_t n_parts;                  // largest number of parts any pose block is split into (informational; gacc_gather_parts sums them in one step)
+    int32_t w_gacc;                   // the gather accumulators of the last full linearization, [UVS_NT][8 * UVS_GROWS] (k_solve: re-damping after a rejected step)
+    int32_t redamp_ok;                // 1: k_solve may re-damp the last linearization after a rejected step instead of linearizing again (no pseudo-frame blocks; every line chunk has room for the tables)
 };
 
 #define UVS_WIMU_STRIDE 936
+#define UVS_LN_X 24               // workspace doubles per line: Hinv g [4] | g [4] | damping [4] | undamped H = J_l^T J_l, lower packed [10] | 2 spare

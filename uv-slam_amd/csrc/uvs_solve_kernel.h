@@ -711,8 +711,12 @@ UVS_DEV void gather_walk(const int* ent, int e0, int e1, Load load, Use use) {
 }
 
 // EXT = the window has pseudo-frame blocks (ESTIMATE_TD / ESTIMATE_EXTRINSIC); the default instantiation folds all their special cases away
-template <bool EXT>
-UVS_DEV void gather_points(int grp, const int* lists, const double* S0, GAcc& A) {
+// DELTA (re-damping after a rejected step, see redamp_chunk): only the Schur walk runs -- the staged "E H_ll^-1" rows hold E times the CHANGE of
+// H_ll^-1, so the walk adds the change of the Schur complement -- and the diagonal blocks also take the change of the reduced gradient,
+// - E_a (H_ll^-1 g_l)_new + E_a (H_ll^-1 g_l)_old, from the rows staged `goff` doubles from the E rows (a diagonal block's Schur entries are
+// exactly one (slot, slot) pair per landmark seen in its frame).
+template <bool EXT, bool DELTA = false>
+UVS_DEV void gather_points(int grp, const int* lists, const double* S0, GAcc& A, int goff = 0) {
     const int g = lane_tid() / UVS_GLANES, r0 = GR * (lane_tid() % UVS_GLANES);
     const bool on = grp >= 0;
     const bool diag = on && ((grp >> 8) & 1);
@@ -724,7 +728,7 @@ UVS_DEV void gather_points(int grp, const int* lists, const double* S0, GAcc& A)
     const int* ent = lists + LIST_HDR;
     // ---- Schur: acc[r][c] -= E_a[r0 + r] * Einv_b[c], two entries per stage
     {
-        struct Ops { double ea[2][GR]; d2_t q[2][3]; };
+        struct Ops { double ea[2][GR]; d2_t q[2][3]; double gg[2][DELTA ? GR : 1]; };
         const int e0 = on ? lists[g] : 0, e1 = on ? lists[g + 1] : 0;
         gather_walk<2, Ops>(ent, e0, e1,
             [&](int, const int* w, Ops& o) {
@@ -735,6 +739,10 @@ UVS_DEV void gather_points(int grp, const int* lists, const double* S0, GAcc& A)
 #pragma unroll
                     for (int r = 0; r < GR; ++r) o.ea[u][r] = pa[r];
                     o.q[u][0] = lds2(pb); o.q[u][1] = lds2(pb + 2); o.q[u][2] = lds2(pb + 4);
+                    if (DELTA) {
+#pragma unroll
+                        for (int r = 0; r < GR; ++r) o.gg[u][r] = pa[goff + r];
+                    }
                 }
             },
             [&](int i, Ops& o) {
@@ -743,9 +751,14 @@ UVS_DEV void gather_points(int grp, const int* lists, const double* S0, GAcc& A)
                     const bool ok = i + u < e1;
 #pragma unroll
                     for (int r = 0; r < GR; ++r) row_fma(A.v + 6 * r, ok ? -o.ea[u][r] : 0.0, o.q[u]);
+                    if (DELTA) {
+#pragma unroll
+                        for (int r = 0; r < GR; ++r) A.g[r] -= (ok && diag) ? o.gg[u][r] : 0.0;
+                    }
                 }
             });
     }
+    if (DELTA) return;
     // ---- direct: acc[r][c] += J1[0][r0+r] J2[0][c] + J1[1][r0+r] J2[1][c] ; diagonal blocks (J1 == J2) also g and diag(J^T J)
     {
         struct Ops { double p0[GR], p1[GR]; d2_t q0[3], q1[3], rc; };
@@ -772,17 +785,21 @@ UVS_DEV void gather_points(int grp, const int* lists, const double* S0, GAcc& A)
     }
 }
 
-UVS_DEV void gather_lines(int grp, const int* lists, const double* S0, GAcc& A) {
+// DELTA: as for the points; the gradient rows are one 6-vector per observation at S0 + goff + (E offset - eoff) / 4 (E rows are 24 doubles per observation)
+template <bool DELTA = false>
+UVS_DEV void gather_lines(int grp, const int* lists, const double* S0, GAcc& A, int goff = 0, int eoff = 0) {
     const int g = lane_tid() / UVS_GLANES, r0 = GR * (lane_tid() % UVS_GLANES);
     const bool on = grp >= 0;
+    const bool diag = on && ((grp >> 8) & 1);
     const int* ent = lists + LIST_HDR;
     // ---- Schur: acc[r][c] -= sum_q E_a[q][r0 + r] * Y_b[q][c]
     {
-        struct Ops { double ea[4][GR]; d2_t y[4][3]; };
+        struct Ops { double ea[4][GR]; d2_t y[4][3]; double gg[DELTA ? GR : 1]; };
         const int e0 = on ? lists[g] : 0, e1 = on ? lists[g + 1] : 0;
         gather_walk<1, Ops>(ent, e0, e1,
             [&](int, const int* w, Ops& o) {
-                const double* pa = S0 + (w[0] & 0x7fff) + r0;
+                const int lo = w[0] & 0x7fff;
+                const double* pa = S0 + lo + r0;
                 const double* pb = S0 + ((unsigned)w[0] >> 16);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -790,14 +807,24 @@ UVS_DEV void gather_lines(int grp, const int* lists, const double* S0, GAcc& A) 
                     for (int r = 0; r < GR; ++r) o.ea[q][r] = pa[6 * q + r];
                     o.y[q][0] = lds2(pb + 6 * q); o.y[q][1] = lds2(pb + 6 * q + 2); o.y[q][2] = lds2(pb + 6 * q + 4);
                 }
+                if (DELTA) {
+                    const double* pg = S0 + goff + ((lo - eoff) >> 2) + r0;
+#pragma unroll
+                    for (int r = 0; r < GR; ++r) o.gg[r] = pg[r];
+                }
             },
             [&](int, Ops& o) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
 #pragma unroll
                     for (int r = 0; r < GR; ++r) row_fma(A.v + 6 * r, -o.ea[q][r], o.y[q]);
+                if (DELTA) {
+#pragma unroll
+                    for (int r = 0; r < GR; ++r) A.g[r] -= diag ? o.gg[r] : 0.0;
+                }
             });
     }
+    if (DELTA) return;
     // ---- direct (always a diagonal block): 3 pose-Jacobian rows (line, line, vanishing point) + corrected residuals
     {
         struct Ops { double p[3][GR]; d2_t q[3][3], rc01; double rc2; };
@@ -939,6 +966,35 @@ UVS_DEV double lin_imu(const Ctx& c, const double* x, ImuN& N) {
     return cost;
 }
 UVS_DEV double lin_frames(const Ctx& c, const double* x, ImuN& N) { const double pc = lin_prep(c, x); return pc + lin_imu(c, x, N); }
+
+// Inverse of a damped 4 x 4 line block (lower packed H) through its Cholesky factor, written to X[4][4] (may be LDS), and hg = H^-1 g.
+// One reciprocal square root per pivot (an FP64 division is ~30 instructions; the factor + explicit inverse had 26 of them on ONE lane per
+// line while the other lanes of the workgroup wait): sqrt and reciprocal sqrt together from the hardware seed + FMA-only refinement.
+UVS_DEV void spd4_inverse(const double* H, const double* gl, double* X, double* hg) {
+    double L[10];
+    double i0, i1, i2, i3;
+    rsqrt_pair(H[0], &L[0], &i0);
+    L[1] = H[1] * i0; rsqrt_pair(H[2] - L[1] * L[1], &L[2], &i1);
+    L[3] = H[3] * i0; L[4] = (H[4] - L[3] * L[1]) * i1; rsqrt_pair(H[5] - L[3] * L[3] - L[4] * L[4], &L[5], &i2);
+    L[6] = H[6] * i0; L[7] = (H[7] - L[6] * L[1]) * i1; L[8] = (H[8] - L[6] * L[3] - L[7] * L[4]) * i2;
+    rsqrt_pair(H[9] - L[6] * L[6] - L[7] * L[7] - L[8] * L[8], &L[9], &i3);
+    hg[0] = 0.0; hg[1] = 0.0; hg[2] = 0.0; hg[3] = 0.0;
+#pragma unroll
+    for (int cidx = 0; cidx < 4; ++cidx) {
+        double e[4] = {0, 0, 0, 0}; e[cidx] = 1.0;
+        e[0] = e[0] * i0;
+        e[1] = (e[1] - L[1] * e[0]) * i1;
+        e[2] = (e[2] - L[3] * e[0] - L[4] * e[1]) * i2;
+        e[3] = (e[3] - L[6] * e[0] - L[7] * e[1] - L[8] * e[2]) * i3;
+        e[3] = e[3] * i3;
+        e[2] = (e[2] - L[8] * e[3]) * i2;
+        e[1] = (e[1] - L[4] * e[2] - L[7] * e[3]) * i1;
+        e[0] = (e[0] - L[1] * e[1] - L[3] * e[2] - L[6] * e[3]) * i0;
+        X[0 * 4 + cidx] = e[0]; X[1 * 4 + cidx] = e[1]; X[2 * 4 + cidx] = e[2]; X[3 * 4 + cidx] = e[3];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) hg[a] += e[a] * gl[cidx];
+    }
+}
 
 // ---- linearization, part 2: one landmark chunk: stage -> per-landmark Schur prep -> list-driven gather into acc[]
 UVS_DEV void lin_chunk(const Ctx& c, int ch, const double* x, const double* invd, const double* line, bool first, double radius,
@@ -1115,7 +1171,9 @@ UVS_DEV void lin_chunk(const Ctx& c, int ch, const double* x, const double* invd
                         for (int b = 0; b <= a; ++b) H[(a * (a + 1)) / 2 + b] += R[UVS_LN_JL + a] * R[UVS_LN_JL + b] + R[UVS_LN_JL + 4 + a] * R[UVS_LN_JL + 4 + b] + R[UVS_LN_JL + 8 + a] * R[UVS_LN_JL + 8 + b];
                     }
                 }
-                double* lx = c.ws + h.w_ln_x + 12 * (size_t)k;
+                double* lx = c.ws + h.w_ln_x + UVS_LN_X * (size_t)k;
+#pragma unroll
+                for (int q = 0; q < 10; ++q) lx[12 + q] = H[q];      // undamped: what a re-damping after a rejected step starts from
 #pragma unroll
                 for (int a = 0; a < 4; ++a) {
                     const double hd = H[(a * (a + 1)) / 2 + a];
@@ -1126,35 +1184,10 @@ UVS_DEV void lin_chunk(const Ctx& c, int ch, const double* x, const double* invd
                     lx[4 + a] = gl[a]; lx[8 + a] = dd;
                     gmax_lm = fmax(gmax_lm, fabs(gl[a]));
                 }
-                // Cholesky of the 4x4 and explicit inverse
-                // one reciprocal per pivot (an FP64 division is ~30 instructions; the 4x4 factor + explicit inverse had 26 of them on ONE lane per
-                // line while the other lanes of the workgroup wait)
-                double L[10];
-                // pivots: sqrt and reciprocal sqrt together from the hardware seed + FMA-only refinement (rsqrt_pair): the sqrt / divide pairs were
-                // ~60 dependent instructions per pivot on the one lane that owns the line
-                double i0, i1, i2, i3;
-                rsqrt_pair(H[0], &L[0], &i0);
-                L[1] = H[1] * i0; rsqrt_pair(H[2] - L[1] * L[1], &L[2], &i1);
-                L[3] = H[3] * i0; L[4] = (H[4] - L[3] * L[1]) * i1; rsqrt_pair(H[5] - L[3] * L[3] - L[4] * L[4], &L[5], &i2);
-                L[6] = H[6] * i0; L[7] = (H[7] - L[6] * L[1]) * i1; L[8] = (H[8] - L[6] * L[3] - L[7] * L[4]) * i2;
-                rsqrt_pair(H[9] - L[6] * L[6] - L[7] * L[7] - L[8] * L[8], &L[9], &i3);
+                // Cholesky of the damped 4x4 and explicit inverse
                 double* X = Xb + 20 * li;
-                double hg[4] = {0, 0, 0, 0};
-#pragma unroll
-                for (int cidx = 0; cidx < 4; ++cidx) {
-                    double e[4] = {0, 0, 0, 0}; e[cidx] = 1.0;
-                    e[0] = e[0] * i0;
-                    e[1] = (e[1] - L[1] * e[0]) * i1;
-                    e[2] = (e[2] - L[3] * e[0] - L[4] * e[1]) * i2;
-                    e[3] = (e[3] - L[6] * e[0] - L[7] * e[1] - L[8] * e[2]) * i3;
-                    e[3] = e[3] * i3;
-                    e[2] = (e[2] - L[8] * e[3]) * i2;
-                    e[1] = (e[1] - L[4] * e[2] - L[7] * e[3]) * i1;
-                    e[0] = (e[0] - L[1] * e[1] - L[3] * e[2] - L[6] * e[3]) * i0;
-                    X[0 * 4 + cidx] = e[0]; X[1 * 4 + cidx] = e[1]; X[2 * 4 + cidx] = e[2]; X[3 * 4 + cidx] = e[3];
-#pragma unroll
-                    for (int a = 0; a < 4; ++a) hg[a] += e[a] * gl[cidx];
-                }
+                double hg[4];
+                spd4_inverse(H, gl, X, hg);
 #pragma unroll
                 for (int a = 0; a < 4; ++a) { X[16 + a] = hg[a]; lx[a] = hg[a]; }
             }
@@ -1193,6 +1226,136 @@ UVS_DEV void lin_chunk(const Ctx& c, int ch, const double* x, const double* invd
             gather_lines(grp, lists, rec, acc);
         }
     }
+}
+
+// ---- re-damping: what a REJECTED step needs instead of a new linearization.  x has not moved, so every Jacobian, the cost and the direct
+// J^T J sums are what they were; only the trust-region radius -- the damping of the landmark blocks and of the frame diagonal -- is new
+// (Ceres does not re-evaluate the Jacobian after an unsuccessful step either).  The Schur complement is linear in H_ll^-1:
+//     S_new = S_old - sum_l E_a^T ((H_ll + D_new)^-1 - (H_ll + D_old)^-1) E_b ,   g_new = g_old - sum_l E_a^T ((H_ll + D)^-1 g_l)_{new - old}
+// and E = J_l^T J_p comes back from the back-substitution store of the last linearization (E (H_ll + D_old)^-1 per slot for points,
+// (H_ll + D_old)^-1 E per observation for lines, whose undamped 4 x 4 H_ll sits in the workspace).  Per chunk: recover E, stage E and E times
+// the CHANGE of the inverse where lin_chunk stages E and E H^-1, run the Schur half of the gather (DELTA), rewrite the store and the
+// per-landmark scalars for the back-substitution.  No observation is evaluated, no direct term is gathered: ~7 k cycles per chunk against ~25 k.
+UVS_DEV void redamp_chunk(const Ctx& c, int ch, double radius, int grp, GAcc& acc) {
+    const DevWin& h = *c.hdr;
+    double* sh = c.sh;
+    const int tid = lane_tid();
+    const int* chunks = c.bi + h.i_chunks;
+    const int type = chunks[6 * ch], k0 = chunks[6 * ch + 1], k1 = chunks[6 * ch + 2];
+    const int* glists = c.bi + h.i_lists + chunks[6 * ch + 3];
+    const int nlist = chunks[6 * ch + 4];
+    const int nlm = k1 - k0;
+    __syncthreads();     // previous users of the S region are done
+    double* rec = sh + L_S;
+    if (type == 0) {
+        const int* beg = c.bi + h.i_pt_beg;
+        const int o0 = beg[k0], o1 = beg[k1], nob = o1 - o0;
+        const int PREC = h.pt_rec, XS = h.pt_xslots;      // (XS == 1: no pseudo-frame slots, see DevWin::redamp_ok)
+        double* Gb = rec;                                        // [(nob + XS nlm)][6]  E times the change of H_ll^-1 g_l
+        double* Eb = rec + (size_t)nob * PREC;                   // same places as in lin_chunk: the lists address them
+        double* EIb = Eb + (size_t)(nob + XS * nlm) * 6;
+        int* lists = (int*)(EIb + (size_t)(nob + XS * nlm) * 6);
+        for (int t = tid; t < nlist; t += NT) lists[t] = glists[t];
+        for (int li = tid; li < nlm; li += NT) {
+            const int k = k0 + li, b0 = beg[k] - o0, ns = beg[k + 1] - beg[k] + XS;
+            if (ns == XS) continue;      // a landmark without observations has no entries in the lists and no scalars in the workspace
+            double* px = c.ws + h.w_pt_x + 4 * (size_t)k;
+            const double gl = px[1], dd_old = px[2], hd = px[3], sc = c.ws[h.w_scale_pt + k];
+            const double dd = fmin(fmax(sc * sc * hd, c.o.dlo), c.o.dhi) / (radius * sc * sc);
+            const double hdo = hd + dd_old, hinv = 1.0 / (hd + dd), dh = hinv - 1.0 / hdo;
+            double* Eg = c.ws + h.w_pt_E + 6 * (size_t)(beg[k] + XS * k);
+            const int s0 = 6 * (b0 + XS * li);
+            for (int sl = 0; sl < ns; ++sl) {
+                double e[6];
+#pragma unroll
+                for (int a = 0; a < 6; ++a) e[a] = Eg[6 * sl + a] * hdo;
+#pragma unroll
+                for (int a = 0; a < 6; ++a) { Eb[s0 + 6 * sl + a] = e[a]; EIb[s0 + 6 * sl + a] = e[a] * dh; Gb[s0 + 6 * sl + a] = e[a] * dh * gl; Eg[6 * sl + a] = e[a] * hinv; }
+            }
+            px[0] = gl * hinv; px[2] = dd;
+        }
+        __syncthreads();
+        gather_points<false, true>(grp, lists, rec, acc, -nob * PREC);
+    } else {
+        const int* beg = c.bi + h.i_ln_beg;
+        const int o0 = beg[k0], o1 = beg[k1], nob = o1 - o0;
+        double* T = rec;                                         // [nlm][34]: (H + D_new)^-1 [16] | change of (H + D)^-1 g [4] | H [10] | D_old [4]
+        double* Gb = rec + (size_t)nlm * 34;                     // [nob][6]
+        double* Eb = rec + (size_t)nob * UVS_LN_REC;             // same places as in lin_chunk
+        double* Yb = Eb + (size_t)nob * 24;
+        double* Xb = Yb + (size_t)nob * 24;
+        int* lists = (int*)(Xb + 20 * nlm);
+        for (int t = tid; t < nlist; t += NT) lists[t] = glists[t];
+        for (int li = tid; li < nlm; li += NT) {
+            const int k = k0 + li;
+            double* lx = c.ws + h.w_ln_x + UVS_LN_X * (size_t)k;
+            double H[10], gl[4], ddo[4], hgo[4], hg[4];
+#pragma unroll
+            for (int q = 0; q < 10; ++q) H[q] = lx[12 + q];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) { hgo[a] = lx[a]; gl[a] = lx[4 + a]; ddo[a] = lx[8 + a]; }
+            double* t = T + 34 * li;
+#pragma unroll
+            for (int q = 0; q < 10; ++q) t[20 + q] = H[q];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const double hd = H[(a * (a + 1)) / 2 + a], sc = c.ws[h.w_scale_ln + 4 * k + a];
+                const double dd = fmin(fmax(sc * sc * hd, c.o.dlo), c.o.dhi) / (radius * sc * sc);
+                H[(a * (a + 1)) / 2 + a] = hd + dd;
+                t[30 + a] = ddo[a]; lx[8 + a] = dd;
+            }
+            spd4_inverse(H, gl, t, hg);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) { t[16 + a] = hg[a] - hgo[a]; lx[a] = hg[a]; }
+        }
+        __syncthreads();
+        for (int o = tid; o < nob; o += NT) {
+            const int li = c.bi[h.i_ln_lm + o0 + o] - k0;
+            double tv[34], yo[24];
+#pragma unroll
+            for (int q = 0; q < 34; ++q) tv[q] = T[34 * li + q];
+            double* Yg = c.ws + h.w_ln_Y + 24 * (size_t)(o0 + o);
+#pragma unroll
+            for (int q = 0; q < 24; ++q) yo[q] = Yg[q];
+            double* E = Eb + (size_t)o * 24; double* Y = Yb + (size_t)o * 24; double* G = Gb + (size_t)o * 6;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                double e[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {      // E = (H + D_old) Y_old
+                    double v = tv[30 + q] * yo[6 * q + a];
+#pragma unroll
+                    for (int p2 = 0; p2 < 4; ++p2) { const int hi_ = q > p2 ? q : p2, lo_ = q > p2 ? p2 : q; v += tv[20 + (hi_ * (hi_ + 1)) / 2 + lo_] * yo[6 * p2 + a]; }
+                    e[q] = v; E[6 * q + a] = v;
+                }
+                double ga = 0.0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const double yn = tv[4 * q] * e[0] + tv[4 * q + 1] * e[1] + tv[4 * q + 2] * e[2] + tv[4 * q + 3] * e[3];
+                    Y[6 * q + a] = yn - yo[6 * q + a]; Yg[6 * q + a] = yn;
+                    ga += e[q] * tv[16 + q];
+                }
+                G[a] = ga;
+            }
+        }
+        __syncthreads();
+        gather_lines<true>(grp, lists, rec, acc, nlm * 34, nob * UVS_LN_REC);
+    }
+}
+// the gather accumulators of the last full linearization live in the workspace between the linearization and a possible re-damping
+UVS_DEV void gacc_store(const Ctx& c, const GAcc& A) {
+    double* p = c.ws + c.hdr->w_gacc + (size_t)lane_tid() * (8 * GR);
+#pragma unroll
+    for (int q = 0; q < 6 * GR; ++q) p[q] = A.v[q];
+#pragma unroll
+    for (int q = 0; q < GR; ++q) { p[6 * GR + q] = A.g[q]; p[7 * GR + q] = A.hd[q]; }
+}
+UVS_DEV void gacc_load(const Ctx& c, GAcc& A) {
+    const double* p = c.ws + c.hdr->w_gacc + (size_t)lane_tid() * (8 * GR);
+#pragma unroll
+    for (int q = 0; q < 6 * GR; ++q) A.v[q] = p[q];
+#pragma unroll
+    for (int q = 0; q < GR; ++q) { A.g[q] = p[6 * GR + q]; A.hd[q] = p[7 * GR + q]; }
 }
 
 // ---- linearization, part 3: assemble the damped reduced system in LDS from the gathered pose blocks + IMU + prior
@@ -1410,9 +1573,24 @@ UVS_DEV void linearize(const Ctx& c, const double* x, const double* invd, const 
     GAcc A; gacc_zero(A);
     { const double pc = lin_prep(c, x, prep_mode); lacc_set(c.sh, pc, 0.0); }
     for (int ch = 0; ch < h.n_chunks; ++ch) lin_chunk(c, ch, x, invd, line, first, radius, grp, A);
+    if (h.redamp_ok) gacc_store(c, A);
     ImuN N;
     const double ic = lin_imu(c, x, N);
     lin_assemble(c, x, first, radius, grp, A, N, lacc_cost(c.sh) + ic, lacc_gmax(c.sh));
+}
+
+// After a rejected / invalid step: the same point, a smaller radius.  The per-lane cost / gradient-norm accumulators of the linearization
+// (L_LCOST / L_LGMAX) still hold their values.
+UVS_DEV void relinearize_damping(const Ctx& c, const double* x, double radius) {
+    const DevWin& h = *c.hdr;
+    const int grp = gather_group(c);
+    GAcc A; gacc_load(c, A);
+    (void)lin_prep(c, x, 2);
+    for (int ch = 0; ch < h.n_chunks; ++ch) redamp_chunk(c, ch, radius, grp, A);
+    gacc_store(c, A);
+    ImuN N;
+    const double ic = lin_imu(c, x, N);
+    lin_assemble(c, x, false, radius, grp, A, N, lacc_cost(c.sh) + ic, lacc_gmax(c.sh));
 }
 
 // ------------------------------------------------------------------ back-substitution + candidate + model terms
@@ -1506,7 +1684,7 @@ UVS_DEV void backsub_candidate(const Ctx& c, const double* invd, const double* l
     const int* lbeg = c.bi + h.i_ln_beg;
     for (int k = lk0 + tid; k < lk1; k += NT) {
         const int b0 = lbeg[k], b1 = lbeg[k + 1];
-        const double* lx = c.ws + h.w_ln_x + 12 * (size_t)k;
+        const double* lx = c.ws + h.w_ln_x + UVS_LN_X * (size_t)k;
         double t[4] = {0.0, 0.0, 0.0, 0.0};
         for (int o = b0; o < b1; o += LNB) {      // LNB observations per batch (LNB x 24 independent loads: one round trip per batch)
             int fr[LNB]; double yv[LNB][24];
@@ -1736,6 +1914,10 @@ __global__ __launch_bounds__(NT) void k_solve(char* blobs, const long long* blob
     while (true) {
         if (it >= o.max_it && !first) { term = UVS_TERM_NO_CONVERGENCE; break; }
         if (need_lin) {
+#ifndef UVS_X_NO_REDAMP
+            if (prep_mode == 2 && !first && h.redamp_ok) relinearize_damping(c, sh + L_X, radius);
+            else
+#endif
             linearize(c, sh + L_X, invd[cur], line[cur], first, radius, prep_mode);
             need_lin = false;
             const double lc = sh[L_CTRL + C_COST];

@@ -534,6 +534,10 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
         }
     }
     h.n_chunks = (int)chunks.size() / 6;
+    // re-damping (uvs_solve_kernel.h: redamp_chunk) keeps its per-line table and gradient rows in the record area of a line chunk
+    h.redamp_ok = (!td_on && !ex_on && !relo_on) ? 1 : 0;
+    for (int qc = 0; qc < h.n_chunks && h.redamp_ok; ++qc)
+        if (chunks[6 * qc] == 1) { const long nob = lbeg[chunks[6 * qc + 2]] - lbeg[chunks[6 * qc + 1]], nlm = chunks[6 * qc + 2] - chunks[6 * qc + 1]; if (34 * nlm + 6 * nob > (long)UVS_LN_REC * nob) h.redamp_ok = 0; }
     lap_("lists");
     // layout
     int d = (int)((sizeof(DevWin) + 7) / 8);
@@ -601,7 +605,8 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
     h.w_ltrig0 = wsz; wsz += 8 * std::max(h.n_lines, 1); h.w_ltrig1 = wsz; wsz += 8 * std::max(h.n_lines, 1);
     h.w_scale_pt = wsz; wsz += rup(std::max(h.n_points, 1), 2); h.w_scale_ln = wsz; wsz += 4 * std::max(h.n_lines, 1);
     h.w_pt_E = wsz; wsz += 6 * (h.n_pt_obs + XS * h.n_points) + 6; h.w_pt_x = wsz; wsz += 4 * std::max(h.n_points, 1);
-    h.w_ln_Y = wsz; wsz += 24 * std::max(h.n_ln_obs, 1); h.w_ln_x = wsz; wsz += 12 * std::max(h.n_lines, 1);
+    h.w_ln_Y = wsz; wsz += 24 * std::max(h.n_ln_obs, 1); h.w_ln_x = wsz; wsz += UVS_LN_X * std::max(h.n_lines, 1);
+    h.w_gacc = wsz; wsz += UVS_NT * 8 * UVS_GROWS;
     h.w_imu = wsz; wsz += std::max(h.n_imu, 1) * UVS_WIMU_STRIDE;
     h.w_out = wsz; wsz += UVS_XDIM + std::max(h.n_points, 0) + 4 * std::max(h.n_lines, 0);
     h.n_pblk = (int)pblk.size();
