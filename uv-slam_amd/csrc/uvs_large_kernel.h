@@ -30,7 +30,7 @@ static constexpr int LG_MAXRANKS = 8;
 // frame image written by the extra workgroup of k_large_chunks: S without the landmark blocks and without damping | gradient | diag(J^T J) | {cost of the frame terms}
 static constexpr int FI_S = 0, FI_G = UVS_S_DOUBLES, FI_HD = FI_G + UVS_RD, FI_COST = FI_HD + UVS_RD, LG_FIMG = FI_COST + 8;
 static constexpr int LX_X2 = LG_RED, LX_GMAX = LG_RED + 1, LG_XCH = LG_RED + 1 + LG_MAXRANKS + 7;      // 5016 doubles
-enum { LC_RADIUS = 0, LC_DECR, LC_COST, LC_GMAX, LC_XNORM, LC_FRAME_X2, LC_IT, LC_INVALID, LC_NSUCC, LC_PENDING, LC_TERM, LC_STATUS, LC_FIRST, LC_DONE, LC_SEL, LC_N };
+enum { LC_RADIUS = 0, LC_DECR, LC_COST, LC_GMAX, LC_XNORM, LC_FRAME_X2, LC_IT, LC_INVALID, LC_NSUCC, LC_PENDING, LC_TERM, LC_STATUS, LC_FIRST, LC_DONE, LC_SEL, LC_REDAMP, LC_N };      // LC_REDAMP: the last step was rejected / invalid => the next pass re-damps the same linearization
 struct LargeCtl { const double* ctl; int rank, nranks; };      // ctl == nullptr: the step-wise API (host-side control, arguments as given)
 
 
@@ -45,8 +45,12 @@ __global__ __launch_bounds__(NT) void k_large_chunks(char* blob, double* ws, KOp
     if (lc.ctl) { if (lc.ctl[LC_DONE] != 0.0) return; sel = (int)lc.ctl[LC_SEL]; first = (int)lc.ctl[LC_FIRST]; radius = lc.ctl[LC_RADIUS]; }
     Ctx c; c.hdr = (const DevWin*)blob; c.bd = (const double*)blob; c.bi = (const int*)blob; c.ws = ws; c.sh = sh; c.o = o; c.o.debug = 0;
     const DevWin& h = *c.hdr;
+    // after a rejected step (fused loop): same point, new radius -- the landmark partials are UPDATED by the change of their Schur terms
+    // (redamp_chunk), the frame image (undamped) stays as it is
+    const bool redamp = lc.ctl && lc.ctl[LC_REDAMP] != 0.0 && !first && h.redamp_ok;
     if (tid < 184) sh[L_X + tid] = state[LS_X + tid];
     if ((int)blockIdx.x == n_chunk_wgs) {
+        if (redamp) return;
         if (first) setup_window(c, (double*)blob);
         __syncthreads();
         ImuN N; GAcc none; gacc_zero(none);
@@ -69,7 +73,7 @@ __global__ __launch_bounds__(NT) void k_large_chunks(char* blob, double* ws, KOp
     const double* invd = ws + (sel ? h.w_invd1 : h.w_invd0); const double* line = ws + (sel ? h.w_line1 : h.w_line0);
     // PERSISTENT workgroups: workgroup b takes chunks b, b + gridDim.x, ... and accumulates them into ONE partial (the host sizes the chunks so
     // that their number is a multiple of the grid: 340 LDS-filling chunks on 256 CUs were two full rounds for 1.33 rounds of work)
-    for (int ch = blockIdx.x; ch < h.n_chunks; ch += n_chunk_wgs) lin_chunk(c, ch, sh + L_X, invd, line, first != 0, radius, grp, A);
+    for (int ch = blockIdx.x; ch < h.n_chunks; ch += n_chunk_wgs) { if (redamp) redamp_chunk(c, ch, radius, grp, A); else lin_chunk(c, ch, sh + L_X, invd, line, first != 0, radius, grp, A); }
     double cost = lacc_cost(sh), gmax = lacc_gmax(sh);
     // canonical partial [pose block][row a][8] (6 block entries, gradient, diag(J^T J)), staged in LDS so that the two halves of a
     // split block are summed in a fixed order and the HBM write is coalesced
@@ -94,6 +98,7 @@ __global__ __launch_bounds__(NT) void k_large_chunks(char* blob, double* ws, KOp
         __syncthreads();
     }
     double* P = partials + (size_t)blockIdx.x * LG_RED;
+    if (redamp) { for (int i = tid; i < LG_ACC; i += NT) P[i] += sh[L_S + i]; return; }      // cost and landmark gradient norm of the partial are unchanged
     for (int i = tid; i < LG_ACC; i += NT) P[i] = sh[L_S + i];
     double s4[4] = {cost, 0, 0, 0};
     block_reduce(sh, s4, &gmax);
@@ -276,7 +281,7 @@ __global__ __launch_bounds__(256) void k_large_decide(double* ctl, double* state
             const bool ok = out[LO_CHOLOK] != 0.0 && isfinite(mcc) && isfinite(step2);
             rep->model_cost_change[ti] = mcc;
             if (!ok || !(mcc > 0.0)) {
-                ++invalid; radius /= decr; decr *= 2.0;
+                ++invalid; radius /= decr; decr *= 2.0; ctl[LC_REDAMP] = 1.0;
                 rep->accepted[ti] = -1; rep->cost[ti] = cost; rep->candidate_cost[ti] = cost; rep->radius[ti] = radius; rep->gradient_max_norm[ti] = gmax;
                 if (invalid >= o.max_invalid) { term = UVS_TERM_INVALID_STEPS; done = true; }
             } else {
@@ -290,7 +295,7 @@ __global__ __launch_bounds__(256) void k_large_decide(double* ctl, double* state
                 else if (fabs(cost - cand) <= o.ftol * cost) { term = UVS_TERM_FUNCTION_TOL; stop = true; }
                 if (stop && !(o.keep_cand && successful)) done = true;
                 else if (successful) {
-                    accept_sh = 1;
+                    accept_sh = 1; ctl[LC_REDAMP] = 0.0;
                     sel ^= 1; ++nsucc; x_norm = sqrt(xc2);
                     { const double t3 = 2.0 * rel - 1.0; radius = radius / fmax(1.0 / 3.0, 1.0 - t3 * t3 * t3); }
                     radius = fmin(o.rmax, radius); decr = 2.0;
@@ -298,7 +303,7 @@ __global__ __launch_bounds__(256) void k_large_decide(double* ctl, double* state
                     rep->accepted[ti] = 1; rep->cost[ti] = cost; rep->radius[ti] = radius;
                     if (stop || it >= o.max_it) { if (!stop) term = UVS_TERM_NO_CONVERGENCE; done = true; }
                 } else {
-                    radius /= decr; decr *= 2.0;
+                    radius /= decr; decr *= 2.0; ctl[LC_REDAMP] = 1.0;
                     rep->accepted[ti] = 0; rep->radius[ti] = radius;
                     if (it >= o.max_it) { term = UVS_TERM_NO_CONVERGENCE; done = true; }
                 }
