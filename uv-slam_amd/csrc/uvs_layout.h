@@ -99,7 +99,6 @@ struct DevWin {
     int32_t cur_sel;                  // written by the kernel: which landmark buffer holds the final state
     int32_t max_chunk_doubles;        // LDS doubles the fullest chunk occupies in the staging area (records + Schur factors + lists; <= UVS_S_DOUBLES; informational)
     int32_t n_parts;                  // largest number of parts any pose block is split into (informational; gacc_gather_parts sums them in one step)
-    int32_t w_gacc;                   // the gather accumulators of the last full linearization, [UVS_NT][8 * UVS_GROWS] (k_solve: re-damping after a rejected step)
     int32_t redamp_ok;                // 1: k_solve may re-damp the last linearization after a rejected step instead of linearizing again (no pseudo-frame blocks; every line chunk has room for the tables)
 };
 

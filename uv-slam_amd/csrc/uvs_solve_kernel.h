@@ -1256,25 +1256,36 @@ UVS_DEV void redamp_chunk(const Ctx& c, int ch, double radius, int grp, GAcc& ac
         double* EIb = Eb + (size_t)(nob + XS * nlm) * 6;
         int* lists = (int*)(EIb + (size_t)(nob + XS * nlm) * 6);
         for (int t = tid; t < nlist; t += NT) lists[t] = glists[t];
-        for (int li = tid; li < nlm; li += NT) {
-            const int k = k0 + li, b0 = beg[k] - o0, ns = beg[k + 1] - beg[k] + XS;
-            if (ns == XS) continue;      // a landmark without observations has no entries in the lists and no scalars in the workspace
+        // one lane per slot: first the anchor slots (one per landmark with observations), then
+        // one lane per observation slot.  Slot of observation o of landmark li: (o - o0) + XS li + 1; every lane recomputes its landmark's scalars.
+        for (int t = tid; t < nlm + nob; t += NT) {
+            const bool anchor = t < nlm;
+            const int ol = anchor ? 0 : t - nlm;
+            const int k = anchor ? k0 + t : c.bi[h.i_pt_lm + o0 + ol], li = k - k0;
+            const int nobs = beg[k + 1] - beg[k];
+            if (nobs == 0) continue;      // a landmark without observations has no entries in the lists and no scalars in the workspace
             double* px = c.ws + h.w_pt_x + 4 * (size_t)k;
             const double gl = px[1], dd_old = px[2], hd = px[3], sc = c.ws[h.w_scale_pt + k];
             const double dd = fmin(fmax(sc * sc * hd, c.o.dlo), c.o.dhi) / (radius * sc * sc);
             const double hdo = hd + dd_old, hinv = 1.0 / (hd + dd), dh = hinv - 1.0 / hdo;
-            double* Eg = c.ws + h.w_pt_E + 6 * (size_t)(beg[k] + XS * k);
-            const int s0 = 6 * (b0 + XS * li);
-            for (int sl = 0; sl < ns; ++sl) {
-                double e[6];
+            const int slot = anchor ? (beg[k] - o0) + XS * li : ol + XS * li + 1;
+            double* Eg = c.ws + h.w_pt_E + 6 * (size_t)(anchor ? beg[k] + XS * k : o0 + ol + XS * k + 1);
+            double e[6];
 #pragma unroll
-                for (int a = 0; a < 6; ++a) e[a] = Eg[6 * sl + a] * hdo;
+            for (int a = 0; a < 6; ++a) e[a] = Eg[a] * hdo;
 #pragma unroll
-                for (int a = 0; a < 6; ++a) { Eb[s0 + 6 * sl + a] = e[a]; EIb[s0 + 6 * sl + a] = e[a] * dh; Gb[s0 + 6 * sl + a] = e[a] * dh * gl; Eg[6 * sl + a] = e[a] * hinv; }
-            }
-            px[0] = gl * hinv; px[2] = dd;
+            for (int a = 0; a < 6; ++a) { Eb[6 * slot + a] = e[a]; EIb[6 * slot + a] = e[a] * dh; Gb[6 * slot + a] = e[a] * dh * gl; Eg[a] = e[a] * hinv; }
         }
         __syncthreads();
+        // the landmark scalars are rewritten only now: the lanes above read the OLD damping of their landmark
+        for (int li = tid; li < nlm; li += NT) {
+            const int k = k0 + li;
+            if (beg[k + 1] == beg[k]) continue;
+            double* px = c.ws + h.w_pt_x + 4 * (size_t)k;
+            const double gl = px[1], hd = px[3], sc = c.ws[h.w_scale_pt + k];
+            const double dd = fmin(fmax(sc * sc * hd, c.o.dlo), c.o.dhi) / (radius * sc * sc);
+            px[0] = gl * (1.0 / (hd + dd)); px[2] = dd;
+        }
         gather_points<false, true>(grp, lists, rec, acc, -nob * PREC);
     } else {
         const int* beg = c.bi + h.i_ln_beg;
@@ -1342,22 +1353,6 @@ UVS_DEV void redamp_chunk(const Ctx& c, int ch, double radius, int grp, GAcc& ac
         gather_lines<true>(grp, lists, rec, acc, nlm * 34, nob * UVS_LN_REC);
     }
 }
-// the gather accumulators of the last full linearization live in the workspace between the linearization and a possible re-damping
-UVS_DEV void gacc_store(const Ctx& c, const GAcc& A) {
-    double* p = c.ws + c.hdr->w_gacc + (size_t)lane_tid() * (8 * GR);
-#pragma unroll
-    for (int q = 0; q < 6 * GR; ++q) p[q] = A.v[q];
-#pragma unroll
-    for (int q = 0; q < GR; ++q) { p[6 * GR + q] = A.g[q]; p[7 * GR + q] = A.hd[q]; }
-}
-UVS_DEV void gacc_load(const Ctx& c, GAcc& A) {
-    const double* p = c.ws + c.hdr->w_gacc + (size_t)lane_tid() * (8 * GR);
-#pragma unroll
-    for (int q = 0; q < 6 * GR; ++q) A.v[q] = p[q];
-#pragma unroll
-    for (int q = 0; q < GR; ++q) { A.g[q] = p[6 * GR + q]; A.hd[q] = p[7 * GR + q]; }
-}
-
 // ---- linearization, part 3: assemble the damped reduced system in LDS from the gathered pose blocks + IMU + prior
 // mode 0: everything (k_solve).  The large-window kernels split the work over two workgroups that run concurrently with the landmark
 // chunks resp. after them: mode 1 = the FRAME image only (zero, IMU tiles, prior; no landmark blocks, no damping: k_large_chunks' extra
@@ -1567,13 +1562,13 @@ UVS_DEV void lin_assemble(const Ctx& c, const double* x, bool first, double radi
     UVS_PROF(c, P_ASSEMBLE);
 }
 
-UVS_DEV void linearize(const Ctx& c, const double* x, const double* invd, const double* line, bool first, double radius, int prep_mode = 0) {
+// `A`: the gather accumulators, owned by the caller (k_solve keeps them in registers between a linearization and a possible re-damping)
+UVS_DEV void linearize(const Ctx& c, const double* x, const double* invd, const double* line, bool first, double radius, int prep_mode, GAcc& A) {
     const DevWin& h = *c.hdr;
     const int grp = gather_group(c);       // this lane's gather group: pose block | flags (uvs_layout.h: i_wblk)
-    GAcc A; gacc_zero(A);
+    gacc_zero(A);
     { const double pc = lin_prep(c, x, prep_mode); lacc_set(c.sh, pc, 0.0); }
     for (int ch = 0; ch < h.n_chunks; ++ch) lin_chunk(c, ch, x, invd, line, first, radius, grp, A);
-    if (h.redamp_ok) gacc_store(c, A);
     ImuN N;
     const double ic = lin_imu(c, x, N);
     lin_assemble(c, x, first, radius, grp, A, N, lacc_cost(c.sh) + ic, lacc_gmax(c.sh));
@@ -1581,13 +1576,11 @@ UVS_DEV void linearize(const Ctx& c, const double* x, const double* invd, const 
 
 // After a rejected / invalid step: the same point, a smaller radius.  The per-lane cost / gradient-norm accumulators of the linearization
 // (L_LCOST / L_LGMAX) still hold their values.
-UVS_DEV void relinearize_damping(const Ctx& c, const double* x, double radius) {
+UVS_DEV void relinearize_damping(const Ctx& c, const double* x, double radius, GAcc& A) {
     const DevWin& h = *c.hdr;
     const int grp = gather_group(c);
-    GAcc A; gacc_load(c, A);
     (void)lin_prep(c, x, 2);
     for (int ch = 0; ch < h.n_chunks; ++ch) redamp_chunk(c, ch, radius, grp, A);
-    gacc_store(c, A);
     ImuN N;
     const double ic = lin_imu(c, x, N);
     lin_assemble(c, x, false, radius, grp, A, N, lacc_cost(c.sh) + ic, lacc_gmax(c.sh));
@@ -1909,16 +1902,17 @@ __global__ __launch_bounds__(NT) void k_solve(char* blobs, const long long* blob
     // ONE linearize() call site (the kernel is one big inlined body; a second copy doubles the instruction footprint):
     // need_lin is raised at start, after an accepted step (new point) and after a rejected / invalid step (new radius).
     bool need_lin = true, first = true;
+    GAcc gacc;      // gather accumulators of the current linearization (48 registers per lane, live across the iteration: a re-damping continues from them)
     int prep_mode = 0;        // how much of lin_prep the next linearization can skip (0 nothing, 1 after an accepted step, 2 after a rejected / invalid one)
     int pending = 0;          // trace slot whose cost / gradient norm the next linearization fills in
     while (true) {
         if (it >= o.max_it && !first) { term = UVS_TERM_NO_CONVERGENCE; break; }
         if (need_lin) {
 #ifndef UVS_X_NO_REDAMP
-            if (prep_mode == 2 && !first && h.redamp_ok) relinearize_damping(c, sh + L_X, radius);
+            if (prep_mode == 2 && !first && h.redamp_ok) relinearize_damping(c, sh + L_X, radius, gacc);
             else
 #endif
-            linearize(c, sh + L_X, invd[cur], line[cur], first, radius, prep_mode);
+            linearize(c, sh + L_X, invd[cur], line[cur], first, radius, prep_mode, gacc);
             need_lin = false;
             const double lc = sh[L_CTRL + C_COST];
             gmax = sh[L_CTRL + C_GMAX];

@@ -606,7 +606,6 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
     h.w_scale_pt = wsz; wsz += rup(std::max(h.n_points, 1), 2); h.w_scale_ln = wsz; wsz += 4 * std::max(h.n_lines, 1);
     h.w_pt_E = wsz; wsz += 6 * (h.n_pt_obs + XS * h.n_points) + 6; h.w_pt_x = wsz; wsz += 4 * std::max(h.n_points, 1);
     h.w_ln_Y = wsz; wsz += 24 * std::max(h.n_ln_obs, 1); h.w_ln_x = wsz; wsz += UVS_LN_X * std::max(h.n_lines, 1);
-    h.w_gacc = wsz; wsz += UVS_NT * 8 * UVS_GROWS;
     h.w_imu = wsz; wsz += std::max(h.n_imu, 1) * UVS_WIMU_STRIDE;
     h.w_out = wsz; wsz += UVS_XDIM + std::max(h.n_points, 0) + 4 * std::max(h.n_lines, 0);
     h.n_pblk = (int)pblk.size();
