@@ -95,3 +95,35 @@ def test_repeated_calls_alternating_forms_and_batch_sizes(gpu_api):
     s.upload(ws[:3]); s.solve_resident(); _, reps = s.download()
     assert [r.final_cost for r in reps] == ref[:3]
     s.close()
+
+
+@pytest.mark.parametrize("form", ["persistent", "fused"])
+def test_redamping_equals_relinearizing(gpu_api, form):
+    """After a rejected step the solver re-damps the stored linearization (Schur complement and reduced gradient updated from the stored E rows)
+    instead of linearizing again; UVS_REDAMP=0 switches that off.  Same traces, costs and states on windows whose traces contain rejections."""
+    import os
+    s = gpu_api.Solver(max_batch=1)
+    rejected = 0
+    for index in (3, 5, 11, 14):
+        w = synth.make_window(index, with_prior=(index % 2 == 1), marginalize_fn=(lambda win, flag: s.marginalize(win, flag)) if index % 2 == 1 else None)
+        out = []
+        for flag in (None, "0"):
+            if flag is None: os.environ.pop("UVS_REDAMP", None)
+            else: os.environ["UVS_REDAMP"] = flag
+            try:
+                if form == "fused": st, rep, _ = s.large_solve_fused(w)
+                else: st, rep = s.solve(w)
+            finally:
+                os.environ.pop("UVS_REDAMP", None)
+            out.append((st, rep))
+        (sa, ra), (sb, rb) = out
+        n = ra.num_iterations + 1
+        assert ra.num_iterations == rb.num_iterations and list(ra.accepted[:n]) == list(rb.accepted[:n]) and ra.termination == rb.termination
+        rejected += sum(1 for a in list(ra.accepted[1:n]) if a != 1)
+        assert np.allclose(list(ra.cost[:n]), list(rb.cost[:n]), rtol=1e-10, atol=0.0)
+        assert np.allclose(list(ra.model_cost_change[:n]), list(rb.model_cost_change[:n]), rtol=1e-7, atol=1e-12)
+        dp, dr = pose_deltas(sa.pose, sb.pose)
+        assert dp < 1e-9 and dr < 1e-7
+        assert np.abs(sa.inv_depth - sb.inv_depth).max() < 1e-9 and np.abs(sa.line_orth - sb.line_orth).max() < 1e-7
+    assert rejected >= 4      # the comparison is only worth something if steps WERE rejected
+    s.close()

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(NT) void k_large_chunks(char* blob, double* ws, KOp
     const DevWin& h = *c.hdr;
     // after a rejected step (fused loop): same point, new radius -- the landmark partials are UPDATED by the change of their Schur terms
     // (redamp_chunk), the frame image (undamped) stays as it is
-    const bool redamp = lc.ctl && lc.ctl[LC_REDAMP] != 0.0 && !first && h.redamp_ok;
+    const bool redamp = lc.ctl && lc.ctl[LC_REDAMP] != 0.0 && !first && h.redamp_ok && o.redamp;
     if (tid < 184) sh[L_X + tid] = state[LS_X + tid];
     if ((int)blockIdx.x == n_chunk_wgs) {
         if (redamp) return;

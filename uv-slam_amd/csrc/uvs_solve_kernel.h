@@ -71,6 +71,7 @@ struct KOpts {   // device copy of uvs_options
     double r0, rmax, rmin, min_rel, dlo, dhi, ftol, gtol, ptol;
     int max_invalid;
     int debug;
+    int redamp;      // 1 (default): a rejected step is followed by a re-damping of the stored linearization; 0 (UVS_REDAMP=0 at uvs_create): by a new linearization
 };
 
 __constant__ unsigned char c_blk_fa[UVS_NBLK];
@@ -1909,7 +1910,7 @@ __global__ __launch_bounds__(NT) void k_solve(char* blobs, const long long* blob
         if (it >= o.max_it && !first) { term = UVS_TERM_NO_CONVERGENCE; break; }
         if (need_lin) {
 #ifndef UVS_X_NO_REDAMP
-            if (prep_mode == 2 && !first && h.redamp_ok) relinearize_damping(c, sh + L_X, radius, gacc);
+            if (prep_mode == 2 && !first && h.redamp_ok && o.redamp) relinearize_damping(c, sh + L_X, radius, gacc);
             else
 #endif
             linearize(c, sh + L_X, invd[cur], line[cur], first, radius, prep_mode, gacc);

@@ -88,6 +88,7 @@ static KOpts make_kopts(const uvs_options& o, int debug) {
     k.min_rel = o.min_relative_decrease; k.dlo = o.min_lm_diagonal; k.dhi = o.max_lm_diagonal;
     k.ftol = o.function_tolerance; k.gtol = o.gradient_tolerance; k.ptol = o.parameter_tolerance;
     k.max_invalid = o.max_consecutive_invalid_steps; k.debug = debug;
+    { const char* e = std::getenv("UVS_REDAMP"); k.redamp = (e && e[0] == '0') ? 0 : 1; }      // diagnostic switch, read per launch (tests, A/B): 0 = re-linearize after every rejected step
     return k;
 }
 
