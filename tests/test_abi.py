@@ -109,6 +109,34 @@ def test_pack_layout_host_only():
     assert lib.uvs_debug_pack_layout(C.byref(o), C.byref(wc), info) == abi.UVS_ERR_UNSUPPORTED
 
 
+def test_large_window_chunking_fills_the_grid(monkeypatch):
+    """uvs_large_begin packs with the grid of its persistent kernels (compute units - 1): the chunk count becomes a multiple of the grid (every
+    workgroup carries the same number of chunks), a small window or a shard gets one chunk per workgroup (>= 64 observations each), and
+    every chunk still fits the LDS staging area.  Host-only through UVS_DEBUG_CHUNK_GRID."""
+    lib = uvs.api.lib(); synth = uvs.synth
+    lib.uvs_debug_pack_layout.argtypes = [C.POINTER(abi.Options), C.POINTER(abi.WindowC), C.POINTER(C.c_int32)]
+    o = abi.default_options()
+    def chunks(w, grid):
+        if grid: monkeypatch.setenv("UVS_DEBUG_CHUNK_GRID", str(grid))
+        else: monkeypatch.delenv("UVS_DEBUG_CHUNK_GRID", raising=False)
+        wc, keep = w.to_c(); info = (C.c_int32 * 12)()
+        assert lib.uvs_debug_pack_layout(C.byref(o), C.byref(wc), info) == abi.UVS_OK
+        assert info[7] <= info[8]      # fullest chunk <= staging area
+        return info[2]
+    big = synth.make_window(70, n_points=4000, n_lines=1000, n_tagged=700)
+    n_min = chunks(big, 0)
+    assert n_min > 64
+    for grid in (64, 255):
+        n = chunks(big, grid)
+        assert n % grid == 0 and n >= n_min and n < n_min + grid
+    shard = synth.shard_landmarks(big, 0, 8)[0]
+    n_obs = len(shard.pt_lm) + len(shard.ln_lm)
+    assert chunks(shard, 0) < 64 and chunks(shard, 255) == min(255, n_obs // 64)      # one chunk per workgroup, but not under 64 observations per chunk
+    small = synth.make_window(3)
+    assert chunks(small, 0) == 5 and chunks(small, 255) == (750 + 280) // 64
+    monkeypatch.delenv("UVS_DEBUG_CHUNK_GRID", raising=False)
+
+
 def test_malformed_prior_is_rejected_not_dereferenced():
     """validate_window() checked block_idx / block_frame of the prior but not x0_off, block_size or block_kind, and pack_window
     then read x0[x0_off[b] + k] unchecked (a prior with x0_off = 1e8 crashed the process).  Host-only: no device is touched."""
