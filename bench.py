@@ -149,8 +149,14 @@ def main():
         wl = synth.make_window(70, n_points=20000, n_lines=5000, n_tagged=3750)
         shard = synth.shard_landmarks(wl, rank, world)[0] if world > 1 else wl
         sl = api.Solver(device=local_rank, max_batch=1, max_points=20008, max_point_obs=240000, max_lines=5008, max_line_obs=60000)
-        sl.large_comm_init(dist if world > 1 and dist.get_backend() == "nccl" else None)
-        if world > 1 and dist.get_backend() != "nccl":
+        try:
+            sl.large_comm_init(dist if world > 1 and dist.get_backend() == "nccl" else None)
+            comm_error = None
+        except Exception as e:      # e.g. no RCCL in the process: every rank fails here alike, the headline line must not die with this leg
+            comm_error = repr(e)
+        if comm_error is not None:
+            large = {"error": "uvs_large_comm_init: " + comm_error}
+        elif world > 1 and dist.get_backend() != "nccl":
             large = {"skipped": "the fused loop all-reduces over RCCL; dry runs on another backend skip it"}
         else:
             loop_ms, wall_ms = [], []
