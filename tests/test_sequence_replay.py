@@ -94,13 +94,15 @@ def test_every_recorded_window_of_the_sequence_open_loop(gpu_api, oracle, tmp_pa
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", [0, 2])
-def test_hip_backed_closed_loop_replay(gpu_api, tmp_path, seed):
+@pytest.mark.parametrize("path", ["multi", "persistent"])      # uvs::Options::path of the host mirror: the multi-workgroup fused loop (its default) / the persistent kernel
+def test_hip_backed_closed_loop_replay(gpu_api, tmp_path, seed, path, monkeypatch):
     """CLOSED LOOP: the product host library (HIP behind the C ABI) drives the whole sequence itself.  A 10-iteration LM is not run to
     convergence, so round-off level differences in a prior can flip a termination test or a step acceptance and the two runs then
     follow different (equally valid) LM paths: the per-frame agreement is tight until the first such flip and bounded by the
     measurement noise afterwards; the accuracy against the ground truth (ATE) is the same."""
     seq = seqm.make_sequence(seed, n_frames=36)
     ro = _oracle_replay(seq, tmp_path)
+    monkeypatch.setenv("UVS_HOST_SOLVER_PATH", path)
     rg = _replay(os.path.join(ROOT, "uv-slam_amd", "libuvs_host.so"), seq, tmp_path, "hip")
     assert list(rg["frame"]) == list(ro["frame"]) and np.all(rg["status"] == 0)
     assert np.array_equal(rg["flag"], ro["flag"])
