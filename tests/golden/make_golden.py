@@ -63,6 +63,24 @@ def dict_to_window(d):
     return w
 
 
+CONFIG3 = dict(index=70, n_points=20000, n_lines=5000, n_tagged=3750)      # BASELINE configs[3]: 135 000 observations
+
+
+def config3_trace(orc):
+    """configs[3] at full size is 10 MB of inputs: the fixture holds the generator arguments (synth.make_window is a pure function of them,
+    numpy PCG64) plus a checksum of the generated measurements, and the expected LM trace / frame states / landmark checksums."""
+    w = uvs.synth.make_window(CONFIG3["index"], **{k: v for k, v in CONFIG3.items() if k != "index"})
+    st, rep = orc.solve(w)
+    k = rep.num_iterations + 1
+    np.savez_compressed(os.path.join(HERE, "config3_trace.npz"), synth_args=np.array([CONFIG3[k_] for k_ in ("index", "n_points", "n_lines", "n_tagged")]),
+                        in_checksum=np.array([w.pt_pj.sum(), w.ln_sp.sum(), w.inv_depth.sum(), w.line_orth.sum(), w.pose.sum()]),
+                        out_cost=np.array(rep.cost[:k]), out_radius=np.array(rep.radius[:k]), out_accepted=np.array(rep.accepted[:k]),
+                        out_final_cost=np.array(rep.final_cost), out_initial_cost=np.array(rep.initial_cost), out_termination=np.array(rep.termination),
+                        out_pose=st.pose, out_speedbias=st.speedbias, out_inv_depth_head=st.inv_depth[:64], out_line_orth_head=st.line_orth[:16],
+                        out_landmark_checksum=np.array([st.inv_depth.sum(), np.abs(st.inv_depth).sum(), st.line_orth.sum()]))
+    print("config3_trace iters", rep.num_iterations, "cost", rep.initial_cost, "->", rep.final_cost)
+
+
 def main():
     orc = Oracle()
     marg = lambda win, flag: orc.marginalize(win, flag)
@@ -71,8 +89,13 @@ def main():
         "small_prior": uvs.synth.make_window(102, n_points=40, n_lines=10, n_tagged=8, with_prior=True, marginalize_fn=marg),
         "points_only": uvs.synth.make_window(103, n_points=30, n_lines=0, n_tagged=0),
         "small_relo": uvs.synth.add_relocalization(uvs.synth.make_window(104, n_points=40, n_lines=10, n_tagged=8, with_prior=True, marginalize_fn=marg), relo_frame=5, seed=104),
+        # the BASELINE window itself (W10-P150-L40-V3 with the n = 75 prior; seed 1000 = window 0 of bench.py's batch)
+        "canonical_prior": uvs.synth.make_window(1000, with_prior=True, marginalize_fn=marg),
+        # the same shape with EVERY line tagged with a vanishing point (280 VP blocks instead of 210)
+        "canonical_vp_heavy": uvs.synth.make_window(105, n_tagged=40, with_prior=True, marginalize_fn=marg),
     }
     only = sys.argv[1:]
+    if not only or "config3_trace" in only: config3_trace(orc)
     for name, w in cases.items():
         if only and name not in only: continue
         st, rep = orc.solve(w)

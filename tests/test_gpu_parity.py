@@ -151,5 +151,21 @@ def test_config3_full_size_matches_oracle(gpu_api, oracle):
     s2, r2 = s.large_solve(w)                                         # same handle, same window: bit for bit
     assert np.array_equal(sg.pose, s2.pose) and np.array_equal(sg.inv_depth, s2.inv_depth) and np.array_equal(sg.line_orth, s2.line_orth)
     assert r2.final_cost == rg.final_cost and list(r2.cost[:11]) == list(rg.cost[:11])
+    # the FUSED loop -- the path bench.py times for this configuration (510 balanced chunks on persistent workgroups, the frame-terms
+    # workgroup, trust-region control and re-damping on the device) -- against the same oracle solve, then bit for bit against itself
+    s.large_comm_init(None)
+    sf, rf, loop_ms = s.large_solve_fused(w)
+    n = ro.num_iterations
+    assert rf.status == 0 and rf.num_iterations == n and rf.termination == ro.termination
+    assert list(rf.accepted[: n + 1]) == list(ro.accepted[: n + 1])
+    assert np.allclose(np.array(rf.cost[: n + 1]), np.array(ro.cost[: n + 1]), rtol=1e-8) and np.allclose(np.array(rf.radius[: n + 1]), np.array(ro.radius[: n + 1]), rtol=1e-6)
+    dpf, daf = pose_deltas(sf.pose, so.pose)
+    assert dpf < 1e-6 and daf < 1e-6, (dpf, daf)
+    assert abs(rf.final_cost - ro.final_cost) <= 1e-8 * ro.final_cost and abs(rf.initial_cost - ro.initial_cost) <= 1e-10 * ro.initial_cost
+    assert np.abs(sf.speedbias - so.speedbias).max() < 1e-6
+    assert np.abs(sf.inv_depth - so.inv_depth).max() < 1e-6 and np.abs(sf.line_orth - so.line_orth).max() < 1e-5
+    sf2, rf2, _ = s.large_solve_fused(w)
+    assert np.array_equal(sf.pose, sf2.pose) and np.array_equal(sf.inv_depth, sf2.inv_depth) and np.array_equal(sf.line_orth, sf2.line_orth)
+    assert rf2.final_cost == rf.final_cost and list(rf2.cost[:11]) == list(rf.cost[:11])
     s.close()
-    print("configs[3] full size: max |dp| %.2e m, |dtheta| %.2e rad vs oracle; final cost %.10g | %.10g" % (dp, da, rg.final_cost, ro.final_cost))
+    print("configs[3] full size: max |dp| %.2e m, |dtheta| %.2e rad vs oracle; final cost %.10g | %.10g; fused loop %.2e m, %.10g, %.3f ms" % (dp, da, rg.final_cost, ro.final_cost, dpf, rf.final_cost, loop_ms))

@@ -157,3 +157,80 @@ def test_fused_loop_early_termination_and_zero_iterations(gpu_api):
         s.close()
         assert rep1.num_iterations == rep0.num_iterations and rep1.termination == rep0.termination, kw
         assert abs(rep1.final_cost - rep0.final_cost) <= 1e-12 * rep0.final_cost and pose_deltas(st1.pose, st0.pose)[0] < 1e-12
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# The fused loop with N = 2.  No multi-GPU node is available to the tests, so two processes share the one GPU and the library's
+# dlopen hook (UVS_RCCL_LIB) is pointed at tests/shim/libuvs_fake_nccl.so, which carries the two all-reduces through shared memory.
+# Everything on the solver's side -- the per-rank MAX slots inside the SUM payload, k_large_sum_bsums, the 5-scalar exchange,
+# k_large_decide on identical numbers on both ranks -- is the code that runs over RCCL / xGMI.
+SHIM_DIR = os.path.join(ROOT, "tests", "shim")
+SHIM = os.path.join(SHIM_DIR, "libuvs_fake_nccl.so")
+
+
+def _build_shim():
+    src = os.path.join(SHIM_DIR, "fake_nccl.cpp")
+    if os.path.exists(SHIM) and os.path.getmtime(SHIM) >= os.path.getmtime(src):
+        return
+    import subprocess
+    subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "-O2", "-std=c++17", "-shared", "-fPIC", "-w", src, "-o", SHIM, "-lrt"])
+
+
+FUSED2 = dict(n_points=900, n_lines=200, n_tagged=150)
+
+
+def _fused_worker(rank, world, port, q, seed, shape):
+    os.environ["UVS_RCCL_LIB"] = SHIM            # before libuvs_solver.so resolves RCCL
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import importlib
+    u = importlib.import_module("uv-slam_amd")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)      # carries the 128-byte communicator id, nothing else
+    w = u.synth.make_window(seed, **shape)
+    shard, pk, lk = u.synth.shard_landmarks(w, rank, world)
+    s = u.api.Solver(device=0, max_batch=1, max_points=len(pk) + 8, max_point_obs=12 * len(pk) + 64, max_lines=len(lk) + 8, max_line_obs=12 * len(lk) + 64)
+    s.large_comm_init(dist)
+    st, rep, ms = s.large_solve_fused(shard)
+    st2, rep2, _ = s.large_solve_fused(shard)      # the communicator and the handle are reusable; both ranks must stay in step
+    n = rep.num_iterations
+    q.put((rank, st.pose.copy(), st.speedbias.copy(), st.inv_depth.copy(), st.line_orth.copy(), pk, lk, rep.final_cost, rep.initial_cost, n, list(rep.accepted[:n + 1]),
+           list(rep.cost[:n + 1]), list(rep.radius[:n + 1]), rep.termination, bool(np.array_equal(st.pose, st2.pose) and rep2.final_cost == rep.final_cost)))
+    s.close()
+    dist.barrier(); dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,shape", [(56, FUSED2), (57, dict(n_points=3000, n_lines=700, n_tagged=500))])
+def test_fused_loop_with_two_ranks_on_one_gpu(gpu_api, oracle, seed, shape):
+    """uvs_large_solve_fused with nranks = 2: landmark shards k mod 2, both all-reduces per iteration through the handle's communicator.
+    Must equal the one-process fused solve of the whole window (same LM trace, final cost to 1e-7, states) and the CPU oracle."""
+    _build_shim()
+    world = 2
+    ctx = mp.get_context("spawn"); q = ctx.Queue(); port = _free_port()
+    procs = [ctx.Process(target=_fused_worker, args=(r, world, port, q, seed, shape)) for r in range(world)]
+    for p in procs: p.start()
+    res = sorted([q.get(timeout=420) for _ in range(world)], key=lambda r: r[0])
+    for p in procs: p.join(120)
+    assert all(p.exitcode == 0 for p in procs)
+    w = synth.make_window(seed, **shape)
+    s = gpu_api.Solver(max_batch=1, max_points=shape["n_points"] + 8, max_point_obs=12 * shape["n_points"], max_lines=shape["n_lines"] + 8, max_line_obs=12 * shape["n_lines"])
+    s.large_comm_init(None)
+    st, rep, _ = s.large_solve_fused(w)
+    s.close()
+    so, ro = oracle.solve(w)
+    n = rep.num_iterations
+    assert n == ro.num_iterations and list(rep.accepted[:n + 1]) == list(ro.accepted[:n + 1])
+    # both ranks decided on identical numbers: identical traces, bit for bit, and identical frame states
+    assert res[0][9:14] == res[1][9:14] and res[0][7] == res[1][7]
+    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+    inv_depth = np.zeros(shape["n_points"]); line_orth = np.zeros((shape["n_lines"], 4))
+    for r in res:
+        assert r[14], "second solve on the same communicator differs"
+        assert r[9] == n and r[10] == list(rep.accepted[:n + 1]) and r[13] == rep.termination
+        assert np.allclose(np.array(r[11]), np.array(rep.cost[:n + 1]), rtol=1e-7) and np.allclose(np.array(r[12]), np.array(rep.radius[:n + 1]), rtol=1e-6)
+        assert abs(r[7] - rep.final_cost) <= 1e-7 * rep.final_cost and abs(r[8] - rep.initial_cost) <= 1e-12 * rep.initial_cost
+        assert pose_deltas(r[1], st.pose)[0] < 1e-7 and np.abs(r[2] - st.speedbias).max() < 1e-7
+        inv_depth[r[5]] = r[3]; line_orth[r[6]] = r[4].reshape(-1, 4)
+    assert np.abs(inv_depth - st.inv_depth).max() < 1e-7 and np.abs(line_orth - st.line_orth.reshape(-1, 4)).max() < 1e-6
+    dp, da = pose_deltas(res[0][1], so.pose)
+    assert dp < 1e-6 and da < 1e-6 and abs(res[0][7] - ro.final_cost) <= 1e-7 * ro.final_cost

@@ -148,3 +148,26 @@ def test_td_through_the_host_mirror(gpu_api):
     k = 4 + 11 * 16 + 2 * 150 + 5 * 40
     pn = int(raw[k])
     assert pn > 0            # a new prior was built (it contains the 1-dof td block: n is odd-sized relative to the td-free case)
+
+
+@pytest.mark.gpu
+def test_td_factor_class_evaluates_through_the_gpu(gpu_api, oracle, tmp_path):
+    """ProjectionTdFactor::Evaluate / check (projection_td_factor.h:16-17) of the host mirror: one uvs_evaluate per call on a handle with
+    estimate_td, global-size row-major Jacobians incl. the 2 x 1 td block -- against the oracle's restatement of projection_td_factor.cpp:34-145."""
+    import ctypes as C, os
+    w = synth.add_time_offset(synth.make_window(93), td_true=0.005); w.td = 0.0015
+    path = str(tmp_path / "w.uvsw"); w.save(path)
+    host = C.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "uv-slam_amd", "libuvs_host.so"))
+    host.uvs_host_td_factor_probe.argtypes = [C.c_char_p, abi.c_double_p, C.c_int]; host.uvs_host_td_factor_probe.restype = C.c_int
+    buf = np.zeros(64)
+    n = host.uvs_host_td_factor_probe(path.encode(), abi._dp(buf), len(buf))
+    assert n == 2 + 42 + 2 + 2 + 1, n
+    e = oracle.evaluate(w, robust=False, opts=_td_options())
+    close = lambda a, b: np.abs(np.asarray(a) - np.asarray(b)).max() <= 1e-9 * max(1.0, np.abs(np.asarray(b)).max())
+    assert close(buf[:2], e.pt_r[0])
+    for b in range(3):
+        J = buf[2 + 14 * b:2 + 14 * (b + 1)].reshape(2, 7)
+        assert close(J[:, :6], e.pt_J[0][:, 6 * b:6 * b + 6]) and np.all(J[:, 6] == 0.0)
+    assert close(buf[44:46], e.pt_J[0][:, 18])
+    assert close(buf[46:48], e.pt_Jtd[0])
+    assert 0.0 <= buf[48] < 1e-3 * max(np.abs(e.pt_J[0]).max(), np.abs(e.pt_Jtd[0]).max())      # check(): analytic vs forward differences, td direction included

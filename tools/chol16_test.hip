@@ -1,11 +1,11 @@
-// chol16_test.hip -- stand-alone check + timing of csrc/uvs_chol16.h (the 16x16 diagonal-block factorization of the reduced solve).
+// chol16_test.hip -- stand-alone check + timing of tools/uvs_chol16.h (the 16x16 diagonal-block factorization of the reduced solve).
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/chol16_test.hip -o gpurun_out/chol16_test ; run on the GPU box.
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
-#include "../uv-slam_amd/csrc/uvs_chol16.h"
+#include "uvs_chol16.h"
 using namespace uvsdev;
 
 __global__ __launch_bounds__(64) void k_test(const double* A, double* out /*[n][16*17 + 16 + 1]*/, long long* cyc, int reps) {

@@ -1,7 +1,7 @@
-// micro_dpp.hip -- latency / issue probes for the DPP FP64 operations used by csrc/uvs_chol16.h (gfx950).
+// micro_dpp.hip -- latency / issue probes for the DPP FP64 operations used by tools/uvs_chol16.h (gfx950).
 #include <hip/hip_runtime.h>
 #include <cstdio>
-#include "../uv-slam_amd/csrc/uvs_chol16.h"
+#include "uvs_chol16.h"
 using namespace uvsdev;
 __device__ __forceinline__ double rsq3(double x) { const double y = __builtin_amdgcn_rsq(x); const double e = fma(-x * y, y, 1.0); return fma(y, e * fma(0.375, e, 0.5), y); }
 template <int J> __device__ __forceinline__ double fmac_nonop(double acc, double a, double b) {

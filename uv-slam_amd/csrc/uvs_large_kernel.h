@@ -284,6 +284,7 @@ __global__ __launch_bounds__(256) void k_large_decide(double* ctl, double* state
                 ++invalid; radius /= decr; decr *= 2.0; ctl[LC_REDAMP] = 1.0;
                 rep->accepted[ti] = -1; rep->cost[ti] = cost; rep->candidate_cost[ti] = cost; rep->radius[ti] = radius; rep->gradient_max_norm[ti] = gmax;
                 if (invalid >= o.max_invalid) { term = UVS_TERM_INVALID_STEPS; done = true; }
+                else if (it >= o.max_it) { term = UVS_TERM_NO_CONVERGENCE; done = true; }      // the last enqueued pass may be an invalid step: it still ends the solve (k_solve tests this at its loop top)
             } else {
                 invalid = 0;
                 if (!isfinite(cand)) cand = 1.7976931348623157e308;

@@ -440,7 +440,7 @@ UVS_DEV void chol_store_item(double* sh, int i, int cc, int lane, const d4_t& ac
 }
 
 // (Round 2 tried two restructurings of this factorization; both are correct and both lost on MI355X, so the barrier version stays:
-//  (1) the 16x16 diagonal block on the VALU, one matrix row per lane with DPP row broadcasts as FMA operands (csrc/uvs_chol16.h,
+//  (1) the 16x16 diagonal block on the VALU, one matrix row per lane with DPP row broadcasts as FMA operands (tools/uvs_chol16.h,
 //      tools/chol16_test.hip): 268 cycles per pivot without the inverse, 390 with it, against ~250 for the readlane -> rcp -> rank-1
 //      MFMA chain below -- a dependent FP64 VALU operation costs 14 cycles, a DPP one 21 (tools/micro_dpp.hip), and a link of that
 //      chain has about ten of them;

@@ -22,8 +22,8 @@
 #include "uvs_factors.h"
 #include "uvs_solve_kernel.h"
 #include "uvs_eval_kernel.h"
-#include "uvs_marg.h"
 #include "uvs_large_kernel.h"
+#include "uvs_marg.h"      // LAST: its file-scope `#pragma clang fp contract(...)` must not reach any device code (the kernels are built with the command-line default)
 
 using namespace uvsdev;
 
@@ -539,6 +539,10 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
     h.redamp_ok = (!td_on && !ex_on && !relo_on) ? 1 : 0;
     for (int qc = 0; qc < h.n_chunks && h.redamp_ok; ++qc)
         if (chunks[6 * qc] == 1) { const long nob = lbeg[chunks[6 * qc + 2]] - lbeg[chunks[6 * qc + 1]], nlm = chunks[6 * qc + 2] - chunks[6 * qc + 1]; if (34 * nlm + 6 * nob > (long)UVS_LN_REC * nob) h.redamp_ok = 0; }
+        else {      // point chunk: redamp_chunk's gradient rows Gb[(nob + nlm)][6] sit in front of the E rows at rec + nob * pt_rec -- a chunk made mostly of landmarks WITHOUT observations would run into them
+            const long nob = pbeg[chunks[6 * qc + 2]] - pbeg[chunks[6 * qc + 1]], nlm = chunks[6 * qc + 2] - chunks[6 * qc + 1];
+            if (6 * (nob + nlm) > (long)h.pt_rec * nob) h.redamp_ok = 0;
+        }
     lap_("lists");
     // layout
     int d = (int)((sizeof(DevWin) + 7) / 8);
@@ -1126,9 +1130,12 @@ RcclApi& rccl() {
     static RcclApi api;
     if (api.lib || !api.err.empty()) return api;
     const char* env = std::getenv("UVS_RCCL_LIB");
-    const char* names[3] = {env ? env : "librccl.so", "librccl.so.1", "librccl.so"};
-    for (int pass = 0; pass < 2 && !api.lib; ++pass)              // first a copy that is already loaded, then a fresh one
-        for (const char* n : names) { api.lib = dlopen(n, RTLD_NOW | (pass == 0 ? RTLD_NOLOAD : 0)); if (api.lib) break; }
+    if (env && *env) api.lib = dlopen(env, RTLD_NOW);            // an explicit library is taken as given, even when the process already holds another RCCL (PyTorch's)
+    else {
+        const char* names[2] = {"librccl.so.1", "librccl.so"};
+        for (int pass = 0; pass < 2 && !api.lib; ++pass)          // first a copy that is already loaded, then a fresh one
+            for (const char* n : names) { api.lib = dlopen(n, RTLD_NOW | (pass == 0 ? RTLD_NOLOAD : 0)); if (api.lib) break; }
+    }
     if (!api.lib) { api.err = "RCCL not found (librccl.so / librccl.so.1; set UVS_RCCL_LIB)"; return api; }
     api.GetUniqueId = (int (*)(void*))dlsym(api.lib, "ncclGetUniqueId");
     api.CommInitRank = (int (*)(void**, int, uvs_rccl_id, int))dlsym(api.lib, "ncclCommInitRank");
@@ -1169,6 +1176,15 @@ void uvs_large_comm_destroy(uvs_solver* s) {
     L.rank = 0; L.nranks = 1;
 }
 
+// Error inside the enqueue loop of the fused solve: drain what is already on the stream and leave the handle idle.  With several ranks the
+// peers are still inside their collective -- the communicator must be considered broken afterwards (uvs_large_comm_destroy + re-init).
+static int fused_abort(uvs_solver* s, const char* what) {
+    (void)hipStreamSynchronize(s->stream);
+    s->L.active = false;
+    s->err = what;
+    return UVS_ERR_HIP;
+}
+
 // ONE large window, landmark-sharded over the ranks of the handle's communicator (`w` = this rank's landmarks, frames / IMU / prior
 // replicated), the whole Levenberg-Marquardt loop enqueued on the handle's stream without a host round trip: per iteration
 //   k_large_chunks -> k_large_reduce -> ncclAllReduce(reduced, SUM, in place) -> k_large_solve -> k_large_backsub -> k_large_sum_bsums
@@ -1186,7 +1202,7 @@ int uvs_large_solve_fused(uvs_solver* s, const uvs_window* w, uvs_state* out, uv
     {
         double* keep_ctl = L.d_ctl; uvs_report* keep_rep = L.d_rep; void* keep_comm = L.comm; const int keep_rank = L.rank, keep_nranks = L.nranks; double* keep_fimg = L.d_fimg;
         L = uvs_solver::Large{L.active, 0, 0, 0, 0, 0, 0, 0, 0, true, true, false, 0, 2, 0, 0, 0, 0, L.d_state, L.d_partials, L.d_reduced, L.d_bsums, L.d_out, L.d_sc5, L.cap_partials, L.cap_bsums, {}};
-        L.active = true; L.n_chunks = h.n_chunks; L.radius = o.initial_trust_region_radius;
+        L.active = false; L.n_chunks = h.n_chunks; L.radius = o.initial_trust_region_radius;      // active only while work is enqueued (set below): an allocation failure leaves the handle idle
         L.grid = std::min(h.n_chunks, s->chunk_wgs());
         L.d_ctl = keep_ctl; L.d_rep = keep_rep; L.comm = keep_comm; L.rank = keep_rank; L.nranks = keep_nranks; L.d_fimg = keep_fimg;
     }
@@ -1207,6 +1223,7 @@ int uvs_large_solve_fused(uvs_solver* s, const uvs_window* w, uvs_state* out, uv
     for (int k = 0; k < 4 * w->n_lines; ++k) l2 += w->line_orth[k] * w->line_orth[k];
     L.local_x2 = l2; L.x_norm = std::sqrt(x2 + l2); L.frame_x2 = x2;
     std::memcpy(L.relo_pose_in, w->relo_pose, sizeof(L.relo_pose_in));
+    L.active = true;
     hipLaunchKernelGGL(k_large_init, dim3(16), dim3(256), 0, s->stream, s->d_blobs, s->d_ws, L.d_state, L.d_ctl, L.d_rep, L.d_reduced, o.initial_trust_region_radius, L.frame_x2, L.local_x2);
     const KOpts ko = make_kopts(o, 0);
     const LargeCtl lc{L.d_ctl, L.rank, L.nranks};
@@ -1218,12 +1235,12 @@ int uvs_large_solve_fused(uvs_solver* s, const uvs_window* w, uvs_state* out, uv
         hipLaunchKernelGGL(k_large_chunks, dim3(L.grid + 1), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, 0, 0, 0.0, L.d_partials, lc, L.grid, L.d_fimg);
         // (summing the partial rows inside k_large_solve instead of by a launch of its own was measured: one workgroup needs 15-24 us for what 314 do in 5)
         hipLaunchKernelGGL(k_large_reduce, dim3((LG_RED + 15) / 16), dim3(256), 0, s->stream, L.d_partials, rows, L.d_reduced, lc);
-        if (L.comm) { const int e = r.AllReduce(L.d_reduced, L.d_reduced, LG_XCH, kNcclDouble, kNcclSum, L.comm, s->stream); if (e != 0) { s->err = "ncclAllReduce failed"; return UVS_ERR_HIP; } }
+        if (L.comm) { const int e = r.AllReduce(L.d_reduced, L.d_reduced, LG_XCH, kNcclDouble, kNcclSum, L.comm, s->stream); if (e != 0) return fused_abort(s, "ncclAllReduce(reduced) failed"); }
         hipLaunchKernelGGL(k_large_solve, dim3(1), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, L.d_reduced, 0, 0.0, L.d_out, lc, L.d_fimg);
         hipLaunchKernelGGL(k_large_backsub, dim3(L.grid + 1), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, 0, L.d_bsums, lc, L.grid, L.d_out);
         if (L.comm) {
             hipLaunchKernelGGL(k_large_sum_bsums, dim3(1), dim3(256), 0, s->stream, L.d_bsums, L.n_chunks, L.d_sc5, lc);
-            const int e = r.AllReduce(L.d_sc5, L.d_sc5, 8, kNcclDouble, kNcclSum, L.comm, s->stream); if (e != 0) { s->err = "ncclAllReduce failed"; return UVS_ERR_HIP; }
+            const int e = r.AllReduce(L.d_sc5, L.d_sc5, 8, kNcclDouble, kNcclSum, L.comm, s->stream); if (e != 0) return fused_abort(s, "ncclAllReduce(step scalars) failed");
             hipLaunchKernelGGL(k_large_decide, dim3(1), dim3(256), 0, s->stream, L.d_ctl, L.d_state, L.d_out, L.d_sc5, L.d_reduced, ko, L.d_rep, (const double*)nullptr, 0);
         } else hipLaunchKernelGGL(k_large_decide, dim3(1), dim3(256), 0, s->stream, L.d_ctl, L.d_state, L.d_out, L.d_sc5, L.d_reduced, ko, L.d_rep, (const double*)L.d_bsums, L.n_chunks);
     }
@@ -1236,9 +1253,14 @@ int uvs_large_solve_fused(uvs_solver* s, const uvs_window* w, uvs_state* out, uv
     const double* ho = (const double*)s->h_out;
     const double* ctl = ho;
     L.active = false;
-    if (ctl[LC_DONE] == 0.0) { s->err = "fused large-window loop did not terminate within max_num_iterations passes"; return UVS_ERR_NUMERIC; }
+    const bool unterminated = ctl[LC_DONE] == 0.0;      // cannot happen since k_large_decide tests the iteration cap on every branch; if it ever does, the caller still gets the last accepted state
     L.sel = (int)ctl[LC_SEL]; L.it = (int)ctl[LC_IT]; L.nsucc = (int)ctl[LC_NSUCC]; L.term = (int)ctl[LC_TERM]; L.status = (int)ctl[LC_STATUS]; L.cost = ctl[LC_COST]; L.done = true;
     std::memcpy(rep, ho + 64, sizeof(uvs_report));
+    if (unterminated) {
+        L.status = UVS_ERR_NUMERIC; L.term = UVS_TERM_NO_CONVERGENCE;
+        rep->status = L.status; rep->termination = L.term; rep->num_iterations = L.it; rep->num_successful = L.nsucc; rep->final_cost = L.cost;
+        s->err = "fused large-window loop did not terminate within max_num_iterations passes";
+    }
     L.rep = *rep;
     const double* fr = ho + 64 + RD;
     std::memcpy(out->pose, fr, 77 * 8); std::memcpy(out->speedbias, fr + 77, 99 * 8); std::memcpy(out->ex_pose, fr + 176, 7 * 8); out->td = fr[183];

@@ -1,6 +1,6 @@
-// estimator.cpp -- Estimator::optimization() / vector2double() / double2vector() with the reference's structure
-// (vins_estimator/src/estimator.cpp:526-711, 761-1233), the Ceres problem replaced by uvs::Problem and the
-// marginalization by uvs_marginalize().  See INTEGRATION.md for the diff a maintainer applies to the reference file.
+// estimator.cpp -- Estimator::optimization() / vector2double() / double2vector() (vins_estimator/src/estimator.cpp:526-711, 761-1233):
+// the Ceres problem construction becomes a flat window descriptor (window_assembly.h), ceres::Solve one C-ABI call, the marginalization
+// uvs_marginalize_resident().  See INTEGRATION.md for the diff a maintainer applies to the reference file.
 #include <chrono>
 #include "estimator.h"
 #include <cstdlib>
@@ -134,101 +134,67 @@ void Estimator::setReloFrame(double stamp, int index, std::vector<Eigen::Vector3
 
 namespace { double ms_since(std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); } }
 
+// Everything the solver reads besides the parameter values: the prior, the IMU links, and one index-addressed observation per residual
+// block, in the order the landmark rows of para_Feature / para_Ortho_plucker were filled by vector2double().  Which tracks take part
+// (FeatureManager::usedPoint / usedLine) and the emission order are behaviour of estimator.cpp:803-978 that the ABI relies on.
+void Estimator::assembleWindow(uvs::WindowAssembly& wa) {
+    if (last_marginalization_info && last_marginalization_info->prior.n > 0) wa.prior = &last_marginalization_info->prior;
+    for (int later = 1; later <= WINDOW_SIZE; ++later) {
+        const IntegrationBase& pre = *pre_integrations[later];
+        if (pre.sum_dt <= 10.0) wa.addImu(later - 1, pre);      // a pre-integration over more than 10 s is too uncertain to constrain anything
+    }
+    // loop-closure matches arrive sorted by feature id, like the track list: one forward cursor serves all tracks
+    auto match = match_points.cbegin();
+    const auto matches_end = relocalization_info ? match_points.cend() : match_points.cbegin();
+    for (FeaturePerId& track : f_manager.feature) {
+        if (!FeatureManager::usedPoint(track)) continue;
+        const int landmark = wa.n_points;
+        wa.addPointTrack(track, ESTIMATE_TD != 0);
+        if (match == matches_end || track.start_frame > relo_frame_local_index) continue;
+        match = std::find_if(match, matches_end, [&](const Eigen::Vector3d& m) { return (int)m.z() >= track.feature_id; });
+        if (match != matches_end && (int)match->z() == track.feature_id) { wa.addReloMatch(landmark, track.feature_per_frame.front().point, match->x(), match->y()); ++match; }
+    }
+    for (LineFeaturePerId& track : f_manager.line_feature)
+        if (FeatureManager::usedLine(track)) wa.addLineTrack(track);
+}
+
 void Estimator::optimization() {      // estimator.cpp:761-1233
     const auto t_begin = std::chrono::steady_clock::now();
-    uvs::AddressMap amap{para_Pose, para_SpeedBias, para_Ex_Pose, para_Feature, para_Ortho_plucker, para_Td, relo_Pose};
-    uvs::Problem problem(amap);
-    ceres_like::LossFunction* loss_function = new ceres_like::CauchyLoss(1.0);
-    ceres_like::LossFunction* line_loss_function = new ceres_like::CauchyLoss(0.1);
-    ceres_like::LossFunction* vp_loss_function = new ceres_like::CauchyLoss(1.0);
-    for (int i = 0; i < WINDOW_SIZE + 1; i++) {
-        problem.AddParameterBlock(para_Pose[i], SIZE_POSE, new PoseLocalParameterization());
-        problem.AddParameterBlock(para_SpeedBias[i], SIZE_SPEEDBIAS);
-    }
-    for (int i = 0; i < NUM_OF_CAM; i++) {
-        problem.AddParameterBlock(para_Ex_Pose[i], SIZE_POSE, new PoseLocalParameterization());
-        if (!ESTIMATE_EXTRINSIC) problem.SetParameterBlockConstant(para_Ex_Pose[i]);
-    }
-    if (ESTIMATE_TD) problem.AddParameterBlock(para_Td[0], 1);                                    // estimator.cpp:790-797
     vector2double();
-    if (last_marginalization_info && last_marginalization_info->prior.n > 0)
-        problem.AddResidualBlock(new MarginalizationFactor(last_marginalization_info), NULL, std::vector<double*>{});
-    for (int i = 0; i < WINDOW_SIZE; i++) {
-        int j = i + 1;
-        if (pre_integrations[j]->sum_dt > 10.0) continue;
-        problem.AddResidualBlock(new IMUFactor(pre_integrations[j]), NULL, para_Pose[i], para_SpeedBias[i], para_Pose[j], para_SpeedBias[j]);
-    }
-    int feature_index = -1;
-    for (auto& it_per_id : f_manager.feature) {
-        it_per_id.used_num = it_per_id.feature_per_frame.size();
-        if (!(it_per_id.used_num >= 2 && it_per_id.start_frame < WINDOW_SIZE - 2)) continue;
-        ++feature_index;
-        int imu_i = it_per_id.start_frame, imu_j = imu_i - 1;
-        Eigen::Vector3d pts_i = it_per_id.feature_per_frame[0].point;
-        for (auto& it_per_frame : it_per_id.feature_per_frame) {
-            imu_j++;
-            if (imu_i == imu_j) continue;
-            if (ESTIMATE_TD)                                                                      // estimator.cpp:853-858
-                problem.AddResidualBlock(new ProjectionTdFactor(pts_i, it_per_frame.point, it_per_id.feature_per_frame[0].velocity, it_per_frame.velocity,
-                                                                it_per_id.feature_per_frame[0].cur_td, it_per_frame.cur_td, it_per_id.feature_per_frame[0].uv.y(), it_per_frame.uv.y()),
-                                         loss_function, para_Pose[imu_i], para_Pose[imu_j], para_Ex_Pose[0], para_Feature[feature_index], para_Td[0]);
-            else
-                problem.AddResidualBlock(new ProjectionFactor(pts_i, it_per_frame.point), loss_function, para_Pose[imu_i], para_Pose[imu_j], para_Ex_Pose[0], para_Feature[feature_index]);
-        }
-    }
-    int line_feature_index = -1;
-    for (auto& it_per_id : f_manager.line_feature) {
-        it_per_id.used_num = it_per_id.line_feature_per_frame.size();
-        if (it_per_id.used_num < LINE_WINDOW) continue;
-        ++line_feature_index;
-        int imu_j = it_per_id.start_frame - 1;
-        for (auto& it_per_frame : it_per_id.line_feature_per_frame) {
-            imu_j++;
-            problem.AddResidualBlock(new LineProjectionFactor(ric[0], tic[0], it_per_frame.start_point, it_per_frame.end_point), line_loss_function, para_Pose[imu_j], para_Ortho_plucker[line_feature_index]);
-            if (it_per_frame.vp(2) == 1)
-                problem.AddResidualBlock(new VPProjectionFactor(ric[0], tic[0], it_per_frame.start_point, it_per_frame.end_point, it_per_frame.vp), vp_loss_function, para_Pose[imu_j], para_Ortho_plucker[line_feature_index]);
-        }
-    }
-    if (relocalization_info) {        // estimator.cpp:944-978
-        problem.AddParameterBlock(relo_Pose, SIZE_POSE, new PoseLocalParameterization());
-        int retrive_feature_index = 0;
-        int relo_feature_index = -1;
-        for (auto& it_per_id : f_manager.feature) {
-            it_per_id.used_num = it_per_id.feature_per_frame.size();
-            if (!(it_per_id.used_num >= 2 && it_per_id.start_frame < WINDOW_SIZE - 2)) continue;
-            ++relo_feature_index;
-            int start = it_per_id.start_frame;
-            if (start <= relo_frame_local_index) {
-                // (the reference reads match_points[retrive_feature_index] without a bound; an exhausted list simply matches nothing more)
-                while (retrive_feature_index < (int)match_points.size() && (int)match_points[retrive_feature_index].z() < it_per_id.feature_id) retrive_feature_index++;
-                if (retrive_feature_index < (int)match_points.size() && (int)match_points[retrive_feature_index].z() == it_per_id.feature_id) {
-                    Eigen::Vector3d pts_j = Eigen::Vector3d(match_points[retrive_feature_index].x(), match_points[retrive_feature_index].y(), 1.0);
-                    Eigen::Vector3d pts_i = it_per_id.feature_per_frame[0].point;
-                    problem.AddResidualBlock(new ProjectionFactor(pts_i, pts_j), loss_function, para_Pose[start], relo_Pose, para_Ex_Pose[0], para_Feature[relo_feature_index]);
-                    retrive_feature_index++;
-                }
-            }
-        }
-    }
+    uvs::WindowAssembly wa;
+    assembleWindow(wa);
+    uvs_window w = wa.view(para_Pose, para_SpeedBias, para_Ex_Pose[0], para_Td[0][0], &para_Feature[0][0], &para_Ortho_plucker[0][0], relo_Pose);
     // record hook (the reference has no serialisation): UVS_DUMP_WINDOWS=<dir> writes every window exactly as the
     // solver receives it (the state after vector2double(), estimator.cpp:800) to <dir>/window_NNNN.bin for replay without ROS
     if (const char* dump_dir = std::getenv("UVS_DUMP_WINDOWS")) {
         static int dump_index = 0;
-        uvs_window dw; problem.fill(&dw, feature_index + 1, line_feature_index + 1);
         char name[32]; std::snprintf(name, sizeof(name), "/window_%04d.bin", dump_index++);
-        WindowFile::save(std::string(dump_dir) + name, dw, relo_frame_local_index);
+        WindowFile::save(std::string(dump_dir) + name, w, relo_frame_local_index);
     }
-    uvs::Options options; options.max_num_iterations = NUM_ITERATIONS;
-    { const auto t0 = std::chrono::steady_clock::now(); uvs::Solve(options, &problem, &last_summary, solver, feature_index + 1, line_feature_index + 1); solve_ms += ms_since(t0); }
-    // ---- marginalization on the post-solve para_* arrays, BEFORE double2vector() re-anchors the gauge: the reference calls
-    // vector2double() again at :1004, i.e. it marginalizes at the re-anchored state; we follow it exactly below.
+    {   // == ceres::Solve(options, &problem, &summary) at :992; the result goes back into the para_* arrays, which double2vector() reads
+        const auto t0 = std::chrono::steady_clock::now();
+        std::vector<double> depths(std::max(wa.n_points, 1)), lines(4 * std::max(wa.n_lines, 1));
+        uvs_state result; std::memset(&result, 0, sizeof(result));
+        result.inv_depth = depths.data(); result.line_orth = lines.data();
+        const bool multi = uvs::resolve_path(solver_path) == uvs::MULTI_WORKGROUP && w.n_relo_obs == 0;      // (the fused loop takes no relocalization blocks)
+        last_summary.status = multi ? uvs_large_solve_fused(solver, &w, &result, &last_summary.report, nullptr) : uvs_solve_window(solver, &w, &result, &last_summary.report);
+        if (last_summary.status == UVS_OK || (last_summary.status == UVS_ERR_NUMERIC && last_summary.report.num_iterations > 0)) {      // like the reference, nobody looks at the summary; a call that failed before the solve leaves the state alone
+            std::memcpy(para_Pose, result.pose, sizeof(para_Pose)); std::memcpy(para_SpeedBias, result.speedbias, sizeof(para_SpeedBias));
+            std::memcpy(para_Ex_Pose[0], result.ex_pose, sizeof(result.ex_pose));      // unchanged unless ESTIMATE_EXTRINSIC
+            para_Td[0][0] = result.td;
+            if (w.n_relo_obs > 0) std::memcpy(relo_Pose, result.relo_pose, sizeof(relo_Pose));
+            for (int k = 0; k < wa.n_points; ++k) para_Feature[k][0] = depths[k];
+            std::copy(lines.begin(), lines.begin() + 4 * wa.n_lines, &para_Ortho_plucker[0][0]);
+        }
+        solve_ms += ms_since(t0);
+    }
+    // ---- marginalization: the reference re-anchors first (double2vector) and packs again (vector2double at :1004 / :1167), i.e. it
+    // marginalizes at the re-anchored state.  The factors are the ones the solve just uploaded; only that state goes to the device again.
     double2vector();
     vector2double();
     {
-        uvs_window w; problem.fill(&w, feature_index + 1, line_feature_index + 1);
         std::memcpy(w.pose, para_Pose, sizeof(w.pose)); std::memcpy(w.speedbias, para_SpeedBias, sizeof(w.speedbias));
         MarginalizationInfo* marginalization_info = new MarginalizationInfo();
-        // the factors are the ones uvs::Solve() just uploaded; only the (re-anchored) state goes to the device again
         const auto t0 = std::chrono::steady_clock::now();
         const int rc = uvs_marginalize_resident(solver, &w, marginalization_flag == MARGIN_OLD ? 0 : 1, &marginalization_info->prior);
         marginalize_ms += ms_since(t0);
@@ -239,11 +205,6 @@ void Estimator::optimization() {      // estimator.cpp:761-1233
             delete last_marginalization_info; last_marginalization_info = nullptr;
         }
     }
-    // losses that were never attached to a residual block are not owned by the Problem
-    if (problem.pt_lm.empty()) delete loss_function;
-    if (problem.ln_lm.empty()) delete line_loss_function;
-    bool any_vp = false; for (int v : problem.ln_has_vp) any_vp |= (v != 0);
-    if (!any_vp) delete vp_loss_function;
     optimization_ms += ms_since(t_begin); ++optimization_calls;
 }
 
@@ -316,10 +277,10 @@ void Estimator::processImage(const FeatureManager::ImagePoints& image, const Fea
         solver_flag = NON_LINEAR;
     }
     solveOdometry();
-    if (tracking && failureDetection()) {      // restart from scratch; double2vector() re-anchors the next window on last_R0 / last_P0
+    if (tracking && failureDetection()) {      // restart from scratch (estimator.cpp:198-204): the flag is raised BEFORE clearState(), which lowers it
+        failure_occur = true;                  // again (:77) -- so, as in the reference, the re-initialised window is NOT re-anchored on last_R0 / last_P0
         clearState();
         setParameter();
-        failure_occur = true;
         return;
     }
     slideWindow();

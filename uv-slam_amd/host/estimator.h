@@ -9,7 +9,8 @@
 #include <map>
 #include "parameters.h"
 #include "feature_manager.h"
-#include "problem.h"
+#include "factor/factors.h"
+#include "window_assembly.h"
 
 namespace std_msgs { struct Header { struct Stamp { double t = 0; double toSec() const { return t; } } stamp; }; }      // the one field of std_msgs::Header the estimator reads
 
@@ -19,6 +20,7 @@ class Estimator {
     ~Estimator();
     void setParameter();
     void optimization();
+    void assembleWindow(uvs::WindowAssembly& wa);      // the problem-construction part of optimization() (:803-978) as index-addressed arrays
     void vector2double();
     void double2vector();
     // ---- per-frame state machine (post-initialization)
@@ -85,6 +87,7 @@ class Estimator {
     // the reference keeps a vector<double*> of the prior's parameter blocks; here the block table lives inside uvs_prior
     uvs_solver* solver;          // HIP back-end handle (created in the constructor; throws when no GPU is present)
     uvs::Summary last_summary;   // kept for diagnostics (the reference discards ceres::Solver::Summary)
+    uvs::SolverPath solver_path = uvs::AUTO;      // which single-window form optimization() calls (window_assembly.h)
     // wall-clock spent inside optimization() (sums over the calls): whole call, uvs::Solve() alone, marginalization alone
     double optimization_ms = 0, solve_ms = 0, marginalize_ms = 0; int optimization_calls = 0;
 };

@@ -78,13 +78,16 @@ bool ProjectionFactor::Evaluate(double const* const* parameters, double* residua
     return true;
 }
 
-double ProjectionFactor::check(double** parameters) const {
-    double r0[2], Ja[14], Jb[14], Jc[14], Jd[2]; double* jac[4] = {Ja, Jb, Jc, Jd};
-    if (!Evaluate(parameters, r0, jac)) return -1.0;
+// the forward-difference self test shared by ProjectionFactor::check and ProjectionTdFactor::check (projection_factor.cpp:178-283,
+// projection_td_factor.cpp:147-...): `n_scalar` trailing 1-dof blocks after the three pose blocks
+namespace {
+template <class Factor> double projection_check(const Factor& f, double** parameters, int n_scalar) {
+    double r0[2], Jp[3][14], Js[2][2]; double* jac[5] = {Jp[0], Jp[1], Jp[2], Js[0], Js[1]};
+    if (!f.Evaluate(parameters, r0, jac)) return -1.0;
     const double eps = 1e-6;
     double worst = 0.0;
-    for (int k = 0; k < 19; ++k) {      // 6 + 6 + 6 tangent directions, then the inverse depth
-        double P[3][7], lam = parameters[3][0];
+    for (int k = 0; k < 18 + n_scalar; ++k) {      // 6 + 6 + 6 tangent directions, then the scalars
+        double P[3][7], sc[2] = {parameters[3][0], n_scalar > 1 ? parameters[4][0] : 0.0};
         for (int b = 0; b < 3; ++b) std::memcpy(P[b], parameters[b], sizeof(P[b]));
         if (k < 18) {
             const int b = k / 6, a = k % 6;
@@ -94,17 +97,48 @@ double ProjectionFactor::check(double** parameters) const {
                 const Eigen::Quaterniond q = (Eigen::Quaterniond(P[b][6], P[b][3], P[b][4], P[b][5]) * Utility::deltaQ(d)).normalized();
                 P[b][3] = q.x(); P[b][4] = q.y(); P[b][5] = q.z(); P[b][6] = q.w();
             }
-        } else lam += eps;
-        const double* pp[4] = {P[0], P[1], P[2], &lam};
+        } else sc[k - 18] += eps;
+        const double* pp[5] = {P[0], P[1], P[2], &sc[0], &sc[1]};
         double r1[2];
-        if (!Evaluate(pp, r1, nullptr)) return -1.0;
+        if (!f.Evaluate(pp, r1, nullptr)) return -1.0;
         for (int row = 0; row < 2; ++row) {
-            const double analytic = k < 18 ? jac[k / 6][row * 7 + k % 6] : Jd[row];
+            const double analytic = k < 18 ? Jp[k / 6][row * 7 + k % 6] : Js[k - 18][row];
             worst = std::max(worst, std::fabs((r1[row] - r0[row]) / eps - analytic));
         }
     }
     return worst;
 }
+}  // namespace
+
+double ProjectionFactor::check(double** parameters) const { return projection_check(*this, parameters, 1); }
+
+bool ProjectionTdFactor::Evaluate(double const* const* parameters, double* residuals, double** jacobians) const {
+    uvs_solver* s = uvs::evaluation_solver();
+    if (!s) return false;
+    uvs_window w; empty_window(w);
+    std::memcpy(w.pose[0], parameters[0], 7 * sizeof(double));
+    std::memcpy(w.pose[1], parameters[1], 7 * sizeof(double));
+    std::memcpy(w.ex_pose, parameters[2], 7 * sizeof(double));
+    double inv_depth = parameters[3][0];
+    w.td = parameters[4][0];
+    int32_t lm = 0, fi = 0, fj = 1;
+    const double pi[3] = {pts_i.x(), pts_i.y(), pts_i.z()}, pj[3] = {pts_j.x(), pts_j.y(), pts_j.z()};
+    const double vi[2] = {velocity_i.x(), velocity_i.y()}, vj[2] = {velocity_j.x(), velocity_j.y()};
+    const double tdi = td_i - TR / ROW * row_i, tdj = td_j - TR / ROW * row_j;      // the rolling-shutter term folded into the capture offset (include/uvs_solver.h)
+    w.n_points = 1; w.n_point_obs = 1; w.inv_depth = &inv_depth; w.pt_lm = &lm; w.pt_fi = &fi; w.pt_fj = &fj; w.pt_pi = pi; w.pt_pj = pj;
+    w.pt_vel_i = vi; w.pt_vel_j = vj; w.pt_td_i = &tdi; w.pt_td_j = &tdj;
+    double r[2], J[38], Jtd[2];      // [2][pose_i 6 | pose_j 6 | ex 6 | lambda], d r / d td
+    uvs_eval ev; std::memset(&ev, 0, sizeof(ev)); ev.pt_r = r; ev.pt_J = J; ev.pt_Jtd = Jtd;
+    if (uvs_evaluate(s, &w, 0, &ev) != UVS_OK) return false;      // (a handle without estimate_td rejects the time-offset arrays)
+    residuals[0] = r[0]; residuals[1] = r[1];
+    if (jacobians) {
+        for (int b = 0; b < 3; ++b) if (jacobians[b]) widen(J, 2, 19, 6 * b, 6, 7, jacobians[b]);
+        if (jacobians[3]) widen(J, 2, 19, 18, 1, 1, jacobians[3]);
+        if (jacobians[4]) { jacobians[4][0] = Jtd[0]; jacobians[4][1] = Jtd[1]; }
+    }
+    return true;
+}
+double ProjectionTdFactor::check(double** parameters) const { return projection_check(*this, parameters, 2); }
 
 bool IMUFactor::Evaluate(double const* const* parameters, double* residuals, double** jacobians) const {
     uvs_solver* s = uvs::evaluation_solver();

@@ -1,7 +1,7 @@
 // factors.h -- host-side factor classes with the reference's names and constructor signatures.
 // In the reference each class derives from a Ceres cost function and its Evaluate() runs on the CPU; here the classes are
-// DATA CARRIERS for the solve: uvs::Problem::AddResidualBlock() copies their members into the flat uvs_window and the residuals /
-// Jacobians are evaluated by the HIP kernels (csrc/uvs_factors.h).  The per-block evaluation surface of the reference is kept all the
+// DATA CARRIERS: Estimator::optimization() does not build them at all (it fills the flat uvs_window straight from the track lists,
+// window_assembly.h) and the residuals / Jacobians are evaluated by the HIP kernels (csrc/uvs_factors.h).  The per-block evaluation surface of the reference is kept all the
 // same -- Evaluate(parameters, residuals, jacobians) for the hand-coded factors (projection_factor.h:23, imu_factor.h:19,
 // marginalization_factor.h:78), operator()(pose, line, residuals) for the two auto-differentiated functors
 // (line_projection_factor.h:16-19, vp_projection_factor.h:19-22) -- and is ROUTED THROUGH THE GPU: each call builds the one-block
@@ -67,6 +67,11 @@ class ProjectionTdFactor : public uvs::CostFunction {      // projection_td_fact
                        const double _td_i, const double _td_j, const double _row_i, const double _row_j)
         : pts_i(_pts_i), pts_j(_pts_j), velocity_i(_velocity_i), velocity_j(_velocity_j), td_i(_td_i), td_j(_td_j), row_i(_row_i - ROW / 2), row_j(_row_j - ROW / 2) {}
     uvs::FactorKind kind() const override { return uvs::F_PROJECTION_TD; }
+    // parameters: Pose_i[7], Pose_j[7], Ex_Pose[7], Feature[1], Td[1]; residuals[2]; jacobians 2x7, 2x7, 2x7, 2x1, 2x1
+    // (projection_td_factor.cpp:34-145).  Needs an evaluation handle created with estimate_td = 1 (the Estimator's is when ESTIMATE_TD is set).
+    bool Evaluate(double const* const* parameters, double* residuals, double** jacobians) const;
+    // projection_td_factor.h:17 -- forward differences (eps = 1e-6, Q * deltaQ) against the analytic Jacobians, 20 directions incl. td
+    double check(double** parameters) const;
     Eigen::Vector3d pts_i, pts_j; Eigen::Vector2d velocity_i, velocity_j; double td_i, td_j, row_i, row_j;
 };
 struct LineProjectionFactor : public uvs::CostFunction {   // line_projection_factor.h:11-19

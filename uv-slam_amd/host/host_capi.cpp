@@ -319,3 +319,33 @@ extern "C" int uvs_host_factor_api_probe(const char* path, double* out, int cap)
     std::memcpy(out, v.data(), v.size() * sizeof(double));
     return fail((int)v.size());
 }
+
+// Test hook for ProjectionTdFactor::Evaluate / check (projection_td_factor.h:16-17): the first point observation of a window file that
+// carries the time-offset inputs, through the CLASS API on a handle created with estimate_td = 1.
+// out = [r2 | J 2x7 2x7 2x7 | J_lambda 2 | J_td 2 | check()]; returns the number of doubles written, < 0 on failure.
+extern "C" int uvs_host_td_factor_probe(const char* path, double* out, int cap) {
+    WindowFile wf;
+    if (!wf.load(path) || !wf.has_td || wf.w.n_point_obs < 1 || cap < 2 + 42 + 2 + 2 + 1) return -1;
+    setEurocParameters();
+    uvs_options o; uvs_default_options(&o); o.estimate_td = 1;
+    uvs_solver* s = nullptr;
+    if (uvs_create(&o, 0, 1, 1000, 16000, 1000, 16000, &s) != UVS_OK) return -2;
+    uvs::set_evaluation_solver(s);
+    ProjectionFactor::sqrt_info = FOCAL_LENGTH / 1.6;
+    const uvs_window& w = wf.w;
+    // TR = 0 in the EuRoC parameters, so the row arguments drop out and the file's folded capture offsets are td_i / td_j themselves
+    ProjectionTdFactor f(Eigen::Vector3d(w.pt_pi[0], w.pt_pi[1], w.pt_pi[2]), Eigen::Vector3d(w.pt_pj[0], w.pt_pj[1], w.pt_pj[2]),
+                         Eigen::Vector2d(w.pt_vel_i[0], w.pt_vel_i[1]), Eigen::Vector2d(w.pt_vel_j[0], w.pt_vel_j[1]), w.pt_td_i[0], w.pt_td_j[0], ROW / 2, ROW / 2);
+    double lam = w.inv_depth[w.pt_lm[0]], td = w.td, r[2], J0[14], J1[14], J2[14], J3[2], J4[2]; double* jac[5] = {J0, J1, J2, J3, J4};
+    double pi_[7], pj_[7], ex_[7]; std::memcpy(pi_, w.pose[w.pt_fi[0]], 56); std::memcpy(pj_, w.pose[w.pt_fj[0]], 56); std::memcpy(ex_, w.ex_pose, 56);
+    double* params[5] = {pi_, pj_, ex_, &lam, &td};
+    int n = -3;
+    if (f.Evaluate(params, r, jac)) {
+        std::vector<double> v(r, r + 2);
+        v.insert(v.end(), J0, J0 + 14); v.insert(v.end(), J1, J1 + 14); v.insert(v.end(), J2, J2 + 14); v.insert(v.end(), J3, J3 + 2); v.insert(v.end(), J4, J4 + 2);
+        v.push_back(f.check(params));
+        std::memcpy(out, v.data(), v.size() * sizeof(double)); n = (int)v.size();
+    }
+    uvs::set_evaluation_solver(nullptr); uvs_destroy(s);
+    return n;
+}
