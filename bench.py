@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=0, help="windows timed on the CPU oracle (0 = auto ~15 s)")
     ap.add_argument("--no-prior", action="store_true")
+    ap.add_argument("--no-stream", action="store_true", help="skip the end-to-end stream of fresh batches (profiling runs)")
     ap.add_argument("--no-replay", action="store_true", help="skip the closed-loop sequence replay (profiling runs)")
     ap.add_argument("--no-large", action="store_true", help="skip the configs[3] large-window timing (profiling runs)")
     ap.add_argument("--no-fused-single", action="store_true", help="skip the multi-workgroup form of the single window (keeps a kernel trace of the configs[3] leg clean)")
@@ -142,6 +143,24 @@ def main():
     states, reps = solver.download()
     n_total = args.batch * world * args.steps
     value = n_total / elapsed
+
+    # ---- end to end (never `value`): a STREAM of fresh batches through uvs_batch_stream -- host packing (threads), H2D, solve, D2H of consecutive
+    # batches overlapped on two buffer sets.  The same 256 windows are packed and uploaded again for every batch (nothing is cached between batches).
+    end_to_end = None
+    if rank == 0 and not args.no_stream:
+        nb = 8
+        try:
+            _, sreps, _ = solver.stream(windows * 2, args.batch, want_states=False)      # warm-up: second buffer set, pinned staging, packing buffers
+            _, sreps, wall_ms = solver.stream(windows * nb, args.batch, want_states=False)
+            ok = all(r.status == 0 for r in sreps) and all(sreps[i].final_cost == reps[i % args.batch].final_cost for i in range(len(sreps)))
+            end_to_end = {"what": "uvs_batch_stream: %d batches of %d windows, packing + H2D + solve + D2H overlapped (two buffer sets); wall time of the C-ABI call" % (nb, args.batch),
+                          "solves_per_s": nb * args.batch / (wall_ms * 1e-3), "ms_per_batch": wall_ms / nb, "bitwise_equal_to_resident_solves": bool(ok),
+                          "serial_reference": {"what": "upload (pack + H2D) then solve then download of ONE batch, nothing overlapped",
+                                               "ms_per_batch": None}}
+            solver.upload(windows); up = solver.last_upload_ms; kms = solver.solve_resident(); solver.download()      # C-ABI call times only (no ctypes conversion)
+            end_to_end["serial_reference"]["ms_per_batch"] = up + kms + solver.last_download_ms; end_to_end["serial_reference"]["pack_upload_ms"] = up
+        except Exception as e:
+            end_to_end = {"error": repr(e)}
 
     # ---- BASELINE configs[3]: ONE window with 20 000 points + 5 000 lines, landmarks sharded k mod N over the ranks (all ranks take part)
     large = None
@@ -315,7 +334,7 @@ def main():
                        "windows_per_gpu": args.batch, "frames": 11, "points": 150, "lines": 40, "vp_tagged_lines": 30,
                        "prior": (not args.no_prior), "max_lm_iterations": 10, "parallelism": f"replicas x{world}"},
             "lm_iterations_mean": float(its.mean()), "lm_successful_steps_mean": float(np.mean([r.num_successful for r in reps])), "final_cost_mean": float(np.mean([r.final_cost for r in reps])),
-            "batch_pack_upload_ms": pack_upload_ms,
+            "batch_pack_upload_ms": pack_upload_ms, "value_end_to_end": (end_to_end or {}).get("solves_per_s"), "end_to_end": end_to_end,
             "single_window": single, "single_window_ms": sw_ms, "single_window_solves_per_s": 1e3 / sw_ms, "single_window_pcie_inclusive_ms": pcie * 1e3,
             "replay": replay, "large_window": large, "roofline": roofline, "cpu_baseline": cpu,
         }

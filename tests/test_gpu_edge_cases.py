@@ -178,3 +178,27 @@ def test_threaded_batch_packing_equals_serial(gpu_api):
     s1, r1 = run(1); s8, r8 = run(8)
     for a, b, ra, rb in zip(s1, s8, r1, r8):
         assert ra.status == 0 and ra.final_cost == rb.final_cost and np.array_equal(a.pose, b.pose) and np.array_equal(a.inv_depth, b.inv_depth) and np.array_equal(a.line_orth, b.line_orth)
+
+
+def test_batch_stream_equals_batch_by_batch(gpu_api):
+    """uvs_batch_stream: five heterogeneous batches through the double-buffered pipeline (packing of batch k + 1 on host threads while the GPU
+    runs H2D -> k_solve -> gather -> D2H of batch k; the two buffer sets alternate and each is reused twice) against upload / solve / download
+    of every batch on a fresh handle: bitwise equal states and reports.  Then once more on the same handle (the twin buffer set is reused)."""
+    rng = np.random.default_rng(12)
+    per, nb = 12, 5
+    ws = [synth.make_window(1200 + i, n_points=int(rng.integers(20, 200)), n_lines=int(rng.integers(0, 50)), n_tagged=0) for i in range(per * nb)]
+    s = gpu_api.Solver(max_batch=16)
+    st, rep, ms = s.stream(ws, per)
+    st2, rep2, ms2 = s.stream(ws, per)
+    s.close()
+    assert ms > 0.0 and len(st) == per * nb
+    ref = gpu_api.Solver(max_batch=16)
+    for k in range(nb):
+        ref.upload(ws[k * per:(k + 1) * per]); ref.solve_resident(); sr, rr = ref.download()
+        for b in range(per):
+            i = k * per + b
+            assert rep[i].status == 0 and rep[i].final_cost == rr[b].final_cost and rep[i].num_iterations == rr[b].num_iterations
+            assert np.array_equal(st[i].pose, sr[b].pose) and np.array_equal(st[i].speedbias, sr[b].speedbias)
+            assert np.array_equal(st[i].inv_depth, sr[b].inv_depth) and np.array_equal(st[i].line_orth, sr[b].line_orth)
+            assert rep2[i].final_cost == rep[i].final_cost and np.array_equal(st2[i].pose, st[i].pose)
+    ref.close()

@@ -18,7 +18,7 @@ _lib = None
 
 EXPORTS = [
     "uvs_abi_version", "uvs_default_options", "uvs_create", "uvs_destroy", "uvs_last_error", "uvs_status_string",
-    "uvs_solve_window", "uvs_batch_upload", "uvs_batch_solve", "uvs_batch_download", "uvs_evaluate", "uvs_marginalize", "uvs_marginalize_resident",
+    "uvs_solve_window", "uvs_batch_upload", "uvs_batch_solve", "uvs_batch_download", "uvs_batch_stream", "uvs_evaluate", "uvs_marginalize", "uvs_marginalize_resident",
     "uvs_reduced_dim",
 ]
 
@@ -45,6 +45,8 @@ def lib():
         L.uvs_batch_solve.restype = C.c_int
         L.uvs_batch_download.argtypes = [C.c_void_p, C.c_int, C.POINTER(abi.StateC), C.POINTER(abi.Report)]
         L.uvs_batch_download.restype = C.c_int
+        L.uvs_batch_stream.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.POINTER(abi.WindowC)), C.POINTER(abi.StateC), C.POINTER(abi.Report), C.POINTER(C.c_double)]
+        L.uvs_batch_stream.restype = C.c_int
         L.uvs_evaluate.argtypes = [C.c_void_p, C.POINTER(abi.WindowC), C.c_int, C.POINTER(abi.EvalC)]
         L.uvs_evaluate.restype = C.c_int
         L.uvs_marginalize.argtypes = [C.c_void_p, C.POINTER(abi.WindowC), C.c_int, C.POINTER(abi.Prior)]
@@ -146,10 +148,31 @@ class Solver:
         for i, st in enumerate(states):
             sarr[i].inv_depth = abi._dp(st.inv_depth); sarr[i].line_orth = abi._dp(st.line_orth)
         reps = (abi.Report * n)()
-        self._check(lib().uvs_batch_download(self._h, n, sarr, reps), allow=(abi.UVS_OK, abi.UVS_ERR_NUMERIC))
+        t0 = time.perf_counter()
+        rc = lib().uvs_batch_download(self._h, n, sarr, reps)
+        self.last_download_ms = (time.perf_counter() - t0) * 1e3      # the C-ABI call alone
+        self._check(rc, allow=(abi.UVS_OK, abi.UVS_ERR_NUMERIC))
         for i, st in enumerate(states):
             st.from_c(sarr[i])
         return states, list(reps)
+
+    def stream(self, windows, per_batch, want_states=True):
+        """len(windows) / per_batch batches end to end (uvs_batch_stream): host packing, upload, solve and download of consecutive batches
+        overlap.  Returns (states, reports, wall_ms of the C-ABI call)."""
+        n = len(windows)
+        assert n % per_batch == 0
+        cs = [w.to_c() for w in windows]
+        arr = (C.POINTER(abi.WindowC) * n)(*[C.pointer(c[0]) for c in cs])
+        states = [abi.State(len(w.inv_depth), len(w.line_orth)) for w in windows] if want_states else []
+        sarr = (abi.StateC * n)() if want_states else None
+        for i, st in enumerate(states):
+            sarr[i].inv_depth = abi._dp(st.inv_depth); sarr[i].line_orth = abi._dp(st.line_orth)
+        reps = (abi.Report * n)()
+        ms = C.c_double(0.0)
+        self._check(lib().uvs_batch_stream(self._h, n // per_batch, per_batch, arr, sarr, reps, C.byref(ms)), allow=(abi.UVS_OK, abi.UVS_ERR_NUMERIC))
+        for i, st in enumerate(states):
+            st.from_c(sarr[i])
+        return states, list(reps), float(ms.value)
 
     # ---- one large window over the whole GPU / several GPUs (BASELINE configs[3]) ----
     def large_solve(self, w: abi.Window, dist=None, device=None):

@@ -32,6 +32,7 @@ struct uvs_solver {
     int device;
     int max_batch;
     int max_points = 0, max_point_obs = 0, max_lines = 0, max_line_obs = 0;      // per-window capacities promised at uvs_create
+    uvs_solver* twin = nullptr;              // second buffer set of uvs_batch_stream (created on first use, destroyed with this handle)
     int n_cus = 256;                         // compute units of the device
     int chunk_wgs() const { return std::max(1, n_cus - 1); }      // chunk workgroups of the persistent large-window kernels: one compute unit stays free for the frame-terms workgroup of the same launch
     hipStream_t stream;
@@ -42,6 +43,7 @@ struct uvs_solver {
     std::vector<DevWin> hdrs;                // host copies of the per-window headers
     std::vector<long long> blob_off, ws_off;
     std::vector<char> host_blobs;
+    std::vector<std::vector<char>> slot_blobs;      // batch uploads: one packing buffer per batch slot, kept (with its pages) from batch to batch
     // ONE host -> device copy per upload: [blobs | blob_off[n] | ws_off[n] | out_tab[3 n]] staged in pinned memory; the three tables
     // live behind the blobs in the same device allocation (d_blob_off / d_ws_off / d_out_tab point into it)
     char* d_blobs = nullptr; size_t d_blobs_cap = 0;
@@ -171,6 +173,7 @@ int uvs_create(const uvs_options* opts, int device, int max_batch, int max_point
 
 void uvs_destroy(uvs_solver* s) {
     if (!s) return;
+    if (s->twin) { uvs_destroy(s->twin); s->twin = nullptr; }
     (void)hipSetDevice(s->device);      // teardown: nothing useful to do with an error
     if (s->d_blobs) (void)hipFree(s->d_blobs);
     if (s->d_ws) (void)hipFree(s->d_ws);
@@ -741,6 +744,7 @@ static int upload_windows(uvs_solver* s, int n, const uvs_window* const* ws, boo
     // packed by several host threads into per-window buffers and concatenated -- 0.3 ms per window on one core was 83 ms for the 256-window
     // batch, 45 x the solve it feeds.  UVS_PACK_THREADS overrides the thread count (1 = the serial path, also taken for small batches).
     int nthreads = 1;
+    size_t packed_total = 0;      // > 0: the windows sit in s->slot_blobs (threaded path) and go straight into the pinned staging buffer below
     if (n >= 8) {
         const char* env = std::getenv("UVS_PACK_THREADS");
         nthreads = env ? std::atoi(env) : (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
@@ -753,19 +757,22 @@ static int upload_windows(uvs_solver* s, int n, const uvs_window* const* ws, boo
             if (rc != UVS_OK) { s->n_loaded = 0; return rc; }
         }
     } else {
-        std::vector<std::vector<char>> parts(n);
+        // per-slot buffers that live in the handle: a fresh 260 KB vector per window was a page fault per 4 KB of it, every batch (0.9 ms per window
+        // on a cold buffer against 0.12 ms on a warm one)
+        if ((int)s->slot_blobs.size() < n) s->slot_blobs.resize(n);
         std::vector<int> rcs(n, UVS_OK); std::vector<std::string> errs(n);
-        std::vector<std::thread> pool;
-        for (int t = 0; t < nthreads; ++t)
-            pool.emplace_back([&, t] { for (int b = t; b < n; b += nthreads) rcs[b] = pack_window(ws[b], s->opts, parts[b], s->hdrs[b], errs[b], chunk_grid); });
-        for (auto& th : pool) th.join();
+        {
+            std::vector<std::thread> pool;
+            for (int t = 0; t < nthreads; ++t)
+                pool.emplace_back([&, t] { for (int b = t; b < n; b += nthreads) { s->slot_blobs[b].clear(); rcs[b] = pack_window(ws[b], s->opts, s->slot_blobs[b], s->hdrs[b], errs[b], chunk_grid); } });
+            for (auto& th : pool) th.join();
+        }
         size_t total = 0;
         for (int b = 0; b < n; ++b) {
             if (rcs[b] != UVS_OK) { s->err = errs[b]; s->n_loaded = 0; return rcs[b]; }      // the first failing window in batch order, as the serial path reports it
-            s->blob_off[b] = (long long)total; total += parts[b].size();
+            s->blob_off[b] = (long long)total; total += s->slot_blobs[b].size();
         }
-        s->host_blobs.resize(total);
-        for (int b = 0; b < n; ++b) std::memcpy(s->host_blobs.data() + s->blob_off[b], parts[b].data(), parts[b].size());
+        packed_total = total;
     }
     for (int b = 0; b < n; ++b) { s->ws_off[b] = wtot; wtot += s->hdrs[b].ws_doubles; }
     s->out_tab.resize(3 * (size_t)n); s->out_total = 0;
@@ -776,18 +783,24 @@ static int upload_windows(uvs_solver* s, int n, const uvs_window* const* ws, boo
         s->out_total += cnt;
     }
     int rc;
-    const size_t blob_bytes = (s->host_blobs.size() + 7) & ~(size_t)7, up_bytes = blob_bytes + (size_t)n * 40;
+    const size_t raw_bytes = packed_total ? packed_total : s->host_blobs.size();
+    const size_t blob_bytes = (raw_bytes + 7) & ~(size_t)7, up_bytes = blob_bytes + (size_t)n * 40;
     // the staging buffer may still feed the previous upload's copy (the single-window path does not wait for it): drain before reuse
     HIPCHK(s, hipStreamSynchronize(s->stream));
-    if ((rc = ensure_pinned(s, &s->h_up, &s->h_up_cap, blob_bytes <= ((size_t)4 << 20) ? up_bytes : (size_t)n * 40)) != UVS_OK) return rc;
+    // small uploads (the online single-window case) and threaded batch uploads are staged in pinned memory together with their tables: ONE copy that the
+    // host need not wait for; a single large blob (configs[3]: 20 MB) would pay a second serial pass over memory for it and goes from the pageable vector directly
+    const bool staged = packed_total > 0 || blob_bytes <= ((size_t)4 << 20);
+    if ((rc = ensure_pinned(s, &s->h_up, &s->h_up_cap, staged ? up_bytes : (size_t)n * 40)) != UVS_OK) return rc;
     if ((rc = ensure(s, (void**)&s->d_blobs, &s->d_blobs_cap, up_bytes)) != UVS_OK) return rc;
     if ((rc = ensure(s, (void**)&s->d_outpack, &s->d_outpack_cap, (size_t)s->out_total * 8 + (size_t)n * sizeof(uvs_report))) != UVS_OK) return rc;
     if ((rc = ensure(s, (void**)&s->d_ws, &s->d_ws_cap, (size_t)wtot * 8)) != UVS_OK) return rc;
     if ((rc = ensure(s, (void**)&s->d_reports, &s->d_rep_cap, (size_t)n * sizeof(uvs_report))) != UVS_OK) return rc;
-    // small uploads (the online single-window case) are staged in pinned memory together with their tables: ONE copy that the host need not wait
-    // for; a large blob (configs[3]: 20 MB) would pay a second pass over memory for it and goes from the pageable vector directly
-    const bool staged = blob_bytes <= ((size_t)4 << 20);
-    if (staged) std::memcpy(s->h_up, s->host_blobs.data(), s->host_blobs.size());
+    if (packed_total) {      // every packing thread moves its own windows (67 MB for 256 canonical windows: one core would need ~10 ms)
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nthreads; ++t)
+            pool.emplace_back([&, t] { for (int b = t; b < n; b += nthreads) std::memcpy(s->h_up + s->blob_off[b], s->slot_blobs[b].data(), s->slot_blobs[b].size()); });
+        for (auto& th : pool) th.join();
+    } else if (staged) std::memcpy(s->h_up, s->host_blobs.data(), s->host_blobs.size());
     long long* tabs = (long long*)(s->h_up + (staged ? blob_bytes : 0));
     std::memcpy(tabs, s->blob_off.data(), (size_t)n * 8);
     std::memcpy(tabs + n, s->ws_off.data(), (size_t)n * 8);
@@ -832,10 +845,8 @@ int uvs_batch_solve(uvs_solver* s, float* elapsed_ms) {
     return launch_solve(s, 0, elapsed_ms);
 }
 
-int uvs_batch_download(uvs_solver* s, int n, uvs_state* states, uvs_report* reps) {
-    if (!s || n < 1 || n > s->n_loaded) return UVS_ERR_INVALID_ARG;
-    HIPCHK(s, hipSetDevice(s->device));
-    int worst = UVS_OK;
+// the two halves of a download: enqueue (gather kernel + ONE copy into pinned memory, nothing waits) and finish (wait, unpack)
+static int download_enqueue(uvs_solver* s, int n) {
     // every window's final state (frames | inv_depth | line_orth, written by k_solve into its workspace) and its report are gathered on the
     // device and fetched with ONE copy into pinned memory (256 windows were 256 synchronous round trips once)
     const size_t nst = (size_t)(s->out_tab[3 * (size_t)(n - 1) + 2] + s->out_tab[3 * (size_t)(n - 1) + 1]);      // doubles of the first n states
@@ -845,7 +856,12 @@ int uvs_batch_download(uvs_solver* s, int n, uvs_state* states, uvs_report* reps
     hipLaunchKernelGGL(k_pack_outputs, dim3(n), dim3(256), 0, s->stream, s->d_ws, s->d_out_tab, s->d_outpack, s->d_reports, (long long)nst);
     HIPCHK(s, hipGetLastError());
     HIPCHK(s, hipMemcpyAsync(s->h_out, s->d_outpack, tot, hipMemcpyDeviceToHost, s->stream));
+    return UVS_OK;
+}
+static int download_finish(uvs_solver* s, int n, uvs_state* states, uvs_report* reps) {
     HIPCHK(s, hipStreamSynchronize(s->stream));
+    const size_t nst = (size_t)(s->out_tab[3 * (size_t)(n - 1) + 2] + s->out_tab[3 * (size_t)(n - 1) + 1]);
+    int worst = UVS_OK;
     const uvs_report* hr = (const uvs_report*)(s->h_out + nst * 8);
     for (int b = 0; b < n; ++b) if (hr[b].status != UVS_OK) worst = hr[b].status;
     if (reps) std::memcpy(reps, hr, sizeof(uvs_report) * (size_t)n);
@@ -861,6 +877,52 @@ int uvs_batch_download(uvs_solver* s, int n, uvs_state* states, uvs_report* reps
         if (st.inv_depth) std::memcpy(st.inv_depth, buf + UVS_XDIM, sizeof(double) * h.n_points);
         if (st.line_orth) std::memcpy(st.line_orth, buf + UVS_XDIM + h.n_points, sizeof(double) * 4 * h.n_lines);
     }
+    return worst;
+}
+
+int uvs_batch_download(uvs_solver* s, int n, uvs_state* states, uvs_report* reps) {
+    if (!s || n < 1 || n > s->n_loaded) return UVS_ERR_INVALID_ARG;
+    HIPCHK(s, hipSetDevice(s->device));
+    const int rc = download_enqueue(s, n);
+    if (rc != UVS_OK) return rc;
+    return download_finish(s, n, states, reps);
+}
+
+// A STREAM of batches, end to end: packing (host threads), upload, solve and download of consecutive batches overlap.  Two buffer sets -- this handle and a
+// twin created on first use with the same options and capacities, each with its own stream, pinned staging and device buffers -- alternate: while the GPU
+// runs  H2D -> k_solve -> gather -> D2H  of batch k on one set, the host packs batch k + 1 into the other; a set is drained (wait + unpack) right before it
+// is reused.  Results equal uvs_batch_upload / solve / download of each batch (same packing, same kernel).
+int uvs_batch_stream(uvs_solver* s, int n_batches, int per_batch, const uvs_window* const* ws, uvs_state* states, uvs_report* reps, double* wall_ms) {
+    if (!s || n_batches < 1 || per_batch < 1 || !ws) return UVS_ERR_INVALID_ARG;
+    if (per_batch > s->max_batch) { s->err = "batch larger than max_batch"; return UVS_ERR_CAPACITY; }
+    if (!s->twin) {
+        const int rc = uvs_create(&s->opts, s->device, s->max_batch, s->max_points, s->max_point_obs, s->max_lines, s->max_line_obs, &s->twin);
+        if (rc != UVS_OK) { s->err = "uvs_batch_stream: could not create the second buffer set"; return rc; }
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    uvs_solver* set[2] = {s, s->twin};
+    int pending[2] = {-1, -1};      // batch index in flight on each set
+    int worst = UVS_OK;
+    const auto drain = [&](int q) -> int {
+        if (pending[q] < 0) return UVS_OK;
+        const size_t off = (size_t)pending[q] * per_batch;
+        const int rc = download_finish(set[q], per_batch, states ? states + off : nullptr, reps ? reps + off : nullptr);
+        pending[q] = -1;
+        if (rc != UVS_OK && rc != UVS_ERR_NUMERIC) { if (set[q] != s) s->err = set[q]->err; return rc; }
+        if (rc != UVS_OK) worst = rc;
+        return UVS_OK;
+    };
+    for (int k = 0; k < n_batches; ++k) {
+        const int q = k & 1;
+        int rc = drain(q);
+        if (rc == UVS_OK) rc = upload_windows(set[q], per_batch, ws + (size_t)k * per_batch, false);
+        if (rc == UVS_OK) rc = launch_solve(set[q], 0, nullptr, false);
+        if (rc == UVS_OK) rc = download_enqueue(set[q], per_batch);
+        if (rc != UVS_OK) { if (set[q] != s) s->err = set[q]->err; (void)hipStreamSynchronize(set[0]->stream); (void)hipStreamSynchronize(set[1]->stream); return rc; }
+        pending[q] = k;
+    }
+    for (int q = 0; q < 2; ++q) { const int rc = drain(q); if (rc != UVS_OK) return rc; }
+    if (wall_ms) *wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return worst;
 }
 
