@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define UVS_ABI_VERSION 4
+#define UVS_ABI_VERSION 5
 
 #define UVS_WINDOW_SIZE 10                    /* parameters.h:12 WINDOW_SIZE  */
 #define UVS_NUM_FRAMES (UVS_WINDOW_SIZE + 1)  /* frames 0..WINDOW_SIZE        */
@@ -60,7 +60,8 @@ enum {
     UVS_TERM_FUNCTION_TOL = 3,
     UVS_TERM_MIN_RADIUS = 4,
     UVS_TERM_INVALID_STEPS = 5,        /* max_num_consecutive_invalid_steps    */
-    UVS_TERM_NUMERIC_FAILURE = 6
+    UVS_TERM_NUMERIC_FAILURE = 6,
+    UVS_TERM_MAX_TIME = 7              /* max_solver_time_in_seconds reached (Ceres: NO_CONVERGENCE, "Maximum solver time reached") */
 };
 
 /* Solver options == the globals Estimator::optimization() reads
@@ -92,6 +93,9 @@ typedef struct uvs_options {
     double parameter_tolerance;           /* 1e-8 */
     int32_t max_consecutive_invalid_steps;/* 5 */
     int32_t jacobi_scaling;               /* 1 */
+    double max_solver_time_in_seconds;    /* options.max_solver_time_in_seconds = SOLVER_TIME or 0.8 SOLVER_TIME (estimator.cpp:987-991); checked at the top of
+                                           * every LM iteration with the GPU's 100 MHz wall clock.  0 (default) = no cap: the iteration count is then
+                                           * deterministic, which the parity runs need */
 } uvs_options;
 
 /* One IMU pre-integration block == the fields of IntegrationBase that

@@ -70,17 +70,6 @@ def test_time_offset_and_free_extrinsic(gpu_api):
     _same_solve(s, w, cost_rtol=1e-7, pose_tol=1e-6)
     s.close()
 
-
-def test_relocalization_blocks_are_refused_by_the_fused_form(gpu_api):
-    s = gpu_api.Solver(max_batch=1)
-    w = synth.add_relocalization(synth.make_window(2), seed=2)
-    with pytest.raises(Exception):
-        s.large_solve_fused(w)
-    st, rep = s.solve(w)      # the persistent kernel takes them
-    assert rep.num_iterations > 0
-    s.close()
-
-
 def test_repeated_calls_alternating_forms_and_batch_sizes(gpu_api):
     """The two forms share the handle's staging buffers (pinned upload / download, device blobs): interleaved calls must not disturb each other."""
     s = gpu_api.Solver(max_batch=8)

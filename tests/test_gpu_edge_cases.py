@@ -202,3 +202,23 @@ def test_batch_stream_equals_batch_by_batch(gpu_api):
             assert np.array_equal(st[i].inv_depth, sr[b].inv_depth) and np.array_equal(st[i].line_orth, sr[b].line_orth)
             assert rep2[i].final_cost == rep[i].final_cost and np.array_equal(st2[i].pose, st[i].pose)
     ref.close()
+
+
+@pytest.mark.parametrize("form", ["persistent", "fused", "step-wise"])
+def test_max_solver_time_in_seconds(gpu_api, form):
+    """options.max_solver_time_in_seconds (estimator.cpp:987-991, SOLVER_TIME): checked at the top of every LM iteration (the GPU's 100 MHz wall clock in
+    the kernels, the host's clock in the host-driven loop).  A cap far above a solve changes nothing (bitwise); a cap of 100 ns stops after the first
+    iteration with UVS_TERM_MAX_TIME and a VALID state (the first accepted step); 0 = no cap is the default."""
+    w = synth.make_window(61)
+    def run(cap):
+        o = abi.default_options(); o.max_solver_time_in_seconds = cap
+        s = gpu_api.Solver(o, max_batch=2)
+        if form == "persistent": st, rep = s.solve(w)
+        elif form == "fused": s.large_comm_init(None); st, rep, _ = s.large_solve_fused(w)
+        else: st, rep = s.large_solve(w)
+        s.close()
+        return st, rep
+    s0, r0 = run(0.0); s1, r1 = run(10.0); s2, r2 = run(1e-7)
+    assert r0.termination != 7 and r1.num_iterations == r0.num_iterations and r1.final_cost == r0.final_cost and np.array_equal(s1.pose, s0.pose)
+    assert r2.termination == 7 and r2.status == 0 and r2.num_iterations == 1 and abs(r2.final_cost - r0.cost[1]) <= 1e-12 * r0.cost[1] and r2.final_cost < r2.initial_cost      # (the candidate-cost sum vs the next linearization's: another summation order)
+    assert np.isfinite(s2.pose).all() and not np.array_equal(s2.pose, w.pose)

@@ -140,9 +140,7 @@ def test_relo_rejected_combinations(gpu_api):
         with pytest.raises(RuntimeError, match="uvs error %d" % abi.UVS_ERR_UNSUPPORTED):
             s.solve(wq)
         s.close()
-    s = gpu_api.Solver(max_batch=2)
-    with pytest.raises(RuntimeError, match="uvs error %d" % abi.UVS_ERR_UNSUPPORTED):
-        s.large_solve(w)
+    s = gpu_api.Solver(max_batch=2)      # (the large-window path takes the blocks since round 3: test_relo_blocks_in_the_multi_workgroup_forms)
     bad = w.copy(); bad.relo_lm = bad.relo_lm[::-1].copy()
     with pytest.raises(RuntimeError, match="uvs error %d" % abi.UVS_ERR_INVALID_ARG):
         s.solve(bad)
@@ -186,3 +184,29 @@ def test_host_estimator_relocalization(gpu_api, tmp_path):
     assert abs(rel_yaw - e) < 1e-7
     # gauge-free cross-check straight from the raw solver output
     assert np.abs(rel_t - R(st.relo_pose[3:]).T @ (st.pose[k, :3] - st.relo_pose[:3])).max() < 1e-8
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("index,kw", [(21, dict(relo_frame=5)), (22, dict(relo_frame=0, fraction=0.3)), (23, dict(relo_frame=9, with_prior=True))])
+def test_relo_blocks_in_the_multi_workgroup_forms(gpu_api, oracle, index, kw):
+    """Relocalization blocks through the landmark-sharded path (round 3: relo_Pose travels in the 192-double frame state of the large kernels): the
+    step-wise loop and the fused device-side loop -- what the host mirror's Estimator::optimization() calls during a loop closure -- against the
+    persistent kernel and the oracle: identical LM traces, relo_Pose and poses to 1e-8."""
+    if kw.get("with_prior"):
+        kw = dict(kw); kw["marginalize_fn"] = lambda win, flag: oracle.marginalize(win, flag)
+    w = _relo_window(index, **kw)
+    assert len(w.relo_lm) > 5
+    s = gpu_api.Solver(max_batch=2)
+    s0, r0 = s.solve(w)
+    s1, r1 = s.large_solve(w)
+    s.large_comm_init(None)
+    s2, r2, _ = s.large_solve_fused(w)
+    s.close()
+    so, ro = oracle.solve(w)
+    n = ro.num_iterations
+    for name, (st, rep) in {"step-wise": (s1, r1), "fused": (s2, r2), "persistent": (s0, r0)}.items():
+        assert rep.status == 0 and rep.num_iterations == n and list(rep.accepted[:n + 1]) == list(ro.accepted[:n + 1]), name
+        assert abs(rep.final_cost - ro.final_cost) <= 1e-7 * ro.final_cost, name
+        assert pose_deltas(st.pose, so.pose)[0] < 1e-7 and np.abs(st.relo_pose - so.relo_pose).max() < 1e-7, name
+        assert np.abs(st.inv_depth - so.inv_depth).max() < 1e-6, name
+    assert np.abs(s2.relo_pose - w.relo_pose).max() > 1e-3      # relo_Pose did move

@@ -34,6 +34,7 @@ class Options(C.Structure):
         ("min_relative_decrease", C.c_double), ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double),
         ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double), ("parameter_tolerance", C.c_double),
         ("max_consecutive_invalid_steps", C.c_int32), ("jacobi_scaling", C.c_int32),
+        ("max_solver_time_in_seconds", C.c_double),
     ]
 
 

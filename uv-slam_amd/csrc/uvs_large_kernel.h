@@ -18,8 +18,8 @@ namespace uvsdev {
 
 static constexpr int LG_ACC = UVS_NBLKX * 64;               // 4992 accumulator slots [gather block (66 pose blocks + 12 time-offset blocks)][row a][8] -- canonical, independent of the per-window group balance
 static constexpr int LG_RED = LG_ACC + 8;                  // + {landmark cost, max |g_l|, 6 spare}
-enum { LS_X = 0, LS_XC = 184, LS_DLT = 368, LS_G = 544, LS_DD = 720, LS_SC = 896, LS_END = LS_SC + UVS_RD };
-static constexpr int LG_STATE = 1280;                      // doubles: X[184] XC[184] DLT[176] G[176] DD[176] SC[176]
+enum { LS_X = 0, LS_XC = UVS_XDIM, LS_DLT = 2 * UVS_XDIM, LS_G = LS_DLT + UVS_RD, LS_DD = LS_G + UVS_RD, LS_SC = LS_DD + UVS_RD, LS_END = LS_SC + UVS_RD };
+static constexpr int LG_STATE = 1280;                      // doubles: X[192] XC[192] DLT[176] G[176] DD[176] SC[176]   (X = pose | speedbias | ex_pose | td | relo_pose | pad)
 static_assert(LS_END <= LG_STATE, "large-path state vector overflows its allocation");
 enum { LO_COST = 0, LO_GMAX, LO_CHOLOK, LO_GD, LO_DD2, LO_STEP2, LO_XC2, LO_FRAMECOST, LO_N };
 // ---- device-resident trust-region state of the FUSED loop (uvs_large_solve_fused: no host round trip per iteration).
@@ -30,7 +30,7 @@ static constexpr int LG_MAXRANKS = 8;
 // frame image written by the extra workgroup of k_large_chunks: S without the landmark blocks and without damping | gradient | diag(J^T J) | {cost of the frame terms}
 static constexpr int FI_S = 0, FI_G = UVS_S_DOUBLES, FI_HD = FI_G + UVS_RD, FI_COST = FI_HD + UVS_RD, LG_FIMG = FI_COST + 8;
 static constexpr int LX_X2 = LG_RED, LX_GMAX = LG_RED + 1, LG_XCH = LG_RED + 1 + LG_MAXRANKS + 7;      // 5016 doubles
-enum { LC_RADIUS = 0, LC_DECR, LC_COST, LC_GMAX, LC_XNORM, LC_FRAME_X2, LC_IT, LC_INVALID, LC_NSUCC, LC_PENDING, LC_TERM, LC_STATUS, LC_FIRST, LC_DONE, LC_SEL, LC_REDAMP, LC_N };      // LC_REDAMP: the last step was rejected / invalid => the next pass re-damps the same linearization
+enum { LC_RADIUS = 0, LC_DECR, LC_COST, LC_GMAX, LC_XNORM, LC_FRAME_X2, LC_IT, LC_INVALID, LC_NSUCC, LC_PENDING, LC_TERM, LC_STATUS, LC_FIRST, LC_DONE, LC_SEL, LC_REDAMP, LC_T0, LC_N };      // LC_REDAMP: the last step was rejected / invalid => the next pass re-damps the same linearization
 struct LargeCtl { const double* ctl; int rank, nranks; };      // ctl == nullptr: the step-wise API (host-side control, arguments as given)
 
 
@@ -48,7 +48,7 @@ __global__ __launch_bounds__(NT) void k_large_chunks(char* blob, double* ws, KOp
     // after a rejected step (fused loop): same point, new radius -- the landmark partials are UPDATED by the change of their Schur terms
     // (redamp_chunk), the frame image (undamped) stays as it is
     const bool redamp = lc.ctl && lc.ctl[LC_REDAMP] != 0.0 && !first && h.redamp_ok && o.redamp;
-    if (tid < 184) sh[L_X + tid] = state[LS_X + tid];
+    if (tid < UVS_XDIM) sh[L_X + tid] = state[LS_X + tid];
     if ((int)blockIdx.x == n_chunk_wgs) {
         if (redamp) return;
         if (first) setup_window(c, (double*)blob);
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(NT) void k_large_solve(char* blob, double* ws, KOpt
         for (int r = 0; r < LG_MAXRANKS; ++r) gmax_lm = fmax(gmax_lm, reduced[LX_GMAX + r]);
     }
     Ctx c; c.hdr = (const DevWin*)blob; c.bd = (const double*)blob; c.bi = (const int*)blob; c.ws = ws; c.sh = sh; c.o = o; c.o.debug = 0;
-    if (tid < 184) sh[L_X + tid] = state[LS_X + tid];
+    if (tid < UVS_XDIM) sh[L_X + tid] = state[LS_X + tid];
     if (tid < UVS_RD && !first) sh[L_SC + tid] = state[LS_SC + tid];
     // the frame image (k_large_chunks' extra workgroup): 147 KB, 16-byte loads, everything in flight before the first store
     {
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(NT) void k_large_solve(char* blob, double* ws, KOpt
     chol_solve(c);
     backsub_candidate(c, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, true, out + LO_GD);      // frames only
     if (tid < UVS_RD) { state[LS_DLT + tid] = sh[L_DLT + tid]; state[LS_G + tid] = sh[L_G + tid]; state[LS_DD + tid] = sh[L_DD + tid]; state[LS_SC + tid] = sh[L_SC + tid]; }
-    if (tid < 184) state[LS_XC + tid] = sh[L_XC + tid];
+    if (tid < UVS_XDIM) state[LS_XC + tid] = sh[L_XC + tid];
     if (tid == 0) { out[LO_COST] = sh[L_CTRL + C_COST]; out[LO_GMAX] = sh[L_CTRL + C_GMAX]; out[LO_CHOLOK] = sh[L_CTRL + C_CHOLOK]; }
     // (the frame part of the candidate cost -- prior + IMU at x_c -- is k_large_backsub's extra workgroup)
 }
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(NT) void k_large_backsub(char* blob, double* ws, KO
     if (lc.ctl) { if (lc.ctl[LC_DONE] != 0.0) return; sel = (int)lc.ctl[LC_SEL]; }
     Ctx c; c.hdr = (const DevWin*)blob; c.bd = (const double*)blob; c.bi = (const int*)blob; c.ws = ws; c.sh = sh; c.o = o; c.o.debug = 0;
     const DevWin& h = *c.hdr;
-    if (tid < 184) sh[L_XC + tid] = state[LS_XC + tid];
+    if (tid < UVS_XDIM) sh[L_XC + tid] = state[LS_XC + tid];
     if (tid < UVS_RD) sh[L_DLT + tid] = state[LS_DLT + tid];
     __syncthreads();
     stage_rotations(c, sh + L_XC);
@@ -269,6 +269,7 @@ __global__ __launch_bounds__(256) void k_large_decide(double* ctl, double* state
         pending = 0;
         if (!done) {
             if (it >= o.max_it) { term = UVS_TERM_NO_CONVERGENCE; done = true; }
+            else if (o.max_ticks > 0 && it > 0 && (double)wall_clock64() - ctl[LC_T0] >= (double)o.max_ticks) { term = UVS_TERM_MAX_TIME; done = true; }      // options.max_solver_time_in_seconds
             else if (gmax <= o.gtol) { term = UVS_TERM_GRADIENT_TOL; done = true; }
             else if (radius <= o.rmin) { term = UVS_TERM_MIN_RADIUS; done = true; }
         }
@@ -318,7 +319,7 @@ __global__ __launch_bounds__(256) void k_large_decide(double* ctl, double* state
         }
     }
     __syncthreads();
-    if (accept_sh && tid < 184) state[LS_X + tid] = state[LS_XC + tid];
+    if (accept_sh && tid < UVS_XDIM) state[LS_X + tid] = state[LS_XC + tid];
 }
 
 // Start of a fused solve, on the device: state <- frames of the blob, landmark buffers 0 <- blob, control words and report reset.  Replaces five
@@ -327,14 +328,14 @@ __global__ __launch_bounds__(256) void k_large_init(const char* blob, double* ws
                                                     double radius0, double frame_x2, double local_x2) {
     const DevWin& h = *(const DevWin*)blob; const double* bd = (const double*)blob;
     const int t = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
-    for (int i = t; i < LG_STATE; i += nt) state[i] = (i >= LS_X && i < LS_X + 184) ? bd[h.d_frames + (i - LS_X)] : 0.0;
+    for (int i = t; i < LG_STATE; i += nt) state[i] = (i >= LS_X && i < LS_X + UVS_XDIM) ? bd[h.d_frames + (i - LS_X)] : 0.0;
     for (int i = t; i < h.n_points; i += nt) ws[h.w_invd0 + i] = bd[h.d_invd + i];
     for (int i = t; i < 4 * h.n_lines; i += nt) ws[h.w_line0 + i] = bd[h.d_line + i];
     for (int i = t; i < LG_XCH; i += nt) reduced[i] = (i == LX_X2) ? local_x2 : 0.0;
-    for (int i = t; i < 64; i += nt) ctl[i] = i == LC_RADIUS ? radius0 : i == LC_DECR ? 2.0 : i == LC_FIRST ? 1.0 : i == LC_FRAME_X2 ? frame_x2 : 0.0;
+    for (int i = t; i < 64; i += nt) ctl[i] = i == LC_RADIUS ? radius0 : i == LC_DECR ? 2.0 : i == LC_FIRST ? 1.0 : i == LC_FRAME_X2 ? frame_x2 : i == LC_T0 ? (double)wall_clock64() : 0.0;
     for (int i = t; i < (int)(sizeof(uvs_report) / 4); i += nt) ((int*)rep)[i] = 0;
 }
-// End of a fused solve: everything the host reads back, gathered into one buffer [ctl 64 | report | frames 184 | inverse depths | line parameters]
+// End of a fused solve: everything the host reads back, gathered into one buffer [ctl 64 | report | frames 192 | inverse depths | line parameters]
 // (the landmark buffer that holds the accepted values is only known on the device: ctl[LC_SEL])
 __global__ __launch_bounds__(256) void k_large_pack(const char* blob, const double* ws, const double* state, const double* ctl, const uvs_report* rep, double* out) {
     const DevWin& h = *(const DevWin*)blob;
@@ -343,8 +344,8 @@ __global__ __launch_bounds__(256) void k_large_pack(const char* blob, const doub
     const int t = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
     for (int i = t; i < 64; i += nt) out[i] = ctl[i];
     for (int i = t; i < RD; i += nt) out[64 + i] = ((const double*)rep)[i];
-    for (int i = t; i < 184; i += nt) out[64 + RD + i] = state[LS_X + i];
-    double* o2 = out + 64 + RD + 184;
+    for (int i = t; i < UVS_XDIM; i += nt) out[64 + RD + i] = state[LS_X + i];
+    double* o2 = out + 64 + RD + UVS_XDIM;
     for (int i = t; i < h.n_points; i += nt) o2[i] = ws[(sel ? h.w_invd1 : h.w_invd0) + i];
     for (int i = t; i < 4 * h.n_lines; i += nt) o2[h.n_points + i] = ws[(sel ? h.w_line1 : h.w_line0) + i];
 }

@@ -63,7 +63,7 @@ enum { P_SETUP = 0, P_OBS, P_LMPREP, P_GATHER, P_ASSEMBLE, P_CHOL, P_TRSV, P_BAC
 static constexpr size_t LDS_BYTES = (size_t)L_TOTAL * 8;
 
 enum { C_COST = 0, C_RADIUS, C_DECR, C_XNORM, C_GMAX, C_CAND, C_MCC, C_STEP2, C_XC2, C_GO, C_IT, C_INVALID, C_CUR, C_FIRST,
-       C_TERM, C_NSUCC, C_CHOLOK, C_GMAXLM };
+       C_TERM, C_NSUCC, C_CHOLOK, C_GMAXLM, C_TIMEUP };
 
 struct KOpts {   // device copy of uvs_options
     int max_it, ex_free, keep_cand, jacobi;
@@ -71,6 +71,7 @@ struct KOpts {   // device copy of uvs_options
     double r0, rmax, rmin, min_rel, dlo, dhi, ftol, gtol, ptol;
     int max_invalid;
     int debug;
+    long long max_ticks;      // options.max_solver_time_in_seconds in ticks of the 100 MHz wall clock (wall_clock64); 0 = no cap
     int redamp;      // 1 (default): a rejected step is followed by a re-damping of the stored linearization; 0 (UVS_REDAMP=0 at uvs_create): by a new linearization
 };
 
@@ -1906,8 +1907,15 @@ __global__ __launch_bounds__(NT) void k_solve(char* blobs, const long long* blob
     GAcc gacc;      // gather accumulators of the current linearization (48 registers per lane, live across the iteration: a re-damping continues from them)
     int prep_mode = 0;        // how much of lin_prep the next linearization can skip (0 nothing, 1 after an accepted step, 2 after a rejected / invalid one)
     int pending = 0;          // trace slot whose cost / gradient norm the next linearization fills in
+    const long long t_wall0 = wall_clock64();
     while (true) {
         if (it >= o.max_it && !first) { term = UVS_TERM_NO_CONVERGENCE; break; }
+        if (o.max_ticks > 0 && !first) {      // options.max_solver_time_in_seconds (estimator.cpp:987-991): one lane reads the clock, everybody follows it
+            __syncthreads();
+            if (tid == 0) sh[L_CTRL + C_TIMEUP] = (wall_clock64() - t_wall0 >= o.max_ticks) ? 1.0 : 0.0;
+            __syncthreads();
+            if (sh[L_CTRL + C_TIMEUP] != 0.0) { term = UVS_TERM_MAX_TIME; break; }
+        }
         if (need_lin) {
 #ifndef UVS_X_NO_REDAMP
             if (prep_mode == 2 && !first && h.redamp_ok && o.redamp) relinearize_damping(c, sh + L_X, radius, gacc);

@@ -71,6 +71,7 @@ struct uvs_solver {
         double relo_pose_in[7] = {0, 0, 0, 0, 0, 0, 0};      // passes through to uvs_large_finish (this path takes no relocalization blocks)
         int grid = 0;                                           // chunk workgroups of k_large_chunks / k_large_backsub = partial rows (min(n_chunks, compute units)); every launch adds ONE for the frame terms
         double* d_fimg = nullptr;                               // frame image of the reduced system (k_large_chunks' extra workgroup -> k_large_solve)
+        std::chrono::steady_clock::time_point t_begin;          // start of the host-driven loop (options.max_solver_time_in_seconds)
     } L;
 };
 
@@ -89,6 +90,7 @@ static KOpts make_kopts(const uvs_options& o, int debug) {
     k.r0 = o.initial_trust_region_radius; k.rmax = o.max_trust_region_radius; k.rmin = o.min_trust_region_radius;
     k.min_rel = o.min_relative_decrease; k.dlo = o.min_lm_diagonal; k.dhi = o.max_lm_diagonal;
     k.ftol = o.function_tolerance; k.gtol = o.gradient_tolerance; k.ptol = o.parameter_tolerance;
+    k.max_ticks = o.max_solver_time_in_seconds > 0.0 ? std::max(1LL, (long long)(o.max_solver_time_in_seconds * 1e8)) : 0LL;      // wall_clock64(): 100 MHz
     k.max_invalid = o.max_consecutive_invalid_steps; k.debug = debug;
     { const char* e = std::getenv("UVS_REDAMP"); k.redamp = (e && e[0] == '0') ? 0 : 1; }      // diagnostic switch, read per launch (tests, A/B): 0 = re-linearize after every rejected step
     return k;
@@ -117,6 +119,7 @@ void uvs_default_options(uvs_options* o) {
     o->min_relative_decrease = 1e-3; o->min_lm_diagonal = 1e-6; o->max_lm_diagonal = 1e32;
     o->function_tolerance = 1e-6; o->gradient_tolerance = 1e-10; o->parameter_tolerance = 1e-8;
     o->max_consecutive_invalid_steps = 5; o->jacobi_scaling = 1;
+    o->max_solver_time_in_seconds = 0.0;      // no wall-clock cap (the reference sets 0.1 s / 0.08 s, estimator.cpp:987-991: two orders of magnitude above a solve here)
 }
 
 const char* uvs_status_string(int st) {
@@ -242,6 +245,23 @@ static int validate_window(const uvs_window* w, std::string& err) {
 // chunk_grid > 0 (large-window path): the landmark chunks are made SMALLER than the LDS staging area allows so that their number is a
 // multiple of chunk_grid (the persistent workgroups of k_large_chunks / k_large_backsub then all carry the same number of chunks), or
 // -- a shard with few landmarks -- so that every compute unit gets one
+// [0, n) split into `nt` contiguous ranges, one host thread each (nt <= 1: the caller's thread).  Used INSIDE the packing of one large window
+// (configs[3]: 510 chunks, 135 000 observations); batches of small windows are threaded across windows instead (upload_windows).
+template <class F> static void pack_parallel(int n, int nt, F&& fn) {
+    if (nt <= 1 || n < 2) { fn(0, n, 0); return; }
+    nt = std::min(nt, n);
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; ++t) pool.emplace_back([&, t] { fn((int)((long long)n * t / nt), (int)((long long)n * (t + 1) / nt), t); });
+    fn(0, (int)((long long)n / nt), 0);
+    for (auto& th : pool) th.join();
+}
+static int pack_inner_threads(int n_obs) {
+    if (n_obs < 20000) return 1;
+    const char* env = std::getenv("UVS_PACK_THREADS");
+    const int nt = env ? std::atoi(env) : (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
+    return std::max(1, nt);
+}
+
 static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vector<char>& out, DevWin& hdr, std::string& err, int chunk_grid) {
     const bool prof_ = std::getenv("UVS_PACK_PROFILE") != nullptr;
     auto t_prev_ = std::chrono::steady_clock::now();
@@ -426,17 +446,27 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
             }
         }
     };
-    for (int qc = 0; qc < n_ch; ++qc) {
-        long cs[UVS_NBLKX] = {0}, cd[UVS_NBLKX] = {0};
-        chunk_entries(qc, [&](int b, int) { ++cs[b]; }, [&](int b, int) { ++cd[b]; });
-        const int type = chunks[6 * qc];
-        // work units ~ cycles per entry of the rows-per-lane gather
-        for (int b = 0; b < UVS_NBLKX; ++b) {
-            // measured per entry on MI355X (per-wave timers, UVS_DEBUG_GATHER_TIMERS): point Schur 350 cycles, point direct 675 cycles
-            const long ws_ = (type == 0 ? 18 : 72) * cs[b], wd_ = (type == 0 ? 35 : 63) * cd[b];
-            blk_s[b] += ws_; blk_d[b] += wd_;
-            (type == 0 ? blk_wp : blk_wl)[b] += ws_ + wd_;      // per landmark family: the chunks of a family are separated by barriers
-        }
+    const int inner_threads = pack_inner_threads(h.n_pt_obs + h.n_ln_obs);
+    {
+        struct Cnt { long s[UVS_NBLKX], d[UVS_NBLKX], wp[UVS_NBLKX], wl[UVS_NBLKX]; };
+        std::vector<Cnt> part((size_t)std::max(inner_threads, 1));
+        for (auto& c : part) std::memset(&c, 0, sizeof(c));
+        pack_parallel(n_ch, inner_threads, [&](int q0, int q1, int t) {
+            Cnt& c = part[t];
+            for (int qc = q0; qc < q1; ++qc) {
+                long cs[UVS_NBLKX] = {0}, cd[UVS_NBLKX] = {0};
+                chunk_entries(qc, [&](int b, int) { ++cs[b]; }, [&](int b, int) { ++cd[b]; });
+                const int type = chunks[6 * qc];
+                // work units ~ cycles per entry of the rows-per-lane gather
+                for (int b = 0; b < UVS_NBLKX; ++b) {
+                    // measured per entry on MI355X (per-wave timers, UVS_DEBUG_GATHER_TIMERS): point Schur 350 cycles, point direct 675 cycles
+                    const long ws_ = (type == 0 ? 18 : 72) * cs[b], wd_ = (type == 0 ? 35 : 63) * cd[b];
+                    c.s[b] += ws_; c.d[b] += wd_;
+                    (type == 0 ? c.wp : c.wl)[b] += ws_ + wd_;      // per landmark family: the chunks of a family are separated by barriers
+                }
+            }
+        });
+        for (const auto& c : part) for (int b = 0; b < UVS_NBLKX; ++b) { blk_s[b] += c.s[b]; blk_d[b] += c.d[b]; blk_wp[b] += c.wp[b]; blk_wl[b] += c.wl[b]; }
     }
     lap_("entries");
     // gather groups: 256 two-lane groups, at least one per pose block; the spare ones split the heaviest blocks further.  Groups are dealt to
@@ -497,44 +527,68 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
     }
     lap_("groups");
     std::vector<int> lists;
-    std::vector<std::vector<int>> eS(UVS_NBLKX), eD(UVS_NBLKX);
-    for (int qc = 0; qc < n_ch; ++qc) {
-        for (int b = 0; b < UVS_NBLKX; ++b) { eS[b].clear(); eD[b].clear(); }
-        chunk_entries(qc, [&](int b, int v) { eS[b].push_back(v); }, [&](int b, int v) { eD[b].push_back(v); });
-        chunks[6 * qc + 3] = (int)lists.size();
-        const size_t base = lists.size();
-        lists.resize(base + 2 * (UVS_NGRP + 1));
-        std::vector<int> ent;
-        for (int pass = 0; pass < 2; ++pass) {
-            const auto& L = pass == 0 ? eS : eD;
-            for (int g = 0; g < UVS_NGRP; ++g) {
-                lists[base + pass * (UVS_NGRP + 1) + g] = (int)ent.size();
-                if (g_blk[g] < 0) continue;
-                const auto& v = L[g_blk[g]];
-                const size_t n = v.size(), lo = n * g_part[g] / g_np[g], hi = n * (g_part[g] + 1) / g_np[g];
-                ent.insert(ent.end(), v.begin() + lo, v.begin() + hi);
+    {
+        // every thread builds the lists of a contiguous range of chunks into its own vector (offsets relative to it); the ranges are concatenated
+        // in chunk order afterwards, so the result does not depend on the thread count
+        struct Part { std::vector<int> lists; int max_used = 0; bool overflow = false; int q0 = 0, q1 = 0; };
+        std::vector<Part> part((size_t)std::max(inner_threads, 1));
+        const bool dbg_lists = std::getenv("UVS_DEBUG_LISTS") != nullptr;
+        pack_parallel(n_ch, dbg_lists ? 1 : inner_threads, [&](int q0, int q1, int t) {
+            Part& P = part[t]; P.q0 = q0; P.q1 = q1;
+            std::vector<std::vector<int>> eS(UVS_NBLKX), eD(UVS_NBLKX);
+            std::vector<int> ent;
+            for (int qc = q0; qc < q1; ++qc) {
+                for (int b = 0; b < UVS_NBLKX; ++b) { eS[b].clear(); eD[b].clear(); }
+                chunk_entries(qc, [&](int b, int v) { eS[b].push_back(v); }, [&](int b, int v) { eD[b].push_back(v); });
+                chunks[6 * qc + 3] = (int)P.lists.size();      // relative to this part for now
+                const size_t base = P.lists.size();
+                P.lists.resize(base + 2 * (UVS_NGRP + 1));
+                ent.clear();
+                for (int pass = 0; pass < 2; ++pass) {
+                    const auto& L = pass == 0 ? eS : eD;
+                    for (int g = 0; g < UVS_NGRP; ++g) {
+                        P.lists[base + pass * (UVS_NGRP + 1) + g] = (int)ent.size();
+                        if (g_blk[g] < 0) continue;
+                        const auto& v = L[g_blk[g]];
+                        const size_t n = v.size(), lo = n * g_part[g] / g_np[g], hi = n * (g_part[g] + 1) / g_np[g];
+                        ent.insert(ent.end(), v.begin() + lo, v.begin() + hi);
+                    }
+                    P.lists[base + pass * (UVS_NGRP + 1) + UVS_NGRP] = (int)ent.size();
+                }
+                P.lists.insert(P.lists.end(), ent.begin(), ent.end());
+                chunks[6 * qc + 4] = (int)(P.lists.size() - base);
+                {   // the chunk as the kernel lays it out must fit the staging area: records + Schur factors + the lists just built (an estimate that
+                    // is too small would let the lists run over the LM state that follows S in LDS)
+                    const int type = chunks[6 * qc], k0 = chunks[6 * qc + 1], k1 = chunks[6 * qc + 2];
+                    const long nlist = (long)(P.lists.size() - base);
+                    long used;
+                    if (type == 0) { const long nob = pbeg[k1] - pbeg[k0], nlm = k1 - k0; used = (long)PREC * nob + 12 * (nob + XS * nlm) + (nlist + 1) / 2; }
+                    else { const long nob = lbeg[k1] - lbeg[k0], nlm = k1 - k0; used = (long)(UVS_LN_REC + 48) * nob + 20 * nlm + (nlist + 1) / 2; }
+                    if (used > UVS_S_DOUBLES) P.overflow = true;
+                    P.max_used = std::max(P.max_used, (int)used);
+                }
+                if (dbg_lists) {
+                    fprintf(stderr, "chunk %d type %d lm [%d,%d):\n", qc, chunks[6 * qc], chunks[6 * qc + 1], chunks[6 * qc + 2]);
+                    for (int wv = 0; wv < NW; ++wv) {
+                        fprintf(stderr, "  wave %d:", wv);
+                        for (int q = 0; q < GRP_PER_WAVE; ++q) { const int g = wv * GRP_PER_WAVE + q; fprintf(stderr, " b%d.%d(%d,%d)", g_blk[g], g_part[g], P.lists[base + g + 1] - P.lists[base + g], P.lists[base + UVS_NGRP + 2 + g] - P.lists[base + UVS_NGRP + 1 + g]); }
+                        fprintf(stderr, "\n");
+                    }
+                }
             }
-            lists[base + pass * (UVS_NGRP + 1) + UVS_NGRP] = (int)ent.size();
-        }
-        lists.insert(lists.end(), ent.begin(), ent.end());
-        chunks[6 * qc + 4] = (int)(lists.size() - base);
-        {   // the chunk as the kernel lays it out must fit the staging area: records + Schur factors + the lists just built (an estimate that
-            // is too small would let the lists run over the LM state that follows S in LDS)
-            const int type = chunks[6 * qc], k0 = chunks[6 * qc + 1], k1 = chunks[6 * qc + 2];
-            const long nlist = (long)(lists.size() - base);
-            long used;
-            if (type == 0) { const long nob = pbeg[k1] - pbeg[k0], nlm = k1 - k0; used = (long)PREC * nob + 12 * (nob + XS * nlm) + (nlist + 1) / 2; }
-            else { const long nob = lbeg[k1] - lbeg[k0], nlm = k1 - k0; used = (long)(UVS_LN_REC + 48) * nob + 20 * nlm + (nlist + 1) / 2; }
-            if (used > UVS_S_DOUBLES) { err = "internal: chunk layout exceeds the LDS staging area"; return UVS_ERR_CAPACITY; }
-            h.max_chunk_doubles = std::max(h.max_chunk_doubles, (int)used);
-        }
-        if (getenv("UVS_DEBUG_LISTS")) {
-            fprintf(stderr, "chunk %d type %d lm [%d,%d):\n", qc, chunks[6 * qc], chunks[6 * qc + 1], chunks[6 * qc + 2]);
-            for (int wv = 0; wv < NW; ++wv) {
-                fprintf(stderr, "  wave %d:", wv);
-                for (int q = 0; q < GRP_PER_WAVE; ++q) { const int g = wv * GRP_PER_WAVE + q; fprintf(stderr, " b%d.%d(%d,%d)", g_blk[g], g_part[g], lists[base + g + 1] - lists[base + g], lists[base + UVS_NGRP + 2 + g] - lists[base + UVS_NGRP + 1 + g]); }
-                fprintf(stderr, "\n");
-            }
+        });
+        const int nparts = (int)part.size();
+        size_t total = 0;
+        for (const auto& P : part) total += P.lists.size();
+        lists.resize(total);
+        size_t at = 0;
+        for (int t = 0; t < nparts; ++t) {
+            const Part& P = part[t];
+            if (P.overflow) { err = "internal: chunk layout exceeds the LDS staging area"; return UVS_ERR_CAPACITY; }
+            h.max_chunk_doubles = std::max(h.max_chunk_doubles, P.max_used);
+            if (!P.lists.empty()) std::memcpy(lists.data() + at, P.lists.data(), P.lists.size() * sizeof(int));
+            for (int qc = P.q0; qc < P.q1; ++qc) chunks[6 * qc + 3] += (int)at;      // part-relative -> absolute (parts are in chunk order: thread t took the t-th range)
+            at += P.lists.size();
         }
     }
     h.n_chunks = (int)chunks.size() / 6;
@@ -634,14 +688,16 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
     std::memcpy(D + h.d_frames + 184, w->relo_pose, sizeof(double) * 7);
     if (relo_on) for (int k = 0; k < h.n_pt_obs; ++k) I[h.i_pt_eidx + k] = eidx[k];
     for (int k = 0; k < h.n_points; ++k) D[h.d_invd + k] = w->inv_depth[k];
-    for (int k = 0; k < h.n_pt_obs; ++k) {
-        for (int q = 0; q < 3; ++q) { D[h.d_ptmeas + q * h.pt_stride + k] = w->pt_pi[3 * k + q]; D[h.d_ptmeas + (3 + q) * h.pt_stride + k] = w->pt_pj[3 * k + q]; }
-        I[h.i_pt_lm + k] = w->pt_lm[k]; I[h.i_pt_fi + k] = w->pt_fi[k]; I[h.i_pt_fj + k] = w->pt_fj[k];
-        if (td_on) {
-            for (int q = 0; q < 2; ++q) { D[h.d_ptvel + q * h.pt_stride + k] = w->pt_vel_i[2 * k + q]; D[h.d_ptvel + (2 + q) * h.pt_stride + k] = w->pt_vel_j[2 * k + q]; }
-            D[h.d_ptvel + 4 * h.pt_stride + k] = w->pt_td_i[k]; D[h.d_ptvel + 5 * h.pt_stride + k] = w->pt_td_j[k];
+    pack_parallel(h.n_pt_obs, inner_threads, [&](int k0_, int k1_, int) {
+        for (int k = k0_; k < k1_; ++k) {
+            for (int q = 0; q < 3; ++q) { D[h.d_ptmeas + q * h.pt_stride + k] = w->pt_pi[3 * k + q]; D[h.d_ptmeas + (3 + q) * h.pt_stride + k] = w->pt_pj[3 * k + q]; }
+            I[h.i_pt_lm + k] = w->pt_lm[k]; I[h.i_pt_fi + k] = w->pt_fi[k]; I[h.i_pt_fj + k] = w->pt_fj[k];
+            if (td_on) {
+                for (int q = 0; q < 2; ++q) { D[h.d_ptvel + q * h.pt_stride + k] = w->pt_vel_i[2 * k + q]; D[h.d_ptvel + (2 + q) * h.pt_stride + k] = w->pt_vel_j[2 * k + q]; }
+                D[h.d_ptvel + 4 * h.pt_stride + k] = w->pt_td_i[k]; D[h.d_ptvel + 5 * h.pt_stride + k] = w->pt_td_j[k];
+            }
         }
-    }
+    });
     for (int k = 0; k <= h.n_points; ++k) I[h.i_pt_beg + k] = pbeg[k];
     for (int k = 0; k < 4 * h.n_lines; ++k) D[h.d_line + k] = w->line_orth[k];
     for (int k = 0; k < h.n_ln_obs; ++k) {
@@ -693,7 +749,7 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
         for (size_t q = 0; q < csrc.size(); ++q) { I[h.i_cimg + q] = csrc[q]; I[h.i_cimg + csrc.size() + q] = coff[q]; }
     }
     for (size_t q = 0; q < chunks.size(); ++q) I[h.i_chunks + q] = chunks[q];
-    for (size_t q = 0; q < lists.size(); ++q) I[h.i_lists + q] = lists[q];
+    if (!lists.empty()) std::memcpy(I + h.i_lists, lists.data(), lists.size() * sizeof(int));
     for (int q = 0; q < UVS_NGRP; ++q) I[h.i_wblk + q] = wblk[q];
     lap_("blob");
     hdr = h;
@@ -787,9 +843,9 @@ static int upload_windows(uvs_solver* s, int n, const uvs_window* const* ws, boo
     const size_t blob_bytes = (raw_bytes + 7) & ~(size_t)7, up_bytes = blob_bytes + (size_t)n * 40;
     // the staging buffer may still feed the previous upload's copy (the single-window path does not wait for it): drain before reuse
     HIPCHK(s, hipStreamSynchronize(s->stream));
-    // small uploads (the online single-window case) and threaded batch uploads are staged in pinned memory together with their tables: ONE copy that the
-    // host need not wait for; a single large blob (configs[3]: 20 MB) would pay a second serial pass over memory for it and goes from the pageable vector directly
-    const bool staged = packed_total > 0 || blob_bytes <= ((size_t)4 << 20);
+    // every upload is staged in pinned memory together with its tables: ONE DMA copy that the host need not wait for (a copy from the pageable vector
+    // is staged by the runtime anyway, synchronously and on one thread); a large blob (configs[3]: 13 MB) is moved there by several threads
+    const bool staged = true;
     if ((rc = ensure_pinned(s, &s->h_up, &s->h_up_cap, staged ? up_bytes : (size_t)n * 40)) != UVS_OK) return rc;
     if ((rc = ensure(s, (void**)&s->d_blobs, &s->d_blobs_cap, up_bytes)) != UVS_OK) return rc;
     if ((rc = ensure(s, (void**)&s->d_outpack, &s->d_outpack_cap, (size_t)s->out_total * 8 + (size_t)n * sizeof(uvs_report))) != UVS_OK) return rc;
@@ -800,7 +856,10 @@ static int upload_windows(uvs_solver* s, int n, const uvs_window* const* ws, boo
         for (int t = 0; t < nthreads; ++t)
             pool.emplace_back([&, t] { for (int b = t; b < n; b += nthreads) std::memcpy(s->h_up + s->blob_off[b], s->slot_blobs[b].data(), s->slot_blobs[b].size()); });
         for (auto& th : pool) th.join();
-    } else if (staged) std::memcpy(s->h_up, s->host_blobs.data(), s->host_blobs.size());
+    } else if (s->host_blobs.size() > ((size_t)4 << 20)) {
+        const size_t nb_ = s->host_blobs.size(); const int ct = pack_inner_threads(1 << 30);
+        pack_parallel((int)((nb_ + 65535) >> 16), ct, [&](int c0, int c1, int) { const size_t a0 = (size_t)c0 << 16, a1 = std::min(nb_, (size_t)c1 << 16); if (a1 > a0) std::memcpy(s->h_up + a0, s->host_blobs.data() + a0, a1 - a0); });
+    } else std::memcpy(s->h_up, s->host_blobs.data(), s->host_blobs.size());
     long long* tabs = (long long*)(s->h_up + (staged ? blob_bytes : 0));
     std::memcpy(tabs, s->blob_off.data(), (size_t)n * 8);
     std::memcpy(tabs + n, s->ws_off.data(), (size_t)n * 8);
@@ -1012,7 +1071,6 @@ extern "C" {
 
 int uvs_large_begin(uvs_solver* s, const uvs_window* w) {
     if (!s || !w) return UVS_ERR_INVALID_ARG;
-    if (w->n_relo_obs > 0) { s->err = "relocalization blocks are not taken by the large-window path"; return UVS_ERR_UNSUPPORTED; }
     const uvs_window* arr[1] = {w};
     int rc = upload_windows(s, 1, arr, true, s->chunk_wgs());
     if (rc != UVS_OK) return rc;
@@ -1029,13 +1087,14 @@ int uvs_large_begin(uvs_solver* s, const uvs_window* w) {
     if ((r2 = ensure(s, (void**)&L.d_bsums, &L.cap_bsums, (size_t)std::max(L.n_chunks, 1) * 8 * 8)) != UVS_OK) return r2;
     HIPCHK(s, hipMemsetAsync(L.d_state, 0, LG_STATE * 8, s->stream));
     // frames -> state.X ; landmark parameters -> workspace buffer 0 (device-to-device from the blob)
-    HIPCHK(s, hipMemcpyAsync(L.d_state + LS_X, s->d_blobs + (size_t)h.d_frames * 8, 184 * 8, hipMemcpyDeviceToDevice, s->stream));
+    HIPCHK(s, hipMemcpyAsync(L.d_state + LS_X, s->d_blobs + (size_t)h.d_frames * 8, UVS_XDIM * 8, hipMemcpyDeviceToDevice, s->stream));
     if (h.n_points) HIPCHK(s, hipMemcpyAsync(s->d_ws + h.w_invd0, s->d_blobs + (size_t)h.d_invd * 8, (size_t)h.n_points * 8, hipMemcpyDeviceToDevice, s->stream));
     if (h.n_lines) HIPCHK(s, hipMemcpyAsync(s->d_ws + h.w_line0, s->d_blobs + (size_t)h.d_line * 8, (size_t)h.n_lines * 32, hipMemcpyDeviceToDevice, s->stream));
     double x2 = 0.0;
     for (int f = 0; f < UVS_NUM_FRAMES; ++f) { for (int k = 0; k < 7; ++k) x2 += w->pose[f][k] * w->pose[f][k]; for (int k = 0; k < 9; ++k) x2 += w->speedbias[f][k] * w->speedbias[f][k]; }
     if (s->opts.estimate_td) x2 += w->td * w->td;
     if (s->opts.estimate_extrinsic) for (int k = 0; k < 7; ++k) x2 += w->ex_pose[k] * w->ex_pose[k];
+    if (w->n_relo_obs > 0) for (int k = 0; k < 7; ++k) x2 += w->relo_pose[k] * w->relo_pose[k];      // relo_Pose is a free block of the problem (estimator.cpp:947)
     double l2 = 0.0;
     for (int k = 0; k < w->n_points; ++k) l2 += w->inv_depth[k] * w->inv_depth[k];
     for (int k = 0; k < 4 * w->n_lines; ++k) l2 += w->line_orth[k] * w->line_orth[k];
@@ -1043,6 +1102,7 @@ int uvs_large_begin(uvs_solver* s, const uvs_window* w) {
     std::memset(&L.rep, 0, sizeof(L.rep));
     std::memcpy(L.relo_pose_in, w->relo_pose, sizeof(L.relo_pose_in));
     HIPCHK(s, hipStreamSynchronize(s->stream));
+    L.t_begin = std::chrono::steady_clock::now();
     return UVS_OK;
 }
 
@@ -1106,6 +1166,9 @@ int uvs_large_decide(uvs_solver* s) {
     } else if (L.pending > 0) { L.cost = lc; L.gmax = gm; rep.cost[L.pending] = lc; rep.gradient_max_norm[L.pending] = gm; }
     L.pending = 0; L.need_lin = false;
     if (L.it >= o.max_num_iterations) { L.term = UVS_TERM_NO_CONVERGENCE; L.done = true; return UVS_OK; }
+    if (o.max_solver_time_in_seconds > 0.0 && L.it > 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - L.t_begin).count() >= o.max_solver_time_in_seconds) {      // the host-driven loop uses the host's clock
+        L.term = UVS_TERM_MAX_TIME; L.done = true; return UVS_OK;
+    }
     if (L.gmax <= o.gradient_tolerance) { L.term = UVS_TERM_GRADIENT_TOL; L.done = true; return UVS_OK; }
     if (L.radius <= o.min_trust_region_radius) { L.term = UVS_TERM_MIN_RADIUS; L.done = true; return UVS_OK; }
     ++L.it;
@@ -1131,7 +1194,7 @@ int uvs_large_decide(uvs_solver* s) {
     else if (std::fabs(L.cost - cand) <= o.function_tolerance * L.cost) { L.term = UVS_TERM_FUNCTION_TOL; stop = true; }
     if (stop && !(o.function_tol_keeps_candidate && successful)) { L.done = true; return UVS_OK; }
     if (successful) {
-        HIPCHK(s, hipMemcpyAsync(L.d_state + LS_X, L.d_state + LS_XC, 184 * 8, hipMemcpyDeviceToDevice, s->stream));   // stream-ordered with the next launch (a plain D2D hipMemcpy
+        HIPCHK(s, hipMemcpyAsync(L.d_state + LS_X, L.d_state + LS_XC, UVS_XDIM * 8, hipMemcpyDeviceToDevice, s->stream));   // stream-ordered with the next launch (a plain D2D hipMemcpy
         // runs on the null stream, which this non-blocking stream does not wait for)
         L.sel ^= 1; ++L.nsucc; L.x_norm = std::sqrt(xc2);
         L.radius = L.radius / std::fmax(1.0 / 3.0, 1.0 - std::pow(2.0 * rel - 1.0, 3.0));
@@ -1152,10 +1215,10 @@ int uvs_large_finish(uvs_solver* s, uvs_state* out, uvs_report* rep) {
     auto& L = s->L; const DevWin& h = s->hdrs[0];
     L.rep.status = L.status; L.rep.termination = L.term; L.rep.num_iterations = L.it; L.rep.num_successful = L.nsucc; L.rep.final_cost = L.cost;
     *rep = L.rep;
-    double fr[184];
+    double fr[UVS_XDIM];
     HIPCHK(s, hipMemcpy(fr, L.d_state + LS_X, sizeof(fr), hipMemcpyDeviceToHost));
     std::memcpy(out->pose, fr, 77 * 8); std::memcpy(out->speedbias, fr + 77, 99 * 8); std::memcpy(out->ex_pose, fr + 176, 7 * 8); out->td = fr[183];
-    std::memcpy(out->relo_pose, L.relo_pose_in, sizeof(out->relo_pose));      // the large path takes no relocalization blocks: the input value passes through
+    std::memcpy(out->relo_pose, fr + 184, sizeof(out->relo_pose));      // optimized when the window carries relocalization blocks, the input value otherwise
     if (out->inv_depth && h.n_points) HIPCHK(s, hipMemcpy(out->inv_depth, s->d_ws + (L.sel ? h.w_invd1 : h.w_invd0), (size_t)h.n_points * 8, hipMemcpyDeviceToHost));
     if (out->line_orth && h.n_lines) HIPCHK(s, hipMemcpy(out->line_orth, s->d_ws + (L.sel ? h.w_line1 : h.w_line0), (size_t)h.n_lines * 32, hipMemcpyDeviceToHost));
     L.active = false;
@@ -1254,7 +1317,6 @@ static int fused_abort(uvs_solver* s, const char* what) {
 // Every rank decides on identical numbers, so all ranks follow the same path; kernels of iterations after termination return at once.
 int uvs_large_solve_fused(uvs_solver* s, const uvs_window* w, uvs_state* out, uvs_report* rep, float* loop_ms) {
     if (!s || !w || !out || !rep) return UVS_ERR_INVALID_ARG;
-    if (w->n_relo_obs > 0) { s->err = "relocalization blocks are not taken by the large-window path"; return UVS_ERR_UNSUPPORTED; }
     // ONE stream, ONE wait: pinned upload -> k_large_init -> the passes -> k_large_pack -> pinned download.  (The step-wise API keeps
     // uvs_large_begin's host-side copies; here every small copy / memset is a line of k_large_init.)
     const uvs_window* arr[1] = {w};
@@ -1274,13 +1336,14 @@ int uvs_large_solve_fused(uvs_solver* s, const uvs_window* w, uvs_state* out, uv
     if ((rc = ensure(s, (void**)&L.d_partials, &L.cap_partials, (size_t)std::max(L.grid, 1) * LG_RED * 8)) != UVS_OK) return rc;
     if ((rc = ensure(s, (void**)&L.d_bsums, &L.cap_bsums, (size_t)std::max(L.n_chunks, 1) * 8 * 8)) != UVS_OK) return rc;
     constexpr int RD = (int)(sizeof(uvs_report) / 8);
-    const size_t out_doubles = 64 + RD + 184 + (size_t)h.n_points + 4 * (size_t)h.n_lines;
+    const size_t out_doubles = 64 + RD + UVS_XDIM + (size_t)h.n_points + 4 * (size_t)h.n_lines;
     if ((rc = ensure(s, (void**)&s->d_outpack, &s->d_outpack_cap, out_doubles * 8)) != UVS_OK) return rc;
     if ((rc = ensure_pinned(s, &s->h_out, &s->h_out_cap, out_doubles * 8)) != UVS_OK) return rc;
     double x2 = 0.0, l2 = 0.0;      // ||x||^2: frames (identical on every rank) and this rank's landmarks (summed over the ranks by the first all-reduce)
     for (int f = 0; f < UVS_NUM_FRAMES; ++f) { for (int k = 0; k < 7; ++k) x2 += w->pose[f][k] * w->pose[f][k]; for (int k = 0; k < 9; ++k) x2 += w->speedbias[f][k] * w->speedbias[f][k]; }
     if (o.estimate_td) x2 += w->td * w->td;
     if (o.estimate_extrinsic) for (int k = 0; k < 7; ++k) x2 += w->ex_pose[k] * w->ex_pose[k];
+    if (w->n_relo_obs > 0) for (int k = 0; k < 7; ++k) x2 += w->relo_pose[k] * w->relo_pose[k];
     for (int k = 0; k < w->n_points; ++k) l2 += w->inv_depth[k] * w->inv_depth[k];
     for (int k = 0; k < 4 * w->n_lines; ++k) l2 += w->line_orth[k] * w->line_orth[k];
     L.local_x2 = l2; L.x_norm = std::sqrt(x2 + l2); L.frame_x2 = x2;
@@ -1326,9 +1389,9 @@ int uvs_large_solve_fused(uvs_solver* s, const uvs_window* w, uvs_state* out, uv
     L.rep = *rep;
     const double* fr = ho + 64 + RD;
     std::memcpy(out->pose, fr, 77 * 8); std::memcpy(out->speedbias, fr + 77, 99 * 8); std::memcpy(out->ex_pose, fr + 176, 7 * 8); out->td = fr[183];
-    std::memcpy(out->relo_pose, L.relo_pose_in, sizeof(out->relo_pose));      // the large path takes no relocalization blocks: the input value passes through
-    if (out->inv_depth && h.n_points) std::memcpy(out->inv_depth, fr + 184, (size_t)h.n_points * 8);
-    if (out->line_orth && h.n_lines) std::memcpy(out->line_orth, fr + 184 + h.n_points, (size_t)h.n_lines * 32);
+    std::memcpy(out->relo_pose, fr + 184, sizeof(out->relo_pose));      // optimized when the window carries relocalization blocks, the input value otherwise
+    if (out->inv_depth && h.n_points) std::memcpy(out->inv_depth, fr + UVS_XDIM, (size_t)h.n_points * 8);
+    if (out->line_orth && h.n_lines) std::memcpy(out->line_orth, fr + UVS_XDIM + h.n_points, (size_t)h.n_lines * 32);
     return L.status;
 }
 
