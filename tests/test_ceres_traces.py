@@ -41,3 +41,28 @@ def test_oracle_follows_ceres(oracle, trace, window):
     dp, dq = pose_deltas(pose, st.pose)
     assert dp < 1e-4 and dq < 1e-4 and np.abs(sb - st.speedbias).max() < 1e-4          # north_star tolerance
     assert np.abs(invd - st.inv_depth).max() < 1e-4 * max(1.0, np.abs(invd).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not PAIRS, reason="no Ceres traces committed (tools/ceres_harness/make_traces.sh): parity unpinned by the reference")
+@pytest.mark.parametrize("trace,window", PAIRS)
+@pytest.mark.parametrize("form", ["persistent", "fused"])
+def test_hip_solver_follows_ceres(gpu_api, trace, window, form):
+    """The same comparison for the HIP solver itself, both single-window forms: real Ceres' per-iteration (cost, radius, successful) and final
+    para_* arrays against the kernel, north_star tolerance on the poses."""
+    its, term, pose, sb, invd, lines = read_trace(trace)
+    w = abi.Window.load(window)
+    s = gpu_api.Solver(max_batch=2)
+    if form == "fused":
+        s.large_comm_init(None); st, rep, _ = s.large_solve_fused(w)
+    else:
+        st, rep = s.solve(w)
+    s.close()
+    n = rep.num_iterations
+    assert rep.status == 0 and n == len(its) - 1
+    assert [int(i["successful"]) for i in its[1:]] == [1 if a == 1 else 0 for a in rep.accepted[1:n + 1]]
+    assert np.allclose([i["cost"] for i in its], np.array(rep.cost[:n + 1]), rtol=1e-6)
+    assert np.allclose([i["radius"] for i in its], np.array(rep.radius[:n + 1]), rtol=1e-6)
+    dp, dq = pose_deltas(pose, st.pose)
+    assert dp < 1e-4 and dq < 1e-4 and np.abs(sb - st.speedbias).max() < 1e-4          # north_star tolerance
+    assert np.abs(invd - st.inv_depth).max() < 1e-4 * max(1.0, np.abs(invd).max())
