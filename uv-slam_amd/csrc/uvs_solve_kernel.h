@@ -654,22 +654,32 @@ UVS_DEV d2_t lds2(const double* p) { return *(const d2_t*)p; }
 UVS_DEV void gacc_gather_parts(GAcc& A, int grp, double* scr) {
     const int tid = lane_tid();
     const int part = grp >= 0 ? (grp >> 9) & 15 : 0, np = grp >= 0 ? ((grp >> 21) & 15) + 1 : 1;
-    if (part > 0) {
-        double* D = scr + (8 * GR + 1) * tid;
+    constexpr int NV = 8 * GR, LD = NV + 1;      // 24 values per lane (18 block entries, 3 gradient, 3 diagonal), odd stride
+    double* D = scr + LD * tid;
+    if (np > 1) {
 #pragma unroll
         for (int q = 0; q < 6 * GR; ++q) D[q] = A.v[q];
 #pragma unroll
         for (int q = 0; q < GR; ++q) { D[6 * GR + q] = A.g[q]; D[7 * GR + q] = A.hd[q]; }
     }
     __syncthreads();
-    if (part == 0) {
-        for (int p = 1; p < np; ++p) {
-            const double* D = scr + (8 * GR + 1) * (tid + p * UVS_GLANES);
-#pragma unroll
-            for (int q = 0; q < 6 * GR; ++q) A.v[q] += D[q];
-#pragma unroll
-            for (int q = 0; q < GR; ++q) { A.g[q] += D[6 * GR + q]; A.hd[q] += D[7 * GR + q]; }
+    // every lane of a split block sums a SLICE of the 24 values over all parts (value q belongs to the part q mod np), in part order, into the part-0
+    // lane's slot: np lanes share the np x 24 loads that the part-0 lane alone used to issue (up to 15 x 24 dependent LDS round trips: 8.8 k cycles
+    // per linearization, the largest single piece of the assembly).  The value order of every sum is unchanged: part 0 + part 1 + ... .
+    if (np > 1) {
+        const double* D0 = D - LD * UVS_GLANES * part;      // the part-0 lane of this lane's row half
+        for (int q = part; q < NV; q += np) {
+            double sacc = D0[q];
+            for (int p = 1; p < np; ++p) sacc += D0[LD * UVS_GLANES * p + q];      // (all 16 possible parts in flight with clamped loads + selects was measured: slower, 86 k against 63 k cycles per solve -- issue slots, not latency)
+            const_cast<double*>(D0)[q] = sacc;              // only this lane reads or writes column q of the block's slots
         }
+    }
+    __syncthreads();
+    if (np > 1 && part == 0) {
+#pragma unroll
+        for (int q = 0; q < 6 * GR; ++q) A.v[q] = D[q];
+#pragma unroll
+        for (int q = 0; q < GR; ++q) { A.g[q] = D[6 * GR + q]; A.hd[q] = D[7 * GR + q]; }
     }
 }
 UVS_DEV void gacc_zero(GAcc& A) {
@@ -1369,12 +1379,16 @@ UVS_DEV void lin_assemble(const Ctx& c, const double* x, bool first, double radi
     // ---- assemble the reduced system in LDS
     // parts of split blocks -> their part-0 group (the staging area is free now; S is zeroed only after the sums are in registers)
     GAcc A = Ain;
+    long long tz_ = clock64();
+#define UVS_TZ(slot) if (c.o.debug == 3 && tid == 0) { const long long t_ = clock64(); sh[L_WPROF + slot] += (double)(t_ - tz_); tz_ = t_; }
     if (mode == 0) { gacc_gather_parts(A, grp, sh + L_S); __syncthreads(); }
+    UVS_TZ(4)
     if (mode != 2) {
         { const d2_t z2 = {0.0, 0.0}; for (int i = tid; i < UVS_S_DOUBLES / 2; i += NT) *(d2_t*)(sh + L_S + 2 * i) = z2; }      // ds_write_b128
         if (tid < UVS_RD) { sh[L_G + tid] = 0.0; sh[L_HD + tid] = 0.0; }
         __syncthreads();
     }
+    UVS_TZ(5)
     // the part-0 group of every pose block adds its rows (one writer per block: a single round)
     if (mode != 1) {
         if (grp >= 0 && ((grp >> 9) & 15) == 0) {
@@ -1428,6 +1442,8 @@ UVS_DEV void lin_assemble(const Ctx& c, const double* x, bool first, double radi
         }
         __syncthreads();
     }
+    UVS_TZ(6)
+#undef UVS_TZ
     UVS_PROF(c, P_AS_ZERO);
     // IMU normal-equation tiles from the registers of lin_imu (even blocks, then odd: consecutive blocks share a diagonal frame block)
     if (mode != 2) {
