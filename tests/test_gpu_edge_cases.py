@@ -222,3 +222,36 @@ def test_max_solver_time_in_seconds(gpu_api, form):
     assert r0.termination != 7 and r1.num_iterations == r0.num_iterations and r1.final_cost == r0.final_cost and np.array_equal(s1.pose, s0.pose)
     assert r2.termination == 7 and r2.status == 0 and r2.num_iterations == 1 and abs(r2.final_cost - r0.cost[1]) <= 1e-12 * r0.cost[1] and r2.final_cost < r2.initial_cost      # (the candidate-cost sum vs the next linearization's: another summation order)
     assert np.isfinite(s2.pose).all() and not np.array_equal(s2.pose, w.pose)
+
+
+def test_structure_cache_of_large_windows(gpu_api):
+    """Windows of >= 20 000 observations keep their structure (chunking, work split, gather lists) in the handle: a second window with the SAME index arrays
+    rewrites only the value sections of the blob and uploads only that prefix.  Same structure / new values, then a different structure, then the first one
+    again -- every result bitwise equal to a fresh handle's (UVS_NO_PACK_CACHE=1), in both forms of the large path."""
+    import os
+    shape = dict(n_points=3000, n_lines=600, n_tagged=450)
+    wa = synth.make_window(71, **shape)
+    wb = wa.copy(); rng = np.random.default_rng(5)
+    wb.pose = wa.pose.copy(); wb.pose[:, :3] += 1e-3 * rng.standard_normal((11, 3)); wb.inv_depth = wa.inv_depth * (1.0 + 1e-3 * rng.standard_normal(len(wa.inv_depth)))
+    wb.pt_pj = wa.pt_pj.copy(); wb.pt_pj[:, :2] += 1e-4 * rng.standard_normal((len(wa.pt_lm), 2))
+    wc = synth.make_window(72, n_points=2900, n_lines=640, n_tagged=450)      # other structure
+    cap = dict(max_batch=1, max_points=3008, max_point_obs=40000, max_lines=648, max_line_obs=8000)
+    def run(ws, fused, cache):
+        old = os.environ.pop("UVS_NO_PACK_CACHE", None)
+        if not cache: os.environ["UVS_NO_PACK_CACHE"] = "1"
+        try:
+            s = gpu_api.Solver(**cap); s.large_comm_init(None); out = []
+            for w in ws:
+                st, rep = (s.large_solve_fused(w)[:2] if fused else s.large_solve(w))
+                out.append((st.pose.copy(), st.inv_depth.copy(), rep.final_cost, rep.num_iterations))
+            s.close()
+        finally:
+            os.environ.pop("UVS_NO_PACK_CACHE", None)
+            if old is not None: os.environ["UVS_NO_PACK_CACHE"] = old
+        return out
+    seq = [wa, wb, wa, wc, wa, wb]
+    for fused in (True, False):
+        a = run(seq, fused, True); b = run(seq, fused, False)
+        for (pa, da, ca, na), (pb, db, cb, nb) in zip(a, b):
+            assert na == nb and ca == cb and np.array_equal(pa, pb) and np.array_equal(da, db)
+        assert a[0][2] != a[1][2] and a[0][2] == a[2][2]      # the values did change between the calls, and came back

@@ -27,6 +27,8 @@
 
 using namespace uvsdev;
 
+struct PackCache;
+static void free_pack_cache(PackCache* c);
 struct uvs_solver {
     uvs_options opts;
     int device;
@@ -43,6 +45,7 @@ struct uvs_solver {
     std::vector<DevWin> hdrs;                // host copies of the per-window headers
     std::vector<long long> blob_off, ws_off;
     std::vector<char> host_blobs;
+    PackCache* pack_cache = nullptr;      // structure of the last large single window (allocated on first use)
     std::vector<std::vector<char>> slot_blobs;      // batch uploads: one packing buffer per batch slot, kept (with its pages) from batch to batch
     // ONE host -> device copy per upload: [blobs | blob_off[n] | ws_off[n] | out_tab[3 n]] staged in pinned memory; the three tables
     // live behind the blobs in the same device allocation (d_blob_off / d_ws_off / d_out_tab point into it)
@@ -97,7 +100,7 @@ static KOpts make_kopts(const uvs_options& o, int debug) {
 }
 
 struct DevWin;
-static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vector<char>& out, DevWin& hdr, std::string& err, int chunk_grid = 0);
+static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vector<char>& out, DevWin& hdr, std::string& err, int chunk_grid = 0, PackCache* cache = nullptr);
 
 extern "C" {
 
@@ -177,6 +180,7 @@ int uvs_create(const uvs_options* opts, int device, int max_batch, int max_point
 void uvs_destroy(uvs_solver* s) {
     if (!s) return;
     if (s->twin) { uvs_destroy(s->twin); s->twin = nullptr; }
+    free_pack_cache(s->pack_cache); s->pack_cache = nullptr;
     (void)hipSetDevice(s->device);      // teardown: nothing useful to do with an error
     if (s->d_blobs) (void)hipFree(s->d_blobs);
     if (s->d_ws) (void)hipFree(s->d_ws);
@@ -262,7 +266,106 @@ static int pack_inner_threads(int n_obs) {
     return std::max(1, nt);
 }
 
-static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vector<char>& out, DevWin& hdr, std::string& err, int chunk_grid) {
+// The STRUCTURE of the last large window packed through a handle (index arrays, IMU links, prior block table, options): when the next window has the same
+// structure -- the same landmarks observed from the same frames, only states and measurements moved on: repeated solves of one map, a benchmark loop --
+// chunking, work split and gather lists (3/4 of the packing time) are reused and only the value sections of the blob are rewritten.  Compared exactly
+// (memcmp of the arrays), no hashing.  Small windows do not use it: their structure changes with every frame of a live sequence.
+struct PackCache {
+    bool valid = false, device_holds_tables = false;
+    int chunk_grid = 0, td_on = 0, ex_on = 0;
+    int n_points = 0, n_pt_obs = 0, n_lines = 0, n_ln_obs = 0, n_imu = 0;
+    std::vector<int32_t> pt_lm, pt_fi, pt_fj, ln_lm, ln_fj, ln_has_vp;
+    int imu_fs[UVS_WINDOW_SIZE][2];
+    bool have_prior = false; int prior_n = 0, prior_nb = 0; int prior_tab[5][UVS_MAX_PRIOR_BLOCKS];
+    DevWin hdr;
+    bool matches(const uvs_window* w, const uvs_options& o, int grid) const {
+        if (!valid || !w || grid != chunk_grid || (o.estimate_td != 0) != (td_on != 0) || (o.estimate_extrinsic != 0) != (ex_on != 0) || w->n_relo_obs > 0) return false;
+        if (w->n_points != n_points || w->n_point_obs != n_pt_obs || w->n_lines != n_lines || w->n_line_obs != n_ln_obs || w->n_imu != n_imu) return false;
+        const bool hp = w->prior && w->prior->n > 0;
+        if (hp != have_prior) return false;
+        if (hp) {
+            const uvs_prior& p = *w->prior;
+            if (p.n != prior_n || p.n_blocks != prior_nb || p.n_blocks > UVS_MAX_PRIOR_BLOCKS) return false;
+            for (int b = 0; b < p.n_blocks; ++b) if (p.block_kind[b] != prior_tab[0][b] || p.block_frame[b] != prior_tab[1][b] || p.block_size[b] != prior_tab[2][b] || p.block_idx[b] != prior_tab[3][b] || p.x0_off[b] != prior_tab[4][b]) return false;
+            if (!p.linearized_jacobians || !p.linearized_residuals || !p.x0) return false;
+        }
+        if ((n_pt_obs && (!w->pt_lm || !w->pt_fi || !w->pt_fj || !w->pt_pi || !w->pt_pj || !w->inv_depth)) || (n_ln_obs && (!w->ln_lm || !w->ln_fj || !w->ln_sp || !w->ln_ep || !w->ln_has_vp || !w->ln_vp || !w->line_orth)) || (n_imu && !w->imu)) return false;
+        if (td_on && n_pt_obs && (!w->pt_vel_i || !w->pt_vel_j || !w->pt_td_i || !w->pt_td_j)) return false;
+        for (int b = 0; b < n_imu; ++b) if (w->imu[b].frame_i != imu_fs[b][0] || (w->imu[b].skip ? 1 : 0) != imu_fs[b][1]) return false;
+        const size_t np_ = (size_t)n_pt_obs * 4, nl_ = (size_t)n_ln_obs * 4;
+        return (!np_ || (!std::memcmp(w->pt_lm, pt_lm.data(), np_) && !std::memcmp(w->pt_fi, pt_fi.data(), np_) && !std::memcmp(w->pt_fj, pt_fj.data(), np_))) &&
+               (!nl_ || (!std::memcmp(w->ln_lm, ln_lm.data(), nl_) && !std::memcmp(w->ln_fj, ln_fj.data(), nl_) && !std::memcmp(w->ln_has_vp, ln_has_vp.data(), nl_)));
+    }
+    void store(const uvs_window* w, const uvs_options& o, int grid, const DevWin& h) {
+        valid = true; device_holds_tables = false; chunk_grid = grid; td_on = o.estimate_td != 0; ex_on = o.estimate_extrinsic != 0;
+        n_points = w->n_points; n_pt_obs = w->n_point_obs; n_lines = w->n_lines; n_ln_obs = w->n_line_obs; n_imu = w->n_imu;
+        pt_lm.assign(w->pt_lm, w->pt_lm + n_pt_obs); pt_fi.assign(w->pt_fi, w->pt_fi + n_pt_obs); pt_fj.assign(w->pt_fj, w->pt_fj + n_pt_obs);
+        ln_lm.assign(w->ln_lm, w->ln_lm + n_ln_obs); ln_fj.assign(w->ln_fj, w->ln_fj + n_ln_obs); ln_has_vp.assign(w->ln_has_vp, w->ln_has_vp + n_ln_obs);
+        for (int b = 0; b < n_imu; ++b) { imu_fs[b][0] = w->imu[b].frame_i; imu_fs[b][1] = w->imu[b].skip ? 1 : 0; }
+        have_prior = w->prior && w->prior->n > 0;
+        if (have_prior) { const uvs_prior& p = *w->prior; prior_n = p.n; prior_nb = p.n_blocks; for (int b = 0; b < p.n_blocks; ++b) { prior_tab[0][b] = p.block_kind[b]; prior_tab[1][b] = p.block_frame[b]; prior_tab[2][b] = p.block_size[b]; prior_tab[3][b] = p.block_idx[b]; prior_tab[4][b] = p.x0_off[b]; } }
+        hdr = h;
+    }
+};
+static void free_pack_cache(PackCache* c) { delete c; }
+static constexpr int kPackCacheMinObs = 20000;      // windows at least this large use the structure cache (and the inner packing threads)
+
+// the VALUE sections of a blob (everything that is not index bookkeeping): header, frame states, landmark parameters, measurements, IMU blocks, prior
+static void fill_values(char* B, const DevWin& h, const uvs_window* w, bool td_on, int threads) {
+    double* D = (double*)B;
+    std::memcpy(B, &h, sizeof(h));
+    std::memcpy(D + h.d_frames, w->pose, sizeof(double) * 77);
+    std::memcpy(D + h.d_frames + 77, w->speedbias, sizeof(double) * 99);
+    std::memcpy(D + h.d_frames + 176, w->ex_pose, sizeof(double) * 7);
+    D[h.d_frames + 183] = w->td;
+    std::memcpy(D + h.d_frames + 184, w->relo_pose, sizeof(double) * 7);
+    for (int k = 0; k < h.n_points; ++k) D[h.d_invd + k] = w->inv_depth[k];
+    pack_parallel(h.n_pt_obs, threads, [&](int k0_, int k1_, int) {
+        for (int k = k0_; k < k1_; ++k) {
+            for (int q = 0; q < 3; ++q) { D[h.d_ptmeas + q * h.pt_stride + k] = w->pt_pi[3 * k + q]; D[h.d_ptmeas + (3 + q) * h.pt_stride + k] = w->pt_pj[3 * k + q]; }
+            if (td_on) {
+                for (int q = 0; q < 2; ++q) { D[h.d_ptvel + q * h.pt_stride + k] = w->pt_vel_i[2 * k + q]; D[h.d_ptvel + (2 + q) * h.pt_stride + k] = w->pt_vel_j[2 * k + q]; }
+                D[h.d_ptvel + 4 * h.pt_stride + k] = w->pt_td_i[k]; D[h.d_ptvel + 5 * h.pt_stride + k] = w->pt_td_j[k];
+            }
+        }
+    });
+    for (int k = 0; k < 4 * h.n_lines; ++k) D[h.d_line + k] = w->line_orth[k];
+    pack_parallel(h.n_ln_obs, threads, [&](int k0_, int k1_, int) {
+        for (int k = k0_; k < k1_; ++k)
+            for (int q = 0; q < 3; ++q) {
+                D[h.d_lnmeas + q * h.ln_stride + k] = w->ln_sp[3 * k + q]; D[h.d_lnmeas + (3 + q) * h.ln_stride + k] = w->ln_ep[3 * k + q];
+                D[h.d_lnmeas + (6 + q) * h.ln_stride + k] = w->ln_vp[3 * k + q];
+            }
+    });
+    for (int b = 0; b < h.n_imu; ++b) {
+        const uvs_imu_block& ib = w->imu[b];
+        double* blk = D + h.d_imu + (size_t)b * UVS_IMU_STRIDE;
+        blk[0] = ib.sum_dt;
+        for (int q = 0; q < 3; ++q) { blk[1 + q] = ib.delta_p[q]; blk[8 + q] = ib.delta_v[q]; blk[11 + q] = ib.linearized_ba[q]; blk[14 + q] = ib.linearized_bg[q]; }
+        for (int q = 0; q < 4; ++q) blk[4 + q] = ib.delta_q[q];
+        {   // only the five 3x3 blocks the factor reads, packed (UVS_IMU_JIDX)
+            const int RC[5][2] = {{0, 9}, {0, 12}, {3, 12}, {6, 9}, {6, 12}};
+            for (int q = 0; q < 5; ++q) for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) blk[UVS_IMU_JAC + 9 * q + 3 * i + j] = ib.jacobian[(RC[q][0] + i) * 15 + RC[q][1] + j];
+        }
+        std::memcpy(blk + UVS_IMU_COV, ib.covariance, sizeof(double) * 225);
+    }
+    if (h.prior_n > 0) {
+        const uvs_prior& p = *w->prior;
+        const int n = p.n;
+        for (int r = 0; r < n; ++r) for (int cc = 0; cc < n; ++cc) { D[h.d_prior + r * n + cc] = p.linearized_jacobians[r * n + cc]; D[h.d_prior + n * n + cc * n + r] = p.linearized_jacobians[r * n + cc]; }
+        for (int r = 0; r < n; ++r) D[h.d_prior + 2 * n * n + r] = p.linearized_residuals[r];
+        // linearization point of block b at stride 9 (not at x0_off[b]): the kernel's loads of it then do not depend on a table load
+        for (int b = 0; b < p.n_blocks && b < 16; ++b) for (int k = 0; k < p.block_size[b] && k < 9; ++k) D[h.d_prior + 2 * n * n + 2 * n + 9 * b + k] = p.x0[p.x0_off[b] + k];
+    }
+}
+
+static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vector<char>& out, DevWin& hdr, std::string& err, int chunk_grid, PackCache* cache) {
+    if (cache && cache->matches(w_in, opts, chunk_grid) && out.size() == (size_t)cache->hdr.blob_bytes) {      // same structure as the blob still sitting in `out`: values only
+        fill_values(out.data(), cache->hdr, w_in, opts.estimate_td != 0, pack_inner_threads(w_in->n_point_obs + w_in->n_line_obs));
+        hdr = cache->hdr;
+        return UVS_OK;
+    }
+    if (cache) { cache->valid = false; cache->device_holds_tables = false; out.clear(); }
     const bool prof_ = std::getenv("UVS_PACK_PROFILE") != nullptr;
     auto t_prev_ = std::chrono::steady_clock::now();
     auto lap_ = [&](const char* what) { if (prof_) { const auto n_ = std::chrono::steady_clock::now(); fprintf(stderr, "pack %-10s %.3f ms\n", what, std::chrono::duration<double, std::milli>(n_ - t_prev_).count()); t_prev_ = n_; } };
@@ -680,54 +783,16 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
     out.resize(base + h.blob_bytes, 0);
     char* B = out.data() + base;
     double* D = (double*)B; int* I = (int*)B;
-    std::memcpy(B, &h, sizeof(h));
-    std::memcpy(D + h.d_frames, w->pose, sizeof(double) * 77);
-    std::memcpy(D + h.d_frames + 77, w->speedbias, sizeof(double) * 99);
-    std::memcpy(D + h.d_frames + 176, w->ex_pose, sizeof(double) * 7);
-    D[h.d_frames + 183] = w->td;
-    std::memcpy(D + h.d_frames + 184, w->relo_pose, sizeof(double) * 7);
+    fill_values(B, h, w, td_on, inner_threads);
+    // ---- the tables (index bookkeeping)
     if (relo_on) for (int k = 0; k < h.n_pt_obs; ++k) I[h.i_pt_eidx + k] = eidx[k];
-    for (int k = 0; k < h.n_points; ++k) D[h.d_invd + k] = w->inv_depth[k];
-    pack_parallel(h.n_pt_obs, inner_threads, [&](int k0_, int k1_, int) {
-        for (int k = k0_; k < k1_; ++k) {
-            for (int q = 0; q < 3; ++q) { D[h.d_ptmeas + q * h.pt_stride + k] = w->pt_pi[3 * k + q]; D[h.d_ptmeas + (3 + q) * h.pt_stride + k] = w->pt_pj[3 * k + q]; }
-            I[h.i_pt_lm + k] = w->pt_lm[k]; I[h.i_pt_fi + k] = w->pt_fi[k]; I[h.i_pt_fj + k] = w->pt_fj[k];
-            if (td_on) {
-                for (int q = 0; q < 2; ++q) { D[h.d_ptvel + q * h.pt_stride + k] = w->pt_vel_i[2 * k + q]; D[h.d_ptvel + (2 + q) * h.pt_stride + k] = w->pt_vel_j[2 * k + q]; }
-                D[h.d_ptvel + 4 * h.pt_stride + k] = w->pt_td_i[k]; D[h.d_ptvel + 5 * h.pt_stride + k] = w->pt_td_j[k];
-            }
-        }
-    });
+    for (int k = 0; k < h.n_pt_obs; ++k) { I[h.i_pt_lm + k] = w->pt_lm[k]; I[h.i_pt_fi + k] = w->pt_fi[k]; I[h.i_pt_fj + k] = w->pt_fj[k]; }
     for (int k = 0; k <= h.n_points; ++k) I[h.i_pt_beg + k] = pbeg[k];
-    for (int k = 0; k < 4 * h.n_lines; ++k) D[h.d_line + k] = w->line_orth[k];
-    for (int k = 0; k < h.n_ln_obs; ++k) {
-        for (int q = 0; q < 3; ++q) {
-            D[h.d_lnmeas + q * h.ln_stride + k] = w->ln_sp[3 * k + q]; D[h.d_lnmeas + (3 + q) * h.ln_stride + k] = w->ln_ep[3 * k + q];
-            D[h.d_lnmeas + (6 + q) * h.ln_stride + k] = w->ln_vp[3 * k + q];
-        }
-        I[h.i_ln_lm + k] = w->ln_lm[k]; I[h.i_ln_fj + k] = w->ln_fj[k]; I[h.i_ln_vp + k] = w->ln_has_vp[k] ? 1 : 0;
-    }
+    for (int k = 0; k < h.n_ln_obs; ++k) { I[h.i_ln_lm + k] = w->ln_lm[k]; I[h.i_ln_fj + k] = w->ln_fj[k]; I[h.i_ln_vp + k] = w->ln_has_vp[k] ? 1 : 0; }
     for (int k = 0; k <= h.n_lines; ++k) I[h.i_ln_beg + k] = lbeg[k];
-    for (int b = 0; b < h.n_imu; ++b) {
-        const uvs_imu_block& ib = w->imu[b];
-        double* blk = D + h.d_imu + (size_t)b * UVS_IMU_STRIDE;
-        blk[0] = ib.sum_dt;
-        for (int q = 0; q < 3; ++q) { blk[1 + q] = ib.delta_p[q]; blk[8 + q] = ib.delta_v[q]; blk[11 + q] = ib.linearized_ba[q]; blk[14 + q] = ib.linearized_bg[q]; }
-        for (int q = 0; q < 4; ++q) blk[4 + q] = ib.delta_q[q];
-        {   // only the five 3x3 blocks the factor reads, packed (UVS_IMU_JIDX)
-            const int RC[5][2] = {{0, 9}, {0, 12}, {3, 12}, {6, 9}, {6, 12}};
-            for (int q = 0; q < 5; ++q) for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) blk[UVS_IMU_JAC + 9 * q + 3 * i + j] = ib.jacobian[(RC[q][0] + i) * 15 + RC[q][1] + j];
-        }
-        std::memcpy(blk + UVS_IMU_COV, ib.covariance, sizeof(double) * 225);
-        I[h.i_imu + 2 * b] = ib.frame_i; I[h.i_imu + 2 * b + 1] = ib.skip ? 1 : 0;
-    }
+    for (int b = 0; b < h.n_imu; ++b) { I[h.i_imu + 2 * b] = w->imu[b].frame_i; I[h.i_imu + 2 * b + 1] = w->imu[b].skip ? 1 : 0; }
     if (have_prior) {
         const uvs_prior& p = *w->prior;
-        const int n = p.n;
-        for (int r = 0; r < n; ++r) for (int cc = 0; cc < n; ++cc) { D[h.d_prior + r * n + cc] = p.linearized_jacobians[r * n + cc]; D[h.d_prior + n * n + cc * n + r] = p.linearized_jacobians[r * n + cc]; }
-        for (int r = 0; r < n; ++r) D[h.d_prior + 2 * n * n + r] = p.linearized_residuals[r];
-        // linearization point of block b at stride 9 (not at x0_off[b]): the kernel's loads of it then do not depend on a table load
-        for (int b = 0; b < p.n_blocks && b < 16; ++b) for (int k = 0; k < p.block_size[b] && k < 9; ++k) D[h.d_prior + 2 * n * n + 2 * n + 9 * b + k] = p.x0[p.x0_off[b] + k];
         int* pt = I + h.i_prior;
         for (int q = 0; q < 80 + UVS_MAX_PRIOR_DIM + UVS_RD + UVS_NBLK; ++q) pt[q] = -1;
         for (int b = 0; b < p.n_blocks; ++b) {
@@ -753,6 +818,7 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
     for (int q = 0; q < UVS_NGRP; ++q) I[h.i_wblk + q] = wblk[q];
     lap_("blob");
     hdr = h;
+    if (cache && !relo_on && h.n_pt_obs + h.n_ln_obs >= kPackCacheMinObs) cache->store(w_in, opts, chunk_grid, h);
     return UVS_OK;
 }
 
@@ -790,7 +856,7 @@ static int upload_windows(uvs_solver* s, int n, const uvs_window* const* ws, boo
     if (!s || n < 1 || !ws) return UVS_ERR_INVALID_ARG;
     if (n > s->max_batch) { s->err = "batch larger than max_batch"; return UVS_ERR_CAPACITY; }
     HIPCHK(s, hipSetDevice(s->device));
-    s->host_blobs.clear(); s->hdrs.resize(n); s->blob_off.resize(n); s->ws_off.resize(n);
+    s->hdrs.resize(n); s->blob_off.resize(n); s->ws_off.resize(n);
     long long wtot = 0;
     for (int b = 0; b < n; ++b)
         if (ws[b] && (ws[b]->n_points > s->max_points || ws[b]->n_point_obs + std::max(ws[b]->n_relo_obs, 0) > s->max_point_obs || ws[b]->n_lines > s->max_lines || ws[b]->n_line_obs > s->max_line_obs)) {
@@ -806,13 +872,24 @@ static int upload_windows(uvs_solver* s, int n, const uvs_window* const* ws, boo
         nthreads = env ? std::atoi(env) : (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
         nthreads = std::max(1, std::min(nthreads, n));
     }
-    if (nthreads == 1) {
+    bool values_only = false;      // structure-cache hit AND the device still holds this window's tables: only the value sections travel
+    if (n == 1 && ws[0] && ws[0]->n_point_obs + ws[0]->n_line_obs >= kPackCacheMinObs && !std::getenv("UVS_NO_PACK_CACHE")) {
+        if (!s->pack_cache) s->pack_cache = new PackCache();
+        const bool was_valid = s->pack_cache->valid, dev = s->pack_cache->device_holds_tables;
+        s->blob_off[0] = 0;
+        int rc = pack_window(ws[0], s->opts, s->host_blobs, s->hdrs[0], s->err, chunk_grid, s->pack_cache);
+        if (rc != UVS_OK) { s->n_loaded = 0; return rc; }
+        values_only = was_valid && dev && s->pack_cache->valid && s->pack_cache->device_holds_tables;      // (a miss resets both flags)
+    } else if (nthreads == 1) {
+        s->host_blobs.clear();
+        if (s->pack_cache) { s->pack_cache->valid = false; s->pack_cache->device_holds_tables = false; }
         for (int b = 0; b < n; ++b) {
             s->blob_off[b] = (long long)s->host_blobs.size();
             int rc = pack_window(ws[b], s->opts, s->host_blobs, s->hdrs[b], s->err, chunk_grid);
             if (rc != UVS_OK) { s->n_loaded = 0; return rc; }
         }
     } else {
+        if (s->pack_cache) { s->pack_cache->valid = false; s->pack_cache->device_holds_tables = false; }
         // per-slot buffers that live in the handle: a fresh 260 KB vector per window was a page fault per 4 KB of it, every batch (0.9 ms per window
         // on a cold buffer against 0.12 ms on a warm one)
         if ((int)s->slot_blobs.size() < n) s->slot_blobs.resize(n);
@@ -847,7 +924,9 @@ static int upload_windows(uvs_solver* s, int n, const uvs_window* const* ws, boo
     // is staged by the runtime anyway, synchronously and on one thread); a large blob (configs[3]: 13 MB) is moved there by several threads
     const bool staged = true;
     if ((rc = ensure_pinned(s, &s->h_up, &s->h_up_cap, staged ? up_bytes : (size_t)n * 40)) != UVS_OK) return rc;
-    if ((rc = ensure(s, (void**)&s->d_blobs, &s->d_blobs_cap, up_bytes)) != UVS_OK) return rc;
+    { char* before = s->d_blobs; if ((rc = ensure(s, (void**)&s->d_blobs, &s->d_blobs_cap, up_bytes)) != UVS_OK) return rc; if (s->d_blobs != before) values_only = false; }
+    // all doubles of a blob precede its int tables (pack_window: i = 2 d), so the value sections are ONE prefix
+    const size_t value_bytes = values_only ? (size_t)4 * (size_t)s->hdrs[0].i_pt_lm : 0;
     if ((rc = ensure(s, (void**)&s->d_outpack, &s->d_outpack_cap, (size_t)s->out_total * 8 + (size_t)n * sizeof(uvs_report))) != UVS_OK) return rc;
     if ((rc = ensure(s, (void**)&s->d_ws, &s->d_ws_cap, (size_t)wtot * 8)) != UVS_OK) return rc;
     if ((rc = ensure(s, (void**)&s->d_reports, &s->d_rep_cap, (size_t)n * sizeof(uvs_report))) != UVS_OK) return rc;
@@ -857,7 +936,7 @@ static int upload_windows(uvs_solver* s, int n, const uvs_window* const* ws, boo
             pool.emplace_back([&, t] { for (int b = t; b < n; b += nthreads) std::memcpy(s->h_up + s->blob_off[b], s->slot_blobs[b].data(), s->slot_blobs[b].size()); });
         for (auto& th : pool) th.join();
     } else if (s->host_blobs.size() > ((size_t)4 << 20)) {
-        const size_t nb_ = s->host_blobs.size(); const int ct = pack_inner_threads(1 << 30);
+        const size_t nb_ = values_only ? value_bytes : s->host_blobs.size(); const int ct = pack_inner_threads(1 << 30);
         pack_parallel((int)((nb_ + 65535) >> 16), ct, [&](int c0, int c1, int) { const size_t a0 = (size_t)c0 << 16, a1 = std::min(nb_, (size_t)c1 << 16); if (a1 > a0) std::memcpy(s->h_up + a0, s->host_blobs.data() + a0, a1 - a0); });
     } else std::memcpy(s->h_up, s->host_blobs.data(), s->host_blobs.size());
     long long* tabs = (long long*)(s->h_up + (staged ? blob_bytes : 0));
@@ -865,13 +944,17 @@ static int upload_windows(uvs_solver* s, int n, const uvs_window* const* ws, boo
     std::memcpy(tabs + n, s->ws_off.data(), (size_t)n * 8);
     std::memcpy(tabs + 2 * (size_t)n, s->out_tab.data(), (size_t)n * 24);
     s->d_blob_off = (long long*)(s->d_blobs + blob_bytes); s->d_ws_off = s->d_blob_off + n; s->d_out_tab = s->d_blob_off + 2 * (size_t)n;
-    if (staged) HIPCHK(s, hipMemcpyAsync(s->d_blobs, s->h_up, up_bytes, hipMemcpyHostToDevice, s->stream));
+    if (values_only) {      // the tables of this window are on the device already (structure cache): the value prefix and the three small offset tables
+        HIPCHK(s, hipMemcpyAsync(s->d_blobs, s->h_up, value_bytes, hipMemcpyHostToDevice, s->stream));
+        HIPCHK(s, hipMemcpyAsync(s->d_blobs + blob_bytes, s->h_up + blob_bytes, (size_t)n * 40, hipMemcpyHostToDevice, s->stream));
+    } else if (staged) HIPCHK(s, hipMemcpyAsync(s->d_blobs, s->h_up, up_bytes, hipMemcpyHostToDevice, s->stream));
     else {
         HIPCHK(s, hipMemcpyAsync(s->d_blobs, s->host_blobs.data(), s->host_blobs.size(), hipMemcpyHostToDevice, s->stream));
         HIPCHK(s, hipMemcpyAsync(s->d_blobs + blob_bytes, s->h_up, (size_t)n * 40, hipMemcpyHostToDevice, s->stream));
         wait = true;      // host_blobs is reused by the next upload
     }
     if (wait) HIPCHK(s, hipStreamSynchronize(s->stream));
+    if (s->pack_cache && s->pack_cache->valid && n == 1) s->pack_cache->device_holds_tables = true;
     s->n_loaded = n;
     return UVS_OK;
 }
