@@ -41,3 +41,30 @@ def test_hip_prior_matches_extended_precision(gpu_api, index, with_prior):
     eH, eb = _check(lambda x: s.evaluate(x, robust=True), lambda x: s.marginalize(x, 0), w.with_state(st), 5e-7, 1e-8)
     print("HIP prior vs longdouble Schur complement: H %.2e, b %.2e (relative to the largest entry)" % (eH, eb))
     s.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("index", [41, 42, 43])
+def test_device_marginalization_equals_host_path(gpu_api, oracle, index):
+    """MARGIN_OLD on the device (round 3): the factors of frame 0 as a window of their own, ONE linearization with an infinite radius by the solver's kernels
+    (= assembly + elimination of every dropped landmark block), frame-0 elimination and the n x n factorization on the host -- against the host path
+    (UVS_MARG_HOST=1: k_evaluate + assembly + block elimination in csrc/uvs_marg.h) and against the oracle, in the information form."""
+    import os
+    marg = lambda win, flag: oracle.marginalize(win, flag)
+    w = synth.make_window(index, with_prior=True, marginalize_fn=marg)
+    s = gpu_api.Solver(max_batch=2)
+    st, rep = s.solve(w)
+    ws = w.with_state(st)
+    pd = s.marginalize(ws, 0)
+    os.environ["UVS_MARG_HOST"] = "1"
+    try: ph = s.marginalize(ws, 0)
+    finally: os.environ.pop("UVS_MARG_HOST")
+    s.close()
+    po = oracle.marginalize(ws, 0)
+    assert pd.n == ph.n == po.n and pd.n_blocks == ph.n_blocks and list(pd.block_kind[:pd.n_blocks]) == list(ph.block_kind[:ph.n_blocks]) and list(pd.block_idx[:pd.n_blocks]) == list(ph.block_idx[:ph.n_blocks])
+    Ad, Ah, Ao = pd.J0().T @ pd.J0(), ph.J0().T @ ph.J0(), po.J0().T @ po.J0()
+    bd, bh, bo = pd.J0().T @ pd.r0(), ph.J0().T @ ph.r0(), po.J0().T @ po.r0()
+    sc = np.abs(Ao).max()
+    assert np.abs(Ad - Ah).max() <= 1e-7 * sc and np.abs(Ad - Ao).max() <= 1e-6 * sc
+    assert np.abs(bd - bh).max() <= 1e-6 * max(1.0, np.abs(bo).max()) and np.abs(bd - bo).max() <= 1e-5 * max(1.0, np.abs(bo).max())
+    assert np.array_equal(np.asarray(pd.x0[:80]), np.asarray(ph.x0[:80]))

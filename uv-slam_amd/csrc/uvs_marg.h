@@ -190,6 +190,93 @@ static void host_sym_eig(int n, std::vector<double>& M, std::vector<double>& V, 
 UVS_HOST_SIMD static void row_axpy(int n, double* __restrict y, const double* __restrict x, double a) { for (int k = 0; k < n; ++k) y[k] += a * x[k]; }      // y[0..n) += a x
 #pragma clang fp contract(on)
 
+// X <- B^+ X for a small symmetric block B (sz <= 15) and sz x nr right-hand sides (row stride ldx).  Regular case: Cholesky solve
+// (an eigen-based inverse of the frame block, whose eigenvalues span 1e5..1e14, costs four digits in J0^T r0); a pivot at or under
+// eps means the reference's cut would bite, and only then the pseudo-inverse is formed from the block's eigen-decomposition.
+static void marg_solve_small(int sz, const double* Bm, double* X, int nr, int ldx, double eps) {
+        double Lc[225]; bool regular = true;
+        for (int i = 0; i < sz && regular; ++i) for (int j = 0; j <= i; ++j) {
+            double t = Bm[i * sz + j];
+            for (int k = 0; k < j; ++k) t -= Lc[i * sz + k] * Lc[j * sz + k];
+            if (i == j) { if (!(t > eps)) { regular = false; break; } Lc[i * sz + i] = std::sqrt(t); } else Lc[i * sz + j] = t / Lc[j * sz + j];
+        }
+        if (regular) {
+            for (int c2 = 0; c2 < nr; ++c2) {
+                for (int i = 0; i < sz; ++i) { double t = X[(size_t)i * ldx + c2]; for (int k = 0; k < i; ++k) t -= Lc[i * sz + k] * X[(size_t)k * ldx + c2]; X[(size_t)i * ldx + c2] = t / Lc[i * sz + i]; }
+                for (int i = sz - 1; i >= 0; --i) { double t = X[(size_t)i * ldx + c2]; for (int k = i + 1; k < sz; ++k) t -= Lc[k * sz + i] * X[(size_t)k * ldx + c2]; X[(size_t)i * ldx + c2] = t / Lc[i * sz + i]; }
+            }
+            return;
+        }
+        std::vector<double> M2(Bm, Bm + (size_t)sz * sz), Vs, ls, Binv((size_t)sz * sz, 0.0), col(sz);
+        host_sym_eig_jacobi(sz, M2, Vs, ls);
+        for (int k = 0; k < sz; ++k) { if (!(ls[k] > eps)) continue; const double il = 1.0 / ls[k]; for (int i = 0; i < sz; ++i) for (int j = 0; j < sz; ++j) Binv[(size_t)i * sz + j] += Vs[(size_t)i * sz + k] * il * Vs[(size_t)j * sz + k]; }
+        for (int c2 = 0; c2 < nr; ++c2) {
+            for (int i = 0; i < sz; ++i) { double t = 0.0; for (int k = 0; k < sz; ++k) t += Binv[(size_t)i * sz + k] * X[(size_t)k * ldx + c2]; col[i] = t; }
+            for (int i = 0; i < sz; ++i) X[(size_t)i * ldx + c2] = col[i];
+        }
+    }
+
+// The tail of a marginalization, shared by the host path (A assembled and its landmark blocks eliminated on the host) and the device path (A = the reduced
+// frame system a linearization kernel delivered): A is N x N with the dropped FRAME dofs in rows / columns [0, md) and the kept ones in [m, N); rows
+// [md, m) (eliminated landmarks) are not read.  Eliminates the dropped frame block, factors the kept system J0 = sqrt(S) V^T, r0 = sqrt(S^-1) V^T b
+// (marginalization_factor.cpp:263-291) and fills the block table with the shifted frames (estimator.cpp:1139-1152 / :1196-1219).
+static void marg_finish(int N, int m, int md, int n, std::vector<double>& A, std::vector<double>& bv, const std::vector<int>& pos, const std::vector<int>& keep_ids,
+                        const uvs_window* w, int flag, uvs_prior* out, EvalScratch& sc, bool prof, const double* us_pre) {
+    auto tnow = [] { return std::chrono::steady_clock::now(); };
+    auto t3 = tnow();
+    const double eps = 1e-8;                           // marginalization_factor.h:70
+    const int NFR = UVS_NF;
+    auto gsize = [&](int id) { return id < NFR ? 7 : id < 2 * NFR ? 9 : id == 22 ? 7 : id == 23 ? 1 : 1; };
+    std::vector<double> Sd((size_t)md * md), Xd((size_t)md * (n + 1)), br(n);
+    std::vector<double>& Ar = sc.work[6]; Ar.assign((size_t)n * n, 0.0);
+    for (int i = 0; i < md; ++i) for (int j = 0; j < md; ++j) Sd[(size_t)i * md + j] = 0.5 * (A[(size_t)i * N + j] + A[(size_t)j * N + i]);
+    for (int i = 0; i < md; ++i) { for (int j = 0; j < n; ++j) Xd[(size_t)i * (n + 1) + j] = A[(size_t)i * N + m + j]; Xd[(size_t)i * (n + 1) + n] = bv[i]; }
+    marg_solve_small(md, Sd.data(), Xd.data(), n + 1, n + 1, eps);                   // X = S^+ [A_dr | b_d]
+    for (int i = 0; i < n; ++i) {
+        const double* ad = &A[(size_t)(m + i) * N];
+        double sacc = bv[m + i]; for (int k = 0; k < md; ++k) sacc -= ad[k] * Xd[(size_t)k * (n + 1) + n]; br[i] = sacc;
+        for (int j = 0; j < n; ++j) { double t = ad[m + j]; for (int k = 0; k < md; ++k) t -= ad[k] * Xd[(size_t)k * (n + 1) + j]; Ar[(size_t)i * n + j] = t; }
+    }
+    // ---- second eigen-decomposition -> J0 = sqrt(S) V^T, r0 = sqrt(S^-1) V^T b   (:278-291); lower triangle is read, like Eigen
+    std::vector<double>&As = sc.work[7], &V2 = sc.work[8], &lam2 = sc.work[9];
+    As.assign((size_t)n * n, 0.0);
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) As[(size_t)i * n + j] = (j <= i) ? Ar[(size_t)i * n + j] : Ar[(size_t)j * n + i];
+    auto t4 = tnow();
+    host_sym_eig(n, As, V2, lam2);
+    auto t5 = tnow();
+    if (prof) {
+        auto us = [](auto a, auto b) { return (double)std::chrono::duration_cast<std::chrono::nanoseconds>(b - a).count() * 1e-3; };
+        std::fprintf(stderr, "[uvs_marginalize] m %d n %d: evaluate / device linearization %.0f us, assemble %.0f us, landmark blocks %.0f us, frame block + schur %.0f us, eig(n) %.0f us\n", m, n, us_pre[0], us_pre[1], us_pre[2], us(t3, t4), us(t4, t5));
+    }
+    std::vector<int> ord(n); for (int i = 0; i < n; ++i) ord[i] = i;
+    std::stable_sort(ord.begin(), ord.end(), [&](int a, int b2) { return lam2[a] < lam2[b2]; });
+    std::memset(out, 0, sizeof(*out));
+    out->n = n; out->n_blocks = (int)keep_ids.size();
+    for (int row = 0; row < n; ++row) {
+        const int k = ord[row];
+        const bool on = lam2[k] > eps;
+        const double ss = on ? std::sqrt(lam2[k]) : 0.0, si = on ? std::sqrt(1.0 / lam2[k]) : 0.0;
+        double vb = 0.0;
+        for (int j = 0; j < n; ++j) { out->linearized_jacobians[(size_t)row * n + j] = ss * V2[(size_t)j * n + k]; vb += V2[(size_t)j * n + k] * br[j]; }
+        out->linearized_residuals[row] = si * vb;
+    }
+    // ---- kept blocks, linearization point = current values, addr_shift (estimator.cpp:1139-1152 / :1196-1219)
+    int xo = 0;
+    for (int b = 0; b < out->n_blocks; ++b) {
+        const int id = keep_ids[b];
+        int kind, frame = 0; const double* data;
+        if (id < NFR) { kind = UVS_BLOCK_POSE; frame = id; data = w->pose[frame]; }
+        else if (id < 2 * NFR) { kind = UVS_BLOCK_SPEEDBIAS; frame = id - NFR; data = w->speedbias[frame]; }
+        else if (id == 23) { kind = UVS_BLOCK_TD; data = &w->td; }
+        else { kind = UVS_BLOCK_EX_POSE; data = w->ex_pose; }
+        int nf = frame;
+        if (kind == UVS_BLOCK_POSE || kind == UVS_BLOCK_SPEEDBIAS) nf = (flag == 0) ? frame - 1 : (frame == UVS_WINDOW_SIZE ? frame - 1 : frame);
+        out->block_kind[b] = kind; out->block_frame[b] = nf; out->block_size[b] = gsize(id); out->block_idx[b] = pos[id] - m; out->x0_off[b] = xo;
+        for (int q = 0; q < gsize(id); ++q) out->x0[xo + q] = data[q];
+        xo += gsize(id);
+    }
+}
+
 struct MFactor { int rows; int nb; int id[5]; int sz[5]; const double* r; const double* J; int ld; int coff[5]; const double* Jx; int xcol; };   // J row stride ld, column offset per block; block with coff < 0 reads its single column from Jx[row stride 1... 2 entries]   // J row stride ld, column offset per block
 
 static int run_marginalize(int device, hipStream_t stream, char* d_blob, double* d_ws, const DevWin& h, const uvs_window* w, const KOpts& ko,
@@ -326,31 +413,6 @@ static int run_marginalize(int device, hipStream_t stream, char* d_blob, double*
     // Schur complement to 1e-14 in b (tests/test_marginalization.py), and it is O(m) instead of O(m^3).
     int md = 0;
     for (int id = 0; id < PT0; ++id) if (used[id] && drop[id]) md += lsize(id);
-    // X <- B^+ X for a small symmetric block B (sz <= 15) and sz x nr right-hand sides (row stride ldx).  Regular case: Cholesky solve
-    // (an eigen-based inverse of the frame block, whose eigenvalues span 1e5..1e14, costs four digits in J0^T r0); a pivot at or under
-    // eps means the reference's cut would bite, and only then the pseudo-inverse is formed from the block's eigen-decomposition.
-    auto solve_small = [&](int sz, const double* Bm, double* X, int nr, int ldx) {
-        double Lc[225]; bool regular = true;
-        for (int i = 0; i < sz && regular; ++i) for (int j = 0; j <= i; ++j) {
-            double t = Bm[i * sz + j];
-            for (int k = 0; k < j; ++k) t -= Lc[i * sz + k] * Lc[j * sz + k];
-            if (i == j) { if (!(t > eps)) { regular = false; break; } Lc[i * sz + i] = std::sqrt(t); } else Lc[i * sz + j] = t / Lc[j * sz + j];
-        }
-        if (regular) {
-            for (int c2 = 0; c2 < nr; ++c2) {
-                for (int i = 0; i < sz; ++i) { double t = X[(size_t)i * ldx + c2]; for (int k = 0; k < i; ++k) t -= Lc[i * sz + k] * X[(size_t)k * ldx + c2]; X[(size_t)i * ldx + c2] = t / Lc[i * sz + i]; }
-                for (int i = sz - 1; i >= 0; --i) { double t = X[(size_t)i * ldx + c2]; for (int k = i + 1; k < sz; ++k) t -= Lc[k * sz + i] * X[(size_t)k * ldx + c2]; X[(size_t)i * ldx + c2] = t / Lc[i * sz + i]; }
-            }
-            return;
-        }
-        std::vector<double> M2(Bm, Bm + (size_t)sz * sz), Vs, ls, Binv((size_t)sz * sz, 0.0), col(sz);
-        host_sym_eig_jacobi(sz, M2, Vs, ls);
-        for (int k = 0; k < sz; ++k) { if (!(ls[k] > eps)) continue; const double il = 1.0 / ls[k]; for (int i = 0; i < sz; ++i) for (int j = 0; j < sz; ++j) Binv[(size_t)i * sz + j] += Vs[(size_t)i * sz + k] * il * Vs[(size_t)j * sz + k]; }
-        for (int c2 = 0; c2 < nr; ++c2) {
-            for (int i = 0; i < sz; ++i) { double t = 0.0; for (int k = 0; k < sz; ++k) t += Binv[(size_t)i * sz + k] * X[(size_t)k * ldx + c2]; col[i] = t; }
-            for (int i = 0; i < sz; ++i) X[(size_t)i * ldx + c2] = col[i];
-        }
-    };
     std::vector<int> coupled; coupled.reserve(N);
     std::vector<double>&Xk = sc.work[4], &Uk = sc.work[5];
     for (int id = PT0; id < NID; ++id) {
@@ -363,7 +425,7 @@ static int run_marginalize(int device, hipStream_t stream, char* d_blob, double*
         const int nc = (int)coupled.size(), ldx = nc + 1;
         Xk.assign((size_t)sz * ldx, 0.0);                                  // X = B^+ [A_{block, coupled} | b_block]
         for (int q = 0; q < sz; ++q) { for (int cj = 0; cj < nc; ++cj) Xk[(size_t)q * ldx + cj] = A[(size_t)(o + q) * N + coupled[cj]]; Xk[(size_t)q * ldx + nc] = bv[o + q]; }
-        solve_small(sz, Bm, Xk.data(), ldx, ldx);
+        marg_solve_small(sz, Bm, Xk.data(), ldx, ldx, eps);
         // U = A_{coupled, block} X  (nc x (nc + 1), contiguous rows: the inner loops vectorise), then scattered; per entry the sum over q runs in
         // the same order as the scalar loop it replaces
         Uk.assign((size_t)nc * ldx, 0.0);
@@ -381,54 +443,9 @@ static int run_marginalize(int device, hipStream_t stream, char* d_blob, double*
         }
     }
     auto t3 = tnow();
-    std::vector<double> Sd((size_t)md * md), Xd((size_t)md * (n + 1)), br(n);
-    std::vector<double>& Ar = sc.work[6]; Ar.assign((size_t)n * n, 0.0);
-    for (int i = 0; i < md; ++i) for (int j = 0; j < md; ++j) Sd[(size_t)i * md + j] = 0.5 * (A[(size_t)i * N + j] + A[(size_t)j * N + i]);
-    for (int i = 0; i < md; ++i) { for (int j = 0; j < n; ++j) Xd[(size_t)i * (n + 1) + j] = A[(size_t)i * N + m + j]; Xd[(size_t)i * (n + 1) + n] = bv[i]; }
-    solve_small(md, Sd.data(), Xd.data(), n + 1, n + 1);                   // X = S^+ [A_dr | b_d]
-    for (int i = 0; i < n; ++i) {
-        const double* ad = &A[(size_t)(m + i) * N];
-        double sacc = bv[m + i]; for (int k = 0; k < md; ++k) sacc -= ad[k] * Xd[(size_t)k * (n + 1) + n]; br[i] = sacc;
-        for (int j = 0; j < n; ++j) { double t = ad[m + j]; for (int k = 0; k < md; ++k) t -= ad[k] * Xd[(size_t)k * (n + 1) + j]; Ar[(size_t)i * n + j] = t; }
-    }
-    // ---- second eigen-decomposition -> J0 = sqrt(S) V^T, r0 = sqrt(S^-1) V^T b   (:278-291); lower triangle is read, like Eigen
-    std::vector<double>&As = sc.work[7], &V2 = sc.work[8], &lam2 = sc.work[9];
-    As.assign((size_t)n * n, 0.0);
-    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) As[(size_t)i * n + j] = (j <= i) ? Ar[(size_t)i * n + j] : Ar[(size_t)j * n + i];
-    auto t4 = tnow();
-    host_sym_eig(n, As, V2, lam2);
-    auto t5 = tnow();
-    if (prof) {
-        auto us = [](auto a, auto b) { return (double)std::chrono::duration_cast<std::chrono::nanoseconds>(b - a).count() * 1e-3; };
-        std::fprintf(stderr, "[uvs_marginalize] m %d n %d: evaluate %.0f us, assemble %.0f us, landmark blocks %.0f us, frame block + schur %.0f us, eig(n) %.0f us\n", m, n, us(t0, t1), us(t1, t2), us(t2, t3), us(t3, t4), us(t4, t5));
-    }
-    std::vector<int> ord(n); for (int i = 0; i < n; ++i) ord[i] = i;
-    std::stable_sort(ord.begin(), ord.end(), [&](int a, int b2) { return lam2[a] < lam2[b2]; });
-    std::memset(out, 0, sizeof(*out));
-    out->n = n; out->n_blocks = (int)keep_ids.size();
-    for (int row = 0; row < n; ++row) {
-        const int k = ord[row];
-        const bool on = lam2[k] > eps;
-        const double ss = on ? std::sqrt(lam2[k]) : 0.0, si = on ? std::sqrt(1.0 / lam2[k]) : 0.0;
-        double vb = 0.0;
-        for (int j = 0; j < n; ++j) { out->linearized_jacobians[(size_t)row * n + j] = ss * V2[(size_t)j * n + k]; vb += V2[(size_t)j * n + k] * br[j]; }
-        out->linearized_residuals[row] = si * vb;
-    }
-    // ---- kept blocks, linearization point = current values, addr_shift (estimator.cpp:1139-1152 / :1196-1219)
-    int xo = 0;
-    for (int b = 0; b < out->n_blocks; ++b) {
-        const int id = keep_ids[b];
-        int kind, frame = 0; const double* data;
-        if (id < NFR) { kind = UVS_BLOCK_POSE; frame = id; data = w->pose[frame]; }
-        else if (id < 2 * NFR) { kind = UVS_BLOCK_SPEEDBIAS; frame = id - NFR; data = w->speedbias[frame]; }
-        else if (id == 23) { kind = UVS_BLOCK_TD; data = &w->td; }
-        else { kind = UVS_BLOCK_EX_POSE; data = w->ex_pose; }
-        int nf = frame;
-        if (kind == UVS_BLOCK_POSE || kind == UVS_BLOCK_SPEEDBIAS) nf = (flag == 0) ? frame - 1 : (frame == UVS_WINDOW_SIZE ? frame - 1 : frame);
-        out->block_kind[b] = kind; out->block_frame[b] = nf; out->block_size[b] = gsize(id); out->block_idx[b] = pos[id] - m; out->x0_off[b] = xo;
-        for (int q = 0; q < gsize(id); ++q) out->x0[xo + q] = data[q];
-        xo += gsize(id);
-    }
+    double us_pre[3] = {0, 0, 0};
+    if (prof) { auto us = [](auto a_, auto b_) { return (double)std::chrono::duration_cast<std::chrono::nanoseconds>(b_ - a_).count() * 1e-3; }; us_pre[0] = us(t0, t1); us_pre[1] = us(t1, t2); us_pre[2] = us(t2, t3); }
+    marg_finish(N, m, md, n, A, bv, pos, keep_ids, w, flag, out, sc, prof, us_pre);
     return UVS_OK;
 }
 

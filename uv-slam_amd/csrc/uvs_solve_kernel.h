@@ -2042,4 +2042,57 @@ __global__ __launch_bounds__(NT) void k_solve(char* blobs, const long long* blob
     }
 }
 
+// ------------------------------------------------------------------ marginalization on the device (MARGIN_OLD)
+// The window here is the SUB-window of the factors that touch the departing frame 0 (marginalization_factor.cpp:174-297 via estimator.cpp:1002-1135: IMU block 0,
+// the points anchored in frame 0, the lines that start there without their anchor observation, the prior), packed with a FREE extrinsic (the reference's prior
+// keeps para_Ex_Pose whether or not the solve estimates it).  One linearization of it at the post-solve state with an infinite trust-region radius IS the
+// assembly A = sum J^T J, b = sum J^T r of the reference followed by the elimination of every dropped landmark block: the kernel's reduced frame system.
+// out = [S lower packed (i >= j: i (i + 1) / 2 + j, padded indices) | g[176] | {cost, number of lanes with a landmark pivot <= 1e-8, 0...}[8]].
+// The host eliminates the 15 dofs of frame 0 from it and factors the rest (csrc/uvs_marg.h: marg_finish).
+static constexpr int MARG_OUT = UVS_RD * (UVS_RD + 1) / 2 + UVS_RD + 8;
+__global__ __launch_bounds__(NT) void k_marg_linearize(char* blob, double* ws, KOpts o, double* out) {
+    extern __shared__ __attribute__((aligned(16))) double sh[];
+    const int tid = lane_tid();
+    Ctx c;
+    c.hdr = (const DevWin*)blob; c.bd = (const double*)blob; c.bi = (const int*)blob; c.ws = ws; c.sh = sh; c.o = o; c.o.debug = 0;
+    const DevWin& h = *c.hdr;
+    if (tid < UVS_XDIM) sh[L_X + tid] = c.bd[h.d_frames + tid];
+    for (int k = tid; k < h.n_points; k += NT) c.ws[h.w_invd0 + k] = c.bd[h.d_invd + k];
+    for (int k = tid; k < 4 * h.n_lines; k += NT) c.ws[h.w_line0 + k] = c.bd[h.d_line + k];
+    for (int k = tid; k < h.n_lines; k += NT) line_trig(c.bd + h.d_line + 4 * k, c.ws + h.w_ltrig0 + 8 * k);
+    c.ltrig_ok = 1;
+    if (tid < 24) sh[L_PROF + tid] = 0.0;
+    if (tid < 8) sh[L_WPROF + tid] = 0.0;
+    setup_window(c, (double*)blob);
+    __syncthreads();
+    GAcc gacc;
+    linearize(c, sh + L_X, c.ws + h.w_invd0, c.ws + h.w_line0, true, o.r0, 0, gacc);
+    // smallest pivot of the UNDAMPED landmark blocks (the reference cuts eigenvalues of A_mm at 1e-8: a landmark block that is not safely regular
+    // sends the caller to the host path, which applies that cut)
+    double worst = 1e300;
+    for (int k = tid; k < h.n_points; k += NT) if (c.bi[h.i_pt_beg + k + 1] > c.bi[h.i_pt_beg + k]) worst = fmin(worst, c.ws[h.w_pt_x + 4 * (size_t)k + 3]);
+    for (int k = tid; k < h.n_lines; k += NT) {
+        if (c.bi[h.i_ln_beg + k + 1] == c.bi[h.i_ln_beg + k]) continue;
+        const double* H = c.ws + h.w_ln_x + UVS_LN_X * (size_t)k + 12;      // lower packed (0,0)(1,0)(1,1)(2,0)...
+        double L[10];
+        const double p0 = H[0]; L[0] = sqrt(fmax(p0, 1e-300));
+        L[1] = H[1] / L[0]; const double p1 = H[2] - L[1] * L[1]; L[2] = sqrt(fmax(p1, 1e-300));
+        L[3] = H[3] / L[0]; L[4] = (H[4] - L[3] * L[1]) / L[2]; const double p2 = H[5] - L[3] * L[3] - L[4] * L[4]; L[5] = sqrt(fmax(p2, 1e-300));
+        L[6] = H[6] / L[0]; L[7] = (H[7] - L[6] * L[1]) / L[2]; L[8] = (H[8] - L[6] * L[3] - L[7] * L[4]) / L[5];
+        const double p3 = H[9] - L[6] * L[6] - L[7] * L[7] - L[8] * L[8];
+        worst = fmin(worst, fmin(fmin(p0, p1), fmin(p2, p3)));
+    }
+    double s4[4] = {(worst > 1e-8) ? 0.0 : 1.0, 0, 0, 0}, mx = 0.0;      // lanes that hold a landmark block with a pivot at or under the reference's eps (marginalization_factor.h:70)
+    block_reduce(sh, s4, &mx);
+    for (int t = tid; t < UVS_RD * (UVS_RD + 1) / 2; t += NT) {
+        int i = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+        while ((i + 1) * (i + 2) / 2 <= t) ++i;
+        while (i * (i + 1) / 2 > t) --i;
+        const int j = t - i * (i + 1) / 2;
+        out[t] = sh[L_S + sidx(i, j)];
+    }
+    if (tid < UVS_RD) out[UVS_RD * (UVS_RD + 1) / 2 + tid] = sh[L_G + tid];
+    if (tid == 0) { double* sc = out + UVS_RD * (UVS_RD + 1) / 2 + UVS_RD; sc[0] = sh[L_CTRL + C_COST]; sc[1] = s4[0]; }
+}
+
 }  // namespace uvsdev

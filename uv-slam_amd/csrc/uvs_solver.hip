@@ -29,6 +29,8 @@ using namespace uvsdev;
 
 struct PackCache;
 static void free_pack_cache(PackCache* c);
+struct MargDevScratch;
+static void free_marg_scratch(MargDevScratch* m);
 struct uvs_solver {
     uvs_options opts;
     int device;
@@ -45,6 +47,7 @@ struct uvs_solver {
     std::vector<DevWin> hdrs;                // host copies of the per-window headers
     std::vector<long long> blob_off, ws_off;
     std::vector<char> host_blobs;
+    MargDevScratch* marg_dev = nullptr;   // buffers of the device marginalization (sub-window blob, its workspace, the reduced system)
     PackCache* pack_cache = nullptr;      // structure of the last large single window (allocated on first use)
     std::vector<std::vector<char>> slot_blobs;      // batch uploads: one packing buffer per batch slot, kept (with its pages) from batch to batch
     // ONE host -> device copy per upload: [blobs | blob_off[n] | ws_off[n] | out_tab[3 n]] staged in pinned memory; the three tables
@@ -181,6 +184,7 @@ void uvs_destroy(uvs_solver* s) {
     if (!s) return;
     if (s->twin) { uvs_destroy(s->twin); s->twin = nullptr; }
     free_pack_cache(s->pack_cache); s->pack_cache = nullptr;
+    free_marg_scratch(s->marg_dev); s->marg_dev = nullptr;
     (void)hipSetDevice(s->device);      // teardown: nothing useful to do with an error
     if (s->d_blobs) (void)hipFree(s->d_blobs);
     if (s->d_ws) (void)hipFree(s->d_ws);
@@ -959,6 +963,134 @@ static int upload_windows(uvs_solver* s, int n, const uvs_window* const* ws, boo
     return UVS_OK;
 }
 
+// ---------------------------------------------------------------- MARGIN_OLD on the device (round 3)
+// The factors the reference marginalizes (estimator.cpp:1002-1135) form a small window of their own; ONE linearization of it by the solver's own kernels
+// (k_marg_linearize) delivers the assembled and landmark-eliminated system, and only the elimination of frame 0's 15 dofs and the n x n factorization stay
+// on the host (uvs_marg.h: marg_finish).  Returns UVS_OK, an error, or kMargFallback when the host path must take the call (no such factors, a landmark
+// block that is not safely regular, relocalization blocks in the way).
+namespace { constexpr int kMargFallback = 1000; }
+struct MargDevScratch {
+    std::vector<int32_t> pt_lm, pt_fi, pt_fj, ln_lm, ln_fj, ln_vpf; std::vector<double> pt_pi, pt_pj, pt_vi, pt_vj, pt_tdi, pt_tdj, invd, ln_sp, ln_ep, ln_vp, lorth;
+    std::vector<uvs_imu_block> imu; std::vector<int> pmap, lmap, lstart;
+    std::vector<char> blob;
+    char* d_blob = nullptr; size_t d_blob_cap = 0; double* d_ws = nullptr; size_t d_ws_cap = 0; double* d_out = nullptr; char* h_out = nullptr; size_t h_out_cap = 0;
+    char* h_up = nullptr; size_t h_up_cap = 0;
+};
+static void free_marg_scratch(MargDevScratch* m) {
+    if (!m) return;
+    if (m->d_blob) (void)hipFree(m->d_blob); if (m->d_ws) (void)hipFree(m->d_ws); if (m->d_out) (void)hipFree(m->d_out);
+    if (m->h_out) (void)hipHostFree(m->h_out); if (m->h_up) (void)hipHostFree(m->h_up);
+    delete m;
+}
+static int marginalize_old_device(uvs_solver* s, const uvs_window* w, uvs_prior* out) {
+    if (std::getenv("UVS_MARG_HOST")) return kMargFallback;      // (relocalization blocks are not marginalized, estimator.cpp:1002-1228: the sub-window simply leaves them out)
+    const bool prof = std::getenv("UVS_MARG_PROFILE") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    if (!s->marg_dev) s->marg_dev = new MargDevScratch();
+    MargDevScratch& M = *s->marg_dev;
+    const bool td_on = s->opts.estimate_td != 0;
+    const int NFR = UVS_NF;
+    // ---- the sub-window: which blocks it touches (ids: pose f -> f ; speedbias f -> 11 + f ; ex -> 22 ; td -> 23)
+    bool used[24] = {false};
+    const bool have_prior = w->prior && w->prior->n > 0;
+    if (have_prior) for (int b = 0; b < w->prior->n_blocks; ++b) {
+        const uvs_prior& p = *w->prior;
+        used[p.block_kind[b] == UVS_BLOCK_POSE ? p.block_frame[b] : p.block_kind[b] == UVS_BLOCK_SPEEDBIAS ? NFR + p.block_frame[b] : p.block_kind[b] == UVS_BLOCK_TD ? 23 : 22] = true;
+    }
+    M.imu.clear();
+    for (int b = 0; b < w->n_imu; ++b) {
+        if (w->imu[b].frame_i != 0 || !(w->imu[b].sum_dt < 10.0)) continue;
+        uvs_imu_block ib = w->imu[b]; ib.skip = 0; M.imu.push_back(ib);
+        used[0] = used[NFR] = used[1] = used[NFR + 1] = true;
+    }
+    M.pmap.assign(std::max(w->n_points, 1), -1); M.lmap.assign(std::max(w->n_lines, 1), -1); M.lstart.assign(std::max(w->n_lines, 1), -1);
+    M.pt_lm.clear(); M.pt_fi.clear(); M.pt_fj.clear(); M.pt_pi.clear(); M.pt_pj.clear(); M.pt_vi.clear(); M.pt_vj.clear(); M.pt_tdi.clear(); M.pt_tdj.clear(); M.invd.clear();
+    for (int k = 0; k < w->n_point_obs; ++k) {
+        if (w->pt_fi[k] != 0) continue;
+        const int lm = w->pt_lm[k];
+        if (M.pmap[lm] < 0) { M.pmap[lm] = (int)M.invd.size(); M.invd.push_back(w->inv_depth[lm]); }
+        M.pt_lm.push_back(M.pmap[lm]); M.pt_fi.push_back(0); M.pt_fj.push_back(w->pt_fj[k]);
+        for (int q = 0; q < 3; ++q) { M.pt_pi.push_back(w->pt_pi[3 * k + q]); M.pt_pj.push_back(w->pt_pj[3 * k + q]); }
+        if (td_on) { for (int q = 0; q < 2; ++q) { M.pt_vi.push_back(w->pt_vel_i[2 * k + q]); M.pt_vj.push_back(w->pt_vel_j[2 * k + q]); } M.pt_tdi.push_back(w->pt_td_i[k]); M.pt_tdj.push_back(w->pt_td_j[k]); }
+        used[0] = used[w->pt_fj[k]] = used[22] = true; if (td_on) used[23] = true;
+    }
+    M.ln_lm.clear(); M.ln_fj.clear(); M.ln_vpf.clear(); M.ln_sp.clear(); M.ln_ep.clear(); M.ln_vp.clear(); M.lorth.clear();
+    for (int k = 0; k < w->n_line_obs; ++k) if (M.lstart[w->ln_lm[k]] < 0) M.lstart[w->ln_lm[k]] = w->ln_fj[k];
+    for (int k = 0; k < w->n_line_obs; ++k) {
+        const int lm = w->ln_lm[k], fj = w->ln_fj[k];
+        if (M.lstart[lm] != 0 || fj == 0) continue;      // lines that start in frame 0, without the anchor observation (estimator.cpp:1102-1104)
+        if (M.lmap[lm] < 0) { M.lmap[lm] = (int)(M.lorth.size() / 4); for (int q = 0; q < 4; ++q) M.lorth.push_back(w->line_orth[4 * lm + q]); }
+        M.ln_lm.push_back(M.lmap[lm]); M.ln_fj.push_back(fj); M.ln_vpf.push_back(w->ln_has_vp[k] ? 1 : 0);
+        for (int q = 0; q < 3; ++q) { M.ln_sp.push_back(w->ln_sp[3 * k + q]); M.ln_ep.push_back(w->ln_ep[3 * k + q]); M.ln_vp.push_back(w->ln_vp[3 * k + q]); }
+        used[fj] = true;
+    }
+    if (M.imu.empty() && M.pt_lm.empty() && M.ln_lm.empty() && !have_prior) return kMargFallback;
+    uvs_window sub; std::memset(&sub, 0, sizeof(sub));
+    std::memcpy(sub.pose, w->pose, sizeof(sub.pose)); std::memcpy(sub.speedbias, w->speedbias, sizeof(sub.speedbias)); std::memcpy(sub.ex_pose, w->ex_pose, sizeof(sub.ex_pose));
+    sub.td = w->td; for (int q = 0; q < 7; ++q) sub.relo_pose[q] = q == 6 ? 1.0 : 0.0;
+    sub.n_points = (int)M.invd.size(); sub.n_point_obs = (int)M.pt_lm.size(); sub.inv_depth = M.invd.data();
+    sub.pt_lm = M.pt_lm.data(); sub.pt_fi = M.pt_fi.data(); sub.pt_fj = M.pt_fj.data(); sub.pt_pi = M.pt_pi.data(); sub.pt_pj = M.pt_pj.data();
+    if (td_on) { sub.pt_vel_i = M.pt_vi.data(); sub.pt_vel_j = M.pt_vj.data(); sub.pt_td_i = M.pt_tdi.data(); sub.pt_td_j = M.pt_tdj.data(); }
+    sub.n_lines = (int)(M.lorth.size() / 4); sub.n_line_obs = (int)M.ln_lm.size(); sub.line_orth = M.lorth.data();
+    sub.ln_lm = M.ln_lm.data(); sub.ln_fj = M.ln_fj.data(); sub.ln_has_vp = M.ln_vpf.data(); sub.ln_sp = M.ln_sp.data(); sub.ln_ep = M.ln_ep.data(); sub.ln_vp = M.ln_vp.data();
+    sub.n_imu = (int)M.imu.size(); sub.imu = M.imu.data(); sub.prior = have_prior ? w->prior : nullptr;
+    // ---- pack with a FREE extrinsic (the prior keeps para_Ex_Pose), upload, one linearization
+    uvs_options o = s->opts; o.estimate_extrinsic = 1; o.initial_trust_region_radius = 1e300;
+    DevWin h; M.blob.clear();
+    const auto tp0 = std::chrono::steady_clock::now();
+    int rc = pack_window(&sub, o, M.blob, h, s->err);
+    const auto tp1 = std::chrono::steady_clock::now();
+    if (rc == UVS_ERR_UNSUPPORTED || rc == UVS_ERR_CAPACITY) return kMargFallback;
+    if (rc != UVS_OK) return rc;
+    HIPCHK(s, hipSetDevice(s->device));
+    const auto ens = [&](void** p, size_t* cap, size_t need) -> int { if (*cap >= need) return UVS_OK; if (*p) (void)hipFree(*p); *p = nullptr; *cap = 0; HIPCHK(s, hipMalloc(p, need + need / 2)); *cap = need + need / 2; return UVS_OK; };
+    if ((rc = ens((void**)&M.d_blob, &M.d_blob_cap, M.blob.size())) != UVS_OK) return rc;
+    if ((rc = ens((void**)&M.d_ws, &M.d_ws_cap, (size_t)h.ws_doubles * 8)) != UVS_OK) return rc;
+    if (!M.d_out) HIPCHK(s, hipMalloc((void**)&M.d_out, MARG_OUT * 8));
+    if (!M.h_out) { HIPCHK(s, hipHostMalloc((void**)&M.h_out, MARG_OUT * 8, hipHostMallocDefault)); M.h_out_cap = MARG_OUT * 8; }
+    if ((rc = ensure_pinned(s, &M.h_up, &M.h_up_cap, M.blob.size())) != UVS_OK) return rc;
+    HIPCHK(s, hipStreamSynchronize(s->stream));      // the staging buffer may still feed the previous call's copy
+    std::memcpy(M.h_up, M.blob.data(), M.blob.size());
+    HIPCHK(s, hipMemcpyAsync(M.d_blob, M.h_up, M.blob.size(), hipMemcpyHostToDevice, s->stream));
+    const KOpts ko = make_kopts(o, 0);
+    hipLaunchKernelGGL(k_marg_linearize, dim3(1), dim3(NT), LDS_BYTES, s->stream, M.d_blob, M.d_ws, ko, M.d_out);
+    HIPCHK(s, hipGetLastError());
+    HIPCHK(s, hipMemcpyAsync(M.h_out, M.d_out, MARG_OUT * 8, hipMemcpyDeviceToHost, s->stream));
+    HIPCHK(s, hipStreamSynchronize(s->stream));
+    const auto t1 = std::chrono::steady_clock::now();
+    if (prof) { auto us = [](auto a_, auto b_) { return (double)std::chrono::duration_cast<std::chrono::nanoseconds>(b_ - a_).count() * 1e-3; };
+                std::fprintf(stderr, "[uvs_marginalize] device path: sub-window %.0f us, pack %.0f us (%zu bytes), upload + kernel + download %.0f us\n", us(t0, tp0), us(tp0, tp1), M.blob.size(), us(tp1, t1)); }
+    const double* S = (const double*)M.h_out; const double* g = S + UVS_RD * (UVS_RD + 1) / 2; const double* scal = g + UVS_RD;
+    if (scal[1] != 0.0 || !std::isfinite(scal[0])) return kMargFallback;      // a landmark block the reference's eps cut would touch: the host path applies that cut
+    // ---- ordering: the dropped frame blocks (Pose[0], SpeedBias[0]) first, then the kept ones in id order
+    auto lsize = [&](int id) { return id < NFR ? 6 : id < 2 * NFR ? 9 : id == 22 ? 6 : 1; };
+    auto pad = [&](int id, int q) { return id < NFR ? 16 * id + q : id < 2 * NFR ? 16 * (id - NFR) + 6 + q : id == 22 ? UVS_EX_INDEX(q) : UVS_TD_INDEX; };
+    std::vector<int> pos(24, -1), keep_ids;
+    int md = 0;
+    for (int id : {0, NFR}) if (used[id]) { pos[id] = md; md += lsize(id); }
+    int N = md;
+    for (int id = 0; id < 24; ++id) if (used[id] && id != 0 && id != NFR) { pos[id] = N; N += lsize(id); keep_ids.push_back(id); }
+    const int n = N - md;
+    if (n > UVS_MAX_PRIOR_DIM || (int)keep_ids.size() > UVS_MAX_PRIOR_BLOCKS) { s->err = "prior capacity"; return UVS_ERR_CAPACITY; }
+    if (md == 0 || n == 0) return kMargFallback;
+    std::vector<double>&A = s->eval_scratch.work[0], &bv = s->eval_scratch.work[1];
+    A.assign((size_t)N * N, 0.0); bv.assign(N, 0.0);
+    for (int a = 0; a < 24; ++a) {
+        if (pos[a] < 0) continue;
+        for (int qa = 0; qa < lsize(a); ++qa) {
+            const int ia = pad(a, qa);
+            bv[pos[a] + qa] = g[ia];
+            for (int b = 0; b < 24; ++b) {
+                if (pos[b] < 0) continue;
+                for (int qb = 0; qb < lsize(b); ++qb) { const int ib = pad(b, qb); const int hi = ia >= ib ? ia : ib, lo = ia >= ib ? ib : ia; A[(size_t)(pos[a] + qa) * N + pos[b] + qb] = S[(size_t)hi * (hi + 1) / 2 + lo]; }
+            }
+        }
+    }
+    double us_pre[3] = {(double)std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count() * 1e-3, 0.0, 0.0};
+    marg_finish(N, md, md, n, A, bv, pos, keep_ids, w, 0, out, s->eval_scratch, prof, us_pre);
+    return UVS_OK;
+}
+
 extern "C" {
 
 int uvs_batch_upload(uvs_solver* s, int n, const uvs_window* const* ws) { return upload_windows(s, n, ws, true); }
@@ -1108,6 +1240,7 @@ int uvs_evaluate(uvs_solver* s, const uvs_window* w, int robust, uvs_eval* out) 
 
 int uvs_marginalize(uvs_solver* s, const uvs_window* w, int flag, uvs_prior* out) {
     if (!s || !w || !out || (flag != 0 && flag != 1)) return UVS_ERR_INVALID_ARG;
+    if (flag == 0) { const int rd = marginalize_old_device(s, w, out); if (rd != kMargFallback) return rd; }
     const uvs_window* arr[1] = {w};
     const auto tu0 = std::chrono::steady_clock::now();
     int rc = uvs_batch_upload(s, 1, arr);
@@ -1125,6 +1258,7 @@ int uvs_marginalize_resident(uvs_solver* s, const uvs_window* w, int flag, uvs_p
     if (h.n_points != w->n_points || h.n_pt_obs - h.n_relo != w->n_point_obs || h.n_lines != w->n_lines || h.n_ln_obs != w->n_line_obs || h.n_imu != w->n_imu || h.prior_n != pn) {
         s->err = "uvs_marginalize_resident: the window does not match the resident one"; return UVS_ERR_INVALID_ARG;
     }
+    if (flag == 0) { const int rd = marginalize_old_device(s, w, out); if (rd != kMargFallback) return rd; }      // (needs nothing of the resident blob: the factors of frame 0 travel as a window of their own)
     HIPCHK(s, hipSetDevice(s->device));
     // state sections of the resident blob: frames[184] = pose | speedbias | ex_pose | td, inverse depths, line parameters
     // staged in the pinned upload buffer (copies from the caller's pageable arrays would each be a synchronous staging round trip)
