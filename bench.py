@@ -79,6 +79,35 @@ def algorithmic_flops(w, n_iterations):
     return (1 + n_iterations) * lin + n_iterations * cost_only
 
 
+def project_large_window(measured_n):
+    """UNMEASURED projection of the configs[3] LM iteration on 2 / 4 / 8 GPUs from the per-kernel times of the committed 1-GPU rocprofv3 trace
+    (profiles/r03_kernel_stats_large.csv): the landmark-sharded kernels divide by N, the reduced solve and the trust-region step are replicated, and every
+    iteration pays two in-place RCCL all-reduces (40 KB and 64 B: latency bound, 15 us each ASSUMED -- no multi-GPU node was available to measure them)."""
+    path = os.path.join(ROOT, "profiles", "r03_kernel_stats_large.csv")
+    if not os.path.exists(path):
+        return None
+    import csv
+    avg = {}
+    for row in csv.DictReader(open(path)):
+        for key in ("k_large_chunks", "k_large_backsub", "k_large_reduce", "k_large_solve", "k_large_decide"):
+            if "uvsdev::" + key + "(" in row["Name"]:
+                avg[key] = float(row["AverageNs"]) * 1e-3
+    if len(avg) < 5:
+        return None
+    sharded = avg["k_large_chunks"] + avg["k_large_backsub"] + avg["k_large_reduce"]
+    replicated = avg["k_large_solve"] + avg["k_large_decide"]
+    allreduce_us = 15.0
+    out = {"status": "UNMEASURED projection from 1-GPU kernel times (profiles/r03_kernel_stats_large.csv); the all-reduce latency is an assumption",
+           "per_iteration_us_1gpu": {"sharded (chunks + backsub + reduce)": sharded, "replicated (reduced solve + decide)": replicated},
+           "assumed_allreduce_us_each": allreduce_us, "iteration_us": {}, "speedup_vs_1gpu": {}}
+    t1 = sharded + replicated
+    for n in (1, 2, 4, 8):
+        t = sharded / n + replicated + (2 * allreduce_us if n > 1 else 0.0)
+        out["iteration_us"][str(n)] = t; out["speedup_vs_1gpu"][str(n)] = t1 / t
+    out["measured_on_n_gpus"] = measured_n
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -205,6 +234,7 @@ def main():
                                   "peak": FP64_PEAK_TFLOPS * world, "unit": "TFLOP/s", "frac": fl / (lm * 1e-3) / 1e12 / (FP64_PEAK_TFLOPS * world),
                                   "algorithmic_flops_per_solve": fl, "algorithmic_bytes_per_solve": float(synth.algorithmic_bytes(wl)), "traffic": None,
                                   "note": "whole resident LM loop (all kernels + collectives) against N x the FP64 roof; SURVEY.md 8d flop model"}}
+            large["projected"] = project_large_window(world)
         sl.close()
 
     if rank == 0:
