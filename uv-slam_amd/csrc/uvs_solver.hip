@@ -620,7 +620,9 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
         // direct work) to the same wave, idle groups last
         std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b2) { return a.shape != b2.shape ? a.shape > b2.shape : a.work > b2.work; });
         int wave_of_rank[NW];
-        for (int r = 0; r < NW; ++r) wave_of_rank[r] = r < 4 ? r : NW - 1 - (r - 4);
+        // (identity: the parts of a split block must sit in CONSECUTIVE groups -- gacc_gather_parts addresses part p at lane + p * UVS_GLANES -- and a block may
+        // straddle two ranks; the round-2 order for 8 waves, heavy ranks paired with light ones on a SIMD, broke exactly that: the wrong pose blocks of the 512-thread builds)
+        for (int r = 0; r < NW; ++r) wave_of_rank[r] = r;
         h.n_parts = 1;
         for (int b = 0; b < UVS_NBLKX; ++b) h.n_parts = std::max(h.n_parts, np[b]);
         for (int g = 0; g < UVS_NGRP; ++g) { wblk[g] = -1; g_blk[g] = -1; g_part[g] = 0; g_np[g] = 1; }

@@ -22,7 +22,7 @@ void setEurocParameters() {          // config/euroc/euroc_config.yaml
     TIC.assign(1, Eigen::Vector3d(-0.0216401454975, -0.064676986768, 0.00981073058949));
 }
 
-Estimator::Estimator() : frame_count(0), first_imu(false), sum_of_back(0), sum_of_front(0), solver_flag(NON_LINEAR), marginalization_flag(MARGIN_OLD), td(0), failure_occur(false), last_marginalization_info(nullptr), relocalization_info(false), relo_frame_stamp(0), relo_frame_index(0), relo_frame_local_index(0), relo_relative_yaw(0), solver(nullptr) {
+Estimator::Estimator() : frame_count(0), first_imu(false), sum_of_back(0), sum_of_front(0), solver_flag(NON_LINEAR), marginalization_flag(MARGIN_OLD), td(0), failure_occur(false), last_marginalization_info(nullptr), relocalization_info(false), relo_frame_stamp(0), relo_frame_index(0), relo_frame_local_index(0), relo_relative_yaw(0), solver(nullptr), eval_solver(nullptr) {
     f_manager.Rs = Rs;      // estimator.cpp:9 `f_manager{Rs}`
     for (auto& p : pre_integrations) p = nullptr;
     for (int i = 0; i <= WINDOW_SIZE; ++i) Rs[i].setIdentity();
@@ -30,9 +30,14 @@ Estimator::Estimator() : frame_count(0), first_imu(false), sum_of_back(0), sum_o
     o.estimate_td = ESTIMATE_TD; o.estimate_extrinsic = ESTIMATE_EXTRINSIC != 0;      // fixed for the lifetime of the handle, like the reference's globals (parameters.cpp)
     const int rc = uvs_create(&o, 0, 1, NUM_OF_F, NUM_OF_F * (WINDOW_SIZE + 1), NUM_OF_LF, NUM_OF_LF * (WINDOW_SIZE + 1), &solver);
     if (rc != UVS_OK) throw std::runtime_error(std::string("uvs_create: ") + uvs_status_string(rc));     // no CPU fallback
-    if (!uvs::evaluation_solver()) uvs::set_evaluation_solver(solver);      // the factor classes' per-block Evaluate() runs on this handle unless another was registered
+    // The factor classes' per-block Evaluate() gets a handle of its OWN (one-block windows): a call between the solve and the marginalization of optimization()
+    // would otherwise replace the window that uvs_marginalize_resident() expects to find on the solver's handle.
+    if (!uvs::evaluation_solver() && uvs_create(&o, 0, 1, 8, 16, 8, 16, &eval_solver) == UVS_OK) uvs::set_evaluation_solver(eval_solver);
 }
-Estimator::~Estimator() { if (uvs::evaluation_solver() == solver) uvs::set_evaluation_solver(nullptr); uvs_destroy(solver); delete last_marginalization_info; for (auto* p : pre_integrations) delete p; }
+Estimator::~Estimator() {
+    if (eval_solver) { if (uvs::evaluation_solver() == eval_solver) uvs::set_evaluation_solver(nullptr); uvs_destroy(eval_solver); }
+    uvs_destroy(solver); delete last_marginalization_info; for (auto* p : pre_integrations) delete p;
+}
 
 // ---- small helpers of this file: a 7-double parameter block (px py pz qx qy qz qw, estimator.cpp:530-537) <-> (translation, rotation)
 namespace {

@@ -86,6 +86,7 @@ class Estimator {
     double relo_relative_yaw;
     // the reference keeps a vector<double*> of the prior's parameter blocks; here the block table lives inside uvs_prior
     uvs_solver* solver;          // HIP back-end handle (created in the constructor; throws when no GPU is present)
+    uvs_solver* eval_solver;     // second, small handle for the factor classes' per-block Evaluate() (registered with uvs::set_evaluation_solver unless one is registered already)
     uvs::Summary last_summary;   // kept for diagnostics (the reference discards ceres::Solver::Summary)
     uvs::SolverPath solver_path = uvs::AUTO;      // which single-window form optimization() calls (window_assembly.h)
     // wall-clock spent inside optimization() (sums over the calls): whole call, uvs::Solve() alone, marginalization alone
