@@ -259,7 +259,7 @@ UVS_DEV double cost_pass(const Ctx& c, const double* x, const double* invd, cons
     const double* ltrig = line_trig_of(c, line);
     double cost = 0.0;
     long long tq_ = clock64();
-#define UVS_CQ(slot) if (c.o.debug && tid == 0) { const long long t_ = clock64(); c.sh[L_WPROF + slot] += (double)(t_ - tq_); tq_ = t_; }
+#define UVS_CQ(slot) if (c.o.debug == 1 && tid == 0) { const long long t_ = clock64(); c.sh[L_WPROF + slot] += (double)(t_ - tq_); tq_ = t_; }
     // Observations in batches of four per lane: the index loads and the measurement loads of a batch go out together and the
     // landmark parameters (the only loads whose address depends on an index) follow as a second group, so a lane pays two HBM/L2
     // round trips per BATCH instead of two per observation (one wave per SIMD: nothing else hides that latency).
@@ -380,8 +380,10 @@ UVS_DEV double rcp_newton(double x) {
 //   S3  the panel L_ik = S_ik W^T (and the rhs row y_k = b_k W^T) is 4 MFMAs per block instead of a 16-step substitution.
 // C/D layout of the f64 MFMA: row = (lane >> 4) + 4 * reg, col = lane & 15;  A[i][k]: lane i + 16k;  B[k][j]: lane j + 16k.
 struct MiniCtx { double* sh; struct { int debug; } o; };      // what UVS_PROF needs inside the dense-solve phases
+template <bool TR = false>
 UVS_DEV void chol_update_item(double* sh, int i, int cc, int j0, int j1, int lane, d4_t& acc) {
-    // acc -= sum_{j in [j0, j1)} L_ij L_cj^T   (i == UVS_NF: the right-hand-side row, y_j^T in L_DLT)
+    // acc -= sum_{j in [j0, j1)} L_ij L_cj^T   (i == UVS_NF: the right-hand-side row, y_j^T in L_DLT);  TR: acc -= sum L_cj L_ij^T, the TRANSPOSED
+    // block (the two MFMA operands have the same load pattern, so transposing the product is swapping them)
     const int li = lane & 15, lk = lane >> 4;
     const bool rhs = (i == UVS_NF);
     const double* Bj = sblk(sh, cc, j0) + li * UVS_BLK_LD + lk;
@@ -397,7 +399,7 @@ UVS_DEV void chol_update_item(double* sh, int i, int cc, int j0, int j1, int lan
     // compiler shuttle it between AGPRs and VGPRs across the loop back-edge (a pipeline drain plus 16 moves every other term).
     double a0[4], b0[4], a1[4], b1[4];
 #define UVS_CH_LOAD(AV, BV) { _Pragma("unroll") for (int q = 0; q < 4; ++q) { AV[q] = Ai[4 * q]; BV[q] = Bj[4 * q]; } Bj += UVS_BLK_SZ; Ai += astep; }
-#define UVS_CH_MFMA(AV, BV) { _Pragma("unroll") for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(AV[q], BV[q], acc, 0, 0, 1); }
+#define UVS_CH_MFMA(AV, BV) { _Pragma("unroll") for (int q = 0; q < 4; ++q) acc = TR ? __builtin_amdgcn_mfma_f64_16x16x4f64(BV[q], AV[q], acc, 0, 0, 1) : __builtin_amdgcn_mfma_f64_16x16x4f64(AV[q], BV[q], acc, 0, 0, 1); }
     UVS_CH_LOAD(a0, b0)
     for (int j = j0;;) {
         if (j + 1 < j1) UVS_CH_LOAD(a1, b1)
@@ -423,6 +425,20 @@ UVS_DEV d4_t chol_load_item(double* sh, int i, int cc, int lane) {
         const double* Cb = sblk(sh, i, cc) + lk * UVS_BLK_LD + li;
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc[q] = Cb[4 * q * UVS_BLK_LD];
+    }
+    return acc;
+}
+// S(i, cc)^T in the C layout = S(i, cc) in the A-operand layout of the panel product (register q: row li, column lk + 4q)
+UVS_DEV d4_t chol_load_item_t(double* sh, int i, int cc, int lane) {
+    const int li = lane & 15, lk = lane >> 4;
+    d4_t acc;
+    if (i != UVS_NF) {
+        const double* Ai = sblk(sh, i, cc) + li * UVS_BLK_LD + lk;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = Ai[4 * q];
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const double yv = sh[L_DLT + 16 * cc + 4 * q + lk]; acc[q] = (li == 0) ? yv : 0.0; }
     }
     return acc;
 }
@@ -465,6 +481,12 @@ UVS_DEV void chol_panel_item(double* sh, int i, int k, int lane, const double* B
     for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], Bw[q], acc, 0, 0, 0);
     chol_store_item(sh, i, k, lane, acc);
 }
+UVS_DEV void chol_panel_from(double* sh, int i, int k, int lane, const double* Bw, const d4_t& av) {      // av = chol_load_item_t layout
+    d4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], Bw[q], acc, 0, 0, 0);
+    chol_store_item(sh, i, k, lane, acc);
+}
 UVS_DEV void chol_panel_operand(double* sh, int k, int lane, double* Bw) {      // W_k[c][m]: strictly-upper slot (m, c) of the diagonal block, 1/L_cc on the diagonal
     const int li = lane & 15, lk = lane >> 4;
     const double* Dk = sblk(sh, k, k);
@@ -492,37 +514,67 @@ UVS_DEV void chol_factor_impl(double* sh, int debug) {
     UVS_PROF(c, P_MISC);
     constexpr int nwork = NW - 1;
     const int wrk = wv - 1;
+    long long tend_ = 0;
+    d4_t Lt = {0.0, 0.0, 0.0, 0.0};      // wave 0: L(k, k-1)^T, the panel result of the previous column, = both operands of the diagonal block's last term
     for (int k = 0; k < UVS_NF; ++k) {
         double* Dk = sblk(sh, k, k);
         __syncthreads();
         const long long tw0_ = debug ? clock64() : 0;
+        long long tl_ = tw0_;
+#define UVS_TL(slot) if (debug == 4 && lane == 0) { const long long t_ = clock64(); sh[L_WPROF + slot] += (double)(t_ - tl_); tl_ = t_; }
+        if (debug == 4 && tid == 0 && k > 0) sh[L_WPROF + 7] += (double)(tw0_ - tend_);
         if (wv == 0) {
             // ---- A: last term (j = k-1) of the diagonal block (kept in MFMA registers) and of the block below it
             d4_t dacc = chol_load_item(sh, k, k, lane);
-            if (k > 0) chol_update_item(sh, k, k, k - 1, k, lane, dacc);
+            if (k > 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dacc = __builtin_amdgcn_mfma_f64_16x16x4f64(Lt[q], Lt[q], dacc, 0, 0, 1);
+            }
             // ---- S2: the diagonal block factored in registers (L -> lower triangle, W^T -> strictly upper, 1/L_jj -> L_DINV)
             d4_t T;
+            UVS_TL(0)
 #pragma unroll
             for (int q = 0; q < 4; ++q) T[q] = (lk + 4 * q == li) ? 1.0 : 0.0;
-            double us_prev = 0.0;
+            double ap_prev = 0.0;
             double pivs[4] = {1.0, 1.0, 1.0, 1.0};      // pivs[q] = pivot of row lk + 4q (this lane's row of register q)
+            // TWO pivots per link of the chain.  Rows j and j + 1 (j even) are k-slots s0 = j & 3 and s0 + 1 of register j >> 2, so the elimination of
+            // the 2 x 2 pivot block is ONE rank-2 MFMA whose A operand holds, for every row c below the block,
+            //     u1[c] = -a'[j+1][c] / d2                       a'[j+1][.] = a[j+1][.] - l10 a[j][.]   (row j + 1 after pivot j),  d2 = a'[j+1][j+1]
+            //     u0[c] = -a[j][c] / a00 - u1[c] l10             l10 = a[j+1][j] / a00
+            // i.e. exactly the two sequential eliminations composed (no 2 x 2 determinant: same stability as one pivot at a time), and for
+            // c = j + 1 the plain multiplier -l10, so that row j + 1 leaves the MFMA as a'[j+1][.], the row the factor needs.  An FP64 MFMA blocks
+            // the wave's FP64 VALU for its 64 cycles (the units are shared), so a link costs its MFMAs PLUS its scalar chain: 336 cycles per
+            // pair against 2 x 230 (tools/micro_chain.hip variants 0 / 6; results equal to 7e-16).  Both rows are made visible in both of their
+            // 16-lane rows by v_permlane16_swap; the inverse's elimination trails by one link as before.
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int reg = j >> 2, slot = j & 3;
-                const double piv = bcast_lane(dacc[reg], 16 * slot + j);
-                // the inverse's elimination trails the factor's by one pivot, so its MFMA never sits between an MFMA result and the
-                // readlane that needs it (B operands need no masks: A is zero outside k-slot `slot` and outside rows > j)
-                if (j > 0) T = __builtin_amdgcn_mfma_f64_16x16x4f64(us_prev, T[(j - 1) >> 2], T, 0, 0, 0);
-                const double m = (lk == slot && li > j) ? dacc[reg] : 0.0;   // a[j][c], c > j, at lane 16*slot + c (symmetric => column j)
-                // us = -m / piv on the serial chain: hardware seed y0 (2^-24) and one third-order correction, 1/piv = y0 (1 + e + e^2) with
-                // e = 1 - piv y0, arranged so that the seed-only product -m y0 runs beside the error term: rcp -> e -> e + e^2 -> us
-                const double y0 = __builtin_amdgcn_rcp(piv);
-                const double e = fma(-piv, y0, 1.0), us0 = -m * y0;
-                const double us = fma(us0, fma(e, e, e), us0);
-                if (lk == slot) pivs[reg] = piv;
-                dacc = __builtin_amdgcn_mfma_f64_16x16x4f64(us, dacc[reg], dacc, 0, 0, 0);
-                us_prev = us;
+            for (int j = 0; j < 16; j += 2) {
+                const int reg = j >> 2, s0 = j & 3, s1 = s0 + 1;
+                const double a00 = bcast_lane(dacc[reg], 16 * s0 + j), a10 = bcast_lane(dacc[reg], 16 * s0 + j + 1), a11 = bcast_lane(dacc[reg], 16 * s1 + j + 1);
+                if (j > 0) T = __builtin_amdgcn_mfma_f64_16x16x4f64(ap_prev, T[(j - 2) >> 2], T, 0, 0, 0);
+                const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(dacc[reg]), __double2loint(dacc[reg]), false, false);
+                const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(dacc[reg]), __double2hiint(dacc[reg]), false, false);
+                const double rj = __hiloint2double(hi[0], lo[0]), rj1 = __hiloint2double(hi[1], lo[1]);      // a[j][c], a[j+1][c] at column c = li (lanes of rows s0, s1)
+                // 1 / a00: hardware seed y0 (2^-24) and one third-order correction 1 / x = y0 (1 + e + e^2), e = 1 - x y0, arranged so that the
+                // seed-only products run beside the error term
+                const double y0 = __builtin_amdgcn_rcp(a00);
+                const double e0 = fma(-a00, y0, 1.0), l0 = a10 * y0, w0s = -rj * y0;
+                const double p0 = fma(e0, e0, e0);
+                const double l10 = fma(l0, p0, l0), w0 = fma(w0s, p0, w0s);
+                const double d2 = fma(-l10, a10, a11);
+                const double t = fma(-l10, rj, rj1);
+                const double y1 = __builtin_amdgcn_rcp(d2);
+                const double e1 = fma(-d2, y1, 1.0), u1s = -t * y1;
+                const double p1 = fma(e1, e1, e1);
+                double u1 = fma(u1s, p1, u1s);
+                u1 = (li > j + 1) ? u1 : 0.0;
+                const double u0 = fma(-u1, l10, w0);
+                const double ap = (lk == s0) ? ((li > j) ? u0 : 0.0) : ((lk == s1) ? u1 : 0.0);
+                if (lk == s0) pivs[reg] = a00;
+                if (lk == s1) pivs[reg] = d2;
+                dacc = __builtin_amdgcn_mfma_f64_16x16x4f64(ap, dacc[reg], dacc, 0, 0, 0);
+                ap_prev = ap;
             }
+            T = __builtin_amdgcn_mfma_f64_16x16x4f64(ap_prev, T[3], T, 0, 0, 0);      // row 15 of W: the multiplier -l10 of the last pair
             // square roots + scaling, lane-parallel and off the chain: register q of this lane belongs to row j = lk + 4q
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -532,28 +584,60 @@ UVS_DEV void chol_factor_impl(double* sh, int debug) {
                 if (li == j) { sh[L_DINV + 16 * k + j] = inv; if (!(pivs[q] > 0.0)) sh[L_CTRL + C_CHOLOK] = 0.0; }
             }
             if (lane == 0) __hip_atomic_store(flg + k, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            UVS_TL(1)
             // ---- S3 for the block below the diagonal (the right-hand-side row for the last column); its last term was the first thing
             // the lightest worker did in this column, 4 k cycles ago
             if (k > 0) while (__hip_atomic_load(flg + 16 + k, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(1);
+            UVS_TL(2)
+            // the product TRANSPOSED, L(k+1, k)^T = W_k S(k+1, k)^T (operands swapped): its C layout is the operand layout of the next
+            // column's first four MFMAs, which therefore need no LDS round trip on the critical path
             double Bw[4]; chol_panel_operand(sh, k, lane, Bw);
-            chol_panel_item(sh, k + 1, k, lane, Bw);
+            {
+                const d4_t av = chol_load_item_t(sh, k + 1, k, lane);
+                Lt = d4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) Lt = __builtin_amdgcn_mfma_f64_16x16x4f64(Bw[q], av[q], Lt, 0, 0, 0);
+                if (k + 1 < UVS_NF) {
+                    double* Lb = sblk(sh, k + 1, k) + li * UVS_BLK_LD + lk;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) Lb[4 * q] = Lt[q];
+                } else if (li == 0) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) sh[L_DLT + 16 * k + lk + 4 * q] = Lt[q];
+                }
+            }
+            UVS_TL(3)
+            tend_ = tl_;
             if (debug == 1 && lane == 0) sh[L_WPROF + 4] += (double)(clock64() - tw0_);
         } else {
-            // ---- A: last term of this wave's rows of column k;  LA: terms j < k of column k + 1 (all rows, the diagonal block included)
+            // ---- A: last term of this wave's rows of column k, TRANSPOSED and kept in registers (= the A operand of the panel product: no
+            // store / reload between the two);  LA: terms j < k of column k + 1 (all rows, the diagonal block included), rows dealt in the
+            // opposite worker order so that the worker with the most rows of column k has the fewest look-ahead items
+            d4_t hold[3];
+            static_assert((UVS_NF - 2 + nwork - 1) / nwork <= 3, "rows of a column (k > 0) per worker");
             if (k > 0) {
-                if (wrk == nwork - 1) {      // the last worker has the fewest rows: it takes the block below the diagonal (whose panel solve is wave 0's) first
+                // the lightest worker takes the block below the diagonal (whose panel solve is wave 0's) first
+                int light = 0, best = 1 << 30;
+#pragma unroll
+                for (int w = 0; w < nwork; ++w) {
+                    const int na = UVS_NF - k - 1 - w, nl = (k + 1 < UVS_NF) ? UVS_NF - k - (nwork - 1 - w) : 0;
+                    const int ca = na > 0 ? (na + nwork - 1) / nwork : 0, cl = nl > 0 ? (nl + nwork - 1) / nwork : 0;
+                    const int load = ca * 17 + cl * (5 + 4 * k);      // in units of one MFMA (64 cycles): item overheads ~5, a term 4, a panel product ~8
+                    if (load < best) { best = load; light = w; }
+                }
+                if (wrk == light) {
                     d4_t acc = chol_load_item(sh, k + 1, k, lane);
                     chol_update_item(sh, k + 1, k, k - 1, k, lane, acc);
                     chol_store_item(sh, k + 1, k, lane, acc);
                     if (lane == 0) __hip_atomic_store(flg + 16 + k, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
-                for (int i = k + 2 + wrk; i <= UVS_NF; i += nwork) {
-                    d4_t acc = chol_load_item(sh, i, k, lane);
-                    chol_update_item(sh, i, k, k - 1, k, lane, acc);
-                    chol_store_item(sh, i, k, lane, acc);
+#pragma unroll
+                for (int n = 0; n < 3; ++n) {
+                    const int i = k + 2 + wrk + n * nwork;
+                    if (i <= UVS_NF) { hold[n] = chol_load_item_t(sh, i, k, lane); chol_update_item<true>(sh, i, k, k - 1, k, lane, hold[n]); }
                 }
                 if (k + 1 < UVS_NF) {
-                    for (int i = k + 1 + wrk; i <= UVS_NF; i += nwork) {
+                    for (int i = k + 1 + (nwork - 1 - wrk); i <= UVS_NF; i += nwork) {
                         d4_t acc = chol_load_item(sh, i, k + 1, lane);
                         chol_update_item(sh, i, k + 1, 0, k, lane, acc);
                         chol_store_item(sh, i, k + 1, lane, acc);
@@ -562,9 +646,17 @@ UVS_DEV void chol_factor_impl(double* sh, int debug) {
             }
             if (debug == 1 && lane == 0) sh[L_WPROF + 4 + wv] += (double)(clock64() - tw0_);
             // ---- S3: panel of this wave's rows, once the diagonal wave has published W_k
+            if (wv == 1) UVS_TL(4)
             while (__hip_atomic_load(flg + k, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(1);
+            if (wv == 1) UVS_TL(5)
             double Bw[4]; chol_panel_operand(sh, k, lane, Bw);
-            for (int i = k + 2 + wrk; i <= UVS_NF; i += nwork) chol_panel_item(sh, i, k, lane, Bw);
+            if (k > 0) {
+#pragma unroll
+                for (int n = 0; n < 3; ++n) { const int i = k + 2 + wrk + n * nwork; if (i <= UVS_NF) chol_panel_from(sh, i, k, lane, Bw, hold[n]); }
+            } else {
+                for (int i = 2 + wrk; i <= UVS_NF; i += nwork) chol_panel_item(sh, i, k, lane, Bw);
+            }
+            if (wv == 1) UVS_TL(6)
         }
         UVS_PROF(c, P_CH_DIAG);
     }
@@ -1994,9 +2086,9 @@ __global__ __launch_bounds__(NT) void k_solve(char* blobs, const long long* blob
         stage_rotations(c, sh + L_XC);
         prior_dx(c, sh + L_XC);
         __syncthreads();
-        if (o.debug && tid == 0) { const long long t_ = clock64(); sh[L_WPROF + 0] += (double)(t_ - tc_); tc_ = t_; }
+        if (o.debug == 1 && tid == 0) { const long long t_ = clock64(); sh[L_WPROF + 0] += (double)(t_ - tc_); tc_ = t_; }
         double cc_ = prior_residual(c, L_PRC);
-        if (o.debug && tid == 0) { const long long t_ = clock64(); sh[L_WPROF + 1] += (double)(t_ - tc_); tc_ = t_; }
+        if (o.debug == 1 && tid == 0) { const long long t_ = clock64(); sh[L_WPROF + 1] += (double)(t_ - tc_); tc_ = t_; }
         cc_ += cost_pass(c, sh + L_XC, invd[cur ^ 1], line[cur ^ 1], 0, h.n_pt_obs, 0, h.n_ln_obs, true);
         double s4[4] = {cc_, 0, 0, 0}, mx = 0.0;
         block_reduce(sh, s4, &mx);

@@ -1220,7 +1220,7 @@ int uvs_debug_first_iteration(uvs_solver* s, const uvs_window* w, double* S_lowe
     const uvs_window* arr[1] = {w};
     int rc = uvs_batch_upload(s, 1, arr);
     if (rc != UVS_OK) return rc;
-    rc = launch_solve(s, std::getenv("UVS_DEBUG_GATHER_TIMERS") ? 2 : std::getenv("UVS_DEBUG_ASM_TIMERS") ? 3 : 1, nullptr);      // 2 / 3: the four per-wave timer slots carry the gather / the assembly's sub-steps instead of the Cholesky column phase
+    rc = launch_solve(s, std::getenv("UVS_DEBUG_GATHER_TIMERS") ? 2 : std::getenv("UVS_DEBUG_ASM_TIMERS") ? 3 : std::getenv("UVS_DEBUG_CHOL_TIMELINE") ? 4 : 1, nullptr);      // 2 / 3: the four per-wave timer slots carry the gather / the assembly's sub-steps instead of the Cholesky column phase
     if (rc != UVS_OK) return rc;
     const size_t nS = (size_t)UVS_RD * UVS_RD;
     if (S_lower) HIPCHK(s, hipMemcpy(S_lower, s->d_dbg, nS * 8, hipMemcpyDeviceToHost));
