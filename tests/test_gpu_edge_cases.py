@@ -87,6 +87,34 @@ def test_prior_from_the_products_own_marginalization(solver, oracle):
 
 
 @pytest.mark.parametrize("form", FORMS)
+def test_prior_that_keeps_the_speed_bias_of_a_later_frame(gpu_api, solver, oracle, form, monkeypatch):
+    """The reduced-system Cholesky pairs the rows of blocks (i, j), j < i - 1, because only the pose rows of such a block can be non-zero --
+    unless a prior couples the speed / bias of a frame >= 2 to an early frame, which the C ABI allows (the reference never builds one:
+    marginalization keeps para_SpeedBias[1] only, estimator.cpp:1010-1083).  Such a window takes the full-row path; same oracle parity.
+    And an ordinary window gives the same trace through both paths (UVS_CHOL_FULL_ROWS forces the full-row one)."""
+    w = synth.make_window(65, with_prior=True, marginalize_fn=lambda win, flag: solver.marginalize(win, flag)).copy()
+    p = w.prior.copy()
+    moved = [b for b in range(p.n_blocks) if p.block_kind[b] == abi.BLOCK_SPEEDBIAS]
+    assert moved
+    for b in moved: p.block_frame[b] = 3
+    x0 = np.ctypeslib.as_array(p.x0)
+    for b in moved: x0[p.x0_off[b]:p.x0_off[b] + 9] = w.speedbias[3]      # linearization point of the moved block: frame 3's state
+    w.prior = p
+    sg, rg = _solve(solver, w, form)
+    so, ro = oracle.solve(w)
+    _same_solution(sg, rg, so, ro)
+    w2 = synth.make_window(66, with_prior=True, marginalize_fn=lambda win, flag: solver.marginalize(win, flag))
+    s_half, r_half = _solve(solver, w2, form)
+    monkeypatch.setenv("UVS_CHOL_FULL_ROWS", "1")
+    s2 = gpu_api.Solver(max_batch=1)
+    s_full, r_full = _solve(s2, w2, form)
+    s2.close()
+    assert r_full.num_iterations == r_half.num_iterations and list(r_full.accepted[:11]) == list(r_half.accepted[:11])
+    assert abs(r_full.final_cost - r_half.final_cost) <= 1e-10 * r_half.final_cost
+    assert np.abs(s_full.pose - s_half.pose).max() < 1e-9
+
+
+@pytest.mark.parametrize("form", FORMS)
 def test_zero_and_one_iterations(gpu_api, oracle, form):
     w = synth.make_window(64)
     for n in (0, 1):

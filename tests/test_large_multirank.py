@@ -136,7 +136,9 @@ def test_fused_device_side_loop_equals_the_host_driven_one(gpu_api, comm):
     s.close()
     n = rep0.num_iterations
     assert rep1.num_iterations == n and list(rep1.accepted[:n + 1]) == list(rep0.accepted[:n + 1]) and rep1.termination == rep0.termination
-    assert np.allclose(np.array(rep1.radius[:n + 1]), np.array(rep0.radius[:n + 1]), rtol=1e-12)
+    # after the rejected steps the fused loop re-damps the stored linearization while the host-driven loop linearizes again: the reduced systems
+    # then differ in the last bits, the costs by ~1e-14, and the radius -- a function of the RATIO of two cost differences -- by ~1e-11
+    assert np.allclose(np.array(rep1.radius[:n + 1]), np.array(rep0.radius[:n + 1]), rtol=1e-9)
     assert np.allclose(np.array(rep1.cost[:n + 1]), np.array(rep0.cost[:n + 1]), rtol=1e-12)
     assert abs(rep1.final_cost - rep0.final_cost) <= 1e-12 * rep0.final_cost and rep1.initial_cost == rep0.initial_cost
     assert pose_deltas(st1.pose, st0.pose)[0] < 1e-12 and np.abs(st1.inv_depth - st0.inv_depth).max() < 1e-12

@@ -99,6 +99,7 @@ struct DevWin {
     int32_t cur_sel;                  // written by the kernel: which landmark buffer holds the final state
     int32_t max_chunk_doubles;        // LDS doubles the fullest chunk occupies in the staging area (records + Schur factors + lists; <= UVS_S_DOUBLES; informational)
     int32_t n_parts;                  // largest number of parts any pose block is split into (informational; gacc_gather_parts sums them in one step)
+    int32_t chol_half_ok;             // 1: blocks (i, j), j < i-1, of the reduced system are non-zero in rows {0..5, 15} only (true unless the prior keeps the speed / bias of a frame >= 2): the Cholesky pairs their rows
     int32_t redamp_ok;                // 1: k_solve may re-damp the last linearization after a rejected step instead of linearizing again (no pseudo-frame blocks; every line chunk has room for the tables)
 };
 

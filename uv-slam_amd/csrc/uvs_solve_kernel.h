@@ -368,16 +368,15 @@ UVS_DEV double rcp_newton(double x) {
 }
 
 // LEFT-LOOKING blocked Cholesky with one column of LOOK-AHEAD:  S = L L^T in place, and the right-hand side carried as block
-// row 11 (one real row), so L_DLT leaves as y = L^-1 rhs.
-// Per block column k (two workgroup barriers):
-//   A   apply the LAST term (j = k-1) to the blocks (i,k): wave 0 keeps the diagonal block in its MFMA registers, the other waves
-//       do the blocks below it (4 x v_mfma_f64_16x16x4_f64 each);
-//   S2  wave 0 factors the 16x16 diagonal block WITHOUT leaving the MFMA C layout: row j of the (symmetric) block lives in lanes
-//       16*(j&3).. of register j>>2, which is exactly k-slot (j&3) of the A/B operands, so pivot j is one readlane, one reciprocal
-//       and one rank-1 MFMA; a second MFMA per pivot runs the same elimination on the identity => W = L_kk^-1; square roots only after the chain;
-//   LA  meanwhile the other waves apply the terms j < k to block column k+1 (the look-ahead), which is what keeps the matrix cores
-//       busy while the pivot chain runs and leaves only ONE term for phase A of the next column;
-//   S3  the panel L_ik = S_ik W^T (and the rhs row y_k = b_k W^T) is 4 MFMAs per block instead of a 16-step substitution.
+// row 11 (one real row), so L_DLT leaves as y = L^-1 rhs.  Wave 0 owns the serial part, the other waves ("workers") everything else:
+//   wave 0, column k:  the diagonal block's last term (j = k-1) from the registers that still hold L(k, k-1)^T;  the 16 x 16 block factored
+//       WITHOUT leaving the MFMA C layout, two pivots per link (one rank-2 MFMA), a second MFMA per link running the same elimination on
+//       the identity => W = L_kk^-1; square roots only after the chain;  then the panel product of the block below, L(k+1, k)^T = W S(k+1, k)^T;
+//   workers, column k: last terms of the blocks (i, k), i >= k+2, kept in registers (transposed) until W_k is published, then their panel
+//       products L_ik = S_ik W^T (4 MFMAs instead of a 16-step substitution);  in between the LOOK-AHEAD: the terms j < k of block column k+1.
+//       Blocks (i, j), j < i-1, have non-zero rows {0..5, 15} only, so two of them share every MFMA (chol_hr below).
+//   No workgroup barrier inside the factorization (half-row path): LDS flags carry the four dependencies (W_k, S(k+1, k) complete, the next
+//       diagonal block's look-ahead complete, L(k+1, k) stored); the workers meet at an LDS counter.
 // C/D layout of the f64 MFMA: row = (lane >> 4) + 4 * reg, col = lane & 15;  A[i][k]: lane i + 16k;  B[k][j]: lane j + 16k.
 struct MiniCtx { double* sh; struct { int debug; } o; };      // what UVS_PROF needs inside the dense-solve phases
 template <bool TR = false>
@@ -456,6 +455,85 @@ UVS_DEV void chol_store_item(double* sh, int i, int cc, int lane, const d4_t& ac
     }
 }
 
+// ---- HALF-ROW PAIRS.  The speed / bias rows (6..14) of frame i couple to frames i-1, i, i+1 only (IMU blocks; a prior keeps the speed / bias of
+// frame 0 or 1), and in the frame-major elimination order no fill reaches them from an earlier frame: every neighbour of such a row lives in a
+// frame >= i-1, so no path through lower-numbered unknowns connects it to a column of a frame j < i-1.  Hence block (i, j), j < i-1, of S AND of L
+// is non-zero only in rows H = {0..5, 15} (pose + the spare slot), and EVERY term the workers apply -- L_ij L_cj^T with j <= c-1 <= i-2, the
+// diagonal block's look-ahead terms j < c-1 included -- touches rows H only.  Two such blocks of one block column therefore share a 16-row MFMA:
+// row x of the pair is row hr(x) of block (x < 8 ? i1 : i2); x = 6 and 7 both map to row 15 (the same value is computed and stored twice).
+// This halves the matrix-core time of the workers (look-ahead, last terms and panel products), which were as loaded as the pivot chain.
+// Host side: DevWin::chol_half_ok = 0 (a prior that keeps the speed / bias of a frame >= 2) selects the full-row path below.
+UVS_DEV int chol_hr(int x) { return ((x & 7) < 6) ? (x & 7) : 15; }
+// pair (i1, i2) of column cc in the A-operand layout (= transposed C layout): register q of lane (lk, li) = S(pair row li, column lk + 4q); never a diagonal block
+// RHS (the first pair of a list): pair row 7 -- otherwise a second copy of row 15 of block i1 -- is the right-hand-side row (L_DLT), which so rides along for free
+template <bool RHS>
+UVS_DEV d4_t chol_load_pair_t(double* sh, int i1, int i2, int cc, int lane) {
+    const int li = lane & 15, lk = lane >> 4;
+    const double* Ai = ((li < 8) ? sblk(sh, i1, cc) : sblk(sh, i2, cc)) + chol_hr(li) * UVS_BLK_LD + lk;
+    if (RHS && li == 7) Ai = sh + L_DLT + 16 * cc + lk;
+    d4_t acc;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = Ai[4 * q];
+    return acc;
+}
+// pair in the C layout: register q = pair row lk + 4q (q < 2: block i1, else i2), column li; a diagonal block (i1 == cc) is read through its lower triangle
+template <bool RHS>
+UVS_DEV d4_t chol_load_pair(double* sh, int i1, int i2, int cc, int lane) {
+    const int li = lane & 15, lk = lane >> 4;
+    d4_t acc;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int blk = q < 2 ? i1 : i2, r = chol_hr(lk + 4 * (q & 1));
+        const double* Cb = sblk(sh, blk, cc);
+        const int hi_ = r >= li ? r : li, lo_ = r >= li ? li : r;
+        const double* src = (blk == cc) ? Cb + hi_ * UVS_BLK_LD + lo_ : Cb + r * UVS_BLK_LD + li;
+        if (RHS && q == 1 && lk == 3) src = sh + L_DLT + 16 * cc + li;
+        acc[q] = *src;
+    }
+    return acc;
+}
+template <bool RHS>
+UVS_DEV void chol_store_pair(double* sh, int i1, int i2, int cc, int lane, const d4_t& acc) {
+    const int li = lane & 15, lk = lane >> 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int blk = q < 2 ? i1 : i2, r = chol_hr(lk + 4 * (q & 1));
+        if (RHS && q == 1 && lk == 3) sh[L_DLT + 16 * cc + li] = acc[q];
+        else if (blk != cc || r >= li) sblk(sh, blk, cc)[r * UVS_BLK_LD + li] = acc[q];
+    }
+}
+// acc -= sum_{j in [j0, j1)} L_(pair)j L_cj^T  (TR: the transposed product), same pipelining as chol_update_item
+template <bool TR, bool RHS>
+UVS_DEV void chol_update_pair(double* sh, int i1, int i2, int cc, int j0, int j1, int lane, d4_t& acc) {
+    const int li = lane & 15, lk = lane >> 4;
+    if (j0 >= j1) return;
+    const double* Bj = sblk(sh, cc, j0) + li * UVS_BLK_LD + lk;
+    const double* Ai = ((li < 8) ? sblk(sh, i1, j0) : sblk(sh, i2, j0)) + chol_hr(li) * UVS_BLK_LD + lk;
+    int astep = UVS_BLK_SZ;
+    if (RHS && li == 7) { Ai = sh + L_DLT + 16 * j0 + lk; astep = 16; }      // y_j: 16 doubles per block column
+    double a0[4], b0[4], a1[4], b1[4];
+#define UVS_CH_LOAD(AV, BV) { _Pragma("unroll") for (int q = 0; q < 4; ++q) { AV[q] = Ai[4 * q]; BV[q] = Bj[4 * q]; } Bj += UVS_BLK_SZ; Ai += astep; }
+#define UVS_CH_MFMA(AV, BV) { _Pragma("unroll") for (int q = 0; q < 4; ++q) acc = TR ? __builtin_amdgcn_mfma_f64_16x16x4f64(BV[q], AV[q], acc, 0, 0, 1) : __builtin_amdgcn_mfma_f64_16x16x4f64(AV[q], BV[q], acc, 0, 0, 1); }
+    UVS_CH_LOAD(a0, b0)
+    for (int j = j0;;) {
+        if (j + 1 < j1) UVS_CH_LOAD(a1, b1)
+        UVS_CH_MFMA(a0, b0)
+        if (++j >= j1) break;
+        if (j + 1 < j1) UVS_CH_LOAD(a0, b0)
+        UVS_CH_MFMA(a1, b1)
+        if (++j >= j1) break;
+    }
+#undef UVS_CH_LOAD
+#undef UVS_CH_MFMA
+}
+template <bool RHS>
+UVS_DEV void chol_panel_pair(double* sh, int i1, int i2, int k, int lane, const double* Bw, const d4_t& av) {      // av = chol_load_pair_t layout
+    d4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], Bw[q], acc, 0, 0, 0);
+    chol_store_pair<RHS>(sh, i1, i2, k, lane, acc);
+}
+
 // (Round 2 tried two restructurings of this factorization; both are correct and both lost on MI355X, so the barrier version stays:
 //  (1) the 16x16 diagonal block on the VALU, one matrix row per lane with DPP row broadcasts as FMA operands (tools/uvs_chol16.h,
 //      tools/chol16_test.hip): 268 cycles per pivot without the inverse, 390 with it, against ~250 for the readlane -> rcp -> rank-1
@@ -503,22 +581,37 @@ UVS_DEV void chol_panel_operand(double* sh, int k, int lane, double* Bw) {      
 // between stay inside one wave, and the only cross-wave dependency left inside the column is W_k, which the workers wait for on an LDS
 // flag after they have done their look-ahead (terms j < k of column k+1).  The two-barrier version made every wave wait for the
 // slowest one twice per column and left the pivot chain idle during the whole panel phase.
-UVS_DEV void chol_factor_impl(double* sh, int debug) {
+UVS_DEV void chol_factor_impl(double* sh, int debug, int half) {
     MiniCtx c; c.sh = sh; c.o.debug = debug;
     const int tid = lane_tid(), lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform ON PURPOSE: item indices derived from it select code paths
     const int li = lane & 15, lk = lane >> 4;
     int* flg = (int*)(sh + L_XC);      // x_c is dead between the assembly and the back-substitution of the landmarks
-    if (tid < 32) flg[tid] = 0;      // [k]: W_k published; [16 + k]: S(k+1, k) carries its last term
+    // [k]: W_k published; [16 + k]: S(k+1, k) carries its last term; half-row path (no workgroup barrier inside the factorization): [32 + c]: the
+    // diagonal block (c, c) carries its look-ahead terms; [48 + k]: L(k+1, k) stored by wave 0; [64]: arrivals at the workers' own barrier
+    if (tid < 80) flg[tid] = 0;
     if (tid == 0) sh[L_CTRL + C_CHOLOK] = 1.0;
     UVS_PROF(c, P_MISC);
     constexpr int nwork = NW - 1;
     const int wrk = wv - 1;
     long long tend_ = 0;
     d4_t Lt = {0.0, 0.0, 0.0, 0.0};      // wave 0: L(k, k-1)^T, the panel result of the previous column, = both operands of the diagonal block's last term
+#define UVS_FLAG_WAIT(idx, val) while (__hip_atomic_load(flg + (idx), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < (val)) __builtin_amdgcn_s_sleep(1);
+#define UVS_FLAG_SET(idx) if (lane == 0) __hip_atomic_store(flg + (idx), 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __syncthreads();
     for (int k = 0; k < UVS_NF; ++k) {
         double* Dk = sblk(sh, k, k);
-        __syncthreads();
+        // Half-row path: NO workgroup barrier per column.  The pivot chain (wave 0) only ever waits for two flags that are raised long before it
+        // needs them (its diagonal block's look-ahead terms, the last term of the block below), so the critical path of the factorization is
+        // chain -> W_k -> panel product of (k+1, k) -> first four MFMAs of the next diagonal block -> chain, without the workers' panel products
+        // in between; the three workers meet at a barrier of their own (an LDS counter) and wait for L(k, k-1), which wave 0 stores.
+        if (!half) { if (k > 0) __syncthreads(); }
+        else if (wv == 0) { if (k >= 2) UVS_FLAG_WAIT(32 + k, 1) }
+        else if (k > 0) {
+            if (lane == 0) __hip_atomic_fetch_add(flg + 64, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            UVS_FLAG_WAIT(64, nwork * k)
+            UVS_FLAG_WAIT(48 + k - 1, 1)
+        }
         const long long tw0_ = debug ? clock64() : 0;
         long long tl_ = tw0_;
 #define UVS_TL(slot) if (debug == 4 && lane == 0) { const long long t_ = clock64(); sh[L_WPROF + slot] += (double)(t_ - tl_); tl_ = t_; }
@@ -575,6 +668,9 @@ UVS_DEV void chol_factor_impl(double* sh, int debug) {
                 ap_prev = ap;
             }
             T = __builtin_amdgcn_mfma_f64_16x16x4f64(ap_prev, T[3], T, 0, 0, 0);      // row 15 of W: the multiplier -l10 of the last pair
+            // the block below the diagonal (its last term was the first thing worker 0 did in this column) is fetched under the square roots
+            if (k > 0) UVS_FLAG_WAIT(16 + k, 1)
+            const d4_t av = chol_load_item_t(sh, k + 1, k, lane);
             // square roots + scaling, lane-parallel and off the chain: register q of this lane belongs to row j = lk + 4q
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -585,15 +681,12 @@ UVS_DEV void chol_factor_impl(double* sh, int debug) {
             }
             if (lane == 0) __hip_atomic_store(flg + k, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             UVS_TL(1)
-            // ---- S3 for the block below the diagonal (the right-hand-side row for the last column); its last term was the first thing
-            // the lightest worker did in this column, 4 k cycles ago
-            if (k > 0) while (__hip_atomic_load(flg + 16 + k, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(1);
+            // ---- S3 for the block below the diagonal (the right-hand-side row for the last column)
             UVS_TL(2)
             // the product TRANSPOSED, L(k+1, k)^T = W_k S(k+1, k)^T (operands swapped): its C layout is the operand layout of the next
             // column's first four MFMAs, which therefore need no LDS round trip on the critical path
             double Bw[4]; chol_panel_operand(sh, k, lane, Bw);
             {
-                const d4_t av = chol_load_item_t(sh, k + 1, k, lane);
                 Lt = d4_t{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                 for (int q = 0; q < 4; ++q) Lt = __builtin_amdgcn_mfma_f64_16x16x4f64(Bw[q], av[q], Lt, 0, 0, 0);
@@ -605,11 +698,105 @@ UVS_DEV void chol_factor_impl(double* sh, int debug) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) sh[L_DLT + 16 * k + lk + 4 * q] = Lt[q];
                 }
+                UVS_FLAG_SET(48 + k)
             }
             UVS_TL(3)
             tend_ = tl_;
             if (debug == 1 && lane == 0) sh[L_WPROF + 4] += (double)(clock64() - tw0_);
+        } else if (half) {
+            // ---- workers, half-row pairs (see chol_hr): the items of a column are dealt round-robin over ONE list
+            //   [ (k+1, k) alone | last-term items t = 0..: pairs of rows k+2.. | look-ahead items u = 0..: pairs of rows k+1.. ]
+            // the right-hand-side row rides in the first pair of each of the two lists (alone only in column NF-2, which has no rows below k+1);
+            // a last-term item stays in registers, transposed, until W_k is published and its panel product can run (no store / reload in between)
+            const int nPA = (UVS_NF - k - 1) / 2;      // pairs of rows k+2 .. NF-1
+            const int nAi = nPA > 0 ? nPA : ((k + 2 <= UVS_NF) ? 1 : 0);      // (the lone rhs item)
+            const int nPL = (UVS_NF - k) / 2;          // pairs of rows k+1 .. NF-1 (look-ahead on column k+1)
+            // Who does what, by deadline: the look-ahead pair that holds the NEXT diagonal block is the longest item (k terms) and the first thing the
+            // pivot chain waits for, so worker 1 starts with it; worker 0 starts with the block below the diagonal (wave 0's panel product needs it
+            // when the chain of this column ends); the last-term items go round-robin from worker 2 (owner(t) = (t + 2) % nwork, panel products
+            // included); the remaining look-ahead pairs go to whoever is least loaded (every worker runs the same scalar bookkeeping).
+            constexpr int w_la0 = 1 % nwork, w_single = 0;
+            const int t0 = (wrk + nwork - (2 % nwork)) % nwork;
+            d4_t hold[2];
+            static_assert((UVS_NF / 2 + nwork - 1) / nwork <= 2, "last-term items of a column per worker");
+            if (k > 0) {
+                if (wrk == w_la0 && k + 1 < UVS_NF) {
+                    const int i1 = k + 1, i2 = (i1 + 1 < UVS_NF) ? i1 + 1 : i1;
+                    d4_t acc = chol_load_pair<true>(sh, i1, i2, k + 1, lane);
+                    chol_update_pair<false, true>(sh, i1, i2, k + 1, 0, k, lane, acc);
+                    chol_store_pair<true>(sh, i1, i2, k + 1, lane, acc);
+                    UVS_FLAG_SET(32 + k + 1)
+                }
+                if (wrk == w_single) {
+                    if (k + 1 < UVS_NF) {
+                        d4_t acc = chol_load_pair<false>(sh, k + 1, k + 1, k, lane);
+                        chol_update_pair<false, false>(sh, k + 1, k + 1, k, k - 1, k, lane, acc);
+                        chol_store_pair<false>(sh, k + 1, k + 1, k, lane, acc);
+                    } else {
+                        d4_t acc = chol_load_item(sh, k + 1, k, lane);
+                        chol_update_item(sh, k + 1, k, k - 1, k, lane, acc);
+                        chol_store_item(sh, k + 1, k, lane, acc);
+                    }
+                    UVS_FLAG_SET(16 + k)
+                }
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    const int t = t0 + n * nwork;
+                    const int i1 = k + 2 + 2 * t, i2 = (i1 + 1 < UVS_NF) ? i1 + 1 : i1;
+                    if (t < nPA) {
+                        if (t == 0) { hold[n] = chol_load_pair_t<true>(sh, i1, i2, k, lane); chol_update_pair<true, true>(sh, i1, i2, k, k - 1, k, lane, hold[n]); }
+                        else { hold[n] = chol_load_pair_t<false>(sh, i1, i2, k, lane); chol_update_pair<true, false>(sh, i1, i2, k, k - 1, k, lane, hold[n]); }
+                    } else if (t < nAi) {
+                        hold[n] = chol_load_item_t(sh, UVS_NF, k, lane);
+                        chol_update_item<true>(sh, UVS_NF, k, k - 1, k, lane, hold[n]);
+                    }
+                }
+                if (k + 1 < UVS_NF) {
+                    // loads in units of one MFMA (64 cycles): item overheads ~5, a term 4, a panel product ~8
+                    int load[nwork];
+#pragma unroll
+                    for (int w = 0; w < nwork; ++w) {
+                        const int tw = (w + nwork - (2 % nwork)) % nwork;
+                        load[w] = (tw < nAi ? (nAi - tw + nwork - 1) / nwork : 0) * 17 + (w == w_la0 ? 5 + 4 * k : 0) + (w == w_single ? 9 : 0);
+                    }
+                    for (int u = 1; u < nPL; ++u) {
+                        int best = 0;
+#pragma unroll
+                        for (int w = 1; w < nwork; ++w) if (load[w] < load[best]) best = w;
+#pragma unroll
+                        for (int w = 0; w < nwork; ++w) if (w == best) load[w] += 5 + 4 * k;
+                        if (best == wrk) {
+                            const int i1 = k + 1 + 2 * u, i2 = (i1 + 1 < UVS_NF) ? i1 + 1 : i1;
+                            d4_t acc = chol_load_pair<false>(sh, i1, i2, k + 1, lane);
+                            chol_update_pair<false, false>(sh, i1, i2, k + 1, 0, k, lane, acc);
+                            chol_store_pair<false>(sh, i1, i2, k + 1, lane, acc);
+                        }
+                    }
+                }
+            }
+            if (debug == 1 && lane == 0) sh[L_WPROF + 4 + wv] += (double)(clock64() - tw0_);
+            if (wv == 1) UVS_TL(4)
+            while (__hip_atomic_load(flg + k, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(1);
+            if (wv == 1) UVS_TL(5)
+            double Bw[4]; chol_panel_operand(sh, k, lane, Bw);
+            if (k > 0) {
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    const int t = t0 + n * nwork;
+                    const int i1 = k + 2 + 2 * t, i2 = (i1 + 1 < UVS_NF) ? i1 + 1 : i1;
+                    if (t < nPA) { if (t == 0) chol_panel_pair<true>(sh, i1, i2, k, lane, Bw, hold[n]); else chol_panel_pair<false>(sh, i1, i2, k, lane, Bw, hold[n]); }
+                    else if (t < nAi) chol_panel_from(sh, UVS_NF, k, lane, Bw, hold[n]);
+                }
+            } else {
+                for (int t = t0; t < nPA; t += nwork) {
+                    const int i1 = 2 + 2 * t, i2 = (i1 + 1 < UVS_NF) ? i1 + 1 : i1;
+                    if (t == 0) { const d4_t av = chol_load_pair_t<true>(sh, i1, i2, 0, lane); chol_panel_pair<true>(sh, i1, i2, 0, lane, Bw, av); }
+                    else { const d4_t av = chol_load_pair_t<false>(sh, i1, i2, 0, lane); chol_panel_pair<false>(sh, i1, i2, 0, lane, Bw, av); }
+                }
+            }
+            if (wv == 1) UVS_TL(6)
         } else {
+            // (full-row path: windows whose prior keeps the speed / bias of a frame >= 2)
             // ---- A: last term of this wave's rows of column k, TRANSPOSED and kept in registers (= the A operand of the panel product: no
             // store / reload between the two);  LA: terms j < k of column k + 1 (all rows, the diagonal block included), rows dealt in the
             // opposite worker order so that the worker with the most rows of column k has the fewest look-ahead items
@@ -666,11 +853,11 @@ UVS_DEV void chol_factor_impl(double* sh, int debug) {
 // allocation is then independent of the gather / factor code around it, and changes in here cannot perturb that code's allocation
 // (a build at the 512-register cap once produced a wrong cost).  The LDS base is re-declared inside, so the callee still addresses
 // LDS with ds_* instructions (a `double*` parameter would degrade to flat loads).
-__device__ __attribute__((noinline)) void chol_factor_call(int debug) {
+__device__ __attribute__((noinline)) void chol_factor_call(int debug, int half) {
     extern __shared__ __attribute__((aligned(16))) double sh_chol[];
-    chol_factor_impl(sh_chol, debug);
+    chol_factor_impl(sh_chol, debug, half);
 }
-UVS_DEV void chol_factor(const Ctx& c) { chol_factor_call(c.o.debug); }
+UVS_DEV void chol_factor(const Ctx& c) { chol_factor_call(c.o.debug, c.hdr->chol_half_ok); }
 
 // back substitution L^T x = y in place (y in L_DLT, produced by chol_factor); the diagonal solves are mat-vecs with W^T.
 // One wave does all of it: the chain x_k -> (update of the rows above) -> x_k-1 is serial anyway, and inside a single wave it

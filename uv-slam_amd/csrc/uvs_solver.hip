@@ -702,6 +702,9 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
     }
     h.n_chunks = (int)chunks.size() / 6;
     // re-damping (uvs_solve_kernel.h: redamp_chunk) keeps its per-line table and gradient rows in the record area of a line chunk
+    h.chol_half_ok = 1;
+    if (have_prior) for (int b = 0; b < w->prior->n_blocks; ++b) if (w->prior->block_kind[b] == UVS_BLOCK_SPEEDBIAS && w->prior->block_frame[b] >= 2) h.chol_half_ok = 0;
+    if (std::getenv("UVS_CHOL_FULL_ROWS")) h.chol_half_ok = 0;
     h.redamp_ok = (!td_on && !ex_on && !relo_on) ? 1 : 0;
     for (int qc = 0; qc < h.n_chunks && h.redamp_ok; ++qc)
         if (chunks[6 * qc] == 1) { const long nob = lbeg[chunks[6 * qc + 2]] - lbeg[chunks[6 * qc + 1]], nlm = chunks[6 * qc + 2] - chunks[6 * qc + 1]; if (34 * nlm + 6 * nob > (long)UVS_LN_REC * nob) h.redamp_ok = 0; }
