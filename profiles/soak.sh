@@ -1,0 +1,11 @@
+#!/bin/bash
+# The randomized soaks of a round, one record: bash profiles/soak.sh r03  ->  gpurun_out/<tag>_soak.txt (copy it to profiles/).  Run on the GPU box.
+tag=${1:-rXX}
+mkdir -p gpurun_out
+(echo "== gpu_soak.py (persistent kernel)"; python tests/gpu_soak.py 300 31000 persistent 2>&1 | tail -2
+ echo "== gpu_soak.py fused"; python tests/gpu_soak.py 300 31000 fused 2>&1 | tail -2
+ echo "== gpu_soak_relo.py"; python tests/gpu_soak_relo.py 200 32000 2>&1 | tail -2
+ echo "== gpu_soak_options.py"; python tests/gpu_soak_options.py 2>&1 | tail -5
+ echo "== gpu_soak_more.py"; python tests/gpu_soak_more.py 2>&1 | tail -4
+ echo "== gpu_soak_replay.py"; python tests/gpu_soak_replay.py 2>&1 | tail -5
+ echo "== gpu_soak_rejections.py"; python tests/gpu_soak_rejections.py 2>&1 | tail -4) > gpurun_out/${tag}_soak.txt 2>&1
