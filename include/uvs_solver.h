@@ -197,7 +197,9 @@ typedef struct uvs_window {
      * feature's FIRST observation (feature_per_frame[0].point) and pts_j = (match_point.x, match_point.y, 1).  relo_Pose is a free
      * 7-dof block with PoseLocalParameterization (estimator.cpp:947-948); it starts at para_Pose[relo_frame_local_index]
      * (Estimator::setReloFrame, estimator.cpp:1361-1379).  relo_lm must be strictly increasing and every such landmark needs at least
-     * one ordinary observation (its anchor frame imu_i is taken from there).  Only with estimate_extrinsic == 0 and estimate_td == 0. */
+     * one ordinary observation (its anchor frame imu_i is taken from there).  With estimate_td the blocks stay plain ProjectionFactors (no
+     * dependence on td, estimator.cpp:967-970).  Only with estimate_extrinsic == 0: relo_Pose takes the spare rows of the reduced system that
+     * a free extrinsic takes (UVS_ERR_UNSUPPORTED otherwise). */
     int32_t n_relo_obs;
     double relo_pose[UVS_SIZE_POSE];
     const int32_t *relo_lm;            /* [n_relo_obs] feature_index */

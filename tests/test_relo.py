@@ -131,14 +131,41 @@ def test_relo_in_a_batch_and_ignored_by_marginalization(gpu_api, oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("form", ["persistent", "fused", "stepwise"])
+@pytest.mark.parametrize("index,kw", [(130, {}), (131, dict(relo_frame=9, fraction=1.0)), (132, dict(relo_frame=0, pixel_sigma=0.5, with_prior=False))])
+def test_relo_blocks_with_estimate_td(gpu_api, oracle, form, index, kw):
+    """ESTIMATE_TD and relocalization blocks in one window (estimator.cpp:784-797 + :944-978 coexist in the reference): the point blocks are
+    ProjectionTdFactors, the relocalization blocks stay plain ProjectionFactors (no dependence on td), para_Td has its own slot of the reduced
+    system and relo_Pose the six a free extrinsic would take.  Same LM trace and states as the oracle's dense solve, in all three forms."""
+    w = synth.add_time_offset(_relo_window(index, **kw))
+    assert len(w.relo_lm) > 0
+    o = abi.default_options(); o.estimate_td = 1
+    s = gpu_api.Solver(opts=o, max_batch=2)
+    if form == "persistent": sg, rg = s.solve(w)
+    elif form == "fused": sg, rg, _ = s.large_solve_fused(w)
+    else: sg, rg = s.large_solve(w)
+    s.close()
+    so, ro = oracle.solve(w, opts=o)
+    assert rg.status == 0 and rg.num_iterations == ro.num_iterations
+    assert list(rg.accepted[: rg.num_iterations + 1]) == list(ro.accepted[: ro.num_iterations + 1])
+    assert abs(rg.initial_cost - ro.initial_cost) <= 1e-10 * ro.initial_cost
+    dp, da = pose_deltas(sg.pose, so.pose)
+    assert dp < 1e-6 and da < 1e-6, (dp, da)
+    assert abs(sg.td - so.td) < 1e-8 and sg.td != w.td
+    assert np.abs(sg.relo_pose[:3] - so.relo_pose[:3]).max() < 1e-6 and quat_angle(sg.relo_pose[3:], so.relo_pose[3:]) < 1e-6
+    assert not np.array_equal(sg.relo_pose, w.relo_pose)
+    assert np.abs(sg.inv_depth - so.inv_depth).max() < 1e-6
+    assert abs(rg.final_cost - ro.final_cost) <= 1e-6 * ro.final_cost
+
+
+@pytest.mark.gpu
 def test_relo_rejected_combinations(gpu_api):
     w = _relo_window(124)
-    for field in ("estimate_extrinsic", "estimate_td"):
+    for field in ("estimate_extrinsic",):      # relo_Pose takes the spare slots a free extrinsic takes: 12 dofs for 11 slots
         o = abi.default_options(); setattr(o, field, 1)
-        wq = synth.add_time_offset(w) if field == "estimate_td" else w
         s = gpu_api.Solver(opts=o, max_batch=2)
         with pytest.raises(RuntimeError, match="uvs error %d" % abi.UVS_ERR_UNSUPPORTED):
-            s.solve(wq)
+            s.solve(w)
         s.close()
     s = gpu_api.Solver(max_batch=2)      # (the large-window path takes the blocks since round 3: test_relo_blocks_in_the_multi_workgroup_forms)
     bad = w.copy(); bad.relo_lm = bad.relo_lm[::-1].copy()

@@ -1006,13 +1006,15 @@ UVS_DEV void gather_walk(const int* ent, int e0, int e1, Load load, Use use) {
 // H_ll^-1, so the walk adds the change of the Schur complement -- and the diagonal blocks also take the change of the reduced gradient,
 // - E_a (H_ll^-1 g_l)_new + E_a (H_ll^-1 g_l)_old, from the rows staged `goff` doubles from the E rows (a diagonal block's Schur entries are
 // exactly one (slot, slot) pair per landmark seen in its frame).
+// exrows: block row 12 is the camera extrinsic (its Jacobian sits in the record's own J_ex field); false in a window with relocalization blocks,
+// where pseudo frame 12 is relo_Pose, an ordinary second frame
 template <bool EXT, bool DELTA = false>
-UVS_DEV void gather_points(int grp, const int* lists, const double* S0, GAcc& A, int goff = 0) {
+UVS_DEV void gather_points(int grp, const int* lists, const double* S0, GAcc& A, int goff = 0, bool exrows = true) {
     const int g = lane_tid() / UVS_GLANES, r0 = GR * (lane_tid() % UVS_GLANES);
     const bool on = grp >= 0;
     const bool diag = on && ((grp >> 8) & 1);
     const bool tdg = EXT && on && ((grp >> 13) & 15) == UVS_NF;       // block row of the time offset: J1 = (J_td[0], J_td[1]) adjacent, residual 16 doubles below
-    const bool exg = EXT && on && ((grp >> 13) & 15) == UVS_NF + 1;   // block rows of the camera extrinsic: J1 = the 2 x 6 J_ex block of the record
+    const bool exg = EXT && exrows && on && ((grp >> 13) & 15) == UVS_NF + 1;   // block rows of the camera extrinsic: J1 = the 2 x 6 J_ex block of the record
     const bool tdcol = exg && ((grp >> 17) & 15) == UVS_NF;           // (ex, td): J2 is the adjacent J_td pair and only column 0 is real
     const int p1off = tdg ? 1 : 6, rcoff = tdg ? UVS_PT_C - UVS_PT_TD : exg ? UVS_PT_C - UVS_PT_EX : 12;
     const bool dirv = !(tdg && diag) && !tdcol;                 // (td, td): the direct term is the scalar J_td . J_td = the hd accumulator
@@ -1396,7 +1398,7 @@ UVS_DEV void lin_chunk(const Ctx& c, int ch, const double* x, const double* invd
             UVS_PROF(c, P_LMPREP);
             lacc_add(sh, cost, gmax_lm);
             const long long tg0_ = clock64();
-            if (h.td_on | h.ex_on) gather_points<true>(grp, lists, rec, acc); else gather_points<false>(grp, lists, rec, acc);
+            if (h.td_on | h.ex_on) gather_points<true>(grp, lists, rec, acc, 0, h.ex_on != 0); else gather_points<false>(grp, lists, rec, acc);
             if (c.o.debug == 2 && (tid & 63) == 0) sh[L_WPROF + 4 + (tid >> 6)] += (double)(clock64() - tg0_);
         } else {
             const int* beg = c.bi + h.i_ln_beg;

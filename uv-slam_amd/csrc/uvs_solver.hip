@@ -382,11 +382,14 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
     // back to the caller's index (-1 for a relocalization block): uvs_evaluate / uvs_marginalize keep the caller's numbering and skip them.
     const uvs_window* w = w_in;
     uvs_window wm;
-    std::vector<int32_t> m_lm, m_fi, m_fj, eidx; std::vector<double> m_pi, m_pj;
+    std::vector<int32_t> m_lm, m_fi, m_fj, eidx; std::vector<double> m_pi, m_pj, m_vi, m_vj, m_tdi, m_tdj;
     const int n_relo = w_in->n_relo_obs;
     if (n_relo < 0) { err = "bad counts"; return UVS_ERR_INVALID_ARG; }
+    if (td_on && w_in->n_point_obs > 0 && (!w_in->pt_vel_i || !w_in->pt_vel_j || !w_in->pt_td_i || !w_in->pt_td_j)) { err = "estimate_td needs pt_vel_i / pt_vel_j / pt_td_i / pt_td_j"; return UVS_ERR_INVALID_ARG; }
     if (n_relo > 0) {
-        if (td_on || opts.estimate_extrinsic != 0) { err = "relocalization blocks need estimate_extrinsic == 0 and estimate_td == 0 (relo_Pose takes the spare slots of the reduced system)"; return UVS_ERR_UNSUPPORTED; }
+        // relo_Pose takes the six spare slots of the reduced system that a free extrinsic would take; the time offset has its own (index 175), so
+        // ESTIMATE_TD and relocalization blocks coexist (estimator.cpp:784-797 + :944-978)
+        if (opts.estimate_extrinsic != 0) { err = "relocalization blocks need estimate_extrinsic == 0 (relo_Pose takes the spare slots of the reduced system that a free extrinsic takes)"; return UVS_ERR_UNSUPPORTED; }
         if (!w_in->relo_lm || !w_in->relo_pi || !w_in->relo_pj) { err = "null array"; return UVS_ERR_INVALID_ARG; }
         const int npo = w_in->n_point_obs;
         int q = 0;
@@ -394,20 +397,24 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
             const int lm = w_in->pt_lm[k];
             m_lm.push_back(lm); m_fi.push_back(w_in->pt_fi[k]); m_fj.push_back(w_in->pt_fj[k]); eidx.push_back(k);
             for (int c = 0; c < 3; ++c) { m_pi.push_back(w_in->pt_pi[3 * k + c]); m_pj.push_back(w_in->pt_pj[3 * k + c]); }
+            if (td_on) { for (int c = 0; c < 2; ++c) { m_vi.push_back(w_in->pt_vel_i[2 * k + c]); m_vj.push_back(w_in->pt_vel_j[2 * k + c]); } m_tdi.push_back(w_in->pt_td_i[k]); m_tdj.push_back(w_in->pt_td_j[k]); }
             if (k + 1 < npo && w_in->pt_lm[k + 1] == lm) continue;
             if (q < n_relo && w_in->relo_lm[q] < lm) { err = "relo_lm must be strictly increasing and name landmarks that have observations"; return UVS_ERR_INVALID_ARG; }
             if (q < n_relo && w_in->relo_lm[q] == lm) {
                 m_lm.push_back(lm); m_fi.push_back(w_in->pt_fi[k]); m_fj.push_back(UVS_RELO_FRAME); eidx.push_back(-1);
                 for (int c = 0; c < 3; ++c) { m_pi.push_back(w_in->relo_pi[3 * q + c]); m_pj.push_back(w_in->relo_pj[3 * q + c]); }
+                // a relocalization block is the plain ProjectionFactor also under ESTIMATE_TD (estimator.cpp:967-970): zero image velocities
+                // switch the time-offset terms of its record off (no shift of pts_i / pts_j, d r / d td = 0)
+                if (td_on) { for (int c = 0; c < 2; ++c) { m_vi.push_back(0.0); m_vj.push_back(0.0); } m_tdi.push_back(w_in->td); m_tdj.push_back(w_in->td); }
                 ++q;
             }
         }
         if (q != n_relo) { err = "relo_lm must be strictly increasing and name landmarks that have observations"; return UVS_ERR_INVALID_ARG; }
         wm = *w_in;
         wm.n_point_obs = (int)m_lm.size(); wm.pt_lm = m_lm.data(); wm.pt_fi = m_fi.data(); wm.pt_fj = m_fj.data(); wm.pt_pi = m_pi.data(); wm.pt_pj = m_pj.data();
+        if (td_on) { wm.pt_vel_i = m_vi.data(); wm.pt_vel_j = m_vj.data(); wm.pt_td_i = m_tdi.data(); wm.pt_td_j = m_tdj.data(); }
         w = &wm;
     }
-    if (td_on && w->n_point_obs > 0 && (!w->pt_vel_i || !w->pt_vel_j || !w->pt_td_i || !w->pt_td_j)) { err = "estimate_td needs pt_vel_i / pt_vel_j / pt_td_i / pt_td_j"; return UVS_ERR_INVALID_ARG; }
     DevWin h; std::memset(&h, 0, sizeof(h));
     h.n_points = w->n_points; h.n_pt_obs = w->n_point_obs; h.n_lines = w->n_lines; h.n_ln_obs = w->n_line_obs; h.n_imu = w->n_imu;
     const bool have_prior = w->prior && w->prior->n > 0;
@@ -521,14 +528,17 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
                 for (int o = b0; o < b1; ++o) fr[nf++] = w->pt_fj[o0 + o];
                 if (td_on) fr[nf++] = UVS_NUM_FRAMES;                                  // then the td slot of this landmark (pseudo frame 11)
                 if (ex_on) fr[nf++] = UVS_NUM_FRAMES + 1;                              // then its extrinsic slot (pseudo frame 12)
-                for (int sa = 0; sa < nf; ++sa) for (int sb = 0; sb <= sa; ++sb)      // frames increase with the slot => fr[sa] >= fr[sb]
-                    addS(blk_of(fr[sa], fr[sb]), (oE + 6 * (first_slot + sa)) | ((oEI + 6 * (first_slot + sb)) << 16));
+                for (int sa = 0; sa < nf; ++sa) for (int sb = 0; sb <= sa; ++sb) {    // frames increase with the slot, except a relocalization block (pseudo frame 12) ahead of the td slot (11)
+                    const bool up = fr[sa] >= fr[sb];
+                    const int ra = up ? sa : sb, rb = up ? sb : sa;
+                    addS(blk_of(fr[ra], fr[rb]), (oE + 6 * (first_slot + ra)) | ((oEI + 6 * (first_slot + rb)) << 16));
+                }
                 for (int o = b0; o < b1; ++o) {
                     const int fi = w->pt_fi[o0 + o], fj = w->pt_fj[o0 + o], ro = o * PREC;
                     addD(blk_of(fi, fi), (ro + UVS_PT_A) | ((ro + UVS_PT_A) << 16));
                     addD(blk_of(fj, fj), (ro + UVS_PT_B) | ((ro + UVS_PT_B) << 16));
                     addD(blk_of(fj, fi), (ro + UVS_PT_B) | ((ro + UVS_PT_A) << 16));
-                    if (td_on) {                                                       // J_td^T [A | B | J_td]
+                    if (td_on && fj != UVS_RELO_FRAME) {                               // J_td^T [A | B | J_td]  (a relocalization block does not depend on td)
                         addD(blk_of(UVS_NUM_FRAMES, fi), (ro + UVS_PT_TD) | ((ro + UVS_PT_A) << 16));
                         addD(blk_of(UVS_NUM_FRAMES, fj), (ro + UVS_PT_TD) | ((ro + UVS_PT_B) << 16));
                         addD(blk_of(UVS_NUM_FRAMES, UVS_NUM_FRAMES), (ro + UVS_PT_TD) | ((ro + UVS_PT_TD) << 16));
