@@ -1,15 +1,19 @@
 """Randomised parity soak of the relocalization blocks (run by hand on the GPU box): random windows (shape, noise, prior) with a random
-relocalization frame / match fraction / pose offset / match noise, HIP library vs oracle.   python tests/gpu_soak_relo.py [N] [seed0]"""
+relocalization frame / match fraction / pose offset / match noise, HIP library vs oracle.   python tests/gpu_soak_relo.py [N] [seed0] [td]
+(third argument "td": every window also estimates the camera / IMU time offset, ESTIMATE_TD)"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-from helpers import uvs, synth, pose_deltas, quat_angle
+from helpers import uvs, abi, synth, pose_deltas, quat_angle
 from oracle_binding import Oracle
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 31000
-o = Oracle(); s = uvs.api.Solver(max_batch=2, max_points=400, max_point_obs=4800, max_lines=120, max_line_obs=1320)
+with_td = len(sys.argv) > 3 and sys.argv[3] == "td"
+opts = abi.default_options(); opts.estimate_td = 1 if with_td else 0
+o = Oracle(); s = uvs.api.Solver(opts=opts, max_batch=2, max_points=400, max_point_obs=4800, max_lines=120, max_line_obs=1320)
 rng = np.random.default_rng(seed0)
+s_prior = uvs.api.Solver(max_batch=2, max_points=400, max_point_obs=4800, max_lines=120, max_line_obs=1320)      # the previous window's marginalization (no time offset there)
 worst = dict(dp=0.0, dq=0.0, cost=0.0, invd=0.0, relo_p=0.0, relo_q=0.0); mism = []; t0 = time.time(); done = 0
 for i in range(N):
     npt = int(rng.integers(8, 320)); nln = int(rng.integers(0, 90)); ntag = int(rng.integers(0, nln + 1))
@@ -19,13 +23,14 @@ for i in range(N):
               pixel_sigma=float(rng.choice([0.0, 0.5, 2.0])))
     prior = bool(rng.integers(0, 2))
     try:
-        w = synth.make_window(seed0 + i, with_prior=prior, marginalize_fn=(lambda win, flag: s.marginalize(win, flag)) if prior else None, **kw)
+        w = synth.make_window(seed0 + i, with_prior=prior, marginalize_fn=(lambda win, flag: s_prior.marginalize(win, flag)) if prior else None, **kw)
         w = synth.add_relocalization(w, seed=seed0 + i, **rk)
+        if with_td: w = synth.add_time_offset(w)
     except Exception as e:
         print("gen failed", i, kw, e); continue
     if len(w.relo_lm) == 0: continue
     done += 1
-    sg, rg = s.solve(w); so, ro = o.solve(w)
+    sg, rg = s.solve(w); so, ro = o.solve(w, opts=opts)
     same = rg.num_iterations == ro.num_iterations and list(rg.accepted[:rg.num_iterations + 1]) == list(ro.accepted[:ro.num_iterations + 1]) and rg.termination == ro.termination
     dp, dq = pose_deltas(sg.pose, so.pose)
     dc = abs(rg.final_cost - ro.final_cost) / max(ro.final_cost, 1e-300)
@@ -37,5 +42,5 @@ for i in range(N):
         for k, v in (("dp", dp), ("dq", dq), ("cost", dc), ("invd", di), ("relo_p", rp), ("relo_q", rq)): worst[k] = max(worst[k], v)
     if same and (dp > 1e-6 or rp > 1e-6):
         print("LARGE", i, kw, rk, prior, "n_relo %d dp %.2e relo %.2e %.2e" % (len(w.relo_lm), dp, rp, rq))
-print("%d relocalization windows in %.1f s; identical LM trace in %d; worst over those: %s" % (done, time.time() - t0, done - len(mism), {k: "%.2e" % v for k, v in worst.items()}))
+print("%d relocalization windows%s in %.1f s; identical LM trace in %d; worst over those: %s" % (done, " with ESTIMATE_TD" if with_td else "", time.time() - t0, done - len(mism), {k: "%.2e" % v for k, v in worst.items()}))
 for m in mism[:20]: print("TRACE DIFF", m)

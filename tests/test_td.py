@@ -171,3 +171,16 @@ def test_td_factor_class_evaluates_through_the_gpu(gpu_api, oracle, tmp_path):
     assert close(buf[44:46], e.pt_J[0][:, 18])
     assert close(buf[46:48], e.pt_Jtd[0])
     assert 0.0 <= buf[48] < 1e-3 * max(np.abs(e.pt_J[0]).max(), np.abs(e.pt_Jtd[0]).max())      # check(): analytic vs forward differences, td direction included
+
+
+@pytest.mark.gpu
+def test_marginalize_without_the_velocity_arrays_is_an_error_not_a_crash(gpu_api):
+    """uvs_marginalize cuts its sub-window out of the caller's arrays before the packing validates them: with estimate_td and no
+    pt_vel_* / pt_td_* it must answer UVS_ERR_INVALID_ARG like the solve does."""
+    o = abi.default_options(); o.estimate_td = 1
+    s = gpu_api.Solver(opts=o, max_batch=1)
+    w = synth.make_window(77)
+    for flag in (0, 1):
+        with pytest.raises(RuntimeError, match="uvs error %d" % abi.UVS_ERR_INVALID_ARG):
+            s.marginalize(w, flag)
+    s.close()

@@ -1005,6 +1005,9 @@ static int marginalize_old_device(uvs_solver* s, const uvs_window* w, uvs_prior*
     MargDevScratch& M = *s->marg_dev;
     const bool td_on = s->opts.estimate_td != 0;
     const int NFR = UVS_NF;
+    // the sub-window below is cut out of the caller's arrays BEFORE pack_window sees them: same checks first
+    { const int rv = validate_window(w, s->err); if (rv != UVS_OK) return rv; }
+    if (td_on && w->n_point_obs > 0 && (!w->pt_vel_i || !w->pt_vel_j || !w->pt_td_i || !w->pt_td_j)) { s->err = "estimate_td needs pt_vel_i / pt_vel_j / pt_td_i / pt_td_j"; return UVS_ERR_INVALID_ARG; }
     // ---- the sub-window: which blocks it touches (ids: pose f -> f ; speedbias f -> 11 + f ; ex -> 22 ; td -> 23)
     bool used[24] = {false};
     const bool have_prior = w->prior && w->prior->n > 0;
