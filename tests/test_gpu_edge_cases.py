@@ -283,3 +283,15 @@ def test_structure_cache_of_large_windows(gpu_api):
         for (pa, da, ca, na), (pb, db, cb, nb) in zip(a, b):
             assert na == nb and ca == cb and np.array_equal(pa, pb) and np.array_equal(da, db)
         assert a[0][2] != a[1][2] and a[0][2] == a[2][2]      # the values did change between the calls, and came back
+
+
+def test_malformed_windows_are_errors_at_every_entry_point():
+    """tests/gpu_fuzz_bad_windows.py: 21 malformed windows (indices out of range, broken grouping, bad prior tables, a NaN state) through the eight
+    entry points that take a window -- an error status each time, never a crash, and the handle keeps working.  In a child process: a crash of the
+    library must fail this test, not end the session."""
+    import subprocess, sys, os
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gpu_fuzz_bad_windows.py")
+    r = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=600)
+    tail = "\n".join((r.stdout + r.stderr).strip().splitlines()[-12:])
+    assert r.returncode == 0, tail
+    assert "0 wrong outcomes" in r.stdout, tail

@@ -156,7 +156,7 @@ static void host_sym_eig(int n, std::vector<double>& M, std::vector<double>& V, 
     for (int l = 0; l < n; ++l) {
         tst1 = std::max(tst1, std::fabs(d[l]) + std::fabs(e[l]));
         int m = l;
-        while (m < n) { if (std::fabs(e[m]) <= eps * tst1) break; ++m; }
+        while (m < n - 1) { if (std::fabs(e[m]) <= eps * tst1) break; ++m; }      // e[n-1] = 0 ends the scan; the bound keeps a NaN matrix inside the arrays
         if (m > l) {
             int iter = 0;
             do {
@@ -220,8 +220,14 @@ static void marg_solve_small(int sz, const double* Bm, double* X, int nr, int ld
 // frame system a linearization kernel delivered): A is N x N with the dropped FRAME dofs in rows / columns [0, md) and the kept ones in [m, N); rows
 // [md, m) (eliminated landmarks) are not read.  Eliminates the dropped frame block, factors the kept system J0 = sqrt(S) V^T, r0 = sqrt(S^-1) V^T b
 // (marginalization_factor.cpp:263-291) and fills the block table with the shifted frames (estimator.cpp:1139-1152 / :1196-1219).
-static void marg_finish(int N, int m, int md, int n, std::vector<double>& A, std::vector<double>& bv, const std::vector<int>& pos, const std::vector<int>& keep_ids,
+// Returns UVS_ERR_NUMERIC (and leaves *out untouched) when the system is not finite: a prior with NaNs would poison every later window.
+static int marg_finish(int N, int m, int md, int n, std::vector<double>& A, std::vector<double>& bv, const std::vector<int>& pos, const std::vector<int>& keep_ids,
                         const uvs_window* w, int flag, uvs_prior* out, EvalScratch& sc, bool prof, const double* us_pre) {
+    {
+        double chk = 0.0;
+        for (int i = 0; i < N; ++i) { if (i >= md && i < m) continue; chk += bv[i]; const double* ai = &A[(size_t)i * N]; for (int j = 0; j < md; ++j) chk += ai[j]; for (int j = m; j < N; ++j) chk += ai[j]; }
+        if (!std::isfinite(chk)) return UVS_ERR_NUMERIC;
+    }
     auto tnow = [] { return std::chrono::steady_clock::now(); };
     auto t3 = tnow();
     const double eps = 1e-8;                           // marginalization_factor.h:70
@@ -275,6 +281,7 @@ static void marg_finish(int N, int m, int md, int n, std::vector<double>& A, std
         for (int q = 0; q < gsize(id); ++q) out->x0[xo + q] = data[q];
         xo += gsize(id);
     }
+    return UVS_OK;
 }
 
 struct MFactor { int rows; int nb; int id[5]; int sz[5]; const double* r; const double* J; int ld; int coff[5]; const double* Jx; int xcol; };   // J row stride ld, column offset per block; block with coff < 0 reads its single column from Jx[row stride 1... 2 entries]   // J row stride ld, column offset per block
@@ -445,8 +452,7 @@ static int run_marginalize(int device, hipStream_t stream, char* d_blob, double*
     auto t3 = tnow();
     double us_pre[3] = {0, 0, 0};
     if (prof) { auto us = [](auto a_, auto b_) { return (double)std::chrono::duration_cast<std::chrono::nanoseconds>(b_ - a_).count() * 1e-3; }; us_pre[0] = us(t0, t1); us_pre[1] = us(t1, t2); us_pre[2] = us(t2, t3); }
-    marg_finish(N, m, md, n, A, bv, pos, keep_ids, w, flag, out, sc, prof, us_pre);
-    return UVS_OK;
+    return marg_finish(N, m, md, n, A, bv, pos, keep_ids, w, flag, out, sc, prof, us_pre);
 }
 
 }  // namespace uvsdev

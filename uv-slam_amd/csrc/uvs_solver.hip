@@ -1105,8 +1105,9 @@ static int marginalize_old_device(uvs_solver* s, const uvs_window* w, uvs_prior*
         }
     }
     double us_pre[3] = {(double)std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count() * 1e-3, 0.0, 0.0};
-    marg_finish(N, md, md, n, A, bv, pos, keep_ids, w, 0, out, s->eval_scratch, prof, us_pre);
-    return UVS_OK;
+    const int rf = marg_finish(N, md, md, n, A, bv, pos, keep_ids, w, 0, out, s->eval_scratch, prof, us_pre);
+    if (rf != UVS_OK) s->err = "marginalization: the linearized system is not finite";
+    return rf;
 }
 
 extern "C" {
