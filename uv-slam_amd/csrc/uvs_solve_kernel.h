@@ -581,7 +581,8 @@ UVS_DEV void chol_panel_operand(double* sh, int k, int lane, double* Bw) {      
 // between stay inside one wave, and the only cross-wave dependency left inside the column is W_k, which the workers wait for on an LDS
 // flag after they have done their look-ahead (terms j < k of column k+1).  The two-barrier version made every wave wait for the
 // slowest one twice per column and left the pivot chain idle during the whole panel phase.
-UVS_DEV void chol_factor_impl(double* sh, int debug, int half) {
+template <bool half>
+UVS_DEV void chol_factor_impl(double* sh, int debug) {
     MiniCtx c; c.sh = sh; c.o.debug = debug;
     const int tid = lane_tid(), lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform ON PURPOSE: item indices derived from it select code paths
@@ -853,11 +854,17 @@ UVS_DEV void chol_factor_impl(double* sh, int debug, int half) {
 // allocation is then independent of the gather / factor code around it, and changes in here cannot perturb that code's allocation
 // (a build at the 512-register cap once produced a wrong cost).  The LDS base is re-declared inside, so the callee still addresses
 // LDS with ds_* instructions (a `double*` parameter would degrade to flat loads).
-__device__ __attribute__((noinline)) void chol_factor_call(int debug, int half) {
+// Two instantiations (half-row pairs / full rows), each a call of its own: together in one function they need 248 VGPRs + 64 AGPRs, which reaches into the
+// callee-saved registers -- 50 scratch stores and loads per lane around every factorization, 0.18 GB of traffic per 256-window launch.
+__device__ __attribute__((noinline)) void chol_factor_call(int debug) {
     extern __shared__ __attribute__((aligned(16))) double sh_chol[];
-    chol_factor_impl(sh_chol, debug, half);
+    chol_factor_impl<true>(sh_chol, debug);
 }
-UVS_DEV void chol_factor(const Ctx& c) { chol_factor_call(c.o.debug, c.hdr->chol_half_ok); }
+__device__ __attribute__((noinline)) void chol_factor_call_full_rows(int debug) {
+    extern __shared__ __attribute__((aligned(16))) double sh_chol[];
+    chol_factor_impl<false>(sh_chol, debug);
+}
+UVS_DEV void chol_factor(const Ctx& c) { if (c.hdr->chol_half_ok) chol_factor_call(c.o.debug); else chol_factor_call_full_rows(c.o.debug); }
 
 // back substitution L^T x = y in place (y in L_DLT, produced by chol_factor); the diagonal solves are mat-vecs with W^T.
 // One wave does all of it: the chain x_k -> (update of the rows above) -> x_k-1 is serial anyway, and inside a single wave it
