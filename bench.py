@@ -53,7 +53,7 @@ def kernel_source_tag():
     return h.hexdigest()[:16]
 
 
-def algorithmic_flops(w, n_iterations):
+def algorithmic_flops(w, n_iterations, n_successful=None):
     """SURVEY.md section 8d flop model: (1 + it) linearizations + it cost-only evaluations."""
     n_po, n_lo = len(w.pt_lm), len(w.ln_lm)
     n_vp = int(np.sum(w.ln_has_vp))
@@ -76,6 +76,11 @@ def algorithmic_flops(w, n_iterations):
     chol = D ** 3 / 3 + 2 * D * D
     lin = ev + ac + sch + chol
     cost_only = 0.3 * (600 * n_po + 800 * n_lo + 400 * n_vp) + 2000 * n_imu + 2 * n * n
+    if n_successful is not None:
+        # what the kernel EXECUTES since the re-damping change: factor evaluation + Schur products only at the start and after accepted steps; after a
+        # rejected step the stored linearization is re-damped (the Schur accumulation and the factorization run again, the factors do not)
+        n_lin = 1 + n_successful
+        return n_lin * (ev + ac) + (1 + n_iterations) * (sch + chol) + n_iterations * cost_only
     return (1 + n_iterations) * lin + n_iterations * cost_only
 
 
@@ -241,6 +246,7 @@ def main():
         its = np.array([r.num_iterations for r in reps])
         bytes_per_launch = float(sum(synth.algorithmic_bytes(w) for w in windows))
         flops_per_launch = float(sum(algorithmic_flops(w, int(r.num_iterations)) for w, r in zip(windows, reps)))
+        flops_executed = float(sum(algorithmic_flops(w, int(r.num_iterations), int(r.num_successful)) for w, r in zip(windows, reps)))
         k_ms = float(np.mean(kernel_ms))
         ach_tflops = flops_per_launch / (k_ms * 1e-3) / 1e12
         ach_gbs = bytes_per_launch / (k_ms * 1e-3) / 1e9
@@ -259,8 +265,10 @@ def main():
         roofline = {"bound": "mfma", "kernel": "uvsdev::k_solve", "achieved": ach_tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": ach_tflops / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
                     "kernel_ms_per_launch": k_ms, "algorithmic_flops_per_launch": flops_per_launch,
+                    "frac_as_executed": flops_executed / (k_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, "flops_as_executed_per_launch": flops_executed,
                     "algorithmic_bytes_per_launch": bytes_per_launch, "hbm_achieved_GBps": ach_gbs, "hbm_frac": ach_gbs / HBM_PEAK_GBS,
-                    "note": "'mfma' bound = FP64 FLOP roof 78.6 TF/s (FP64 MFMA rate = FP64 vector rate on MI355X); flop/byte model of SURVEY.md 8d; "
+                    "note": "'mfma' bound = FP64 FLOP roof 78.6 TF/s (FP64 MFMA rate = FP64 vector rate on MI355X); flop/byte model of SURVEY.md 8d (frac: every LM iteration credited with a full linearization; "
+                            "frac_as_executed: factor evaluation credited only where it runs -- at the start and after accepted steps, a rejected step is followed by a re-damping of the stored linearization); "
                             "dense reduced solve + IMU blocks run on v_mfma_f64_16x16x4_f64, the sparse 6x6 Schur gather on VALU; the kernel is latency bound "
                             "(one wavefront per SIMD, see DESIGN.md section 5); traffic = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 of the same command (8 B/lane calibration: profiles/fetch_calibration.txt)"}
         # single-window latency mode (BASELINE configs[1]): one window resident, one launch per solve
