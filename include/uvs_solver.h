@@ -44,8 +44,8 @@ extern "C" {
 enum {
     UVS_OK = 0,
     UVS_ERR_INVALID_ARG = 1,    /* null pointer / index out of range / bad count */
-    UVS_ERR_UNSUPPORTED = 2,    /* a combination this path does not take: relocalization blocks together with estimate_extrinsic /
-                                 * estimate_td, or on the large-window path */
+    UVS_ERR_UNSUPPORTED = 2,    /* a combination this path does not take: relocalization blocks together with estimate_extrinsic in the uvs_large_* forms;
+                                 * RCCL not found for a multi-rank communicator */
     UVS_ERR_NO_DEVICE = 3,      /* no HIP device / extension cannot run (never falls back to CPU) */
     UVS_ERR_HIP = 4,            /* a HIP runtime call failed; see uvs_last_error() */
     UVS_ERR_CAPACITY = 5,       /* window larger than the handle was created for */
@@ -198,8 +198,9 @@ typedef struct uvs_window {
      * 7-dof block with PoseLocalParameterization (estimator.cpp:947-948); it starts at para_Pose[relo_frame_local_index]
      * (Estimator::setReloFrame, estimator.cpp:1361-1379).  relo_lm must be strictly increasing and every such landmark needs at least
      * one ordinary observation (its anchor frame imu_i is taken from there).  With estimate_td the blocks stay plain ProjectionFactors (no
-     * dependence on td, estimator.cpp:967-970).  Only with estimate_extrinsic == 0: relo_Pose takes the spare rows of the reduced system that
-     * a free extrinsic takes (UVS_ERR_UNSUPPORTED otherwise). */
+     * dependence on td, estimator.cpp:967-970).  With estimate_extrinsic the 6 + 6 (+ 1) free dofs beside the frames no longer fit the spare rows of
+     * the reduced system: relo_Pose is then eliminated at a second level (same exact solve of the damped system), which uvs_solve_window and the
+     * batch entry points implement; uvs_large_* return UVS_ERR_UNSUPPORTED for that combination. */
     int32_t n_relo_obs;
     double relo_pose[UVS_SIZE_POSE];
     const int32_t *relo_lm;            /* [n_relo_obs] feature_index */

@@ -6,6 +6,8 @@ mkdir -p gpurun_out
  echo "== gpu_soak.py fused"; python tests/gpu_soak.py 300 31000 fused 2>&1 | tail -2
  echo "== gpu_soak_relo.py"; python tests/gpu_soak_relo.py 200 32000 2>&1 | tail -2
  echo "== gpu_soak_relo.py with ESTIMATE_TD"; python tests/gpu_soak_relo.py 150 33000 td 2>&1 | tail -2
+ echo "== gpu_soak_relo.py with ESTIMATE_EXTRINSIC"; python tests/gpu_soak_relo.py 150 34000 ex 2>&1 | tail -2
+ echo "== gpu_soak_relo.py with ESTIMATE_TD + ESTIMATE_EXTRINSIC"; python tests/gpu_soak_relo.py 150 35000 tdex 2>&1 | tail -2
  echo "== gpu_soak_options.py"; python tests/gpu_soak_options.py 2>&1 | tail -5
  echo "== gpu_soak_more.py"; python tests/gpu_soak_more.py 2>&1 | tail -4
  echo "== gpu_soak_replay.py"; python tests/gpu_soak_replay.py 2>&1 | tail -5

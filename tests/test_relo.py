@@ -159,14 +159,42 @@ def test_relo_blocks_with_estimate_td(gpu_api, oracle, form, index, kw):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("td", [0, 1])
+@pytest.mark.parametrize("index,kw", [(140, {}), (141, dict(relo_frame=9, fraction=1.0)), (142, dict(relo_frame=0, pixel_sigma=0.5, with_prior=False)), (143, dict(relo_frame=3, fraction=0.2))])
+def test_relo_blocks_with_a_free_extrinsic(gpu_api, oracle, index, kw, td):
+    """ESTIMATE_EXTRINSIC (and ESTIMATE_TD) together with relocalization blocks: 6 + 6 (+ 1) free dofs do not fit the 11 spare rows of the reduced
+    system, so relo_Pose is eliminated at a second level (rank-6 update of S before the factorization, uvs_solve_kernel.h: relo2_eliminate) -- the
+    same exact solve of the damped system; same LM trace and states as the oracle's dense solve.  Persistent kernel and batches only."""
+    w = _relo_window(index, **kw)
+    if td: w = synth.add_time_offset(w)
+    assert len(w.relo_lm) > 0
+    o = abi.default_options(); o.estimate_extrinsic = 1; o.estimate_td = td
+    s = gpu_api.Solver(opts=o, max_batch=4)
+    sg, rg = s.solve(w)
+    s.upload([w, w]); s.solve_resident(); st2, rp2 = s.download()      # the batch entry points take it as well
+    so, ro = oracle.solve(w, opts=o)
+    assert rg.status == 0 and rg.num_iterations == ro.num_iterations
+    assert list(rg.accepted[: rg.num_iterations + 1]) == list(ro.accepted[: ro.num_iterations + 1])
+    assert abs(rg.initial_cost - ro.initial_cost) <= 1e-10 * ro.initial_cost
+    dp, da = pose_deltas(sg.pose, so.pose)
+    assert dp < 1e-6 and da < 1e-6, (dp, da)
+    assert np.abs(sg.ex_pose[:3] - so.ex_pose[:3]).max() < 1e-7 and quat_angle(sg.ex_pose[3:], so.ex_pose[3:]) < 1e-6
+    assert not np.array_equal(sg.ex_pose, w.ex_pose)
+    if td: assert abs(sg.td - so.td) < 1e-8
+    assert np.abs(sg.relo_pose[:3] - so.relo_pose[:3]).max() < 1e-6 and quat_angle(sg.relo_pose[3:], so.relo_pose[3:]) < 1e-6
+    assert not np.array_equal(sg.relo_pose, w.relo_pose)
+    assert np.abs(sg.inv_depth - so.inv_depth).max() < 1e-6
+    assert abs(rg.final_cost - ro.final_cost) <= 1e-6 * ro.final_cost
+    assert rp2[1].final_cost == rg.final_cost and np.array_equal(st2[1].relo_pose, sg.relo_pose)
+    # the landmark-sharded forms say so instead of solving something else
+    with pytest.raises(RuntimeError, match="uvs error %d" % abi.UVS_ERR_UNSUPPORTED):
+        s.large_solve_fused(w)
+    s.close()
+
+
+@pytest.mark.gpu
 def test_relo_rejected_combinations(gpu_api):
     w = _relo_window(124)
-    for field in ("estimate_extrinsic",):      # relo_Pose takes the spare slots a free extrinsic takes: 12 dofs for 11 slots
-        o = abi.default_options(); setattr(o, field, 1)
-        s = gpu_api.Solver(opts=o, max_batch=2)
-        with pytest.raises(RuntimeError, match="uvs error %d" % abi.UVS_ERR_UNSUPPORTED):
-            s.solve(w)
-        s.close()
     s = gpu_api.Solver(max_batch=2)      # (the large-window path takes the blocks since round 3: test_relo_blocks_in_the_multi_workgroup_forms)
     bad = w.copy(); bad.relo_lm = bad.relo_lm[::-1].copy()
     with pytest.raises(RuntimeError, match="uvs error %d" % abi.UVS_ERR_INVALID_ARG):

@@ -19,6 +19,12 @@
                                                // blocks (estimator.cpp:944-978; only with a fixed extrinsic), the 6 dofs of relo_Pose: pseudo frame 12 is then an
                                                // ORDINARY second frame of a point observation whose S rows / columns are scattered to these slots
 #define UVS_RELO_FRAME (UVS_NF + 1)            // frame index of relo_Pose in pt_fj
+#define UVS_RELO2_BLOCKROW (UVS_NF + 2)        // relocalization blocks in a window with a FREE extrinsic (DevWin::relo2): 6 + 6 (+ 1) dofs do not fit the 11 spare slots, so the
+                                               // gather blocks of relo_Pose get a block row of their own, 13 -- (13, f) = 91 + f, (13, td) = 102, (13, ex) = 103, (13, 13) = 104 --
+                                               // which the assembly writes to a side buffer in the workspace instead of S; relo_Pose is then eliminated from the reduced system by a
+                                               // rank-6 update before the factorization (k_solve only).  pt_fj of a relocalization block stays UVS_RELO_FRAME.
+#define UVS_NBLKX2 (UVS_NBLKX + UVS_NF + 3)    // 105: gather blocks including block row 13 (host packing only; the large-window kernels never see it)
+#define UVS_RELO2_DOUBLES 2304                 // side buffer: R[6][176] | Rrr[36] | g_r[6] | hd_r[6] | sc_r[6] | D_r[6] | Minv[36] | mg[6] | Z[6][176] | dr[6]
 #define UVS_XDIM 192                           // frame state vector: pose[11][7] sb[11][9] ex[7] td relo_pose[7] pad
 #define UVS_TD_INDEX (UVS_RD - 1)              // para_Td sits in the spare 16th slot of the last frame (index 175 of the padded reduced system)
 #define UVS_BLK_LD 17             // padded row stride of a 16x16 LDS block (bank-conflict padding)
@@ -70,6 +76,8 @@ struct DevWin {
     int32_t n_relo;                   // number of relocalization blocks among the n_pt_obs point observations
     int32_t i_pt_eidx;                // relo_on only: [n_pt_obs] the caller's observation index of each packed observation, -1 = relocalization block
     int32_t relo_on;                  // the window carries relocalization blocks: point observations with pt_fj == UVS_RELO_FRAME
+    int32_t relo2;                    // ... in a window with a free extrinsic: relo_Pose is a second-level block (UVS_RELO2_BLOCKROW), its side buffer at w_relo2
+    int32_t w_relo2;
     int32_t pt_rec;                   // doubles per point record in the LDS staging area (30, or 34 with the td Jacobian)
     int32_t pt_xslots;                // Schur slots per point landmark beyond its observations: anchor (+ td) (+ ex)
     int32_t d_line;                   // [n_lines][4]

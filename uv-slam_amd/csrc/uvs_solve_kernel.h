@@ -1339,7 +1339,7 @@ UVS_DEV void lin_chunk(const Ctx& c, int ch, const double* x, const double* invd
                 if (h.ex_on) {      // ESTIMATE_EXTRINSIC only: the 2 x 6 block d r / d ex_pose from a second evaluation, in its own scope so that the
                                     // default path keeps its register footprint (the kernel sits at the 512-register cap)
                     double r2[2], A2[12], B2[12], cl2[2], jex[12];
-                    point_eval<true, true>(x + 7 * fi, RF + 9 * fi, x + 7 * fj, RF + 9 * fj, ric, tic, invd[lm], pi, pj, c.o.sqrt_info, r2, A2, B2, cl2, jex);
+                    point_eval<true, true>(x + 7 * fi, RF + 9 * fi, pose_of(x, fj), RF + 9 * fj, ric, tic, invd[lm], pi, pj, c.o.sqrt_info, r2, A2, B2, cl2, jex);
 #pragma unroll
                     for (int q = 0; q < 12; ++q) R[UVS_PT_EX + q] = sc * jex[q];
                 }
@@ -1653,6 +1653,106 @@ UVS_DEV void redamp_chunk(const Ctx& c, int ch, double radius, int grp, GAcc& ac
         gather_lines<true>(grp, lists, rec, acc, nlm * 34, nob * UVS_LN_REC);
     }
 }
+// ---- relo_Pose as a SECOND-LEVEL block (DevWin::relo2: relocalization blocks in a window with a free extrinsic; uvs_layout.h UVS_RELO2_BLOCKROW).
+// The gather blocks of block row 13 land in a side buffer of the workspace: R = S(relo, frame dofs) [6][176], Rrr = S(relo, relo), its gradient
+// and diag(J^T J).  With M = Rrr + D_r (D_r: the same Jacobi-scaled LM damping every other dof gets) the reduced system loses the block before it is
+// factored -- S -= R^T M^-1 R, g -= R^T M^-1 g_r -- and gets it back after the solve, d_r = -M^-1 (g_r + R d_f): the same exact solve of the damped
+// system as with the block inside S (what happens when the extrinsic is fixed and relo_Pose fits the spare slots), at the price of a rank-6 update
+// through global memory.  R couples relo_Pose to pose / extrinsic / time-offset dofs only (73 indices), never to speed / bias rows, so the
+// half-row structure of the Cholesky survives.
+static constexpr int R2_R = 0, R2_RR = 1056, R2_G = 1092, R2_HD = 1098, R2_SC = 1104, R2_DD = 1110, R2_MI = 1116, R2_MG = 1152, R2_Z = 1158, R2_DR = 2214;
+static_assert(R2_DR + 6 <= UVS_RELO2_DOUBLES, "side buffer");
+UVS_DEV int relo2_index(int p) { return p < 66 ? 16 * (p / 6) + p % 6 : (p < 72 ? UVS_EX_INDEX(p - 66) : UVS_TD_INDEX); }      // the 73 S indices R can touch
+UVS_DEV void relo2_eliminate(const Ctx& c, const double* x, bool first, double radius, double& gmax) {
+    const DevWin& h = *c.hdr;
+    double* sh = c.sh; double* W = c.ws + h.w_relo2;
+    const int tid = lane_tid();
+    __syncthreads();      // the block rows written by the assembly are visible
+    if (tid == 0) {
+        double M[36], L[36], Li[36];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            const double hd = W[R2_HD + a];
+            if (first) W[R2_SC + a] = c.o.jacobi ? 1.0 / (1.0 + sqrt(hd)) : 1.0;
+            const double sc = W[R2_SC + a];
+            const double dd = fmin(fmax(sc * sc * hd, c.o.dlo), c.o.dhi) / (radius * sc * sc);
+            W[R2_DD + a] = dd;
+#pragma unroll
+            for (int b = 0; b < 6; ++b) M[6 * a + b] = W[R2_RR + (a >= b ? 6 * a + b : 6 * b + a)] + (a == b ? dd : 0.0);
+        }
+        // M = L L^T, Li = L^-1, M^-1 = Li^T Li
+#pragma unroll
+        for (int q = 0; q < 36; ++q) { L[q] = 0.0; Li[q] = 0.0; }
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            double dj = M[6 * j + j];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) if (k < j) dj -= L[6 * j + k] * L[6 * j + k];
+            if (!(dj > 0.0)) ok = false;
+            double ljj, inv; rsqrt_pair(dj, &ljj, &inv);
+            L[6 * j + j] = ljj;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) if (i > j) { double v = M[6 * i + j]; for (int k = 0; k < j; ++k) v -= L[6 * i + k] * L[6 * j + k]; L[6 * i + j] = v * inv; }
+        }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {      // column j of L^-1 by forward substitution
+#pragma unroll
+            for (int i = 0; i < 6; ++i) if (i >= j) { double v = (i == j) ? 1.0 : 0.0; for (int k = j; k < i; ++k) v -= L[6 * i + k] * Li[6 * k + j]; Li[6 * i + j] = v / L[6 * i + i]; }
+        }
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            double mg = 0.0;
+#pragma unroll
+            for (int b = 0; b < 6; ++b) { double v = 0.0; for (int k = 0; k < 6; ++k) v += Li[6 * k + a] * Li[6 * k + b]; W[R2_MI + 6 * a + b] = v; mg += v * W[R2_G + b]; }
+            W[R2_MG + a] = mg;
+        }
+        if (!ok) sh[L_CTRL + C_CHOLOK] = 0.0;      // (reset by chol_factor; a failed block shows up there as well: the update below then makes S indefinite)
+    }
+    if (tid == UVS_NF + 1) {      // projected-gradient measure of relo_Pose (its landmark-reduced gradient, like every frame block's)
+        double d[6], xp[7];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) d[k] = -W[R2_G + k];
+        pose_plus(x + 184, d, xp);
+#pragma unroll
+        for (int k = 0; k < 7; ++k) gmax = fmax(gmax, fabs(x[184 + k] - xp[k]));
+    }
+    __syncthreads();
+    if (tid < UVS_RD) {      // Z = M^-1 R (column tid), g -= R^T M^-1 g_r
+        double r[6], gs = 0.0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) { r[a] = W[R2_R + UVS_RD * a + tid]; gs += r[a] * W[R2_MG + a]; }
+#pragma unroll
+        for (int a = 0; a < 6; ++a) { double z = 0.0; for (int b = 0; b < 6; ++b) z += W[R2_MI + 6 * a + b] * r[b]; W[R2_Z + UVS_RD * a + tid] = z; }
+        sh[L_G + tid] -= gs;
+    }
+    __syncthreads();
+    for (int e = tid; e < 73 * 73; e += NT) {      // S -= R^T Z on the 73 x 73 index set (lower triangle of S; the product is symmetric)
+        const int p = e / 73, q = e - 73 * p;
+        if (q > p) continue;
+        const int i = relo2_index(p), j = relo2_index(q);
+        double acc = 0.0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) acc += W[R2_R + UVS_RD * a + i] * W[R2_Z + UVS_RD * a + j];
+        const int hi_ = i >= j ? i : j, lo_ = i >= j ? j : i;
+        sh[L_S + sidx(hi_, lo_)] -= acc;
+    }
+    __syncthreads();
+}
+// the step of relo_Pose after the reduced solve (d_f in L_DLT): d_r = -(M^-1 g_r + Z d_f); mirrored to where an observation of pseudo frame 12 looks for it
+UVS_DEV void relo2_backsub(const Ctx& c) {
+    const DevWin& h = *c.hdr;
+    double* sh = c.sh; double* W = c.ws + h.w_relo2;
+    const int tid = lane_tid();
+    if (tid < 6) {
+        double acc = W[R2_MG + tid];
+        for (int p = 0; p < 73; ++p) { const int i = relo2_index(p); acc += W[R2_Z + UVS_RD * tid + i] * sh[L_DLT + i]; }
+        W[R2_DR + tid] = -acc;
+        sh[L_DLT + 16 * UVS_RELO_FRAME + tid] = -acc;
+    }
+    __syncthreads();
+}
+
 // ---- linearization, part 3: assemble the damped reduced system in LDS from the gathered pose blocks + IMU + prior
 // mode 0: everything (k_solve).  The large-window kernels split the work over two workgroups that run concurrently with the landmark
 // chunks resp. after them: mode 1 = the FRAME image only (zero, IMU tiles, prior; no landmark blocks, no damping: k_large_chunks' extra
@@ -1674,6 +1774,7 @@ UVS_DEV void lin_assemble(const Ctx& c, const double* x, bool first, double radi
     if (mode != 2) {
         { const d2_t z2 = {0.0, 0.0}; for (int i = tid; i < UVS_S_DOUBLES / 2; i += NT) *(d2_t*)(sh + L_S + 2 * i) = z2; }      // ds_write_b128
         if (tid < UVS_RD) { sh[L_G + tid] = 0.0; sh[L_HD + tid] = 0.0; }
+        if (h.relo2) for (int t = tid; t < R2_SC; t += NT) c.ws[h.w_relo2 + t] = 0.0;
         __syncthreads();
     }
     UVS_TZ(5)
@@ -1682,7 +1783,25 @@ UVS_DEV void lin_assemble(const Ctx& c, const double* x, bool first, double radi
         if (grp >= 0 && ((grp >> 9) & 15) == 0) {
             const int r0 = GR * (tid % UVS_GLANES);
             const int fa = (grp >> 13) & 15, fb = (grp >> 17) & 15;
-            if (fa == UVS_NF + 1) {  // camera-extrinsic rows (ESTIMATE_EXTRINSIC): dof a of Ex_Pose sits at S index 16 a + 15, anywhere relative to the column
+            if (fa == UVS_RELO2_BLOCKROW) {      // relo_Pose beside a free extrinsic: its rows go to the side buffer (relo2_eliminate)
+                double* W = c.ws + h.w_relo2;
+#pragma unroll
+                for (int r = 0; r < GR; ++r) {
+                    const int a = r0 + r;
+                    if (fb < UVS_NF) {
+#pragma unroll
+                        for (int cc = 0; cc < 6; ++cc) W[R2_R + UVS_RD * a + 16 * fb + cc] = A.v[6 * r + cc];
+                    } else if (fb == UVS_NF) W[R2_R + UVS_RD * a + UVS_TD_INDEX] = A.v[6 * r];
+                    else if (fb == UVS_NF + 1) {
+#pragma unroll
+                        for (int cc = 0; cc < 6; ++cc) W[R2_R + UVS_RD * a + UVS_EX_INDEX(cc)] = A.v[6 * r + cc];
+                    } else {
+#pragma unroll
+                        for (int cc = 0; cc < 6; ++cc) if (cc <= a) W[R2_RR + 6 * a + cc] = A.v[6 * r + cc];
+                        W[R2_G + a] = A.g[r]; W[R2_HD + a] = A.hd[r];
+                    }
+                }
+            } else if (fa == UVS_NF + 1) {  // camera-extrinsic rows (ESTIMATE_EXTRINSIC): dof a of Ex_Pose sits at S index 16 a + 15, anywhere relative to the column
 #pragma unroll
                 for (int r = 0; r < GR; ++r) {
                     const int a = r0 + r, i = UVS_EX_INDEX(a);
@@ -1853,7 +1972,7 @@ UVS_DEV void lin_assemble(const Ctx& c, const double* x, bool first, double radi
         for (int k = 0; k < 7; ++k) gmax = fmax(gmax, fabs(x[7 * tid + k] - xp[k]));
     }
     if ((h.ex_on | h.relo_on) && tid == UVS_NF) {   // same projected-gradient measure for the extrinsic pose block / relo_Pose
-        const double* xa = x + (h.relo_on ? 184 : 176);
+        const double* xa = x + ((h.relo_on && !h.relo2) ? 184 : 176);
         double d[6], xp[7];
 #pragma unroll
         for (int k = 0; k < 6; ++k) d[k] = -sh[L_G + UVS_EX_INDEX(k)];
@@ -1861,6 +1980,7 @@ UVS_DEV void lin_assemble(const Ctx& c, const double* x, bool first, double radi
 #pragma unroll
         for (int k = 0; k < 7; ++k) gmax = fmax(gmax, fabs(xa[k] - xp[k]));
     }
+    if (h.relo2 && mode == 0) relo2_eliminate(c, x, first, radius, gmax);
     double s4[4] = {cost, 0.0, 0.0, 0.0};
     block_reduce(sh, s4, &gmax);
     if (tid == 0) { sh[L_CTRL + C_COST] = s4[0]; sh[L_CTRL + C_GMAX] = gmax; }
@@ -1904,7 +2024,9 @@ UVS_DEV void backsub_candidate(const Ctx& c, const double* invd, const double* l
     const bool td_on = h.td_on != 0;
     const bool ex_on = h.ex_on != 0, relo_on = h.relo_on != 0;
     double* ltrig_c = const_cast<double*>(line_trig_of(c, line_c));
-    if (relo_on) {      // the step of relo_Pose where an observation of pseudo frame 12 looks for it: d[16 * 12 + a]
+    const bool relo2 = h.relo2 != 0;
+    if (relo2) relo2_backsub(c);
+    else if (relo_on) {      // the step of relo_Pose where an observation of pseudo frame 12 looks for it: d[16 * 12 + a]
         if (tid < 6) sh[L_DLT + 16 * UVS_RELO_FRAME + tid] = d[UVS_EX_INDEX(tid)];
         __syncthreads();
     }
@@ -1932,7 +2054,12 @@ UVS_DEV void backsub_candidate(const Ctx& c, const double* invd, const double* l
         if (relo_on) {      // relo_Pose: a free pose block (estimator.cpp:947-948)
             double de[6], xp[7];
 #pragma unroll
-            for (int k = 0; k < 6; ++k) de[k] = d[UVS_EX_INDEX(k)];
+            for (int k = 0; k < 6; ++k) de[k] = d[16 * UVS_RELO_FRAME + k];
+            if (relo2) {      // its share of g . d and d^T D d: g_r (d_r + M^-1 R d_f) = -g_r . M^-1 g_r (the landmark terms below restore their part the same way)
+                const double* W = c.ws + h.w_relo2;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) { gd -= W[R2_G + k] * W[R2_MG + k]; dd2 += W[R2_DD + k] * de[k] * de[k]; }
+            }
             pose_plus(sh + L_X + 184, de, xp);
 #pragma unroll
             for (int k = 0; k < 7; ++k) { sh[L_XC + 184 + k] = xp[k]; const double e = xp[k] - sh[L_X + 184 + k]; step2 += e * e; xc2 += xp[k] * xp[k]; }

@@ -389,7 +389,9 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
     if (n_relo > 0) {
         // relo_Pose takes the six spare slots of the reduced system that a free extrinsic would take; the time offset has its own (index 175), so
         // ESTIMATE_TD and relocalization blocks coexist (estimator.cpp:784-797 + :944-978)
-        if (opts.estimate_extrinsic != 0) { err = "relocalization blocks need estimate_extrinsic == 0 (relo_Pose takes the spare slots of the reduced system that a free extrinsic takes)"; return UVS_ERR_UNSUPPORTED; }
+        // with a free extrinsic the spare slots are taken: relo_Pose becomes a second-level block (uvs_layout.h: UVS_RELO2_BLOCKROW), which only the persistent
+        // kernel implements (chunk_grid > 0 = the landmark-sharded forms)
+        if (opts.estimate_extrinsic != 0 && chunk_grid > 0) { err = "relocalization blocks together with estimate_extrinsic are taken by uvs_solve_window / the batch entry points only"; return UVS_ERR_UNSUPPORTED; }
         if (!w_in->relo_lm || !w_in->relo_pi || !w_in->relo_pj) { err = "null array"; return UVS_ERR_INVALID_ARG; }
         const int npo = w_in->n_point_obs;
         int q = 0;
@@ -424,6 +426,8 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
     h.td_on = td_on ? 1 : 0; h.ex_on = ex_on ? 1 : 0;
     const bool relo_on = n_relo > 0;
     h.relo_on = relo_on ? 1 : 0; h.n_relo = n_relo;
+    const bool relo2 = relo_on && opts.estimate_extrinsic != 0;      // relo_Pose as a second-level block (block row 13 of the gather)
+    h.relo2 = relo2 ? 1 : 0;
     h.pt_rec = ex_on ? UVS_PT_REC_EX : td_on ? UVS_PT_REC_TD : UVS_PT_REC; h.pt_xslots = 1 + (td_on ? 1 : 0) + (ex_on ? 1 : 0);
     const int PREC = h.pt_rec, XS = h.pt_xslots;
     // CSR by landmark
@@ -512,7 +516,7 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
     // Two passes over the same generator: the first only COUNTS the entries per pose block (what the work split below needs), the second
     // regenerates them chunk by chunk into one reused set of vectors while the lists are written.  (Keeping every chunk's entries
     // alive between the passes cost 80 k small vectors on a configs[3]-sized window: two thirds of the packing time.)
-    std::vector<long> blk_work(UVS_NBLKX, 0), blk_s(UVS_NBLKX, 0), blk_d(UVS_NBLKX, 0), blk_wp(UVS_NBLKX, 0), blk_wl(UVS_NBLKX, 0);
+    std::vector<long> blk_work(UVS_NBLKX2, 0), blk_s(UVS_NBLKX2, 0), blk_d(UVS_NBLKX2, 0), blk_wp(UVS_NBLKX2, 0), blk_wl(UVS_NBLKX2, 0);
     auto blk_of = [](int fa, int fb) { return fa * (fa + 1) / 2 + fb; };   // fa >= fb ; fa == 11 is the time-offset pseudo frame: 66 + fb
     auto chunk_entries = [&](int qc, auto&& addS, auto&& addD) {
         const int type = chunks[6 * qc], k0 = chunks[6 * qc + 1], k1 = chunks[6 * qc + 2];
@@ -523,9 +527,9 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
                 const int li = k - k0, b0 = pbeg[k] - o0, b1 = pbeg[k + 1] - o0;
                 if (b1 == b0) continue;
                 const int first_slot = b0 + XS * li;
-                int fr[UVS_NUM_FRAMES + 3], nf = 0;
+                int fr[UVS_NUM_FRAMES + 4], nf = 0;      // block rows of the landmark's Schur slots
                 fr[nf++] = w->pt_fi[o0 + b0];
-                for (int o = b0; o < b1; ++o) fr[nf++] = w->pt_fj[o0 + o];
+                for (int o = b0; o < b1; ++o) fr[nf++] = (relo2 && w->pt_fj[o0 + o] == UVS_RELO_FRAME) ? UVS_RELO2_BLOCKROW : w->pt_fj[o0 + o];
                 if (td_on) fr[nf++] = UVS_NUM_FRAMES;                                  // then the td slot of this landmark (pseudo frame 11)
                 if (ex_on) fr[nf++] = UVS_NUM_FRAMES + 1;                              // then its extrinsic slot (pseudo frame 12)
                 for (int sa = 0; sa < nf; ++sa) for (int sb = 0; sb <= sa; ++sb) {    // frames increase with the slot, except a relocalization block (pseudo frame 12) ahead of the td slot (11)
@@ -534,11 +538,12 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
                     addS(blk_of(fr[ra], fr[rb]), (oE + 6 * (first_slot + ra)) | ((oEI + 6 * (first_slot + rb)) << 16));
                 }
                 for (int o = b0; o < b1; ++o) {
-                    const int fi = w->pt_fi[o0 + o], fj = w->pt_fj[o0 + o], ro = o * PREC;
+                    const bool is_relo = w->pt_fj[o0 + o] == UVS_RELO_FRAME;
+                    const int fi = w->pt_fi[o0 + o], fj = (relo2 && is_relo) ? UVS_RELO2_BLOCKROW : w->pt_fj[o0 + o], ro = o * PREC;
                     addD(blk_of(fi, fi), (ro + UVS_PT_A) | ((ro + UVS_PT_A) << 16));
                     addD(blk_of(fj, fj), (ro + UVS_PT_B) | ((ro + UVS_PT_B) << 16));
                     addD(blk_of(fj, fi), (ro + UVS_PT_B) | ((ro + UVS_PT_A) << 16));
-                    if (td_on && fj != UVS_RELO_FRAME) {                               // J_td^T [A | B | J_td]  (a relocalization block does not depend on td)
+                    if (td_on && !is_relo) {                                           // J_td^T [A | B | J_td]  (a relocalization block does not depend on td)
                         addD(blk_of(UVS_NUM_FRAMES, fi), (ro + UVS_PT_TD) | ((ro + UVS_PT_A) << 16));
                         addD(blk_of(UVS_NUM_FRAMES, fj), (ro + UVS_PT_TD) | ((ro + UVS_PT_B) << 16));
                         addD(blk_of(UVS_NUM_FRAMES, UVS_NUM_FRAMES), (ro + UVS_PT_TD) | ((ro + UVS_PT_TD) << 16));
@@ -546,8 +551,9 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
                     if (ex_on) {                                                       // J_ex^T [A | B | J_td | J_ex]
                         const int X = UVS_NUM_FRAMES + 1;
                         addD(blk_of(X, fi), (ro + UVS_PT_EX) | ((ro + UVS_PT_A) << 16));
-                        addD(blk_of(X, fj), (ro + UVS_PT_EX) | ((ro + UVS_PT_B) << 16));
-                        if (td_on) addD(blk_of(X, UVS_NUM_FRAMES), (ro + UVS_PT_EX) | ((ro + UVS_PT_TD) << 16));
+                        if (fj > X) addD(blk_of(fj, X), (ro + UVS_PT_B) | ((ro + UVS_PT_EX) << 16));      // (relo_Pose, ex): the rows are relo_Pose's
+                        else addD(blk_of(X, fj), (ro + UVS_PT_EX) | ((ro + UVS_PT_B) << 16));
+                        if (td_on && !is_relo) addD(blk_of(X, UVS_NUM_FRAMES), (ro + UVS_PT_EX) | ((ro + UVS_PT_TD) << 16));
                         addD(blk_of(X, X), (ro + UVS_PT_EX) | ((ro + UVS_PT_EX) << 16));
                     }
                 }
@@ -565,17 +571,17 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
     };
     const int inner_threads = pack_inner_threads(h.n_pt_obs + h.n_ln_obs);
     {
-        struct Cnt { long s[UVS_NBLKX], d[UVS_NBLKX], wp[UVS_NBLKX], wl[UVS_NBLKX]; };
+        struct Cnt { long s[UVS_NBLKX2], d[UVS_NBLKX2], wp[UVS_NBLKX2], wl[UVS_NBLKX2]; };
         std::vector<Cnt> part((size_t)std::max(inner_threads, 1));
         for (auto& c : part) std::memset(&c, 0, sizeof(c));
         pack_parallel(n_ch, inner_threads, [&](int q0, int q1, int t) {
             Cnt& c = part[t];
             for (int qc = q0; qc < q1; ++qc) {
-                long cs[UVS_NBLKX] = {0}, cd[UVS_NBLKX] = {0};
+                long cs[UVS_NBLKX2] = {0}, cd[UVS_NBLKX2] = {0};
                 chunk_entries(qc, [&](int b, int) { ++cs[b]; }, [&](int b, int) { ++cd[b]; });
                 const int type = chunks[6 * qc];
                 // work units ~ cycles per entry of the rows-per-lane gather
-                for (int b = 0; b < UVS_NBLKX; ++b) {
+                for (int b = 0; b < UVS_NBLKX2; ++b) {
                     // measured per entry on MI355X (per-wave timers, UVS_DEBUG_GATHER_TIMERS): point Schur 350 cycles, point direct 675 cycles
                     const long ws_ = (type == 0 ? 18 : 72) * cs[b], wd_ = (type == 0 ? 35 : 63) * cd[b];
                     c.s[b] += ws_; c.d[b] += wd_;
@@ -583,7 +589,7 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
                 }
             }
         });
-        for (const auto& c : part) for (int b = 0; b < UVS_NBLKX; ++b) { blk_s[b] += c.s[b]; blk_d[b] += c.d[b]; blk_wp[b] += c.wp[b]; blk_wl[b] += c.wl[b]; }
+        for (const auto& c : part) for (int b = 0; b < UVS_NBLKX2; ++b) { blk_s[b] += c.s[b]; blk_d[b] += c.d[b]; blk_wp[b] += c.wp[b]; blk_wl[b] += c.wl[b]; }
     }
     lap_("entries");
     // gather groups: 256 two-lane groups, at least one per pose block; the spare ones split the heaviest blocks further.  Groups are dealt to
@@ -591,15 +597,16 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
     // waves on a SIMD (waves w and w+4 share one).
     int wblk[UVS_NGRP], g_blk[UVS_NGRP], g_part[UVS_NGRP], g_np[UVS_NGRP];
     {
-        for (int b = 0; b < UVS_NBLKX; ++b) blk_work[b] = blk_s[b] + blk_d[b];
+        for (int b = 0; b < UVS_NBLKX2; ++b) blk_work[b] = blk_s[b] + blk_d[b];
         struct Item { int b, part, np; long work; double shape; };
         // water-filling: hand the spare groups, one at a time, to the block whose per-group share is largest (at most 16 parts)
-        int np[UVS_NBLKX]; int used = 0;
-        for (int b = 0; b < UVS_NBLKX; ++b) {      // the pseudo-frame blocks only exist with their option
-            const bool tdb = b >= UVS_NBLK && b < UVS_NBLK + UVS_NF + 1, exb = b >= UVS_NBLK + UVS_NF + 1;
+        int np[UVS_NBLKX2]; int used = 0;
+        for (int b = 0; b < UVS_NBLKX2; ++b) {      // the pseudo-frame blocks only exist with their option
+            const bool tdb = b >= UVS_NBLK && b < UVS_NBLK + UVS_NF + 1, exb = b >= UVS_NBLK + UVS_NF + 1 && b < UVS_NBLKX;
             // a block nothing contributes to (frames further apart than the longest track, pseudo-frame blocks of an option that is off) gets
             // no group at all: S is zeroed anyway, and its group goes to a heavy block instead (15 of 128 groups for the canonical window)
-            np[b] = ((b < UVS_NBLK || (tdb && td_on) || (exb && (ex_on || relo_on) && (td_on || b != UVS_NBLK + UVS_NF + 1 + UVS_NF))) && blk_work[b] > 0) ? 1 : 0; used += np[b];
+            const bool r2b = b >= UVS_NBLKX;      // block row 13 (relo_Pose beside a free extrinsic)
+            np[b] = ((b < UVS_NBLK || (tdb && td_on) || (!r2b && exb && (ex_on || relo_on) && (td_on || b != UVS_NBLK + UVS_NF + 1 + UVS_NF)) || (r2b && relo2 && (td_on || b != UVS_NBLKX + UVS_NF))) && blk_work[b] > 0) ? 1 : 0; used += np[b];
         }
         // The waves run in lock step inside a chunk and the chunks of the two landmark families are separated by barriers, so what counts
         // is the LARGEST per-group share within each family, not the per-group total: a block that is heavy in the point chunks only (the
@@ -607,14 +614,14 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
         // Greedy: the next spare group goes to the family whose current maximum weighs more, and there to the block that holds it.
         while (used < UVS_NGRP) {
             int bp = -1, bl = -1;
-            for (int b = 0; b < UVS_NBLKX; ++b) {
+            for (int b = 0; b < UVS_NBLKX2; ++b) {
                 if (np[b] == 0 || np[b] >= 16) continue;
                 if (blk_wp[b] > 0 && (bp < 0 || blk_wp[b] * np[bp] > blk_wp[bp] * np[b])) bp = b;
                 if (blk_wl[b] > 0 && (bl < 0 || blk_wl[b] * np[bl] > blk_wl[bl] * np[b])) bl = b;
             }
             // the true maxima include the blocks that cannot be split any further
             double mp = 0.0, ml = 0.0;
-            for (int b = 0; b < UVS_NBLKX; ++b) if (np[b] > 0) { mp = std::max(mp, (double)blk_wp[b] / np[b]); ml = std::max(ml, (double)blk_wl[b] / np[b]); }
+            for (int b = 0; b < UVS_NBLKX2; ++b) if (np[b] > 0) { mp = std::max(mp, (double)blk_wp[b] / np[b]); ml = std::max(ml, (double)blk_wl[b] / np[b]); }
             int best = -1;
             const double sp_ = bp >= 0 ? (double)blk_wp[bp] / np[bp] : -1.0, sl_ = bl >= 0 ? (double)blk_wl[bl] / np[bl] : -1.0;
             if (bp >= 0 && sp_ >= mp && (mp >= ml || bl < 0 || sl_ < ml)) best = bp;
@@ -625,7 +632,7 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
             ++np[best]; ++used;
         }
         std::vector<Item> items;
-        for (int b = 0; b < UVS_NBLKX; ++b) for (int q = 0; q < np[b]; ++q) items.push_back({b, q, np[b], blk_work[b] / np[b], blk_work[b] ? (double)blk_d[b] / (double)blk_work[b] : -1.0});
+        for (int b = 0; b < UVS_NBLKX2; ++b) for (int q = 0; q < np[b]; ++q) items.push_back({b, q, np[b], blk_work[b] / np[b], blk_work[b] ? (double)blk_d[b] / (double)blk_work[b] : -1.0});
         // a wave runs max(Schur count) + max(direct count) iterations over its 32 groups: deal groups of similar SHAPE (share of
         // direct work) to the same wave, idle groups last
         std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b2) { return a.shape != b2.shape ? a.shape > b2.shape : a.work > b2.work; });
@@ -634,12 +641,12 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
         // straddle two ranks; the round-2 order for 8 waves, heavy ranks paired with light ones on a SIMD, broke exactly that: the wrong pose blocks of the 512-thread builds)
         for (int r = 0; r < NW; ++r) wave_of_rank[r] = r;
         h.n_parts = 1;
-        for (int b = 0; b < UVS_NBLKX; ++b) h.n_parts = std::max(h.n_parts, np[b]);
+        for (int b = 0; b < UVS_NBLKX2; ++b) h.n_parts = std::max(h.n_parts, np[b]);
         for (int g = 0; g < UVS_NGRP; ++g) { wblk[g] = -1; g_blk[g] = -1; g_part[g] = 0; g_np[g] = 1; }
         for (size_t q = 0; q < items.size(); ++q) {
             const int g = wave_of_rank[q / GRP_PER_WAVE] * GRP_PER_WAVE + (int)(q % GRP_PER_WAVE);
             const int b = items[q].b;
-            const int bfa = b >= UVS_NBLK + UVS_NF + 1 ? UVS_NUM_FRAMES + 1 : b >= UVS_NBLK ? UVS_NUM_FRAMES : (int)((std::sqrt(8.0 * b + 1.0) - 1.0) * 0.5 + 1e-9), bfb = b - bfa * (bfa + 1) / 2;     // b = fa(fa+1)/2 + fb
+            const int bfa = b >= UVS_NBLKX ? UVS_RELO2_BLOCKROW : b >= UVS_NBLK + UVS_NF + 1 ? UVS_NUM_FRAMES + 1 : b >= UVS_NBLK ? UVS_NUM_FRAMES : (int)((std::sqrt(8.0 * b + 1.0) - 1.0) * 0.5 + 1e-9), bfb = b - bfa * (bfa + 1) / 2;     // b = fa(fa+1)/2 + fb
             wblk[g] = b | (bfa == bfb ? 256 : 0) | (items[q].part << 9) | (bfa << 13) | (bfb << 17) | ((items[q].np - 1) << 21);      // parts of a block sit in consecutive groups
             g_blk[g] = b; g_part[g] = items[q].part; g_np[g] = items[q].np;
         }
@@ -654,10 +661,10 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
         const bool dbg_lists = std::getenv("UVS_DEBUG_LISTS") != nullptr;
         pack_parallel(n_ch, dbg_lists ? 1 : inner_threads, [&](int q0, int q1, int t) {
             Part& P = part[t]; P.q0 = q0; P.q1 = q1;
-            std::vector<std::vector<int>> eS(UVS_NBLKX), eD(UVS_NBLKX);
+            std::vector<std::vector<int>> eS(UVS_NBLKX2), eD(UVS_NBLKX2);
             std::vector<int> ent;
             for (int qc = q0; qc < q1; ++qc) {
-                for (int b = 0; b < UVS_NBLKX; ++b) { eS[b].clear(); eD[b].clear(); }
+                for (int b = 0; b < UVS_NBLKX2; ++b) { eS[b].clear(); eD[b].clear(); }
                 chunk_entries(qc, [&](int b, int v) { eS[b].push_back(v); }, [&](int b, int v) { eD[b].push_back(v); });
                 chunks[6 * qc + 3] = (int)P.lists.size();      // relative to this part for now
                 const size_t base = P.lists.size();
@@ -796,6 +803,7 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
     h.w_prior_img = wsz; wsz += std::max(h.n_pblk, 1) * UVS_BLK_SZ + UVS_RD;      // dense tiles (written once per solve), diag(J0^T J0) per S index
     h.n_cimg = (int)csrc.size();
     h.w_prior_cimg = wsz; wsz += rup(std::max(h.n_cimg, 1), 2);
+    h.w_relo2 = wsz; if (relo2) wsz += UVS_RELO2_DOUBLES;
     h.ws_doubles = rup(wsz, 32);
     // fill
     const size_t base = out.size();
