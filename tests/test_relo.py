@@ -242,6 +242,31 @@ def test_host_estimator_relocalization(gpu_api, tmp_path):
 
 
 @pytest.mark.gpu
+def test_host_estimator_relocalization_with_a_free_extrinsic(gpu_api, tmp_path, monkeypatch):
+    """Estimator::optimization() with ESTIMATE_EXTRINSIC = 1 and relocalization blocks: the host mirror hands the window to the persistent kernel
+    (the multi-workgroup form does not take that combination) and gets the same solve as the C ABI called directly on the window it assembled.
+    (Directly = on the DUMPED window: vector2double() rebuilds every quaternion from its rotation matrix, and the line / VP factors differentiate with
+    respect to the raw quaternion -- deviation D1 of the reference -- so q and -q are different inputs to the same problem.)"""
+    from test_host_mirror import _host
+    w = _relo_window(131, relo_frame=4)
+    pin, pout = str(tmp_path / "in.uvsw"), str(tmp_path / "out.bin")
+    w.save(pin)
+    monkeypatch.setenv("UVS_HOST_ESTIMATE_EXTRINSIC", "1")
+    monkeypatch.setenv("UVS_DUMP_WINDOWS", str(tmp_path))
+    assert _host().uvs_host_replay_window(pin.encode(), pout.encode(), 0) == 0
+    raw = np.fromfile(pout, dtype=np.float64)
+    status, iters, c0, c1 = raw[:4]
+    wd = abi.Window.load(str(tmp_path / "window_0000.bin"))
+    assert len(wd.relo_lm) == len(w.relo_lm) > 0
+    o = abi.default_options(); o.estimate_extrinsic = 1
+    s = gpu_api.Solver(opts=o, max_batch=2)
+    st, rep = s.solve(wd)
+    s.close()
+    assert status == 0 and iters == rep.num_iterations and abs(c0 - rep.initial_cost) <= 1e-9 * c0 and abs(c1 - rep.final_cost) <= 1e-9 * c1
+    assert np.abs(raw[-28:-21] - st.relo_pose).max() < 1e-9 and not np.array_equal(st.ex_pose, wd.ex_pose)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("index,kw", [(21, dict(relo_frame=5)), (22, dict(relo_frame=0, fraction=0.3)), (23, dict(relo_frame=9, with_prior=True))])
 def test_relo_blocks_in_the_multi_workgroup_forms(gpu_api, oracle, index, kw):
     """Relocalization blocks through the landmark-sharded path (round 3: relo_Pose travels in the 192-double frame state of the large kernels): the

@@ -12,6 +12,7 @@ extern "C" int uvs_host_replay_window(const char* in_path, const char* out_path,
     const uvs_window& w = wf.w;
     setEurocParameters();
     ESTIMATE_TD = wf.has_td ? 1 : 0;      // a window recorded with the ProjectionTdFactor inputs replays with ESTIMATE_TD (euroc_config.yaml: estimate_td)
+    if (const char* e = std::getenv("UVS_HOST_ESTIMATE_EXTRINSIC")) ESTIMATE_EXTRINSIC = std::atoi(e);      // (euroc_config.yaml: estimate_extrinsic; the window file does not record it)
     try {
         Estimator est;
         est.td = w.td;
