@@ -327,9 +327,12 @@ int uvs_marginalize_resident(uvs_solver *s, const uvs_window *w, int flag, uvs_p
 
 /* ---- ONE large window spread over the GPU and, with an all-reduce between the steps, over several GPUs (BASELINE configs[3]) ----
  * Landmarks shard (rank r holds the landmarks k with k % G == r; frames / IMU / prior are replicated); the only exchanged data are
- * the pose-block partials returned by uvs_large_reduced() (SUM, except entry [n-7] which is a MAX) and the 5 scalars of
- * uvs_large_scalars() (SUM).  Both are DEVICE pointers so that RCCL can reduce them in place.  On one GPU skip the all-reduces
- * or call uvs_large_solve().  Loop: begin; while (!done) { if (need_linearize) { linearize; allreduce(reduced) } step; allreduce(scalars); decide } finish. */
+ * the pose-block partials returned by uvs_large_reduced() (SUM, except entry [n-7] which is a MAX) and the n = 6 scalars of
+ * uvs_large_scalars() (SUM; the sixth is this rank's vote that options.max_solver_time_in_seconds is used up: reduced with the rest, so that
+ * every rank ends the solve at the same iteration).  Both are DEVICE pointers so that RCCL can reduce them in place.  On one GPU skip the all-reduces
+ * or call uvs_large_solve().  Loop: begin; while (!done) { if (need_linearize) { linearize; allreduce(reduced) } step; allreduce(scalars); decide } finish.
+ * Relocalization blocks (n_relo_obs > 0) are taken on ONE rank only: a landmark shard cannot tell from its own observations whether relo_Pose is a
+ * free block of the window, so in a solve over several ranks no rank may pass them (uvs_large_solve_fused answers UVS_ERR_UNSUPPORTED). */
 int uvs_large_begin(uvs_solver *s, const uvs_window *w);
 int uvs_large_need_linearize(const uvs_solver *s);
 int uvs_large_linearize(uvs_solver *s);

@@ -264,6 +264,11 @@ def test_host_estimator_relocalization_with_a_free_extrinsic(gpu_api, tmp_path, 
     s.close()
     assert status == 0 and iters == rep.num_iterations and abs(c0 - rep.initial_cost) <= 1e-9 * c0 and abs(c1 - rep.final_cost) <= 1e-9 * c1
     assert np.abs(raw[-28:-21] - st.relo_pose).max() < 1e-9 and not np.array_equal(st.ex_pose, wd.ex_pose)
+    # the prior built after the solve is linearized at the POST-solve extrinsic (estimator.cpp:1004: vector2double() again before the marginalization)
+    x0 = np.fromfile(pout + ".x0", dtype=np.float64).reshape(-1, 12)
+    exb = x0[x0[:, 0] == abi.UVS_BLOCK_EX_POSE]
+    assert len(exb) == 1 and np.abs(exb[0, 3:6] - st.ex_pose[:3]).max() < 1e-9 and np.abs(np.abs(exb[0, 6:10]) - np.abs(st.ex_pose[3:])).max() < 1e-9
+    assert np.abs(exb[0, 3:6] - wd.ex_pose[:3]).max() > 1e-6
 
 
 @pytest.mark.gpu

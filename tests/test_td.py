@@ -140,7 +140,12 @@ def test_td_through_the_host_mirror(gpu_api):
         w.save(pin)
         assert host.uvs_host_replay_window(pin.encode(), pout.encode(), 0) == 0
         raw = np.fromfile(pout, dtype=np.float64)
+        x0 = np.fromfile(pout + ".x0", dtype=np.float64).reshape(-1, 12)
     status, iters, c0, c1 = raw[:4]
+    # the prior built after the solve remembers the POST-solve time offset as the linearization point of its td block (the reference packs again,
+    # estimator.cpp:1004, before it marginalizes; a descriptor that still carried the pre-solve td was the round-3 advisor's finding)
+    tdb = x0[x0[:, 0] == abi.UVS_BLOCK_TD]
+    assert len(tdb) == 1 and abs(tdb[0, 3] - raw[-1]) < 1e-12 and abs(tdb[0, 3] - w.td) > 1e-4      # (the window starts at td = 0 and ends near 0.005)
     # same kernel, inputs differ by one rounding (R -> q -> R in vector2double, 1 / (1 / lambda)): the first linearization agrees to 1e-9;
     # late accept / reject decisions of this window are marginal, so the end state is compared at the LM tolerance, not bitwise
     assert status == 0 and iters == rep.num_iterations and abs(c0 - rep.initial_cost) <= 1e-9 * c0 and abs(c1 - rep.final_cost) <= 2e-2 * c1

@@ -219,8 +219,12 @@ __global__ __launch_bounds__(NT) void k_large_backsub(char* blob, double* ws, KO
         if (tid == 0) bo[4] = s4[0];
     }
 }
-__global__ __launch_bounds__(256) void k_large_sum_bsums(const double* bsums, int n_chunks, double* out5, LargeCtl lc) {
+// out5[5] (fused loop with a communicator): THIS rank's vote "options.max_solver_time_in_seconds is used up" -- the SUM all-reduce of the 8 doubles turns the votes
+// into one number that is the same on every rank, and k_large_decide ends the solve when it is non-zero: a rank that tested its own clock could stop an
+// iteration before its peers and leave stale sums in the collectives they have already enqueued (round-3 advisor finding).
+__global__ __launch_bounds__(256) void k_large_sum_bsums(const double* bsums, int n_chunks, double* out5, LargeCtl lc, long long max_ticks) {
     if (lc.ctl && lc.ctl[LC_DONE] != 0.0) return;
+    if (threadIdx.x == 255) { out5[5] = (lc.ctl && max_ticks > 0 && lc.ctl[LC_IT] > 0.0 && (double)wall_clock64() - lc.ctl[LC_T0] >= (double)max_ticks) ? 1.0 : 0.0; out5[6] = 0.0; out5[7] = 0.0; }
     // 5 scalars x n_chunks: 32 contiguous chunk slices per scalar (8 lanes idle per slice row), slice sums added in slice order
     __shared__ double part[32][8];
     const int i = threadIdx.x & 7, p = threadIdx.x >> 3;
@@ -251,7 +255,7 @@ __global__ __launch_bounds__(256) void k_large_decide(double* ctl, double* state
         part[p][i] = sl;
         __syncthreads();
         if (p == 0 && i < 5) { double t = part[0][i]; for (int q = 1; q < 32; ++q) t += part[q][i]; sc5_sh[i] = t; }
-    } else if (tid < 5) sc5_sh[tid] = sc5_in[tid];
+    } else if (tid < 6) sc5_sh[tid] = sc5_in[tid];
     __syncthreads();
     const double* sc5 = sc5_sh;
     if (tid == 0) {
@@ -269,7 +273,8 @@ __global__ __launch_bounds__(256) void k_large_decide(double* ctl, double* state
         pending = 0;
         if (!done) {
             if (it >= o.max_it) { term = UVS_TERM_NO_CONVERGENCE; done = true; }
-            else if (o.max_ticks > 0 && it > 0 && (double)wall_clock64() - ctl[LC_T0] >= (double)o.max_ticks) { term = UVS_TERM_MAX_TIME; done = true; }      // options.max_solver_time_in_seconds
+            // options.max_solver_time_in_seconds: one process reads its own clock; with a communicator the decision is the all-reduced vote of the ranks (sc5[5]), identical everywhere
+            else if (o.max_ticks > 0 && it > 0 && (bsums ? (double)wall_clock64() - ctl[LC_T0] >= (double)o.max_ticks : sc5[5] > 0.0)) { term = UVS_TERM_MAX_TIME; done = true; }
             else if (gmax <= o.gtol) { term = UVS_TERM_GRADIENT_TOL; done = true; }
             else if (radius <= o.rmin) { term = UVS_TERM_MIN_RADIUS; done = true; }
         }

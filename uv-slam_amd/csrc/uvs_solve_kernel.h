@@ -33,6 +33,14 @@ static __device__ __forceinline__ int lane_tid() { return threadIdx.x; }
 #endif
 static constexpr int NT = UVS_NT;              // threads per workgroup
 static constexpr int NW = NT / 64;
+// Loads in flight per lane.  One wave per SIMD (NT = 256) hides memory latency only with its own independent loads, so the streaming loops batch
+// several observations per lane; with two resident waves per SIMD (NT = 512) the other wave covers the latency and the batches shrink to what
+// fits 256 registers per lane.
+static constexpr int CP_PB = NT > 256 ? 2 : 4;      // cost pass: point observations per batch
+static constexpr int CP_LB = NT > 256 ? 1 : 2;      // cost pass: line observations per batch
+static constexpr int BS_LNB = NT > 256 ? 2 : 4;     // back substitution: line observations per batch
+static constexpr int PR_UN = NT > 256 ? 12 : 24;    // prior residual: rows of J0^T in flight
+static constexpr int PG_UN = NT > 256 ? 16 : 32;    // prior gradient: rows of J0 in flight
 
 // ---- LDS map (in doubles)
 static constexpr int L_S = 0;
@@ -232,12 +240,12 @@ UVS_DEV double prior_residual(const Ctx& c, int dst = L_PR) {
         const int kb = (n * part) / parts, ke = (n * (part + 1)) / parts;
         // 24 independent loads in flight per trip: the n = 75 prior (19 rows per lane) is ONE HBM/L2 round trip, not three
         double p8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int k = kb; k < ke; k += 24) {
-            double jv[24];
+        for (int k = kb; k < ke; k += PR_UN) {
+            double jv[PR_UN];
 #pragma unroll
-            for (int u = 0; u < 24; ++u) jv[u] = J0T[(k + u < ke ? k + u : kb) * n + row];
+            for (int u = 0; u < PR_UN; ++u) jv[u] = J0T[(k + u < ke ? k + u : kb) * n + row];
 #pragma unroll
-            for (int u = 0; u < 24; ++u) if (k + u < ke) p8[u & 7] += jv[u] * c.sh[L_PDX + k + u];
+            for (int u = 0; u < PR_UN; ++u) if (k + u < ke) p8[u & 7] += jv[u] * c.sh[L_PDX + k + u];
         }
         c.sh[L_S + 128 * part + row] = ((p8[0] + p8[1]) + (p8[2] + p8[3])) + ((p8[4] + p8[5]) + (p8[6] + p8[7]));
     }
@@ -263,20 +271,20 @@ UVS_DEV double cost_pass(const Ctx& c, const double* x, const double* invd, cons
     // Observations in batches of four per lane: the index loads and the measurement loads of a batch go out together and the
     // landmark parameters (the only loads whose address depends on an index) follow as a second group, so a lane pays two HBM/L2
     // round trips per BATCH instead of two per observation (one wave per SIMD: nothing else hides that latency).
-    for (int o0 = po0 + tid; o0 < po1; o0 += 4 * NT) {
-        int lm[4], fi[4], fj[4]; bool in[4];
-        double pi[4][3], pj[4][3], vij[4][4], idp[4];
+    for (int o0 = po0 + tid; o0 < po1; o0 += CP_PB * NT) {
+        int lm[CP_PB], fi[CP_PB], fj[CP_PB]; bool in[CP_PB];
+        double pi[CP_PB][3], pj[CP_PB][3], vij[CP_PB][4], idp[CP_PB];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < CP_PB; ++u) {
             const int o = o0 + u * NT; in[u] = o < po1;
             const int oo = in[u] ? o : o0;
             lm[u] = c.bi[h.i_pt_lm + oo]; fi[u] = c.bi[h.i_pt_fi + oo]; fj[u] = c.bi[h.i_pt_fj + oo];
             load_point_obs(c, oo, x[183], pi[u], pj[u], vij[u]);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) idp[u] = invd[lm[u]];
+        for (int u = 0; u < CP_PB; ++u) idp[u] = invd[lm[u]];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < CP_PB; ++u) {
             if (!in[u]) continue;
             double r[2];
             point_eval<false, false>(x + 7 * fi[u], RF + 9 * fi[u], pose_of(x, fj[u]), RF + 9 * fj[u], ric, tic, idp[u], pi[u], pj[u], c.o.sqrt_info, r, nullptr, nullptr, nullptr, nullptr);
@@ -284,12 +292,12 @@ UVS_DEV double cost_pass(const Ctx& c, const double* x, const double* invd, cons
         }
     }
     // lines + vp, two per batch
-    for (int o0 = lo0 + tid; o0 < lo1; o0 += 2 * NT) {
-        int lm[2], fj[2], hv[2]; bool in[2];
-        double ms[2][9], lp[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, tg[2][8];
+    for (int o0 = lo0 + tid; o0 < lo1; o0 += CP_LB * NT) {
+        int lm[CP_LB], fj[CP_LB], hv[CP_LB]; bool in[CP_LB];
+        double ms[CP_LB][9], lp[CP_LB][4] = {}, tg[CP_LB][8];
         const int st = h.ln_stride;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < CP_LB; ++u) {
             const int o = o0 + u * NT; in[u] = o < lo1;
             const int oo = in[u] ? o : o0;
             lm[u] = c.bi[h.i_ln_lm + oo]; fj[u] = c.bi[h.i_ln_fj + oo]; hv[u] = c.bi[h.i_ln_vp + oo];
@@ -298,7 +306,7 @@ UVS_DEV double cost_pass(const Ctx& c, const double* x, const double* invd, cons
             for (int q = 0; q < 9; ++q) ms[u][q] = m[q * st];
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < CP_LB; ++u) {
             if (ltrig) {
 #pragma unroll
                 for (int q = 0; q < 8; ++q) tg[u][q] = ltrig[8 * lm[u] + q];
@@ -308,7 +316,7 @@ UVS_DEV double cost_pass(const Ctx& c, const double* x, const double* invd, cons
             }
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < CP_LB; ++u) {
             if (!in[u]) continue;
             const double sp[3] = {ms[u][0], ms[u][1], ms[u][2]}, ep[3] = {ms[u][3], ms[u][4], ms[u][5]}, vp[3] = {ms[u][6], ms[u][7], ms[u][8]};
             LineGeom g;
@@ -1928,12 +1936,12 @@ UVS_DEV void lin_assemble(const Ctx& c, const double* x, bool first, double radi
             if (part < parts) {
                 const int ib = (n * part) / parts, ie = (n * (part + 1)) / parts;
                 double p8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                for (int i = ib; i < ie; i += 32) {      // 32 independent loads in flight: one round trip for the 25 rows per lane of the n = 75 prior
-                    double jv[32];
+                for (int i = ib; i < ie; i += PG_UN) {      // 32 independent loads in flight: one round trip for the 25 rows per lane of the n = 75 prior
+                    double jv[PG_UN];
 #pragma unroll
-                    for (int u = 0; u < 32; ++u) jv[u] = J0[(i + u < ie ? i + u : ib) * n + col];
+                    for (int u = 0; u < PG_UN; ++u) jv[u] = J0[(i + u < ie ? i + u : ib) * n + col];
 #pragma unroll
-                    for (int u = 0; u < 32; ++u) if (i + u < ie) p8[u & 7] += jv[u] * sh[L_PR + i + u];
+                    for (int u = 0; u < PG_UN; ++u) if (i + u < ie) p8[u & 7] += jv[u] * sh[L_PR + i + u];
                 }
                 scr[col] = ((p8[0] + p8[1]) + (p8[2] + p8[3])) + ((p8[4] + p8[5]) + (p8[6] + p8[7]));
             }
@@ -2106,7 +2114,7 @@ UVS_DEV void backsub_candidate(const Ctx& c, const double* invd, const double* l
         gd += px[1] * (dl + t); dd2 += px[2] * dl * dl; step2 += dl * dl; xc2 += v * v;
     }
     // lines: delta(4) = -Hinv g - sum_s Y[s] delta_pose
-    constexpr int LNB = 4;
+    constexpr int LNB = BS_LNB;
     const int* lbeg = c.bi + h.i_ln_beg;
     for (int k = lk0 + tid; k < lk1; k += NT) {
         const int b0 = lbeg[k], b1 = lbeg[k + 1];

@@ -1357,12 +1357,12 @@ void uvs_large_set_landmark_x2(uvs_solver* s, double all_ranks_x2) { if (s) { au
 int uvs_large_need_linearize(const uvs_solver* s) { return s && s->L.active && !s->L.done && s->L.need_lin; }
 int uvs_large_done(const uvs_solver* s) { return !s || !s->L.active || s->L.done; }
 double* uvs_large_reduced(uvs_solver* s, int* n) { if (n) *n = LG_RED; return s ? s->L.d_reduced : nullptr; }     // DEVICE pointer; [LG_ACC+1] is a MAX entry
-double* uvs_large_scalars(uvs_solver* s, int* n) { if (n) *n = 5; return s ? s->L.d_sc5 : nullptr; }             // DEVICE pointer
+double* uvs_large_scalars(uvs_solver* s, int* n) { if (n) *n = 6; return s ? s->L.d_sc5 : nullptr; }             // DEVICE pointer; [5] = this rank's "time is up" vote (SUM over ranks > 0 ends the solve on every rank)
 
 // host-staged access to the two exchange vectors (which = 0: reduced[LG_RED], 1: scalars[5]); set != 0 writes host -> device
 int uvs_large_exchange_host(uvs_solver* s, int which, double* buf, int set) {
     if (!s || !s->L.active || !buf) return UVS_ERR_INVALID_ARG;
-    double* d = which == 0 ? s->L.d_reduced : s->L.d_sc5; const size_t n = which == 0 ? LG_RED : 5;
+    double* d = which == 0 ? s->L.d_reduced : s->L.d_sc5; const size_t n = which == 0 ? LG_RED : 6;
     HIPCHK(s, hipSetDevice(s->device));
     if (set) HIPCHK(s, hipMemcpy(d, buf, n * 8, hipMemcpyHostToDevice)); else HIPCHK(s, hipMemcpy(buf, d, n * 8, hipMemcpyDeviceToHost));
     return UVS_OK;
@@ -1387,9 +1387,13 @@ int uvs_large_step(uvs_solver* s) {
     KOpts ko = make_kopts(s->opts, 0);
     hipLaunchKernelGGL(k_large_solve, dim3(1), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, L.d_reduced, L.first ? 1 : 0, L.radius, L.d_out, LargeCtl{nullptr, 0, 0}, L.d_fimg);
     hipLaunchKernelGGL(k_large_backsub, dim3(L.grid + 1), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, L.sel, L.d_bsums, LargeCtl{nullptr, 0, 0}, L.grid, L.d_out);
-    hipLaunchKernelGGL(k_large_sum_bsums, dim3(1), dim3(256), 0, s->stream, L.d_bsums, L.n_chunks, L.d_sc5, LargeCtl{nullptr, 0, 0});
+    hipLaunchKernelGGL(k_large_sum_bsums, dim3(1), dim3(256), 0, s->stream, L.d_bsums, L.n_chunks, L.d_sc5, LargeCtl{nullptr, 0, 0}, 0LL);
     HIPCHK(s, hipGetLastError());
     HIPCHK(s, hipStreamSynchronize(s->stream));
+    // options.max_solver_time_in_seconds on the host-driven loop: this process's vote travels as scalar [5], so that ranks which all-reduce the scalars decide together
+    const uvs_options& o = s->opts;
+    const double vote = (o.max_solver_time_in_seconds > 0.0 && L.it > 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - L.t_begin).count() >= o.max_solver_time_in_seconds) ? 1.0 : 0.0;
+    if (o.max_solver_time_in_seconds > 0.0) HIPCHK(s, hipMemcpy(L.d_sc5 + 5, &vote, 8, hipMemcpyHostToDevice));
     return UVS_OK;
 }
 
@@ -1398,7 +1402,7 @@ int uvs_large_step(uvs_solver* s) {
 int uvs_large_decide(uvs_solver* s) {
     if (!s || !s->L.active) return UVS_ERR_INVALID_ARG;
     auto& L = s->L; const uvs_options& o = s->opts;
-    double out[LO_N + 8], sc[5];
+    double out[LO_N + 8], sc[6];
     HIPCHK(s, hipMemcpy(out, L.d_out, sizeof(double) * (LO_N + 4), hipMemcpyDeviceToHost));
     HIPCHK(s, hipMemcpy(sc, L.d_sc5, sizeof(sc), hipMemcpyDeviceToHost));
     uvs_report& rep = L.rep;
@@ -1410,7 +1414,7 @@ int uvs_large_decide(uvs_solver* s) {
     } else if (L.pending > 0) { L.cost = lc; L.gmax = gm; rep.cost[L.pending] = lc; rep.gradient_max_norm[L.pending] = gm; }
     L.pending = 0; L.need_lin = false;
     if (L.it >= o.max_num_iterations) { L.term = UVS_TERM_NO_CONVERGENCE; L.done = true; return UVS_OK; }
-    if (o.max_solver_time_in_seconds > 0.0 && L.it > 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - L.t_begin).count() >= o.max_solver_time_in_seconds) {      // the host-driven loop uses the host's clock
+    if (o.max_solver_time_in_seconds > 0.0 && L.it > 0 && sc[5] > 0.0) {      // the host's clock, read in uvs_large_step; the vote is part of the scalars the ranks all-reduce, so every rank stops at the same iteration
         L.term = UVS_TERM_MAX_TIME; L.done = true; return UVS_OK;
     }
     if (L.gmax <= o.gradient_tolerance) { L.term = UVS_TERM_GRADIENT_TOL; L.done = true; return UVS_OK; }
@@ -1567,6 +1571,9 @@ int uvs_large_solve_fused(uvs_solver* s, const uvs_window* w, uvs_state* out, uv
     int rc = upload_windows(s, 1, arr, false, s->chunk_wgs());
     if (rc != UVS_OK) return rc;
     auto& L = s->L; const DevWin& h = s->hdrs[0]; const uvs_options& o = s->opts;
+    // relocalization blocks are per-landmark, so a landmark shard may hold none of them while the all-reduced system carries the other ranks' relo_Pose rows: a rank
+    // cannot tell from its own shard whether relo_Pose is a free block.  Not taken by a multi-rank solve (NO rank may pass n_relo_obs > 0; one rank takes them).
+    if (L.nranks > 1 && w->n_relo_obs > 0) { s->err = "relocalization blocks are not taken by a landmark-sharded solve over several ranks"; return UVS_ERR_UNSUPPORTED; }
     {
         double* keep_ctl = L.d_ctl; uvs_report* keep_rep = L.d_rep; void* keep_comm = L.comm; const int keep_rank = L.rank, keep_nranks = L.nranks; double* keep_fimg = L.d_fimg;
         L = uvs_solver::Large{L.active, 0, 0, 0, 0, 0, 0, 0, 0, true, true, false, 0, 2, 0, 0, 0, 0, L.d_state, L.d_partials, L.d_reduced, L.d_bsums, L.d_out, L.d_sc5, L.cap_partials, L.cap_bsums, {}};
@@ -1608,7 +1615,7 @@ int uvs_large_solve_fused(uvs_solver* s, const uvs_window* w, uvs_state* out, uv
         hipLaunchKernelGGL(k_large_solve, dim3(1), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, L.d_reduced, 0, 0.0, L.d_out, lc, L.d_fimg);
         hipLaunchKernelGGL(k_large_backsub, dim3(L.grid + 1), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, 0, L.d_bsums, lc, L.grid, L.d_out);
         if (L.comm) {
-            hipLaunchKernelGGL(k_large_sum_bsums, dim3(1), dim3(256), 0, s->stream, L.d_bsums, L.n_chunks, L.d_sc5, lc);
+            hipLaunchKernelGGL(k_large_sum_bsums, dim3(1), dim3(256), 0, s->stream, L.d_bsums, L.n_chunks, L.d_sc5, lc, ko.max_ticks);
             const int e = r.AllReduce(L.d_sc5, L.d_sc5, 8, kNcclDouble, kNcclSum, L.comm, s->stream); if (e != 0) return fused_abort(s, "ncclAllReduce(step scalars) failed");
             hipLaunchKernelGGL(k_large_decide, dim3(1), dim3(256), 0, s->stream, L.d_ctl, L.d_state, L.d_out, L.d_sc5, L.d_reduced, ko, L.d_rep, (const double*)nullptr, 0);
         } else hipLaunchKernelGGL(k_large_decide, dim3(1), dim3(256), 0, s->stream, L.d_ctl, L.d_state, L.d_out, L.d_sc5, L.d_reduced, ko, L.d_rep, (const double*)L.d_bsums, L.n_chunks);

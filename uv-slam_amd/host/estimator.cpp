@@ -199,7 +199,10 @@ void Estimator::optimization() {      // estimator.cpp:761-1233
     double2vector();
     vector2double();
     {
+        // every by-value state field of the descriptor is refreshed: the solve moved para_Ex_Pose / para_Td too when they are estimated, and the prior
+        // must be linearized at -- and remember as x0 -- the post-solve values (the reference packs again at :1004 before it marginalizes)
         std::memcpy(w.pose, para_Pose, sizeof(w.pose)); std::memcpy(w.speedbias, para_SpeedBias, sizeof(w.speedbias));
+        std::memcpy(w.ex_pose, para_Ex_Pose[0], sizeof(w.ex_pose)); w.td = para_Td[0][0];
         MarginalizationInfo* marginalization_info = new MarginalizationInfo();
         const auto t0 = std::chrono::steady_clock::now();
         const int rc = uvs_marginalize_resident(solver, &w, marginalization_flag == MARGIN_OLD ? 0 : 1, &marginalization_info->prior);

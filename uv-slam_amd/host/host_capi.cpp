@@ -3,6 +3,7 @@
 // file, runs optimization() (HIP solve + marginalization), and writes the resulting members back to a flat file.
 #include <cstdio>
 #include <map>
+#include <string>
 #include "estimator.h"
 #include "window_io.h"
 
@@ -101,6 +102,16 @@ extern "C" int uvs_host_replay_window(const char* in_path, const char* out_path,
             double tail[2] = {est.relo_relative_yaw, est.relocalization_info ? 1.0 : 0.0}; std::fwrite(tail, 8, 2, f);
         }
         std::fclose(f);
+        // side file <out>.x0: the linearization point the new prior remembers, per kept block {kind, frame, size, x0[9]} -- the test of "the prior is built
+        // at the POST-solve extrinsic / time offset" (estimator.cpp:1004 packs again before marginalizing) reads it
+        if (FILE* fx = std::fopen((std::string(out_path) + ".x0").c_str(), "wb")) {
+            for (int b = 0; pn > 0 && b < p.n_blocks; ++b) {
+                double rec[12] = {(double)p.block_kind[b], (double)p.block_frame[b], (double)p.block_size[b]};
+                for (int k = 0; k < 9; ++k) rec[3 + k] = k < p.block_size[b] ? p.x0[p.x0_off[b] + k] : 0.0;
+                std::fwrite(rec, 8, 12, fx);
+            }
+            std::fclose(fx);
+        }
     } catch (const std::exception& e) { std::fprintf(stderr, "uvs_host_replay_window: %s\n", e.what()); return -7; }
     return 0;
 }
