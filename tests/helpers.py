@@ -166,3 +166,40 @@ def prior_information(p, n_frame_cols=165):
         cols += [base + k for k in range(loc)]; src += [idx + k for k in range(loc)]
     Jc = J0[:, src]
     return Jc.T @ Jc, Jc.T @ r0, cols
+
+
+def first_divergence(rg, ro, opts=None):
+    """Where and how narrowly two LM traces (uvs_report of the HIP solver, of the oracle) part ways.
+    Returns None when iteration count, accept / reject sequence and termination agree; otherwise a dict with the iteration `k` of the first
+    differing DECISION, which test decided there and how close both sides were to its threshold:
+      kind 'accept'   : the Ceres step test  rho = (cost - candidate) / model_cost_change > min_relative_decrease (estimator.cpp:982-994 -> trust_region_minimizer,
+                        SURVEY.md Appendix B.5); margin = |rho - min_relative_decrease| on each side, rel_margin = margin / max(|rho|, min_relative_decrease)
+      kind 'valid'    : model_cost_change > 0 (an invalid step); margin = |model_cost_change| relative to the cost
+      kind 'terminate': same decisions up to the shorter trace, one side stopped (function / parameter tolerance, Appendix B.4); margin = distance of
+                        |cost - candidate| / cost from function_tolerance on each side (the test that ends these windows)
+    Up to iteration k both solvers made the same decisions, so their states there differ by round-off only and the quantities are comparable."""
+    o = opts if opts is not None else abi.default_options()
+    ng, no = int(rg.num_iterations), int(ro.num_iterations)
+    ag, ao = list(rg.accepted[:ng + 1]), list(ro.accepted[:no + 1])
+    if ng == no and ag == ao and rg.termination == ro.termination: return None
+    n = min(ng, no)
+    k = next((i for i in range(1, n + 1) if ag[i] != ao[i]), None)
+    if k is None:
+        k = n      # identical decisions; one side went on (or the two name different termination reasons at the same iteration)
+        def ft(r):
+            c, cand = r.cost[k], r.candidate_cost[k]
+            return abs(abs(c - cand) / c - o.function_tolerance) if c > 0 else float("nan")
+        return dict(k=k, kind="terminate", gpu=(ng, int(rg.termination)), oracle=(no, int(ro.termination)), margin_gpu=ft(rg), margin_oracle=ft(ro),
+                    rel_margin=max(ft(rg), ft(ro)) / o.function_tolerance)
+    if -1 in (ag[k], ao[k]):
+        mg, mo = rg.model_cost_change[k], ro.model_cost_change[k]
+        return dict(k=k, kind="valid", gpu=ag[k], oracle=ao[k], margin_gpu=abs(mg), margin_oracle=abs(mo), rel_margin=max(abs(mg), abs(mo)) / max(abs(rg.cost[k]), 1e-300))
+    pg, po = rg.relative_decrease[k], ro.relative_decrease[k]
+    thr = o.min_relative_decrease
+    # conditioning of rho = (cost - candidate) / model_cost_change: both costs are sums of ~1e3 squared residuals, so their difference carries an absolute
+    # round-off of a few 1e-16 * cost however it is summed; rho_noise = 4e-16 * cost / |model_cost_change| is the size of that noise in units of rho
+    noise = lambda r: 4e-16 * abs(r.cost[k]) / max(abs(r.model_cost_change[k]), 1e-300)
+    return dict(k=k, kind="accept", gpu=ag[k], oracle=ao[k], rho_gpu=pg, rho_oracle=po, margin_gpu=abs(pg - thr), margin_oracle=abs(po - thr),
+                rel_margin=max(abs(pg - thr), abs(po - thr)) / max(abs(pg), abs(po), thr),
+                mcc_over_cost=(abs(rg.model_cost_change[k]) / abs(rg.cost[k]), abs(ro.model_cost_change[k]) / abs(ro.cost[k])), rho_noise=(noise(rg), noise(ro)),
+                cost_rel_diff=abs(rg.cost[k] - ro.cost[k]) / abs(ro.cost[k]), cand_rel_diff=abs(rg.candidate_cost[k] - ro.candidate_cost[k]) / abs(ro.candidate_cost[k]))

@@ -148,7 +148,7 @@ def test_baseline_batch_is_bitwise_reproducible(solver, oracle):
     and a window solved inside the batch equals the same window solved alone."""
     # the benchmarked batch: every window carries the n = 75 prior built by the product's own marginalization (bench.py does the same)
     marg = lambda win, flag: solver.marginalize(win, flag)
-    ws = [synth.make_window(200 + i, with_prior=True, marginalize_fn=marg) for i in range(256)]
+    ws = [synth.make_window(i, with_prior=True, marginalize_fn=marg) for i in range(256)]      # window indices 0..255: exactly the batch bench.py times on rank 0
     assert all(w.prior is not None and w.prior.n == 75 for w in ws)
     solver.upload(ws); solver.solve_resident(); s1, r1 = solver.download()
     solver.upload(ws); solver.solve_resident(); s2, r2 = solver.download()

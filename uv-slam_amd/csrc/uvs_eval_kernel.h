@@ -35,7 +35,7 @@ __global__ __launch_bounds__(NT) void k_evaluate(char* blob, double* ws, KOpts o
     __syncthreads();
     const double* RF = sh + L_RF; const double* ric = sh + L_EX; const double* tic = sh + L_EX + 9;
     const double* invd = c.bd + h.d_invd; const double* line = c.bd + h.d_line;
-    double cost = prior_residual(c);
+    double cost = prior_residual_rows(c);
     if (tid < h.prior_n) out.prior_r[tid] = sh[L_PR + tid];
     for (int ob = tid; ob < h.n_pt_obs; ob += NT) {
         const int lm = c.bi[h.i_pt_lm + ob], fi = c.bi[h.i_pt_fi + ob], fj = c.bi[h.i_pt_fj + ob];

@@ -196,7 +196,7 @@ __global__ __launch_bounds__(NT) void k_large_backsub(char* blob, double* ws, KO
     if ((int)blockIdx.x == n_chunk_wgs) {      // the LAST workgroup: frame part of the candidate cost (prior + IMU at x_c), beside the landmark chunks
         prior_dx(c, sh + L_XC);
         __syncthreads();
-        double cc = prior_residual(c) + cost_pass(c, sh + L_XC, nullptr, nullptr, 0, 0, 0, 0, true);
+        double cc = prior_quad(c) + cost_pass(c, sh + L_XC, nullptr, nullptr, 0, 0, 0, 0, true);
         double s4[4] = {cc, 0, 0, 0}, mx = 0.0;
         block_reduce(sh, s4, &mx);
         if (tid == 0) out[LO_FRAMECOST] = s4[0];

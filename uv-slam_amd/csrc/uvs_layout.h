@@ -83,7 +83,7 @@ struct DevWin {
     int32_t d_line;                   // [n_lines][4]
     int32_t d_lnmeas;                 // 9 x ln_stride : sp xyz, ep xyz, vp xyz
     int32_t d_imu;                    // n_imu x UVS_IMU_STRIDE
-    int32_t d_prior;                  // J0[n*n] J0^T[n*n] r0[n] b0[n] x0[144]
+    int32_t d_prior;                  // J0[n*n] r0[n] pad[n] x0[144]   (round 4: no transposed copy -- the solve reads J0 once, in setup_window)
     int32_t i_pt_lm, i_pt_fi, i_pt_fj, i_pt_beg;      // obs arrays + CSR begin[n_points+1]
     int32_t i_ln_lm, i_ln_fj, i_ln_vp, i_ln_beg;      // obs arrays + CSR begin[n_lines+1]
     int32_t i_imu;                    // [n_imu][2] : frame_i, skip
@@ -99,9 +99,9 @@ struct DevWin {
     int32_t w_ln_Y, w_ln_x;           // Y store 24*n_ln_obs ; per line UVS_LN_X doubles {Hinv*g[4], g[4], dd[4], H[10]}
     int32_t w_imu;                    // per block: Jraw[450] Jw[450] rraw[15] rw[15] (pad 936)
     int32_t w_out;                    // final state: frames[UVS_XDIM] | inv_depth[n_points] | line_orth[4 n_lines] (k_solve; the large path reads the cur buffers)
-    int32_t w_prior_img;              // J0^T J0 scattered into S block layout: n_pblk x 272 doubles (written by setup_window, added per linearization)
+    int32_t w_prior_h0;               // the prior's quadratic form, written by setup_window: H0 = J0^T J0 dense [n][n] | g0 = J0^T r0 at UVS_PH_G0 | c0 = r0^T r0 / 2 at UVS_PH_C0 | diag(H0) by S index [176] at UVS_PH_HD
     int32_t n_pblk;                   // pose blocks of S the prior touches (ids in i_prior + 352)
-    int32_t n_cimg, i_cimg, w_prior_cimg;   // compact prior image: entries of J0^T J0 that are structurally non-zero in S (17 % of the touched blocks): int32 source index in the dense image [n_cimg] then S offset [n_cimg]; values in the workspace
+    int32_t n_cimg, i_cimg;           // entries of H0 that are structurally non-zero in S: int32 index into the dense n x n H0 [n_cimg], then S offset [n_cimg]
     int32_t ws_doubles;
     int32_t blob_bytes;
     int32_t cur_sel;                  // written by the kernel: which landmark buffer holds the final state
@@ -111,5 +111,9 @@ struct DevWin {
     int32_t redamp_ok;                // 1: k_solve may re-damp the last linearization after a rejected step instead of linearizing again (no pseudo-frame blocks; every line chunk has room for the tables)
 };
 
+#define UVS_PH_G0(n) ((((n) * (n)) + 1) & ~1)
+#define UVS_PH_C0(n) (UVS_PH_G0(n) + UVS_MAX_PRIOR_DIM)
+#define UVS_PH_HD(n) (UVS_PH_C0(n) + 8)
+#define UVS_PH_DOUBLES(n) (UVS_PH_HD(n) + UVS_RD)
 #define UVS_WIMU_STRIDE 936
 #define UVS_LN_X 24               // workspace doubles per line: Hinv g [4] | g [4] | damping [4] | undamped H = J_l^T J_l, lower packed [10] | 2 spare

@@ -55,8 +55,8 @@ static constexpr int L_DINV = L_DD + UVS_RD;   // 1 / L_kk of the Cholesky facto
 static constexpr int L_RF = L_DINV + UVS_RD;   // 11 rotation matrices (row-major) of the CURRENT evaluation point; slot 12 (offset 108) = relo_Pose's
 static constexpr int L_EX = L_RF + 120;        // ric[9] tic[3]
 static constexpr int L_PDX = L_EX + 16;        // prior dx
-static constexpr int L_PR = L_PDX + UVS_MAX_PRIOR_DIM;   // prior residual
-static constexpr int L_PRC = L_PR + UVS_MAX_PRIOR_DIM;   // prior residual at the CANDIDATE (becomes the current one when the step is accepted)
+static constexpr int L_PR = L_PDX + UVS_MAX_PRIOR_DIM;   // prior: y = H0 dx of the current point (k_evaluate: the residual vector r0 + J0 dx)
+static constexpr int L_PRC = L_PR + UVS_MAX_PRIOR_DIM;   // y = H0 dx at the CANDIDATE (becomes the current one when the step is accepted)
 static constexpr int L_RED = L_PRC + UVS_MAX_PRIOR_DIM;  // reduction scratch
 static constexpr int L_CTRL = L_RED + (5 * NW > 24 ? 5 * NW : 24);      // block_reduce uses 5 doubles per wave (an 8-wave build wrote waves 5..7 into the control words: the wrong final costs of the 512-thread experiments)
 static constexpr int L_PROF = L_CTRL + 32;      // per-phase cycle counters (debug launches only)
@@ -209,7 +209,7 @@ UVS_DEV void prior_dx(const Ctx& c, const double* x) {
     if (h.prior_n > 0 && tid < h.prior_nb) {
         const int* pt = c.bi + h.i_prior;
         const int kind = pt[tid], frame = pt[16 + tid], size = pt[32 + tid], idx = pt[48 + tid];
-        const double* x0g = c.bd + h.d_prior + 2 * h.prior_n * h.prior_n + 2 * h.prior_n + 9 * tid;      // stride 9 per block (pack_window): independent of the table
+        const double* x0g = c.bd + h.d_prior + h.prior_n * h.prior_n + 2 * h.prior_n + 9 * tid;      // stride 9 per block (pack_window): independent of the table
         double x0[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k) x0[k] = x0g[k];
@@ -224,26 +224,30 @@ UVS_DEV void prior_dx(const Ctx& c, const double* x) {
         }
     }
 }
-// r = r0 + J0 dx (marginalization_factor.cpp:364) after prior_dx + barrier; fills L_PR, returns this thread's 0.5 r^2 share.
-// Every row's dot product is split over up to 4 lanes (NT / n) with 8 loads in flight each: the 45 KB of J0 come from L2 / HBM on every
-// evaluation and a 75-lane, 75-deep dependent chain paid the full memory latency 75 times.  Partials meet in the (dead) S region;
+// The prior inside the solve (marginalization_factor.cpp:333-381: r = r0 + J0 dx, Jacobian J0 constant) in its QUADRATIC form: with H0 = J0^T J0,
+// g0 = J0^T r0, c0 = r0^T r0 / 2 (built once per solve by setup_window, in the workspace)
+//     cost = c0 + g0 . dx + dx . (H0 dx) / 2 ,      gradient = g0 + H0 dx ,
+// so ONE symmetric n x n mat-vec y = H0 dx serves the cost of an evaluation point and -- when that point is linearized -- the gradient; the
+// n x n Jacobian is read once per solve instead of twice per LM iteration (J0^T for the residual, J0 for J0^T r: 2 x 45 KB of a window's
+// 350 KB working set, and the transposed copy leaves the blob).  After prior_dx + barrier; fills sh[dst .. dst + n) with y and returns this
+// thread's share of the prior cost.  Every row's dot product is split over up to 4 lanes with PR_UN loads in flight each (H0 comes from
+// L2 / HBM on every evaluation; a 75-deep dependent chain would pay the memory latency 75 times).  Partials meet in the (dead) S region;
 // contains one workgroup barrier, so all threads must call it.
-UVS_DEV double prior_residual(const Ctx& c, int dst = L_PR) {
+UVS_DEV double prior_quad(const Ctx& c, int dst = L_PR) {
     const DevWin& h = *c.hdr;
     const int n = h.prior_n, tid = lane_tid();
     double cost = 0.0;
     if (n <= 0) return cost;
+    const double* H0 = c.ws + h.w_prior_h0;
     const int parts = (NT / n) < 4 ? (NT / n) : 4;
     const int part = tid / n, row = tid - part * n;
     if (part < parts) {
-        const double* J0T = c.bd + h.d_prior + n * n;      // transposed copy: consecutive lanes read consecutive addresses
         const int kb = (n * part) / parts, ke = (n * (part + 1)) / parts;
-        // 24 independent loads in flight per trip: the n = 75 prior (19 rows per lane) is ONE HBM/L2 round trip, not three
         double p8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (int k = kb; k < ke; k += PR_UN) {
             double jv[PR_UN];
 #pragma unroll
-            for (int u = 0; u < PR_UN; ++u) jv[u] = J0T[(k + u < ke ? k + u : kb) * n + row];
+            for (int u = 0; u < PR_UN; ++u) jv[u] = H0[(k + u < ke ? k + u : kb) * n + row];      // H0 is symmetric: row k, entry `row` -- consecutive lanes, consecutive addresses
 #pragma unroll
             for (int u = 0; u < PR_UN; ++u) if (k + u < ke) p8[u & 7] += jv[u] * c.sh[L_PDX + k + u];
         }
@@ -251,9 +255,36 @@ UVS_DEV double prior_residual(const Ctx& c, int dst = L_PR) {
     }
     __syncthreads();
     if (tid < n) {
-        double s = c.bd[h.d_prior + 2 * n * n + tid];
-        for (int p = 0; p < parts; ++p) s += c.sh[L_S + 128 * p + tid];
-        c.sh[dst + tid] = s;
+        double y = c.sh[L_S + tid];
+        for (int p = 1; p < parts; ++p) y += c.sh[L_S + 128 * p + tid];
+        c.sh[dst + tid] = y;
+        cost = c.sh[L_PDX + tid] * (c.ws[h.w_prior_h0 + UVS_PH_G0(n) + tid] + 0.5 * y);
+        if (tid == 0) cost += c.ws[h.w_prior_h0 + UVS_PH_C0(n)];
+    }
+    return cost;
+}
+// this thread's share of the prior cost at the point whose dx is staged in L_PDX and whose y = H0 dx sits in sh[src ..)
+UVS_DEV double prior_cost_share(const Ctx& c, int src) {
+    const DevWin& h = *c.hdr;
+    const int n = h.prior_n, tid = lane_tid();
+    double cost = 0.0;
+    if (tid < n) {
+        cost = c.sh[L_PDX + tid] * (c.ws[h.w_prior_h0 + UVS_PH_G0(n) + tid] + 0.5 * c.sh[src + tid]);
+        if (tid == 0) cost += c.ws[h.w_prior_h0 + UVS_PH_C0(n)];
+    }
+    return cost;
+}
+// The residual vector itself, r = r0 + J0 dx (marginalization_factor.cpp:364), for uvs_evaluate / the host marginalization path: one lane per row,
+// J0 read row-wise (not a hot path).  After prior_dx + barrier; fills L_PR, returns this thread's 0.5 r^2.
+UVS_DEV double prior_residual_rows(const Ctx& c) {
+    const DevWin& h = *c.hdr;
+    const int n = h.prior_n, tid = lane_tid();
+    double cost = 0.0;
+    if (tid < n) {
+        const double* Jr = c.bd + h.d_prior + (size_t)tid * n;
+        double s = c.bd[h.d_prior + n * n + tid];
+        for (int k = 0; k < n; ++k) s += Jr[k] * c.sh[L_PDX + k];
+        c.sh[L_PR + tid] = s;
         cost = 0.5 * s * s;
     }
     return cost;
@@ -1173,8 +1204,8 @@ struct ImuN { d4_t n00[IMU_SLOTS], n10[IMU_SLOTS], n11[IMU_SLOTS]; };
 
 // rotations of the evaluation point + prior residual (L_PR); returns this lane's share of the prior cost
 // mode 0: everything.  The persistent kernel knows more: after an ACCEPTED step (mode 1) x is the candidate the cost pass has just
-// evaluated, so the rotations staged in L_RF / L_EX are already x's and the prior residual r0 + J0 dx sits in L_PRC (the 75 x 75
-// mat-vec from HBM is not repeated); after a REJECTED or invalid step (mode 2) x and L_PR are unchanged, only the rotations are restaged.
+// evaluated, so the rotations staged in L_RF / L_EX are already x's and the prior's y = H0 dx sits in L_PRC (the 75 x 75
+// mat-vec from HBM is not repeated); after a REJECTED or invalid step (mode 2) x and L_PR are unchanged, the rotations and dx are restaged.
 UVS_DEV double lin_prep(const Ctx& c, const double* x, int mode = 0) {
     UVS_PROF(c, P_MISC);
     const int tid = lane_tid(), n = c.hdr->prior_n;
@@ -1182,13 +1213,12 @@ UVS_DEV double lin_prep(const Ctx& c, const double* x, int mode = 0) {
         stage_rotations(c, x);
         prior_dx(c, x);
         __syncthreads();
-        return prior_residual(c);
+        return prior_quad(c);
     }
-    if (mode == 2) stage_rotations(c, x);
-    double r = 0.0;
-    if (tid < n) { r = c.sh[(mode == 1 ? L_PRC : L_PR) + tid]; if (mode == 1) c.sh[L_PR + tid] = r; }
+    if (mode == 2) { stage_rotations(c, x); prior_dx(c, x); __syncthreads(); }      // L_PDX held the REJECTED candidate's dx; y = H0 dx of x is still in L_PR
+    else if (tid < n) c.sh[L_PR + tid] = c.sh[L_PRC + tid];                          // mode 1: L_PDX and L_PRC are the accepted candidate's
     __syncthreads();
-    return 0.5 * r * r;
+    return prior_cost_share(c, L_PR);
 }
 // IMU normal-equation tiles; staged in the S region, so it runs when no landmark chunk is staged there (after the last gather,
 // right before the assembly: the 9 accumulator tiles per wave then live only across lin_assemble)
@@ -1909,50 +1939,28 @@ UVS_DEV void lin_assemble(const Ctx& c, const double* x, bool first, double radi
             __syncthreads();
         }
     }
-    // prior: H0 = J0^T J0 (precomputed), g = J0^T r
+    // prior: H0 = J0^T J0 and g = g0 + H0 dx (y = H0 dx came with the cost of this point: prior_quad)
     if (h.prior_n > 0 && mode != 2) {
         const int n = h.prior_n;
         const int* cm = c.bi + h.i_prior + 80;
-        const double* J0 = c.bd + h.d_prior;
-        {   // H0 = J0^T J0 (setup_window): compact image, value + precomputed S offset per structurally non-zero entry
-            const double* cimg = c.ws + h.w_prior_cimg;
+        {   // H0 entries that are structurally non-zero in S: host table of (index into the dense n x n H0, S offset)
+            const double* H0 = c.ws + h.w_prior_h0;
             const int tot = h.n_cimg;
-            const int* off = c.bi + h.i_cimg + tot;
-            for (int t0 = tid; t0 < tot; t0 += 16 * NT) {      // up to 32 independent loads in flight per trip (one trip for the 10-frame prior)
-                int idx[16]; double v[16], cur[16];
+            const int* src = c.bi + h.i_cimg; const int* off = src + tot;
+            for (int t0 = tid; t0 < tot; t0 += 16 * NT) {      // up to 16 independent load pairs in flight per trip (one trip for the 10-frame prior)
+                int idx[16], sr[16]; double v[16], cur[16];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) { const int t = t0 + u * NT; const bool in = t < tot; idx[u] = in ? off[t] : -1; v[u] = in ? cimg[t] : 0.0; }
+                for (int u = 0; u < 16; ++u) { const int t = t0 + u * NT; const bool in = t < tot; idx[u] = in ? off[t] : -1; sr[u] = in ? src[t] : 0; }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v[u] = H0[sr[u]];
 #pragma unroll
                 for (int u = 0; u < 16; ++u) cur[u] = sh[L_S + (idx[u] >= 0 ? idx[u] : 0)];
 #pragma unroll
                 for (int u = 0; u < 16; ++u) if (idx[u] >= 0) sh[L_S + idx[u]] = cur[u] + v[u];
             }
-            if (tid < UVS_RD) sh[L_HD + tid] += c.ws[h.w_prior_img + h.n_pblk * UVS_BLK_SZ + tid];      // diag(J0^T J0) by S index (setup_window)
+            if (tid < UVS_RD) sh[L_HD + tid] += c.ws[h.w_prior_h0 + UVS_PH_HD(n) + tid];      // diag(J0^T J0) by S index (setup_window)
         }
-        {   // g += J0^T r, each column's dot product split over up to 3 lanes; partials in LDS words that are free right now (x_c, rhs, 1/L_kk)
-            const int parts = (NT / n) < 3 ? (NT / n) : 3;
-            const int part = tid / n, col = tid - part * n;
-            double* scr = part == 0 ? sh + L_XC : part == 1 ? sh + L_DLT : sh + L_DINV;
-            if (part < parts) {
-                const int ib = (n * part) / parts, ie = (n * (part + 1)) / parts;
-                double p8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                for (int i = ib; i < ie; i += PG_UN) {      // 32 independent loads in flight: one round trip for the 25 rows per lane of the n = 75 prior
-                    double jv[PG_UN];
-#pragma unroll
-                    for (int u = 0; u < PG_UN; ++u) jv[u] = J0[(i + u < ie ? i + u : ib) * n + col];
-#pragma unroll
-                    for (int u = 0; u < PG_UN; ++u) if (i + u < ie) p8[u & 7] += jv[u] * sh[L_PR + i + u];
-                }
-                scr[col] = ((p8[0] + p8[1]) + (p8[2] + p8[3])) + ((p8[4] + p8[5]) + (p8[6] + p8[7]));
-            }
-            __syncthreads();
-            if (tid < n && cm[tid] >= 0) {
-                double sg = sh[L_XC + tid];
-                if (parts > 1) sg += sh[L_DLT + tid];
-                if (parts > 2) sg += sh[L_DINV + tid];
-                sh[L_G + cm[tid]] += sg;
-            }
-        }
+        if (tid < n && cm[tid] >= 0) sh[L_G + cm[tid]] += c.ws[h.w_prior_h0 + UVS_PH_G0(n) + tid] + sh[L_PR + tid];      // one writer per S index (the IMU adds ended with a barrier)
     }
     __syncthreads();
     UVS_PROF(c, P_AS_ADD);
@@ -2247,29 +2255,27 @@ UVS_DEV void setup_window(const Ctx& c, double* blob_rw, bool with_prior_image =
         imu_whiten_block(blk + UVS_IMU_COV, blk + UVS_IMU_W, c.sh + L_S + 256 * wv, lane);
     }
     if (h.prior_n > 0 && with_prior_image) {
-        // prior normal matrix J0^T J0, computed ONCE per solve straight into S's block layout ("image" of the touched pose blocks in the
-        // workspace): every image entry is owned by one thread (no read-modify-write), J0 is staged in LDS first (coalesced)
+        // The prior's quadratic form, ONCE per solve: H0 = J0^T J0 (dense n x n, both triangles), g0 = J0^T r0, c0 = r0^T r0 / 2 and diag(H0) by S index, in
+        // the workspace.  J0 is staged in LDS (coalesced); the 16 x 16 tiles of H0 in the prior's own column order are a true contraction over the
+        // n rows of J0: tile(ta, tb)[r][c] = sum_i J0[i][16 ta + r] J0[i][16 tb + c], ceil(n / 4) v_mfma_f64_16x16x4_f64 per tile, one tile per wave
+        // at a time (A[r][k]: lane r + 16k, B[k][c]: lane c + 16k), operands five steps at a time.  Only the lower tiles are computed; a product
+        // commutes bitwise and both triangles sum over i in the same order, so the mirrored entries ARE the upper triangle.
         const int n = h.prior_n;
         const double* J0 = blob_rw + h.d_prior;
         double* Jl = c.sh + L_S + 2048;                      // [n][n], beside the whitening scratch
-        const int* inv = c.bi + h.i_prior + 80 + UVS_MAX_PRIOR_DIM;
-        const int* pb = inv + UVS_RD;
+        double* r0l = c.sh + L_S + 1024;                     // [n]
+        const int* inv = c.bi + h.i_prior + 80 + UVS_MAX_PRIOR_DIM;      // S index -> prior column
         for (int t = tid; t < n * n; t += NT) Jl[t] = J0[t];
+        if (tid < n) r0l[tid] = J0[n * n + tid];
         __syncthreads();
-        double* img = c.ws + h.w_prior_img;
-        // column map and block list into LDS: a dependent global load per use otherwise (one wave per SIMD: ~1.5 k cycles each)
-        int* invL = (int*)(c.sh + L_S + 1024); int* pbL = invL + UVS_RD;
-        if (tid < UVS_RD) invL[tid] = inv[tid];
-        if (tid < h.n_pblk) pbL[tid] = pb[tid];
-        __syncthreads();
-        // the 16x16 tiles are a true contraction over the n rows of J0: tile(fa, fb)[r][c] = sum_i J0[i][col(fa, r)] J0[i][col(fb, c)],
-        // 19 x v_mfma_f64_16x16x4_f64 per tile, one tile per wave at a time (A[r][k]: lane r + 16k, B[k][c]: lane c + 16k).
-        // Operands go out five steps at a time.
+        double* H0 = c.ws + h.w_prior_h0;
         const int li = lane & 15, lk = lane >> 4;
-        for (int sl = wv; sl < h.n_pblk; sl += NW) {
-            const int pk = pbL[sl], fa = (pk >> 8) & 15, fb = (pk >> 12) & 15;      // the host packs (block | fa << 8 | fb << 12)
-            const int ca = invL[16 * fa + li], cb = invL[16 * fb + li];
-            const double* Ja = Jl + (ca >= 0 ? ca : 0); const double* Jb = Jl + (cb >= 0 ? cb : 0);
+        const int T = (n + 15) >> 4;
+        for (int t = wv; t < (T * (T + 1)) / 2; t += NW) {
+            int ta = 0; while (((ta + 1) * (ta + 2)) / 2 <= t) ++ta;
+            const int tb = t - (ta * (ta + 1)) / 2;
+            const int ca = 16 * ta + li, cb = 16 * tb + li;
+            const double* Ja = Jl + (ca < n ? ca : 0); const double* Jb = Jl + (cb < n ? cb : 0);
             d4_t acc = {0.0, 0.0, 0.0, 0.0};
             for (int k0 = 0; k0 < n; k0 += 20) {
                 double av[5], bv[5];
@@ -2277,30 +2283,30 @@ UVS_DEV void setup_window(const Ctx& c, double* blob_rw, bool with_prior_image =
                 for (int u = 0; u < 5; ++u) {
                     const int i = k0 + 4 * u + lk, ic = i < n ? i : n - 1;
                     const double a = Ja[ic * n], bq = Jb[ic * n];                   // unconditional loads + selects
-                    av[u] = (ca >= 0 && i < n) ? a : 0.0; bv[u] = (cb >= 0 && i < n) ? bq : 0.0;
+                    av[u] = (ca < n && i < n) ? a : 0.0; bv[u] = (cb < n && i < n) ? bq : 0.0;
                 }
 #pragma unroll
                 for (int u = 0; u < 5; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
             }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) img[sl * UVS_BLK_SZ + (lk + 4 * q) * UVS_BLK_LD + li] = acc[q];
+            for (int q = 0; q < 4; ++q) {      // C layout: row = lk + 4q (tile ta), col = li (tile tb)
+                const int ra = 16 * ta + lk + 4 * q;
+                if (ra < n && cb < n) { H0[ra * n + cb] = acc[q]; if (ta != tb) H0[cb * n + ra] = acc[q]; }
+            }
         }
-        // compact image: the structurally non-zero entries only (host tables: source index in the dense tiles, S offset), what the
-        // per-linearization add reads
-        __threadfence_block();
-        __syncthreads();
-        {
-            const int* csrc = c.bi + h.i_cimg;
-            double* cimg = c.ws + h.w_prior_cimg;
-            for (int j = tid; j < h.n_cimg; j += NT) cimg[j] = img[csrc[j]];
+        if (tid < n) {      // g0 = J0^T r0
+            double p4[4] = {0, 0, 0, 0};
+            for (int i = 0; i < n; ++i) p4[i & 3] += Jl[i * n + tid] * r0l[i];
+            H0[UVS_PH_G0(n) + tid] = (p4[0] + p4[1]) + (p4[2] + p4[3]);
         }
-        double* hdp = img + h.n_pblk * UVS_BLK_SZ;       // diag(J0^T J0) by S index (added to L_HD per linearization)
-        if (tid < UVS_RD) {
-            const int a = invL[tid];
+        if (tid == NT - 1) { double s2 = 0.0; for (int i = 0; i < n; ++i) s2 += r0l[i] * r0l[i]; H0[UVS_PH_C0(n)] = 0.5 * s2; }
+        if (tid < UVS_RD) {      // diag(J0^T J0) by S index (added to L_HD per linearization)
+            const int a = inv[tid];
             double v = 0.0;
             if (a >= 0) for (int i = 0; i < n; ++i) v += Jl[i * n + a] * Jl[i * n + a];
-            hdp[tid] = v;
+            H0[UVS_PH_HD(n) + tid] = v;
         }
+        __threadfence_block();      // the workspace entries are read by other lanes of this workgroup after the caller's barrier
     }
 }
 
@@ -2418,7 +2424,7 @@ __global__ __launch_bounds__(NT) void k_solve(char* blobs, const long long* blob
         prior_dx(c, sh + L_XC);
         __syncthreads();
         if (o.debug == 1 && tid == 0) { const long long t_ = clock64(); sh[L_WPROF + 0] += (double)(t_ - tc_); tc_ = t_; }
-        double cc_ = prior_residual(c, L_PRC);
+        double cc_ = prior_quad(c, L_PRC);
         if (o.debug == 1 && tid == 0) { const long long t_ = clock64(); sh[L_WPROF + 1] += (double)(t_ - tc_); tc_ = t_; }
         cc_ += cost_pass(c, sh + L_XC, invd[cur ^ 1], line[cur ^ 1], 0, h.n_pt_obs, 0, h.n_ln_obs, true);
         double s4[4] = {cc_, 0, 0, 0}, mx = 0.0;

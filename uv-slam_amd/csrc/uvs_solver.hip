@@ -356,10 +356,10 @@ static void fill_values(char* B, const DevWin& h, const uvs_window* w, bool td_o
     if (h.prior_n > 0) {
         const uvs_prior& p = *w->prior;
         const int n = p.n;
-        for (int r = 0; r < n; ++r) for (int cc = 0; cc < n; ++cc) { D[h.d_prior + r * n + cc] = p.linearized_jacobians[r * n + cc]; D[h.d_prior + n * n + cc * n + r] = p.linearized_jacobians[r * n + cc]; }
-        for (int r = 0; r < n; ++r) D[h.d_prior + 2 * n * n + r] = p.linearized_residuals[r];
+        std::memcpy(D + h.d_prior, p.linearized_jacobians, sizeof(double) * (size_t)n * n);      // row-major, read once per solve (setup_window builds J0^T J0, J0^T r0 from it)
+        for (int r = 0; r < n; ++r) D[h.d_prior + n * n + r] = p.linearized_residuals[r];
         // linearization point of block b at stride 9 (not at x0_off[b]): the kernel's loads of it then do not depend on a table load
-        for (int b = 0; b < p.n_blocks && b < 16; ++b) for (int k = 0; k < p.block_size[b] && k < 9; ++k) D[h.d_prior + 2 * n * n + 2 * n + 9 * b + k] = p.x0[p.x0_off[b] + k];
+        for (int b = 0; b < p.n_blocks && b < 16; ++b) for (int k = 0; k < p.block_size[b] && k < 9; ++k) D[h.d_prior + n * n + 2 * n + 9 * b + k] = p.x0[p.x0_off[b] + k];
     }
 }
 
@@ -772,12 +772,12 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
             const int b = pblk[sl] & 255, fa = (pblk[sl] >> 8) & 15, fb = (pblk[sl] >> 12) & 15;
             for (int r = 0; r < 16; ++r) for (int cc = 0; cc < 16; ++cc)
                 if (inv_s[16 * fa + r] >= 0 && inv_s[16 * fb + cc] >= 0 && (fa != fb || cc <= r)) {
-                    csrc.push_back((int)sl * UVS_BLK_SZ + r * UVS_BLK_LD + cc); coff.push_back(b * UVS_BLK_SZ + r * UVS_BLK_LD + cc);
+                    csrc.push_back(inv_s[16 * fa + r] * p.n + inv_s[16 * fb + cc]); coff.push_back(b * UVS_BLK_SZ + r * UVS_BLK_LD + cc);      // (index into the dense n x n H0 of the workspace, S offset)
                 }
         }
     }
     h.d_imu = d; d += std::max(h.n_imu, 1) * UVS_IMU_STRIDE;
-    h.d_prior = d; d += 2 * h.prior_n * h.prior_n + 2 * h.prior_n + 144;
+    h.d_prior = d; d += h.prior_n * h.prior_n + 2 * h.prior_n + 144;
     int i = 2 * d;
     h.i_pt_lm = i; i += h.pt_stride; h.i_pt_fi = i; i += h.pt_stride; h.i_pt_fj = i; i += h.pt_stride; h.i_pt_beg = i; i += rup(h.n_points + 1, 2);
     h.i_pt_eidx = i; i += relo_on ? h.pt_stride : 0;
@@ -800,9 +800,8 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
     h.w_imu = wsz; wsz += std::max(h.n_imu, 1) * UVS_WIMU_STRIDE;
     h.w_out = wsz; wsz += UVS_XDIM + std::max(h.n_points, 0) + 4 * std::max(h.n_lines, 0);
     h.n_pblk = (int)pblk.size();
-    h.w_prior_img = wsz; wsz += std::max(h.n_pblk, 1) * UVS_BLK_SZ + UVS_RD;      // dense tiles (written once per solve), diag(J0^T J0) per S index
+    h.w_prior_h0 = wsz; wsz += UVS_PH_DOUBLES(h.prior_n);      // H0 = J0^T J0, g0, c0, diag(H0) per S index: written once per solve by setup_window
     h.n_cimg = (int)csrc.size();
-    h.w_prior_cimg = wsz; wsz += rup(std::max(h.n_cimg, 1), 2);
     h.w_relo2 = wsz; if (relo2) wsz += UVS_RELO2_DOUBLES;
     h.ws_doubles = rup(wsz, 32);
     // fill
@@ -1219,7 +1218,16 @@ int uvs_batch_stream(uvs_solver* s, int n_batches, int per_batch, const uvs_wind
         if (rc == UVS_OK) rc = upload_windows(set[q], per_batch, ws + (size_t)k * per_batch, false);
         if (rc == UVS_OK) rc = launch_solve(set[q], 0, nullptr, false);
         if (rc == UVS_OK) rc = download_enqueue(set[q], per_batch);
-        if (rc != UVS_OK) { if (set[q] != s) s->err = set[q]->err; (void)hipStreamSynchronize(set[0]->stream); (void)hipStreamSynchronize(set[1]->stream); return rc; }
+        if (rc != UVS_OK) {
+            // batch k failed before it was enqueued: the batch still in flight on the OTHER buffer set (k - 1) is delivered like the ones before it, so that on
+            // return every batch < k holds results and nothing from k on does; the first error code is the one returned
+            if (set[q] != s) s->err = set[q]->err;
+            const std::string first_err = s->err;
+            (void)drain(q ^ 1);
+            (void)hipStreamSynchronize(set[0]->stream); (void)hipStreamSynchronize(set[1]->stream);
+            s->err = first_err;
+            return rc;
+        }
         pending[q] = k;
     }
     for (int q = 0; q < 2; ++q) { const int rc = drain(q); if (rc != UVS_OK) return rc; }
