@@ -12,4 +12,5 @@ mkdir -p gpurun_out
  echo "== gpu_soak_more.py"; python tests/gpu_soak_more.py 2>&1 | tail -4
  echo "== gpu_soak_replay.py"; python tests/gpu_soak_replay.py 2>&1 | tail -5
  echo "== gpu_soak_batch256.py"; python tests/gpu_soak_batch256.py 0 2>&1 | tail -3
- echo "== gpu_soak_rejections.py"; python tests/gpu_soak_rejections.py 2>&1 | tail -70) > gpurun_out/${tag}_soak.txt 2>&1
+ echo "== gpu_soak_rejections.py"; python tests/gpu_soak_rejections.py 2>&1 | tail -70
+ echo "== cpu_soak_oracle_variants.py (no HIP code: two CPU builds of the oracle on the prior-free stress windows)"; python tests/cpu_soak_oracle_variants.py 2>&1 | tail -20 | cut -c1-420) > gpurun_out/${tag}_soak.txt 2>&1
