@@ -53,6 +53,29 @@ def kernel_source_tag():
     return h.hexdigest()[:16]
 
 
+def large_source_tag():
+    """Like kernel_source_tag(), for the landmark-sharded kernels (their own header on top of the shared device code)."""
+    import hashlib
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "uv-slam_amd", "csrc")
+    for f in K_SOLVE_SOURCES + ("uvs_large_kernel.h",):
+        h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def large_traffic(n_iterations):
+    """HBM-side bytes of one configs[3] solve = PMC bytes per LM iteration (profiles/collect.sh: FETCH_SIZE / WRITE_SIZE passes over the k_large_* kernels,
+    profiles/summarize.py) x iterations -- only while the kernel sources still hash to the profiled build (the large-window kernels share the tag's file list)."""
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic_large.json")
+    try:
+        tj = json.load(open(tpath))
+        if tj.get("kernel_source_tag") == large_source_tag():
+            return float(tj["hbm_bytes_per_iteration"]) * n_iterations
+    except Exception:
+        pass
+    return None
+
+
 def algorithmic_flops(w, n_iterations, n_successful=None):
     """SURVEY.md section 8d flop model: (1 + it) linearizations + it cost-only evaluations."""
     n_po, n_lo = len(w.pt_lm), len(w.ln_lm)
@@ -238,7 +261,7 @@ def main():
                      "collectives_per_iteration": 2 if world > 1 else 0, "allreduce_payload_bytes": [5016 * 8, 64],
                      "roofline": {"bound": "mfma", "kernels": "uvsdev::k_large_chunks / k_large_solve / k_large_backsub", "achieved": fl / (lm * 1e-3) / 1e12,
                                   "peak": FP64_PEAK_TFLOPS * world, "unit": "TFLOP/s", "frac": fl / (lm * 1e-3) / 1e12 / (FP64_PEAK_TFLOPS * world),
-                                  "algorithmic_flops_per_solve": fl, "algorithmic_bytes_per_solve": float(synth.algorithmic_bytes(wl)), "traffic": None,
+                                  "algorithmic_flops_per_solve": fl, "algorithmic_bytes_per_solve": float(synth.algorithmic_bytes(wl)), "traffic": large_traffic(int(repl.num_iterations)),
                                   "note": "whole resident LM loop (all kernels + collectives) against N x the FP64 roof; SURVEY.md 8d flop model"}}
             large["projected"] = project_large_window(world)
         sl.close()

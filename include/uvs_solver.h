@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define UVS_ABI_VERSION 5
+#define UVS_ABI_VERSION 6
 
 #define UVS_WINDOW_SIZE 10                    /* parameters.h:12 WINDOW_SIZE  */
 #define UVS_NUM_FRAMES (UVS_WINDOW_SIZE + 1)  /* frames 0..WINDOW_SIZE        */
@@ -325,6 +325,13 @@ int uvs_marginalize(uvs_solver *s, const uvs_window *w, int flag, uvs_prior *out
  * only the state fields (pose, speedbias, ex_pose, td, inv_depth, line_orth) changed; the resident factors are reused and only the
  * state is sent to the device.  Returns UVS_ERR_INVALID_ARG when the block counts do not match the resident window. */
 int uvs_marginalize_resident(uvs_solver *s, const uvs_window *w, int flag, uvs_prior *out);
+/* The same call in two halves (round 4): uvs_marginalize_resident_begin() hands the whole marginalization -- sub-window packing, the device linearization, the
+ * elimination of the departing frame and the n x n factorization -- to a worker thread of the handle and returns at once; uvs_marginalize_wait() blocks until the
+ * prior is there and returns what uvs_marginalize_resident() would have returned.  The prior is first needed by the NEXT uvs_solve_window(), so the caller's own
+ * work between two frames (window slide, IMU integration, feature bookkeeping: estimator.cpp:123-222) runs beside it.  Contract: between begin and wait the handle
+ * must not be used for anything else, and `w` as well as every array it points to (incl. w->prior) must stay valid and unchanged.  uvs_destroy() waits by itself. */
+int uvs_marginalize_resident_begin(uvs_solver *s, const uvs_window *w, int flag);
+int uvs_marginalize_wait(uvs_solver *s, uvs_prior *out);
 
 /* ---- ONE large window spread over the GPU and, with an all-reduce between the steps, over several GPUs (BASELINE configs[3]) ----
  * Landmarks shard (rank r holds the landmarks k with k % G == r; frames / IMU / prior are replicated); the only exchanged data are

@@ -1,4 +1,4 @@
-// oracle_backend.cpp -- TEST INFRASTRUCTURE.  The six C-ABI entry points the host mirror (uv-slam_amd/host) calls, answered by the
+// oracle_backend.cpp -- TEST INFRASTRUCTURE.  The C-ABI entry points the host mirror (uv-slam_amd/host) calls, answered by the
 // CPU oracle instead of the HIP library, so that the SAME mirrored Estimator state machine can replay a frame sequence on the CPU
 // and serve as the checker of the GPU-backed replay (tests/test_sequence_replay.py).  Built into oracle/libuvs_host_oracle.so
 // together with the host sources; nothing under uv-slam_amd/ links or loads it.
@@ -12,7 +12,7 @@ int oracle_marginalize(const uvs_options* opt, const uvs_window* w, int flag, uv
 int oracle_evaluate(const uvs_options* opt, const uvs_window* w, int robust, uvs_eval* out);
 }
 
-struct uvs_solver { uvs_options opt; std::string err; };
+struct uvs_solver { uvs_options opt; std::string err; bool marg_pending = false; int marg_rc = 0; uvs_prior marg_out; };
 
 extern "C" {
 int uvs_abi_version(void) { return UVS_ABI_VERSION; }
@@ -27,7 +27,7 @@ void uvs_default_options(uvs_options* o) {      // config/euroc/euroc_config.yam
 }
 int uvs_create(const uvs_options* opts, int, int, int, int, int, int, uvs_solver** out) {
     if (!opts || !out) return UVS_ERR_INVALID_ARG;
-    *out = new uvs_solver{*opts, ""};
+    *out = new uvs_solver(); (*out)->opt = *opts;
     return UVS_OK;
 }
 void uvs_destroy(uvs_solver* s) { delete s; }
@@ -38,4 +38,7 @@ int uvs_large_solve_fused(uvs_solver* s, const uvs_window* w, uvs_state* out, uv
 int uvs_evaluate(uvs_solver* s, const uvs_window* w, int robust, uvs_eval* out) { return oracle_evaluate(&s->opt, w, robust, out); }
 int uvs_marginalize(uvs_solver* s, const uvs_window* w, int flag, uvs_prior* out) { return oracle_marginalize(&s->opt, w, flag, out); }
 int uvs_marginalize_resident(uvs_solver* s, const uvs_window* w, int flag, uvs_prior* out) { return oracle_marginalize(&s->opt, w, flag, out); }
+// the two-halves form (ABI v6): the oracle answers at once, the wait hands the result over
+int uvs_marginalize_resident_begin(uvs_solver* s, const uvs_window* w, int flag) { if (s->marg_pending) return UVS_ERR_INVALID_ARG; s->marg_rc = oracle_marginalize(&s->opt, w, flag, &s->marg_out); s->marg_pending = true; return UVS_OK; }
+int uvs_marginalize_wait(uvs_solver* s, uvs_prior* out) { if (!s->marg_pending) return UVS_ERR_INVALID_ARG; s->marg_pending = false; if (s->marg_rc == UVS_OK) *out = s->marg_out; return s->marg_rc; }
 }

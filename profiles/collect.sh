@@ -20,8 +20,20 @@ rm -rf $R/gpurun_out/prof_large
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_large -o runc -- $LCMD > $R/gpurun_out/prof_large.log 2>&1
 rm -rf $R/gpurun_out/prof_single_fused
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_single_fused -o runc -- python $R/tools/single_vs_fused.py > $R/gpurun_out/prof_single_fused.log 2>&1      # ONE canonical window through both single-window forms
+# PMC passes for the landmark-sharded kernels (configs[3] fused loop): traffic of the loop (FETCH_SIZE / WRITE_SIZE in separate passes) + wave / wait counters
+rm -rf $R/gpurun_out/prof_large_fetch $R/gpurun_out/prof_large_write $R/gpurun_out/prof_large_sq
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/prof_large_fetch -o runc -- $LCMD > $R/gpurun_out/prof_large_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/prof_large_write -o runc -- $LCMD > $R/gpurun_out/prof_large_write.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $R/gpurun_out/prof_large_sq -o runc -- $LCMD > $R/gpurun_out/prof_large_sq.log 2>&1
 cd $R
+# per-phase cycles of one window with the n = 75 prior (debug launch, thread 0), the batch tail (slowest window / contention) and the instruction-cache / L2 counters:
+# plain text files of the round, not derived from a trace
+python tests/gpu_debug_prior.py > gpurun_out/${TAG}_phase_cycles.txt 2>&1
+python tools/batch_tail.py > gpurun_out/${TAG}_batch_tail.txt 2>&1
+python tools/large_timeline.py config3 > gpurun_out/${TAG}_large_timeline.txt 2>&1; python tools/large_timeline.py canonical >> gpurun_out/${TAG}_large_timeline.txt 2>&1
+bash tools/pmc_icache.sh > gpurun_out/${TAG}_icache_l2_counters.txt 2>&1
 python profiles/summarize.py $TAG      # printed for the log; gpurun only merges gpurun_out/ back, so re-run these two lines locally afterwards:
 #   python profiles/summarize.py $TAG && cp gpurun_out/prof_kt/runc_kernel_stats.csv profiles/${TAG}_kernel_stats_bench256.csv
 #   cp gpurun_out/prof_large/runc_kernel_stats.csv profiles/${TAG}_kernel_stats_large.csv
 #   cp gpurun_out/prof_single_fused/runc_kernel_stats.csv profiles/${TAG}_kernel_stats_single_window_fused.csv
+#   cp gpurun_out/${TAG}_phase_cycles.txt gpurun_out/${TAG}_batch_tail.txt gpurun_out/${TAG}_large_timeline.txt gpurun_out/${TAG}_icache_l2_counters.txt profiles/

@@ -33,7 +33,35 @@ for name in ("prof_fetch", "prof_write", "prof_sq", "prof_sq2"):
 if "FETCH_SIZE_per_launch_mean" in out:
     out["hbm_bytes_per_launch"] = (2 * out["FETCH_SIZE_per_launch_mean"] + out["WRITE_SIZE_per_launch_mean"]) * 1024
     out["hbm_bytes_per_launch_uncorrected"] = (out["FETCH_SIZE_per_launch_mean"] + out["WRITE_SIZE_per_launch_mean"]) * 1024
+# ---- the landmark-sharded kernels of the configs[3] fused loop (prof_large_*): per kernel, mean per launch over the launches that did work (a pass after termination returns at once)
+large = {}
+for name in ("prof_large_fetch", "prof_large_write", "prof_large_sq"):
+    f = _find(name, "_counter_collection.csv")
+    if not f: continue
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        kn = r["Kernel_Name"]
+        if "k_large_" not in kn: continue
+        short = kn.split("(")[0].split("::")[-1]
+        agg[(short, r["Counter_Name"])].append(float(r["Counter_Value"]))
+        large.setdefault(short, {}).update(vgpr=r["VGPR_Count"], lds_block_size=r["LDS_Block_Size"], scratch_size=r["Scratch_Size"], grid=r["Grid_Size"], workgroup=r["Workgroup_Size"])
+    for (short, cn), v in agg.items():
+        nz = [x for x in v if x > 0] or v
+        large[short][cn + "_per_launch_mean"] = sum(nz) / len(nz); large[short][cn + "_launches"] = len(v)
+if large:
+    # FETCH_SIZE / WRITE_SIZE in KiB; same calibration as above (x2 for the 8 B / lane reads).  Per LM iteration = one launch of each kernel.
+    tot = 0.0
+    for k, d in large.items():
+        if "FETCH_SIZE_per_launch_mean" in d and "WRITE_SIZE_per_launch_mean" in d:
+            d["hbm_bytes_per_launch"] = (2 * d["FETCH_SIZE_per_launch_mean"] + d["WRITE_SIZE_per_launch_mean"]) * 1024; tot += d["hbm_bytes_per_launch"]
+    out["large_window_kernels"] = large
+    out["large_window_hbm_bytes_per_iteration"] = tot
 json.dump(out, open(f"{ROOT}/profiles/{tag}_pmc_summary.json", "w"), indent=1)
+if out.get("large_window_hbm_bytes_per_iteration"):
+    sys.path.insert(0, ROOT)
+    import bench as _b
+    json.dump({"hbm_bytes_per_iteration": out["large_window_hbm_bytes_per_iteration"], "source": f"profiles/{tag}_pmc_summary.json", "kernel_source_tag": _b.large_source_tag()},
+              open(f"{ROOT}/profiles/pmc_traffic_large.json", "w"))
 if "hbm_bytes_per_launch" in out:
     # bench.py reports this figure only while the kernel sources still hash to the tag recorded here (run summarize.py on the build that was profiled)
     sys.path.insert(0, ROOT)

@@ -68,3 +68,26 @@ def test_device_marginalization_equals_host_path(gpu_api, oracle, index):
     assert np.abs(Ad - Ah).max() <= 1e-7 * sc and np.abs(Ad - Ao).max() <= 1e-6 * sc
     assert np.abs(bd - bh).max() <= 1e-6 * max(1.0, np.abs(bo).max()) and np.abs(bd - bo).max() <= 1e-5 * max(1.0, np.abs(bo).max())
     assert np.array_equal(np.asarray(pd.x0[:80]), np.asarray(ph.x0[:80]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flag", [0, 1])
+def test_marginalization_in_two_halves_equals_the_one_call_form(gpu_api, flag):
+    """uvs_marginalize_resident_begin / uvs_marginalize_wait (ABI v6: the marginalization on a worker thread of the handle, beside the caller's work between
+    two frames) delivers bit for bit the prior of uvs_marginalize_resident, for both marginalization kinds; a second begin before the wait, and a wait with
+    nothing in flight, are errors and leave the job alone."""
+    s = gpu_api.Solver(max_batch=2)
+    w = synth.make_window(73, with_prior=True, marginalize_fn=lambda win, f: s.marginalize(win, f))
+    st, _ = s.solve(w)
+    ws = w.with_state(st)
+    ref = s.marginalize(ws, flag, resident=True)
+    with pytest.raises(Exception):
+        s.marginalize_wait()
+    st2, _ = s.solve(w)                                   # the factors of w resident again
+    s.marginalize_begin(ws, flag)
+    with pytest.raises(Exception):
+        s.marginalize_begin(ws, flag)
+    p = s.marginalize_wait()
+    assert p.n == ref.n and p.n_blocks == ref.n_blocks
+    assert np.array_equal(np.asarray(p.J0()), np.asarray(ref.J0())) and np.array_equal(np.asarray(p.r0()), np.asarray(ref.r0()))
+    s.close()

@@ -53,6 +53,8 @@ def lib():
         L.uvs_marginalize.restype = C.c_int
         L.uvs_marginalize_resident.argtypes = [C.c_void_p, C.POINTER(abi.WindowC), C.c_int, C.POINTER(abi.Prior)]
         L.uvs_marginalize_resident.restype = C.c_int
+        L.uvs_marginalize_resident_begin.argtypes = [C.c_void_p, C.POINTER(abi.WindowC), C.c_int]; L.uvs_marginalize_resident_begin.restype = C.c_int
+        L.uvs_marginalize_wait.argtypes = [C.c_void_p, C.POINTER(abi.Prior)]; L.uvs_marginalize_wait.restype = C.c_int
         L.uvs_debug_first_iteration.argtypes = [C.c_void_p, C.POINTER(abi.WindowC)] + [abi.c_double_p] * 6
         L.uvs_debug_first_iteration.restype = C.c_int
         L.uvs_reduced_dim.argtypes = [C.POINTER(abi.Options)]; L.uvs_reduced_dim.restype = C.c_int
@@ -270,6 +272,20 @@ class Solver:
         p = abi.Prior()
         fn = lib().uvs_marginalize_resident if resident else lib().uvs_marginalize
         self._check(fn(self._h, C.byref(wc), flag, C.byref(p)))
+        return p
+
+    def marginalize_begin(self, w: abi.Window, flag=0):
+        """uvs_marginalize_resident_begin: the marginalization of the resident window on a worker thread of the handle; marginalize_wait() delivers the prior.
+        The C structures of `w` are kept alive on this object until then (the ABI's contract for the caller's arrays)."""
+        wc, keep = w.to_c()
+        self._marg_keep = (wc, keep, w)
+        self._check(lib().uvs_marginalize_resident_begin(self._h, C.byref(wc), flag))
+
+    def marginalize_wait(self):
+        p = abi.Prior()
+        rc = lib().uvs_marginalize_wait(self._h, C.byref(p))
+        self._marg_keep = None
+        self._check(rc)
         return p
 
     def debug_first_iteration(self, w: abi.Window):

@@ -31,7 +31,11 @@ static constexpr int LG_MAXRANKS = 8;
 static constexpr int FI_S = 0, FI_G = UVS_S_DOUBLES, FI_HD = FI_G + UVS_RD, FI_COST = FI_HD + UVS_RD, LG_FIMG = FI_COST + 8;
 static constexpr int LX_X2 = LG_RED, LX_GMAX = LG_RED + 1, LG_XCH = LG_RED + 1 + LG_MAXRANKS + 7;      // 5016 doubles
 enum { LC_RADIUS = 0, LC_DECR, LC_COST, LC_GMAX, LC_XNORM, LC_FRAME_X2, LC_IT, LC_INVALID, LC_NSUCC, LC_PENDING, LC_TERM, LC_STATUS, LC_FIRST, LC_DONE, LC_SEL, LC_REDAMP, LC_T0, LC_N };      // LC_REDAMP: the last step was rejected / invalid => the next pass re-damps the same linearization
-struct LargeCtl { const double* ctl; int rank, nranks; };      // ctl == nullptr: the step-wise API (host-side control, arguments as given)
+struct LargeCtl { const double* ctl; int rank, nranks; };
+// debug timeline of k_large_chunks (KOpts::debug == 7, UVS_LARGE_PROF=<file> in uvs_large_solve_fused): per workgroup 8 stamps of the 100 MHz wall clock
+// {start, state + rotations staged, first chunk done, all chunks done, parts summed, partial written, -, chunks taken}; the LAST launch wins
+__device__ long long g_large_prof[1024 * 8];
+#define UVS_LPROF(k) do { if (o.debug == 7 && tid == 0 && blockIdx.x < 1024) g_large_prof[8 * blockIdx.x + (k)] = wall_clock64(); } while (0)      // ctl == nullptr: the step-wise API (host-side control, arguments as given)
 
 
 // The LAST workgroup of the grid (blockIdx.x == n_chunk_wgs) carries no landmarks: it builds the FRAME image of the reduced system -- IMU
@@ -45,6 +49,7 @@ __global__ __launch_bounds__(NT) void k_large_chunks(char* blob, double* ws, KOp
     if (lc.ctl) { if (lc.ctl[LC_DONE] != 0.0) return; sel = (int)lc.ctl[LC_SEL]; first = (int)lc.ctl[LC_FIRST]; radius = lc.ctl[LC_RADIUS]; }
     Ctx c; c.hdr = (const DevWin*)blob; c.bd = (const double*)blob; c.bi = (const int*)blob; c.ws = ws; c.sh = sh; c.o = o; c.o.debug = 0;
     const DevWin& h = *c.hdr;
+    UVS_LPROF(0);
     // after a rejected step (fused loop): same point, new radius -- the landmark partials are UPDATED by the change of their Schur terms
     // (redamp_chunk), the frame image (undamped) stays as it is
     const bool redamp = lc.ctl && lc.ctl[LC_REDAMP] != 0.0 && !first && h.redamp_ok && o.redamp;
@@ -62,6 +67,7 @@ __global__ __launch_bounds__(NT) void k_large_chunks(char* blob, double* ws, KOp
         double s4[4] = {cost, 0, 0, 0}, mx = 0.0;
         block_reduce(sh, s4, &mx);
         if (tid == 0) fimg[FI_COST] = s4[0];
+        UVS_LPROF(5);
         return;
     }
     __syncthreads();
@@ -70,16 +76,21 @@ __global__ __launch_bounds__(NT) void k_large_chunks(char* blob, double* ws, KOp
     const int grp = gather_group(c);
     GAcc A; gacc_zero(A);
     lacc_set(sh, 0.0, 0.0);
+    UVS_LPROF(1);
     const double* invd = ws + (sel ? h.w_invd1 : h.w_invd0); const double* line = ws + (sel ? h.w_line1 : h.w_line0);
     // PERSISTENT workgroups: workgroup b takes chunks b, b + gridDim.x, ... and accumulates them into ONE partial (the host sizes the chunks so
     // that their number is a multiple of the grid: 340 LDS-filling chunks on 256 CUs were two full rounds for 1.33 rounds of work)
-    for (int ch = blockIdx.x; ch < h.n_chunks; ch += n_chunk_wgs) { if (redamp) redamp_chunk(c, ch, radius, grp, A); else lin_chunk(c, ch, sh + L_X, invd, line, first != 0, radius, grp, A); }
+    int taken = 0;
+    for (int ch = blockIdx.x; ch < h.n_chunks; ch += n_chunk_wgs) { if (redamp) redamp_chunk(c, ch, radius, grp, A); else lin_chunk(c, ch, sh + L_X, invd, line, first != 0, radius, grp, A); if (taken++ == 0) UVS_LPROF(2); }
+    UVS_LPROF(3);
+    if (o.debug == 7 && tid == 0 && blockIdx.x < 1024) g_large_prof[8 * blockIdx.x + 7] = taken;
     double cost = lacc_cost(sh), gmax = lacc_gmax(sh);
     // canonical partial [pose block][row a][8] (6 block entries, gradient, diag(J^T J)), staged in LDS so that the two halves of a
     // split block are summed in a fixed order and the HBM write is coalesced
     __syncthreads();
     gacc_gather_parts(A, grp, sh + L_S);
     __syncthreads();
+    UVS_LPROF(4);
     for (int i = tid; i < LG_ACC; i += NT) sh[L_S + i] = 0.0;
     __syncthreads();
     {
@@ -103,6 +114,7 @@ __global__ __launch_bounds__(NT) void k_large_chunks(char* blob, double* ws, KOp
     double s4[4] = {cost, 0, 0, 0};
     block_reduce(sh, s4, &gmax);
     if (tid == 0) { P[LG_ACC] = s4[0]; P[LG_ACC + 1] = gmax; }
+    UVS_LPROF(5);
 }
 
 // Deterministic two-level sum of the per-chunk partials: a workgroup owns 16 consecutive entries i, its 16 x 16 threads split the chunk
@@ -182,8 +194,15 @@ __global__ __launch_bounds__(NT) void k_large_solve(char* blob, double* ws, KOpt
     // (the frame part of the candidate cost -- prior + IMU at x_c -- is k_large_backsub's extra workgroup)
 }
 
-// per chunk: landmark back-substitution (candidate parameters into the other buffer) + candidate cost of the chunk's observations
-__global__ __launch_bounds__(NT) void k_large_backsub(char* blob, double* ws, KOpts o, const double* state, int sel, double* bsums, LargeCtl lc, int n_chunk_wgs, double* out) {
+// per chunk: landmark back-substitution (candidate parameters into the other buffer) + candidate cost of the chunk's observations.
+// Round 4: the kernel needs no staging area (only the small LDS arrays + the frame workgroup's scratch: LDS_BYTES_BACKSUB), so several workgroups share a
+// compute unit; the register budget is halved for that (UVS_LARGE_OCC waves per SIMD) and the streaming loops keep fewer loads in flight per lane -- the
+// other resident waves cover the latency that one wave per SIMD had to cover with its own batches.
+#ifndef UVS_LARGE_OCC
+#define UVS_LARGE_OCC 2
+#endif
+static constexpr size_t LDS_BYTES_BACKSUB = (size_t)(L_S + 2048) * 8;      // prior_quad's partials [0, 512), the IMU residual scratch of cost_pass at 1024
+__global__ __launch_bounds__(NT, UVS_LARGE_OCC) void k_large_backsub(char* blob, double* ws, KOpts o, const double* state, int sel, double* bsums, LargeCtl lc, int n_chunk_wgs, double* out) {
     extern __shared__ __attribute__((aligned(16))) double sh[];
     const int tid = threadIdx.x;
     if (lc.ctl) { if (lc.ctl[LC_DONE] != 0.0) return; sel = (int)lc.ctl[LC_SEL]; }
@@ -196,7 +215,7 @@ __global__ __launch_bounds__(NT) void k_large_backsub(char* blob, double* ws, KO
     if ((int)blockIdx.x == n_chunk_wgs) {      // the LAST workgroup: frame part of the candidate cost (prior + IMU at x_c), beside the landmark chunks
         prior_dx(c, sh + L_XC);
         __syncthreads();
-        double cc = prior_quad(c) + cost_pass(c, sh + L_XC, nullptr, nullptr, 0, 0, 0, 0, true);
+        double cc = prior_quad(c) + cost_pass<1, 1>(c, sh + L_XC, nullptr, nullptr, 0, 0, 0, 0, true);
         double s4[4] = {cc, 0, 0, 0}, mx = 0.0;
         block_reduce(sh, s4, &mx);
         if (tid == 0) out[LO_FRAMECOST] = s4[0];
@@ -209,11 +228,11 @@ __global__ __launch_bounds__(NT) void k_large_backsub(char* blob, double* ws, KO
         const int* chunk = c.bi + h.i_chunks + 6 * ch;
         const int type = chunk[0], k0 = chunk[1], k1 = chunk[2];
         double* bo = bsums + 8 * (size_t)ch;
-        backsub_candidate(c, invd, line, invd_c, line_c, type == 0 ? k0 : 0, type == 0 ? k1 : 0, type == 1 ? k0 : 0, type == 1 ? k1 : 0, false, bo);
+        backsub_candidate<2>(c, invd, line, invd_c, line_c, type == 0 ? k0 : 0, type == 0 ? k1 : 0, type == 1 ? k0 : 0, type == 1 ? k1 : 0, false, bo);
         __threadfence_block();
         __syncthreads();
         const int po0 = type == 0 ? pbeg[k0] : 0, po1 = type == 0 ? pbeg[k1] : 0, lo0 = type == 1 ? lbeg[k0] : 0, lo1 = type == 1 ? lbeg[k1] : 0;
-        double cc = cost_pass(c, sh + L_XC, invd_c, line_c, po0, po1, lo0, lo1, false);
+        double cc = cost_pass<2, 1>(c, sh + L_XC, invd_c, line_c, po0, po1, lo0, lo1, false);
         double s4[4] = {cc, 0, 0, 0}, mx = 0.0;
         block_reduce(sh, s4, &mx);
         if (tid == 0) bo[4] = s4[0];

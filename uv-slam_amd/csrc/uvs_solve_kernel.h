@@ -42,9 +42,10 @@ static constexpr int BS_LNB = NT > 256 ? 2 : 4;     // back substitution: line o
 static constexpr int PR_UN = NT > 256 ? 12 : 24;    // prior residual: rows of J0^T in flight
 static constexpr int PG_UN = NT > 256 ? 16 : 32;    // prior gradient: rows of J0 in flight
 
-// ---- LDS map (in doubles)
-static constexpr int L_S = 0;
-static constexpr int L_X = UVS_S_DOUBLES;      // pose[77] sb[99] ex[7] (+1 pad)
+// ---- LDS map (in doubles).  The small arrays come FIRST and the big region (reduced system / staging area) LAST, so that a kernel that needs only part of
+// the region -- the landmark-sharded kernels: k_large_backsub none of it beyond a little scratch, k_large_chunks a chunk's worth -- asks for less dynamic LDS and
+// leaves room for a second workgroup on the compute unit (round 4); every offset below is the same in all kernels.
+static constexpr int L_X = 0;                  // pose[77] sb[99] ex[7] (+1 pad)
 static constexpr int L_XC = L_X + UVS_XDIM;
 static constexpr int L_G = L_XC + UVS_XDIM;    // gradient of the frame block, padded index space (176)
 static constexpr int L_DLT = L_G + UVS_RD;     // rhs / step; [192..197] = copy of the relo_Pose step (pseudo frame 12) for the back-substitution
@@ -64,7 +65,9 @@ static constexpr int L_WPROF = L_PROF + 24;     // debug sub-timers: [0..3] cand
 static constexpr int L_LCOST = L_WPROF + 8;     // per-lane cost accumulator of the current linearization (kept in LDS, not in a register that
 static constexpr int LACC = NT > 256 ? NT / 256 : 1;      // lanes sharing one accumulator slot (the 512-thread build has no LDS left for one per lane)
 static constexpr int L_LGMAX = L_LCOST + NT / LACC;    // would have to live across every phase) ; per-lane max |g_landmark|
-static constexpr int L_TOTAL = L_LGMAX + NT / LACC;
+static constexpr int L_SMALL = (L_LGMAX + NT / LACC + 1) & ~1;      // end of the small arrays (even: the region below holds 16-byte rows)
+static constexpr int L_S = L_SMALL;            // the reduced system S (66 lower 16 x 16 blocks, 17-double rows) / the staging area of a landmark chunk / scratch of the frame phases
+static constexpr int L_TOTAL = L_S + UVS_S_DOUBLES;
 static_assert(L_TOTAL * 8 <= 160 * 1024, "LDS map exceeds the 160 KB of a CU");
 enum { P_SETUP = 0, P_OBS, P_LMPREP, P_GATHER, P_ASSEMBLE, P_CHOL, P_TRSV, P_BACKSUB, P_COST, P_MISC, P_CH_DIAG, P_CH_PANEL, P_CH_TRAIL, P_AS_IMU, P_AS_ZERO, P_AS_ADD, P_LAST };
 #define UVS_PROF(c, k) do { if ((c).o.debug && lane_tid() == 0) { const long long now_ = clock64(); (c).sh[L_PROF + (k)] += (double)(now_ - (long long)(c).sh[L_PROF + 23]); (c).sh[L_PROF + 23] = (double)now_; } } while (0)
@@ -291,6 +294,9 @@ UVS_DEV double prior_residual_rows(const Ctx& c) {
 }
 
 // cost of all residual blocks at the point staged in (x, RF/EX) with landmark buffers invd / line
+// PB / LB: point / line observations per lane and batch (loads in flight); the defaults suit the workgroup size of the persistent kernel, a kernel that runs
+// several workgroups per compute unit passes smaller ones (its other waves hide the latency, its register budget is smaller)
+template <int PB = CP_PB, int LB = CP_LB>
 UVS_DEV double cost_pass(const Ctx& c, const double* x, const double* invd, const double* line, int po0, int po1, int lo0, int lo1, bool with_imu) {
     const DevWin& h = *c.hdr;
     const int tid = lane_tid();
@@ -302,20 +308,20 @@ UVS_DEV double cost_pass(const Ctx& c, const double* x, const double* invd, cons
     // Observations in batches of four per lane: the index loads and the measurement loads of a batch go out together and the
     // landmark parameters (the only loads whose address depends on an index) follow as a second group, so a lane pays two HBM/L2
     // round trips per BATCH instead of two per observation (one wave per SIMD: nothing else hides that latency).
-    for (int o0 = po0 + tid; o0 < po1; o0 += CP_PB * NT) {
-        int lm[CP_PB], fi[CP_PB], fj[CP_PB]; bool in[CP_PB];
-        double pi[CP_PB][3], pj[CP_PB][3], vij[CP_PB][4], idp[CP_PB];
+    for (int o0 = po0 + tid; o0 < po1; o0 += PB * NT) {
+        int lm[PB], fi[PB], fj[PB]; bool in[PB];
+        double pi[PB][3], pj[PB][3], vij[PB][4], idp[PB];
 #pragma unroll
-        for (int u = 0; u < CP_PB; ++u) {
+        for (int u = 0; u < PB; ++u) {
             const int o = o0 + u * NT; in[u] = o < po1;
             const int oo = in[u] ? o : o0;
             lm[u] = c.bi[h.i_pt_lm + oo]; fi[u] = c.bi[h.i_pt_fi + oo]; fj[u] = c.bi[h.i_pt_fj + oo];
             load_point_obs(c, oo, x[183], pi[u], pj[u], vij[u]);
         }
 #pragma unroll
-        for (int u = 0; u < CP_PB; ++u) idp[u] = invd[lm[u]];
+        for (int u = 0; u < PB; ++u) idp[u] = invd[lm[u]];
 #pragma unroll
-        for (int u = 0; u < CP_PB; ++u) {
+        for (int u = 0; u < PB; ++u) {
             if (!in[u]) continue;
             double r[2];
             point_eval<false, false>(x + 7 * fi[u], RF + 9 * fi[u], pose_of(x, fj[u]), RF + 9 * fj[u], ric, tic, idp[u], pi[u], pj[u], c.o.sqrt_info, r, nullptr, nullptr, nullptr, nullptr);
@@ -323,12 +329,12 @@ UVS_DEV double cost_pass(const Ctx& c, const double* x, const double* invd, cons
         }
     }
     // lines + vp, two per batch
-    for (int o0 = lo0 + tid; o0 < lo1; o0 += CP_LB * NT) {
-        int lm[CP_LB], fj[CP_LB], hv[CP_LB]; bool in[CP_LB];
-        double ms[CP_LB][9], lp[CP_LB][4] = {}, tg[CP_LB][8];
+    for (int o0 = lo0 + tid; o0 < lo1; o0 += LB * NT) {
+        int lm[LB], fj[LB], hv[LB]; bool in[LB];
+        double ms[LB][9], lp[LB][4] = {}, tg[LB][8];
         const int st = h.ln_stride;
 #pragma unroll
-        for (int u = 0; u < CP_LB; ++u) {
+        for (int u = 0; u < LB; ++u) {
             const int o = o0 + u * NT; in[u] = o < lo1;
             const int oo = in[u] ? o : o0;
             lm[u] = c.bi[h.i_ln_lm + oo]; fj[u] = c.bi[h.i_ln_fj + oo]; hv[u] = c.bi[h.i_ln_vp + oo];
@@ -337,7 +343,7 @@ UVS_DEV double cost_pass(const Ctx& c, const double* x, const double* invd, cons
             for (int q = 0; q < 9; ++q) ms[u][q] = m[q * st];
         }
 #pragma unroll
-        for (int u = 0; u < CP_LB; ++u) {
+        for (int u = 0; u < LB; ++u) {
             if (ltrig) {
 #pragma unroll
                 for (int q = 0; q < 8; ++q) tg[u][q] = ltrig[8 * lm[u] + q];
@@ -347,7 +353,7 @@ UVS_DEV double cost_pass(const Ctx& c, const double* x, const double* invd, cons
             }
         }
 #pragma unroll
-        for (int u = 0; u < CP_LB; ++u) {
+        for (int u = 0; u < LB; ++u) {
             if (!in[u]) continue;
             const double sp[3] = {ms[u][0], ms[u][1], ms[u][2]}, ep[3] = {ms[u][3], ms[u][4], ms[u][5]}, vp[3] = {ms[u][6], ms[u][7], ms[u][8]};
             LineGeom g;
@@ -2030,6 +2036,7 @@ UVS_DEV void relinearize_damping(const Ctx& c, const double* x, double radius, G
 
 // ------------------------------------------------------------------ back-substitution + candidate + model terms
 // frames: XC = X (+) DLT ; landmarks: cand = cur + delta.  Accumulates into CTRL: MCC, STEP2, XC2.
+template <int LNBT = BS_LNB>
 UVS_DEV void backsub_candidate(const Ctx& c, const double* invd, const double* line, double* invd_c, double* line_c,
                                   int pk0, int pk1, int lk0, int lk1, bool with_frames, double* sums_out) {
     const DevWin& h = *c.hdr;
@@ -2122,7 +2129,7 @@ UVS_DEV void backsub_candidate(const Ctx& c, const double* invd, const double* l
         gd += px[1] * (dl + t); dd2 += px[2] * dl * dl; step2 += dl * dl; xc2 += v * v;
     }
     // lines: delta(4) = -Hinv g - sum_s Y[s] delta_pose
-    constexpr int LNB = BS_LNB;
+    constexpr int LNB = LNBT;
     const int* lbeg = c.bi + h.i_ln_beg;
     for (int k = lk0 + tid; k < lk1; k += NT) {
         const int b0 = lbeg[k], b1 = lbeg[k + 1];

@@ -16,6 +16,7 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <future>
 
 #include "../../include/uvs_solver.h"
 #include "uvs_layout.h"
@@ -48,6 +49,8 @@ struct uvs_solver {
     std::vector<long long> blob_off, ws_off;
     std::vector<char> host_blobs;
     MargDevScratch* marg_dev = nullptr;   // buffers of the device marginalization (sub-window blob, its workspace, the reduced system)
+    std::future<int> marg_job;            // uvs_marginalize_resident_begin(): the marginalization running on a worker thread; its result waits in marg_job_out
+    uvs_prior marg_job_out;
     PackCache* pack_cache = nullptr;      // structure of the last large single window (allocated on first use)
     std::vector<std::vector<char>> slot_blobs;      // batch uploads: one packing buffer per batch slot, kept (with its pages) from batch to batch
     // ONE host -> device copy per upload: [blobs | blob_off[n] | ws_off[n] | out_tab[3 n]] staged in pinned memory; the three tables
@@ -181,6 +184,7 @@ int uvs_create(const uvs_options* opts, int device, int max_batch, int max_point
 }
 
 void uvs_destroy(uvs_solver* s) {
+    if (s && s->marg_job.valid()) (void)s->marg_job.get();      // a marginalization begun and never waited for still uses the handle
     if (!s) return;
     if (s->twin) { uvs_destroy(s->twin); s->twin = nullptr; }
     free_pack_cache(s->pack_cache); s->pack_cache = nullptr;
@@ -1312,6 +1316,21 @@ int uvs_marginalize_resident(uvs_solver* s, const uvs_window* w, int flag, uvs_p
     return run_marginalize(s->device, s->stream, s->d_blobs, s->d_ws, s->hdrs[0], w, make_kopts(s->opts, 0), flag, out, s->err, s->eval_scratch);
 }
 
+int uvs_marginalize_resident_begin(uvs_solver* s, const uvs_window* w, int flag) {
+    if (!s || !w || (flag != 0 && flag != 1)) return UVS_ERR_INVALID_ARG;
+    if (s->marg_job.valid()) { s->err = "uvs_marginalize_resident_begin: the previous marginalization has not been waited for"; return UVS_ERR_INVALID_ARG; }
+    // the worker owns the handle until uvs_marginalize_wait(): device selection is per thread, everything else (stream, pinned buffers, scratch) is the handle's own
+    s->marg_job = std::async(std::launch::async, [s, w, flag]() { return uvs_marginalize_resident(s, w, flag, &s->marg_job_out); });
+    return UVS_OK;
+}
+int uvs_marginalize_wait(uvs_solver* s, uvs_prior* out) {
+    if (!s || !out) return UVS_ERR_INVALID_ARG;
+    if (!s->marg_job.valid()) { s->err = "uvs_marginalize_wait: no marginalization in flight"; return UVS_ERR_INVALID_ARG; }
+    const int rc = s->marg_job.get();
+    if (rc == UVS_OK) *out = s->marg_job_out;
+    return rc;
+}
+
 }  // extern "C"
 
 // ------------------------------------------------------------------ large single window (configs[3]), optionally multi-GPU
@@ -1394,7 +1413,8 @@ int uvs_large_step(uvs_solver* s) {
     HIPCHK(s, hipSetDevice(s->device));
     KOpts ko = make_kopts(s->opts, 0);
     hipLaunchKernelGGL(k_large_solve, dim3(1), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, L.d_reduced, L.first ? 1 : 0, L.radius, L.d_out, LargeCtl{nullptr, 0, 0}, L.d_fimg);
-    hipLaunchKernelGGL(k_large_backsub, dim3(L.grid + 1), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, L.sel, L.d_bsums, LargeCtl{nullptr, 0, 0}, L.grid, L.d_out);
+    { const int bg = std::min(L.n_chunks, UVS_LARGE_OCC * s->chunk_wgs());      // (UVS_LARGE_OCC workgroups per compute unit: the kernel asks for little LDS and half the registers)
+      hipLaunchKernelGGL(k_large_backsub, dim3(bg + 1), dim3(NT), LDS_BYTES_BACKSUB, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, L.sel, L.d_bsums, LargeCtl{nullptr, 0, 0}, bg, L.d_out); }
     hipLaunchKernelGGL(k_large_sum_bsums, dim3(1), dim3(256), 0, s->stream, L.d_bsums, L.n_chunks, L.d_sc5, LargeCtl{nullptr, 0, 0}, 0LL);
     HIPCHK(s, hipGetLastError());
     HIPCHK(s, hipStreamSynchronize(s->stream));
@@ -1609,11 +1629,13 @@ int uvs_large_solve_fused(uvs_solver* s, const uvs_window* w, uvs_state* out, uv
     std::memcpy(L.relo_pose_in, w->relo_pose, sizeof(L.relo_pose_in));
     L.active = true;
     hipLaunchKernelGGL(k_large_init, dim3(16), dim3(256), 0, s->stream, s->d_blobs, s->d_ws, L.d_state, L.d_ctl, L.d_rep, L.d_reduced, o.initial_trust_region_radius, L.frame_x2, L.local_x2);
-    const KOpts ko = make_kopts(o, 0);
+    const char* lprof = std::getenv("UVS_LARGE_PROF");      // debug: per-workgroup timeline of the LAST k_large_chunks launch, written to this file
+    const KOpts ko = make_kopts(o, lprof ? 7 : 0);
     const LargeCtl lc{L.d_ctl, L.rank, L.nranks};
     RcclApi& r = rccl();
     const int passes = std::max(1, o.max_num_iterations);
     const int rows = L.grid;
+    const int bgrid = std::min(L.n_chunks, UVS_LARGE_OCC * s->chunk_wgs());      // k_large_backsub runs UVS_LARGE_OCC workgroups per compute unit
     HIPCHK(s, hipEventRecord(s->ev0, s->stream));
     for (int p = 0; p < passes; ++p) {
         hipLaunchKernelGGL(k_large_chunks, dim3(L.grid + 1), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, 0, 0, 0.0, L.d_partials, lc, L.grid, L.d_fimg);
@@ -1621,7 +1643,7 @@ int uvs_large_solve_fused(uvs_solver* s, const uvs_window* w, uvs_state* out, uv
         hipLaunchKernelGGL(k_large_reduce, dim3((LG_RED + 15) / 16), dim3(256), 0, s->stream, L.d_partials, rows, L.d_reduced, lc);
         if (L.comm) { const int e = r.AllReduce(L.d_reduced, L.d_reduced, LG_XCH, kNcclDouble, kNcclSum, L.comm, s->stream); if (e != 0) return fused_abort(s, "ncclAllReduce(reduced) failed"); }
         hipLaunchKernelGGL(k_large_solve, dim3(1), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, L.d_reduced, 0, 0.0, L.d_out, lc, L.d_fimg);
-        hipLaunchKernelGGL(k_large_backsub, dim3(L.grid + 1), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, 0, L.d_bsums, lc, L.grid, L.d_out);
+        hipLaunchKernelGGL(k_large_backsub, dim3(bgrid + 1), dim3(NT), LDS_BYTES_BACKSUB, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, 0, L.d_bsums, lc, bgrid, L.d_out);
         if (L.comm) {
             hipLaunchKernelGGL(k_large_sum_bsums, dim3(1), dim3(256), 0, s->stream, L.d_bsums, L.n_chunks, L.d_sc5, lc, ko.max_ticks);
             const int e = r.AllReduce(L.d_sc5, L.d_sc5, 8, kNcclDouble, kNcclSum, L.comm, s->stream); if (e != 0) return fused_abort(s, "ncclAllReduce(step scalars) failed");
@@ -1634,6 +1656,10 @@ int uvs_large_solve_fused(uvs_solver* s, const uvs_window* w, uvs_state* out, uv
     HIPCHK(s, hipMemcpyAsync(s->h_out, s->d_outpack, out_doubles * 8, hipMemcpyDeviceToHost, s->stream));
     HIPCHK(s, hipStreamSynchronize(s->stream));
     if (loop_ms) HIPCHK(s, hipEventElapsedTime(loop_ms, s->ev0, s->ev1));
+    if (lprof) {
+        std::vector<long long> tp(1024 * 8);
+        if (hipMemcpyFromSymbol(tp.data(), HIP_SYMBOL(g_large_prof), tp.size() * 8) == hipSuccess) { if (FILE* f = std::fopen(lprof, "wb")) { const int hdr[2] = {L.grid + 1, L.n_chunks}; std::fwrite(hdr, 4, 2, f); std::fwrite(tp.data(), 8, tp.size(), f); std::fclose(f); } }
+    }
     const double* ho = (const double*)s->h_out;
     const double* ctl = ho;
     L.active = false;

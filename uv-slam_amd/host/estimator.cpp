@@ -36,6 +36,7 @@ Estimator::Estimator() : frame_count(0), first_imu(false), sum_of_back(0), sum_o
 }
 Estimator::~Estimator() {
     if (eval_solver) { if (uvs::evaluation_solver() == eval_solver) uvs::set_evaluation_solver(nullptr); uvs_destroy(eval_solver); }
+    finishMarginalization();
     uvs_destroy(solver); delete last_marginalization_info; for (auto* p : pre_integrations) delete p;
 }
 
@@ -163,8 +164,29 @@ void Estimator::assembleWindow(uvs::WindowAssembly& wa) {
         if (FeatureManager::usedLine(track)) wa.addLineTrack(track);
 }
 
+// The window a marginalization in flight reads (uvs_solver.h: uvs_marginalize_resident_begin -- everything `w` points to must outlive the call): the assembly moves
+// here (a moved std::vector keeps its buffer, so the descriptor's pointers stay good); inverse depths / line parameters are the para_* members, which nobody
+// rewrites before finishMarginalization() at the top of the next optimization().
+struct Estimator::PendingMarginalization { uvs::WindowAssembly wa; uvs_window w; };
+
+void Estimator::finishMarginalization() {
+    if (!pending_marginalization) return;
+    const auto t0 = std::chrono::steady_clock::now();
+    MarginalizationInfo* fresh = new MarginalizationInfo();
+    const int rc = uvs_marginalize_wait(solver, &fresh->prior);
+    delete last_marginalization_info;      // the input of the call that has just ended
+    last_marginalization_info = fresh;
+    if (rc != UVS_OK) {      // the reference has no error path here; an un-shifted old prior would attach to the wrong frames, so the prior is dropped
+        std::fprintf(stderr, "Estimator::optimization: marginalization failed (%s: %s); continuing without a prior\n", uvs_status_string(rc), uvs_last_error(solver));
+        delete last_marginalization_info; last_marginalization_info = nullptr;
+    }
+    delete pending_marginalization; pending_marginalization = nullptr;
+    marginalize_ms += ms_since(t0);      // the part of the marginalization the caller had to wait for
+}
+
 void Estimator::optimization() {      // estimator.cpp:761-1233
     const auto t_begin = std::chrono::steady_clock::now();
+    finishMarginalization();             // the prior of the previous frame (usually there already: it was computed beside slideWindow / processIMU / processImage)
     vector2double();
     uvs::WindowAssembly wa;
     assembleWindow(wa);
@@ -203,16 +225,27 @@ void Estimator::optimization() {      // estimator.cpp:761-1233
         // must be linearized at -- and remember as x0 -- the post-solve values (the reference packs again at :1004 before it marginalizes)
         std::memcpy(w.pose, para_Pose, sizeof(w.pose)); std::memcpy(w.speedbias, para_SpeedBias, sizeof(w.speedbias));
         std::memcpy(w.ex_pose, para_Ex_Pose[0], sizeof(w.ex_pose)); w.td = para_Td[0][0];
-        MarginalizationInfo* marginalization_info = new MarginalizationInfo();
         const auto t0 = std::chrono::steady_clock::now();
-        const int rc = uvs_marginalize_resident(solver, &w, marginalization_flag == MARGIN_OLD ? 0 : 1, &marginalization_info->prior);
-        marginalize_ms += ms_since(t0);
-        delete last_marginalization_info;
-        last_marginalization_info = marginalization_info;
-        if (rc != UVS_OK) {      // the reference has no error path here; an un-shifted old prior would attach to the wrong frames, so the prior is dropped
-            std::fprintf(stderr, "Estimator::optimization: marginalization failed (%s: %s); continuing without a prior\n", uvs_status_string(rc), uvs_last_error(solver));
-            delete last_marginalization_info; last_marginalization_info = nullptr;
+        if (std::getenv("UVS_HOST_SYNC_MARGINALIZATION")) {      // the one-call form (diagnostics: its time is then all on the critical path)
+            MarginalizationInfo* marginalization_info = new MarginalizationInfo();
+            const int rc = uvs_marginalize_resident(solver, &w, marginalization_flag == MARGIN_OLD ? 0 : 1, &marginalization_info->prior);
+            delete last_marginalization_info;
+            last_marginalization_info = marginalization_info;
+            if (rc != UVS_OK) {
+                std::fprintf(stderr, "Estimator::optimization: marginalization failed (%s: %s); continuing without a prior\n", uvs_status_string(rc), uvs_last_error(solver));
+                delete last_marginalization_info; last_marginalization_info = nullptr;
+            }
+        } else {
+            // begin now, wait at the top of the next optimization(): the old prior (w.prior) and the observation arrays stay alive in pending_marginalization
+            pending_marginalization = new PendingMarginalization{std::move(wa), w};
+            const int rc = uvs_marginalize_resident_begin(solver, &pending_marginalization->w, marginalization_flag == MARGIN_OLD ? 0 : 1);
+            if (rc != UVS_OK) {
+                std::fprintf(stderr, "Estimator::optimization: marginalization could not start (%s: %s); continuing without a prior\n", uvs_status_string(rc), uvs_last_error(solver));
+                delete pending_marginalization; pending_marginalization = nullptr;
+                delete last_marginalization_info; last_marginalization_info = nullptr;
+            }
         }
+        marginalize_ms += ms_since(t0);
     }
     optimization_ms += ms_since(t_begin); ++optimization_calls;
 }
@@ -234,6 +267,7 @@ void Estimator::clearState() {        // back to "nothing seen yet"
     std::fill(tic, tic + NUM_OF_CAM, Eigen::Vector3d::Zero());
     std::fill(ric, ric + NUM_OF_CAM, Eigen::Matrix3d::Identity());
     f_manager.clearState();
+    finishMarginalization();
     delete last_marginalization_info;
     last_marginalization_info = nullptr;
     drift_correct_t = Eigen::Vector3d::Zero();

@@ -70,6 +70,11 @@ class Estimator {
     double para_Td[1][1];
     double para_Ortho_plucker[NUM_OF_LF][SIZE_LINE_FEATURE];
     MarginalizationInfo* last_marginalization_info;
+    // round 4: the marginalization of optimization() runs beside the caller's work between two frames (uvs_marginalize_resident_begin / _wait).  While it is in
+    // flight the window it reads stays alive here: the assembly (observation arrays), the descriptor that points into it, and the OLD prior (its input).
+    struct PendingMarginalization;
+    PendingMarginalization* pending_marginalization = nullptr;
+    void finishMarginalization();      // blocks until the new prior is there and installs it as last_marginalization_info; a no-op when nothing is in flight
     // relocalization variables (estimator.h:131-144)
     bool relocalization_info;
     double relo_frame_stamp;

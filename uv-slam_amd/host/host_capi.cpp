@@ -78,6 +78,7 @@ extern "C" int uvs_host_replay_window(const char* in_path, const char* out_path,
             std::memcpy(est.relo_Pose, w.relo_pose, sizeof(est.relo_Pose));      // replay the recorded start value exactly
         }
         est.optimization();
+        est.finishMarginalization();      // (the prior is read right below)
         FILE* f = std::fopen(out_path, "wb"); if (!f) return -6;
         double hdr[4] = {(double)est.last_summary.status, (double)est.last_summary.report.num_iterations, est.last_summary.report.initial_cost, est.last_summary.report.final_cost};
         std::fwrite(hdr, 8, 4, f);
