@@ -54,6 +54,7 @@ if large:
     for k, d in large.items():
         if "FETCH_SIZE_per_launch_mean" in d and "WRITE_SIZE_per_launch_mean" in d:
             d["hbm_bytes_per_launch"] = (2 * d["FETCH_SIZE_per_launch_mean"] + d["WRITE_SIZE_per_launch_mean"]) * 1024; tot += d["hbm_bytes_per_launch"]
+            d["hbm_bytes_per_launch_uncorrected"] = (d["FETCH_SIZE_per_launch_mean"] + d["WRITE_SIZE_per_launch_mean"]) * 1024      # (k_large_reduce re-reads the 10.2 MB of partials k_large_chunks has just written: its uncorrected figure is the plausible one -- the x2 of the streaming-read calibration is an upper bound there)
     out["large_window_kernels"] = large
     out["large_window_hbm_bytes_per_iteration"] = tot
 json.dump(out, open(f"{ROOT}/profiles/{tag}_pmc_summary.json", "w"), indent=1)

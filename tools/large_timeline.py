@@ -4,6 +4,7 @@ import importlib, os, sys, struct
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 out = "/tmp/uvs_large_prof.bin"; os.environ["UVS_LARGE_PROF"] = out
+os.environ["UVS_REDAMP"] = "0"      # every pass linearizes: the recorded launch (the last active one) is then a full linearization, not the re-damping after a rejected step
 uvs = importlib.import_module("uv-slam_amd"); synth, api = uvs.synth, uvs.api
 which = sys.argv[1] if len(sys.argv) > 1 else "config3"
 if which == "canonical":

@@ -39,7 +39,7 @@ static constexpr int NW = NT / 64;
 static constexpr int CP_PB = NT > 256 ? 2 : 4;      // cost pass: point observations per batch
 static constexpr int CP_LB = NT > 256 ? 1 : 2;      // cost pass: line observations per batch
 static constexpr int BS_LNB = NT > 256 ? 2 : 4;     // back substitution: line observations per batch
-static constexpr int PR_UN = NT > 256 ? 12 : 24;    // prior residual: rows of J0^T in flight
+static constexpr int PR_UN = NT > 256 ? 13 : 26;    // prior mat-vec: rows of H0 in flight (26: the 25 rows per part of the n = 75 prior are ONE round trip, not 24 + 1)
 static constexpr int PG_UN = NT > 256 ? 16 : 32;    // prior gradient: rows of J0 in flight
 
 // ---- LDS map (in doubles).  The small arrays come FIRST and the big region (reduced system / staging area) LAST, so that a kernel that needs only part of
@@ -64,8 +64,10 @@ static constexpr int L_PROF = L_CTRL + 32;      // per-phase cycle counters (deb
 static constexpr int L_WPROF = L_PROF + 24;     // debug sub-timers: [0..3] candidate-cost phase (stage + dx, prior residual, observations, IMU), [4..7] busy cycles of each wave in the Cholesky column phase
 static constexpr int L_LCOST = L_WPROF + 8;     // per-lane cost accumulator of the current linearization (kept in LDS, not in a register that
 static constexpr int LACC = NT > 256 ? NT / 256 : 1;      // lanes sharing one accumulator slot (the 512-thread build has no LDS left for one per lane)
-static constexpr int L_LGMAX = L_LCOST + NT / LACC;    // would have to live across every phase) ; per-lane max |g_landmark|
-static constexpr int L_SMALL = (L_LGMAX + NT / LACC + 1) & ~1;      // end of the small arrays (even: the region below holds 16-byte rows)
+static constexpr int L_LGMAX = L_LCOST + NT / LACC;    // would have to live across every phase) ; max |g_landmark| per WAVE (a maximum does not care how it is grouped: 8 doubles instead of one per lane)
+static constexpr int L_PX0 = L_LGMAX + 8;              // the prior's linearization point, 9 doubles per kept block, and its block table (kind, frame, size, column offset: 4 x 16 ints) -- staged
+static constexpr int L_PTAB = L_PX0 + 9 * UVS_MAX_PRIOR_BLOCKS;      // once per solve by k_solve (stage_prior_tables): prior_dx runs 21 times per solve and its global round trip was ~2.5 k cycles each
+static constexpr int L_SMALL = (L_PTAB + 2 * UVS_MAX_PRIOR_BLOCKS + 1) & ~1;      // end of the small arrays (even: the region below holds 16-byte rows)
 static constexpr int L_S = L_SMALL;            // the reduced system S (66 lower 16 x 16 blocks, 17-double rows) / the staging area of a landmark chunk / scratch of the frame phases
 static constexpr int L_TOTAL = L_S + UVS_S_DOUBLES;
 static_assert(L_TOTAL * 8 <= 160 * 1024, "LDS map exceeds the 160 KB of a CU");
@@ -153,16 +155,20 @@ UVS_DEV void block_reduce(double* sh, double* s /*[4]*/, double* mx) {
 // per-lane (or per lane pair) accumulators of the running linearization
 UVS_DEV void lacc_set(double* sh, double cost, double gmax) {
     const int tid = lane_tid();
-    if (LACC == 2) { cost += __shfl_xor(cost, 1, 64); gmax = fmax(gmax, __shfl_xor(gmax, 1, 64)); }
-    if (tid % LACC == 0) { sh[L_LCOST + tid / LACC] = cost; sh[L_LGMAX + tid / LACC] = gmax; }
+    if (LACC == 2) cost += __shfl_xor(cost, 1, 64);
+    if (tid % LACC == 0) sh[L_LCOST + tid / LACC] = cost;
+    const double wm = wave_max(gmax);
+    if ((tid & 63) == 0) sh[L_LGMAX + (tid >> 6)] = wm;
 }
 UVS_DEV void lacc_add(double* sh, double cost, double gmax) {
     const int tid = lane_tid();
-    if (LACC == 2) { cost += __shfl_xor(cost, 1, 64); gmax = fmax(gmax, __shfl_xor(gmax, 1, 64)); }
-    if (tid % LACC == 0) { sh[L_LCOST + tid / LACC] += cost; sh[L_LGMAX + tid / LACC] = fmax(sh[L_LGMAX + tid / LACC], gmax); }
+    if (LACC == 2) cost += __shfl_xor(cost, 1, 64);
+    if (tid % LACC == 0) sh[L_LCOST + tid / LACC] += cost;
+    const double wm = wave_max(gmax);
+    if ((tid & 63) == 0) sh[L_LGMAX + (tid >> 6)] = fmax(sh[L_LGMAX + (tid >> 6)], wm);
 }
 UVS_DEV double lacc_cost(const double* sh) { const int tid = lane_tid(); return tid % LACC == 0 ? sh[L_LCOST + tid / LACC] : 0.0; }
-UVS_DEV double lacc_gmax(const double* sh) { return sh[L_LGMAX + lane_tid() / LACC]; }
+UVS_DEV double lacc_gmax(const double* sh) { return sh[L_LGMAX + (lane_tid() >> 6)]; }
 
 struct Ctx {
     const DevWin* hdr;
@@ -172,6 +178,7 @@ struct Ctx {
     double* sh;            // LDS
     KOpts o;
     int ltrig_ok = 0;      // the sin/cos cache of the line parameters (w_ltrig0/1) is maintained (k_solve) -- the step-wise large-window kernels leave it off
+    int ptab_ok = 0;       // the prior's block table and linearization point are staged in LDS (L_PTAB / L_PX0: k_solve) -- the other kernels read them from the blob
 };
 
 // sin/cos cache that belongs to the line-parameter buffer `line` (nullptr: compute on the fly)
@@ -206,16 +213,32 @@ UVS_DEV void load_point_obs(const Ctx& c, int o, double td, double* pi, double* 
 }
 
 // ------------------------------------------------------------------ residual-only cost at `x` (LDS) / landmark buffer `sel`
+UVS_DEV void stage_prior_tables(const Ctx& c) {      // once per solve; the caller's next barrier precedes the first prior_dx
+    const int tid = lane_tid();
+    const DevWin& h = *c.hdr;
+    if (h.prior_n <= 0) return;
+    int* tab = (int*)(c.sh + L_PTAB);
+    if (tid < 4 * UVS_MAX_PRIOR_BLOCKS) tab[tid] = c.bi[h.i_prior + tid];      // kind[16] frame[16] size[16] idx[16]
+    if (tid < 9 * UVS_MAX_PRIOR_BLOCKS) c.sh[L_PX0 + tid] = c.bd[h.d_prior + h.prior_n * h.prior_n + 2 * h.prior_n + tid];
+}
 UVS_DEV void prior_dx(const Ctx& c, const double* x) {
     const int tid = lane_tid();
     const DevWin& h = *c.hdr;
     if (h.prior_n > 0 && tid < h.prior_nb) {
-        const int* pt = c.bi + h.i_prior;
-        const int kind = pt[tid], frame = pt[16 + tid], size = pt[32 + tid], idx = pt[48 + tid];
-        const double* x0g = c.bd + h.d_prior + h.prior_n * h.prior_n + 2 * h.prior_n + 9 * tid;      // stride 9 per block (pack_window): independent of the table
+        int kind, frame, size, idx;
         double x0[9];
+        if (c.ptab_ok) {
+            const int* tab = (const int*)(c.sh + L_PTAB);
+            kind = tab[tid]; frame = tab[16 + tid]; size = tab[32 + tid]; idx = tab[48 + tid];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) x0[k] = x0g[k];
+            for (int k = 0; k < 9; ++k) x0[k] = c.sh[L_PX0 + 9 * tid + k];
+        } else {
+            const int* pt = c.bi + h.i_prior;
+            kind = pt[tid]; frame = pt[16 + tid]; size = pt[32 + tid]; idx = pt[48 + tid];
+            const double* x0g = c.bd + h.d_prior + h.prior_n * h.prior_n + 2 * h.prior_n + 9 * tid;      // stride 9 per block (pack_window): independent of the table
+#pragma unroll
+            for (int k = 0; k < 9; ++k) x0[k] = x0g[k];
+        }
         const double* xb = (kind == UVS_BLOCK_POSE) ? x + 7 * frame : (kind == UVS_BLOCK_SPEEDBIAS) ? x + 77 + 9 * frame : (kind == UVS_BLOCK_TD) ? x + 183 : x + 176;
         double* dx = c.sh + L_PDX + idx;
         if (size != 7) { for (int k = 0; k < size; ++k) dx[k] = xb[k] - x0[k]; }
@@ -250,7 +273,7 @@ UVS_DEV double prior_quad(const Ctx& c, int dst = L_PR) {
         for (int k = kb; k < ke; k += PR_UN) {
             double jv[PR_UN];
 #pragma unroll
-            for (int u = 0; u < PR_UN; ++u) jv[u] = H0[(k + u < ke ? k + u : kb) * n + row];      // H0 is symmetric: row k, entry `row` -- consecutive lanes, consecutive addresses
+            for (int u = 0; u < PR_UN; ++u) jv[u] = H0[(k + u < ke ? k + u : kb) * n + row];      // H0 is symmetric: row k, entry `row` -- consecutive lanes, consecutive addresses (the packed lower triangle, 23 instead of 45 KB per evaluation, was measured: its scattered upper-half reads cost more than the bytes, -0.6 % on the batch)
 #pragma unroll
             for (int u = 0; u < PR_UN; ++u) if (k + u < ke) p8[u & 7] += jv[u] * c.sh[L_PDX + k + u];
         }
@@ -2341,6 +2364,9 @@ __global__ __launch_bounds__(NT) void k_solve(char* blobs, const long long* blob
     for (int k = tid; k < 4 * h.n_lines; k += NT) c.ws[h.w_line0 + k] = c.bd[h.d_line + k];
     for (int k = tid; k < h.n_lines; k += NT) line_trig(c.bd + h.d_line + 4 * k, c.ws + h.w_ltrig0 + 8 * k);
     c.ltrig_ok = 1;
+#ifndef UVS_X_NO_PTAB
+    stage_prior_tables(c); c.ptab_ok = 1;
+#endif
     for (int i = tid; i < (int)(sizeof(uvs_report) / 4); i += NT) ((int*)rep)[i] = 0;
     if (tid < 24) sh[L_PROF + tid] = (tid == 23) ? (double)clock64() : 0.0;
     if (tid < 8) sh[L_WPROF + tid] = 0.0;

@@ -574,6 +574,7 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
         }
     };
     const int inner_threads = pack_inner_threads(h.n_pt_obs + h.n_ln_obs);
+    std::vector<int> cnt_s((size_t)n_ch * UVS_NBLKX2), cnt_d((size_t)n_ch * UVS_NBLKX2);      // entries per chunk and pose block (first pass), reused when the lists are written
     {
         struct Cnt { long s[UVS_NBLKX2], d[UVS_NBLKX2], wp[UVS_NBLKX2], wl[UVS_NBLKX2]; };
         std::vector<Cnt> part((size_t)std::max(inner_threads, 1));
@@ -583,6 +584,7 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
             for (int qc = q0; qc < q1; ++qc) {
                 long cs[UVS_NBLKX2] = {0}, cd[UVS_NBLKX2] = {0};
                 chunk_entries(qc, [&](int b, int) { ++cs[b]; }, [&](int b, int) { ++cd[b]; });
+                for (int b = 0; b < UVS_NBLKX2; ++b) { cnt_s[(size_t)qc * UVS_NBLKX2 + b] = (int)cs[b]; cnt_d[(size_t)qc * UVS_NBLKX2 + b] = (int)cd[b]; }
                 const int type = chunks[6 * qc];
                 // work units ~ cycles per entry of the rows-per-lane gather
                 for (int b = 0; b < UVS_NBLKX2; ++b) {
@@ -616,16 +618,18 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
         // is the LARGEST per-group share within each family, not the per-group total: a block that is heavy in the point chunks only (the
         // diagonal blocks: all the J^T J terms) must be split until its point share matches the others', even if its total looks average.
         // Greedy: the next spare group goes to the family whose current maximum weighs more, and there to the block that holds it.
+        int act[UVS_NBLKX2], na = 0;      // the blocks that take part (ascending: the scans below keep the tie-breaking order of a scan over all blocks)
+        for (int b = 0; b < UVS_NBLKX2; ++b) if (np[b] > 0) act[na++] = b;
         while (used < UVS_NGRP) {
             int bp = -1, bl = -1;
-            for (int b = 0; b < UVS_NBLKX2; ++b) {
-                if (np[b] == 0 || np[b] >= 16) continue;
+            double mp = 0.0, ml = 0.0;      // the true maxima include the blocks that cannot be split any further
+            for (int q = 0; q < na; ++q) {
+                const int b = act[q];
+                mp = std::max(mp, (double)blk_wp[b] / np[b]); ml = std::max(ml, (double)blk_wl[b] / np[b]);
+                if (np[b] >= 16) continue;
                 if (blk_wp[b] > 0 && (bp < 0 || blk_wp[b] * np[bp] > blk_wp[bp] * np[b])) bp = b;
                 if (blk_wl[b] > 0 && (bl < 0 || blk_wl[b] * np[bl] > blk_wl[bl] * np[b])) bl = b;
             }
-            // the true maxima include the blocks that cannot be split any further
-            double mp = 0.0, ml = 0.0;
-            for (int b = 0; b < UVS_NBLKX2; ++b) if (np[b] > 0) { mp = std::max(mp, (double)blk_wp[b] / np[b]); ml = std::max(ml, (double)blk_wl[b] / np[b]); }
             int best = -1;
             const double sp_ = bp >= 0 ? (double)blk_wp[bp] / np[bp] : -1.0, sl_ = bl >= 0 ? (double)blk_wl[bl] / np[bl] : -1.0;
             if (bp >= 0 && sp_ >= mp && (mp >= ml || bl < 0 || sl_ < ml)) best = bp;
@@ -665,27 +669,50 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
         const bool dbg_lists = std::getenv("UVS_DEBUG_LISTS") != nullptr;
         pack_parallel(n_ch, dbg_lists ? 1 : inner_threads, [&](int q0, int q1, int t) {
             Part& P = part[t]; P.q0 = q0; P.q1 = q1;
-            std::vector<std::vector<int>> eS(UVS_NBLKX2), eD(UVS_NBLKX2);
-            std::vector<int> ent;
+            // A group's list is a contiguous slice [n p / np, n (p + 1) / np) of its block's entries in generation order; with the counts of the first pass the
+            // destination of every entry is known before it is generated, so the entries go straight to their place (no per-block vectors: they were half of
+            // the packing time of a canonical window).
+            int first_grp[UVS_NBLKX2], blk_np[UVS_NBLKX2];
+            for (int b = 0; b < UVS_NBLKX2; ++b) { first_grp[b] = -1; blk_np[b] = 0; }
+            for (int g = 0; g < UVS_NGRP; ++g) if (g_blk[g] >= 0) { blk_np[g_blk[g]] = g_np[g]; if (g_part[g] == 0) first_grp[g_blk[g]] = g; }
+            int dst[2][UVS_NGRP], lo_of[2][UVS_NGRP], fill[2][UVS_NBLKX2], cur_part[2][UVS_NBLKX2], cur_hi[2][UVS_NBLKX2];
             for (int qc = q0; qc < q1; ++qc) {
-                for (int b = 0; b < UVS_NBLKX2; ++b) { eS[b].clear(); eD[b].clear(); }
-                chunk_entries(qc, [&](int b, int v) { eS[b].push_back(v); }, [&](int b, int v) { eD[b].push_back(v); });
+                const int* cS = cnt_s.data() + (size_t)qc * UVS_NBLKX2; const int* cD = cnt_d.data() + (size_t)qc * UVS_NBLKX2;
                 chunks[6 * qc + 3] = (int)P.lists.size();      // relative to this part for now
                 const size_t base = P.lists.size();
-                P.lists.resize(base + 2 * (UVS_NGRP + 1));
-                ent.clear();
+                int at = 0;
                 for (int pass = 0; pass < 2; ++pass) {
-                    const auto& L = pass == 0 ? eS : eD;
+                    const int* cnt = pass == 0 ? cS : cD;
                     for (int g = 0; g < UVS_NGRP; ++g) {
-                        P.lists[base + pass * (UVS_NGRP + 1) + g] = (int)ent.size();
+                        dst[pass][g] = at; lo_of[pass][g] = 0;
                         if (g_blk[g] < 0) continue;
-                        const auto& v = L[g_blk[g]];
-                        const size_t n = v.size(), lo = n * g_part[g] / g_np[g], hi = n * (g_part[g] + 1) / g_np[g];
-                        ent.insert(ent.end(), v.begin() + lo, v.begin() + hi);
+                        const long n = cnt[g_blk[g]], lo = n * g_part[g] / g_np[g], hi = n * (g_part[g] + 1) / g_np[g];
+                        lo_of[pass][g] = (int)lo; at += (int)(hi - lo);
                     }
-                    P.lists[base + pass * (UVS_NGRP + 1) + UVS_NGRP] = (int)ent.size();
                 }
-                P.lists.insert(P.lists.end(), ent.begin(), ent.end());
+                const int n_ent = at;
+                P.lists.resize(base + 2 * (UVS_NGRP + 1) + n_ent);
+                int* hdrp = P.lists.data() + base; int* ent = hdrp + 2 * (UVS_NGRP + 1);
+                for (int pass = 0; pass < 2; ++pass) {
+                    for (int g = 0; g < UVS_NGRP; ++g) hdrp[pass * (UVS_NGRP + 1) + g] = dst[pass][g];
+                    hdrp[pass * (UVS_NGRP + 1) + UVS_NGRP] = pass == 0 ? dst[1][0] : n_ent;
+                }
+                // (the entries of a block arrive in order, so its current part and that part's end are carried along: no division per entry)
+                for (int b = 0; b < UVS_NBLKX2; ++b) for (int pass = 0; pass < 2; ++pass) {
+                    fill[pass][b] = 0; cur_part[pass][b] = 0;
+                    const long n = (pass == 0 ? cS : cD)[b];
+                    cur_hi[pass][b] = blk_np[b] > 0 ? (int)(n / blk_np[b]) : 0;
+                    while (blk_np[b] > 0 && cur_part[pass][b] + 1 < blk_np[b] && cur_hi[pass][b] == 0) { ++cur_part[pass][b]; cur_hi[pass][b] = (int)(n * (cur_part[pass][b] + 1) / blk_np[b]); }      // leading empty parts
+                }
+                const auto put = [&](int pass, int b, int v) {
+                    const int np_ = blk_np[b];
+                    if (np_ <= 0) return;      // (a block without a group has no work by construction)
+                    const int e = fill[pass][b]++;
+                    while (e >= cur_hi[pass][b] && cur_part[pass][b] + 1 < np_) { ++cur_part[pass][b]; cur_hi[pass][b] = (int)((long)(pass == 0 ? cS : cD)[b] * (cur_part[pass][b] + 1) / np_); }
+                    const int g = first_grp[b] + cur_part[pass][b];
+                    ent[dst[pass][g] + (e - lo_of[pass][g])] = v;
+                };
+                chunk_entries(qc, [&](int b, int v) { put(0, b, v); }, [&](int b, int v) { put(1, b, v); });
                 chunks[6 * qc + 4] = (int)(P.lists.size() - base);
                 {   // the chunk as the kernel lays it out must fit the staging area: records + Schur factors + the lists just built (an estimate that
                     // is too small would let the lists run over the LM state that follows S in LDS)
