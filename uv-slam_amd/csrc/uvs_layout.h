@@ -52,6 +52,9 @@
 #define UVS_LN_JP 2               // pose-Jacobian rows at 2, 8, 14
 #define UVS_LN_RV 20              // VP residual, later its Schur-corrected value
 #define UVS_LN_JL 22              // line-parameter Jacobian rows at 22, 26, 30
+#define UVS_LN_EY 26              // LDS doubles per line observation in the staged E = J_l^T J_p and Y = H_ll^-1 E (4 rows of 6 + 2 pad): with the natural 24 (48 dwords) the
+                                  // observations fall into only FOUR bank classes of the 64-bank LDS (gcd(48, 64) = 16) and the 32 gather groups of a wave -- and the 48 stores per lane
+                                  // of pass B2 -- collided 8-fold; 52 dwords give the 16 classes a 16-byte access can have (round 4)
 #ifndef UVS_NT
 #define UVS_NT 256                // threads per workgroup of the solve kernels
 #endif

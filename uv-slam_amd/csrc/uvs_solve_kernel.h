@@ -1176,7 +1176,7 @@ UVS_DEV void gather_lines(int grp, const int* lists, const double* S0, GAcc& A, 
                     o.y[q][0] = lds2(pb + 6 * q); o.y[q][1] = lds2(pb + 6 * q + 2); o.y[q][2] = lds2(pb + 6 * q + 4);
                 }
                 if (DELTA) {
-                    const double* pg = S0 + goff + ((lo - eoff) >> 2) + r0;
+                    const double* pg = S0 + goff + 6 * ((lo - eoff) / UVS_LN_EY) + r0;
 #pragma unroll
                     for (int r = 0; r < GR; ++r) o.gg[r] = pg[r];
                 }
@@ -1478,9 +1478,9 @@ UVS_DEV void lin_chunk(const Ctx& c, int ch, const double* x, const double* invd
             const int* beg = c.bi + h.i_ln_beg;
             const int o0 = beg[k0], o1 = beg[k1], nob = o1 - o0;
             double* rec = sh + L_S;                                  // [nob][33]
-            double* Eb = rec + (size_t)nob * UVS_LN_REC;             // [nob][24]  E[c][a] = (J_l^T J_p)
-            double* Yb = Eb + (size_t)nob * 24;                      // [nob][24]  Y = Hinv E
-            double* Xb = Yb + (size_t)nob * 24;                      // [nlm][20] : Hinv[16], Hinv*g[4]
+            double* Eb = rec + (size_t)nob * UVS_LN_REC;             // [nob][UVS_LN_EY]  E[c][a] = (J_l^T J_p)   (24 used, see uvs_layout.h)
+            double* Yb = Eb + (size_t)nob * UVS_LN_EY;               // [nob][UVS_LN_EY]  Y = Hinv E
+            double* Xb = Yb + (size_t)nob * UVS_LN_EY;               // [nlm][20] : Hinv[16], Hinv*g[4]
             int* lists = (int*)(Xb + 20 * nlm);
             for (int t = tid; t < nlist; t += NT) lists[t] = glists[t];
             // pass A
@@ -1563,7 +1563,7 @@ UVS_DEV void lin_chunk(const Ctx& c, int ch, const double* x, const double* invd
             for (int o = tid; o < nob; o += NT) {
                 double* R = rec + (size_t)o * UVS_LN_REC;
                 const int li = (int)R[UVS_LN_RV + 1];
-                double* E = Eb + (size_t)o * 24; double* Y = Yb + (size_t)o * 24;
+                double* E = Eb + (size_t)o * UVS_LN_EY; double* Y = Yb + (size_t)o * UVS_LN_EY;
                 double* Yg = c.ws + h.w_ln_Y + 24 * (size_t)(o0 + o);
                 // all LDS reads BEFORE the first LDS write (the compiler must assume the E / Y stores alias the record)
                 double Xv[20], Jl[12], Jp[18];
@@ -1660,8 +1660,8 @@ UVS_DEV void redamp_chunk(const Ctx& c, int ch, double radius, int grp, GAcc& ac
         double* T = rec;                                         // [nlm][34]: (H + D_new)^-1 [16] | change of (H + D)^-1 g [4] | H [10] | D_old [4]
         double* Gb = rec + (size_t)nlm * 34;                     // [nob][6]
         double* Eb = rec + (size_t)nob * UVS_LN_REC;             // same places as in lin_chunk
-        double* Yb = Eb + (size_t)nob * 24;
-        double* Xb = Yb + (size_t)nob * 24;
+        double* Yb = Eb + (size_t)nob * UVS_LN_EY;
+        double* Xb = Yb + (size_t)nob * UVS_LN_EY;
         int* lists = (int*)(Xb + 20 * nlm);
         for (int t = tid; t < nlist; t += NT) lists[t] = glists[t];
         for (int li = tid; li < nlm; li += NT) {
@@ -1695,7 +1695,7 @@ UVS_DEV void redamp_chunk(const Ctx& c, int ch, double radius, int grp, GAcc& ac
             double* Yg = c.ws + h.w_ln_Y + 24 * (size_t)(o0 + o);
 #pragma unroll
             for (int q = 0; q < 24; ++q) yo[q] = Yg[q];
-            double* E = Eb + (size_t)o * 24; double* Y = Yb + (size_t)o * 24; double* G = Gb + (size_t)o * 6;
+            double* E = Eb + (size_t)o * UVS_LN_EY; double* Y = Yb + (size_t)o * UVS_LN_EY; double* G = Gb + (size_t)o * 6;
 #pragma unroll
             for (int a = 0; a < 6; ++a) {
                 double e[4];

@@ -458,7 +458,7 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
             long nob = lbeg[k1] - lbeg[k0], nlm = k1 - k0, nli = list_hdr;
             for (int k = k0; k < k1; ++k) { const long no = lbeg[k + 1] - lbeg[k]; nli += no * (no + 1) / 2 + no; }
             if (nlm > 1023 || nob > 16383) return -1;
-            return (long)(UVS_LN_REC + 48) * nob + 20 * nlm + (nli + 1) / 2;
+            return (long)(UVS_LN_REC + 2 * UVS_LN_EY) * nob + 20 * nlm + (nli + 1) / 2;
         };
         // smallest number of chunks whose EVEN split (by observation count) fits; the kernel pays a fixed cost per chunk, so a
         // greedy fill that leaves a nearly empty last chunk would waste a whole pass
@@ -482,7 +482,7 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
             if (n_lm == 0) return UVS_OK;
             // start at the capacity lower bound (records + Schur factors alone; the lists come on top): walking n = 1, 2, ... costs
             // O(n * landmarks) per attempt, milliseconds for the 340 chunks of configs[3]
-            const long mine = type == 0 ? (long)PREC * h.n_pt_obs + 12L * (h.n_pt_obs + XS * h.n_points) : (long)(UVS_LN_REC + 48) * h.n_ln_obs + 20L * h.n_lines;
+            const long mine = type == 0 ? (long)PREC * h.n_pt_obs + 12L * (h.n_pt_obs + XS * h.n_points) : (long)(UVS_LN_REC + 2 * UVS_LN_EY) * h.n_ln_obs + 20L * h.n_lines;
             const int n_first = (int)std::min<long>(n_lm, std::max<long>(std::max(1, n_from), mine / UVS_S_DOUBLES));
             for (int n = n_first; n <= n_lm; ++n) { cut = cuts_for(n, n_lm, beg, need); if (!cut.empty()) return UVS_OK; }
             return UVS_ERR_CAPACITY;
@@ -493,7 +493,7 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
         if (chunk_grid > 0) {
             const int n_pt = cut_pt.empty() ? 0 : (int)cut_pt.size() - 1, n_ln = cut_ln.empty() ? 0 : (int)cut_ln.size() - 1, n_min = n_pt + n_ln;
             // work per family ~ its staging volume; a chunk should keep at least ~64 observations (its fixed cost is a few microseconds)
-            const double w_pt = (double)PREC * h.n_pt_obs + 12.0 * (h.n_pt_obs + XS * h.n_points), w_ln = (double)(UVS_LN_REC + 48) * h.n_ln_obs + 20.0 * h.n_lines;
+            const double w_pt = (double)PREC * h.n_pt_obs + 12.0 * (h.n_pt_obs + XS * h.n_points), w_ln = (double)(UVS_LN_REC + 2 * UVS_LN_EY) * h.n_ln_obs + 20.0 * h.n_lines;
             static const long min_obs = std::getenv("UVS_CHUNK_MIN_OBS") ? std::max(1, std::atoi(std::getenv("UVS_CHUNK_MIN_OBS"))) : 64;
             const long by_size = (long)(h.n_pt_obs + h.n_ln_obs) / min_obs;
             long target = n_min >= chunk_grid ? (long)((n_min + chunk_grid - 1) / chunk_grid) * chunk_grid : std::min<long>(chunk_grid, std::max<long>(n_min, by_size));
@@ -564,11 +564,11 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
             }
         } else {
             const int o0 = lbeg[k0], nob = lbeg[k1] - o0;
-            const int oE = nob * UVS_LN_REC, oY = oE + 24 * nob;
+            const int oE = nob * UVS_LN_REC, oY = oE + UVS_LN_EY * nob;
             for (int k = k0; k < k1; ++k) {
                 const int b0 = lbeg[k] - o0, b1 = lbeg[k + 1] - o0;
                 for (int sa = 0; sa < b1 - b0; ++sa) for (int sb = 0; sb <= sa; ++sb)
-                    addS(blk_of(w->ln_fj[o0 + b0 + sa], w->ln_fj[o0 + b0 + sb]), (oE + 24 * (b0 + sa)) | ((oY + 24 * (b0 + sb)) << 16));
+                    addS(blk_of(w->ln_fj[o0 + b0 + sa], w->ln_fj[o0 + b0 + sb]), (oE + UVS_LN_EY * (b0 + sa)) | ((oY + UVS_LN_EY * (b0 + sb)) << 16));
                 for (int o = b0; o < b1; ++o) addD(blk_of(w->ln_fj[o0 + o], w->ln_fj[o0 + o]), o * UVS_LN_REC);
             }
         }
@@ -720,7 +720,7 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
                     const long nlist = (long)(P.lists.size() - base);
                     long used;
                     if (type == 0) { const long nob = pbeg[k1] - pbeg[k0], nlm = k1 - k0; used = (long)PREC * nob + 12 * (nob + XS * nlm) + (nlist + 1) / 2; }
-                    else { const long nob = lbeg[k1] - lbeg[k0], nlm = k1 - k0; used = (long)(UVS_LN_REC + 48) * nob + 20 * nlm + (nlist + 1) / 2; }
+                    else { const long nob = lbeg[k1] - lbeg[k0], nlm = k1 - k0; used = (long)(UVS_LN_REC + 2 * UVS_LN_EY) * nob + 20 * nlm + (nlist + 1) / 2; }
                     if (used > UVS_S_DOUBLES) P.overflow = true;
                     P.max_used = std::max(P.max_used, (int)used);
                 }
