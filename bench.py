@@ -38,7 +38,7 @@ FP64_PEAK_TFLOPS = 78.6      # MI355X FP64 vector = FP64 matrix (datasheet; not 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-K_SOLVE_SOURCES = ("uvs_solve_kernel.h", "uvs_factors.h", "uvs_layout.h", "uvs_solver.hip")      # k_solve's device code + the packing that lays its inputs out
+K_SOLVE_SOURCES = ("uvs_solve_kernel.h", "uvs_factors.h", "uvs_layout.h", "uvs_solver.hip", "uvs_solve512.hip")      # k_solve's device code + the packing that lays its inputs out
 
 
 def kernel_source_tag():

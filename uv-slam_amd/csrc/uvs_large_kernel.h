@@ -225,13 +225,14 @@ __global__ __launch_bounds__(NT, UVS_LARGE_OCC) void k_large_backsub(char* blob,
     double* invd_c = ws + (sel ? h.w_invd0 : h.w_invd1); double* line_c = ws + (sel ? h.w_line0 : h.w_line1);
     const int* pbeg = c.bi + h.i_pt_beg; const int* lbeg = c.bi + h.i_ln_beg;
     for (int ch = blockIdx.x; ch < h.n_chunks; ch += n_chunk_wgs) {      // persistent workgroups, as in k_large_chunks; the sums stay per chunk (8 doubles)
-        const int* chunk = c.bi + h.i_chunks + 6 * ch;
+        const int* chunk = c.bi + h.i_chunks + UVS_CHUNK_INTS * ch;
         const int type = chunk[0], k0 = chunk[1], k1 = chunk[2];
         double* bo = bsums + 8 * (size_t)ch;
         backsub_candidate<2>(c, invd, line, invd_c, line_c, type == 0 ? k0 : 0, type == 0 ? k1 : 0, type == 1 ? k0 : 0, type == 1 ? k1 : 0, false, bo);
         __threadfence_block();
         __syncthreads();
-        const int po0 = type == 0 ? pbeg[k0] : 0, po1 = type == 0 ? pbeg[k1] : 0, lo0 = type == 1 ? lbeg[k0] : 0, lo1 = type == 1 ? lbeg[k1] : 0;
+        const int ob0 = chunk[6], ob1 = ob0 + chunk[7];      // the chunk's observation range (descriptor: no dependent loads from the CSR arrays)
+        const int po0 = type == 0 ? ob0 : 0, po1 = type == 0 ? ob1 : 0, lo0 = type == 1 ? ob0 : 0, lo1 = type == 1 ? ob1 : 0;
         double cc = cost_pass<2, 1>(c, sh + L_XC, invd_c, line_c, po0, po1, lo0, lo1, false);
         double s4[4] = {cc, 0, 0, 0}, mx = 0.0;
         block_reduce(sh, s4, &mx);

@@ -59,14 +59,20 @@
 #define UVS_NT 256                // threads per workgroup of the solve kernels
 #endif
 #if UVS_NT != 256 && !defined(UVS_ALLOW_EXPERIMENTAL_NT)
-#error "only the 256-thread workgroup is validated: the 512-thread build is an occupancy experiment (DESIGN.md 6b) whose results differ; define UVS_ALLOW_EXPERIMENTAL_NT to build it anyway"
+#error "the library is built with 256 threads per workgroup; only uvs_solve512.hip instantiates the persistent kernel with 512 (it defines UVS_ALLOW_EXPERIMENTAL_NT)"
 #endif
 #ifndef UVS_GLANES
 #define UVS_GLANES 2                // lanes per gather group: 2 = three rows of the 6x6 block per lane, 1 = all six rows in one lane
 #endif
 #define UVS_GROWS (6 / UVS_GLANES)  // block rows held by one lane
-#define UVS_NGRP (UVS_NT / UVS_GLANES)      // gather groups; each owns one 6x6 pose block or one part of a split one
+#if UVS_NT > 256 && !defined(UVS_GATHER_ALL)
+#define UVS_GT 256                  // threads that hold gather accumulators: in the 512-thread build waves 4..7 (waves 0..3 evaluate observations; uvs_solve_kernel.h: ROLES)
+#else
+#define UVS_GT UVS_NT
+#endif
+#define UVS_NGRP (UVS_GT / UVS_GLANES)      // gather groups; each owns one 6x6 pose block or one part of a split one
 
+#define UVS_CHUNK_INTS 8
 struct DevWin {
     int32_t n_points, n_pt_obs, n_lines, n_ln_obs, n_imu, prior_n, prior_nb, n_chunks;
     int32_t pt_stride, ln_stride;     // SoA strides of the measurement arrays
@@ -91,7 +97,8 @@ struct DevWin {
     int32_t i_ln_lm, i_ln_fj, i_ln_vp, i_ln_beg;      // obs arrays + CSR begin[n_lines+1]
     int32_t i_imu;                    // [n_imu][2] : frame_i, skip
     int32_t i_prior;                  // kind[16] frame[16] size[16] idx[16] x0off[16] colmap[96] inverse colmap[176] touched S blocks[66]
-    int32_t i_chunks;                 // [n_chunks][6] : type(0 pt,1 ln), lm_begin, lm_end, offset of the chunk's gather lists in i_lists, their length, 0
+    int32_t i_chunks;                 // [n_chunks][UVS_CHUNK_INTS] : type(0 pt,1 ln), lm_begin, lm_end, offset of the chunk's gather lists in i_lists, their length, 0, first observation, observations
+                                      // (the last two save the kernel two dependent loads from the CSR arrays at the head of every chunk: the whole descriptor is ONE 32-byte scalar load)
     int32_t i_wblk;                   // [UVS_NGRP] gather group -> pose block id | 256 (diagonal block) | part << 9 (4 bits, split blocks) | fa << 13 | fb << 17 | (parts - 1) << 21 (the parts of a block are consecutive groups); -1 = idle
     int32_t i_lists;                  // per chunk: schur_off[81] direct_off[81] entries[...]  (group-major, see pack_window in uvs_solver.hip)
     // workspace
@@ -104,6 +111,7 @@ struct DevWin {
     int32_t w_out;                    // final state: frames[UVS_XDIM] | inv_depth[n_points] | line_orth[4 n_lines] (k_solve; the large path reads the cur buffers)
     int32_t w_prior_h0;               // the prior's quadratic form, written by setup_window: H0 = J0^T J0 dense [n][n] | g0 = J0^T r0 at UVS_PH_G0 | c0 = r0^T r0 / 2 at UVS_PH_C0 | diag(H0) by S index [176] at UVS_PH_HD
     int32_t n_pblk;                   // pose blocks of S the prior touches (ids in i_prior + 352)
+    int32_t w_gacc;                   // 512-thread build only: the gather accumulators of the last linearization, [24][UVS_GT] (what a re-damping continues from; the 256-thread build keeps them in registers)
     int32_t n_cimg, i_cimg;           // entries of H0 that are structurally non-zero in S: int32 index into the dense n x n H0 [n_cimg], then S offset [n_cimg]
     int32_t ws_doubles;
     int32_t blob_bytes;

@@ -1,0 +1,42 @@
+// uvs_solve512.hip -- the persistent LM kernel (uvs_solve_kernel.h: k_solve) instantiated with 512 threads per workgroup: two resident
+// wavefronts per SIMD, 256 registers per lane, waves 0..3 evaluate observations and waves 4..7 own the gather groups (ROLES).
+//
+// It is its own translation unit because the workgroup size is a compile-time constant of the kernel header (LDS map, loop strides, batch
+// sizes): everything else in the library -- the landmark-sharded kernels, k_evaluate, k_marg_linearize, the 256-thread k_solve that
+// UVS_KSOLVE_NT=256 selects for A/B runs -- is built with 256 threads in uvs_solver.hip.  The namespace is renamed so that the two
+// instantiations do not collide at link time; the blob and workspace layout (uvs_layout.h: UVS_GT = 256 gather threads either way), the
+// kernel arguments and the report are the same, so the host side only picks which launcher to call (launch_solve).
+//
+// Build flag of THIS file: -mllvm -disable-machine-licm.  Machine LICM hoists loop-invariant address arithmetic out of the LM loop -- the
+// whole kernel body -- and the hoisted values (hundreds) are live across every phase: 428 spilled VGPRs with it, 46 without (round 4).
+#define UVS_NT 512
+#define UVS_ALLOW_EXPERIMENTAL_NT 1
+#define UVS_SOLVE_KERNEL_ONLY 1
+#define uvsdev uvsdev512
+#include "uvs_solve_kernel.h"
+
+using namespace uvsdev512;
+
+extern "C" {
+// block table of the output-stationary gather (the __constant__ copies of this translation unit) + the LDS opt-in; once per device
+int uvs_k_solve512_init(const unsigned char* fa, const unsigned char* fb, int n) {
+    if (n != UVS_NBLK) return UVS_ERR_INVALID_ARG;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(c_blk_fa), fa, n) != hipSuccess || hipMemcpyToSymbol(HIP_SYMBOL(c_blk_fb), fb, n) != hipSuccess) return UVS_ERR_HIP;
+    if (hipFuncSetAttribute((const void*)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES) != hipSuccess) return UVS_ERR_HIP;
+    return UVS_OK;
+}
+// kopts / dbg: the caller's uvsdev::KOpts / uvsdev::DebugOut (same definitions, other namespace)
+void uvs_k_solve512_launch(int n_windows, hipStream_t stream, char* blobs, const long long* blob_off, double* ws_all, const long long* ws_off,
+                           const void* kopts, size_t kopts_bytes, uvs_report* reports, const void* dbg, size_t dbg_bytes) {
+    KOpts ko; DebugOut d;
+    if (kopts_bytes != sizeof(ko) || dbg_bytes != sizeof(d)) return;      // (the caller checks hipGetLastError and the reports; a layout mismatch is a build error)
+    __builtin_memcpy(&ko, kopts, sizeof(ko)); __builtin_memcpy(&d, dbg, sizeof(d));
+    hipLaunchKernelGGL(k_solve, dim3(n_windows), dim3(NT), LDS_BYTES, stream, blobs, blob_off, ws_all, ws_off, ko, reports, d);
+}
+size_t uvs_k_solve512_arg_bytes(int which) { return which == 0 ? sizeof(KOpts) : sizeof(DebugOut); }
+// debug == 5: the per-wave step log of the last launch (tools/lin_timeline.py)
+int uvs_k_solve512_timeline(long long* out, size_t n) {
+    if (n != sizeof(g_lin_tl) / sizeof(long long)) return UVS_ERR_INVALID_ARG;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lin_tl), n * sizeof(long long)) == hipSuccess ? UVS_OK : UVS_ERR_HIP;
+}
+}

@@ -33,13 +33,30 @@ static __device__ __forceinline__ int lane_tid() { return threadIdx.x; }
 #endif
 static constexpr int NT = UVS_NT;              // threads per workgroup
 static constexpr int NW = NT / 64;
+// Wave roles of the 512-thread build (two waves per SIMD, 256 registers per lane).  One body for all eight waves does not fit: the gather accumulators
+// (48 VGPRs per lane, live from the first chunk to a possible re-damping) and the observation temporaries of the evaluation passes together are what
+// spilled 500 registers in the round-3 experiment.  So the linearization is split by wave: waves 0..3 (EVALUATORS, one per SIMD) run the observation
+// passes, the per-landmark Schur preparation and the IMU tiles exactly as the four waves of the 256-thread build do; waves 4..7 (GATHERERS, again one
+// per SIMD) own the 128 gather groups.  Every other phase (assembly, factorization, back substitution, cost) uses all eight waves.
+static constexpr bool ROLES = NT > 256;
+static constexpr int ET = ROLES ? 256 : NT;       // evaluator threads = stride of the evaluation loops
+static constexpr int EW = ET / 64;                // evaluator waves
+static constexpr int GT0 = NT - UVS_GT;           // first gatherer thread (0: every thread is both)
+UVS_DEV int wave_uniform() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+UVS_DEV bool role_eval() { return !ROLES || wave_uniform() < EW; }
 // Loads in flight per lane.  One wave per SIMD (NT = 256) hides memory latency only with its own independent loads, so the streaming loops batch
 // several observations per lane; with two resident waves per SIMD (NT = 512) the other wave covers the latency and the batches shrink to what
 // fits 256 registers per lane.
-static constexpr int CP_PB = NT > 256 ? 2 : 4;      // cost pass: point observations per batch
-static constexpr int CP_LB = NT > 256 ? 1 : 2;      // cost pass: line observations per batch
-static constexpr int BS_LNB = NT > 256 ? 2 : 4;     // back substitution: line observations per batch
-static constexpr int PR_UN = NT > 256 ? 13 : 26;    // prior mat-vec: rows of H0 in flight (26: the 25 rows per part of the n = 75 prior are ONE round trip, not 24 + 1)
+#ifndef UVS_T_CP_PB
+#define UVS_T_CP_PB 2
+#define UVS_T_CP_LB 1
+#define UVS_T_BS_LNB 4
+#define UVS_T_PR_UN 26
+#endif
+static constexpr int CP_PB = NT > 256 ? UVS_T_CP_PB : 4;      // cost pass: point observations per batch
+static constexpr int CP_LB = NT > 256 ? UVS_T_CP_LB : 2;      // cost pass: line observations per batch
+static constexpr int BS_LNB = NT > 256 ? UVS_T_BS_LNB : 4;     // back substitution: line observations per batch
+static constexpr int PR_UN = NT > 256 ? UVS_T_PR_UN : 26;    // prior mat-vec: rows of H0 in flight (26: the 25 rows per part of the n = 75 prior are ONE round trip, not 24 + 1)
 static constexpr int PG_UN = NT > 256 ? 16 : 32;    // prior gradient: rows of J0 in flight
 
 // ---- LDS map (in doubles).  The small arrays come FIRST and the big region (reduced system / staging area) LAST, so that a kernel that needs only part of
@@ -63,8 +80,8 @@ static constexpr int L_CTRL = L_RED + (5 * NW > 24 ? 5 * NW : 24);      // block
 static constexpr int L_PROF = L_CTRL + 32;      // per-phase cycle counters (debug launches only)
 static constexpr int L_WPROF = L_PROF + 24;     // debug sub-timers: [0..3] candidate-cost phase (stage + dx, prior residual, observations, IMU), [4..7] busy cycles of each wave in the Cholesky column phase
 static constexpr int L_LCOST = L_WPROF + 8;     // per-lane cost accumulator of the current linearization (kept in LDS, not in a register that
-static constexpr int LACC = NT > 256 ? NT / 256 : 1;      // lanes sharing one accumulator slot (the 512-thread build has no LDS left for one per lane)
-static constexpr int L_LGMAX = L_LCOST + NT / LACC;    // would have to live across every phase) ; max |g_landmark| per WAVE (a maximum does not care how it is grouped: 8 doubles instead of one per lane)
+static constexpr int LACC = 1;                  // (one slot per EVALUATOR lane: the gatherer waves of the 512-thread build evaluate nothing)
+static constexpr int L_LGMAX = L_LCOST + ET / LACC;    // would have to live across every phase) ; max |g_landmark| per WAVE (a maximum does not care how it is grouped: 8 doubles instead of one per lane)
 static constexpr int L_PX0 = L_LGMAX + 8;              // the prior's linearization point, 9 doubles per kept block, and its block table (kind, frame, size, column offset: 4 x 16 ints) -- staged
 static constexpr int L_PTAB = L_PX0 + 9 * UVS_MAX_PRIOR_BLOCKS;      // once per solve by k_solve (stage_prior_tables): prior_dx runs 21 times per solve and its global round trip was ~2.5 k cycles each
 static constexpr int L_SMALL = (L_PTAB + 2 * UVS_MAX_PRIOR_BLOCKS + 1) & ~1;      // end of the small arrays (even: the region below holds 16-byte rows)
@@ -74,6 +91,11 @@ static_assert(L_TOTAL * 8 <= 160 * 1024, "LDS map exceeds the 160 KB of a CU");
 enum { P_SETUP = 0, P_OBS, P_LMPREP, P_GATHER, P_ASSEMBLE, P_CHOL, P_TRSV, P_BACKSUB, P_COST, P_MISC, P_CH_DIAG, P_CH_PANEL, P_CH_TRAIL, P_AS_IMU, P_AS_ZERO, P_AS_ADD, P_LAST };
 #define UVS_PROF(c, k) do { if ((c).o.debug && lane_tid() == 0) { const long long now_ = clock64(); (c).sh[L_PROF + (k)] += (double)(now_ - (long long)(c).sh[L_PROF + 23]); (c).sh[L_PROF + 23] = (double)now_; } } while (0)
 static constexpr size_t LDS_BYTES = (size_t)L_TOTAL * 8;
+// debug == 5 (UVS_DEBUG_LIN_TIMELINE, first window of a launch): every wave logs (stamp id, clock) pairs of the linearization's inner steps; tools/lin_timeline.py prints them
+static constexpr int TL_PER_WAVE = 4096;
+__device__ long long g_lin_tl[8 * TL_PER_WAVE * 2];
+#define UVS_TLOG(c, id) do { if ((c).o.debug == 5 && (threadIdx.x & 63) == 0 && blockIdx.x == 0) { const int w_ = threadIdx.x >> 6; const int n_ = (int)(c).sh[L_WPROF + w_]; \
+    if (n_ < TL_PER_WAVE) { g_lin_tl[2 * (w_ * TL_PER_WAVE + n_)] = (id); g_lin_tl[2 * (w_ * TL_PER_WAVE + n_) + 1] = clock64(); (c).sh[L_WPROF + w_] = (double)(n_ + 1); } } } while (0)
 
 enum { C_COST = 0, C_RADIUS, C_DECR, C_XNORM, C_GMAX, C_CAND, C_MCC, C_STEP2, C_XC2, C_GO, C_IT, C_INVALID, C_CUR, C_FIRST,
        C_TERM, C_NSUCC, C_CHOLOK, C_GMAXLM, C_TIMEUP };
@@ -155,19 +177,17 @@ UVS_DEV void block_reduce(double* sh, double* s /*[4]*/, double* mx) {
 // per-lane (or per lane pair) accumulators of the running linearization
 UVS_DEV void lacc_set(double* sh, double cost, double gmax) {
     const int tid = lane_tid();
-    if (LACC == 2) cost += __shfl_xor(cost, 1, 64);
-    if (tid % LACC == 0) sh[L_LCOST + tid / LACC] = cost;
+    if (tid < ET) sh[L_LCOST + tid] = cost;
     const double wm = wave_max(gmax);
     if ((tid & 63) == 0) sh[L_LGMAX + (tid >> 6)] = wm;
 }
 UVS_DEV void lacc_add(double* sh, double cost, double gmax) {
     const int tid = lane_tid();
-    if (LACC == 2) cost += __shfl_xor(cost, 1, 64);
-    if (tid % LACC == 0) sh[L_LCOST + tid / LACC] += cost;
+    if (tid < ET) sh[L_LCOST + tid] += cost;
     const double wm = wave_max(gmax);
     if ((tid & 63) == 0) sh[L_LGMAX + (tid >> 6)] = fmax(sh[L_LGMAX + (tid >> 6)], wm);
 }
-UVS_DEV double lacc_cost(const double* sh) { const int tid = lane_tid(); return tid % LACC == 0 ? sh[L_LCOST + tid / LACC] : 0.0; }
+UVS_DEV double lacc_cost(const double* sh) { const int tid = lane_tid(); return tid < ET ? sh[L_LCOST + tid] : 0.0; }
 UVS_DEV double lacc_gmax(const double* sh) { return sh[L_LGMAX + (lane_tid() >> 6)]; }
 
 struct Ctx {
@@ -319,6 +339,22 @@ UVS_DEV double prior_residual_rows(const Ctx& c) {
 // cost of all residual blocks at the point staged in (x, RF/EX) with landmark buffers invd / line
 // PB / LB: point / line observations per lane and batch (loads in flight); the defaults suit the workgroup size of the persistent kernel, a kernel that runs
 // several workgroups per compute unit passes smaller ones (its other waves hide the latency, its register budget is smaller)
+// raw IMU residual of block (lane - lane0) -> scratch in the S region (cost_pass whitens them after its barrier)
+UVS_DEV void cost_imu_raw(const Ctx& c, const double* x, int lane0) {
+    const DevWin& h = *c.hdr;
+    const int b = lane_tid() - lane0;
+    double* rs = c.sh + L_S + 1024;
+    if (b >= 0 && b < h.n_imu) {
+        const int fi = c.bi[h.i_imu + 2 * b], skip = c.bi[h.i_imu + 2 * b + 1];
+        if (!skip) {
+            const double* blk = c.bd + h.d_imu + (size_t)b * UVS_IMU_STRIDE;
+            double r[15];
+            imu_raw(blk, blk + UVS_IMU_JAC, c.o.G, x + 7 * fi, x + 77 + 9 * fi, x + 7 * (fi + 1), x + 77 + 9 * (fi + 1), r, nullptr);
+#pragma unroll
+            for (int i = 0; i < 15; ++i) rs[16 * b + i] = r[i];
+        }
+    }
+}
 template <int PB = CP_PB, int LB = CP_LB>
 UVS_DEV double cost_pass(const Ctx& c, const double* x, const double* invd, const double* line, int po0, int po1, int lo0, int lo1, bool with_imu) {
     const DevWin& h = *c.hdr;
@@ -328,6 +364,13 @@ UVS_DEV double cost_pass(const Ctx& c, const double* x, const double* invd, cons
     double cost = 0.0;
     long long tq_ = clock64();
 #define UVS_CQ(slot) if (c.o.debug == 1 && tid == 0) { const long long t_ = clock64(); c.sh[L_WPROF + slot] += (double)(t_ - tq_); tq_ = t_; }
+    // 512-thread build: the raw IMU residuals (one lane per block, a long serial chain of quaternion algebra) go to the LAST wave and run FIRST: that wave has
+    // half the observations of waves 0..3 (one point, no line), so the chain that used to follow the observations on wave 0 -- with seven waves waiting at the
+    // barrier below -- now runs beside them
+    const int imu_lane0 = ROLES ? NT - 64 : 0;
+#ifndef UVS_X_NO_IMU_WAVE
+    if (ROLES && with_imu) cost_imu_raw(c, x, imu_lane0);
+#endif
     // Observations in batches of four per lane: the index loads and the measurement loads of a batch go out together and the
     // landmark parameters (the only loads whose address depends on an index) follow as a second group, so a lane pays two HBM/L2
     // round trips per BATCH instead of two per observation (one wave per SIMD: nothing else hides that latency).
@@ -393,16 +436,10 @@ UVS_DEV double cost_pass(const Ctx& c, const double* x, const double* invd, cons
     // nothing live between the triangular solve and the next linearization (prior_residual uses its first 512 doubles the same way).
     if (with_imu) {
         double* rs = c.sh + L_S + 1024;
-        if (tid < h.n_imu) {
-            const int fi = c.bi[h.i_imu + 2 * tid], skip = c.bi[h.i_imu + 2 * tid + 1];
-            if (!skip) {
-                const double* blk = c.bd + h.d_imu + (size_t)tid * UVS_IMU_STRIDE;
-                double r[15];
-                imu_raw(blk, blk + UVS_IMU_JAC, c.o.G, x + 7 * fi, x + 77 + 9 * fi, x + 7 * (fi + 1), x + 77 + 9 * (fi + 1), r, nullptr);
-#pragma unroll
-                for (int i = 0; i < 15; ++i) rs[16 * tid + i] = r[i];
-            }
-        }
+#ifndef UVS_X_NO_IMU_WAVE
+        if (!ROLES)
+#endif
+        cost_imu_raw(c, x, 0);
         __syncthreads();
         const int b = tid >> 4, i = tid & 15;
         if (b < h.n_imu && i < 15 && !c.bi[h.i_imu + 2 * b + 1]) {
@@ -661,8 +698,15 @@ UVS_DEV void chol_factor_impl(double* sh, int debug) {
     if (tid < 80) flg[tid] = 0;
     if (tid == 0) sh[L_CTRL + C_CHOLOK] = 1.0;
     UVS_PROF(c, P_MISC);
-    constexpr int nwork = NW - 1;
-    const int wrk = wv - 1;
+#ifndef UVS_X_CHOL_ALL_WORKERS
+    // 512-thread build: wave 4 shares its SIMD with the pivot chain (waves w and w + 4 sit on one SIMD) and stays out of the factorization: six workers
+    constexpr bool chain_alone = ROLES;
+#else
+    constexpr bool chain_alone = false;
+#endif
+    constexpr int nwork = chain_alone ? NW - 2 : NW - 1;
+    const int wrk = chain_alone ? (wv < 4 ? wv - 1 : wv - 2) : wv - 1;
+    const bool idle_wave = chain_alone && wv == 4;
     long long tend_ = 0;
     d4_t Lt = {0.0, 0.0, 0.0, 0.0};      // wave 0: L(k, k-1)^T, the panel result of the previous column, = both operands of the diagonal block's last term
 #define UVS_FLAG_WAIT(idx, val) while (__hip_atomic_load(flg + (idx), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < (val)) __builtin_amdgcn_s_sleep(1);
@@ -670,6 +714,7 @@ UVS_DEV void chol_factor_impl(double* sh, int debug) {
     __syncthreads();
     for (int k = 0; k < UVS_NF; ++k) {
         double* Dk = sblk(sh, k, k);
+        if (idle_wave) { if (!half && k > 0) __syncthreads(); continue; }
         // Half-row path: NO workgroup barrier per column.  The pivot chain (wave 0) only ever waits for two flags that are raised long before it
         // needs them (its diagonal block's look-ahead terms, the last term of the block below), so the critical path of the factorization is
         // chain -> W_k -> panel product of (k+1, k) -> first four MFMAs of the next diagonal block -> chain, without the workers' panel products
@@ -1006,7 +1051,7 @@ UVS_DEV d2_t lds2(const double* p) { return *(const d2_t*)p; }
 // brackets the call with barriers as documented).  Part order => the same fixed summation order as one add round per part, but
 // ONE barrier-separated step instead of up to 16 rounds.  All lanes must call it.
 UVS_DEV void gacc_gather_parts(GAcc& A, int grp, double* scr) {
-    const int tid = lane_tid();
+    const int tid = lane_tid() - GT0;
     const int part = grp >= 0 ? (grp >> 9) & 15 : 0, np = grp >= 0 ? ((grp >> 21) & 15) + 1 : 1;
     constexpr int NV = 8 * GR, LD = NV + 1;      // 24 values per lane (18 block entries, 3 gradient, 3 diagonal), odd stride
     double* D = scr + LD * tid;
@@ -1048,7 +1093,7 @@ UVS_DEV void row_fma(double* v, double s, const d2_t* q) {
 }
 
 // this lane's group descriptor (-1 = idle group), see uvs_layout.h: i_wblk
-UVS_DEV int gather_group(const Ctx& c) { return c.bi[c.hdr->i_wblk + (lane_tid() / UVS_GLANES)]; }
+UVS_DEV int gather_group(const Ctx& c) { const int t = lane_tid() - GT0; return t >= 0 ? c.bi[c.hdr->i_wblk + (t / UVS_GLANES)] : -1; }
 
 // Walks entries [e0, e1) of a gather list, K per stage, SOFTWARE PIPELINED over two register sets: while the FMAs of stage t issue, the
 // LDS loads of stage t + 1 (addresses from the entries fetched during stage t - 1) and the entry words of stage t + 2 are already in
@@ -1085,7 +1130,7 @@ UVS_DEV void gather_walk(const int* ent, int e0, int e1, Load load, Use use) {
 // where pseudo frame 12 is relo_Pose, an ordinary second frame
 template <bool EXT, bool DELTA = false>
 UVS_DEV void gather_points(int grp, const int* lists, const double* S0, GAcc& A, int goff = 0, bool exrows = true) {
-    const int g = lane_tid() / UVS_GLANES, r0 = GR * (lane_tid() % UVS_GLANES);
+    const int g = (lane_tid() - GT0) / UVS_GLANES, r0 = GR * (lane_tid() % UVS_GLANES);
     const bool on = grp >= 0;
     const bool diag = on && ((grp >> 8) & 1);
     const bool tdg = EXT && on && ((grp >> 13) & 15) == UVS_NF;       // block row of the time offset: J1 = (J_td[0], J_td[1]) adjacent, residual 16 doubles below
@@ -1156,7 +1201,7 @@ UVS_DEV void gather_points(int grp, const int* lists, const double* S0, GAcc& A,
 // DELTA: as for the points; the gradient rows are one 6-vector per observation at S0 + goff + (E offset - eoff) / 4 (E rows are 24 doubles per observation)
 template <bool DELTA = false>
 UVS_DEV void gather_lines(int grp, const int* lists, const double* S0, GAcc& A, int goff = 0, int eoff = 0) {
-    const int g = lane_tid() / UVS_GLANES, r0 = GR * (lane_tid() % UVS_GLANES);
+    const int g = (lane_tid() - GT0) / UVS_GLANES, r0 = GR * (lane_tid() % UVS_GLANES);
     const bool on = grp >= 0;
     const bool diag = on && ((grp >> 8) & 1);
     const int* ent = lists + LIST_HDR;
@@ -1228,7 +1273,7 @@ UVS_DEV void gather_lines(int grp, const int* lists, const double* S0, GAcc& A, 
 static constexpr int IMU_JLD = 48;                       // row stride of Jaug / T in LDS (16 rows; 48 = 16 mod 32: no bank conflicts between k-groups)
 static constexpr int IMU_WOFF = 16 * IMU_JLD;            // W as [16][17] after the operand tile
 static constexpr int IMU_BLK = IMU_WOFF + UVS_BLK_SZ;    // 1040 doubles of LDS staging per block
-static constexpr int IMU_SLOTS = (UVS_NF - 1 + NW - 1) / NW;   // IMU blocks per wave (block b -> wave b % NW, slot b / NW)
+static constexpr int IMU_SLOTS = (UVS_NF - 1 + EW - 1) / EW;   // IMU blocks per evaluator wave (block b -> wave b % EW, slot b / EW)
 struct ImuN { d4_t n00[IMU_SLOTS], n10[IMU_SLOTS], n11[IMU_SLOTS]; };
 
 // rotations of the evaluation point + prior residual (L_PR); returns this lane's share of the prior cost
@@ -1261,14 +1306,14 @@ UVS_DEV double lin_imu(const Ctx& c, const double* x, ImuN& N) {
     double* IM = sh + L_S;
     // the whitening matrices W (global, written by setup_window) are requested first and stored last: their latency runs beside the
     // blocks' own loads and the raw evaluation instead of after them
-    constexpr int WPL = ((UVS_NF - 1) * 225 + NT - 1) / NT;
+    constexpr int WPL = ((UVS_NF - 1) * 225 + ET - 1) / ET;
     double wreg[WPL];
 #pragma unroll
     for (int q = 0; q < WPL; ++q) {
-        const int t = tid + q * NT, tc = t < h.n_imu * 225 ? t : 0, b = tc / 225, e = tc - 225 * b;
+        const int t = tid + q * ET, tc = t < h.n_imu * 225 ? t : 0, b = tc / 225, e = tc - 225 * b;
         wreg[q] = c.bd[h.d_imu + (size_t)b * UVS_IMU_STRIDE + UVS_IMU_W + e];
     }
-    for (int t = tid; t < h.n_imu * IMU_BLK; t += NT) IM[t] = 0.0;      // operand tiles are mostly structural zeros
+    for (int t = tid; t < h.n_imu * IMU_BLK; t += ET) IM[t] = 0.0;      // operand tiles are mostly structural zeros
     __syncthreads();
     // raw residual + Jacobian of block `lane`, its four Jacobian groups on four different waves (one lane doing all of it was a 10 k-cycle
     // serial chain with 246 lanes idle; divergent parts inside one wave would serialise just the same)
@@ -1278,7 +1323,7 @@ UVS_DEV double lin_imu(const Ctx& c, const double* x, ImuN& N) {
         double* T = IM + IMU_BLK * lane;
         const double* pi_ = x + 7 * fi; const double* si_ = x + 77 + 9 * fi; const double* pj_ = x + 7 * (fi + 1); const double* sj_ = x + 77 + 9 * (fi + 1);
         double r[15];
-        if (NW < 4) { imu_raw<IMU_JLD, 1, false>(blk, blk + UVS_IMU_JAC, c.o.G, pi_, si_, pj_, sj_, r, T); for (int i = 0; i < 15; ++i) T[i * IMU_JLD + 31] = r[i]; }
+        if (EW < 4) { imu_raw<IMU_JLD, 1, false>(blk, blk + UVS_IMU_JAC, c.o.G, pi_, si_, pj_, sj_, r, T); for (int i = 0; i < 15; ++i) T[i * IMU_JLD + 31] = r[i]; }
         else if (wv == 0) { imu_raw<IMU_JLD, 1, false, 1>(blk, blk + UVS_IMU_JAC, c.o.G, pi_, si_, pj_, sj_, r, T); for (int i = 0; i < 15; ++i) T[i * IMU_JLD + 31] = r[i]; }
         else if (wv == 1) imu_raw<IMU_JLD, 1, false, 2>(blk, blk + UVS_IMU_JAC, c.o.G, pi_, si_, pj_, sj_, r, T);
         else if (wv == 2) imu_raw<IMU_JLD, 1, false, 4>(blk, blk + UVS_IMU_JAC, c.o.G, pi_, si_, pj_, sj_, r, T);
@@ -1286,7 +1331,7 @@ UVS_DEV double lin_imu(const Ctx& c, const double* x, ImuN& N) {
     }
 #pragma unroll
     for (int q = 0; q < WPL; ++q) {
-        const int t = tid + q * NT;
+        const int t = tid + q * ET;
         if (t < h.n_imu * 225) { const int b = t / 225, e = t - 225 * b, i = e / 15, k = e - 15 * i; IM[IMU_BLK * b + IMU_WOFF + i * UVS_BLK_LD + k] = wreg[q]; }
     }
     __syncthreads();
@@ -1294,7 +1339,7 @@ UVS_DEV double lin_imu(const Ctx& c, const double* x, ImuN& N) {
     bool act[IMU_SLOTS];
 #pragma unroll
     for (int s = 0; s < IMU_SLOTS; ++s) {
-        const int b = wv + s * NW;
+        const int b = wv + s * EW;
         act[s] = b < h.n_imu && !c.bi[h.i_imu + 2 * (b < h.n_imu ? b : 0) + 1];
         if (act[s]) {
             double* Jb = IM + IMU_BLK * b; const double* Wb = Jb + IMU_WOFF;
@@ -1312,7 +1357,7 @@ UVS_DEV double lin_imu(const Ctx& c, const double* x, ImuN& N) {
     wave_sync();
 #pragma unroll
     for (int s = 0; s < IMU_SLOTS; ++s) {
-        const int b = wv + s * NW;
+        const int b = wv + s * EW;
         d4_t n00 = {0.0, 0.0, 0.0, 0.0}, n10 = n00, n11 = n00;
         if (act[s]) {
             const double* Jb = IM + IMU_BLK * b;
@@ -1364,32 +1409,54 @@ UVS_DEV void spd4_inverse(const double* H, const double* gl, double* X, double* 
 }
 
 // ---- linearization, part 2: one landmark chunk: stage -> per-landmark Schur prep -> list-driven gather into acc[]
-UVS_DEV void lin_chunk(const Ctx& c, int ch, const double* x, const double* invd, const double* line, bool first, double radius,
-                       int grp, GAcc& acc) {
+// The evaluation half (observation passes, per-landmark Schur preparation, the chunk's lists -> staging area; FOUR workgroup barriers, the first before
+// anything is written) and the gather half (no barrier).  In the 256-thread build every thread runs both, one after the other (lin_chunk); in the
+// 512-thread build the evaluator waves run the first and the gatherer waves the second behind four barriers of their own (linearize).
+struct ChunkDesc { int type, k0, k1, o0, nob, nlm, nlist; const int* glists; };
+UVS_DEV ChunkDesc chunk_desc(const Ctx& c, int ch) {
+    const DevWin& h = *c.hdr;
+    const int* chunks = c.bi + h.i_chunks;
+    ChunkDesc d;
+    d.type = chunks[UVS_CHUNK_INTS * ch]; d.k0 = chunks[UVS_CHUNK_INTS * ch + 1]; d.k1 = chunks[UVS_CHUNK_INTS * ch + 2];
+    d.glists = c.bi + h.i_lists + chunks[UVS_CHUNK_INTS * ch + 3];      // gather lists of this chunk (HBM)
+    d.nlist = chunks[UVS_CHUNK_INTS * ch + 4];
+    d.nlm = d.k1 - d.k0;
+    d.o0 = chunks[UVS_CHUNK_INTS * ch + 6]; d.nob = chunks[UVS_CHUNK_INTS * ch + 7];
+    return d;
+}
+// where the gather lists of a staged chunk sit (after the records and the Schur factors)
+UVS_DEV int* chunk_lists(const Ctx& c, const ChunkDesc& d) {
+    const DevWin& h = *c.hdr;
+    double* rec = c.sh + L_S;
+    if (d.type == 0) return (int*)(rec + (size_t)d.nob * h.pt_rec + (size_t)(d.nob + h.pt_xslots * d.nlm) * 12);
+    return (int*)(rec + (size_t)d.nob * (UVS_LN_REC + 2 * UVS_LN_EY) + 20 * d.nlm);
+}
+UVS_DEV void chunk_eval(const Ctx& c, const ChunkDesc& d, const double* x, const double* invd, const double* line, bool first, double radius) {
     const DevWin& h = *c.hdr;
     double* sh = c.sh;
     const int tid = lane_tid();
     const double* RF = sh + L_RF; const double* ric = sh + L_EX; const double* tic = sh + L_EX + 9;
-    const int* chunks = c.bi + h.i_chunks;
     double cost = 0.0, gmax_lm = 0.0;      // this chunk's share; flushed to the per-lane LDS accumulators before the gather
     {
-        const int type = chunks[6 * ch], k0 = chunks[6 * ch + 1], k1 = chunks[6 * ch + 2];
-        const int* glists = c.bi + h.i_lists + chunks[6 * ch + 3];      // gather lists of this chunk (HBM)
-        const int nlist = chunks[6 * ch + 4];
-        const int nlm = k1 - k0;
+        const int type = d.type, k0 = d.k0, k1 = d.k1;
+        const int* glists = d.glists;
+        const int nlist = d.nlist;
+        const int nlm = d.nlm;
+        UVS_TLOG(c, 1);
         __syncthreads();     // previous users of the S region are done
         UVS_PROF(c, P_GATHER);
+        UVS_TLOG(c, 2);
         if (type == 0) {
             const int* beg = c.bi + h.i_pt_beg;
-            const int o0 = beg[k0], o1 = beg[k1], nob = o1 - o0;
+            const int o0 = d.o0, nob = d.nob, o1 = o0 + nob;
             const int PREC = h.pt_rec, XS = h.pt_xslots;
             double* rec = sh + L_S;                                  // [nob][PREC]
             double* Eb = rec + (size_t)nob * PREC;                   // [(nob + XS * nlm)][6]   slots per landmark: anchor, observations, (td)
             double* EIb = Eb + (size_t)(nob + XS * nlm) * 6;         // [(nob + XS * nlm)][6]  Einv = E / h_ll
             int* lists = (int*)(EIb + (size_t)(nob + XS * nlm) * 6); // gather lists staged in LDS (one HBM latency per chunk)
-            for (int t = tid; t < nlist; t += NT) lists[t] = glists[t];
+            for (int t = tid; t < nlist; t += ET) lists[t] = glists[t];
             // pass A: one lane per observation
-            for (int o = o0 + tid; o < o1; o += NT) {
+            for (int o = o0 + tid; o < o1; o += ET) {
                 const int lm = c.bi[h.i_pt_lm + o], fi = c.bi[h.i_pt_fi + o], fj = c.bi[h.i_pt_fj + o];
                 double pi[3], pj[3], vij[4] = {0.0, 0.0, 0.0, 0.0};
                 load_point_obs(c, o, x[183], pi, pj, vij);
@@ -1411,12 +1478,14 @@ UVS_DEV void lin_chunk(const Ctx& c, int ch, const double* x, const double* invd
                     for (int q = 0; q < 12; ++q) R[UVS_PT_EX + q] = sc * jex[q];
                 }
             }
+            UVS_TLOG(c, 3);
             __syncthreads();
             UVS_PROF(c, P_OBS);
+            UVS_TLOG(c, 4);
             // pass B: one lane per observation (its landmark's h_ll / g_l are recomputed per lane, cheap);
             // the lane of a landmark's first observation also owns the anchor slot and the per-landmark scalars.
             // Reads of the d r/d lambda columns happen before the barrier, the corrected residuals overwrite them after it.
-            for (int ol = tid; ol < nob; ol += NT) {
+            for (int ol = tid; ol < nob; ol += ET) {
                 const int k = c.bi[h.i_pt_lm + o0 + ol], li = k - k0, b0 = beg[k] - o0, b1 = beg[k + 1] - o0;
                 double hd = 0.0, gl = 0.0;
                 for (int o = b0; o < b1; ++o) { const double* R = rec + (size_t)o * PREC; hd += R[UVS_PT_C] * R[UVS_PT_C] + R[UVS_PT_C + 1] * R[UVS_PT_C + 1]; gl += R[UVS_PT_C] * R[0] + R[UVS_PT_C + 1] * R[1]; }
@@ -1427,7 +1496,7 @@ UVS_DEV void lin_chunk(const Ctx& c, int ch, const double* x, const double* invd
                 const double hinv = 1.0 / (hd + dd), ginv = gl * hinv;
                 const int s = ol - b0 + 1;
                 double* E = Eb + (size_t)(b0 + XS * li) * 6; double* EI = EIb + (size_t)(b0 + XS * li) * 6;
-                double* Eg = c.ws + h.w_pt_E + 6 * (size_t)(beg[k] + XS * k);
+                double* Eg = c.ws + h.w_pt_E + 6 * (size_t)(o0 + b0 + XS * k);
                 double* R = rec + (size_t)ol * PREC;
                 const double c0 = R[UVS_PT_C], c1 = R[UVS_PT_C + 1], rr0 = R[0], rr1 = R[1];
                 double Bv[12];      // all LDS reads of the record BEFORE the first LDS write (the compiler must assume E / EI alias it)
@@ -1466,26 +1535,26 @@ UVS_DEV void lin_chunk(const Ctx& c, int ch, const double* x, const double* invd
                     }
                 }
             }
+            UVS_TLOG(c, 5);
             __syncthreads();
-            for (int ol = tid; ol < nob; ol += NT) { double* R = rec + (size_t)ol * PREC; R[UVS_PT_C] = R[UVS_PT_RC2]; R[UVS_PT_C + 1] = R[UVS_PT_RC2 + 1]; }
+            UVS_TLOG(c, 6);
+            for (int ol = tid; ol < nob; ol += ET) { double* R = rec + (size_t)ol * PREC; R[UVS_PT_C] = R[UVS_PT_RC2]; R[UVS_PT_C + 1] = R[UVS_PT_RC2 + 1]; }
             __syncthreads();
             UVS_PROF(c, P_LMPREP);
+            UVS_TLOG(c, 7);
             lacc_add(sh, cost, gmax_lm);
-            const long long tg0_ = clock64();
-            if (h.td_on | h.ex_on) gather_points<true>(grp, lists, rec, acc, 0, h.ex_on != 0); else gather_points<false>(grp, lists, rec, acc);
-            if (c.o.debug == 2 && (tid & 63) == 0) sh[L_WPROF + 4 + (tid >> 6)] += (double)(clock64() - tg0_);
         } else {
             const int* beg = c.bi + h.i_ln_beg;
-            const int o0 = beg[k0], o1 = beg[k1], nob = o1 - o0;
+            const int o0 = d.o0, nob = d.nob, o1 = o0 + nob;
             double* rec = sh + L_S;                                  // [nob][33]
             double* Eb = rec + (size_t)nob * UVS_LN_REC;             // [nob][UVS_LN_EY]  E[c][a] = (J_l^T J_p)   (24 used, see uvs_layout.h)
             double* Yb = Eb + (size_t)nob * UVS_LN_EY;               // [nob][UVS_LN_EY]  Y = Hinv E
             double* Xb = Yb + (size_t)nob * UVS_LN_EY;               // [nlm][20] : Hinv[16], Hinv*g[4]
             int* lists = (int*)(Xb + 20 * nlm);
-            for (int t = tid; t < nlist; t += NT) lists[t] = glists[t];
+            for (int t = tid; t < nlist; t += ET) lists[t] = glists[t];
             // pass A
             const double* ltrig = line_trig_of(c, line);
-            for (int o = o0 + tid; o < o1; o += NT) {
+            for (int o = o0 + tid; o < o1; o += ET) {
                 const int lm = c.bi[h.i_ln_lm + o], fj = c.bi[h.i_ln_fj + o], hv = c.bi[h.i_ln_vp + o];
                 const double* m = c.bd + h.d_lnmeas + o; const int st = h.ln_stride;
                 const double sp[3] = {m[0], m[st], m[2 * st]}, ep[3] = {m[3 * st], m[4 * st], m[5 * st]}, vp[3] = {m[6 * st], m[7 * st], m[8 * st]};
@@ -1518,10 +1587,12 @@ UVS_DEV void lin_chunk(const Ctx& c, int ch, const double* x, const double* invd
                     for (int q = 0; q < 4; ++q) R[UVS_LN_JL + 8 + q] = 0.0;
                 }
             }
+            UVS_TLOG(c, 3);
             __syncthreads();
             UVS_PROF(c, P_OBS);
+            UVS_TLOG(c, 4);
             // pass B1: one lane per line: H_ll, g_l, damping, 4x4 inverse
-            for (int li = tid; li < nlm; li += NT) {
+            for (int li = tid; li < nlm; li += ET) {
                 const int k = k0 + li, b0 = beg[k] - o0, b1 = beg[k + 1] - o0;
                 double H[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, gl[4] = {0, 0, 0, 0};   // lower packed (0,0)(1,0)(1,1)(2,0)...
                 double scl[4] = {1.0, 1.0, 1.0, 1.0};      // Jacobi scales: requested before the accumulation loop, used after it
@@ -1558,9 +1629,11 @@ UVS_DEV void lin_chunk(const Ctx& c, int ch, const double* x, const double* invd
 #pragma unroll
                 for (int a = 0; a < 4; ++a) { X[16 + a] = hg[a]; lx[a] = hg[a]; }
             }
+            UVS_TLOG(c, 5);
             __syncthreads();
+            UVS_TLOG(c, 6);
             // pass B2: one lane per line observation: E and Y = Hinv E
-            for (int o = tid; o < nob; o += NT) {
+            for (int o = tid; o < nob; o += ET) {
                 double* R = rec + (size_t)o * UVS_LN_REC;
                 const int li = (int)R[UVS_LN_RV + 1];
                 double* E = Eb + (size_t)o * UVS_LN_EY; double* Y = Yb + (size_t)o * UVS_LN_EY;
@@ -1589,10 +1662,29 @@ UVS_DEV void lin_chunk(const Ctx& c, int ch, const double* x, const double* invd
             }
             __syncthreads();
             UVS_PROF(c, P_LMPREP);
+            UVS_TLOG(c, 7);
             lacc_add(sh, cost, gmax_lm);
-            gather_lines(grp, lists, rec, acc);
         }
     }
+}
+static constexpr int CHUNK_EVAL_BARRIERS = 4;      // workgroup barriers inside chunk_eval, for either landmark family
+UVS_DEV void chunk_gather(const Ctx& c, const ChunkDesc& d, int grp, GAcc& acc) {
+    const DevWin& h = *c.hdr;
+    const double* rec = c.sh + L_S;
+    const int* lists = chunk_lists(c, d);
+    UVS_TLOG(c, 8);
+    if (d.type == 0) {
+        const long long tg0_ = clock64();
+        if (h.td_on | h.ex_on) gather_points<true>(grp, lists, rec, acc, 0, h.ex_on != 0); else gather_points<false>(grp, lists, rec, acc);
+        if (c.o.debug == 2 && (lane_tid() & 63) == 0) c.sh[L_WPROF + 4 + ((lane_tid() >> 6) & 3)] += (double)(clock64() - tg0_);
+    } else gather_lines(grp, lists, rec, acc);
+    UVS_TLOG(c, 10);
+}
+UVS_DEV void lin_chunk(const Ctx& c, int ch, const double* x, const double* invd, const double* line, bool first, double radius,
+                       int grp, GAcc& acc) {
+    const ChunkDesc d = chunk_desc(c, ch);
+    chunk_eval(c, d, x, invd, line, first, radius);
+    chunk_gather(c, d, grp, acc);
 }
 
 // ---- re-damping: what a REJECTED step needs instead of a new linearization.  x has not moved, so every Jacobian, the cost and the direct
@@ -1603,29 +1695,30 @@ UVS_DEV void lin_chunk(const Ctx& c, int ch, const double* x, const double* invd
 // (H_ll + D_old)^-1 E per observation for lines, whose undamped 4 x 4 H_ll sits in the workspace).  Per chunk: recover E, stage E and E times
 // the CHANGE of the inverse where lin_chunk stages E and E H^-1, run the Schur half of the gather (DELTA), rewrite the store and the
 // per-landmark scalars for the back-substitution.  No observation is evaluated, no direct term is gathered: ~7 k cycles per chunk against ~25 k.
-UVS_DEV void redamp_chunk(const Ctx& c, int ch, double radius, int grp, GAcc& acc) {
+// redamp_prep: the staging half (2 workgroup barriers for a point chunk, 3 for a line chunk: redamp_barriers); redamp_gather: the Schur walk.
+UVS_DEV int redamp_barriers(const ChunkDesc& d) { return d.type == 0 ? 2 : 3; }
+UVS_DEV void redamp_prep(const Ctx& c, const ChunkDesc& d, double radius) {
     const DevWin& h = *c.hdr;
     double* sh = c.sh;
     const int tid = lane_tid();
-    const int* chunks = c.bi + h.i_chunks;
-    const int type = chunks[6 * ch], k0 = chunks[6 * ch + 1], k1 = chunks[6 * ch + 2];
-    const int* glists = c.bi + h.i_lists + chunks[6 * ch + 3];
-    const int nlist = chunks[6 * ch + 4];
-    const int nlm = k1 - k0;
+    const int type = d.type, k0 = d.k0;
+    const int* glists = d.glists;
+    const int nlist = d.nlist;
+    const int nlm = d.nlm;
     __syncthreads();     // previous users of the S region are done
     double* rec = sh + L_S;
     if (type == 0) {
         const int* beg = c.bi + h.i_pt_beg;
-        const int o0 = beg[k0], o1 = beg[k1], nob = o1 - o0;
+        const int o0 = d.o0, nob = d.nob;
         const int PREC = h.pt_rec, XS = h.pt_xslots;      // (XS == 1: no pseudo-frame slots, see DevWin::redamp_ok)
         double* Gb = rec;                                        // [(nob + XS nlm)][6]  E times the change of H_ll^-1 g_l
         double* Eb = rec + (size_t)nob * PREC;                   // same places as in lin_chunk: the lists address them
         double* EIb = Eb + (size_t)(nob + XS * nlm) * 6;
         int* lists = (int*)(EIb + (size_t)(nob + XS * nlm) * 6);
-        for (int t = tid; t < nlist; t += NT) lists[t] = glists[t];
+        for (int t = tid; t < nlist; t += ET) lists[t] = glists[t];
         // one lane per slot: first the anchor slots (one per landmark with observations), then
         // one lane per observation slot.  Slot of observation o of landmark li: (o - o0) + XS li + 1; every lane recomputes its landmark's scalars.
-        for (int t = tid; t < nlm + nob; t += NT) {
+        for (int t = tid; t < nlm + nob; t += ET) {
             const bool anchor = t < nlm;
             const int ol = anchor ? 0 : t - nlm;
             const int k = anchor ? k0 + t : c.bi[h.i_pt_lm + o0 + ol], li = k - k0;
@@ -1645,7 +1738,7 @@ UVS_DEV void redamp_chunk(const Ctx& c, int ch, double radius, int grp, GAcc& ac
         }
         __syncthreads();
         // the landmark scalars are rewritten only now: the lanes above read the OLD damping of their landmark
-        for (int li = tid; li < nlm; li += NT) {
+        for (int li = tid; li < nlm; li += ET) {
             const int k = k0 + li;
             if (beg[k + 1] == beg[k]) continue;
             double* px = c.ws + h.w_pt_x + 4 * (size_t)k;
@@ -1653,18 +1746,16 @@ UVS_DEV void redamp_chunk(const Ctx& c, int ch, double radius, int grp, GAcc& ac
             const double dd = fmin(fmax(sc * sc * hd, c.o.dlo), c.o.dhi) / (radius * sc * sc);
             px[0] = gl * (1.0 / (hd + dd)); px[2] = dd;
         }
-        gather_points<false, true>(grp, lists, rec, acc, -nob * PREC);
     } else {
-        const int* beg = c.bi + h.i_ln_beg;
-        const int o0 = beg[k0], o1 = beg[k1], nob = o1 - o0;
+        const int o0 = d.o0, nob = d.nob;
         double* T = rec;                                         // [nlm][34]: (H + D_new)^-1 [16] | change of (H + D)^-1 g [4] | H [10] | D_old [4]
         double* Gb = rec + (size_t)nlm * 34;                     // [nob][6]
         double* Eb = rec + (size_t)nob * UVS_LN_REC;             // same places as in lin_chunk
         double* Yb = Eb + (size_t)nob * UVS_LN_EY;
         double* Xb = Yb + (size_t)nob * UVS_LN_EY;
         int* lists = (int*)(Xb + 20 * nlm);
-        for (int t = tid; t < nlist; t += NT) lists[t] = glists[t];
-        for (int li = tid; li < nlm; li += NT) {
+        for (int t = tid; t < nlist; t += ET) lists[t] = glists[t];
+        for (int li = tid; li < nlm; li += ET) {
             const int k = k0 + li;
             double* lx = c.ws + h.w_ln_x + UVS_LN_X * (size_t)k;
             double H[10], gl[4], ddo[4], hgo[4], hg[4];
@@ -1687,7 +1778,7 @@ UVS_DEV void redamp_chunk(const Ctx& c, int ch, double radius, int grp, GAcc& ac
             for (int a = 0; a < 4; ++a) { t[16 + a] = hg[a] - hgo[a]; lx[a] = hg[a]; }
         }
         __syncthreads();
-        for (int o = tid; o < nob; o += NT) {
+        for (int o = tid; o < nob; o += ET) {
             const int li = c.bi[h.i_ln_lm + o0 + o] - k0;
             double tv[34], yo[24];
 #pragma unroll
@@ -1717,8 +1808,18 @@ UVS_DEV void redamp_chunk(const Ctx& c, int ch, double radius, int grp, GAcc& ac
             }
         }
         __syncthreads();
-        gather_lines<true>(grp, lists, rec, acc, nlm * 34, nob * UVS_LN_REC);
     }
+}
+UVS_DEV void redamp_gather(const Ctx& c, const ChunkDesc& d, int grp, GAcc& acc) {
+    const double* rec = c.sh + L_S;
+    const int* lists = chunk_lists(c, d);
+    if (d.type == 0) gather_points<false, true>(grp, lists, rec, acc, -d.nob * c.hdr->pt_rec);
+    else gather_lines<true>(grp, lists, rec, acc, d.nlm * 34, d.nob * UVS_LN_REC);
+}
+UVS_DEV void redamp_chunk(const Ctx& c, int ch, double radius, int grp, GAcc& acc) {
+    const ChunkDesc d = chunk_desc(c, ch);
+    redamp_prep(c, d, radius);
+    redamp_gather(c, d, grp, acc);
 }
 // ---- relo_Pose as a SECOND-LEVEL block (DevWin::relo2: relocalization blocks in a window with a free extrinsic; uvs_layout.h UVS_RELO2_BLOCKROW).
 // The gather blocks of block row 13 land in a side buffer of the workspace: R = S(relo, frame dofs) [6][176], Rrr = S(relo, relo), its gradient
@@ -1825,151 +1926,139 @@ UVS_DEV void relo2_backsub(const Ctx& c) {
 // chunks resp. after them: mode 1 = the FRAME image only (zero, IMU tiles, prior; no landmark blocks, no damping: k_large_chunks' extra
 // workgroup writes S / G / HD to global memory), mode 2 = landmark blocks + damping / scaling / gradient norm ONTO an image already in LDS
 // (k_large_solve; `Ain` must hold the complete sums in the part-0 groups, nothing is gathered from other parts).
-UVS_DEV void lin_assemble(const Ctx& c, const double* x, bool first, double radius, int grp, const GAcc& Ain, const ImuN& N, double cost, double gmax_lm, int mode = 0) {
-    const DevWin& h = *c.hdr;
-    double* sh = c.sh;
-    const int tid = lane_tid();
-    __syncthreads();
-    UVS_PROF(c, P_GATHER);
-    // ---- assemble the reduced system in LDS
-    // parts of split blocks -> their part-0 group (the staging area is free now; S is zeroed only after the sums are in registers)
-    GAcc A = Ain;
-    long long tz_ = clock64();
-#define UVS_TZ(slot) if (c.o.debug == 3 && tid == 0) { const long long t_ = clock64(); sh[L_WPROF + slot] += (double)(t_ - tz_); tz_ = t_; }
-    if (mode == 0) { gacc_gather_parts(A, grp, sh + L_S); __syncthreads(); }
-    UVS_TZ(4)
-    if (mode != 2) {
-        { const d2_t z2 = {0.0, 0.0}; for (int i = tid; i < UVS_S_DOUBLES / 2; i += NT) *(d2_t*)(sh + L_S + 2 * i) = z2; }      // ds_write_b128
-        if (tid < UVS_RD) { sh[L_G + tid] = 0.0; sh[L_HD + tid] = 0.0; }
-        if (h.relo2) for (int t = tid; t < R2_SC; t += NT) c.ws[h.w_relo2 + t] = 0.0;
-        __syncthreads();
-    }
-    UVS_TZ(5)
-    // the part-0 group of every pose block adds its rows (one writer per block: a single round)
-    if (mode != 1) {
-        if (grp >= 0 && ((grp >> 9) & 15) == 0) {
-            const int r0 = GR * (tid % UVS_GLANES);
-            const int fa = (grp >> 13) & 15, fb = (grp >> 17) & 15;
-            if (fa == UVS_RELO2_BLOCKROW) {      // relo_Pose beside a free extrinsic: its rows go to the side buffer (relo2_eliminate)
-                double* W = c.ws + h.w_relo2;
-#pragma unroll
-                for (int r = 0; r < GR; ++r) {
-                    const int a = r0 + r;
-                    if (fb < UVS_NF) {
-#pragma unroll
-                        for (int cc = 0; cc < 6; ++cc) W[R2_R + UVS_RD * a + 16 * fb + cc] = A.v[6 * r + cc];
-                    } else if (fb == UVS_NF) W[R2_R + UVS_RD * a + UVS_TD_INDEX] = A.v[6 * r];
-                    else if (fb == UVS_NF + 1) {
-#pragma unroll
-                        for (int cc = 0; cc < 6; ++cc) W[R2_R + UVS_RD * a + UVS_EX_INDEX(cc)] = A.v[6 * r + cc];
-                    } else {
-#pragma unroll
-                        for (int cc = 0; cc < 6; ++cc) if (cc <= a) W[R2_RR + 6 * a + cc] = A.v[6 * r + cc];
-                        W[R2_G + a] = A.g[r]; W[R2_HD + a] = A.hd[r];
-                    }
-                }
-            } else if (fa == UVS_NF + 1) {  // camera-extrinsic rows (ESTIMATE_EXTRINSIC): dof a of Ex_Pose sits at S index 16 a + 15, anywhere relative to the column
-#pragma unroll
-                for (int r = 0; r < GR; ++r) {
-                    const int a = r0 + r, i = UVS_EX_INDEX(a);
-                    if (fb < UVS_NF) {
-#pragma unroll
-                        for (int cc = 0; cc < 6; ++cc) { const int j = 16 * fb + cc; sh[L_S + (i >= j ? sidx(i, j) : sidx(j, i))] += A.v[6 * r + cc]; }
-                    } else if (fb == UVS_NF) sh[L_S + sidx(UVS_TD_INDEX, i)] += A.v[6 * r];
-                    else {
-#pragma unroll
-                        for (int cc = 0; cc < 6; ++cc) if (cc <= a) sh[L_S + sidx(i, UVS_EX_INDEX(cc))] += A.v[6 * r + cc];
-                        sh[L_G + i] += A.g[r]; sh[L_HD + i] += A.hd[r];
-                    }
-                }
-            } else if (fa == UVS_NF) {      // time-offset row (ESTIMATE_TD): row UVS_TD_INDEX of S, only row 0 of lane 0 of the group is real
-                if (r0 == 0) {
-                    if (fb < UVS_NF) {
-                        double* row = sh + L_S + sidx(UVS_TD_INDEX, 16 * fb);
-                        double cur[6];
-#pragma unroll
-                        for (int cc = 0; cc < 6; ++cc) cur[cc] = row[cc];
-#pragma unroll
-                        for (int cc = 0; cc < 6; ++cc) row[cc] = cur[cc] + A.v[cc];
-                    } else {
-                        sh[L_S + sidx(UVS_TD_INDEX, UVS_TD_INDEX)] += A.v[0] + A.hd[0];      // Schur part + J_td . J_td
-                        sh[L_G + UVS_TD_INDEX] += A.g[0]; sh[L_HD + UVS_TD_INDEX] += A.hd[0];
-                    }
-                }
-            } else {
-            const bool dg = fa == fb;
-            double* row0 = sh + L_S + sidx(16 * fa + r0, 16 * fb);
-            double cur[6 * GR], cg[GR], chd[GR];      // all reads before the first write (every "+=" to LDS otherwise waits for the one before)
+// ---- pieces of the assembly (shared by lin_assemble and the role-split linearization of the 512-thread build)
+// zero the image: S, G, HD (and the side buffer of a second-level relo_Pose)
+UVS_DEV void asm_zero(const Ctx& c) {
+    const DevWin& h = *c.hdr; double* sh = c.sh; const int tid = lane_tid();
+    { const d2_t z2 = {0.0, 0.0}; for (int i = tid; i < UVS_S_DOUBLES / 2; i += NT) *(d2_t*)(sh + L_S + 2 * i) = z2; }      // ds_write_b128
+    if (tid < UVS_RD) { sh[L_G + tid] = 0.0; sh[L_HD + tid] = 0.0; }
+    if (h.relo2) for (int t = tid; t < R2_SC; t += NT) c.ws[h.w_relo2 + t] = 0.0;
+}
+// the part-0 group of every pose block adds its rows (one writer per block: a single round)
+UVS_DEV void asm_part0(const Ctx& c, int grp, const GAcc& A) {
+    const DevWin& h = *c.hdr; double* sh = c.sh; const int tid = lane_tid();
+    if (grp >= 0 && ((grp >> 9) & 15) == 0) {
+        const int r0 = GR * (tid % UVS_GLANES);
+        const int fa = (grp >> 13) & 15, fb = (grp >> 17) & 15;
+        if (fa == UVS_RELO2_BLOCKROW) {      // relo_Pose beside a free extrinsic: its rows go to the side buffer (relo2_eliminate)
+            double* W = c.ws + h.w_relo2;
 #pragma unroll
             for (int r = 0; r < GR; ++r) {
+                const int a = r0 + r;
+                if (fb < UVS_NF) {
 #pragma unroll
-                for (int cc = 0; cc < 6; ++cc) cur[6 * r + cc] = row0[r * UVS_BLK_LD + cc];
-                cg[r] = sh[L_G + 16 * fa + r0 + r]; chd[r] = sh[L_HD + 16 * fa + r0 + r];
+                    for (int cc = 0; cc < 6; ++cc) W[R2_R + UVS_RD * a + 16 * fb + cc] = A.v[6 * r + cc];
+                } else if (fb == UVS_NF) W[R2_R + UVS_RD * a + UVS_TD_INDEX] = A.v[6 * r];
+                else if (fb == UVS_NF + 1) {
+#pragma unroll
+                    for (int cc = 0; cc < 6; ++cc) W[R2_R + UVS_RD * a + UVS_EX_INDEX(cc)] = A.v[6 * r + cc];
+                } else {
+#pragma unroll
+                    for (int cc = 0; cc < 6; ++cc) if (cc <= a) W[R2_RR + 6 * a + cc] = A.v[6 * r + cc];
+                    W[R2_G + a] = A.g[r]; W[R2_HD + a] = A.hd[r];
+                }
             }
+        } else if (fa == UVS_NF + 1) {  // camera-extrinsic rows (ESTIMATE_EXTRINSIC): dof a of Ex_Pose sits at S index 16 a + 15, anywhere relative to the column
 #pragma unroll
             for (int r = 0; r < GR; ++r) {
+                const int a = r0 + r, i = UVS_EX_INDEX(a);
+                if (fb < UVS_NF) {
 #pragma unroll
-                for (int cc = 0; cc < 6; ++cc) if (!dg || cc <= r0 + r) row0[r * UVS_BLK_LD + cc] = cur[6 * r + cc] + A.v[6 * r + cc];
-                if (dg) { sh[L_G + 16 * fa + r0 + r] = cg[r] + A.g[r]; sh[L_HD + 16 * fa + r0 + r] = chd[r] + A.hd[r]; }
+                    for (int cc = 0; cc < 6; ++cc) { const int j = 16 * fb + cc; sh[L_S + (i >= j ? sidx(i, j) : sidx(j, i))] += A.v[6 * r + cc]; }
+                } else if (fb == UVS_NF) sh[L_S + sidx(UVS_TD_INDEX, i)] += A.v[6 * r];
+                else {
+#pragma unroll
+                    for (int cc = 0; cc < 6; ++cc) if (cc <= a) sh[L_S + sidx(i, UVS_EX_INDEX(cc))] += A.v[6 * r + cc];
+                    sh[L_G + i] += A.g[r]; sh[L_HD + i] += A.hd[r];
+                }
             }
+        } else if (fa == UVS_NF) {      // time-offset row (ESTIMATE_TD): row UVS_TD_INDEX of S, only row 0 of lane 0 of the group is real
+            if (r0 == 0) {
+                if (fb < UVS_NF) {
+                    double* row = sh + L_S + sidx(UVS_TD_INDEX, 16 * fb);
+                    double cur[6];
+#pragma unroll
+                    for (int cc = 0; cc < 6; ++cc) cur[cc] = row[cc];
+#pragma unroll
+                    for (int cc = 0; cc < 6; ++cc) row[cc] = cur[cc] + A.v[cc];
+                } else {
+                    sh[L_S + sidx(UVS_TD_INDEX, UVS_TD_INDEX)] += A.v[0] + A.hd[0];      // Schur part + J_td . J_td
+                    sh[L_G + UVS_TD_INDEX] += A.g[0]; sh[L_HD + UVS_TD_INDEX] += A.hd[0];
+                }
             }
+        } else {
+        const bool dg = fa == fb;
+        double* row0 = sh + L_S + sidx(16 * fa + r0, 16 * fb);
+        double cur[6 * GR], cg[GR], chd[GR];      // all reads before the first write (every "+=" to LDS otherwise waits for the one before)
+#pragma unroll
+        for (int r = 0; r < GR; ++r) {
+#pragma unroll
+            for (int cc = 0; cc < 6; ++cc) cur[6 * r + cc] = row0[r * UVS_BLK_LD + cc];
+            cg[r] = sh[L_G + 16 * fa + r0 + r]; chd[r] = sh[L_HD + 16 * fa + r0 + r];
         }
-        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < GR; ++r) {
+#pragma unroll
+            for (int cc = 0; cc < 6; ++cc) if (!dg || cc <= r0 + r) row0[r * UVS_BLK_LD + cc] = cur[6 * r + cc] + A.v[6 * r + cc];
+            if (dg) { sh[L_G + 16 * fa + r0 + r] = cg[r] + A.g[r]; sh[L_HD + 16 * fa + r0 + r] = chd[r] + A.hd[r]; }
+        }
+        }
     }
-    UVS_TZ(6)
-#undef UVS_TZ
-    UVS_PROF(c, P_AS_ZERO);
-    // IMU normal-equation tiles from the registers of lin_imu (even blocks, then odd: consecutive blocks share a diagonal frame block)
-    if (mode != 2) {
-        const int lane = tid & 63, wv = tid >> 6, li = lane & 15, lk = lane >> 4;
-        int fis[IMU_SLOTS]; bool act[IMU_SLOTS];
+}
+// IMU normal-equation tiles from the registers of lin_imu (even blocks, then odd: consecutive blocks share a diagonal frame block); TWO workgroup barriers
+UVS_DEV void asm_imu(const Ctx& c, const ImuN& N) {
+    const DevWin& h = *c.hdr; double* sh = c.sh; const int tid = lane_tid();
+    const int lane = tid & 63, wv = tid >> 6, li = lane & 15, lk = lane >> 4;
+    int fis[IMU_SLOTS]; bool act[IMU_SLOTS];
 #pragma unroll
-        for (int s = 0; s < IMU_SLOTS; ++s) {      // block table fetched once (HBM/L2 latency), not once per pass
-            const int b = wv + s * NW;
-            act[s] = b < h.n_imu && !c.bi[h.i_imu + 2 * (b < h.n_imu ? b : 0) + 1] && li < 15;
-            fis[s] = c.bi[h.i_imu + 2 * (b < h.n_imu ? b : 0)];
-        }
-        for (int par = 0; par < 2; ++par) {
+    for (int s = 0; s < IMU_SLOTS; ++s) {      // block table fetched once (HBM/L2 latency), not once per pass
+        const int b = wv + s * EW;
+        act[s] = wv < EW && b < h.n_imu && !c.bi[h.i_imu + 2 * (b < h.n_imu ? b : 0) + 1] && li < 15;
+        fis[s] = c.bi[h.i_imu + 2 * (b < h.n_imu ? b : 0)];
+    }
+    for (int par = 0; par < 2; ++par) {
 #pragma unroll
-            for (int s = 0; s < IMU_SLOTS; ++s) {
-                const int b = wv + s * NW;
-                if (act[s] && (b & 1) == par) {
-                    const int fi = fis[s], fj = fi + 1;
-                    // C layout: row = lk + 4q, col = li.  Rows < 15 go to S (lower triangles of the diagonal tiles), row 15 is J^T r.
-                    double* b10 = sblk(sh, fj, fi) + lk * UVS_BLK_LD + li;
-                    double* b00 = sblk(sh, fi, fi) + lk * UVS_BLK_LD + li;
-                    double* b11 = sblk(sh, fj, fj) + lk * UVS_BLK_LD + li;
-                    double c10[4], c00[4], c11[4];      // reads first, then writes
+        for (int s = 0; s < IMU_SLOTS; ++s) {
+            const int b = wv + s * EW;
+            if (act[s] && (b & 1) == par) {
+                const int fi = fis[s], fj = fi + 1;
+                // C layout: row = lk + 4q, col = li.  Rows < 15 go to S (lower triangles of the diagonal tiles), row 15 is J^T r.
+                double* b10 = sblk(sh, fj, fi) + lk * UVS_BLK_LD + li;
+                double* b00 = sblk(sh, fi, fi) + lk * UVS_BLK_LD + li;
+                double* b11 = sblk(sh, fj, fj) + lk * UVS_BLK_LD + li;
+                double c10[4], c00[4], c11[4];      // reads first, then writes
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int row = lk + 4 * q;
-                        const bool isg = row == 15;
-                        c10[q] = isg ? sh[L_G + 16 * fi + li] : b10[4 * q * UVS_BLK_LD];
-                        c11[q] = isg ? sh[L_G + 16 * fj + li] : b11[4 * q * UVS_BLK_LD];
-                        c00[q] = b00[4 * q * UVS_BLK_LD];
-                    }
+                for (int q = 0; q < 4; ++q) {
+                    const int row = lk + 4 * q;
+                    const bool isg = row == 15;
+                    c10[q] = isg ? sh[L_G + 16 * fi + li] : b10[4 * q * UVS_BLK_LD];
+                    c11[q] = isg ? sh[L_G + 16 * fj + li] : b11[4 * q * UVS_BLK_LD];
+                    c00[q] = b00[4 * q * UVS_BLK_LD];
+                }
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int row = lk + 4 * q;
-                        if (row < 15) {
-                            b10[4 * q * UVS_BLK_LD] = c10[q] + N.n10[s][q];
-                            if (li <= row) {
-                                b00[4 * q * UVS_BLK_LD] = c00[q] + N.n00[s][q];
-                                b11[4 * q * UVS_BLK_LD] = c11[q] + N.n11[s][q];
-                                if (li == row) { sh[L_HD + 16 * fi + row] += N.n00[s][q]; sh[L_HD + 16 * fj + row] += N.n11[s][q]; }
-                            }
-                        } else {
-                            sh[L_G + 16 * fi + li] = c10[q] + N.n10[s][q];
-                            sh[L_G + 16 * fj + li] = c11[q] + N.n11[s][q];
+                for (int q = 0; q < 4; ++q) {
+                    const int row = lk + 4 * q;
+                    if (row < 15) {
+                        b10[4 * q * UVS_BLK_LD] = c10[q] + N.n10[s][q];
+                        if (li <= row) {
+                            b00[4 * q * UVS_BLK_LD] = c00[q] + N.n00[s][q];
+                            b11[4 * q * UVS_BLK_LD] = c11[q] + N.n11[s][q];
+                            if (li == row) { sh[L_HD + 16 * fi + row] += N.n00[s][q]; sh[L_HD + 16 * fj + row] += N.n11[s][q]; }
                         }
+                    } else {
+                        sh[L_G + 16 * fi + li] = c10[q] + N.n10[s][q];
+                        sh[L_G + 16 * fj + li] = c11[q] + N.n11[s][q];
                     }
                 }
             }
-            __syncthreads();
         }
+        __syncthreads();
     }
-    // prior: H0 = J0^T J0 and g = g0 + H0 dx (y = H0 dx came with the cost of this point: prior_quad)
-    if (h.prior_n > 0 && mode != 2) {
+}
+// prior: H0 = J0^T J0 and g = g0 + H0 dx (y = H0 dx came with the cost of this point: prior_quad)
+UVS_DEV void asm_prior(const Ctx& c) {
+    const DevWin& h = *c.hdr; double* sh = c.sh; const int tid = lane_tid();
+    if (h.prior_n > 0) {
         const int n = h.prior_n;
         const int* cm = c.bi + h.i_prior + 80;
         {   // H0 entries that are structurally non-zero in S: host table of (index into the dense n x n H0, S offset)
@@ -1991,10 +2080,10 @@ UVS_DEV void lin_assemble(const Ctx& c, const double* x, bool first, double radi
         }
         if (tid < n && cm[tid] >= 0) sh[L_G + cm[tid]] += c.ws[h.w_prior_h0 + UVS_PH_G0(n) + tid] + sh[L_PR + tid];      // one writer per S index (the IMU adds ended with a barrier)
     }
-    __syncthreads();
-    UVS_PROF(c, P_AS_ADD);
-    if (mode == 1) return;
-    // frame damping, Jacobi scaling (first linearization only), dummy pivots, projected-gradient max norm
+}
+// frame damping, Jacobi scaling (first linearization only), dummy pivots, projected-gradient max norm, the linearization's cost -> control words
+UVS_DEV void asm_finish(const Ctx& c, const double* x, bool first, double radius, double cost, double gmax_lm, int mode) {
+    const DevWin& h = *c.hdr; double* sh = c.sh; const int tid = lane_tid();
     double gmax = gmax_lm;
     if (tid < UVS_RD) {
         const int k = tid & 15;
@@ -2030,16 +2119,165 @@ UVS_DEV void lin_assemble(const Ctx& c, const double* x, bool first, double radi
     block_reduce(sh, s4, &gmax);
     if (tid == 0) { sh[L_CTRL + C_COST] = s4[0]; sh[L_CTRL + C_GMAX] = gmax; }
     __syncthreads();
+}
+UVS_DEV void lin_assemble(const Ctx& c, const double* x, bool first, double radius, int grp, const GAcc& Ain, const ImuN& N, double cost, double gmax_lm, int mode = 0) {
+    const DevWin& h = *c.hdr;
+    double* sh = c.sh;
+    const int tid = lane_tid();
+    __syncthreads();
+    UVS_PROF(c, P_GATHER);
+    // ---- assemble the reduced system in LDS
+    // parts of split blocks -> their part-0 group (the staging area is free now; S is zeroed only after the sums are in registers)
+    GAcc A = Ain;
+    long long tz_ = clock64();
+#define UVS_TZ(slot) if (c.o.debug == 3 && tid == 0) { const long long t_ = clock64(); sh[L_WPROF + slot] += (double)(t_ - tz_); tz_ = t_; }
+    if (mode == 0) { gacc_gather_parts(A, grp, sh + L_S); __syncthreads(); }
+    UVS_TZ(4)
+    if (mode != 2) {
+        asm_zero(c);
+        __syncthreads();
+    }
+    UVS_TZ(5)
+    // the part-0 group of every pose block adds its rows (one writer per block: a single round)
+    if (mode != 1) {
+        asm_part0(c, grp, A);
+        __syncthreads();
+    }
+    UVS_TZ(6)
+#undef UVS_TZ
+    UVS_PROF(c, P_AS_ZERO);
+    // IMU normal-equation tiles from the registers of lin_imu (even blocks, then odd: consecutive blocks share a diagonal frame block)
+    if (mode != 2) {
+        asm_imu(c, N);
+    }
+    // prior: H0 = J0^T J0 and g = g0 + H0 dx (y = H0 dx came with the cost of this point: prior_quad)
+    if (mode != 2) asm_prior(c);
+    __syncthreads();
+    UVS_PROF(c, P_AS_ADD);
+    if (mode == 1) return;
+    asm_finish(c, x, first, radius, cost, gmax_lm, mode);
     UVS_PROF(c, P_ASSEMBLE);
+}
+
+// ---- the role-split linearization of the 512-thread build (ROLES).  Evaluator and gatherer waves run DIFFERENT code between the same workgroup
+// barriers (s_barrier counts arriving waves, not program counters); the two branches below must therefore execute the same NUMBER of barriers:
+//     per chunk      evaluators: chunk_eval (4 barriers inside)            gatherers: 4 barriers, then the chunk's gather walk
+//     frame terms    evaluators: lin_imu (3 barriers: entry, zeroed, raw)  gatherers: entry barrier, then gacc_gather_parts (2 barriers) beside the IMU staging
+//     assembly       barrier | zero | barrier | part-0 rows (gatherers) | barrier | IMU tiles (evaluators, 2 barriers) | prior (all) | barrier | asm_finish (all)
+// The gather accumulators exist only in the gatherer branch and the IMU tiles only in the evaluator branch, so neither occupies registers where the
+// other branch's temporaries live.  redamp = true: re-damping of the stored linearization (relinearize_damping) instead of a new one.
+static constexpr bool GALL = ROLES && UVS_GT == NT;      // experiment (-DUVS_GATHER_ALL): every wave gathers (256 groups), waves 0..3 evaluate as well
+static constexpr int ROLE_PARTS_OFF = GALL ? 0 : (UVS_NF - 1) * IMU_BLK;      // the part sums of split blocks meet behind the IMU staging tiles
+static_assert(ROLE_PARTS_OFF + (8 * GR + 1) * UVS_GT <= UVS_S_DOUBLES, "IMU staging + part sums exceed the S region");
+UVS_DEV void role_barriers(int n) { for (int i = 0; i < n; ++i) __syncthreads(); }
+// the accumulators of the last linearization in the workspace, component-major (one 512-byte run per wave and component)
+UVS_DEV void gacc_store(const Ctx& c, const GAcc& A) {
+    double* W = c.ws + c.hdr->w_gacc + (lane_tid() - GT0);
+#pragma unroll
+    for (int q = 0; q < 6 * GR; ++q) __builtin_nontemporal_store(A.v[q], W + q * UVS_GT);
+#pragma unroll
+    for (int q = 0; q < GR; ++q) { __builtin_nontemporal_store(A.g[q], W + (6 * GR + q) * UVS_GT); __builtin_nontemporal_store(A.hd[q], W + (7 * GR + q) * UVS_GT); }
+}
+UVS_DEV void gacc_load(const Ctx& c, GAcc& A) {
+    const double* W = c.ws + c.hdr->w_gacc + (lane_tid() - GT0);
+#pragma unroll
+    for (int q = 0; q < 6 * GR; ++q) A.v[q] = W[q * UVS_GT];
+#pragma unroll
+    for (int q = 0; q < GR; ++q) { A.g[q] = W[(6 * GR + q) * UVS_GT]; A.hd[q] = W[(7 * GR + q) * UVS_GT]; }
+}
+UVS_DEV void linearize_roles(const Ctx& c, const double* x, const double* invd, const double* line, bool first, double radius, int prep_mode, bool redamp, GAcc& Akeep) {
+    const DevWin& h = *c.hdr;
+    const bool ev = role_eval();
+    { const double pc = lin_prep(c, x, redamp ? 2 : prep_mode); if (!redamp) lacc_set(c.sh, pc, 0.0); }
+    double ic = 0.0;
+    if (GALL) {
+        const int grp = gather_group(c);
+        GAcc A;
+        if (redamp) gacc_load(c, A); else gacc_zero(A);
+        for (int ch = 0; ch < h.n_chunks; ++ch) {
+            const ChunkDesc d = chunk_desc(c, ch);
+            if (redamp) { if (ev) redamp_prep(c, d, radius); else role_barriers(redamp_barriers(d)); redamp_gather(c, d, grp, A); }
+            else { if (ev) chunk_eval(c, d, x, invd, line, first, radius); else role_barriers(CHUNK_EVAL_BARRIERS); chunk_gather(c, d, grp, A); }
+        }
+        __syncthreads();
+        if (h.redamp_ok && c.o.redamp) gacc_store(c, A);
+        gacc_gather_parts(A, grp, c.sh + L_S);
+        ImuN N;
+        if (ev) ic = lin_imu(c, x, N); else role_barriers(3);
+        __syncthreads();
+        asm_zero(c);
+        __syncthreads();
+        asm_part0(c, grp, A);
+        __syncthreads();
+        if (ev) asm_imu(c, N); else role_barriers(2);
+        asm_prior(c);
+        __syncthreads();
+        asm_finish(c, x, first && !redamp, radius, lacc_cost(c.sh) + ic, lacc_gmax(c.sh), 0);
+        return;
+    }
+    if (ev) {
+        ChunkDesc d = chunk_desc(c, 0);
+        for (int ch = 0; ch < h.n_chunks; ++ch) {
+            if (redamp) redamp_prep(c, d, radius); else chunk_eval(c, d, x, invd, line, first, radius);
+            if (ch + 1 < h.n_chunks) d = chunk_desc(c, ch + 1);
+        }
+        ImuN N;
+        ic = lin_imu(c, x, N);
+        __syncthreads();
+        asm_zero(c);
+        __syncthreads();
+        __syncthreads();
+        asm_imu(c, N);
+    } else {
+        const int grp = gather_group(c);
+#ifdef UVS_ROLES_KEEP_A
+        GAcc& A = Akeep;
+        if (!redamp) gacc_zero(A);
+#else
+        GAcc A;
+        if (redamp) gacc_load(c, A); else gacc_zero(A);
+#endif
+        ChunkDesc d = chunk_desc(c, 0);
+        for (int ch = 0; ch < h.n_chunks; ++ch) {
+            if (redamp) { role_barriers(redamp_barriers(d)); redamp_gather(c, d, grp, A); }
+            else { role_barriers(CHUNK_EVAL_BARRIERS); chunk_gather(c, d, grp, A); }
+            if (ch + 1 < h.n_chunks) d = chunk_desc(c, ch + 1);
+        }
+        __syncthreads();      // (lin_imu's entry barrier: every gather walk is done, the staging area is free)
+#ifdef UVS_ROLES_KEEP_A
+        GAcc T = A;
+#else
+        if (h.redamp_ok && c.o.redamp) gacc_store(c, A);      // per part: a re-damping continues from these
+        GAcc& T = A;
+#endif
+        gacc_gather_parts(T, grp, c.sh + L_S + ROLE_PARTS_OFF);
+        __syncthreads();
+        asm_zero(c);
+        __syncthreads();
+        asm_part0(c, grp, T);
+        __syncthreads();
+        role_barriers(2);
+    }
+    asm_prior(c);
+    __syncthreads();
+    asm_finish(c, x, first && !redamp, radius, lacc_cost(c.sh) + ic, lacc_gmax(c.sh), 0);
 }
 
 // `A`: the gather accumulators, owned by the caller (k_solve keeps them in registers between a linearization and a possible re-damping)
 UVS_DEV void linearize(const Ctx& c, const double* x, const double* invd, const double* line, bool first, double radius, int prep_mode, GAcc& A) {
+    if (ROLES) { linearize_roles(c, x, invd, line, first, radius, prep_mode, false, A); return; }
     const DevWin& h = *c.hdr;
     const int grp = gather_group(c);       // this lane's gather group: pose block | flags (uvs_layout.h: i_wblk)
     gacc_zero(A);
     { const double pc = lin_prep(c, x, prep_mode); lacc_set(c.sh, pc, 0.0); }
-    for (int ch = 0; ch < h.n_chunks; ++ch) lin_chunk(c, ch, x, invd, line, first, radius, grp, A);
+    {
+        ChunkDesc d = chunk_desc(c, 0);
+        for (int ch = 0; ch < h.n_chunks; ++ch) {
+            chunk_eval(c, d, x, invd, line, first, radius);
+            chunk_gather(c, d, grp, A);
+            if (ch + 1 < h.n_chunks) d = chunk_desc(c, ch + 1);
+        }
+    }
     ImuN N;
     const double ic = lin_imu(c, x, N);
     lin_assemble(c, x, first, radius, grp, A, N, lacc_cost(c.sh) + ic, lacc_gmax(c.sh));
@@ -2048,10 +2286,18 @@ UVS_DEV void linearize(const Ctx& c, const double* x, const double* invd, const 
 // After a rejected / invalid step: the same point, a smaller radius.  The per-lane cost / gradient-norm accumulators of the linearization
 // (L_LCOST / L_LGMAX) still hold their values.
 UVS_DEV void relinearize_damping(const Ctx& c, const double* x, double radius, GAcc& A) {
+    if (ROLES) { linearize_roles(c, x, nullptr, nullptr, false, radius, 2, true, A); return; }
     const DevWin& h = *c.hdr;
     const int grp = gather_group(c);
     (void)lin_prep(c, x, 2);
-    for (int ch = 0; ch < h.n_chunks; ++ch) redamp_chunk(c, ch, radius, grp, A);
+    {
+        ChunkDesc d = chunk_desc(c, 0);
+        for (int ch = 0; ch < h.n_chunks; ++ch) {
+            redamp_prep(c, d, radius);
+            redamp_gather(c, d, grp, A);
+            if (ch + 1 < h.n_chunks) d = chunk_desc(c, ch + 1);
+        }
+    }
     ImuN N;
     const double ic = lin_imu(c, x, N);
     lin_assemble(c, x, false, radius, grp, A, N, lacc_cost(c.sh) + ic, lacc_gmax(c.sh));
@@ -2504,6 +2750,7 @@ __global__ __launch_bounds__(NT) void k_solve(char* blobs, const long long* blob
     }
 }
 
+#ifndef UVS_SOLVE_KERNEL_ONLY      // (uvs_solve512.hip instantiates k_solve alone)
 // ------------------------------------------------------------------ marginalization on the device (MARGIN_OLD)
 // The window here is the SUB-window of the factors that touch the departing frame 0 (marginalization_factor.cpp:174-297 via estimator.cpp:1002-1135: IMU block 0,
 // the points anchored in frame 0, the lines that start there without their anchor observation, the prior), packed with a FREE extrinsic (the reference's prior
@@ -2557,4 +2804,5 @@ __global__ __launch_bounds__(NT) void k_marg_linearize(char* blob, double* ws, K
     if (tid == 0) { double* sc = out + UVS_RD * (UVS_RD + 1) / 2 + UVS_RD; sc[0] = sh[L_CTRL + C_COST]; sc[1] = s4[0]; }
 }
 
+#endif
 }  // namespace uvsdev

@@ -28,6 +28,15 @@
 
 using namespace uvsdev;
 
+// the 512-thread instantiation of the persistent kernel (uvs_solve512.hip)
+extern "C" {
+int uvs_k_solve512_init(const unsigned char* fa, const unsigned char* fb, int n);
+void uvs_k_solve512_launch(int n_windows, hipStream_t stream, char* blobs, const long long* blob_off, double* ws_all, const long long* ws_off,
+                           const void* kopts, size_t kopts_bytes, uvs_report* reports, const void* dbg, size_t dbg_bytes);
+size_t uvs_k_solve512_arg_bytes(int which);
+int uvs_k_solve512_timeline(long long* out, size_t n);
+}
+
 struct PackCache;
 static void free_pack_cache(PackCache* c);
 struct MargDevScratch;
@@ -39,6 +48,7 @@ struct uvs_solver {
     int max_points = 0, max_point_obs = 0, max_lines = 0, max_line_obs = 0;      // per-window capacities promised at uvs_create
     uvs_solver* twin = nullptr;              // second buffer set of uvs_batch_stream (created on first use, destroyed with this handle)
     int n_cus = 256;                         // compute units of the device
+    int ksolve_nt = 512;                     // which instantiation of the persistent kernel launch_solve uses (uvs_solve512.hip / this file's 256-thread one)
     int chunk_wgs() const { return std::max(1, n_cus - 1); }      // chunk workgroups of the persistent large-window kernels: one compute unit stays free for the frame-terms workgroup of the same launch
     hipStream_t stream;
     hipEvent_t ev0, ev1;
@@ -176,6 +186,8 @@ int uvs_create(const uvs_options* opts, int device, int max_batch, int max_point
     unsigned char fa[UVS_NBLK], fb[UVS_NBLK];
     for (int i = 0, b = 0; i < UVS_NF; ++i) for (int j = 0; j <= i; ++j, ++b) { fa[b] = (unsigned char)i; fb[b] = (unsigned char)j; }
     if (hipMemcpyToSymbol(HIP_SYMBOL(c_blk_fa), fa, sizeof(fa)) != hipSuccess || hipMemcpyToSymbol(HIP_SYMBOL(c_blk_fb), fb, sizeof(fb)) != hipSuccess) { delete s; return UVS_ERR_HIP; }
+    if (uvs_k_solve512_arg_bytes(0) != sizeof(KOpts) || uvs_k_solve512_arg_bytes(1) != sizeof(DebugOut) || uvs_k_solve512_init(fa, fb, UVS_NBLK) != UVS_OK) { delete s; return UVS_ERR_HIP; }
+    { const char* e = std::getenv("UVS_KSOLVE_NT"); s->ksolve_nt = (e && std::atoi(e) == 256) ? 256 : 512; }      // A/B switch: 256 = the one-wave-per-SIMD instantiation of the persistent kernel
     // the LDS opt-in is a per-device function attribute: every handle sets it for its own device (the current one since hipSetDevice above)
     for (const void* fn : {(const void*)k_solve, (const void*)k_evaluate, (const void*)k_large_chunks, (const void*)k_large_solve, (const void*)k_large_backsub})
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES) != hipSuccess) { delete s; return UVS_ERR_HIP; }
@@ -442,7 +454,7 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
     for (int k = 0; k < h.n_lines; ++k) lbeg[k + 1] += lbeg[k];
     // chunks: greedy packing of whole landmarks into the LDS staging area (UVS_S_DOUBLES doubles).  A chunk holds the
     // observation records, the per-landmark Schur factors AND its gather lists (ints, 2 per double).
-    std::vector<int> chunks;     // 6 ints per chunk
+    std::vector<int> chunks;     // UVS_CHUNK_INTS ints per chunk (uvs_layout.h: i_chunks)
     {
         const long list_hdr = 2 * (UVS_NGRP + 1);
         // LDS doubles a chunk of landmarks [k0, k1) needs (records + Schur factors + gather lists), -1 if an index field overflows
@@ -507,8 +519,8 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
                 if (t_ln > n_ln && split(1, h.n_lines, lbeg, need_ln, t_ln, c2) == UVS_OK) cut_ln = c2;
             }
         }
-        for (size_t j = 0; j + 1 < cut_pt.size(); ++j) chunks.insert(chunks.end(), {0, cut_pt[j], cut_pt[j + 1], 0, 0, 0});
-        for (size_t j = 0; j + 1 < cut_ln.size(); ++j) chunks.insert(chunks.end(), {1, cut_ln[j], cut_ln[j + 1], 0, 0, 0});
+        for (size_t j = 0; j + 1 < cut_pt.size(); ++j) chunks.insert(chunks.end(), {0, cut_pt[j], cut_pt[j + 1], 0, 0, 0, pbeg[cut_pt[j]], pbeg[cut_pt[j + 1]] - pbeg[cut_pt[j]]});
+        for (size_t j = 0; j + 1 < cut_ln.size(); ++j) chunks.insert(chunks.end(), {1, cut_ln[j], cut_ln[j + 1], 0, 0, 0, lbeg[cut_ln[j]], lbeg[cut_ln[j + 1]] - lbeg[cut_ln[j]]});
     }
     lap_("split");
     // gather lists per chunk and per lower 6x6 pose block (see uvs_solve_kernel.h: gather_points / gather_lines),
@@ -516,14 +528,14 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
     //   points: rec[nob][30] | E[(nob+nlm)][6] | EI[(nob+nlm)][6] | lists      lines: rec[nob][34] | E[nob][24] | Y[nob][24] | X[nlm][20] | lists
     //   Schur entry : offset(E row of frame a) | offset(EI / Y row of frame b) << 16
     //   direct entry: points: offset(first Jacobian block) | offset(second) << 16   (A^T A, B^T B, B^T A) ; lines: record offset
-    const int n_ch = (int)chunks.size() / 6;
+    const int n_ch = (int)chunks.size() / UVS_CHUNK_INTS;
     // Two passes over the same generator: the first only COUNTS the entries per pose block (what the work split below needs), the second
     // regenerates them chunk by chunk into one reused set of vectors while the lists are written.  (Keeping every chunk's entries
     // alive between the passes cost 80 k small vectors on a configs[3]-sized window: two thirds of the packing time.)
     std::vector<long> blk_work(UVS_NBLKX2, 0), blk_s(UVS_NBLKX2, 0), blk_d(UVS_NBLKX2, 0), blk_wp(UVS_NBLKX2, 0), blk_wl(UVS_NBLKX2, 0);
     auto blk_of = [](int fa, int fb) { return fa * (fa + 1) / 2 + fb; };   // fa >= fb ; fa == 11 is the time-offset pseudo frame: 66 + fb
     auto chunk_entries = [&](int qc, auto&& addS, auto&& addD) {
-        const int type = chunks[6 * qc], k0 = chunks[6 * qc + 1], k1 = chunks[6 * qc + 2];
+        const int type = chunks[UVS_CHUNK_INTS * qc], k0 = chunks[UVS_CHUNK_INTS * qc + 1], k1 = chunks[UVS_CHUNK_INTS * qc + 2];
         if (type == 0) {
             const int o0 = pbeg[k0], nob = pbeg[k1] - o0, nlm = k1 - k0;
             const int oE = nob * PREC, oEI = oE + 6 * (nob + XS * nlm);
@@ -585,7 +597,7 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
                 long cs[UVS_NBLKX2] = {0}, cd[UVS_NBLKX2] = {0};
                 chunk_entries(qc, [&](int b, int) { ++cs[b]; }, [&](int b, int) { ++cd[b]; });
                 for (int b = 0; b < UVS_NBLKX2; ++b) { cnt_s[(size_t)qc * UVS_NBLKX2 + b] = (int)cs[b]; cnt_d[(size_t)qc * UVS_NBLKX2 + b] = (int)cd[b]; }
-                const int type = chunks[6 * qc];
+                const int type = chunks[UVS_CHUNK_INTS * qc];
                 // work units ~ cycles per entry of the rows-per-lane gather
                 for (int b = 0; b < UVS_NBLKX2; ++b) {
                     // measured per entry on MI355X (per-wave timers, UVS_DEBUG_GATHER_TIMERS): point Schur 350 cycles, point direct 675 cycles
@@ -678,7 +690,7 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
             int dst[2][UVS_NGRP], lo_of[2][UVS_NGRP], fill[2][UVS_NBLKX2], cur_part[2][UVS_NBLKX2], cur_hi[2][UVS_NBLKX2];
             for (int qc = q0; qc < q1; ++qc) {
                 const int* cS = cnt_s.data() + (size_t)qc * UVS_NBLKX2; const int* cD = cnt_d.data() + (size_t)qc * UVS_NBLKX2;
-                chunks[6 * qc + 3] = (int)P.lists.size();      // relative to this part for now
+                chunks[UVS_CHUNK_INTS * qc + 3] = (int)P.lists.size();      // relative to this part for now
                 const size_t base = P.lists.size();
                 int at = 0;
                 for (int pass = 0; pass < 2; ++pass) {
@@ -713,10 +725,10 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
                     ent[dst[pass][g] + (e - lo_of[pass][g])] = v;
                 };
                 chunk_entries(qc, [&](int b, int v) { put(0, b, v); }, [&](int b, int v) { put(1, b, v); });
-                chunks[6 * qc + 4] = (int)(P.lists.size() - base);
+                chunks[UVS_CHUNK_INTS * qc + 4] = (int)(P.lists.size() - base);
                 {   // the chunk as the kernel lays it out must fit the staging area: records + Schur factors + the lists just built (an estimate that
                     // is too small would let the lists run over the LM state that follows S in LDS)
-                    const int type = chunks[6 * qc], k0 = chunks[6 * qc + 1], k1 = chunks[6 * qc + 2];
+                    const int type = chunks[UVS_CHUNK_INTS * qc], k0 = chunks[UVS_CHUNK_INTS * qc + 1], k1 = chunks[UVS_CHUNK_INTS * qc + 2];
                     const long nlist = (long)(P.lists.size() - base);
                     long used;
                     if (type == 0) { const long nob = pbeg[k1] - pbeg[k0], nlm = k1 - k0; used = (long)PREC * nob + 12 * (nob + XS * nlm) + (nlist + 1) / 2; }
@@ -725,7 +737,7 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
                     P.max_used = std::max(P.max_used, (int)used);
                 }
                 if (dbg_lists) {
-                    fprintf(stderr, "chunk %d type %d lm [%d,%d):\n", qc, chunks[6 * qc], chunks[6 * qc + 1], chunks[6 * qc + 2]);
+                    fprintf(stderr, "chunk %d type %d lm [%d,%d):\n", qc, chunks[UVS_CHUNK_INTS * qc], chunks[UVS_CHUNK_INTS * qc + 1], chunks[UVS_CHUNK_INTS * qc + 2]);
                     for (int wv = 0; wv < NW; ++wv) {
                         fprintf(stderr, "  wave %d:", wv);
                         for (int q = 0; q < GRP_PER_WAVE; ++q) { const int g = wv * GRP_PER_WAVE + q; fprintf(stderr, " b%d.%d(%d,%d)", g_blk[g], g_part[g], P.lists[base + g + 1] - P.lists[base + g], P.lists[base + UVS_NGRP + 2 + g] - P.lists[base + UVS_NGRP + 1 + g]); }
@@ -744,20 +756,20 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
             if (P.overflow) { err = "internal: chunk layout exceeds the LDS staging area"; return UVS_ERR_CAPACITY; }
             h.max_chunk_doubles = std::max(h.max_chunk_doubles, P.max_used);
             if (!P.lists.empty()) std::memcpy(lists.data() + at, P.lists.data(), P.lists.size() * sizeof(int));
-            for (int qc = P.q0; qc < P.q1; ++qc) chunks[6 * qc + 3] += (int)at;      // part-relative -> absolute (parts are in chunk order: thread t took the t-th range)
+            for (int qc = P.q0; qc < P.q1; ++qc) chunks[UVS_CHUNK_INTS * qc + 3] += (int)at;      // part-relative -> absolute (parts are in chunk order: thread t took the t-th range)
             at += P.lists.size();
         }
     }
-    h.n_chunks = (int)chunks.size() / 6;
+    h.n_chunks = (int)chunks.size() / UVS_CHUNK_INTS;
     // re-damping (uvs_solve_kernel.h: redamp_chunk) keeps its per-line table and gradient rows in the record area of a line chunk
     h.chol_half_ok = 1;
     if (have_prior) for (int b = 0; b < w->prior->n_blocks; ++b) if (w->prior->block_kind[b] == UVS_BLOCK_SPEEDBIAS && w->prior->block_frame[b] >= 2) h.chol_half_ok = 0;
     if (std::getenv("UVS_CHOL_FULL_ROWS")) h.chol_half_ok = 0;
     h.redamp_ok = (!td_on && !ex_on && !relo_on) ? 1 : 0;
     for (int qc = 0; qc < h.n_chunks && h.redamp_ok; ++qc)
-        if (chunks[6 * qc] == 1) { const long nob = lbeg[chunks[6 * qc + 2]] - lbeg[chunks[6 * qc + 1]], nlm = chunks[6 * qc + 2] - chunks[6 * qc + 1]; if (34 * nlm + 6 * nob > (long)UVS_LN_REC * nob) h.redamp_ok = 0; }
+        if (chunks[UVS_CHUNK_INTS * qc] == 1) { const long nob = lbeg[chunks[UVS_CHUNK_INTS * qc + 2]] - lbeg[chunks[UVS_CHUNK_INTS * qc + 1]], nlm = chunks[UVS_CHUNK_INTS * qc + 2] - chunks[UVS_CHUNK_INTS * qc + 1]; if (34 * nlm + 6 * nob > (long)UVS_LN_REC * nob) h.redamp_ok = 0; }
         else {      // point chunk: redamp_chunk's gradient rows Gb[(nob + nlm)][6] sit in front of the E rows at rec + nob * pt_rec -- a chunk made mostly of landmarks WITHOUT observations would run into them
-            const long nob = pbeg[chunks[6 * qc + 2]] - pbeg[chunks[6 * qc + 1]], nlm = chunks[6 * qc + 2] - chunks[6 * qc + 1];
+            const long nob = pbeg[chunks[UVS_CHUNK_INTS * qc + 2]] - pbeg[chunks[UVS_CHUNK_INTS * qc + 1]], nlm = chunks[UVS_CHUNK_INTS * qc + 2] - chunks[UVS_CHUNK_INTS * qc + 1];
             if (6 * (nob + nlm) > (long)h.pt_rec * nob) h.redamp_ok = 0;
         }
     lap_("lists");
@@ -816,7 +828,7 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
     h.i_imu = i; i += 2 * std::max(h.n_imu, 1);
     h.i_prior = i; i += 80 + UVS_MAX_PRIOR_DIM + UVS_RD + UVS_NBLK;
     h.i_cimg = i; i += 2 * (int)csrc.size() + 2;
-    h.i_chunks = i; i += 6 * std::max(h.n_chunks, 1);
+    h.i_chunks = i; i += UVS_CHUNK_INTS * std::max(h.n_chunks, 1);
     h.i_wblk = i; i += UVS_NGRP;
     h.i_lists = i; i += (int)lists.size() + 2;
     h.blob_bytes = rup(4 * i, 256);
@@ -834,6 +846,7 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
     h.w_prior_h0 = wsz; wsz += UVS_PH_DOUBLES(h.prior_n);      // H0 = J0^T J0, g0, c0, diag(H0) per S index: written once per solve by setup_window
     h.n_cimg = (int)csrc.size();
     h.w_relo2 = wsz; if (relo2) wsz += UVS_RELO2_DOUBLES;
+    h.w_gacc = wsz; wsz += 8 * UVS_GROWS * UVS_GT;      // (the 512-thread k_solve: gather accumulators of the last linearization)
     h.ws_doubles = rup(wsz, 32);
     // fill
     const size_t base = out.size();
@@ -1162,7 +1175,8 @@ static int launch_solve(uvs_solver* s, int debug, float* elapsed_ms, bool wait =
         dbg.S = s->d_dbg; dbg.g = dbg.S + UVS_RD * UVS_RD; dbg.hd = dbg.g + UVS_RD; dbg.dd = dbg.hd + UVS_RD; dbg.step = dbg.dd + UVS_RD; dbg.scal = dbg.step + UVS_RD;
     }
     HIPCHK(s, hipEventRecord(s->ev0, s->stream));
-    hipLaunchKernelGGL(k_solve, dim3(s->n_loaded), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_blob_off, s->d_ws, s->d_ws_off, ko, s->d_reports, dbg);
+    if (s->ksolve_nt == 512) uvs_k_solve512_launch(s->n_loaded, s->stream, s->d_blobs, s->d_blob_off, s->d_ws, s->d_ws_off, &ko, sizeof(ko), s->d_reports, &dbg, sizeof(dbg));
+    else hipLaunchKernelGGL(k_solve, dim3(s->n_loaded), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_blob_off, s->d_ws, s->d_ws_off, ko, s->d_reports, dbg);
     HIPCHK(s, hipGetLastError());
     HIPCHK(s, hipEventRecord(s->ev1, s->stream));
     if (!wait) return UVS_OK;
@@ -1284,8 +1298,13 @@ int uvs_debug_first_iteration(uvs_solver* s, const uvs_window* w, double* S_lowe
     const uvs_window* arr[1] = {w};
     int rc = uvs_batch_upload(s, 1, arr);
     if (rc != UVS_OK) return rc;
-    rc = launch_solve(s, std::getenv("UVS_DEBUG_GATHER_TIMERS") ? 2 : std::getenv("UVS_DEBUG_ASM_TIMERS") ? 3 : std::getenv("UVS_DEBUG_CHOL_TIMELINE") ? 4 : 1, nullptr);      // 2 / 3: the four per-wave timer slots carry the gather / the assembly's sub-steps instead of the Cholesky column phase
+    const char* tl_path = std::getenv("UVS_DEBUG_LIN_TIMELINE");      // debug: (stamp, clock) log of every wave's steps through the linearizations of this solve, written to this file
+    rc = launch_solve(s, tl_path ? 5 : std::getenv("UVS_DEBUG_GATHER_TIMERS") ? 2 : std::getenv("UVS_DEBUG_ASM_TIMERS") ? 3 : std::getenv("UVS_DEBUG_CHOL_TIMELINE") ? 4 : 1, nullptr);      // 2 / 3: the four per-wave timer slots carry the gather / the assembly's sub-steps instead of the Cholesky column phase
     if (rc != UVS_OK) return rc;
+    if (tl_path) {
+        std::vector<long long> tl(8 * TL_PER_WAVE * 2);
+        if ((s->ksolve_nt == 512 ? uvs_k_solve512_timeline(tl.data(), tl.size()) == UVS_OK : hipMemcpyFromSymbol(tl.data(), HIP_SYMBOL(g_lin_tl), tl.size() * 8) == hipSuccess)) { if (FILE* f = std::fopen(tl_path, "wb")) { std::fwrite(tl.data(), 8, tl.size(), f); std::fclose(f); } }
+    }
     const size_t nS = (size_t)UVS_RD * UVS_RD;
     if (S_lower) HIPCHK(s, hipMemcpy(S_lower, s->d_dbg, nS * 8, hipMemcpyDeviceToHost));
     if (g) HIPCHK(s, hipMemcpy(g, s->d_dbg + nS, UVS_RD * 8, hipMemcpyDeviceToHost));
