@@ -44,6 +44,20 @@ static constexpr int EW = ET / 64;                // evaluator waves
 static constexpr int GT0 = NT - UVS_GT;           // first gatherer thread (0: every thread is both)
 UVS_DEV int wave_uniform() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 UVS_DEV bool role_eval() { return !ROLES || wave_uniform() < EW; }
+// Lane order of the LINE loop of the back substitution, which walks points and lines one after the other with one lane per landmark.  A window has fewer
+// points / lines than the 512-thread build has lanes, so both families would sit on the low waves and run back to back; started at wave 4, the lines run
+// beside the points: 269 k -> 178 k cycles per solve.  (The cost pass keeps its lines on the low waves: its last wave carries the raw IMU residuals, and with
+// the lines on waves 4..7 as well that wave became the longest -- measured, observations + IMU 121 k -> 143 k cycles per solve.)
+#ifndef UVS_X_NO_LINE_ROTATE
+UVS_DEV int line_lane() { return ROLES ? (lane_tid() ^ 256) : lane_tid(); }
+#else
+UVS_DEV int line_lane() { return lane_tid(); }
+#endif
+#ifdef UVS_X_COST_LINE_ROTATE
+#define UVS_COST_LINE_LANE line_lane()
+#else
+#define UVS_COST_LINE_LANE tid
+#endif
 // Loads in flight per lane.  One wave per SIMD (NT = 256) hides memory latency only with its own independent loads, so the streaming loops batch
 // several observations per lane; with two resident waves per SIMD (NT = 512) the other wave covers the latency and the batches shrink to what
 // fits 256 registers per lane.
@@ -395,7 +409,7 @@ UVS_DEV double cost_pass(const Ctx& c, const double* x, const double* invd, cons
         }
     }
     // lines + vp, two per batch
-    for (int o0 = lo0 + tid; o0 < lo1; o0 += LB * NT) {
+    for (int o0 = lo0 + UVS_COST_LINE_LANE; o0 < lo1; o0 += LB * NT) {
         int lm[LB], fj[LB], hv[LB]; bool in[LB];
         double ms[LB][9], lp[LB][4] = {}, tg[LB][8];
         const int st = h.ln_stride;
@@ -1273,8 +1287,8 @@ UVS_DEV void gather_lines(int grp, const int* lists, const double* S0, GAcc& A, 
 static constexpr int IMU_JLD = 48;                       // row stride of Jaug / T in LDS (16 rows; 48 = 16 mod 32: no bank conflicts between k-groups)
 static constexpr int IMU_WOFF = 16 * IMU_JLD;            // W as [16][17] after the operand tile
 static constexpr int IMU_BLK = IMU_WOFF + UVS_BLK_SZ;    // 1040 doubles of LDS staging per block
-static constexpr int IMU_SLOTS = (UVS_NF - 1 + EW - 1) / EW;   // IMU blocks per evaluator wave (block b -> wave b % EW, slot b / EW)
-struct ImuN { d4_t n00[IMU_SLOTS], n10[IMU_SLOTS], n11[IMU_SLOTS]; };
+static constexpr int IMU_SLOTS = (UVS_NF - 1 + NW - 1) / NW;   // IMU blocks per wave (block b -> wave b % NW, slot b / NW): the MFMA stages and the tile adds use ALL waves (the staging before them only the evaluators)
+struct ImuN { d4_t n00[IMU_SLOTS], n10[IMU_SLOTS], n11[IMU_SLOTS]; int fi[IMU_SLOTS]; bool act[IMU_SLOTS]; };      // fi / act: first frame of the wave's blocks, block present (asm_imu)
 
 // rotations of the evaluation point + prior residual (L_PR); returns this lane's share of the prior cost
 // mode 0: everything.  The persistent kernel knows more: after an ACCEPTED step (mode 1) x is the candidate the cost pass has just
@@ -1296,11 +1310,12 @@ UVS_DEV double lin_prep(const Ctx& c, const double* x, int mode = 0) {
 }
 // IMU normal-equation tiles; staged in the S region, so it runs when no landmark chunk is staged there (after the last gather,
 // right before the assembly: the 9 accumulator tiles per wave then live only across lin_assemble)
-UVS_DEV double lin_imu(const Ctx& c, const double* x, ImuN& N) {
+// lin_imu_stage: W + raw residuals / Jacobians -> the operand tiles in LDS (evaluator waves; THREE workgroup barriers, the last one at its end);
+// lin_imu_tiles: the MFMA stages of this wave's blocks (every wave), returns this lane's cost share
+UVS_DEV void lin_imu_stage(const Ctx& c, const double* x) {
     const DevWin& h = *c.hdr;
     double* sh = c.sh;
-    const int tid = lane_tid(), lane = tid & 63, wv = tid >> 6, li = lane & 15, lk = lane >> 4;
-    double cost = 0.0;
+    const int tid = lane_tid(), lane = tid & 63, wv = tid >> 6;
     __syncthreads();      // previous users of the S region are done
     UVS_PROF(c, P_GATHER);
     double* IM = sh + L_S;
@@ -1314,7 +1329,9 @@ UVS_DEV double lin_imu(const Ctx& c, const double* x, ImuN& N) {
         wreg[q] = c.bd[h.d_imu + (size_t)b * UVS_IMU_STRIDE + UVS_IMU_W + e];
     }
     for (int t = tid; t < h.n_imu * IMU_BLK; t += ET) IM[t] = 0.0;      // operand tiles are mostly structural zeros
+    UVS_TLOG(c, 40);
     __syncthreads();
+    UVS_TLOG(c, 41);
     // raw residual + Jacobian of block `lane`, its four Jacobian groups on four different waves (one lane doing all of it was a 10 k-cycle
     // serial chain with 246 lanes idle; divergent parts inside one wave would serialise just the same)
     if (lane < h.n_imu && wv < 4 && !c.bi[h.i_imu + 2 * lane + 1]) {
@@ -1334,13 +1351,23 @@ UVS_DEV double lin_imu(const Ctx& c, const double* x, ImuN& N) {
         const int t = tid + q * ET;
         if (t < h.n_imu * 225) { const int b = t / 225, e = t - 225 * b, i = e / 15, k = e - 15 * i; IM[IMU_BLK * b + IMU_WOFF + i * UVS_BLK_LD + k] = wreg[q]; }
     }
+    UVS_TLOG(c, 42);
     __syncthreads();
+    UVS_TLOG(c, 43);
+}
+UVS_DEV double lin_imu_tiles(const Ctx& c, ImuN& N) {
+    const DevWin& h = *c.hdr;
+    double* sh = c.sh;
+    const int tid = lane_tid(), lane = tid & 63, wv = tid >> 6, li = lane & 15, lk = lane >> 4;
+    double cost = 0.0;
+    double* IM = sh + L_S;
     // stage 1 for all of this wave's blocks, ONE wave-level hand-over, then stage 2: the LDS round trips and MFMA drains of the slots overlap
     bool act[IMU_SLOTS];
 #pragma unroll
     for (int s = 0; s < IMU_SLOTS; ++s) {
-        const int b = wv + s * EW;
+        const int b = wv + s * NW;
         act[s] = b < h.n_imu && !c.bi[h.i_imu + 2 * (b < h.n_imu ? b : 0) + 1];
+        N.act[s] = act[s]; N.fi[s] = c.bi[h.i_imu + 2 * (b < h.n_imu ? b : 0)];
         if (act[s]) {
             double* Jb = IM + IMU_BLK * b; const double* Wb = Jb + IMU_WOFF;
             d4_t t0 = {0.0, 0.0, 0.0, 0.0}, t1 = t0;
@@ -1357,7 +1384,7 @@ UVS_DEV double lin_imu(const Ctx& c, const double* x, ImuN& N) {
     wave_sync();
 #pragma unroll
     for (int s = 0; s < IMU_SLOTS; ++s) {
-        const int b = wv + s * EW;
+        const int b = wv + s * NW;
         d4_t n00 = {0.0, 0.0, 0.0, 0.0}, n10 = n00, n11 = n00;
         if (act[s]) {
             const double* Jb = IM + IMU_BLK * b;
@@ -1377,6 +1404,7 @@ UVS_DEV double lin_imu(const Ctx& c, const double* x, ImuN& N) {
     UVS_PROF(c, P_AS_IMU);
     return cost;
 }
+UVS_DEV double lin_imu(const Ctx& c, const double* x, ImuN& N) { lin_imu_stage(c, x); return lin_imu_tiles(c, N); }
 UVS_DEV double lin_frames(const Ctx& c, const double* x, ImuN& N) { const double pc = lin_prep(c, x); return pc + lin_imu(c, x, N); }
 
 // Inverse of a damped 4 x 4 line block (lower packed H) through its Cholesky factor, written to X[4][4] (may be LDS), and hg = H^-1 g.
@@ -2011,15 +2039,14 @@ UVS_DEV void asm_imu(const Ctx& c, const ImuN& N) {
     const int lane = tid & 63, wv = tid >> 6, li = lane & 15, lk = lane >> 4;
     int fis[IMU_SLOTS]; bool act[IMU_SLOTS];
 #pragma unroll
-    for (int s = 0; s < IMU_SLOTS; ++s) {      // block table fetched once (HBM/L2 latency), not once per pass
-        const int b = wv + s * EW;
-        act[s] = wv < EW && b < h.n_imu && !c.bi[h.i_imu + 2 * (b < h.n_imu ? b : 0) + 1] && li < 15;
-        fis[s] = c.bi[h.i_imu + 2 * (b < h.n_imu ? b : 0)];
+    for (int s = 0; s < IMU_SLOTS; ++s) {      // (the block table came with the tiles: lin_imu)
+        act[s] = N.act[s] && li < 15;
+        fis[s] = N.fi[s];
     }
     for (int par = 0; par < 2; ++par) {
 #pragma unroll
         for (int s = 0; s < IMU_SLOTS; ++s) {
-            const int b = wv + s * EW;
+            const int b = wv + s * NW;
             if (act[s] && (b & 1) == par) {
                 const int fi = fis[s], fj = fi + 1;
                 // C layout: row = lk + 4q, col = li.  Rows < 15 go to S (lower triangles of the diagonal tiles), row 15 is J^T r.
@@ -2080,6 +2107,44 @@ UVS_DEV void asm_prior(const Ctx& c) {
         }
         if (tid < n && cm[tid] >= 0) sh[L_G + cm[tid]] += c.ws[h.w_prior_h0 + UVS_PH_G0(n) + tid] + sh[L_PR + tid];      // one writer per S index (the IMU adds ended with a barrier)
     }
+}
+// The same in two halves (512-thread build): everything asm_prior reads from global memory -- two dependent round trips, table then H0 entry -- is requested
+// BEFORE the image is zeroed and crosses the zero / landmark / IMU steps of the assembly in registers; the adds then only touch LDS.
+static constexpr int PA_UN = 8;      // entries per lane held ahead (the 10-frame prior has ~2.6 k structural entries: 6 per lane)
+struct PriorAdd { int idx[PA_UN]; double v[PA_UN]; double hd, g; int cmi; };
+UVS_DEV void asm_prior_load(const Ctx& c, PriorAdd& pa) {
+    const DevWin& h = *c.hdr; const int tid = lane_tid();
+    pa.hd = 0.0; pa.g = 0.0; pa.cmi = -1;
+#pragma unroll
+    for (int u = 0; u < PA_UN; ++u) { pa.idx[u] = -1; pa.v[u] = 0.0; }
+    if (h.prior_n <= 0) return;
+    const int n = h.prior_n, tot = h.n_cimg;
+    const double* H0 = c.ws + h.w_prior_h0;
+    const int* src = c.bi + h.i_cimg; const int* off = src + tot;
+    int sr[PA_UN];
+#pragma unroll
+    for (int u = 0; u < PA_UN; ++u) { const int t = tid + u * NT; const bool in = t < tot; pa.idx[u] = in ? off[t] : -1; sr[u] = in ? src[t] : 0; }
+#pragma unroll
+    for (int u = 0; u < PA_UN; ++u) pa.v[u] = H0[sr[u]];
+    if (tid < UVS_RD) pa.hd = c.ws[h.w_prior_h0 + UVS_PH_HD(n) + tid];
+    if (tid < n) { pa.cmi = c.bi[h.i_prior + 80 + tid]; pa.g = c.ws[h.w_prior_h0 + UVS_PH_G0(n) + tid]; }
+}
+UVS_DEV void asm_prior_add(const Ctx& c, const PriorAdd& pa) {
+    const DevWin& h = *c.hdr; double* sh = c.sh; const int tid = lane_tid();
+    if (h.prior_n <= 0) return;
+    double cur[PA_UN];
+#pragma unroll
+    for (int u = 0; u < PA_UN; ++u) cur[u] = sh[L_S + (pa.idx[u] >= 0 ? pa.idx[u] : 0)];
+#pragma unroll
+    for (int u = 0; u < PA_UN; ++u) if (pa.idx[u] >= 0) sh[L_S + pa.idx[u]] = cur[u] + pa.v[u];
+    {   // a prior with more structural entries than PA_UN per lane: the rest as in asm_prior
+        const double* H0 = c.ws + h.w_prior_h0;
+        const int tot = h.n_cimg;
+        const int* src = c.bi + h.i_cimg; const int* off = src + tot;
+        for (int t = tid + PA_UN * NT; t < tot; t += NT) sh[L_S + off[t]] += H0[src[t]];
+    }
+    if (tid < UVS_RD) sh[L_HD + tid] += pa.hd;
+    if (pa.cmi >= 0) sh[L_G + pa.cmi] += pa.g + sh[L_PR + tid];
 }
 // frame damping, Jacobi scaling (first linearization only), dummy pivots, projected-gradient max norm, the linearization's cost -> control words
 UVS_DEV void asm_finish(const Ctx& c, const double* x, bool first, double radius, double cost, double gmax_lm, int mode) {
@@ -2190,6 +2255,9 @@ UVS_DEV void linearize_roles(const Ctx& c, const double* x, const double* invd, 
     const bool ev = role_eval();
     { const double pc = lin_prep(c, x, redamp ? 2 : prep_mode); if (!redamp) lacc_set(c.sh, pc, 0.0); }
     double ic = 0.0;
+    UVS_TLOG(c, 20);
+    PriorAdd pa;
+    ImuN N;
     if (GALL) {
         const int grp = gather_group(c);
         GAcc A;
@@ -2202,14 +2270,14 @@ UVS_DEV void linearize_roles(const Ctx& c, const double* x, const double* invd, 
         __syncthreads();
         if (h.redamp_ok && c.o.redamp) gacc_store(c, A);
         gacc_gather_parts(A, grp, c.sh + L_S);
-        ImuN N;
-        if (ev) ic = lin_imu(c, x, N); else role_barriers(3);
+        if (ev) lin_imu_stage(c, x); else role_barriers(3);
+        ic = lin_imu_tiles(c, N);
         __syncthreads();
         asm_zero(c);
         __syncthreads();
         asm_part0(c, grp, A);
         __syncthreads();
-        if (ev) asm_imu(c, N); else role_barriers(2);
+        asm_imu(c, N);
         asm_prior(c);
         __syncthreads();
         asm_finish(c, x, first && !redamp, radius, lacc_cost(c.sh) + ic, lacc_gmax(c.sh), 0);
@@ -2221,13 +2289,21 @@ UVS_DEV void linearize_roles(const Ctx& c, const double* x, const double* invd, 
             if (redamp) redamp_prep(c, d, radius); else chunk_eval(c, d, x, invd, line, first, radius);
             if (ch + 1 < h.n_chunks) d = chunk_desc(c, ch + 1);
         }
-        ImuN N;
-        ic = lin_imu(c, x, N);
+        UVS_TLOG(c, 21);
+        lin_imu_stage(c, x);
+        ic = lin_imu_tiles(c, N);
+        UVS_TLOG(c, 22);
+#ifndef UVS_X_NO_PRIOR_AHEAD
+        asm_prior_load(c, pa);
+#endif
         __syncthreads();
         asm_zero(c);
         __syncthreads();
+        UVS_TLOG(c, 23);
         __syncthreads();
+        UVS_TLOG(c, 24);
         asm_imu(c, N);
+        UVS_TLOG(c, 25);
     } else {
         const int grp = gather_group(c);
 #ifdef UVS_ROLES_KEEP_A
@@ -2251,16 +2327,26 @@ UVS_DEV void linearize_roles(const Ctx& c, const double* x, const double* invd, 
         GAcc& T = A;
 #endif
         gacc_gather_parts(T, grp, c.sh + L_S + ROLE_PARTS_OFF);
+        ic = lin_imu_tiles(c, N);      // (the operand tiles are complete since gacc_gather_parts' second barrier = the last one of lin_imu_stage)
+#ifndef UVS_X_NO_PRIOR_AHEAD
+        asm_prior_load(c, pa);
+#endif
         __syncthreads();
         asm_zero(c);
         __syncthreads();
         asm_part0(c, grp, T);
         __syncthreads();
-        role_barriers(2);
+        asm_imu(c, N);
     }
+#ifndef UVS_X_NO_PRIOR_AHEAD
+    asm_prior_add(c, pa);
+#else
     asm_prior(c);
+#endif
     __syncthreads();
+    UVS_TLOG(c, 26);
     asm_finish(c, x, first && !redamp, radius, lacc_cost(c.sh) + ic, lacc_gmax(c.sh), 0);
+    UVS_TLOG(c, 27);
 }
 
 // `A`: the gather accumulators, owned by the caller (k_solve keeps them in registers between a linearization and a possible re-damping)
@@ -2400,7 +2486,7 @@ UVS_DEV void backsub_candidate(const Ctx& c, const double* invd, const double* l
     // lines: delta(4) = -Hinv g - sum_s Y[s] delta_pose
     constexpr int LNB = LNBT;
     const int* lbeg = c.bi + h.i_ln_beg;
-    for (int k = lk0 + tid; k < lk1; k += NT) {
+    for (int k = lk0 + line_lane(); k < lk1; k += NT) {
         const int b0 = lbeg[k], b1 = lbeg[k + 1];
         const double* lx = c.ws + h.w_ln_x + UVS_LN_X * (size_t)k;
         double t[4] = {0.0, 0.0, 0.0, 0.0};
@@ -2674,13 +2760,17 @@ __global__ __launch_bounds__(NT) void k_solve(char* blobs, const long long* blob
             if (tid < UVS_RD) { dbg.g[tid] = sh[L_G + tid]; dbg.hd[tid] = sh[L_HD + tid]; dbg.dd[tid] = sh[L_DD + tid]; }
         }
         UVS_PROF(c, P_MISC);
+        UVS_TLOG(c, 30);
         chol_factor(c);
         UVS_PROF(c, P_CHOL);
+        UVS_TLOG(c, 31);
         chol_solve(c);
         UVS_PROF(c, P_TRSV);
+        UVS_TLOG(c, 32);
         bool ok = sh[L_CTRL + C_CHOLOK] != 0.0;
         backsub_candidate(c, invd[cur], line[cur], invd[cur ^ 1], line[cur ^ 1], 0, h.n_points, 0, h.n_lines, true, nullptr);
         UVS_PROF(c, P_BACKSUB);
+        UVS_TLOG(c, 33);
         const double mcc = sh[L_CTRL + C_MCC], step2 = sh[L_CTRL + C_STEP2], xc2 = sh[L_CTRL + C_XC2];
         if (o.debug && it == 1 && dbg.S) {
             if (tid < UVS_RD) dbg.step[tid] = sh[L_DLT + tid];
@@ -2703,11 +2793,15 @@ __global__ __launch_bounds__(NT) void k_solve(char* blobs, const long long* blob
         prior_dx(c, sh + L_XC);
         __syncthreads();
         if (o.debug == 1 && tid == 0) { const long long t_ = clock64(); sh[L_WPROF + 0] += (double)(t_ - tc_); tc_ = t_; }
+        UVS_TLOG(c, 34);
         double cc_ = prior_quad(c, L_PRC);
+        UVS_TLOG(c, 35);
         if (o.debug == 1 && tid == 0) { const long long t_ = clock64(); sh[L_WPROF + 1] += (double)(t_ - tc_); tc_ = t_; }
         cc_ += cost_pass(c, sh + L_XC, invd[cur ^ 1], line[cur ^ 1], 0, h.n_pt_obs, 0, h.n_ln_obs, true);
+        UVS_TLOG(c, 36);
         double s4[4] = {cc_, 0, 0, 0}, mx = 0.0;
         block_reduce(sh, s4, &mx);
+        UVS_TLOG(c, 37);
         UVS_PROF(c, P_COST);
         double cand = s4[0];
         if (!isfinite(cand)) cand = 1.7976931348623157e308;
