@@ -43,6 +43,8 @@
 #define UVS_PT_A 2
 #define UVS_PT_C 14
 #define UVS_PT_B 16
+#define UVS_PT_ENTRY_A 0x8000      // bit 15 of a DIRECT gather entry of a point chunk (the offsets use 15 bits): the entry is an observation's A^T A term, whose Schur-corrected residual
+                                   // is read from the record's rc slot (UVS_PT_RC2) at A + 26; every other diagonal entry finds it 12 doubles behind its first operand (B + 12 = rc slot)
 #define UVS_PT_RC2 28
 #define UVS_PT_TD 30               // d r / d td (2 doubles) + 2 zero pads: only in ESTIMATE_TD records (34 doubles)
 #define UVS_PT_REC_TD 34

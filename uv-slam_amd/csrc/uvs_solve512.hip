@@ -12,6 +12,7 @@
 #define UVS_NT 512
 #define UVS_ALLOW_EXPERIMENTAL_NT 1
 #define UVS_SOLVE_KERNEL_ONLY 1
+#define UVS_CHUNK_TOUCH 1
 #define uvsdev uvsdev512
 #include "uvs_solve_kernel.h"
 

@@ -67,6 +67,7 @@ UVS_DEV int line_lane() { return lane_tid(); }
 #define UVS_T_BS_LNB 4
 #define UVS_T_PR_UN 26
 #endif
+static_assert(UVS_PT_C == UVS_PT_A + 12, "pt_anchor_pass reads A and c as one run");
 static constexpr int CP_PB = NT > 256 ? UVS_T_CP_PB : 4;      // cost pass: point observations per batch
 static constexpr int CP_LB = NT > 256 ? UVS_T_CP_LB : 2;      // cost pass: line observations per batch
 static constexpr int BS_LNB = NT > 256 ? UVS_T_BS_LNB : 4;     // back substitution: line observations per batch
@@ -1150,7 +1151,7 @@ UVS_DEV void gather_points(int grp, const int* lists, const double* S0, GAcc& A,
     const bool tdg = EXT && on && ((grp >> 13) & 15) == UVS_NF;       // block row of the time offset: J1 = (J_td[0], J_td[1]) adjacent, residual 16 doubles below
     const bool exg = EXT && exrows && on && ((grp >> 13) & 15) == UVS_NF + 1;   // block rows of the camera extrinsic: J1 = the 2 x 6 J_ex block of the record
     const bool tdcol = exg && ((grp >> 17) & 15) == UVS_NF;           // (ex, td): J2 is the adjacent J_td pair and only column 0 is real
-    const int p1off = tdg ? 1 : 6, rcoff = tdg ? UVS_PT_C - UVS_PT_TD : exg ? UVS_PT_C - UVS_PT_EX : 12;
+    const int p1off = tdg ? 1 : 6, rcoff = tdg ? UVS_PT_RC2 - UVS_PT_TD : exg ? UVS_PT_RC2 - UVS_PT_EX : 12;      // the corrected residual is read where pass B left it (the record's rc slot)
     const bool dirv = !(tdg && diag) && !tdcol;                 // (td, td): the direct term is the scalar J_td . J_td = the hd accumulator
     const int* ent = lists + LIST_HDR;
     // ---- Schur: acc[r][c] -= E_a[r0 + r] * Einv_b[c], two entries per stage
@@ -1199,7 +1200,7 @@ UVS_DEV void gather_points(int grp, const int* lists, const double* S0, GAcc& A,
                 for (int r = 0; r < GR; ++r) { o.p0[r] = pa[r]; o.p1[r] = pa[p1off + r]; }
 #pragma unroll
                 for (int k = 0; k < 3; ++k) { o.q0[k] = lds2(pb + 2 * k); o.q1[k] = lds2(pb + 6 + 2 * k); }
-                o.rc = lds2(S0 + lo + rcoff);
+                o.rc = lds2(S0 + lo + ((w[0] & UVS_PT_ENTRY_A) ? UVS_PT_RC2 - UVS_PT_A : rcoff));
             },
             [&](int, Ops& o) {
 #pragma unroll
@@ -1437,9 +1438,16 @@ UVS_DEV void spd4_inverse(const double* H, const double* gl, double* X, double* 
 }
 
 // ---- linearization, part 2: one landmark chunk: stage -> per-landmark Schur prep -> list-driven gather into acc[]
-// The evaluation half (observation passes, per-landmark Schur preparation, the chunk's lists -> staging area; FOUR workgroup barriers, the first before
+// The evaluation half (observation passes, per-landmark Schur preparation, the chunk's lists -> staging area; chunk_eval_barriers() workgroup barriers -- three for a point chunk, four for a line chunk --, the first before
 // anything is written) and the gather half (no barrier).  In the 256-thread build every thread runs both, one after the other (lin_chunk); in the
 // 512-thread build the evaluator waves run the first and the gatherer waves the second behind four barriers of their own (linearize).
+// 512-thread build: the gatherer waves copy a chunk's lists into the staging area themselves, between the entry barrier and the three that follow (they have
+// nothing else to do while the evaluators run passes A / B, and the evaluators' own loads no longer queue behind the list words)
+#ifndef UVS_X_NO_LISTS_BY_GATHERERS
+static constexpr bool LISTS_BY_GATHERERS = ROLES && !(UVS_GT == NT);
+#else
+static constexpr bool LISTS_BY_GATHERERS = false;
+#endif
 struct ChunkDesc { int type, k0, k1, o0, nob, nlm, nlist; const int* glists; };
 UVS_DEV ChunkDesc chunk_desc(const Ctx& c, int ch) {
     const DevWin& h = *c.hdr;
@@ -1458,6 +1466,146 @@ UVS_DEV int* chunk_lists(const Ctx& c, const ChunkDesc& d) {
     double* rec = c.sh + L_S;
     if (d.type == 0) return (int*)(rec + (size_t)d.nob * h.pt_rec + (size_t)(d.nob + h.pt_xslots * d.nlm) * 12);
     return (int*)(rec + (size_t)d.nob * (UVS_LN_REC + 2 * UVS_LN_EY) + 20 * d.nlm);
+}
+// What the landmark as a whole contributes to a staged point chunk, beside its observations' own slots: the scalars of the back substitution, the anchor-frame
+// slot E_0 = sum_o c_o A_o (and the time-offset / extrinsic slots).  One lane per landmark: the lane of its first observation in the 256-thread build, a lane of
+// the otherwise idle gatherer waves in the 512-thread build (pt_anchor_pass).
+UVS_DEV void pt_landmark_slots(const Ctx& c, const ChunkDesc& d, int k, int b0, int b1, double hd, double gl, double dd, double hinv, double ginv, double* gmax_lm) {
+    const DevWin& h = *c.hdr;
+    const int PREC = h.pt_rec, XS = h.pt_xslots, li = k - d.k0;
+    double* rec = c.sh + L_S;
+    double* Eb = rec + (size_t)d.nob * PREC;
+    double* EIb = Eb + (size_t)(d.nob + XS * d.nlm) * 6;
+    double* E = Eb + (size_t)(b0 + XS * li) * 6; double* EI = EIb + (size_t)(b0 + XS * li) * 6;
+    double* Eg = c.ws + h.w_pt_E + 6 * (size_t)(d.o0 + b0 + XS * k);
+        double* px = c.ws + h.w_pt_x + 4 * (size_t)k; px[0] = ginv; px[1] = gl; px[2] = dd; px[3] = hd;
+        *gmax_lm = fmax(*gmax_lm, fabs(gl));
+        double e0[6] = {0, 0, 0, 0, 0, 0}, etd = 0.0;
+        for (int o = b0; o < b1; ++o) {
+            const double* Ro = rec + (size_t)o * PREC;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) e0[a] += Ro[UVS_PT_C] * Ro[UVS_PT_A + a] + Ro[UVS_PT_C + 1] * Ro[UVS_PT_A + 6 + a];
+            if (h.td_on) etd += Ro[UVS_PT_C] * Ro[UVS_PT_TD] + Ro[UVS_PT_C + 1] * Ro[UVS_PT_TD + 1];
+        }
+#pragma unroll
+        for (int a = 0; a < 6; ++a) { E[a] = e0[a]; EI[a] = e0[a] * hinv; Eg[a] = e0[a] * hinv; }
+        if (h.td_on) {      // slot after the observations: the time-offset "row" J_l^T J_td (a 6-vector whose first entry is the only real one)
+            const int st_ = 6 * (b1 - b0 + 1);
+#pragma unroll
+            for (int a = 0; a < 6; ++a) { const double e = a == 0 ? etd : 0.0; E[st_ + a] = e; EI[st_ + a] = e * hinv; Eg[st_ + a] = e * hinv; }
+        }
+        if (h.ex_on) {      // last slot: the extrinsic row J_l^T J_ex
+            double ex6[6] = {0, 0, 0, 0, 0, 0};
+            for (int o = b0; o < b1; ++o) {
+                const double* Ro = rec + (size_t)o * PREC;
+#pragma unroll
+                for (int a = 0; a < 6; ++a) ex6[a] += Ro[UVS_PT_C] * Ro[UVS_PT_EX + a] + Ro[UVS_PT_C + 1] * Ro[UVS_PT_EX + 6 + a];
+            }
+            const int st_ = 6 * (b1 - b0 + 1 + (h.td_on ? 1 : 0));
+#pragma unroll
+            for (int a = 0; a < 6; ++a) { E[st_ + a] = ex6[a]; EI[st_ + a] = ex6[a] * hinv; Eg[st_ + a] = ex6[a] * hinv; }
+        }
+}
+// hd = sum c^2, gl = sum c . r over the observations [b0, b1) of a landmark (every lane that needs them runs this same loop: identical values)
+UVS_DEV void pt_landmark_hd_gl(const double* rec, int PREC, int b0, int b1, double* hd_, double* gl_) {
+    double hd = 0.0, gl = 0.0;
+    for (int o = b0; o < b1; ++o) { const double* R = rec + (size_t)o * PREC; hd += R[UVS_PT_C] * R[UVS_PT_C] + R[UVS_PT_C + 1] * R[UVS_PT_C + 1]; gl += R[UVS_PT_C] * R[0] + R[UVS_PT_C + 1] * R[1]; }
+    *hd_ = hd; *gl_ = gl;
+}
+#ifndef UVS_X_NO_ANCHOR_BY_GATHERERS
+static constexpr bool ANCHOR_BY_GATHERERS = ROLES && !(UVS_GT == NT);
+#else
+static constexpr bool ANCHOR_BY_GATHERERS = false;
+#endif
+// 512-thread build, gatherer waves, between the second and the third barrier of a point chunk (beside pass B): one lane per landmark
+UVS_DEV void pt_anchor_pass(const Ctx& c, const ChunkDesc& d, bool first, double radius) {
+    const DevWin& h = *c.hdr;
+    const int* beg = c.bi + h.i_pt_beg;
+    const double* rec = c.sh + L_S;
+    double gmax_lm = 0.0;
+    for (int li = lane_tid() - GT0; li < d.nlm; li += UVS_GT) {
+        const int k = d.k0 + li, b0 = beg[k] - d.o0, b1 = beg[k + 1] - d.o0;
+        const double sc_old = first ? 1.0 : c.ws[h.w_scale_pt + k];      // (requested with the CSR range, used after the loop)
+        if (b1 <= b0) continue;
+        if (h.td_on | h.ex_on) {
+            double hd, gl; pt_landmark_hd_gl(rec, h.pt_rec, b0, b1, &hd, &gl);
+            double sc;
+            if (first) { sc = c.o.jacobi ? 1.0 / (1.0 + sqrt(hd)) : 1.0; c.ws[h.w_scale_pt + k] = sc; } else sc = sc_old;
+            const double dd = fmin(fmax(sc * sc * hd, c.o.dlo), c.o.dhi) / (radius * sc * sc);
+            const double hinv = 1.0 / (hd + dd), ginv = gl * hinv;
+            pt_landmark_slots(c, d, k, b0, b1, hd, gl, dd, hinv, ginv, &gmax_lm);
+            continue;
+        }
+        // the usual window (no pseudo-frame slots): h_ll, g_l and the anchor slot in ONE walk over the landmark's records (the same sums in the same order as
+        // pt_landmark_hd_gl / pt_landmark_slots; half the dependent LDS round trips)
+        const int PREC = h.pt_rec;
+        double hd = 0.0, gl = 0.0, e0[6] = {0, 0, 0, 0, 0, 0};
+        for (int o = b0; o < b1; o += 2) {      // two records per trip: their 32 LDS reads are one round trip (the sums still take the records in order)
+            const double* R = rec + (size_t)o * PREC;
+            const bool two = o + 1 < b1;
+            const double* R2 = two ? R + PREC : R;
+            double v[16], w[16];
+            v[0] = R[0]; v[1] = R[1]; w[0] = R2[0]; w[1] = R2[1];
+#pragma unroll
+            for (int a = 0; a < 14; ++a) { v[2 + a] = R[UVS_PT_A + a]; w[2 + a] = R2[UVS_PT_A + a]; }      // A[12] then c[2] (UVS_PT_C = UVS_PT_A + 12)
+            {
+                const double c0 = v[14], c1 = v[15];
+                hd += c0 * c0 + c1 * c1; gl += c0 * v[0] + c1 * v[1];
+#pragma unroll
+                for (int a = 0; a < 6; ++a) e0[a] += c0 * v[2 + a] + c1 * v[8 + a];
+            }
+            if (two) {
+                const double c0 = w[14], c1 = w[15];
+                hd += c0 * c0 + c1 * c1; gl += c0 * w[0] + c1 * w[1];
+#pragma unroll
+                for (int a = 0; a < 6; ++a) e0[a] += c0 * w[2 + a] + c1 * w[8 + a];
+            }
+        }
+        double sc;
+        if (first) { sc = c.o.jacobi ? 1.0 / (1.0 + sqrt(hd)) : 1.0; c.ws[h.w_scale_pt + k] = sc; } else sc = sc_old;
+        const double dd = fmin(fmax(sc * sc * hd, c.o.dlo), c.o.dhi) / (radius * sc * sc);
+        const double hinv = 1.0 / (hd + dd), ginv = gl * hinv;
+        double* px = c.ws + h.w_pt_x + 4 * (size_t)k; px[0] = ginv; px[1] = gl; px[2] = dd; px[3] = hd;
+        gmax_lm = fmax(gmax_lm, fabs(gl));
+        double* Eb = c.sh + L_S + (size_t)d.nob * PREC;
+        double* E = Eb + (size_t)(b0 + li) * 6; double* EI = E + (size_t)(d.nob + d.nlm) * 6;
+        double* Eg = c.ws + h.w_pt_E + 6 * (size_t)(d.o0 + b0 + k);
+#pragma unroll
+        for (int a = 0; a < 6; ++a) { E[a] = e0[a]; EI[a] = e0[a] * hinv; Eg[a] = e0[a] * hinv; }
+    }
+    lacc_add(c.sh, 0.0, gmax_lm);
+}
+// 512-thread build: while the gatherer waves walk chunk t, an evaluator lane READS what passes A / B of chunk t + 1 will want from global memory for its first
+// observation (index words, measurements, the landmark's parameters, CSR range and scale) and throws it away: the lines then sit in the compute unit's vector
+// L1, which nothing else uses during a gather walk (LDS traffic only), and the dependent loads at the head of the next passes hit there instead of in L2.
+UVS_DEV void chunk_touch(const Ctx& c, const ChunkDesc& d, const double* invd, const double* line) {
+    const DevWin& h = *c.hdr;
+    const int tid = lane_tid();
+    if (tid >= d.nob) return;
+    const int o = d.o0 + tid;
+    double acc = 0.0; int iacc = 0;
+    if (d.type == 0) {
+        const int lm = c.bi[h.i_pt_lm + o]; iacc = c.bi[h.i_pt_fi + o] + c.bi[h.i_pt_fj + o];
+        const double* m = c.bd + h.d_ptmeas + o; const int st = h.pt_stride;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) acc += m[q * st];
+        acc += invd[lm] + c.ws[h.w_scale_pt + lm];
+        iacc += c.bi[h.i_pt_beg + lm] + c.bi[h.i_pt_beg + lm + 1];
+    } else {
+        const int lm = c.bi[h.i_ln_lm + o]; iacc = c.bi[h.i_ln_fj + o] + c.bi[h.i_ln_vp + o];
+        const double* m = c.bd + h.d_lnmeas + o; const int st = h.ln_stride;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) acc += m[q * st];
+        const double* ltrig = line_trig_of(c, line);
+        if (ltrig) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc += ltrig[8 * lm + q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc += line[4 * lm + q];
+        }
+    }
+    asm volatile("" :: "v"(acc), "v"(iacc));
 }
 UVS_DEV void chunk_eval(const Ctx& c, const ChunkDesc& d, const double* x, const double* invd, const double* line, bool first, double radius) {
     const DevWin& h = *c.hdr;
@@ -1482,7 +1630,7 @@ UVS_DEV void chunk_eval(const Ctx& c, const ChunkDesc& d, const double* x, const
             double* Eb = rec + (size_t)nob * PREC;                   // [(nob + XS * nlm)][6]   slots per landmark: anchor, observations, (td)
             double* EIb = Eb + (size_t)(nob + XS * nlm) * 6;         // [(nob + XS * nlm)][6]  Einv = E / h_ll
             int* lists = (int*)(EIb + (size_t)(nob + XS * nlm) * 6); // gather lists staged in LDS (one HBM latency per chunk)
-            for (int t = tid; t < nlist; t += ET) lists[t] = glists[t];
+            if (!LISTS_BY_GATHERERS) for (int t = tid; t < nlist; t += ET) lists[t] = glists[t];
             // pass A: one lane per observation
             for (int o = o0 + tid; o < o1; o += ET) {
                 const int lm = c.bi[h.i_pt_lm + o], fi = c.bi[h.i_pt_fi + o], fj = c.bi[h.i_pt_fj + o];
@@ -1496,7 +1644,7 @@ UVS_DEV void chunk_eval(const Ctx& c, const ChunkDesc& d, const double* x, const
                 R[0] = sc * r[0]; R[1] = sc * r[1];
 #pragma unroll
                 for (int q = 0; q < 12; ++q) { R[UVS_PT_A + q] = sc * A[q]; R[UVS_PT_B + q] = sc * B[q]; }
-                R[UVS_PT_C] = sc * cl[0]; R[UVS_PT_C + 1] = sc * cl[1];      // d r / d lambda; replaced by the corrected residual in pass B
+                R[UVS_PT_C] = sc * cl[0]; R[UVS_PT_C + 1] = sc * cl[1];      // d r / d lambda (the Schur-corrected residual goes to its own slot in pass B)
                 if (h.td_on || h.ex_on) { R[UVS_PT_TD] = sc * jtd[0]; R[UVS_PT_TD + 1] = sc * jtd[1]; R[UVS_PT_TD + 2] = 0.0; R[UVS_PT_TD + 3] = 0.0; }
                 if (h.ex_on) {      // ESTIMATE_EXTRINSIC only: the 2 x 6 block d r / d ex_pose from a second evaluation, in its own scope so that the
                                     // default path keeps its register footprint (the kernel sits at the 512-register cap)
@@ -1512,14 +1660,13 @@ UVS_DEV void chunk_eval(const Ctx& c, const ChunkDesc& d, const double* x, const
             UVS_TLOG(c, 4);
             // pass B: one lane per observation (its landmark's h_ll / g_l are recomputed per lane, cheap);
             // the lane of a landmark's first observation also owns the anchor slot and the per-landmark scalars.
-            // Reads of the d r/d lambda columns happen before the barrier, the corrected residuals overwrite them after it.
+            // The corrected residual goes to the record's own rc slot (UVS_PT_RC2); the d r / d lambda columns other lanes of the landmark still read stay as they are.
             for (int ol = tid; ol < nob; ol += ET) {
                 const int k = c.bi[h.i_pt_lm + o0 + ol], li = k - k0, b0 = beg[k] - o0, b1 = beg[k + 1] - o0;
-                double hd = 0.0, gl = 0.0;
-                for (int o = b0; o < b1; ++o) { const double* R = rec + (size_t)o * PREC; hd += R[UVS_PT_C] * R[UVS_PT_C] + R[UVS_PT_C + 1] * R[UVS_PT_C + 1]; gl += R[UVS_PT_C] * R[0] + R[UVS_PT_C + 1] * R[1]; }
+                double hd, gl; pt_landmark_hd_gl(rec, PREC, b0, b1, &hd, &gl);
                 const bool lead = ol == b0;
                 double sc;
-                if (first) { sc = c.o.jacobi ? 1.0 / (1.0 + sqrt(hd)) : 1.0; if (lead) c.ws[h.w_scale_pt + k] = sc; } else sc = c.ws[h.w_scale_pt + k];
+                if (first) { sc = c.o.jacobi ? 1.0 / (1.0 + sqrt(hd)) : 1.0; if (lead && !ANCHOR_BY_GATHERERS) c.ws[h.w_scale_pt + k] = sc; } else sc = c.ws[h.w_scale_pt + k];
                 const double dd = fmin(fmax(sc * sc * hd, c.o.dlo), c.o.dhi) / (radius * sc * sc);
                 const double hinv = 1.0 / (hd + dd), ginv = gl * hinv;
                 const int s = ol - b0 + 1;
@@ -1533,40 +1680,9 @@ UVS_DEV void chunk_eval(const Ctx& c, const ChunkDesc& d, const double* x, const
 #pragma unroll
                 for (int a = 0; a < 6; ++a) { const double e = c0 * Bv[a] + c1 * Bv[6 + a]; E[6 * s + a] = e; EI[6 * s + a] = e * hinv; Eg[6 * s + a] = e * hinv; }
                 R[UVS_PT_RC2] = rr0 - c0 * ginv; R[UVS_PT_RC2 + 1] = rr1 - c1 * ginv;       // rc = r - J_l h^-1 g_l (slot nobody reads in this pass)
-                if (lead) {
-                    double* px = c.ws + h.w_pt_x + 4 * (size_t)k; px[0] = ginv; px[1] = gl; px[2] = dd; px[3] = hd;
-                    gmax_lm = fmax(gmax_lm, fabs(gl));
-                    double e0[6] = {0, 0, 0, 0, 0, 0}, etd = 0.0;
-                    for (int o = b0; o < b1; ++o) {
-                        const double* Ro = rec + (size_t)o * PREC;
-#pragma unroll
-                        for (int a = 0; a < 6; ++a) e0[a] += Ro[UVS_PT_C] * Ro[UVS_PT_A + a] + Ro[UVS_PT_C + 1] * Ro[UVS_PT_A + 6 + a];
-                        if (h.td_on) etd += Ro[UVS_PT_C] * Ro[UVS_PT_TD] + Ro[UVS_PT_C + 1] * Ro[UVS_PT_TD + 1];
-                    }
-#pragma unroll
-                    for (int a = 0; a < 6; ++a) { E[a] = e0[a]; EI[a] = e0[a] * hinv; Eg[a] = e0[a] * hinv; }
-                    if (h.td_on) {      // slot after the observations: the time-offset "row" J_l^T J_td (a 6-vector whose first entry is the only real one)
-                        const int st_ = 6 * (b1 - b0 + 1);
-#pragma unroll
-                        for (int a = 0; a < 6; ++a) { const double e = a == 0 ? etd : 0.0; E[st_ + a] = e; EI[st_ + a] = e * hinv; Eg[st_ + a] = e * hinv; }
-                    }
-                    if (h.ex_on) {      // last slot: the extrinsic row J_l^T J_ex
-                        double ex6[6] = {0, 0, 0, 0, 0, 0};
-                        for (int o = b0; o < b1; ++o) {
-                            const double* Ro = rec + (size_t)o * PREC;
-#pragma unroll
-                            for (int a = 0; a < 6; ++a) ex6[a] += Ro[UVS_PT_C] * Ro[UVS_PT_EX + a] + Ro[UVS_PT_C + 1] * Ro[UVS_PT_EX + 6 + a];
-                        }
-                        const int st_ = 6 * (b1 - b0 + 1 + (h.td_on ? 1 : 0));
-#pragma unroll
-                        for (int a = 0; a < 6; ++a) { E[st_ + a] = ex6[a]; EI[st_ + a] = ex6[a] * hinv; Eg[st_ + a] = ex6[a] * hinv; }
-                    }
-                }
+                if (lead && !ANCHOR_BY_GATHERERS) pt_landmark_slots(c, d, k, b0, b1, hd, gl, dd, hinv, ginv, &gmax_lm);
             }
             UVS_TLOG(c, 5);
-            __syncthreads();
-            UVS_TLOG(c, 6);
-            for (int ol = tid; ol < nob; ol += ET) { double* R = rec + (size_t)ol * PREC; R[UVS_PT_C] = R[UVS_PT_RC2]; R[UVS_PT_C + 1] = R[UVS_PT_RC2 + 1]; }
             __syncthreads();
             UVS_PROF(c, P_LMPREP);
             UVS_TLOG(c, 7);
@@ -1579,7 +1695,7 @@ UVS_DEV void chunk_eval(const Ctx& c, const ChunkDesc& d, const double* x, const
             double* Yb = Eb + (size_t)nob * UVS_LN_EY;               // [nob][UVS_LN_EY]  Y = Hinv E
             double* Xb = Yb + (size_t)nob * UVS_LN_EY;               // [nlm][20] : Hinv[16], Hinv*g[4]
             int* lists = (int*)(Xb + 20 * nlm);
-            for (int t = tid; t < nlist; t += ET) lists[t] = glists[t];
+            if (!LISTS_BY_GATHERERS) for (int t = tid; t < nlist; t += ET) lists[t] = glists[t];
             // pass A
             const double* ltrig = line_trig_of(c, line);
             for (int o = o0 + tid; o < o1; o += ET) {
@@ -1695,7 +1811,7 @@ UVS_DEV void chunk_eval(const Ctx& c, const ChunkDesc& d, const double* x, const
         }
     }
 }
-static constexpr int CHUNK_EVAL_BARRIERS = 4;      // workgroup barriers inside chunk_eval, for either landmark family
+UVS_DEV int chunk_eval_barriers(const ChunkDesc& d) { return d.type == 0 ? 3 : 4; }      // workgroup barriers inside chunk_eval
 UVS_DEV void chunk_gather(const Ctx& c, const ChunkDesc& d, int grp, GAcc& acc) {
     const DevWin& h = *c.hdr;
     const double* rec = c.sh + L_S;
@@ -2226,7 +2342,7 @@ UVS_DEV void lin_assemble(const Ctx& c, const double* x, bool first, double radi
 
 // ---- the role-split linearization of the 512-thread build (ROLES).  Evaluator and gatherer waves run DIFFERENT code between the same workgroup
 // barriers (s_barrier counts arriving waves, not program counters); the two branches below must therefore execute the same NUMBER of barriers:
-//     per chunk      evaluators: chunk_eval (4 barriers inside)            gatherers: 4 barriers, then the chunk's gather walk
+//     per chunk      evaluators: chunk_eval (3 / 4 barriers inside)        gatherers: as many barriers (the lists and the anchor slots in between), then the gather walk
 //     frame terms    evaluators: lin_imu (3 barriers: entry, zeroed, raw)  gatherers: entry barrier, then gacc_gather_parts (2 barriers) beside the IMU staging
 //     assembly       barrier | zero | barrier | part-0 rows (gatherers) | barrier | IMU tiles (evaluators, 2 barriers) | prior (all) | barrier | asm_finish (all)
 // The gather accumulators exist only in the gatherer branch and the IMU tiles only in the evaluator branch, so neither occupies registers where the
@@ -2265,7 +2381,7 @@ UVS_DEV void linearize_roles(const Ctx& c, const double* x, const double* invd, 
         for (int ch = 0; ch < h.n_chunks; ++ch) {
             const ChunkDesc d = chunk_desc(c, ch);
             if (redamp) { if (ev) redamp_prep(c, d, radius); else role_barriers(redamp_barriers(d)); redamp_gather(c, d, grp, A); }
-            else { if (ev) chunk_eval(c, d, x, invd, line, first, radius); else role_barriers(CHUNK_EVAL_BARRIERS); chunk_gather(c, d, grp, A); }
+            else { if (ev) chunk_eval(c, d, x, invd, line, first, radius); else role_barriers(chunk_eval_barriers(d)); chunk_gather(c, d, grp, A); }
         }
         __syncthreads();
         if (h.redamp_ok && c.o.redamp) gacc_store(c, A);
@@ -2287,7 +2403,12 @@ UVS_DEV void linearize_roles(const Ctx& c, const double* x, const double* invd, 
         ChunkDesc d = chunk_desc(c, 0);
         for (int ch = 0; ch < h.n_chunks; ++ch) {
             if (redamp) redamp_prep(c, d, radius); else chunk_eval(c, d, x, invd, line, first, radius);
-            if (ch + 1 < h.n_chunks) d = chunk_desc(c, ch + 1);
+            if (ch + 1 < h.n_chunks) {
+                d = chunk_desc(c, ch + 1);
+#ifdef UVS_CHUNK_TOUCH
+                if (!redamp) chunk_touch(c, d, invd, line);
+#endif
+            }
         }
         UVS_TLOG(c, 21);
         lin_imu_stage(c, x);
@@ -2316,7 +2437,14 @@ UVS_DEV void linearize_roles(const Ctx& c, const double* x, const double* invd, 
         ChunkDesc d = chunk_desc(c, 0);
         for (int ch = 0; ch < h.n_chunks; ++ch) {
             if (redamp) { role_barriers(redamp_barriers(d)); redamp_gather(c, d, grp, A); }
-            else { role_barriers(CHUNK_EVAL_BARRIERS); chunk_gather(c, d, grp, A); }
+            else {
+                __syncthreads();      // the chunk's entry barrier: the staging area is free
+                if (LISTS_BY_GATHERERS) { int* lists = chunk_lists(c, d); for (int t = lane_tid() - GT0; t < d.nlist; t += UVS_GT) lists[t] = d.glists[t]; }
+                __syncthreads();      // pass A is done: the records are complete
+                if (ANCHOR_BY_GATHERERS && d.type == 0) pt_anchor_pass(c, d, first, radius);
+                role_barriers(chunk_eval_barriers(d) - 2);
+                chunk_gather(c, d, grp, A);
+            }
             if (ch + 1 < h.n_chunks) d = chunk_desc(c, ch + 1);
         }
         __syncthreads();      // (lin_imu's entry barrier: every gather walk is done, the staging area is free)

@@ -556,7 +556,7 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
                 for (int o = b0; o < b1; ++o) {
                     const bool is_relo = w->pt_fj[o0 + o] == UVS_RELO_FRAME;
                     const int fi = w->pt_fi[o0 + o], fj = (relo2 && is_relo) ? UVS_RELO2_BLOCKROW : w->pt_fj[o0 + o], ro = o * PREC;
-                    addD(blk_of(fi, fi), (ro + UVS_PT_A) | ((ro + UVS_PT_A) << 16));
+                    addD(blk_of(fi, fi), (ro + UVS_PT_A) | UVS_PT_ENTRY_A | ((ro + UVS_PT_A) << 16));      // (flag: this entry's corrected residual sits 26, not 12, doubles behind its first operand)
                     addD(blk_of(fj, fj), (ro + UVS_PT_B) | ((ro + UVS_PT_B) << 16));
                     addD(blk_of(fj, fi), (ro + UVS_PT_B) | ((ro + UVS_PT_A) << 16));
                     if (td_on && !is_relo) {                                           // J_td^T [A | B | J_td]  (a relocalization block does not depend on td)
