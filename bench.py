@@ -286,7 +286,8 @@ def main():
                     traffic_note = "profiles/pmc_traffic.json was measured on another kernel build (tag %s, this build %s): not reported" % (tj.get("kernel_source_tag"), kernel_source_tag())
             except Exception as e:
                 traffic_note = "unreadable profiles/pmc_traffic.json: %s" % e
-        roofline = {"bound": "mfma", "kernel": "uvsdev::k_solve", "achieved": ach_tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+        ksolve_512 = os.environ.get("UVS_KSOLVE_NT", "512") != "256"      # which instantiation of the persistent kernel the library launches (csrc/uvs_solve512.hip / the 256-thread one)
+        roofline = {"bound": "mfma", "kernel": "uvsdev512::k_solve (512 threads: two waves per SIMD, evaluator / gatherer wave roles)" if ksolve_512 else "uvsdev::k_solve (256 threads, UVS_KSOLVE_NT=256)", "achieved": ach_tflops, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": ach_tflops / FP64_PEAK_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
                     "kernel_ms_per_launch": k_ms, "algorithmic_flops_per_launch": flops_per_launch,
                     "frac_as_executed": flops_executed / (k_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, "flops_as_executed_per_launch": flops_executed,

@@ -302,6 +302,8 @@ UVS_DEV double prior_quad(const Ctx& c, int dst = L_PR) {
     const double* H0 = c.ws + h.w_prior_h0;
     const int parts = (NT / n) < 4 ? (NT / n) : 4;
     const int part = tid / n, row = tid - part * n;
+    // g0 / c0 are requested with the rows of H0, not after the barrier below (where they were a second memory round trip with every wave waiting)
+    const double g0v = tid < n ? c.ws[h.w_prior_h0 + UVS_PH_G0(n) + tid] : 0.0, c0v = tid == 0 ? c.ws[h.w_prior_h0 + UVS_PH_C0(n)] : 0.0;
     if (part < parts) {
         const int kb = (n * part) / parts, ke = (n * (part + 1)) / parts;
         double p8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -319,8 +321,8 @@ UVS_DEV double prior_quad(const Ctx& c, int dst = L_PR) {
         double y = c.sh[L_S + tid];
         for (int p = 1; p < parts; ++p) y += c.sh[L_S + 128 * p + tid];
         c.sh[dst + tid] = y;
-        cost = c.sh[L_PDX + tid] * (c.ws[h.w_prior_h0 + UVS_PH_G0(n) + tid] + 0.5 * y);
-        if (tid == 0) cost += c.ws[h.w_prior_h0 + UVS_PH_C0(n)];
+        cost = c.sh[L_PDX + tid] * (g0v + 0.5 * y);
+        if (tid == 0) cost += c0v;
     }
     return cost;
 }
@@ -2412,11 +2414,11 @@ UVS_DEV void linearize_roles(const Ctx& c, const double* x, const double* invd, 
         }
         UVS_TLOG(c, 21);
         lin_imu_stage(c, x);
+#ifndef UVS_X_NO_PRIOR_AHEAD
+        asm_prior_load(c, pa);      // (before the MFMA stages: a workgroup barrier waits for outstanding loads, so they have to be in flight beside real work)
+#endif
         ic = lin_imu_tiles(c, N);
         UVS_TLOG(c, 22);
-#ifndef UVS_X_NO_PRIOR_AHEAD
-        asm_prior_load(c, pa);
-#endif
         __syncthreads();
         asm_zero(c);
         __syncthreads();
@@ -2455,10 +2457,10 @@ UVS_DEV void linearize_roles(const Ctx& c, const double* x, const double* invd, 
         GAcc& T = A;
 #endif
         gacc_gather_parts(T, grp, c.sh + L_S + ROLE_PARTS_OFF);
-        ic = lin_imu_tiles(c, N);      // (the operand tiles are complete since gacc_gather_parts' second barrier = the last one of lin_imu_stage)
 #ifndef UVS_X_NO_PRIOR_AHEAD
         asm_prior_load(c, pa);
 #endif
+        ic = lin_imu_tiles(c, N);      // (the operand tiles are complete since gacc_gather_parts' second barrier = the last one of lin_imu_stage)
         __syncthreads();
         asm_zero(c);
         __syncthreads();
@@ -2614,6 +2616,40 @@ UVS_DEV void backsub_candidate(const Ctx& c, const double* invd, const double* l
     // lines: delta(4) = -Hinv g - sum_s Y[s] delta_pose
     constexpr int LNB = LNBT;
     const int* lbeg = c.bi + h.i_ln_beg;
+#ifndef UVS_X_NO_LINE_QSPLIT
+    if (ROLES && ltrig_c) {
+        // 512-thread build: one lane per (line, parameter).  The four sums t[q] of a line are independent and each parameter's sin / cos (an FP64 sincos is a few
+        // hundred instructions; four of them back to back were the longest chain of the phase) goes with its own lane.  t[q] takes its terms in the same order.
+        for (int e = 4 * lk0 + line_lane(); e < 4 * lk1; e += NT) {
+            const int k = e >> 2, q = e & 3;
+            const int b0 = lbeg[k], b1 = lbeg[k + 1];
+            const double* lx = c.ws + h.w_ln_x + UVS_LN_X * (size_t)k;
+            double t = 0.0;
+            for (int o = b0; o < b1; o += 4) {
+                int fr[4]; double yv[4][6];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int oc = o + u < b1 ? o + u : o;
+                    fr[u] = c.bi[h.i_ln_fj + oc];
+                    const double* Y = c.ws + h.w_ln_Y + 24 * (size_t)oc + 6 * q;
+#pragma unroll
+                    for (int a = 0; a < 6; ++a) yv[u][a] = Y[a];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (o + u >= b1) continue;
+#pragma unroll
+                    for (int a = 0; a < 6; ++a) t += yv[u][a] * d[16 * fr[u] + a];
+                }
+            }
+            const double dl = -lx[q] - t;
+            const double v = line[4 * k + q] + dl;
+            line_c[4 * k + q] = v;
+            gd += lx[4 + q] * (dl + t); dd2 += lx[8 + q] * dl * dl; step2 += dl * dl; xc2 += v * v;
+            sincos(v, ltrig_c + 8 * k + 2 * q, ltrig_c + 8 * k + 2 * q + 1);
+        }
+    } else
+#endif
     for (int k = lk0 + line_lane(); k < lk1; k += NT) {
         const int b0 = lbeg[k], b1 = lbeg[k + 1];
         const double* lx = c.ws + h.w_ln_x + UVS_LN_X * (size_t)k;
