@@ -29,6 +29,12 @@ cd $R
 # per-phase cycles of one window with the n = 75 prior (debug launch, thread 0), the batch tail (slowest window / contention) and the instruction-cache / L2 counters:
 # plain text files of the round, not derived from a trace
 python tests/gpu_debug_prior.py > gpurun_out/${TAG}_phase_cycles.txt 2>&1
+UVS_KSOLVE_NT=256 python tests/gpu_debug_prior.py > gpurun_out/${TAG}_phase_cycles_256_threads.txt 2>&1      # the one-wave-per-SIMD instantiation of the persistent kernel, same window
+# per-wave step log of one LM iteration (second linearization of the canonical window with its prior), both instantiations
+UVS_DEBUG_LIN_TIMELINE=$R/gpurun_out/${TAG}_tl512.bin python tests/gpu_debug_prior.py > /dev/null 2>&1; python tools/lin_timeline.py gpurun_out/${TAG}_tl512.bin 2 > gpurun_out/${TAG}_lin_timeline.txt 2>&1
+UVS_KSOLVE_NT=256 UVS_DEBUG_LIN_TIMELINE=$R/gpurun_out/${TAG}_tl256.bin python tests/gpu_debug_prior.py > /dev/null 2>&1; echo "---- UVS_KSOLVE_NT=256" >> gpurun_out/${TAG}_lin_timeline.txt; python tools/lin_timeline.py gpurun_out/${TAG}_tl256.bin 2 >> gpurun_out/${TAG}_lin_timeline.txt 2>&1
+# same-box A/B of the two instantiations (batch of 256 + one window), twice each
+for rep_ in 1 2; do for nt_ in 512 256; do UVS_KSOLVE_NT=$nt_ python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-replay --no-large --no-stream 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('UVS_KSOLVE_NT=$nt_', 'batch ms %.4f (kernel %.4f) value %.0f  single window %.4f ms' % (d['ms_per_step'], d['roofline']['kernel_ms_per_launch'], d['value'], d['single_window_ms']))"; done; done > gpurun_out/${TAG}_ab_512_vs_256_threads.txt 2>&1
 python tools/batch_tail.py > gpurun_out/${TAG}_batch_tail.txt 2>&1
 python tools/large_timeline.py config3 > gpurun_out/${TAG}_large_timeline.txt 2>&1; python tools/large_timeline.py canonical >> gpurun_out/${TAG}_large_timeline.txt 2>&1
 bash tools/pmc_icache.sh > gpurun_out/${TAG}_icache_l2_counters.txt 2>&1
@@ -36,4 +42,4 @@ python profiles/summarize.py $TAG      # printed for the log; gpurun only merges
 #   python profiles/summarize.py $TAG && cp gpurun_out/prof_kt/runc_kernel_stats.csv profiles/${TAG}_kernel_stats_bench256.csv
 #   cp gpurun_out/prof_large/runc_kernel_stats.csv profiles/${TAG}_kernel_stats_large.csv
 #   cp gpurun_out/prof_single_fused/runc_kernel_stats.csv profiles/${TAG}_kernel_stats_single_window_fused.csv
-#   cp gpurun_out/${TAG}_phase_cycles.txt gpurun_out/${TAG}_batch_tail.txt gpurun_out/${TAG}_large_timeline.txt gpurun_out/${TAG}_icache_l2_counters.txt profiles/
+#   cp gpurun_out/${TAG}_phase_cycles.txt gpurun_out/${TAG}_phase_cycles_256_threads.txt gpurun_out/${TAG}_lin_timeline.txt gpurun_out/${TAG}_ab_512_vs_256_threads.txt gpurun_out/${TAG}_batch_tail.txt gpurun_out/${TAG}_large_timeline.txt gpurun_out/${TAG}_icache_l2_counters.txt profiles/
