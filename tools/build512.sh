@@ -1,5 +1,7 @@
 #!/bin/bash
-# Build the 512-thread (two waves per SIMD) variant of the solver library into /tmp/b and print k_solve's resources + spill map.
+# HISTORIC (rounds 3 / 4 experiments): builds the WHOLE library with 512 threads into /tmp/b and prints k_solve's resources + spill map.  Only k_solve is
+# valid in such a build (the landmark-sharded kernels assume 256 threads); the product builds the 512-thread k_solve as its own translation unit
+# (csrc/uvs_solve512.hip, __graft_entry__.build).  Kept because the experiment records in tools/experiments/README.md were made with it.
 # usage: tools/build512.sh [extra -D flags...]
 set -e
 mkdir -p /tmp/b && cd /tmp/b
