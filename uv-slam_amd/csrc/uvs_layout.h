@@ -67,7 +67,7 @@
 #define UVS_GLANES 2                // lanes per gather group: 2 = three rows of the 6x6 block per lane, 1 = all six rows in one lane
 #endif
 #define UVS_GROWS (6 / UVS_GLANES)  // block rows held by one lane
-#if UVS_NT > 256 && !defined(UVS_GATHER_ALL)
+#if UVS_NT > 256
 #define UVS_GT 256                  // threads that hold gather accumulators: in the 512-thread build waves 4..7 (waves 0..3 evaluate observations; uvs_solve_kernel.h: ROLES)
 #else
 #define UVS_GT UVS_NT

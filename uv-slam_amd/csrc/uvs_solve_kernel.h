@@ -53,11 +53,7 @@ UVS_DEV int line_lane() { return ROLES ? (lane_tid() ^ 256) : lane_tid(); }
 #else
 UVS_DEV int line_lane() { return lane_tid(); }
 #endif
-#ifdef UVS_X_COST_LINE_ROTATE
-#define UVS_COST_LINE_LANE line_lane()
-#else
 #define UVS_COST_LINE_LANE tid
-#endif
 // Loads in flight per lane.  One wave per SIMD (NT = 256) hides memory latency only with its own independent loads, so the streaming loops batch
 // several observations per lane; with two resident waves per SIMD (NT = 512) the other wave covers the latency and the batches shrink to what
 // fits 256 registers per lane.
@@ -1446,7 +1442,7 @@ UVS_DEV void spd4_inverse(const double* H, const double* gl, double* X, double* 
 // 512-thread build: the gatherer waves copy a chunk's lists into the staging area themselves, between the entry barrier and the three that follow (they have
 // nothing else to do while the evaluators run passes A / B, and the evaluators' own loads no longer queue behind the list words)
 #ifndef UVS_X_NO_LISTS_BY_GATHERERS
-static constexpr bool LISTS_BY_GATHERERS = ROLES && !(UVS_GT == NT);
+static constexpr bool LISTS_BY_GATHERERS = ROLES;
 #else
 static constexpr bool LISTS_BY_GATHERERS = false;
 #endif
@@ -1515,7 +1511,7 @@ UVS_DEV void pt_landmark_hd_gl(const double* rec, int PREC, int b0, int b1, doub
     *hd_ = hd; *gl_ = gl;
 }
 #ifndef UVS_X_NO_ANCHOR_BY_GATHERERS
-static constexpr bool ANCHOR_BY_GATHERERS = ROLES && !(UVS_GT == NT);
+static constexpr bool ANCHOR_BY_GATHERERS = ROLES;
 #else
 static constexpr bool ANCHOR_BY_GATHERERS = false;
 #endif
@@ -2349,8 +2345,7 @@ UVS_DEV void lin_assemble(const Ctx& c, const double* x, bool first, double radi
 //     assembly       barrier | zero | barrier | part-0 rows (gatherers) | barrier | IMU tiles (evaluators, 2 barriers) | prior (all) | barrier | asm_finish (all)
 // The gather accumulators exist only in the gatherer branch and the IMU tiles only in the evaluator branch, so neither occupies registers where the
 // other branch's temporaries live.  redamp = true: re-damping of the stored linearization (relinearize_damping) instead of a new one.
-static constexpr bool GALL = ROLES && UVS_GT == NT;      // experiment (-DUVS_GATHER_ALL): every wave gathers (256 groups), waves 0..3 evaluate as well
-static constexpr int ROLE_PARTS_OFF = GALL ? 0 : (UVS_NF - 1) * IMU_BLK;      // the part sums of split blocks meet behind the IMU staging tiles
+static constexpr int ROLE_PARTS_OFF = (UVS_NF - 1) * IMU_BLK;      // the part sums of split blocks meet behind the IMU staging tiles
 static_assert(ROLE_PARTS_OFF + (8 * GR + 1) * UVS_GT <= UVS_S_DOUBLES, "IMU staging + part sums exceed the S region");
 UVS_DEV void role_barriers(int n) { for (int i = 0; i < n; ++i) __syncthreads(); }
 // the accumulators of the last linearization in the workspace, component-major (one 512-byte run per wave and component)
@@ -2368,7 +2363,7 @@ UVS_DEV void gacc_load(const Ctx& c, GAcc& A) {
 #pragma unroll
     for (int q = 0; q < GR; ++q) { A.g[q] = W[(6 * GR + q) * UVS_GT]; A.hd[q] = W[(7 * GR + q) * UVS_GT]; }
 }
-UVS_DEV void linearize_roles(const Ctx& c, const double* x, const double* invd, const double* line, bool first, double radius, int prep_mode, bool redamp, GAcc& Akeep) {
+UVS_DEV void linearize_roles(const Ctx& c, const double* x, const double* invd, const double* line, bool first, double radius, int prep_mode, bool redamp) {
     const DevWin& h = *c.hdr;
     const bool ev = role_eval();
     { const double pc = lin_prep(c, x, redamp ? 2 : prep_mode); if (!redamp) lacc_set(c.sh, pc, 0.0); }
@@ -2376,31 +2371,6 @@ UVS_DEV void linearize_roles(const Ctx& c, const double* x, const double* invd, 
     UVS_TLOG(c, 20);
     PriorAdd pa;
     ImuN N;
-    if (GALL) {
-        const int grp = gather_group(c);
-        GAcc A;
-        if (redamp) gacc_load(c, A); else gacc_zero(A);
-        for (int ch = 0; ch < h.n_chunks; ++ch) {
-            const ChunkDesc d = chunk_desc(c, ch);
-            if (redamp) { if (ev) redamp_prep(c, d, radius); else role_barriers(redamp_barriers(d)); redamp_gather(c, d, grp, A); }
-            else { if (ev) chunk_eval(c, d, x, invd, line, first, radius); else role_barriers(chunk_eval_barriers(d)); chunk_gather(c, d, grp, A); }
-        }
-        __syncthreads();
-        if (h.redamp_ok && c.o.redamp) gacc_store(c, A);
-        gacc_gather_parts(A, grp, c.sh + L_S);
-        if (ev) lin_imu_stage(c, x); else role_barriers(3);
-        ic = lin_imu_tiles(c, N);
-        __syncthreads();
-        asm_zero(c);
-        __syncthreads();
-        asm_part0(c, grp, A);
-        __syncthreads();
-        asm_imu(c, N);
-        asm_prior(c);
-        __syncthreads();
-        asm_finish(c, x, first && !redamp, radius, lacc_cost(c.sh) + ic, lacc_gmax(c.sh), 0);
-        return;
-    }
     if (ev) {
         ChunkDesc d = chunk_desc(c, 0);
         for (int ch = 0; ch < h.n_chunks; ++ch) {
@@ -2429,13 +2399,8 @@ UVS_DEV void linearize_roles(const Ctx& c, const double* x, const double* invd, 
         UVS_TLOG(c, 25);
     } else {
         const int grp = gather_group(c);
-#ifdef UVS_ROLES_KEEP_A
-        GAcc& A = Akeep;
-        if (!redamp) gacc_zero(A);
-#else
         GAcc A;
         if (redamp) gacc_load(c, A); else gacc_zero(A);
-#endif
         ChunkDesc d = chunk_desc(c, 0);
         for (int ch = 0; ch < h.n_chunks; ++ch) {
             if (redamp) { role_barriers(redamp_barriers(d)); redamp_gather(c, d, grp, A); }
@@ -2450,12 +2415,8 @@ UVS_DEV void linearize_roles(const Ctx& c, const double* x, const double* invd, 
             if (ch + 1 < h.n_chunks) d = chunk_desc(c, ch + 1);
         }
         __syncthreads();      // (lin_imu's entry barrier: every gather walk is done, the staging area is free)
-#ifdef UVS_ROLES_KEEP_A
-        GAcc T = A;
-#else
         if (h.redamp_ok && c.o.redamp) gacc_store(c, A);      // per part: a re-damping continues from these
         GAcc& T = A;
-#endif
         gacc_gather_parts(T, grp, c.sh + L_S + ROLE_PARTS_OFF);
 #ifndef UVS_X_NO_PRIOR_AHEAD
         asm_prior_load(c, pa);
@@ -2481,7 +2442,7 @@ UVS_DEV void linearize_roles(const Ctx& c, const double* x, const double* invd, 
 
 // `A`: the gather accumulators, owned by the caller (k_solve keeps them in registers between a linearization and a possible re-damping)
 UVS_DEV void linearize(const Ctx& c, const double* x, const double* invd, const double* line, bool first, double radius, int prep_mode, GAcc& A) {
-    if (ROLES) { linearize_roles(c, x, invd, line, first, radius, prep_mode, false, A); return; }
+    if (ROLES) { linearize_roles(c, x, invd, line, first, radius, prep_mode, false); return; }
     const DevWin& h = *c.hdr;
     const int grp = gather_group(c);       // this lane's gather group: pose block | flags (uvs_layout.h: i_wblk)
     gacc_zero(A);
@@ -2502,7 +2463,7 @@ UVS_DEV void linearize(const Ctx& c, const double* x, const double* invd, const 
 // After a rejected / invalid step: the same point, a smaller radius.  The per-lane cost / gradient-norm accumulators of the linearization
 // (L_LCOST / L_LGMAX) still hold their values.
 UVS_DEV void relinearize_damping(const Ctx& c, const double* x, double radius, GAcc& A) {
-    if (ROLES) { linearize_roles(c, x, nullptr, nullptr, false, radius, 2, true, A); return; }
+    if (ROLES) { linearize_roles(c, x, nullptr, nullptr, false, radius, 2, true); return; }
     const DevWin& h = *c.hdr;
     const int grp = gather_group(c);
     (void)lin_prep(c, x, 2);
