@@ -1591,6 +1591,10 @@ UVS_DEV void chunk_touch(const Ctx& c, const ChunkDesc& d, const double* invd, c
         iacc += c.bi[h.i_pt_beg + lm] + c.bi[h.i_pt_beg + lm + 1];
     } else {
         const int lm = c.bi[h.i_ln_lm + o]; iacc = c.bi[h.i_ln_fj + o] + c.bi[h.i_ln_vp + o];
+#ifndef UVS_X_NO_TOUCH_B1
+        iacc += c.bi[h.i_ln_beg + lm] + c.bi[h.i_ln_beg + lm + 1];      // what pass B1 asks for per line: its CSR range, its four Jacobi scales (one 32-byte run)
+        acc += c.ws[h.w_scale_ln + 4 * lm] + c.ws[h.w_scale_ln + 4 * lm + 3];
+#endif
         const double* m = c.bd + h.d_lnmeas + o; const int st = h.ln_stride;
 #pragma unroll
         for (int q = 0; q < 9; ++q) acc += m[q * st];
