@@ -198,6 +198,9 @@ __global__ __launch_bounds__(NT) void k_large_solve(char* blob, double* ws, KOpt
 // Round 4: the kernel needs no staging area (only the small LDS arrays + the frame workgroup's scratch: LDS_BYTES_BACKSUB), so several workgroups share a
 // compute unit; the register budget is halved for that (UVS_LARGE_OCC waves per SIMD) and the streaming loops keep fewer loads in flight per lane -- the
 // other resident waves cover the latency that one wave per SIMD had to cover with its own batches.
+#ifndef UVS_LARGE_PSB
+#define UVS_LARGE_PSB 8      // Schur slots of a point per batch of loads in k_large_backsub (a typical track has 5 - 7: one round trip)
+#endif
 #ifndef UVS_LARGE_OCC
 #define UVS_LARGE_OCC 2
 #endif
@@ -228,7 +231,26 @@ __global__ __launch_bounds__(NT, UVS_LARGE_OCC) void k_large_backsub(char* blob,
         const int* chunk = c.bi + h.i_chunks + UVS_CHUNK_INTS * ch;
         const int type = chunk[0], k0 = chunk[1], k1 = chunk[2];
         double* bo = bsums + 8 * (size_t)ch;
-        backsub_candidate<2>(c, invd, line, invd_c, line_c, type == 0 ? k0 : 0, type == 0 ? k1 : 0, type == 1 ? k0 : 0, type == 1 ? k1 : 0, false, bo);
+#ifndef UVS_X_NO_LARGE_TOUCH
+        // the first loads of the cost pass below (index words and measurements of this lane's observations) do not depend on the back substitution: requested here,
+        // their memory round trip (HBM latency in a window of this size) runs beside the back substitution's own chain; dropped after it, the lines stay in L1 / L2
+        double tacc = 0.0; int tiacc = 0;
+        {
+            const int obA = chunk[6], obB = obA + chunk[7];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int o = obA + tid + u * NT;
+                if (o < obB) {
+                    if (type == 0) { tiacc += c.bi[h.i_pt_lm + o] + c.bi[h.i_pt_fi + o] + c.bi[h.i_pt_fj + o]; const double* m = c.bd + h.d_ptmeas + o; for (int q = 0; q < 6; ++q) tacc += m[q * h.pt_stride]; }
+                    else { tiacc += c.bi[h.i_ln_lm + o] + c.bi[h.i_ln_fj + o] + c.bi[h.i_ln_vp + o]; const double* m = c.bd + h.d_lnmeas + o; for (int q = 0; q < 9; ++q) tacc += m[q * h.ln_stride]; }
+                }
+            }
+        }
+#endif
+        backsub_candidate<2, UVS_LARGE_PSB, true>(c, invd, line, invd_c, line_c, type == 0 ? k0 : 0, type == 0 ? k1 : 0, type == 1 ? k0 : 0, type == 1 ? k1 : 0, false, bo);
+#ifndef UVS_X_NO_LARGE_TOUCH
+        asm volatile("" :: "v"(tacc), "v"(tiacc));
+#endif
         __threadfence_block();
         __syncthreads();
         const int ob0 = chunk[6], ob1 = ob0 + chunk[7];      // the chunk's observation range (descriptor: no dependent loads from the CSR arrays)

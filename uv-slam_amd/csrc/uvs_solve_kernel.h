@@ -2486,7 +2486,9 @@ UVS_DEV void relinearize_damping(const Ctx& c, const double* x, double radius, G
 
 // ------------------------------------------------------------------ back-substitution + candidate + model terms
 // frames: XC = X (+) DLT ; landmarks: cand = cur + delta.  Accumulates into CTRL: MCC, STEP2, XC2.
-template <int LNBT = BS_LNB>
+// PSB: Schur slots of a point per batch of loads; STREAM (the landmark-sharded kernel, whose lanes pay HBM latency per dependent load): the per-landmark scalars are
+// requested with the CSR range instead of after the slot loop, and the lines run one lane per (line, parameter) as in the 512-thread persistent kernel
+template <int LNBT = BS_LNB, int PSB = 4, bool STREAM = false>
 UVS_DEV void backsub_candidate(const Ctx& c, const double* invd, const double* line, double* invd_c, double* line_c,
                                   int pk0, int pk1, int lk0, int lk1, bool with_frames, double* sums_out) {
     const DevWin& h = *c.hdr;
@@ -2544,22 +2546,24 @@ UVS_DEV void backsub_candidate(const Ctx& c, const double* invd, const double* l
         const int b0 = pbeg[k], b1 = pbeg[k + 1];
         const double* px = c.ws + h.w_pt_x + 4 * (size_t)k;
         const double* Eg = c.ws + h.w_pt_E + 6 * (size_t)(b0 + h.pt_xslots * k);
+        double px0 = 0.0, px1 = 0.0, px2 = 0.0, iv0 = 0.0;
+        if (STREAM) { px0 = px[0]; px1 = px[1]; px2 = px[2]; iv0 = invd[k]; }
         double t = 0.0;      // Einv . delta_pose  (the landmark's share of the frame step)
         if (b1 > b0) {
             // slots (anchor, observations) four at a time: the frame indices and the 6-vectors of a batch are independent loads, so a lane
             // pays one HBM/L2 round trip per BATCH instead of one per observation
             const int ns = b1 - b0 + 1;
-            for (int s0 = 0; s0 < ns; s0 += 4) {
-                int fr[4]; double ev[4][6];
+            for (int s0 = 0; s0 < ns; s0 += PSB) {
+                int fr[PSB]; double ev[PSB][6];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < PSB; ++u) {
                     const int sl = s0 + u, slc = sl < ns ? sl : 0;
                     fr[u] = slc == 0 ? c.bi[h.i_pt_fi + b0] : c.bi[h.i_pt_fj + b0 + slc - 1];
 #pragma unroll
                     for (int a = 0; a < 6; ++a) ev[u][a] = Eg[6 * slc + a];
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < PSB; ++u) {
                     if (s0 + u >= ns) continue;
 #pragma unroll
                     for (int a = 0; a < 6; ++a) t += ev[u][a] * d[16 * fr[u] + a];
@@ -2572,17 +2576,18 @@ UVS_DEV void backsub_candidate(const Ctx& c, const double* invd, const double* l
                 for (int a = 0; a < 6; ++a) t += e[a] * d[UVS_EX_INDEX(a)];
             }
         }
-        const double dl = -px[0] - t;
-        const double v = invd[k] + dl;
+        if (!STREAM) { px0 = px[0]; px1 = px[1]; px2 = px[2]; iv0 = invd[k]; }
+        const double dl = -px0 - t;
+        const double v = iv0 + dl;
         invd_c[k] = v;
         // L_G holds the Schur-REDUCED frame gradient g_f - E^T h^-1 g_l; (E delta_f) h^-1 g_l = t * g_l restores the full g_f . delta_f
-        gd += px[1] * (dl + t); dd2 += px[2] * dl * dl; step2 += dl * dl; xc2 += v * v;
+        gd += px1 * (dl + t); dd2 += px2 * dl * dl; step2 += dl * dl; xc2 += v * v;
     }
     // lines: delta(4) = -Hinv g - sum_s Y[s] delta_pose
     constexpr int LNB = LNBT;
     const int* lbeg = c.bi + h.i_ln_beg;
 #ifndef UVS_X_NO_LINE_QSPLIT
-    if (ROLES && ltrig_c) {
+    if ((ROLES && ltrig_c) || STREAM) {
         // 512-thread build: one lane per (line, parameter).  The four sums t[q] of a line are independent and each parameter's sin / cos (an FP64 sincos is a few
         // hundred instructions; four of them back to back were the longest chain of the phase) goes with its own lane.  t[q] takes its terms in the same order.
         for (int e = 4 * lk0 + line_lane(); e < 4 * lk1; e += NT) {
@@ -2590,10 +2595,12 @@ UVS_DEV void backsub_candidate(const Ctx& c, const double* invd, const double* l
             const int b0 = lbeg[k], b1 = lbeg[k + 1];
             const double* lx = c.ws + h.w_ln_x + UVS_LN_X * (size_t)k;
             double t = 0.0;
-            for (int o = b0; o < b1; o += 4) {
-                int fr[4]; double yv[4][6];
+            constexpr int QB = STREAM ? 8 : 4;      // observations per batch of loads
+            const double lxq = STREAM ? lx[q] : 0.0, lx4 = STREAM ? lx[4 + q] : 0.0, lx8 = STREAM ? lx[8 + q] : 0.0, ln0 = STREAM ? line[4 * k + q] : 0.0;
+            for (int o = b0; o < b1; o += QB) {
+                int fr[QB]; double yv[QB][6];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < QB; ++u) {
                     const int oc = o + u < b1 ? o + u : o;
                     fr[u] = c.bi[h.i_ln_fj + oc];
                     const double* Y = c.ws + h.w_ln_Y + 24 * (size_t)oc + 6 * q;
@@ -2601,17 +2608,17 @@ UVS_DEV void backsub_candidate(const Ctx& c, const double* invd, const double* l
                     for (int a = 0; a < 6; ++a) yv[u][a] = Y[a];
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < QB; ++u) {
                     if (o + u >= b1) continue;
 #pragma unroll
                     for (int a = 0; a < 6; ++a) t += yv[u][a] * d[16 * fr[u] + a];
                 }
             }
-            const double dl = -lx[q] - t;
-            const double v = line[4 * k + q] + dl;
+            const double dl = -(STREAM ? lxq : lx[q]) - t;
+            const double v = (STREAM ? ln0 : line[4 * k + q]) + dl;
             line_c[4 * k + q] = v;
-            gd += lx[4 + q] * (dl + t); dd2 += lx[8 + q] * dl * dl; step2 += dl * dl; xc2 += v * v;
-            sincos(v, ltrig_c + 8 * k + 2 * q, ltrig_c + 8 * k + 2 * q + 1);
+            gd += (STREAM ? lx4 : lx[4 + q]) * (dl + t); dd2 += (STREAM ? lx8 : lx[8 + q]) * dl * dl; step2 += dl * dl; xc2 += v * v;
+            if (ltrig_c) sincos(v, ltrig_c + 8 * k + 2 * q, ltrig_c + 8 * k + 2 * q + 1);
         }
     } else
 #endif
