@@ -1516,14 +1516,29 @@ static constexpr bool ANCHOR_BY_GATHERERS = ROLES;
 static constexpr bool ANCHOR_BY_GATHERERS = false;
 #endif
 // 512-thread build, gatherer waves, between the second and the third barrier of a point chunk (beside pass B): one lane per landmark
-UVS_DEV void pt_anchor_pass(const Ctx& c, const ChunkDesc& d, bool first, double radius) {
+// what the anchor lane of the FIRST round needs from global memory (its landmark's CSR range and Jacobi scale): requested by the gatherer lane while pass A is
+// still running (pt_anchor_pre, before the barrier that ends pass A), so the pass itself starts on LDS data
+struct AnchorPre { int b0, b1; double sc; };
+UVS_DEV void pt_anchor_pre(const Ctx& c, const ChunkDesc& d, bool first, AnchorPre& ap) {
+    const DevWin& h = *c.hdr;
+    const int li = lane_tid() - GT0;
+    ap.b0 = 0; ap.b1 = 0; ap.sc = 1.0;
+    if (li >= 0 && li < d.nlm) {
+        const int k = d.k0 + li;
+        ap.b0 = c.bi[h.i_pt_beg + k] - d.o0; ap.b1 = c.bi[h.i_pt_beg + k + 1] - d.o0;
+        if (!first) ap.sc = c.ws[h.w_scale_pt + k];
+    }
+}
+UVS_DEV void pt_anchor_pass(const Ctx& c, const ChunkDesc& d, bool first, double radius, const AnchorPre& ap) {
     const DevWin& h = *c.hdr;
     const int* beg = c.bi + h.i_pt_beg;
     const double* rec = c.sh + L_S;
     double gmax_lm = 0.0;
     for (int li = lane_tid() - GT0; li < d.nlm; li += UVS_GT) {
-        const int k = d.k0 + li, b0 = beg[k] - d.o0, b1 = beg[k + 1] - d.o0;
-        const double sc_old = first ? 1.0 : c.ws[h.w_scale_pt + k];      // (requested with the CSR range, used after the loop)
+        const int k = d.k0 + li;
+        const bool pre = li == lane_tid() - GT0;      // first round: from pt_anchor_pre
+        const int b0 = pre ? ap.b0 : beg[k] - d.o0, b1 = pre ? ap.b1 : beg[k + 1] - d.o0;
+        const double sc_old = pre ? ap.sc : (first ? 1.0 : c.ws[h.w_scale_pt + k]);
         if (b1 <= b0) continue;
         if (h.td_on | h.ex_on) {
             double hd, gl; pt_landmark_hd_gl(rec, h.pt_rec, b0, b1, &hd, &gl);
@@ -2411,8 +2426,10 @@ UVS_DEV void linearize_roles(const Ctx& c, const double* x, const double* invd, 
             else {
                 __syncthreads();      // the chunk's entry barrier: the staging area is free
                 if (LISTS_BY_GATHERERS) { int* lists = chunk_lists(c, d); for (int t = lane_tid() - GT0; t < d.nlist; t += UVS_GT) lists[t] = d.glists[t]; }
+                AnchorPre ap; ap.b0 = 0; ap.b1 = 0; ap.sc = 1.0;
+                if (ANCHOR_BY_GATHERERS && d.type == 0) pt_anchor_pre(c, d, first, ap);
                 __syncthreads();      // pass A is done: the records are complete
-                if (ANCHOR_BY_GATHERERS && d.type == 0) pt_anchor_pass(c, d, first, radius);
+                if (ANCHOR_BY_GATHERERS && d.type == 0) pt_anchor_pass(c, d, first, radius, ap);
                 role_barriers(chunk_eval_barriers(d) - 2);
                 chunk_gather(c, d, grp, A);
             }
