@@ -42,6 +42,30 @@ __device__ long long g_large_prof[1024 * 8];
 // tiles, prior, their gradient and cost (and, on the first linearization, the per-solve setup: IMU whitening, prior normal matrix) --
 // while the others run the landmark chunks, and writes it to `fimg`; k_large_solve then only adds the reduced landmark blocks and factors.
 // (Inside k_large_solve these 45 k cycles sat on the one-workgroup critical path of every iteration.)
+// the workgroup's accumulators -> its canonical partial image in LDS ([pose block][row a][8]: 6 block entries, gradient, diag(J^T J)): the parts of a split block are
+// summed in a fixed order (gacc_gather_parts), the image is zeroed and the part-0 lanes add their rows.  FIVE workgroup barriers; `gather` = this wave holds
+// accumulators (every wave of the 256-thread kernel, waves 4..7 of the 512-thread one, whose evaluator waves only zero their share and keep the barriers)
+UVS_DEV void large_partial_image(const Ctx& c, GAcc& A, int grp, bool gather) {
+    double* sh = c.sh; const int tid = lane_tid();
+    __syncthreads();
+    if (gather) gacc_gather_parts(A, grp, sh + L_S); else role_barriers(2);      // (the part exchange has two barriers inside)
+    __syncthreads();
+    for (int i = tid; i < LG_ACC; i += NT) sh[L_S + i] = 0.0;
+    __syncthreads();
+    if (gather && grp >= 0 && ((grp >> 9) & 15) == 0) {
+        const int r0 = GR * (tid % UVS_GLANES);
+        const bool tdrow = ((grp >> 13) & 15) == UVS_NF;       // time-offset blocks: only row 0 is real
+#pragma unroll
+        for (int r = 0; r < GR; ++r) {
+            if (tdrow && (r0 + r) != 0) continue;
+            double* Q = sh + L_S + (grp & 255) * 64 + (r0 + r) * 8;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) Q[q] += A.v[6 * r + q];
+            Q[6] += A.g[r]; Q[7] += A.hd[r];
+        }
+    }
+    __syncthreads();
+}
 __global__ __launch_bounds__(NT) void k_large_chunks(char* blob, double* ws, KOpts o, const double* state, int sel, int first, double radius, double* partials, LargeCtl lc,
                                                      int n_chunk_wgs, double* fimg) {
     extern __shared__ __attribute__((aligned(16))) double sh[];
@@ -74,40 +98,61 @@ __global__ __launch_bounds__(NT) void k_large_chunks(char* blob, double* ws, KOp
     stage_rotations(c, sh + L_X);
     __syncthreads();
     const int grp = gather_group(c);
-    GAcc A; gacc_zero(A);
+    GAcc A;
+    if (!ROLES) gacc_zero(A);      // (512-thread instantiation: zeroed inside the role branches, so that the accumulators are dead in the evaluators' code)
     lacc_set(sh, 0.0, 0.0);
     UVS_LPROF(1);
     const double* invd = ws + (sel ? h.w_invd1 : h.w_invd0); const double* line = ws + (sel ? h.w_line1 : h.w_line0);
     // PERSISTENT workgroups: workgroup b takes chunks b, b + gridDim.x, ... and accumulates them into ONE partial (the host sizes the chunks so
     // that their number is a multiple of the grid: 340 LDS-filling chunks on 256 CUs were two full rounds for 1.33 rounds of work)
     int taken = 0;
+    if (ROLES) {
+        // 512-thread instantiation (csrc/uvs_solve512.hip): the wave roles of the persistent kernel's linearization (linearize_roles) -- waves 0..3 evaluate, waves 4..7
+        // copy the lists, compute the landmarks' anchor slots and walk the lists; the same barrier ledger per chunk
+        // (two loops per role, re-damping and linearization apart: with both in one loop body the walk's operand sets spilled)
+        const int ch0 = blockIdx.x, chs = n_chunk_wgs;
+        if (role_eval()) {
+            if (redamp) {
+                for (int ch = ch0; ch < h.n_chunks; ch += chs) { redamp_prep(c, chunk_desc(c, ch), radius); if (taken++ == 0) UVS_LPROF(2); }
+            } else {
+                ChunkDesc d = chunk_desc(c, ch0 < h.n_chunks ? ch0 : 0);
+                for (int ch = ch0; ch < h.n_chunks; ch += chs) {
+                    chunk_eval(c, d, sh + L_X, invd, line, first != 0, radius);
+                    if (taken++ == 0) UVS_LPROF(2);
+                    if (ch + chs < h.n_chunks) { d = chunk_desc(c, ch + chs); chunk_touch(c, d, invd, line); }
+                }
+            }
+            GAcc none;
+            large_partial_image(c, none, -1, false);
+        } else {
+            GAcc Ag; gacc_zero(Ag);
+            GAcc& A = Ag;
+            if (redamp) {
+                for (int ch = ch0; ch < h.n_chunks; ch += chs) { const ChunkDesc d = chunk_desc(c, ch); role_barriers(redamp_barriers(d)); redamp_gather(c, d, grp, A); ++taken; }
+            } else {
+                ChunkDesc d = chunk_desc(c, ch0 < h.n_chunks ? ch0 : 0);
+                for (int ch = ch0; ch < h.n_chunks; ch += chs) {
+                    __syncthreads();      // the chunk's entry barrier: the staging area is free
+                    if (LISTS_BY_GATHERERS) { int* lists = chunk_lists(c, d); for (int t = lane_tid() - GT0; t < d.nlist; t += UVS_GT) lists[t] = d.glists[t]; }
+                    AnchorPre ap; ap.b0 = 0; ap.b1 = 0; ap.sc = 1.0;
+                    if (ANCHOR_BY_GATHERERS && d.type == 0) pt_anchor_pre(c, d, first != 0, ap);
+                    __syncthreads();      // pass A is done
+                    if (ANCHOR_BY_GATHERERS && d.type == 0) pt_anchor_pass(c, d, first != 0, radius, ap);
+                    role_barriers(chunk_eval_barriers(d) - 2);
+                    chunk_gather(c, d, grp, A);
+                    ++taken;
+                    if (ch + chs < h.n_chunks) d = chunk_desc(c, ch + chs);
+                }
+            }
+            large_partial_image(c, A, grp, true);
+        }
+        UVS_LPROF(3); UVS_LPROF(4);
+    } else
     for (int ch = blockIdx.x; ch < h.n_chunks; ch += n_chunk_wgs) { if (redamp) redamp_chunk(c, ch, radius, grp, A); else lin_chunk(c, ch, sh + L_X, invd, line, first != 0, radius, grp, A); if (taken++ == 0) UVS_LPROF(2); }
     UVS_LPROF(3);
     if (o.debug == 7 && tid == 0 && blockIdx.x < 1024) g_large_prof[8 * blockIdx.x + 7] = taken;
     double cost = lacc_cost(sh), gmax = lacc_gmax(sh);
-    // canonical partial [pose block][row a][8] (6 block entries, gradient, diag(J^T J)), staged in LDS so that the two halves of a
-    // split block are summed in a fixed order and the HBM write is coalesced
-    __syncthreads();
-    gacc_gather_parts(A, grp, sh + L_S);
-    __syncthreads();
-    UVS_LPROF(4);
-    for (int i = tid; i < LG_ACC; i += NT) sh[L_S + i] = 0.0;
-    __syncthreads();
-    {
-        if (grp >= 0 && ((grp >> 9) & 15) == 0) {
-            const int r0 = GR * (tid % UVS_GLANES);
-            const bool tdrow = ((grp >> 13) & 15) == UVS_NF;       // time-offset blocks: only row 0 is real
-#pragma unroll
-            for (int r = 0; r < GR; ++r) {
-                if (tdrow && (r0 + r) != 0) continue;
-                double* Q = sh + L_S + (grp & 255) * 64 + (r0 + r) * 8;
-#pragma unroll
-                for (int q = 0; q < 6; ++q) Q[q] += A.v[6 * r + q];
-                Q[6] += A.g[r]; Q[7] += A.hd[r];
-            }
-        }
-        __syncthreads();
-    }
+    if (!ROLES) { large_partial_image(c, A, grp, true); UVS_LPROF(4); }
     double* P = partials + (size_t)blockIdx.x * LG_RED;
     if (redamp) { for (int i = tid; i < LG_ACC; i += NT) P[i] += sh[L_S + i]; return; }      // cost and landmark gradient norm of the partial are unchanged
     for (int i = tid; i < LG_ACC; i += NT) P[i] = sh[L_S + i];
@@ -117,6 +162,7 @@ __global__ __launch_bounds__(NT) void k_large_chunks(char* blob, double* ws, KOp
     UVS_LPROF(5);
 }
 
+#ifndef UVS_TU_512      // (csrc/uvs_solve512.hip instantiates k_solve and k_large_chunks only)
 // Deterministic two-level sum of the per-chunk partials: a workgroup owns 16 consecutive entries i, its 16 x 16 threads split the chunk
 // range into 16 contiguous slices (summed in chunk order, loads independent of each other), the 16 slice sums are then added in slice
 // order.  (One thread per entry walking all chunks serially took 137 us for 340 chunks -- more than k_large_chunks itself.)
@@ -397,4 +443,5 @@ __global__ __launch_bounds__(256) void k_large_pack(const char* blob, const doub
     for (int i = t; i < 4 * h.n_lines; i += nt) o2[h.n_points + i] = ws[(sel ? h.w_line1 : h.w_line0) + i];
 }
 
+#endif
 }  // namespace uvsdev

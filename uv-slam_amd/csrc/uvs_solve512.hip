@@ -13,8 +13,10 @@
 #define UVS_ALLOW_EXPERIMENTAL_NT 1
 #define UVS_SOLVE_KERNEL_ONLY 1
 #define UVS_CHUNK_TOUCH 1
+#define UVS_TU_512 1
 #define uvsdev uvsdev512
 #include "uvs_solve_kernel.h"
+#include "uvs_large_kernel.h"      // k_large_chunks only (UVS_TU_512): the chunk kernel of the landmark-sharded forms with the same wave roles
 
 using namespace uvsdev512;
 
@@ -24,7 +26,16 @@ int uvs_k_solve512_init(const unsigned char* fa, const unsigned char* fb, int n)
     if (n != UVS_NBLK) return UVS_ERR_INVALID_ARG;
     if (hipMemcpyToSymbol(HIP_SYMBOL(c_blk_fa), fa, n) != hipSuccess || hipMemcpyToSymbol(HIP_SYMBOL(c_blk_fb), fb, n) != hipSuccess) return UVS_ERR_HIP;
     if (hipFuncSetAttribute((const void*)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES) != hipSuccess) return UVS_ERR_HIP;
+    if (hipFuncSetAttribute((const void*)k_large_chunks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES) != hipSuccess) return UVS_ERR_HIP;
     return UVS_OK;
+}
+// k_large_chunks with 512 threads per workgroup (grid = chunk workgroups + the frame-terms workgroup, as for the 256-thread kernel)
+void uvs_k_large_chunks512_launch(int grid, hipStream_t stream, char* blob, double* ws, const void* kopts, size_t kopts_bytes, const double* state, int sel, int first, double radius,
+                                  double* partials, const double* ctl, int rank, int nranks, int n_chunk_wgs, double* fimg) {
+    KOpts ko;
+    if (kopts_bytes != sizeof(ko)) return;
+    __builtin_memcpy(&ko, kopts, sizeof(ko));
+    hipLaunchKernelGGL(k_large_chunks, dim3(grid), dim3(NT), LDS_BYTES, stream, blob, ws, ko, state, sel, first, radius, partials, LargeCtl{ctl, rank, nranks}, n_chunk_wgs, fimg);
 }
 // kopts / dbg: the caller's uvsdev::KOpts / uvsdev::DebugOut (same definitions, other namespace)
 void uvs_k_solve512_launch(int n_windows, hipStream_t stream, char* blobs, const long long* blob_off, double* ws_all, const long long* ws_off,

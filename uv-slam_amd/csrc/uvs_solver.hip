@@ -35,6 +35,8 @@ void uvs_k_solve512_launch(int n_windows, hipStream_t stream, char* blobs, const
                            const void* kopts, size_t kopts_bytes, uvs_report* reports, const void* dbg, size_t dbg_bytes);
 size_t uvs_k_solve512_arg_bytes(int which);
 int uvs_k_solve512_timeline(long long* out, size_t n);
+void uvs_k_large_chunks512_launch(int grid, hipStream_t stream, char* blob, double* ws, const void* kopts, size_t kopts_bytes, const double* state, int sel, int first, double radius,
+                                  double* partials, const double* ctl, int rank, int nranks, int n_chunk_wgs, double* fimg);
 }
 
 struct PackCache;
@@ -48,6 +50,7 @@ struct uvs_solver {
     int max_points = 0, max_point_obs = 0, max_lines = 0, max_line_obs = 0;      // per-window capacities promised at uvs_create
     uvs_solver* twin = nullptr;              // second buffer set of uvs_batch_stream (created on first use, destroyed with this handle)
     int n_cus = 256;                         // compute units of the device
+    int large_chunks_nt = 512;               // likewise for k_large_chunks (UVS_LARGE_CHUNKS_NT=256 selects the 256-thread kernel of this file)
     int ksolve_nt = 512;                     // which instantiation of the persistent kernel launch_solve uses (uvs_solve512.hip / this file's 256-thread one)
     int chunk_wgs() const { return std::max(1, n_cus - 1); }      // chunk workgroups of the persistent large-window kernels: one compute unit stays free for the frame-terms workgroup of the same launch
     hipStream_t stream;
@@ -187,7 +190,8 @@ int uvs_create(const uvs_options* opts, int device, int max_batch, int max_point
     for (int i = 0, b = 0; i < UVS_NF; ++i) for (int j = 0; j <= i; ++j, ++b) { fa[b] = (unsigned char)i; fb[b] = (unsigned char)j; }
     if (hipMemcpyToSymbol(HIP_SYMBOL(c_blk_fa), fa, sizeof(fa)) != hipSuccess || hipMemcpyToSymbol(HIP_SYMBOL(c_blk_fb), fb, sizeof(fb)) != hipSuccess) { delete s; return UVS_ERR_HIP; }
     if (uvs_k_solve512_arg_bytes(0) != sizeof(KOpts) || uvs_k_solve512_arg_bytes(1) != sizeof(DebugOut) || uvs_k_solve512_init(fa, fb, UVS_NBLK) != UVS_OK) { delete s; return UVS_ERR_HIP; }
-    { const char* e = std::getenv("UVS_KSOLVE_NT"); s->ksolve_nt = (e && std::atoi(e) == 256) ? 256 : 512; }      // A/B switch: 256 = the one-wave-per-SIMD instantiation of the persistent kernel
+    { const char* e = std::getenv("UVS_KSOLVE_NT"); s->ksolve_nt = (e && std::atoi(e) == 256) ? 256 : 512; }
+    { const char* e = std::getenv("UVS_LARGE_CHUNKS_NT"); s->large_chunks_nt = (e && std::atoi(e) == 256) ? 256 : 512; }      // A/B switch: 256 = the one-wave-per-SIMD instantiation of the persistent kernel
     // the LDS opt-in is a per-device function attribute: every handle sets it for its own device (the current one since hipSetDevice above)
     for (const void* fn : {(const void*)k_solve, (const void*)k_evaluate, (const void*)k_large_chunks, (const void*)k_large_solve, (const void*)k_large_backsub})
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES) != hipSuccess) { delete s; return UVS_ERR_HIP; }
@@ -1446,7 +1450,8 @@ int uvs_large_linearize(uvs_solver* s) {
     auto& L = s->L;
     HIPCHK(s, hipSetDevice(s->device));
     KOpts ko = make_kopts(s->opts, 0);
-    hipLaunchKernelGGL(k_large_chunks, dim3(L.grid + 1), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, L.sel, L.first ? 1 : 0, L.radius, L.d_partials, LargeCtl{nullptr, 0, 0}, L.grid, L.d_fimg);
+    if (s->large_chunks_nt == 512) uvs_k_large_chunks512_launch(L.grid + 1, s->stream, s->d_blobs, s->d_ws, &ko, sizeof(ko), L.d_state, L.sel, L.first ? 1 : 0, L.radius, L.d_partials, nullptr, 0, 0, L.grid, L.d_fimg);
+    else hipLaunchKernelGGL(k_large_chunks, dim3(L.grid + 1), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, L.sel, L.first ? 1 : 0, L.radius, L.d_partials, LargeCtl{nullptr, 0, 0}, L.grid, L.d_fimg);
     hipLaunchKernelGGL(k_large_reduce, dim3((LG_RED + 15) / 16), dim3(256), 0, s->stream, L.d_partials, L.grid, L.d_reduced, LargeCtl{nullptr, 0, 0});
     HIPCHK(s, hipGetLastError());
     HIPCHK(s, hipStreamSynchronize(s->stream));
@@ -1684,7 +1689,8 @@ int uvs_large_solve_fused(uvs_solver* s, const uvs_window* w, uvs_state* out, uv
     const int bgrid = std::min(L.n_chunks, UVS_LARGE_OCC * s->chunk_wgs());      // k_large_backsub runs UVS_LARGE_OCC workgroups per compute unit
     HIPCHK(s, hipEventRecord(s->ev0, s->stream));
     for (int p = 0; p < passes; ++p) {
-        hipLaunchKernelGGL(k_large_chunks, dim3(L.grid + 1), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, 0, 0, 0.0, L.d_partials, lc, L.grid, L.d_fimg);
+        if (s->large_chunks_nt == 512) uvs_k_large_chunks512_launch(L.grid + 1, s->stream, s->d_blobs, s->d_ws, &ko, sizeof(ko), L.d_state, 0, 0, 0.0, L.d_partials, lc.ctl, lc.rank, lc.nranks, L.grid, L.d_fimg);
+        else hipLaunchKernelGGL(k_large_chunks, dim3(L.grid + 1), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, 0, 0, 0.0, L.d_partials, lc, L.grid, L.d_fimg);
         // (summing the partial rows inside k_large_solve instead of by a launch of its own was measured: one workgroup needs 15-24 us for what 314 do in 5)
         hipLaunchKernelGGL(k_large_reduce, dim3((LG_RED + 15) / 16), dim3(256), 0, s->stream, L.d_partials, rows, L.d_reduced, lc);
         if (L.comm) { const int e = r.AllReduce(L.d_reduced, L.d_reduced, LG_XCH, kNcclDouble, kNcclSum, L.comm, s->stream); if (e != 0) return fused_abort(s, "ncclAllReduce(reduced) failed"); }
