@@ -46,6 +46,11 @@ void uvs_k_solve512_launch(int n_windows, hipStream_t stream, char* blobs, const
     hipLaunchKernelGGL(k_solve, dim3(n_windows), dim3(NT), LDS_BYTES, stream, blobs, blob_off, ws_all, ws_off, ko, reports, d);
 }
 size_t uvs_k_solve512_arg_bytes(int which) { return which == 0 ? sizeof(KOpts) : sizeof(DebugOut); }
+// debug == 7 (UVS_LARGE_PROF): the per-workgroup stamps of the last k_large_chunks launch (tools/large_timeline.py)
+int uvs_k_large_chunks512_prof(long long* out, size_t n) {
+    if (n != sizeof(g_large_prof) / sizeof(long long)) return UVS_ERR_INVALID_ARG;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_large_prof), n * sizeof(long long)) == hipSuccess ? UVS_OK : UVS_ERR_HIP;
+}
 // debug == 5: the per-wave step log of the last launch (tools/lin_timeline.py)
 int uvs_k_solve512_timeline(long long* out, size_t n) {
     if (n != sizeof(g_lin_tl) / sizeof(long long)) return UVS_ERR_INVALID_ARG;

@@ -35,6 +35,7 @@ void uvs_k_solve512_launch(int n_windows, hipStream_t stream, char* blobs, const
                            const void* kopts, size_t kopts_bytes, uvs_report* reports, const void* dbg, size_t dbg_bytes);
 size_t uvs_k_solve512_arg_bytes(int which);
 int uvs_k_solve512_timeline(long long* out, size_t n);
+int uvs_k_large_chunks512_prof(long long* out, size_t n);
 void uvs_k_large_chunks512_launch(int grid, hipStream_t stream, char* blob, double* ws, const void* kopts, size_t kopts_bytes, const double* state, int sel, int first, double radius,
                                   double* partials, const double* ctl, int rank, int nranks, int n_chunk_wgs, double* fimg);
 }
@@ -1710,7 +1711,7 @@ int uvs_large_solve_fused(uvs_solver* s, const uvs_window* w, uvs_state* out, uv
     if (loop_ms) HIPCHK(s, hipEventElapsedTime(loop_ms, s->ev0, s->ev1));
     if (lprof) {
         std::vector<long long> tp(1024 * 8);
-        if (hipMemcpyFromSymbol(tp.data(), HIP_SYMBOL(g_large_prof), tp.size() * 8) == hipSuccess) { if (FILE* f = std::fopen(lprof, "wb")) { const int hdr[2] = {L.grid + 1, L.n_chunks}; std::fwrite(hdr, 4, 2, f); std::fwrite(tp.data(), 8, tp.size(), f); std::fclose(f); } }
+        if ((s->large_chunks_nt == 512 ? uvs_k_large_chunks512_prof(tp.data(), tp.size()) == UVS_OK : hipMemcpyFromSymbol(tp.data(), HIP_SYMBOL(g_large_prof), tp.size() * 8) == hipSuccess)) { if (FILE* f = std::fopen(lprof, "wb")) { const int hdr[2] = {L.grid + 1, L.n_chunks}; std::fwrite(hdr, 4, 2, f); std::fwrite(tp.data(), 8, tp.size(), f); std::fclose(f); } }
     }
     const double* ho = (const double*)s->h_out;
     const double* ctl = ho;
