@@ -162,7 +162,6 @@ __global__ __launch_bounds__(NT) void k_large_chunks(char* blob, double* ws, KOp
     UVS_LPROF(5);
 }
 
-#ifndef UVS_TU_512      // (csrc/uvs_solve512.hip instantiates k_solve and k_large_chunks only)
 // Deterministic two-level sum of the per-chunk partials: a workgroup owns 16 consecutive entries i, its 16 x 16 threads split the chunk
 // range into 16 contiguous slices (summed in chunk order, loads independent of each other), the 16 slice sums are then added in slice
 // order.  (One thread per entry walking all chunks serially took 137 us for 340 chunks -- more than k_large_chunks itself.)
@@ -240,6 +239,7 @@ __global__ __launch_bounds__(NT) void k_large_solve(char* blob, double* ws, KOpt
     // (the frame part of the candidate cost -- prior + IMU at x_c -- is k_large_backsub's extra workgroup)
 }
 
+#ifndef UVS_TU_512      // (csrc/uvs_solve512.hip instantiates k_solve, k_large_chunks and k_large_solve; the kernels below exist with 256 threads only)
 // per chunk: landmark back-substitution (candidate parameters into the other buffer) + candidate cost of the chunk's observations.
 // Round 4: the kernel needs no staging area (only the small LDS arrays + the frame workgroup's scratch: LDS_BYTES_BACKSUB), so several workgroups share a
 // compute unit; the register budget is halved for that (UVS_LARGE_OCC waves per SIMD) and the streaming loops keep fewer loads in flight per lane -- the

@@ -16,7 +16,7 @@
 #define UVS_TU_512 1
 #define uvsdev uvsdev512
 #include "uvs_solve_kernel.h"
-#include "uvs_large_kernel.h"      // k_large_chunks only (UVS_TU_512): the chunk kernel of the landmark-sharded forms with the same wave roles
+#include "uvs_large_kernel.h"      // k_large_chunks (the chunk kernel of the landmark-sharded forms with the same wave roles) and k_large_solve (UVS_TU_512)
 
 using namespace uvsdev512;
 
@@ -27,6 +27,7 @@ int uvs_k_solve512_init(const unsigned char* fa, const unsigned char* fb, int n)
     if (hipMemcpyToSymbol(HIP_SYMBOL(c_blk_fa), fa, n) != hipSuccess || hipMemcpyToSymbol(HIP_SYMBOL(c_blk_fb), fb, n) != hipSuccess) return UVS_ERR_HIP;
     if (hipFuncSetAttribute((const void*)k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES) != hipSuccess) return UVS_ERR_HIP;
     if (hipFuncSetAttribute((const void*)k_large_chunks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES) != hipSuccess) return UVS_ERR_HIP;
+    if (hipFuncSetAttribute((const void*)k_large_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES) != hipSuccess) return UVS_ERR_HIP;
     return UVS_OK;
 }
 // k_large_chunks with 512 threads per workgroup (grid = chunk workgroups + the frame-terms workgroup, as for the 256-thread kernel)
@@ -46,6 +47,14 @@ void uvs_k_solve512_launch(int n_windows, hipStream_t stream, char* blobs, const
     hipLaunchKernelGGL(k_solve, dim3(n_windows), dim3(NT), LDS_BYTES, stream, blobs, blob_off, ws_all, ws_off, ko, reports, d);
 }
 size_t uvs_k_solve512_arg_bytes(int which) { return which == 0 ? sizeof(KOpts) : sizeof(DebugOut); }
+// k_large_solve with 512 threads (one workgroup): the frame image arrives with twice the loads in flight, the factorization has six workers and the pivot chain its SIMD alone
+void uvs_k_large_solve512_launch(hipStream_t stream, char* blob, double* ws, const void* kopts, size_t kopts_bytes, double* state, const double* reduced, int first, double radius, double* out,
+                                 const double* ctl, int rank, int nranks, const double* fimg) {
+    KOpts ko;
+    if (kopts_bytes != sizeof(ko)) return;
+    __builtin_memcpy(&ko, kopts, sizeof(ko));
+    hipLaunchKernelGGL(k_large_solve, dim3(1), dim3(NT), LDS_BYTES, stream, blob, ws, ko, state, reduced, first, radius, out, LargeCtl{ctl, rank, nranks}, fimg);
+}
 // debug == 7 (UVS_LARGE_PROF): the per-workgroup stamps of the last k_large_chunks launch (tools/large_timeline.py)
 int uvs_k_large_chunks512_prof(long long* out, size_t n) {
     if (n != sizeof(g_large_prof) / sizeof(long long)) return UVS_ERR_INVALID_ARG;

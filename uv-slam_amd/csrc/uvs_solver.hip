@@ -36,6 +36,8 @@ void uvs_k_solve512_launch(int n_windows, hipStream_t stream, char* blobs, const
 size_t uvs_k_solve512_arg_bytes(int which);
 int uvs_k_solve512_timeline(long long* out, size_t n);
 int uvs_k_large_chunks512_prof(long long* out, size_t n);
+void uvs_k_large_solve512_launch(hipStream_t stream, char* blob, double* ws, const void* kopts, size_t kopts_bytes, double* state, const double* reduced, int first, double radius, double* out,
+                                 const double* ctl, int rank, int nranks, const double* fimg);
 void uvs_k_large_chunks512_launch(int grid, hipStream_t stream, char* blob, double* ws, const void* kopts, size_t kopts_bytes, const double* state, int sel, int first, double radius,
                                   double* partials, const double* ctl, int rank, int nranks, int n_chunk_wgs, double* fimg);
 }
@@ -51,6 +53,7 @@ struct uvs_solver {
     int max_points = 0, max_point_obs = 0, max_lines = 0, max_line_obs = 0;      // per-window capacities promised at uvs_create
     uvs_solver* twin = nullptr;              // second buffer set of uvs_batch_stream (created on first use, destroyed with this handle)
     int n_cus = 256;                         // compute units of the device
+    int large_solve_nt = 512;                // ... and for k_large_solve (UVS_LARGE_SOLVE_NT=256)
     int large_chunks_nt = 512;               // likewise for k_large_chunks (UVS_LARGE_CHUNKS_NT=256 selects the 256-thread kernel of this file)
     int ksolve_nt = 512;                     // which instantiation of the persistent kernel launch_solve uses (uvs_solve512.hip / this file's 256-thread one)
     int chunk_wgs() const { return std::max(1, n_cus - 1); }      // chunk workgroups of the persistent large-window kernels: one compute unit stays free for the frame-terms workgroup of the same launch
@@ -192,7 +195,8 @@ int uvs_create(const uvs_options* opts, int device, int max_batch, int max_point
     if (hipMemcpyToSymbol(HIP_SYMBOL(c_blk_fa), fa, sizeof(fa)) != hipSuccess || hipMemcpyToSymbol(HIP_SYMBOL(c_blk_fb), fb, sizeof(fb)) != hipSuccess) { delete s; return UVS_ERR_HIP; }
     if (uvs_k_solve512_arg_bytes(0) != sizeof(KOpts) || uvs_k_solve512_arg_bytes(1) != sizeof(DebugOut) || uvs_k_solve512_init(fa, fb, UVS_NBLK) != UVS_OK) { delete s; return UVS_ERR_HIP; }
     { const char* e = std::getenv("UVS_KSOLVE_NT"); s->ksolve_nt = (e && std::atoi(e) == 256) ? 256 : 512; }
-    { const char* e = std::getenv("UVS_LARGE_CHUNKS_NT"); s->large_chunks_nt = (e && std::atoi(e) == 256) ? 256 : 512; }      // A/B switch: 256 = the one-wave-per-SIMD instantiation of the persistent kernel
+    { const char* e = std::getenv("UVS_LARGE_CHUNKS_NT"); s->large_chunks_nt = (e && std::atoi(e) == 256) ? 256 : 512; }
+    { const char* e = std::getenv("UVS_LARGE_SOLVE_NT"); s->large_solve_nt = (e && std::atoi(e) == 256) ? 256 : 512; }      // A/B switch: 256 = the one-wave-per-SIMD instantiation of the persistent kernel
     // the LDS opt-in is a per-device function attribute: every handle sets it for its own device (the current one since hipSetDevice above)
     for (const void* fn : {(const void*)k_solve, (const void*)k_evaluate, (const void*)k_large_chunks, (const void*)k_large_solve, (const void*)k_large_backsub})
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES) != hipSuccess) { delete s; return UVS_ERR_HIP; }
@@ -1464,7 +1468,8 @@ int uvs_large_step(uvs_solver* s) {
     auto& L = s->L;
     HIPCHK(s, hipSetDevice(s->device));
     KOpts ko = make_kopts(s->opts, 0);
-    hipLaunchKernelGGL(k_large_solve, dim3(1), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, L.d_reduced, L.first ? 1 : 0, L.radius, L.d_out, LargeCtl{nullptr, 0, 0}, L.d_fimg);
+    if (s->large_solve_nt == 512) uvs_k_large_solve512_launch(s->stream, s->d_blobs, s->d_ws, &ko, sizeof(ko), L.d_state, L.d_reduced, L.first ? 1 : 0, L.radius, L.d_out, nullptr, 0, 0, L.d_fimg);
+    else hipLaunchKernelGGL(k_large_solve, dim3(1), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, L.d_reduced, L.first ? 1 : 0, L.radius, L.d_out, LargeCtl{nullptr, 0, 0}, L.d_fimg);
     { const int bg = std::min(L.n_chunks, UVS_LARGE_OCC * s->chunk_wgs());      // (UVS_LARGE_OCC workgroups per compute unit: the kernel asks for little LDS and half the registers)
       hipLaunchKernelGGL(k_large_backsub, dim3(bg + 1), dim3(NT), LDS_BYTES_BACKSUB, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, L.sel, L.d_bsums, LargeCtl{nullptr, 0, 0}, bg, L.d_out); }
     hipLaunchKernelGGL(k_large_sum_bsums, dim3(1), dim3(256), 0, s->stream, L.d_bsums, L.n_chunks, L.d_sc5, LargeCtl{nullptr, 0, 0}, 0LL);
@@ -1695,7 +1700,8 @@ int uvs_large_solve_fused(uvs_solver* s, const uvs_window* w, uvs_state* out, uv
         // (summing the partial rows inside k_large_solve instead of by a launch of its own was measured: one workgroup needs 15-24 us for what 314 do in 5)
         hipLaunchKernelGGL(k_large_reduce, dim3((LG_RED + 15) / 16), dim3(256), 0, s->stream, L.d_partials, rows, L.d_reduced, lc);
         if (L.comm) { const int e = r.AllReduce(L.d_reduced, L.d_reduced, LG_XCH, kNcclDouble, kNcclSum, L.comm, s->stream); if (e != 0) return fused_abort(s, "ncclAllReduce(reduced) failed"); }
-        hipLaunchKernelGGL(k_large_solve, dim3(1), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, L.d_reduced, 0, 0.0, L.d_out, lc, L.d_fimg);
+        if (s->large_solve_nt == 512) uvs_k_large_solve512_launch(s->stream, s->d_blobs, s->d_ws, &ko, sizeof(ko), L.d_state, L.d_reduced, 0, 0.0, L.d_out, lc.ctl, lc.rank, lc.nranks, L.d_fimg);
+        else hipLaunchKernelGGL(k_large_solve, dim3(1), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, L.d_reduced, 0, 0.0, L.d_out, lc, L.d_fimg);
         hipLaunchKernelGGL(k_large_backsub, dim3(bgrid + 1), dim3(NT), LDS_BYTES_BACKSUB, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, 0, L.d_bsums, lc, bgrid, L.d_out);
         if (L.comm) {
             hipLaunchKernelGGL(k_large_sum_bsums, dim3(1), dim3(256), 0, s->stream, L.d_bsums, L.n_chunks, L.d_sc5, lc, ko.max_ticks);
