@@ -64,3 +64,31 @@ def test_both_instantiations_walk_the_same_path(kind):
         assert abs(rep512[i].final_cost - rep256[i].final_cost) <= 1e-9 * max(1.0, abs(rep256[i].final_cost)), (kind, i)
         a, b = np.asarray(st512[i].pose), np.asarray(st256[i].pose)
         assert np.abs(a - b).max() < 1e-8, (kind, i)
+
+
+def _fused(w, chunks_nt, solve_nt):
+    old = {k: os.environ.get(k) for k in ("UVS_LARGE_CHUNKS_NT", "UVS_LARGE_SOLVE_NT")}
+    os.environ["UVS_LARGE_CHUNKS_NT"] = str(chunks_nt); os.environ["UVS_LARGE_SOLVE_NT"] = str(solve_nt)
+    try:
+        s = uvs.api.Solver(device=0, max_batch=1, max_points=max(1000, len(w.inv_depth)), max_point_obs=max(16000, len(w.pt_lm)), max_lines=max(1000, len(w.line_orth)), max_line_obs=max(16000, len(w.ln_lm)))
+    finally:
+        for k, v in old.items():
+            if v is None: os.environ.pop(k, None)
+            else: os.environ[k] = v
+    st, rep, _ = s.large_solve_fused(w)
+    s.close()
+    return st, rep
+
+
+@pytest.mark.parametrize("shape", ["canonical", "many_chunks"])
+def test_landmark_sharded_kernels_in_both_instantiations(shape):
+    """k_large_chunks and k_large_solve exist with 512 threads (wave roles, csrc/uvs_solve512.hip: the default) and with 256 (UVS_LARGE_CHUNKS_NT / UVS_LARGE_SOLVE_NT = 256):
+    the fused loop must take the same LM path with either and end at the same state."""
+    w = synth.make_window(31) if shape == "canonical" else synth.make_window(32, n_points=2500, n_lines=400, n_tagged=200)
+    a, ra = _fused(w, 512, 512)
+    for cn, sn in ((256, 256), (512, 256), (256, 512)):
+        b, rb = _fused(w, cn, sn)
+        assert ra.status == 0 and rb.status == 0
+        assert _trace(ra) == _trace(rb), (shape, cn, sn)
+        assert abs(ra.final_cost - rb.final_cost) <= 1e-9 * max(1.0, abs(rb.final_cost)), (shape, cn, sn)
+        assert np.abs(np.asarray(a.pose) - np.asarray(b.pose)).max() < 1e-8, (shape, cn, sn)
