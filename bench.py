@@ -109,23 +109,25 @@ def algorithmic_flops(w, n_iterations, n_successful=None):
 
 def project_large_window(measured_n):
     """UNMEASURED projection of the configs[3] LM iteration on 2 / 4 / 8 GPUs from the per-kernel times of the committed 1-GPU rocprofv3 trace
-    (profiles/r03_kernel_stats_large.csv): the landmark-sharded kernels divide by N, the reduced solve and the trust-region step are replicated, and every
+    (the newest profiles/rNN_kernel_stats_large.csv): the landmark-sharded kernels divide by N, the reduced solve and the trust-region step are replicated, and every
     iteration pays two in-place RCCL all-reduces (40 KB and 64 B: latency bound, 15 us each ASSUMED -- no multi-GPU node was available to measure them)."""
-    path = os.path.join(ROOT, "profiles", "r03_kernel_stats_large.csv")
-    if not os.path.exists(path):
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_kernel_stats_large.csv")))
+    if not cands:
         return None
+    path = cands[-1]
     import csv
     avg = {}
     for row in csv.DictReader(open(path)):
         for key in ("k_large_chunks", "k_large_backsub", "k_large_reduce", "k_large_solve", "k_large_decide"):
-            if "uvsdev::" + key + "(" in row["Name"]:
+            if "::" + key + "(" in row["Name"]:      # (uvsdev:: or uvsdev512::, whichever instantiation the profiled build launched)
                 avg[key] = float(row["AverageNs"]) * 1e-3
     if len(avg) < 5:
         return None
     sharded = avg["k_large_chunks"] + avg["k_large_backsub"] + avg["k_large_reduce"]
     replicated = avg["k_large_solve"] + avg["k_large_decide"]
     allreduce_us = 15.0
-    out = {"status": "UNMEASURED projection from 1-GPU kernel times (profiles/r03_kernel_stats_large.csv); the all-reduce latency is an assumption",
+    out = {"status": "UNMEASURED projection from 1-GPU kernel times (profiles/%s); the all-reduce latency is an assumption" % os.path.basename(path),
            "per_iteration_us_1gpu": {"sharded (chunks + backsub + reduce)": sharded, "replicated (reduced solve + decide)": replicated},
            "assumed_allreduce_us_each": allreduce_us, "iteration_us": {}, "speedup_vs_1gpu": {}}
     t1 = sharded + replicated
