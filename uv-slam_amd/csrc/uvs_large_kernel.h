@@ -318,7 +318,13 @@ __global__ __launch_bounds__(256) void k_large_sum_bsums(const double* bsums, in
     const int i = threadIdx.x & 7, p = threadIdx.x >> 3;
     const int per = (n_chunks + 31) / 32, c0 = p * per, c1 = (c0 + per < n_chunks) ? c0 + per : n_chunks;
     double s = 0.0;
-    if (i < 5) for (int ch = c0; ch < c1; ++ch) s += bsums[8 * (size_t)ch + i];
+    if (i < 5) for (int cb = c0; cb < c1; cb += 16) {      // (16 rows per batch of loads, as in k_large_decide)
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = bsums[8 * (size_t)(cb + u < c1 ? cb + u : cb) + i];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) if (cb + u < c1) s += v[u];
+    }
     part[p][i] = s;
     __syncthreads();
     if (p == 0 && i < 5) { double t = part[0][i]; for (int q = 1; q < 32; ++q) t += part[q][i]; out5[i] = t; }
@@ -339,7 +345,13 @@ __global__ __launch_bounds__(256) void k_large_decide(double* ctl, double* state
         const int i = tid & 7, p = tid >> 3;
         const int per = (n_rows + 31) / 32, c0 = p * per, c1 = (c0 + per < n_rows) ? c0 + per : n_rows;
         double sl = 0.0;
-        if (i < 5) for (int ch = c0; ch < c1; ++ch) sl += bsums[8 * (size_t)ch + i];
+        if (i < 5) for (int cb = c0; cb < c1; cb += 16) {      // 16 rows per batch of loads (the plain loop paid a memory round trip per row: 16 of them for the 510 rows of configs[3]); same order of the sum
+            double v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = bsums[8 * (size_t)(cb + u < c1 ? cb + u : cb) + i];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) if (cb + u < c1) sl += v[u];
+        }
         part[p][i] = sl;
         __syncthreads();
         if (p == 0 && i < 5) { double t = part[0][i]; for (int q = 1; q < 32; ++q) t += part[q][i]; sc5_sh[i] = t; }
