@@ -174,8 +174,13 @@ __global__ __launch_bounds__(256) void k_large_reduce(const double* partials, in
     const int per = (n_chunks + 15) / 16, c0 = p * per, c1 = (c0 + per < n_chunks) ? c0 + per : n_chunks;
     double s = 0.0;
     if (i < LG_RED) {
-        if (is_max) { for (int ch = c0; ch < c1; ++ch) s = fmax(s, partials[(size_t)ch * LG_RED + i]); }
-        else for (int ch = c0; ch < c1; ++ch) s += partials[(size_t)ch * LG_RED + i];
+        for (int cb = c0; cb < c1; cb += 16) {      // 16 rows per batch of loads, summed in row order (the plain loop compiled to a few loads per memory round trip)
+            double v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = partials[(size_t)(cb + u < c1 ? cb + u : cb) * LG_RED + i];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) if (cb + u < c1) s = is_max ? fmax(s, v[u]) : s + v[u];
+        }
     }
     part[p][il] = s;
     __syncthreads();
