@@ -133,7 +133,7 @@ __global__ __launch_bounds__(NT) void k_large_chunks(char* blob, double* ws, KOp
                 ChunkDesc d = chunk_desc(c, ch0 < h.n_chunks ? ch0 : 0);
                 for (int ch = ch0; ch < h.n_chunks; ch += chs) {
                     __syncthreads();      // the chunk's entry barrier: the staging area is free
-                    if (LISTS_BY_GATHERERS) { int* lists = chunk_lists(c, d); for (int t = lane_tid() - GT0; t < d.nlist; t += UVS_GT) lists[t] = d.glists[t]; }
+                    if (LISTS_BY_GATHERERS) copy_lists_gatherers(c, d);
                     AnchorPre ap; ap.b0 = 0; ap.b1 = 0; ap.sc = 1.0;
                     if (ANCHOR_BY_GATHERERS && d.type == 0) pt_anchor_pre(c, d, first != 0, ap);
                     __syncthreads();      // pass A is done
@@ -368,10 +368,14 @@ __global__ __launch_bounds__(256) void k_large_decide(double* ctl, double* state
         double radius = ctl[LC_RADIUS], decr = ctl[LC_DECR], cost = ctl[LC_COST], gmax = ctl[LC_GMAX], x_norm = ctl[LC_XNORM];
         int it = (int)ctl[LC_IT], invalid = (int)ctl[LC_INVALID], nsucc = (int)ctl[LC_NSUCC], pending = (int)ctl[LC_PENDING], sel = (int)ctl[LC_SEL];
         int term = UVS_TERM_NO_CONVERGENCE, status = UVS_OK; bool done = false;
+        // every global value this lane needs, requested BEFORE the first store below (the report and control words may alias them as far as the compiler knows:
+        // a load placed after a store waits for a memory round trip of its own -- a dozen of them in a row on one lane were most of this launch's 4 - 6 us)
         const double lc_ = out[LO_COST], gm = out[LO_GMAX];
-        if (ctl[LC_FIRST] != 0.0) {
+        const double o_gd = out[LO_GD], o_dd2 = out[LO_DD2], o_step2 = out[LO_STEP2], o_xc2 = out[LO_XC2], o_fcost = out[LO_FRAMECOST], o_cholok = out[LO_CHOLOK];
+        const double c_first = ctl[LC_FIRST], c_fx2 = ctl[LC_FRAME_X2], c_t0 = ctl[LC_T0], r_x2 = reduced[LX_X2];
+        if (c_first != 0.0) {
             cost = lc_; gmax = gm; ctl[LC_FIRST] = 0.0;
-            x_norm = sqrt(ctl[LC_FRAME_X2] + reduced[LX_X2]);      // frames (host) + every rank's landmarks (all-reduced)
+            x_norm = sqrt(c_fx2 + r_x2);      // frames (host) + every rank's landmarks (all-reduced)
             rep->initial_cost = lc_; rep->cost[0] = lc_; rep->radius[0] = radius; rep->gradient_max_norm[0] = gm; rep->accepted[0] = 1;
             if (!isfinite(lc_)) { term = UVS_TERM_NUMERIC_FAILURE; status = UVS_ERR_NUMERIC; done = true; }
         } else if (pending > 0) { cost = lc_; gmax = gm; rep->cost[pending] = lc_; rep->gradient_max_norm[pending] = gm; }
@@ -379,17 +383,17 @@ __global__ __launch_bounds__(256) void k_large_decide(double* ctl, double* state
         if (!done) {
             if (it >= o.max_it) { term = UVS_TERM_NO_CONVERGENCE; done = true; }
             // options.max_solver_time_in_seconds: one process reads its own clock; with a communicator the decision is the all-reduced vote of the ranks (sc5[5]), identical everywhere
-            else if (o.max_ticks > 0 && it > 0 && (bsums ? (double)wall_clock64() - ctl[LC_T0] >= (double)o.max_ticks : sc5[5] > 0.0)) { term = UVS_TERM_MAX_TIME; done = true; }
+            else if (o.max_ticks > 0 && it > 0 && (bsums ? (double)wall_clock64() - c_t0 >= (double)o.max_ticks : sc5[5] > 0.0)) { term = UVS_TERM_MAX_TIME; done = true; }
             else if (gmax <= o.gtol) { term = UVS_TERM_GRADIENT_TOL; done = true; }
             else if (radius <= o.rmin) { term = UVS_TERM_MIN_RADIUS; done = true; }
         }
         if (!done) {
             ++it;
             const int ti = it < UVS_MAX_ITER ? it : UVS_MAX_ITER;
-            const double gd = out[LO_GD] + sc5[0], dd2 = out[LO_DD2] + sc5[1], step2 = out[LO_STEP2] + sc5[2], xc2 = out[LO_XC2] + sc5[3];
+            const double gd = o_gd + sc5[0], dd2 = o_dd2 + sc5[1], step2 = o_step2 + sc5[2], xc2 = o_xc2 + sc5[3];
             const double mcc = 0.5 * (dd2 - gd);
-            double cand = out[LO_FRAMECOST] + sc5[4];
-            const bool ok = out[LO_CHOLOK] != 0.0 && isfinite(mcc) && isfinite(step2);
+            double cand = o_fcost + sc5[4];
+            const bool ok = o_cholok != 0.0 && isfinite(mcc) && isfinite(step2);
             rep->model_cost_change[ti] = mcc;
             if (!ok || !(mcc > 0.0)) {
                 ++invalid; radius /= decr; decr *= 2.0; ctl[LC_REDAMP] = 1.0;

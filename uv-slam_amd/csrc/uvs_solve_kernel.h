@@ -1624,6 +1624,20 @@ UVS_DEV void chunk_touch(const Ctx& c, const ChunkDesc& d, const double* invd, c
     }
     asm volatile("" :: "v"(acc), "v"(iacc));
 }
+// the gatherer waves' copy of a chunk's lists into the staging area: LG_UN words per lane in flight (a plain copy loop compiles to batches of four loads and a
+// one-load-per-trip remainder; the lists of a full chunk of a large window are ~12 words per lane, i.e. several memory round trips at HBM latency)
+static constexpr int LG_UN = 16;
+UVS_DEV void copy_lists_gatherers(const Ctx& c, const ChunkDesc& d) {
+    int* lists = chunk_lists(c, d);
+    const int t0 = lane_tid() - GT0;
+    for (int tb = t0; tb < d.nlist; tb += LG_UN * UVS_GT) {
+        int w[LG_UN];
+#pragma unroll
+        for (int u = 0; u < LG_UN; ++u) { const int t = tb + u * UVS_GT; w[u] = d.glists[t < d.nlist ? t : tb]; }
+#pragma unroll
+        for (int u = 0; u < LG_UN; ++u) { const int t = tb + u * UVS_GT; if (t < d.nlist) lists[t] = w[u]; }
+    }
+}
 UVS_DEV void chunk_eval(const Ctx& c, const ChunkDesc& d, const double* x, const double* invd, const double* line, bool first, double radius) {
     const DevWin& h = *c.hdr;
     double* sh = c.sh;
@@ -2425,7 +2439,7 @@ UVS_DEV void linearize_roles(const Ctx& c, const double* x, const double* invd, 
             if (redamp) { role_barriers(redamp_barriers(d)); redamp_gather(c, d, grp, A); }
             else {
                 __syncthreads();      // the chunk's entry barrier: the staging area is free
-                if (LISTS_BY_GATHERERS) { int* lists = chunk_lists(c, d); for (int t = lane_tid() - GT0; t < d.nlist; t += UVS_GT) lists[t] = d.glists[t]; }
+                if (LISTS_BY_GATHERERS) copy_lists_gatherers(c, d);
                 AnchorPre ap; ap.b0 = 0; ap.b1 = 0; ap.sc = 1.0;
                 if (ANCHOR_BY_GATHERERS && d.type == 0) pt_anchor_pre(c, d, first, ap);
                 __syncthreads();      // pass A is done: the records are complete
@@ -2780,7 +2794,13 @@ UVS_DEV void setup_window(const Ctx& c, double* blob_rw, bool with_prior_image =
         double* Jl = c.sh + L_S + 2048;                      // [n][n], beside the whitening scratch
         double* r0l = c.sh + L_S + 1024;                     // [n]
         const int* inv = c.bi + h.i_prior + 80 + UVS_MAX_PRIOR_DIM;      // S index -> prior column
-        for (int t = tid; t < n * n; t += NT) Jl[t] = J0[t];
+        for (int tb = tid; tb < n * n; tb += 12 * NT) {      // J0 -> LDS, 12 loads per lane in flight (once per solve; the plain loop was one memory round trip per 4 * NT entries)
+            double v[12];
+#pragma unroll
+            for (int u = 0; u < 12; ++u) { const int t = tb + u * NT; v[u] = J0[t < n * n ? t : tb]; }
+#pragma unroll
+            for (int u = 0; u < 12; ++u) { const int t = tb + u * NT; if (t < n * n) Jl[t] = v[u]; }
+        }
         if (tid < n) r0l[tid] = J0[n * n + tid];
         __syncthreads();
         double* H0 = c.ws + h.w_prior_h0;
