@@ -8,7 +8,8 @@
 // kernel arguments and the report are the same, so the host side only picks which launcher to call (launch_solve).
 //
 // Build flag of THIS file: -mllvm -disable-machine-licm.  Machine LICM hoists loop-invariant address arithmetic out of the LM loop -- the
-// whole kernel body -- and the hoisted values (hundreds) are live across every phase: 428 spilled VGPRs with it, 46 without (round 4).
+// whole kernel body -- and the hoisted values (hundreds) are live across every phase: 428 spilled VGPRs with it, 46 without (round 4);
+// -mllvm -sink-insts-to-avoid-spills takes another dozen away (34).
 #define UVS_NT 512
 #define UVS_ALLOW_EXPERIMENTAL_NT 1
 #define UVS_SOLVE_KERNEL_ONLY 1
