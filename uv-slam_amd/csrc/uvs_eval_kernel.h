@@ -94,7 +94,7 @@ __global__ __launch_bounds__(NT) void k_evaluate(char* blob, double* ws, KOpts o
     for (int t = tid; t < h.n_imu * 465; t += NT) {
         const int b = t / 465, e = t - b * 465;
         const bool skip = c.bi[h.i_imu + 2 * b + 1] != 0 || (marg0 && c.bi[h.i_imu + 2 * b] != 0);
-        const double* W = c.bd + h.d_imu + (size_t)b * UVS_IMU_STRIDE + UVS_IMU_W;
+        const double* W = c.ws + h.w_imu_w + (size_t)b * UVS_IMU_WS;
         const double* wj = c.ws + h.w_imu + (size_t)b * UVS_WIMU_STRIDE;
         if (e < 450) { const int r = e / 30, cc = e - r * 30; double s = 0.0; if (!skip) for (int k = r; k < 15; ++k) s += W[r * 15 + k] * wj[k * 30 + cc]; out.imu_J[450 * (size_t)b + e] = s; }
         else { const int r = e - 450; double s = 0.0; if (!skip) for (int k = r; k < 15; ++k) s += W[r * 15 + k] * wj[900 + k]; out.imu_r[15 * b + r] = s; cost += 0.5 * s * s; }

@@ -31,10 +31,11 @@
 #define UVS_BLK_SZ (16 * UVS_BLK_LD)            // 272 doubles
 #define UVS_S_DOUBLES (UVS_NBLK * UVS_BLK_SZ)   // 17952 doubles = 143616 B
 
-#define UVS_IMU_STRIDE 520        // doubles per IMU block: 20 header + packed jac 48 + cov 225 + W 225 (+2 pad)
+#define UVS_IMU_STRIDE 296        // doubles per IMU block in the blob: 20 header + packed jac 48 + cov 225 (+3 pad).  The whitening matrix W (225 doubles, written by the device: setup_window)
+                                  // lives in the WORKSPACE since round 4 (DevWin::w_imu_w, UVS_IMU_WS doubles per block): 18 KB per window less to pack and to send over PCIe
 #define UVS_IMU_JAC 20            // the five 3x3 blocks of the pre-integration Jacobian the factor reads (dp_dba, dp_dbg, dq_dbg, dv_dba, dv_dbg), 9 doubles each
 #define UVS_IMU_COV 68
-#define UVS_IMU_W 293
+#define UVS_IMU_WS 226            // workspace doubles per block for W (15 x 15 row-major + 1 pad)
 // packed index of jacobian(R + i, C + j) for (R, C) in {(0,9) (0,12) (3,12) (6,9) (6,12)}  (integration_base.h O_P/O_R/O_V rows, O_BA/O_BG columns)
 #define UVS_IMU_JIDX(R, C, i, j) (9 * ((R) == 0 ? ((C) == 9 ? 0 : 1) : (R) == 3 ? 2 : ((C) == 9 ? 3 : 4)) + 3 * (i) + (j))
 
@@ -110,6 +111,7 @@ struct DevWin {
     int32_t w_pt_E, w_pt_x;           // Einv store 6*(n_pt_obs+n_points) ; per point {ginv, g, dd, 0}
     int32_t w_ln_Y, w_ln_x;           // Y store 24*n_ln_obs ; per line UVS_LN_X doubles {Hinv*g[4], g[4], dd[4], H[10]}
     int32_t w_imu;                    // per block: Jraw[450] Jw[450] rraw[15] rw[15] (pad 936)
+    int32_t w_imu_w;                  // per block: W[225] = chol(cov^-1)^T, upper triangular (UVS_IMU_WS doubles), written once per solve by setup_window
     int32_t w_out;                    // final state: frames[UVS_XDIM] | inv_depth[n_points] | line_orth[4 n_lines] (k_solve; the large path reads the cur buffers)
     int32_t w_prior_h0;               // the prior's quadratic form, written by setup_window: H0 = J0^T J0 dense [n][n] | g0 = J0^T r0 at UVS_PH_G0 | c0 = r0^T r0 / 2 at UVS_PH_C0 | diag(H0) by S index [176] at UVS_PH_HD
     int32_t n_pblk;                   // pose blocks of S the prior touches (ids in i_prior + 352)

@@ -456,7 +456,7 @@ UVS_DEV double cost_pass(const Ctx& c, const double* x, const double* invd, cons
         __syncthreads();
         const int b = tid >> 4, i = tid & 15;
         if (b < h.n_imu && i < 15 && !c.bi[h.i_imu + 2 * b + 1]) {
-            const double* W = c.bd + h.d_imu + (size_t)b * UVS_IMU_STRIDE + UVS_IMU_W + i * 15;
+            const double* W = c.ws + h.w_imu_w + (size_t)b * UVS_IMU_WS + i * 15;
             double wv[15];
 #pragma unroll
             for (int k = 0; k < 15; ++k) wv[k] = (k >= i) ? W[k] : 0.0;
@@ -1325,7 +1325,7 @@ UVS_DEV void lin_imu_stage(const Ctx& c, const double* x) {
 #pragma unroll
     for (int q = 0; q < WPL; ++q) {
         const int t = tid + q * ET, tc = t < h.n_imu * 225 ? t : 0, b = tc / 225, e = tc - 225 * b;
-        wreg[q] = c.bd[h.d_imu + (size_t)b * UVS_IMU_STRIDE + UVS_IMU_W + e];
+        wreg[q] = c.ws[h.w_imu_w + (size_t)b * UVS_IMU_WS + e];
     }
     for (int t = tid; t < h.n_imu * IMU_BLK; t += ET) IM[t] = 0.0;      // operand tiles are mostly structural zeros
     UVS_TLOG(c, 40);
@@ -2780,8 +2780,8 @@ UVS_DEV void setup_window(const Ctx& c, double* blob_rw, bool with_prior_image =
     const int tid = lane_tid(), lane = tid & 63, wv = tid >> 6;
     for (int b = wv; b < h.n_imu; b += NW) {
         if (only_imu_frame >= 0 && c.bi[h.i_imu + 2 * b] != only_imu_frame) continue;      // marginalization: the one block that touches the departing frame
-        double* blk = blob_rw + h.d_imu + (size_t)b * UVS_IMU_STRIDE;
-        imu_whiten_block(blk + UVS_IMU_COV, blk + UVS_IMU_W, c.sh + L_S + 256 * wv, lane);
+        const double* blk = blob_rw + h.d_imu + (size_t)b * UVS_IMU_STRIDE;
+        imu_whiten_block(blk + UVS_IMU_COV, c.ws + h.w_imu_w + (size_t)b * UVS_IMU_WS, c.sh + L_S + 256 * wv, lane);
     }
     if (h.prior_n > 0 && with_prior_image) {
         // The prior's quadratic form, ONCE per solve: H0 = J0^T J0 (dense n x n, both triangles), g0 = J0^T r0, c0 = r0^T r0 / 2 and diag(H0) by S index, in

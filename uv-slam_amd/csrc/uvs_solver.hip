@@ -850,6 +850,7 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
     h.w_pt_E = wsz; wsz += 6 * (h.n_pt_obs + XS * h.n_points) + 6; h.w_pt_x = wsz; wsz += 4 * std::max(h.n_points, 1);
     h.w_ln_Y = wsz; wsz += 24 * std::max(h.n_ln_obs, 1); h.w_ln_x = wsz; wsz += UVS_LN_X * std::max(h.n_lines, 1);
     h.w_imu = wsz; wsz += std::max(h.n_imu, 1) * UVS_WIMU_STRIDE;
+    h.w_imu_w = wsz; wsz += std::max(h.n_imu, 1) * UVS_IMU_WS;
     h.w_out = wsz; wsz += UVS_XDIM + std::max(h.n_points, 0) + 4 * std::max(h.n_lines, 0);
     h.n_pblk = (int)pblk.size();
     h.w_prior_h0 = wsz; wsz += UVS_PH_DOUBLES(h.prior_n);      // H0 = J0^T J0, g0, c0, diag(H0) per S index: written once per solve by setup_window
