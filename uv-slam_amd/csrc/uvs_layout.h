@@ -116,7 +116,8 @@ struct DevWin {
     int32_t w_prior_h0;               // the prior's quadratic form, written by setup_window: H0 = J0^T J0 dense [n][n] | g0 = J0^T r0 at UVS_PH_G0 | c0 = r0^T r0 / 2 at UVS_PH_C0 | diag(H0) by S index [176] at UVS_PH_HD
     int32_t n_pblk;                   // pose blocks of S the prior touches (ids in i_prior + 352)
     int32_t w_gacc;                   // 512-thread build only: the gather accumulators of the last linearization, [24][UVS_GT] (what a re-damping continues from; the 256-thread build keeps them in registers)
-    int32_t n_cimg, i_cimg;           // entries of H0 that are structurally non-zero in S: int32 index into the dense n x n H0 [n_cimg], then S offset [n_cimg]
+    int32_t n_cimg, w_cimg;           // entries of H0 that are structurally non-zero in S (pairs of prior columns a, b whose S indices satisfy i >= j): int32 index into the dense n x n H0 [n_cimg],
+                                      // then S offset [n_cimg] -- in the WORKSPACE (w_cimg, as ints), generated by setup_window from the prior's column map (round 4: it was 21 KB of every blob)
     int32_t ws_doubles;
     int32_t blob_bytes;
     int32_t cur_sel;                  // written by the kernel: which landmark buffer holds the final state

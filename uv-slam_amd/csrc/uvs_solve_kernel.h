@@ -2238,7 +2238,7 @@ UVS_DEV void asm_prior(const Ctx& c) {
         {   // H0 entries that are structurally non-zero in S: host table of (index into the dense n x n H0, S offset)
             const double* H0 = c.ws + h.w_prior_h0;
             const int tot = h.n_cimg;
-            const int* src = c.bi + h.i_cimg; const int* off = src + tot;
+            const int* src = (const int*)(c.ws + h.w_cimg); const int* off = src + tot;
             for (int t0 = tid; t0 < tot; t0 += 16 * NT) {      // up to 16 independent load pairs in flight per trip (one trip for the 10-frame prior)
                 int idx[16], sr[16]; double v[16], cur[16];
 #pragma unroll
@@ -2267,7 +2267,7 @@ UVS_DEV void asm_prior_load(const Ctx& c, PriorAdd& pa) {
     if (h.prior_n <= 0) return;
     const int n = h.prior_n, tot = h.n_cimg;
     const double* H0 = c.ws + h.w_prior_h0;
-    const int* src = c.bi + h.i_cimg; const int* off = src + tot;
+    const int* src = (const int*)(c.ws + h.w_cimg); const int* off = src + tot;
     int sr[PA_UN];
 #pragma unroll
     for (int u = 0; u < PA_UN; ++u) { const int t = tid + u * NT; const bool in = t < tot; pa.idx[u] = in ? off[t] : -1; sr[u] = in ? src[t] : 0; }
@@ -2287,7 +2287,7 @@ UVS_DEV void asm_prior_add(const Ctx& c, const PriorAdd& pa) {
     {   // a prior with more structural entries than PA_UN per lane: the rest as in asm_prior
         const double* H0 = c.ws + h.w_prior_h0;
         const int tot = h.n_cimg;
-        const int* src = c.bi + h.i_cimg; const int* off = src + tot;
+        const int* src = (const int*)(c.ws + h.w_cimg); const int* off = src + tot;
         for (int t = tid + PA_UN * NT; t < tot; t += NT) sh[L_S + off[t]] += H0[src[t]];
     }
     if (tid < UVS_RD) sh[L_HD + tid] += pa.hd;
@@ -2784,6 +2784,21 @@ UVS_DEV void setup_window(const Ctx& c, double* blob_rw, bool with_prior_image =
         imu_whiten_block(blk + UVS_IMU_COV, c.ws + h.w_imu_w + (size_t)b * UVS_IMU_WS, c.sh + L_S + 256 * wv, lane);
     }
     if (h.prior_n > 0 && with_prior_image) {
+        {   // The (H0 entry, S offset) table of the assembly (asm_prior): every pair of prior columns (a, b) whose S indices satisfy i >= j, in any order (each S entry takes
+            // exactly one of them, so the order of the table does not reach the sums).  Generated here from the column map instead of packed and uploaded per window.
+            const int n = h.prior_n, tot = h.n_cimg;
+            const int* cm = c.bi + h.i_prior + 80;
+            int* tab = (int*)(c.ws + h.w_cimg);
+            int* cnt = (int*)(c.sh + L_RED);
+            __syncthreads();
+            if (tid == 0) *cnt = 0;
+            __syncthreads();
+            for (int t = tid; t < n * n; t += NT) {
+                const int a = t / n, b = t - a * n, i = cm[a], j = cm[b];
+                if (i >= 0 && j >= 0 && i >= j) { const int k = atomicAdd(cnt, 1); if (k < tot) { tab[k] = t; tab[tot + k] = sidx(i, j); } }
+            }
+            __syncthreads();
+        }
         // The prior's quadratic form, ONCE per solve: H0 = J0^T J0 (dense n x n, both triangles), g0 = J0^T r0, c0 = r0^T r0 / 2 and diag(H0) by S index, in
         // the workspace.  J0 is staged in LDS (coalesced); the 16 x 16 tiles of H0 in the prior's own column order are a true contraction over the
         // n rows of J0: tile(ta, tb)[r][c] = sum_i J0[i][16 ta + r] J0[i][16 tb + c], ceil(n / 4) v_mfma_f64_16x16x4_f64 per tile, one tile per wave

@@ -802,7 +802,7 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
     }
     // compact image: only the entries whose row AND column are prior columns (a pose block owns 6 of the 16 rows of its S block, so 36 of 272
     // entries of a pose-pose block): what the per-linearization add reads (value + S offset) shrinks from 15 k to ~2.6 k entries
-    std::vector<int> csrc, coff;
+    int n_cimg = 0;      // (the table itself is generated on the device: setup_window)
     if (have_prior) {
         int inv_s[UVS_RD]; for (int q = 0; q < UVS_RD; ++q) inv_s[q] = -1;
         const uvs_prior& p = *w->prior;
@@ -820,13 +820,7 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
             const bool exb = p.block_kind[b] == UVS_BLOCK_EX_POSE && ex_on;
             for (int q = 0; q < loc; ++q) { const int si = exb ? UVS_EX_INDEX(q) : (basecol < 0 ? -1 : basecol + q); if (si >= 0) inv_s[si] = p.block_idx[b] + q; }
         }
-        for (size_t sl = 0; sl < pblk.size(); ++sl) {
-            const int b = pblk[sl] & 255, fa = (pblk[sl] >> 8) & 15, fb = (pblk[sl] >> 12) & 15;
-            for (int r = 0; r < 16; ++r) for (int cc = 0; cc < 16; ++cc)
-                if (inv_s[16 * fa + r] >= 0 && inv_s[16 * fb + cc] >= 0 && (fa != fb || cc <= r)) {
-                    csrc.push_back(inv_s[16 * fa + r] * p.n + inv_s[16 * fb + cc]); coff.push_back(b * UVS_BLK_SZ + r * UVS_BLK_LD + cc);      // (index into the dense n x n H0 of the workspace, S offset)
-                }
-        }
+        { int mapped = 0; for (int q = 0; q < UVS_RD; ++q) mapped += inv_s[q] >= 0; n_cimg = mapped * (mapped + 1) / 2; }      // pairs of mapped S indices i >= j
     }
     h.d_imu = d; d += std::max(h.n_imu, 1) * UVS_IMU_STRIDE;
     h.d_prior = d; d += h.prior_n * h.prior_n + 2 * h.prior_n + 144;
@@ -836,7 +830,6 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
     h.i_ln_lm = i; i += h.ln_stride; h.i_ln_fj = i; i += h.ln_stride; h.i_ln_vp = i; i += h.ln_stride; h.i_ln_beg = i; i += rup(h.n_lines + 1, 2);
     h.i_imu = i; i += 2 * std::max(h.n_imu, 1);
     h.i_prior = i; i += 80 + UVS_MAX_PRIOR_DIM + UVS_RD + UVS_NBLK;
-    h.i_cimg = i; i += 2 * (int)csrc.size() + 2;
     h.i_chunks = i; i += UVS_CHUNK_INTS * std::max(h.n_chunks, 1);
     h.i_wblk = i; i += UVS_NGRP;
     h.i_lists = i; i += (int)lists.size() + 2;
@@ -854,7 +847,8 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
     h.w_out = wsz; wsz += UVS_XDIM + std::max(h.n_points, 0) + 4 * std::max(h.n_lines, 0);
     h.n_pblk = (int)pblk.size();
     h.w_prior_h0 = wsz; wsz += UVS_PH_DOUBLES(h.prior_n);      // H0 = J0^T J0, g0, c0, diag(H0) per S index: written once per solve by setup_window
-    h.n_cimg = (int)csrc.size();
+    h.n_cimg = n_cimg;
+    h.w_cimg = wsz; wsz += n_cimg + 2;      // 2 x n_cimg ints
     h.w_relo2 = wsz; if (relo2) wsz += UVS_RELO2_DOUBLES;
     h.w_gacc = wsz; wsz += 8 * UVS_GROWS * UVS_GT;      // (the 512-thread k_solve: gather accumulators of the last linearization)
     h.ws_doubles = rup(wsz, 32);
@@ -891,7 +885,7 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
             }
         }
         for (size_t q = 0; q < pblk.size(); ++q) pt[80 + UVS_MAX_PRIOR_DIM + UVS_RD + q] = pblk[q];
-        for (size_t q = 0; q < csrc.size(); ++q) { I[h.i_cimg + q] = csrc[q]; I[h.i_cimg + csrc.size() + q] = coff[q]; }
+
     }
     for (size_t q = 0; q < chunks.size(); ++q) I[h.i_chunks + q] = chunks[q];
     if (!lists.empty()) std::memcpy(I + h.i_lists, lists.data(), lists.size() * sizeof(int));
