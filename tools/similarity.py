@@ -18,6 +18,9 @@ PAIRS = [  # (repo file, reference files)
     ("uv-slam_amd/host/utility.h", ["utility/utility.h", "utility/utility.cpp"]),
     ("uv-slam_amd/host/integration_base.h", ["factor/integration_base.h"]),
 ]
+# a repo function whose formulas live under ANOTHER name in the reference is compared with that one as well (the judge's round-4 note: the F / V block table of
+# the host's `propagate` is the reference's `midPointIntegration`, integration_base.h:54-128)
+ALIASES = {"propagate": ["midPointIntegration"]}
 TOKEN = re.compile(r"[A-Za-z_]\w*|\d+\.?\d*(?:[eE][-+]?\d+)?|->|::|<<|>>|<=|>=|==|!=|&&|\|\||\+\+|--|[-+*/%=<>!&|^~?:;,.(){}\[\]]")
 
 
@@ -69,12 +72,13 @@ def main():
                 for k, v in functions(strip(open(p).read())).items():
                     b.setdefault(k, []).extend(v)
         for name, defs in sorted(a.items()):
-            if name not in b:
+            cands = [tb for nm in [name] + ALIASES.get(name, []) for tb in b.get(nm, [])]
+            if not cands:
                 continue
             for ta in defs:
                 if len(ta) < 40:
                     continue
-                ratio = max(difflib.SequenceMatcher(None, ta, tb, autojunk=False).ratio() for tb in b[name])
+                ratio = max(difflib.SequenceMatcher(None, ta, tb, autojunk=False).ratio() for tb in cands)
                 rows.append((ratio, mine, name, len(ta)))
                 worst = max(worst, ratio)
     for ratio, mine, name, n in sorted(rows, reverse=True):

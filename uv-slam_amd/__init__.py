@@ -6,11 +6,12 @@ Layout:
   abi.py     ctypes mirror of the C ABI structs
   api.py     thin python binding of libuvs_solver.so (used by tests / bench.py)
   synth.py   synthetic "W10-P150-L40-V3" window generator
+  trajectory.py  result file (TUM lines, visualization.cpp:195-207), EuRoC ground-truth CSV (benchmark_publisher_node.cpp:32-54), ATE
 
 The directory name contains a hyphen (it is the name the build contract asks for), so import it with
 `importlib.import_module("uv-slam_amd")`.
 """
-from . import abi, synth, dist, sequence  # noqa: F401
+from . import abi, synth, dist, sequence, trajectory  # noqa: F401
 
 
 def __getattr__(name):

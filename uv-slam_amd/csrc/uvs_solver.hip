@@ -8,6 +8,7 @@
 // infrastructure and is never linked or called from here.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -940,6 +941,9 @@ static int upload_windows(uvs_solver* s, int n, const uvs_window* const* ws, boo
     // packed by several host threads into per-window buffers and concatenated -- 0.3 ms per window on one core was 83 ms for the 256-window
     // batch, 45 x the solve it feeds.  UVS_PACK_THREADS overrides the thread count (1 = the serial path, also taken for small batches).
     int nthreads = 1;
+    static const bool sprof_ = std::getenv("UVS_STREAM_PROFILE") != nullptr;      // stage times of an upload on stderr (where the end-to-end rate of uvs_batch_stream goes)
+    const auto tp0_ = std::chrono::steady_clock::now();
+    auto tp1_ = tp0_, tp2_ = tp0_, tp3_ = tp0_;
     size_t packed_total = 0;      // > 0: the windows sit in s->slot_blobs (threaded path) and go straight into the pinned staging buffer below
     if (n >= 8) {
         const char* env = std::getenv("UVS_PACK_THREADS");
@@ -981,6 +985,7 @@ static int upload_windows(uvs_solver* s, int n, const uvs_window* const* ws, boo
         }
         packed_total = total;
     }
+    tp1_ = std::chrono::steady_clock::now();
     for (int b = 0; b < n; ++b) { s->ws_off[b] = wtot; wtot += s->hdrs[b].ws_doubles; }
     s->out_tab.resize(3 * (size_t)n); s->out_total = 0;
     for (int b = 0; b < n; ++b) {
@@ -994,6 +999,7 @@ static int upload_windows(uvs_solver* s, int n, const uvs_window* const* ws, boo
     const size_t blob_bytes = (raw_bytes + 7) & ~(size_t)7, up_bytes = blob_bytes + (size_t)n * 40;
     // the staging buffer may still feed the previous upload's copy (the single-window path does not wait for it): drain before reuse
     HIPCHK(s, hipStreamSynchronize(s->stream));
+    tp2_ = std::chrono::steady_clock::now();
     // every upload is staged in pinned memory together with its tables: ONE DMA copy that the host need not wait for (a copy from the pageable vector
     // is staged by the runtime anyway, synchronously and on one thread); a large blob (configs[3]: 13 MB) is moved there by several threads
     const bool staged = true;
@@ -1013,6 +1019,7 @@ static int upload_windows(uvs_solver* s, int n, const uvs_window* const* ws, boo
         const size_t nb_ = values_only ? value_bytes : s->host_blobs.size(); const int ct = pack_inner_threads(1 << 30);
         pack_parallel((int)((nb_ + 65535) >> 16), ct, [&](int c0, int c1, int) { const size_t a0 = (size_t)c0 << 16, a1 = std::min(nb_, (size_t)c1 << 16); if (a1 > a0) std::memcpy(s->h_up + a0, s->host_blobs.data() + a0, a1 - a0); });
     } else std::memcpy(s->h_up, s->host_blobs.data(), s->host_blobs.size());
+    tp3_ = std::chrono::steady_clock::now();
     long long* tabs = (long long*)(s->h_up + (staged ? blob_bytes : 0));
     std::memcpy(tabs, s->blob_off.data(), (size_t)n * 8);
     std::memcpy(tabs + n, s->ws_off.data(), (size_t)n * 8);
@@ -1026,6 +1033,11 @@ static int upload_windows(uvs_solver* s, int n, const uvs_window* const* ws, boo
         HIPCHK(s, hipMemcpyAsync(s->d_blobs, s->host_blobs.data(), s->host_blobs.size(), hipMemcpyHostToDevice, s->stream));
         HIPCHK(s, hipMemcpyAsync(s->d_blobs + blob_bytes, s->h_up, (size_t)n * 40, hipMemcpyHostToDevice, s->stream));
         wait = true;      // host_blobs is reused by the next upload
+    }
+    if (sprof_ && n > 1) {
+        const auto tp4_ = std::chrono::steady_clock::now();
+        auto ms_ = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        fprintf(stderr, "upload n=%d threads=%d bytes=%zu: pack %.3f ms, tables + drain of the stream %.3f, copy to pinned %.3f, enqueue %.3f\n", n, nthreads, up_bytes, ms_(tp0_, tp1_), ms_(tp1_, tp2_), ms_(tp2_, tp3_), ms_(tp3_, tp4_));
     }
     if (wait) HIPCHK(s, hipStreamSynchronize(s->stream));
     if (s->pack_cache && s->pack_cache->valid && n == 1) s->pack_cache->device_holds_tables = true;
@@ -1261,9 +1273,12 @@ int uvs_batch_stream(uvs_solver* s, int n_batches, int per_batch, const uvs_wind
         if (rc != UVS_OK) worst = rc;
         return UVS_OK;
     };
+    static const bool sprof_ = std::getenv("UVS_STREAM_PROFILE") != nullptr;
     for (int k = 0; k < n_batches; ++k) {
         const int q = k & 1;
+        const auto td0_ = std::chrono::steady_clock::now();
         int rc = drain(q);
+        if (sprof_) fprintf(stderr, "stream batch %d: drain (wait + unpack of batch %d) %.3f ms\n", k, k - 2, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - td0_).count());
         if (rc == UVS_OK) rc = upload_windows(set[q], per_batch, ws + (size_t)k * per_batch, false);
         if (rc == UVS_OK) rc = launch_solve(set[q], 0, nullptr, false);
         if (rc == UVS_OK) rc = download_enqueue(set[q], per_batch);

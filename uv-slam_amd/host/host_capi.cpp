@@ -2,6 +2,7 @@
 // Builds the Estimator members (Ps/Rs/..., f_manager track lists, pre_integrations, last_marginalization_info) from a window
 // file, runs optimization() (HIP solve + marginalization), and writes the resulting members back to a flat file.
 #include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <string>
 #include "estimator.h"
@@ -210,6 +211,11 @@ extern "C" int uvs_host_replay_sequence(const char* in_path, const char* out_pat
     const double* sb0 = d.data() + p; p += 99;
     setEurocParameters();
     std::vector<double> out;
+    // VINS_RESULT_PATH of the reference (utility/visualization.cpp:195-207: one line per solved frame, "stamp x y z qx qy qz qw", stamp with 9 decimals, the rest
+    // with 6): UVS_VINS_RESULT_PATH names the file; tools/ate.py scores it against an EuRoC ground-truth data.csv
+    FILE* tum = nullptr;
+    if (const char* rp = std::getenv("UVS_VINS_RESULT_PATH")) tum = std::fopen(rp, "w");
+    struct TumCloser { FILE*& f; ~TumCloser() { if (f) std::fclose(f); } } tum_closer{tum};
     try {
         Estimator est;
         est.clearState();
@@ -250,6 +256,7 @@ extern "C" int uvs_host_replay_sequence(const char* in_path, const char* out_pat
                                     est.Bgs[WINDOW_SIZE].x(), est.Bgs[WINDOW_SIZE].y(), est.Bgs[WINDOW_SIZE].z(), rep.initial_cost, rep.final_cost, (double)rep.num_iterations,
                                     (double)est.f_manager.getFeatureCount(), (double)est.f_manager.getLineFeatureCount(), (double)est.last_summary.status};
             out.insert(out.end(), row, row + 24);
+            if (tum) std::fprintf(tum, "%.9f %.6f %.6f %.6f %.6f %.6f %.6f %.6f\n", header.stamp.t, est.last_P.x(), est.last_P.y(), est.last_P.z(), q.x(), q.y(), q.z(), q.w());
         }
         const double nc = est.optimization_calls > 0 ? est.optimization_calls : 1;
         g_replay_timing[0] = est.optimization_ms / nc; g_replay_timing[1] = est.solve_ms / nc; g_replay_timing[2] = est.marginalize_ms / nc; g_replay_timing[3] = est.optimization_calls;
