@@ -8,7 +8,7 @@ TL = 4096
 a = np.fromfile(sys.argv[1], dtype=np.int64).reshape(8, TL, 2)
 which = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 names = {1: "start", 2: "B0", 3: "passA", 4: "B1", 5: "passB", 6: "B2", 7: "B3", 8: "gather>", 10: "gather<", 20: "prep", 21: "chunks", 22: "imu", 23: "zero", 24: "part0", 25: "imuadd", 26: "prior", 27: "finish",
-         40: "imu:zeroed", 41: "imu:B", 42: "imu:raw", 43: "imu:B2", 30: "solve>", 31: "chol", 32: "trsv", 33: "backsub", 34: "staged", 35: "priorq", 36: "cost", 37: "reduced"}
+         50: "ds>", 51: "ds<", 52: "E1", 53: "xchg", 54: "stored", 55: "fold", 56: "imuB3", 40: "imu:zeroed", 41: "imu:B", 42: "imu:raw", 43: "imu:B2", 30: "solve>", 31: "chol", 32: "trsv", 33: "backsub", 34: "staged", 35: "priorq", 36: "cost", 37: "reduced"}
 waves = [w for w in range(8) if a[w, 0, 0] != 0]
 ev = [w for w in waves if (a[w, :, 0] == 1).any()]      # waves that log evaluation stamps
 # linearization boundaries on the first evaluator wave: stamp 1 that follows a stamp 10 / 7 by a long gap -> use chunk count: count stamps "1"
