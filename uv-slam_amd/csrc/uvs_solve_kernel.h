@@ -1462,7 +1462,11 @@ UVS_DEV ChunkDesc chunk_desc(const Ctx& c, int ch) {
 // ---- the DENSE Schur path (uvs_layout.h: UVS_DS_*; DevWin::dense; role-split linearization only).  Layout of a staged chunk:
 //     points:  rec[nob + 1][pt_rec] | Et[rup4(nlm)][UVS_DS_LD] | step table      lines:  rec[nob + 1][UVS_LN_REC] | X[nlm][UVS_DS_LNX] | Et[4 nlm][UVS_DS_LD] | step table
 // and the C buffer (15 tiles) at the end of the staging area, alive across the chunks of a linearization.
-static constexpr bool DENSE_CAP = ROLES;
+#ifdef UVS_DENSE_TU
+static constexpr bool DENSE_CAP = ROLES;      // (csrc/uvs_solve512d.hip: the instantiation that carries the dense path -- kept out of the default kernel, whose list walk it slowed by 1.7 % just by being there)
+#else
+static constexpr bool DENSE_CAP = false;
+#endif
 UVS_DEV bool dense_on(const Ctx& c) { return DENSE_CAP && c.hdr->dense != 0; }
 UVS_DEV int ds_rows(const ChunkDesc& d) { return d.type == 0 ? ((d.nlm + 3) & ~3) : 4 * d.nlm; }
 UVS_DEV double* ds_operand(const Ctx& c, const ChunkDesc& d) {

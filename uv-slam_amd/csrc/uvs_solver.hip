@@ -35,6 +35,11 @@ int uvs_k_solve512_init(const unsigned char* fa, const unsigned char* fb, int n)
 void uvs_k_solve512_launch(int n_windows, hipStream_t stream, char* blobs, const long long* blob_off, double* ws_all, const long long* ws_off,
                            const void* kopts, size_t kopts_bytes, uvs_report* reports, const void* dbg, size_t dbg_bytes);
 size_t uvs_k_solve512_arg_bytes(int which);
+// ... and the one that carries the dense path (uvs_solve512d.hip; UVS_DENSE_SCHUR=1)
+int uvs_k_solve512d_init(const unsigned char* fa, const unsigned char* fb, int n);
+int uvs_k_solve512d_launch(int n_windows, hipStream_t stream, char* blobs, const long long* blob_off, double* ws_all, const long long* ws_off,
+                           const void* kopts, size_t kopts_bytes, uvs_report* reports, const void* dbg, size_t dbg_bytes);
+int uvs_k_solve512d_timeline(long long* out, size_t n);
 int uvs_k_solve512_timeline(long long* out, size_t n);
 int uvs_k_large_chunks512_prof(long long* out, size_t n);
 void uvs_k_large_solve512_launch(hipStream_t stream, char* blob, double* ws, const void* kopts, size_t kopts_bytes, double* state, const double* reduced, int first, double radius, double* out,
@@ -57,7 +62,8 @@ struct uvs_solver {
     int large_solve_nt = 512;                // ... and for k_large_solve (UVS_LARGE_SOLVE_NT=256)
     int large_chunks_nt = 512;               // likewise for k_large_chunks (UVS_LARGE_CHUNKS_NT=256 selects the 256-thread kernel of this file)
     int ksolve_nt = 512;                     // which instantiation of the persistent kernel launch_solve uses (uvs_solve512.hip / this file's 256-thread one)
-    bool dense_schur = true;                 // windows for the persistent kernel are packed for the dense matrix-core Schur product (512-thread kernel only; UVS_DENSE_SCHUR=0: the list walk)
+    bool dense_schur = false;                // UVS_DENSE_SCHUR=1: windows for the persistent kernel are packed for the DENSE path of the 512-thread kernel (uvs_layout.h: UVS_DS_*: landmark Schur
+                                             // complement and direct terms on the matrix cores, no gather lists).  Parity-green and measured slower than the list walk on MI355X: opt-in
     int chunk_wgs() const { return std::max(1, n_cus - 1); }      // chunk workgroups of the persistent large-window kernels: one compute unit stays free for the frame-terms workgroup of the same launch
     hipStream_t stream;
     hipEvent_t ev0, ev1;
@@ -197,9 +203,9 @@ int uvs_create(const uvs_options* opts, int device, int max_batch, int max_point
     unsigned char fa[UVS_NBLK], fb[UVS_NBLK];
     for (int i = 0, b = 0; i < UVS_NF; ++i) for (int j = 0; j <= i; ++j, ++b) { fa[b] = (unsigned char)i; fb[b] = (unsigned char)j; }
     if (hipMemcpyToSymbol(HIP_SYMBOL(c_blk_fa), fa, sizeof(fa)) != hipSuccess || hipMemcpyToSymbol(HIP_SYMBOL(c_blk_fb), fb, sizeof(fb)) != hipSuccess) { delete s; return UVS_ERR_HIP; }
-    if (uvs_k_solve512_arg_bytes(0) != sizeof(KOpts) || uvs_k_solve512_arg_bytes(1) != sizeof(DebugOut) || uvs_k_solve512_init(fa, fb, UVS_NBLK) != UVS_OK) { delete s; return UVS_ERR_HIP; }
+    if (uvs_k_solve512_arg_bytes(0) != sizeof(KOpts) || uvs_k_solve512_arg_bytes(1) != sizeof(DebugOut) || uvs_k_solve512_init(fa, fb, UVS_NBLK) != UVS_OK || uvs_k_solve512d_init(fa, fb, UVS_NBLK) != UVS_OK) { delete s; return UVS_ERR_HIP; }
     { const char* e = std::getenv("UVS_KSOLVE_NT"); s->ksolve_nt = (e && std::atoi(e) == 256) ? 256 : 512; }
-    { const char* e = std::getenv("UVS_DENSE_SCHUR"); s->dense_schur = s->ksolve_nt == 512 && !(e && std::atoi(e) == 0); }
+    { const char* e = std::getenv("UVS_DENSE_SCHUR"); s->dense_schur = s->ksolve_nt == 512 && e && std::atoi(e) != 0; }
     { const char* e = std::getenv("UVS_LARGE_CHUNKS_NT"); s->large_chunks_nt = (e && std::atoi(e) == 256) ? 256 : 512; }
     { const char* e = std::getenv("UVS_LARGE_SOLVE_NT"); s->large_solve_nt = (e && std::atoi(e) == 256) ? 256 : 512; }      // A/B switch: 256 = the one-wave-per-SIMD instantiation of the persistent kernel
     // the LDS opt-in is a per-device function attribute: every handle sets it for its own device (the current one since hipSetDevice above)
@@ -1302,7 +1308,8 @@ static int launch_solve(uvs_solver* s, int debug, float* elapsed_ms, bool wait =
         dbg.S = s->d_dbg; dbg.g = dbg.S + UVS_RD * UVS_RD; dbg.hd = dbg.g + UVS_RD; dbg.dd = dbg.hd + UVS_RD; dbg.step = dbg.dd + UVS_RD; dbg.scal = dbg.step + UVS_RD;
     }
     HIPCHK(s, hipEventRecord(s->ev0, s->stream));
-    if (s->ksolve_nt == 512) uvs_k_solve512_launch(s->n_loaded, s->stream, s->d_blobs, s->d_blob_off, s->d_ws, s->d_ws_off, &ko, sizeof(ko), s->d_reports, &dbg, sizeof(dbg));
+    if (s->ksolve_nt == 512 && s->dense_schur) { if (uvs_k_solve512d_launch(s->n_loaded, s->stream, s->d_blobs, s->d_blob_off, s->d_ws, s->d_ws_off, &ko, sizeof(ko), s->d_reports, &dbg, sizeof(dbg)) != UVS_OK) { s->err = "k_solve (dense instantiation): argument layout mismatch"; return UVS_ERR_HIP; } }
+    else if (s->ksolve_nt == 512) uvs_k_solve512_launch(s->n_loaded, s->stream, s->d_blobs, s->d_blob_off, s->d_ws, s->d_ws_off, &ko, sizeof(ko), s->d_reports, &dbg, sizeof(dbg));
     else hipLaunchKernelGGL(k_solve, dim3(s->n_loaded), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_blob_off, s->d_ws, s->d_ws_off, ko, s->d_reports, dbg);
     HIPCHK(s, hipGetLastError());
     HIPCHK(s, hipEventRecord(s->ev1, s->stream));
@@ -1433,7 +1440,7 @@ int uvs_debug_first_iteration(uvs_solver* s, const uvs_window* w, double* S_lowe
     if (rc != UVS_OK) return rc;
     if (tl_path) {
         std::vector<long long> tl(8 * TL_PER_WAVE * 2);
-        if ((s->ksolve_nt == 512 ? uvs_k_solve512_timeline(tl.data(), tl.size()) == UVS_OK : hipMemcpyFromSymbol(tl.data(), HIP_SYMBOL(g_lin_tl), tl.size() * 8) == hipSuccess)) { if (FILE* f = std::fopen(tl_path, "wb")) { std::fwrite(tl.data(), 8, tl.size(), f); std::fclose(f); } }
+        if ((s->ksolve_nt == 512 ? (s->dense_schur ? uvs_k_solve512d_timeline(tl.data(), tl.size()) : uvs_k_solve512_timeline(tl.data(), tl.size())) == UVS_OK : hipMemcpyFromSymbol(tl.data(), HIP_SYMBOL(g_lin_tl), tl.size() * 8) == hipSuccess)) { if (FILE* f = std::fopen(tl_path, "wb")) { std::fwrite(tl.data(), 8, tl.size(), f); std::fclose(f); } }
     }
     const size_t nS = (size_t)UVS_RD * UVS_RD;
     if (S_lower) HIPCHK(s, hipMemcpy(S_lower, s->d_dbg, nS * 8, hipMemcpyDeviceToHost));
