@@ -18,6 +18,10 @@
 #include <thread>
 #include <vector>
 #include <future>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 
 #include "../../include/uvs_solver.h"
 #include "uvs_layout.h"
@@ -48,6 +52,35 @@ void uvs_k_large_chunks512_launch(int grid, hipStream_t stream, char* blob, doub
                                   double* partials, const double* ctl, int rank, int nranks, int n_chunk_wgs, double* fimg);
 }
 
+// Worker threads of a handle for batch packing: created once, woken per batch (sixteen std::thread creations and joins per batch -- twice: packing, then the copy into
+// the pinned staging buffer -- were a third of a millisecond of the 2.5 ms a 256-window batch spends on the host).
+struct PackPool {
+    std::vector<std::thread> th; std::mutex m; std::condition_variable cv_go, cv_done;
+    const std::function<void(int)>* job = nullptr; int gen = 0, pending = 0; bool stop = false;
+    void worker(int t) {
+        int seen = 0;
+        for (;;) {
+            const std::function<void(int)>* f;
+            { std::unique_lock<std::mutex> lk(m); cv_go.wait(lk, [&] { return stop || gen != seen; }); if (stop) return; seen = gen; f = job; }
+            (*f)(t);
+            { std::lock_guard<std::mutex> lk(m); if (--pending == 0) cv_done.notify_one(); }
+        }
+    }
+    bool ensure(int n) {      // false: thread creation failed (the caller packs on its own thread)
+        try { while ((int)th.size() < n) { const int t = (int)th.size(); th.emplace_back([this, t] { worker(t); }); } } catch (...) { return false; }
+        return true;
+    }
+    void run(int n, const std::function<void(int)>& f) {      // f(0 .. n-1) on n workers (n <= th.size()), the caller waits; workers beyond n see the generation and return at once
+        const std::function<void(int)> g = [&](int t) { if (t < n) f(t); };
+        { std::lock_guard<std::mutex> lk(m); job = &g; pending = (int)th.size(); ++gen; }
+        cv_go.notify_all();
+        std::unique_lock<std::mutex> lk(m); cv_done.wait(lk, [&] { return pending == 0; });
+    }
+    ~PackPool() { { std::lock_guard<std::mutex> lk(m); stop = true; } cv_go.notify_all(); for (auto& t : th) t.join(); }
+};
+// where pack_window may put a blob instead of the caller's vector: a bump allocator over the pinned staging buffer of the handle (batch packing: the windows of a batch go
+// straight to where the one host -> device copy starts; off = -1 afterwards: no room, the blob is in the vector)
+struct PackDst { std::atomic<size_t>* bump; char* base; size_t cap; long long off = -1; };
 struct PackCache;
 static void free_pack_cache(PackCache* c);
 struct MargDevScratch;
@@ -78,6 +111,7 @@ struct uvs_solver {
     uvs_prior marg_job_out;
     PackCache* pack_cache = nullptr;      // structure of the last large single window (allocated on first use)
     std::vector<std::vector<char>> slot_blobs;      // batch uploads: one packing buffer per batch slot, kept (with its pages) from batch to batch
+    PackPool* pool = nullptr;                       // ... and the worker threads that fill them (created on the first threaded batch)
     // ONE host -> device copy per upload: [blobs | blob_off[n] | ws_off[n] | out_tab[3 n]] staged in pinned memory; the three tables
     // live behind the blobs in the same device allocation (d_blob_off / d_ws_off / d_out_tab point into it)
     char* d_blobs = nullptr; size_t d_blobs_cap = 0;
@@ -131,7 +165,7 @@ static KOpts make_kopts(const uvs_options& o, int debug) {
 }
 
 struct DevWin;
-static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vector<char>& out, DevWin& hdr, std::string& err, int chunk_grid = 0, PackCache* cache = nullptr, bool want_dense = false);
+static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vector<char>& out, DevWin& hdr, std::string& err, int chunk_grid = 0, PackCache* cache = nullptr, bool want_dense = false, PackDst* dst = nullptr);
 
 extern "C" {
 
@@ -220,6 +254,7 @@ void uvs_destroy(uvs_solver* s) {
     if (!s) return;
     if (s->twin) { uvs_destroy(s->twin); s->twin = nullptr; }
     free_pack_cache(s->pack_cache); s->pack_cache = nullptr;
+    delete s->pool; s->pool = nullptr;
     free_marg_scratch(s->marg_dev); s->marg_dev = nullptr;
     (void)hipSetDevice(s->device);      // teardown: nothing useful to do with an error
     if (s->d_blobs) (void)hipFree(s->d_blobs);
@@ -399,7 +434,7 @@ static void fill_values(char* B, const DevWin& h, const uvs_window* w, bool td_o
     }
 }
 
-static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vector<char>& out, DevWin& hdr, std::string& err, int chunk_grid, PackCache* cache, bool want_dense) {
+static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vector<char>& out, DevWin& hdr, std::string& err, int chunk_grid, PackCache* cache, bool want_dense, PackDst* dst) {
     if (cache && cache->matches(w_in, opts, chunk_grid) && out.size() == (size_t)cache->hdr.blob_bytes) {      // same structure as the blob still sitting in `out`: values only
         fill_values(out.data(), cache->hdr, w_in, opts.estimate_td != 0, pack_inner_threads(w_in->n_point_obs + w_in->n_line_obs));
         hdr = cache->hdr;
@@ -971,9 +1006,16 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
     h.w_gacc = wsz; wsz += 8 * UVS_GROWS * UVS_GT;      // (the 512-thread k_solve: gather accumulators of the last linearization)
     h.ws_doubles = rup(wsz, 32);
     // fill
-    const size_t base = out.size();
-    out.resize(base + h.blob_bytes, 0);
-    char* B = out.data() + base;
+    char* B = nullptr;
+    if (dst && dst->base) {      // straight into the pinned staging buffer when it has room (blob offsets are multiples of 256 bytes either way)
+        const size_t at = dst->bump->fetch_add((size_t)h.blob_bytes);
+        if (at + (size_t)h.blob_bytes <= dst->cap) { B = dst->base + at; dst->off = (long long)at; std::memset(B, 0, (size_t)h.blob_bytes); }
+    }
+    if (!B) {
+        const size_t base = out.size();
+        out.resize(base + h.blob_bytes, 0);
+        B = out.data() + base;
+    }
     double* D = (double*)B; int* I = (int*)B;
     fill_values(B, h, w, td_on, inner_threads);
     // ---- the tables (index bookkeeping)
@@ -1062,9 +1104,10 @@ static int upload_windows(uvs_solver* s, int n, const uvs_window* const* ws, boo
     const auto tp0_ = std::chrono::steady_clock::now();
     auto tp1_ = tp0_, tp2_ = tp0_, tp3_ = tp0_;
     size_t packed_total = 0;      // > 0: the windows sit in s->slot_blobs (threaded path) and go straight into the pinned staging buffer below
+    bool packed_direct = false;   // ... or are there already (packed in place)
     if (n >= 8) {
         const char* env = std::getenv("UVS_PACK_THREADS");
-        nthreads = env ? std::atoi(env) : (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+        nthreads = env ? std::atoi(env) : (int)std::min<unsigned>(32u, std::max(1u, std::thread::hardware_concurrency() / 2));      // (half the hardware threads at most: SMT siblings share a core)
         nthreads = std::max(1, std::min(nthreads, n));
     }
     bool values_only = false;      // structure-cache hit AND the device still holds this window's tables: only the value sections travel
@@ -1088,21 +1131,38 @@ static int upload_windows(uvs_solver* s, int n, const uvs_window* const* ws, boo
         // per-slot buffers that live in the handle: a fresh 260 KB vector per window was a page fault per 4 KB of it, every batch (0.9 ms per window
         // on a cold buffer against 0.12 ms on a warm one)
         if ((int)s->slot_blobs.size() < n) s->slot_blobs.resize(n);
-        std::vector<int> rcs(n, UVS_OK); std::vector<std::string> errs(n);
-        {
-            std::vector<std::thread> pool;
-            for (int t = 0; t < nthreads; ++t)
-                pool.emplace_back([&, t] { for (int b = t; b < n; b += nthreads) { s->slot_blobs[b].clear(); rcs[b] = pack_window(ws[b], s->opts, s->slot_blobs[b], s->hdrs[b], errs[b], chunk_grid, nullptr, s->dense_schur); } });
-            for (auto& th : pool) th.join();
-        }
-        size_t total = 0;
+        std::vector<int> rcs(n, UVS_OK); std::vector<std::string> errs(n); std::vector<long long> placed(n, -1);
+        // The windows go STRAIGHT into the pinned staging buffer when it is large enough (it is from the second batch of a size on: the first one takes the vectors and
+        // sizes the buffer): every worker claims room with an atomic bump, so the blobs sit in completion order -- the kernel finds them through blob_off.  The buffer
+        // may still feed the previous upload's copy: drain first.
+        HIPCHK(s, hipStreamSynchronize(s->stream));
+        std::atomic<size_t> bump{0};
+        const size_t direct_cap = s->h_up_cap > (size_t)n * 40 + 64 ? s->h_up_cap - (size_t)n * 40 - 64 : 0;
+        const auto job = [&](int t) {
+            for (int b = t; b < n; b += nthreads) {
+                PackDst d{&bump, direct_cap ? s->h_up : nullptr, direct_cap, -1};
+                s->slot_blobs[b].clear();
+                rcs[b] = pack_window(ws[b], s->opts, s->slot_blobs[b], s->hdrs[b], errs[b], chunk_grid, nullptr, s->dense_schur, &d);
+                placed[b] = d.off;
+            }
+        };
+        if (!s->pool) s->pool = new PackPool();
+        if (s->pool->ensure(nthreads)) s->pool->run(nthreads, job);
+        else { const int nt_ = nthreads; nthreads = 1; job(0); nthreads = nt_; }      // (no worker threads: this thread packs everything)
+        bool all_placed = direct_cap > 0;
         for (int b = 0; b < n; ++b) {
             if (rcs[b] != UVS_OK) { s->err = errs[b]; s->n_loaded = 0; return rcs[b]; }      // the first failing window in batch order, as the serial path reports it
-            s->blob_off[b] = (long long)total; total += s->slot_blobs[b].size();
+            if (placed[b] < 0) all_placed = false;
+        }
+        size_t total = 0;
+        if (all_placed) { for (int b = 0; b < n; ++b) s->blob_off[b] = placed[b]; total = bump.load(); packed_direct = true; }
+        else {
+            // (a window that found no room has its blob in its vector; one that did is copied back out: this path runs when the batch outgrew the buffer)
+            for (int b = 0; b < n; ++b) if (placed[b] >= 0) s->slot_blobs[b].assign(s->h_up + placed[b], s->h_up + placed[b] + s->hdrs[b].blob_bytes);
+            for (int b = 0; b < n; ++b) { s->blob_off[b] = (long long)total; total += s->slot_blobs[b].size(); }
         }
         packed_total = total;
     }
-    tp1_ = std::chrono::steady_clock::now();
     for (int b = 0; b < n; ++b) { s->ws_off[b] = wtot; wtot += s->hdrs[b].ws_doubles; }
     s->out_tab.resize(3 * (size_t)n); s->out_total = 0;
     for (int b = 0; b < n; ++b) {
@@ -1120,18 +1180,17 @@ static int upload_windows(uvs_solver* s, int n, const uvs_window* const* ws, boo
     // every upload is staged in pinned memory together with its tables: ONE DMA copy that the host need not wait for (a copy from the pageable vector
     // is staged by the runtime anyway, synchronously and on one thread); a large blob (configs[3]: 13 MB) is moved there by several threads
     const bool staged = true;
-    if ((rc = ensure_pinned(s, &s->h_up, &s->h_up_cap, staged ? up_bytes : (size_t)n * 40)) != UVS_OK) return rc;
+    if ((rc = ensure_pinned(s, &s->h_up, &s->h_up_cap, staged ? up_bytes + (packed_total && !packed_direct ? up_bytes / 8 + 4096 : 0) : (size_t)n * 40)) != UVS_OK) return rc;      // (slack: the next batch of this size packs in place)
     { char* before = s->d_blobs; if ((rc = ensure(s, (void**)&s->d_blobs, &s->d_blobs_cap, up_bytes)) != UVS_OK) return rc; if (s->d_blobs != before) values_only = false; }
     // all doubles of a blob precede its int tables (pack_window: i = 2 d), so the value sections are ONE prefix
     const size_t value_bytes = values_only ? (size_t)4 * (size_t)s->hdrs[0].i_pt_lm : 0;
     if ((rc = ensure(s, (void**)&s->d_outpack, &s->d_outpack_cap, (size_t)s->out_total * 8 + (size_t)n * sizeof(uvs_report))) != UVS_OK) return rc;
     if ((rc = ensure(s, (void**)&s->d_ws, &s->d_ws_cap, (size_t)wtot * 8)) != UVS_OK) return rc;
     if ((rc = ensure(s, (void**)&s->d_reports, &s->d_rep_cap, (size_t)n * sizeof(uvs_report))) != UVS_OK) return rc;
-    if (packed_total) {      // every packing thread moves its own windows (67 MB for 256 canonical windows: one core would need ~10 ms)
-        std::vector<std::thread> pool;
-        for (int t = 0; t < nthreads; ++t)
-            pool.emplace_back([&, t] { for (int b = t; b < n; b += nthreads) std::memcpy(s->h_up + s->blob_off[b], s->slot_blobs[b].data(), s->slot_blobs[b].size()); });
-        for (auto& th : pool) th.join();
+    if (packed_direct) { /* the blobs are in the staging buffer already */ }
+    else if (packed_total) {      // every packing thread moves its own windows (67 MB for 256 canonical windows: one core would need ~10 ms)
+        const auto cp = [&](int t) { for (int b = t; b < n; b += nthreads) std::memcpy(s->h_up + s->blob_off[b], s->slot_blobs[b].data(), s->slot_blobs[b].size()); };
+        if (s->pool && s->pool->ensure(nthreads)) s->pool->run(nthreads, cp); else for (int t = 0; t < nthreads; ++t) cp(t);
     } else if (s->host_blobs.size() > ((size_t)4 << 20)) {
         const size_t nb_ = values_only ? value_bytes : s->host_blobs.size(); const int ct = pack_inner_threads(1 << 30);
         pack_parallel((int)((nb_ + 65535) >> 16), ct, [&](int c0, int c1, int) { const size_t a0 = (size_t)c0 << 16, a1 = std::min(nb_, (size_t)c1 << 16); if (a1 > a0) std::memcpy(s->h_up + a0, s->host_blobs.data() + a0, a1 - a0); });
