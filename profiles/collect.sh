@@ -8,7 +8,7 @@ TAG=${1:-r01}
 R=$(pwd)
 export TMPDIR=/tmp
 CMD="python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-replay --no-large --no-stream"
-LCMD="python $R/bench.py --steps 2 --warmup 1 --batch 4 --no-cpu-baseline --no-replay --no-fused-single --no-stream"      # the configs[3] window through the fused loop (kernel trace only)
+LCMD="python $R/bench.py --steps 2 --warmup 1 --batch 4 --no-cpu-baseline --no-replay --no-fused-single --no-stream --no-scale-point"      # the configs[3] window through the fused loop (kernel trace only)
 cd /tmp
 rm -rf $R/gpurun_out/prof_kt $R/gpurun_out/prof_fetch $R/gpurun_out/prof_write $R/gpurun_out/prof_sq $R/gpurun_out/prof_sq2
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_kt -o runc -- $CMD > $R/gpurun_out/prof_kt.log 2>&1

@@ -181,3 +181,22 @@ def test_window_file_loader_rejects_corrupt_headers(tmp_path):
         open(path, "wb").write(bad)
         with pytest.raises(ValueError):
             abi.Window.load(path)
+
+
+def test_prior_that_keeps_a_block_twice_is_refused(oracle):
+    """Two kept blocks on the same parameter block (or overlapping prior columns) would map two prior columns to one index of the reduced system; the device's (H0 entry,
+    S offset) table has one slot per pair of S indices (setup_window), so the packing refuses such a prior instead of letting the table overrun (round-4 advisor finding)."""
+    lib = uvs.api.lib()
+    lib.uvs_debug_pack_layout.argtypes = [C.POINTER(abi.Options), C.POINTER(abi.WindowC), C.POINTER(C.c_int32)]
+    w = uvs.synth.make_window(3, with_prior=True, marginalize_fn=lambda win, flag: oracle.marginalize(win, flag))
+    o = abi.default_options(); info = (C.c_int32 * 12)()
+    wc, keep = w.to_c()
+    assert lib.uvs_debug_pack_layout(C.byref(o), C.byref(wc), info) == abi.UVS_OK
+    poses = [b for b in range(w.prior.n_blocks) if w.prior.block_kind[b] == abi.BLOCK_POSE]
+    assert len(poses) >= 2
+    dup = w.copy(); dup.prior.block_frame[poses[1]] = dup.prior.block_frame[poses[0]]      # the same pose block twice
+    wc, keep = dup.to_c()
+    assert lib.uvs_debug_pack_layout(C.byref(o), C.byref(wc), info) == abi.UVS_ERR_INVALID_ARG
+    ov = w.copy(); ov.prior.block_idx[poses[1]] = ov.prior.block_idx[poses[0]] + 3        # overlapping columns of J0
+    wc, keep = ov.to_c()
+    assert lib.uvs_debug_pack_layout(C.byref(o), C.byref(wc), info) == abi.UVS_ERR_INVALID_ARG

@@ -295,3 +295,30 @@ def test_malformed_windows_are_errors_at_every_entry_point():
     tail = "\n".join((r.stdout + r.stderr).strip().splitlines()[-12:])
     assert r.returncode == 0, tail
     assert "0 wrong outcomes" in r.stdout, tail
+
+
+def test_prior_residual_near_zero_with_a_large_linearized_residual(solver, oracle):
+    """The kernel carries the prior in its quadratic form (cost = c0 + g0 . dx + dx . H0 dx / 2: prior_quad), the reference and the oracle as 0.5 |r0 + J0 dx|^2
+    (marginalization_factor.cpp:364).  The three terms cancel when the prior is (nearly) satisfied at a point far from its linearization point: |r0| large, r0 + J0 dx ~ 0.
+    Such a prior is built here from the product's own one -- r0 := r0 - (r0 + J0 dx(start)) + eps -- and the solve must still walk the oracle's path to its cost."""
+    marg = lambda win, flag: solver.marginalize(win, flag)
+    rng = np.random.default_rng(9)
+    for index in (2, 6):
+        w = synth.make_window(index, with_prior=True, marginalize_fn=marg).copy()
+        # move the start away from the prior's linearization point, so that |J0 dx| (and with it the new |r0|) is large
+        w.pose[:, :3] += 0.05 * rng.standard_normal((w.pose.shape[0], 3)); w.speedbias[:, :3] += 0.05 * rng.standard_normal((w.speedbias.shape[0], 3))
+        ev = oracle.evaluate(w, robust=True)
+        n = w.prior.n
+        r_at_start = np.asarray(ev.prior_r[:n], dtype=np.float64)
+        r0_old = w.prior.r0()
+        r0_new = r0_old - r_at_start + 1e-7 * rng.standard_normal(n)      # => residual at the start ~ 1e-7, |r0_new| = O(|J0 dx|)
+        for k in range(n): w.prior.linearized_residuals[k] = float(r0_new[k])
+        ev2 = oracle.evaluate(w, robust=True)
+        assert np.abs(np.asarray(ev2.prior_r[:n])).max() < 1e-5 and np.abs(r0_new).max() > 1e3 * np.abs(np.asarray(ev2.prior_r[:n])).max()
+        so, ro = oracle.solve(w)
+        sg, rg = solver.solve(w)
+        assert rg.status == 0 and rg.num_iterations == ro.num_iterations
+        assert list(rg.accepted[: rg.num_iterations + 1]) == list(ro.accepted[: ro.num_iterations + 1]) and rg.termination == ro.termination
+        assert abs(rg.initial_cost - ro.initial_cost) <= 1e-9 * ro.initial_cost and abs(rg.final_cost - ro.final_cost) <= 1e-6 * ro.final_cost
+        dp, dq = pose_deltas(sg.pose, so.pose)
+        assert dp < 1e-6 and dq < 1e-6

@@ -32,29 +32,32 @@ int uvs_k_solve512_init(const unsigned char* fa, const unsigned char* fb, int n)
     return UVS_OK;
 }
 // k_large_chunks with 512 threads per workgroup (grid = chunk workgroups + the frame-terms workgroup, as for the 256-thread kernel)
-void uvs_k_large_chunks512_launch(int grid, hipStream_t stream, char* blob, double* ws, const void* kopts, size_t kopts_bytes, const double* state, int sel, int first, double radius,
-                                  double* partials, const double* ctl, int rank, int nranks, int n_chunk_wgs, double* fimg) {
+int uvs_k_large_chunks512_launch(int grid, hipStream_t stream, char* blob, double* ws, const void* kopts, size_t kopts_bytes, const double* state, int sel, int first, double radius,
+                                 double* partials, const double* ctl, int rank, int nranks, int n_chunk_wgs, double* fimg) {
     KOpts ko;
-    if (kopts_bytes != sizeof(ko)) return;
+    if (kopts_bytes != sizeof(ko)) return UVS_ERR_INVALID_ARG;      // (nothing is launched: the caller must not read results)
     __builtin_memcpy(&ko, kopts, sizeof(ko));
     hipLaunchKernelGGL(k_large_chunks, dim3(grid), dim3(NT), LDS_BYTES, stream, blob, ws, ko, state, sel, first, radius, partials, LargeCtl{ctl, rank, nranks}, n_chunk_wgs, fimg);
+    return UVS_OK;
 }
 // kopts / dbg: the caller's uvsdev::KOpts / uvsdev::DebugOut (same definitions, other namespace)
-void uvs_k_solve512_launch(int n_windows, hipStream_t stream, char* blobs, const long long* blob_off, double* ws_all, const long long* ws_off,
-                           const void* kopts, size_t kopts_bytes, uvs_report* reports, const void* dbg, size_t dbg_bytes) {
+int uvs_k_solve512_launch(int n_windows, hipStream_t stream, char* blobs, const long long* blob_off, double* ws_all, const long long* ws_off,
+                          const void* kopts, size_t kopts_bytes, uvs_report* reports, const void* dbg, size_t dbg_bytes) {
     KOpts ko; DebugOut d;
-    if (kopts_bytes != sizeof(ko) || dbg_bytes != sizeof(d)) return;      // (the caller checks hipGetLastError and the reports; a layout mismatch is a build error)
+    if (kopts_bytes != sizeof(ko) || dbg_bytes != sizeof(d)) return UVS_ERR_INVALID_ARG;      // (nothing is launched: the caller reports an error instead of downloading stale reports)
     __builtin_memcpy(&ko, kopts, sizeof(ko)); __builtin_memcpy(&d, dbg, sizeof(d));
     hipLaunchKernelGGL(k_solve, dim3(n_windows), dim3(NT), LDS_BYTES, stream, blobs, blob_off, ws_all, ws_off, ko, reports, d);
+    return UVS_OK;
 }
 size_t uvs_k_solve512_arg_bytes(int which) { return which == 0 ? sizeof(KOpts) : sizeof(DebugOut); }
 // k_large_solve with 512 threads (one workgroup): the frame image arrives with twice the loads in flight, the factorization has six workers and the pivot chain its SIMD alone
-void uvs_k_large_solve512_launch(hipStream_t stream, char* blob, double* ws, const void* kopts, size_t kopts_bytes, double* state, const double* reduced, int first, double radius, double* out,
-                                 const double* ctl, int rank, int nranks, const double* fimg) {
+int uvs_k_large_solve512_launch(hipStream_t stream, char* blob, double* ws, const void* kopts, size_t kopts_bytes, double* state, const double* reduced, int first, double radius, double* out,
+                                const double* ctl, int rank, int nranks, const double* fimg) {
     KOpts ko;
-    if (kopts_bytes != sizeof(ko)) return;
+    if (kopts_bytes != sizeof(ko)) return UVS_ERR_INVALID_ARG;
     __builtin_memcpy(&ko, kopts, sizeof(ko));
     hipLaunchKernelGGL(k_large_solve, dim3(1), dim3(NT), LDS_BYTES, stream, blob, ws, ko, state, reduced, first, radius, out, LargeCtl{ctl, rank, nranks}, fimg);
+    return UVS_OK;
 }
 // debug == 7 (UVS_LARGE_PROF): the per-workgroup stamps of the last k_large_chunks launch (tools/large_timeline.py)
 int uvs_k_large_chunks512_prof(long long* out, size_t n) {

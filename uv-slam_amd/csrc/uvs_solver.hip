@@ -36,7 +36,7 @@ using namespace uvsdev;
 // the 512-thread instantiation of the persistent kernel (uvs_solve512.hip)
 extern "C" {
 int uvs_k_solve512_init(const unsigned char* fa, const unsigned char* fb, int n);
-void uvs_k_solve512_launch(int n_windows, hipStream_t stream, char* blobs, const long long* blob_off, double* ws_all, const long long* ws_off,
+int uvs_k_solve512_launch(int n_windows, hipStream_t stream, char* blobs, const long long* blob_off, double* ws_all, const long long* ws_off,
                            const void* kopts, size_t kopts_bytes, uvs_report* reports, const void* dbg, size_t dbg_bytes);
 size_t uvs_k_solve512_arg_bytes(int which);
 // ... and the one that carries the dense path (uvs_solve512d.hip; UVS_DENSE_SCHUR=1)
@@ -46,9 +46,9 @@ int uvs_k_solve512d_launch(int n_windows, hipStream_t stream, char* blobs, const
 int uvs_k_solve512d_timeline(long long* out, size_t n);
 int uvs_k_solve512_timeline(long long* out, size_t n);
 int uvs_k_large_chunks512_prof(long long* out, size_t n);
-void uvs_k_large_solve512_launch(hipStream_t stream, char* blob, double* ws, const void* kopts, size_t kopts_bytes, double* state, const double* reduced, int first, double radius, double* out,
+int uvs_k_large_solve512_launch(hipStream_t stream, char* blob, double* ws, const void* kopts, size_t kopts_bytes, double* state, const double* reduced, int first, double radius, double* out,
                                  const double* ctl, int rank, int nranks, const double* fimg);
-void uvs_k_large_chunks512_launch(int grid, hipStream_t stream, char* blob, double* ws, const void* kopts, size_t kopts_bytes, const double* state, int sel, int first, double radius,
+int uvs_k_large_chunks512_launch(int grid, hipStream_t stream, char* blob, double* ws, const void* kopts, size_t kopts_bytes, const double* state, int sel, int first, double radius,
                                   double* partials, const double* ctl, int rank, int nranks, int n_chunk_wgs, double* fimg);
 }
 
@@ -321,6 +321,14 @@ static int validate_window(const uvs_window* w, std::string& err) {
             const int loc = p.block_size[b] == 7 ? 6 : p.block_size[b];
             if (p.block_idx[b] < 0 || p.block_idx[b] + loc > p.n) { err = "prior block index out of range"; return UVS_ERR_INVALID_ARG; }
             if ((p.block_kind[b] == UVS_BLOCK_POSE || p.block_kind[b] == UVS_BLOCK_SPEEDBIAS) && (p.block_frame[b] < 0 || p.block_frame[b] >= UVS_NUM_FRAMES)) { err = "prior frame out of range"; return UVS_ERR_INVALID_ARG; }
+            // every kept block once, every prior column once: two blocks on the same parameter block would map two prior columns to one index of the reduced system, and the
+            // device's (H0 entry, S offset) table -- generated with one slot per pair of S indices -- would be overrun (setup_window)
+            for (int a = 0; a < b; ++a) {
+                const int loca = p.block_size[a] == 7 ? 6 : p.block_size[a];
+                const bool same_block = p.block_kind[a] == kind && (kind == UVS_BLOCK_EX_POSE || kind == UVS_BLOCK_TD || p.block_frame[a] == p.block_frame[b]);
+                const bool overlap = p.block_idx[a] < p.block_idx[b] + loc && p.block_idx[b] < p.block_idx[a] + loca;
+                if (same_block || overlap) { err = "prior keeps a parameter block twice / its blocks overlap"; return UVS_ERR_INVALID_ARG; }
+            }
         }
     }
     return UVS_OK;
@@ -1377,7 +1385,7 @@ static int launch_solve(uvs_solver* s, int debug, float* elapsed_ms, bool wait =
     }
     HIPCHK(s, hipEventRecord(s->ev0, s->stream));
     if (s->ksolve_nt == 512 && s->dense_schur) { if (uvs_k_solve512d_launch(s->n_loaded, s->stream, s->d_blobs, s->d_blob_off, s->d_ws, s->d_ws_off, &ko, sizeof(ko), s->d_reports, &dbg, sizeof(dbg)) != UVS_OK) { s->err = "k_solve (dense instantiation): argument layout mismatch"; return UVS_ERR_HIP; } }
-    else if (s->ksolve_nt == 512) uvs_k_solve512_launch(s->n_loaded, s->stream, s->d_blobs, s->d_blob_off, s->d_ws, s->d_ws_off, &ko, sizeof(ko), s->d_reports, &dbg, sizeof(dbg));
+    else if (s->ksolve_nt == 512) { if (uvs_k_solve512_launch(s->n_loaded, s->stream, s->d_blobs, s->d_blob_off, s->d_ws, s->d_ws_off, &ko, sizeof(ko), s->d_reports, &dbg, sizeof(dbg)) != UVS_OK) { s->err = "k_solve (512 threads): argument layout mismatch between the translation units"; return UVS_ERR_HIP; } }
     else hipLaunchKernelGGL(k_solve, dim3(s->n_loaded), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_blob_off, s->d_ws, s->d_ws_off, ko, s->d_reports, dbg);
     HIPCHK(s, hipGetLastError());
     HIPCHK(s, hipEventRecord(s->ev1, s->stream));
@@ -1632,7 +1640,12 @@ int uvs_marginalize_resident_begin(uvs_solver* s, const uvs_window* w, int flag)
     if (!s || !w || (flag != 0 && flag != 1)) return UVS_ERR_INVALID_ARG;
     if (s->marg_job.valid()) { s->err = "uvs_marginalize_resident_begin: the previous marginalization has not been waited for"; return UVS_ERR_INVALID_ARG; }
     // the worker owns the handle until uvs_marginalize_wait(): device selection is per thread, everything else (stream, pinned buffers, scratch) is the handle's own
-    s->marg_job = std::async(std::launch::async, [s, w, flag]() { return uvs_marginalize_resident(s, w, flag, &s->marg_job_out); });
+    try {
+        s->marg_job = std::async(std::launch::async, [s, w, flag]() { return uvs_marginalize_resident(s, w, flag, &s->marg_job_out); });
+    } catch (const std::exception& e) {      // (std::system_error when no thread can be created: nothing may cross the C boundary)
+        s->err = std::string("uvs_marginalize_resident_begin: could not start the worker thread: ") + e.what();
+        return UVS_ERR_HIP;
+    }
     return UVS_OK;
 }
 int uvs_marginalize_wait(uvs_solver* s, uvs_prior* out) {
@@ -1712,7 +1725,7 @@ int uvs_large_linearize(uvs_solver* s) {
     auto& L = s->L;
     HIPCHK(s, hipSetDevice(s->device));
     KOpts ko = make_kopts(s->opts, 0);
-    if (s->large_chunks_nt == 512) uvs_k_large_chunks512_launch(L.grid + 1, s->stream, s->d_blobs, s->d_ws, &ko, sizeof(ko), L.d_state, L.sel, L.first ? 1 : 0, L.radius, L.d_partials, nullptr, 0, 0, L.grid, L.d_fimg);
+    if (s->large_chunks_nt == 512) { if (uvs_k_large_chunks512_launch(L.grid + 1, s->stream, s->d_blobs, s->d_ws, &ko, sizeof(ko), L.d_state, L.sel, L.first ? 1 : 0, L.radius, L.d_partials, nullptr, 0, 0, L.grid, L.d_fimg) != UVS_OK) { s->err = "k_large_chunks (512 threads): argument layout mismatch"; return UVS_ERR_HIP; } }
     else hipLaunchKernelGGL(k_large_chunks, dim3(L.grid + 1), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, L.sel, L.first ? 1 : 0, L.radius, L.d_partials, LargeCtl{nullptr, 0, 0}, L.grid, L.d_fimg);
     hipLaunchKernelGGL(k_large_reduce, dim3((LG_RED + 15) / 16), dim3(256), 0, s->stream, L.d_partials, L.grid, L.d_reduced, LargeCtl{nullptr, 0, 0});
     HIPCHK(s, hipGetLastError());
@@ -1725,7 +1738,7 @@ int uvs_large_step(uvs_solver* s) {
     auto& L = s->L;
     HIPCHK(s, hipSetDevice(s->device));
     KOpts ko = make_kopts(s->opts, 0);
-    if (s->large_solve_nt == 512) uvs_k_large_solve512_launch(s->stream, s->d_blobs, s->d_ws, &ko, sizeof(ko), L.d_state, L.d_reduced, L.first ? 1 : 0, L.radius, L.d_out, nullptr, 0, 0, L.d_fimg);
+    if (s->large_solve_nt == 512) { if (uvs_k_large_solve512_launch(s->stream, s->d_blobs, s->d_ws, &ko, sizeof(ko), L.d_state, L.d_reduced, L.first ? 1 : 0, L.radius, L.d_out, nullptr, 0, 0, L.d_fimg) != UVS_OK) { s->err = "k_large_solve (512 threads): argument layout mismatch"; return UVS_ERR_HIP; } }
     else hipLaunchKernelGGL(k_large_solve, dim3(1), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, L.d_reduced, L.first ? 1 : 0, L.radius, L.d_out, LargeCtl{nullptr, 0, 0}, L.d_fimg);
     { const int bg = std::min(L.n_chunks, UVS_LARGE_OCC * s->chunk_wgs());      // (UVS_LARGE_OCC workgroups per compute unit: the kernel asks for little LDS and half the registers)
       hipLaunchKernelGGL(k_large_backsub, dim3(bg + 1), dim3(NT), LDS_BYTES_BACKSUB, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, L.sel, L.d_bsums, LargeCtl{nullptr, 0, 0}, bg, L.d_out); }
@@ -1952,12 +1965,12 @@ int uvs_large_solve_fused(uvs_solver* s, const uvs_window* w, uvs_state* out, uv
     const int bgrid = std::min(L.n_chunks, UVS_LARGE_OCC * s->chunk_wgs());      // k_large_backsub runs UVS_LARGE_OCC workgroups per compute unit
     HIPCHK(s, hipEventRecord(s->ev0, s->stream));
     for (int p = 0; p < passes; ++p) {
-        if (s->large_chunks_nt == 512) uvs_k_large_chunks512_launch(L.grid + 1, s->stream, s->d_blobs, s->d_ws, &ko, sizeof(ko), L.d_state, 0, 0, 0.0, L.d_partials, lc.ctl, lc.rank, lc.nranks, L.grid, L.d_fimg);
+        if (s->large_chunks_nt == 512) { if (uvs_k_large_chunks512_launch(L.grid + 1, s->stream, s->d_blobs, s->d_ws, &ko, sizeof(ko), L.d_state, 0, 0, 0.0, L.d_partials, lc.ctl, lc.rank, lc.nranks, L.grid, L.d_fimg) != UVS_OK) return fused_abort(s, "k_large_chunks (512 threads): argument layout mismatch"); }
         else hipLaunchKernelGGL(k_large_chunks, dim3(L.grid + 1), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, 0, 0, 0.0, L.d_partials, lc, L.grid, L.d_fimg);
         // (summing the partial rows inside k_large_solve instead of by a launch of its own was measured: one workgroup needs 15-24 us for what 314 do in 5)
         hipLaunchKernelGGL(k_large_reduce, dim3((LG_RED + 15) / 16), dim3(256), 0, s->stream, L.d_partials, rows, L.d_reduced, lc);
         if (L.comm) { const int e = r.AllReduce(L.d_reduced, L.d_reduced, LG_XCH, kNcclDouble, kNcclSum, L.comm, s->stream); if (e != 0) return fused_abort(s, "ncclAllReduce(reduced) failed"); }
-        if (s->large_solve_nt == 512) uvs_k_large_solve512_launch(s->stream, s->d_blobs, s->d_ws, &ko, sizeof(ko), L.d_state, L.d_reduced, 0, 0.0, L.d_out, lc.ctl, lc.rank, lc.nranks, L.d_fimg);
+        if (s->large_solve_nt == 512) { if (uvs_k_large_solve512_launch(s->stream, s->d_blobs, s->d_ws, &ko, sizeof(ko), L.d_state, L.d_reduced, 0, 0.0, L.d_out, lc.ctl, lc.rank, lc.nranks, L.d_fimg) != UVS_OK) return fused_abort(s, "k_large_solve (512 threads): argument layout mismatch"); }
         else hipLaunchKernelGGL(k_large_solve, dim3(1), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, L.d_reduced, 0, 0.0, L.d_out, lc, L.d_fimg);
         hipLaunchKernelGGL(k_large_backsub, dim3(bgrid + 1), dim3(NT), LDS_BYTES_BACKSUB, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, 0, L.d_bsums, lc, bgrid, L.d_out);
         if (L.comm) {

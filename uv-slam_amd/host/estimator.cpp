@@ -165,9 +165,17 @@ void Estimator::assembleWindow(uvs::WindowAssembly& wa) {
 }
 
 // The window a marginalization in flight reads (uvs_solver.h: uvs_marginalize_resident_begin -- everything `w` points to must outlive the call): the assembly moves
-// here (a moved std::vector keeps its buffer, so the descriptor's pointers stay good); inverse depths / line parameters are the para_* members, which nobody
-// rewrites before finishMarginalization() at the top of the next optimization().
-struct Estimator::PendingMarginalization { uvs::WindowAssembly wa; uvs_window w; };
+// here (a moved std::vector keeps its buffer, so the descriptor's pointers stay good); inverse depths / line parameters are copied (the para_* members are public and
+// vector2double() rewrites them); the OLD prior (w.prior = &last_marginalization_info->prior) is read in place: see the rule at pending_marginalization in estimator.h.
+struct Estimator::PendingMarginalization {
+    uvs::WindowAssembly wa; uvs_window w;
+    std::vector<double> inv_depth, line_orth;      // the worker's OWN copies of the landmark parameters: the para_* members they come from are public and rewritten by vector2double()
+    PendingMarginalization(uvs::WindowAssembly&& a, const uvs_window& v) : wa(std::move(a)), w(v) {
+        inv_depth.assign(v.inv_depth, v.inv_depth + std::max(v.n_points, 0)); line_orth.assign(v.line_orth, v.line_orth + 4 * std::max(v.n_lines, 0));
+        inv_depth.push_back(0.0); line_orth.push_back(0.0);      // (never empty: the descriptor wants non-null arrays)
+        w.inv_depth = inv_depth.data(); w.line_orth = line_orth.data();
+    }
+};
 
 void Estimator::finishMarginalization() {
     if (!pending_marginalization) return;
@@ -237,7 +245,7 @@ void Estimator::optimization() {      // estimator.cpp:761-1233
             }
         } else {
             // begin now, wait at the top of the next optimization(): the old prior (w.prior) and the observation arrays stay alive in pending_marginalization
-            pending_marginalization = new PendingMarginalization{std::move(wa), w};
+            pending_marginalization = new PendingMarginalization(std::move(wa), w);
             const int rc = uvs_marginalize_resident_begin(solver, &pending_marginalization->w, marginalization_flag == MARGIN_OLD ? 0 : 1);
             if (rc != UVS_OK) {
                 std::fprintf(stderr, "Estimator::optimization: marginalization could not start (%s: %s); continuing without a prior\n", uvs_status_string(rc), uvs_last_error(solver));

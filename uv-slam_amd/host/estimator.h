@@ -72,6 +72,9 @@ class Estimator {
     MarginalizationInfo* last_marginalization_info;
     // round 4: the marginalization of optimization() runs beside the caller's work between two frames (uvs_marginalize_resident_begin / _wait).  While it is in
     // flight the window it reads stays alive here: the assembly (observation arrays), the descriptor that points into it, and the OLD prior (its input).
+    // A marginalization may be IN FLIGHT between two optimization() calls (uvs_marginalize_resident_begin: a worker thread of the solver handle).  It owns copies of the
+    // observation arrays and of the landmark parameters, and reads last_marginalization_info (the previous prior) in place: call finishMarginalization() before touching
+    // last_marginalization_info from outside optimization() -- it blocks until the new prior is installed.
     struct PendingMarginalization;
     PendingMarginalization* pending_marginalization = nullptr;
     void finishMarginalization();      // blocks until the new prior is there and installs it as last_marginalization_info; a no-op when nothing is in flight
