@@ -290,7 +290,7 @@ int uvs_batch_upload(uvs_solver *s, int n, const uvs_window *const *ws);
 int uvs_batch_solve(uvs_solver *s, float *elapsed_ms);
 int uvs_batch_download(uvs_solver *s, int n, uvs_state *states, uvs_report *reps);
 /* A stream of n_batches batches of per_batch windows each (ws[k * per_batch + b] = window b of batch k), END TO END: host packing, upload, solve
- * and download of consecutive batches overlap on two buffer sets (no reference equivalent: offline replay of recorded windows, estimator.cpp:992
+ * and download of consecutive batches overlap on three buffer sets (no reference equivalent: offline replay of recorded windows, estimator.cpp:992
  * once per window).  states / reps: n_batches * per_batch entries (either may be NULL); wall_ms: wall time of the whole call.  Results are those
  * of uvs_batch_upload / uvs_batch_solve / uvs_batch_download batch by batch.  On an error in batch k (e.g. a malformed window) the batches before k have been
  * delivered, batch k and the later ones have not been touched, and the code of the first error is returned. */

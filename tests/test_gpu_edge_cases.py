@@ -209,11 +209,12 @@ def test_threaded_batch_packing_equals_serial(gpu_api):
 
 
 def test_batch_stream_equals_batch_by_batch(gpu_api):
-    """uvs_batch_stream: five heterogeneous batches through the double-buffered pipeline (packing of batch k + 1 on host threads while the GPU
-    runs H2D -> k_solve -> gather -> D2H of batch k; the two buffer sets alternate and each is reused twice) against upload / solve / download
-    of every batch on a fresh handle: bitwise equal states and reports.  Then once more on the same handle (the twin buffer set is reused)."""
+    """uvs_batch_stream: eight heterogeneous batches through the pipeline (packing of batch k + 1 on host threads and its H2D copy while the GPU
+    runs k_solve -> gather of batch k; three buffer sets take turns and each is reused at least twice; the results are written into pinned host
+    memory by the gather kernel) against upload / solve / download of every batch on a fresh handle: bitwise equal states and reports.  Then once
+    more on the same handle (the buffer sets are reused)."""
     rng = np.random.default_rng(12)
-    per, nb = 12, 5
+    per, nb = 12, 8
     ws = [synth.make_window(1200 + i, n_points=int(rng.integers(20, 200)), n_lines=int(rng.integers(0, 50)), n_tagged=0) for i in range(per * nb)]
     s = gpu_api.Solver(max_batch=16)
     st, rep, ms = s.stream(ws, per)
@@ -230,6 +231,22 @@ def test_batch_stream_equals_batch_by_batch(gpu_api):
             assert np.array_equal(st[i].inv_depth, sr[b].inv_depth) and np.array_equal(st[i].line_orth, sr[b].line_orth)
             assert rep2[i].final_cost == rep[i].final_cost and np.array_equal(st2[i].pose, st[i].pose)
     ref.close()
+
+
+@pytest.mark.parametrize("env", [{"UVS_STREAM_SETS": "2"}, {"UVS_STREAM_CHAIN": "0"}, {"UVS_STREAM_D2H_COPY": "1"}])
+def test_batch_stream_switches(gpu_api, env, monkeypatch):
+    """The A/B switches of the stream (two buffer sets; kernels not chained by events; results fetched by a device-to-host copy) give the same bits.
+    (Read once per process: this test runs them in a child.)"""
+    import subprocess, sys, os
+    code = ("import importlib, numpy as np, sys; sys.path.insert(0, %r); u = importlib.import_module('uv-slam_amd'); "
+            "ws = [u.synth.make_window(1300 + i, n_points=30 + 7 * i, n_lines=i %% 9, n_tagged=0) for i in range(28)]; s = u.api.Solver(max_batch=8); "
+            "st, rep, ms = s.stream(ws, 4); print(' '.join(repr(float(r.final_cost)) for r in rep)); print(repr(float(sum(np.abs(x.pose).sum() for x in st))))") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for e in ({}, env):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **e), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout)
+    assert outs[0] == outs[1] and len(outs[0].split()) == 29
 
 
 @pytest.mark.parametrize("form", ["persistent", "fused", "step-wise"])

@@ -115,6 +115,7 @@ struct uvs_solver {
     PackCache* pack_cache = nullptr;      // structure of the last large single window (allocated on first use)
     std::vector<std::vector<char>> slot_blobs;      // batch uploads: one packing buffer per batch slot, kept (with its pages) from batch to batch
     PackPool* pool = nullptr;                       // ... and the worker threads that fill them (created on the first threaded batch)
+    bool pool_borrowed = false;                     // (a buffer set of uvs_batch_stream uses its owner's pool)
     // ONE host -> device copy per upload: [blobs | blob_off[n] | ws_off[n] | out_tab[3 n]] staged in pinned memory; the three tables
     // live behind the blobs in the same device allocation (d_blob_off / d_ws_off / d_out_tab point into it)
     char* d_blobs = nullptr; size_t d_blobs_cap = 0;
@@ -260,7 +261,8 @@ void uvs_destroy(uvs_solver* s) {
     if (s->twin2) { uvs_destroy(s->twin2); s->twin2 = nullptr; }
     if (s->ev_done) { (void)hipEventDestroy(s->ev_done); s->ev_done = nullptr; }
     free_pack_cache(s->pack_cache); s->pack_cache = nullptr;
-    delete s->pool; s->pool = nullptr;
+    if (!s->pool_borrowed) delete s->pool;
+    s->pool = nullptr;
     free_marg_scratch(s->marg_dev); s->marg_dev = nullptr;
     (void)hipSetDevice(s->device);      // teardown: nothing useful to do with an error
     if (s->d_blobs) (void)hipFree(s->d_blobs);
@@ -1401,16 +1403,22 @@ int uvs_batch_solve(uvs_solver* s, float* elapsed_ms) {
 }
 
 // the two halves of a download: enqueue (gather kernel + ONE copy into pinned memory, nothing waits) and finish (wait, unpack)
-static int download_enqueue(uvs_solver* s, int n) {
+// `direct`: the gather kernel writes into the pinned host buffer itself and no copy is enqueued (uvs_batch_stream).  A device-to-host copy that waits for a kernel
+// holds up the copies enqueued after it on OTHER streams -- the upload of the next batch started only when this download had been done, i.e. after k_solve, and the
+// stream ran copy and kernel in series (profiles/r05_stream_timeline_before.txt; tools/micro_overlap.hip shows that the device itself overlaps them) --, and 1 MB of
+// posted writes over PCIe cost the gather kernel nothing that the copy did not cost.
+static int download_enqueue(uvs_solver* s, int n, bool direct = false) {
     // every window's final state (frames | inv_depth | line_orth, written by k_solve into its workspace) and its report are gathered on the
     // device and fetched with ONE copy into pinned memory (256 windows were 256 synchronous round trips once)
     const size_t nst = (size_t)(s->out_tab[3 * (size_t)(n - 1) + 2] + s->out_tab[3 * (size_t)(n - 1) + 1]);      // doubles of the first n states
     const size_t tot = nst * 8 + (size_t)n * sizeof(uvs_report);
     int rc;
     if ((rc = ensure_pinned(s, &s->h_out, &s->h_out_cap, tot)) != UVS_OK) return rc;
-    hipLaunchKernelGGL(k_pack_outputs, dim3(n), dim3(256), 0, s->stream, s->d_ws, s->d_out_tab, s->d_outpack, s->d_reports, (long long)nst);
+    double* out = s->d_outpack;
+    if (direct) { void* dp = nullptr; HIPCHK(s, hipHostGetDevicePointer(&dp, s->h_out, 0)); out = (double*)dp; }
+    hipLaunchKernelGGL(k_pack_outputs, dim3(n), dim3(256), 0, s->stream, s->d_ws, s->d_out_tab, out, s->d_reports, (long long)nst);
     HIPCHK(s, hipGetLastError());
-    HIPCHK(s, hipMemcpyAsync(s->h_out, s->d_outpack, tot, hipMemcpyDeviceToHost, s->stream));
+    if (!direct) HIPCHK(s, hipMemcpyAsync(s->h_out, s->d_outpack, tot, hipMemcpyDeviceToHost, s->stream));
     return UVS_OK;
 }
 static int download_finish(uvs_solver* s, int n, uvs_state* states, uvs_report* reps) {
@@ -1443,15 +1451,18 @@ int uvs_batch_download(uvs_solver* s, int n, uvs_state* states, uvs_report* reps
     return download_finish(s, n, states, reps);
 }
 
-// A STREAM of batches, end to end: packing (host threads), upload, solve and download of consecutive batches overlap.  Two buffer sets -- this handle and a
-// twin created on first use with the same options and capacities, each with its own stream, pinned staging and device buffers -- alternate: while the GPU
-// runs  H2D -> k_solve -> gather -> D2H  of batch k on one set, the host packs batch k + 1 into the other; a set is drained (wait + unpack) right before it
-// is reused.  Results equal uvs_batch_upload / solve / download of each batch (same packing, same kernel).
-// The prefetching form (UVS_STREAM_PREFETCH=1; the default is the copy-engine form below): THREE buffer sets.  Batch k is packed into the pinned
-// buffer of set k mod 3 and NOT copied: k_solve of batch k - 1 moves it to the device while it solves (KOpts::pf_*: every workgroup a slice, by the wave that sits out the
-// factorization), because on this platform a host-to-device copy does not overlap a kernel that holds every compute unit (profiles/r05_stream_timeline_before.txt: copy and
-// kernel strictly alternate, 0.85 + 1.46 ms per batch).  Only the first batch travels through hipMemcpyAsync.  In flight at once: batch k being packed by the host, batch k - 1
-// being solved (and prefetching k), batch k - 2 being downloaded; a set is drained (wait + unpack) right before it is packed again.
+// A STREAM of batches, end to end: packing (host threads), upload, solve and download of consecutive batches overlap.  Three buffer sets -- this handle and two
+// twins created on first use with the same options and capacities, each with its own stream, pinned staging and device buffers -- take turns: while the GPU runs
+// k_solve -> gather of batch k on one set, the copy engine moves batch k + 1 into the second and the host packs batch k + 2 into the third; a set is drained (wait +
+// unpack) right before it is reused.  Results equal uvs_batch_upload / solve / download of each batch (same packing, same kernel).
+// Two things decide whether copy and kernel really overlap (round 5; tools/micro_overlap.hip, tools/stream_trace.py, profiles/r05_stream_timeline*.txt):
+//   * NO device-to-host copy may be enqueued behind a kernel.  Such a copy waits in the copy engine's queue for its kernel, and the host-to-device copy of the next batch,
+//     enqueued later on ANOTHER stream, waits behind it: copy and kernel then strictly alternate (95 k solves/s).  The gather kernel therefore writes the results
+//     into the pinned host buffer itself (download_enqueue(direct)).
+//   * the kernels of consecutive batches are chained by events, see below.
+// With both the stream runs at 155 - 170 k solves/s, 1.50 - 1.65 ms per batch beside a kernel of 1.46 ms.
+// The PREFETCHING form (UVS_STREAM_PREFETCH=1) dates from before the first point was understood -- it lets k_solve of batch k - 1 fetch batch k from the pinned
+// buffer (KOpts::pf_*: every workgroup a slice, by the wave that sits out the factorization) -- and is slower than the copy engine: kept as an experiment.
 static int batch_stream_prefetch(uvs_solver* s, int n_batches, int per_batch, const uvs_window* const* ws, uvs_state* states, uvs_report* reps, double* wall_ms) {
     for (uvs_solver** t : {&s->twin, &s->twin2})
         if (!*t) { const int rc = uvs_create(&s->opts, s->device, s->max_batch, s->max_points, s->max_point_obs, s->max_lines, s->max_line_obs, t); if (rc != UVS_OK) { s->err = "uvs_batch_stream: could not create a buffer set"; return rc; } }
@@ -1508,16 +1519,23 @@ static int batch_stream_prefetch(uvs_solver* s, int n_batches, int per_batch, co
 int uvs_batch_stream(uvs_solver* s, int n_batches, int per_batch, const uvs_window* const* ws, uvs_state* states, uvs_report* reps, double* wall_ms) {
     if (!s || n_batches < 1 || per_batch < 1 || !ws) return UVS_ERR_INVALID_ARG;
     if (per_batch > s->max_batch) { s->err = "batch larger than max_batch"; return UVS_ERR_CAPACITY; }
-    // (UVS_STREAM_PREFETCH=1: the in-kernel prefetch of the next batch -- built, bitwise equal, and SLOWER on this platform: 66 - 83 k against 99 k solves/s end to end, a wave's
-    // 16-byte reads of pinned host memory do not reach the copy engine's rate)
+    // (UVS_STREAM_PREFETCH=1: the in-kernel prefetch of the next batch -- built, bitwise equal, and slower: a wave's 16-byte reads of pinned host memory do not reach the copy
+    // engine's rate)
     { const char* e = std::getenv("UVS_STREAM_PREFETCH"); if (s->ksolve_nt == 512 && per_batch >= 8 && e && std::atoi(e) != 0) return batch_stream_prefetch(s, n_batches, per_batch, ws, states, reps, wall_ms); }
-    if (!s->twin) {
-        const int rc = uvs_create(&s->opts, s->device, s->max_batch, s->max_points, s->max_point_obs, s->max_lines, s->max_line_obs, &s->twin);
-        if (rc != UVS_OK) { s->err = "uvs_batch_stream: could not create the second buffer set"; return rc; }
+    // THREE buffer sets by default (UVS_STREAM_SETS=2: two): with two, the host can pack batch k only after batch k - 2 has been solved, and pack + copy (1.0 + 0.85 ms) then sit on
+    // the critical path of every second kernel (1.72 ms per batch measured); with three the GPU always has a copied batch waiting
+    static const int NS = [] { const char* e = std::getenv("UVS_STREAM_SETS"); return e && std::atoi(e) == 2 ? 2 : 3; }();
+    for (uvs_solver** t : {&s->twin, &s->twin2}) {
+        if (t == &s->twin2 && NS < 3) break;
+        if (!*t) { const int rc = uvs_create(&s->opts, s->device, s->max_batch, s->max_points, s->max_point_obs, s->max_lines, s->max_line_obs, t); if (rc != UVS_OK) { s->err = "uvs_batch_stream: could not create a buffer set"; return rc; } }
+        if (!s->pool) s->pool = new PackPool();
+        if (!(*t)->pool) { (*t)->pool = s->pool; (*t)->pool_borrowed = true; }      // one pool of packing threads for all sets (they pack one after the other)
     }
     const auto t0 = std::chrono::steady_clock::now();
-    uvs_solver* set[2] = {s, s->twin};
-    int pending[2] = {-1, -1};      // batch index in flight on each set
+    uvs_solver* set[3] = {s, s->twin, s->twin2};
+    static const bool chain_ = [] { const char* e = std::getenv("UVS_STREAM_CHAIN"); return !(e && e[0] == '0'); }();
+    for (int j = 0; j < NS; ++j) if (!set[j]->ev_done) HIPCHK(s, hipEventCreateWithFlags(&set[j]->ev_done, hipEventDisableTiming));
+    int pending[3] = {-1, -1, -1};      // batch index in flight on each set
     int worst = UVS_OK;
     const auto drain = [&](int q) -> int {
         if (pending[q] < 0) return UVS_OK;
@@ -1530,26 +1548,30 @@ int uvs_batch_stream(uvs_solver* s, int n_batches, int per_batch, const uvs_wind
     };
     static const bool sprof_ = std::getenv("UVS_STREAM_PROFILE") != nullptr;
     for (int k = 0; k < n_batches; ++k) {
-        const int q = k & 1;
+        const int q = k % NS;
         const auto td0_ = std::chrono::steady_clock::now();
         int rc = drain(q);
-        if (sprof_) fprintf(stderr, "stream batch %d: drain (wait + unpack of batch %d) %.3f ms\n", k, k - 2, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - td0_).count());
+        if (sprof_) fprintf(stderr, "stream batch %d: drain (wait + unpack of batch %d) %.3f ms\n", k, k - NS, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - td0_).count());
         if (rc == UVS_OK) rc = upload_windows(set[q], per_batch, ws + (size_t)k * per_batch, false);
+        // the kernels run one after the other (an event chain through the sets): two k_solve launches on two streams otherwise share the compute units workgroup by workgroup,
+        // both finish late and together, and the host -- which packs batch k + 1 into the set of the batch that finishes first -- stalls and then has two batches to pack in a row
+        if (rc == UVS_OK && chain_ && k > 0 && hipStreamWaitEvent(set[q]->stream, set[(k - 1) % NS]->ev_done, 0) != hipSuccess) { s->err = "hipStreamWaitEvent failed"; rc = UVS_ERR_HIP; }
         if (rc == UVS_OK) rc = launch_solve(set[q], 0, nullptr, false);
-        if (rc == UVS_OK) rc = download_enqueue(set[q], per_batch);
+        if (rc == UVS_OK && chain_ && hipEventRecord(set[q]->ev_done, set[q]->stream) != hipSuccess) { s->err = "hipEventRecord failed"; rc = UVS_ERR_HIP; }
+        if (rc == UVS_OK) rc = download_enqueue(set[q], per_batch, std::getenv("UVS_STREAM_D2H_COPY") == nullptr);
         if (rc != UVS_OK) {
             // batch k failed before it was enqueued: the batch still in flight on the OTHER buffer set (k - 1) is delivered like the ones before it, so that on
             // return every batch < k holds results and nothing from k on does; the first error code is the one returned
             if (set[q] != s) s->err = set[q]->err;
             const std::string first_err = s->err;
-            (void)drain(q ^ 1);
-            (void)hipStreamSynchronize(set[0]->stream); (void)hipStreamSynchronize(set[1]->stream);
+            for (int j = 1; j < NS; ++j) (void)drain((q + j) % NS);      // (oldest first)
+            for (int j = 0; j < NS; ++j) (void)hipStreamSynchronize(set[j]->stream);
             s->err = first_err;
             return rc;
         }
         pending[q] = k;
     }
-    for (int q = 0; q < 2; ++q) { const int rc = drain(q); if (rc != UVS_OK) return rc; }
+    for (int j = 0; j < NS; ++j) { const int rc = drain((n_batches + j) % NS); if (rc != UVS_OK) return rc; }      // (oldest first)
     if (wall_ms) *wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return worst;
 }
