@@ -109,8 +109,7 @@ __device__ long long g_lin_tl[8 * TL_PER_WAVE * 2];
     if (n_ < TL_PER_WAVE) { g_lin_tl[2 * (w_ * TL_PER_WAVE + n_)] = (id); g_lin_tl[2 * (w_ * TL_PER_WAVE + n_) + 1] = clock64(); (c).sh[L_WPROF + w_] = (double)(n_ + 1); } } } while (0)
 
 enum { C_COST = 0, C_RADIUS, C_DECR, C_XNORM, C_GMAX, C_CAND, C_MCC, C_STEP2, C_XC2, C_GO, C_IT, C_INVALID, C_CUR, C_FIRST,
-       C_TERM, C_NSUCC, C_CHOLOK, C_GMAXLM, C_TIMEUP,
-       C_PF_SRC, C_PF_DST, C_PF_POS, C_PF_END };      // prefetch slice of this workgroup: source / destination pointers (bit patterns), next and last 16-byte unit
+       C_TERM, C_NSUCC, C_CHOLOK, C_GMAXLM, C_TIMEUP };
 
 struct KOpts {   // device copy of uvs_options
     int max_it, ex_free, keep_cand, jacobi;
@@ -120,11 +119,6 @@ struct KOpts {   // device copy of uvs_options
     int debug;
     long long max_ticks;      // options.max_solver_time_in_seconds in ticks of the 100 MHz wall clock (wall_clock64); 0 = no cap
     int redamp;      // 1 (default): a rejected step is followed by a re-damping of the stored linearization; 0 (UVS_REDAMP=0 at uvs_create): by a new linearization
-    // In-kernel prefetch of the NEXT batch (uvs_batch_stream): while this launch solves its windows, every workgroup moves an equal slice of the next batch's packed blobs from
-    // the pinned host buffer (pf_src, mapped into the device's address space) to the device buffer the next launch reads (pf_dst).  On this platform a host-to-device copy does
-    // not overlap a kernel that holds every register of every SIMD (profiles/r05_stream_timeline_before.txt): the copy engine's work is done by the wave that sits out the
-    // factorization instead (chol_factor: the pivot chain's SIMD neighbour), 16 bytes per lane and load, a few KB per LM iteration.  pf_bytes = 0: nothing to prefetch.
-    const char* pf_src; char* pf_dst; long long pf_bytes;
 };
 
 __constant__ unsigned char c_blk_fa[UVS_NBLK];
@@ -700,41 +694,13 @@ UVS_DEV void chol_panel_operand(double* sh, int k, int lane, double* Bw) {      
     }
 }
 
-// ---- in-kernel prefetch of the next batch's blobs (KOpts::pf_*).  The slice of this workgroup, in 16-byte units, and the progress live in LDS control words.
-typedef unsigned long long u64_t;
-typedef int i4_t __attribute__((ext_vector_type(4)));
-UVS_DEV double u64_as_double(u64_t v) { return __longlong_as_double((long long)v); }
-UVS_DEV u64_t double_as_u64(double v) { return (u64_t)__double_as_longlong(v); }
-UVS_DEV void prefetch_init(double* sh, const KOpts& o) {      // one lane, before the first barrier of the kernel
-    const long long units = (o.pf_bytes + 15) >> 4, per = (units + gridDim.x - 1) / gridDim.x;
-    const long long lo = per * blockIdx.x, hi = lo + per < units ? lo + per : units;
-    sh[L_CTRL + C_PF_SRC] = u64_as_double((u64_t)o.pf_src); sh[L_CTRL + C_PF_DST] = u64_as_double((u64_t)o.pf_dst);
-    sh[L_CTRL + C_PF_POS] = (double)(lo < hi ? lo : hi); sh[L_CTRL + C_PF_END] = (double)hi;
-}
-// `lanes` consecutive lanes (lane index `l`) move up to `max_units` units: PF_UN loads per lane in flight (a read of pinned host memory is a PCIe round trip of a few microseconds)
-static constexpr int PF_UN = 8;
-UVS_DEV void prefetch_piece(double* sh, int l, int lanes, long long max_units, bool keep_pos = true) {
-    const long long pos = (long long)sh[L_CTRL + C_PF_POS], end = (long long)sh[L_CTRL + C_PF_END];
-    if (pos >= end) return;
-    const i4_t* src = (const i4_t*)double_as_u64(sh[L_CTRL + C_PF_SRC]); i4_t* dst = (i4_t*)double_as_u64(sh[L_CTRL + C_PF_DST]);
-    const long long stop = pos + max_units < end ? pos + max_units : end;
-    for (long long b = pos + l; b < stop; b += (long long)PF_UN * lanes) {
-        i4_t v[PF_UN];
-#pragma unroll
-        for (int u = 0; u < PF_UN; ++u) { const long long i = b + (long long)u * lanes; v[u] = src[i < stop ? i : b]; }
-#pragma unroll
-        for (int u = 0; u < PF_UN; ++u) { const long long i = b + (long long)u * lanes; if (i < stop) __builtin_nontemporal_store(v[u], dst + i); }
-    }
-    wave_sync();
-    if (keep_pos && l == 0) sh[L_CTRL + C_PF_POS] = (double)stop;      // (read again only after a workgroup barrier; the kernel's last call, by all waves, leaves it alone)
-}
 // ONE workgroup barrier per block column.  Inside a column the rows are statically owned -- wave 0: the diagonal block (k, k) and the
 // block (k+1, k) below it; worker w: rows k+2+w, k+2+w+nwork, ... -- so a block's last term (A), its panel solve (S3) and the store in
 // between stay inside one wave, and the only cross-wave dependency left inside the column is W_k, which the workers wait for on an LDS
 // flag after they have done their look-ahead (terms j < k of column k+1).  The two-barrier version made every wave wait for the
 // slowest one twice per column and left the pivot chain idle during the whole panel phase.
 template <bool half>
-UVS_DEV void chol_factor_impl(double* sh, int debug, int pf) {
+UVS_DEV void chol_factor_impl(double* sh, int debug) {
     MiniCtx c; c.sh = sh; c.o.debug = debug;
     const int tid = lane_tid(), lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform ON PURPOSE: item indices derived from it select code paths
@@ -759,8 +725,6 @@ UVS_DEV void chol_factor_impl(double* sh, int debug, int pf) {
 #define UVS_FLAG_WAIT(idx, val) while (__hip_atomic_load(flg + (idx), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < (val)) __builtin_amdgcn_s_sleep(1);
 #define UVS_FLAG_SET(idx) if (lane == 0) __hip_atomic_store(flg + (idx), 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     __syncthreads();
-    // the wave that sits out the factorization (the pivot chain's SIMD neighbour) moves a piece of the next batch's blobs meanwhile: 1536 units = 24 KB per factorization
-    if (pf && idle_wave && half) prefetch_piece(sh, lane, 64, 1536);
     for (int k = 0; k < UVS_NF; ++k) {
         double* Dk = sblk(sh, k, k);
         if (idle_wave) { if (!half && k > 0) __syncthreads(); continue; }
@@ -1018,16 +982,15 @@ UVS_DEV void chol_factor_impl(double* sh, int debug, int pf) {
 // LDS with ds_* instructions (a `double*` parameter would degrade to flat loads).
 // Two instantiations (half-row pairs / full rows), each a call of its own: together in one function they need 248 VGPRs + 64 AGPRs, which reaches into the
 // callee-saved registers -- 50 scratch stores and loads per lane around every factorization, 0.18 GB of traffic per 256-window launch.
-__device__ __attribute__((noinline)) void chol_factor_call(int debug, int pf) {
+__device__ __attribute__((noinline)) void chol_factor_call(int debug) {
     extern __shared__ __attribute__((aligned(16))) double sh_chol[];
-    chol_factor_impl<true>(sh_chol, debug, pf);
+    chol_factor_impl<true>(sh_chol, debug);
 }
 __device__ __attribute__((noinline)) void chol_factor_call_full_rows(int debug) {
     extern __shared__ __attribute__((aligned(16))) double sh_chol[];
-    chol_factor_impl<false>(sh_chol, debug, 0);
+    chol_factor_impl<false>(sh_chol, debug);
 }
-// pf: the calling kernel has set up a prefetch slice (k_solve with KOpts::pf_bytes > 0; the other kernels that factor leave the control words alone)
-UVS_DEV void chol_factor(const Ctx& c, int pf = 0) { if (c.hdr->chol_half_ok) chol_factor_call(c.o.debug, pf); else chol_factor_call_full_rows(c.o.debug); }
+UVS_DEV void chol_factor(const Ctx& c) { if (c.hdr->chol_half_ok) chol_factor_call(c.o.debug); else chol_factor_call_full_rows(c.o.debug); }
 
 // back substitution L^T x = y in place (y in L_DLT, produced by chol_factor); the diagonal solves are mat-vecs with W^T.
 // One wave does all of it: the chain x_k -> (update of the rows above) -> x_k-1 is serial anyway, and inside a single wave it
@@ -3521,7 +3484,6 @@ __global__ __launch_bounds__(NT) void k_solve(char* blobs, const long long* blob
     for (int i = tid; i < (int)(sizeof(uvs_report) / 4); i += NT) ((int*)rep)[i] = 0;
     if (tid < 24) sh[L_PROF + tid] = (tid == 23) ? (double)clock64() : 0.0;
     if (tid < 8) sh[L_WPROF + tid] = 0.0;
-    if (tid == 0) prefetch_init(sh, o);
     setup_window(c, (double*)blob);
     __syncthreads();
     UVS_PROF(c, P_SETUP);
@@ -3581,7 +3543,7 @@ __global__ __launch_bounds__(NT) void k_solve(char* blobs, const long long* blob
         }
         UVS_PROF(c, P_MISC);
         UVS_TLOG(c, 30);
-        chol_factor(c, o.pf_bytes > 0 ? 1 : 0);
+        chol_factor(c);
         UVS_PROF(c, P_CHOL);
         UVS_TLOG(c, 31);
         chol_solve(c);
@@ -3652,7 +3614,6 @@ __global__ __launch_bounds__(NT) void k_solve(char* blobs, const long long* blob
     }
     __syncthreads();
     UVS_PROF(c, P_MISC);
-    if (o.pf_bytes > 0) prefetch_piece(sh, tid, NT, 1LL << 40, false);      // what the factorizations of this window left of its slice (a solve that ended early, the 256-thread build)
     if (o.debug && dbg.scal && tid < P_LAST) dbg.scal[8 + tid] = sh[L_PROF + tid];
     if (o.debug && dbg.scal && tid < 8) dbg.scal[24 + tid] = sh[L_WPROF + tid];
     if (tid < UVS_XDIM) c.ws[h.w_out + tid] = sh[L_X + tid];

@@ -91,9 +91,8 @@ struct uvs_solver {
     int max_batch;
     int max_points = 0, max_point_obs = 0, max_lines = 0, max_line_obs = 0;      // per-window capacities promised at uvs_create
     uvs_solver* twin = nullptr;              // second buffer set of uvs_batch_stream (created on first use, destroyed with this handle)
-    uvs_solver* twin2 = nullptr;             // ... and the third (the prefetching form of the stream keeps three batches in flight: packed | prefetched | solving)
-    hipEvent_t ev_done = nullptr;            // recorded behind a set's k_solve in the prefetching stream: the next set's launch waits for it (its blobs are this kernel's output)
-    size_t up_bytes_last = 0;                // bytes of the last staged upload (blobs + tables): what a prefetching launch moves
+    uvs_solver* twin2 = nullptr;             // ... and the third (in flight at once: a batch being packed, one being copied, one being solved)
+    hipEvent_t ev_done = nullptr;            // recorded behind a set's k_solve in the stream: the next set's launch waits for it (the kernels of consecutive batches run one after the other)
     int n_cus = 256;                         // compute units of the device
     int large_solve_nt = 512;                // ... and for k_large_solve (UVS_LARGE_SOLVE_NT=256)
     int large_chunks_nt = 512;               // likewise for k_large_chunks (UVS_LARGE_CHUNKS_NT=256 selects the 256-thread kernel of this file)
@@ -164,7 +163,6 @@ static KOpts make_kopts(const uvs_options& o, int debug) {
     k.ftol = o.function_tolerance; k.gtol = o.gradient_tolerance; k.ptol = o.parameter_tolerance;
     k.max_ticks = o.max_solver_time_in_seconds > 0.0 ? std::max(1LL, (long long)(o.max_solver_time_in_seconds * 1e8)) : 0LL;      // wall_clock64(): 100 MHz
     k.max_invalid = o.max_consecutive_invalid_steps; k.debug = debug;
-    k.pf_src = nullptr; k.pf_dst = nullptr; k.pf_bytes = 0;
     { const char* e = std::getenv("UVS_REDAMP"); k.redamp = (e && e[0] == '0') ? 0 : 1; }      // diagnostic switch, read per launch (tests, A/B): 0 = re-linearize after every rejected step
     return k;
 }
@@ -1102,7 +1100,7 @@ __global__ void k_pack_outputs(const double* ws, const long long* tab, double* o
     for (int t = threadIdx.x; t < RD; t += blockDim.x) out[rep_dst + (long long)blockIdx.x * RD + t] = r[t];
 }
 
-static int upload_windows(uvs_solver* s, int n, const uvs_window* const* ws, bool wait, int chunk_grid = 0, bool no_copy = false) {
+static int upload_windows(uvs_solver* s, int n, const uvs_window* const* ws, bool wait, int chunk_grid = 0) {
     if (!s || n < 1 || !ws) return UVS_ERR_INVALID_ARG;
     if (n > s->max_batch) { s->err = "batch larger than max_batch"; return UVS_ERR_CAPACITY; }
     HIPCHK(s, hipSetDevice(s->device));
@@ -1197,7 +1195,7 @@ static int upload_windows(uvs_solver* s, int n, const uvs_window* const* ws, boo
     // is staged by the runtime anyway, synchronously and on one thread); a large blob (configs[3]: 13 MB) is moved there by several threads
     const bool staged = true;
     if ((rc = ensure_pinned(s, &s->h_up, &s->h_up_cap, staged ? up_bytes + (packed_total && !packed_direct ? up_bytes / 8 + 4096 : 0) : (size_t)n * 40)) != UVS_OK) return rc;      // (slack: the next batch of this size packs in place)
-    { char* before = s->d_blobs; if ((rc = ensure(s, (void**)&s->d_blobs, &s->d_blobs_cap, up_bytes + 64)) != UVS_OK) return rc; if (s->d_blobs != before) values_only = false; }
+    { char* before = s->d_blobs; if ((rc = ensure(s, (void**)&s->d_blobs, &s->d_blobs_cap, up_bytes)) != UVS_OK) return rc; if (s->d_blobs != before) values_only = false; }
     // all doubles of a blob precede its int tables (pack_window: i = 2 d), so the value sections are ONE prefix
     const size_t value_bytes = values_only ? (size_t)4 * (size_t)s->hdrs[0].i_pt_lm : 0;
     if ((rc = ensure(s, (void**)&s->d_outpack, &s->d_outpack_cap, (size_t)s->out_total * 8 + (size_t)n * sizeof(uvs_report))) != UVS_OK) return rc;
@@ -1217,9 +1215,7 @@ static int upload_windows(uvs_solver* s, int n, const uvs_window* const* ws, boo
     std::memcpy(tabs + n, s->ws_off.data(), (size_t)n * 8);
     std::memcpy(tabs + 2 * (size_t)n, s->out_tab.data(), (size_t)n * 24);
     s->d_blob_off = (long long*)(s->d_blobs + blob_bytes); s->d_ws_off = s->d_blob_off + n; s->d_out_tab = s->d_blob_off + 2 * (size_t)n;
-    s->up_bytes_last = up_bytes;
-    if (no_copy) { /* staged only: a prefetching k_solve of the batch before moves it (uvs_batch_stream) */ }
-    else if (values_only) {      // the tables of this window are on the device already (structure cache): the value prefix and the three small offset tables
+    if (values_only) {      // the tables of this window are on the device already (structure cache): the value prefix and the three small offset tables
         HIPCHK(s, hipMemcpyAsync(s->d_blobs, s->h_up, value_bytes, hipMemcpyHostToDevice, s->stream));
         HIPCHK(s, hipMemcpyAsync(s->d_blobs + blob_bytes, s->h_up + blob_bytes, (size_t)n * 40, hipMemcpyHostToDevice, s->stream));
     } else if (staged) HIPCHK(s, hipMemcpyAsync(s->d_blobs, s->h_up, up_bytes, hipMemcpyHostToDevice, s->stream));
@@ -1375,11 +1371,10 @@ extern "C" {
 
 int uvs_batch_upload(uvs_solver* s, int n, const uvs_window* const* ws) { return upload_windows(s, n, ws, true); }
 
-static int launch_solve(uvs_solver* s, int debug, float* elapsed_ms, bool wait = true, const char* pf_src = nullptr, char* pf_dst = nullptr, size_t pf_bytes = 0) {
+static int launch_solve(uvs_solver* s, int debug, float* elapsed_ms, bool wait = true) {
     if (s->n_loaded < 1) { s->err = "no batch uploaded"; return UVS_ERR_INVALID_ARG; }
     HIPCHK(s, hipSetDevice(s->device));
     KOpts ko = make_kopts(s->opts, debug);
-    ko.pf_src = pf_src; ko.pf_dst = pf_dst; ko.pf_bytes = (long long)pf_bytes;
     DebugOut dbg; std::memset(&dbg, 0, sizeof(dbg));
     if (debug) {
         if (!s->d_dbg) HIPCHK(s, hipMalloc((void**)&s->d_dbg, sizeof(double) * (UVS_RD * UVS_RD + 5 * UVS_RD + 40)));
@@ -1461,67 +1456,11 @@ int uvs_batch_download(uvs_solver* s, int n, uvs_state* states, uvs_report* reps
 //     into the pinned host buffer itself (download_enqueue(direct)).
 //   * the kernels of consecutive batches are chained by events, see below.
 // With both the stream runs at 155 - 170 k solves/s, 1.50 - 1.65 ms per batch beside a kernel of 1.46 ms.
-// The PREFETCHING form (UVS_STREAM_PREFETCH=1) dates from before the first point was understood -- it lets k_solve of batch k - 1 fetch batch k from the pinned
-// buffer (KOpts::pf_*: every workgroup a slice, by the wave that sits out the factorization) -- and is slower than the copy engine: kept as an experiment.
-static int batch_stream_prefetch(uvs_solver* s, int n_batches, int per_batch, const uvs_window* const* ws, uvs_state* states, uvs_report* reps, double* wall_ms) {
-    for (uvs_solver** t : {&s->twin, &s->twin2})
-        if (!*t) { const int rc = uvs_create(&s->opts, s->device, s->max_batch, s->max_points, s->max_point_obs, s->max_lines, s->max_line_obs, t); if (rc != UVS_OK) { s->err = "uvs_batch_stream: could not create a buffer set"; return rc; } }
-    uvs_solver* set[3] = {s, s->twin, s->twin2};
-    for (uvs_solver* q : set) if (!q->ev_done) HIPCHK(s, hipEventCreateWithFlags(&q->ev_done, hipEventDisableTiming));
-    const auto t0 = std::chrono::steady_clock::now();
-    static const bool sprof_ = std::getenv("UVS_STREAM_PROFILE") != nullptr;
-    int pending[3] = {-1, -1, -1};
-    int worst = UVS_OK;
-    const auto drain = [&](int q) -> int {
-        if (pending[q] < 0) return UVS_OK;
-        const size_t off = (size_t)pending[q] * per_batch;
-        const int rc = download_finish(set[q], per_batch, states ? states + off : nullptr, reps ? reps + off : nullptr);
-        pending[q] = -1;
-        if (rc != UVS_OK && rc != UVS_ERR_NUMERIC) { if (set[q] != s) s->err = set[q]->err; return rc; }
-        if (rc != UVS_OK) worst = rc;
-        return UVS_OK;
-    };
-    const auto fail = [&](int rc, int q) -> int {
-        if (set[q] != s) s->err = set[q]->err;
-        const std::string first_err = s->err;
-        for (uvs_solver* t : set) (void)hipStreamSynchronize(t->stream);
-        for (int qq = 0; qq < 3; ++qq) (void)drain(qq);
-        s->err = first_err;
-        return rc;
-    };
-    // launch of batch k on its set: waits for the kernel of batch k - 1 (which wrote this set's blobs, or -- batch 0 -- for nothing), prefetches batch k + 1 if it is packed
-    const auto launch = [&](int k, bool with_next) -> int {
-        const int q = k % 3, qn = (k + 1) % 3, qp = (k + 2) % 3;
-        if (k > 0) HIPCHK(s, hipStreamWaitEvent(set[q]->stream, set[qp]->ev_done, 0));
-        int rc = launch_solve(set[q], 0, nullptr, false, with_next ? set[qn]->h_up : nullptr, with_next ? set[qn]->d_blobs : nullptr, with_next ? set[qn]->up_bytes_last : 0);
-        if (rc != UVS_OK) return rc;
-        HIPCHK(s, hipEventRecord(set[q]->ev_done, set[q]->stream));
-        rc = download_enqueue(set[q], per_batch);
-        if (rc == UVS_OK) pending[q] = k;
-        return rc;
-    };
-    for (int k = 0; k < n_batches; ++k) {
-        const int q = k % 3;
-        const auto td0_ = std::chrono::steady_clock::now();
-        int rc = drain(q);      // batch k - 3
-        if (sprof_) fprintf(stderr, "stream batch %d: drain (wait + unpack of batch %d) %.3f ms\n", k, k - 3, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - td0_).count());
-        if (rc != UVS_OK) return fail(rc, q);
-        rc = upload_windows(set[q], per_batch, ws + (size_t)k * per_batch, false, 0, /*no_copy=*/k > 0);
-        if (rc != UVS_OK) return fail(rc, q);
-        if (k > 0) { rc = launch(k - 1, true); if (rc != UVS_OK) return fail(rc, (k - 1) % 3); }
-    }
-    { const int rc = launch(n_batches - 1, false); if (rc != UVS_OK) return fail(rc, (n_batches - 1) % 3); }
-    for (int q = 0; q < 3; ++q) { const int rc = drain(q); if (rc != UVS_OK) return rc; }
-    if (wall_ms) *wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    return worst;
-}
-
+// (An in-kernel prefetch of the next batch -- k_solve's idle wave reading the pinned buffer -- was built before the first point was understood and is slower than the copy
+// engine: tools/experiments/r05_stream_prefetch.patch.)
 int uvs_batch_stream(uvs_solver* s, int n_batches, int per_batch, const uvs_window* const* ws, uvs_state* states, uvs_report* reps, double* wall_ms) {
     if (!s || n_batches < 1 || per_batch < 1 || !ws) return UVS_ERR_INVALID_ARG;
     if (per_batch > s->max_batch) { s->err = "batch larger than max_batch"; return UVS_ERR_CAPACITY; }
-    // (UVS_STREAM_PREFETCH=1: the in-kernel prefetch of the next batch -- built, bitwise equal, and slower: a wave's 16-byte reads of pinned host memory do not reach the copy
-    // engine's rate)
-    { const char* e = std::getenv("UVS_STREAM_PREFETCH"); if (s->ksolve_nt == 512 && per_batch >= 8 && e && std::atoi(e) != 0) return batch_stream_prefetch(s, n_batches, per_batch, ws, states, reps, wall_ms); }
     // THREE buffer sets by default (UVS_STREAM_SETS=2: two): with two, the host can pack batch k only after batch k - 2 has been solved, and pack + copy (1.0 + 0.85 ms) then sit on
     // the critical path of every second kernel (1.72 ms per batch measured); with three the GPU always has a copied batch waiting
     static const int NS = [] { const char* e = std::getenv("UVS_STREAM_SETS"); return e && std::atoi(e) == 2 ? 2 : 3; }();
