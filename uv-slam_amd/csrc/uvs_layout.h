@@ -142,6 +142,8 @@ struct DevWin {
     int32_t chol_half_ok;             // 1: blocks (i, j), j < i-1, of the reduced system are non-zero in rows {0..5, 15} only (true unless the prior keeps the speed / bias of a frame >= 2): the Cholesky pairs their rows
     int32_t dense;                    // 1: the landmark Schur complement of this window goes through the dense matrix-core product (UVS_DS_*: 512-thread k_solve only; no pseudo-frame blocks); the gather
                                       // lists then hold direct entries only and the chunks are laid out  rec | (line table) | Et | lists  with the C buffer at the end of the staging area
+    int64_t out_host;                 // uvs_batch_stream: address (in the device's view) of this window's slot in the pinned result buffer of the host -- k_solve writes the final state there as well, so that
+                                      // no gather kernel and no device-to-host copy follow the solve; 0 = none.  Patched into the staged header by upload_windows, not by pack_window.
     int32_t redamp_ok;                // 1: k_solve may re-damp the last linearization after a rejected step instead of linearizing again (no pseudo-frame blocks; every line chunk has room for the tables)
 };
 

@@ -3620,6 +3620,12 @@ __global__ __launch_bounds__(NT) void k_solve(char* blobs, const long long* blob
     // the accepted landmark parameters follow the frames, so that the host fetches ONE small contiguous block per window
     for (int k = tid; k < h.n_points; k += NT) c.ws[h.w_out + UVS_XDIM + k] = invd[cur][k];
     for (int k = tid; k < 4 * h.n_lines; k += NT) c.ws[h.w_out + UVS_XDIM + h.n_points + k] = line[cur][k];
+    if (h.out_host) {      // uvs_batch_stream: the state ALSO goes where the host reads it (DevWin::out_host; posted writes over PCIe: nobody waits for them before the kernel ends)
+        double* od = (double*)h.out_host;
+        if (tid < UVS_XDIM) od[tid] = sh[L_X + tid];
+        for (int k = tid; k < h.n_points; k += NT) od[UVS_XDIM + k] = invd[cur][k];
+        for (int k = tid; k < 4 * h.n_lines; k += NT) od[UVS_XDIM + h.n_points + k] = line[cur][k];
+    }
     if (tid == 0) {
         rep->status = status; rep->termination = term; rep->num_iterations = it; rep->num_successful = nsucc; rep->final_cost = cost;
         ((DevWin*)blob)->cur_sel = cur;

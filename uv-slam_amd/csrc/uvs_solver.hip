@@ -1100,7 +1100,8 @@ __global__ void k_pack_outputs(const double* ws, const long long* tab, double* o
     for (int t = threadIdx.x; t < RD; t += blockDim.x) out[rep_dst + (long long)blockIdx.x * RD + t] = r[t];
 }
 
-static int upload_windows(uvs_solver* s, int n, const uvs_window* const* ws, bool wait, int chunk_grid = 0) {
+// out_direct: (uvs_batch_stream) every staged header gets the address of its window's slot in the pinned result buffer (DevWin::out_host): k_solve then writes the final state there itself
+static int upload_windows(uvs_solver* s, int n, const uvs_window* const* ws, bool wait, int chunk_grid = 0, bool out_direct = false) {
     if (!s || n < 1 || !ws) return UVS_ERR_INVALID_ARG;
     if (n > s->max_batch) { s->err = "batch larger than max_batch"; return UVS_ERR_CAPACITY; }
     HIPCHK(s, hipSetDevice(s->device));
@@ -1210,6 +1211,11 @@ static int upload_windows(uvs_solver* s, int n, const uvs_window* const* ws, boo
         pack_parallel((int)((nb_ + 65535) >> 16), ct, [&](int c0, int c1, int) { const size_t a0 = (size_t)c0 << 16, a1 = std::min(nb_, (size_t)c1 << 16); if (a1 > a0) std::memcpy(s->h_up + a0, s->host_blobs.data() + a0, a1 - a0); });
     } else std::memcpy(s->h_up, s->host_blobs.data(), s->host_blobs.size());
     tp3_ = std::chrono::steady_clock::now();
+    if (out_direct && !values_only) {
+        if ((rc = ensure_pinned(s, &s->h_out, &s->h_out_cap, (size_t)s->out_total * 8 + (size_t)n * sizeof(uvs_report))) != UVS_OK) return rc;
+        void* dp = nullptr; HIPCHK(s, hipHostGetDevicePointer(&dp, s->h_out, 0));
+        for (int b = 0; b < n; ++b) ((DevWin*)(s->h_up + s->blob_off[b]))->out_host = (int64_t)(uintptr_t)((double*)dp + s->out_tab[3 * (size_t)b + 2]);
+    }
     long long* tabs = (long long*)(s->h_up + (staged ? blob_bytes : 0));
     std::memcpy(tabs, s->blob_off.data(), (size_t)n * 8);
     std::memcpy(tabs + n, s->ws_off.data(), (size_t)n * 8);
@@ -1371,19 +1377,25 @@ extern "C" {
 
 int uvs_batch_upload(uvs_solver* s, int n, const uvs_window* const* ws) { return upload_windows(s, n, ws, true); }
 
-static int launch_solve(uvs_solver* s, int debug, float* elapsed_ms, bool wait = true) {
+// rep_direct: (uvs_batch_stream after upload_windows(out_direct)) the reports go into the pinned result buffer as well
+static int launch_solve(uvs_solver* s, int debug, float* elapsed_ms, bool wait = true, bool rep_direct = false) {
     if (s->n_loaded < 1) { s->err = "no batch uploaded"; return UVS_ERR_INVALID_ARG; }
     HIPCHK(s, hipSetDevice(s->device));
     KOpts ko = make_kopts(s->opts, debug);
+    uvs_report* d_reports = s->d_reports;
+    if (rep_direct) {
+        void* dp = nullptr; HIPCHK(s, hipHostGetDevicePointer(&dp, s->h_out, 0));
+        d_reports = (uvs_report*)((double*)dp + s->out_total);
+    }
     DebugOut dbg; std::memset(&dbg, 0, sizeof(dbg));
     if (debug) {
         if (!s->d_dbg) HIPCHK(s, hipMalloc((void**)&s->d_dbg, sizeof(double) * (UVS_RD * UVS_RD + 5 * UVS_RD + 40)));
         dbg.S = s->d_dbg; dbg.g = dbg.S + UVS_RD * UVS_RD; dbg.hd = dbg.g + UVS_RD; dbg.dd = dbg.hd + UVS_RD; dbg.step = dbg.dd + UVS_RD; dbg.scal = dbg.step + UVS_RD;
     }
     HIPCHK(s, hipEventRecord(s->ev0, s->stream));
-    if (s->ksolve_nt == 512 && s->dense_schur) { if (uvs_k_solve512d_launch(s->n_loaded, s->stream, s->d_blobs, s->d_blob_off, s->d_ws, s->d_ws_off, &ko, sizeof(ko), s->d_reports, &dbg, sizeof(dbg)) != UVS_OK) { s->err = "k_solve (dense instantiation): argument layout mismatch"; return UVS_ERR_HIP; } }
-    else if (s->ksolve_nt == 512) { if (uvs_k_solve512_launch(s->n_loaded, s->stream, s->d_blobs, s->d_blob_off, s->d_ws, s->d_ws_off, &ko, sizeof(ko), s->d_reports, &dbg, sizeof(dbg)) != UVS_OK) { s->err = "k_solve (512 threads): argument layout mismatch between the translation units"; return UVS_ERR_HIP; } }
-    else hipLaunchKernelGGL(k_solve, dim3(s->n_loaded), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_blob_off, s->d_ws, s->d_ws_off, ko, s->d_reports, dbg);
+    if (s->ksolve_nt == 512 && s->dense_schur) { if (uvs_k_solve512d_launch(s->n_loaded, s->stream, s->d_blobs, s->d_blob_off, s->d_ws, s->d_ws_off, &ko, sizeof(ko), d_reports, &dbg, sizeof(dbg)) != UVS_OK) { s->err = "k_solve (dense instantiation): argument layout mismatch"; return UVS_ERR_HIP; } }
+    else if (s->ksolve_nt == 512) { if (uvs_k_solve512_launch(s->n_loaded, s->stream, s->d_blobs, s->d_blob_off, s->d_ws, s->d_ws_off, &ko, sizeof(ko), d_reports, &dbg, sizeof(dbg)) != UVS_OK) { s->err = "k_solve (512 threads): argument layout mismatch between the translation units"; return UVS_ERR_HIP; } }
+    else hipLaunchKernelGGL(k_solve, dim3(s->n_loaded), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_blob_off, s->d_ws, s->d_ws_off, ko, d_reports, dbg);
     HIPCHK(s, hipGetLastError());
     HIPCHK(s, hipEventRecord(s->ev1, s->stream));
     if (!wait) return UVS_OK;
@@ -1398,10 +1410,7 @@ int uvs_batch_solve(uvs_solver* s, float* elapsed_ms) {
 }
 
 // the two halves of a download: enqueue (gather kernel + ONE copy into pinned memory, nothing waits) and finish (wait, unpack)
-// `direct`: the gather kernel writes into the pinned host buffer itself and no copy is enqueued (uvs_batch_stream).  A device-to-host copy that waits for a kernel
-// holds up the copies enqueued after it on OTHER streams -- the upload of the next batch started only when this download had been done, i.e. after k_solve, and the
-// stream ran copy and kernel in series (profiles/r05_stream_timeline_before.txt; tools/micro_overlap.hip shows that the device itself overlaps them) --, and 1 MB of
-// posted writes over PCIe cost the gather kernel nothing that the copy did not cost.
+// `direct`: the gather kernel writes into the pinned host buffer itself and no copy is enqueued (uvs_batch_stream with UVS_STREAM_D2H_COPY=2; its default lets k_solve write the results)
 static int download_enqueue(uvs_solver* s, int n, bool direct = false) {
     // every window's final state (frames | inv_depth | line_orth, written by k_solve into its workspace) and its report are gathered on the
     // device and fetched with ONE copy into pinned memory (256 windows were 256 synchronous round trips once)
@@ -1450,12 +1459,14 @@ int uvs_batch_download(uvs_solver* s, int n, uvs_state* states, uvs_report* reps
 // twins created on first use with the same options and capacities, each with its own stream, pinned staging and device buffers -- take turns: while the GPU runs
 // k_solve -> gather of batch k on one set, the copy engine moves batch k + 1 into the second and the host packs batch k + 2 into the third; a set is drained (wait +
 // unpack) right before it is reused.  Results equal uvs_batch_upload / solve / download of each batch (same packing, same kernel).
-// Two things decide whether copy and kernel really overlap (round 5; tools/micro_overlap.hip, tools/stream_trace.py, profiles/r05_stream_timeline*.txt):
-//   * NO device-to-host copy may be enqueued behind a kernel.  Such a copy waits in the copy engine's queue for its kernel, and the host-to-device copy of the next batch,
-//     enqueued later on ANOTHER stream, waits behind it: copy and kernel then strictly alternate (95 k solves/s).  The gather kernel therefore writes the results
-//     into the pinned host buffer itself (download_enqueue(direct)).
-//   * the kernels of consecutive batches are chained by events, see below.
-// With both the stream runs at 155 - 170 k solves/s, 1.50 - 1.65 ms per batch beside a kernel of 1.46 ms.
+// What it took to make copy and kernel overlap (round 5; tools/micro_overlap.hip, tools/stream_trace.py, profiles/r05_stream_timeline*.txt, r05_stream_ab.txt):
+//   * With TWO sets and the results fetched by a device-to-host copy enqueued behind k_solve, the upload of batch k + 1 -- enqueued on the other stream while k_solve of batch k
+//     ran -- did not start until that download had been done, i.e. after the kernel: copy and kernel strictly alternated (95 - 105 k solves/s).  The device itself overlaps
+//     them completely (micro_overlap).  Nothing is enqueued behind k_solve any more: k_solve writes every window's final state and report into the pinned result buffer
+//     itself (DevWin::out_host, patched into the staged headers by upload_windows; the report pointer of the launch) -- UVS_STREAM_D2H_COPY=2: a gather kernel does, =1: gather
+//     kernel + copy, the old form.
+//   * three sets, and the kernels of consecutive batches chained by events, see below.
+// With these the stream runs at 155 - 170 k solves/s: 1.50 - 1.65 ms per batch beside a kernel of 1.45 ms.
 // (An in-kernel prefetch of the next batch -- k_solve's idle wave reading the pinned buffer -- was built before the first point was understood and is slower than the copy
 // engine: tools/experiments/r05_stream_prefetch.patch.)
 int uvs_batch_stream(uvs_solver* s, int n_batches, int per_batch, const uvs_window* const* ws, uvs_state* states, uvs_report* reps, double* wall_ms) {
@@ -1473,8 +1484,11 @@ int uvs_batch_stream(uvs_solver* s, int n_batches, int per_batch, const uvs_wind
     const auto t0 = std::chrono::steady_clock::now();
     uvs_solver* set[3] = {s, s->twin, s->twin2};
     static const bool chain_ = [] { const char* e = std::getenv("UVS_STREAM_CHAIN"); return !(e && e[0] == '0'); }();
+    static const int d2h_ = [] { const char* e = std::getenv("UVS_STREAM_D2H_COPY"); return e ? std::atoi(e) : 0; }();      // 0: k_solve writes the results into the pinned buffer; 1: gather kernel + device-to-host copy; 2: the gather kernel writes them
     for (int j = 0; j < NS; ++j) if (!set[j]->ev_done) HIPCHK(s, hipEventCreateWithFlags(&set[j]->ev_done, hipEventDisableTiming));
     int pending[3] = {-1, -1, -1};      // batch index in flight on each set
+    // the resident blobs of this call carry addresses into its pinned result buffers (DevWin::out_host): whatever way the call ends, a later uvs_batch_solve needs its own upload
+    struct Invalidate { uvs_solver** set; int n; bool on; ~Invalidate() { if (on) for (int j = 0; j < n; ++j) set[j]->n_loaded = 0; } } invalidate_{set, NS, d2h_ == 0};
     int worst = UVS_OK;
     const auto drain = [&](int q) -> int {
         if (pending[q] < 0) return UVS_OK;
@@ -1491,13 +1505,13 @@ int uvs_batch_stream(uvs_solver* s, int n_batches, int per_batch, const uvs_wind
         const auto td0_ = std::chrono::steady_clock::now();
         int rc = drain(q);
         if (sprof_) fprintf(stderr, "stream batch %d: drain (wait + unpack of batch %d) %.3f ms\n", k, k - NS, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - td0_).count());
-        if (rc == UVS_OK) rc = upload_windows(set[q], per_batch, ws + (size_t)k * per_batch, false);
+        if (rc == UVS_OK) rc = upload_windows(set[q], per_batch, ws + (size_t)k * per_batch, false, 0, d2h_ == 0);
         // the kernels run one after the other (an event chain through the sets): two k_solve launches on two streams otherwise share the compute units workgroup by workgroup,
         // both finish late and together, and the host -- which packs batch k + 1 into the set of the batch that finishes first -- stalls and then has two batches to pack in a row
         if (rc == UVS_OK && chain_ && k > 0 && hipStreamWaitEvent(set[q]->stream, set[(k - 1) % NS]->ev_done, 0) != hipSuccess) { s->err = "hipStreamWaitEvent failed"; rc = UVS_ERR_HIP; }
-        if (rc == UVS_OK) rc = launch_solve(set[q], 0, nullptr, false);
+        if (rc == UVS_OK) rc = launch_solve(set[q], 0, nullptr, false, d2h_ == 0);
         if (rc == UVS_OK && chain_ && hipEventRecord(set[q]->ev_done, set[q]->stream) != hipSuccess) { s->err = "hipEventRecord failed"; rc = UVS_ERR_HIP; }
-        if (rc == UVS_OK) rc = download_enqueue(set[q], per_batch, std::getenv("UVS_STREAM_D2H_COPY") == nullptr);
+        if (rc == UVS_OK && d2h_ != 0) rc = download_enqueue(set[q], per_batch, d2h_ == 2);
         if (rc != UVS_OK) {
             // batch k failed before it was enqueued: the batch still in flight on the OTHER buffer set (k - 1) is delivered like the ones before it, so that on
             // return every batch < k holds results and nothing from k on does; the first error code is the one returned
