@@ -293,7 +293,8 @@ int uvs_batch_download(uvs_solver *s, int n, uvs_state *states, uvs_report *reps
  * and download of consecutive batches overlap on three buffer sets (no reference equivalent: offline replay of recorded windows, estimator.cpp:992
  * once per window).  states / reps: n_batches * per_batch entries (either may be NULL); wall_ms: wall time of the whole call.  Results are those
  * of uvs_batch_upload / uvs_batch_solve / uvs_batch_download batch by batch.  On an error in batch k (e.g. a malformed window) the batches before k have been
- * delivered, batch k and the later ones have not been touched, and the code of the first error is returned. */
+ * delivered, batch k and the later ones have not been touched, and the code of the first error is returned.  The call leaves NO resident batch behind:
+ * uvs_batch_solve / uvs_batch_download after it need their own uvs_batch_upload. */
 int uvs_batch_stream(uvs_solver *s, int n_batches, int per_batch, const uvs_window *const *ws, uvs_state *states, uvs_report *reps, double *wall_ms);
 
 /* One evaluation of every residual block at the window's state (no solve).  Relocalization blocks (n_relo_obs) are solve-only: they are
