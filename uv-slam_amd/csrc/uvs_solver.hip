@@ -1132,7 +1132,7 @@ static int upload_windows(uvs_solver* s, int n, const uvs_window* const* ws, boo
         s->blob_off[0] = 0;
         int rc = pack_window(ws[0], s->opts, s->host_blobs, s->hdrs[0], s->err, chunk_grid, s->pack_cache, s->dense_schur);
         if (rc != UVS_OK) { s->n_loaded = 0; return rc; }
-        values_only = was_valid && dev && s->pack_cache->valid && s->pack_cache->device_holds_tables;      // (a miss resets both flags)
+        values_only = !out_direct && was_valid && dev && s->pack_cache->valid && s->pack_cache->device_holds_tables;      // (a miss resets both flags; the stream patches every staged header -- DevWin::out_host -- so the whole blob travels)
     } else if (nthreads == 1) {
         s->host_blobs.clear();
         if (s->pack_cache) { s->pack_cache->valid = false; s->pack_cache->device_holds_tables = false; }
@@ -1211,7 +1211,7 @@ static int upload_windows(uvs_solver* s, int n, const uvs_window* const* ws, boo
         pack_parallel((int)((nb_ + 65535) >> 16), ct, [&](int c0, int c1, int) { const size_t a0 = (size_t)c0 << 16, a1 = std::min(nb_, (size_t)c1 << 16); if (a1 > a0) std::memcpy(s->h_up + a0, s->host_blobs.data() + a0, a1 - a0); });
     } else std::memcpy(s->h_up, s->host_blobs.data(), s->host_blobs.size());
     tp3_ = std::chrono::steady_clock::now();
-    if (out_direct && !values_only) {
+    if (out_direct) {
         if ((rc = ensure_pinned(s, &s->h_out, &s->h_out_cap, (size_t)s->out_total * 8 + (size_t)n * sizeof(uvs_report))) != UVS_OK) return rc;
         void* dp = nullptr; HIPCHK(s, hipHostGetDevicePointer(&dp, s->h_out, 0));
         for (int b = 0; b < n; ++b) ((DevWin*)(s->h_up + s->blob_off[b]))->out_host = (int64_t)(uintptr_t)((double*)dp + s->out_tab[3 * (size_t)b + 2]);
