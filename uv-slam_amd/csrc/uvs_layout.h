@@ -72,7 +72,6 @@
 #define UVS_DS_CBUF (67 * UVS_DS_CLD)          // doubles of the C buffer
 #define UVS_DS_CTOT (UVS_DS_CBUF + 80)         // ... followed by diag(J^T J) of the direct terms in the compact pose index space (66 used, the rest stays zero)
 #define UVS_DS_LNX 32             // per-line table of a dense line chunk: H_ll^-1 [16] | L^-1 lower packed [10] | 6 spare
-#define UVS_DG_NGRP 256           // gather groups of a dense window: ONE lane per group (all six rows of the block), on the 256 gatherer lanes
 #define UVS_DS_LNT 60             // per-line table of a dense re-damping (uvs_solve_kernel.h: redamp_dense_tables), 58 used
 #ifndef UVS_NT
 #define UVS_NT 256                // threads per workgroup of the solve kernels

@@ -1141,8 +1141,7 @@ UVS_DEV void gather_walk(const int* ent, int e0, int e1, Load load, Use use) {
 // exactly one (slot, slot) pair per landmark seen in its frame).
 // exrows: block row 12 is the camera extrinsic (its Jacobian sits in the record's own J_ex field); false in a window with relocalization blocks,
 // where pseudo frame 12 is relo_Pose, an ordinary second frame
-// RAW (dense Schur path): the diagonal entries take the record's RAW residual (the Schur part of the reduced gradient comes out of the dense product: dense_fold)
-template <bool EXT, bool DELTA = false, bool RAW = false>
+template <bool EXT, bool DELTA = false>
 UVS_DEV void gather_points(int grp, const int* lists, const double* S0, GAcc& A, int goff = 0, bool exrows = true) {
     const int g = (lane_tid() - GT0) / UVS_GLANES, r0 = GR * (lane_tid() % UVS_GLANES);
     const bool on = grp >= 0;
@@ -1199,7 +1198,7 @@ UVS_DEV void gather_points(int grp, const int* lists, const double* S0, GAcc& A,
                 for (int r = 0; r < GR; ++r) { o.p0[r] = pa[r]; o.p1[r] = pa[p1off + r]; }
 #pragma unroll
                 for (int k = 0; k < 3; ++k) { o.q0[k] = lds2(pb + 2 * k); o.q1[k] = lds2(pb + 6 + 2 * k); }
-                o.rc = RAW ? lds2(S0 + lo - ((w[0] & UVS_PT_ENTRY_A) ? UVS_PT_A : UVS_PT_B)) : lds2(S0 + lo + ((w[0] & UVS_PT_ENTRY_A) ? UVS_PT_RC2 - UVS_PT_A : rcoff));
+                o.rc = lds2(S0 + lo + ((w[0] & UVS_PT_ENTRY_A) ? UVS_PT_RC2 - UVS_PT_A : rcoff));
             },
             [&](int, Ops& o) {
 #pragma unroll

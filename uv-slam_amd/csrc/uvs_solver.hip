@@ -521,10 +521,7 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
     const bool dense = want_dense && chunk_grid == 0 && !td_on && !ex_on && !relo_on && (h.n_pt_obs + h.n_ln_obs) > 0;
     h.dense = dense ? 1 : 0;
     const long stage_cap = dense ? (long)UVS_S_DOUBLES - UVS_DS_CTOT : (long)UVS_S_DOUBLES;      // the C buffer of the dense product takes the end of the staging area
-    // gather groups: two-lane groups, or -- dense path -- UVS_DG_NGRP one-lane groups (uvs_solve_kernel.h: dg_points / dg_lines)
-    constexpr int NGMAX = UVS_DG_NGRP;
-    static_assert(UVS_DG_NGRP >= UVS_NGRP, "group tables are sized for the dense path");
-    const int NG = dense ? UVS_DG_NGRP : UVS_NGRP, GPW = dense ? 64 : GRP_PER_WAVE;
+    constexpr int NGMAX = UVS_NGRP, NG = UVS_NGRP, GPW = GRP_PER_WAVE;      // gather groups (two lanes each); the dense path has none, its step tables are built further down
     // CSR by landmark
     std::vector<int> pbeg(h.n_points + 1, 0), lbeg(h.n_lines + 1, 0);
     for (int k = 0; k < h.n_pt_obs; ++k) pbeg[w->pt_lm[k] + 1]++;
