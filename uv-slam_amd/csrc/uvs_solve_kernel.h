@@ -1286,7 +1286,17 @@ UVS_DEV void gather_lines(int grp, const int* lists, const double* S0, GAcc& A, 
 static constexpr int IMU_JLD = 48;                       // row stride of Jaug / T in LDS (16 rows; 48 = 16 mod 32: no bank conflicts between k-groups)
 static constexpr int IMU_WOFF = 16 * IMU_JLD;            // W as [16][17] after the operand tile
 static constexpr int IMU_BLK = IMU_WOFF + UVS_BLK_SZ;    // 1040 doubles of LDS staging per block
+#ifndef UVS_IMU_SLOT_SWAP
+#define UVS_IMU_SLOT_SWAP 1
+#endif
 static constexpr int IMU_SLOTS = (UVS_NF - 1 + NW - 1) / NW;   // IMU blocks per wave (block b -> wave b % NW, slot b / NW): the MFMA stages and the tile adds use ALL waves (the staging before them only the evaluators)
+// which IMU block a wave holds in slot s.  Eight waves, ten blocks: the two second-slot blocks go to waves whose FIRST block has the other parity (block 8 to wave 1, block 9 to wave 0),
+// so that in each of asm_imu's two rounds (even blocks, odd blocks) every wave adds at most ONE block's tiles (with b = wv + 8 s waves 0 and 1 added two each, 3 k of the 6.5 k cycles of
+// that step).  Four waves: blocks wv, wv + 4, wv + 8 as before.  NF - 1 or more = no block.
+UVS_DEV int imu_block_of(int wv, int s) {
+    if (NW == 8 && UVS_IMU_SLOT_SWAP) return s == 0 ? wv : (wv == 0 ? 9 : wv == 1 ? 8 : UVS_NF);
+    return wv + s * NW;
+}
 struct ImuN { d4_t n00[IMU_SLOTS], n10[IMU_SLOTS], n11[IMU_SLOTS]; int fi[IMU_SLOTS]; bool act[IMU_SLOTS]; };      // fi / act: first frame of the wave's blocks, block present (asm_imu)
 
 // rotations of the evaluation point + prior residual (L_PR); returns this lane's share of the prior cost
@@ -1364,7 +1374,7 @@ UVS_DEV double lin_imu_tiles(const Ctx& c, ImuN& N) {
     bool act[IMU_SLOTS];
 #pragma unroll
     for (int s = 0; s < IMU_SLOTS; ++s) {
-        const int b = wv + s * NW;
+        const int b = imu_block_of(wv, s);
         act[s] = b < h.n_imu && !c.bi[h.i_imu + 2 * (b < h.n_imu ? b : 0) + 1];
         N.act[s] = act[s]; N.fi[s] = c.bi[h.i_imu + 2 * (b < h.n_imu ? b : 0)];
         if (act[s]) {
@@ -1383,7 +1393,7 @@ UVS_DEV double lin_imu_tiles(const Ctx& c, ImuN& N) {
     wave_sync();
 #pragma unroll
     for (int s = 0; s < IMU_SLOTS; ++s) {
-        const int b = wv + s * NW;
+        const int b = imu_block_of(wv, s);
         d4_t n00 = {0.0, 0.0, 0.0, 0.0}, n10 = n00, n11 = n00;
         if (act[s]) {
             const double* Jb = IM + IMU_BLK * b;
@@ -2727,8 +2737,7 @@ UVS_DEV void asm_imu(const Ctx& c, const ImuN& N) {
     for (int par = 0; par < 2; ++par) {
 #pragma unroll
         for (int s = 0; s < IMU_SLOTS; ++s) {
-            const int b = wv + s * NW;
-            if (act[s] && (b & 1) == par) {
+            if (act[s] && (fis[s] & 1) == par) {      // (blocks of one parity share no frame: fi' - fi >= 2)
                 const int fi = fis[s], fj = fi + 1;
                 // C layout: row = lk + 4q, col = li.  Rows < 15 go to S (lower triangles of the diagonal tiles), row 15 is J^T r.
                 double* b10 = sblk(sh, fj, fi) + lk * UVS_BLK_LD + li;
