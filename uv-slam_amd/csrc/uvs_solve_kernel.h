@@ -253,9 +253,9 @@ UVS_DEV void stage_prior_tables(const Ctx& c) {      // once per solve; the call
     if (tid < 9 * UVS_MAX_PRIOR_BLOCKS) c.sh[L_PX0 + tid] = c.bd[h.d_prior + h.prior_n * h.prior_n + 2 * h.prior_n + tid];
 }
 UVS_DEV void prior_dx(const Ctx& c, const double* x) {
-    const int tid = lane_tid();
+    const int tid = lane_tid() - 64;      // the lanes of the SECOND wave: its callers stage the rotations on the first lanes of wave 0 in the same breath, and one wave would run the two one after the other
     const DevWin& h = *c.hdr;
-    if (h.prior_n > 0 && tid < h.prior_nb) {
+    if (h.prior_n > 0 && tid >= 0 && tid < h.prior_nb) {
         int kind, frame, size, idx;
         double x0[9];
         if (c.ptab_ok) {
@@ -2852,15 +2852,16 @@ UVS_DEV void asm_finish(const Ctx& c, const double* x, bool first, double radius
             if (k >= 6 && !(k == 15 && tid < 96)) gmax = fmax(gmax, fabs(sh[L_G + tid]));      // Euclidean blocks (the Ex_Pose slots are a manifold block, below)
         } else { sh[L_S + sidx(tid, tid)] = 1.0; sh[L_DD + tid] = 0.0; sh[L_G + tid] = 0.0; sh[L_SC + tid] = 1.0; }
     }
-    if (tid < UVS_NF) {   // || x - Plus(x, -g) ||_inf on the pose block
+    const int pt = tid - (NT - 64);      // the projected-gradient measures on the LAST wave, beside the damping on the first three (one wave would run them one after the other)
+    if (pt >= 0 && pt < UVS_NF) {   // || x - Plus(x, -g) ||_inf on the pose block
         double d[6], xp[7];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) d[k] = -sh[L_G + 16 * tid + k];
-        pose_plus(x + 7 * tid, d, xp);
+        for (int k = 0; k < 6; ++k) d[k] = -sh[L_G + 16 * pt + k];
+        pose_plus(x + 7 * pt, d, xp);
 #pragma unroll
-        for (int k = 0; k < 7; ++k) gmax = fmax(gmax, fabs(x[7 * tid + k] - xp[k]));
+        for (int k = 0; k < 7; ++k) gmax = fmax(gmax, fabs(x[7 * pt + k] - xp[k]));
     }
-    if ((h.ex_on | h.relo_on) && tid == UVS_NF) {   // same projected-gradient measure for the extrinsic pose block / relo_Pose
+    if ((h.ex_on | h.relo_on) && pt == UVS_NF) {   // same projected-gradient measure for the extrinsic pose block / relo_Pose
         const double* xa = x + ((h.relo_on && !h.relo2) ? 184 : 176);
         double d[6], xp[7];
 #pragma unroll
