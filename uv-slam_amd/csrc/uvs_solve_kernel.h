@@ -3122,6 +3122,9 @@ UVS_DEV void relinearize_damping(const Ctx& c, const double* x, double radius, G
 // frames: XC = X (+) DLT ; landmarks: cand = cur + delta.  Accumulates into CTRL: MCC, STEP2, XC2.
 // PSB: Schur slots of a point per batch of loads; STREAM (the landmark-sharded kernel, whose lanes pay HBM latency per dependent load): the per-landmark scalars are
 // requested with the CSR range instead of after the slot loop, and the lines run one lane per (line, parameter) as in the 512-thread persistent kernel
+#ifndef UVS_BS_FRAME_LANE0
+#define UVS_BS_FRAME_LANE0 192
+#endif
 template <int LNBT = BS_LNB, int PSB = 4, bool STREAM = false>
 UVS_DEV void backsub_candidate(const Ctx& c, const double* invd, const double* line, double* invd_c, double* line_c,
                                   int pk0, int pk1, int lk0, int lk1, bool with_frames, double* sums_out) {
@@ -3140,15 +3143,18 @@ UVS_DEV void backsub_candidate(const Ctx& c, const double* invd, const double* l
         __syncthreads();
     }
     if (with_frames && tid < UVS_RD && ((tid & 15) < 15 || (td_on && tid == UVS_TD_INDEX) || ((ex_on | relo_on) && tid < 96))) { gd += sh[L_G + tid] * d[tid]; dd2 += sh[L_DD + tid] * d[tid] * d[tid]; }
-    if (with_frames && tid < UVS_NF) {
+    // the frame blocks' candidates on the lanes of wave 3 (no landmark work there in a canonical window: points sit on the first waves, line parameters from wave 4 on), not in front
+    // of the point loop of wave 0
+    const int ft = tid - UVS_BS_FRAME_LANE0;
+    if (with_frames && ft >= 0 && ft < UVS_NF) {
         double xp[7];
-        pose_plus(sh + L_X + 7 * tid, d + 16 * tid, xp);
+        pose_plus(sh + L_X + 7 * ft, d + 16 * ft, xp);
 #pragma unroll
-        for (int k = 0; k < 7; ++k) { sh[L_XC + 7 * tid + k] = xp[k]; const double e = xp[k] - sh[L_X + 7 * tid + k]; step2 += e * e; xc2 += xp[k] * xp[k]; }
+        for (int k = 0; k < 7; ++k) { sh[L_XC + 7 * ft + k] = xp[k]; const double e = xp[k] - sh[L_X + 7 * ft + k]; step2 += e * e; xc2 += xp[k] * xp[k]; }
 #pragma unroll
-        for (int k = 0; k < 9; ++k) { const double v = sh[L_X + 77 + 9 * tid + k] + d[16 * tid + 6 + k]; sh[L_XC + 77 + 9 * tid + k] = v; step2 += d[16 * tid + 6 + k] * d[16 * tid + 6 + k]; xc2 += v * v; }
+        for (int k = 0; k < 9; ++k) { const double v = sh[L_X + 77 + 9 * ft + k] + d[16 * ft + 6 + k]; sh[L_XC + 77 + 9 * ft + k] = v; step2 += d[16 * ft + 6 + k] * d[16 * ft + 6 + k]; xc2 += v * v; }
     }
-    if (with_frames && tid == UVS_NF) {   // Ex_Pose moves only with ESTIMATE_EXTRINSIC, para_Td only with ESTIMATE_TD
+    if (with_frames && ft == UVS_NF) {   // Ex_Pose moves only with ESTIMATE_EXTRINSIC, para_Td only with ESTIMATE_TD
         if (ex_on) {
             double de[6], xp[7];
 #pragma unroll
