@@ -46,5 +46,8 @@ def test_stress_windows_diverge_from_the_oracle_only_by_amplified_round_off(gpu_
         dp, dq = pose_deltas(sg.pose, so.pose)
         worst_dp, worst_dq = max(worst_dp, dp), max(worst_dq, dq)
     assert worst_dp <= 1e-4 and worst_dq <= 1e-4, (worst_dp, worst_dq)                                   # (d)
-    assert n_diff <= 15      # 7 of 60 in rounds 3 - 4; a jump would mean the amplification started earlier than round-off explains
+    print("stress windows (%s): LM traces differ from the oracle's in %d of 60" % (form, n_diff))
+    # 7 of 60 in rounds 3 - 5 -- the rate at which two CPU builds of the oracle itself part ways on these windows (4 of the 30 prior-free ones:
+    # tests/test_cpu_oracle_variants.py asserts that); a jump would mean the amplification started earlier than round-off explains
+    assert n_diff <= 9, n_diff
     s.close()

@@ -96,3 +96,10 @@ def test_replay_writes_the_result_file_and_it_scores_like_the_in_memory_ate(tmp_
     monkeypatch.delenv("UVS_VINS_RESULT_PATH")
     lib.uvs_host_replay_sequence(pin.encode(), pout.encode())       # (no result file requested: the earlier one stays as it is)
     assert [l.split()[1:] for l in open(res2)] == [l.split()[1:] for l in open(res)]
+    # the file is APPENDED to, like the reference's (std::ios::app, visualization.cpp:195): a second replay into the same path adds its lines
+    res3 = str(tmp_path / "twice.txt")
+    monkeypatch.setenv("UVS_VINS_RESULT_PATH", res3)
+    short = seqm.make_sequence(0, n_frames=13); seqm.save(short, pin)
+    assert lib.uvs_host_replay_sequence(pin.encode(), pout.encode()) == 0 and lib.uvs_host_replay_sequence(pin.encode(), pout.encode()) == 0
+    lines = open(res3).read().splitlines()
+    assert len(lines) == 6 and lines[:3] == lines[3:]

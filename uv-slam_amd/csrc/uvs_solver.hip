@@ -57,17 +57,26 @@ int uvs_k_large_chunks512_launch(int grid, hipStream_t stream, char* blob, doubl
 struct PackPool {
     std::vector<std::thread> th; std::mutex m; std::condition_variable cv_go, cv_done;
     const std::function<void(int)>* job = nullptr; int gen = 0, pending = 0; bool stop = false;
-    void worker(int t) {
-        int seen = 0;
+    // A worker joins at the generation that was current when it was created (`seen0`): a pool that grows after it has run must not hand the new thread the job of a
+    // run() that has already returned (its std::function lived on that run()'s stack) nor let it decrement a `pending` it was never counted in.
+    void worker(int t, int seen0) {
+        int seen = seen0;
         for (;;) {
             const std::function<void(int)>* f;
             { std::unique_lock<std::mutex> lk(m); cv_go.wait(lk, [&] { return stop || gen != seen; }); if (stop) return; seen = gen; f = job; }
+            if (f == nullptr) continue;      // (a generation whose run() is already over: nothing to do, nothing to count)
             (*f)(t);
             { std::lock_guard<std::mutex> lk(m); if (--pending == 0) cv_done.notify_one(); }
         }
     }
-    bool ensure(int n) {      // false: thread creation failed (the caller packs on its own thread)
-        try { while ((int)th.size() < n) { const int t = (int)th.size(); th.emplace_back([this, t] { worker(t); }); } } catch (...) { return false; }
+    bool ensure(int n) {      // false: thread creation failed (the caller packs on its own thread).  Called by the thread that calls run(), never beside a run() in flight.
+        try {
+            while ((int)th.size() < n) {
+                const int t = (int)th.size(); int g0;
+                { std::lock_guard<std::mutex> lk(m); g0 = gen; }
+                th.emplace_back([this, t, g0] { worker(t, g0); });
+            }
+        } catch (...) { return false; }
         return true;
     }
     void run(int n, const std::function<void(int)>& f) {      // f(0 .. n-1) on n workers (n <= th.size()), the caller waits; workers beyond n see the generation and return at once
@@ -75,6 +84,7 @@ struct PackPool {
         { std::lock_guard<std::mutex> lk(m); job = &g; pending = (int)th.size(); ++gen; }
         cv_go.notify_all();
         std::unique_lock<std::mutex> lk(m); cv_done.wait(lk, [&] { return pending == 0; });
+        job = nullptr;      // `g` dies with this frame
     }
     ~PackPool() { { std::lock_guard<std::mutex> lk(m); stop = true; } cv_go.notify_all(); for (auto& t : th) t.join(); }
 };
@@ -1175,6 +1185,7 @@ static int upload_windows(uvs_solver* s, int n, const uvs_window* const* ws, boo
         }
         packed_total = total;
     }
+    tp1_ = std::chrono::steady_clock::now();      // packing ends here; the offset tables and the drain of the stream follow
     for (int b = 0; b < n; ++b) { s->ws_off[b] = wtot; wtot += s->hdrs[b].ws_doubles; }
     s->out_tab.resize(3 * (size_t)n); s->out_total = 0;
     for (int b = 0; b < n; ++b) {

@@ -214,7 +214,12 @@ extern "C" int uvs_host_replay_sequence(const char* in_path, const char* out_pat
     // VINS_RESULT_PATH of the reference (utility/visualization.cpp:195-207: one line per solved frame, "stamp x y z qx qy qz qw", stamp with 9 decimals, the rest
     // with 6): UVS_VINS_RESULT_PATH names the file; tools/ate.py scores it against an EuRoC ground-truth data.csv
     FILE* tum = nullptr;
-    if (const char* rp = std::getenv("UVS_VINS_RESULT_PATH")) tum = std::fopen(rp, "w");
+    // APPENDED to, as the reference does (std::ios::app, visualization.cpp:195): a second replay into the same path adds its lines behind the first one's.  The
+    // position / attitude written are last_P / last_R = Ps[WINDOW_SIZE] / Rs[WINDOW_SIZE] as processImage() leaves them (what pubOdometry reads after the same call).
+    if (const char* rp = std::getenv("UVS_VINS_RESULT_PATH")) {
+        tum = std::fopen(rp, "a");
+        if (!tum) std::fprintf(stderr, "uvs_host_replay_sequence: cannot open UVS_VINS_RESULT_PATH=%s for appending; no result file is written\n", rp);
+    }
     struct TumCloser { FILE*& f; ~TumCloser() { if (f) std::fclose(f); } } tum_closer{tum};
     try {
         Estimator est;

@@ -54,6 +54,17 @@ def read_euroc_groundtruth(path):
     return dict(t=a[:, 0] / 1e9, p=val[:, 0:3], q_wxyz=val[:, 3:7], v=val[:, 7:10], bw=val[:, 10:13], ba=val[:, 13:16])
 
 
+def load_groundtruth_fixture(path):
+    """tests/golden/mh05_groundtruth.npz (written by tests/golden/make_mh05_fixture.py from the reference's
+    benchmark_publisher/config/MH_05_difficult/data.csv): the same dict `read_euroc_groundtruth` returns for that CSV, bit for bit --
+    integer nanosecond stamps and integer micro-unit values, stored as first differences."""
+    z = np.load(path)
+    t_ns = np.concatenate([z["t0_ns"], z["t0_ns"][0] + np.cumsum(z["dt_ns"].astype(np.int64))])
+    micro = np.vstack([z["v0_micro"], z["v0_micro"][0] + np.cumsum(z["dv_micro"].T.astype(np.int64), axis=0)])
+    val = (micro / 1e6).astype(np.float32).astype(np.float64)
+    return dict(t=t_ns.astype(np.float64) / 1e9, p=val[:, 0:3], q_wxyz=val[:, 3:7], v=val[:, 7:10], bw=val[:, 10:13], ba=val[:, 13:16])
+
+
 def write_euroc_groundtruth(path, t, p, q_wxyz, v=None, bw=None, ba=None):
     """The same layout (tests and synthetic sequences): stamps in integer nanoseconds, six decimals like the dataset."""
     n = len(t)
@@ -85,9 +96,9 @@ def align_rigid(P_est, P_true):
 
 
 def ate(est_path, gt_path):
-    """ATE of a result file against an EuRoC ground-truth CSV: dict(rmse_m, mean_m, max_m, n_matched, n_estimates)."""
+    """ATE of a result file against an EuRoC ground-truth CSV (or the committed fixture of one, *.npz, or the parsed dict): dict(rmse_m, mean_m, max_m, n_matched, n_estimates)."""
     ts, P, _ = read_tum(est_path)
-    gt = read_euroc_groundtruth(gt_path)
+    gt = gt_path if isinstance(gt_path, dict) else load_groundtruth_fixture(gt_path) if str(gt_path).endswith(".npz") else read_euroc_groundtruth(gt_path)
     idx, keep = associate(ts, gt["t"])
     if keep.sum() < 3:
         raise ValueError("fewer than 3 estimates fall inside the ground truth's time span")
