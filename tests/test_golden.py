@@ -15,7 +15,7 @@ from helpers import uvs, abi, pose_deltas
 HERE = os.path.dirname(os.path.abspath(__file__))
 spec = importlib.util.spec_from_file_location("make_golden", os.path.join(HERE, "golden", "make_golden.py"))
 mg = importlib.util.module_from_spec(spec); spec.loader.exec_module(mg)
-CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(HERE, "golden", "*.npz")) if not p.endswith("config3_trace.npz"))
+CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(HERE, "golden", "*.npz")) if not p.endswith(("config3_trace.npz", "mh05_groundtruth.npz")))      # (window fixtures; the other two are a trace and a trajectory)
 
 
 def load(name):

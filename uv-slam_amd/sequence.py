@@ -107,27 +107,30 @@ def make_groundtruth_sequence(gt, seed=0, t_start=3.0, t_end=None, frame_stride=
     Messages and file layout as `make_sequence`."""
     from scipy.interpolate import CubicSpline
     from scipy.spatial.transform import Rotation, RotationSpline
-    rng = np.random.default_rng([52525, seed])
+    # independent streams, each consumed in time order: a sequence cut short with `t_end` is a PREFIX of the longer one, message for message
+    rng, rng_acc, rng_gyr, rng_init = (np.random.default_rng([52525, seed, k]) for k in range(4))
     NF = abi.NUM_FRAMES
     ex = ex_pose_euroc()
     t_abs = np.asarray(gt["t"], dtype=np.float64)
     i0 = int(np.searchsorted(t_abs, t_abs[0] + t_start))
     i1 = len(t_abs) if t_end is None else int(np.searchsorted(t_abs, t_abs[0] + t_end))
-    rows = np.arange(i0, i1, frame_stride)                     # ground-truth row of every frame
+    knots = np.arange(i0, len(t_abs), frame_stride)            # the splines always run through the WHOLE recording (a spline is global: cut short, it would differ)
+    rows = knots[knots < i1]                                   # ground-truth row of every frame
     n_frames = len(rows)
     if n_frames < NF + 1:
         raise ValueError("ground truth too short: %d frames" % n_frames)
     tk = t_abs[rows] - t_abs[i0]
-    q_xyzw = gt["q_wxyz"][rows][:, [1, 2, 3, 0]]
-    q_xyzw = q_xyzw / np.linalg.norm(q_xyzw, axis=1, keepdims=True)      # (the file prints six decimals)
-    pos = CubicSpline(tk, gt["p"][rows])
-    rot = RotationSpline(tk, Rotation.from_quat(q_xyzw))
+    q_knots = gt["q_wxyz"][knots][:, [1, 2, 3, 0]]
+    q_knots = q_knots / np.linalg.norm(q_knots, axis=1, keepdims=True)      # (the file prints six decimals)
+    q_xyzw = q_knots[:n_frames]
+    pos = CubicSpline(t_abs[knots] - t_abs[i0], gt["p"][knots])
+    rot = RotationSpline(t_abs[knots] - t_abs[i0], Rotation.from_quat(q_knots))
     # ---- 200 Hz IMU on the rows' stamps
     srows = np.arange(rows[0], rows[-1] + 1)
     ts = t_abs[srows] - t_abs[i0]
     Rw = rot(ts).as_matrix()
-    acc = np.einsum("nji,nj->ni", Rw, pos(ts, 2) + G) + gt["ba"][srows] + rng.normal(0, acc_sigma, (len(ts), 3))
-    gyr = rot(ts, 1) + gt["bw"][srows] + rng.normal(0, gyr_sigma, (len(ts), 3))      # RotationSpline's rate is the body rate
+    acc = np.einsum("nji,nj->ni", Rw, pos(ts, 2) + G) + gt["ba"][srows] + acc_sigma * rng_acc.standard_normal((len(ts), 3))
+    gyr = rot(ts, 1) + gt["bw"][srows] + gyr_sigma * rng_gyr.standard_normal((len(ts), 3))      # RotationSpline's rate is the body rate
     samples = [[(0.0, acc[0], gyr[0])]]
     for f in range(1, n_frames):
         a, b = rows[f - 1] - rows[0], rows[f] - rows[0]
@@ -218,9 +221,9 @@ def make_groundtruth_sequence(gt, seed=0, t_start=3.0, t_end=None, frame_stride=
     sb0 = np.hstack([Vs[:NF], seq.ba[:NF], seq.bg[:NF]])
     if perturb:       # an imperfect visual-inertial alignment
         for f in range(NF):
-            pose0[f, :3] += rng.normal(0, 0.02, 3)
-            q = quat_mul(pose0[f, 3:], exp_quat(rng.normal(0, np.deg2rad(0.5), 3))); pose0[f, 3:] = q / np.linalg.norm(q)
-            sb0[f, 0:3] += rng.normal(0, 0.05, 3); sb0[f, 3:6] += rng.normal(0, 0.01, 3); sb0[f, 6:9] += rng.normal(0, 0.001, 3)
+            pose0[f, :3] += rng_init.normal(0, 0.02, 3)
+            q = quat_mul(pose0[f, 3:], exp_quat(rng_init.normal(0, np.deg2rad(0.5), 3))); pose0[f, 3:] = q / np.linalg.norm(q)
+            sb0[f, 0:3] += rng_init.normal(0, 0.05, 3); sb0[f, 3:6] += rng_init.normal(0, 0.01, 3); sb0[f, 6:9] += rng_init.normal(0, 0.001, 3)
     seq.pose0, seq.sb0 = pose0, sb0
     return seq
 
