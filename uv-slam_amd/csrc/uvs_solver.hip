@@ -17,6 +17,8 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <sched.h>
+#include <pthread.h>
 #include <future>
 #include <atomic>
 #include <condition_variable>
@@ -61,6 +63,17 @@ struct PackPool {
     // run() that has already returned (its std::function lived on that run()'s stack) nor let it decrement a `pending` it was never counted in.
     void worker(int t, int seen0) {
         int seen = seen0;
+        // UVS_PACK_PIN=1: worker t stays on the (t + 1)-th CPU of the process's affinity mask (CPU 0 of the mask is left to the calling thread; on the EPYC hosts of the MI355X
+        // boxes the SMT sibling of CPU i is i + 128, so the first 32 are distinct cores).  Off by default: on a shared host a pinned worker cannot move away from a core
+        // another tenant is using (tools/stream_ab.py measures both; profiles/r06_stream_ab.txt)
+        if (const char* e = std::getenv("UVS_PACK_PIN")) if (e[0] == '1') {
+            cpu_set_t all; CPU_ZERO(&all);
+            if (sched_getaffinity(0, sizeof(all), &all) == 0) {
+                int want = t + 1, cpu = -1, count = CPU_COUNT(&all);
+                if (count > 1) { want %= count; for (int c = 0; c < CPU_SETSIZE; ++c) if (CPU_ISSET(c, &all) && want-- == 0) { cpu = c; break; } }
+                if (cpu >= 0) { cpu_set_t one; CPU_ZERO(&one); CPU_SET(cpu, &one); (void)pthread_setaffinity_np(pthread_self(), sizeof(one), &one); }
+            }
+        }
         for (;;) {
             const std::function<void(int)>* f;
             { std::unique_lock<std::mutex> lk(m); cv_go.wait(lk, [&] { return stop || gen != seen; }); if (stop) return; seen = gen; f = job; }
@@ -1482,7 +1495,8 @@ int uvs_batch_stream(uvs_solver* s, int n_batches, int per_batch, const uvs_wind
     if (per_batch > s->max_batch) { s->err = "batch larger than max_batch"; return UVS_ERR_CAPACITY; }
     // THREE buffer sets by default (UVS_STREAM_SETS=2: two): with two, the host can pack batch k only after batch k - 2 has been solved, and pack + copy (1.0 + 0.85 ms) then sit on
     // the critical path of every second kernel (1.72 ms per batch measured); with three the GPU always has a copied batch waiting
-    static const int NS = [] { const char* e = std::getenv("UVS_STREAM_SETS"); return e && std::atoi(e) == 2 ? 2 : 3; }();
+    // (the three knobs are read per CALL, not once per process: tools/stream_ab.py alternates the configurations inside one process, on the same windows)
+    const int NS = [] { const char* e = std::getenv("UVS_STREAM_SETS"); return e && std::atoi(e) == 2 ? 2 : 3; }();
     for (uvs_solver** t : {&s->twin, &s->twin2}) {
         if (t == &s->twin2 && NS < 3) break;
         if (!*t) { const int rc = uvs_create(&s->opts, s->device, s->max_batch, s->max_points, s->max_point_obs, s->max_lines, s->max_line_obs, t); if (rc != UVS_OK) { s->err = "uvs_batch_stream: could not create a buffer set"; return rc; } }
@@ -1491,8 +1505,8 @@ int uvs_batch_stream(uvs_solver* s, int n_batches, int per_batch, const uvs_wind
     }
     const auto t0 = std::chrono::steady_clock::now();
     uvs_solver* set[3] = {s, s->twin, s->twin2};
-    static const bool chain_ = [] { const char* e = std::getenv("UVS_STREAM_CHAIN"); return !(e && e[0] == '0'); }();
-    static const int d2h_ = [] { const char* e = std::getenv("UVS_STREAM_D2H_COPY"); return e ? std::atoi(e) : 0; }();      // 0: k_solve writes the results into the pinned buffer; 1: gather kernel + device-to-host copy; 2: the gather kernel writes them
+    const bool chain_ = [] { const char* e = std::getenv("UVS_STREAM_CHAIN"); return !(e && e[0] == '0'); }();
+    const int d2h_ = [] { const char* e = std::getenv("UVS_STREAM_D2H_COPY"); return e ? std::atoi(e) : 0; }();      // 0: k_solve writes the results into the pinned buffer; 1: gather kernel + device-to-host copy; 2: the gather kernel writes them
     for (int j = 0; j < NS; ++j) if (!set[j]->ev_done) HIPCHK(s, hipEventCreateWithFlags(&set[j]->ev_done, hipEventDisableTiming));
     int pending[3] = {-1, -1, -1};      // batch index in flight on each set
     // the resident blobs of this call carry addresses into its pinned result buffers (DevWin::out_host): whatever way the call ends, a later uvs_batch_solve needs its own upload
