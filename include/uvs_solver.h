@@ -44,7 +44,7 @@ extern "C" {
 enum {
     UVS_OK = 0,
     UVS_ERR_INVALID_ARG = 1,    /* null pointer / index out of range / bad count */
-    UVS_ERR_UNSUPPORTED = 2,    /* a combination this path does not take: relocalization blocks together with estimate_extrinsic in the uvs_large_* forms;
+    UVS_ERR_UNSUPPORTED = 2,    /* a combination this path does not take: relocalization blocks in a landmark-sharded solve over SEVERAL ranks;
                                  * RCCL not found for a multi-rank communicator */
     UVS_ERR_NO_DEVICE = 3,      /* no HIP device / extension cannot run (never falls back to CPU) */
     UVS_ERR_HIP = 4,            /* a HIP runtime call failed; see uvs_last_error() */
@@ -199,8 +199,8 @@ typedef struct uvs_window {
      * (Estimator::setReloFrame, estimator.cpp:1361-1379).  relo_lm must be strictly increasing and every such landmark needs at least
      * one ordinary observation (its anchor frame imu_i is taken from there).  With estimate_td the blocks stay plain ProjectionFactors (no
      * dependence on td, estimator.cpp:967-970).  With estimate_extrinsic the 6 + 6 (+ 1) free dofs beside the frames no longer fit the spare rows of
-     * the reduced system: relo_Pose is then eliminated at a second level (same exact solve of the damped system), which uvs_solve_window and the
-     * batch entry points implement; uvs_large_* return UVS_ERR_UNSUPPORTED for that combination. */
+     * the reduced system: relo_Pose is then eliminated at a second level (same exact solve of the damped system) -- by uvs_solve_window, the batch
+     * entry points and, on one rank, the uvs_large_* forms. */
     int32_t n_relo_obs;
     double relo_pose[UVS_SIZE_POSE];
     const int32_t *relo_lm;            /* [n_relo_obs] feature_index */
@@ -371,7 +371,7 @@ int uvs_large_solve(uvs_solver *s, const uvs_window *w, uvs_state *out, uvs_repo
  * terms in a workgroup beside them, the reduced solve in one workgroup; one upload, one stream of launches, one download, one wait.
  * On MI355X a canonical 10-keyframe window takes 1.2 ms per call this way against 1.7 ms through uvs_solve_window() (which keeps the
  * whole solve on one compute unit and is what a BATCH of windows uses per window).  Same LM controller, same results to rounding
- * (tests/test_fused_single.py); relocalization blocks are only taken by uvs_solve_window(). */
+ * (tests/test_fused_single.py); relocalization blocks are taken on one rank (tests/test_relo.py). */
 typedef struct uvs_rccl_id { char internal[128]; } uvs_rccl_id;      /* == ncclUniqueId */
 int uvs_large_comm_unique_id(uvs_rccl_id *id);
 int uvs_large_comm_init(uvs_solver *s, int nranks, int rank, const uvs_rccl_id *id);

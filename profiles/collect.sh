@@ -45,9 +45,10 @@ UVS_DENSE_SCHUR=1 python tests/gpu_debug_prior.py > gpurun_out/${TAG}_phase_cycl
 UVS_DENSE_SCHUR=1 UVS_DEBUG_LIN_TIMELINE=$R/gpurun_out/${TAG}_tl512d.bin python tests/gpu_debug_prior.py > /dev/null 2>&1; python tools/lin_timeline.py gpurun_out/${TAG}_tl512d.bin 2 > gpurun_out/${TAG}_lin_timeline_dense.txt 2>&1
 (cd /tmp; rm -rf $R/gpurun_out/prof_stream; rocprofv3 --kernel-trace --memory-copy-trace --hip-runtime-trace --output-format csv -d $R/gpurun_out/prof_stream -o s -- python $R/tools/stream_rate.py 16 > /dev/null 2>&1)
 python tools/stream_trace.py gpurun_out/prof_stream 14 > gpurun_out/${TAG}_stream_timeline.txt 2>&1
-(cd /tmp; rm -rf $R/gpurun_out/prof_stream_d2h; UVS_STREAM_D2H_COPY=1 UVS_STREAM_SETS=2 UVS_STREAM_CHAIN=0 rocprofv3 --kernel-trace --memory-copy-trace --hip-runtime-trace --output-format csv -d $R/gpurun_out/prof_stream_d2h -o s -- python $R/tools/stream_rate.py 16 > /dev/null 2>&1)
+(cd /tmp; rm -rf $R/gpurun_out/prof_stream_d2h; UVS_STREAM_D2H_COPY=1 UVS_STREAM_SETS=2 rocprofv3 --kernel-trace --memory-copy-trace --hip-runtime-trace --output-format csv -d $R/gpurun_out/prof_stream_d2h -o s -- python $R/tools/stream_rate.py 16 > /dev/null 2>&1)
 python tools/stream_trace.py gpurun_out/prof_stream_d2h 14 > gpurun_out/${TAG}_stream_timeline_d2h_copy.txt 2>&1
-{ for cfg in "" "UVS_STREAM_SETS=2" "UVS_STREAM_CHAIN=0" "UVS_STREAM_D2H_COPY=2" "UVS_STREAM_D2H_COPY=1" "UVS_STREAM_D2H_COPY=1 UVS_STREAM_SETS=2 UVS_STREAM_CHAIN=0" "UVS_PACK_THREADS=16" "UVS_PACK_THREADS=64"; do echo "== ${cfg:-default (three sets, chained kernels, results written into pinned memory by k_solve, 32 packing threads)}"; env $cfg REPS=4 python tools/stream_rate.py 32 | head -4; done; } > gpurun_out/${TAG}_stream_ab.txt 2>&1
+# (round 6: the switches are read per call; ONE process alternates the configurations on the same windows, ten runs each: median / quartiles)
+python tools/stream_ab.py 10 32 256 > gpurun_out/${TAG}_stream_ab.txt 2>&1
 (cd tools && hipcc --offload-arch=gfx950 -O2 -o micro_overlap micro_overlap.hip -lpthread 2>/dev/null; ./micro_overlap 46 1.5) > gpurun_out/${TAG}_micro_overlap.txt 2>&1
 python profiles/summarize.py $TAG      # printed for the log; gpurun only merges gpurun_out/ back, so re-run these two lines locally afterwards:
 #   bash profiles/copy_back.sh $TAG

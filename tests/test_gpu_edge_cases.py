@@ -235,11 +235,11 @@ def test_batch_stream_equals_batch_by_batch(gpu_api):
     ref.close()
 
 
-@pytest.mark.parametrize("env", [{"UVS_STREAM_SETS": "2"}, {"UVS_STREAM_CHAIN": "0"}, {"UVS_STREAM_D2H_COPY": "1"}, {"UVS_STREAM_D2H_COPY": "2"}])
+@pytest.mark.parametrize("env", [{"UVS_STREAM_SETS": "2"}, {"UVS_STREAM_CHAIN": "1"}, {"UVS_STREAM_D2H_COPY": "1"}, {"UVS_STREAM_D2H_COPY": "2"}])
 def test_batch_stream_switches(gpu_api, env, monkeypatch):
-    """The A/B switches of the stream (two buffer sets; kernels not chained by events; results gathered on the device and fetched by a copy, or written to the host by the gather
+    """The A/B switches of the stream (two buffer sets; kernels of consecutive batches chained by events; results gathered on the device and fetched by a copy, or written to the host by the gather
     kernel, instead of by k_solve itself) give the same bits.
-    (Read once per process: this test runs them in a child.)"""
+    (Each variant in a child process of its own.)"""
     import subprocess, sys, os
     code = ("import importlib, numpy as np, sys; sys.path.insert(0, %r); u = importlib.import_module('uv-slam_amd'); "
             "ws = [u.synth.make_window(1300 + i, n_points=30 + 7 * i, n_lines=i %% 9, n_tagged=0) for i in range(28)]; s = u.api.Solver(max_batch=8); "

@@ -164,7 +164,7 @@ def test_relo_blocks_with_estimate_td(gpu_api, oracle, form, index, kw):
 def test_relo_blocks_with_a_free_extrinsic(gpu_api, oracle, index, kw, td):
     """ESTIMATE_EXTRINSIC (and ESTIMATE_TD) together with relocalization blocks: 6 + 6 (+ 1) free dofs do not fit the 11 spare rows of the reduced
     system, so relo_Pose is eliminated at a second level (rank-6 update of S before the factorization, uvs_solve_kernel.h: relo2_eliminate) -- the
-    same exact solve of the damped system; same LM trace and states as the oracle's dense solve.  Persistent kernel and batches only."""
+    same exact solve of the damped system; same LM trace and states as the oracle's dense solve.  Persistent kernel, batches, and (round 6) the multi-workgroup forms."""
     w = _relo_window(index, **kw)
     if td: w = synth.add_time_offset(w)
     assert len(w.relo_lm) > 0
@@ -186,9 +186,19 @@ def test_relo_blocks_with_a_free_extrinsic(gpu_api, oracle, index, kw, td):
     assert np.abs(sg.inv_depth - so.inv_depth).max() < 1e-6
     assert abs(rg.final_cost - ro.final_cost) <= 1e-6 * ro.final_cost
     assert rp2[1].final_cost == rg.final_cost and np.array_equal(st2[1].relo_pose, sg.relo_pose)
-    # the landmark-sharded forms say so instead of solving something else
-    with pytest.raises(RuntimeError, match="uvs error %d" % abi.UVS_ERR_UNSUPPORTED):
-        s.large_solve_fused(w)
+    # the landmark-sharded forms of one rank (round 6): the 14 gather blocks of block row 13 travel behind the canonical partial, k_large_solve eliminates relo_Pose
+    # at the second level like k_solve does (uvs_large_kernel.h: LG_R2) -- the fused device-side loop and the step-wise loop, same trace and states
+    sf, rf, _ = s.large_solve_fused(w)
+    s1, r1 = s.large_solve(w)
+    for name, (st, rep) in {"fused": (sf, rf), "step-wise": (s1, r1)}.items():
+        assert rep.status == 0 and rep.num_iterations == ro.num_iterations, name
+        assert list(rep.accepted[: rep.num_iterations + 1]) == list(ro.accepted[: ro.num_iterations + 1]), name
+        dpf, daf = pose_deltas(st.pose, so.pose)
+        assert dpf < 1e-6 and daf < 1e-6, (name, dpf, daf)
+        assert np.abs(st.ex_pose[:3] - so.ex_pose[:3]).max() < 1e-7 and quat_angle(st.ex_pose[3:], so.ex_pose[3:]) < 1e-6, name
+        assert np.abs(st.relo_pose[:3] - so.relo_pose[:3]).max() < 1e-6 and quat_angle(st.relo_pose[3:], so.relo_pose[3:]) < 1e-6, name
+        if td: assert abs(st.td - so.td) < 1e-8, name
+        assert np.abs(st.inv_depth - so.inv_depth).max() < 1e-6 and abs(rep.final_cost - ro.final_cost) <= 1e-6 * ro.final_cost, name
     s.close()
 
 

@@ -17,8 +17,8 @@ api, synth = pkg.api, pkg.synth
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 nb = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 per = int(sys.argv[3]) if len(sys.argv) > 3 else 256
-CONFIGS = [("default", {}), ("UVS_STREAM_CHAIN=0", {"UVS_STREAM_CHAIN": "0"}), ("UVS_PACK_THREADS=64", {"UVS_PACK_THREADS": "64"}),
-           ("UVS_PACK_THREADS=16", {"UVS_PACK_THREADS": "16"}), ("UVS_STREAM_CHAIN=0 UVS_PACK_THREADS=64", {"UVS_STREAM_CHAIN": "0", "UVS_PACK_THREADS": "64"})]
+CONFIGS = [("default (un-chained, 32 packing threads)", {"UVS_STREAM_CHAIN": "0"}), ("UVS_STREAM_CHAIN=1", {"UVS_STREAM_CHAIN": "1"}), ("UVS_PACK_THREADS=64", {"UVS_STREAM_CHAIN": "0", "UVS_PACK_THREADS": "64"}),
+           ("UVS_PACK_THREADS=16", {"UVS_STREAM_CHAIN": "0", "UVS_PACK_THREADS": "16"}), ("UVS_STREAM_CHAIN=1 UVS_PACK_THREADS=64", {"UVS_STREAM_CHAIN": "1", "UVS_PACK_THREADS": "64"})]
 if os.environ.get("UVS_AB_EXTRA"):      # e.g. UVS_AB_EXTRA="UVS_PACK_PIN=1;UVS_PACK_PIN=1,UVS_STREAM_CHAIN=0"
     for spec in os.environ["UVS_AB_EXTRA"].split(";"):
         CONFIGS.append((spec.replace(",", " "), dict(kv.split("=") for kv in spec.split(","))))

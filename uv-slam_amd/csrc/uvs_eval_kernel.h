@@ -108,7 +108,7 @@ __global__ __launch_bounds__(NT) void k_evaluate(char* blob, double* ws, KOpts o
 struct EvalScratch {
     double* d = nullptr; size_t cap = 0;       // device, doubles
     double* h = nullptr; size_t hcap = 0;      // pinned host, doubles
-    std::vector<double> work[10];              // host work arrays of the marginalization, kept between calls (a fresh 160 KB vector per call is an mmap / page-fault / munmap round trip)
+    std::vector<double> work[11];              // host work arrays of the marginalization, kept between calls (a fresh 160 KB vector per call is an mmap / page-fault / munmap round trip)
     void release() { if (d) (void)hipFree(d); if (h) (void)hipHostFree(h); d = h = nullptr; cap = hcap = 0; }
 };
 

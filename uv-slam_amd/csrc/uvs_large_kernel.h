@@ -16,8 +16,13 @@
 
 namespace uvsdev {
 
-static constexpr int LG_ACC = UVS_NBLKX * 64;               // 4992 accumulator slots [gather block (66 pose blocks + 12 time-offset blocks)][row a][8] -- canonical, independent of the per-window group balance
+static constexpr int LG_ACC = UVS_NBLKX * 64;               // 5824 accumulator slots [gather block (66 pose blocks + 12 time-offset blocks + 13 extrinsic / relo_Pose blocks)][row a][8] -- canonical, independent of the per-window group balance
 static constexpr int LG_RED = LG_ACC + 8;                  // + {landmark cost, max |g_l|, 6 spare}
+// Relocalization blocks beside a FREE extrinsic (DevWin::relo2, round 6): the 14 gather blocks of block row 13 (relo_Pose x {11 frames, td, extrinsic, itself}) travel as a TAIL
+// behind everything else -- in a partial row at [LG_RED, LG_ROW), in `reduced` at [LG_XCH, LG_XCH_ALL) -- so that no offset, loop bound or all-reduce payload of a window without
+// them changes; in the LDS image of large_partial_image they follow the canonical blocks directly (block b at 64 b).  Single rank only (uvs_large_solve_fused rejects several).
+static constexpr int LG_R2 = (UVS_NBLKX2 - UVS_NBLKX) * 64;   // 896
+static constexpr int LG_ROW = LG_RED + LG_R2;                 // row stride of `partials`
 enum { LS_X = 0, LS_XC = UVS_XDIM, LS_DLT = 2 * UVS_XDIM, LS_G = LS_DLT + UVS_RD, LS_DD = LS_G + UVS_RD, LS_SC = LS_DD + UVS_RD, LS_END = LS_SC + UVS_RD };
 static constexpr int LG_STATE = 1280;                      // doubles: X[192] XC[192] DLT[176] G[176] DD[176] SC[176]   (X = pose | speedbias | ex_pose | td | relo_pose | pad)
 static_assert(LS_END <= LG_STATE, "large-path state vector overflows its allocation");
@@ -29,7 +34,8 @@ enum { LO_COST = 0, LO_GMAX, LO_CHOLOK, LO_GD, LO_DD2, LO_STEP2, LO_XC2, LO_FRAM
 static constexpr int LG_MAXRANKS = 8;
 // frame image written by the extra workgroup of k_large_chunks: S without the landmark blocks and without damping | gradient | diag(J^T J) | {cost of the frame terms}
 static constexpr int FI_S = 0, FI_G = UVS_S_DOUBLES, FI_HD = FI_G + UVS_RD, FI_COST = FI_HD + UVS_RD, LG_FIMG = FI_COST + 8;
-static constexpr int LX_X2 = LG_RED, LX_GMAX = LG_RED + 1, LG_XCH = LG_RED + 1 + LG_MAXRANKS + 7;      // 5016 doubles
+static constexpr int LX_X2 = LG_RED, LX_GMAX = LG_RED + 1, LG_XCH = LG_RED + 1 + LG_MAXRANKS + 7;      // 5848 doubles
+static constexpr int LG_XCH_ALL = LG_XCH + LG_R2;      // allocation of `reduced` (the relo2 tail behind the exchange vector)
 enum { LC_RADIUS = 0, LC_DECR, LC_COST, LC_GMAX, LC_XNORM, LC_FRAME_X2, LC_IT, LC_INVALID, LC_NSUCC, LC_PENDING, LC_TERM, LC_STATUS, LC_FIRST, LC_DONE, LC_SEL, LC_REDAMP, LC_T0, LC_N };      // LC_REDAMP: the last step was rejected / invalid => the next pass re-damps the same linearization
 struct LargeCtl { const double* ctl; int rank, nranks; };
 // debug timeline of k_large_chunks (KOpts::debug == 7, UVS_LARGE_PROF=<file> in uvs_large_solve_fused): per workgroup 8 stamps of the 100 MHz wall clock
@@ -50,7 +56,7 @@ UVS_DEV void large_partial_image(const Ctx& c, GAcc& A, int grp, bool gather) {
     __syncthreads();
     if (gather) gacc_gather_parts(A, grp, sh + L_S); else role_barriers(2);      // (the part exchange has two barriers inside)
     __syncthreads();
-    for (int i = tid; i < LG_ACC; i += NT) sh[L_S + i] = 0.0;
+    for (int i = tid; i < LG_ACC + LG_R2; i += NT) sh[L_S + i] = 0.0;
     __syncthreads();
     if (gather && grp >= 0 && ((grp >> 9) & 15) == 0) {
         const int r0 = GR * (tid % UVS_GLANES);
@@ -153,9 +159,14 @@ __global__ __launch_bounds__(NT) void k_large_chunks(char* blob, double* ws, KOp
     if (o.debug == 7 && tid == 0 && blockIdx.x < 1024) g_large_prof[8 * blockIdx.x + 7] = taken;
     double cost = lacc_cost(sh), gmax = lacc_gmax(sh);
     if (!ROLES) { large_partial_image(c, A, grp, true); UVS_LPROF(4); }
-    double* P = partials + (size_t)blockIdx.x * LG_RED;
-    if (redamp) { for (int i = tid; i < LG_ACC; i += NT) P[i] += sh[L_S + i]; return; }      // cost and landmark gradient norm of the partial are unchanged
+    double* P = partials + (size_t)blockIdx.x * LG_ROW;
+    if (redamp) {      // cost and landmark gradient norm of the partial are unchanged
+        for (int i = tid; i < LG_ACC; i += NT) P[i] += sh[L_S + i];
+        if (h.relo2) for (int i = tid; i < LG_R2; i += NT) P[LG_RED + i] += sh[L_S + LG_ACC + i];
+        return;
+    }
     for (int i = tid; i < LG_ACC; i += NT) P[i] = sh[L_S + i];
+    if (h.relo2) for (int i = tid; i < LG_R2; i += NT) P[LG_RED + i] = sh[L_S + LG_ACC + i];
     double s4[4] = {cost, 0, 0, 0};
     block_reduce(sh, s4, &gmax);
     if (tid == 0) { P[LG_ACC] = s4[0]; P[LG_ACC + 1] = gmax; }
@@ -165,7 +176,7 @@ __global__ __launch_bounds__(NT) void k_large_chunks(char* blob, double* ws, KOp
 // Deterministic two-level sum of the per-chunk partials: a workgroup owns 16 consecutive entries i, its 16 x 16 threads split the chunk
 // range into 16 contiguous slices (summed in chunk order, loads independent of each other), the 16 slice sums are then added in slice
 // order.  (One thread per entry walking all chunks serially took 137 us for 340 chunks -- more than k_large_chunks itself.)
-__global__ __launch_bounds__(256) void k_large_reduce(const double* partials, int n_chunks, double* reduced, LargeCtl lc) {
+__global__ __launch_bounds__(256) void k_large_reduce(const double* partials, int n_chunks, double* reduced, LargeCtl lc, int n_ent /* LG_RED, or LG_ROW with the relo2 tail */) {
     __shared__ double part[16][17];
     if (lc.ctl && lc.ctl[LC_DONE] != 0.0) return;
     const int il = threadIdx.x & 15, p = threadIdx.x >> 4;
@@ -173,21 +184,21 @@ __global__ __launch_bounds__(256) void k_large_reduce(const double* partials, in
     const bool is_max = (i == LG_ACC + 1);
     const int per = (n_chunks + 15) / 16, c0 = p * per, c1 = (c0 + per < n_chunks) ? c0 + per : n_chunks;
     double s = 0.0;
-    if (i < LG_RED) {
+    if (i < n_ent) {      // (entries >= LG_RED: the relo2 tail)
         for (int cb = c0; cb < c1; cb += 16) {      // 16 rows per batch of loads, summed in row order (the plain loop compiled to a few loads per memory round trip)
             double v[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) v[u] = partials[(size_t)(cb + u < c1 ? cb + u : cb) * LG_RED + i];
+            for (int u = 0; u < 16; ++u) v[u] = partials[(size_t)(cb + u < c1 ? cb + u : cb) * LG_ROW + i];
 #pragma unroll
             for (int u = 0; u < 16; ++u) if (cb + u < c1) s = is_max ? fmax(s, v[u]) : s + v[u];
         }
     }
     part[p][il] = s;
     __syncthreads();
-    if (p == 0 && i < LG_RED) {
+    if (p == 0 && i < n_ent) {
         double t = part[0][il];
         for (int q = 1; q < 16; ++q) t = is_max ? fmax(t, part[q][il]) : t + part[q][il];      // fixed order => deterministic
-        reduced[i] = t;
+        reduced[i < LG_RED ? i : LG_XCH + (i - LG_RED)] = t;
         // fused multi-GPU exchange: the landmark gradient max-norm travels in this rank's slot of a SUM all-reduce
         if (is_max && lc.ctl) for (int r = 0; r < LG_MAXRANKS; ++r) reduced[LX_GMAX + r] = (r == lc.rank) ? t : 0.0;
     }
@@ -225,13 +236,15 @@ __global__ __launch_bounds__(NT) void k_large_solve(char* blob, double* ws, KOpt
         const bool ld = grp >= 0 && !((grp >> 9) & 15);       // part 0 carries the whole (already summed) block
 #pragma unroll
         for (int r = 0; r < GR; ++r) {
-            const double* Q = reduced + (grp & 255) * 64 + (r0 + r) * 8;
+            const int gb = grp & 255;
+            const double* Q = reduced + (gb < UVS_NBLKX ? gb * 64 : LG_XCH + (gb - UVS_NBLKX) * 64) + (r0 + r) * 8;
 #pragma unroll
             for (int q = 0; q < 6; ++q) A.v[6 * r + q] = ld ? Q[q] : 0.0;
             A.g[r] = ld ? Q[6] : 0.0; A.hd[r] = ld ? Q[7] : 0.0;
         }
     }
     ImuN N;      // unused in mode 2
+    if (c.hdr->relo2) for (int t = tid; t < R2_SC; t += NT) c.ws[c.hdr->w_relo2 + t] = 0.0;      // side buffer of the second-level relo_Pose (asm_zero does this for k_solve; lin_assemble's first barrier precedes the rows' stores)
     const double cost = tid == 0 ? fimg[FI_COST] + reduced[LG_ACC] : 0.0;
     lin_assemble(c, sh + L_X, first != 0, radius, grp, A, N, cost, gmax_lm, 2);
     if (tid < UVS_RD) sh[L_DLT + tid] = -sh[L_G + tid];

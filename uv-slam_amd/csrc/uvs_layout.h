@@ -23,7 +23,7 @@
                                                // gather blocks of relo_Pose get a block row of their own, 13 -- (13, f) = 91 + f, (13, td) = 102, (13, ex) = 103, (13, 13) = 104 --
                                                // which the assembly writes to a side buffer in the workspace instead of S; relo_Pose is then eliminated from the reduced system by a
                                                // rank-6 update before the factorization (k_solve only).  pt_fj of a relocalization block stays UVS_RELO_FRAME.
-#define UVS_NBLKX2 (UVS_NBLKX + UVS_NF + 3)    // 105: gather blocks including block row 13 (host packing only; the large-window kernels never see it)
+#define UVS_NBLKX2 (UVS_NBLKX + UVS_NF + 3)    // 105: gather blocks including block row 13 (the large-window kernels carry its 14 blocks as a tail behind the canonical partial: uvs_large_kernel.h LG_R2)
 #define UVS_RELO2_DOUBLES 2304                 // side buffer: R[6][176] | Rrr[36] | g_r[6] | hd_r[6] | sc_r[6] | D_r[6] | Minv[36] | mg[6] | Z[6][176] | dr[6]
 #define UVS_XDIM 192                           // frame state vector: pose[11][7] sb[11][9] ex[7] td relo_pose[7] pad
 #define UVS_TD_INDEX (UVS_RD - 1)              // para_Td sits in the spare 16th slot of the last frame (index 175 of the padded reduced system)

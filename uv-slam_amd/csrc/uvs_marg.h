@@ -284,6 +284,37 @@ static int marg_finish(int N, int m, int md, int n, std::vector<double>& A, std:
     return UVS_OK;
 }
 
+// The prior's residual r = r0 + J0 dx at the window's state, on the HOST (marginalization_factor.cpp:340-365: Euclidean difference per kept block, for a pose block
+// [p - p0 ; 2 sign(w) vec(q0^-1 (x) q)]): what MARGIN_SECOND_NEW needs and all it needs -- that marginalization reads the old prior and nothing else (estimator.cpp:1159-1176),
+// so it takes no device round trip at all (round 6; before, the whole window was packed, uploaded and evaluated on the device for this one vector).
+static void host_prior_residual(const uvs_prior& p, const uvs_window* w, std::vector<double>& r) {
+    const int n = p.n;
+    double dx[UVS_MAX_PRIOR_DIM];
+    for (int k = 0; k < n; ++k) dx[k] = 0.0;
+    for (int b = 0; b < p.n_blocks; ++b) {
+        const int kind = p.block_kind[b], size = p.block_size[b];
+        const double* x = kind == UVS_BLOCK_POSE ? w->pose[p.block_frame[b]] : kind == UVS_BLOCK_SPEEDBIAS ? w->speedbias[p.block_frame[b]] : kind == UVS_BLOCK_TD ? &w->td : w->ex_pose;
+        const double* x0 = p.x0 + p.x0_off[b];
+        double* d = dx + p.block_idx[b];
+        if (size != 7) { for (int k = 0; k < size; ++k) d[k] = x[k] - x0[k]; continue; }
+        for (int k = 0; k < 3; ++k) d[k] = x[k] - x0[k];
+        // e = q0^-1 (x) q, quaternions stored (x, y, z, w); Eigen's inverse() divides the conjugate by the squared norm
+        const double ax = -x0[3], ay = -x0[4], az = -x0[5], aw = x0[6], nn = x0[3] * x0[3] + x0[4] * x0[4] + x0[5] * x0[5] + x0[6] * x0[6];
+        const double bx = x[3], by = x[4], bz = x[5], bw = x[6];
+        const double ex = (aw * bx + ax * bw + ay * bz - az * by) / nn, ey = (aw * by - ax * bz + ay * bw + az * bx) / nn, ez = (aw * bz + ax * by - ay * bx + az * bw) / nn;
+        const double ew = (aw * bw - ax * bx - ay * by - az * bz) / nn;
+        const double sg = ew >= 0.0 ? 2.0 : -2.0;
+        d[3] = sg * ex; d[4] = sg * ey; d[5] = sg * ez;
+    }
+    r.assign(n, 0.0);
+    for (int i = 0; i < n; ++i) {
+        const double* Ji = &p.linearized_jacobians[(size_t)i * n];
+        double acc = p.linearized_residuals[i];
+        for (int k = 0; k < n; ++k) acc += Ji[k] * dx[k];
+        r[i] = acc;
+    }
+}
+
 struct MFactor { int rows; int nb; int id[5]; int sz[5]; const double* r; const double* J; int ld; int coff[5]; const double* Jx; int xcol; };   // J row stride ld, column offset per block; block with coff < 0 reads its single column from Jx[row stride 1... 2 entries]   // J row stride ld, column offset per block
 
 static int run_marginalize(int device, hipStream_t stream, char* d_blob, double* d_ws, const DevWin& h, const uvs_window* w, const KOpts& ko,
@@ -299,9 +330,14 @@ static int run_marginalize(int device, hipStream_t stream, char* d_blob, double*
     // MARGIN_OLD reads only the factors that touch frame 0 (a fifth of the window): the kernel skips the rest (mode bit 1); MARGIN_SECOND_NEW
     // reads the prior residual only, which the same subset mode delivers without evaluating a single observation of frame 0... it does evaluate
     // those, a few microseconds, to keep one code path
-    int rc = run_evaluate(device, stream, d_blob, d_ws, h, ko, 1 | 2, &ev, err, sc, true);
-    if (rc != UVS_OK) return rc;
-    const double *pt_r = ev.pt_r, *pt_J = ev.pt_J, *ln_r = ev.ln_r, *ln_J = ev.ln_J, *vp_r = ev.vp_r, *vp_J = ev.vp_J, *imu_r = ev.imu_r, *imu_J = ev.imu_J, *prior_r = ev.prior_r, *pt_Jtd = ev.pt_Jtd;
+    std::vector<double>& prior_r_host = sc.work[10];
+    if (flag == 1) {      // MARGIN_SECOND_NEW reads the prior only: its residual at the window's state is an n x n mat-vec on the host (host_prior_residual), no kernel, no copies
+        if (w->prior && w->prior->n > 0) host_prior_residual(*w->prior, w, prior_r_host);
+    } else {
+        const int rc = run_evaluate(device, stream, d_blob, d_ws, h, ko, 1 | 2, &ev, err, sc, true);
+        if (rc != UVS_OK) return rc;
+    }
+    const double *pt_r = ev.pt_r, *pt_J = ev.pt_J, *ln_r = ev.ln_r, *ln_J = ev.ln_J, *vp_r = ev.vp_r, *vp_J = ev.vp_J, *imu_r = ev.imu_r, *imu_J = ev.imu_J, *prior_r = flag == 1 ? prior_r_host.data() : ev.prior_r, *pt_Jtd = ev.pt_Jtd;
     auto t1 = tnow();
     // ---- host: block bookkeeping.  ids: pose f -> f ; speedbias f -> 11+f ; ex -> 22 ; td -> 23 ; point k -> 24+k ; line l -> 24+Np+l
     const int Np = w->n_points, Nl = w->n_lines, PT0 = 24, NID = PT0 + Np + Nl;

@@ -2870,7 +2870,7 @@ UVS_DEV void asm_finish(const Ctx& c, const double* x, bool first, double radius
 #pragma unroll
         for (int k = 0; k < 7; ++k) gmax = fmax(gmax, fabs(xa[k] - xp[k]));
     }
-    if (h.relo2 && mode == 0) relo2_eliminate(c, x, first, radius, gmax);
+    if (h.relo2) relo2_eliminate(c, x, first, radius, gmax);      // (mode 0: k_solve; mode 2: k_large_solve, whose side buffer was filled from the reduced tail of block row 13)
     double s4[4] = {cost, 0.0, 0.0, 0.0};
     block_reduce(sh, s4, &gmax);
     if (tid == 0) { sh[L_CTRL + C_COST] = s4[0]; sh[L_CTRL + C_GMAX] = gmax; }

@@ -497,9 +497,8 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
     if (n_relo > 0) {
         // relo_Pose takes the six spare slots of the reduced system that a free extrinsic would take; the time offset has its own (index 175), so
         // ESTIMATE_TD and relocalization blocks coexist (estimator.cpp:784-797 + :944-978)
-        // with a free extrinsic the spare slots are taken: relo_Pose becomes a second-level block (uvs_layout.h: UVS_RELO2_BLOCKROW), which only the persistent
-        // kernel implements (chunk_grid > 0 = the landmark-sharded forms)
-        if (opts.estimate_extrinsic != 0 && chunk_grid > 0) { err = "relocalization blocks together with estimate_extrinsic are taken by uvs_solve_window / the batch entry points only"; return UVS_ERR_UNSUPPORTED; }
+        // with a free extrinsic the spare slots are taken: relo_Pose becomes a second-level block (uvs_layout.h: UVS_RELO2_BLOCKROW) -- in the persistent kernel and, since
+        // round 6, in the landmark-sharded forms of one rank (chunk_grid > 0; uvs_large_kernel.h: LG_R2)
         if (!w_in->relo_lm || !w_in->relo_pi || !w_in->relo_pj) { err = "null array"; return UVS_ERR_INVALID_ARG; }
         const int npo = w_in->n_point_obs;
         int q = 0;
@@ -1505,7 +1504,10 @@ int uvs_batch_stream(uvs_solver* s, int n_batches, int per_batch, const uvs_wind
     }
     const auto t0 = std::chrono::steady_clock::now();
     uvs_solver* set[3] = {s, s->twin, s->twin2};
-    const bool chain_ = [] { const char* e = std::getenv("UVS_STREAM_CHAIN"); return !(e && e[0] == '0'); }();
+    // UVS_STREAM_CHAIN=1: the kernels of consecutive batches chained by events (round 5's default).  Round 6 measured both forms alternately in one process, ten runs of 32 batches each
+    // (tools/stream_ab.py, profiles/r06_stream_ab.txt): un-chained 175.4 k solves/s median (quartiles 171.3 - 175.9 k), chained 167.5 k (167.3 - 167.8 k) -- the chain is steadier and
+    // 4.5 % slower (a batch's kernel then never starts under the tail of the previous one, whose last workgroups leave compute units idle), so the default is un-chained.
+    const bool chain_ = [] { const char* e = std::getenv("UVS_STREAM_CHAIN"); return e && e[0] == '1'; }();
     const int d2h_ = [] { const char* e = std::getenv("UVS_STREAM_D2H_COPY"); return e ? std::atoi(e) : 0; }();      // 0: k_solve writes the results into the pinned buffer; 1: gather kernel + device-to-host copy; 2: the gather kernel writes them
     for (int j = 0; j < NS; ++j) if (!set[j]->ev_done) HIPCHK(s, hipEventCreateWithFlags(&set[j]->ev_done, hipEventDisableTiming));
     int pending[3] = {-1, -1, -1};      // batch index in flight on each set
@@ -1528,8 +1530,8 @@ int uvs_batch_stream(uvs_solver* s, int n_batches, int per_batch, const uvs_wind
         int rc = drain(q);
         if (sprof_) fprintf(stderr, "stream batch %d: drain (wait + unpack of batch %d) %.3f ms\n", k, k - NS, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - td0_).count());
         if (rc == UVS_OK) rc = upload_windows(set[q], per_batch, ws + (size_t)k * per_batch, false, 0, d2h_ == 0);
-        // the kernels run one after the other (an event chain through the sets): two k_solve launches on two streams otherwise share the compute units workgroup by workgroup,
-        // both finish late and together, and the host -- which packs batch k + 1 into the set of the batch that finishes first -- stalls and then has two batches to pack in a row
+        // (UVS_STREAM_CHAIN=1) the kernels run one after the other (an event chain through the sets): two k_solve launches on two streams otherwise share the compute units workgroup by
+        // workgroup, both finish late and together, and the host -- which packs batch k + 1 into the set of the batch that finishes first -- stalls and then has two batches to pack in a row
         if (rc == UVS_OK && chain_ && k > 0 && hipStreamWaitEvent(set[q]->stream, set[(k - 1) % NS]->ev_done, 0) != hipSuccess) { s->err = "hipStreamWaitEvent failed"; rc = UVS_ERR_HIP; }
         if (rc == UVS_OK) rc = launch_solve(set[q], 0, nullptr, false, d2h_ == 0);
         if (rc == UVS_OK && chain_ && hipEventRecord(set[q]->ev_done, set[q]->stream) != hipSuccess) { s->err = "hipEventRecord failed"; rc = UVS_ERR_HIP; }
@@ -1594,8 +1596,18 @@ int uvs_evaluate(uvs_solver* s, const uvs_window* w, int robust, uvs_eval* out) 
     return run_evaluate(s->device, s->stream, s->d_blobs, s->d_ws, s->hdrs[0], make_kopts(s->opts, 0), robust, out, s->err, s->eval_scratch);
 }
 
+// MARGIN_SECOND_NEW (estimator.cpp:1159-1228) marginalizes Pose[WINDOW_SIZE - 1] out of the OLD PRIOR and reads nothing else: no factor is evaluated, so no kernel runs and nothing is
+// copied -- r = r0 + J0 dx, A = J0^T J0, b = J0^T r, the 6 x 6 elimination and the n x n factorization are host work (uvs_marg.h).  Round 5 packed and uploaded the window and
+// evaluated it on the device to obtain that one vector r (0.2 ms of the 0.5 ms a call took).
+static int marginalize_second_new_host(uvs_solver* s, const uvs_window* w, uvs_prior* out) {
+    { const int rv = validate_window(w, s->err); if (rv != UVS_OK) return rv; }
+    DevWin h; std::memset(&h, 0, sizeof(h)); h.td_on = s->opts.estimate_td != 0;
+    return run_marginalize(s->device, s->stream, nullptr, nullptr, h, w, make_kopts(s->opts, 0), 1, out, s->err, s->eval_scratch);
+}
+
 int uvs_marginalize(uvs_solver* s, const uvs_window* w, int flag, uvs_prior* out) {
     if (!s || !w || !out || (flag != 0 && flag != 1)) return UVS_ERR_INVALID_ARG;
+    if (flag == 1) return marginalize_second_new_host(s, w, out);
     if (flag == 0) { const int rd = marginalize_old_device(s, w, out); if (rd != kMargFallback) return rd; }
     const uvs_window* arr[1] = {w};
     const auto tu0 = std::chrono::steady_clock::now();
@@ -1614,6 +1626,7 @@ int uvs_marginalize_resident(uvs_solver* s, const uvs_window* w, int flag, uvs_p
     if (h.n_points != w->n_points || h.n_pt_obs - h.n_relo != w->n_point_obs || h.n_lines != w->n_lines || h.n_ln_obs != w->n_line_obs || h.n_imu != w->n_imu || h.prior_n != pn) {
         s->err = "uvs_marginalize_resident: the window does not match the resident one"; return UVS_ERR_INVALID_ARG;
     }
+    if (flag == 1) return marginalize_second_new_host(s, w, out);      // (reads the old prior only: host work, no device round trip)
     if (flag == 0) { const int rd = marginalize_old_device(s, w, out); if (rd != kMargFallback) return rd; }      // (needs nothing of the resident blob: the factors of frame 0 travel as a window of their own)
     HIPCHK(s, hipSetDevice(s->device));
     // state sections of the resident blob: frames[184] = pose | speedbias | ex_pose | td, inverse depths, line parameters
@@ -1673,10 +1686,10 @@ int uvs_large_begin(uvs_solver* s, const uvs_window* w) {
     L.active = true; L.n_chunks = h.n_chunks; L.radius = s->opts.initial_trust_region_radius;
     L.grid = std::min(h.n_chunks, s->chunk_wgs());
     L.d_ctl = keep_ctl; L.d_rep = keep_rep; L.comm = keep_comm; L.rank = keep_rank; L.nranks = keep_nranks; L.d_fimg = keep_fimg;
-    if (!L.d_state) { HIPCHK(s, hipMalloc((void**)&L.d_state, LG_STATE * 8)); HIPCHK(s, hipMalloc((void**)&L.d_reduced, LG_XCH * 8)); HIPCHK(s, hipMemset(L.d_reduced, 0, LG_XCH * 8)); HIPCHK(s, hipMalloc((void**)&L.d_out, 64 * 8)); HIPCHK(s, hipMalloc((void**)&L.d_sc5, 8 * 8)); }
+    if (!L.d_state) { HIPCHK(s, hipMalloc((void**)&L.d_state, LG_STATE * 8)); HIPCHK(s, hipMalloc((void**)&L.d_reduced, LG_XCH_ALL * 8)); HIPCHK(s, hipMemset(L.d_reduced, 0, LG_XCH_ALL * 8)); HIPCHK(s, hipMalloc((void**)&L.d_out, 64 * 8)); HIPCHK(s, hipMalloc((void**)&L.d_sc5, 8 * 8)); }
     if (!L.d_fimg) HIPCHK(s, hipMalloc((void**)&L.d_fimg, LG_FIMG * 8));
     int r2;
-    if ((r2 = ensure(s, (void**)&L.d_partials, &L.cap_partials, (size_t)std::max(L.grid, 1) * LG_RED * 8)) != UVS_OK) return r2;
+    if ((r2 = ensure(s, (void**)&L.d_partials, &L.cap_partials, (size_t)std::max(L.grid, 1) * LG_ROW * 8)) != UVS_OK) return r2;
     if ((r2 = ensure(s, (void**)&L.d_bsums, &L.cap_bsums, (size_t)std::max(L.n_chunks, 1) * 8 * 8)) != UVS_OK) return r2;
     HIPCHK(s, hipMemsetAsync(L.d_state, 0, LG_STATE * 8, s->stream));
     // frames -> state.X ; landmark parameters -> workspace buffer 0 (device-to-device from the blob)
@@ -1724,7 +1737,7 @@ int uvs_large_linearize(uvs_solver* s) {
     KOpts ko = make_kopts(s->opts, 0);
     if (s->large_chunks_nt == 512) { if (uvs_k_large_chunks512_launch(L.grid + 1, s->stream, s->d_blobs, s->d_ws, &ko, sizeof(ko), L.d_state, L.sel, L.first ? 1 : 0, L.radius, L.d_partials, nullptr, 0, 0, L.grid, L.d_fimg) != UVS_OK) { s->err = "k_large_chunks (512 threads): argument layout mismatch"; return UVS_ERR_HIP; } }
     else hipLaunchKernelGGL(k_large_chunks, dim3(L.grid + 1), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, L.sel, L.first ? 1 : 0, L.radius, L.d_partials, LargeCtl{nullptr, 0, 0}, L.grid, L.d_fimg);
-    hipLaunchKernelGGL(k_large_reduce, dim3((LG_RED + 15) / 16), dim3(256), 0, s->stream, L.d_partials, L.grid, L.d_reduced, LargeCtl{nullptr, 0, 0});
+    { const int n_ent = s->hdrs[0].relo2 ? LG_ROW : LG_RED; hipLaunchKernelGGL(k_large_reduce, dim3((n_ent + 15) / 16), dim3(256), 0, s->stream, L.d_partials, L.grid, L.d_reduced, LargeCtl{nullptr, 0, 0}, n_ent); }
     HIPCHK(s, hipGetLastError());
     HIPCHK(s, hipStreamSynchronize(s->stream));
     return UVS_OK;
@@ -1933,10 +1946,10 @@ int uvs_large_solve_fused(uvs_solver* s, const uvs_window* w, uvs_state* out, uv
         L.grid = std::min(h.n_chunks, s->chunk_wgs());
         L.d_ctl = keep_ctl; L.d_rep = keep_rep; L.comm = keep_comm; L.rank = keep_rank; L.nranks = keep_nranks; L.d_fimg = keep_fimg;
     }
-    if (!L.d_state) { HIPCHK(s, hipMalloc((void**)&L.d_state, LG_STATE * 8)); HIPCHK(s, hipMalloc((void**)&L.d_reduced, LG_XCH * 8)); HIPCHK(s, hipMalloc((void**)&L.d_out, 64 * 8)); HIPCHK(s, hipMalloc((void**)&L.d_sc5, 8 * 8)); }
+    if (!L.d_state) { HIPCHK(s, hipMalloc((void**)&L.d_state, LG_STATE * 8)); HIPCHK(s, hipMalloc((void**)&L.d_reduced, LG_XCH_ALL * 8)); HIPCHK(s, hipMalloc((void**)&L.d_out, 64 * 8)); HIPCHK(s, hipMalloc((void**)&L.d_sc5, 8 * 8)); }
     if (!L.d_fimg) HIPCHK(s, hipMalloc((void**)&L.d_fimg, LG_FIMG * 8));
     if (!L.d_ctl) { HIPCHK(s, hipMalloc((void**)&L.d_ctl, 64 * 8)); HIPCHK(s, hipMalloc((void**)&L.d_rep, sizeof(uvs_report))); }
-    if ((rc = ensure(s, (void**)&L.d_partials, &L.cap_partials, (size_t)std::max(L.grid, 1) * LG_RED * 8)) != UVS_OK) return rc;
+    if ((rc = ensure(s, (void**)&L.d_partials, &L.cap_partials, (size_t)std::max(L.grid, 1) * LG_ROW * 8)) != UVS_OK) return rc;
     if ((rc = ensure(s, (void**)&L.d_bsums, &L.cap_bsums, (size_t)std::max(L.n_chunks, 1) * 8 * 8)) != UVS_OK) return rc;
     constexpr int RD = (int)(sizeof(uvs_report) / 8);
     const size_t out_doubles = 64 + RD + UVS_XDIM + (size_t)h.n_points + 4 * (size_t)h.n_lines;
@@ -1965,7 +1978,7 @@ int uvs_large_solve_fused(uvs_solver* s, const uvs_window* w, uvs_state* out, uv
         if (s->large_chunks_nt == 512) { if (uvs_k_large_chunks512_launch(L.grid + 1, s->stream, s->d_blobs, s->d_ws, &ko, sizeof(ko), L.d_state, 0, 0, 0.0, L.d_partials, lc.ctl, lc.rank, lc.nranks, L.grid, L.d_fimg) != UVS_OK) return fused_abort(s, "k_large_chunks (512 threads): argument layout mismatch"); }
         else hipLaunchKernelGGL(k_large_chunks, dim3(L.grid + 1), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, 0, 0, 0.0, L.d_partials, lc, L.grid, L.d_fimg);
         // (summing the partial rows inside k_large_solve instead of by a launch of its own was measured: one workgroup needs 15-24 us for what 314 do in 5)
-        hipLaunchKernelGGL(k_large_reduce, dim3((LG_RED + 15) / 16), dim3(256), 0, s->stream, L.d_partials, rows, L.d_reduced, lc);
+        { const int n_ent = s->hdrs[0].relo2 ? LG_ROW : LG_RED; hipLaunchKernelGGL(k_large_reduce, dim3((n_ent + 15) / 16), dim3(256), 0, s->stream, L.d_partials, rows, L.d_reduced, lc, n_ent); }
         if (L.comm) { const int e = r.AllReduce(L.d_reduced, L.d_reduced, LG_XCH, kNcclDouble, kNcclSum, L.comm, s->stream); if (e != 0) return fused_abort(s, "ncclAllReduce(reduced) failed"); }
         if (s->large_solve_nt == 512) { if (uvs_k_large_solve512_launch(s->stream, s->d_blobs, s->d_ws, &ko, sizeof(ko), L.d_state, L.d_reduced, 0, 0.0, L.d_out, lc.ctl, lc.rank, lc.nranks, L.d_fimg) != UVS_OK) return fused_abort(s, "k_large_solve (512 threads): argument layout mismatch"); }
         else hipLaunchKernelGGL(k_large_solve, dim3(1), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_ws, ko, L.d_state, L.d_reduced, 0, 0.0, L.d_out, lc, L.d_fimg);

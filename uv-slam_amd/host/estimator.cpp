@@ -211,8 +211,7 @@ void Estimator::optimization() {      // estimator.cpp:761-1233
         std::vector<double> depths(std::max(wa.n_points, 1)), lines(4 * std::max(wa.n_lines, 1));
         uvs_state result; std::memset(&result, 0, sizeof(result));
         result.inv_depth = depths.data(); result.line_orth = lines.data();
-        // (relocalization blocks beside a free extrinsic are a second-level block of the persistent kernel only: uvs_solver.h, uvs_window::n_relo_obs)
-        const bool multi = uvs::resolve_path(solver_path) == uvs::MULTI_WORKGROUP && !(w.n_relo_obs > 0 && ESTIMATE_EXTRINSIC);
+        const bool multi = uvs::resolve_path(solver_path) == uvs::MULTI_WORKGROUP;      // (relocalization blocks beside a free extrinsic: both forms take them since round 6)
         last_summary.status = multi ? uvs_large_solve_fused(solver, &w, &result, &last_summary.report, nullptr) : uvs_solve_window(solver, &w, &result, &last_summary.report);
         if (last_summary.status == UVS_OK || (last_summary.status == UVS_ERR_NUMERIC && last_summary.report.num_iterations > 0)) {      // like the reference, nobody looks at the summary; a call that failed before the solve leaves the state alone
             std::memcpy(para_Pose, result.pose, sizeof(para_Pose)); std::memcpy(para_SpeedBias, result.speedbias, sizeof(para_SpeedBias));
