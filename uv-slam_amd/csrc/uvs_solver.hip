@@ -1601,6 +1601,8 @@ int uvs_evaluate(uvs_solver* s, const uvs_window* w, int robust, uvs_eval* out) 
 // evaluated it on the device to obtain that one vector r (0.2 ms of the 0.5 ms a call took).
 static int marginalize_second_new_host(uvs_solver* s, const uvs_window* w, uvs_prior* out) {
     { const int rv = validate_window(w, s->err); if (rv != UVS_OK) return rv; }
+    // (the same complaint the packing of the window made when this path still uploaded it)
+    if (s->opts.estimate_td != 0 && w->n_point_obs > 0 && (!w->pt_vel_i || !w->pt_vel_j || !w->pt_td_i || !w->pt_td_j)) { s->err = "estimate_td needs pt_vel_i / pt_vel_j / pt_td_i / pt_td_j"; return UVS_ERR_INVALID_ARG; }
     DevWin h; std::memset(&h, 0, sizeof(h)); h.td_on = s->opts.estimate_td != 0;
     return run_marginalize(s->device, s->stream, nullptr, nullptr, h, w, make_kopts(s->opts, 0), 1, out, s->err, s->eval_scratch);
 }
