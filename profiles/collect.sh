@@ -38,11 +38,8 @@ for rep_ in 1 2; do for nt_ in 512 256; do UVS_KSOLVE_NT=$nt_ python bench.py --
 python tools/batch_tail.py > gpurun_out/${TAG}_batch_tail.txt 2>&1
 python tools/large_timeline.py config3 > gpurun_out/${TAG}_large_timeline.txt 2>&1; python tools/large_timeline.py canonical >> gpurun_out/${TAG}_large_timeline.txt 2>&1
 bash tools/pmc_icache.sh > gpurun_out/${TAG}_icache_l2_counters.txt 2>&1
-# ---- round 5: the dense path (UVS_DENSE_SCHUR=1: Schur complement and direct terms on the matrix cores, csrc/uvs_solve512d.hip) beside the list walk: same-box A/B, its phase
-# cycles and its per-wave step log; the end-to-end stream: host calls / copies / kernels timeline of the default form and of the form before round 5's fix (results fetched by a copy, two sets), the switches' A/B, the overlap probe
-for rep_ in 1 2; do for m_ in 0 1; do UVS_DENSE_SCHUR=$m_ python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-replay --no-large 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('UVS_DENSE_SCHUR=$m_', 'batch ms %.4f (kernel %.4f) value %.0f  single window %.4f ms  end to end %.0f solves/s (pack + upload of one batch alone %.3f ms)' % (d['ms_per_step'], d['roofline']['kernel_ms_per_launch'], d['value'], d['single_window_ms'], d['value_end_to_end'], d['end_to_end']['serial_reference']['pack_upload_ms']))"; done; done > gpurun_out/${TAG}_ab_dense_vs_lists.txt 2>&1
-UVS_DENSE_SCHUR=1 python tests/gpu_debug_prior.py > gpurun_out/${TAG}_phase_cycles_dense.txt 2>&1
-UVS_DENSE_SCHUR=1 UVS_DEBUG_LIN_TIMELINE=$R/gpurun_out/${TAG}_tl512d.bin python tests/gpu_debug_prior.py > /dev/null 2>&1; python tools/lin_timeline.py gpurun_out/${TAG}_tl512d.bin 2 > gpurun_out/${TAG}_lin_timeline_dense.txt 2>&1
+# ---- the end-to-end stream: host calls / copies / kernels timeline of the default form and of the form before round 5's fix (results fetched by a copy, two sets), the switches' A/B, the overlap probe
+# (round 5 also ran the opt-in dense landmark path here; it left the tree in round 6: tools/experiments/r05_dense/)
 (cd /tmp; rm -rf $R/gpurun_out/prof_stream; rocprofv3 --kernel-trace --memory-copy-trace --hip-runtime-trace --output-format csv -d $R/gpurun_out/prof_stream -o s -- python $R/tools/stream_rate.py 16 > /dev/null 2>&1)
 python tools/stream_trace.py gpurun_out/prof_stream 14 > gpurun_out/${TAG}_stream_timeline.txt 2>&1
 (cd /tmp; rm -rf $R/gpurun_out/prof_stream_d2h; UVS_STREAM_D2H_COPY=1 UVS_STREAM_SETS=2 rocprofv3 --kernel-trace --memory-copy-trace --hip-runtime-trace --output-format csv -d $R/gpurun_out/prof_stream_d2h -o s -- python $R/tools/stream_rate.py 16 > /dev/null 2>&1)

@@ -7,7 +7,6 @@ R=$(cd "$(dirname "$0")/../.." && pwd); C=$R/uv-slam_amd/csrc; mkdir -p $R/ab /t
 common="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -w -mllvm -disable-machine-licm"
 /opt/rocm/bin/hipcc $common "$@" -c $C/uvs_solver.hip -o /tmp/abv_$name/a.o &
 /opt/rocm/bin/hipcc $common -mllvm -sink-insts-to-avoid-spills "$@" -c $C/uvs_solve512.hip -o /tmp/abv_$name/b.o &
-/opt/rocm/bin/hipcc $common -mllvm -sink-insts-to-avoid-spills "$@" -c $C/uvs_solve512d.hip -o /tmp/abv_$name/c.o &
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC /tmp/abv_$name/a.o /tmp/abv_$name/b.o /tmp/abv_$name/c.o -o $R/ab/lib_$name.so -ldl -pthread
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC /tmp/abv_$name/a.o /tmp/abv_$name/b.o -o $R/ab/lib_$name.so -ldl -pthread
 echo built ab/lib_$name.so

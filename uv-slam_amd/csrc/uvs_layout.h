@@ -58,21 +58,6 @@
 #define UVS_LN_EY 26              // LDS doubles per line observation in the staged E = J_l^T J_p and Y = H_ll^-1 E (4 rows of 6 + 2 pad): with the natural 24 (48 dwords) the
                                   // observations fall into only FOUR bank classes of the 64-bank LDS (gcd(48, 64) = 16) and the 32 gather groups of a wave -- and the 48 stores per lane
                                   // of pass B2 -- collided 8-fold; 52 dwords give the 16 classes a 16-byte access can have (round 4)
-// ---- DENSE Schur operand of the 512-thread persistent kernel (DevWin::dense, round 5).  The landmark half of the reduced system, S_pp -= sum_l E_l^T H_ll^-1 E_l, as ONE
-// symmetric product on the FP64 matrix cores: every landmark parameter owns a ROW of the operand Et[K][UVS_DS_LD] in the staging area -- a point one row,
-// sqrt(1 / h_ll) E_l, a line four, L_l^-1 E_l with H_ll = L L^T -- in the compact pose index space p = 6 * frame + dof (66 columns) followed by the landmark's share of
-// the gradient (column 66: sqrt(1 / h_ll) g_l resp. L_l^-1 g_l), so that C = Et^T Et holds the Schur complement in C[p][q] and the Schur part of the reduced gradient in
-// C[66][q].  Five 16-wide tile columns (67 of 80 used), 15 lower tiles, K / 4 v_mfma_f64_16x16x4_f64 per tile and chunk, accumulated across the chunks in an LDS buffer
-// (UVS_DS_CBUF) at the END of the staging area; the evaluator waves run the product beside the gatherer waves' direct (J^T J) list walk.
-#define UVS_DS_LD 80              // row stride of Et in doubles (160 dwords = 32 mod 64: the four k-rows of an operand load hit disjoint bank halves)
-#define UVS_DS_GCOL 66            // the gradient column
-#define UVS_DS_TILES 15
-#define UVS_DS_CLD 68                          // row stride of the C buffer: a plain row-major [67][68] matrix over the compact pose index space + the gradient row 66 (the direct terms
-                                               // leave a run's tile at  (6 f_j + r) * 68 + 6 f_i + c : one add per lane; the Schur tiles of a wave are loaded / stored at constant offsets)
-#define UVS_DS_CBUF (67 * UVS_DS_CLD)          // doubles of the C buffer
-#define UVS_DS_CTOT (UVS_DS_CBUF + 80)         // ... followed by diag(J^T J) of the direct terms in the compact pose index space (66 used, the rest stays zero)
-#define UVS_DS_LNX 32             // per-line table of a dense line chunk: H_ll^-1 [16] | L^-1 lower packed [10] | 6 spare
-#define UVS_DS_LNT 60             // per-line table of a dense re-damping (uvs_solve_kernel.h: redamp_dense_tables), 58 used
 #ifndef UVS_NT
 #define UVS_NT 256                // threads per workgroup of the solve kernels
 #endif
@@ -139,8 +124,7 @@ struct DevWin {
     int32_t max_chunk_doubles;        // LDS doubles the fullest chunk occupies in the staging area (records + Schur factors + lists; <= UVS_S_DOUBLES; informational)
     int32_t n_parts;                  // largest number of parts any pose block is split into (informational; gacc_gather_parts sums them in one step)
     int32_t chol_half_ok;             // 1: blocks (i, j), j < i-1, of the reduced system are non-zero in rows {0..5, 15} only (true unless the prior keeps the speed / bias of a frame >= 2): the Cholesky pairs their rows
-    int32_t dense;                    // 1: the landmark Schur complement of this window goes through the dense matrix-core product (UVS_DS_*: 512-thread k_solve only; no pseudo-frame blocks); the gather
-                                      // lists then hold direct entries only and the chunks are laid out  rec | (line table) | Et | lists  with the C buffer at the end of the staging area
+    int32_t reserved0;                // (round 5's opt-in dense landmark path lived behind this flag: tools/experiments/r05_dense_landmark_path.patch; always 0)
     int64_t out_host;                 // uvs_batch_stream: address (in the device's view) of this window's slot in the pinned result buffer of the host -- k_solve writes the final state there as well, so that
                                       // no gather kernel and no device-to-host copy follow the solve; 0 = none.  Patched into the staged header by upload_windows, not by pack_window.
     int32_t redamp_ok;                // 1: k_solve may re-damp the last linearization after a rejected step instead of linearizing again (no pseudo-frame blocks; every line chunk has room for the tables)

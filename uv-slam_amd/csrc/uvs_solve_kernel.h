@@ -1468,26 +1468,10 @@ UVS_DEV ChunkDesc chunk_desc(const Ctx& c, int ch) {
     d.o0 = chunks[UVS_CHUNK_INTS * ch + 6]; d.nob = chunks[UVS_CHUNK_INTS * ch + 7];
     return d;
 }
-// ---- the DENSE Schur path (uvs_layout.h: UVS_DS_*; DevWin::dense; role-split linearization only).  Layout of a staged chunk:
-//     points:  rec[nob + 1][pt_rec] | Et[rup4(nlm)][UVS_DS_LD] | step table      lines:  rec[nob + 1][UVS_LN_REC] | X[nlm][UVS_DS_LNX] | Et[4 nlm][UVS_DS_LD] | step table
-// and the C buffer (15 tiles) at the end of the staging area, alive across the chunks of a linearization.
-#ifdef UVS_DENSE_TU
-static constexpr bool DENSE_CAP = ROLES;      // (csrc/uvs_solve512d.hip: the instantiation that carries the dense path -- kept out of the default kernel, whose list walk it slowed by 1.7 % just by being there)
-#else
-static constexpr bool DENSE_CAP = false;
-#endif
-UVS_DEV bool dense_on(const Ctx& c) { return DENSE_CAP && c.hdr->dense != 0; }
-UVS_DEV int ds_rows(const ChunkDesc& d) { return d.type == 0 ? ((d.nlm + 3) & ~3) : 4 * d.nlm; }
-UVS_DEV double* ds_operand(const Ctx& c, const ChunkDesc& d) {
-    double* rec = c.sh + L_S;
-    return d.type == 0 ? rec + (size_t)(d.nob + 1) * c.hdr->pt_rec : rec + (size_t)(d.nob + 1) * UVS_LN_REC + (size_t)UVS_DS_LNX * d.nlm;      // (record nob: all zeros, see dd_steps)
-}
-UVS_DEV double* ds_cbuf(const Ctx& c) { return c.sh + L_S + UVS_S_DOUBLES - UVS_DS_CTOT; }      // C buffer [UVS_DS_CBUF] | diag(J^T J) of the direct terms [80]
 // where the gather lists of a staged chunk sit (after the records and the Schur factors)
 UVS_DEV int* chunk_lists(const Ctx& c, const ChunkDesc& d) {
     const DevWin& h = *c.hdr;
     double* rec = c.sh + L_S;
-    if (dense_on(c)) return (int*)(ds_operand(c, d) + (size_t)ds_rows(d) * UVS_DS_LD);
     if (d.type == 0) return (int*)(rec + (size_t)d.nob * h.pt_rec + (size_t)(d.nob + h.pt_xslots * d.nlm) * 12);
     return (int*)(rec + (size_t)d.nob * (UVS_LN_REC + 2 * UVS_LN_EY) + 20 * d.nlm);
 }
@@ -1607,15 +1591,6 @@ UVS_DEV void pt_anchor_pass(const Ctx& c, const ChunkDesc& d, bool first, double
         double* px = c.ws + h.w_pt_x + 4 * (size_t)k; px[0] = ginv; px[1] = gl; px[2] = dd; px[3] = hd;
         gmax_lm = fmax(gmax_lm, fabs(gl));
         double* Eg = c.ws + h.w_pt_E + 6 * (size_t)(d.o0 + b0 + k);
-        if (dense_on(c)) {      // the anchor frame's entries of the landmark's operand row and its gradient column (uvs_layout.h: UVS_DS_*)
-            const double sh = sqrt(hinv);
-            const int fi = (int)rec[(size_t)b0 * PREC + UVS_PT_RC2 + 1];
-            double* row = ds_operand(c, d) + (size_t)li * UVS_DS_LD;
-#pragma unroll
-            for (int a = 0; a < 6; ++a) { row[6 * fi + a] = e0[a] * sh; Eg[a] = e0[a] * hinv; }
-            row[UVS_DS_GCOL] = gl * sh;
-            continue;
-        }
         double* Eb = c.sh + L_S + (size_t)d.nob * PREC;
         double* E = Eb + (size_t)(b0 + li) * 6; double* EI = E + (size_t)(d.nob + d.nlm) * 6;
 #pragma unroll
@@ -1673,386 +1648,6 @@ UVS_DEV void copy_lists_gatherers(const Ctx& c, const ChunkDesc& d) {
         for (int u = 0; u < LG_UN; ++u) { const int t = tb + u * UVS_GT; if (t < d.nlist) lists[t] = w[u]; }
     }
 }
-// the gatherer waves zero a chunk's operand rows between the chunk's entry barrier and the one that ends pass A (rows of a point beyond its frames, the pad columns
-// 67..79 and the rows that round a point chunk up to a multiple of four must be zeros)
-UVS_DEV void ds_zero(const Ctx& c, const ChunkDesc& d) {
-    double* Et = ds_operand(c, d);
-    const int n2 = ds_rows(d) * (UVS_DS_LD / 2);
-    const d2_t z2 = {0.0, 0.0};
-    for (int i = lane_tid() - GT0; i < n2; i += UVS_GT) *(d2_t*)(Et + 2 * i) = z2;
-    const int REC = d.type == 0 ? c.hdr->pt_rec : UVS_LN_REC;      // the all-zero record behind the chunk's (padding slots and structural zeros of the direct operand)
-    double* zr = c.sh + L_S + (size_t)d.nob * REC;
-    for (int i = lane_tid() - GT0; i < REC; i += UVS_GT) zr[i] = 0.0;
-}
-// damped 4 x 4 line block H = L L^T (lower packed): Li = L^-1 (lower packed), X = H^-1 = Li^T Li (full), hg = H^-1 g, lg = Li g
-UVS_DEV void spd4_factor(const double* H, const double* gl, double* Li, double* X, double* hg, double* lg) {
-    double L[10];
-    double i0, i1, i2, i3;
-    rsqrt_pair(H[0], &L[0], &i0);
-    L[1] = H[1] * i0; rsqrt_pair(H[2] - L[1] * L[1], &L[2], &i1);
-    L[3] = H[3] * i0; L[4] = (H[4] - L[3] * L[1]) * i1; rsqrt_pair(H[5] - L[3] * L[3] - L[4] * L[4], &L[5], &i2);
-    L[6] = H[6] * i0; L[7] = (H[7] - L[6] * L[1]) * i1; L[8] = (H[8] - L[6] * L[3] - L[7] * L[4]) * i2;
-    rsqrt_pair(H[9] - L[6] * L[6] - L[7] * L[7] - L[8] * L[8], &L[9], &i3);
-    Li[0] = i0;
-    Li[1] = -L[1] * i0 * i1; Li[2] = i1;
-    Li[3] = -(L[3] * Li[0] + L[4] * Li[1]) * i2; Li[4] = -L[4] * Li[2] * i2; Li[5] = i2;
-    Li[6] = -(L[6] * Li[0] + L[7] * Li[1] + L[8] * Li[3]) * i3; Li[7] = -(L[7] * Li[2] + L[8] * Li[4]) * i3; Li[8] = -L[8] * Li[5] * i3; Li[9] = i3;
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b <= a; ++b) {
-            double v = 0.0;
-#pragma unroll
-            for (int k = a; k < 4; ++k) v += Li[(k * (k + 1)) / 2 + a] * Li[(k * (k + 1)) / 2 + b];
-            X[4 * a + b] = v; X[4 * b + a] = v;
-        }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) { double v = 0.0;
-#pragma unroll
-        for (int p2 = 0; p2 <= q; ++p2) v += Li[(q * (q + 1)) / 2 + p2] * gl[p2];
-        lg[q] = v; }
-#pragma unroll
-    for (int a = 0; a < 4; ++a) { double v = 0.0;
-#pragma unroll
-        for (int k = a; k < 4; ++k) v += Li[(k * (k + 1)) / 2 + a] * lg[k];
-        hg[a] = v; }
-}
-// ---- C += Et^T Et on the matrix cores, ALL EIGHT waves: wave W owns one or two of the 15 lower tiles (waves w and w + 4 share a SIMD: four tiles per SIMD, three on the last),
-// loads them from the C buffer -- which the direct terms of the chunk have already been subtracted from (dense_direct) --, accumulates over the chunk's K operand rows and
-// parks them again.  Operand element (row k0 + lk, column 16 t + li) is the A operand of tile row t AND the B operand of tile column t; three operand sets, the loads of step
-// k + 2 in flight under the MFMAs of step k.  Rows [Kneg, K) are SUBTRACTED (a re-damping first takes the Schur complement of the old damping out: Kneg = 0).
-UVS_DEV constexpr int ds_ta(int w, int t) { return w < 2 ? 4 : w == 2 ? (t == 0 ? 4 : 3) : w == 3 ? 3 : w == 4 ? (t == 0 ? 3 : 2) : w == 5 ? 2 : w == 6 ? 1 : 0; }
-UVS_DEV constexpr int ds_tb(int w, int t) { return w == 0 ? t : w == 1 ? 2 + t : w == 2 ? (t == 0 ? 4 : 0) : w == 3 ? 1 + t : w == 4 ? (t == 0 ? 3 : 0) : w == 5 ? 1 + t : w == 6 ? t : 0; }
-UVS_DEV constexpr int ds_nt(int w) { return w == 7 ? 1 : 2; }
-UVS_DEV constexpr bool ds_need(int w, int col) { bool n = false; for (int t = 0; t < ds_nt(w); ++t) n = n || ds_ta(w, t) == col || ds_tb(w, t) == col; return n; }
-template <int W>
-UVS_DEV void dense_schur_wave(double* Cb, const double* Et, int K, int Kneg) {
-    constexpr int NTL = ds_nt(W);
-    const int lane = lane_tid() & 63, li = lane & 15, lk = lane >> 4;
-    d4_t acc[NTL];
-#pragma unroll
-    for (int t = 0; t < NTL; ++t) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {      // C layout of the tile: row 16 ta + lk + 4 q, column 16 tb + li; rows / columns beyond the gradient row 66 do not exist
-            const int R = 16 * ds_ta(W, t) + lk + 4 * q, Cc = 16 * ds_tb(W, t) + li;
-            const bool in = (ds_ta(W, t) < 4 || R <= UVS_DS_GCOL) && (ds_tb(W, t) < 4 || Cc < UVS_DS_CLD);
-            acc[t][q] = in ? Cb[in ? R * UVS_DS_CLD + Cc : 0] : 0.0;
-        }
-    }
-    const double* base = Et + lk * UVS_DS_LD + li;
-    double va[5], vb[5], vc[5];
-#define UVS_DS_LOAD(V, K0) { _Pragma("unroll") for (int cc = 0; cc < 5; ++cc) if (ds_need(W, cc)) V[cc] = base[(K0) * UVS_DS_LD + 16 * cc]; }
-#define UVS_DS_MFMA(V, K0) { if ((K0) < Kneg) { _Pragma("unroll") for (int t = 0; t < NTL; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(V[ds_ta(W, t)], V[ds_tb(W, t)], acc[t], 0, 0, 0); } \
-                             else { _Pragma("unroll") for (int t = 0; t < NTL; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(V[ds_ta(W, t)], V[ds_tb(W, t)], acc[t], 0, 0, 1); } }
-    UVS_DS_LOAD(va, 0)
-    if (4 < K) UVS_DS_LOAD(vb, 4)
-    for (int k0 = 0;;) {
-        if (k0 + 8 < K) UVS_DS_LOAD(vc, k0 + 8)
-        UVS_DS_MFMA(va, k0)
-        k0 += 4; if (k0 >= K) break;
-        if (k0 + 8 < K) UVS_DS_LOAD(va, k0 + 8)
-        UVS_DS_MFMA(vb, k0)
-        k0 += 4; if (k0 >= K) break;
-        if (k0 + 8 < K) UVS_DS_LOAD(vb, k0 + 8)
-        UVS_DS_MFMA(vc, k0)
-        k0 += 4; if (k0 >= K) break;
-    }
-#undef UVS_DS_LOAD
-#undef UVS_DS_MFMA
-#pragma unroll
-    for (int t = 0; t < NTL; ++t) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int R = 16 * ds_ta(W, t) + lk + 4 * q, Cc = 16 * ds_tb(W, t) + li;
-            if ((ds_ta(W, t) < 4 || R <= UVS_DS_GCOL) && (ds_tb(W, t) < 4 || Cc < UVS_DS_CLD)) Cb[R * UVS_DS_CLD + Cc] = acc[t][q];
-        }
-    }
-}
-// every wave, after the barrier that completes the chunk's operand
-UVS_DEV void dense_schur(const Ctx& c, const ChunkDesc& d, bool neg) {
-    const int w = wave_uniform();
-    double* Cb = ds_cbuf(c); const double* Et = ds_operand(c, d);
-    const int K = ds_rows(d), K1 = neg ? 0 : K;
-    UVS_TLOG(c, 50);
-    switch (w) {
-        case 0: dense_schur_wave<0>(Cb, Et, K, K1); break;
-        case 1: dense_schur_wave<1>(Cb, Et, K, K1); break;
-        case 2: dense_schur_wave<2>(Cb, Et, K, K1); break;
-        case 3: dense_schur_wave<3>(Cb, Et, K, K1); break;
-        case 4: dense_schur_wave<4>(Cb, Et, K, K1); break;
-        case 5: dense_schur_wave<5>(Cb, Et, K, K1); break;
-        case 6: dense_schur_wave<6>(Cb, Et, K, K1); break;
-        default: dense_schur_wave<7>(Cb, Et, K, K1); break;
-    }
-    UVS_TLOG(c, 51);
-}
-// ---- the DIRECT terms (J^T J, J^T r, diag(J^T J) of the pose blocks) on the matrix cores, gatherer waves, beside pass B of the evaluator waves (the records are complete after
-// pass A).  A step stacks four residual rows -- two point observations, or the three rows of one line observation -- into the operand Z[4][16]; Z^T Z is ONE
-// v_mfma_f64_16x16x4_f64 whose two operands are the same register.  Per-lane column of the operand (li = lane & 15):
-//     pass 0 (points, runs of one frame pair (i, j)):  [ A_o (0..5) | B_o (6..11) | r_o (12) ]   =>  rows / columns 0..5: A^T A, rows 6..11 x columns 0..5: B^T A, row 12: r^T A
-//     pass 1 (points, runs of one second frame j):     [ B_o (0..5) | r_o (6) ]                  =>  B^T B, row 6: r^T B
-//     pass 1 (lines,  runs of one frame j):            [ Jp_o (0..5) | r_o (6) ]                 =>  Jp^T Jp, row 6: r^T Jp
-// A run's tile stays in the wave's accumulator; at its end the lanes that hold useful entries SUBTRACT them from the C buffer (block (j, i), and at the end of a frame's runs
-// its diagonal block and gradient row 66) and add the diagonal to diag(J^T J).  Every frame is owned by one wave (pack_window), so no two waves touch the same entry.
-UVS_DEV int ds_cidx(int p, int q) { return p * UVS_DS_CLD + q; }      // C-buffer entry (p >= q)
-UVS_DEV const int* dd_tables(const Ctx& c, const ChunkDesc& d) { return chunk_lists(c, d); }
-// x -= v on an LDS double whose only writer in this phase is the calling wave: ds_add_f64 without return -- the wave does not wait for the old value (a read-modify-write
-// would put an LDS round trip per run on the matrix-core chain); with a single writer per entry the sum's order is the program's, so the result stays bitwise reproducible
-UVS_DEV void lds_sub(double* p, double v) { (void)__hip_atomic_fetch_add(p, -v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-UVS_DEV void lds_add(double* p, double v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-// the diagonal block of frame f, its gradient row and diag(J^T J) from accumulator registers a0 (rows lk), a1 (rows 4 + lk, lk < 2) and the gradient value g of the lanes
-// `glane` (the row that holds r^T J), lanes li < 6
-UVS_DEV void dd_emit_diag(double* Cb, int f, int li, int lk, double a0, double a1, double g, bool glane) {
-    if (li < 6) {
-        double* Hd = Cb + UVS_DS_CBUF;
-        if (li <= lk) { lds_sub(Cb + ds_cidx(6 * f + lk, 6 * f + li), a0); if (li == lk) lds_add(Hd + 6 * f + lk, a0); }
-        if (lk < 2 && li <= 4 + lk) { lds_sub(Cb + ds_cidx(6 * f + 4 + lk, 6 * f + li), a1); if (li == 4 + lk) lds_add(Hd + 6 * f + 4 + lk, a1); }
-        if (glane) lds_sub(Cb + ds_cidx(UVS_DS_GCOL, 6 * f + li), g);
-    }
-}
-// One FLAT list of steps per wave (pack_window: word 0 = the step's observation indices, two 16-bit fields, padding = the chunk's all-zero record; word 1 = kind |
-// frame_i << 4 | frame_j << 8 | end of run << 12 | end of the frame's runs << 13).  A lone wave issues an instruction every ~8 cycles, so the loop is kept to a handful per step:
-// the lane's element address is  base + index * stride  with per-lane constants (a structural-zero column reads the zero record with stride 0), the step words are fetched four
-// steps ahead and the element two steps ahead of its MFMA, across run boundaries (a run of the canonical window is four steps long), without register copies (six named sets).
-// KIND: 0 = [A | B | r] of two point observations, 1 = [B | r] of two point observations, 2 = [Jp | r] of one line observation (rows line, line, vanishing point).
-template <int KIND>
-UVS_DEV void dd_steps(double* Cb, const double* rec, int REC, int nob, const int* steps, int sb, int se) {
-    if (sb >= se) return;
-    const int lane = lane_tid() & 63, li = lane & 15, lk = lane >> 4;
-    const int cc = KIND == 0 ? (li < 6 ? UVS_PT_A + li + 6 * (lk & 1) : li < 12 ? UVS_PT_B + li - 6 + 6 * (lk & 1) : li == 12 ? (lk & 1) : -1)
-                 : KIND == 1 ? (li < 6 ? UVS_PT_B + li + 6 * (lk & 1) : li == 6 ? (lk & 1) : -1)
-                             : (lk == 3 ? -1 : li < 6 ? UVS_LN_JP + li + 6 * lk : li == 6 ? (lk == 2 ? UVS_LN_RV : lk) : -1);
-    // element address = base + (the step's byte offset of this lane's record, masked away for a structural-zero column, which reads the zero record)
-    const char* base = (const char*)(cc >= 0 ? rec + cc : rec + (size_t)nob * REC);
-    const unsigned fmask = cc >= 0 ? 0xFFFFu : 0u;
-    const int sh16 = KIND == 2 ? 0 : 16 * (lk >> 1);      // which observation of the step this lane's row belongs to
-    typedef int i2_t __attribute__((ext_vector_type(2)));
-    // (one 8-byte LDS read, the same address in every lane -- behind an opaque zero: told that the address is uniform the compiler moves the value to scalar registers
-    // RIGHT AFTER the load, i.e. waits for it, and the lead is gone)
-    int vz = 0; asm volatile("" : "+v"(vz));
-    const i2_t* wp = (const i2_t*)(steps + vz) + sb;
-    const int last = se - 1 - sb;
-    const auto word = [&](int k) { return wp[k]; };      // (pack_window keeps four dummy steps behind every worker's range)
-    const auto elem = [&](i2_t w) { return *(const double*)(base + (((unsigned)w.x >> sh16) & fmask)); };
-    i2_t W0 = word(0), W1 = word(1), W2 = word(2), W3 = word(3), W4, W5;
-    double Z0 = elem(W0), Z1 = elem(W1), Z2, Z3, Z4, Z5;
-    // TWO accumulator chains (even / odd steps): a dependent FP64 MFMA waits for its predecessor's 64 cycles, two chains alternate.  At a run's end their sum leaves through the
-    // LDS adders and both restart from zero -- A^T A of a first frame therefore leaves once per pair, not once per frame.
-    d4_t acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
-    const auto emit = [&](int fi, int fj, const d4_t& a) {
-        if (KIND == 0) {
-            // B^T A of the pair: rows 6..11 = registers 1 (lk >= 2: rows 6, 7) and 2 (rows 8..11), columns 0..5
-            if (li < 6) {
-                if (lk >= 2) lds_sub(Cb + ds_cidx(6 * fj + lk - 2, 6 * fi + li), a[1]);
-                lds_sub(Cb + ds_cidx(6 * fj + lk + 2, 6 * fi + li), a[2]);
-            }
-            dd_emit_diag(Cb, fi, li, lk, a[0], a[1], a[3], lk == 0);
-        } else dd_emit_diag(Cb, fj, li, lk, a[0], a[1], a[1], lk == 2);      // r^T J is row 6 = register 1 of the lanes lk == 2
-    };
-    const auto run_end = [&](int w1) {      // the run ends: its entries leave the accumulators (wave-uniform branch)
-        const int fi = (w1 >> 4) & 15, fj = (w1 >> 8) & 15;
-        const d4_t sum = acc + acc2;      // (an LDS add per entry costs more than waiting for the two chains to drain)
-        emit(fi, fj, sum);
-        acc = d4_t{0.0, 0.0, 0.0, 0.0}; acc2 = d4_t{0.0, 0.0, 0.0, 0.0};
-    };
-#ifdef UVS_X_DD_NO_MFMA
-#define UVS_DD_MFMA(ZA, ACC) ACC[0] += ZA;
-#else
-#define UVS_DD_MFMA(ZA, ACC) ACC = __builtin_amdgcn_mfma_f64_16x16x4f64(ZA, ZA, ACC, 0, 0, 0);
-#endif
-#ifdef UVS_X_DD_NO_EMIT
-#define UVS_DD_EMIT(w) if (((w) >> 14) & 1) run_end(w);
-#else
-#define UVS_DD_EMIT(w) if (((w) >> 12) & 1) run_end(w);
-#endif
-// step k: the words of step k + 4 are requested, the element of step k + 2 is requested with words that were requested TWO steps ago, the MFMA of step k runs on the element
-// requested two steps ago (six named sets, the body unrolled six times: no register copies, nothing waits for a load of the step before)
-#define UVS_DD_STEP(WA, WC, WE, ZA, ZC, ACC, KO) { \
-        WE = word(k + 4 + KO); \
-        ZC = elem(WC); \
-        UVS_DD_MFMA(ZA, ACC) }
-#define UVS_DD_PAIR(WA, WB, WC, WD, WE, WF, ZA, ZB, ZC, ZD) { \
-        UVS_DD_STEP(WA, WC, WE, ZA, ZC, acc, 0) \
-        UVS_DD_STEP(WB, WD, WF, ZB, ZD, acc2, 1) \
-        k += 2; \
-        const int w1_ = __builtin_amdgcn_readfirstlane(WB.y);      /* runs hold an even number of steps: the end of a run is the second step of a pair */ \
-        UVS_DD_EMIT(w1_) \
-        if (k > last) break; }
-    for (int k = 0;;) {
-        UVS_DD_PAIR(W0, W1, W2, W3, W4, W5, Z0, Z1, Z2, Z3)
-        UVS_DD_PAIR(W2, W3, W4, W5, W0, W1, Z2, Z3, Z4, Z5)
-        UVS_DD_PAIR(W4, W5, W0, W1, W2, W3, Z4, Z5, Z0, Z1)
-    }
-#undef UVS_DD_PAIR
-#undef UVS_DD_STEP
-}
-// gatherer wave g = wave - 4 runs its frames' steps (tables staged behind the operand by copy_lists_gatherers)
-UVS_DEV void dense_direct(const Ctx& c, const ChunkDesc& d) {
-    const int wv = wave_uniform();
-    const int g = wv >= EW ? wv - EW : 4 + wv;      // worker: 0..3 the gatherer waves (from the end of pass A), 4..7 the evaluator waves (after their pass B)
-    if (g > 7) return;
-    const int* T = dd_tables(c, d);
-    const int* steps = T + 28;
-    double* Cb = ds_cbuf(c); const double* rec = c.sh + L_S;
-    UVS_TLOG(c, 8);
-    if (d.type == 0) {
-        dd_steps<0>(Cb, rec, c.hdr->pt_rec, d.nob, steps, T[2 * g], T[16 + g]);
-        dd_steps<1>(Cb, rec, c.hdr->pt_rec, d.nob, steps, T[16 + g], T[2 * g + 1]);
-    } else dd_steps<2>(Cb, rec, UVS_LN_REC, d.nob, steps, T[16 + g], T[2 * g + 1]);
-    UVS_TLOG(c, 10);
-}
-// the C buffer and diag(J^T J) zeroed at the head of a linearization (gatherer lanes, with the first chunk's operand), or -- re-damping -- reloaded from the workspace copy of
-// the last linearization's; that copy is written after the last chunk of a linearization
-UVS_DEV void dense_cbuf_init(const Ctx& c, bool reload) {
-    double* Cb = ds_cbuf(c); const double* M = c.ws + c.hdr->w_gacc;
-    for (int i = lane_tid() - GT0; i < UVS_DS_CTOT; i += UVS_GT) Cb[i] = reload ? M[i] : 0.0;
-}
-UVS_DEV void dense_cbuf_save(const Ctx& c) {
-    const double* Cb = ds_cbuf(c); double* M = c.ws + c.hdr->w_gacc;
-    for (int i = lane_tid() - GT0; i < UVS_DS_CTOT; i += UVS_GT) __builtin_nontemporal_store(Cb[i], M + i);
-}
-// The pose blocks out of the C buffer (S = direct - Schur = -C) in two halves around the zeroing of the image: `take` (gatherer lanes, before asm_zero wipes the staging area)
-// keeps this lane's share in registers, `put` stores it into the zeroed image (one writer per entry; the IMU tiles and the prior are added afterwards).
-static constexpr int DT_N = (UVS_NBLK * 36 + UVS_GT - 1) / UVS_GT;      // 66 blocks x 36 entries over the gatherer lanes
-struct DenseTake { double v[DT_N]; int off[DT_N]; double g, hd; };
-UVS_DEV void dense_take(const Ctx& c, DenseTake& tk) {
-    const double* Cb = ds_cbuf(c);
-    const int t = lane_tid() - GT0;
-#pragma unroll
-    for (int k = 0; k < DT_N; ++k) {
-        const int e = t + k * UVS_GT;
-        tk.off[k] = -1; tk.v[k] = 0.0;
-        if (e < UVS_NBLK * 36) {
-            const int b = e / 36, rc = e - 36 * b, r = rc / 6, cc = rc - 6 * r;
-            const int fa = c_blk_fa[b], fb = c_blk_fb[b];
-            if (fa != fb || cc <= r) { tk.v[k] = -Cb[ds_cidx(6 * fa + r, 6 * fb + cc)]; tk.off[k] = sidx(16 * fa + r, 16 * fb + cc); }
-        }
-    }
-    tk.g = 0.0; tk.hd = 0.0;
-    if (t < 6 * UVS_NF) { tk.g = -Cb[ds_cidx(UVS_DS_GCOL, t)]; tk.hd = Cb[UVS_DS_CBUF + t]; }
-}
-UVS_DEV void dense_put(const Ctx& c, const DenseTake& tk) {
-    double* sh = c.sh;
-    const int t = lane_tid() - GT0;
-#pragma unroll
-    for (int k = 0; k < DT_N; ++k) if (tk.off[k] >= 0) sh[L_S + tk.off[k]] = tk.v[k];
-    if (t < 6 * UVS_NF) { const int i = 16 * (t / 6) + t % 6; sh[L_G + i] = tk.g; sh[L_HD + i] = tk.hd; }
-}
-// pass B of a dense point chunk, evaluator lanes: one lane per observation writes its frame's six entries of the landmark's operand row and the slot of the
-// back-substitution store (the anchor frame's entries, the gradient column and the per-landmark scalars are the gatherer lanes': pt_anchor_pass)
-UVS_DEV void pt_passB_dense(const Ctx& c, const ChunkDesc& d, bool first, double radius) {
-    const DevWin& h = *c.hdr;
-    const int tid = lane_tid();
-    const int* beg = c.bi + h.i_pt_beg;
-    const int o0 = d.o0, nob = d.nob, k0 = d.k0, PREC = h.pt_rec;
-    double* rec = c.sh + L_S;
-    double* Et = ds_operand(c, d);
-    for (int ol = tid; ol < nob; ol += ET) {
-        const int k = c.bi[h.i_pt_lm + o0 + ol], li = k - k0, b0 = beg[k] - o0, b1 = beg[k + 1] - o0;
-        double hd, gl; pt_landmark_hd_gl(rec, PREC, b0, b1, &hd, &gl);
-        const double sc = first ? (c.o.jacobi ? 1.0 / (1.0 + sqrt(hd)) : 1.0) : c.ws[h.w_scale_pt + k];
-        const double dd = fmin(fmax(sc * sc * hd, c.o.dlo), c.o.dhi) / (radius * sc * sc);
-        const double hinv = 1.0 / (hd + dd), sh = sqrt(hinv);
-        const int s = ol - b0 + 1;
-        double* Eg = c.ws + h.w_pt_E + 6 * (size_t)(o0 + b0 + k);
-        const double* R = rec + (size_t)ol * PREC;
-        const double c0 = R[UVS_PT_C], c1 = R[UVS_PT_C + 1];
-        const int fj = (int)R[UVS_PT_RC2];
-        double Bv[12];
-#pragma unroll
-        for (int a = 0; a < 12; ++a) Bv[a] = R[UVS_PT_B + a];
-        double* row = Et + (size_t)li * UVS_DS_LD + 6 * fj;
-#pragma unroll
-        for (int a = 0; a < 6; ++a) { const double e = c0 * Bv[a] + c1 * Bv[6 + a]; row[a] = e * sh; Eg[6 * s + a] = e * hinv; }
-    }
-}
-// passes B1 / B2 of a dense line chunk
-UVS_DEV double ln_passB1_dense(const Ctx& c, const ChunkDesc& d, bool first, double radius) {
-    const DevWin& h = *c.hdr;
-    const int tid = lane_tid();
-    const int* beg = c.bi + h.i_ln_beg;
-    const int o0 = d.o0, k0 = d.k0, nlm = d.nlm;
-    double* rec = c.sh + L_S;
-    double* Xb = rec + (size_t)(d.nob + 1) * UVS_LN_REC;
-    double* Et = ds_operand(c, d);
-    double gmax_lm = 0.0;
-    for (int li = tid; li < nlm; li += ET) {
-        const int k = k0 + li, b0 = beg[k] - o0, b1 = beg[k + 1] - o0;
-        double H[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, gl[4] = {0, 0, 0, 0};
-        double scl[4] = {1.0, 1.0, 1.0, 1.0};
-        if (!first) {
-#pragma unroll
-            for (int a = 0; a < 4; ++a) scl[a] = c.ws[h.w_scale_ln + 4 * k + a];
-        }
-        for (int o = b0; o < b1; ++o) {
-            const double* R = rec + (size_t)o * UVS_LN_REC;
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                gl[a] += R[UVS_LN_JL + a] * R[0] + R[UVS_LN_JL + 4 + a] * R[1] + R[UVS_LN_JL + 8 + a] * R[UVS_LN_RV];
-#pragma unroll
-                for (int b = 0; b <= a; ++b) H[(a * (a + 1)) / 2 + b] += R[UVS_LN_JL + a] * R[UVS_LN_JL + b] + R[UVS_LN_JL + 4 + a] * R[UVS_LN_JL + 4 + b] + R[UVS_LN_JL + 8 + a] * R[UVS_LN_JL + 8 + b];
-            }
-        }
-        double* lx = c.ws + h.w_ln_x + UVS_LN_X * (size_t)k;
-#pragma unroll
-        for (int q = 0; q < 10; ++q) lx[12 + q] = H[q];
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const double hd = H[(a * (a + 1)) / 2 + a];
-            double sc;
-            if (first) { sc = c.o.jacobi ? 1.0 / (1.0 + sqrt(hd)) : 1.0; c.ws[h.w_scale_ln + 4 * k + a] = sc; } else sc = scl[a];
-            const double dd = fmin(fmax(sc * sc * hd, c.o.dlo), c.o.dhi) / (radius * sc * sc);
-            H[(a * (a + 1)) / 2 + a] = hd + dd;
-            lx[4 + a] = gl[a]; lx[8 + a] = dd;
-            gmax_lm = fmax(gmax_lm, fabs(gl[a]));
-        }
-        double Li[10], X[16], hg[4], lg[4];
-        spd4_factor(H, gl, Li, X, hg, lg);
-        double* T = Xb + (size_t)UVS_DS_LNX * li;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) T[q] = X[q];
-#pragma unroll
-        for (int q = 0; q < 10; ++q) T[16 + q] = Li[q];
-#pragma unroll
-        for (int a = 0; a < 4; ++a) { lx[a] = hg[a]; Et[(size_t)(4 * li + a) * UVS_DS_LD + UVS_DS_GCOL] = lg[a]; }
-    }
-    return gmax_lm;
-}
-UVS_DEV void ln_passB2_dense(const Ctx& c, const ChunkDesc& d) {
-    const DevWin& h = *c.hdr;
-    const int tid = lane_tid();
-    const int o0 = d.o0, nob = d.nob;
-    double* rec = c.sh + L_S;
-    const double* Xb = rec + (size_t)(nob + 1) * UVS_LN_REC;
-    double* Et = ds_operand(c, d);
-    for (int o = tid; o < nob; o += ET) {
-        const double* R = rec + (size_t)o * UVS_LN_REC;
-        const int code = (int)R[UVS_LN_RV + 1], li = code & 1023, fj = code >> 10;
-        double* Yg = c.ws + h.w_ln_Y + 24 * (size_t)(o0 + o);
-        double Xv[26], Jl[12], Jp[18];
-#pragma unroll
-        for (int q = 0; q < 26; ++q) Xv[q] = Xb[UVS_DS_LNX * li + q];
-#pragma unroll
-        for (int q = 0; q < 12; ++q) Jl[q] = R[UVS_LN_JL + q];
-#pragma unroll
-        for (int q = 0; q < 18; ++q) Jp[q] = R[UVS_LN_JP + q];
-        double* row = Et + (size_t)(4 * li) * UVS_DS_LD + 6 * fj;
-#pragma unroll
-        for (int a = 0; a < 6; ++a) {
-            double e[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) e[q] = Jl[q] * Jp[a] + Jl[4 + q] * Jp[6 + a] + Jl[8 + q] * Jp[12 + a];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                Yg[6 * q + a] = Xv[4 * q] * e[0] + Xv[4 * q + 1] * e[1] + Xv[4 * q + 2] * e[2] + Xv[4 * q + 3] * e[3];
-                double v = 0.0;
-#pragma unroll
-                for (int p2 = 0; p2 <= q; ++p2) v += Xv[16 + (q * (q + 1)) / 2 + p2] * e[p2];
-                row[(size_t)q * UVS_DS_LD + a] = v;
-            }
-        }
-    }
-}
 UVS_DEV void chunk_eval(const Ctx& c, const ChunkDesc& d, const double* x, const double* invd, const double* line, bool first, double radius) {
     const DevWin& h = *c.hdr;
     double* sh = c.sh;
@@ -2091,7 +1686,6 @@ UVS_DEV void chunk_eval(const Ctx& c, const ChunkDesc& d, const double* x, const
 #pragma unroll
                 for (int q = 0; q < 12; ++q) { R[UVS_PT_A + q] = sc * A[q]; R[UVS_PT_B + q] = sc * B[q]; }
                 R[UVS_PT_C] = sc * cl[0]; R[UVS_PT_C + 1] = sc * cl[1];      // d r / d lambda (the Schur-corrected residual goes to its own slot in pass B)
-                if (dense_on(c)) { R[UVS_PT_RC2] = (double)fj; R[UVS_PT_RC2 + 1] = (double)fi; }      // dense Schur path: no corrected residual; the slot carries the frames to pass B / the anchor pass
                 if (h.td_on || h.ex_on) { R[UVS_PT_TD] = sc * jtd[0]; R[UVS_PT_TD + 1] = sc * jtd[1]; R[UVS_PT_TD + 2] = 0.0; R[UVS_PT_TD + 3] = 0.0; }
                 if (h.ex_on) {      // ESTIMATE_EXTRINSIC only: the 2 x 6 block d r / d ex_pose from a second evaluation, in its own scope so that the
                                     // default path keeps its register footprint (the kernel sits at the 512-register cap)
@@ -2108,8 +1702,6 @@ UVS_DEV void chunk_eval(const Ctx& c, const ChunkDesc& d, const double* x, const
             // pass B: one lane per observation (its landmark's h_ll / g_l are recomputed per lane, cheap);
             // the lane of a landmark's first observation also owns the anchor slot and the per-landmark scalars.
             // The corrected residual goes to the record's own rc slot (UVS_PT_RC2); the d r / d lambda columns other lanes of the landmark still read stay as they are.
-            if (dense_on(c)) { pt_passB_dense(c, d, first, radius); dense_direct(c, d); }      // (the evaluator waves' share of the direct terms: the frames pack_window gave them)
-            else
             for (int ol = tid; ol < nob; ol += ET) {
                 const int k = c.bi[h.i_pt_lm + o0 + ol], li = k - k0, b0 = beg[k] - o0, b1 = beg[k + 1] - o0;
                 double hd, gl; pt_landmark_hd_gl(rec, PREC, b0, b1, &hd, &gl);
@@ -2144,7 +1736,7 @@ UVS_DEV void chunk_eval(const Ctx& c, const ChunkDesc& d, const double* x, const
             double* Yb = Eb + (size_t)nob * UVS_LN_EY;               // [nob][UVS_LN_EY]  Y = Hinv E
             double* Xb = Yb + (size_t)nob * UVS_LN_EY;               // [nlm][20] : Hinv[16], Hinv*g[4]
             int* lists = (int*)(Xb + 20 * nlm);
-            if (!LISTS_BY_GATHERERS) for (int t = tid; t < nlist; t += ET) lists[t] = glists[t];      // (never with the dense layout: DENSE_CAP = ROLES = LISTS_BY_GATHERERS)
+            if (!LISTS_BY_GATHERERS) for (int t = tid; t < nlist; t += ET) lists[t] = glists[t];
             // pass A
             const double* ltrig = line_trig_of(c, line);
             for (int o = o0 + tid; o < o1; o += ET) {
@@ -2185,8 +1777,6 @@ UVS_DEV void chunk_eval(const Ctx& c, const ChunkDesc& d, const double* x, const
             UVS_PROF(c, P_OBS);
             UVS_TLOG(c, 4);
             // pass B1: one lane per line: H_ll, g_l, damping, 4x4 inverse
-            if (dense_on(c)) gmax_lm = fmax(gmax_lm, ln_passB1_dense(c, d, first, radius));
-            else
             for (int li = tid; li < nlm; li += ET) {
                 const int k = k0 + li, b0 = beg[k] - o0, b1 = beg[k + 1] - o0;
                 double H[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, gl[4] = {0, 0, 0, 0};   // lower packed (0,0)(1,0)(1,1)(2,0)...
@@ -2228,8 +1818,6 @@ UVS_DEV void chunk_eval(const Ctx& c, const ChunkDesc& d, const double* x, const
             __syncthreads();
             UVS_TLOG(c, 6);
             // pass B2: one lane per line observation: E and Y = Hinv E
-            if (dense_on(c)) { ln_passB2_dense(c, d); dense_direct(c, d); }
-            else
             for (int o = tid; o < nob; o += ET) {
                 double* R = rec + (size_t)o * UVS_LN_REC;
                 const int li = (int)R[UVS_LN_RV + 1] & 1023;
@@ -2405,128 +1993,6 @@ UVS_DEV void redamp_prep(const Ctx& c, const ChunkDesc& d, double radius) {
             }
         }
         __syncthreads();
-    }
-}
-// ---- re-damping on the dense path.  The C buffer of the last linearization (Schur complement of the OLD damping minus the direct terms) rests in the workspace (dense_cbuf_save);
-// x has not moved, so the direct terms stand, and the new reduced system is  C - Schur_old + Schur_new:  per chunk the operand rows are refilled from the back-substitution
-// store of the last linearization (E = stored E h^-1 times the old h for points, (H + D_old) Y_old for lines) TWICE -- with the old damping and the product SUBTRACTED, then with
-// the new damping and the product added -- by the same matrix-core product as a linearization's.  No observation is evaluated, no direct term is touched.
-// Barriers per chunk (both roles): entry | operand zeroed (gatherers), line tables staged | old operand filled | [product, -] | new operand may be written | new operand filled | [product, +]
-UVS_DEV int redamp_dense_barriers() { return 5; }
-// per-line table of a dense re-damping (UVS_DS_LNT doubles): (H + D_new)^-1 [16] | L_new^-1 [10] | undamped H [10] | D_old [4] | L_new^-1 g [4] | L_old^-1 [10] | L_old^-1 g [4]
-UVS_DEV void redamp_dense_tables(const Ctx& c, const ChunkDesc& d, double radius) {
-    const DevWin& h = *c.hdr;
-    if (d.type == 0) return;
-    double* T = c.sh + L_S;      // (the record area is free: nothing is evaluated)
-    for (int li = lane_tid(); li < d.nlm; li += ET) {
-        const int k = d.k0 + li;
-        double* lx = c.ws + h.w_ln_x + UVS_LN_X * (size_t)k;
-        double H[10], Ho[10], gl[4], ddo[4];
-#pragma unroll
-        for (int q = 0; q < 10; ++q) { H[q] = lx[12 + q]; Ho[q] = H[q]; }
-#pragma unroll
-        for (int a = 0; a < 4; ++a) { gl[a] = lx[4 + a]; ddo[a] = lx[8 + a]; }
-        double* t = T + (size_t)UVS_DS_LNT * li;
-#pragma unroll
-        for (int q = 0; q < 10; ++q) t[26 + q] = H[q];
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const double hd = H[(a * (a + 1)) / 2 + a], sc = c.ws[h.w_scale_ln + 4 * k + a];
-            const double dd = fmin(fmax(sc * sc * hd, c.o.dlo), c.o.dhi) / (radius * sc * sc);
-            H[(a * (a + 1)) / 2 + a] = hd + dd; Ho[(a * (a + 1)) / 2 + a] = hd + ddo[a];
-            t[36 + a] = ddo[a]; lx[8 + a] = dd;
-        }
-        double Li[10], X[16], hg[4], lg[4];
-        spd4_factor(Ho, gl, Li, X, hg, lg);
-#pragma unroll
-        for (int q = 0; q < 10; ++q) t[44 + q] = Li[q];
-#pragma unroll
-        for (int a = 0; a < 4; ++a) t[54 + a] = lg[a];
-        spd4_factor(H, gl, Li, X, hg, lg);
-#pragma unroll
-        for (int q = 0; q < 16; ++q) t[q] = X[q];
-#pragma unroll
-        for (int q = 0; q < 10; ++q) t[16 + q] = Li[q];
-#pragma unroll
-        for (int a = 0; a < 4; ++a) { t[40 + a] = lg[a]; lx[a] = hg[a]; }
-    }
-}
-// the operand of the OLD damping (old = true: nothing else changes) or of the new one (also rewrites the back-substitution store: E h_new^-1 / Y_new)
-UVS_DEV void redamp_dense_fill(const Ctx& c, const ChunkDesc& d, double radius, bool old) {
-    const DevWin& h = *c.hdr;
-    const int tid = lane_tid();
-    const int k0 = d.k0, nlm = d.nlm, o0 = d.o0, nob = d.nob;
-    double* Et = ds_operand(c, d);
-    if (d.type == 0) {
-        const int* beg = c.bi + h.i_pt_beg;
-        for (int t = tid; t < nlm + nob; t += ET) {      // one lane per slot: the anchor slots, then the observation slots
-            const bool anchor = t < nlm;
-            const int ol = anchor ? 0 : t - nlm;
-            const int k = anchor ? k0 + t : c.bi[h.i_pt_lm + o0 + ol], li = k - k0;
-            const int bk = beg[k], nobs = beg[k + 1] - bk;
-            if (nobs == 0) continue;
-            const int f = anchor ? c.bi[h.i_pt_fi + bk] : c.bi[h.i_pt_fj + o0 + ol];
-            const double* px = c.ws + h.w_pt_x + 4 * (size_t)k;
-            const double gl = px[1], dd_old = px[2], hd = px[3], sc = c.ws[h.w_scale_pt + k];
-            const double dd = fmin(fmax(sc * sc * hd, c.o.dlo), c.o.dhi) / (radius * sc * sc);
-            const double hdo = hd + dd_old, hinv = 1.0 / (old ? hdo : hd + dd), sh = sqrt(hinv);
-            double* Eg = c.ws + h.w_pt_E + 6 * (size_t)(anchor ? bk + k : o0 + ol + k + 1);
-            double e[6];
-#pragma unroll
-            for (int a = 0; a < 6; ++a) e[a] = Eg[a] * hdo;
-            double* row = Et + (size_t)li * UVS_DS_LD;
-#pragma unroll
-            for (int a = 0; a < 6; ++a) { row[6 * f + a] = e[a] * sh; if (!old) Eg[a] = e[a] * hinv; }
-            if (anchor) row[UVS_DS_GCOL] = gl * sh;
-        }
-    } else {
-        const double* T = c.sh + L_S;
-        for (int o = tid; o < nob; o += ET) {
-            const int li = c.bi[h.i_ln_lm + o0 + o] - k0, fj = c.bi[h.i_ln_fj + o0 + o];
-            double tv[40], Lv[10], yo[24];
-#pragma unroll
-            for (int q = 0; q < 40; ++q) tv[q] = T[(size_t)UVS_DS_LNT * li + q];
-#pragma unroll
-            for (int q = 0; q < 10; ++q) Lv[q] = old ? T[(size_t)UVS_DS_LNT * li + 44 + q] : tv[16 + q];
-            double* Yg = c.ws + h.w_ln_Y + 24 * (size_t)(o0 + o);
-#pragma unroll
-            for (int q = 0; q < 24; ++q) yo[q] = Yg[q];
-            double* row = Et + (size_t)(4 * li) * UVS_DS_LD + 6 * fj;
-#pragma unroll
-            for (int a = 0; a < 6; ++a) {
-                double e[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {      // E = (H + D_old) Y_old
-                    double v = tv[36 + q] * yo[6 * q + a];
-#pragma unroll
-                    for (int p2 = 0; p2 < 4; ++p2) { const int hi_ = q > p2 ? q : p2, lo_ = q > p2 ? p2 : q; v += tv[26 + (hi_ * (hi_ + 1)) / 2 + lo_] * yo[6 * p2 + a]; }
-                    e[q] = v;
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if (!old) Yg[6 * q + a] = tv[4 * q] * e[0] + tv[4 * q + 1] * e[1] + tv[4 * q + 2] * e[2] + tv[4 * q + 3] * e[3];
-                    double v = 0.0;
-#pragma unroll
-                    for (int p2 = 0; p2 <= q; ++p2) v += Lv[(q * (q + 1)) / 2 + p2] * e[p2];
-                    row[(size_t)q * UVS_DS_LD + a] = v;
-                }
-            }
-        }
-        for (int e4 = tid; e4 < 4 * nlm; e4 += ET) Et[(size_t)e4 * UVS_DS_LD + UVS_DS_GCOL] = T[(size_t)UVS_DS_LNT * (e4 >> 2) + (old ? 54 : 40) + (e4 & 3)];
-    }
-}
-// after the new operand has been filled (behind a barrier): the landmark scalars of the back substitution take the new damping (the fills read the OLD one)
-UVS_DEV void redamp_dense_scalars(const Ctx& c, const ChunkDesc& d, double radius) {
-    const DevWin& h = *c.hdr;
-    if (d.type != 0) return;
-    const int* beg = c.bi + h.i_pt_beg;
-    for (int li = lane_tid(); li < d.nlm; li += ET) {
-        const int k = d.k0 + li;
-        if (beg[k + 1] == beg[k]) continue;
-        double* px = c.ws + h.w_pt_x + 4 * (size_t)k;
-        const double gl = px[1], hd = px[3], sc = c.ws[h.w_scale_pt + k];
-        const double dd = fmin(fmax(sc * sc * hd, c.o.dlo), c.o.dhi) / (radius * sc * sc);
-        px[0] = gl * (1.0 / (hd + dd)); px[2] = dd;
     }
 }
 UVS_DEV void redamp_gather(const Ctx& c, const ChunkDesc& d, int grp, GAcc& acc) {
@@ -2949,25 +2415,11 @@ UVS_DEV void linearize_roles(const Ctx& c, const double* x, const double* invd, 
     PriorAdd pa;
     ImuN N;
     if (ev) {
-        const bool dense = dense_on(c);
         ChunkDesc d = chunk_desc(c, 0);
         for (int ch = 0; ch < h.n_chunks; ++ch) {
-            if (dense && redamp) {      // (barrier ledger: redamp_dense_barriers)
-                __syncthreads();
-                redamp_dense_tables(c, d, radius);
-                __syncthreads();
-                redamp_dense_fill(c, d, radius, true);
-                __syncthreads();
-                dense_schur(c, d, true);       // the Schur complement of the OLD damping leaves the C buffer
-                __syncthreads();
-                redamp_dense_fill(c, d, radius, false);
-                __syncthreads();
-                redamp_dense_scalars(c, d, radius);
-                dense_schur(c, d, false);
-            } else if (redamp) redamp_prep(c, d, radius);
+            if (redamp) redamp_prep(c, d, radius);
             else {
                 chunk_eval(c, d, x, invd, line, first, radius);
-                if (dense) dense_schur(c, d, false);      // the landmark Schur complement of this chunk on the matrix cores (all eight waves; the gatherers ran the direct terms beside pass B)
             }
             if (ch + 1 < h.n_chunks) {
                 d = chunk_desc(c, ch + 1);
@@ -2977,7 +2429,6 @@ UVS_DEV void linearize_roles(const Ctx& c, const double* x, const double* invd, 
             }
         }
         UVS_TLOG(c, 21);
-        if (dense) __syncthreads();      // dense path: the chunk loop's closing barrier (every wave's tiles are back in the C buffer; the gatherers copy it to the workspace next)
         lin_imu_stage(c, x);
 #ifndef UVS_X_NO_PRIOR_AHEAD
         asm_prior_load(c, pa);      // (before the MFMA stages: a workgroup barrier waits for outstanding loads, so they have to be in flight beside real work)
@@ -2992,47 +2443,6 @@ UVS_DEV void linearize_roles(const Ctx& c, const double* x, const double* invd, 
         UVS_TLOG(c, 24);
         asm_imu(c, N);
         UVS_TLOG(c, 25);
-    } else if (dense_on(c)) {
-        // ---- gatherer waves, dense path: no lists, no accumulators.  Beside the evaluators' pass B they run the DIRECT terms of the chunk on the matrix cores (dense_direct,
-        // every frame owned by one wave) and wave 4's lanes the per-landmark anchor pass; then all eight waves run the Schur product.  Barrier ledger = chunk_eval's.
-        ChunkDesc d = chunk_desc(c, 0);
-        for (int ch = 0; ch < h.n_chunks; ++ch) {
-            __syncthreads();      // the chunk's entry barrier: the staging area is free
-            ds_zero(c, d);
-            if (ch == 0) dense_cbuf_init(c, redamp);
-            if (redamp) {
-                role_barriers(2);
-                dense_schur(c, d, true);
-                role_barriers(2);
-                dense_schur(c, d, false);
-            } else {
-                copy_lists_gatherers(c, d);      // (the run / permutation tables of dense_direct)
-                AnchorPre ap; ap.b0 = 0; ap.b1 = 0; ap.sc = 1.0;
-                if (d.type == 0) pt_anchor_pre(c, d, first, ap);
-                __syncthreads();      // pass A is done: the records are complete
-                if (d.type == 0) pt_anchor_pass(c, d, first, radius, ap);
-                dense_direct(c, d);
-                role_barriers(chunk_eval_barriers(d) - 2);
-                dense_schur(c, d, false);
-            }
-            if (ch + 1 < h.n_chunks) d = chunk_desc(c, ch + 1);
-        }
-        __syncthreads();      // every product of the chunk loop is done: the C buffer (at the end of the staging area) is complete
-        UVS_TLOG(c, 52);
-        if (h.redamp_ok && c.o.redamp) dense_cbuf_save(c);      // what a re-damping starts from (also after a re-damping: a second rejection in a row continues from THIS damping)
-        role_barriers(3);     // (lin_imu_stage of the evaluator waves: its tiles take the START of the staging area)
-#ifndef UVS_X_NO_PRIOR_AHEAD
-        asm_prior_load(c, pa);
-#endif
-        ic = lin_imu_tiles(c, N);
-        DenseTake tk; dense_take(c, tk);      // this lane's share of the pose blocks, before the image is zeroed over the C buffer
-        UVS_TLOG(c, 56);
-        __syncthreads();
-        asm_zero(c);
-        __syncthreads();
-        dense_put(c, tk);
-        __syncthreads();
-        asm_imu(c, N);
     } else {
         const int grp = gather_group(c);
         GAcc A;

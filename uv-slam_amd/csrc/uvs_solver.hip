@@ -41,11 +41,6 @@ int uvs_k_solve512_init(const unsigned char* fa, const unsigned char* fb, int n)
 int uvs_k_solve512_launch(int n_windows, hipStream_t stream, char* blobs, const long long* blob_off, double* ws_all, const long long* ws_off,
                            const void* kopts, size_t kopts_bytes, uvs_report* reports, const void* dbg, size_t dbg_bytes);
 size_t uvs_k_solve512_arg_bytes(int which);
-// ... and the one that carries the dense path (uvs_solve512d.hip; UVS_DENSE_SCHUR=1)
-int uvs_k_solve512d_init(const unsigned char* fa, const unsigned char* fb, int n);
-int uvs_k_solve512d_launch(int n_windows, hipStream_t stream, char* blobs, const long long* blob_off, double* ws_all, const long long* ws_off,
-                           const void* kopts, size_t kopts_bytes, uvs_report* reports, const void* dbg, size_t dbg_bytes);
-int uvs_k_solve512d_timeline(long long* out, size_t n);
 int uvs_k_solve512_timeline(long long* out, size_t n);
 int uvs_k_large_chunks512_prof(long long* out, size_t n);
 int uvs_k_large_solve512_launch(hipStream_t stream, char* blob, double* ws, const void* kopts, size_t kopts_bytes, double* state, const double* reduced, int first, double radius, double* out,
@@ -120,8 +115,6 @@ struct uvs_solver {
     int large_solve_nt = 512;                // ... and for k_large_solve (UVS_LARGE_SOLVE_NT=256)
     int large_chunks_nt = 512;               // likewise for k_large_chunks (UVS_LARGE_CHUNKS_NT=256 selects the 256-thread kernel of this file)
     int ksolve_nt = 512;                     // which instantiation of the persistent kernel launch_solve uses (uvs_solve512.hip / this file's 256-thread one)
-    bool dense_schur = false;                // UVS_DENSE_SCHUR=1: windows for the persistent kernel are packed for the DENSE path of the 512-thread kernel (uvs_layout.h: UVS_DS_*: landmark Schur
-                                             // complement and direct terms on the matrix cores, no gather lists).  Parity-green and measured slower than the list walk on MI355X: opt-in
     int chunk_wgs() const { return std::max(1, n_cus - 1); }      // chunk workgroups of the persistent large-window kernels: one compute unit stays free for the frame-terms workgroup of the same launch
     hipStream_t stream;
     hipEvent_t ev0, ev1;
@@ -191,7 +184,7 @@ static KOpts make_kopts(const uvs_options& o, int debug) {
 }
 
 struct DevWin;
-static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vector<char>& out, DevWin& hdr, std::string& err, int chunk_grid = 0, PackCache* cache = nullptr, bool want_dense = false, PackDst* dst = nullptr);
+static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vector<char>& out, DevWin& hdr, std::string& err, int chunk_grid = 0, PackCache* cache = nullptr, PackDst* dst = nullptr);
 
 extern "C" {
 
@@ -236,11 +229,9 @@ int uvs_debug_pack_layout(const uvs_options* o, const uvs_window* w, int32_t* in
     if (!o || !w || !info) return UVS_ERR_INVALID_ARG;
     std::vector<char> blob; DevWin h; std::string err;
     const char* grid_env = std::getenv("UVS_DEBUG_CHUNK_GRID");      // CPU tests of the large-window chunking (uvs_large_begin passes the device's CU count)
-    const char* dense_env = std::getenv("UVS_DEBUG_PACK_DENSE");      // the packing the 512-thread persistent kernel gets (dense Schur layout where the window allows it)
-    const bool want_dense = dense_env && std::atoi(dense_env) != 0;
-    const int rc = pack_window(w, *o, blob, h, err, grid_env ? std::atoi(grid_env) : 0, nullptr, want_dense);
+    const int rc = pack_window(w, *o, blob, h, err, grid_env ? std::atoi(grid_env) : 0, nullptr);
     if (rc != UVS_OK) return rc;
-    const int32_t v[12] = {h.blob_bytes, h.ws_doubles, h.n_chunks, h.n_pt_obs, h.n_relo, h.pt_rec, h.pt_xslots, h.max_chunk_doubles, h.dense ? UVS_S_DOUBLES - UVS_DS_CTOT : UVS_S_DOUBLES, h.n_parts, h.n_cimg, h.n_pblk};
+    const int32_t v[12] = {h.blob_bytes, h.ws_doubles, h.n_chunks, h.n_pt_obs, h.n_relo, h.pt_rec, h.pt_xslots, h.max_chunk_doubles, UVS_S_DOUBLES, h.n_parts, h.n_cimg, h.n_pblk};
     std::memcpy(info, v, sizeof(v));
     return UVS_OK;
 }
@@ -263,9 +254,8 @@ int uvs_create(const uvs_options* opts, int device, int max_batch, int max_point
     unsigned char fa[UVS_NBLK], fb[UVS_NBLK];
     for (int i = 0, b = 0; i < UVS_NF; ++i) for (int j = 0; j <= i; ++j, ++b) { fa[b] = (unsigned char)i; fb[b] = (unsigned char)j; }
     if (hipMemcpyToSymbol(HIP_SYMBOL(c_blk_fa), fa, sizeof(fa)) != hipSuccess || hipMemcpyToSymbol(HIP_SYMBOL(c_blk_fb), fb, sizeof(fb)) != hipSuccess) { delete s; return UVS_ERR_HIP; }
-    if (uvs_k_solve512_arg_bytes(0) != sizeof(KOpts) || uvs_k_solve512_arg_bytes(1) != sizeof(DebugOut) || uvs_k_solve512_init(fa, fb, UVS_NBLK) != UVS_OK || uvs_k_solve512d_init(fa, fb, UVS_NBLK) != UVS_OK) { delete s; return UVS_ERR_HIP; }
+    if (uvs_k_solve512_arg_bytes(0) != sizeof(KOpts) || uvs_k_solve512_arg_bytes(1) != sizeof(DebugOut) || uvs_k_solve512_init(fa, fb, UVS_NBLK) != UVS_OK) { delete s; return UVS_ERR_HIP; }
     { const char* e = std::getenv("UVS_KSOLVE_NT"); s->ksolve_nt = (e && std::atoi(e) == 256) ? 256 : 512; }
-    { const char* e = std::getenv("UVS_DENSE_SCHUR"); s->dense_schur = s->ksolve_nt == 512 && e && std::atoi(e) != 0; }
     { const char* e = std::getenv("UVS_LARGE_CHUNKS_NT"); s->large_chunks_nt = (e && std::atoi(e) == 256) ? 256 : 512; }
     { const char* e = std::getenv("UVS_LARGE_SOLVE_NT"); s->large_solve_nt = (e && std::atoi(e) == 256) ? 256 : 512; }      // A/B switch: 256 = the one-wave-per-SIMD instantiation of the persistent kernel
     // the LDS opt-in is a per-device function attribute: every handle sets it for its own device (the current one since hipSetDevice above)
@@ -471,7 +461,7 @@ static void fill_values(char* B, const DevWin& h, const uvs_window* w, bool td_o
     }
 }
 
-static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vector<char>& out, DevWin& hdr, std::string& err, int chunk_grid, PackCache* cache, bool want_dense, PackDst* dst) {
+static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vector<char>& out, DevWin& hdr, std::string& err, int chunk_grid, PackCache* cache, PackDst* dst) {
     if (cache && cache->matches(w_in, opts, chunk_grid) && out.size() == (size_t)cache->hdr.blob_bytes) {      // same structure as the blob still sitting in `out`: values only
         fill_values(out.data(), cache->hdr, w_in, opts.estimate_td != 0, pack_inner_threads(w_in->n_point_obs + w_in->n_line_obs));
         hdr = cache->hdr;
@@ -537,13 +527,8 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
     h.relo2 = relo2 ? 1 : 0;
     h.pt_rec = ex_on ? UVS_PT_REC_EX : td_on ? UVS_PT_REC_TD : UVS_PT_REC; h.pt_xslots = 1 + (td_on ? 1 : 0) + (ex_on ? 1 : 0);
     const int PREC = h.pt_rec, XS = h.pt_xslots;
-    // The dense Schur path (uvs_layout.h: UVS_DS_*): only where the caller launches the 512-thread persistent kernel, and only for windows without pseudo-frame blocks.
-    // validate_window has made sure that a landmark's slots sit in pairwise different frames (shared imu_i < strictly increasing imu_j), so every slot owns its six
-    // columns of the landmark's operand row.
-    const bool dense = want_dense && chunk_grid == 0 && !td_on && !ex_on && !relo_on && (h.n_pt_obs + h.n_ln_obs) > 0;
-    h.dense = dense ? 1 : 0;
-    const long stage_cap = dense ? (long)UVS_S_DOUBLES - UVS_DS_CTOT : (long)UVS_S_DOUBLES;      // the C buffer of the dense product takes the end of the staging area
-    constexpr int NGMAX = UVS_NGRP, NG = UVS_NGRP, GPW = GRP_PER_WAVE;      // gather groups (two lanes each); the dense path has none, its step tables are built further down
+    const long stage_cap = (long)UVS_S_DOUBLES;
+    constexpr int NGMAX = UVS_NGRP, NG = UVS_NGRP, GPW = GRP_PER_WAVE;      // gather groups (two lanes each)
     // CSR by landmark
     std::vector<int> pbeg(h.n_points + 1, 0), lbeg(h.n_lines + 1, 0);
     for (int k = 0; k < h.n_pt_obs; ++k) pbeg[w->pt_lm[k] + 1]++;
@@ -558,10 +543,6 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
         // LDS doubles a chunk of landmarks [k0, k1) needs (records + Schur factors + gather lists), -1 if an index field overflows
         auto need_pt = [&](int k0, int k1) -> long {
             long nob = pbeg[k1] - pbeg[k0], nlm = k1 - k0, nli = list_hdr;
-            if (dense) {      // rec | Et[rup4(nlm)][LD] | lists with three direct entries per observation
-                if (nlm > 1023 || (nob + 1) * 8L * PREC > 65535) return -1;      // (the step table of the direct terms carries 16-bit byte offsets of the records)
-                return (long)PREC * (nob + 1) + (long)UVS_DS_LD * ((nlm + 3) & ~3L) + (2 * nob + 360 + 1) / 2;      // (one all-zero record behind the chunk's: padding slots and structural zeros of the direct operand) step table: 16 + 2 steps, steps <= nob + 33 (two passes, one padded step per run at most)
-            }
             // Schur entries: all slot pairs of the landmark; direct entries per observation: 3, + 3 with td, + 3 with ex (+ 1 more with both: (ex, td))
             const long dper = 3 + (td_on ? 3 : 0) + (ex_on ? 3 + (td_on ? 1 : 0) : 0);
             for (int k = k0; k < k1; ++k) { const long no = pbeg[k + 1] - pbeg[k]; nli += no ? (no + XS) * (no + XS + 1) / 2 + dper * no : 0; }
@@ -570,10 +551,6 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
         };
         auto need_ln = [&](int k0, int k1) -> long {
             long nob = lbeg[k1] - lbeg[k0], nlm = k1 - k0, nli = list_hdr;
-            if (dense) {      // rec | X[nlm][LNX] | Et[4 nlm][LD] | lists with one direct entry per observation; a re-damping stages its per-line tables in the record area
-                if (nlm > 1023 || (nob + 1) * 8L * UVS_LN_REC > 65535) return -1;
-                return (long)UVS_LN_REC * (nob + 1) + (long)UVS_DS_LNX * nlm + (long)UVS_DS_LD * 4 * nlm + (2 * nob + 160 + 1) / 2;      // step table: 28 + 2 steps, one step per observation
-            }
             for (int k = k0; k < k1; ++k) { const long no = lbeg[k + 1] - lbeg[k]; nli += no * (no + 1) / 2 + no; }
             if (nlm > 1023 || nob > 16383) return -1;
             return (long)(UVS_LN_REC + 2 * UVS_LN_EY) * nob + 20 * nlm + (nli + 1) / 2;
@@ -600,8 +577,7 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
             if (n_lm == 0) return UVS_OK;
             // start at the capacity lower bound (records + Schur factors alone; the lists come on top): walking n = 1, 2, ... costs
             // O(n * landmarks) per attempt, milliseconds for the 340 chunks of configs[3]
-            const long mine = dense ? (type == 0 ? (long)PREC * h.n_pt_obs + (long)UVS_DS_LD * h.n_points : (long)UVS_LN_REC * h.n_ln_obs + (long)(UVS_DS_LNX + 4 * UVS_DS_LD) * h.n_lines)
-                                    : type == 0 ? (long)PREC * h.n_pt_obs + 12L * (h.n_pt_obs + XS * h.n_points) : (long)(UVS_LN_REC + 2 * UVS_LN_EY) * h.n_ln_obs + 20L * h.n_lines;
+            const long mine = type == 0 ? (long)PREC * h.n_pt_obs + 12L * (h.n_pt_obs + XS * h.n_points) : (long)(UVS_LN_REC + 2 * UVS_LN_EY) * h.n_ln_obs + 20L * h.n_lines;
             const int n_first = (int)std::min<long>(n_lm, std::max<long>(std::max(1, n_from), mine / stage_cap));
             for (int n = n_first; n <= n_lm; ++n) { cut = cuts_for(n, n_lm, beg, need); if (!cut.empty()) return UVS_OK; }
             return UVS_ERR_CAPACITY;
@@ -640,7 +616,7 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
     int wblk[NGMAX];
     for (int g = 0; g < NGMAX; ++g) wblk[g] = -1;
     h.n_parts = 1;
-    if (!dense) {
+    {
     const int n_ch = (int)chunks.size() / UVS_CHUNK_INTS;
     // Two passes over the same generator: the first only COUNTS the entries per pose block (what the work split below needs), the second
     // regenerates them chunk by chunk into one reused set of vectors while the lists are written.  (Keeping every chunk's entries
@@ -661,7 +637,6 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
                 for (int o = b0; o < b1; ++o) fr[nf++] = (relo2 && w->pt_fj[o0 + o] == UVS_RELO_FRAME) ? UVS_RELO2_BLOCKROW : w->pt_fj[o0 + o];
                 if (td_on) fr[nf++] = UVS_NUM_FRAMES;                                  // then the td slot of this landmark (pseudo frame 11)
                 if (ex_on) fr[nf++] = UVS_NUM_FRAMES + 1;                              // then its extrinsic slot (pseudo frame 12)
-                if (!dense)
                 for (int sa = 0; sa < nf; ++sa) for (int sb = 0; sb <= sa; ++sb) {    // frames increase with the slot, except a relocalization block (pseudo frame 12) ahead of the td slot (11)
                     const bool up = fr[sa] >= fr[sb];
                     const int ra = up ? sa : sb, rb = up ? sb : sa;
@@ -693,7 +668,6 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
             const int oE = nob * UVS_LN_REC, oY = oE + UVS_LN_EY * nob;
             for (int k = k0; k < k1; ++k) {
                 const int b0 = lbeg[k] - o0, b1 = lbeg[k + 1] - o0;
-                if (!dense)
                 for (int sa = 0; sa < b1 - b0; ++sa) for (int sb = 0; sb <= sa; ++sb)
                     addS(blk_of(w->ln_fj[o0 + b0 + sa], w->ln_fj[o0 + b0 + sb]), (oE + UVS_LN_EY * (b0 + sa)) | ((oY + UVS_LN_EY * (b0 + sb)) << 16));
                 for (int o = b0; o < b1; ++o) addD(blk_of(w->ln_fj[o0 + o], w->ln_fj[o0 + o]), o * UVS_LN_REC);
@@ -739,7 +713,6 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
             // no group at all: S is zeroed anyway, and its group goes to a heavy block instead (15 of 128 groups for the canonical window)
             const bool r2b = b >= UVS_NBLKX;      // block row 13 (relo_Pose beside a free extrinsic)
             np[b] = ((b < UVS_NBLK || (tdb && td_on) || (!r2b && exb && (ex_on || relo_on) && (td_on || b != UVS_NBLK + UVS_NF + 1 + UVS_NF)) || (r2b && relo2 && (td_on || b != UVS_NBLKX + UVS_NF))) && blk_work[b] > 0) ? 1 : 0;
-            if (dense && b < UVS_NBLK) np[b] = 1;      // dense Schur path: the block's share of the C buffer reaches S through its part-0 group, direct entries or not
             used += np[b];
         }
         // The waves run in lock step inside a chunk and the chunks of the two landmark families are separated by barriers, so what counts
@@ -846,8 +819,8 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
                     const int type = chunks[UVS_CHUNK_INTS * qc], k0 = chunks[UVS_CHUNK_INTS * qc + 1], k1 = chunks[UVS_CHUNK_INTS * qc + 2];
                     const long nlist = (long)(P.lists.size() - base);
                     long used;
-                    if (type == 0) { const long nob = pbeg[k1] - pbeg[k0], nlm = k1 - k0; used = dense ? (long)PREC * nob + (long)UVS_DS_LD * ((nlm + 3) & ~3L) + (nlist + 1) / 2 : (long)PREC * nob + 12 * (nob + XS * nlm) + (nlist + 1) / 2; }
-                    else { const long nob = lbeg[k1] - lbeg[k0], nlm = k1 - k0; used = dense ? (long)UVS_LN_REC * nob + (long)(UVS_DS_LNX + 4 * UVS_DS_LD) * nlm + (nlist + 1) / 2 : (long)(UVS_LN_REC + 2 * UVS_LN_EY) * nob + 20 * nlm + (nlist + 1) / 2; }
+                    if (type == 0) { const long nob = pbeg[k1] - pbeg[k0], nlm = k1 - k0; used = (long)PREC * nob + 12 * (nob + XS * nlm) + (nlist + 1) / 2; }
+                    else { const long nob = lbeg[k1] - lbeg[k0], nlm = k1 - k0; used = (long)(UVS_LN_REC + 2 * UVS_LN_EY) * nob + 20 * nlm + (nlist + 1) / 2; }
                     if (used > stage_cap) P.overflow = true;
                     P.max_used = std::max(P.max_used, (int)used);
                 }
@@ -875,83 +848,6 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
             at += P.lists.size();
         }
     }
-    } else {
-        // ---- dense path (uvs_layout.h: UVS_DS_*): NO gather lists.  The direct terms J^T J, J^T r go through the matrix cores as well: the observations of a chunk are stacked
-        // two (points) or one (lines) per 4-row step into operand rows  [A_o | B_o | r_o]  resp.  [B_o | r_o], [Jp_o | r_o], whose product with itself holds A^T A, B^T A, J^T r
-        // (and B^T B) of the step; steps that share a frame pair (pass 0) resp. a second frame (pass 1) form a RUN that accumulates in one tile, and every frame -- its diagonal
-        // block, its gradient and diag(J^T J) -- is OWNED by one gatherer wave, which so is the only writer of the C-buffer entries its runs touch.  Per chunk (ints):
-        //     T[0..15]   step range [begin, end) of worker w at 2 w       T[16 + w]  first pass-1 step of worker w       T[24]  number of steps
-        //     steps[n][2]  (below)
-        const int n_ch = (int)chunks.size() / UVS_CHUNK_INTS;
-        for (int qc = 0; qc < n_ch; ++qc) {
-            const int type = chunks[UVS_CHUNK_INTS * qc], k0 = chunks[UVS_CHUNK_INTS * qc + 1], k1 = chunks[UVS_CHUNK_INTS * qc + 2];
-            const int o0 = type == 0 ? pbeg[k0] : lbeg[k0], nob = (type == 0 ? pbeg[k1] : lbeg[k1]) - o0;
-            const int slots = type == 0 ? 2 : 1;
-            // observations by key, in observation order within a key (counting sort: deterministic)
-            std::vector<int> by_pair[UVS_NUM_FRAMES + 2][UVS_NUM_FRAMES + 2], by_j[UVS_NUM_FRAMES + 2];
-            for (int o = 0; o < nob; ++o) {
-                if (type == 0) { by_pair[w->pt_fi[o0 + o]][w->pt_fj[o0 + o]].push_back(o); by_j[w->pt_fj[o0 + o]].push_back(o); }
-                else by_j[w->ln_fj[o0 + o]].push_back(o);
-            }
-            auto steps_of = [&](size_t n) { return (int)((n + slots - 1) / slots); };
-            auto steps_even = [&](size_t n) { return (steps_of(n) + 1) & ~1; };
-            // frame ownership: longest-processing-time over the four gatherer waves; wave 0 also runs the anchor pass of a point chunk (one lane per landmark, a chain about
-            // as long as 60 steps), so it starts with that handicap
-            long fw[UVS_NUM_FRAMES] = {0};
-            for (int f = 0; f < UVS_NUM_FRAMES; ++f) {
-                fw[f] = steps_even(by_j[f].size());
-                if (type == 0) for (int j = 0; j < UVS_NUM_FRAMES; ++j) fw[f] += steps_even(by_pair[f][j].size());
-            }
-            int order[UVS_NUM_FRAMES]; for (int f = 0; f < UVS_NUM_FRAMES; ++f) order[f] = f;
-            std::stable_sort(order, order + UVS_NUM_FRAMES, [&](int a, int b2) { return fw[a] > fw[b2]; });
-            // EIGHT workers: 0..3 = the gatherer waves (free from the end of pass A; the first also runs the anchor pass of a point chunk, ~60 steps' worth), 4..7 = the evaluator
-            // waves, which join after their pass B (~26 steps' worth for a point chunk; the two long passes of a line chunk leave them next to nothing)
-            constexpr int NWK = 8;
-            long load[NWK]; int owner[UVS_NUM_FRAMES];
-            for (int g = 0; g < NWK; ++g) load[g] = g == 0 ? (type == 0 ? 60 : 0) : g < 4 ? 0 : (type == 0 ? 26 : 90);
-            for (int q = 0; q < UVS_NUM_FRAMES; ++q) { int best = 0; for (int g = 1; g < NWK; ++g) if (load[g] < load[best]) best = g; owner[order[q]] = best; load[best] += fw[order[q]]; }
-            // flat step list per worker: word 0 = first observation | second << 16 (padding: the all-zero record behind the chunk's); word 1 = kind (0 point pair, 1 points by
-            // second frame, 2 lines) | frame_i << 4 | frame_j << 8 | last step of its run << 12 | last step of its frame's runs of this pass << 13
-            std::vector<int> T(28, 0), steps;      // T[2 w], T[2 w + 1]: step range of worker w; T[16 + w]: where its pass-1 steps begin; T[24]: number of steps
-            const int recb = 8 * (type == 0 ? PREC : UVS_LN_REC);      // word 0 carries the BYTE offsets of the two records (16 bits each: <= 16383 observations x 46 doubles would not fit,
-                                                                       // but a chunk's records end below 64 KB: checked below)
-            auto add_run = [&](int kind, int fi, int fj, const std::vector<int>& v, bool last_of_frame) {
-                const int ns0 = steps_of(v.size()), ns = (ns0 + 1) & ~1;      // an EVEN number of steps per run (the kernel tests for the end of a run every second step): padded with the zero record
-                for (int q = 0; q < ns; ++q) {
-                    const int oa = (size_t)slots * q < v.size() ? v[(size_t)slots * q] : nob, ob = (slots == 2 && (size_t)(2 * q + 1) < v.size()) ? v[(size_t)2 * q + 1] : nob;
-                    const bool last = q + 1 == ns;
-                    steps.push_back((oa * recb) | ((ob * recb) << 16));
-                    steps.push_back(kind | (fi << 4) | (fj << 8) | ((last ? 1 : 0) << 12) | ((last && last_of_frame ? 1 : 0) << 13));
-                }
-            };
-            if ((long)(nob + 1) * recb > 65535) { err = "internal: dense chunk records exceed 64 KB"; return UVS_ERR_CAPACITY; }
-            for (int g = 0; g < NWK; ++g) {
-                T[2 * g] = (int)steps.size() / 2;
-                if (type == 0) for (int f = 0; f < UVS_NUM_FRAMES; ++f) {      // pass 0: the frame pairs (f, j) of the owned first frames
-                    if (owner[f] != g) continue;
-                    int last_j = -1;
-                    for (int j = 0; j < UVS_NUM_FRAMES; ++j) if (!by_pair[f][j].empty()) last_j = j;
-                    for (int j = 0; j < UVS_NUM_FRAMES; ++j) if (!by_pair[f][j].empty()) add_run(0, f, j, by_pair[f][j], j == last_j);
-                }
-                T[16 + g] = (int)steps.size() / 2;
-                for (int f = 0; f < UVS_NUM_FRAMES; ++f) if (owner[f] == g && !by_j[f].empty()) add_run(type == 0 ? 1 : 2, f, f, by_j[f], true);      // pass 1: the owned (second) frames
-                T[2 * g + 1] = (int)steps.size() / 2;
-                for (int q = 0; q < 4; ++q) { steps.push_back((nob * recb) | ((nob * recb) << 16)); steps.push_back(0); }      // (what the kernel's four-steps-ahead fetch reads behind the range)
-            }
-            T[24] = (int)steps.size() / 2;
-            if (std::getenv("UVS_DEBUG_LISTS")) fprintf(stderr, "dense chunk %d type %d: %d observations, steps per worker %d %d %d %d | %d %d %d %d (frame weights:%s)\n", qc, type, nob, T[1] - T[0], T[3] - T[2], T[5] - T[4], T[7] - T[6],
-                                                        T[9] - T[8], T[11] - T[10], T[13] - T[12], T[15] - T[14],
-                                                        [&] { static std::string t; t.clear(); for (int f = 0; f < UVS_NUM_FRAMES; ++f) t += " " + std::to_string(fw[f]) + "@" + std::to_string(owner[f]); return t.c_str(); }());
-            chunks[UVS_CHUNK_INTS * qc + 3] = (int)lists.size();
-            lists.insert(lists.end(), T.begin(), T.end()); lists.insert(lists.end(), steps.begin(), steps.end());
-            if (lists.size() & 1) lists.push_back(0);
-            const long nlist = (long)lists.size() - chunks[UVS_CHUNK_INTS * qc + 3];
-            chunks[UVS_CHUNK_INTS * qc + 4] = (int)nlist;
-            const long nlm = k1 - k0;
-            const long used = type == 0 ? (long)PREC * (nob + 1) + (long)UVS_DS_LD * ((nlm + 3) & ~3L) + (nlist + 1) / 2 : (long)UVS_LN_REC * (nob + 1) + (long)(UVS_DS_LNX + 4 * UVS_DS_LD) * nlm + (nlist + 1) / 2;
-            if (used > stage_cap) { err = "internal: dense chunk layout exceeds the LDS staging area"; return UVS_ERR_CAPACITY; }
-            h.max_chunk_doubles = std::max(h.max_chunk_doubles, (int)used);
-        }
     }
     h.n_chunks = (int)chunks.size() / UVS_CHUNK_INTS;
     // re-damping (uvs_solve_kernel.h: redamp_chunk) keeps its per-line table and gradient rows in the record area of a line chunk
@@ -959,9 +855,7 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
     if (have_prior) for (int b = 0; b < w->prior->n_blocks; ++b) if (w->prior->block_kind[b] == UVS_BLOCK_SPEEDBIAS && w->prior->block_frame[b] >= 2) h.chol_half_ok = 0;
     if (std::getenv("UVS_CHOL_FULL_ROWS")) h.chol_half_ok = 0;
     h.redamp_ok = (!td_on && !ex_on && !relo_on) ? 1 : 0;
-    if (dense) for (int qc = 0; qc < h.n_chunks; ++qc)      // a dense re-damping stages its per-line tables in the record area, in front of the operand
-        if (chunks[UVS_CHUNK_INTS * qc] == 1) { const long nob = lbeg[chunks[UVS_CHUNK_INTS * qc + 2]] - lbeg[chunks[UVS_CHUNK_INTS * qc + 1]], nlm = chunks[UVS_CHUNK_INTS * qc + 2] - chunks[UVS_CHUNK_INTS * qc + 1]; if ((long)UVS_DS_LNT * nlm > (long)UVS_LN_REC * nob + (long)UVS_DS_LNX * nlm) h.redamp_ok = 0; }
-    for (int qc = 0; qc < h.n_chunks && h.redamp_ok && !dense; ++qc)
+    for (int qc = 0; qc < h.n_chunks && h.redamp_ok; ++qc)
         if (chunks[UVS_CHUNK_INTS * qc] == 1) { const long nob = lbeg[chunks[UVS_CHUNK_INTS * qc + 2]] - lbeg[chunks[UVS_CHUNK_INTS * qc + 1]], nlm = chunks[UVS_CHUNK_INTS * qc + 2] - chunks[UVS_CHUNK_INTS * qc + 1]; if (34 * nlm + 6 * nob > (long)UVS_LN_REC * nob) h.redamp_ok = 0; }
         else {      // point chunk: redamp_chunk's gradient rows Gb[(nob + nlm)][6] sit in front of the E rows at rec + nob * pt_rec -- a chunk made mostly of landmarks WITHOUT observations would run into them
             const long nob = pbeg[chunks[UVS_CHUNK_INTS * qc + 2]] - pbeg[chunks[UVS_CHUNK_INTS * qc + 1]], nlm = chunks[UVS_CHUNK_INTS * qc + 2] - chunks[UVS_CHUNK_INTS * qc + 1];
@@ -1017,7 +911,7 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
     h.i_imu = i; i += 2 * std::max(h.n_imu, 1);
     h.i_prior = i; i += 80 + UVS_MAX_PRIOR_DIM + UVS_RD + UVS_NBLK;
     h.i_chunks = i; i += UVS_CHUNK_INTS * std::max(h.n_chunks, 1);
-    h.i_wblk = i; i += dense ? 0 : NG;
+    h.i_wblk = i; i += NG;
     h.i_lists = i; i += (int)lists.size() + 2;
     h.blob_bytes = rup(4 * i, 256);
     // workspace layout
@@ -1082,7 +976,7 @@ static int pack_window(const uvs_window* w_in, const uvs_options& opts, std::vec
     }
     for (size_t q = 0; q < chunks.size(); ++q) I[h.i_chunks + q] = chunks[q];
     if (!lists.empty()) std::memcpy(I + h.i_lists, lists.data(), lists.size() * sizeof(int));
-    if (!dense) for (int q = 0; q < NG; ++q) I[h.i_wblk + q] = wblk[q];
+    for (int q = 0; q < NG; ++q) I[h.i_wblk + q] = wblk[q];
     lap_("blob");
     hdr = h;
     if (cache && !relo_on && h.n_pt_obs + h.n_ln_obs >= kPackCacheMinObs) cache->store(w_in, opts, chunk_grid, h);
@@ -1149,7 +1043,7 @@ static int upload_windows(uvs_solver* s, int n, const uvs_window* const* ws, boo
         if (!s->pack_cache) s->pack_cache = new PackCache();
         const bool was_valid = s->pack_cache->valid, dev = s->pack_cache->device_holds_tables;
         s->blob_off[0] = 0;
-        int rc = pack_window(ws[0], s->opts, s->host_blobs, s->hdrs[0], s->err, chunk_grid, s->pack_cache, s->dense_schur);
+        int rc = pack_window(ws[0], s->opts, s->host_blobs, s->hdrs[0], s->err, chunk_grid, s->pack_cache);
         if (rc != UVS_OK) { s->n_loaded = 0; return rc; }
         values_only = !out_direct && was_valid && dev && s->pack_cache->valid && s->pack_cache->device_holds_tables;      // (a miss resets both flags; the stream patches every staged header -- DevWin::out_host -- so the whole blob travels)
     } else if (nthreads == 1) {
@@ -1157,7 +1051,7 @@ static int upload_windows(uvs_solver* s, int n, const uvs_window* const* ws, boo
         if (s->pack_cache) { s->pack_cache->valid = false; s->pack_cache->device_holds_tables = false; }
         for (int b = 0; b < n; ++b) {
             s->blob_off[b] = (long long)s->host_blobs.size();
-            int rc = pack_window(ws[b], s->opts, s->host_blobs, s->hdrs[b], s->err, chunk_grid, nullptr, s->dense_schur);
+            int rc = pack_window(ws[b], s->opts, s->host_blobs, s->hdrs[b], s->err, chunk_grid, nullptr);
             if (rc != UVS_OK) { s->n_loaded = 0; return rc; }
         }
     } else {
@@ -1176,7 +1070,7 @@ static int upload_windows(uvs_solver* s, int n, const uvs_window* const* ws, boo
             for (int b = t; b < n; b += nthreads) {
                 PackDst d{&bump, direct_cap ? s->h_up : nullptr, direct_cap, -1};
                 s->slot_blobs[b].clear();
-                rcs[b] = pack_window(ws[b], s->opts, s->slot_blobs[b], s->hdrs[b], errs[b], chunk_grid, nullptr, s->dense_schur, &d);
+                rcs[b] = pack_window(ws[b], s->opts, s->slot_blobs[b], s->hdrs[b], errs[b], chunk_grid, nullptr, &d);
                 placed[b] = d.off;
             }
         };
@@ -1413,8 +1307,7 @@ static int launch_solve(uvs_solver* s, int debug, float* elapsed_ms, bool wait =
         dbg.S = s->d_dbg; dbg.g = dbg.S + UVS_RD * UVS_RD; dbg.hd = dbg.g + UVS_RD; dbg.dd = dbg.hd + UVS_RD; dbg.step = dbg.dd + UVS_RD; dbg.scal = dbg.step + UVS_RD;
     }
     HIPCHK(s, hipEventRecord(s->ev0, s->stream));
-    if (s->ksolve_nt == 512 && s->dense_schur) { if (uvs_k_solve512d_launch(s->n_loaded, s->stream, s->d_blobs, s->d_blob_off, s->d_ws, s->d_ws_off, &ko, sizeof(ko), d_reports, &dbg, sizeof(dbg)) != UVS_OK) { s->err = "k_solve (dense instantiation): argument layout mismatch"; return UVS_ERR_HIP; } }
-    else if (s->ksolve_nt == 512) { if (uvs_k_solve512_launch(s->n_loaded, s->stream, s->d_blobs, s->d_blob_off, s->d_ws, s->d_ws_off, &ko, sizeof(ko), d_reports, &dbg, sizeof(dbg)) != UVS_OK) { s->err = "k_solve (512 threads): argument layout mismatch between the translation units"; return UVS_ERR_HIP; } }
+    if (s->ksolve_nt == 512) { if (uvs_k_solve512_launch(s->n_loaded, s->stream, s->d_blobs, s->d_blob_off, s->d_ws, s->d_ws_off, &ko, sizeof(ko), d_reports, &dbg, sizeof(dbg)) != UVS_OK) { s->err = "k_solve (512 threads): argument layout mismatch between the translation units"; return UVS_ERR_HIP; } }
     else hipLaunchKernelGGL(k_solve, dim3(s->n_loaded), dim3(NT), LDS_BYTES, s->stream, s->d_blobs, s->d_blob_off, s->d_ws, s->d_ws_off, ko, d_reports, dbg);
     HIPCHK(s, hipGetLastError());
     HIPCHK(s, hipEventRecord(s->ev1, s->stream));
@@ -1576,7 +1469,7 @@ int uvs_debug_first_iteration(uvs_solver* s, const uvs_window* w, double* S_lowe
     if (rc != UVS_OK) return rc;
     if (tl_path) {
         std::vector<long long> tl(8 * TL_PER_WAVE * 2);
-        if ((s->ksolve_nt == 512 ? (s->dense_schur ? uvs_k_solve512d_timeline(tl.data(), tl.size()) : uvs_k_solve512_timeline(tl.data(), tl.size())) == UVS_OK : hipMemcpyFromSymbol(tl.data(), HIP_SYMBOL(g_lin_tl), tl.size() * 8) == hipSuccess)) { if (FILE* f = std::fopen(tl_path, "wb")) { std::fwrite(tl.data(), 8, tl.size(), f); std::fclose(f); } }
+        if ((s->ksolve_nt == 512 ? uvs_k_solve512_timeline(tl.data(), tl.size()) == UVS_OK : hipMemcpyFromSymbol(tl.data(), HIP_SYMBOL(g_lin_tl), tl.size() * 8) == hipSuccess)) { if (FILE* f = std::fopen(tl_path, "wb")) { std::fwrite(tl.data(), 8, tl.size(), f); std::fclose(f); } }
     }
     const size_t nS = (size_t)UVS_RD * UVS_RD;
     if (S_lower) HIPCHK(s, hipMemcpy(S_lower, s->d_dbg, nS * 8, hipMemcpyDeviceToHost));
