@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define UVS_ABI_VERSION 6
+#define UVS_ABI_VERSION 7
 
 #define UVS_WINDOW_SIZE 10                    /* parameters.h:12 WINDOW_SIZE  */
 #define UVS_NUM_FRAMES (UVS_WINDOW_SIZE + 1)  /* frames 0..WINDOW_SIZE        */
@@ -333,6 +333,14 @@ int uvs_marginalize_resident(uvs_solver *s, const uvs_window *w, int flag, uvs_p
  * must not be used for anything else, and `w` as well as every array it points to (incl. w->prior) must stay valid and unchanged.  uvs_destroy() waits by itself. */
 int uvs_marginalize_resident_begin(uvs_solver *s, const uvs_window *w, int flag);
 int uvs_marginalize_wait(uvs_solver *s, uvs_prior *out);
+/* The marginalization of a BATCH of independent windows (ABI v7, round 6): out[b] = what uvs_marginalize(s, ws[b], flags[b], &out[b]) returns, for b = 0 .. n - 1, with the
+ * cubic work of all windows in two launches -- the sub-windows of the MARGIN_OLD windows (flag 0) are linearized by one launch (assembly A = sum J^T J, b = sum J^T r and elimination
+ * of the dropped landmark blocks, marginalization_factor.cpp:232-276), then ONE launch eliminates every window's dropped frame block, forms the Schur complement and factors it
+ * (J0 = sqrt(S) V^T, r0 = sqrt(S^-1) V^T b with the eps = 1e-8 cut, :278-291; a parallel cyclic Jacobi per window, csrc/uvs_marg_kernel.h).  MARGIN_SECOND_NEW windows (flag 1)
+ * read their old prior only and join the second launch.  Host work per window (sub-window packing, the block tables) runs on the handle's packing threads.  status (may be NULL)
+ * receives the per-window code; the return value is the first one that is not UVS_OK.  A window the device path does not take (a landmark or frame block the reference's eps cut
+ * would touch, N = dropped + kept frame dofs > 96) is sent through uvs_marginalize().  What a batched closed-loop replay calls between two uvs_batch_solve(). */
+int uvs_marginalize_batch(uvs_solver *s, int n, const uvs_window *const *ws, const int *flags, uvs_prior *out, int *status);
 
 /* ---- ONE large window spread over the GPU and, with an all-reduce between the steps, over several GPUs (BASELINE configs[3]) ----
  * Landmarks shard (rank r holds the landmarks k with k % G == r; frames / IMU / prior are replicated); the only exchanged data are

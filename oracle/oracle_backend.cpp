@@ -38,7 +38,12 @@ int uvs_large_solve_fused(uvs_solver* s, const uvs_window* w, uvs_state* out, uv
 int uvs_evaluate(uvs_solver* s, const uvs_window* w, int robust, uvs_eval* out) { return oracle_evaluate(&s->opt, w, robust, out); }
 int uvs_marginalize(uvs_solver* s, const uvs_window* w, int flag, uvs_prior* out) { return oracle_marginalize(&s->opt, w, flag, out); }
 int uvs_marginalize_resident(uvs_solver* s, const uvs_window* w, int flag, uvs_prior* out) { return oracle_marginalize(&s->opt, w, flag, out); }
-// the two-halves form (ABI v6): the oracle answers at once, the wait hands the result over
+int uvs_marginalize_batch(uvs_solver* s, int n, const uvs_window* const* ws, const int* flags, uvs_prior* out, int* status) {      // (ABI v7: window by window here)
+    int first = UVS_OK;
+    for (int b = 0; b < n; ++b) { const int rc = oracle_marginalize(&s->opt, ws[b], flags[b], &out[b]); if (status) status[b] = rc; if (rc != UVS_OK && first == UVS_OK) first = rc; }
+    return first;
+}
+// the two-halves form (since ABI v6): the oracle answers at once, the wait hands the result over
 int uvs_marginalize_resident_begin(uvs_solver* s, const uvs_window* w, int flag) { if (s->marg_pending) return UVS_ERR_INVALID_ARG; s->marg_rc = oracle_marginalize(&s->opt, w, flag, &s->marg_out); s->marg_pending = true; return UVS_OK; }
 int uvs_marginalize_wait(uvs_solver* s, uvs_prior* out) { if (!s->marg_pending) return UVS_ERR_INVALID_ARG; s->marg_pending = false; if (s->marg_rc == UVS_OK) *out = s->marg_out; return s->marg_rc; }
 }

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 14
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/uvs_solver.h but not exported by libuvs_solver.so"
-    assert lib.uvs_abi_version() == 6
+    assert lib.uvs_abi_version() == 7
 
 
 def test_default_options_match_python_mirror():

@@ -91,3 +91,52 @@ def test_marginalization_in_two_halves_equals_the_one_call_form(gpu_api, flag):
     assert p.n == ref.n and p.n_blocks == ref.n_blocks
     assert np.array_equal(np.asarray(p.J0()), np.asarray(ref.J0())) and np.array_equal(np.asarray(p.r0()), np.asarray(ref.r0()))
     s.close()
+
+
+@pytest.mark.gpu
+def test_batched_marginalization_equals_the_one_window_call(gpu_api, oracle):
+    """uvs_marginalize_batch (ABI v7, round 6): both marginalization kinds, windows with and without a prior, one window without any factor of frame 0 -- the frame-block
+    elimination, the Schur complement and the eigen-decomposition of ALL windows in one launch (csrc/uvs_marg_kernel.h: parallel cyclic Jacobi) against the one-window
+    call (host finish: Cholesky + tridiagonal QL) and against the oracle, in the information form the next solve reads (H = J0^T J0, b = J0^T r0), plus the block tables
+    and linearization points bit for bit; and against the extended-precision Schur complement of test_hip_prior_matches_extended_precision."""
+    s = gpu_api.Solver(max_batch=2)
+    marg = lambda win, flag: s.marginalize(win, flag)
+    wins, flags = [], []
+    for k, (index, with_prior) in enumerate([(70, False), (71, True), (72, True), (41, True), (42, True), (43, True), (73, True), (74, True)]):
+        w = synth.make_window(index, with_prior=with_prior, marginalize_fn=marg)
+        st, _ = s.solve(w)
+        ws_ = w.with_state(st)
+        wins.append(ws_); flags.append(0)
+        if with_prior: wins.append(ws_); flags.append(1)
+    single = [s.marginalize(w, f) for w, f in zip(wins, flags)]
+    batch, status = s.marginalize_batch(wins, flags)
+    assert status == [0] * len(wins)
+    worst = [0.0, 0.0, 0.0, 0.0]
+    for k, (w, f, p1, pb) in enumerate(zip(wins, flags, single, batch)):
+        assert pb.n == p1.n and pb.n_blocks == p1.n_blocks, (k, f)
+        nb = p1.n_blocks
+        for fld in ("block_kind", "block_frame", "block_size", "block_idx", "x0_off"):
+            assert list(getattr(pb, fld)[:nb]) == list(getattr(p1, fld)[:nb]), (k, fld)
+        assert np.array_equal(np.asarray(pb.x0[:9 * nb]), np.asarray(p1.x0[:9 * nb]))
+        if p1.n == 0: continue
+        po = oracle.marginalize(w, f)
+        Hb, H1, Ho = pb.J0().T @ pb.J0(), p1.J0().T @ p1.J0(), po.J0().T @ po.J0()
+        bb, b1, bo = pb.J0().T @ pb.r0(), p1.J0().T @ p1.r0(), po.J0().T @ po.r0()
+        sc, sb = np.abs(Ho).max(), max(1.0, np.abs(bo).max())
+        e = [np.abs(Hb - H1).max() / sc, np.abs(bb - b1).max() / sb, np.abs(Hb - Ho).max() / sc, np.abs(bb - bo).max() / sb]
+        assert e[0] <= 1e-7 and e[1] <= 1e-6 and e[2] <= 1e-6 and e[3] <= 1e-5, (k, f, e)
+        # the constant of the prior's cost, r0^T r0 = b^T H^+ b, which the termination tests of the next solve see
+        c_b, c_1 = float(pb.r0() @ pb.r0()), float(p1.r0() @ p1.r0())
+        assert abs(c_b - c_1) <= 1e-6 * max(1.0, abs(c_1)), (k, c_b, c_1)
+        worst = [max(a, b_) for a, b_ in zip(worst, e)]
+    # extended precision (MARGIN_OLD of the first three windows)
+    for k in (0, 1, 3):
+        w = wins[k]
+        ev = s.evaluate(w, robust=True)
+        Ar, br, kp = marginalization_reference(w, ev)
+        H, b, cols = prior_information(batch[k])
+        perm = [cols.index(c) for c in kp]
+        H, b = H[np.ix_(perm, perm)], b[perm]
+        assert np.abs(H - Ar).max() / np.abs(Ar).max() < 5e-7 and np.abs(b - br).max() / np.abs(br).max() < 1e-8
+    print("batched marginalization of %d windows vs one-window calls: H %.1e, b %.1e; vs oracle: H %.1e, b %.1e (relative)" % (len(wins), *worst))
+    s.close()

@@ -18,7 +18,7 @@ _lib = None
 
 EXPORTS = [
     "uvs_abi_version", "uvs_default_options", "uvs_create", "uvs_destroy", "uvs_last_error", "uvs_status_string",
-    "uvs_solve_window", "uvs_batch_upload", "uvs_batch_solve", "uvs_batch_download", "uvs_batch_stream", "uvs_evaluate", "uvs_marginalize", "uvs_marginalize_resident",
+    "uvs_solve_window", "uvs_batch_upload", "uvs_batch_solve", "uvs_batch_download", "uvs_batch_stream", "uvs_evaluate", "uvs_marginalize", "uvs_marginalize_resident", "uvs_marginalize_batch",
     "uvs_reduced_dim",
 ]
 
@@ -273,6 +273,20 @@ class Solver:
         fn = lib().uvs_marginalize_resident if resident else lib().uvs_marginalize
         self._check(fn(self._h, C.byref(wc), flag, C.byref(p)))
         return p
+
+    def marginalize_batch(self, windows, flags):
+        """uvs_marginalize_batch: the marginalization of independent windows with the cubic work of all of them in two launches; returns (priors, per-window status codes)."""
+        n = len(windows)
+        keeps = [w.to_c() for w in windows]
+        arr = (C.POINTER(abi.WindowC) * n)(*[C.pointer(k[0]) for k in keeps])
+        fl = (C.c_int * n)(*[int(f) for f in flags])
+        pri = (abi.Prior * n)()
+        st = (C.c_int * n)()
+        L = lib()
+        L.uvs_marginalize_batch.restype = C.c_int
+        rc = L.uvs_marginalize_batch(self._h, n, arr, fl, pri, st)
+        self._check(rc)
+        return [pri[i] for i in range(n)], list(st)
 
     def marginalize_begin(self, w: abi.Window, flag=0):
         """uvs_marginalize_resident_begin: the marginalization of the resident window on a worker thread of the handle; marginalize_wait() delivers the prior.

@@ -216,6 +216,28 @@ static void marg_solve_small(int sz, const double* Bm, double* X, int nr, int ld
         }
     }
 
+// The block table of a new prior: the kept blocks in id order with their local sizes, column offsets and the linearization point = the window's current values, frames shifted as the
+// window will be (addr_shift, estimator.cpp:1139-1152 for MARGIN_OLD / :1196-1219 for MARGIN_SECOND_NEW).  out->n must be set; m = first kept row of the ordering `pos`.
+static void marg_fill_blocks(uvs_prior* out, const std::vector<int>& pos, const std::vector<int>& keep_ids, int m, const uvs_window* w, int flag) {
+    const int NFR = UVS_NF;
+    auto gsize = [&](int id) { return id < NFR ? 7 : id < 2 * NFR ? 9 : id == 22 ? 7 : 1; };
+    out->n_blocks = (int)keep_ids.size();
+    int xo = 0;
+    for (int b = 0; b < out->n_blocks; ++b) {
+        const int id = keep_ids[b];
+        int kind, frame = 0; const double* data;
+        if (id < NFR) { kind = UVS_BLOCK_POSE; frame = id; data = w->pose[frame]; }
+        else if (id < 2 * NFR) { kind = UVS_BLOCK_SPEEDBIAS; frame = id - NFR; data = w->speedbias[frame]; }
+        else if (id == 23) { kind = UVS_BLOCK_TD; data = &w->td; }
+        else { kind = UVS_BLOCK_EX_POSE; data = w->ex_pose; }
+        int nf = frame;
+        if (kind == UVS_BLOCK_POSE || kind == UVS_BLOCK_SPEEDBIAS) nf = (flag == 0) ? frame - 1 : (frame == UVS_WINDOW_SIZE ? frame - 1 : frame);
+        out->block_kind[b] = kind; out->block_frame[b] = nf; out->block_size[b] = gsize(id); out->block_idx[b] = pos[id] - m; out->x0_off[b] = xo;
+        for (int q = 0; q < gsize(id); ++q) out->x0[xo + q] = data[q];
+        xo += gsize(id);
+    }
+}
+
 // The tail of a marginalization, shared by the host path (A assembled and its landmark blocks eliminated on the host) and the device path (A = the reduced
 // frame system a linearization kernel delivered): A is N x N with the dropped FRAME dofs in rows / columns [0, md) and the kept ones in [m, N); rows
 // [md, m) (eliminated landmarks) are not read.  Eliminates the dropped frame block, factors the kept system J0 = sqrt(S) V^T, r0 = sqrt(S^-1) V^T b
@@ -266,21 +288,7 @@ static int marg_finish(int N, int m, int md, int n, std::vector<double>& A, std:
         for (int j = 0; j < n; ++j) { out->linearized_jacobians[(size_t)row * n + j] = ss * V2[(size_t)j * n + k]; vb += V2[(size_t)j * n + k] * br[j]; }
         out->linearized_residuals[row] = si * vb;
     }
-    // ---- kept blocks, linearization point = current values, addr_shift (estimator.cpp:1139-1152 / :1196-1219)
-    int xo = 0;
-    for (int b = 0; b < out->n_blocks; ++b) {
-        const int id = keep_ids[b];
-        int kind, frame = 0; const double* data;
-        if (id < NFR) { kind = UVS_BLOCK_POSE; frame = id; data = w->pose[frame]; }
-        else if (id < 2 * NFR) { kind = UVS_BLOCK_SPEEDBIAS; frame = id - NFR; data = w->speedbias[frame]; }
-        else if (id == 23) { kind = UVS_BLOCK_TD; data = &w->td; }
-        else { kind = UVS_BLOCK_EX_POSE; data = w->ex_pose; }
-        int nf = frame;
-        if (kind == UVS_BLOCK_POSE || kind == UVS_BLOCK_SPEEDBIAS) nf = (flag == 0) ? frame - 1 : (frame == UVS_WINDOW_SIZE ? frame - 1 : frame);
-        out->block_kind[b] = kind; out->block_frame[b] = nf; out->block_size[b] = gsize(id); out->block_idx[b] = pos[id] - m; out->x0_off[b] = xo;
-        for (int q = 0; q < gsize(id); ++q) out->x0[xo + q] = data[q];
-        xo += gsize(id);
-    }
+    marg_fill_blocks(out, pos, keep_ids, m, w, flag);
     return UVS_OK;
 }
 
@@ -317,8 +325,13 @@ static void host_prior_residual(const uvs_prior& p, const uvs_window* w, std::ve
 
 struct MFactor { int rows; int nb; int id[5]; int sz[5]; const double* r; const double* J; int ld; int coff[5]; const double* Jx; int xcol; };   // J row stride ld, column offset per block; block with coff < 0 reads its single column from Jx[row stride 1... 2 entries]   // J row stride ld, column offset per block
 
-static int run_marginalize(int device, hipStream_t stream, char* d_blob, double* d_ws, const DevWin& h, const uvs_window* w, const KOpts& ko,
-                           int flag, uvs_prior* out, std::string& err, EvalScratch& sc) {
+// what the assembly leaves for the tail: the ordering (dropped blocks first) and the sizes; A = sc.work[0] (N x N), b = sc.work[1]
+struct MargSystem { int N = 0, m = 0, md = 0, n = 0; std::vector<int> pos, keep_ids; double us_pre[3] = {0, 0, 0}; bool prof = false; };
+// Everything of a marginalization up to the elimination of the dropped landmark blocks.  `done` = *out is final already (no prior / no factors / a prior that does not touch the
+// dropped pose): the caller returns the status as it is.
+static int marg_assemble_host(int device, hipStream_t stream, char* d_blob, double* d_ws, const DevWin& h, const uvs_window* w, const KOpts& ko,
+                              int flag, uvs_prior* out, std::string& err, EvalScratch& sc, MargSystem& ms, bool& done) {
+    done = true;
     const bool td_on = h.td_on != 0;
     const double eps = 1e-8;                           // marginalization_factor.h:70
     const int NFR = UVS_NF;
@@ -486,9 +499,17 @@ static int run_marginalize(int device, hipStream_t stream, char* d_blob, double*
         }
     }
     auto t3 = tnow();
-    double us_pre[3] = {0, 0, 0};
-    if (prof) { auto us = [](auto a_, auto b_) { return (double)std::chrono::duration_cast<std::chrono::nanoseconds>(b_ - a_).count() * 1e-3; }; us_pre[0] = us(t0, t1); us_pre[1] = us(t1, t2); us_pre[2] = us(t2, t3); }
-    return marg_finish(N, m, md, n, A, bv, pos, keep_ids, w, flag, out, sc, prof, us_pre);
+    if (prof) { auto us = [](auto a_, auto b_) { return (double)std::chrono::duration_cast<std::chrono::nanoseconds>(b_ - a_).count() * 1e-3; }; ms.us_pre[0] = us(t0, t1); ms.us_pre[1] = us(t1, t2); ms.us_pre[2] = us(t2, t3); }
+    ms.N = N; ms.m = m; ms.md = md; ms.n = n; ms.pos = pos; ms.keep_ids = keep_ids; ms.prof = prof;
+    done = false;
+    return UVS_OK;
+}
+static int run_marginalize(int device, hipStream_t stream, char* d_blob, double* d_ws, const DevWin& h, const uvs_window* w, const KOpts& ko,
+                           int flag, uvs_prior* out, std::string& err, EvalScratch& sc) {
+    MargSystem ms; bool done = false;
+    const int rc = marg_assemble_host(device, stream, d_blob, d_ws, h, w, ko, flag, out, err, sc, ms, done);
+    if (rc != UVS_OK || done) return rc;
+    return marg_finish(ms.N, ms.m, ms.md, ms.n, sc.work[0], sc.work[1], ms.pos, ms.keep_ids, w, flag, out, sc, ms.prof, ms.us_pre);
 }
 
 }  // namespace uvsdev

@@ -3066,8 +3066,7 @@ __global__ __launch_bounds__(NT) void k_solve(char* blobs, const long long* blob
 // out = [S lower packed (i >= j: i (i + 1) / 2 + j, padded indices) | g[176] | {cost, number of lanes with a landmark pivot <= 1e-8, 0...}[8]].
 // The host eliminates the 15 dofs of frame 0 from it and factors the rest (csrc/uvs_marg.h: marg_finish).
 static constexpr int MARG_OUT = UVS_RD * (UVS_RD + 1) / 2 + UVS_RD + 8;
-__global__ __launch_bounds__(NT) void k_marg_linearize(char* blob, double* ws, KOpts o, double* out) {
-    extern __shared__ __attribute__((aligned(16))) double sh[];
+UVS_DEV void marg_linearize_body(char* blob, double* ws, KOpts o, double* out, double* sh) {
     const int tid = lane_tid();
     Ctx c;
     c.hdr = (const DevWin*)blob; c.bd = (const double*)blob; c.bi = (const int*)blob; c.ws = ws; c.sh = sh; c.o = o; c.o.debug = 0;
@@ -3109,6 +3108,15 @@ __global__ __launch_bounds__(NT) void k_marg_linearize(char* blob, double* ws, K
     }
     if (tid < UVS_RD) out[UVS_RD * (UVS_RD + 1) / 2 + tid] = sh[L_G + tid];
     if (tid == 0) { double* sc = out + UVS_RD * (UVS_RD + 1) / 2 + UVS_RD; sc[0] = sh[L_CTRL + C_COST]; sc[1] = s4[0]; }
+}
+__global__ __launch_bounds__(NT) void k_marg_linearize(char* blob, double* ws, KOpts o, double* out) {
+    extern __shared__ __attribute__((aligned(16))) double sh[];
+    marg_linearize_body(blob, ws, o, out, sh);
+}
+// the same for a BATCH of sub-windows (uvs_marginalize_batch): one workgroup per window, blobs / workspaces through offset tables like k_solve, outputs MARG_OUT doubles apart
+__global__ __launch_bounds__(NT) void k_marg_linearize_batch(char* blobs, const long long* blob_off, double* ws_all, const long long* ws_off, KOpts o, double* out_all) {
+    extern __shared__ __attribute__((aligned(16))) double sh[];
+    marg_linearize_body(blobs + blob_off[blockIdx.x], ws_all + ws_off[blockIdx.x], o, out_all + (size_t)MARG_OUT * blockIdx.x, sh);
 }
 
 #endif

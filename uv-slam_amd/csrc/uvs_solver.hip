@@ -31,6 +31,7 @@
 #include "uvs_solve_kernel.h"
 #include "uvs_eval_kernel.h"
 #include "uvs_large_kernel.h"
+#include "uvs_marg_kernel.h"
 #include "uvs_marg.h"      // LAST: its file-scope `#pragma clang fp contract(...)` must not reach any device code (the kernels are built with the command-line default)
 
 using namespace uvsdev;
@@ -103,6 +104,8 @@ struct PackCache;
 static void free_pack_cache(PackCache* c);
 struct MargDevScratch;
 static void free_marg_scratch(MargDevScratch* m);
+struct MargBatchBuf;
+static void free_marg_batch(MargBatchBuf* m);
 struct uvs_solver {
     uvs_options opts;
     int device;
@@ -125,6 +128,7 @@ struct uvs_solver {
     std::vector<long long> blob_off, ws_off;
     std::vector<char> host_blobs;
     MargDevScratch* marg_dev = nullptr;   // buffers of the device marginalization (sub-window blob, its workspace, the reduced system)
+    struct MargBatchBuf* marg_batch = nullptr;      // ... and of uvs_marginalize_batch (allocated on first use)
     std::future<int> marg_job;            // uvs_marginalize_resident_begin(): the marginalization running on a worker thread; its result waits in marg_job_out
     uvs_prior marg_job_out;
     PackCache* pack_cache = nullptr;      // structure of the last large single window (allocated on first use)
@@ -259,8 +263,9 @@ int uvs_create(const uvs_options* opts, int device, int max_batch, int max_point
     { const char* e = std::getenv("UVS_LARGE_CHUNKS_NT"); s->large_chunks_nt = (e && std::atoi(e) == 256) ? 256 : 512; }
     { const char* e = std::getenv("UVS_LARGE_SOLVE_NT"); s->large_solve_nt = (e && std::atoi(e) == 256) ? 256 : 512; }      // A/B switch: 256 = the one-wave-per-SIMD instantiation of the persistent kernel
     // the LDS opt-in is a per-device function attribute: every handle sets it for its own device (the current one since hipSetDevice above)
-    for (const void* fn : {(const void*)k_solve, (const void*)k_evaluate, (const void*)k_large_chunks, (const void*)k_large_solve, (const void*)k_large_backsub})
+    for (const void* fn : {(const void*)k_solve, (const void*)k_evaluate, (const void*)k_large_chunks, (const void*)k_large_solve, (const void*)k_large_backsub, (const void*)k_marg_linearize, (const void*)k_marg_linearize_batch})
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES) != hipSuccess) { delete s; return UVS_ERR_HIP; }
+    if (hipFuncSetAttribute((const void*)uvsmarg::k_marg_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)uvsmarg::MF_LDS_BYTES) != hipSuccess) { delete s; return UVS_ERR_HIP; }
     *out = s;
     return UVS_OK;
 }
@@ -275,6 +280,7 @@ void uvs_destroy(uvs_solver* s) {
     if (!s->pool_borrowed) delete s->pool;
     s->pool = nullptr;
     free_marg_scratch(s->marg_dev); s->marg_dev = nullptr;
+    free_marg_batch(s->marg_batch); s->marg_batch = nullptr;
     (void)hipSetDevice(s->device);      // teardown: nothing useful to do with an error
     if (s->d_blobs) (void)hipFree(s->d_blobs);
     if (s->d_ws) (void)hipFree(s->d_ws);
@@ -1174,19 +1180,17 @@ static void free_marg_scratch(MargDevScratch* m) {
     if (m->h_out) (void)hipHostFree(m->h_out); if (m->h_up) (void)hipHostFree(m->h_up);
     delete m;
 }
-static int marginalize_old_device(uvs_solver* s, const uvs_window* w, uvs_prior* out) {
-    if (std::getenv("UVS_MARG_HOST")) return kMargFallback;      // (relocalization blocks are not marginalized, estimator.cpp:1002-1228: the sub-window simply leaves them out)
-    const bool prof = std::getenv("UVS_MARG_PROFILE") != nullptr;
-    const auto t0 = std::chrono::steady_clock::now();
-    if (!s->marg_dev) s->marg_dev = new MargDevScratch();
-    MargDevScratch& M = *s->marg_dev;
+// The sub-window of the factors MARGIN_OLD reads (estimator.cpp:1002-1135): the prior, the IMU link of frame 0, the observations of the points anchored in frame 0 and of the lines
+// that start there (without their anchor observation).  Its arrays live in M; used[] = the frame blocks (ids: pose f -> f ; speedbias f -> 11 + f ; ex -> 22 ; td -> 23) it touches.
+static int marg_build_sub(uvs_solver* s, const uvs_window* w, MargDevScratch& M, bool used[24], uvs_window& sub, std::string& err_) {
+    std::string& serr = err_;
+    for (int k = 0; k < 24; ++k) used[k] = false;
     const bool td_on = s->opts.estimate_td != 0;
     const int NFR = UVS_NF;
     // the sub-window below is cut out of the caller's arrays BEFORE pack_window sees them: same checks first
-    { const int rv = validate_window(w, s->err); if (rv != UVS_OK) return rv; }
-    if (td_on && w->n_point_obs > 0 && (!w->pt_vel_i || !w->pt_vel_j || !w->pt_td_i || !w->pt_td_j)) { s->err = "estimate_td needs pt_vel_i / pt_vel_j / pt_td_i / pt_td_j"; return UVS_ERR_INVALID_ARG; }
+    { const int rv = validate_window(w, serr); if (rv != UVS_OK) return rv; }
+    if (td_on && w->n_point_obs > 0 && (!w->pt_vel_i || !w->pt_vel_j || !w->pt_td_i || !w->pt_td_j)) { serr = "estimate_td needs pt_vel_i / pt_vel_j / pt_td_i / pt_td_j"; return UVS_ERR_INVALID_ARG; }
     // ---- the sub-window: which blocks it touches (ids: pose f -> f ; speedbias f -> 11 + f ; ex -> 22 ; td -> 23)
-    bool used[24] = {false};
     const bool have_prior = w->prior && w->prior->n > 0;
     if (have_prior) for (int b = 0; b < w->prior->n_blocks; ++b) {
         const uvs_prior& p = *w->prior;
@@ -1220,7 +1224,7 @@ static int marginalize_old_device(uvs_solver* s, const uvs_window* w, uvs_prior*
         used[fj] = true;
     }
     if (M.imu.empty() && M.pt_lm.empty() && M.ln_lm.empty() && !have_prior) return kMargFallback;
-    uvs_window sub; std::memset(&sub, 0, sizeof(sub));
+    std::memset(&sub, 0, sizeof(sub));
     std::memcpy(sub.pose, w->pose, sizeof(sub.pose)); std::memcpy(sub.speedbias, w->speedbias, sizeof(sub.speedbias)); std::memcpy(sub.ex_pose, w->ex_pose, sizeof(sub.ex_pose));
     sub.td = w->td; for (int q = 0; q < 7; ++q) sub.relo_pose[q] = q == 6 ? 1.0 : 0.0;
     sub.n_points = (int)M.invd.size(); sub.n_point_obs = (int)M.pt_lm.size(); sub.inv_depth = M.invd.data();
@@ -1229,6 +1233,29 @@ static int marginalize_old_device(uvs_solver* s, const uvs_window* w, uvs_prior*
     sub.n_lines = (int)(M.lorth.size() / 4); sub.n_line_obs = (int)M.ln_lm.size(); sub.line_orth = M.lorth.data();
     sub.ln_lm = M.ln_lm.data(); sub.ln_fj = M.ln_fj.data(); sub.ln_has_vp = M.ln_vpf.data(); sub.ln_sp = M.ln_sp.data(); sub.ln_ep = M.ln_ep.data(); sub.ln_vp = M.ln_vp.data();
     sub.n_imu = (int)M.imu.size(); sub.imu = M.imu.data(); sub.prior = have_prior ? w->prior : nullptr;
+    return UVS_OK;
+}
+// Ordering of the frame blocks of a device-linearized sub-window: the dropped ones (Pose[0], SpeedBias[0]) first, then the kept ones in id order.  map[i] = index of row i in
+// k_marg_linearize's padded reduced system (16 x frame + dof, the extrinsic / time-offset slots).
+static void marg_frame_order(const bool used[24], std::vector<int>& pos, std::vector<int>& keep_ids, int& md, int& n, std::vector<int>& map) {
+    const int NFR = UVS_NF;
+    auto lsize = [&](int id) { return id < NFR ? 6 : id < 2 * NFR ? 9 : id == 22 ? 6 : 1; };
+    auto pad = [&](int id, int q) { return id < NFR ? 16 * id + q : id < 2 * NFR ? 16 * (id - NFR) + 6 + q : id == 22 ? UVS_EX_INDEX(q) : UVS_TD_INDEX; };
+    pos.assign(24, -1); keep_ids.clear(); map.clear();
+    md = 0;
+    for (int id : {0, NFR}) if (used[id]) { pos[id] = md; md += lsize(id); for (int q = 0; q < lsize(id); ++q) map.push_back(pad(id, q)); }
+    int N = md;
+    for (int id = 0; id < 24; ++id) if (used[id] && id != 0 && id != NFR) { pos[id] = N; N += lsize(id); keep_ids.push_back(id); for (int q = 0; q < lsize(id); ++q) map.push_back(pad(id, q)); }
+    n = N - md;
+}
+static int marginalize_old_device(uvs_solver* s, const uvs_window* w, uvs_prior* out) {
+    if (std::getenv("UVS_MARG_HOST")) return kMargFallback;      // (relocalization blocks are not marginalized, estimator.cpp:1002-1228: the sub-window simply leaves them out)
+    const bool prof = std::getenv("UVS_MARG_PROFILE") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    if (!s->marg_dev) s->marg_dev = new MargDevScratch();
+    MargDevScratch& M = *s->marg_dev;
+    bool used[24]; uvs_window sub;
+    { const int rb = marg_build_sub(s, w, M, used, sub, s->err); if (rb != UVS_OK) return rb; }
     // ---- pack with a FREE extrinsic (the prior keeps para_Ex_Pose), upload, one linearization
     uvs_options o = s->opts; o.estimate_extrinsic = 1; o.initial_trust_region_radius = 1e300;
     DevWin h; M.blob.clear();
@@ -1258,28 +1285,17 @@ static int marginalize_old_device(uvs_solver* s, const uvs_window* w, uvs_prior*
     const double* S = (const double*)M.h_out; const double* g = S + UVS_RD * (UVS_RD + 1) / 2; const double* scal = g + UVS_RD;
     if (scal[1] != 0.0 || !std::isfinite(scal[0])) return kMargFallback;      // a landmark block the reference's eps cut would touch: the host path applies that cut
     // ---- ordering: the dropped frame blocks (Pose[0], SpeedBias[0]) first, then the kept ones in id order
-    auto lsize = [&](int id) { return id < NFR ? 6 : id < 2 * NFR ? 9 : id == 22 ? 6 : 1; };
-    auto pad = [&](int id, int q) { return id < NFR ? 16 * id + q : id < 2 * NFR ? 16 * (id - NFR) + 6 + q : id == 22 ? UVS_EX_INDEX(q) : UVS_TD_INDEX; };
-    std::vector<int> pos(24, -1), keep_ids;
-    int md = 0;
-    for (int id : {0, NFR}) if (used[id]) { pos[id] = md; md += lsize(id); }
-    int N = md;
-    for (int id = 0; id < 24; ++id) if (used[id] && id != 0 && id != NFR) { pos[id] = N; N += lsize(id); keep_ids.push_back(id); }
-    const int n = N - md;
+    std::vector<int> pos, keep_ids, map; int md = 0, n = 0;
+    marg_frame_order(used, pos, keep_ids, md, n, map);
+    const int N = md + n;
     if (n > UVS_MAX_PRIOR_DIM || (int)keep_ids.size() > UVS_MAX_PRIOR_BLOCKS) { s->err = "prior capacity"; return UVS_ERR_CAPACITY; }
     if (md == 0 || n == 0) return kMargFallback;
     std::vector<double>&A = s->eval_scratch.work[0], &bv = s->eval_scratch.work[1];
     A.assign((size_t)N * N, 0.0); bv.assign(N, 0.0);
-    for (int a = 0; a < 24; ++a) {
-        if (pos[a] < 0) continue;
-        for (int qa = 0; qa < lsize(a); ++qa) {
-            const int ia = pad(a, qa);
-            bv[pos[a] + qa] = g[ia];
-            for (int b = 0; b < 24; ++b) {
-                if (pos[b] < 0) continue;
-                for (int qb = 0; qb < lsize(b); ++qb) { const int ib = pad(b, qb); const int hi = ia >= ib ? ia : ib, lo = ia >= ib ? ib : ia; A[(size_t)(pos[a] + qa) * N + pos[b] + qb] = S[(size_t)hi * (hi + 1) / 2 + lo]; }
-            }
-        }
+    for (int i = 0; i < N; ++i) {
+        const int ia = map[i];
+        bv[i] = g[ia];
+        for (int j = 0; j < N; ++j) { const int ib = map[j]; const int hi = ia >= ib ? ia : ib, lo = ia >= ib ? ib : ia; A[(size_t)i * N + j] = S[(size_t)hi * (hi + 1) / 2 + lo]; }
     }
     double us_pre[3] = {(double)std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count() * 1e-3, 0.0, 0.0};
     const int rf = marg_finish(N, md, md, n, A, bv, pos, keep_ids, w, 0, out, s->eval_scratch, prof, us_pre);
@@ -1562,6 +1578,166 @@ int uvs_marginalize_wait(uvs_solver* s, uvs_prior* out) {
 }
 
 }  // extern "C"
+
+
+// ---------------------------------------------------------------- marginalization of a BATCH of windows (round 6, ABI v7)
+// Per window the same result as uvs_marginalize(), with everything that is O(n^3) on the device for all windows at once: the sub-windows of the MARGIN_OLD windows are packed by the
+// handle's packing threads and linearized by ONE launch (k_marg_linearize_batch: assembly + elimination of the dropped landmarks), the dropped frame block, the Schur complement and the
+// n x n eigen-decomposition of every window run in ONE launch of k_marg_finish (uvs_marg_kernel.h: parallel cyclic Jacobi).  MARGIN_SECOND_NEW windows send their prior-only system
+// (assembled on the packing threads) to the same kernel.  A window the device path does not take (a landmark or frame block the reference's eps cut would touch, a system larger than
+// the kernel's LDS layout, no factors at all) goes through uvs_marginalize() on the calling thread.
+struct MargBatchBuf {
+    char* h_stage = nullptr; size_t h_stage_cap = 0;      // pinned: blobs | tables | descriptors | dense systems
+    char* h_out = nullptr; size_t h_out_cap = 0;          // pinned: finish outputs | linearization scalars
+    char* d_blobs = nullptr; size_t d_blobs_cap = 0; double* d_ws = nullptr; size_t d_ws_cap = 0; double* d_lin = nullptr; size_t d_lin_cap = 0;
+    char* d_tab = nullptr; size_t d_tab_cap = 0; double* d_in = nullptr; size_t d_in_cap = 0; double* d_out = nullptr; size_t d_out_cap = 0;
+    std::vector<MargDevScratch> thread_sub; std::vector<EvalScratch> thread_eval;
+};
+static void free_marg_batch(MargBatchBuf* m) {
+    if (!m) return;
+    if (m->h_stage) (void)hipHostFree(m->h_stage); if (m->h_out) (void)hipHostFree(m->h_out);
+    for (void* p : {(void*)m->d_blobs, (void*)m->d_ws, (void*)m->d_lin, (void*)m->d_tab, (void*)m->d_in, (void*)m->d_out}) if (p) (void)hipFree(p);
+    delete m;
+}
+namespace {
+struct MargBatchItem {
+    int path = 3;      // 0: *out is final already; 1: device linearization + device finish (MARGIN_OLD); 2: device finish of a host-assembled system (MARGIN_SECOND_NEW); 3: uvs_marginalize()
+    int rc = UVS_OK; std::string err;
+    bool used[24]; std::vector<int> pos, keep_ids, map; int md = 0, n = 0;
+    std::vector<char> blob; DevWin h;
+    std::vector<double> dense;      // path 2: A [N][N] | b [N]
+};
+}
+extern "C" int uvs_marginalize_batch(uvs_solver* s, int n_win, const uvs_window* const* ws, const int* flags, uvs_prior* out, int* status) {
+    using namespace uvsmarg;
+    if (!s || n_win < 0 || (n_win > 0 && (!ws || !flags || !out))) return UVS_ERR_INVALID_ARG;
+    for (int b = 0; b < n_win; ++b) if (!ws[b] || (flags[b] != 0 && flags[b] != 1)) { s->err = "uvs_marginalize_batch: null window or flag outside {0, 1}"; return UVS_ERR_INVALID_ARG; }
+    if (s->marg_job.valid()) { s->err = "uvs_marginalize_batch: a marginalization begun with uvs_marginalize_resident_begin has not been waited for"; return UVS_ERR_INVALID_ARG; }
+    if (n_win == 0) return UVS_OK;
+    HIPCHK(s, hipSetDevice(s->device));
+    if (!s->marg_batch) s->marg_batch = new MargBatchBuf();
+    MargBatchBuf& B = *s->marg_batch;
+    int nthreads = 1;
+    if (n_win >= 4) {
+        const char* env = std::getenv("UVS_PACK_THREADS");
+        nthreads = env ? std::atoi(env) : (int)std::min<unsigned>(32u, std::max(1u, std::thread::hardware_concurrency() / 2));
+        nthreads = std::max(1, std::min(nthreads, n_win));
+    }
+    if ((int)B.thread_sub.size() < nthreads) { B.thread_sub.resize(nthreads); B.thread_eval.resize(nthreads); }
+    std::vector<MargBatchItem> items((size_t)n_win);
+    uvs_options o_sub = s->opts; o_sub.estimate_extrinsic = 1; o_sub.initial_trust_region_radius = 1e300;      // (as marginalize_old_device: the prior keeps para_Ex_Pose)
+    const bool host_only = std::getenv("UVS_MARG_HOST") != nullptr;
+    // ---- host stage, per window, on the packing threads
+    const auto job = [&](int t) {
+        for (int b = t; b < n_win; b += nthreads) {
+            MargBatchItem& it = items[b]; const uvs_window* w = ws[b];
+            it.path = 3;
+            if (host_only) continue;
+            if (flags[b] == 0) {
+                uvs_window sub;
+                const int rb = marg_build_sub(s, w, B.thread_sub[t], it.used, sub, it.err);
+                if (rb == kMargFallback) continue;
+                if (rb != UVS_OK) { it.rc = rb; it.path = 0; continue; }
+                const int rp = pack_window(&sub, o_sub, it.blob, it.h, it.err);
+                if (rp == UVS_ERR_UNSUPPORTED || rp == UVS_ERR_CAPACITY) continue;
+                if (rp != UVS_OK) { it.rc = rp; it.path = 0; continue; }
+                marg_frame_order(it.used, it.pos, it.keep_ids, it.md, it.n, it.map);
+                if (it.n > UVS_MAX_PRIOR_DIM || (int)it.keep_ids.size() > UVS_MAX_PRIOR_BLOCKS) { it.err = "prior capacity"; it.rc = UVS_ERR_CAPACITY; it.path = 0; continue; }
+                if (it.md == 0 || it.n == 0 || it.md > MF_MD || it.n > MF_NKEEP || it.md + it.n > MF_NMAX) continue;
+                it.path = 1;
+            } else {
+                { const int rv = validate_window(w, it.err); if (rv != UVS_OK) { it.rc = rv; it.path = 0; continue; } }
+                if (s->opts.estimate_td != 0 && w->n_point_obs > 0 && (!w->pt_vel_i || !w->pt_vel_j || !w->pt_td_i || !w->pt_td_j)) { it.err = "estimate_td needs pt_vel_i / pt_vel_j / pt_td_i / pt_td_j"; it.rc = UVS_ERR_INVALID_ARG; it.path = 0; continue; }
+                DevWin h; std::memset(&h, 0, sizeof(h)); h.td_on = s->opts.estimate_td != 0;
+                MargSystem ms; bool done = false;
+                EvalScratch& sc = B.thread_eval[t];
+                const int ra = marg_assemble_host(s->device, s->stream, nullptr, nullptr, h, w, make_kopts(s->opts, 0), 1, &out[b], it.err, sc, ms, done);
+                if (ra != UVS_OK || done) { it.rc = ra; it.path = 0; continue; }
+                if (ms.m != ms.md || ms.md > MF_MD || ms.n > MF_NKEEP || ms.N > MF_NMAX || ms.md == 0 || ms.n == 0) continue;      // (never for MARGIN_SECOND_NEW: it drops one pose and no landmark)
+                it.md = ms.md; it.n = ms.n; it.pos = ms.pos; it.keep_ids = ms.keep_ids;
+                it.dense.assign(sc.work[0].begin(), sc.work[0].begin() + (size_t)ms.N * ms.N);
+                it.dense.insert(it.dense.end(), sc.work[1].begin(), sc.work[1].begin() + ms.N);
+                it.path = 2;
+            }
+        }
+    };
+    if (nthreads > 1) { if (!s->pool) s->pool = new PackPool(); if (s->pool->ensure(nthreads)) s->pool->run(nthreads, job); else { const int nt_ = nthreads; nthreads = 1; job(0); nthreads = nt_; } }
+    else job(0);
+    // ---- device stage: finish slots = the path-1 windows (their linearization slots), then the path-2 windows
+    std::vector<int> slot_win; slot_win.reserve(n_win);
+    for (int b = 0; b < n_win; ++b) if (items[b].path == 1) slot_win.push_back(b);
+    const int n1 = (int)slot_win.size();
+    for (int b = 0; b < n_win; ++b) if (items[b].path == 2) slot_win.push_back(b);
+    const int nfin = (int)slot_win.size();
+    if (nfin > 0) {
+        // staging layout: [blobs (8-byte aligned each)] [blob_off n1][ws_off n1] [desc nfin x MF_DESC ints] [dense (nfin - n1) x MF_IN doubles]
+        std::vector<long long> blob_off(std::max(n1, 1)), ws_off(std::max(n1, 1));
+        size_t blob_total = 0; long long ws_total = 0;
+        for (int q = 0; q < n1; ++q) { const MargBatchItem& it = items[slot_win[q]]; blob_off[q] = (long long)blob_total; blob_total += (it.blob.size() + 255) & ~(size_t)255; ws_off[q] = ws_total; ws_total += it.h.ws_doubles; }
+        const size_t tab_bytes = (size_t)n1 * 16 + (size_t)nfin * MF_DESC * 4, dense_bytes = (size_t)(nfin - n1) * MF_IN * 8;
+        int rc;
+        if ((rc = ensure_pinned(s, &B.h_stage, &B.h_stage_cap, blob_total + tab_bytes + dense_bytes + 64)) != UVS_OK) return rc;
+        if ((rc = ensure_pinned(s, &B.h_out, &B.h_out_cap, (size_t)nfin * MF_OUT * 8 + (size_t)std::max(n1, 1) * 64)) != UVS_OK) return rc;
+        if ((rc = ensure(s, (void**)&B.d_blobs, &B.d_blobs_cap, std::max<size_t>(blob_total, 256))) != UVS_OK) return rc;
+        if ((rc = ensure(s, (void**)&B.d_ws, &B.d_ws_cap, std::max<size_t>((size_t)ws_total * 8, 256))) != UVS_OK) return rc;
+        if ((rc = ensure(s, (void**)&B.d_lin, &B.d_lin_cap, (size_t)std::max(n1, 1) * MARG_OUT * 8)) != UVS_OK) return rc;
+        if ((rc = ensure(s, (void**)&B.d_tab, &B.d_tab_cap, tab_bytes + 64)) != UVS_OK) return rc;
+        if ((rc = ensure(s, (void**)&B.d_in, &B.d_in_cap, std::max<size_t>(dense_bytes, 256))) != UVS_OK) return rc;
+        if ((rc = ensure(s, (void**)&B.d_out, &B.d_out_cap, (size_t)nfin * MF_OUT * 8)) != UVS_OK) return rc;
+        HIPCHK(s, hipStreamSynchronize(s->stream));      // the staging buffer may still feed an earlier call's copies
+        char* hb = B.h_stage; char* ht = hb + blob_total; char* hd = ht + ((tab_bytes + 7) & ~(size_t)7);
+        for (int q = 0; q < n1; ++q) { const MargBatchItem& it = items[slot_win[q]]; std::memcpy(hb + blob_off[q], it.blob.data(), it.blob.size()); }
+        long long* t_off = (long long*)ht; int* t_desc = (int*)(ht + (size_t)n1 * 16);
+        for (int q = 0; q < n1; ++q) { t_off[q] = blob_off[q]; t_off[n1 + q] = ws_off[q]; }
+        for (int q = 0; q < nfin; ++q) {
+            const MargBatchItem& it = items[slot_win[q]]; int* d = t_desc + (size_t)q * MF_DESC;
+            std::memset(d, 0, MF_DESC * 4);
+            d[0] = it.md + it.n; d[1] = it.md; d[2] = it.n; d[3] = q < n1 ? 0 : 1;
+            if (q < n1) for (int i = 0; i < it.md + it.n; ++i) d[4 + i] = it.map[i];
+            else std::memcpy(hd + (size_t)(q - n1) * MF_IN * 8, it.dense.data(), it.dense.size() * 8);
+        }
+        if (n1 > 0) HIPCHK(s, hipMemcpyAsync(B.d_blobs, hb, blob_total, hipMemcpyHostToDevice, s->stream));
+        HIPCHK(s, hipMemcpyAsync(B.d_tab, ht, tab_bytes, hipMemcpyHostToDevice, s->stream));
+        if (nfin > n1) HIPCHK(s, hipMemcpyAsync(B.d_in, hd, dense_bytes, hipMemcpyHostToDevice, s->stream));
+        const KOpts ko = make_kopts(o_sub, 0);
+        if (n1 > 0) {
+            hipLaunchKernelGGL(k_marg_linearize_batch, dim3(n1), dim3(NT), LDS_BYTES, s->stream, B.d_blobs, (const long long*)B.d_tab, B.d_ws, (const long long*)B.d_tab + n1, ko, B.d_lin);
+            HIPCHK(s, hipGetLastError());
+        }
+        // (path-2 slots read their dense system at slot - n1: the pointer is shifted so that the kernel's `in_all + MF_IN * blockIdx.x` lands there)
+        hipLaunchKernelGGL(k_marg_finish, dim3(nfin), dim3(MF_NT), MF_LDS_BYTES, s->stream, (const int*)(B.d_tab + (size_t)n1 * 16), (const double*)B.d_in - (size_t)n1 * MF_IN, (const double*)B.d_lin, (int)MARG_OUT,
+                           (int)UVS_RD, B.d_out, 1e-8);
+        HIPCHK(s, hipGetLastError());
+        HIPCHK(s, hipMemcpyAsync(B.h_out, B.d_out, (size_t)nfin * MF_OUT * 8, hipMemcpyDeviceToHost, s->stream));
+        double* h_scal = (double*)(B.h_out + (size_t)nfin * MF_OUT * 8);
+        if (n1 > 0) HIPCHK(s, hipMemcpy2DAsync(h_scal, 64, B.d_lin + (MARG_OUT - 8), (size_t)MARG_OUT * 8, 64, (size_t)n1, hipMemcpyDeviceToHost, s->stream));
+        HIPCHK(s, hipStreamSynchronize(s->stream));
+        for (int q = 0; q < nfin; ++q) {
+            const int b = slot_win[q]; MargBatchItem& it = items[b];
+            const double* fo = (const double*)B.h_out + (size_t)q * MF_OUT;
+            const int st = (int)fo[MF_OUT_S];
+            if (q < n1 && (h_scal[8 * q + 1] != 0.0 || !std::isfinite(h_scal[8 * q]))) { it.path = 3; continue; }      // a landmark block the reference's eps cut would touch: the host path applies that cut
+            if (st == MF_NONFINITE) { it.rc = UVS_ERR_NUMERIC; it.err = "marginalization: the linearized system is not finite"; it.path = 0; continue; }
+            if (st != MF_OK) { it.path = 3; continue; }
+            uvs_prior* po = &out[b];
+            std::memset(po, 0, sizeof(*po));
+            po->n = it.n;
+            std::memcpy(po->linearized_jacobians, fo, (size_t)it.n * it.n * 8);
+            std::memcpy(po->linearized_residuals, fo + MF_OUT_R, (size_t)it.n * 8);
+            marg_fill_blocks(po, it.pos, it.keep_ids, it.md, ws[b], flags[b]);
+            it.path = 0;
+        }
+    }
+    // ---- the windows the device path did not take
+    int first_bad = UVS_OK;
+    for (int b = 0; b < n_win; ++b) {
+        MargBatchItem& it = items[b];
+        if (it.path == 3) { it.rc = uvs_marginalize(s, ws[b], flags[b], &out[b]); if (it.rc != UVS_OK) it.err = s->err; }
+        if (status) status[b] = it.rc;
+        if (it.rc != UVS_OK && first_bad == UVS_OK) { first_bad = it.rc; s->err = it.err; }
+    }
+    return first_bad;
+}
 
 // ------------------------------------------------------------------ large single window (configs[3]), optionally multi-GPU
 // Step-wise so that the caller can all-reduce the two device vectors between steps (RCCL through torch.distributed in
