@@ -16,9 +16,9 @@
 
 namespace uvsmarg {
 
-static constexpr int MF_NT = 512;
+static constexpr int MF_NT = 1024;          // sixteen waves: a rotation step is three barriers plus n / 2 pairs dealt over the waves (1024 against 512 threads: 3.3 -> see DESIGN.md)
 static constexpr int MF_NMAX = 96;            // N = md + n the device path takes (the reference's largest: 15 + 76 = 91)
-static constexpr int MF_NKEEP = 80;           // n it takes
+static constexpr int MF_NKEEP = 80;           // n it takes (<= 128: a row is two lane-strides long)
 static constexpr int MF_LDA = MF_NMAX + 1;    // odd row strides: a column walk touches every LDS bank
 static constexpr int MF_LDV = MF_NKEEP + 1;
 static constexpr int MF_MD = 15;
@@ -30,13 +30,13 @@ static constexpr int MF_OUT = UVS_MAX_PRIOR_DIM * UVS_MAX_PRIOR_DIM + UVS_MAX_PR
 static constexpr int MF_OUT_R = UVS_MAX_PRIOR_DIM * UVS_MAX_PRIOR_DIM, MF_OUT_S = MF_OUT_R + UVS_MAX_PRIOR_DIM;
 enum { MF_OK = 0, MF_IRREGULAR = 1, MF_NONFINITE = 2, MF_UNCONVERGED = 3 };      // status[0]; status[1] = sweeps, status[2] = rotations, status[3] = eigenvalues cut
 static constexpr int MF_NP = MF_NKEEP / 2 + 1;   // rotations of a step
-static constexpr size_t MF_LDS_DOUBLES = (size_t)MF_NMAX * MF_LDA + (size_t)MF_NKEEP * MF_LDV + (size_t)MF_MD * (MF_NKEEP + 2) + 4 * MF_NMAX + 7 * MF_NP + 16;
+static constexpr size_t MF_LDS_DOUBLES = (size_t)MF_NMAX * MF_LDA + (size_t)MF_NKEEP * MF_LDV + (size_t)MF_MD * (MF_NKEEP + 2) + 4 * MF_NMAX + 7 * MF_NP + 16;      // (the last 16: control words, 8 doubles used)
 static constexpr size_t MF_LDS_BYTES = MF_LDS_DOUBLES * 8;
 
 __global__ __launch_bounds__(MF_NT) void k_marg_finish(const int* __restrict__ desc_all, const double* __restrict__ in_all, const double* __restrict__ lin_all, int lin_stride,
                                                        int tri_n, double* __restrict__ out_all, double eps) {
     extern __shared__ __attribute__((aligned(16))) double sh[];
-    const int tid = threadIdx.x, b = blockIdx.x;
+    const int tid = threadIdx.x, b = blockIdx.x, wv = tid >> 6, lane = tid & 63;
     const int* desc = desc_all + (size_t)MF_DESC * b;
     const int N = desc[0], md = desc[1], n = desc[2], mode = desc[3];
     double* out = out_all + (size_t)MF_OUT * b;
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(MF_NT) void k_marg_finish(const int* __restrict__ d
     double* rc = Ld + MF_NMAX;                             // per pair: c, s, t, apq, app, aqq
     int* pq = (int*)(rc + 6 * MF_NP);                      // per pair: p, q
     int* ictl = (int*)(rc + 7 * MF_NP);                    // [0] rotations of the sweep, [1] bad flag, [2] total rotations, [3] irregular, [4] eigenvalues cut
-    if (tid < 8) ictl[tid] = 0;
+    if (tid < 16) ictl[tid] = 0;
     if (N < 1 || N > MF_NMAX || n < 1 || n > MF_NKEEP || md < 0 || md > MF_MD || md + n != N) {      // (the host sends such a window down its own path; never reached through the ABI)
         if (tid == 0) { out[MF_OUT_S] = (double)MF_IRREGULAR; out[MF_OUT_S + 1] = 0; out[MF_OUT_S + 2] = 0; out[MF_OUT_S + 3] = 0; }
         return;
@@ -145,50 +145,67 @@ __global__ __launch_bounds__(MF_NT) void k_marg_finish(const int* __restrict__ d
     const int np = ne / 2;
     int sweeps = 0; bool converged = false;
     for (int sweep = 0; sweep < 40 && !converged; ++sweep) {
-        if (tid == 0) ictl[0] = 0;
+        if (tid == 0) { ictl[0] = 0; ictl[6] = 0; }
         __syncthreads();
         for (int step = 0; step < ne - 1; ++step) {
             // pair i of this step (circle method): i = 0: (ne - 1, step); i > 0: ((step + i) mod (ne - 1), (step + ne - 1 - i) mod (ne - 1))
+            if (tid == 64) ictl[6 + ((step + 1) & 1)] = 0;      // the NEXT step's "some pair rotates" flag (nobody reads it before that step's first barrier; this step's was cleared a step ago)
             if (tid < np) {
                 int p = tid == 0 ? ne - 1 : (step + tid) % (ne - 1), q = tid == 0 ? step : (step + ne - 1 - tid) % (ne - 1);
                 if (p > q) { const int t_ = p; p = q; q = t_; }
                 double c = 1.0, s = 0.0, t = 0.0, apq = 0.0, app = 0.0, aqq = 0.0;
                 if (q < n) {
                     apq = A[p * MF_LDA + q]; app = A[p * MF_LDA + p]; aqq = A[q * MF_LDA + q];
-                    if (apq != 0.0 && !(fabs(apq) <= 1.1e-16 * sqrt(fabs(app * aqq)))) {
+                    // (a pair INSIDE the subspace the eps cut discards -- both diagonal entries and the coupling a thousand times under eps, so both eigenvalues of the 2 x 2 block
+                    // are -- is left alone: its rotation would only mix two rows of V^T that leave as zero rows of J0; without this rule the relative criterion keeps such pairs,
+                    // whose entries are round-off of a matrix of norm 1e8..1e14, rotating for another 6 - 8 sweeps)
+                    const bool in_cut = fabs(app) <= 1e-3 * eps && fabs(aqq) <= 1e-3 * eps && fabs(apq) <= 1e-3 * eps;
+                    if (apq != 0.0 && !in_cut && !(fabs(apq) <= 1.1e-16 * sqrt(fabs(app * aqq)))) {
                         const double tau = (aqq - app) / (2.0 * apq);
                         t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
                         c = 1.0 / sqrt(1.0 + t * t); s = t * c;
-                        atomicAdd(&ictl[0], 1);
+                        atomicAdd(&ictl[0], 1); ictl[6 + (step & 1)] = 1;
                     } else apq = 0.0;      // (no rotation: the pair's 2 x 2 block stays as it is, exactly)
                 }
                 double* r = rc + 6 * tid; r[0] = c; r[1] = s; r[2] = t; r[3] = apq; r[4] = app; r[5] = aqq;
                 pq[2 * tid] = p; pq[2 * tid + 1] = q;
             }
             __syncthreads();
-            // rows p, q of A and of V^T
-            for (int e = tid; e < np * 2 * n; e += MF_NT) {
-                const int i = e / (2 * n), k2 = e - i * 2 * n;
+            if (ictl[6 + (step & 1)] == 0) continue;      // nothing rotates in this step (the late sweeps): no passes, no barriers -- the same decision in every thread
+            // rows p, q of A and of V^T: wave w takes the pairs w, w + 16, ...; its lanes run along the rows (unit stride: conflict-free), all four loads of an iteration in flight
+            // before the first store.  The rotation parameters are wave-uniform (every lane reads the same LDS words: a broadcast).
+            for (int i = wv; i < np; i += MF_NT / 64) {
                 const double* r = rc + 6 * i;
                 if (r[3] == 0.0) continue;
+                const double c = r[0], sn = r[1];
                 const int p = pq[2 * i], q = pq[2 * i + 1];
-                const bool isv = k2 >= n; const int k = isv ? k2 - n : k2;
-                double* Mp = isv ? Vt + p * MF_LDV + k : A + p * MF_LDA + k; double* Mq = isv ? Vt + q * MF_LDV + k : A + q * MF_LDA + k;
-                const double a = *Mp, bq = *Mq;
-                *Mp = r[0] * a - r[1] * bq; *Mq = r[1] * a + r[0] * bq;
+                double* Ap = A + p * MF_LDA; double* Aq = A + q * MF_LDA; double* Vp = Vt + p * MF_LDV; double* Vq = Vt + q * MF_LDV;
+                const int k0 = lane, k1 = lane + 64;
+                const bool h1 = k1 < n;
+                if (k0 < n) {
+                    const double a0 = Ap[k0], b0 = Aq[k0], va0 = Vp[k0], vb0 = Vq[k0];
+                    const double a1 = h1 ? Ap[k1] : 0.0, b1 = h1 ? Aq[k1] : 0.0, va1 = h1 ? Vp[k1] : 0.0, vb1 = h1 ? Vq[k1] : 0.0;
+                    Ap[k0] = c * a0 - sn * b0; Aq[k0] = sn * a0 + c * b0; Vp[k0] = c * va0 - sn * vb0; Vq[k0] = sn * va0 + c * vb0;
+                    if (h1) { Ap[k1] = c * a1 - sn * b1; Aq[k1] = sn * a1 + c * b1; Vp[k1] = c * va1 - sn * vb1; Vq[k1] = sn * va1 + c * vb1; }
+                }
             }
             __syncthreads();
             // columns p, q of A (rows k outside the pair), and the pair's 2 x 2 block in closed form
-            for (int e = tid; e < np * n; e += MF_NT) {
-                const int i = e / n, k = e - i * n;
+            for (int i = wv; i < np; i += MF_NT / 64) {
                 const double* r = rc + 6 * i;
                 if (r[3] == 0.0) continue;
+                const double c = r[0], sn = r[1];
                 const int p = pq[2 * i], q = pq[2 * i + 1];
-                if (k == p) { A[p * MF_LDA + p] = r[4] - r[2] * r[3]; A[p * MF_LDA + q] = 0.0; continue; }
-                if (k == q) { A[q * MF_LDA + q] = r[5] + r[2] * r[3]; A[q * MF_LDA + p] = 0.0; continue; }
-                double* Mk = A + k * MF_LDA;
-                const double a = Mk[p], bq = Mk[q];
-                Mk[p] = r[0] * a - r[1] * bq; Mk[q] = r[1] * a + r[0] * bq;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int k = lane + 64 * u;
+                    if (k >= n) continue;
+                    double* Mk = A + k * MF_LDA;
+                    if (k == p) { Mk[p] = r[4] - r[2] * r[3]; Mk[q] = 0.0; continue; }
+                    if (k == q) { Mk[q] = r[5] + r[2] * r[3]; Mk[p] = 0.0; continue; }
+                    const double a = Mk[p], bq = Mk[q];
+                    Mk[p] = c * a - sn * bq; Mk[q] = sn * a + c * bq;
+                }
             }
             __syncthreads();
         }

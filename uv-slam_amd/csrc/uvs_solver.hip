@@ -1617,6 +1617,9 @@ extern "C" int uvs_marginalize_batch(uvs_solver* s, int n_win, const uvs_window*
     HIPCHK(s, hipSetDevice(s->device));
     if (!s->marg_batch) s->marg_batch = new MargBatchBuf();
     MargBatchBuf& B = *s->marg_batch;
+    const bool prof = std::getenv("UVS_MARG_PROFILE") != nullptr;
+    const auto tb0 = std::chrono::steady_clock::now();
+    auto tb1 = tb0, tb2 = tb0, tb3 = tb0;
     int nthreads = 1;
     if (n_win >= 4) {
         const char* env = std::getenv("UVS_PACK_THREADS");
@@ -1663,12 +1666,14 @@ extern "C" int uvs_marginalize_batch(uvs_solver* s, int n_win, const uvs_window*
     };
     if (nthreads > 1) { if (!s->pool) s->pool = new PackPool(); if (s->pool->ensure(nthreads)) s->pool->run(nthreads, job); else { const int nt_ = nthreads; nthreads = 1; job(0); nthreads = nt_; } }
     else job(0);
+    tb1 = std::chrono::steady_clock::now();
     // ---- device stage: finish slots = the path-1 windows (their linearization slots), then the path-2 windows
     std::vector<int> slot_win; slot_win.reserve(n_win);
     for (int b = 0; b < n_win; ++b) if (items[b].path == 1) slot_win.push_back(b);
     const int n1 = (int)slot_win.size();
     for (int b = 0; b < n_win; ++b) if (items[b].path == 2) slot_win.push_back(b);
     const int nfin = (int)slot_win.size();
+    const int n1_prof = n1, nfin_prof = nfin;
     if (nfin > 0) {
         // staging layout: [blobs (8-byte aligned each)] [blob_off n1][ws_off n1] [desc nfin x MF_DESC ints] [dense (nfin - n1) x MF_IN doubles]
         std::vector<long long> blob_off(std::max(n1, 1)), ws_off(std::max(n1, 1));
@@ -1711,7 +1716,11 @@ extern "C" int uvs_marginalize_batch(uvs_solver* s, int n_win, const uvs_window*
         HIPCHK(s, hipMemcpyAsync(B.h_out, B.d_out, (size_t)nfin * MF_OUT * 8, hipMemcpyDeviceToHost, s->stream));
         double* h_scal = (double*)(B.h_out + (size_t)nfin * MF_OUT * 8);
         if (n1 > 0) HIPCHK(s, hipMemcpy2DAsync(h_scal, 64, B.d_lin + (MARG_OUT - 8), (size_t)MARG_OUT * 8, 64, (size_t)n1, hipMemcpyDeviceToHost, s->stream));
+        tb2 = std::chrono::steady_clock::now();
         HIPCHK(s, hipStreamSynchronize(s->stream));
+        tb3 = std::chrono::steady_clock::now();
+        if (prof) { double sw = 0, rot = 0, cut = 0; for (int q = 0; q < nfin; ++q) { const double* fo = (const double*)B.h_out + (size_t)q * MF_OUT; sw += fo[MF_OUT_S + 1]; rot += fo[MF_OUT_S + 2]; cut += fo[MF_OUT_S + 3]; }
+                    std::fprintf(stderr, "[uvs_marginalize_batch] k_marg_finish: %.1f Jacobi sweeps, %.0f rotations, %.1f eigenvalues cut per window (mean over %d)\n", sw / nfin, rot / nfin, cut / nfin, nfin); }
         for (int q = 0; q < nfin; ++q) {
             const int b = slot_win[q]; MargBatchItem& it = items[b];
             const double* fo = (const double*)B.h_out + (size_t)q * MF_OUT;
@@ -1735,6 +1744,12 @@ extern "C" int uvs_marginalize_batch(uvs_solver* s, int n_win, const uvs_window*
         if (it.path == 3) { it.rc = uvs_marginalize(s, ws[b], flags[b], &out[b]); if (it.rc != UVS_OK) it.err = s->err; }
         if (status) status[b] = it.rc;
         if (it.rc != UVS_OK && first_bad == UVS_OK) { first_bad = it.rc; s->err = it.err; }
+    }
+    if (prof) {
+        auto us = [](auto a_, auto b_) { return (double)std::chrono::duration_cast<std::chrono::nanoseconds>(b_ - a_).count() * 1e-3; };
+        int n_fb = 0; for (int b = 0; b < n_win; ++b) n_fb += items[b].path == 3 ? 1 : 0;
+        std::fprintf(stderr, "[uvs_marginalize_batch] %d windows on %d threads: host stage (sub-windows, packing, prior-only systems) %.0f us, staging + enqueue %.0f us, device (copies, k_marg_linearize_batch x %d, k_marg_finish x %d) %.0f us, priors + one-window fallbacks (%d) %.0f us\n",
+                     n_win, nthreads, us(tb0, tb1), us(tb1, tb2), us(tb2, tb3), n1_prof, nfin_prof, n_fb, us(tb3, std::chrono::steady_clock::now()));
     }
     return first_bad;
 }
