@@ -493,6 +493,29 @@ def main():
                 replay["prefix_vs_oracle_backend"] = {"windows": m, "ate_hip_m": seqm.ate(r["P"][:m], Pt), "ate_oracle_m": seqm.ate(ro["P"], Pt),
                                                       "max_dP_m": float(np.linalg.norm(r["P"][:m] - ro["P"], axis=1).max()),
                                                       "same_marginalization_flags": bool(np.array_equal(r["flag"][:m], ro["flag"]))}
+        # the marginalization that follows every solve of a replay, for the WHOLE batch in one call (uvs_marginalize_batch, ABI v7): the post-solve windows of the timed batch
+        marg_batch = None
+        if world == 1 and not args.no_prior and not args.no_replay:
+            import ctypes as C
+            post = [w.with_state(st) for w, st in zip(windows, states)]
+            keeps = [w.to_c() for w in post]
+            n = len(post)
+            arr = (C.POINTER(abi.WindowC) * n)(*[C.pointer(k[0]) for k in keeps])
+            pri = (abi.Prior * n)(); stc = (C.c_int * n)()
+            L = uvs.api.lib(); L.uvs_marginalize_batch.restype = C.c_int
+            marg_batch = {"windows": n}
+            for flag, name in ((0, "margin_old"), (1, "margin_second_new")):
+                fl = (C.c_int * n)(*([flag] * n))
+                ts = []
+                for _ in range(4):
+                    t1 = time.perf_counter(); rc = L.uvs_marginalize_batch(solver._h, n, arr, fl, pri, stc); ts.append(time.perf_counter() - t1)
+                t1 = time.perf_counter()
+                for k in range(16): L.uvs_marginalize(solver._h, C.byref(keeps[k][0]), flag, C.byref(pri[k]))
+                one = (time.perf_counter() - t1) / 16
+                marg_batch[name] = {"batch_call_ms": float(np.median(ts[1:])) * 1e3, "us_per_window": float(np.median(ts[1:])) / n * 1e6, "status": int(rc),
+                                    "one_window_call_ms": one * 1e3}
+            marg_batch["note"] = ("C-ABI call times. One launch linearizes the sub-windows of all MARGIN_OLD windows (k_marg_linearize_batch), one launch eliminates every window's dropped frame block "
+                                  "and factors its n x n Schur complement (k_marg_finish: parallel cyclic Jacobi, csrc/uvs_marg_kernel.h); the one-window call finishes on a host core")
         out = {
             "metric": "sliding-window solves/sec (10 KF, 150 pts, 40 lines, 3 VP)", "value": value, "unit": "solves/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -504,7 +527,7 @@ def main():
             "lm_iterations_mean": float(its.mean()), "lm_successful_steps_mean": float(np.mean([r.num_successful for r in reps])), "final_cost_mean": float(np.mean([r.final_cost for r in reps])),
             "batch_pack_upload_ms": pack_upload_ms, "value_end_to_end": (end_to_end or {}).get("solves_per_s"), "end_to_end": end_to_end,
             "single_window": single, "single_window_ms": sw_ms, "single_window_solves_per_s": 1e3 / sw_ms, "single_window_pcie_inclusive_ms": pcie * 1e3,
-            "replay": replay, "large_window": large, "roofline": roofline, "cpu_baseline": cpu,
+            "replay": replay, "marginalization_batch": marg_batch, "large_window": large, "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
     solver.close()

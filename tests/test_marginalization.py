@@ -143,3 +143,44 @@ def test_batched_marginalization_equals_the_one_window_call(gpu_api, oracle):
         assert np.abs(H - Ar).max() / np.abs(Ar).max() < 5e-7 and np.abs(b - br).max() / np.abs(br).max() < 1e-8
     print("batched marginalization of %d windows vs one-window calls: H %.1e, b %.1e; vs oracle: H %.1e, b %.1e; cost constant %.1e (relative)" % (len(wins), *worst))
     s.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("td,ex", [(1, 0), (0, 1), (1, 1)])
+def test_batched_marginalization_with_time_offset_and_free_extrinsic(gpu_api, td, ex):
+    """uvs_marginalize_batch under ESTIMATE_TD / ESTIMATE_EXTRINSIC (the time-offset and extrinsic blocks are KEPT blocks of the prior: n = 76 with td), windows with
+    relocalization blocks (not marginalized: the sub-window leaves them out) and a window without a prior in the same batch: block tables and x0 bit for bit, information
+    form to rounding against the one-window call."""
+    o = abi.default_options(); o.estimate_td = td; o.estimate_extrinsic = ex
+    s = gpu_api.Solver(opts=o, max_batch=2)
+    marg = lambda win, flag: s.marginalize(win, flag)
+    wins, flags = [], []
+    for index, with_prior, relo in [(80, True, False), (81, True, True), (82, False, False), (83, True, False)]:
+        w = synth.make_window(index, with_prior=with_prior, marginalize_fn=marg)
+        if td: w = synth.add_time_offset(w)
+        if relo: w = synth.add_relocalization(w, relo_frame=4, fraction=0.5, seed=index)
+        st, _ = s.solve(w)
+        ws_ = w.with_state(st)
+        wins.append(ws_); flags.append(0)
+        if with_prior: wins.append(ws_); flags.append(1)
+    single = [s.marginalize(w, f) for w, f in zip(wins, flags)]
+    batch, status = s.marginalize_batch(wins, flags)
+    assert status == [0] * len(wins)
+    for k, (p1, pb) in enumerate(zip(single, batch)):
+        assert pb.n == p1.n and pb.n_blocks == p1.n_blocks and p1.n >= 69, k
+        nb = p1.n_blocks
+        for fld in ("block_kind", "block_frame", "block_size", "block_idx", "x0_off"):
+            assert list(getattr(pb, fld)[:nb]) == list(getattr(p1, fld)[:nb]), (k, fld)
+        assert np.array_equal(np.asarray(pb.x0[:9 * nb]), np.asarray(p1.x0[:9 * nb]))
+        if td: assert abi.UVS_BLOCK_TD in list(pb.block_kind[:nb])
+        Hb, H1 = pb.J0().T @ pb.J0(), p1.J0().T @ p1.J0()
+        bb, b1 = pb.J0().T @ pb.r0(), p1.J0().T @ p1.r0()
+        assert np.abs(Hb - H1).max() <= 1e-7 * np.abs(H1).max() and np.abs(bb - b1).max() <= 1e-6 * max(1.0, np.abs(b1).max()), k
+    # errors of one window do not take the others down: the per-window status says which one
+    bad = wins[0].copy(); bad.pt_lm = bad.pt_lm[::-1].copy()
+    with pytest.raises(RuntimeError):
+        s.marginalize_batch([wins[1], bad], [0, 0])
+    pri, st = s.marginalize_batch([wins[1], bad, wins[0]], [flags[1], 0, 0], check=False)
+    assert st[0] == 0 and st[1] == abi.UVS_ERR_INVALID_ARG and st[2] == 0
+    assert np.array_equal(np.asarray(pri[0].J0()), np.asarray(batch[1].J0())) and np.array_equal(np.asarray(pri[2].J0()), np.asarray(batch[0].J0()))      # (and the batch is reproducible bit for bit)
+    s.close()

@@ -274,8 +274,9 @@ class Solver:
         self._check(fn(self._h, C.byref(wc), flag, C.byref(p)))
         return p
 
-    def marginalize_batch(self, windows, flags):
-        """uvs_marginalize_batch: the marginalization of independent windows with the cubic work of all of them in two launches; returns (priors, per-window status codes)."""
+    def marginalize_batch(self, windows, flags, check=True):
+        """uvs_marginalize_batch: the marginalization of independent windows with the cubic work of all of them in two launches; returns (priors, per-window status codes).
+        check=False: a failing window does not raise -- its status code says so, the other windows' priors are valid."""
         n = len(windows)
         keeps = [w.to_c() for w in windows]
         arr = (C.POINTER(abi.WindowC) * n)(*[C.pointer(k[0]) for k in keeps])
@@ -285,7 +286,7 @@ class Solver:
         L = lib()
         L.uvs_marginalize_batch.restype = C.c_int
         rc = L.uvs_marginalize_batch(self._h, n, arr, fl, pri, st)
-        self._check(rc)
+        if check: self._check(rc)
         return [pri[i] for i in range(n)], list(st)
 
     def marginalize_begin(self, w: abi.Window, flag=0):
