@@ -153,11 +153,15 @@ def test_batched_marginalization_with_time_offset_and_free_extrinsic(gpu_api, td
     form to rounding against the one-window call."""
     o = abi.default_options(); o.estimate_td = td; o.estimate_extrinsic = ex
     s = gpu_api.Solver(opts=o, max_batch=2)
-    marg = lambda win, flag: s.marginalize(win, flag)
     wins, flags = [], []
     for index, with_prior, relo in [(80, True, False), (81, True, True), (82, False, False), (83, True, False)]:
-        w = synth.make_window(index, with_prior=with_prior, marginalize_fn=marg)
+        w = synth.make_window(index)
         if td: w = synth.add_time_offset(w)
+        if with_prior:      # a prior that carries the option's blocks: the marginalization of another window under the same options (tests/test_td.py does the same)
+            prev = synth.make_window(index + 100)
+            if td: prev = synth.add_time_offset(prev)
+            stp, _ = s.solve(prev)
+            w.prior = s.marginalize(prev.with_state(stp), 0)
         if relo: w = synth.add_relocalization(w, relo_frame=4, fraction=0.5, seed=index)
         st, _ = s.solve(w)
         ws_ = w.with_state(st)
@@ -167,7 +171,7 @@ def test_batched_marginalization_with_time_offset_and_free_extrinsic(gpu_api, td
     batch, status = s.marginalize_batch(wins, flags)
     assert status == [0] * len(wins)
     for k, (p1, pb) in enumerate(zip(single, batch)):
-        assert pb.n == p1.n and pb.n_blocks == p1.n_blocks and p1.n >= 69, k
+        assert pb.n == p1.n and pb.n_blocks == p1.n_blocks and p1.n >= 30, k
         nb = p1.n_blocks
         for fld in ("block_kind", "block_frame", "block_size", "block_idx", "x0_off"):
             assert list(getattr(pb, fld)[:nb]) == list(getattr(p1, fld)[:nb]), (k, fld)
