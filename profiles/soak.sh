@@ -8,6 +8,8 @@ mkdir -p gpurun_out
  echo "== gpu_soak_relo.py with ESTIMATE_TD"; python tests/gpu_soak_relo.py 150 33000 td 2>&1 | tail -2
  echo "== gpu_soak_relo.py with ESTIMATE_EXTRINSIC"; python tests/gpu_soak_relo.py 150 34000 ex 2>&1 | tail -2
  echo "== gpu_soak_relo.py with ESTIMATE_TD + ESTIMATE_EXTRINSIC"; python tests/gpu_soak_relo.py 150 35000 tdex 2>&1 | tail -2
+ echo "== gpu_soak_relo.py with ESTIMATE_EXTRINSIC, fused multi-workgroup loop (relo_Pose as a second-level block of k_large_solve)"; python tests/gpu_soak_relo.py 150 36000 ex fused 2>&1 | tail -2
+ echo "== gpu_soak_relo.py with ESTIMATE_TD + ESTIMATE_EXTRINSIC, fused multi-workgroup loop"; python tests/gpu_soak_relo.py 150 37000 tdex fused 2>&1 | tail -2
  echo "== gpu_soak_options.py"; python tests/gpu_soak_options.py 2>&1 | tail -5
  echo "== gpu_soak_more.py"; python tests/gpu_soak_more.py 2>&1 | tail -4
  echo "== gpu_soak_replay.py"; python tests/gpu_soak_replay.py 2>&1 | tail -5

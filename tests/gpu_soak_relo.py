@@ -1,5 +1,5 @@
 """Randomised parity soak of the relocalization blocks (run by hand on the GPU box): random windows (shape, noise, prior) with a random
-relocalization frame / match fraction / pose offset / match noise, HIP library vs oracle.   python tests/gpu_soak_relo.py [N] [seed0] [td|ex|tdex]
+relocalization frame / match fraction / pose offset / match noise, HIP library vs oracle.   python tests/gpu_soak_relo.py [N] [seed0] [td|ex|tdex|-] [persistent|fused]
 (third argument: every window also estimates the camera / IMU time offset (ESTIMATE_TD), the extrinsic (ESTIMATE_EXTRINSIC: relo_Pose is then a second-level
 block of the persistent kernel), or both)"""
 import sys, os, time
@@ -11,6 +11,7 @@ from oracle_binding import Oracle
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 31000
 mode = sys.argv[3] if len(sys.argv) > 3 else ""
+form = sys.argv[4] if len(sys.argv) > 4 else "persistent"      # "fused": the multi-workgroup fused loop (uvs_large_solve_fused; with ex: relo_Pose as a second-level block of k_large_solve, round 6)
 with_td = "td" in mode; with_ex = "ex" in mode
 opts = abi.default_options(); opts.estimate_td = 1 if with_td else 0; opts.estimate_extrinsic = 1 if with_ex else 0
 o = Oracle(); s = uvs.api.Solver(opts=opts, max_batch=2, max_points=400, max_point_obs=4800, max_lines=120, max_line_obs=1320)
@@ -32,7 +33,9 @@ for i in range(N):
         print("gen failed", i, kw, e); continue
     if len(w.relo_lm) == 0: continue
     done += 1
-    sg, rg = s.solve(w); so, ro = o.solve(w, opts=opts)
+    if form == "fused": sg, rg, _ = s.large_solve_fused(w)
+    else: sg, rg = s.solve(w)
+    so, ro = o.solve(w, opts=opts)
     same = rg.num_iterations == ro.num_iterations and list(rg.accepted[:rg.num_iterations + 1]) == list(ro.accepted[:ro.num_iterations + 1]) and rg.termination == ro.termination
     dp, dq = pose_deltas(sg.pose, so.pose)
     dc = abs(rg.final_cost - ro.final_cost) / max(ro.final_cost, 1e-300)
@@ -44,5 +47,5 @@ for i in range(N):
         for k, v in (("dp", dp), ("dq", dq), ("cost", dc), ("invd", di), ("relo_p", rp), ("relo_q", rq)): worst[k] = max(worst[k], v)
     if same and (dp > 1e-6 or rp > 1e-6):
         print("LARGE", i, kw, rk, prior, "n_relo %d dp %.2e relo %.2e %.2e" % (len(w.relo_lm), dp, rp, rq))
-print("%d relocalization windows%s in %.1f s; identical LM trace in %d; worst over those: %s" % (done, (" with ESTIMATE_TD" if with_td else "") + (" with ESTIMATE_EXTRINSIC" if with_ex else ""), time.time() - t0, done - len(mism), {k: "%.2e" % v for k, v in worst.items()}))
+print("%d relocalization windows%s (%s form) in %.1f s; identical LM trace in %d; worst over those: %s" % (done, (" with ESTIMATE_TD" if with_td else "") + (" with ESTIMATE_EXTRINSIC" if with_ex else ""), form, time.time() - t0, done - len(mism), {k: "%.2e" % v for k, v in worst.items()}))
 for m in mism[:20]: print("TRACE DIFF", m)
