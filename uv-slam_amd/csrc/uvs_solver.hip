@@ -1272,16 +1272,20 @@ static int marginalize_old_device(uvs_solver* s, const uvs_window* w, uvs_prior*
     if (!M.h_out) { HIPCHK(s, hipHostMalloc((void**)&M.h_out, MARG_OUT * 8, hipHostMallocDefault)); M.h_out_cap = MARG_OUT * 8; }
     if ((rc = ensure_pinned(s, &M.h_up, &M.h_up_cap, M.blob.size())) != UVS_OK) return rc;
     HIPCHK(s, hipStreamSynchronize(s->stream));      // the staging buffer may still feed the previous call's copy
+    const auto tq0 = std::chrono::steady_clock::now();
     std::memcpy(M.h_up, M.blob.data(), M.blob.size());
+    const auto tq1 = std::chrono::steady_clock::now();
     HIPCHK(s, hipMemcpyAsync(M.d_blob, M.h_up, M.blob.size(), hipMemcpyHostToDevice, s->stream));
     const KOpts ko = make_kopts(o, 0);
     hipLaunchKernelGGL(k_marg_linearize, dim3(1), dim3(NT), LDS_BYTES, s->stream, M.d_blob, M.d_ws, ko, M.d_out);
     HIPCHK(s, hipGetLastError());
     HIPCHK(s, hipMemcpyAsync(M.h_out, M.d_out, MARG_OUT * 8, hipMemcpyDeviceToHost, s->stream));
+    const auto tq2 = std::chrono::steady_clock::now();
     HIPCHK(s, hipStreamSynchronize(s->stream));
     const auto t1 = std::chrono::steady_clock::now();
     if (prof) { auto us = [](auto a_, auto b_) { return (double)std::chrono::duration_cast<std::chrono::nanoseconds>(b_ - a_).count() * 1e-3; };
-                std::fprintf(stderr, "[uvs_marginalize] device path: sub-window %.0f us, pack %.0f us (%zu bytes), upload + kernel + download %.0f us\n", us(t0, tp0), us(tp0, tp1), M.blob.size(), us(tp1, t1)); }
+                std::fprintf(stderr, "[uvs_marginalize] device path: sub-window %.0f us, pack %.0f us (%zu bytes), upload + kernel + download %.0f us (allocations + drain %.0f, copy into pinned %.0f, three enqueues %.0f, wait %.0f)\n",
+                             us(t0, tp0), us(tp0, tp1), M.blob.size(), us(tp1, t1), us(tp1, tq0), us(tq0, tq1), us(tq1, tq2), us(tq2, t1)); }
     const double* S = (const double*)M.h_out; const double* g = S + UVS_RD * (UVS_RD + 1) / 2; const double* scal = g + UVS_RD;
     if (scal[1] != 0.0 || !std::isfinite(scal[0])) return kMargFallback;      // a landmark block the reference's eps cut would touch: the host path applies that cut
     // ---- ordering: the dropped frame blocks (Pose[0], SpeedBias[0]) first, then the kept ones in id order
