@@ -339,7 +339,8 @@ int uvs_marginalize_wait(uvs_solver *s, uvs_prior *out);
  * (J0 = sqrt(S) V^T, r0 = sqrt(S^-1) V^T b with the eps = 1e-8 cut, :278-291; a parallel cyclic Jacobi per window, csrc/uvs_marg_kernel.h).  MARGIN_SECOND_NEW windows (flag 1)
  * read their old prior only and join the second launch.  Host work per window (sub-window packing, the block tables) runs on the handle's packing threads.  status (may be NULL)
  * receives the per-window code; the return value is the first one that is not UVS_OK.  A window the device path does not take (a landmark or frame block the reference's eps cut
- * would touch, N = dropped + kept frame dofs > 96) is sent through uvs_marginalize().  What a batched closed-loop replay calls between two uvs_batch_solve(). */
+ * would touch, N = dropped + kept frame dofs > 96) is sent through uvs_marginalize() -- which, like every one-window call, may replace the handle's resident batch.  Synchronous; not
+ * to be called while a uvs_marginalize_resident_begin() is in flight.  What a batched closed-loop replay calls between two uvs_batch_solve(). */
 int uvs_marginalize_batch(uvs_solver *s, int n, const uvs_window *const *ws, const int *flags, uvs_prior *out, int *status);
 
 /* ---- ONE large window spread over the GPU and, with an all-reduce between the steps, over several GPUs (BASELINE configs[3]) ----

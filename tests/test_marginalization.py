@@ -188,3 +188,31 @@ def test_batched_marginalization_with_time_offset_and_free_extrinsic(gpu_api, td
     assert st[0] == 0 and st[1] == abi.UVS_ERR_INVALID_ARG and st[2] == 0
     assert np.array_equal(np.asarray(pri[0].J0()), np.asarray(batch[1].J0())) and np.array_equal(np.asarray(pri[2].J0()), np.asarray(batch[0].J0()))      # (and the batch is reproducible bit for bit)
     s.close()
+
+
+@pytest.mark.gpu
+def test_batched_marginalization_argument_errors(gpu_api):
+    """Misuse of uvs_marginalize_batch is an error code, never a crash: an empty batch is fine, null arrays / a null window / a flag outside {0, 1} are UVS_ERR_INVALID_ARG with a message,
+    and a marginalization begun with uvs_marginalize_resident_begin must be waited for first."""
+    import ctypes as C
+    s = gpu_api.Solver(max_batch=2)
+    L = gpu_api.lib(); L.uvs_marginalize_batch.restype = C.c_int
+    assert L.uvs_marginalize_batch(s._h, 0, None, None, None, None) == abi.UVS_OK
+    w = synth.make_window(75)
+    st, _ = s.solve(w); ws_ = w.with_state(st)
+    wc, keep = ws_.to_c()
+    arr = (C.POINTER(abi.WindowC) * 2)(C.pointer(wc), None)
+    pri = (abi.Prior * 2)(); stc = (C.c_int * 2)()
+    assert L.uvs_marginalize_batch(s._h, 2, arr, (C.c_int * 2)(0, 0), pri, stc) == abi.UVS_ERR_INVALID_ARG                 # a null window
+    arr[1] = C.pointer(wc)
+    assert L.uvs_marginalize_batch(s._h, 2, arr, (C.c_int * 2)(0, 2), pri, stc) == abi.UVS_ERR_INVALID_ARG                 # a flag that is neither MARGIN_OLD nor MARGIN_SECOND_NEW
+    assert b"flag" in L.uvs_last_error(s._h)
+    assert L.uvs_marginalize_batch(s._h, 2, None, (C.c_int * 2)(0, 0), pri, stc) == abi.UVS_ERR_INVALID_ARG
+    assert L.uvs_marginalize_batch(s._h, 2, arr, (C.c_int * 2)(0, 0), None, stc) == abi.UVS_ERR_INVALID_ARG
+    assert L.uvs_marginalize_batch(None, 2, arr, (C.c_int * 2)(0, 0), pri, stc) == abi.UVS_ERR_INVALID_ARG
+    s.solve(w); s.marginalize_begin(ws_, 0)
+    assert L.uvs_marginalize_batch(s._h, 2, arr, (C.c_int * 2)(0, 0), pri, stc) == abi.UVS_ERR_INVALID_ARG                 # the worker thread owns the handle until the wait
+    s.marginalize_wait()
+    assert L.uvs_marginalize_batch(s._h, 2, arr, (C.c_int * 2)(0, 0), pri, None) == abi.UVS_OK and pri[0].n == pri[1].n > 0  # status may be NULL
+    assert np.array_equal(np.asarray(pri[0].J0()), np.asarray(pri[1].J0()))
+    s.close()
