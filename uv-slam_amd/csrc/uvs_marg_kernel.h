@@ -26,8 +26,8 @@ static constexpr int MF_MD = 15;
 static constexpr int MF_DESC = 128;           // {N, md, n, mode, map[N]}: mode 0 = rows gathered from a packed lower triangle + gradient (k_marg_linearize's output; map = padded index of row i),
                                               //                             mode 1 = dense A [N][N] row-major followed by b [N]
 static constexpr int MF_IN = MF_NMAX * MF_NMAX + MF_NMAX;
-static constexpr int MF_OUT = UVS_MAX_PRIOR_DIM * UVS_MAX_PRIOR_DIM + UVS_MAX_PRIOR_DIM + 8;      // J0 [n][n] (leading dimension n) | r0 [n] at MF_OUT_R | status words at MF_OUT_S
-static constexpr int MF_OUT_R = UVS_MAX_PRIOR_DIM * UVS_MAX_PRIOR_DIM, MF_OUT_S = MF_OUT_R + UVS_MAX_PRIOR_DIM;
+static constexpr int MF_OUT = UVS_MAX_PRIOR_DIM * UVS_MAX_PRIOR_DIM + UVS_MAX_PRIOR_DIM + 8;      // status words at MF_OUT_S | r0 [n] at MF_OUT_R | J0 [n][n] (leading dimension n) at MF_OUT_J:
+static constexpr int MF_OUT_S = 0, MF_OUT_R = 8, MF_OUT_J = 8 + UVS_MAX_PRIOR_DIM;                 // the used part of a slot is its HEAD (104 + n^2 doubles): the host copies only that much of every slot
 enum { MF_OK = 0, MF_IRREGULAR = 1, MF_NONFINITE = 2, MF_UNCONVERGED = 3 };      // status[0]; status[1] = sweeps, status[2] = rotations, status[3] = eigenvalues cut
 static constexpr int MF_NP = MF_NKEEP / 2 + 1;   // rotations of a step
 static constexpr size_t MF_LDS_DOUBLES = (size_t)MF_NMAX * MF_LDA + (size_t)MF_NKEEP * MF_LDV + (size_t)MF_MD * (MF_NKEEP + 2) + 4 * MF_NMAX + 7 * MF_NP + 16;      // (the last 16: control words, 8 doubles used)
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(MF_NT) void k_marg_finish(const int* __restrict__ d
     for (int e = tid; e < n * n; e += MF_NT) {
         const int k = e / n, j = e - k * n;
         const double l = lam[k]; const bool on = l > eps;
-        out[(size_t)((int)Ld[k]) * n + j] = on ? sqrt(l) * Vt[k * MF_LDV + j] : 0.0;
+        out[MF_OUT_J + (size_t)((int)Ld[k]) * n + j] = on ? sqrt(l) * Vt[k * MF_LDV + j] : 0.0;
     }
     if (tid < n) {
         const double l = lam[tid]; const bool on = l > eps;

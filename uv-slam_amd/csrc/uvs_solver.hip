@@ -1707,7 +1707,10 @@ extern "C" int uvs_marginalize_batch(uvs_solver* s, int n_win, const uvs_window*
         }
         if (n1 > 0) HIPCHK(s, hipMemcpyAsync(B.d_blobs, hb, blob_total, hipMemcpyHostToDevice, s->stream));
         HIPCHK(s, hipMemcpyAsync(B.d_tab, ht, tab_bytes, hipMemcpyHostToDevice, s->stream));
-        if (nfin > n1) HIPCHK(s, hipMemcpyAsync(B.d_in, hd, dense_bytes, hipMemcpyHostToDevice, s->stream));
+        if (nfin > n1) {      // (likewise only the used head N^2 + N of every dense input slot)
+            int N_max = 1; for (int q = n1; q < nfin; ++q) N_max = std::max(N_max, items[slot_win[q]].md + items[slot_win[q]].n);
+            HIPCHK(s, hipMemcpy2DAsync(B.d_in, (size_t)MF_IN * 8, hd, (size_t)MF_IN * 8, (size_t)(N_max * N_max + N_max) * 8, (size_t)(nfin - n1), hipMemcpyHostToDevice, s->stream));
+        }
         const KOpts ko = make_kopts(o_sub, 0);
         if (n1 > 0) {
             hipLaunchKernelGGL(k_marg_linearize_batch, dim3(n1), dim3(NT), LDS_BYTES, s->stream, B.d_blobs, (const long long*)B.d_tab, B.d_ws, (const long long*)B.d_tab + n1, ko, B.d_lin);
@@ -1717,7 +1720,9 @@ extern "C" int uvs_marginalize_batch(uvs_solver* s, int n_win, const uvs_window*
         hipLaunchKernelGGL(k_marg_finish, dim3(nfin), dim3(MF_NT), MF_LDS_BYTES, s->stream, (const int*)(B.d_tab + (size_t)n1 * 16), (const double*)B.d_in - (size_t)n1 * MF_IN, (const double*)B.d_lin, (int)MARG_OUT,
                            (int)UVS_RD, B.d_out, 1e-8);
         HIPCHK(s, hipGetLastError());
-        HIPCHK(s, hipMemcpyAsync(B.h_out, B.d_out, (size_t)nfin * MF_OUT * 8, hipMemcpyDeviceToHost, s->stream));
+        int n_max = 1; for (int q = 0; q < nfin; ++q) n_max = std::max(n_max, items[slot_win[q]].n);
+        // (only the used head of every output slot travels: status | r0 | J0 [n][n])
+        HIPCHK(s, hipMemcpy2DAsync(B.h_out, (size_t)MF_OUT * 8, B.d_out, (size_t)MF_OUT * 8, (size_t)(MF_OUT_J + n_max * n_max) * 8, (size_t)nfin, hipMemcpyDeviceToHost, s->stream));
         double* h_scal = (double*)(B.h_out + (size_t)nfin * MF_OUT * 8);
         if (n1 > 0) HIPCHK(s, hipMemcpy2DAsync(h_scal, 64, B.d_lin + (MARG_OUT - 8), (size_t)MARG_OUT * 8, 64, (size_t)n1, hipMemcpyDeviceToHost, s->stream));
         tb2 = std::chrono::steady_clock::now();
@@ -1735,7 +1740,7 @@ extern "C" int uvs_marginalize_batch(uvs_solver* s, int n_win, const uvs_window*
             uvs_prior* po = &out[b];
             std::memset(po, 0, sizeof(*po));
             po->n = it.n;
-            std::memcpy(po->linearized_jacobians, fo, (size_t)it.n * it.n * 8);
+            std::memcpy(po->linearized_jacobians, fo + MF_OUT_J, (size_t)it.n * it.n * 8);
             std::memcpy(po->linearized_residuals, fo + MF_OUT_R, (size_t)it.n * 8);
             marg_fill_blocks(po, it.pos, it.keep_ids, it.md, ws[b], flags[b]);
             it.path = 0;
