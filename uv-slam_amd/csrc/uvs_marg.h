@@ -9,8 +9,11 @@
 // through k_evaluate; the dense (m+n)^2 assembly, the Schur complement and the n x n factorisation run on the
 // host in this file, as they do in the reference (4 pthreads + Eigen).  The pseudo-inverse of A_mm is applied by
 // block elimination (see run_marginalize) and the factorisation J0 = sqrt(S) V^T by Householder + implicit QL;
-// UVS_MARG_PROFILE=1 prints the stage times.  A device-resident variant is future work; it is outside
-// the solves/s metric.
+// UVS_MARG_PROFILE=1 prints the stage times.  Since then: round 3 moved the assembly + landmark elimination of MARGIN_OLD to the
+// device (k_marg_linearize: the host path below is what a window falls back to), round 6 made MARGIN_SECOND_NEW host-only (no
+// device round trip: host_prior_residual) and added the BATCHED form whose back half runs on the device as well
+// (uvs_marg_kernel.h: k_marg_finish; uvs_marginalize_batch in uvs_solver.hip uses marg_assemble_host / marg_fill_blocks of this file).
+// For ONE window the host finish below (marg_finish: Cholesky of the frame block + Householder / QL) stays the faster one.
 //
 // Block order is deterministic (the reference's depends on pointer hashes, Appendix D6):
 // dropped = {Pose, SpeedBias, point landmarks, line landmarks}, kept = {Pose asc., SpeedBias asc., Ex_Pose}.
