@@ -305,3 +305,32 @@ def test_relo_blocks_in_the_multi_workgroup_forms(gpu_api, oracle, index, kw):
         assert pose_deltas(st.pose, so.pose)[0] < 1e-7 and np.abs(st.relo_pose - so.relo_pose).max() < 1e-7, name
         assert np.abs(st.inv_depth - so.inv_depth).max() < 1e-6, name
     assert np.abs(s2.relo_pose - w.relo_pose).max() > 1e-3      # relo_Pose did move
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("td", [0, 1])
+def test_relo_blocks_with_a_free_extrinsic_on_a_large_window(gpu_api, oracle, td):
+    """The second-level relo_Pose of the landmark-sharded forms (round 6) where its partial sums cross many chunks and persistent workgroups: 1 000 points with
+    ten-frame tracks and 300 lines, EVERY point matched in the loop-closure frame, ESTIMATE_EXTRINSIC (and ESTIMATE_TD) -- the 14 gather blocks of block row 13
+    accumulate over dozens of chunks into the tail of the partial rows, are summed by k_large_reduce and eliminated in k_large_solve.  Fused loop, step-wise loop
+    and the persistent kernel against the oracle: same LM trace, same states."""
+    kw = dict(n_points=1000, n_lines=300, n_tagged=200, pt_track=10, ln_track=10)
+    w = synth.add_relocalization(synth.make_window(78, **kw), relo_frame=9, fraction=1.0, pixel_sigma=0.5, seed=2)
+    if td: w = synth.add_time_offset(w)
+    assert len(w.relo_lm) >= 900
+    o = abi.default_options(); o.estimate_extrinsic = 1; o.estimate_td = td
+    s = gpu_api.Solver(opts=o, max_batch=2, max_points=1100, max_point_obs=12000, max_lines=320, max_line_obs=3400)
+    so, ro = oracle.solve(w, opts=o)
+    sf, rf, _ = s.large_solve_fused(w)
+    s1, r1 = s.large_solve(w)
+    s0, r0 = s.solve(w)
+    s.close()
+    for name, (st, rep) in {"fused": (sf, rf), "step-wise": (s1, r1), "persistent": (s0, r0)}.items():
+        assert rep.status == 0 and rep.num_iterations == ro.num_iterations, name
+        assert list(rep.accepted[: rep.num_iterations + 1]) == list(ro.accepted[: ro.num_iterations + 1]), name
+        dp, da = pose_deltas(st.pose, so.pose)
+        assert dp < 1e-6 and da < 1e-6, (name, dp, da)
+        assert np.abs(st.relo_pose[:3] - so.relo_pose[:3]).max() < 1e-6 and quat_angle(st.relo_pose[3:], so.relo_pose[3:]) < 1e-6, name
+        assert np.abs(st.ex_pose[:3] - so.ex_pose[:3]).max() < 1e-7 and quat_angle(st.ex_pose[3:], so.ex_pose[3:]) < 1e-6, name
+        assert np.abs(st.inv_depth - so.inv_depth).max() < 1e-6 and abs(rep.final_cost - ro.final_cost) <= 1e-6 * ro.final_cost, name
+    assert not np.array_equal(sf.relo_pose, w.relo_pose) and not np.array_equal(sf.ex_pose, w.ex_pose)
