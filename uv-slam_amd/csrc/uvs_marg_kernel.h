@@ -16,9 +16,9 @@
 
 namespace uvsmarg {
 
-static constexpr int MF_NT = 1024;          // sixteen waves: a rotation step is three barriers plus n / 2 pairs dealt over the waves (256 windows: 2.9 ms per launch against 3.7 ms with 512 threads)
+static constexpr int MF_NT = 640;           // ten waves = sixteen lanes for each of the <= 40 rotations of a step (MF_NKEEP / 2); a step is three barriers around them
 static constexpr int MF_NMAX = 96;            // N = md + n the device path takes (the reference's largest: 15 + 76 = 91)
-static constexpr int MF_NKEEP = 80;           // n it takes (<= 128: a row is two lane-strides long)
+static constexpr int MF_NKEEP = 80;           // n it takes
 static constexpr int MF_LDA = MF_NMAX + 1;    // odd row strides: a column walk touches every LDS bank
 static constexpr int MF_LDV = MF_NKEEP + 1;
 static constexpr int MF_MD = 15;
@@ -30,13 +30,18 @@ static constexpr int MF_OUT = UVS_MAX_PRIOR_DIM * UVS_MAX_PRIOR_DIM + UVS_MAX_PR
 static constexpr int MF_OUT_S = 0, MF_OUT_R = 8, MF_OUT_J = 8 + UVS_MAX_PRIOR_DIM;                 // the used part of a slot is its HEAD (104 + n^2 doubles): the host copies only that much of every slot
 enum { MF_OK = 0, MF_IRREGULAR = 1, MF_NONFINITE = 2, MF_UNCONVERGED = 3 };      // status[0]; status[1] = sweeps, status[2] = rotations, status[3] = eigenvalues cut
 static constexpr int MF_NP = MF_NKEEP / 2 + 1;   // rotations of a step
+static constexpr int MF_RS = (MF_NKEEP + 15) / 16;   // lane-strides of a row
+static_assert(16 * (MF_NKEEP / 2) <= MF_NT, "sixteen lanes per pair");
 static constexpr size_t MF_LDS_DOUBLES = (size_t)MF_NMAX * MF_LDA + (size_t)MF_NKEEP * MF_LDV + (size_t)MF_MD * (MF_NKEEP + 2) + 4 * MF_NMAX + 7 * MF_NP + 16;      // (the last 16: control words, 8 doubles used)
 static constexpr size_t MF_LDS_BYTES = MF_LDS_DOUBLES * 8;
 
+// 1 / x and 1 / sqrt(x) from the hardware seeds (v_rcp_f64 / v_rsq_f64, ~2^-26 relative) + two Newton steps (quadratic: 2^-52 after the first, the second absorbs the seed's worst case)
+__device__ __forceinline__ double mf_rcp(double x) { double y = __builtin_amdgcn_rcp(x); double e = fma(-x, y, 1.0); y = fma(y, e, y); e = fma(-x, y, 1.0); return fma(y, e, y); }
+__device__ __forceinline__ double mf_rsq(double x) { double y = __builtin_amdgcn_rsq(x); double e = fma(-x * y, y, 1.0); y = fma(0.5 * y, e, y); e = fma(-x * y, y, 1.0); return fma(0.5 * y, e, y); }
 __global__ __launch_bounds__(MF_NT) void k_marg_finish(const int* __restrict__ desc_all, const double* __restrict__ in_all, const double* __restrict__ lin_all, int lin_stride,
                                                        int tri_n, double* __restrict__ out_all, double eps) {
     extern __shared__ __attribute__((aligned(16))) double sh[];
-    const int tid = threadIdx.x, b = blockIdx.x, wv = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, b = blockIdx.x;
     const int* desc = desc_all + (size_t)MF_DESC * b;
     const int N = desc[0], md = desc[1], n = desc[2], mode = desc[3];
     double* out = out_all + (size_t)MF_OUT * b;
@@ -144,10 +149,12 @@ __global__ __launch_bounds__(MF_NT) void k_marg_finish(const int* __restrict__ d
     // ---- parallel cyclic Jacobi
     const int np = ne / 2;
     int sweeps = 0; bool converged = false;
+    long long cyc[3] = {0, 0, 0};      // shader-clock cycles of thread 0 in the three parts of the steps (status words 4 .. 6: rotation parameters, row pass, column pass)
     for (int sweep = 0; sweep < 40 && !converged; ++sweep) {
         if (tid == 0) { ictl[0] = 0; ictl[6] = 0; }
         __syncthreads();
         for (int step = 0; step < ne - 1; ++step) {
+            const long long tc0 = clock64();
             // pair i of this step (circle method): i = 0: (ne - 1, step); i > 0: ((step + i) mod (ne - 1), (step + ne - 1 - i) mod (ne - 1))
             if (tid == 64) ictl[6 + ((step + 1) & 1)] = 0;      // the NEXT step's "some pair rotates" flag (nobody reads it before that step's first barrier; this step's was cleared a step ago)
             if (tid < np) {
@@ -160,10 +167,14 @@ __global__ __launch_bounds__(MF_NT) void k_marg_finish(const int* __restrict__ d
                     // are -- is left alone: its rotation would only mix two rows of V^T that leave as zero rows of J0; without this rule the relative criterion keeps such pairs,
                     // whose entries are round-off of a matrix of norm 1e8..1e14, rotating for another 6 - 8 sweeps)
                     const bool in_cut = fabs(app) <= 1e-3 * eps && fabs(aqq) <= 1e-3 * eps && fabs(apq) <= 1e-3 * eps;
-                    if (apq != 0.0 && !in_cut && !(fabs(apq) <= 1.1e-16 * sqrt(fabs(app * aqq)))) {
-                        const double tau = (aqq - app) / (2.0 * apq);
-                        t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-                        c = 1.0 / sqrt(1.0 + t * t); s = t * c;
+                    // (this lane's arithmetic is the serial part of a step: the stopping rule is compared in squares -- no square root --, and the two divisions and two
+                    // square roots of the rotation use the hardware reciprocal / reciprocal-square-root seeds with two Newton steps each instead of the IEEE sequences:
+                    // c and s are orthonormal to 1e-16 either way, which is all a Jacobi rotation needs)
+                    if (apq != 0.0 && !in_cut && !(apq * apq <= 1.21e-32 * fabs(app * aqq))) {
+                        const double tau = (aqq - app) * mf_rcp(2.0 * apq);
+                        const double w1 = fma(tau, tau, 1.0);
+                        t = (tau >= 0.0 ? 1.0 : -1.0) * mf_rcp(fabs(tau) + w1 * mf_rsq(w1));
+                        c = mf_rsq(fma(t, t, 1.0)); s = t * c;
                         atomicAdd(&ictl[0], 1); ictl[6 + (step & 1)] = 1;
                     } else apq = 0.0;      // (no rotation: the pair's 2 x 2 block stays as it is, exactly)
                 }
@@ -171,43 +182,44 @@ __global__ __launch_bounds__(MF_NT) void k_marg_finish(const int* __restrict__ d
                 pq[2 * tid] = p; pq[2 * tid + 1] = q;
             }
             __syncthreads();
-            if (ictl[6 + (step & 1)] == 0) continue;      // nothing rotates in this step (the late sweeps): no passes, no barriers -- the same decision in every thread
-            // rows p, q of A and of V^T: wave w takes the pairs w, w + 16, ...; its lanes run along the rows (unit stride: conflict-free), all four loads of an iteration in flight
-            // before the first store.  The rotation parameters are wave-uniform (every lane reads the same LDS words: a broadcast).
-            for (int i = wv; i < np; i += MF_NT / 64) {
-                const double* r = rc + 6 * i;
-                if (r[3] == 0.0) continue;
-                const double c = r[0], sn = r[1];
-                const int p = pq[2 * i], q = pq[2 * i + 1];
+            const long long tc1 = clock64();
+            if (ictl[6 + (step & 1)] == 0) { cyc[0] += tc1 - tc0; continue; }      // nothing rotates in this step (the late sweeps): no passes, no barriers -- the same decision in every thread
+            // rows p, q of A and of V^T, then columns p, q of A: SIXTEEN lanes per pair (all n / 2 <= 40 pairs of the step at once on 640 threads; a row is five
+            // lane-strides long), every load of a lane in flight before its first store.  The rotation parameters are read once per lane (a broadcast within the 16 lanes).
+            const int gi = tid >> 4, l16 = tid & 15;
+            const bool mine = gi < np && rc[6 * (gi < np ? gi : 0) + 3] != 0.0;
+            double c = 1.0, sn = 0.0; int p = 0, q = 0;
+            if (mine) { c = rc[6 * gi]; sn = rc[6 * gi + 1]; p = pq[2 * gi]; q = pq[2 * gi + 1]; }
+            if (mine) {
                 double* Ap = A + p * MF_LDA; double* Aq = A + q * MF_LDA; double* Vp = Vt + p * MF_LDV; double* Vq = Vt + q * MF_LDV;
-                const int k0 = lane, k1 = lane + 64;
-                const bool h1 = k1 < n;
-                if (k0 < n) {
-                    const double a0 = Ap[k0], b0 = Aq[k0], va0 = Vp[k0], vb0 = Vq[k0];
-                    const double a1 = h1 ? Ap[k1] : 0.0, b1 = h1 ? Aq[k1] : 0.0, va1 = h1 ? Vp[k1] : 0.0, vb1 = h1 ? Vq[k1] : 0.0;
-                    Ap[k0] = c * a0 - sn * b0; Aq[k0] = sn * a0 + c * b0; Vp[k0] = c * va0 - sn * vb0; Vq[k0] = sn * va0 + c * vb0;
-                    if (h1) { Ap[k1] = c * a1 - sn * b1; Aq[k1] = sn * a1 + c * b1; Vp[k1] = c * va1 - sn * vb1; Vq[k1] = sn * va1 + c * vb1; }
+                double a[MF_RS], bq[MF_RS], va[MF_RS], vb[MF_RS];
+#pragma unroll
+                for (int u = 0; u < MF_RS; ++u) { const int k = l16 + 16 * u; const bool in = k < n; a[u] = in ? Ap[k] : 0.0; bq[u] = in ? Aq[k] : 0.0; va[u] = in ? Vp[k] : 0.0; vb[u] = in ? Vq[k] : 0.0; }
+#pragma unroll
+                for (int u = 0; u < MF_RS; ++u) {
+                    const int k = l16 + 16 * u;
+                    if (k < n) { Ap[k] = c * a[u] - sn * bq[u]; Aq[k] = sn * a[u] + c * bq[u]; Vp[k] = c * va[u] - sn * vb[u]; Vq[k] = sn * va[u] + c * vb[u]; }
                 }
             }
             __syncthreads();
-            // columns p, q of A (rows k outside the pair), and the pair's 2 x 2 block in closed form
-            for (int i = wv; i < np; i += MF_NT / 64) {
-                const double* r = rc + 6 * i;
-                if (r[3] == 0.0) continue;
-                const double c = r[0], sn = r[1];
-                const int p = pq[2 * i], q = pq[2 * i + 1];
+            const long long tc2 = clock64();
+            if (mine) {      // columns p, q (rows k outside the pair), and the pair's 2 x 2 block in closed form
+                const double* r = rc + 6 * gi;
+                double a[MF_RS], bq[MF_RS];
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int k = lane + 64 * u;
+                for (int u = 0; u < MF_RS; ++u) { const int k = l16 + 16 * u; const bool in = k < n; a[u] = in ? A[k * MF_LDA + p] : 0.0; bq[u] = in ? A[k * MF_LDA + q] : 0.0; }
+#pragma unroll
+                for (int u = 0; u < MF_RS; ++u) {
+                    const int k = l16 + 16 * u;
                     if (k >= n) continue;
                     double* Mk = A + k * MF_LDA;
-                    if (k == p) { Mk[p] = r[4] - r[2] * r[3]; Mk[q] = 0.0; continue; }
-                    if (k == q) { Mk[q] = r[5] + r[2] * r[3]; Mk[p] = 0.0; continue; }
-                    const double a = Mk[p], bq = Mk[q];
-                    Mk[p] = c * a - sn * bq; Mk[q] = sn * a + c * bq;
+                    if (k == p) { Mk[p] = r[4] - r[2] * r[3]; Mk[q] = 0.0; }
+                    else if (k == q) { Mk[q] = r[5] + r[2] * r[3]; Mk[p] = 0.0; }
+                    else { Mk[p] = c * a[u] - sn * bq[u]; Mk[q] = sn * a[u] + c * bq[u]; }
                 }
             }
             __syncthreads();
+            { const long long tc3 = clock64(); cyc[0] += tc1 - tc0; cyc[1] += tc2 - tc1; cyc[2] += tc3 - tc2; }
         }
         ++sweeps;
         if (tid == 0) ictl[2] += ictl[0];
@@ -236,7 +248,8 @@ __global__ __launch_bounds__(MF_NT) void k_marg_finish(const int* __restrict__ d
         if (!on) atomicAdd(&ictl[4], 1);
     }
     __syncthreads();
-    if (tid == 0) { out[MF_OUT_S] = (double)(converged ? MF_OK : MF_UNCONVERGED); out[MF_OUT_S + 1] = (double)sweeps; out[MF_OUT_S + 2] = (double)ictl[2]; out[MF_OUT_S + 3] = (double)ictl[4]; }
+    if (tid == 0) { out[MF_OUT_S] = (double)(converged ? MF_OK : MF_UNCONVERGED); out[MF_OUT_S + 1] = (double)sweeps; out[MF_OUT_S + 2] = (double)ictl[2]; out[MF_OUT_S + 3] = (double)ictl[4];
+                    out[MF_OUT_S + 4] = (double)cyc[0]; out[MF_OUT_S + 5] = (double)cyc[1]; out[MF_OUT_S + 6] = (double)cyc[2]; }
 }
 
 }  // namespace uvsmarg
