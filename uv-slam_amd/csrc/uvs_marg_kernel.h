@@ -8,7 +8,7 @@
 // The eigen-decomposition is a PARALLEL cyclic Jacobi (round-robin ordering: n / 2 disjoint rotations per step, n - 1 steps per sweep) with the same rotation formulas and the
 // same RELATIVE stopping rule |a_pq| <= 1.1e-16 sqrt(|a_pp a_qq|) as the host's host_sym_eig_jacobi (uvs_marg.h:30-58): the matrices are graded over twenty orders of magnitude
 // and Jacobi resolves the small eigenvalues relative to their own scale.  For ONE window this is no faster than the host's tridiagonal QL (~0.3 ms against ~0.2 ms): a rotation step
-// is a workgroup barrier away from the next and there are ~700 of them.  For a BATCH it is what makes the marginalization scale with the solve: 256 windows take one launch instead
+// is two workgroup barriers and there are ~1 000 of them.  For a BATCH it is what makes the marginalization scale with the solve: 256 windows take one launch instead
 // of 256 x 0.2 ms on a host core (uvs_marginalize_batch).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -16,7 +16,7 @@
 
 namespace uvsmarg {
 
-static constexpr int MF_NT = 640;           // ten waves = sixteen lanes for each of the <= 40 rotations of a step (MF_NKEEP / 2); a step is three barriers around them
+static constexpr int MF_NT = 704, MF_CT = 640;           // ten compute waves = sixteen lanes for each of the <= 40 rotations of a step (MF_NKEEP / 2), threads >= MF_CT = the control wave (rotation parameters of the next step)
 static constexpr int MF_NMAX = 96;            // N = md + n the device path takes (the reference's largest: 15 + 76 = 91)
 static constexpr int MF_NKEEP = 80;           // n it takes
 static constexpr int MF_LDA = MF_NMAX + 1;    // odd row strides: a column walk touches every LDS bank
@@ -31,8 +31,9 @@ static constexpr int MF_OUT_S = 0, MF_OUT_R = 8, MF_OUT_J = 8 + UVS_MAX_PRIOR_DI
 enum { MF_OK = 0, MF_IRREGULAR = 1, MF_NONFINITE = 2, MF_UNCONVERGED = 3 };      // status[0]; status[1] = sweeps, status[2] = rotations, status[3] = eigenvalues cut
 static constexpr int MF_NP = MF_NKEEP / 2 + 1;   // rotations of a step
 static constexpr int MF_RS = (MF_NKEEP + 15) / 16;   // lane-strides of a row
-static_assert(16 * (MF_NKEEP / 2) <= MF_NT, "sixteen lanes per pair");
-static constexpr size_t MF_LDS_DOUBLES = (size_t)MF_NMAX * MF_LDA + (size_t)MF_NKEEP * MF_LDV + (size_t)MF_MD * (MF_NKEEP + 2) + 4 * MF_NMAX + 7 * MF_NP + 16;      // (the last 16: control words, 8 doubles used)
+static constexpr int MF_NBLK = ((MF_NKEEP / 2) * (MF_NKEEP / 2 + 1) / 2 + 1) & ~1;   // 2 x 2 blocks (i >= j) of a step's pairs
+static_assert(16 * (MF_NKEEP / 2) <= MF_CT && MF_CT % 64 == 0 && MF_NT - MF_CT >= MF_NKEEP / 2 + 1, "sixteen lanes per pair, the control wave holds a lane per pair");
+static constexpr size_t MF_LDS_DOUBLES = (size_t)MF_NMAX * MF_LDA + (size_t)MF_NKEEP * MF_LDV + (size_t)MF_MD * (MF_NKEEP + 2) + 4 * MF_NMAX + 14 * MF_NP + 16 + MF_NBLK / 2;      // (16: control words, 8 doubles used; then the block table of the A pass, one int per block)
 static constexpr size_t MF_LDS_BYTES = MF_LDS_DOUBLES * 8;
 
 // 1 / x and 1 / sqrt(x) from the hardware seeds (v_rcp_f64 / v_rsq_f64, ~2^-26 relative) + two Newton steps (quadratic: 2^-52 after the first, the second absorbs the seed's worst case)
@@ -52,9 +53,10 @@ __global__ __launch_bounds__(MF_NT) void k_marg_finish(const int* __restrict__ d
     double* br = bv + MF_NMAX;                             // [n]
     double* lam = br + MF_NMAX;                            // [n]
     double* Ld = lam + MF_NMAX;                            // scratch [MF_NMAX]: 1 / L_kk of the frame block; later the ranks (as doubles)
-    double* rc = Ld + MF_NMAX;                             // per pair: c, s, t, apq, app, aqq
-    int* pq = (int*)(rc + 6 * MF_NP);                      // per pair: p, q
-    int* ictl = (int*)(rc + 7 * MF_NP);                    // [0] rotations of the sweep, [1] bad flag, [2] total rotations, [3] irregular, [4] eigenvalues cut
+    double* rc = Ld + MF_NMAX;                             // two buffers of: per pair c, s, t, apq, app, aqq
+    int* pq = (int*)(rc + 12 * MF_NP);                     // two buffers of: per pair p, q
+    int* ictl = (int*)(rc + 14 * MF_NP);                   // [0] rotations of the sweep, [1] bad flag, [2] total rotations, [3] irregular, [4] eigenvalues cut
+    int* blk = (int*)(rc + 14 * MF_NP + 16);               // block t of the A pass: i | j << 8 (i >= j), filled once per window
     if (tid < 16) ictl[tid] = 0;
     if (N < 1 || N > MF_NMAX || n < 1 || n > MF_NKEEP || md < 0 || md > MF_MD || md + n != N) {      // (the host sends such a window down its own path; never reached through the ABI)
         if (tid == 0) { out[MF_OUT_S] = (double)MF_IRREGULAR; out[MF_OUT_S + 1] = 0; out[MF_OUT_S + 2] = 0; out[MF_OUT_S + 3] = 0; }
@@ -146,84 +148,101 @@ __global__ __launch_bounds__(MF_NT) void k_marg_finish(const int* __restrict__ d
     __syncthreads();
     for (int e = tid; e < n * n; e += MF_NT) { const int i = e / n, j = e - i * n; Vt[i * MF_LDV + j] = (i == j) ? 1.0 : 0.0; }
     __syncthreads();
-    // ---- parallel cyclic Jacobi
+    // ---- parallel cyclic Jacobi.  A step (n / 2 disjoint rotations J = prod J_i) is TWO workgroup barriers:
+    //   [A pass]  A <- J^T A J in ONE sweep over the 2 x 2 blocks of pairs: block (i, j) = rows {p_i, q_i} x columns {p_j, q_j} becomes R_i^T M R_j -- one load and one store per
+    //             entry of A (rows-then-columns would be two each, and the kernel is bound by LDS traffic); blocks i > j are computed and mirrored, the diagonal blocks are set in
+    //             closed form.  The n / 2 (n / 2 + 1) / 2 blocks are dealt evenly over the compute threads.
+    //   [V pass]  rows p_i, q_i of V^T rotate (sixteen lanes per pair), WHILE the control wave (threads >= MF_CT) computes the NEXT step's rotation parameters from the A the A pass
+    //             just finished (the V pass does not touch A): the serial FP64 chain of a rotation's c, s hides behind the V traffic.  Parameters are double-buffered.
     const int np = ne / 2;
     int sweeps = 0; bool converged = false;
-    long long cyc[3] = {0, 0, 0};      // shader-clock cycles of thread 0 in the three parts of the steps (status words 4 .. 6: rotation parameters, row pass, column pass)
+    long long cyc[3] = {0, 0, 0};      // shader-clock cycles of thread 0 (status words 4 .. 6): first parameters of a sweep, A pass, V pass (+ next parameters on the control wave)
+    const bool ctl_wave = tid >= MF_CT;
+    const int nblk = np * (np + 1) / 2;
+    for (int t = tid; t < nblk; t += MF_NT) { int i = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5); while ((i + 1) * (i + 2) / 2 <= t) ++i; while (i * (i + 1) / 2 > t) --i; blk[t] = i | ((t - i * (i + 1) / 2) << 8); }
+    const int gi = tid >> 4, l16 = tid & 15;      // (compute threads: row pair gi, lane l16 of its sixteen)
+    // rotation parameters of `step` into buffer `buf` (control wave; pair i of a step by the circle method: i = 0: (ne - 1, step); i > 0: ((step + i) mod (ne - 1), (step - i) mod (ne - 1)))
+    auto parameters = [&](int step, int buf) {
+        const int i = tid - MF_CT;
+        bool rot = false;
+        if (i < np) {
+            int p = i == 0 ? ne - 1 : (step + i) % (ne - 1), q = i == 0 ? step : (step + ne - 1 - i) % (ne - 1);
+            if (p > q) { const int t_ = p; p = q; q = t_; }
+            double c = 1.0, sn = 0.0, t = 0.0, apq = 0.0, app = 0.0, aqq = 0.0;
+            if (q < n) {
+                apq = A[p * MF_LDA + q]; app = A[p * MF_LDA + p]; aqq = A[q * MF_LDA + q];
+                // (a pair INSIDE the subspace the eps cut discards -- both diagonal entries and the coupling a thousand times under eps, so both eigenvalues of the 2 x 2 block
+                // are -- is left alone: its rotation would only mix two rows of V^T that leave as zero rows of J0; without this rule the relative criterion keeps such pairs,
+                // whose entries are round-off of a matrix of norm 1e8..1e14, rotating for another two sweeps)
+                const bool in_cut = fabs(app) <= 1e-3 * eps && fabs(aqq) <= 1e-3 * eps && fabs(apq) <= 1e-3 * eps;
+                // (the stopping rule |a_pq| <= 1.1e-16 sqrt(|a_pp a_qq|) compared in squares; the two divisions and two square roots of the rotation from the hardware
+                // reciprocal / reciprocal-square-root seeds with two Newton steps each: c and s are orthonormal to 1e-16 either way, which is all a Jacobi rotation needs)
+                if (apq != 0.0 && !in_cut && !(apq * apq <= 1.21e-32 * fabs(app * aqq))) {
+                    const double tau = (aqq - app) * mf_rcp(2.0 * apq);
+                    const double w1 = fma(tau, tau, 1.0);
+                    t = (tau >= 0.0 ? 1.0 : -1.0) * mf_rcp(fabs(tau) + w1 * mf_rsq(w1));
+                    c = mf_rsq(fma(t, t, 1.0)); sn = t * c;
+                    rot = true;
+                } else apq = 0.0;      // (no rotation: the pair's entries stay as they are, exactly)
+            }
+            double* r = rc + (size_t)buf * 6 * MF_NP + 6 * i; r[0] = c; r[1] = sn; r[2] = t; r[3] = apq; r[4] = app; r[5] = aqq;
+            pq[buf * 2 * MF_NP + 2 * i] = p; pq[buf * 2 * MF_NP + 2 * i + 1] = q;
+        }
+        const unsigned long long any = __ballot(rot);
+        if (tid == MF_CT) { const int cnt = __popcll(any); ictl[6 + buf] = cnt; ictl[0] += cnt; }
+    };
     for (int sweep = 0; sweep < 40 && !converged; ++sweep) {
-        if (tid == 0) { ictl[0] = 0; ictl[6] = 0; }
+        const long long ts0 = clock64();
+        if (tid == MF_CT) ictl[0] = 0;
+        if (ctl_wave) parameters(0, 0);
         __syncthreads();
+        cyc[0] += clock64() - ts0;
         for (int step = 0; step < ne - 1; ++step) {
+            const int buf = step & 1;
+            const double* rcb = rc + (size_t)buf * 6 * MF_NP; const int* pqb = pq + buf * 2 * MF_NP;
+            const bool active = ictl[6 + buf] != 0;      // some pair of this step rotates (the same word in every thread: written before the last barrier)
             const long long tc0 = clock64();
-            // pair i of this step (circle method): i = 0: (ne - 1, step); i > 0: ((step + i) mod (ne - 1), (step + ne - 1 - i) mod (ne - 1))
-            if (tid == 64) ictl[6 + ((step + 1) & 1)] = 0;      // the NEXT step's "some pair rotates" flag (nobody reads it before that step's first barrier; this step's was cleared a step ago)
-            if (tid < np) {
-                int p = tid == 0 ? ne - 1 : (step + tid) % (ne - 1), q = tid == 0 ? step : (step + ne - 1 - tid) % (ne - 1);
-                if (p > q) { const int t_ = p; p = q; q = t_; }
-                double c = 1.0, s = 0.0, t = 0.0, apq = 0.0, app = 0.0, aqq = 0.0;
-                if (q < n) {
-                    apq = A[p * MF_LDA + q]; app = A[p * MF_LDA + p]; aqq = A[q * MF_LDA + q];
-                    // (a pair INSIDE the subspace the eps cut discards -- both diagonal entries and the coupling a thousand times under eps, so both eigenvalues of the 2 x 2 block
-                    // are -- is left alone: its rotation would only mix two rows of V^T that leave as zero rows of J0; without this rule the relative criterion keeps such pairs,
-                    // whose entries are round-off of a matrix of norm 1e8..1e14, rotating for another 6 - 8 sweeps)
-                    const bool in_cut = fabs(app) <= 1e-3 * eps && fabs(aqq) <= 1e-3 * eps && fabs(apq) <= 1e-3 * eps;
-                    // (this lane's arithmetic is the serial part of a step: the stopping rule is compared in squares -- no square root --, and the two divisions and two
-                    // square roots of the rotation use the hardware reciprocal / reciprocal-square-root seeds with two Newton steps each instead of the IEEE sequences:
-                    // c and s are orthonormal to 1e-16 either way, which is all a Jacobi rotation needs)
-                    if (apq != 0.0 && !in_cut && !(apq * apq <= 1.21e-32 * fabs(app * aqq))) {
-                        const double tau = (aqq - app) * mf_rcp(2.0 * apq);
-                        const double w1 = fma(tau, tau, 1.0);
-                        t = (tau >= 0.0 ? 1.0 : -1.0) * mf_rcp(fabs(tau) + w1 * mf_rsq(w1));
-                        c = mf_rsq(fma(t, t, 1.0)); s = t * c;
-                        atomicAdd(&ictl[0], 1); ictl[6 + (step & 1)] = 1;
-                    } else apq = 0.0;      // (no rotation: the pair's 2 x 2 block stays as it is, exactly)
+            if (active && !ctl_wave) {
+                // the blocks dealt evenly: thread t takes blocks t and t + MF_CT of the nblk <= 820 (a row pair per sixteen lanes left the lanes of the short rows idle)
+#pragma unroll
+                for (int u = 0; u < (MF_NBLK + MF_CT - 1) / MF_CT; ++u) {
+                    const int t = tid + MF_CT * u;
+                    if (t >= nblk) continue;
+                    const int ij = blk[t], i = ij & 255, j = ij >> 8;
+                    const double ci = rcb[6 * i], si = rcb[6 * i + 1], roti = rcb[6 * i + 3], cj = rcb[6 * j], sj = rcb[6 * j + 1], rotj = rcb[6 * j + 3];
+                    if (roti == 0.0 && rotj == 0.0) continue;
+                    const int pi = pqb[2 * i], qi = pqb[2 * i + 1];
+                    if (i == j) {      // the pair's own 2 x 2 block in closed form
+                        const double tt = rcb[6 * i + 2];
+                        A[pi * MF_LDA + pi] = rcb[6 * i + 4] - tt * roti; A[qi * MF_LDA + qi] = rcb[6 * i + 5] + tt * roti; A[pi * MF_LDA + qi] = 0.0; A[qi * MF_LDA + pi] = 0.0;
+                        continue;
+                    }
+                    const int pj = pqb[2 * j], qj = pqb[2 * j + 1];
+                    const double m00 = A[pi * MF_LDA + pj], m01 = A[pi * MF_LDA + qj], m10 = A[qi * MF_LDA + pj], m11 = A[qi * MF_LDA + qj];
+                    const double r0 = ci * m00 - si * m10, r1 = ci * m01 - si * m11, r2 = si * m00 + ci * m10, r3 = si * m01 + ci * m11;      // rows rotated by pair i
+                    const double n00 = cj * r0 - sj * r1, n01 = sj * r0 + cj * r1, n10 = cj * r2 - sj * r3, n11 = sj * r2 + cj * r3;          // columns rotated by pair j
+                    A[pi * MF_LDA + pj] = n00; A[pi * MF_LDA + qj] = n01; A[qi * MF_LDA + pj] = n10; A[qi * MF_LDA + qj] = n11;
+                    A[pj * MF_LDA + pi] = n00; A[qj * MF_LDA + pi] = n01; A[pj * MF_LDA + qi] = n10; A[qj * MF_LDA + qi] = n11;
                 }
-                double* r = rc + 6 * tid; r[0] = c; r[1] = s; r[2] = t; r[3] = apq; r[4] = app; r[5] = aqq;
-                pq[2 * tid] = p; pq[2 * tid + 1] = q;
             }
             __syncthreads();
             const long long tc1 = clock64();
-            if (ictl[6 + (step & 1)] == 0) { cyc[0] += tc1 - tc0; continue; }      // nothing rotates in this step (the late sweeps): no passes, no barriers -- the same decision in every thread
-            // rows p, q of A and of V^T, then columns p, q of A: SIXTEEN lanes per pair (all n / 2 <= 40 pairs of the step at once on 640 threads; a row is five
-            // lane-strides long), every load of a lane in flight before its first store.  The rotation parameters are read once per lane (a broadcast within the 16 lanes).
-            const int gi = tid >> 4, l16 = tid & 15;
-            const bool mine = gi < np && rc[6 * (gi < np ? gi : 0) + 3] != 0.0;
-            double c = 1.0, sn = 0.0; int p = 0, q = 0;
-            if (mine) { c = rc[6 * gi]; sn = rc[6 * gi + 1]; p = pq[2 * gi]; q = pq[2 * gi + 1]; }
-            if (mine) {
-                double* Ap = A + p * MF_LDA; double* Aq = A + q * MF_LDA; double* Vp = Vt + p * MF_LDV; double* Vq = Vt + q * MF_LDV;
-                double a[MF_RS], bq[MF_RS], va[MF_RS], vb[MF_RS];
+            if (ctl_wave) { if (step + 1 < ne - 1) parameters(step + 1, buf ^ 1); }
+            else if (active && gi < np && rcb[6 * gi + 3] != 0.0) {
+                const double c = rcb[6 * gi], sn = rcb[6 * gi + 1];
+                double* Vp = Vt + pqb[2 * gi] * MF_LDV; double* Vq = Vt + pqb[2 * gi + 1] * MF_LDV;
+                double va[MF_RS], vb[MF_RS];
 #pragma unroll
-                for (int u = 0; u < MF_RS; ++u) { const int k = l16 + 16 * u; const bool in = k < n; a[u] = in ? Ap[k] : 0.0; bq[u] = in ? Aq[k] : 0.0; va[u] = in ? Vp[k] : 0.0; vb[u] = in ? Vq[k] : 0.0; }
+                for (int u = 0; u < MF_RS; ++u) { const int k = l16 + 16 * u; const bool in = k < n; va[u] = in ? Vp[k] : 0.0; vb[u] = in ? Vq[k] : 0.0; }
 #pragma unroll
-                for (int u = 0; u < MF_RS; ++u) {
-                    const int k = l16 + 16 * u;
-                    if (k < n) { Ap[k] = c * a[u] - sn * bq[u]; Aq[k] = sn * a[u] + c * bq[u]; Vp[k] = c * va[u] - sn * vb[u]; Vq[k] = sn * va[u] + c * vb[u]; }
-                }
+                for (int u = 0; u < MF_RS; ++u) { const int k = l16 + 16 * u; if (k < n) { Vp[k] = c * va[u] - sn * vb[u]; Vq[k] = sn * va[u] + c * vb[u]; } }
             }
             __syncthreads();
-            const long long tc2 = clock64();
-            if (mine) {      // columns p, q (rows k outside the pair), and the pair's 2 x 2 block in closed form
-                const double* r = rc + 6 * gi;
-                double a[MF_RS], bq[MF_RS];
-#pragma unroll
-                for (int u = 0; u < MF_RS; ++u) { const int k = l16 + 16 * u; const bool in = k < n; a[u] = in ? A[k * MF_LDA + p] : 0.0; bq[u] = in ? A[k * MF_LDA + q] : 0.0; }
-#pragma unroll
-                for (int u = 0; u < MF_RS; ++u) {
-                    const int k = l16 + 16 * u;
-                    if (k >= n) continue;
-                    double* Mk = A + k * MF_LDA;
-                    if (k == p) { Mk[p] = r[4] - r[2] * r[3]; Mk[q] = 0.0; }
-                    else if (k == q) { Mk[q] = r[5] + r[2] * r[3]; Mk[p] = 0.0; }
-                    else { Mk[p] = c * a[u] - sn * bq[u]; Mk[q] = sn * a[u] + c * bq[u]; }
-                }
-            }
-            __syncthreads();
-            { const long long tc3 = clock64(); cyc[0] += tc1 - tc0; cyc[1] += tc2 - tc1; cyc[2] += tc3 - tc2; }
+            { const long long tc2 = clock64(); cyc[1] += tc1 - tc0; cyc[2] += tc2 - tc1; }
         }
         ++sweeps;
-        if (tid == 0) ictl[2] += ictl[0];
         converged = ictl[0] == 0;
+        if (tid == MF_CT) ictl[2] += ictl[0];
         __syncthreads();
     }
     // ---- eigenvalues in ascending order (ties by index, like the host's stable sort), rows of J0 / r0 in that order

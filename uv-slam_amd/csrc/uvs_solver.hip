@@ -1729,7 +1729,7 @@ extern "C" int uvs_marginalize_batch(uvs_solver* s, int n_win, const uvs_window*
         HIPCHK(s, hipStreamSynchronize(s->stream));
         tb3 = std::chrono::steady_clock::now();
         if (prof) { double sw = 0, swmax = 0, rot = 0, cut = 0, cy[3] = {0, 0, 0}; for (int q = 0; q < nfin; ++q) { const double* fo = (const double*)B.h_out + (size_t)q * MF_OUT; sw += fo[MF_OUT_S + 1]; swmax = std::max(swmax, fo[MF_OUT_S + 1]); rot += fo[MF_OUT_S + 2]; cut += fo[MF_OUT_S + 3]; for (int k = 0; k < 3; ++k) cy[k] += fo[MF_OUT_S + 4 + k]; }
-                    std::fprintf(stderr, "[uvs_marginalize_batch] k_marg_finish: %.1f Jacobi sweeps (most: %.0f), %.0f rotations, %.1f eigenvalues cut per window (mean over %d); shader-clock cycles per window in the steps: rotation parameters %.0f k, row pass %.0f k, column pass %.0f k\n",
+                    std::fprintf(stderr, "[uvs_marginalize_batch] k_marg_finish: %.1f Jacobi sweeps (most: %.0f), %.0f rotations, %.1f eigenvalues cut per window (mean over %d); shader-clock cycles per window: first rotation parameters of the sweeps %.0f k, A passes %.0f k, V passes (beside the next step's parameters) %.0f k\n",
                                  sw / nfin, swmax, rot / nfin, cut / nfin, nfin, cy[0] / nfin * 1e-3, cy[1] / nfin * 1e-3, cy[2] / nfin * 1e-3); }
         for (int q = 0; q < nfin; ++q) {
             const int b = slot_win[q]; MargBatchItem& it = items[b];
