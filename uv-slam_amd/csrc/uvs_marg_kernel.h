@@ -7,8 +7,8 @@
 //
 // The eigen-decomposition is a PARALLEL cyclic Jacobi (round-robin ordering: n / 2 disjoint rotations per step, n - 1 steps per sweep) with the same rotation formulas and the
 // same RELATIVE stopping rule |a_pq| <= 1.1e-16 sqrt(|a_pp a_qq|) as the host's host_sym_eig_jacobi (uvs_marg.h:30-58): the matrices are graded over twenty orders of magnitude
-// and Jacobi resolves the small eigenvalues relative to their own scale.  For ONE window this is no faster than the host's tridiagonal QL (~0.3 ms against ~0.2 ms): a rotation step
-// is two workgroup barriers and there are ~1 000 of them.  For a BATCH it is what makes the marginalization scale with the solve: 256 windows take one launch instead
+// and Jacobi resolves the small eigenvalues relative to their own scale.  For ONE window this is much slower than the host's tridiagonal QL (1.6 ms against ~0.2 ms): a rotation step
+// is two workgroup barriers and there are ~1 000 of them, whether one workgroup runs or 256.  For a BATCH it is what makes the marginalization scale with the solve: 256 windows take one launch instead
 // of 256 x 0.2 ms on a host core (uvs_marginalize_batch).
 #pragma once
 #include <hip/hip_runtime.h>
