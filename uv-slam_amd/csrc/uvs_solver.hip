@@ -106,6 +106,9 @@ struct MargDevScratch;
 static void free_marg_scratch(MargDevScratch* m);
 struct MargBatchBuf;
 static void free_marg_batch(MargBatchBuf* m);
+struct MargWorker;
+static void free_marg_worker(MargWorker* w);
+static bool marg_in_flight(const uvs_solver* s);
 struct uvs_solver {
     uvs_options opts;
     int device;
@@ -129,8 +132,8 @@ struct uvs_solver {
     std::vector<char> host_blobs;
     MargDevScratch* marg_dev = nullptr;   // buffers of the device marginalization (sub-window blob, its workspace, the reduced system)
     struct MargBatchBuf* marg_batch = nullptr;      // ... and of uvs_marginalize_batch (allocated on first use)
-    std::future<int> marg_job;            // uvs_marginalize_resident_begin(): the marginalization running on a worker thread; its result waits in marg_job_out
-    uvs_prior marg_job_out;
+    struct MargWorker* marg_worker = nullptr;      // uvs_marginalize_resident_begin(): the marginalization runs on this handle's worker thread (created on first use, kept: a thread per call was
+    uvs_prior marg_job_out;                        // 30 - 60 us of every optimization() of a replay); its result waits in marg_job_out
     PackCache* pack_cache = nullptr;      // structure of the last large single window (allocated on first use)
     std::vector<std::vector<char>> slot_blobs;      // batch uploads: one packing buffer per batch slot, kept (with its pages) from batch to batch
     PackPool* pool = nullptr;                       // ... and the worker threads that fill them (created on the first threaded batch)
@@ -271,7 +274,7 @@ int uvs_create(const uvs_options* opts, int device, int max_batch, int max_point
 }
 
 void uvs_destroy(uvs_solver* s) {
-    if (s && s->marg_job.valid()) (void)s->marg_job.get();      // a marginalization begun and never waited for still uses the handle
+    if (s) { free_marg_worker(s->marg_worker); s->marg_worker = nullptr; }      // (waits for a marginalization begun and never waited for: it still uses the handle)
     if (!s) return;
     if (s->twin) { uvs_destroy(s->twin); s->twin = nullptr; }
     if (s->twin2) { uvs_destroy(s->twin2); s->twin2 = nullptr; }
@@ -1509,6 +1512,60 @@ int uvs_evaluate(uvs_solver* s, const uvs_window* w, int robust, uvs_eval* out) 
     return run_evaluate(s->device, s->stream, s->d_blobs, s->d_ws, s->hdrs[0], make_kopts(s->opts, 0), robust, out, s->err, s->eval_scratch);
 }
 
+// The handle's marginalization worker (uvs_marginalize_resident_begin / uvs_marginalize_wait): ONE thread per handle, created on the first begin and parked on a condition
+// variable between jobs.
+struct MargWorker {
+    std::thread th; std::mutex m; std::condition_variable cv_job, cv_done;
+    uvs_solver* s = nullptr; const uvs_window* w = nullptr; int flag = 0, rc = UVS_OK;
+    bool has_job = false, done = false, stop = false, in_flight = false;
+    void loop() {
+        for (;;) {
+            std::unique_lock<std::mutex> lk(m);
+            cv_job.wait(lk, [&] { return stop || has_job; });
+            if (stop) return;
+            has_job = false;
+            const uvs_window* w_ = w; const int f_ = flag;
+            lk.unlock();
+            const int r = uvs_marginalize_resident(s, w_, f_, &s->marg_job_out);
+            lk.lock();
+            rc = r; done = true;
+            cv_done.notify_all();
+        }
+    }
+};
+static bool marg_in_flight(const uvs_solver* s) { return s->marg_worker && s->marg_worker->in_flight; }      // (only the caller's thread reads / writes in_flight)
+static int marg_worker_begin(uvs_solver* s, const uvs_window* w, int flag) {
+    if (!s->marg_worker) {
+        MargWorker* mw = new MargWorker(); mw->s = s;
+        try { mw->th = std::thread([mw] { mw->loop(); }); }
+        catch (const std::exception& e) {      // (std::system_error when no thread can be created: nothing may cross the C boundary)
+            delete mw; s->err = std::string("uvs_marginalize_resident_begin: could not start the worker thread: ") + e.what();
+            return UVS_ERR_HIP;
+        }
+        s->marg_worker = mw;
+    }
+    MargWorker& mw = *s->marg_worker;
+    { std::lock_guard<std::mutex> lk(mw.m); mw.w = w; mw.flag = flag; mw.has_job = true; mw.done = false; }
+    mw.in_flight = true;
+    mw.cv_job.notify_one();
+    return UVS_OK;
+}
+static int marg_worker_wait(uvs_solver* s) {
+    MargWorker& mw = *s->marg_worker;
+    std::unique_lock<std::mutex> lk(mw.m);
+    mw.cv_done.wait(lk, [&] { return mw.done; });
+    mw.done = false; mw.in_flight = false;
+    return mw.rc;
+}
+static void free_marg_worker(MargWorker* mw) {
+    if (!mw) return;
+    if (mw->in_flight) { std::unique_lock<std::mutex> lk(mw->m); mw->cv_done.wait(lk, [&] { return mw->done; }); }
+    { std::lock_guard<std::mutex> lk(mw->m); mw->stop = true; }
+    mw->cv_job.notify_one();
+    if (mw->th.joinable()) mw->th.join();
+    delete mw;
+}
+
 // MARGIN_SECOND_NEW (estimator.cpp:1159-1228) marginalizes Pose[WINDOW_SIZE - 1] out of the OLD PRIOR and reads nothing else: no factor is evaluated, so no kernel runs and nothing is
 // copied -- r = r0 + J0 dx, A = J0^T J0, b = J0^T r, the 6 x 6 elimination and the n x n factorization are host work (uvs_marg.h).  Round 5 packed and uploaded the window and
 // evaluated it on the device to obtain that one vector r (0.2 ms of the 0.5 ms a call took).
@@ -1563,20 +1620,14 @@ int uvs_marginalize_resident(uvs_solver* s, const uvs_window* w, int flag, uvs_p
 
 int uvs_marginalize_resident_begin(uvs_solver* s, const uvs_window* w, int flag) {
     if (!s || !w || (flag != 0 && flag != 1)) return UVS_ERR_INVALID_ARG;
-    if (s->marg_job.valid()) { s->err = "uvs_marginalize_resident_begin: the previous marginalization has not been waited for"; return UVS_ERR_INVALID_ARG; }
+    if (marg_in_flight(s)) { s->err = "uvs_marginalize_resident_begin: the previous marginalization has not been waited for"; return UVS_ERR_INVALID_ARG; }
     // the worker owns the handle until uvs_marginalize_wait(): device selection is per thread, everything else (stream, pinned buffers, scratch) is the handle's own
-    try {
-        s->marg_job = std::async(std::launch::async, [s, w, flag]() { return uvs_marginalize_resident(s, w, flag, &s->marg_job_out); });
-    } catch (const std::exception& e) {      // (std::system_error when no thread can be created: nothing may cross the C boundary)
-        s->err = std::string("uvs_marginalize_resident_begin: could not start the worker thread: ") + e.what();
-        return UVS_ERR_HIP;
-    }
-    return UVS_OK;
+    return marg_worker_begin(s, w, flag);
 }
 int uvs_marginalize_wait(uvs_solver* s, uvs_prior* out) {
     if (!s || !out) return UVS_ERR_INVALID_ARG;
-    if (!s->marg_job.valid()) { s->err = "uvs_marginalize_wait: no marginalization in flight"; return UVS_ERR_INVALID_ARG; }
-    const int rc = s->marg_job.get();
+    if (!marg_in_flight(s)) { s->err = "uvs_marginalize_wait: no marginalization in flight"; return UVS_ERR_INVALID_ARG; }
+    const int rc = marg_worker_wait(s);
     if (rc == UVS_OK) *out = s->marg_job_out;
     return rc;
 }
@@ -1616,7 +1667,7 @@ extern "C" int uvs_marginalize_batch(uvs_solver* s, int n_win, const uvs_window*
     using namespace uvsmarg;
     if (!s || n_win < 0 || (n_win > 0 && (!ws || !flags || !out))) return UVS_ERR_INVALID_ARG;
     for (int b = 0; b < n_win; ++b) if (!ws[b] || (flags[b] != 0 && flags[b] != 1)) { s->err = "uvs_marginalize_batch: null window or flag outside {0, 1}"; return UVS_ERR_INVALID_ARG; }
-    if (s->marg_job.valid()) { s->err = "uvs_marginalize_batch: a marginalization begun with uvs_marginalize_resident_begin has not been waited for"; return UVS_ERR_INVALID_ARG; }
+    if (marg_in_flight(s)) { s->err = "uvs_marginalize_batch: a marginalization begun with uvs_marginalize_resident_begin has not been waited for"; return UVS_ERR_INVALID_ARG; }
     if (n_win == 0) return UVS_OK;
     HIPCHK(s, hipSetDevice(s->device));
     if (!s->marg_batch) s->marg_batch = new MargBatchBuf();
