@@ -12,6 +12,7 @@ mkdir -p gpurun_out
  echo "== gpu_soak_relo.py with ESTIMATE_TD + ESTIMATE_EXTRINSIC, fused multi-workgroup loop"; python tests/gpu_soak_relo.py 150 37000 tdex fused 2>&1 | tail -2
  echo "== gpu_soak_options.py"; python tests/gpu_soak_options.py 2>&1 | tail -5
  echo "== gpu_soak_more.py"; python tests/gpu_soak_more.py 2>&1 | tail -4
+ echo "== gpu_soak_marg_batch.py (uvs_marginalize_batch vs the one-window call)"; python tests/gpu_soak_marg_batch.py 192 41000 2>&1 | tail -4
  echo "== gpu_soak_replay.py"; python tests/gpu_soak_replay.py 2>&1 | tail -5
  echo "== gpu_soak_batch256.py"; python tests/gpu_soak_batch256.py 0 2>&1 | tail -3
  echo "== gpu_soak_rejections.py"; python tests/gpu_soak_rejections.py 2>&1 | tail -70
