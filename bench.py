@@ -212,13 +212,13 @@ def main():
         try:
             _, sreps, _ = solver.stream(windows * 6, args.batch, want_states=False)      # warm-up: every buffer set twice (the first batch of a set sizes its pinned staging buffer, the second packs in place)
             walls = []
-            for _ in range(3):      # three streams, the median reported (the packing threads share the host with whatever else runs on it: single streams scatter by +-10 %)
-                _, sreps, wall_ms = solver.stream(windows * nb, args.batch, want_states=False)
+            for _ in range(5):      # five streams, the median reported (the packing threads share the host with whatever else runs on it: single streams scatter by +-10 %,
+                _, sreps, wall_ms = solver.stream(windows * nb, args.batch, want_states=False)      # and a busy second of the host took two of three streams in one round-6 run)
                 walls.append(wall_ms)
-            wall_ms = sorted(walls)[1]
+            wall_ms = sorted(walls)[2]
             ok = all(r.status == 0 for r in sreps) and all(sreps[i].final_cost == reps[i % args.batch].final_cost for i in range(len(sreps)))
             end_to_end = {"what": "uvs_batch_stream: %d batches of %d windows, packing + H2D + solve + results overlapped (three buffer sets); wall time of the C-ABI call" % (nb, args.batch),
-                          "solves_per_s": nb * args.batch / (wall_ms * 1e-3), "ms_per_batch": wall_ms / nb, "solves_per_s_of_the_three_streams": [nb * args.batch / (w * 1e-3) for w in walls], "bitwise_equal_to_resident_solves": bool(ok),
+                          "solves_per_s": nb * args.batch / (wall_ms * 1e-3), "ms_per_batch": wall_ms / nb, "solves_per_s_of_the_streams": [nb * args.batch / (w * 1e-3) for w in walls], "bitwise_equal_to_resident_solves": bool(ok),
                           "serial_reference": {"what": "upload (pack + H2D) then solve then download of ONE batch, nothing overlapped",
                                                "ms_per_batch": None}}
             solver.upload(windows); up = solver.last_upload_ms; kms = solver.solve_resident(); solver.download()      # C-ABI call times only (no ctypes conversion)
