@@ -18,13 +18,13 @@ rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 nb = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 per = int(sys.argv[3]) if len(sys.argv) > 3 else 256
 CONFIGS = [("default (un-chained, 32 packing threads)", {"UVS_STREAM_CHAIN": "0"}), ("UVS_STREAM_CHAIN=1", {"UVS_STREAM_CHAIN": "1"}), ("UVS_PACK_THREADS=64", {"UVS_STREAM_CHAIN": "0", "UVS_PACK_THREADS": "64"}),
-           ("UVS_PACK_THREADS=16", {"UVS_STREAM_CHAIN": "0", "UVS_PACK_THREADS": "16"}), ("UVS_STREAM_CHAIN=1 UVS_PACK_THREADS=64", {"UVS_STREAM_CHAIN": "1", "UVS_PACK_THREADS": "64"})]
+           ("UVS_PACK_THREADS=16", {"UVS_STREAM_CHAIN": "0", "UVS_PACK_THREADS": "16"}), ("UVS_STREAM_SETS=4", {"UVS_STREAM_CHAIN": "0", "UVS_STREAM_SETS": "4"}), ("UVS_STREAM_CHAIN=1 UVS_PACK_THREADS=64", {"UVS_STREAM_CHAIN": "1", "UVS_PACK_THREADS": "64"})]
 if os.environ.get("UVS_AB_EXTRA"):      # e.g. UVS_AB_EXTRA="UVS_PACK_PIN=1;UVS_PACK_PIN=1,UVS_STREAM_CHAIN=0"
     for spec in os.environ["UVS_AB_EXTRA"].split(";"):
         CONFIGS.append((spec.replace(",", " "), dict(kv.split("=") for kv in spec.split(","))))
 s = api.Solver(max_batch=per)
 windows = [synth.make_window(i, with_prior=True, marginalize_fn=lambda w, f: s.marginalize(w, f)) for i in range(per)]
-s.stream(windows * 6, per, want_states=False)      # every buffer set twice: the first batch of a set sizes its pinned buffer, the second packs in place
+os.environ["UVS_STREAM_SETS"] = "4"; s.stream(windows * 8, per, want_states=False); del os.environ["UVS_STREAM_SETS"]      # every buffer set twice: the first batch of a set sizes its pinned buffer, the second packs in place
 rates = {name: [] for name, _ in CONFIGS}
 for r in range(rounds):
     order = CONFIGS[r % len(CONFIGS):] + CONFIGS[:r % len(CONFIGS)]      # rotate who goes first

@@ -116,6 +116,7 @@ struct uvs_solver {
     int max_points = 0, max_point_obs = 0, max_lines = 0, max_line_obs = 0;      // per-window capacities promised at uvs_create
     uvs_solver* twin = nullptr;              // second buffer set of uvs_batch_stream (created on first use, destroyed with this handle)
     uvs_solver* twin2 = nullptr;             // ... and the third (in flight at once: a batch being packed, one being copied, one being solved)
+    uvs_solver* twin3 = nullptr;             // ... and a fourth (UVS_STREAM_SETS=4: one more batch of slack for a host whose packing threads get descheduled)
     hipEvent_t ev_done = nullptr;            // recorded behind a set's k_solve in the stream: the next set's launch waits for it (the kernels of consecutive batches run one after the other)
     int n_cus = 256;                         // compute units of the device
     int large_solve_nt = 512;                // ... and for k_large_solve (UVS_LARGE_SOLVE_NT=256)
@@ -278,6 +279,7 @@ void uvs_destroy(uvs_solver* s) {
     if (!s) return;
     if (s->twin) { uvs_destroy(s->twin); s->twin = nullptr; }
     if (s->twin2) { uvs_destroy(s->twin2); s->twin2 = nullptr; }
+    if (s->twin3) { uvs_destroy(s->twin3); s->twin3 = nullptr; }
     if (s->ev_done) { (void)hipEventDestroy(s->ev_done); s->ev_done = nullptr; }
     free_pack_cache(s->pack_cache); s->pack_cache = nullptr;
     if (!s->pool_borrowed) delete s->pool;
@@ -1411,22 +1413,22 @@ int uvs_batch_stream(uvs_solver* s, int n_batches, int per_batch, const uvs_wind
     // THREE buffer sets by default (UVS_STREAM_SETS=2: two): with two, the host can pack batch k only after batch k - 2 has been solved, and pack + copy (1.0 + 0.85 ms) then sit on
     // the critical path of every second kernel (1.72 ms per batch measured); with three the GPU always has a copied batch waiting
     // (the three knobs are read per CALL, not once per process: tools/stream_ab.py alternates the configurations inside one process, on the same windows)
-    const int NS = [] { const char* e = std::getenv("UVS_STREAM_SETS"); return e && std::atoi(e) == 2 ? 2 : 3; }();
-    for (uvs_solver** t : {&s->twin, &s->twin2}) {
-        if (t == &s->twin2 && NS < 3) break;
+    const int NS = [] { const char* e = std::getenv("UVS_STREAM_SETS"); const int v = e ? std::atoi(e) : 3; return v == 2 || v == 4 ? v : 3; }();
+    for (uvs_solver** t : {&s->twin, &s->twin2, &s->twin3}) {
+        if ((t == &s->twin2 && NS < 3) || (t == &s->twin3 && NS < 4)) break;
         if (!*t) { const int rc = uvs_create(&s->opts, s->device, s->max_batch, s->max_points, s->max_point_obs, s->max_lines, s->max_line_obs, t); if (rc != UVS_OK) { s->err = "uvs_batch_stream: could not create a buffer set"; return rc; } }
         if (!s->pool) s->pool = new PackPool();
         if (!(*t)->pool) { (*t)->pool = s->pool; (*t)->pool_borrowed = true; }      // one pool of packing threads for all sets (they pack one after the other)
     }
     const auto t0 = std::chrono::steady_clock::now();
-    uvs_solver* set[3] = {s, s->twin, s->twin2};
+    uvs_solver* set[4] = {s, s->twin, s->twin2, s->twin3};
     // UVS_STREAM_CHAIN=1: the kernels of consecutive batches chained by events (round 5's default).  Round 6 measured both forms alternately in one process, ten runs of 32 batches each
     // (tools/stream_ab.py, profiles/r06_stream_ab.txt): un-chained 175.4 k solves/s median (quartiles 171.3 - 175.9 k), chained 167.5 k (167.3 - 167.8 k) -- the chain is steadier and
     // 4.5 % slower (a batch's kernel then never starts under the tail of the previous one, whose last workgroups leave compute units idle), so the default is un-chained.
     const bool chain_ = [] { const char* e = std::getenv("UVS_STREAM_CHAIN"); return e && e[0] == '1'; }();
     const int d2h_ = [] { const char* e = std::getenv("UVS_STREAM_D2H_COPY"); return e ? std::atoi(e) : 0; }();      // 0: k_solve writes the results into the pinned buffer; 1: gather kernel + device-to-host copy; 2: the gather kernel writes them
     for (int j = 0; j < NS; ++j) if (!set[j]->ev_done) HIPCHK(s, hipEventCreateWithFlags(&set[j]->ev_done, hipEventDisableTiming));
-    int pending[3] = {-1, -1, -1};      // batch index in flight on each set
+    int pending[4] = {-1, -1, -1, -1};      // batch index in flight on each set
     // the resident blobs of this call carry addresses into its pinned result buffers (DevWin::out_host): whatever way the call ends, a later uvs_batch_solve needs its own upload
     struct Invalidate { uvs_solver** set; int n; bool on; ~Invalidate() { if (on) for (int j = 0; j < n; ++j) set[j]->n_loaded = 0; } } invalidate_{set, NS, d2h_ == 0};
     int worst = UVS_OK;
