@@ -235,7 +235,7 @@ def test_batch_stream_equals_batch_by_batch(gpu_api):
     ref.close()
 
 
-@pytest.mark.parametrize("env", [{"UVS_STREAM_SETS": "2"}, {"UVS_STREAM_CHAIN": "1"}, {"UVS_STREAM_D2H_COPY": "1"}, {"UVS_STREAM_D2H_COPY": "2"}])
+@pytest.mark.parametrize("env", [{"UVS_STREAM_SETS": "2"}, {"UVS_STREAM_SETS": "4"}, {"UVS_STREAM_CHAIN": "1"}, {"UVS_STREAM_D2H_COPY": "1"}, {"UVS_STREAM_D2H_COPY": "2"}])
 def test_batch_stream_switches(gpu_api, env, monkeypatch):
     """The A/B switches of the stream (two buffer sets; kernels of consecutive batches chained by events; results gathered on the device and fetched by a copy, or written to the host by the gather
     kernel, instead of by k_solve itself) give the same bits.
