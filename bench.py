@@ -516,8 +516,16 @@ def main():
                     t1 = time.perf_counter()
                     for k in range(16): L.uvs_marginalize(solver._h, C.byref(keeps[k][0]), flag, C.byref(pri[k]))
                     one = (time.perf_counter() - t1) / 16
-                    marg_batch[name] = {"batch_call_ms": float(np.median(ts[1:])) * 1e3, "us_per_window": float(np.median(ts[1:])) / n * 1e6, "status": int(rc),
-                                        "one_window_call_ms": one * 1e3}
+                    # (the last 16 one-window calls overwrote pri[0..15]: compare them with the batch's priors of the same windows, in the information form the next solve reads)
+                    one_pri = [(np.array(pri[k].J0()), np.array(pri[k].r0())) for k in range(16)]
+                    rc2 = L.uvs_marginalize_batch(solver._h, n, arr, fl, pri, stc)
+                    worst = 0.0
+                    for k in range(16):
+                        J1, r1 = one_pri[k]; Jb, rb = np.array(pri[k].J0()), np.array(pri[k].r0())
+                        H1, Hb = J1.T @ J1, Jb.T @ Jb
+                        worst = max(worst, float(np.abs(Hb - H1).max() / max(np.abs(H1).max(), 1e-300)), float(np.abs(Jb.T @ rb - J1.T @ r1).max() / max(1.0, np.abs(J1.T @ r1).max())))
+                    marg_batch[name] = {"batch_call_ms": float(np.median(ts[1:])) * 1e3, "us_per_window": float(np.median(ts[1:])) / n * 1e6, "status": int(rc) | int(rc2),
+                                        "windows_ok": int(sum(1 for x in stc if x == 0)), "one_window_call_ms": one * 1e3, "max_rel_diff_vs_one_window_call_16_samples": worst}
                 marg_batch["note"] = ("C-ABI call times. One launch linearizes the sub-windows of all MARGIN_OLD windows (k_marg_linearize_batch), one launch eliminates every window's dropped frame block "
                                       "and factors its n x n Schur complement (k_marg_finish: parallel cyclic Jacobi, csrc/uvs_marg_kernel.h); the one-window call finishes on a host core")
             except Exception as e:      # (a secondary leg must never cost the bench line)
