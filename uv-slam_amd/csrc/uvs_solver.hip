@@ -1413,6 +1413,9 @@ int uvs_batch_stream(uvs_solver* s, int n_batches, int per_batch, const uvs_wind
     // THREE buffer sets by default (UVS_STREAM_SETS=2: two): with two, the host can pack batch k only after batch k - 2 has been solved, and pack + copy (1.0 + 0.85 ms) then sit on
     // the critical path of every second kernel (1.72 ms per batch measured); with three the GPU always has a copied batch waiting
     // (the three knobs are read per CALL, not once per process: tools/stream_ab.py alternates the configurations inside one process, on the same windows)
+    // UVS_STREAM_SETS=4: a fourth set with at most two kernels in flight (below) -- a batch of slack for a host whose packing threads get descheduled.  Measured against the three-set default
+    // in four alternating A/Bs on busy and quiet hosts (profiles/r06_stream_ab_four_sets.txt): medians 172.5 / 173.6 / 150.8 k against 173.5 / 175.8 / 174.8 k, tighter quartiles in one of
+    // them, wider in another -- the host's noise decides, not the set count; the default stays three.
     const int NS = [] { const char* e = std::getenv("UVS_STREAM_SETS"); const int v = e ? std::atoi(e) : 3; return v == 2 || v == 4 ? v : 3; }();
     for (uvs_solver** t : {&s->twin, &s->twin2, &s->twin3}) {
         if ((t == &s->twin2 && NS < 3) || (t == &s->twin3 && NS < 4)) break;
@@ -1451,8 +1454,11 @@ int uvs_batch_stream(uvs_solver* s, int n_batches, int per_batch, const uvs_wind
         // (UVS_STREAM_CHAIN=1) the kernels run one after the other (an event chain through the sets): two k_solve launches on two streams otherwise share the compute units workgroup by
         // workgroup, both finish late and together, and the host -- which packs batch k + 1 into the set of the batch that finishes first -- stalls and then has two batches to pack in a row
         if (rc == UVS_OK && chain_ && k > 0 && hipStreamWaitEvent(set[q]->stream, set[(k - 1) % NS]->ev_done, 0) != hipSuccess) { s->err = "hipStreamWaitEvent failed"; rc = UVS_ERR_HIP; }
+        // four sets, un-chained: at most TWO kernels in flight (batch k waits for batch k - 2), so that the fourth set is slack for the host and not a third kernel sharing the compute units
+        const bool chain2_ = !chain_ && NS == 4;
+        if (rc == UVS_OK && chain2_ && k > 1 && hipStreamWaitEvent(set[q]->stream, set[(k - 2) % NS]->ev_done, 0) != hipSuccess) { s->err = "hipStreamWaitEvent failed"; rc = UVS_ERR_HIP; }
         if (rc == UVS_OK) rc = launch_solve(set[q], 0, nullptr, false, d2h_ == 0);
-        if (rc == UVS_OK && chain_ && hipEventRecord(set[q]->ev_done, set[q]->stream) != hipSuccess) { s->err = "hipEventRecord failed"; rc = UVS_ERR_HIP; }
+        if (rc == UVS_OK && (chain_ || chain2_) && hipEventRecord(set[q]->ev_done, set[q]->stream) != hipSuccess) { s->err = "hipEventRecord failed"; rc = UVS_ERR_HIP; }
         if (rc == UVS_OK && d2h_ != 0) rc = download_enqueue(set[q], per_batch, d2h_ == 2);
         if (rc != UVS_OK) {
             // batch k failed before it was enqueued: the batch still in flight on the OTHER buffer set (k - 1) is delivered like the ones before it, so that on
