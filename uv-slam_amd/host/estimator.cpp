@@ -143,8 +143,7 @@ namespace { double ms_since(std::chrono::steady_clock::time_point t0) { return s
 // Everything the solver reads besides the parameter values: the prior, the IMU links, and one index-addressed observation per residual
 // block, in the order the landmark rows of para_Feature / para_Ortho_plucker were filled by vector2double().  Which tracks take part
 // (FeatureManager::usedPoint / usedLine) and the emission order are behaviour of estimator.cpp:803-978 that the ABI relies on.
-void Estimator::assembleWindow(uvs::WindowAssembly& wa) {
-    if (last_marginalization_info && last_marginalization_info->prior.n > 0) wa.prior = &last_marginalization_info->prior;
+void Estimator::assembleWindow(uvs::WindowAssembly& wa) {      // (the prior is attached by optimization(), after the wait for the marginalization that produces it)
     for (int later = 1; later <= WINDOW_SIZE; ++later) {
         const IntegrationBase& pre = *pre_integrations[later];
         if (pre.sum_dt <= 10.0) wa.addImu(later - 1, pre);      // a pre-integration over more than 10 s is too uncertain to constrain anything
@@ -194,10 +193,13 @@ void Estimator::finishMarginalization() {
 
 void Estimator::optimization() {      // estimator.cpp:761-1233
     const auto t_begin = std::chrono::steady_clock::now();
-    finishMarginalization();             // the prior of the previous frame (usually there already: it was computed beside slideWindow / processIMU / processImage)
+    // packing the state and walking the track lists need nothing of the new prior: they run BESIDE the tail of the previous frame's marginalization (the worker reads its own copies of
+    // the landmark parameters and the old prior, see PendingMarginalization), the wait comes after them
     vector2double();
     uvs::WindowAssembly wa;
     assembleWindow(wa);
+    finishMarginalization();             // the prior of the previous frame (in a live system there already: it was computed beside slideWindow / processIMU / processImage)
+    if (last_marginalization_info && last_marginalization_info->prior.n > 0) wa.prior = &last_marginalization_info->prior;
     uvs_window w = wa.view(para_Pose, para_SpeedBias, para_Ex_Pose[0], para_Td[0][0], &para_Feature[0][0], &para_Ortho_plucker[0][0], relo_Pose);
     // record hook (the reference has no serialisation): UVS_DUMP_WINDOWS=<dir> writes every window exactly as the
     // solver receives it (the state after vector2double(), estimator.cpp:800) to <dir>/window_NNNN.bin for replay without ROS
